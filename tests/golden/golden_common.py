@@ -1,0 +1,127 @@
+"""Case lists and seeded inputs shared by make_golden.py (reference side) and the tests.
+
+Inputs are regenerated from (case key -> crc32 -> numpy PCG64 stream), so fixtures only
+need to store expected outputs."""
+import zlib
+
+import numpy as np
+
+B = 2  # batch used by all per-op cases
+
+ALL_PRIMS = ["identity", "se_conv", "dil_conv", "dep_conv", "conv", "avg_pool", "max_pool",
+             "down_se_conv", "down_dil_conv", "down_dep_conv", "down_conv",
+             "up_se_conv", "up_dep_conv", "up_conv", "up_dil_conv"]
+_WIDE_SUBSET = ["identity", "conv", "dil_conv", "down_conv", "up_conv", "down_se_conv", "up_dep_conv",
+                "dep_conv", "max_pool"]
+
+
+def _rng(key, salt=0):
+    return np.random.default_rng([zlib.crc32(key.encode()), salt])
+
+
+def case_input(key, shape):
+    return _rng(key, 1).standard_normal(shape).astype(np.float32)
+
+
+def case_cotangent(key, shape):
+    return _rng(key, 2).standard_normal(shape).astype(np.float32)
+
+
+def case_alpha(key, n):
+    a = _rng(key, 3).standard_normal(n)
+    e = np.exp(a - a.max())
+    return (e / e.sum()).astype(np.float32)
+
+
+def case_alpha_matrix(key, rows, n):
+    a = _rng(key, 4).standard_normal((rows, n))
+    e = np.exp(a - a.max(axis=1, keepdims=True))
+    return (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+
+
+def case_probs(key, shape):
+    return _rng(key, 5).uniform(0.01, 0.99, shape).astype(np.float32)
+
+
+def case_targets(key, shape):
+    return (_rng(key, 6).uniform(0, 1, shape) < 0.3).astype(np.float32)
+
+
+def prim_key(name, c):
+    return "prim/%s/c%d" % (name, c)
+
+
+def prim_cases():
+    """(name, C, input spatial shape).  Even, non-cubic shapes; C=32/64 exercise multi-group GN."""
+    shapes = {4: (4, 6, 8), 8: (8, 6, 4), 16: (4, 4, 6), 32: (4, 4, 4), 64: (2, 2, 2)}
+    cases = []
+    for c in (4, 8, 16):
+        for n in ALL_PRIMS:
+            cases.append((n, c, shapes[c]))
+    for c in (32, 64):
+        for n in _WIDE_SUBSET:
+            cases.append((n, c, shapes[c]))
+    return cases
+
+
+def convops_cases():
+    """(key, ConvOps kwargs, Cin, input spatial shape) for stems / preprocess / head."""
+    return [
+        ("convops/stem0", dict(out_channels=12, kernel_size=1, ops_order="weight_norm"), 4, (4, 6, 8)),
+        ("convops/stem1", dict(out_channels=12, kernel_size=3, stride=2, ops_order="weight_norm"), 4, (4, 6, 8)),
+        ("convops/pre0_down", dict(out_channels=8, kernel_size=1, stride=2, ops_order="act_weight_norm"), 12, (4, 6, 8)),
+        ("convops/pre1", dict(out_channels=16, kernel_size=1, ops_order="act_weight_norm"), 24, (4, 4, 6)),
+        ("convops/pre_wide", dict(out_channels=64, kernel_size=1, ops_order="act_weight_norm"), 192, (2, 2, 2)),
+        ("convops/pre_wide2", dict(out_channels=32, kernel_size=1, ops_order="act_weight_norm"), 96, (4, 2, 2)),
+        ("convops/head", dict(out_channels=3, kernel_size=1, ops_order="weight"), 12, (4, 6, 8)),
+        ("convops/plain_k3_4to8", dict(out_channels=8, kernel_size=3, ops_order="weight_norm_act"), 4, (4, 6, 8)),
+    ]
+
+
+def mixed_cases():
+    """(key, C, stride, transposed, input spatial shape)"""
+    return [
+        ("mixed/norm/c8", 8, 1, False, (4, 6, 8)),
+        ("mixed/down/c8", 8, 2, False, (4, 6, 8)),
+        ("mixed/up/c8", 8, 2, True, (4, 6, 4)),
+        ("mixed/norm/c4", 4, 1, False, (4, 4, 6)),
+        ("mixed/up/c16", 16, 2, True, (2, 4, 4)),
+        ("mixed/down/c32", 32, 2, False, (4, 4, 4)),
+    ]
+
+
+def cell_cases():
+    """(key, c0, c1, c_node, downward, x0 spatial, x1 spatial).
+    down: x0 is one level finer than x1 (preprocess0 has stride 2); up: x1 is one level coarser."""
+    return [
+        ("cell/down", 12, 12, 8, True, (8, 8, 8), (4, 4, 4)),
+        ("cell/up", 24, 48, 8, False, (4, 4, 8), (2, 2, 4)),
+        ("cell/down_wide", 24, 48, 32, True, (8, 8, 4), (4, 4, 2)),
+    ]
+
+
+def net_cases():
+    """(key, kind, genotype name, depth, patch size, batch, adam steps)"""
+    return [
+        ("net/searched/G_CONV/d4s32", "searched", "G_CONV", 4, 32, 2, 3),
+        ("net/searched/G_ALL/d4s32", "searched", "G_ALL", 4, 32, 2, 3),
+        ("net/searched/G_CONV/d2s16", "searched", "G_CONV", 2, 16, 2, 0),
+        ("net/supernet/d2s16", "supernet", None, 2, 16, 2, 3),
+        ("net/supernet/d4s32", "supernet", None, 4, 32, 1, 0),
+        ("net/searched/G_CONV/d4s64", "searched", "G_CONV", 4, 64, 1, 0),
+    ]
+
+
+def net_batch(key, batch, size):
+    """Parity batches: N(0,1) inputs and Bernoulli(0.3) targets."""
+    x = _rng(key, 7).standard_normal((batch, 4, size, size, size)).astype(np.float32)
+    t = (_rng(key, 8).uniform(0, 1, (batch, 3, size, size, size)) < 0.3).astype(np.float32)
+    return x, t
+
+
+def dice_cases():
+    return [("dice/a", (2, 3, 4, 6, 8)), ("dice/b", (1, 3, 16, 16, 16)), ("dice/c", (3, 3, 2, 2, 2))]
+
+
+def geno_cases():
+    return ["geno/%d" % i for i in range(8)]
