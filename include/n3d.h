@@ -1,0 +1,171 @@
+/*
+ * n3d.h -- C ABI of libn3d.so: gfx950 (MI355X) HIP kernels for the nas_3d_unet hot path.
+ *
+ * The reference (woodywff/nas_3d_unet) has NO native layer and NO FFI: its hot path is a
+ * Python module API (prim_ops.py / cell.py) whose arithmetic is delegated to torch.nn.
+ * Each entry point below therefore cites the reference *call site* whose torch op it replaces
+ * (file:line relative to the reference root).  The Python host (nas_3d_unet_amd/) binds these
+ * with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (n3d_last_error() has the text);
+ *     nothing throws, allocates, or synchronises; all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*), so calls are HIP-graph capturable.
+ *   - activations are fp32, NDHWC ("channels-last-3d"): element (b,d,h,w,c) of a tensor with
+ *     voxel pitch `ld` (floats, ld >= C) lives at ((((b*D+d)*H+h)*W+w)*ld + c).  A pitch larger
+ *     than C addresses a channel slice of a wider buffer (zero-copy concat, cell.py:82).
+ *   - weights keep torch's native layouts: Conv3d (Cout, Cin/g, k,k,k), ConvTranspose3d
+ *     (Cin, Cout/g, k,k,k), Linear (out, in), so reference state_dicts load unchanged.
+ *   - per-(sample,channel) reductions are deterministic two-stage sums: a producer kernel writes
+ *     one partial row of doubles per workgroup, `double[B][rows][C][nv]`, and a tiny coefficient
+ *     kernel adds the rows in a fixed order.  `rows` comes from n3d_stats_rows() /
+ *     n3d_conv_stats_rows() so the caller can size the buffer; no atomics, no zeroing.
+ */
+#ifndef N3D_H_
+#define N3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define N3D_OK 0
+#define N3D_ERR_INVALID (-1)
+#define N3D_ERR_UNSUPPORTED (-2)
+#define N3D_ERR_HIP (-3)
+#define N3D_ERR_WORKSPACE (-4)
+
+/* flags */
+#define N3D_RELU_IN 1     /* apply ReLU to the conv input on load ('act_weight_norm', cell.py:47-50) */
+#define N3D_RELU 2        /* epilogue activation is ReLU (prim_ops.py:63,80) */
+#define N3D_ACCUMULATE 4  /* destination += result instead of = result */
+#define N3D_POOL_MAX 8    /* pooling type (prim_ops.py:160-163) */
+#define N3D_NO_MFMA 16    /* force the generic VALU kernels (A/B testing) */
+
+/* Geometry of a (possibly strided / dilated) 3-D convolution, torch Conv3d semantics:
+ * o = floor((i + 2*pad - dil*(k-1) - 1)/stride) + 1.  "i side" is what the window slides over.
+ * For a transposed convolution the i side is its OUTPUT and the o side its INPUT. */
+typedef struct n3d_conv_geom {
+  int32_t B;
+  int32_t Di, Hi, Wi, Ci;
+  int32_t Do, Ho, Wo, Co;
+  int32_t k, stride, dil, pad;
+  int32_t depthwise; /* 1: groups == Ci == Co (prim_ops.py:95-97,105-106) */
+} n3d_conv_geom;
+
+const char* n3d_last_error(void);
+int n3d_version(void);
+/* 1 if the library was built for gfx950 and a HIP device is usable, 0 otherwise */
+int n3d_device_ok(void);
+
+int n3d_zero(void* p, size_t bytes, void* stream);
+
+/* ---- convolution family: nn.Conv3d / nn.ConvTranspose3d (prim_ops.py:95-110,140-147) -------------
+ * workspace: packed weights; query with n3d_conv_workspace_bytes().
+ * in_gate : optional (B, Ci_of_the_conv_input) per-sample channel scale applied on load: the SE
+ *           gate x*y (prim_ops.py:152) or a Dropout3d mask (prim_ops.py:72-73).
+ * stats   : optional double[B][rows][Cout][2] partial (sum, sum of squares) of the raw output incl.
+ *           bias: GroupNorm statistics produced in the conv epilogue (prim_ops.py:58,77). */
+size_t n3d_conv_workspace_bytes(const n3d_conv_geom* g);
+/* rows per sample that n3d_conv_fwd (transposed=0) / n3d_convT_fwd (transposed=1) write into `stats` */
+int n3d_conv_stats_rows(const n3d_conv_geom* g, int transposed, int flags);
+/* rows per sample written by n3d_channel_stats / n3d_affine_act_bwd_reduce for N voxels, C channels */
+int n3d_stats_rows(int64_t N, int C);
+
+/* y[o side] = conv(x[i side]) + bias */
+int n3d_conv_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias,
+                 float* y, int64_t yld, int flags, const float* in_gate, double* stats,
+                 void* ws, size_t ws_bytes, void* stream);
+/* dx[i side] (+)= conv^T(dy[o side]); if relu_src != NULL (N3D_RELU_IN) dx is masked by relu_src > 0;
+ * out_gate multiplies dx per (b, ci) */
+int n3d_conv_bwd_data(const n3d_conv_geom* g, const float* dy, int64_t dyld, const float* w,
+                      float* dx, int64_t dxld, int flags, const float* relu_src, int64_t rld,
+                      const float* out_gate, void* ws, size_t ws_bytes, void* stream);
+/* dw (native layout) = sum x * dy, dbias = sum dy (either may be NULL) */
+int n3d_conv_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld,
+                        float* dw, float* dbias, int flags, const float* in_gate,
+                        void* ws, size_t ws_bytes, void* stream);
+/* transposed convolution y[i side] = convT(x[o side]) + bias; same kernels with the roles swapped */
+int n3d_convT_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias,
+                  float* y, int64_t yld, int flags, const float* in_gate, double* stats,
+                  void* ws, size_t ws_bytes, void* stream);
+int n3d_convT_bwd_data(const n3d_conv_geom* g, const float* dy, int64_t dyld, const float* w,
+                       float* dx, int64_t dxld, int flags, void* ws, size_t ws_bytes, void* stream);
+int n3d_convT_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld,
+                         float* dw, float* dbias, int flags, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- per-(sample,channel) statistics and the normalise / activate / weighted-sum epilogue ----------
+ * n3d_channel_stats: stats[b][row][c] = partial (sum x, sum x^2) over the N voxels (GroupNorm of a tensor
+ *   that no conv of ours produced: IdentityOp prim_ops.py:170-174; SE mean prim_ops.py:149). */
+int n3d_channel_stats(const float* x, int64_t ld, int B, int64_t N, int C, double* stats, void* stream);
+/* GroupNorm(G, C) statistics -> per-(b,c) affine y = a*x + b; mean_rstd[b][g] = (mean, rstd) (prim_ops.py:56-58) */
+int n3d_gn_coeffs(const double* stats, int rows, const float* gamma, const float* beta, int B, int C, int G,
+                  int64_t N, float eps, float* a, float* b, float* mean_rstd, void* stream);
+/* out (+)= w * act(a[b,c]*raw + b[b,c]);  a,b NULL -> identity affine; wptr NULL -> 1.
+ * This is GroupNorm-apply + ReLU (prim_ops.py:75-80) fused with the MixedOp weighting and the node
+ * sum (cell.py:29-32,81; searched.py:50). */
+int n3d_affine_act(const float* raw, int64_t rld, const float* a, const float* b, const float* wptr,
+                   float* out, int64_t old_, int B, int64_t N, int C, int flags, void* stream);
+/* backward, pass 1: sums[b][row][c] = partial (S1 = sum g, S2 = sum g*raw, Sz = sum dout*z),
+ * g = dout * act'(a*raw+b), z = act(a*raw+b) */
+int n3d_affine_act_bwd_reduce(const float* dout, int64_t dld, const float* raw, int64_t rld, const float* a,
+                              const float* b, int B, int64_t N, int C, int flags, double* sums, void* stream);
+/* GroupNorm backward coefficients: dgamma, dbeta (summed over b), dalpha = sum Sz (if not NULL),
+ * and the per-(b,c) affine draw = A*g + Bc + Cc*raw.  wptr: the MixedOp weight (NULL -> 1). */
+int n3d_gn_bwd_coeffs(const double* sums, int rows, const float* gamma, const float* mean_rstd,
+                      const float* wptr, int B, int C, int G, int64_t N, float* dgamma, float* dbeta,
+                      float* dalpha, float* A, float* Bc, float* Cc, void* stream);
+/* plain (no norm) epilogue backward coefficients: A = w, Bc = Cc = 0, dalpha = sum Sz */
+int n3d_plain_bwd_coeffs(const double* sums, int rows, const float* wptr, int B, int C, float* dalpha,
+                         float* A, void* stream);
+/* backward, pass 2: draw (+)= A[b,c]*g + Bc[b,c] + Cc[b,c]*raw   (Bc, Cc may be NULL) */
+int n3d_affine_act_bwd_apply(const float* dout, int64_t dld, const float* raw, int64_t rld, const float* a,
+                             const float* b, const float* A, const float* Bc, const float* Cc, float* draw,
+                             int64_t drld, int B, int64_t N, int C, int flags, void* stream);
+
+/* ---- squeeze-excitation gate (prim_ops.py:133-139,148-152) ----------------------------------------
+ * fwd: mean = stats.sum/N; hidden = relu(w1.mean + b1); gate = sigmoid(w2*hidden + b2) */
+int n3d_se_gate_fwd(const double* stats, int rows, int64_t N, const float* w1, const float* b1,
+                    const float* w2, const float* b2, int B, int C, float* mean, float* hidden, float* gate,
+                    void* stream);
+/* bwd: dgate[b,c] = w * sums[b][c].S2; returns fc grads and the input-side affine
+ * dx = A*g + Bc with A = w*gate, Bc = dmean/N; dalpha = sum Sz if not NULL */
+int n3d_se_gate_bwd(const double* sums, int rows, const float* wptr, const float* mean, const float* hidden,
+                    const float* gate, const float* w1, const float* w2, int B, int C, int64_t N,
+                    float* dw1, float* db1, float* dw2, float* db2, float* dalpha, float* A, float* Bc,
+                    void* stream);
+
+/* ---- 2x2x2 pooling, stride 2 (prim_ops.py:160-163) ------------------------------------------------ */
+int n3d_pool2_fwd(const float* x, int64_t xld, float* y, int64_t yld, int B, int Di, int Hi, int Wi, int C,
+                  int flags, void* stream);
+int n3d_pool2_bwd(const float* dy, int64_t dyld, const float* x, int64_t xld, float* dx, int64_t dxld, int B,
+                  int Di, int Hi, int Wi, int C, int flags, void* stream);
+
+/* ---- sigmoid head + Dice loss (nas.py:52, searched.py:93, loss.py:12-14) --------------------------
+ * element (b,c,v) of p / t / dp is at  ptr[b*sb + c*sc + v*sv]  (works for NCDHW and NDHWC).
+ * partial: double[B][C][n3d_dice_rows(N)][3] scratch; sums: double[B][C][3] (sum p*t, sum p, sum t). */
+int n3d_dice_rows(int64_t N);
+int n3d_dice_fwd(const float* p, int64_t psb, int64_t psc, int64_t psv, const float* t, int64_t tsb, int64_t tsc,
+                 int64_t tsv, int B, int C, int64_t N, float smooth, double* partial, double* sums,
+                 float* loss, void* stream);
+int n3d_dice_bwd(const float* p, int64_t psb, int64_t psc, int64_t psv, const float* t, int64_t tsb, int64_t tsc,
+                 int64_t tsv, int B, int C, int64_t N, float smooth, const double* sums, const float* dloss,
+                 float* dp, int64_t dsb, int64_t dsc, int64_t dsv, void* stream);
+
+/* ---- layout: NCDHW <-> NDHWC (caller tensors arrive NCDHW: train.py:118-119) ---------------------- */
+int n3d_ncdhw_to_ndhwc(const float* src, float* dst, int64_t dld, int B, int C, int64_t N, void* stream);
+int n3d_ndhwc_to_ncdhw(const float* src, int64_t sld, float* dst, int B, int C, int64_t N, void* stream);
+
+/* ---- flat Adam (train.py:49,128; search.py:103-104,228,238): torch.optim.Adam defaults ------------
+ * step_ptr: device int32 holding the number of steps already taken; if inc_step != 0 a second tiny
+ * launch increments it after the update (graph-replay safe).  grad_scale multiplies g (DP mean). */
+int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t* step_ptr,
+                  int inc_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* N3D_H_ */

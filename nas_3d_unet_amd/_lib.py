@@ -1,0 +1,105 @@
+"""ctypes binding of libn3d.so (include/n3d.h).
+
+The product path has NO fallback: if the library is missing, was not built for gfx950, or a
+tensor is not on a HIP device, the call raises.  (tests/ use the CPU oracle only as a checker.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+# torch bundles its own HIP runtime (libamdhip64.so.7); it must be the one already resident when
+# libn3d.so is dlopen'ed so that both share ONE runtime (same soname -> the loader reuses it).
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libn3d.so")
+
+
+class N3DError(RuntimeError):
+    pass
+
+
+class ConvGeom(C.Structure):
+    """n3d_conv_geom (include/n3d.h)"""
+    _fields_ = [(n, C.c_int32) for n in
+                ("B", "Di", "Hi", "Wi", "Ci", "Do", "Ho", "Wo", "Co", "k", "stride", "dil", "pad", "depthwise")]
+
+
+_p = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_f = C.c_float
+_sz = C.c_size_t
+_gp = C.POINTER(ConvGeom)
+
+# name -> (restype, argtypes); must list every function declared in include/n3d.h
+PROTOTYPES = {
+    "n3d_last_error": (C.c_char_p, []),
+    "n3d_version": (_i, []),
+    "n3d_device_ok": (_i, []),
+    "n3d_zero": (_i, [_p, _sz, _p]),
+    "n3d_conv_workspace_bytes": (_sz, [_gp]),
+    "n3d_conv_stats_rows": (_i, [_gp, _i, _i]),
+    "n3d_stats_rows": (_i, [_i64, _i]),
+    "n3d_conv_fwd": (_i, [_gp, _p, _i64, _p, _p, _p, _i64, _i, _p, _p, _p, _sz, _p]),
+    "n3d_conv_bwd_data": (_i, [_gp, _p, _i64, _p, _p, _i64, _i, _p, _i64, _p, _p, _sz, _p]),
+    "n3d_conv_bwd_weight": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i, _p, _p, _sz, _p]),
+    "n3d_convT_fwd": (_i, [_gp, _p, _i64, _p, _p, _p, _i64, _i, _p, _p, _p, _sz, _p]),
+    "n3d_convT_bwd_data": (_i, [_gp, _p, _i64, _p, _p, _i64, _i, _p, _sz, _p]),
+    "n3d_convT_bwd_weight": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i, _p, _sz, _p]),
+    "n3d_channel_stats": (_i, [_p, _i64, _i, _i64, _i, _p, _p]),
+    "n3d_gn_coeffs": (_i, [_p, _i, _p, _p, _i, _i, _i, _i64, _f, _p, _p, _p, _p]),
+    "n3d_affine_act": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i, _i64, _i, _i, _p]),
+    "n3d_affine_act_bwd_reduce": (_i, [_p, _i64, _p, _i64, _p, _p, _i, _i64, _i, _i, _p, _p]),
+    "n3d_gn_bwd_coeffs": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "n3d_plain_bwd_coeffs": (_i, [_p, _i, _p, _i, _i, _p, _p, _p]),
+    "n3d_affine_act_bwd_apply": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i, _i64, _i, _i, _p]),
+    "n3d_se_gate_fwd": (_i, [_p, _i, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
+    "n3d_se_gate_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "n3d_pool2_fwd": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i, _i, _i, _p]),
+    "n3d_pool2_bwd": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _i, _i, _i, _p]),
+    "n3d_dice_rows": (_i, [_i64]),
+    "n3d_dice_fwd": (_i, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i, _i, _i64, _f, _p, _p, _p, _p]),
+    "n3d_dice_bwd": (_i, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i, _i, _i64, _f, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "n3d_ncdhw_to_ndhwc": (_i, [_p, _p, _i64, _i, _i, _i64, _p]),
+    "n3d_ndhwc_to_ncdhw": (_i, [_p, _i64, _p, _i, _i, _i64, _p]),
+    "n3d_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _i, _p]),
+}
+
+# flags (include/n3d.h)
+RELU_IN, RELU, ACCUMULATE, POOL_MAX, NO_MFMA = 1, 2, 4, 8, 16
+
+_lib = None
+
+
+def load(path: str | None = None):
+    """dlopen libn3d.so and attach prototypes.  Raises N3DError if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise N3DError(
+            "libn3d.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C nas_3d_unet_amd/csrc`; there is no CPU fallback." % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().n3d_last_error()
+        raise N3DError("%s failed (%d): %s" % (what or "libn3d call", status, msg.decode() if msg else "?"))
+
+
+def require_device():
+    lib = load()
+    if not lib.n3d_device_ok():
+        raise N3DError("libn3d needs a gfx950 HIP device: %s" % lib.n3d_last_error().decode())

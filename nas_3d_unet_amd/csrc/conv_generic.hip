@@ -1,0 +1,754 @@
+// Generic (any k/stride/dilation/channel count) convolution family on the VALU.
+// One "gather" kernel serves Conv3d forward, its data gradient, ConvTranspose3d forward and its
+// data gradient: dst[v][cd] = bias + sum_tap sum_cs src[map(v,tap)][cs] * W[tap][cs][cd].
+// Weights are wave-uniform -> the compiler fetches them with scalar loads (s_load_dwordx4..16)
+// from the packed [tap][cs][cd] copy; activations are 16-byte vector loads of NDHWC voxels.
+// These kernels cover every shape of the path; the MFMA kernels in conv_mfma.hip take over the
+// FLOP-heavy 3x3x3 shapes.
+#include "n3d_common.h"
+
+namespace n3d {
+
+struct GatherArgs {
+  const float* src; int64_t sld; int Ds, Hs, Ws, Cs;
+  float* dst; int64_t dld; int Dd, Hd, Wd, Cd;
+  const float* wp; int Cdp;
+  const float* bias;
+  int k, sn, off, dt, den;
+  int flags;
+  const float* in_gate;
+  const float* relu_src; int64_t rld;
+  const float* out_gate;
+  double* stats;
+};
+
+// pack native (Co, Ci, k^3) weights into wp[tap][cs][cdp]; transpose=0: cs=ci, cd=co (forward);
+// transpose=1: cs=co, cd=ci (data gradient / transposed forward)
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int taps, int Cdp, int transpose) {
+  const int Cs = transpose ? Co : Ci, Cd = transpose ? Ci : Co;
+  const int total = taps * Cs * Cdp;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cd = i % Cdp, cs = (i / Cdp) % Cs, tap = i / (Cdp * Cs);
+  float v = 0.f;
+  if (cd < Cd) {
+    const int co = transpose ? cs : cd, ci = transpose ? cd : cs;
+    v = w[((int64_t)co * Ci + ci) * taps + tap];
+  }
+  wp[i] = v;
+}
+
+template <int CO_T, int SV>
+__global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
+  __shared__ double red[4][CO_T * 2];
+  const int b = blockIdx.z, cot = blockIdx.y;
+  const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd, Ns = (int64_t)a.Ds * a.Hs * a.Ws;
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = v < Nd;
+  const int64_t vv = valid ? v : 0;
+  const int w_ = (int)(vv % a.Wd), h_ = (int)((vv / a.Wd) % a.Hd), d_ = (int)(vv / ((int64_t)a.Wd * a.Hd));
+  float acc[CO_T];
+#pragma unroll
+  for (int j = 0; j < CO_T; ++j) {
+    const int c = cot * CO_T + j;
+    acc[j] = (a.bias && c < a.Cd) ? a.bias[c] : 0.f;
+  }
+  const float* srcb = a.src + (int64_t)b * Ns * a.sld;
+  const float* gate = a.in_gate ? a.in_gate + (int64_t)b * a.Cs : nullptr;
+  const bool relu_in = a.flags & N3D_RELU_IN;
+  const int k = a.k;
+  for (int kd = 0; kd < k; ++kd) {
+    int nd = d_ * a.sn + a.off + kd * a.dt;
+    bool okd = true;
+    if (a.den == 2) { okd = !(nd & 1); nd >>= 1; }
+    okd = okd && nd >= 0 && nd < a.Ds;
+    for (int kh = 0; kh < k; ++kh) {
+      int nh = h_ * a.sn + a.off + kh * a.dt;
+      bool okh = okd;
+      if (a.den == 2) { okh = okh && !(nh & 1); nh >>= 1; }
+      okh = okh && nh >= 0 && nh < a.Hs;
+      for (int kw = 0; kw < k; ++kw) {
+        int nw = w_ * a.sn + a.off + kw * a.dt;
+        bool ok = okh && valid;
+        if (a.den == 2) { ok = ok && !(nw & 1); nw >>= 1; }
+        ok = ok && nw >= 0 && nw < a.Ws;
+        const int tap = (kd * k + kh) * k + kw;
+        const float* wr = a.wp + (int64_t)tap * a.Cs * a.Cdp + cot * CO_T;
+        if (ok) {
+          const float* xs = srcb + (((int64_t)nd * a.Hs + nh) * a.Ws + nw) * a.sld;
+          if (SV == 4) {
+            for (int c4 = 0; c4 < a.Cs; c4 += 4) {
+              float4 q = *reinterpret_cast<const float4*>(xs + c4);
+              float xv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float x = xv[j];
+                if (relu_in) x = fmaxf(x, 0.f);
+                if (gate) x *= gate[c4 + j];
+                const float* wrow = wr + (int64_t)(c4 + j) * a.Cdp;
+#pragma unroll
+                for (int co = 0; co < CO_T; ++co) acc[co] = fmaf(x, wrow[co], acc[co]);
+              }
+            }
+          } else {
+            for (int c = 0; c < a.Cs; ++c) {
+              float x = xs[c];
+              if (relu_in) x = fmaxf(x, 0.f);
+              if (gate) x *= gate[c];
+              const float* wrow = wr + (int64_t)c * a.Cdp;
+#pragma unroll
+              for (int co = 0; co < CO_T; ++co) acc[co] = fmaf(x, wrow[co], acc[co]);
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- epilogue
+  const int c0 = cot * CO_T;
+  if (valid) {
+    if (a.relu_src) {
+      const float* rs = a.relu_src + ((int64_t)b * Nd + v) * a.rld + c0;
+#pragma unroll
+      for (int j = 0; j < CO_T; ++j)
+        if (c0 + j < a.Cd && !(rs[j] > 0.f)) acc[j] = 0.f;
+    }
+    if (a.out_gate) {
+#pragma unroll
+      for (int j = 0; j < CO_T; ++j)
+        if (c0 + j < a.Cd) acc[j] *= a.out_gate[(int64_t)b * a.Cd + c0 + j];
+    }
+    float* o = a.dst + ((int64_t)b * Nd + v) * a.dld + c0;
+    const bool accum = a.flags & N3D_ACCUMULATE;
+    if (CO_T % 4 == 0 && (a.Cd % 4 == 0) && (a.dld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0)) {
+#pragma unroll
+      for (int j = 0; j < CO_T; j += 4) {
+        float4* op = reinterpret_cast<float4*>(o + j);
+        float4 r = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+        if (accum) { const float4 p = *op; r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w; acc[j] = r.x; acc[j + 1] = r.y; acc[j + 2] = r.z; acc[j + 3] = r.w; }
+        *op = r;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CO_T; ++j)
+        if (c0 + j < a.Cd) { if (accum) acc[j] += o[j]; o[j] = acc[j]; }
+    }
+  }
+  if (a.stats) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) {
+      const float val = valid ? acc[j] : 0.f;
+      const double s = wave_sum_d((double)val), ss = wave_sum_d((double)val * (double)val);
+      if (lane == 0) { red[wave][j * 2] = s; red[wave][j * 2 + 1] = ss; }
+    }
+    __syncthreads();
+    if (threadIdx.x < CO_T * 2) {
+      const int j = threadIdx.x >> 1, kk = threadIdx.x & 1;
+      if (c0 + j < a.Cd) {
+        const double s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        a.stats[(((int64_t)b * gridDim.x + blockIdx.x) * a.Cd + c0 + j) * 2 + kk] = s;
+      }
+    }
+  }
+}
+
+static int pick_cot(int Cd) {
+  if (Cd % 16 == 0) return 16;
+  if (Cd % 12 == 0) return 12;
+  if (Cd % 8 == 0) return 8;
+  return 4;
+}
+
+template <int CO_T>
+static void launch_gather_t(const GatherArgs& a, int B, hipStream_t s) {
+  const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
+  dim3 grid((unsigned)cdiv(Nd, 256), (unsigned)(a.Cdp / CO_T), (unsigned)B);
+  const bool vec = (a.Cs % 4 == 0) && (a.sld % 4 == 0) && aligned16(a.src);
+  if (vec) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_gather_kernel<CO_T, 1>), grid, dim3(256), 0, s, a);
+}
+
+static void launch_gather(const GatherArgs& a, int B, hipStream_t s) {
+  switch (pick_cot(a.Cd)) {
+    case 16: launch_gather_t<16>(a, B, s); break;
+    case 12: launch_gather_t<12>(a, B, s); break;
+    case 8: launch_gather_t<8>(a, B, s); break;
+    default: launch_gather_t<4>(a, B, s); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: dW[co][ci][tap] = sum_{b,o} dy[b,o,co] * f(x[b, o*s - pad + tap*dil, ci])
+// one block = (chunk of flattened (b,o), one (tap, ci tile, co tile)); per-thread register outer
+// products, wave reduction, partial slabs, then a fixed-order final reduction (deterministic).
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* x; int64_t xld; int Di, Hi, Wi, Ci;
+  const float* dy; int64_t dyld; int Do, Ho, Wo, Co;
+  int B, k, stride, dil, pad, flags;
+  const float* in_gate;
+  float* partial;   // [nchunks][ntiles][CI_T*CO_T]
+  float* pbias;     // [nchunks][tco][CO_T]
+  int tci, tco;
+  int64_t chunk;
+};
+
+template <int CI_T, int CO_T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  __shared__ float red[4][CI_T * CO_T + CO_T];
+  const int tile = blockIdx.y;
+  const int cot = tile % a.tco, cit = (tile / a.tco) % a.tci, tap = tile / (a.tco * a.tci);
+  const int kw = tap % a.k, kh = (tap / a.k) % a.k, kd = tap / (a.k * a.k);
+  const int64_t No = (int64_t)a.Do * a.Ho * a.Wo, Ni = (int64_t)a.Di * a.Hi * a.Wi;
+  const int64_t total = (int64_t)a.B * No;
+  const int64_t i0 = (int64_t)blockIdx.x * a.chunk;
+  int64_t i1 = i0 + a.chunk;
+  if (i1 > total) i1 = total;
+  const bool relu_in = a.flags & N3D_RELU_IN;
+  const bool do_bias = (tap == 0 && cit == 0);
+  const bool covec = (a.Co % 4 == 0) && (a.dyld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.dy) & 15) == 0);
+  float acc[CI_T][CO_T];
+  float bacc[CO_T];
+#pragma unroll
+  for (int i = 0; i < CI_T; ++i)
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) acc[i][j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < CO_T; ++j) bacc[j] = 0.f;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const int b = (int)(i / No);
+    const int64_t o = i % No;
+    const int ow = (int)(o % a.Wo), oh = (int)((o / a.Wo) % a.Ho), od = (int)(o / ((int64_t)a.Wo * a.Ho));
+    float dyv[CO_T];
+    const float* dp = a.dy + i * a.dyld + cot * CO_T;
+    if (covec) {
+#pragma unroll
+      for (int j = 0; j < CO_T; j += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(dp + j);
+        dyv[j] = q.x; dyv[j + 1] = q.y; dyv[j + 2] = q.z; dyv[j + 3] = q.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CO_T; ++j) dyv[j] = (cot * CO_T + j < a.Co) ? dp[j] : 0.f;
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int j = 0; j < CO_T; ++j) bacc[j] += dyv[j];
+    }
+    const int id = od * a.stride - a.pad + kd * a.dil, ih = oh * a.stride - a.pad + kh * a.dil, iw = ow * a.stride - a.pad + kw * a.dil;
+    if (id < 0 || id >= a.Di || ih < 0 || ih >= a.Hi || iw < 0 || iw >= a.Wi) continue;
+    const float* xp = a.x + ((int64_t)b * Ni + ((int64_t)id * a.Hi + ih) * a.Wi + iw) * a.xld + cit * CI_T;
+    float xv[CI_T];
+#pragma unroll
+    for (int c = 0; c < CI_T; c += 4) {
+      const float4 q = *reinterpret_cast<const float4*>(xp + c);
+      xv[c] = q.x; xv[c + 1] = q.y; xv[c + 2] = q.z; xv[c + 3] = q.w;
+    }
+#pragma unroll
+    for (int c = 0; c < CI_T; ++c) {
+      if (relu_in) xv[c] = fmaxf(xv[c], 0.f);
+      if (a.in_gate) xv[c] *= a.in_gate[(int64_t)b * a.Ci + cit * CI_T + c];
+    }
+#pragma unroll
+    for (int c = 0; c < CI_T; ++c)
+#pragma unroll
+      for (int j = 0; j < CO_T; ++j) acc[c][j] = fmaf(xv[c], dyv[j], acc[c][j]);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < CI_T; ++c)
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) {
+      const float s = wave_sum_f(acc[c][j]);
+      if (lane == 0) red[wave][c * CO_T + j] = s;
+    }
+#pragma unroll
+  for (int j = 0; j < CO_T; ++j) {
+    const float s = wave_sum_f(bacc[j]);
+    if (lane == 0) red[wave][CI_T * CO_T + j] = s;
+  }
+  __syncthreads();
+  const int ntiles = gridDim.y;
+  for (int q = threadIdx.x; q < CI_T * CO_T; q += 256)
+    a.partial[((int64_t)blockIdx.x * ntiles + tile) * (CI_T * CO_T) + q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+  if (do_bias && threadIdx.x < CO_T) {
+    const int q = CI_T * CO_T + threadIdx.x;
+    a.pbias[((int64_t)blockIdx.x * a.tco + cot) * CO_T + threadIdx.x] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_final_kernel(const float* __restrict__ partial, const float* __restrict__ pbias, int nchunks,
+                                                               int ntiles, int tci, int tco, int CI_T, int CO_T, int Co, int Ci, int taps,
+                                                               float* __restrict__ dw, float* __restrict__ dbias) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int nw = Co * Ci * taps;
+  if (i < nw) {
+    if (dw) {
+      const int tap = i % taps, ci = (i / taps) % Ci, co = i / (taps * Ci);
+      const int cit = ci / CI_T, cot = co / CO_T;
+      const int tile = (tap * tci + cit) * tco + cot;
+      const int q = (ci % CI_T) * CO_T + (co % CO_T);
+      float s = 0.f;
+      for (int c = 0; c < nchunks; ++c) s += partial[((int64_t)c * ntiles + tile) * (CI_T * CO_T) + q];
+      dw[i] = s;
+    }
+  } else if (i < nw + Co && dbias) {
+    const int co = i - nw;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += pbias[((int64_t)c * tco + co / CO_T) * CO_T + co % CO_T];
+    dbias[co] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// depthwise family (groups == C): per-lane weights, float4 over 4 channels
+// ------------------------------------------------------------------------------------------------
+struct DwArgs {
+  const float* src; int64_t sld; int Ds, Hs, Ws;
+  float* dst; int64_t dld; int Dd, Hd, Wd;
+  int C;
+  const float* w;   // native (C,1,k,k,k)
+  const float* bias;
+  int k, sn, off, dt, den, flags;
+};
+
+__global__ __launch_bounds__(256) void dw_gather_kernel(DwArgs a) {
+  const int cpb = a.C / 4;
+  const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd, Ns = (int64_t)a.Ds * a.Hs * a.Ws;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Nd * cpb) return;
+  const int b = blockIdx.y;
+  const int c4 = (int)(idx % cpb);
+  const int64_t v = idx / cpb;
+  const int w_ = (int)(v % a.Wd), h_ = (int)((v / a.Wd) % a.Hd), d_ = (int)(v / ((int64_t)a.Wd * a.Hd));
+  const int k = a.k, taps = k * k * k;
+  float acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = a.bias ? a.bias[c4 * 4 + j] : 0.f;
+  const float* srcb = a.src + (int64_t)b * Ns * a.sld + c4 * 4;
+  const float* wc = a.w + (int64_t)c4 * 4 * taps;
+  for (int kd = 0; kd < k; ++kd) {
+    int nd = d_ * a.sn + a.off + kd * a.dt;
+    if (a.den == 2) { if (nd & 1) continue; nd >>= 1; }
+    if (nd < 0 || nd >= a.Ds) continue;
+    for (int kh = 0; kh < k; ++kh) {
+      int nh = h_ * a.sn + a.off + kh * a.dt;
+      if (a.den == 2) { if (nh & 1) continue; nh >>= 1; }
+      if (nh < 0 || nh >= a.Hs) continue;
+      for (int kw = 0; kw < k; ++kw) {
+        int nw = w_ * a.sn + a.off + kw * a.dt;
+        if (a.den == 2) { if (nw & 1) continue; nw >>= 1; }
+        if (nw < 0 || nw >= a.Ws) continue;
+        const int tap = (kd * k + kh) * k + kw;
+        const float4 q = *reinterpret_cast<const float4*>(srcb + (((int64_t)nd * a.Hs + nh) * a.Ws + nw) * a.sld);
+        acc[0] = fmaf(q.x, wc[tap], acc[0]);
+        acc[1] = fmaf(q.y, wc[taps + tap], acc[1]);
+        acc[2] = fmaf(q.z, wc[2 * taps + tap], acc[2]);
+        acc[3] = fmaf(q.w, wc[3 * taps + tap], acc[3]);
+      }
+    }
+  }
+  float4* op = reinterpret_cast<float4*>(a.dst + ((int64_t)b * Nd + v) * a.dld + c4 * 4);
+  if (a.flags & N3D_ACCUMULATE) { const float4 p = *op; acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w; }
+  *op = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+struct DwWgradArgs {
+  const float* x; int64_t xld; int Di, Hi, Wi;
+  const float* dy; int64_t dyld; int Do, Ho, Wo;
+  int B, C, k, stride, pad;
+  float* partial;  // [nchunks][27+1][C]
+  int64_t chunk;   // flattened (b,o) voxels per block
+};
+
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
+  extern __shared__ float dyn[];
+  const int cpb = a.C / 4, vpb = 256 / cpb;
+  const int t = threadIdx.x, c4 = t % cpb, vl = t / cpb;
+  const int64_t No = (int64_t)a.Do * a.Ho * a.Wo, Ni = (int64_t)a.Di * a.Hi * a.Wi;
+  const int64_t total = (int64_t)a.B * No;
+  const int64_t i0 = (int64_t)blockIdx.x * a.chunk;
+  int64_t i1 = i0 + a.chunk;
+  if (i1 > total) i1 = total;
+  float acc[28][4];
+#pragma unroll
+  for (int q = 0; q < 28; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[q][j] = 0.f;
+  if (vl < vpb) {
+    for (int64_t i = i0 + vl; i < i1; i += vpb) {
+      const int b = (int)(i / No);
+      const int64_t o = i % No;
+      const int ow = (int)(o % a.Wo), oh = (int)((o / a.Wo) % a.Ho), od = (int)(o / ((int64_t)a.Wo * a.Ho));
+      const float4 g = *reinterpret_cast<const float4*>(a.dy + i * a.dyld + c4 * 4);
+      acc[27][0] += g.x; acc[27][1] += g.y; acc[27][2] += g.z; acc[27][3] += g.w;
+      const float* xb = a.x + (int64_t)b * Ni * a.xld + c4 * 4;
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) {
+        const int id = od * a.stride - a.pad + kd;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int ih = oh * a.stride - a.pad + kh;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int iw = ow * a.stride - a.pad + kw;
+            if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi) {
+              const float4 q = *reinterpret_cast<const float4*>(xb + (((int64_t)id * a.Hi + ih) * a.Wi + iw) * a.xld);
+              const int tap = (kd * 3 + kh) * 3 + kw;
+              acc[tap][0] = fmaf(q.x, g.x, acc[tap][0]);
+              acc[tap][1] = fmaf(q.y, g.y, acc[tap][1]);
+              acc[tap][2] = fmaf(q.z, g.z, acc[tap][2]);
+              acc[tap][3] = fmaf(q.w, g.w, acc[tap][3]);
+            }
+          }
+        }
+      }
+    }
+  }
+  // wave-level strided reduction, then LDS across waves: dyn[wave][class c4][28][4]
+  const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+  for (int q = 0; q < 28; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[q][j] = wave_sum_strided_f(acc[q][j], cpb);
+  if (lane < cpb) {
+    const int cls = (wave * 64 + lane) % cpb;
+#pragma unroll
+    for (int q = 0; q < 28; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dyn[((wave * cpb + cls) * 28 + q) * 4 + j] = acc[q][j];
+  }
+  __syncthreads();
+  const int nq = cpb * 28 * 4;
+  for (int i = t; i < nq; i += 256) {
+    const int j = i % 4, q = (i / 4) % 28, cls = i / (4 * 28);
+    float s = 0.f;
+    for (int w = 0; w < 4; ++w) s += dyn[((w * cpb + cls) * 28 + q) * 4 + j];
+    a.partial[((int64_t)blockIdx.x * 28 + q) * a.C + cls * 4 + j] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void dw_wgrad_final_kernel(const float* __restrict__ partial, int nchunks, int C, float* __restrict__ dw,
+                                                             float* __restrict__ dbias) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 28 * C) return;
+  const int c = i % C, q = i / C;
+  float s = 0.f;
+  for (int k = 0; k < nchunks; ++k) s += partial[((int64_t)k * 28 + q) * C + c];
+  if (q < 27) { if (dw) dw[c * 27 + q] = s; }
+  else if (dbias) dbias[c] = s;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// per-channel sum over all (b, voxel): bias gradient of a transposed convolution
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, int64_t ld, int64_t total, int C, int64_t chunk,
+                                                          float* __restrict__ partial /*[nblk][C]*/) {
+  extern __shared__ float dyn[];
+  const int cpb = C / 4, vpb = 256 / cpb;
+  const int t = threadIdx.x, c4 = t % cpb, vl = t / cpb;
+  const int64_t i0 = (int64_t)blockIdx.x * chunk;
+  int64_t i1 = i0 + chunk;
+  if (i1 > total) i1 = total;
+  float acc[4] = {0, 0, 0, 0};
+  if (vl < vpb)
+    for (int64_t i = i0 + vl; i < i1; i += vpb) {
+      const float4 q = *reinterpret_cast<const float4*>(x + i * ld + c4 * 4);
+      acc[0] += q.x; acc[1] += q.y; acc[2] += q.z; acc[3] += q.w;
+    }
+  const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = wave_sum_strided_f(acc[j], cpb);
+  if (lane < cpb) {
+    const int cls = (wave * 64 + lane) % cpb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dyn[(wave * cpb + cls) * 4 + j] = acc[j];
+  }
+  __syncthreads();
+  for (int i = t; i < C; i += 256) {
+    const int cls = i / 4, j = i % 4;
+    float s = 0.f;
+    for (int w = 0; w < 4; ++w) s += dyn[(w * cpb + cls) * 4 + j];
+    partial[(int64_t)blockIdx.x * C + i] = s;
+  }
+}
+__global__ void channel_sum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < nblk; ++k) s += partial[(int64_t)k * C + c];
+  out[c] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launch helpers shared with the C ABI
+// ------------------------------------------------------------------------------------------------
+static int wgrad_tiles(int Ci, int Co, int* ci_t, int* co_t) {
+  *ci_t = (Ci % 8 == 0) ? 8 : 4;
+  *co_t = (Co % 16 == 0) ? 16 : (Co % 8 == 0 ? 8 : 4);
+  return 0;
+}
+
+struct WgradPlan { int ci_t, co_t, tci, tco, ntiles, nchunks; int64_t chunk; size_t partial_floats, pbias_floats; };
+
+static WgradPlan wgrad_plan(int B, int64_t No, int Ci, int Co, int taps) {
+  WgradPlan p;
+  wgrad_tiles(Ci, Co, &p.ci_t, &p.co_t);
+  p.tci = Ci / p.ci_t;
+  p.tco = (int)cdiv(Co, p.co_t);
+  p.ntiles = taps * p.tci * p.tco;
+  const int64_t total = (int64_t)B * No;
+  int64_t nch = cdiv(total, 4096);
+  // keep the grid around a few thousand blocks
+  while (nch * p.ntiles > 8192 && nch > 1) nch = (nch + 1) / 2;
+  if (nch > 512) nch = 512;
+  p.chunk = cdiv(total, nch);
+  p.chunk = cdiv(p.chunk, 256) * 256;
+  p.nchunks = (int)cdiv(total, p.chunk);
+  p.partial_floats = (size_t)p.nchunks * p.ntiles * p.ci_t * p.co_t;
+  p.pbias_floats = (size_t)p.nchunks * p.tco * p.co_t;
+  return p;
+}
+
+template <int CI_T, int CO_T>
+static void launch_wgrad_t(const WgradArgs& a, const WgradPlan& p, hipStream_t s) {
+  hipLaunchKernelGGL((conv_wgrad_kernel<CI_T, CO_T>), dim3(p.nchunks, p.ntiles), dim3(256), 0, s, a);
+}
+
+}  // namespace n3d
+
+using namespace n3d;
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static size_t packed_floats(const n3d_conv_geom* g) {
+  const int taps = g->k * g->k * g->k;
+  const int cmax = g->Ci > g->Co ? g->Ci : g->Co;
+  const int cpad = (int)align_up(cmax, 16);
+  return (size_t)taps * cmax * cpad;
+}
+
+static int check_geom(const n3d_conv_geom* g, const char* who) {
+  if (!g) { set_error("%s: null geometry", who); return N3D_ERR_INVALID; }
+  if (g->B <= 0 || g->Di <= 0 || g->Hi <= 0 || g->Wi <= 0 || g->Ci <= 0 || g->Do <= 0 || g->Ho <= 0 || g->Wo <= 0 || g->Co <= 0) {
+    set_error("%s: non-positive dimension", who); return N3D_ERR_INVALID;
+  }
+  if (!(g->k == 1 || g->k == 3) || !(g->stride == 1 || g->stride == 2) || !(g->dil == 1 || g->dil == 2) || g->pad < 0) {
+    set_error("%s: unsupported k=%d stride=%d dil=%d", who, g->k, g->stride, g->dil); return N3D_ERR_UNSUPPORTED;
+  }
+  auto odim = [&](int i) { return (i + 2 * g->pad - g->dil * (g->k - 1) - 1) / g->stride + 1; };
+  // for transposed use the o side is smaller by construction; accept any o with odim(i) == o
+  if (odim(g->Di) != g->Do || odim(g->Hi) != g->Ho || odim(g->Wi) != g->Wo) {
+    set_error("%s: geometry mismatch: i=(%d,%d,%d) o=(%d,%d,%d) k=%d s=%d d=%d p=%d", who, g->Di, g->Hi, g->Wi, g->Do, g->Ho, g->Wo, g->k,
+              g->stride, g->dil, g->pad);
+    return N3D_ERR_INVALID;
+  }
+  if (g->depthwise && (g->Ci != g->Co || g->Ci % 4 != 0 || g->k != 3 || g->dil != 1)) {
+    set_error("%s: depthwise needs Ci == Co, C %% 4 == 0, k=3, dil=1", who); return N3D_ERR_UNSUPPORTED;
+  }
+  return 0;
+}
+
+namespace n3d {
+// implemented in conv_mfma.hip: returns 1 if it handled the call, 0 to fall through, <0 on error
+int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
+                  int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate, double* stats,
+                  void* ws, size_t ws_bytes, hipStream_t s);
+int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags);
+}
+
+extern "C" {
+
+size_t n3d_conv_workspace_bytes(const n3d_conv_geom* g) {
+  if (!g) return 0;
+  const int taps = g->k * g->k * g->k;
+  size_t bytes = align_up(packed_floats(g) * 4, 256);
+  // weight-gradient partial slabs (dense) or depthwise partials
+  const int64_t No = (int64_t)g->Do * g->Ho * g->Wo, Ni = (int64_t)g->Di * g->Hi * g->Wi;
+  if (g->depthwise) {
+    bytes += align_up((size_t)512 * 28 * g->Ci * 4, 256);
+  } else {
+    WgradPlan p1 = wgrad_plan(g->B, No, g->Ci, g->Co, taps);
+    WgradPlan p2 = wgrad_plan(g->B, No, g->Co, g->Ci, taps);  // transposed roles
+    size_t a = (p1.partial_floats + p1.pbias_floats) * 4, b = (p2.partial_floats + p2.pbias_floats) * 4;
+    bytes += align_up(a > b ? a : b, 256) + 256;
+  }
+  (void)Ni;
+  return bytes;
+}
+
+// number of partial-statistics rows per sample the forward (transposed=0) or transposed-forward
+// (transposed=1) kernel writes into `stats` ([B][rows][Cout][2] doubles)
+int n3d_conv_stats_rows(const n3d_conv_geom* g, int transposed, int flags) {
+  if (!g) return 0;
+  int r = mfma_conv_stats_rows(g, transposed != 0, flags);
+  if (r > 0) return r;
+  const int64_t Nd = transposed ? (int64_t)g->Di * g->Hi * g->Wi : (int64_t)g->Do * g->Ho * g->Wo;
+  return (int)cdiv(Nd, 256);
+}
+
+static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
+                      int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate,
+                      double* stats, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (g->depthwise) {
+    N3D_CHECK_ARG(!in_gate && !relu_src && !out_gate && !stats && !(flags & N3D_RELU_IN), "depthwise conv: gate/relu/stats not supported");
+    N3D_CHECK_ARG(sld % 4 == 0 && dld % 4 == 0 && aligned16(src) && aligned16(dst), "depthwise conv: needs 16-byte aligned pitched rows");
+    DwArgs a;
+    a.C = g->Ci; a.w = w; a.bias = bias; a.k = g->k; a.flags = flags;
+    if (!data_grad) { a.src = src; a.sld = sld; a.Ds = g->Di; a.Hs = g->Hi; a.Ws = g->Wi; a.dst = dst; a.dld = dld; a.Dd = g->Do; a.Hd = g->Ho; a.Wd = g->Wo;
+      a.sn = g->stride; a.off = -g->pad; a.dt = g->dil; a.den = 1; }
+    else { a.src = src; a.sld = sld; a.Ds = g->Do; a.Hs = g->Ho; a.Ws = g->Wo; a.dst = dst; a.dld = dld; a.Dd = g->Di; a.Hd = g->Hi; a.Wd = g->Wi;
+      a.sn = 1; a.off = g->pad; a.dt = -g->dil; a.den = g->stride; }
+    const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
+    hipLaunchKernelGGL(dw_gather_kernel, dim3((unsigned)cdiv(Nd * (a.C / 4), 256), g->B), dim3(256), 0, s, a);
+    N3D_LAUNCH_CHECK();
+    return N3D_OK;
+  }
+  if (!(flags & N3D_NO_MFMA)) {
+    int r = mfma_conv_try(g, data_grad, src, sld, w, bias, dst, dld, flags, in_gate, relu_src, rld, out_gate, stats, ws, ws_bytes, s);
+    if (r != 0) return r < 0 ? r : N3D_OK;
+  }
+  const int taps = g->k * g->k * g->k;
+  GatherArgs a;
+  a.bias = bias; a.k = g->k; a.flags = flags; a.in_gate = in_gate; a.relu_src = relu_src; a.rld = rld; a.out_gate = out_gate; a.stats = stats;
+  a.src = src; a.sld = sld; a.dst = dst; a.dld = dld;
+  if (!data_grad) { a.Ds = g->Di; a.Hs = g->Hi; a.Ws = g->Wi; a.Cs = g->Ci; a.Dd = g->Do; a.Hd = g->Ho; a.Wd = g->Wo; a.Cd = g->Co;
+    a.sn = g->stride; a.off = -g->pad; a.dt = g->dil; a.den = 1; }
+  else { a.Ds = g->Do; a.Hs = g->Ho; a.Ws = g->Wo; a.Cs = g->Co; a.Dd = g->Di; a.Hd = g->Hi; a.Wd = g->Wi; a.Cd = g->Ci;
+    a.sn = 1; a.off = g->pad; a.dt = -g->dil; a.den = g->stride; }
+  const int cot = pick_cot(a.Cd);
+  a.Cdp = (int)align_up(a.Cd, cot);
+  const size_t need = (size_t)taps * a.Cs * a.Cdp * 4;
+  if (!ws || ws_bytes < need) { set_error("conv: workspace too small (%zu < %zu)", ws_bytes, need); return N3D_ERR_WORKSPACE; }
+  float* wp = (float*)ws;
+  a.wp = wp;
+  const int total = taps * a.Cs * a.Cdp;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g->Co, g->Ci, taps, a.Cdp, data_grad ? 1 : 0);
+  launch_gather(a, g->B, s);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_conv_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias, float* y, int64_t yld, int flags,
+                 const float* in_gate, double* stats, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_geom(g, "conv_fwd")) return e;
+  N3D_CHECK_ARG(x && w && y && xld >= g->Ci && yld >= g->Co, "conv_fwd: bad pointers/pitches");
+  return run_gather(g, false, x, xld, w, bias, y, yld, flags, in_gate, nullptr, 0, nullptr, stats, ws, ws_bytes, stream);
+}
+
+int n3d_conv_bwd_data(const n3d_conv_geom* g, const float* dy, int64_t dyld, const float* w, float* dx, int64_t dxld, int flags,
+                      const float* relu_src, int64_t rld, const float* out_gate, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_geom(g, "conv_bwd_data")) return e;
+  N3D_CHECK_ARG(dy && w && dx && dyld >= g->Co && dxld >= g->Ci, "conv_bwd_data: bad pointers/pitches");
+  return run_gather(g, true, dy, dyld, w, nullptr, dx, dxld, flags & ~N3D_RELU_IN, nullptr, relu_src, rld, out_gate, nullptr, ws, ws_bytes,
+                    stream);
+}
+
+int n3d_convT_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias, float* y, int64_t yld, int flags,
+                  const float* in_gate, double* stats, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_geom(g, "convT_fwd")) return e;
+  N3D_CHECK_ARG(x && w && y && xld >= g->Co && yld >= g->Ci, "convT_fwd: bad pointers/pitches");
+  return run_gather(g, true, x, xld, w, bias, y, yld, flags, in_gate, nullptr, 0, nullptr, stats, ws, ws_bytes, stream);
+}
+
+int n3d_convT_bwd_data(const n3d_conv_geom* g, const float* dy, int64_t dyld, const float* w, float* dx, int64_t dxld, int flags, void* ws,
+                       size_t ws_bytes, void* stream) {
+  if (int e = check_geom(g, "convT_bwd_data")) return e;
+  N3D_CHECK_ARG(dy && w && dx && dyld >= g->Ci && dxld >= g->Co, "convT_bwd_data: bad pointers/pitches");
+  return run_gather(g, false, dy, dyld, w, nullptr, dx, dxld, flags & ~N3D_RELU_IN, nullptr, nullptr, 0, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, float* dw, float* dbias, int flags,
+                     const float* in_gate, void* ws, size_t ws_bytes, void* stream, bool transposed) {
+  hipStream_t s = (hipStream_t)stream;
+  const int taps = g->k * g->k * g->k;
+  const int64_t No = (int64_t)g->Do * g->Ho * g->Wo;
+  const size_t skip = align_up(packed_floats(g) * 4, 256);
+  if (!ws || ws_bytes <= skip) { set_error("conv_bwd_weight: workspace too small"); return N3D_ERR_WORKSPACE; }
+  float* wsf = (float*)((char*)ws + skip);
+  const size_t avail = (ws_bytes - skip) / 4;
+  if (g->depthwise) {
+    // conv-side roles: X on the i side, DY on the o side (callers of the transposed form pass them swapped)
+    N3D_CHECK_ARG(!in_gate && !(flags & N3D_RELU_IN), "depthwise wgrad: gate/relu not supported");
+    DwWgradArgs a;
+    a.x = x; a.xld = xld; a.Di = g->Di; a.Hi = g->Hi; a.Wi = g->Wi; a.dy = dy; a.dyld = dyld; a.Do = g->Do; a.Ho = g->Ho; a.Wo = g->Wo;
+    a.B = g->B; a.C = g->Ci; a.k = 3; a.stride = g->stride; a.pad = g->pad; a.partial = wsf;
+    const int64_t total = (int64_t)g->B * No;
+    int64_t nch = cdiv(total, 2048);
+    if (nch > 512) nch = 512;
+    a.chunk = cdiv(total, nch);
+    const int nchunks = (int)cdiv(total, a.chunk);
+    if ((size_t)nchunks * 28 * a.C > avail) { set_error("dw wgrad: workspace too small"); return N3D_ERR_WORKSPACE; }
+    const int cpb = a.C / 4;
+    hipLaunchKernelGGL(dw_wgrad_kernel, dim3(nchunks), dim3(256), (size_t)4 * cpb * 28 * 4 * sizeof(float), s, a);
+    hipLaunchKernelGGL(dw_wgrad_final_kernel, dim3((unsigned)cdiv(28 * a.C, 256)), dim3(256), 0, s, wsf, nchunks, a.C, dw, dbias);
+    N3D_LAUNCH_CHECK();
+    return N3D_OK;
+  }
+  // dense: the kernel computes G[co'][ci'][tap] = sum dyK[o][co'] * xK[i(o,tap)][ci'] with xK on the i side.
+  // forward conv: xK = x (Ci), dyK = dy (Co), dw native (Co,Ci,k^3) = G.
+  // transposed conv (weight (CinT=Co_geom, CoutT=Ci_geom)): xK = dy_T (i side, Ci), dyK = x_T (o side, Co): same G layout.
+  WgradPlan p = wgrad_plan(g->B, No, g->Ci, g->Co, taps);
+  if (p.partial_floats + p.pbias_floats > avail) { set_error("conv_bwd_weight: workspace too small"); return N3D_ERR_WORKSPACE; }
+  WgradArgs a;
+  a.x = x; a.xld = xld; a.Di = g->Di; a.Hi = g->Hi; a.Wi = g->Wi; a.Ci = g->Ci;
+  a.dy = dy; a.dyld = dyld; a.Do = g->Do; a.Ho = g->Ho; a.Wo = g->Wo; a.Co = g->Co;
+  a.B = g->B; a.k = g->k; a.stride = g->stride; a.dil = g->dil; a.pad = g->pad; a.flags = flags; a.in_gate = in_gate;
+  a.partial = wsf; a.pbias = wsf + p.partial_floats; a.tci = p.tci; a.tco = p.tco; a.chunk = p.chunk;
+  N3D_CHECK_ARG(g->Ci % 4 == 0 && xld % 4 == 0 && aligned16(x), "conv_bwd_weight: i-side tensor needs C %% 4 == 0 and 16-byte alignment");
+  if (p.ci_t == 8 && p.co_t == 16) launch_wgrad_t<8, 16>(a, p, s);
+  else if (p.ci_t == 8 && p.co_t == 8) launch_wgrad_t<8, 8>(a, p, s);
+  else if (p.ci_t == 8 && p.co_t == 4) launch_wgrad_t<8, 4>(a, p, s);
+  else if (p.ci_t == 4 && p.co_t == 16) launch_wgrad_t<4, 16>(a, p, s);
+  else if (p.ci_t == 4 && p.co_t == 8) launch_wgrad_t<4, 8>(a, p, s);
+  else launch_wgrad_t<4, 4>(a, p, s);
+  const int nout = g->Co * g->Ci * taps + g->Co;
+  hipLaunchKernelGGL(conv_wgrad_final_kernel, dim3((unsigned)cdiv(nout, 256)), dim3(256), 0, s, a.partial, a.pbias, p.nchunks, p.ntiles, p.tci,
+                     p.tco, p.ci_t, p.co_t, g->Co, g->Ci, taps, dw, transposed ? nullptr : dbias);
+  N3D_LAUNCH_CHECK();
+  (void)transposed;
+  return N3D_OK;
+}
+
+int n3d_conv_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, float* dw, float* dbias, int flags,
+                        const float* in_gate, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_geom(g, "conv_bwd_weight")) return e;
+  N3D_CHECK_ARG(x && dy && (dw || dbias), "conv_bwd_weight: bad pointers");
+  return run_wgrad(g, x, xld, dy, dyld, dw, dbias, flags, in_gate, ws, ws_bytes, stream, false);
+}
+
+
+int n3d_convT_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, float* dw, float* dbias, int flags,
+                         void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_geom(g, "convT_bwd_weight")) return e;
+  N3D_CHECK_ARG(x && dy && (dw || dbias) && xld >= g->Co && dyld >= g->Ci, "convT_bwd_weight: bad pointers/pitches");
+  // kernel roles: i-side tensor = dy (Ci channels), o-side tensor = x (Co channels); see run_wgrad
+  if (dw) {
+    int e = run_wgrad(g, dy, dyld, x, xld, dw, nullptr, flags & ~N3D_RELU_IN, nullptr, ws, ws_bytes, stream, true);
+    if (e) return e;
+  }
+  if (dbias) {
+    // bias gradient = per-channel sum of dy over the i side
+    hipStream_t s = (hipStream_t)stream;
+    N3D_CHECK_ARG(g->Ci % 4 == 0 && dyld % 4 == 0 && aligned16(dy) && g->Ci <= 256, "convT_bwd_weight: dy needs C %% 4 == 0");
+    const size_t skip = align_up(packed_floats(g) * 4, 256);
+    float* wsf = (float*)((char*)ws + skip);
+    const int64_t total = (int64_t)g->B * g->Di * g->Hi * g->Wi;
+    int64_t nblk = cdiv(total, 4096);
+    if (nblk > 256) nblk = 256;
+    const int64_t chunk = cdiv(total, nblk);
+    nblk = cdiv(total, chunk);
+    // the slab region is free again once run_wgrad's final kernel has been enqueued (stream order)
+    if (!ws || ws_bytes < skip + (size_t)nblk * g->Ci * 4) { set_error("convT_bwd_weight: workspace too small"); return N3D_ERR_WORKSPACE; }
+    hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)nblk), dim3(256), (size_t)4 * (g->Ci / 4) * 4 * sizeof(float), s, dy, dyld, total, g->Ci,
+                       chunk, wsf);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((unsigned)cdiv(g->Ci, 256)), dim3(256), 0, s, wsf, (int)nblk, g->Ci, dbias);
+    N3D_LAUNCH_CHECK();
+  }
+  return N3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,816 @@
+// Bandwidth-bound kernels of the hot path: per-channel statistics, the normalise/activate/
+// weighted-sum epilogue and its backward, SE gate, pooling, Dice, layout, Adam.
+// All are HBM-bound streaming passes: 16-byte accesses, lane-consecutive addresses, >= 256 blocks
+// where the tensor is large enough, partial rows + a tiny finalize kernel instead of atomics.
+#include "n3d_common.h"
+
+namespace n3d {
+
+// ------------------------------------------------------------------------------------------------
+// block-level reduction of NV4 = 4*NV doubles per thread over the threads that share a channel quad;
+// writes row[c*NV + k] for the block's sample.  vals are laid out [k][j] (k value kind, j channel in quad)
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void block_reduce_to_row(double (&vals)[NV * 4], int cpb, double* __restrict__ row,
+                                                    double* lds /* [4 waves][cpb max 64][NV*4] */) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NV * 4; ++q) vals[q] = wave_sum_strided(vals[q], cpb);
+  // the class of lane l (< cpb) in this wave is (wave*64 + l) % cpb
+  if (lane < cpb) {
+    const int c4 = (wave * 64 + lane) % cpb;
+#pragma unroll
+    for (int q = 0; q < NV * 4; ++q) lds[(wave * 64 + c4) * (NV * 4) + q] = vals[q];
+  }
+  __syncthreads();
+  const int nq = cpb * NV * 4;
+  for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+    const int c4 = i / (NV * 4), q = i % (NV * 4);
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += lds[(w * 64 + c4) * (NV * 4) + q];
+    const int k = q / 4, j = q % 4;
+    row[(c4 * 4 + j) * NV + k] = s;
+  }
+}
+
+// NOTE on wave classes: when 64 % cpb != 0 the lanes < cpb of different waves hold different
+// classes; the LDS slot is indexed by the class, and every class is present in every wave
+// (cpb <= 64), so each (wave, class) slot is written exactly once.
+
+// ------------------------------------------------------------------------------------------------
+// channel statistics
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, int64_t ld, int64_t N, int C,
+                                                            EwMap m, double* __restrict__ stats) {
+  __shared__ double lds[4 * 64 * 8];
+  const int b = blockIdx.y;
+  const int t = threadIdx.x;
+  const int c4 = t % m.cpb, vl = t / m.cpb;
+  const bool active = vl < m.vpb;
+  const int64_t v0 = (int64_t)blockIdx.x * m.vpc;
+  float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  if (active) {
+    const float* xb = x + (int64_t)b * N * ld + c4 * 4;
+    for (int it = 0; it < m.iters; ++it) {
+      const int64_t v = v0 + (int64_t)it * m.vpb + vl;
+      if (v < N) {
+        const float4 q = *reinterpret_cast<const float4*>(xb + v * ld);
+        s[0] += q.x; s[1] += q.y; s[2] += q.z; s[3] += q.w;
+        ss[0] += q.x * q.x; ss[1] += q.y * q.y; ss[2] += q.z * q.z; ss[3] += q.w * q.w;
+      }
+    }
+  }
+  double vals[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { vals[j] = s[j]; vals[4 + j] = ss[j]; }
+  double* row = stats + ((int64_t)b * gridDim.x + blockIdx.x) * C * 2;
+  block_reduce_to_row<2>(vals, m.cpb, row, lds);
+}
+
+// sum partial rows: out[q] for q < ncol, executed by a whole 256-thread block; result in lds_out
+__device__ __forceinline__ void reduce_rows(const double* __restrict__ rows, int nrows, int ncol, double* lds_part /*[256]*/,
+                                            double* lds_out /*[ncol]*/) {
+  const int t = threadIdx.x;
+  const int nrl = 256 / ncol > 0 ? 256 / ncol : 1;
+  // ncol <= 256 guaranteed by callers (C <= 64, NV <= 3 -> 192)
+  const int q = t % ncol, rl = t / ncol;
+  double s = 0;
+  if (rl < nrl)
+    for (int r = rl; r < nrows; r += nrl) s += rows[(int64_t)r * ncol + q];
+  lds_part[t] = s;
+  __syncthreads();
+  if (t < ncol) {
+    double a = 0;
+    for (int r = 0; r < nrl; ++r) a += lds_part[r * ncol + t];
+    lds_out[t] = a;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void gn_coeffs_kernel(const double* __restrict__ stats, int rows, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int C, int G, double count, float eps,
+                                                        float* __restrict__ a, float* __restrict__ bb, float* __restrict__ mean_rstd) {
+  __shared__ double part[256];
+  __shared__ double tot[192];
+  __shared__ double mr[64 * 2];
+  const int b = blockIdx.x;
+  reduce_rows(stats + (int64_t)b * rows * C * 2, rows, C * 2, part, tot);
+  const int t = threadIdx.x;
+  const int cg = C / G;
+  if (t < G) {
+    double s = 0, ss = 0;
+    for (int c = t * cg; c < (t + 1) * cg; ++c) { s += tot[c * 2]; ss += tot[c * 2 + 1]; }
+    const double n = count * cg;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    mr[t * 2] = mean; mr[t * 2 + 1] = rstd;
+    if (mean_rstd) { mean_rstd[(b * G + t) * 2] = (float)mean; mean_rstd[(b * G + t) * 2 + 1] = (float)rstd; }
+  }
+  __syncthreads();
+  if (t < C) {
+    const int g = t / cg;
+    const float rstd = (float)mr[g * 2 + 1], mean = (float)mr[g * 2];
+    const float av = gamma[t] * rstd;
+    a[b * C + t] = av;
+    bb[b * C + t] = beta[t] - mean * av;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// epilogue forward: out (+)= w * act(a*raw + b)
+// ------------------------------------------------------------------------------------------------
+template <bool RELU, bool ACC>
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ raw, int64_t rld, const float* __restrict__ a,
+                                                         const float* __restrict__ bb, const float* __restrict__ wptr,
+                                                         float* __restrict__ out, int64_t old_, int64_t N, int C, EwMap m) {
+  const int b = blockIdx.y;
+  const int t = threadIdx.x;
+  const int c4 = t % m.cpb, vl = t / m.cpb;
+  if (vl >= m.vpb) return;
+  float4 av = make_float4(1, 1, 1, 1), bv = make_float4(0, 0, 0, 0);
+  if (a) av = *reinterpret_cast<const float4*>(a + b * C + c4 * 4);
+  if (bb) bv = *reinterpret_cast<const float4*>(bb + b * C + c4 * 4);
+  const float w = wptr ? *wptr : 1.0f;
+  const float* rb = raw + (int64_t)b * N * rld + c4 * 4;
+  float* ob = out + (int64_t)b * N * old_ + c4 * 4;
+  const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+#pragma unroll 4
+  for (int it = 0; it < m.iters; ++it) {
+    const int64_t v = v0 + (int64_t)it * m.vpb;
+    if (v >= N) break;
+    const float4 q = *reinterpret_cast<const float4*>(rb + v * rld);
+    float4 z;
+    z.x = fmaf(av.x, q.x, bv.x); z.y = fmaf(av.y, q.y, bv.y); z.z = fmaf(av.z, q.z, bv.z); z.w = fmaf(av.w, q.w, bv.w);
+    if (RELU) { z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f); }
+    float4* op = reinterpret_cast<float4*>(ob + v * old_);
+    if (ACC) {
+      float4 o = *op;
+      o.x = fmaf(w, z.x, o.x); o.y = fmaf(w, z.y, o.y); o.z = fmaf(w, z.z, o.z); o.w = fmaf(w, z.w, o.w);
+      *op = o;
+    } else {
+      z.x *= w; z.y *= w; z.z *= w; z.w *= w;
+      *op = z;
+    }
+  }
+}
+
+// backward pass 1
+template <bool RELU>
+__global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(const float* __restrict__ dout, int64_t dld, const float* __restrict__ raw,
+                                                                int64_t rld, const float* __restrict__ a, const float* __restrict__ bb,
+                                                                int64_t N, int C, EwMap m, double* __restrict__ sums) {
+  __shared__ double lds[4 * 64 * 12];
+  const int b = blockIdx.y;
+  const int t = threadIdx.x;
+  const int c4 = t % m.cpb, vl = t / m.cpb;
+  const bool active = vl < m.vpb;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, sz[4] = {0, 0, 0, 0};
+  if (active) {
+    float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
+    if (a) { const float4 q = *reinterpret_cast<const float4*>(a + b * C + c4 * 4); av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w; }
+    if (bb) { const float4 q = *reinterpret_cast<const float4*>(bb + b * C + c4 * 4); bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w; }
+    const float* db = dout + (int64_t)b * N * dld + c4 * 4;
+    const float* rb = raw + (int64_t)b * N * rld + c4 * 4;
+    const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+    for (int it = 0; it < m.iters; ++it) {
+      const int64_t v = v0 + (int64_t)it * m.vpb;
+      if (v >= N) break;
+      const float4 dq = *reinterpret_cast<const float4*>(db + v * dld);
+      const float4 rq = *reinterpret_cast<const float4*>(rb + v * rld);
+      const float d[4] = {dq.x, dq.y, dq.z, dq.w};
+      const float r[4] = {rq.x, rq.y, rq.z, rq.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float z = fmaf(av[j], r[j], bv[j]);
+        float g = d[j];
+        if (RELU) { g = z > 0.f ? g : 0.f; z = fmaxf(z, 0.f); }
+        s1[j] += g;
+        s2[j] = fmaf(g, r[j], s2[j]);
+        sz[j] = fmaf(d[j], z, sz[j]);
+      }
+    }
+  }
+  double vals[12];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { vals[j] = s1[j]; vals[4 + j] = s2[j]; vals[8 + j] = sz[j]; }
+  double* row = sums + ((int64_t)b * gridDim.x + blockIdx.x) * C * 3;
+  block_reduce_to_row<3>(vals, m.cpb, row, lds);
+}
+
+// GroupNorm backward coefficients; one block, loops over samples (B is small)
+__global__ __launch_bounds__(256) void gn_bwd_coeffs_kernel(const double* __restrict__ sums, int rows, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean_rstd, const float* __restrict__ wptr, int B,
+                                                            int C, int G, double count, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dalpha, float* __restrict__ A,
+                                                            float* __restrict__ Bc, float* __restrict__ Cc) {
+  __shared__ double part[256];
+  __shared__ double tot[192];
+  __shared__ double gc[64 * 2];
+  __shared__ double zred[64];
+  const int t = threadIdx.x;
+  const int cg = C / G;
+  const double w = wptr ? (double)*wptr : 1.0;
+  double dg = 0, db = 0, dz = 0;
+  for (int b = 0; b < B; ++b) {
+    reduce_rows(sums + (int64_t)b * rows * C * 3, rows, C * 3, part, tot);
+    if (t < G) {
+      const double mean = mean_rstd[(b * G + t) * 2], rstd = mean_rstd[(b * G + t) * 2 + 1];
+      double c1 = 0, c2 = 0;
+      for (int c = t * cg; c < (t + 1) * cg; ++c) {
+        const double S1 = tot[c * 3], S2 = tot[c * 3 + 1];
+        c1 += (double)gamma[c] * w * S1;
+        c2 += (double)gamma[c] * w * rstd * (S2 - mean * S1);
+      }
+      const double n = count * cg;
+      gc[t * 2] = c1 / n; gc[t * 2 + 1] = c2 / n;
+    }
+    __syncthreads();
+    if (t < C) {
+      const int g = t / cg;
+      const double mean = mean_rstd[(b * G + g) * 2], rstd = mean_rstd[(b * G + g) * 2 + 1];
+      const double S1 = tot[t * 3], S2 = tot[t * 3 + 1], Sz = tot[t * 3 + 2];
+      dg += w * rstd * (S2 - mean * S1);
+      db += w * S1;
+      dz += Sz;
+      const double c1 = gc[g * 2], c2 = gc[g * 2 + 1];
+      A[b * C + t] = (float)(rstd * (double)gamma[t] * w);
+      Bc[b * C + t] = (float)(-rstd * c1 + rstd * rstd * c2 * mean);
+      Cc[b * C + t] = (float)(-rstd * rstd * c2);
+    }
+    __syncthreads();
+  }
+  if (t < C) {
+    if (dgamma) dgamma[t] = (float)dg;
+    if (dbeta) dbeta[t] = (float)db;
+  }
+  if (dalpha) {
+    if (t < 64) zred[t] = (t < C) ? dz : 0.0;
+    __syncthreads();
+    if (t == 0) {
+      double s = 0;
+      for (int i = 0; i < 64; ++i) s += zred[i];
+      *dalpha = (float)s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void plain_bwd_coeffs_kernel(const double* __restrict__ sums, int rows, const float* __restrict__ wptr,
+                                                               int B, int C, float* __restrict__ dalpha, float* __restrict__ A) {
+  __shared__ double part[256];
+  __shared__ double tot[192];
+  __shared__ double zred[64];
+  const int t = threadIdx.x;
+  const float w = wptr ? *wptr : 1.0f;
+  double dz = 0;
+  for (int b = 0; b < B; ++b) {
+    if (dalpha) {
+      reduce_rows(sums + (int64_t)b * rows * C * 3, rows, C * 3, part, tot);
+      if (t < C) dz += tot[t * 3 + 2];
+      __syncthreads();
+    }
+    if (t < C && A) A[b * C + t] = w;
+  }
+  if (dalpha) {
+    if (t < 64) zred[t] = (t < C) ? dz : 0.0;
+    __syncthreads();
+    if (t == 0) {
+      double s = 0;
+      for (int i = 0; i < 64; ++i) s += zred[i];
+      *dalpha = (float)s;
+    }
+  }
+}
+
+// backward pass 2
+template <bool RELU, bool ACC>
+__global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __restrict__ dout, int64_t dld, const float* __restrict__ raw,
+                                                               int64_t rld, const float* __restrict__ a, const float* __restrict__ bb,
+                                                               const float* __restrict__ A, const float* __restrict__ Bc,
+                                                               const float* __restrict__ Cc, float* __restrict__ draw, int64_t drld,
+                                                               int64_t N, int C, EwMap m) {
+  const int b = blockIdx.y;
+  const int t = threadIdx.x;
+  const int c4 = t % m.cpb, vl = t / m.cpb;
+  if (vl >= m.vpb) return;
+  float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0}, Av[4] = {1, 1, 1, 1}, Bv[4] = {0, 0, 0, 0}, Cv[4] = {0, 0, 0, 0};
+  const int co = b * C + c4 * 4;
+  if (a) { const float4 q = *reinterpret_cast<const float4*>(a + co); av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w; }
+  if (bb) { const float4 q = *reinterpret_cast<const float4*>(bb + co); bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w; }
+  if (A) { const float4 q = *reinterpret_cast<const float4*>(A + co); Av[0] = q.x; Av[1] = q.y; Av[2] = q.z; Av[3] = q.w; }
+  if (Bc) { const float4 q = *reinterpret_cast<const float4*>(Bc + co); Bv[0] = q.x; Bv[1] = q.y; Bv[2] = q.z; Bv[3] = q.w; }
+  if (Cc) { const float4 q = *reinterpret_cast<const float4*>(Cc + co); Cv[0] = q.x; Cv[1] = q.y; Cv[2] = q.z; Cv[3] = q.w; }
+  const float* db = dout + (int64_t)b * N * dld + c4 * 4;
+  const float* rb = raw + (int64_t)b * N * rld + c4 * 4;
+  float* ob = draw + (int64_t)b * N * drld + c4 * 4;
+  const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+#pragma unroll 2
+  for (int it = 0; it < m.iters; ++it) {
+    const int64_t v = v0 + (int64_t)it * m.vpb;
+    if (v >= N) break;
+    const float4 dq = *reinterpret_cast<const float4*>(db + v * dld);
+    const float4 rq = *reinterpret_cast<const float4*>(rb + v * rld);
+    const float d[4] = {dq.x, dq.y, dq.z, dq.w};
+    const float r[4] = {rq.x, rq.y, rq.z, rq.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float g = d[j];
+      if (RELU) { const float z = fmaf(av[j], r[j], bv[j]); g = z > 0.f ? g : 0.f; }
+      o[j] = fmaf(Av[j], g, fmaf(Cv[j], r[j], Bv[j]));
+    }
+    float4* op = reinterpret_cast<float4*>(ob + v * drld);
+    if (ACC) { const float4 p = *op; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+    *op = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SE gate
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const double* __restrict__ stats, int rows, double count, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          int C, float* __restrict__ mean, float* __restrict__ hidden, float* __restrict__ gate) {
+  __shared__ double part[256];
+  __shared__ double tot[192];
+  __shared__ float hsh;
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  reduce_rows(stats + (int64_t)b * rows * C * 2, rows, C * 2, part, tot);
+  if (t < C) mean[b * C + t] = (float)(tot[t * 2] / count);
+  __syncthreads();
+  if (t == 0) {
+    float h = b1[0];
+    for (int c = 0; c < C; ++c) h = fmaf(w1[c], (float)(tot[c * 2] / count), h);
+    h = fmaxf(h, 0.f);
+    hidden[b] = h;
+    hsh = h;
+  }
+  __syncthreads();
+  if (t < C) {
+    const float pre = fmaf(w2[t], hsh, b2[t]);
+    gate[b * C + t] = 1.0f / (1.0f + __expf(-pre));
+  }
+}
+
+__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const double* __restrict__ sums, int rows, const float* __restrict__ wptr,
+                                                          const float* __restrict__ mean, const float* __restrict__ hidden,
+                                                          const float* __restrict__ gate, const float* __restrict__ w1,
+                                                          const float* __restrict__ w2, int B, int C, double count, float* __restrict__ dw1,
+                                                          float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
+                                                          float* __restrict__ dalpha, float* __restrict__ A, float* __restrict__ Bc) {
+  __shared__ double part[256];
+  __shared__ double tot[192];
+  __shared__ double red[64];
+  __shared__ double dpre1_sh;
+  const int t = threadIdx.x;
+  const double w = wptr ? (double)*wptr : 1.0;
+  double a_dw1 = 0, a_dw2 = 0, a_db2 = 0, a_db1 = 0, a_dz = 0;
+  for (int b = 0; b < B; ++b) {
+    reduce_rows(sums + (int64_t)b * rows * C * 3, rows, C * 3, part, tot);
+    double dpre2 = 0;
+    if (t < C) {
+      const double g = gate[b * C + t];
+      const double dgate = w * tot[t * 3 + 1];
+      dpre2 = dgate * g * (1.0 - g);
+      a_dz += tot[t * 3 + 2];
+      a_dw2 += dpre2 * (double)hidden[b];
+      a_db2 += dpre2;
+    }
+    if (t < 64) red[t] = (t < C) ? dpre2 * (double)w2[t] : 0.0;
+    __syncthreads();
+    if (t == 0) {
+      double dh = 0;
+      for (int i = 0; i < 64; ++i) dh += red[i];
+      dpre1_sh = hidden[b] > 0.f ? dh : 0.0;
+    }
+    __syncthreads();
+    const double dpre1 = dpre1_sh;
+    if (t < C) {
+      a_dw1 += dpre1 * (double)mean[b * C + t];
+      A[b * C + t] = (float)(w * (double)gate[b * C + t]);
+      Bc[b * C + t] = (float)(dpre1 * (double)w1[t] / count);
+    }
+    if (t == 0) a_db1 += dpre1;
+    __syncthreads();
+  }
+  if (t < C) { dw1[t] = (float)a_dw1; dw2[t] = (float)a_dw2; db2[t] = (float)a_db2; }
+  if (t == 0) db1[0] = (float)a_db1;
+  if (dalpha) {
+    if (t < 64) red[t] = (t < C) ? a_dz : 0.0;
+    __syncthreads();
+    if (t == 0) {
+      double s = 0;
+      for (int i = 0; i < 64; ++i) s += red[i];
+      *dalpha = (float)s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooling 2x2x2 / 2
+// ------------------------------------------------------------------------------------------------
+template <bool MAX>
+__global__ __launch_bounds__(256) void pool2_fwd_kernel(const float* __restrict__ x, int64_t xld, float* __restrict__ y, int64_t yld, int Di,
+                                                        int Hi, int Wi, int C) {
+  const int Do = Di / 2, Ho = Hi / 2, Wo = Wi / 2;
+  const int cpb = C / 4;
+  const int64_t total = (int64_t)Do * Ho * Wo * cpb;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int b = blockIdx.y;
+  const int c4 = idx % cpb;
+  int64_t v = idx / cpb;
+  const int wo = v % Wo; v /= Wo;
+  const int ho = v % Ho;
+  const int d_o = v / Ho;
+  const float* xb = x + (int64_t)b * Di * Hi * Wi * xld + c4 * 4;
+  float4 acc = MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) {
+        const int64_t vi = ((int64_t)(2 * d_o + kd) * Hi + (2 * ho + kh)) * Wi + (2 * wo + kw);
+        const float4 q = *reinterpret_cast<const float4*>(xb + vi * xld);
+        if (MAX) { acc.x = fmaxf(acc.x, q.x); acc.y = fmaxf(acc.y, q.y); acc.z = fmaxf(acc.z, q.z); acc.w = fmaxf(acc.w, q.w); }
+        else { acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+      }
+  if (!MAX) { acc.x *= 0.125f; acc.y *= 0.125f; acc.z *= 0.125f; acc.w *= 0.125f; }
+  const int64_t vo = ((int64_t)d_o * Ho + ho) * Wo + wo;
+  *reinterpret_cast<float4*>(y + ((int64_t)b * Do * Ho * Wo + vo) * yld + c4 * 4) = acc;
+}
+
+// one thread per OUTPUT voxel quad: routes dy to its 8 inputs (avg: /8; max: first arg-max in
+// (d,h,w) scan order, the choice torch's max_pool3d backward makes)
+template <bool MAX, bool ACC>
+__global__ __launch_bounds__(256) void pool2_bwd_kernel(const float* __restrict__ dy, int64_t dyld, const float* __restrict__ x, int64_t xld,
+                                                        float* __restrict__ dx, int64_t dxld, int Di, int Hi, int Wi, int C) {
+  const int Do = Di / 2, Ho = Hi / 2, Wo = Wi / 2;
+  const int cpb = C / 4;
+  const int64_t total = (int64_t)Do * Ho * Wo * cpb;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int b = blockIdx.y;
+  const int c4 = idx % cpb;
+  int64_t v = idx / cpb;
+  const int wo = v % Wo; v /= Wo;
+  const int ho = v % Ho;
+  const int d_o = v / Ho;
+  const int64_t vo = ((int64_t)d_o * Ho + ho) * Wo + wo;
+  const float4 gq = *reinterpret_cast<const float4*>(dy + ((int64_t)b * Do * Ho * Wo + vo) * dyld + c4 * 4);
+  const float g[4] = {gq.x, gq.y, gq.z, gq.w};
+  const float* xb = x ? x + (int64_t)b * Di * Hi * Wi * xld + c4 * 4 : nullptr;
+  float* db = dx + (int64_t)b * Di * Hi * Wi * dxld + c4 * 4;
+  int arg[4] = {0, 0, 0, 0};
+  if (MAX) {
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t vi = ((int64_t)(2 * d_o + (k >> 2)) * Hi + (2 * ho + ((k >> 1) & 1))) * Wi + (2 * wo + (k & 1));
+      const float4 q = *reinterpret_cast<const float4*>(xb + vi * xld);
+      const float qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (qq[j] > best[j] || qq[j] != qq[j]) { best[j] = qq[j]; arg[j] = k; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int64_t vi = ((int64_t)(2 * d_o + (k >> 2)) * Hi + (2 * ho + ((k >> 1) & 1))) * Wi + (2 * wo + (k & 1));
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = MAX ? (arg[j] == k ? g[j] : 0.f) : g[j] * 0.125f;
+    float4* op = reinterpret_cast<float4*>(db + vi * dxld);
+    if (ACC) { const float4 p = *op; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+    *op = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dice
+// ------------------------------------------------------------------------------------------------
+#define DICE_CHUNK 4096
+__global__ __launch_bounds__(256) void dice_reduce_kernel(const float* __restrict__ p, int64_t psb, int64_t psc, int64_t psv,
+                                                          const float* __restrict__ t, int64_t tsb, int64_t tsc, int64_t tsv, int64_t N,
+                                                          double* __restrict__ partial /*[B][C][rows][3]*/) {
+  __shared__ double red[3][4];
+  const int b = blockIdx.z, c = blockIdx.y;
+  const float* pp = p + b * psb + c * psc;
+  const float* tp = t + b * tsb + c * tsc;
+  float spt = 0, sp = 0, st = 0;
+  const int64_t v0 = (int64_t)blockIdx.x * DICE_CHUNK;
+  for (int i = threadIdx.x; i < DICE_CHUNK; i += 256) {
+    const int64_t v = v0 + i;
+    if (v < N) {
+      const float a = pp[v * psv], q = tp[v * tsv];
+      spt = fmaf(a, q, spt); sp += a; st += q;
+    }
+  }
+  double d0 = wave_sum_d(spt), d1 = wave_sum_d(sp), d2 = wave_sum_d(st);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = d0; red[1][wave] = d1; red[2][wave] = d2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double* o = partial + (((int64_t)b * gridDim.y + c) * gridDim.x + blockIdx.x) * 3;
+    o[threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+  }
+}
+
+__global__ __launch_bounds__(256) void dice_finalize_kernel(const double* __restrict__ partial, int rows, int BC, double smooth,
+                                                            double* __restrict__ sums /*[BC][3]*/, float* __restrict__ loss) {
+  __shared__ double ratio[256];
+  const int t = threadIdx.x;
+  double acc = 0;
+  for (int i = t; i < BC; i += 256) {
+    double s[3] = {0, 0, 0};
+    for (int r = 0; r < rows; ++r)
+      for (int k = 0; k < 3; ++k) s[k] += partial[((int64_t)i * rows + r) * 3 + k];
+    sums[i * 3] = s[0]; sums[i * 3 + 1] = s[1]; sums[i * 3 + 2] = s[2];
+    acc += (2.0 * s[0] + smooth) / (s[1] + s[2] + smooth);
+  }
+  ratio[t] = acc;
+  __syncthreads();
+  if (t == 0) {
+    double s = 0;
+    for (int i = 0; i < 256; ++i) s += ratio[i];
+    *loss = (float)(1.0 - s / BC);
+  }
+}
+
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ p, int64_t psb, int64_t psc, int64_t psv,
+                                                       const float* __restrict__ t, int64_t tsb, int64_t tsc, int64_t tsv, int64_t N, int BC,
+                                                       double smooth, const double* __restrict__ sums, const float* __restrict__ dloss,
+                                                       float* __restrict__ dp, int64_t dsb, int64_t dsc, int64_t dsv) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int i = b * gridDim.y + c;
+  const double num = 2.0 * sums[i * 3] + smooth, den = sums[i * 3 + 1] + sums[i * 3 + 2] + smooth;
+  const float gl = dloss ? *dloss : 1.0f;
+  // d loss / d p = -(1/BC) * (2 t den - num) / den^2
+  const float k2 = (float)(-(double)gl / BC * 2.0 / den);
+  const float k0 = (float)((double)gl / BC * num / (den * den));
+  const float* tp = t + b * tsb + c * tsc;
+  float* op = dp + b * dsb + c * dsc;
+  const int64_t v0 = (int64_t)blockIdx.x * DICE_CHUNK;
+  for (int j = threadIdx.x; j < DICE_CHUNK; j += 256) {
+    const int64_t v = v0 + j;
+    if (v < N) op[v * dsv] = fmaf(k2, tp[v * tsv], k0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ncdhw_to_ndhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t dld, int C, int64_t N) {
+  const int b = blockIdx.y;
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= N) return;
+  const float* s = src + (int64_t)b * C * N + v;
+  float* d = dst + ((int64_t)b * N + v) * dld;
+  for (int c = 0; c < C; ++c) d[c] = s[(int64_t)c * N];
+}
+__global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const float* __restrict__ src, int64_t sld, float* __restrict__ dst, int C, int64_t N) {
+  const int b = blockIdx.y;
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= N) return;
+  const float* s = src + ((int64_t)b * N + v) * sld;
+  float* d = dst + (int64_t)b * C * N + v;
+  for (int c = 0; c < C; ++c) d[(int64_t)c * N] = s[c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam, amsgrad=False, maximize=False)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t n, float lr, float b1, float b2, float eps, float wd, float gscale,
+                                                   const int32_t* __restrict__ step_ptr) {
+  const int step = *step_ptr + 1;
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+    const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+__global__ void step_inc_kernel(int32_t* step_ptr) { *step_ptr += 1; }
+
+}  // namespace n3d
+
+using namespace n3d;
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int n3d_stats_rows(int64_t N, int C) { return ew_map(N, C).rows; }
+int n3d_dice_rows(int64_t N) { return (int)cdiv(N, DICE_CHUNK); }
+
+static int check_vec(const void* p, int64_t ld, int C, const char* what) {
+  if (C % 4 != 0 || ld % 4 != 0 || !aligned16(p) || C > 64 * 4) {
+    set_error("%s: needs C %% 4 == 0, ld %% 4 == 0, 16-byte aligned base (C=%d ld=%lld)", what, C, (long long)ld);
+    return N3D_ERR_UNSUPPORTED;
+  }
+  return 0;
+}
+
+int n3d_channel_stats(const float* x, int64_t ld, int B, int64_t N, int C, double* stats, void* stream) {
+  N3D_CHECK_ARG(x && stats && B > 0 && N > 0 && C > 0 && C <= 64, "channel_stats: bad args");
+  if (int e = check_vec(x, ld, C, "channel_stats")) return e;
+  EwMap m = ew_map(N, C);
+  hipLaunchKernelGGL(channel_stats_kernel, dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, x, ld, N, C, m, stats);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_gn_coeffs(const double* stats, int rows, const float* gamma, const float* beta, int B, int C, int G, int64_t N, float eps,
+                  float* a, float* b, float* mean_rstd, void* stream) {
+  N3D_CHECK_ARG(stats && gamma && beta && a && b && C <= 64 && G >= 1 && C % G == 0 && rows >= 1, "gn_coeffs: bad args");
+  hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, stats, rows, gamma, beta, C, G, (double)N, eps, a, b,
+                     mean_rstd);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_affine_act(const float* raw, int64_t rld, const float* a, const float* b, const float* wptr, float* out, int64_t old_, int B,
+                   int64_t N, int C, int flags, void* stream) {
+  N3D_CHECK_ARG(raw && out && B > 0 && N > 0, "affine_act: bad args");
+  if (int e = check_vec(raw, rld, C, "affine_act(raw)")) return e;
+  if (int e = check_vec(out, old_, C, "affine_act(out)")) return e;
+  EwMap m = ew_map(N, C);
+  dim3 grid(m.rows, B), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bool relu = flags & N3D_RELU, acc = flags & N3D_ACCUMULATE;
+  if (relu && acc) hipLaunchKernelGGL((affine_act_kernel<true, true>), grid, blk, 0, s, raw, rld, a, b, wptr, out, old_, N, C, m);
+  else if (relu) hipLaunchKernelGGL((affine_act_kernel<true, false>), grid, blk, 0, s, raw, rld, a, b, wptr, out, old_, N, C, m);
+  else if (acc) hipLaunchKernelGGL((affine_act_kernel<false, true>), grid, blk, 0, s, raw, rld, a, b, wptr, out, old_, N, C, m);
+  else hipLaunchKernelGGL((affine_act_kernel<false, false>), grid, blk, 0, s, raw, rld, a, b, wptr, out, old_, N, C, m);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_affine_act_bwd_reduce(const float* dout, int64_t dld, const float* raw, int64_t rld, const float* a, const float* b, int B,
+                              int64_t N, int C, int flags, double* sums, void* stream) {
+  N3D_CHECK_ARG(dout && raw && sums && C <= 64, "affine_act_bwd_reduce: bad args");
+  if (int e = check_vec(dout, dld, C, "bwd_reduce(dout)")) return e;
+  if (int e = check_vec(raw, rld, C, "bwd_reduce(raw)")) return e;
+  EwMap m = ew_map(N, C);
+  dim3 grid(m.rows, B), blk(256);
+  if (flags & N3D_RELU) hipLaunchKernelGGL((affine_bwd_reduce_kernel<true>), grid, blk, 0, (hipStream_t)stream, dout, dld, raw, rld, a, b, N, C, m, sums);
+  else hipLaunchKernelGGL((affine_bwd_reduce_kernel<false>), grid, blk, 0, (hipStream_t)stream, dout, dld, raw, rld, a, b, N, C, m, sums);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_gn_bwd_coeffs(const double* sums, int rows, const float* gamma, const float* mean_rstd, const float* wptr, int B, int C, int G,
+                      int64_t N, float* dgamma, float* dbeta, float* dalpha, float* A, float* Bc, float* Cc, void* stream) {
+  N3D_CHECK_ARG(sums && gamma && mean_rstd && A && Bc && Cc && C <= 64 && C % G == 0, "gn_bwd_coeffs: bad args");
+  hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, rows, gamma, mean_rstd, wptr, B, C, G, (double)N,
+                     dgamma, dbeta, dalpha, A, Bc, Cc);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_plain_bwd_coeffs(const double* sums, int rows, const float* wptr, int B, int C, float* dalpha, float* A, void* stream) {
+  N3D_CHECK_ARG(C <= 64 && (A || dalpha), "plain_bwd_coeffs: bad args");
+  N3D_CHECK_ARG(!dalpha || sums, "plain_bwd_coeffs: dalpha needs sums");
+  hipLaunchKernelGGL(plain_bwd_coeffs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, rows, wptr, B, C, dalpha, A);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_affine_act_bwd_apply(const float* dout, int64_t dld, const float* raw, int64_t rld, const float* a, const float* b, const float* A,
+                             const float* Bc, const float* Cc, float* draw, int64_t drld, int B, int64_t N, int C, int flags,
+                             void* stream) {
+  N3D_CHECK_ARG(dout && raw && draw, "affine_act_bwd_apply: bad args");
+  if (int e = check_vec(dout, dld, C, "bwd_apply(dout)")) return e;
+  if (int e = check_vec(raw, rld, C, "bwd_apply(raw)")) return e;
+  if (int e = check_vec(draw, drld, C, "bwd_apply(draw)")) return e;
+  EwMap m = ew_map(N, C);
+  dim3 grid(m.rows, B), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bool relu = flags & N3D_RELU, acc = flags & N3D_ACCUMULATE;
+  if (relu && acc) hipLaunchKernelGGL((affine_bwd_apply_kernel<true, true>), grid, blk, 0, s, dout, dld, raw, rld, a, b, A, Bc, Cc, draw, drld, N, C, m);
+  else if (relu) hipLaunchKernelGGL((affine_bwd_apply_kernel<true, false>), grid, blk, 0, s, dout, dld, raw, rld, a, b, A, Bc, Cc, draw, drld, N, C, m);
+  else if (acc) hipLaunchKernelGGL((affine_bwd_apply_kernel<false, true>), grid, blk, 0, s, dout, dld, raw, rld, a, b, A, Bc, Cc, draw, drld, N, C, m);
+  else hipLaunchKernelGGL((affine_bwd_apply_kernel<false, false>), grid, blk, 0, s, dout, dld, raw, rld, a, b, A, Bc, Cc, draw, drld, N, C, m);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_se_gate_fwd(const double* stats, int rows, int64_t N, const float* w1, const float* b1, const float* w2, const float* b2, int B,
+                    int C, float* mean, float* hidden, float* gate, void* stream) {
+  N3D_CHECK_ARG(stats && w1 && b1 && w2 && b2 && mean && hidden && gate && C <= 64, "se_gate_fwd: bad args");
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, stats, rows, (double)N, w1, b1, w2, b2, C, mean, hidden, gate);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_se_gate_bwd(const double* sums, int rows, const float* wptr, const float* mean, const float* hidden, const float* gate,
+                    const float* w1, const float* w2, int B, int C, int64_t N, float* dw1, float* db1, float* dw2, float* db2,
+                    float* dalpha, float* A, float* Bc, void* stream) {
+  N3D_CHECK_ARG(sums && mean && hidden && gate && w1 && w2 && dw1 && db1 && dw2 && db2 && A && Bc && C <= 64, "se_gate_bwd: bad args");
+  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, rows, wptr, mean, hidden, gate, w1, w2, B, C,
+                     (double)N, dw1, db1, dw2, db2, dalpha, A, Bc);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_pool2_fwd(const float* x, int64_t xld, float* y, int64_t yld, int B, int Di, int Hi, int Wi, int C, int flags, void* stream) {
+  N3D_CHECK_ARG(x && y && Di % 2 == 0 && Hi % 2 == 0 && Wi % 2 == 0, "pool2_fwd: spatial dims must be even");
+  if (int e = check_vec(x, xld, C, "pool2_fwd(x)")) return e;
+  if (int e = check_vec(y, yld, C, "pool2_fwd(y)")) return e;
+  const int64_t total = (int64_t)(Di / 2) * (Hi / 2) * (Wi / 2) * (C / 4);
+  dim3 grid((unsigned)cdiv(total, 256), B), blk(256);
+  if (flags & N3D_POOL_MAX) hipLaunchKernelGGL((pool2_fwd_kernel<true>), grid, blk, 0, (hipStream_t)stream, x, xld, y, yld, Di, Hi, Wi, C);
+  else hipLaunchKernelGGL((pool2_fwd_kernel<false>), grid, blk, 0, (hipStream_t)stream, x, xld, y, yld, Di, Hi, Wi, C);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_pool2_bwd(const float* dy, int64_t dyld, const float* x, int64_t xld, float* dx, int64_t dxld, int B, int Di, int Hi, int Wi, int C,
+                  int flags, void* stream) {
+  const bool mx = flags & N3D_POOL_MAX, acc = flags & N3D_ACCUMULATE;
+  N3D_CHECK_ARG(dy && dx && (!mx || x), "pool2_bwd: bad args");
+  if (int e = check_vec(dy, dyld, C, "pool2_bwd(dy)")) return e;
+  if (int e = check_vec(dx, dxld, C, "pool2_bwd(dx)")) return e;
+  if (mx) if (int e = check_vec(x, xld, C, "pool2_bwd(x)")) return e;
+  const int64_t total = (int64_t)(Di / 2) * (Hi / 2) * (Wi / 2) * (C / 4);
+  dim3 grid((unsigned)cdiv(total, 256), B), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (mx && acc) hipLaunchKernelGGL((pool2_bwd_kernel<true, true>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C);
+  else if (mx) hipLaunchKernelGGL((pool2_bwd_kernel<true, false>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C);
+  else if (acc) hipLaunchKernelGGL((pool2_bwd_kernel<false, true>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C);
+  else hipLaunchKernelGGL((pool2_bwd_kernel<false, false>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_dice_fwd(const float* p, int64_t psb, int64_t psc, int64_t psv, const float* t, int64_t tsb, int64_t tsc, int64_t tsv, int B, int C,
+                 int64_t N, float smooth, double* partial, double* sums, float* loss, void* stream) {
+  N3D_CHECK_ARG(p && t && partial && sums && loss && B > 0 && C > 0 && N > 0, "dice_fwd: bad args");
+  const int rows = (int)cdiv(N, DICE_CHUNK);
+  hipLaunchKernelGGL(dice_reduce_kernel, dim3(rows, C, B), dim3(256), 0, (hipStream_t)stream, p, psb, psc, psv, t, tsb, tsc, tsv, N, partial);
+  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, rows, B * C, (double)smooth, sums, loss);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_dice_bwd(const float* p, int64_t psb, int64_t psc, int64_t psv, const float* t, int64_t tsb, int64_t tsc, int64_t tsv, int B, int C,
+                 int64_t N, float smooth, const double* sums, const float* dloss, float* dp, int64_t dsb, int64_t dsc, int64_t dsv,
+                 void* stream) {
+  N3D_CHECK_ARG(t && sums && dp, "dice_bwd: bad args");
+  const int rows = (int)cdiv(N, DICE_CHUNK);
+  hipLaunchKernelGGL(dice_bwd_kernel, dim3(rows, C, B), dim3(256), 0, (hipStream_t)stream, p, psb, psc, psv, t, tsb, tsc, tsv, N, B * C,
+                     (double)smooth, sums, dloss, dp, dsb, dsc, dsv);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_ncdhw_to_ndhwc(const float* src, float* dst, int64_t dld, int B, int C, int64_t N, void* stream) {
+  N3D_CHECK_ARG(src && dst && dld >= C, "ncdhw_to_ndhwc: bad args");
+  hipLaunchKernelGGL(ncdhw_to_ndhwc_kernel, dim3((unsigned)cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, src, dst, dld, C, N);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+int n3d_ndhwc_to_ncdhw(const float* src, int64_t sld, float* dst, int B, int C, int64_t N, void* stream) {
+  N3D_CHECK_ARG(src && dst && sld >= C, "ndhwc_to_ncdhw: bad args");
+  hipLaunchKernelGGL(ndhwc_to_ncdhw_kernel, dim3((unsigned)cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, src, sld, dst, C, N);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float grad_scale, int32_t* step_ptr, int inc_step, void* stream) {
+  N3D_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_ptr && n > 0, "adam_step: bad args");
+  int64_t blocks = cdiv(n, 256 * 4);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                     beta2, eps, weight_decay, grad_scale, step_ptr);
+  if (inc_step) hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_ptr);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_zero(void* p, size_t bytes, void* stream) {
+  N3D_CHECK_ARG(p || bytes == 0, "zero: null");
+  if (bytes == 0) return N3D_OK;
+  hipError_t e = hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);
+  if (e != hipSuccess) { set_error("hipMemsetAsync: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+  return N3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// Shared host/device helpers for libn3d (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/n3d.h"
+
+namespace n3d {
+
+void set_error(const char* fmt, ...);
+
+#define N3D_CHECK_ARG(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      n3d::set_error(__VA_ARGS__);      \
+      return N3D_ERR_INVALID;           \
+    }                                   \
+  } while (0)
+
+#define N3D_UNSUPPORTED(...)            \
+  do {                                  \
+    n3d::set_error(__VA_ARGS__);        \
+    return N3D_ERR_UNSUPPORTED;         \
+  } while (0)
+
+#define N3D_LAUNCH_CHECK()                                                     \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) {                                                   \
+      n3d::set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__,         \
+                     hipGetErrorString(e__));                                  \
+      return N3D_ERR_HIP;                                                      \
+    }                                                                          \
+  } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// Element-wise mapping over a pitched NDHWC tensor with C % 4 == 0:
+// a 256-thread block covers `vpb` voxels x `cpb` channel quads per iteration; thread t handles
+// channel quad t % cpb of voxel t / cpb, so consecutive lanes touch consecutive 16-byte pieces.
+// A block walks `iters` iterations = one "row" of `vpc` voxels; per-sample reductions emit one
+// partial row per block (deterministic two-stage reduction, no atomics).
+// ---------------------------------------------------------------------------------------------
+struct EwMap {
+  int cpb;      // channel quads per voxel
+  int vpb;      // voxels per block iteration
+  int iters;    // iterations per block
+  int64_t vpc;  // voxels per block (chunk)
+  int rows;     // blocks (partial rows) per sample
+};
+
+static inline EwMap ew_map(int64_t N, int C) {
+  EwMap m;
+  m.cpb = C / 4;
+  if (m.cpb < 1) m.cpb = 1;
+  m.vpb = 256 / m.cpb;
+  if (m.vpb < 1) m.vpb = 1;
+  int64_t nit = cdiv(N, m.vpb);          // block-iterations per sample
+  int64_t it = cdiv(nit, 1024);          // cap rows per sample at 1024
+  if (it < 4) it = nit < 4 ? (nit < 1 ? 1 : nit) : 4;
+  m.iters = (int)it;
+  m.vpc = (int64_t)m.vpb * m.iters;
+  m.rows = (int)cdiv(N, m.vpc);
+  return m;
+}
+
+#ifdef __HIPCC__
+// sum over the lanes of a wave that share (lane % cpb); result valid in lanes < cpb
+__device__ __forceinline__ double wave_sum_strided(double v, int cpb) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const int off = s * cpb;
+    if (off < 64) {
+      double o = __shfl_down(v, off, 64);
+      if (lane + off < 64) v += o;
+    }
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum_strided_f(float v, int cpb) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const int off = s * cpb;
+    if (off < 64) {
+      float o = __shfl_down(v, off, 64);
+      if (lane + off < 64) v += o;
+    }
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+  return v;
+}
+#endif
+
+}  // namespace n3d

@@ -1,0 +1,292 @@
+"""Thin Python wrappers: torch tensors -> pitched-NDHWC views -> libn3d C ABI calls.
+
+torch is used for device memory (caching allocator) and the current HIP stream only; every
+arithmetic kernel on the path is a libn3d kernel.  Logical tensor shape is the reference's
+(B, C, D, H, W) (prim_ops.py / cell.py callers); physical layout is NDHWC with a voxel pitch
+`ld` so that channel slices of a wider buffer (torch.cat(dim=1), cell.py:82) need no copy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACCUMULATE, POOL_MAX, RELU, RELU_IN, ConvGeom, N3DError, check
+
+__all__ = ["View", "as_view", "empty_ndhwc", "stream_ptr", "conv_geom", "ptr"]
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a tensor (or None)"""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def empty_ndhwc(B, Cc, D, H, W, device, dtype=torch.float32):
+    """Dense NDHWC storage presented with the reference's logical (B, C, D, H, W) shape."""
+    return torch.empty((B, D, H, W, Cc), device=device, dtype=dtype).permute(0, 4, 1, 2, 3)
+
+
+def zeros_ndhwc(B, Cc, D, H, W, device, dtype=torch.float32):
+    return torch.zeros((B, D, H, W, Cc), device=device, dtype=dtype).permute(0, 4, 1, 2, 3)
+
+
+class View:
+    """Pitched NDHWC view of a logical (B, C, D, H, W) fp32 device tensor."""
+    __slots__ = ("t", "p", "ld", "B", "C", "D", "H", "W", "N")
+
+    def __init__(self, t, ld):
+        self.t = t
+        self.p = C.c_void_p(t.data_ptr())
+        self.ld = int(ld)
+        self.B, self.C, self.D, self.H, self.W = (int(s) for s in t.shape)
+        self.N = self.D * self.H * self.W
+
+
+def _pitch_of(t):
+    """Return the voxel pitch if `t` is a pitched NDHWC view, else None."""
+    B, Cc, D, H, W = t.shape
+    s = t.stride()
+    if W > 1:
+        ld = s[4]
+    elif H > 1:
+        ld = s[3]
+    elif D > 1:
+        ld = s[2]
+    elif B > 1:
+        ld = s[0]
+    else:
+        ld = Cc
+    if ld < Cc:
+        return None
+    if Cc > 1 and s[1] != 1:
+        return None
+    if W > 1 and s[4] != ld:
+        return None
+    if H > 1 and s[3] != W * ld:
+        return None
+    if D > 1 and s[2] != H * W * ld:
+        return None
+    if B > 1 and s[0] != D * H * W * ld:
+        return None
+    return ld
+
+
+def as_view(t, what="tensor"):
+    """Validate (or repack with a copy) a logical (B,C,D,H,W) tensor into a pitched NDHWC view."""
+    if not isinstance(t, torch.Tensor) or t.dim() != 5:
+        raise N3DError("%s: expected a 5-D (B,C,D,H,W) tensor" % what)
+    if not t.is_cuda:
+        raise N3DError("%s is on %s: the nas_3d_unet_amd ops only run on a HIP (gfx950) device; "
+                       "there is no CPU fallback" % (what, t.device))
+    if t.dtype != torch.float32:
+        raise N3DError("%s: fp32 expected, got %s" % (what, t.dtype))
+    ld = _pitch_of(t)
+    if ld is None or (t.data_ptr() % 16 != 0) or (ld % 4 != 0 and t.shape[1] % 4 == 0):
+        B, Cc, D, H, W = t.shape
+        n = empty_ndhwc(B, Cc, D, H, W, t.device)
+        n.copy_(t)  # layout plumbing (strided copy); arithmetic stays in libn3d
+        t, ld = n, Cc
+    return View(t, ld)
+
+
+def conv_geom(B, Di, Hi, Wi, Ci, Co, k, stride, dil, pad, depthwise=False):
+    def od(i):
+        return (i + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    return ConvGeom(B, Di, Hi, Wi, Ci, od(Di), od(Hi), od(Wi), Co, k, stride, dil, pad, 1 if depthwise else 0)
+
+
+def _ws(g, device):
+    n = _lib.load().n3d_conv_workspace_bytes(C.byref(g))
+    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=device), int(n)
+
+
+# ------------------------------------------------------------------------------------------ convs
+def conv_stats_rows(g, transposed, flags=0):
+    return int(_lib.load().n3d_conv_stats_rows(C.byref(g), 1 if transposed else 0, flags))
+
+
+def stats_rows(N, Cc):
+    return int(_lib.load().n3d_stats_rows(N, Cc))
+
+
+def conv_fwd(g, x: View, w, bias, y: View, flags=0, in_gate=None, stats=None, transposed=False):
+    ws, n = _ws(g, x.t.device)
+    fn = _lib.load().n3d_convT_fwd if transposed else _lib.load().n3d_conv_fwd
+    check(fn(C.byref(g), x.p, x.ld, ptr(w), ptr(bias), y.p, y.ld, flags, ptr(in_gate), ptr(stats), ptr(ws), n,
+             stream_ptr()), "n3d_convT_fwd" if transposed else "n3d_conv_fwd")
+
+
+def conv_bwd_data(g, dy: View, w, dx: View, flags=0, relu_src: View | None = None, out_gate=None, transposed=False):
+    ws, n = _ws(g, dy.t.device)
+    lib = _lib.load()
+    if transposed:
+        if relu_src is not None or out_gate is not None:
+            raise N3DError("convT_bwd_data: relu/gate epilogue not supported")
+        check(lib.n3d_convT_bwd_data(C.byref(g), dy.p, dy.ld, ptr(w), dx.p, dx.ld, flags, ptr(ws), n, stream_ptr()),
+              "n3d_convT_bwd_data")
+    else:
+        check(lib.n3d_conv_bwd_data(C.byref(g), dy.p, dy.ld, ptr(w), dx.p, dx.ld, flags,
+                                    relu_src.p if relu_src is not None else None,
+                                    relu_src.ld if relu_src is not None else 0, ptr(out_gate), ptr(ws), n,
+                                    stream_ptr()), "n3d_conv_bwd_data")
+
+
+def conv_bwd_weight(g, x: View, dy: View, dw, dbias, flags=0, in_gate=None, transposed=False):
+    ws, n = _ws(g, x.t.device)
+    lib = _lib.load()
+    if transposed:
+        if in_gate is not None:
+            raise N3DError("convT_bwd_weight: gate not supported")
+        check(lib.n3d_convT_bwd_weight(C.byref(g), x.p, x.ld, dy.p, dy.ld, ptr(dw), ptr(dbias), flags, ptr(ws), n,
+                                       stream_ptr()), "n3d_convT_bwd_weight")
+    else:
+        check(lib.n3d_conv_bwd_weight(C.byref(g), x.p, x.ld, dy.p, dy.ld, ptr(dw), ptr(dbias), flags, ptr(in_gate),
+                                      ptr(ws), n, stream_ptr()), "n3d_conv_bwd_weight")
+
+
+# ------------------------------------------------------------------------------------------ epilogue
+def channel_stats(x: View):
+    rows = stats_rows(x.N, x.C)
+    st = torch.empty((x.B, rows, x.C, 2), dtype=torch.float64, device=x.t.device)
+    check(_lib.load().n3d_channel_stats(x.p, x.ld, x.B, x.N, x.C, ptr(st), stream_ptr()), "n3d_channel_stats")
+    return st, rows
+
+
+def gn_coeffs(stats, rows, gamma, beta, B, Cc, G, N, eps=1e-5):
+    dev = stats.device
+    a = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    b = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    mr = torch.empty((B, G, 2), dtype=torch.float32, device=dev)
+    check(_lib.load().n3d_gn_coeffs(ptr(stats), rows, ptr(gamma), ptr(beta), B, Cc, G, N, eps, ptr(a), ptr(b), ptr(mr),
+                                    stream_ptr()), "n3d_gn_coeffs")
+    return a, b, mr
+
+
+def affine_act(raw: View, a, b, wptr, out: View, flags=0):
+    check(_lib.load().n3d_affine_act(raw.p, raw.ld, ptr(a), ptr(b), wptr, out.p, out.ld, raw.B, raw.N, raw.C, flags,
+                                     stream_ptr()), "n3d_affine_act")
+
+
+def affine_act_bwd_reduce(dout: View, raw: View, a, b, flags=0):
+    rows = stats_rows(raw.N, raw.C)
+    sums = torch.empty((raw.B, rows, raw.C, 3), dtype=torch.float64, device=raw.t.device)
+    check(_lib.load().n3d_affine_act_bwd_reduce(dout.p, dout.ld, raw.p, raw.ld, ptr(a), ptr(b), raw.B, raw.N, raw.C,
+                                                flags, ptr(sums), stream_ptr()), "n3d_affine_act_bwd_reduce")
+    return sums, rows
+
+
+def gn_bwd_coeffs(sums, rows, gamma, mean_rstd, wptr, B, Cc, G, N, dalpha_ptr=None):
+    dev = sums.device
+    dgamma = torch.empty((Cc,), dtype=torch.float32, device=dev)
+    dbeta = torch.empty((Cc,), dtype=torch.float32, device=dev)
+    A = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    Bc = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    Cc_ = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    check(_lib.load().n3d_gn_bwd_coeffs(ptr(sums), rows, ptr(gamma), ptr(mean_rstd), wptr, B, Cc, G, N, ptr(dgamma),
+                                        ptr(dbeta), dalpha_ptr, ptr(A), ptr(Bc), ptr(Cc_), stream_ptr()),
+          "n3d_gn_bwd_coeffs")
+    return dgamma, dbeta, A, Bc, Cc_
+
+
+def plain_bwd_coeffs(sums, rows, wptr, B, Cc, device, dalpha_ptr=None, want_A=True):
+    A = torch.empty((B, Cc), dtype=torch.float32, device=device) if want_A else None
+    check(_lib.load().n3d_plain_bwd_coeffs(ptr(sums), rows, wptr, B, Cc, dalpha_ptr, ptr(A), stream_ptr()),
+          "n3d_plain_bwd_coeffs")
+    return A
+
+
+def affine_act_bwd_apply(dout: View, raw: View, a, b, A, Bc, Cc_, draw: View, flags=0):
+    check(_lib.load().n3d_affine_act_bwd_apply(dout.p, dout.ld, raw.p, raw.ld, ptr(a), ptr(b), ptr(A), ptr(Bc), ptr(Cc_),
+                                               draw.p, draw.ld, raw.B, raw.N, raw.C, flags, stream_ptr()),
+          "n3d_affine_act_bwd_apply")
+
+
+# ------------------------------------------------------------------------------------------ SE / pool
+def se_gate_fwd(stats, rows, N, w1, b1, w2, b2, B, Cc):
+    dev = stats.device
+    mean = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    hidden = torch.empty((B,), dtype=torch.float32, device=dev)
+    gate = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    check(_lib.load().n3d_se_gate_fwd(ptr(stats), rows, N, ptr(w1), ptr(b1), ptr(w2), ptr(b2), B, Cc, ptr(mean),
+                                      ptr(hidden), ptr(gate), stream_ptr()), "n3d_se_gate_fwd")
+    return mean, hidden, gate
+
+
+def se_gate_bwd(sums, rows, wptr, mean, hidden, gate, w1, w2, B, Cc, N, dalpha_ptr=None):
+    dev = sums.device
+    dw1 = torch.empty((1, Cc), dtype=torch.float32, device=dev)
+    db1 = torch.empty((1,), dtype=torch.float32, device=dev)
+    dw2 = torch.empty((Cc, 1), dtype=torch.float32, device=dev)
+    db2 = torch.empty((Cc,), dtype=torch.float32, device=dev)
+    A = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    Bc = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    check(_lib.load().n3d_se_gate_bwd(ptr(sums), rows, wptr, ptr(mean), ptr(hidden), ptr(gate), ptr(w1), ptr(w2), B, Cc,
+                                      N, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), dalpha_ptr, ptr(A), ptr(Bc),
+                                      stream_ptr()), "n3d_se_gate_bwd")
+    return dw1, db1, dw2, db2, A, Bc
+
+
+def pool2_fwd(x: View, y: View, is_max):
+    check(_lib.load().n3d_pool2_fwd(x.p, x.ld, y.p, y.ld, x.B, x.D, x.H, x.W, x.C, POOL_MAX if is_max else 0,
+                                    stream_ptr()), "n3d_pool2_fwd")
+
+
+def pool2_bwd(dy: View, x: View, dx: View, is_max, accumulate=False):
+    fl = (POOL_MAX if is_max else 0) | (ACCUMULATE if accumulate else 0)
+    check(_lib.load().n3d_pool2_bwd(dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.B, x.D, x.H, x.W, x.C, fl, stream_ptr()),
+          "n3d_pool2_bwd")
+
+
+# ------------------------------------------------------------------------------------------ dice / adam
+def _bcv_strides(t):
+    """(sb, sc, sv) element strides of a (B,C,D,H,W) tensor whose voxels are uniformly strided, or None."""
+    B, Cc, D, H, W = t.shape
+    s = t.stride()
+    sv = s[4] if W > 1 else (s[3] if H > 1 else (s[2] if D > 1 else 1))
+    if (H > 1 and s[3] != W * sv) or (D > 1 and s[2] != H * W * sv):
+        return None
+    return s[0], s[1], sv
+
+
+def dice_fwd(p, t, smooth):
+    lib = _lib.load()
+    B, Cc = p.shape[0], p.shape[1]
+    N = p.shape[2] * p.shape[3] * p.shape[4]
+    ps, ts = _bcv_strides(p), _bcv_strides(t)
+    rows = int(lib.n3d_dice_rows(N))
+    partial = torch.empty((B, Cc, rows, 3), dtype=torch.float64, device=p.device)
+    sums = torch.empty((B, Cc, 3), dtype=torch.float64, device=p.device)
+    loss = torch.empty((), dtype=torch.float32, device=p.device)
+    check(lib.n3d_dice_fwd(ptr(p), ps[0], ps[1], ps[2], ptr(t), ts[0], ts[1], ts[2], B, Cc, N, smooth, ptr(partial),
+                           ptr(sums), ptr(loss), stream_ptr()), "n3d_dice_fwd")
+    return loss, sums
+
+
+def dice_bwd(p, t, smooth, sums, dloss, dp):
+    B, Cc = p.shape[0], p.shape[1]
+    N = p.shape[2] * p.shape[3] * p.shape[4]
+    ps, ts, ds = _bcv_strides(p), _bcv_strides(t), _bcv_strides(dp)
+    check(_lib.load().n3d_dice_bwd(ptr(p), ps[0], ps[1], ps[2], ptr(t), ts[0], ts[1], ts[2], B, Cc, N, smooth, ptr(sums),
+                                   ptr(dloss), ptr(dp), ds[0], ds[1], ds[2], stream_ptr()), "n3d_dice_bwd")
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step_t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+              grad_scale=1.0, inc_step=True):
+    check(_lib.load().n3d_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, beta1, beta2,
+                                    eps, weight_decay, grad_scale, ptr(step_t), 1 if inc_step else 0, stream_ptr()),
+          "n3d_adam_step")
+
+
+def ncdhw_to_ndhwc(src):
+    """(B,C,D,H,W) contiguous NCDHW -> dense NDHWC (logical shape unchanged)."""
+    B, Cc, D, H, W = src.shape
+    dst = empty_ndhwc(B, Cc, D, H, W, src.device)
+    check(_lib.load().n3d_ncdhw_to_ndhwc(ptr(src), ptr(dst), Cc, B, Cc, D * H * W, stream_ptr()), "n3d_ncdhw_to_ndhwc")
+    return dst

@@ -1,0 +1,465 @@
+"""Launch programs: how one reference op (prim_ops.BaseOp subclasses) maps onto libn3d kernels.
+
+A *segment* is the canonical fused sequence  [ReLU-on-load] -> [weight op] -> [GroupNorm] -> [ReLU]
+followed by an optional weighted accumulation into a destination (MixedOp weight / node sum).
+BaseOp.forward (prim_ops.py:68-83) walks `ops_order`; every order used by the reference
+('weight_norm_act', 'act_weight_norm', 'weight_norm', 'weight') is a single segment, any other
+order is split into several.  Forward and backward of a segment are plain kernel launch
+sequences (`seg_forward` / `seg_backward`) so that the op-level, MixedOp-level and cell-level
+autograd Functions can share them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import kernels as K
+from ._lib import ACCUMULATE, RELU, RELU_IN, N3DError
+
+
+def group_count(c):
+    """GroupNorm group rule of the reference (prim_ops.py:57)."""
+    return 1 if c % 16 != 0 else c // 16
+
+
+class Saved:
+    """bag of tensors / scalars kept between forward and backward of one segment"""
+    pass
+
+
+# =================================================================================================
+# weight programs
+# =================================================================================================
+class WeightProgram:
+    produces_stats = False
+
+    def params(self):
+        return []
+
+    def out_shape(self, x):
+        raise NotImplementedError
+
+
+class IdentityW(WeightProgram):
+    """IdentityOp.weight_call (prim_ops.py:173-174)"""
+
+    def out_shape(self, x):
+        return (x.B, x.C, x.D, x.H, x.W)
+
+    def fwd(self, x, relu_in, gate, want_stats):
+        if relu_in or gate is not None:
+            raise N3DError("identity weight op with act-before-weight / dropout is not supported")
+        return x, None, 0, None
+
+    def bwd(self, saved, draw, need_dx, dx_out, dx_acc):
+        if not need_dx:
+            return None, []
+        if dx_out is None:
+            return draw.t, []
+        K.affine_act(draw, None, None, None, dx_out, ACCUMULATE if dx_acc else 0)
+        return dx_out.t, []
+
+
+class PoolW(WeightProgram):
+    """PoolingOp.weight_call: AvgPool3d(2,2) / MaxPool3d(2,2) (prim_ops.py:160-168)"""
+
+    def __init__(self, is_max):
+        self.is_max = is_max
+
+    def out_shape(self, x):
+        return (x.B, x.C, x.D // 2, x.H // 2, x.W // 2)
+
+    def fwd(self, x, relu_in, gate, want_stats):
+        if relu_in or gate is not None:
+            raise N3DError("pooling with act-before-weight / dropout is not supported")
+        if x.D % 2 or x.H % 2 or x.W % 2:
+            raise N3DError("pool2: spatial dims must be even, got %s" % ((x.D, x.H, x.W),))
+        y = K.as_view(K.empty_ndhwc(x.B, x.C, x.D // 2, x.H // 2, x.W // 2, x.t.device))
+        K.pool2_fwd(x, y, self.is_max)
+        s = Saved()
+        s.x = x
+        return y, None, 0, s
+
+    def bwd(self, saved, draw, need_dx, dx_out, dx_acc):
+        if not need_dx:
+            return None, []
+        x = saved.x
+        if dx_out is None:
+            dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+            dx_acc = False
+        K.pool2_bwd(draw, x, dx_out, self.is_max, dx_acc)
+        return dx_out.t, []
+
+
+def _materialise_pre(x, relu_in, gate):
+    """u = relu?(x) * gate  as a real tensor (rare orders only)."""
+    u = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+    K.affine_act(x, gate, None, None, u, RELU if (relu_in and gate is None) else 0)
+    if relu_in and gate is not None:
+        # relu(x)*gate with a possibly negative gate: do it in two passes
+        K.affine_act(x, None, None, None, u, RELU)
+        K.affine_act(u, gate, None, None, u, 0)
+    return u
+
+
+def _pre_backward(x, relu_in, gate, du, dx_out, dx_acc):
+    """dx (+)= du * gate * [x > 0]"""
+    if dx_out is None:
+        dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+        dx_acc = False
+    fl = (RELU if relu_in else 0) | (ACCUMULATE if dx_acc else 0)
+    K.affine_act_bwd_apply(du, x, None, None, gate, None, None, dx_out, fl)
+    return dx_out
+
+
+class DenseConvW(WeightProgram):
+    """nn.Conv3d / nn.ConvTranspose3d of ConvOps / SEConvOp (prim_ops.py:100-102,109-110,142-147)."""
+    produces_stats = True
+
+    def __init__(self, conv_module, k, stride, dil, pad, transposed):
+        self.m = conv_module
+        self.k, self.stride, self.dil, self.pad, self.transposed = k, stride, dil, pad, transposed
+
+    def params(self):
+        return [self.m.weight, self.m.bias]
+
+    def geom(self, x):
+        w = self.m.weight
+        if self.transposed:
+            cin_t, cout_t = w.shape[0], w.shape[1]
+            if x.C != cin_t:
+                raise N3DError("conv_transpose: input has %d channels, weight expects %d" % (x.C, cin_t))
+            opad = 0 if self.stride == 1 else 1
+            def od(i):
+                return (i - 1) * self.stride - 2 * self.pad + self.dil * (self.k - 1) + opad + 1
+            return K.conv_geom(x.B, od(x.D), od(x.H), od(x.W), cout_t, cin_t, self.k, self.stride, self.dil, self.pad)
+        cout, cin = w.shape[0], w.shape[1]
+        if x.C != cin:
+            raise N3DError("conv: input has %d channels, weight expects %d" % (x.C, cin))
+        return K.conv_geom(x.B, x.D, x.H, x.W, cin, cout, self.k, self.stride, self.dil, self.pad)
+
+    def out_shape(self, x):
+        g = self.geom(x)
+        return (g.B, g.Ci, g.Di, g.Hi, g.Wi) if self.transposed else (g.B, g.Co, g.Do, g.Ho, g.Wo)
+
+    def fwd(self, x, relu_in, gate, want_stats):
+        s = Saved()
+        s.pre = None
+        if self.transposed and (relu_in or gate is not None):
+            s.pre = (x, relu_in, gate)
+            x = _materialise_pre(x, relu_in, gate)
+            relu_in, gate = False, None
+        g = self.geom(x)
+        shp = self.out_shape(x)
+        y = K.as_view(K.empty_ndhwc(*shp, x.t.device))
+        stats, rows = None, 0
+        if want_stats:
+            rows = K.conv_stats_rows(g, self.transposed)
+            stats = torch.empty((x.B, rows, shp[1], 2), dtype=torch.float64, device=x.t.device)
+        K.conv_fwd(g, x, self.m.weight, self.m.bias, y, RELU_IN if relu_in else 0, gate, stats, self.transposed)
+        s.x, s.g, s.relu_in, s.gate = x, g, relu_in, gate
+        return y, stats, rows, s
+
+    def bwd(self, saved, draw, need_dx, dx_out, dx_acc):
+        x, g = saved.x, saved.g
+        w = self.m.weight
+        dw = torch.empty_like(w) if w.requires_grad else None
+        db = torch.empty_like(self.m.bias) if (self.m.bias is not None and self.m.bias.requires_grad) else None
+        if dw is not None or db is not None:
+            K.conv_bwd_weight(g, x, draw, dw, db, RELU_IN if saved.relu_in else 0, saved.gate, self.transposed)
+        dx = None
+        if need_dx:
+            if saved.pre is not None:
+                du = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+                K.conv_bwd_data(g, draw, w, du, 0, None, None, self.transposed)
+                x0, r0, g0 = saved.pre
+                dx = _pre_backward(x0, r0, g0, du, dx_out, dx_acc).t
+            else:
+                if dx_out is None:
+                    dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+                    dx_acc = False
+                K.conv_bwd_data(g, draw, w, dx_out, ACCUMULATE if dx_acc else 0, x if saved.relu_in else None, saved.gate,
+                                self.transposed)
+                dx = dx_out.t
+        return dx, [dw, db]
+
+
+class DepthSepW(WeightProgram):
+    """depth_conv -> point_conv of a depthwised ConvOps (prim_ops.py:95-98,105-107,111-114)."""
+    produces_stats = True
+
+    def __init__(self, depth_module, point_module, stride, pad, transposed):
+        self.dm, self.pm = depth_module, point_module
+        self.stride, self.pad, self.transposed = stride, pad, transposed
+
+    def params(self):
+        return [self.dm.weight, self.dm.bias, self.pm.weight, self.pm.bias]
+
+    def dgeom(self, x):
+        c = x.C
+        if self.transposed:
+            opad = 0 if self.stride == 1 else 1
+            def od(i):
+                return (i - 1) * self.stride - 2 * self.pad + 2 + opad + 1
+            return K.conv_geom(x.B, od(x.D), od(x.H), od(x.W), c, c, 3, self.stride, 1, self.pad, True)
+        return K.conv_geom(x.B, x.D, x.H, x.W, c, c, 3, self.stride, 1, self.pad, True)
+
+    def out_shape(self, x):
+        g = self.dgeom(x)
+        co = self.pm.weight.shape[0]
+        return (g.B, co, g.Di, g.Hi, g.Wi) if self.transposed else (g.B, co, g.Do, g.Ho, g.Wo)
+
+    def fwd(self, x, relu_in, gate, want_stats):
+        s = Saved()
+        s.pre = None
+        if relu_in or gate is not None:
+            s.pre = (x, relu_in, gate)
+            x = _materialise_pre(x, relu_in, gate)
+        gd = self.dgeom(x)
+        mid_shape = (gd.B, gd.Ci, gd.Di, gd.Hi, gd.Wi) if self.transposed else (gd.B, gd.Co, gd.Do, gd.Ho, gd.Wo)
+        mid = K.as_view(K.empty_ndhwc(*mid_shape, x.t.device))
+        K.conv_fwd(gd, x, self.dm.weight, self.dm.bias, mid, 0, None, None, self.transposed)
+        co = self.pm.weight.shape[0]
+        gp = K.conv_geom(mid.B, mid.D, mid.H, mid.W, mid.C, co, 1, 1, 1, 0)
+        y = K.as_view(K.empty_ndhwc(mid.B, co, mid.D, mid.H, mid.W, x.t.device))
+        stats, rows = None, 0
+        if want_stats:
+            rows = K.conv_stats_rows(gp, False)
+            stats = torch.empty((x.B, rows, co, 2), dtype=torch.float64, device=x.t.device)
+        K.conv_fwd(gp, mid, self.pm.weight, self.pm.bias, y, 0, None, stats, False)
+        s.x, s.mid, s.gd, s.gp = x, mid, gd, gp
+        return y, stats, rows, s
+
+    def bwd(self, saved, draw, need_dx, dx_out, dx_acc):
+        x, mid, gd, gp = saved.x, saved.mid, saved.gd, saved.gp
+        pw, pb, dwt, dbs = self.pm.weight, self.pm.bias, self.dm.weight, self.dm.bias
+        g_pw = torch.empty_like(pw) if pw.requires_grad else None
+        g_pb = torch.empty_like(pb) if pb.requires_grad else None
+        if g_pw is not None or g_pb is not None:
+            K.conv_bwd_weight(gp, mid, draw, g_pw, g_pb, 0, None, False)
+        dmid = K.as_view(K.empty_ndhwc(mid.B, mid.C, mid.D, mid.H, mid.W, x.t.device))
+        K.conv_bwd_data(gp, draw, pw, dmid, 0, None, None, False)
+        g_dw = torch.empty_like(dwt) if dwt.requires_grad else None
+        g_db = torch.empty_like(dbs) if dbs.requires_grad else None
+        if g_dw is not None or g_db is not None:
+            K.conv_bwd_weight(gd, x, dmid, g_dw, g_db, 0, None, self.transposed)
+        dx = None
+        if need_dx:
+            if saved.pre is not None:
+                du = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+                K.conv_bwd_data(gd, dmid, dwt, du, 0, None, None, self.transposed)
+                x0, r0, g0 = saved.pre
+                dx = _pre_backward(x0, r0, g0, du, dx_out, dx_acc).t
+            else:
+                if dx_out is None:
+                    dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+                    dx_acc = False
+                K.conv_bwd_data(gd, dmid, dwt, dx_out, ACCUMULATE if dx_acc else 0, None, None, self.transposed)
+                dx = dx_out.t
+        return dx, [g_dw, g_db, g_pw, g_pb]
+
+
+class SEGate:
+    """avg_pool -> fc of SEConvOp (prim_ops.py:133-139,148-151); shared by the two SE programs."""
+
+    def __init__(self, fc):
+        self.fc = fc  # nn.Sequential(Linear(C,1), ReLU, Linear(1,C), Sigmoid)
+
+    def params(self):
+        return [self.fc[0].weight, self.fc[0].bias, self.fc[2].weight, self.fc[2].bias]
+
+    def fwd(self, x):
+        st, rows = K.channel_stats(x)
+        mean, hidden, gate = K.se_gate_fwd(st, rows, x.N, self.fc[0].weight, self.fc[0].bias, self.fc[2].weight,
+                                           self.fc[2].bias, x.B, x.C)
+        return mean, hidden, gate
+
+
+class SEConvW(WeightProgram):
+    """SEConvOp.weight_call with stride 2: conv(x * gate(x)) (prim_ops.py:148-153)."""
+    produces_stats = True
+
+    def __init__(self, fc, conv_module, stride, pad, transposed):
+        self.gate = SEGate(fc)
+        self.conv = DenseConvW(conv_module, 3, stride, 1, pad, transposed)
+
+    def params(self):
+        return self.gate.params() + self.conv.params()
+
+    def out_shape(self, x):
+        return self.conv.out_shape(x)
+
+    def fwd(self, x, relu_in, gate, want_stats):
+        if relu_in or gate is not None:
+            raise N3DError("SE conv with act-before-weight / dropout is not supported")
+        mean, hidden, g = self.gate.fwd(x)
+        u = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+        K.affine_act(x, g, None, None, u, 0)
+        y, stats, rows, cs = self.conv.fwd(u, False, None, want_stats)
+        s = Saved()
+        s.x, s.mean, s.hidden, s.gate, s.cs = x, mean, hidden, g, cs
+        return y, stats, rows, s
+
+    def bwd(self, saved, draw, need_dx, dx_out, dx_acc):
+        x = saved.x
+        du_t, cg = self.conv.bwd(saved.cs, draw, True, None, False)
+        du = K.as_view(du_t)
+        sums, rows = K.affine_act_bwd_reduce(du, x, None, None, 0)
+        fc = self.gate.fc
+        dw1, db1, dw2, db2, A, Bc = K.se_gate_bwd(sums, rows, None, saved.mean, saved.hidden, saved.gate, fc[0].weight,
+                                                  fc[2].weight, x.B, x.C, x.N)
+        dx = None
+        if need_dx:
+            if dx_out is None:
+                dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+                dx_acc = False
+            K.affine_act_bwd_apply(du, x, None, None, A, Bc, None, dx_out, ACCUMULATE if dx_acc else 0)
+            dx = dx_out.t
+        return dx, [dw1, db1, dw2, db2] + cg
+
+
+# =================================================================================================
+# segments
+# =================================================================================================
+class Segment:
+    """[relu_in] -> weight -> [norm] -> [relu_out]; `se_gate` marks the stride-1 SE op whose whole
+    effect is the epilogue scale x * gate (prim_ops.py:127-128,152)."""
+
+    def __init__(self, weight, norm=None, relu_in=False, relu_out=False, se_gate=None, dropout=None):
+        self.weight = weight if weight is not None else IdentityW()
+        self.norm = norm
+        self.relu_in = relu_in
+        self.relu_out = relu_out
+        self.se_gate = se_gate
+        self.dropout = dropout  # nn.Dropout3d applied before the weight op (prim_ops.py:72-73)
+
+    def params(self):
+        p = list(self.weight.params())
+        if self.se_gate is not None:
+            p += self.se_gate.params()
+        if self.norm is not None:
+            p += [self.norm.weight, self.norm.bias]
+        return p
+
+
+def _wptr(alpha_row, k):
+    if alpha_row is None:
+        return None
+    return C.c_void_p(alpha_row.data_ptr() + 4 * k)
+
+
+def seg_forward(seg, x, drop_gate=None, out=None, accumulate=False, alpha_row=None, alpha_k=0):
+    """Run one segment.  x/out: kernels.View.  Returns (out_view, saved)."""
+    s = Saved()
+    wp = _wptr(alpha_row, alpha_k)
+    want_stats = seg.norm is not None and seg.weight.produces_stats
+    raw, stats, rows, ws = seg.weight.fwd(x, seg.relu_in, drop_gate, want_stats)
+    s.ws, s.raw = ws, raw
+    s.a = s.b = s.mr = None
+    s.kind = "plain"
+    if seg.norm is not None:
+        if stats is None:
+            stats, rows = K.channel_stats(raw)
+        cn = raw.C
+        G = group_count(cn)
+        s.a, s.b, s.mr = K.gn_coeffs(stats, rows, seg.norm.weight, seg.norm.bias, raw.B, cn, G, raw.N, seg.norm.eps)
+        s.kind, s.G = "gn", G
+    elif seg.se_gate is not None:
+        s.mean, s.hidden, s.a = seg.se_gate.fwd(raw)
+        s.kind = "se"
+    need_pass = s.kind != "plain" or seg.relu_out or wp is not None or out is not None
+    if not need_pass:
+        return raw, s
+    if out is None:
+        out = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
+        accumulate = False
+    fl = (RELU if seg.relu_out else 0) | (ACCUMULATE if accumulate else 0)
+    K.affine_act(raw, s.a, s.b, wp, out, fl)
+    return out, s
+
+
+def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_row=None, alpha_k=0, dalpha=None):
+    """Backward of one segment.  dout: View of d(out).  Returns (dx tensor | None, [param grads])
+    with param grads ordered like seg.params().  If `dalpha` (a float tensor) is given,
+    dalpha[alpha_k] = <dout, z> is written (MixedOp architecture gradient, cell.py:29-32)."""
+    wp = _wptr(alpha_row, alpha_k)
+    dap = C.c_void_p(dalpha.data_ptr() + 4 * alpha_k) if dalpha is not None else None
+    raw = s.raw
+    fl = RELU if seg.relu_out else 0
+    extra = []
+    if s.kind == "gn":
+        sums, rows = K.affine_act_bwd_reduce(dout, raw, s.a, s.b, fl)
+        dgamma, dbeta, A, Bc, Cc = K.gn_bwd_coeffs(sums, rows, seg.norm.weight, s.mr, wp, raw.B, raw.C, s.G, raw.N, dap)
+        if isinstance(seg.weight, IdentityW) and need_dx:
+            # the raw tensor is the input itself: write dx directly
+            if dx_out is None:
+                dx_out = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
+                dx_acc = False
+            K.affine_act_bwd_apply(dout, raw, s.a, s.b, A, Bc, Cc, dx_out, fl | (ACCUMULATE if dx_acc else 0))
+            return dx_out.t, [dgamma, dbeta]
+        draw = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
+        K.affine_act_bwd_apply(dout, raw, s.a, s.b, A, Bc, Cc, draw, fl)
+        extra = [dgamma, dbeta]
+    elif s.kind == "se":
+        sums, rows = K.affine_act_bwd_reduce(dout, raw, s.a, None, 0)
+        fc = seg.se_gate.fc
+        dw1, db1, dw2, db2, A, Bc = K.se_gate_bwd(sums, rows, wp, s.mean, s.hidden, s.a, fc[0].weight, fc[2].weight,
+                                                  raw.B, raw.C, raw.N, dap)
+        dx = None
+        if need_dx:
+            if dx_out is None:
+                dx_out = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
+                dx_acc = False
+            K.affine_act_bwd_apply(dout, raw, None, None, A, Bc, None, dx_out, ACCUMULATE if dx_acc else 0)
+            dx = dx_out.t
+        return dx, [dw1, db1, dw2, db2]
+    else:
+        if seg.relu_out or wp is not None or dap is not None:
+            sums, rows = (None, 0)
+            if dap is not None:
+                sums, rows = K.affine_act_bwd_reduce(dout, raw, None, None, fl)
+            A = K.plain_bwd_coeffs(sums, rows, wp, raw.B, raw.C, raw.t.device, dap, want_A=True)
+            draw = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
+            K.affine_act_bwd_apply(dout, raw, None, None, A, None, None, draw, fl)
+        else:
+            draw = dout
+    dx, wg = seg.weight.bwd(s.ws, draw, need_dx, dx_out, dx_acc)
+    return dx, list(wg) + extra
+
+
+# =================================================================================================
+# op-level autograd Function (one reference BaseOp call = one autograd node per segment)
+# =================================================================================================
+class SegmentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg, drop_gate, x, *params):
+        xv = K.as_view(x, "input")
+        out, s = seg_forward(seg, xv, drop_gate)
+        ctx.seg, ctx.s = seg, s
+        ctx.nparams = len(params)
+        return out.t
+
+    @staticmethod
+    def backward(ctx, dout):
+        seg, s = ctx.seg, ctx.s
+        dv = K.as_view(dout, "grad_output")
+        dx, grads = seg_backward(seg, s, dv, need_dx=ctx.needs_input_grad[2])
+        plist = seg.params()
+        out = []
+        for i, p in enumerate(plist):
+            g = grads[i] if i < len(grads) else None
+            out.append(g if ctx.needs_input_grad[3 + i] else None)
+        ctx.s = None
+        return (None, None, dx) + tuple(out)
+
+
+def run_segment(seg, x, training):
+    gate = None
+    if seg.dropout is not None and training and seg.dropout.p > 0:
+        # Dropout3d zeroes whole channels per sample and rescales by 1/(1-p) (prim_ops.py:66,72-73);
+        # the (B, C) mask is generated by torch's RNG and folded into the conv as an input gate.
+        p = seg.dropout.p
+        B, Cc = x.shape[0], x.shape[1]
+        gate = (torch.rand((B, Cc), device=x.device) >= p).to(torch.float32) * (1.0 / (1.0 - p))
+    return SegmentFn.apply(seg, gate, x, *seg.params())
