@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 4x64^3 patches/s of one searched-net (G_conv) train step
+(zero_grad -> forward -> Dice -> backward -> Adam, + RCCL gradient all-reduce when N > 1),
+batch 2 per GPU, fp32, synthetic data, random-init weights  (BASELINE.json configs[1] / [3]).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  "roofline":     the dominant kernel (3x3x3 conv, C=4 @ 64^3) timed live with HIP events
+  "cpu_baseline": the CPU oracle (oracle/, torch CPU = the reference's own arithmetic) on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# benchmark genotype G_conv (the reference ships no genotype)
+G_CONV = dict(
+    down=[("down_conv", 0), ("down_dil_conv", 1), ("down_conv", 1), ("conv", 2), ("dil_conv", 2), ("conv", 3)],
+    up=[("conv", 0), ("up_conv", 1), ("up_conv", 1), ("dil_conv", 2), ("conv", 3), ("up_dil_conv", 1)],
+)
+CFG = dict(in_channels=4, init_n_kernels=4, out_channels=3, depth=4, n_nodes=3, channel_change=True)
+# algorithmic work per 4x64^3 patch, searched net / G_conv
+FLOP_FWD_BWD_PER_PATCH = 5.41e9
+BYTES_FWD_PER_PATCH = 148.3e6
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = vector rate
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_batch(batch, size, seed):
+    """Masked clipped-Gaussian volume in [10,110] inside a centred ball, nested-ball targets."""
+    rng = np.random.default_rng(seed)
+    g = np.arange(size, dtype=np.float64) - (size - 1) / 2.0
+    r = np.sqrt(g[:, None, None] ** 2 + g[None, :, None] ** 2 + g[None, None, :] ** 2)
+    x = np.clip(50.0 + 25.0 * rng.standard_normal((batch, 4, size, size, size)), 10.0, 110.0) * (r <= 0.45 * size)
+    t = np.stack([(r <= 0.22 * size), (r <= 0.30 * size), (r <= 0.12 * size)]).astype(np.float32)
+    return x.astype(np.float32), np.broadcast_to(t, (batch,) + t.shape).copy()
+
+
+def conv_kernel_roofline(device, batch, size, iters=20):
+    """Time the dominant kernel -- the 3x3x3 stride-1 conv at C=4 on (batch, 4, size^3), the shape of
+    up-cell 4 (43 % of the net's FLOPs) -- with HIP events on the launch stream."""
+    import ctypes as C
+    from nas_3d_unet_amd import _lib, kernels as K
+    lib = _lib.load()
+    c = 4
+    x = K.as_view(K.empty_ndhwc(batch, c, size, size, size, device).normal_())
+    y = K.as_view(K.empty_ndhwc(batch, c, size, size, size, device))
+    w = torch.randn(c, c, 3, 3, 3, device=device) * 0.1
+    b = torch.randn(c, device=device) * 0.1
+    g = K.conv_geom(batch, size, size, size, c, c, 3, 1, 1, 1)
+    rows = K.conv_stats_rows(g, False)
+    stats = torch.empty((batch, rows, c, 2), dtype=torch.float64, device=device)
+    stream = torch.cuda.current_stream()
+    for _ in range(3):
+        K.conv_fwd(g, x, w, b, y, 0, None, stats, False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        K.conv_fwd(g, x, w, b, y, 0, None, stats, False)
+    e1.record(stream)
+    e1.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    flops = 2.0 * batch * size ** 3 * c * c * 27
+    bytes_ = 2.0 * batch * size ** 3 * c * 4
+    ach = flops / sec / 1e12
+    return {"bound": "mfma", "kernel": "conv3x3x3 s1 d1 C=4 fwd (incl. weight pack + GN-stats epilogue)",
+            "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
+            "us_per_launch": round(sec * 1e6, 2), "algorithmic_gbs": round(bytes_ / sec / 1e9, 1), "traffic": None}
+
+
+def cpu_baseline(batch, size, budget_s=25.0):
+    """The CPU oracle (functional torch-CPU restatement, proven equal to the reference by the golden
+    tests) timed on this box's host cores: forward + Dice + backward at the same batch."""
+    from oracle import ref_path as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = orc.make_params(orc.searched_param_specs(orc.DEFAULT_CFG, orc.G_CONV), requires_grad=True)
+    xn, tn = synthetic_batch(batch, size, 99)
+    x, t = torch.from_numpy(xn), torch.from_numpy(tn)
+
+    def one():
+        for q in P.values():
+            q.grad = None
+        l = orc.dice_loss(orc.searched_forward(P, x, orc.G_CONV), t)
+        l.backward()
+    one()  # warm-up
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_all) < budget_s:
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": round(batch / med, 3), "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": "%d timed fwd+bwd iterations of the same net at batch %d, 4x%d^3 fp32 (median %.3f s)" % (len(times), batch, size, med)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=2, help="patches per GPU")
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    from nas_3d_unet_amd import _lib, searched
+    from nas_3d_unet_amd.train import Trainer
+    _lib.require_device()
+
+    torch.manual_seed(1234)  # same random-init weights on every rank (then broadcast anyway)
+    net = searched.SearchedNet(CFG["in_channels"], CFG["init_n_kernels"], CFG["out_channels"], CFG["depth"],
+                               CFG["n_nodes"], CFG["channel_change"], searched.Genotype(**G_CONV)).to(device)
+    net.train()  # head Dropout3d(0.5) active, as in training (searched.py:91-93)
+    trainer = Trainer(net, graph=not args.no_graph)
+
+    xn, tn = synthetic_batch(args.batch, args.size, 1234 + rank)
+    x, t = torch.from_numpy(xn).to(device), torch.from_numpy(tn).to(device)
+
+    for _ in range(args.warmup):
+        loss = trainer.step(x, t)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(x, t)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        patches = world * args.batch * args.steps
+        value = patches / dt
+        out = {
+            "metric": "4x64^3 patches/sec (train step: fwd + Dice + bwd + Adam%s)" % (" + RCCL all-reduce" if world > 1 else ""),
+            "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "searched.py SearchedNet/G_conv train step, batch=%d 4x%d^3 fp32 per GPU" % (args.batch, args.size),
+                       "global_batch": world * args.batch, "patch": [4, args.size, args.size, args.size],
+                       "parallelism": "dp%d" % world, "hip_graph": not args.no_graph, "final_loss": round(final_loss, 5)},
+            "whole_net": {"tflops_fwd_bwd": round(value * FLOP_FWD_BWD_PER_PATCH / 1e12, 3),
+                          "algorithmic_gbs": round(value * 3 * BYTES_FWD_PER_PATCH / 1e9, 1),
+                          "hbm_frac_of_8TBs": round(value * 3 * BYTES_FWD_PER_PATCH / 1e9 / world / PEAK_HBM_GBS, 4)},
+        }
+        if not args.no_roofline:
+            out["roofline"] = conv_kernel_roofline(device, args.batch, args.size)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.batch, args.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

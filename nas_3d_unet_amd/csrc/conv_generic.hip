@@ -557,6 +557,8 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
                   int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate, double* stats,
                   void* ws, size_t ws_bytes, hipStream_t s);
 int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags);
+int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
+                   float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s);
 }
 
 extern "C" {
@@ -573,6 +575,11 @@ size_t n3d_conv_workspace_bytes(const n3d_conv_geom* g) {
     WgradPlan p1 = wgrad_plan(g->B, No, g->Ci, g->Co, taps);
     WgradPlan p2 = wgrad_plan(g->B, No, g->Co, g->Ci, taps);  // transposed roles
     size_t a = (p1.partial_floats + p1.pbias_floats) * 4, b = (p2.partial_floats + p2.pbias_floats) * 4;
+    if (g->Ci % 16 == 0 && g->Co % 16 == 0) {  // MFMA weight-gradient slabs (conv_mfma.hip)
+      const size_t nt = (size_t)taps * (g->Ci / 16) * (g->Co / 16);
+      const size_t c = (1024 + nt) * (256 + 16) * 4;
+      if (c > a) a = c;
+    }
     bytes += align_up(a > b ? a : b, 256) + 256;
   }
   (void)Ni;
@@ -585,6 +592,7 @@ int n3d_conv_stats_rows(const n3d_conv_geom* g, int transposed, int flags) {
   if (!g) return 0;
   int r = mfma_conv_stats_rows(g, transposed != 0, flags);
   if (r > 0) return r;
+  if (r < 0) return 0;  // the kernel for this shape cannot emit statistics: use n3d_channel_stats
   const int64_t Nd = transposed ? (int64_t)g->Di * g->Hi * g->Wi : (int64_t)g->Do * g->Ho * g->Wo;
   return (int)cdiv(Nd, 256);
 }
@@ -691,6 +699,19 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   // dense: the kernel computes G[co'][ci'][tap] = sum dyK[o][co'] * xK[i(o,tap)][ci'] with xK on the i side.
   // forward conv: xK = x (Ci), dyK = dy (Co), dw native (Co,Ci,k^3) = G.
   // transposed conv (weight (CinT=Co_geom, CoutT=Ci_geom)): xK = dy_T (i side, Ci), dyK = x_T (o side, Co): same G layout.
+  if (!(flags & N3D_NO_MFMA) && xld % 4 == 0 && dyld % 4 == 0) {
+    int nch = 0, ntl = 0;
+    const size_t nt16 = (size_t)taps * (g->Ci / 16) * (g->Co / 16);
+    float* pb = wsf + (1024 + nt16) * 256;
+    if (g->Ci % 16 == 0 && g->Co % 16 == 0 && (1024 + nt16) * (256 + 16) <= avail &&
+        mfma_wgrad_try(g, x, xld, dy, dyld, flags, in_gate, wsf, pb, (1024 + nt16) * 256, &nch, &ntl, s) == 1) {
+      const int nout = g->Co * g->Ci * taps + g->Co;
+      hipLaunchKernelGGL(conv_wgrad_final_kernel, dim3((unsigned)cdiv(nout, 256)), dim3(256), 0, s, wsf, pb, nch, ntl, g->Ci / 16, g->Co / 16,
+                         16, 16, g->Co, g->Ci, taps, dw, transposed ? nullptr : dbias);
+      N3D_LAUNCH_CHECK();
+      return N3D_OK;
+    }
+  }
   WgradPlan p = wgrad_plan(g->B, No, g->Ci, g->Co, taps);
   if (p.partial_floats + p.pbias_floats > avail) { set_error("conv_bwd_weight: workspace too small"); return N3D_ERR_WORKSPACE; }
   WgradArgs a;

@@ -1,7 +1,604 @@
-// MFMA implicit-GEMM kernels for the FLOP-heavy 3x3x3 shapes (placeholder: filled in below).
+// MFMA implicit-GEMM convolution kernels (fp32 in / fp32 accumulate, exact fp32: v_mfma_f32_16x16x4_f32).
+//
+// gemm16 family -- channel counts that are multiples of 16 (the deep U-net levels, C = 16/32/64, and the
+// wide 1x1x1 cell-preprocess convs): GEMM view  D[voxel][cd] = sum_{tap,cs} S[map(voxel,tap)][cs] * W[tap][cs][cd]
+//   M = voxels (16 per MFMA tile, lane&15), N = cd (16 per tile), K = taps * Cs (4 per MFMA).
+//   A operand: lane (m = lane&15, kk = lane>>4) loads ONE float4 = S[voxel m][16*c16 + 4*kk + j], j = 0..3,
+//              i.e. 16 voxels x 64 contiguous bytes; element j feeds MFMA step j (k-slot kk <-> channel 16*c16+4*kk+j).
+//   B operand: packed weights Wp[tap][c16][kk][cd][j] -> one float4 per lane, 1 KiB contiguous per wave.
+// These levels have only 16..8192 voxels, so the kernels are latency-bound: the K loop (taps x Cs/16) is split
+// over the 4 waves of a workgroup (KSPLIT = 4) and reduced through LDS when there are few tiles.
+//
+// The same kernel is the data-gradient / transposed-conv kernel through the gather map
+//   src coordinate = (dst*sn + off + tap*dt) / den   (valid iff divisible and in range).
 #include "n3d_common.h"
+
 namespace n3d {
-int mfma_conv_try(const n3d_conv_geom*, bool, const float*, int64_t, const float*, const float*, float*, int64_t, int, const float*,
-                  const float*, int64_t, const float*, double*, void*, size_t, hipStream_t) { return 0; }
-int mfma_conv_stats_rows(const n3d_conv_geom*, bool, int) { return 0; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MfArgs {
+  const float* src; int64_t sld; int Ds, Hs, Ws, Cs;
+  float* dst; int64_t dld; int Dd, Hd, Wd, Cd;
+  const float* wp;
+  const float* bias;
+  int k, sn, off, dt, den, flags, B;
+  const float* in_gate;
+  const float* relu_src; int64_t rld;
+  const float* out_gate;
+  double* stats;
+  int rows_per_sample;
+};
+
+// Wp[tap][c16][kk][cd][j] <- w native (Co, Ci, taps); transpose=0: cs=ci, cd=co; transpose=1: cs=co, cd=ci
+__global__ void pack16_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int taps, int transpose) {
+  const int Cs = transpose ? Co : Ci, Cd = transpose ? Ci : Co;
+  const int total = taps * Cs * Cd;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int j = i & 3;
+  const int cd = (i >> 2) % Cd;
+  const int rest = (i >> 2) / Cd;  // (tap*(Cs/16) + c16)*4 + kk
+  const int kk = rest & 3, c16 = (rest >> 2) % (Cs / 16), tap = (rest >> 2) / (Cs / 16);
+  const int cs = c16 * 16 + kk * 4 + j;
+  const int co = transpose ? cs : cd, ci = transpose ? cd : cs;
+  wp[i] = w[((int64_t)co * Ci + ci) * taps + tap];
+}
+
+template <int MT, int NT, int KSPLIT>
+__global__ __launch_bounds__(256) void conv_gemm16_kernel(MfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, kk = lane >> 4;
+  const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd, Ns = (int64_t)a.Ds * a.Hs * a.Ws;
+  const int64_t Mtot = (int64_t)a.B * Nd;
+  constexpr int ROWS_PER_WAVE = 16 * MT;
+  constexpr int ROWS_PER_BLOCK = ROWS_PER_WAVE * (KSPLIT == 1 ? 4 : 1);
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (KSPLIT == 1 ? wave * ROWS_PER_WAVE : 0);
+  const int n0 = blockIdx.y * 16 * NT;
+
+  // A-side rows of this lane (voxel m of each M tile)
+  int rb[MT], rd[MT], rh[MT], rw[MT];
+  bool rvalid[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int64_t i = row0 + t * 16 + m;
+    rvalid[t] = i < Mtot;
+    const int64_t ii = rvalid[t] ? i : 0;
+    rb[t] = (int)(ii / Nd);
+    const int64_t v = ii % Nd;
+    rw[t] = (int)(v % a.Wd); rh[t] = (int)((v / a.Wd) % a.Hd); rd[t] = (int)(v / ((int64_t)a.Wd * a.Hd));
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int k = a.k, taps = k * k * k;
+  const int c16n = a.Cs >> 4;
+  const int ngroups = taps * c16n;
+  const bool relu_in = a.flags & N3D_RELU_IN;
+  const float4* __restrict__ wp4 = reinterpret_cast<const float4*>(a.wp);
+
+  int cur_tap = -1;
+  const float* sp[MT];
+  bool sok[MT];
+  for (int g = (KSPLIT == 4 ? wave : 0); g < ngroups; g += (KSPLIT == 4 ? 4 : 1)) {
+    const int tap = g / c16n, c16 = g - tap * c16n;
+    if (tap != cur_tap) {
+      cur_tap = tap;
+      const int kw = tap % k, kh = (tap / k) % k, kd = tap / (k * k);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        int nd = rd[t] * a.sn + a.off + kd * a.dt, nh = rh[t] * a.sn + a.off + kh * a.dt, nw = rw[t] * a.sn + a.off + kw * a.dt;
+        bool ok = rvalid[t];
+        if (a.den == 2) { ok = ok && !((nd | nh | nw) & 1); nd >>= 1; nh >>= 1; nw >>= 1; }
+        ok = ok && nd >= 0 && nd < a.Ds && nh >= 0 && nh < a.Hs && nw >= 0 && nw < a.Ws;
+        sok[t] = ok;
+        sp[t] = a.src + ((int64_t)rb[t] * Ns + ((int64_t)nd * a.Hs + nh) * a.Ws + nw) * a.sld + kk * 4;
+      }
+    }
+    float4 av[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      av[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sok[t]) {
+        av[t] = *reinterpret_cast<const float4*>(sp[t] + c16 * 16);
+        if (relu_in) { av[t].x = fmaxf(av[t].x, 0.f); av[t].y = fmaxf(av[t].y, 0.f); av[t].z = fmaxf(av[t].z, 0.f); av[t].w = fmaxf(av[t].w, 0.f); }
+        if (a.in_gate) {
+          const float4 gq = *reinterpret_cast<const float4*>(a.in_gate + (int64_t)rb[t] * a.Cs + c16 * 16 + kk * 4);
+          av[t].x *= gq.x; av[t].y *= gq.y; av[t].z *= gq.z; av[t].w *= gq.w;
+        }
+      }
+    }
+    float4 bv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bv[n] = wp4[((int64_t)g * 4 + kk) * a.Cd + n0 + n * 16 + m];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].x, bv[n].x, acc[t][n], 0, 0, 0);
+        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].y, bv[n].y, acc[t][n], 0, 0, 0);
+        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].z, bv[n].z, acc[t][n], 0, 0, 0);
+        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].w, bv[n].w, acc[t][n], 0, 0, 0);
+      }
+  }
+
+  if (KSPLIT == 4) {
+    // reduce the four K-slices through LDS into wave 0
+    f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+    if (wave > 0) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) l4[(((wave - 1) * MT + t) * NT + n) * 64 + lane] = acc[t][n];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[t][n] += l4[((w * MT + t) * NT + n) * 64 + lane];
+    }
+  }
+
+  // ---- epilogue: D layout -> lane holds column n = lane&15, rows 4*(lane>>4) + r
+  const bool writer = (KSPLIT == 1) || (wave == 0);
+  float csum[NT], csq[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) { csum[n] = 0.f; csq[n] = 0.f; }
+  if (writer) {
+    const bool accum = a.flags & N3D_ACCUMULATE;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t i = row0 + t * 16 + kk * 4 + r;
+        if (i >= Mtot) continue;
+        const int b = (int)(i / Nd);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int c = n0 + n * 16 + m;
+          float v = acc[t][n][r];
+          if (a.bias) v += a.bias[c];
+          if (a.relu_src) { if (!(a.relu_src[i * a.rld + c] > 0.f)) v = 0.f; }
+          if (a.out_gate) v *= a.out_gate[(int64_t)b * a.Cd + c];
+          float* o = a.dst + i * a.dld + c;
+          if (accum) v += *o;
+          *o = v;
+          csum[n] += v; csq[n] = fmaf(v, v, csq[n]);
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    // all rows of a block belong to one sample (host guarantees Nd % ROWS_PER_BLOCK == 0)
+    double* red = reinterpret_cast<double*>(lds + (KSPLIT == 4 ? 3 * MT * NT * 256 : 0));
+    if (KSPLIT == 4) __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      double s = csum[n], q = csq[n];
+      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      if (writer && kk == 0) { red[((wave * NT + n) * 16 + m) * 2] = s; red[((wave * NT + n) * 16 + m) * 2 + 1] = q; }
+    }
+    __syncthreads();
+    const int nw = (KSPLIT == 1) ? 4 : 1;
+    if (threadIdx.x < NT * 16 * 2) {
+      const int q2 = threadIdx.x & 1, col = (threadIdx.x >> 1) & 15, n = threadIdx.x >> 5;
+      double s = 0;
+      for (int w = 0; w < nw; ++w) s += red[((w * NT + n) * 16 + col) * 2 + q2];
+      const int64_t first = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
+      const int b = (int)(first / Nd);
+      const int row = (int)((first % Nd) / ROWS_PER_BLOCK);
+      a.stats[(((int64_t)b * a.rows_per_sample + row) * a.Cd + n0 + n * 16 + col) * 2 + q2] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient for 16-multiple channel counts:  G[ci][co] (per tap) = sum_v X[map(v,tap)][ci] * dY[v][co]
+//   MFMA A[m = ci][k = voxel], B[k = voxel][n = co]; the voxel range is split over workgroups (grid.y) and
+//   over the 4 waves of a workgroup; partial slabs are summed by conv_wgrad_final_kernel in fixed order.
+// ------------------------------------------------------------------------------------------------
+struct Wg16Args {
+  const float* x; int64_t xld; int Di, Hi, Wi, Ci;
+  const float* dy; int64_t dyld; int Do, Ho, Wo, Co;
+  int B, k, stride, dil, pad, flags;
+  const float* in_gate;
+  float* partial;  // [nchunks][ntiles][256]
+  float* pbias;    // [nchunks][tco][16]
+  int tci, tco;
+  int64_t chunk;   // voxels (flattened b,o) per workgroup, multiple of 16
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad16_kernel(Wg16Args a) {
+  __shared__ f32x4 l4[3 * 64];
+  __shared__ float lb[4][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, kk = lane >> 4;
+  const int tile = blockIdx.x;
+  const int cot = tile % a.tco, cit = (tile / a.tco) % a.tci, tap = tile / (a.tco * a.tci);
+  const int kw = tap % a.k, kh = (tap / a.k) % a.k, kd = tap / (a.k * a.k);
+  const int64_t No = (int64_t)a.Do * a.Ho * a.Wo, Ni = (int64_t)a.Di * a.Hi * a.Wi;
+  const int64_t total = (int64_t)a.B * No;
+  const int64_t c0 = (int64_t)blockIdx.y * a.chunk;
+  int64_t c1 = c0 + a.chunk;
+  if (c1 > total) c1 = total;
+  const bool relu_in = a.flags & N3D_RELU_IN;
+  const bool do_bias = (tap == 0 && cit == 0);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  // this lane's voxel walks i = c0 + wave*4 + kk, step 16
+  int64_t i = c0 + wave * 4 + kk;
+  int b = (int)(i / No);
+  int64_t o = i % No;
+  int ow = (int)(o % a.Wo), oh = (int)((o / a.Wo) % a.Ho), od = (int)(o / ((int64_t)a.Wo * a.Ho));
+  for (; i - kk - wave * 4 < c1; i += 16) {
+    float av = 0.f, bv = 0.f;
+    if (i < c1) {
+      bv = a.dy[i * a.dyld + cot * 16 + m];
+      const int id = od * a.stride - a.pad + kd * a.dil, ih = oh * a.stride - a.pad + kh * a.dil, iw = ow * a.stride - a.pad + kw * a.dil;
+      if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi) {
+        av = a.x[((int64_t)b * Ni + ((int64_t)id * a.Hi + ih) * a.Wi + iw) * a.xld + cit * 16 + m];
+        if (relu_in) av = fmaxf(av, 0.f);
+        if (a.in_gate) av *= a.in_gate[(int64_t)b * a.Ci + cit * 16 + m];
+      }
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    bsum += bv;
+    // advance this lane's voxel by 16
+    ow += 16;
+    while (ow >= a.Wo) {
+      ow -= a.Wo;
+      if (++oh >= a.Ho) { oh = 0; if (++od >= a.Do) { od = 0; ++b; } }
+    }
+  }
+  if (wave > 0) l4[(wave - 1) * 64 + lane] = acc;
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (kk == 0) lb[wave][m] = bsum;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    acc += l4[lane]; acc += l4[64 + lane]; acc += l4[128 + lane];
+    const int ntiles = gridDim.x;
+    float* p = a.partial + ((int64_t)blockIdx.y * ntiles + tile) * 256;
+    // D: rows (ci) 4*kk + r, column (co) m  ->  q = ci*16 + co
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[(kk * 4 + r) * 16 + m] = acc[r];
+    if (do_bias && lane < 16) a.pbias[((int64_t)blockIdx.y * a.tco + cot) * 16 + lane] = lb[0][lane] + lb[1][lane] + lb[2][lane] + lb[3][lane];
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// vox64 family -- the FLOP-heavy shallow levels: 3x3x3 stride-1 (dilation 1 or 2) convolution with C = 4 or 8
+// channels on 16^3 .. 128^3 volumes (up-cells 3/4 and their data gradients: > 60 % of the net's FLOPs).
+//   N = C is far too small for the 16x16 / 32x32 MFMA shapes, so the kernel uses the 16-block form
+//   v_mfma_f32_4x4x1_16b_f32: one instruction = 16 independent (4 voxels x 4 channels) outer products,
+//   i.e. 64 voxels x 4 output channels x K=1 at the full fp32 matrix rate (512 FLOP / 8 cycles / SIMD).
+//   A operand: lane l = voxel l of a 64-voxel group (one W row of 64, 2 rows of 32 or 4 rows of 16),
+//              read from the LDS halo tile as one ds_read_b128 = 4 input channels of one tap;
+//   B operand: lane l holds W[tap][cd = 4*half + (l&3)][cs], the same in all 16 blocks (weights broadcast),
+//              kept in VGPRs for one kd plane of taps at a time;
+//   D: lane (block b = l>>2, j = l&3) holds channel j of voxels 4b .. 4b+3 in its 4 accumulator registers.
+// Workgroup = 4 waves; tile = 4 (D) x 4*GH (H) x GW (W) output voxels; the (4+2d) x (TH+2d) x (GW+2d) input halo
+// tile is staged once in LDS as [channel quad][d][h][w] float4, so every tap read is conflict-free
+// (a 16-lane ds_read_b128 group always lies inside one W row).  Two workgroups per CU overlap one tile's
+// HBM/L2 fill with the other's MFMA phase.  The data gradient is the same kernel on spatially flipped,
+// channel-transposed weights (done by the pack kernel).
+// ------------------------------------------------------------------------------------------------
+struct VxArgs {
+  const float* src; int64_t sld;
+  float* dst; int64_t dld;
+  const float* wq;      // packed [27][C (cd)][C (cs)]
+  const float* bias;
+  int D, H, W, flags;
+  double* stats; int rows_per_sample;
+};
+
+// Wq[tap][cd][cs]; forward: cd=co, cs=ci, tap'=tap; data gradient: cd=ci, cs=co, tap'=26-tap
+__global__ void pack_vox_kernel(const float* __restrict__ w, float* __restrict__ wq, int C, int data_grad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 27 * C * C) return;
+  const int cs = i % C, cd = (i / C) % C, tap = i / (C * C);
+  const int co = data_grad ? cs : cd, ci = data_grad ? cd : cs, t2 = data_grad ? 26 - tap : tap;
+  wq[i] = w[((int64_t)co * C + ci) * 27 + t2];
+}
+
+template <int C, int GW, int DIL>
+__global__ __launch_bounds__(256) void conv_vox64_kernel(VxArgs a) {
+  constexpr int Q = C / 4, GH = 64 / GW, TH = 4 * GH, TD = 4;
+  constexpr int LD = TD + 2 * DIL, LH = TH + 2 * DIL, LW = GW + 2 * DIL;
+  constexpr int PLANE = LH * LW, QSTRIDE = LD * PLANE;
+  extern __shared__ __attribute__((aligned(16))) float4 tile[];  // [Q][LD][LH][LW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int tw_n = a.W / GW, th_n = a.H / TH;
+  int bx = blockIdx.x;
+  const int w0 = (bx % tw_n) * GW; bx /= tw_n;
+  const int h0 = (bx % th_n) * TH;
+  const int d0 = (bx / th_n) * TD;
+  const int64_t N = (int64_t)a.D * a.H * a.W;
+  const float* srcb = a.src + (int64_t)b * N * a.sld;
+
+  // ---- stage the halo tile (zero padding outside the volume)
+  for (int idx = tid; idx < LD * PLANE; idx += 256) {
+    const int wx = idx % LW, hy = (idx / LW) % LH, dz = idx / PLANE;
+    const int gd = d0 - DIL + dz, gh = h0 - DIL + hy, gw = w0 - DIL + wx;
+    const bool inb = gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+    const float* p = srcb + (((int64_t)gd * a.H + gh) * a.W + gw) * a.sld;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (inb) v = *reinterpret_cast<const float4*>(p + q * 4);
+      tile[q * QSTRIDE + idx] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- this lane's voxel inside the wave's 64-voxel group
+  const int hh = lane / GW, ww = lane % GW;
+  const int hl = wave * GH + hh;  // local h of the A-side voxel
+  const int j = lane & 3;
+  f32x4 acc[TD][Q];
+#pragma unroll
+  for (int g = 0; g < TD; ++g)
+#pragma unroll
+    for (int hf = 0; hf < Q; ++hf) {
+      const float bv = a.bias ? a.bias[hf * 4 + j] : 0.f;
+      acc[g][hf] = (f32x4){bv, bv, bv, bv};
+    }
+  const float4* __restrict__ wq4 = reinterpret_cast<const float4*>(a.wq);
+#pragma unroll 1
+  for (int kd = 0; kd < 3; ++kd) {
+    float4 wreg[9][Q][Q];  // [kh*3+kw][half][quad]: W[tap][cd = 4*half + j][cs = 4*quad .. +3]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int hf = 0; hf < Q; ++hf)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) wreg[t][hf][q] = wq4[((kd * 9 + t) * C + hf * 4 + j) * Q + q];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int kh = t / 3, kw = t % 3;
+      float4 av[TD][Q];
+#pragma unroll
+      for (int g = 0; g < TD; ++g)
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          av[g][q] = tile[q * QSTRIDE + (g + kd * DIL) * PLANE + (hl + kh * DIL) * LW + (ww + kw * DIL)];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int g = 0; g < TD; ++g)
+#pragma unroll
+          for (int hf = 0; hf < Q; ++hf) acc[g][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[g][q].x, wreg[t][hf][q].x, acc[g][hf], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < TD; ++g)
+#pragma unroll
+          for (int hf = 0; hf < Q; ++hf) acc[g][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[g][q].y, wreg[t][hf][q].y, acc[g][hf], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < TD; ++g)
+#pragma unroll
+          for (int hf = 0; hf < Q; ++hf) acc[g][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[g][q].z, wreg[t][hf][q].z, acc[g][hf], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < TD; ++g)
+#pragma unroll
+          for (int hf = 0; hf < Q; ++hf) acc[g][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[g][q].w, wreg[t][hf][q].w, acc[g][hf], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane (blk, j) holds channel 4*half + j of voxels 4*blk + r, r = 0..3, of each group
+  const int blk = lane >> 2;
+  float* dstb = a.dst + (int64_t)b * N * a.dld;
+  const bool accum = a.flags & N3D_ACCUMULATE;
+  float csum[Q], csq[Q];
+#pragma unroll
+  for (int hf = 0; hf < Q; ++hf) { csum[hf] = 0.f; csq[hf] = 0.f; }
+#pragma unroll
+  for (int g = 0; g < TD; ++g) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int vr = blk * 4 + r;
+      const int oh = h0 + wave * GH + vr / GW, ow = w0 + vr % GW;
+      float* o = dstb + (((int64_t)(d0 + g) * a.H + oh) * a.W + ow) * a.dld + j;
+#pragma unroll
+      for (int hf = 0; hf < Q; ++hf) {
+        float v = acc[g][hf][r];
+        if (accum) v += o[hf * 4];
+        o[hf * 4] = v;
+        csum[hf] += v; csq[hf] = fmaf(v, v, csq[hf]);
+      }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();  // everyone is done reading the tile: reuse its first bytes
+    double* red = reinterpret_cast<double*>(tile);
+#pragma unroll
+    for (int hf = 0; hf < Q; ++hf) {
+      double s = csum[hf], q2 = csq[hf];
+#pragma unroll
+      for (int off = 4; off < 64; off <<= 1) { s += __shfl_xor(s, off, 64); q2 += __shfl_xor(q2, off, 64); }
+      if (lane < 4) { red[(wave * C + hf * 4 + lane) * 2] = s; red[(wave * C + hf * 4 + lane) * 2 + 1] = q2; }
+    }
+    __syncthreads();
+    if (tid < C * 2) {
+      double s = 0;
+      for (int w = 0; w < 4; ++w) s += red[w * C * 2 + tid];
+      a.stats[(((int64_t)b * a.rows_per_sample + blockIdx.x) * C) * 2 + tid] = s;
+    }
+  }
+}
+
+struct VxPlan { bool ok; int C, gw, dil, tiles; size_t lds; };
+
+static VxPlan vx_plan(const n3d_conv_geom* g) {
+  VxPlan p; p.ok = false;
+  if (g->depthwise || g->k != 3 || g->stride != 1 || g->Ci != g->Co || (g->Ci != 4 && g->Ci != 8)) return p;
+  if (!(g->dil == 1 || g->dil == 2) || g->pad != g->dil) return p;
+  const int W = g->Wi, H = g->Hi, D = g->Di;
+  int gw;
+  if (W % 64 == 0) gw = 64; else if (W == 32) gw = 32; else if (W == 16) gw = 16; else return p;
+  const int th = 4 * (64 / gw);
+  if (D % 4 != 0 || H % th != 0) return p;
+  p.ok = true; p.C = g->Ci; p.gw = gw; p.dil = g->dil;
+  p.tiles = (W / gw) * (H / th) * (D / 4);
+  p.lds = (size_t)(g->Ci / 4) * (4 + 2 * g->dil) * (th + 2 * g->dil) * (gw + 2 * g->dil) * 16;
+  return p;
+}
+
+template <int C, int GW, int DIL>
+static int launch_vox_t(const VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_vox64_kernel<C, GW, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_vox64_kernel<C, GW, DIL>), dim3(p.tiles, B), dim3(256), p.lds, s, a);
+  return 1;
+}
+
+template <int C>
+static int launch_vox_c(const VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
+  if (p.dil == 1) {
+    if (p.gw == 64) return launch_vox_t<C, 64, 1>(a, p, B, s);
+    if (p.gw == 32) return launch_vox_t<C, 32, 1>(a, p, B, s);
+    return launch_vox_t<C, 16, 1>(a, p, B, s);
+  }
+  if (p.gw == 64) return launch_vox_t<C, 64, 2>(a, p, B, s);
+  if (p.gw == 32) return launch_vox_t<C, 32, 2>(a, p, B, s);
+  return launch_vox_t<C, 16, 2>(a, p, B, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct G16Plan { int mt, nt, ksplit, rows_per_block; bool ok; };
+
+static G16Plan g16_plan(const n3d_conv_geom* g, bool data_grad) {
+  G16Plan p; p.ok = false; p.mt = 1; p.nt = 1; p.ksplit = 4; p.rows_per_block = 16;
+  if (g->depthwise) return p;
+  const int Cs = data_grad ? g->Co : g->Ci, Cd = data_grad ? g->Ci : g->Co;
+  if (Cs % 16 != 0 || Cd % 16 != 0) return p;
+  const int64_t Nd = data_grad ? (int64_t)g->Di * g->Hi * g->Wi : (int64_t)g->Do * g->Ho * g->Wo;
+  const int64_t M = (int64_t)g->B * Nd;
+  const int64_t tiles = cdiv(M, 16) * (Cd / 16);
+  if (tiles <= 1024) { p.mt = 1; p.nt = 1; p.ksplit = 4; p.rows_per_block = 16; }
+  else { p.mt = 2; p.nt = (Cd % 32 == 0) ? 2 : 1; p.ksplit = 1; p.rows_per_block = 128; }
+  p.ok = true;
+  return p;
+}
+
+int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags) {
+  if (flags & N3D_NO_MFMA) return 0;
+  {
+    VxPlan v = vx_plan(g);
+    if (v.ok) return v.tiles;
+  }
+  G16Plan p = g16_plan(g, data_grad);
+  if (!p.ok) return 0;
+  const int64_t Nd = data_grad ? (int64_t)g->Di * g->Hi * g->Wi : (int64_t)g->Do * g->Ho * g->Wo;
+  if (Nd % p.rows_per_block != 0) return -1;  // statistics not produced by this kernel: caller must use n3d_channel_stats
+  return (int)(Nd / p.rows_per_block);
+}
+
+template <int MT, int NT, int KS>
+static void launch_g16(const MfArgs& a, int64_t M, hipStream_t s) {
+  constexpr int RPB = 16 * MT * (KS == 1 ? 4 : 1);
+  dim3 grid((unsigned)cdiv(M, RPB), (unsigned)(a.Cd / (16 * NT)));
+  size_t shm = (KS == 4 ? (size_t)3 * MT * NT * 256 * sizeof(float) : 0) + (size_t)4 * NT * 16 * 2 * sizeof(double);
+  hipLaunchKernelGGL((conv_gemm16_kernel<MT, NT, KS>), grid, dim3(256), shm, s, a);
+}
+
+int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
+                  int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate, double* stats,
+                  void* ws, size_t ws_bytes, hipStream_t s) {
+  {
+    VxPlan v = vx_plan(g);
+    if (v.ok) {
+      if (in_gate || relu_src || out_gate || (flags & N3D_RELU_IN) || sld % 4 != 0 || dld % 4 != 0 || !aligned16(src) || !aligned16(dst)) {
+        if (stats) { set_error("conv(vox64): unsupported extras with statistics"); return N3D_ERR_UNSUPPORTED; }
+        return 0;
+      }
+      const size_t need = (size_t)27 * v.C * v.C * 4;
+      if (!ws || ws_bytes < need) { set_error("conv(vox64): workspace too small"); return N3D_ERR_WORKSPACE; }
+      float* wq = (float*)ws;
+      hipLaunchKernelGGL(pack_vox_kernel, dim3((unsigned)cdiv(27 * v.C * v.C, 256)), dim3(256), 0, s, w, wq, v.C, data_grad ? 1 : 0);
+      VxArgs a;
+      a.src = src; a.sld = sld; a.dst = dst; a.dld = dld; a.wq = wq; a.bias = bias; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.flags = flags;
+      a.stats = stats; a.rows_per_sample = v.tiles;
+      if (v.C == 4) launch_vox_c<4>(a, v, g->B, s); else launch_vox_c<8>(a, v, g->B, s);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) { set_error("conv(vox64) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+      return 1;
+    }
+  }
+  G16Plan p = g16_plan(g, data_grad);
+  if (!p.ok) return 0;
+  if (sld % 4 != 0 || !aligned16(src)) return 0;
+  const int taps = g->k * g->k * g->k;
+  MfArgs a;
+  a.src = src; a.sld = sld; a.dst = dst; a.dld = dld; a.bias = bias; a.k = g->k; a.flags = flags; a.B = g->B;
+  a.in_gate = in_gate; a.relu_src = relu_src; a.rld = rld; a.out_gate = out_gate; a.stats = stats;
+  if (!data_grad) { a.Ds = g->Di; a.Hs = g->Hi; a.Ws = g->Wi; a.Cs = g->Ci; a.Dd = g->Do; a.Hd = g->Ho; a.Wd = g->Wo; a.Cd = g->Co;
+    a.sn = g->stride; a.off = -g->pad; a.dt = g->dil; a.den = 1; }
+  else { a.Ds = g->Do; a.Hs = g->Ho; a.Ws = g->Wo; a.Cs = g->Co; a.Dd = g->Di; a.Hd = g->Hi; a.Wd = g->Wi; a.Cd = g->Ci;
+    a.sn = 1; a.off = g->pad; a.dt = -g->dil; a.den = g->stride; }
+  const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
+  if (stats) {
+    if (Nd % p.rows_per_block != 0) { set_error("conv(mfma): statistics requested for a shape whose n3d_conv_stats_rows() is -1"); return N3D_ERR_INVALID; }
+    a.rows_per_sample = (int)(Nd / p.rows_per_block);
+  } else a.rows_per_sample = 0;
+  const size_t need = (size_t)taps * a.Cs * a.Cd * 4;
+  if (!ws || ws_bytes < need) { set_error("conv(mfma): workspace too small (%zu < %zu)", ws_bytes, need); return N3D_ERR_WORKSPACE; }
+  float* wp = (float*)ws;
+  a.wp = wp;
+  const int total = taps * a.Cs * a.Cd;
+  hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g->Co, g->Ci, taps, data_grad ? 1 : 0);
+  const int64_t M = (int64_t)g->B * Nd;
+  if (p.ksplit == 4) launch_g16<1, 1, 4>(a, M, s);
+  else if (p.nt == 2) launch_g16<2, 2, 1>(a, M, s);
+  else launch_g16<2, 1, 1>(a, M, s);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("conv(mfma) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+  return 1;
+}
+
+// returns 1 if handled
+int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
+                   float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s) {
+  if (g->depthwise || g->Ci % 16 != 0 || g->Co % 16 != 0) return 0;
+  const int taps = g->k * g->k * g->k;
+  const int64_t No = (int64_t)g->Do * g->Ho * g->Wo;
+  const int64_t total = (int64_t)g->B * No;
+  Wg16Args a;
+  a.x = x; a.xld = xld; a.Di = g->Di; a.Hi = g->Hi; a.Wi = g->Wi; a.Ci = g->Ci;
+  a.dy = dy; a.dyld = dyld; a.Do = g->Do; a.Ho = g->Ho; a.Wo = g->Wo; a.Co = g->Co;
+  a.B = g->B; a.k = g->k; a.stride = g->stride; a.dil = g->dil; a.pad = g->pad; a.flags = flags; a.in_gate = in_gate;
+  a.tci = g->Ci / 16; a.tco = g->Co / 16;
+  const int ntiles = taps * a.tci * a.tco;
+  // aim for ~1024 workgroups; each needs at least 64 voxels to amortise the LDS reduction
+  int64_t nch = cdiv(1024, ntiles);
+  if (nch < 1) nch = 1;
+  int64_t maxch = cdiv(total, 64);
+  if (nch > maxch) nch = maxch;
+  if (nch > 256) nch = 256;
+  int64_t chunk = cdiv(cdiv(total, nch), 16) * 16;
+  nch = cdiv(total, chunk);
+  if ((size_t)nch * ntiles * 256 > avail_floats) return 0;
+  a.chunk = chunk; a.partial = partial; a.pbias = pbias;
+  hipLaunchKernelGGL(conv_wgrad16_kernel, dim3(ntiles, (unsigned)nch), dim3(256), 0, s, a);
+  *nchunks_out = (int)nch; *ntiles_out = ntiles;
+  return 1;
+}
+
 }  // namespace n3d

@@ -182,10 +182,20 @@ def affine_act_bwd_reduce(dout: View, raw: View, a, b, flags=0):
     return sums, rows
 
 
-def gn_bwd_coeffs(sums, rows, gamma, mean_rstd, wptr, B, Cc, G, N, dalpha_ptr=None):
+def grad_target(p):
+    """Where the gradient of parameter `p` is written: its slice of a flat gradient buffer when a
+    trainer installed one (`p._n3d_grad`, written in place, no autograd accumulation kernels), else a
+    fresh tensor that the autograd Function returns."""
+    if p is None or not p.requires_grad:
+        return None
+    t = getattr(p, "_n3d_grad", None)
+    return t if t is not None else torch.empty_like(p)
+
+
+def gn_bwd_coeffs(sums, rows, gamma, mean_rstd, wptr, B, Cc, G, N, dalpha_ptr=None, beta=None):
     dev = sums.device
-    dgamma = torch.empty((Cc,), dtype=torch.float32, device=dev)
-    dbeta = torch.empty((Cc,), dtype=torch.float32, device=dev)
+    dgamma = grad_target(gamma) if isinstance(gamma, torch.nn.Parameter) else torch.empty((Cc,), dtype=torch.float32, device=dev)
+    dbeta = grad_target(beta) if isinstance(beta, torch.nn.Parameter) else torch.empty((Cc,), dtype=torch.float32, device=dev)
     A = torch.empty((B, Cc), dtype=torch.float32, device=dev)
     Bc = torch.empty((B, Cc), dtype=torch.float32, device=dev)
     Cc_ = torch.empty((B, Cc), dtype=torch.float32, device=dev)
@@ -219,12 +229,17 @@ def se_gate_fwd(stats, rows, N, w1, b1, w2, b2, B, Cc):
     return mean, hidden, gate
 
 
-def se_gate_bwd(sums, rows, wptr, mean, hidden, gate, w1, w2, B, Cc, N, dalpha_ptr=None):
+def se_gate_bwd(sums, rows, wptr, mean, hidden, gate, w1, w2, B, Cc, N, dalpha_ptr=None, fc=None):
     dev = sums.device
-    dw1 = torch.empty((1, Cc), dtype=torch.float32, device=dev)
-    db1 = torch.empty((1,), dtype=torch.float32, device=dev)
-    dw2 = torch.empty((Cc, 1), dtype=torch.float32, device=dev)
-    db2 = torch.empty((Cc,), dtype=torch.float32, device=dev)
+    if fc is not None:
+        dw1, db1, dw2, db2 = (grad_target(fc[0].weight), grad_target(fc[0].bias), grad_target(fc[2].weight),
+                              grad_target(fc[2].bias))
+    else:
+        dw1 = db1 = dw2 = db2 = None
+    dw1 = dw1 if dw1 is not None else torch.empty((1, Cc), dtype=torch.float32, device=dev)
+    db1 = db1 if db1 is not None else torch.empty((1,), dtype=torch.float32, device=dev)
+    dw2 = dw2 if dw2 is not None else torch.empty((Cc, 1), dtype=torch.float32, device=dev)
+    db2 = db2 if db2 is not None else torch.empty((Cc,), dtype=torch.float32, device=dev)
     A = torch.empty((B, Cc), dtype=torch.float32, device=dev)
     Bc = torch.empty((B, Cc), dtype=torch.float32, device=dev)
     check(_lib.load().n3d_se_gate_bwd(ptr(sums), rows, wptr, ptr(mean), ptr(hidden), ptr(gate), ptr(w1), ptr(w2), B, Cc,

@@ -156,7 +156,8 @@ class DenseConvW(WeightProgram):
         stats, rows = None, 0
         if want_stats:
             rows = K.conv_stats_rows(g, self.transposed)
-            stats = torch.empty((x.B, rows, shp[1], 2), dtype=torch.float64, device=x.t.device)
+            if rows > 0:  # 0: this shape's kernel cannot emit statistics -> seg_forward runs n3d_channel_stats
+                stats = torch.empty((x.B, rows, shp[1], 2), dtype=torch.float64, device=x.t.device)
         K.conv_fwd(g, x, self.m.weight, self.m.bias, y, RELU_IN if relu_in else 0, gate, stats, self.transposed)
         s.x, s.g, s.relu_in, s.gate = x, g, relu_in, gate
         return y, stats, rows, s
@@ -164,8 +165,8 @@ class DenseConvW(WeightProgram):
     def bwd(self, saved, draw, need_dx, dx_out, dx_acc):
         x, g = saved.x, saved.g
         w = self.m.weight
-        dw = torch.empty_like(w) if w.requires_grad else None
-        db = torch.empty_like(self.m.bias) if (self.m.bias is not None and self.m.bias.requires_grad) else None
+        dw = K.grad_target(w)
+        db = K.grad_target(self.m.bias)
         if dw is not None or db is not None:
             K.conv_bwd_weight(g, x, draw, dw, db, RELU_IN if saved.relu_in else 0, saved.gate, self.transposed)
         dx = None
@@ -226,7 +227,8 @@ class DepthSepW(WeightProgram):
         stats, rows = None, 0
         if want_stats:
             rows = K.conv_stats_rows(gp, False)
-            stats = torch.empty((x.B, rows, co, 2), dtype=torch.float64, device=x.t.device)
+            if rows > 0:
+                stats = torch.empty((x.B, rows, co, 2), dtype=torch.float64, device=x.t.device)
         K.conv_fwd(gp, mid, self.pm.weight, self.pm.bias, y, 0, None, stats, False)
         s.x, s.mid, s.gd, s.gp = x, mid, gd, gp
         return y, stats, rows, s
@@ -234,14 +236,14 @@ class DepthSepW(WeightProgram):
     def bwd(self, saved, draw, need_dx, dx_out, dx_acc):
         x, mid, gd, gp = saved.x, saved.mid, saved.gd, saved.gp
         pw, pb, dwt, dbs = self.pm.weight, self.pm.bias, self.dm.weight, self.dm.bias
-        g_pw = torch.empty_like(pw) if pw.requires_grad else None
-        g_pb = torch.empty_like(pb) if pb.requires_grad else None
+        g_pw = K.grad_target(pw)
+        g_pb = K.grad_target(pb)
         if g_pw is not None or g_pb is not None:
             K.conv_bwd_weight(gp, mid, draw, g_pw, g_pb, 0, None, False)
         dmid = K.as_view(K.empty_ndhwc(mid.B, mid.C, mid.D, mid.H, mid.W, x.t.device))
         K.conv_bwd_data(gp, draw, pw, dmid, 0, None, None, False)
-        g_dw = torch.empty_like(dwt) if dwt.requires_grad else None
-        g_db = torch.empty_like(dbs) if dbs.requires_grad else None
+        g_dw = K.grad_target(dwt)
+        g_db = K.grad_target(dbs)
         if g_dw is not None or g_db is not None:
             K.conv_bwd_weight(gd, x, dmid, g_dw, g_db, 0, None, self.transposed)
         dx = None
@@ -308,7 +310,7 @@ class SEConvW(WeightProgram):
         sums, rows = K.affine_act_bwd_reduce(du, x, None, None, 0)
         fc = self.gate.fc
         dw1, db1, dw2, db2, A, Bc = K.se_gate_bwd(sums, rows, None, saved.mean, saved.hidden, saved.gate, fc[0].weight,
-                                                  fc[2].weight, x.B, x.C, x.N)
+                                                  fc[2].weight, x.B, x.C, x.N, None, fc)
         dx = None
         if need_dx:
             if dx_out is None:
@@ -390,7 +392,8 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
     extra = []
     if s.kind == "gn":
         sums, rows = K.affine_act_bwd_reduce(dout, raw, s.a, s.b, fl)
-        dgamma, dbeta, A, Bc, Cc = K.gn_bwd_coeffs(sums, rows, seg.norm.weight, s.mr, wp, raw.B, raw.C, s.G, raw.N, dap)
+        dgamma, dbeta, A, Bc, Cc = K.gn_bwd_coeffs(sums, rows, seg.norm.weight, s.mr, wp, raw.B, raw.C, s.G, raw.N, dap,
+                                                   seg.norm.bias)
         if isinstance(seg.weight, IdentityW) and need_dx:
             # the raw tensor is the input itself: write dx directly
             if dx_out is None:
@@ -405,7 +408,7 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
         sums, rows = K.affine_act_bwd_reduce(dout, raw, s.a, None, 0)
         fc = seg.se_gate.fc
         dw1, db1, dw2, db2, A, Bc = K.se_gate_bwd(sums, rows, wp, s.mean, s.hidden, s.a, fc[0].weight, fc[2].weight,
-                                                  raw.B, raw.C, raw.N, dap)
+                                                  raw.B, raw.C, raw.N, dap, fc)
         dx = None
         if need_dx:
             if dx_out is None:
@@ -449,6 +452,8 @@ class SegmentFn(torch.autograd.Function):
         out = []
         for i, p in enumerate(plist):
             g = grads[i] if i < len(grads) else None
+            if getattr(p, "_n3d_grad", None) is not None:
+                g = None  # already written in place into the trainer's flat gradient buffer
             out.append(g if ctx.needs_input_grad[3 + i] else None)
         ctx.s = None
         return (None, None, dx) + tuple(out)
