@@ -46,7 +46,7 @@ __global__ void pack16_kernel(const float* __restrict__ w, float* __restrict__ w
 }
 
 template <int MT, int NT, int KSPLIT>
-__global__ __launch_bounds__(256) void conv_gemm16_kernel(MfArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_gemm16_kernel(MfArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, kk = lane >> 4;
@@ -69,11 +69,11 @@ __global__ __launch_bounds__(256) void conv_gemm16_kernel(MfArgs a) {
     const int64_t v = ii % Nd;
     rw[t] = (int)(v % a.Wd); rh[t] = (int)((v / a.Wd) % a.Hd); rd[t] = (int)(v / ((int64_t)a.Wd * a.Hd));
   }
-  f32x4 acc[MT][NT];
+  f32x4 acc[MT][NT], acc2[MT][NT];
 #pragma unroll
   for (int t = 0; t < MT; ++t)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NT; ++n) { acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
   const int k = a.k, taps = k * k * k;
   const int c16n = a.Cs >> 4;
@@ -115,16 +115,26 @@ __global__ __launch_bounds__(256) void conv_gemm16_kernel(MfArgs a) {
     float4 bv[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) bv[n] = wp4[((int64_t)g * 4 + kk) * a.Cd + n0 + n * 16 + m];
+    // two accumulator chains per tile (x,z / y,w): a dependent 16x16x4 MFMA has 40 cycles latency vs 32 issue
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].x, bv[n].x, acc[t][n], 0, 0, 0);
-        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].y, bv[n].y, acc[t][n], 0, 0, 0);
+        acc2[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].y, bv[n].y, acc2[t][n], 0, 0, 0);
+      }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
         acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].z, bv[n].z, acc[t][n], 0, 0, 0);
-        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].w, bv[n].w, acc[t][n], 0, 0, 0);
+        acc2[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].w, bv[n].w, acc2[t][n], 0, 0, 0);
       }
   }
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[t][n] += acc2[t][n];
 
   if (KSPLIT == 4) {
     // reduce the four K-slices through LDS into wave 0
@@ -216,7 +226,7 @@ struct Wg16Args {
   int64_t chunk;   // voxels (flattened b,o) per workgroup, multiple of 16
 };
 
-__global__ __launch_bounds__(256) void conv_wgrad16_kernel(Wg16Args a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wg16Args a) {
   __shared__ f32x4 l4[3 * 64];
   __shared__ float lb[4][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -283,16 +293,17 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(Wg16Args a) {
 //   N = C is far too small for the 16x16 / 32x32 MFMA shapes, so the kernel uses the 16-block form
 //   v_mfma_f32_4x4x1_16b_f32: one instruction = 16 independent (4 voxels x 4 channels) outer products,
 //   i.e. 64 voxels x 4 output channels x K=1 at the full fp32 matrix rate (512 FLOP / 8 cycles / SIMD).
-//   A operand: lane l = voxel l of a 64-voxel group (one W row of 64, 2 rows of 32 or 4 rows of 16),
-//              read from the LDS halo tile as one ds_read_b128 = 4 input channels of one tap;
-//   B operand: lane l holds W[tap][cd = 4*half + (l&3)][cs], the same in all 16 blocks (weights broadcast),
-//              kept in VGPRs for one kd plane of taps at a time;
-//   D: lane (block b = l>>2, j = l&3) holds channel j of voxels 4b .. 4b+3 in its 4 accumulator registers.
-// Workgroup = 4 waves; tile = 4 (D) x 4*GH (H) x GW (W) output voxels; the (4+2d) x (TH+2d) x (GW+2d) input halo
-// tile is staged once in LDS as [channel quad][d][h][w] float4, so every tap read is conflict-free
-// (a 16-lane ds_read_b128 group always lies inside one W row).  Two workgroups per CU overlap one tile's
-// HBM/L2 fill with the other's MFMA phase.  The data gradient is the same kernel on spatially flipped,
-// channel-transposed weights (done by the pack kernel).
+//   A operand: lane l = voxel l of a 64-voxel group (4 H rows x 16 W), read from the LDS halo tile with one
+//              ds_read_b128 = 4 input channels of one tap;
+//   B operand: lane l holds W[tap][cd = 4*half + (l&3)][cs]: identical in all 16 blocks (weight broadcast),
+//              read from an LDS copy of the packed weights (4 distinct addresses per wave -> broadcast);
+//   D: lane (block b = l>>2, j = l&3) holds channel 4*half + j of voxels 4b .. 4b+3 (4 accumulator registers).
+// ONE WAVE = ONE WORKGROUP: a wave stages its own (TD+2d) x (4+2d) x (16+2d) halo tile (10-28 KB of LDS), so
+// there is no barrier anywhere; 8-12 independent waves per CU hide each other's fill latency, and small tiles
+// give thousands of workgroups even on the 32^3 level.  Loop order: (kh,kw) outer with the three kd weights in
+// registers, input plane dz inner, so every A read feeds up to 3 output planes (12 MFMAs on 3 independent
+// accumulator chains) -- 54 + 27 LDS reads per 432 MFMAs at C = 4.
+// The data gradient is the same kernel on spatially flipped, channel-transposed weights (pack kernel).
 // ------------------------------------------------------------------------------------------------
 struct VxArgs {
   const float* src; int64_t sld;
@@ -312,41 +323,70 @@ __global__ void pack_vox_kernel(const float* __restrict__ w, float* __restrict__
   wq[i] = w[((int64_t)co * C + ci) * 27 + t2];
 }
 
-template <int C, int GW, int DIL>
-__global__ __launch_bounds__(256) void conv_vox64_kernel(VxArgs a) {
-  constexpr int Q = C / 4, GH = 64 / GW, TH = 4 * GH, TD = 4;
-  constexpr int LD = TD + 2 * DIL, LH = TH + 2 * DIL, LW = GW + 2 * DIL;
-  constexpr int PLANE = LH * LW, QSTRIDE = LD * PLANE;
-  extern __shared__ __attribute__((aligned(16))) float4 tile[];  // [Q][LD][LH][LW]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <int C, int TD, int DIL>
+__global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
+  constexpr int Q = C / 4, GH = 4, GW = 16;
+  constexpr int LD = TD + 2 * DIL, LH = GH + 2 * DIL, LW = GW + 2 * DIL;
+  constexpr int PLANE = LH * LW, QSTRIDE = LD * PLANE, NVOX = LD * PLANE;
+  constexpr int NW4 = 27 * C * Q;  // float4 count of the packed weights
+  extern __shared__ __attribute__((aligned(16))) float4 vlds[];  // tile [Q][LD][LH][LW], then weights [27][C][Q]
+  float4* tile = vlds;
+  float4* wl = vlds + Q * QSTRIDE;
+  const int lane = threadIdx.x;
   const int b = blockIdx.y;
-  const int tw_n = a.W / GW, th_n = a.H / TH;
+  const int tw_n = a.W / GW, th_n = a.H / GH;
   int bx = blockIdx.x;
   const int w0 = (bx % tw_n) * GW; bx /= tw_n;
-  const int h0 = (bx % th_n) * TH;
+  const int h0 = (bx % th_n) * GH;
   const int d0 = (bx / th_n) * TD;
   const int64_t N = (int64_t)a.D * a.H * a.W;
   const float* srcb = a.src + (int64_t)b * N * a.sld;
+  const int j = lane & 3, blk = lane >> 2;
 
-  // ---- stage the halo tile (zero padding outside the volume)
-  for (int idx = tid; idx < LD * PLANE; idx += 256) {
-    const int wx = idx % LW, hy = (idx / LW) % LH, dz = idx / PLANE;
-    const int gd = d0 - DIL + dz, gh = h0 - DIL + hy, gw = w0 - DIL + wx;
-    const bool inb = gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-    const float* p = srcb + (((int64_t)gd * a.H + gh) * a.W + gw) * a.sld;
+  // ---- stage weights and the halo tile (zero padding outside the volume); same wave reads them: no barrier.
+  // All global loads are issued back to back (clamped addresses + select, no branches) so that the
+  // wave pays ONE memory latency for the whole tile, then the LDS writes follow.
+  {
+    const float4* __restrict__ wq4 = reinterpret_cast<const float4*>(a.wq);
+    constexpr int NWI = (NW4 + 63) / 64;
+    float4 wv[NWI];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (inb) v = *reinterpret_cast<const float4*>(p + q * 4);
-      tile[q * QSTRIDE + idx] = v;
+    for (int i = 0; i < NWI; ++i) { const int idx = lane + i * 64; wv[i] = wq4[idx < NW4 ? idx : NW4 - 1]; }
+    constexpr int NFI = (NVOX + 63) / 64;
+    float4 fv[NFI][Q];
+#pragma unroll
+    for (int i = 0; i < NFI; ++i) {
+      const int idx = (lane + i * 64 < NVOX) ? lane + i * 64 : NVOX - 1;
+      const int wx = idx % LW, hy = (idx / LW) % LH, dz = idx / PLANE;
+      const int gd = d0 - DIL + dz, gh = h0 - DIL + hy, gw = w0 - DIL + wx;
+      const bool inb = gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      const int cd_ = min(max(gd, 0), a.D - 1), ch_ = min(max(gh, 0), a.H - 1), cw_ = min(max(gw, 0), a.W - 1);
+      const float* p = srcb + (((int64_t)cd_ * a.H + ch_) * a.W + cw_) * a.sld;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+#ifdef VOX_NO_LOAD
+        float4 v = make_float4(1.f, 1.f, 1.f, 1.f);
+#else
+        float4 v = *reinterpret_cast<const float4*>(p + q * 4);
+#endif
+        fv[i][q] = inb ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) { const int idx = lane + i * 64; if (idx < NW4) wl[idx] = wv[i]; }
+#pragma unroll
+    for (int i = 0; i < NFI; ++i) {
+      const int idx = lane + i * 64;
+      if (idx < NVOX) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) tile[q * QSTRIDE + idx] = fv[i][q];
+      }
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();  // single-wave workgroup: orders the LDS writes above before the reads below
 
-  // ---- this lane's voxel inside the wave's 64-voxel group
-  const int hh = lane / GW, ww = lane % GW;
-  const int hl = wave * GH + hh;  // local h of the A-side voxel
-  const int j = lane & 3;
+  const int hh = lane >> 4, ww = lane & 15;
   f32x4 acc[TD][Q];
 #pragma unroll
   for (int g = 0; g < TD; ++g)
@@ -355,128 +395,152 @@ __global__ __launch_bounds__(256) void conv_vox64_kernel(VxArgs a) {
       const float bv = a.bias ? a.bias[hf * 4 + j] : 0.f;
       acc[g][hf] = (f32x4){bv, bv, bv, bv};
     }
-  const float4* __restrict__ wq4 = reinterpret_cast<const float4*>(a.wq);
+#ifdef VOX_NO_MFMA
 #pragma unroll 1
-  for (int kd = 0; kd < 3; ++kd) {
-    float4 wreg[9][Q][Q];  // [kh*3+kw][half][quad]: W[tap][cd = 4*half + j][cs = 4*quad .. +3]
+  for (int t9 = 0; t9 < 0; ++t9) {
+#else
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+  for (int t9 = 0; t9 < 9; ++t9) {
+#endif
+    const int kh = t9 / 3, kw = t9 % 3;
+    float4 wr[3][Q][Q];  // [kd][half][quad]
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
       for (int hf = 0; hf < Q; ++hf)
 #pragma unroll
-        for (int q = 0; q < Q; ++q) wreg[t][hf][q] = wq4[((kd * 9 + t) * C + hf * 4 + j) * Q + q];
+        for (int q = 0; q < Q; ++q) wr[kd][hf][q] = wl[((kd * 9 + t9) * C + hf * 4 + j) * Q + q];
+    const int base = (hh + kh * DIL) * LW + (ww + kw * DIL);
+    // all input planes of this (kh,kw) are requested up front: LD*Q ds_read_b128 in flight, the MFMAs of
+    // plane dz start as soon as its read has landed (counted lgkmcnt waits)
+    float4 av[LD][Q];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int kh = t / 3, kw = t % 3;
-      float4 av[TD][Q];
+    for (int dz = 0; dz < LD; ++dz)
 #pragma unroll
-      for (int g = 0; g < TD; ++g)
+      for (int q = 0; q < Q; ++q) av[dz][q] = tile[q * QSTRIDE + dz * PLANE + base];
 #pragma unroll
-        for (int q = 0; q < Q; ++q)
-          av[g][q] = tile[q * QSTRIDE + (g + kd * DIL) * PLANE + (hl + kh * DIL) * LW + (ww + kw * DIL)];
+    for (int dz = 0; dz < LD; ++dz) {
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
 #pragma unroll
-        for (int g = 0; g < TD; ++g)
+        for (int e = 0; e < 4; ++e) {
+          const float ae = e == 0 ? av[dz][q].x : (e == 1 ? av[dz][q].y : (e == 2 ? av[dz][q].z : av[dz][q].w));
 #pragma unroll
-          for (int hf = 0; hf < Q; ++hf) acc[g][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[g][q].x, wreg[t][hf][q].x, acc[g][hf], 0, 0, 0);
+          for (int kd = 0; kd < 3; ++kd) {
+            const int g = dz - kd * DIL;
+            if (g >= 0 && g < TD) {
 #pragma unroll
-        for (int g = 0; g < TD; ++g)
-#pragma unroll
-          for (int hf = 0; hf < Q; ++hf) acc[g][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[g][q].y, wreg[t][hf][q].y, acc[g][hf], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < TD; ++g)
-#pragma unroll
-          for (int hf = 0; hf < Q; ++hf) acc[g][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[g][q].z, wreg[t][hf][q].z, acc[g][hf], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < TD; ++g)
-#pragma unroll
-          for (int hf = 0; hf < Q; ++hf) acc[g][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[g][q].w, wreg[t][hf][q].w, acc[g][hf], 0, 0, 0);
+              for (int hf = 0; hf < Q; ++hf) {
+                const float4 wv = wr[kd][hf][q];
+                const float be = e == 0 ? wv.x : (e == 1 ? wv.y : (e == 2 ? wv.z : wv.w));
+                acc[g][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(ae, be, acc[g][hf], 0, 0, 0);
+              }
+            }
+          }
+        }
       }
     }
   }
 
-  // ---- epilogue: lane (blk, j) holds channel 4*half + j of voxels 4*blk + r, r = 0..3, of each group
-  const int blk = lane >> 2;
+  // ---- epilogue: lane (blk, j) holds channel 4*half + j of voxels 4*blk + r (r = register) of each group.
+  // GroupNorm statistics are taken in that layout (one channel per lane); for the store the 4x4 block held
+  // by each lane quad is transposed with two DPP butterfly stages so that lane (blk, i) owns all four
+  // channels of voxel 4*blk + i and issues ONE 16-byte store (a wave writes 4 rows x 256 contiguous bytes).
   float* dstb = a.dst + (int64_t)b * N * a.dld;
   const bool accum = a.flags & N3D_ACCUMULATE;
-  float csum[Q], csq[Q];
+  if (a.stats) {
 #pragma unroll
-  for (int hf = 0; hf < Q; ++hf) { csum[hf] = 0.f; csq[hf] = 0.f; }
+    for (int hf = 0; hf < Q; ++hf) {
+      float cs = 0.f, cq = 0.f;
 #pragma unroll
-  for (int g = 0; g < TD; ++g) {
+      for (int g = 0; g < TD; ++g)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int vr = blk * 4 + r;
-      const int oh = h0 + wave * GH + vr / GW, ow = w0 + vr % GW;
-      float* o = dstb + (((int64_t)(d0 + g) * a.H + oh) * a.W + ow) * a.dld + j;
+        for (int r = 0; r < 4; ++r) { const float v = acc[g][hf][r]; cs += v; cq = fmaf(v, v, cq); }
+      double sm = cs, q2 = cq;
 #pragma unroll
-      for (int hf = 0; hf < Q; ++hf) {
-        float v = acc[g][hf][r];
-        if (accum) v += o[hf * 4];
-        o[hf * 4] = v;
-        csum[hf] += v; csq[hf] = fmaf(v, v, csq[hf]);
+      for (int off = 4; off < 64; off <<= 1) { sm += __shfl_xor(sm, off, 64); q2 += __shfl_xor(q2, off, 64); }
+      if (lane < 4) {
+        double* o = a.stats + (((int64_t)b * a.rows_per_sample + blockIdx.x) * C + hf * 4 + lane) * 2;
+        o[0] = sm; o[1] = q2;
       }
     }
   }
-  if (a.stats) {
-    __syncthreads();  // everyone is done reading the tile: reuse its first bytes
-    double* red = reinterpret_cast<double*>(tile);
+  const int vr = lane;  // after the transpose this lane owns voxel `lane` of the group
+  const int64_t vox_off = ((int64_t)(h0 + (vr >> 4)) * a.W + w0 + (vr & 15));
+#pragma unroll
+  for (int g = 0; g < TD; ++g) {
+    float* o = dstb + (((int64_t)(d0 + g) * a.H * a.W) + vox_off) * a.dld;
 #pragma unroll
     for (int hf = 0; hf < Q; ++hf) {
-      double s = csum[hf], q2 = csq[hf];
-#pragma unroll
-      for (int off = 4; off < 64; off <<= 1) { s += __shfl_xor(s, off, 64); q2 += __shfl_xor(q2, off, 64); }
-      if (lane < 4) { red[(wave * C + hf * 4 + lane) * 2] = s; red[(wave * C + hf * 4 + lane) * 2 + 1] = q2; }
-    }
-    __syncthreads();
-    if (tid < C * 2) {
-      double s = 0;
-      for (int w = 0; w < 4; ++w) s += red[w * C * 2 + tid];
-      a.stats[(((int64_t)b * a.rows_per_sample + blockIdx.x) * C) * 2 + tid] = s;
+      float x0 = acc[g][hf][0], x1 = acc[g][hf][1], x2 = acc[g][hf][2], x3 = acc[g][hf][3];
+      // stage 1: exchange with lane^1 (quad_perm [1,0,3,2] = 0xB1)
+      {
+        const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x0), 0xB1, 0xF, 0xF, true));
+        const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x1), 0xB1, 0xF, 0xF, true));
+        const float p2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x2), 0xB1, 0xF, 0xF, true));
+        const float p3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x3), 0xB1, 0xF, 0xF, true));
+        const bool odd = j & 1;
+        const float n0 = odd ? p1 : x0, n1 = odd ? x1 : p0, n2 = odd ? p3 : x2, n3 = odd ? x3 : p2;
+        x0 = n0; x1 = n1; x2 = n2; x3 = n3;
+      }
+      // stage 2: exchange with lane^2 (quad_perm [2,3,0,1] = 0x4E)
+      {
+        const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x0), 0x4E, 0xF, 0xF, true));
+        const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x1), 0x4E, 0xF, 0xF, true));
+        const float p2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x2), 0x4E, 0xF, 0xF, true));
+        const float p3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x3), 0x4E, 0xF, 0xF, true));
+        const bool hi = j & 2;
+        const float n0 = hi ? p2 : x0, n1 = hi ? p3 : x1, n2 = hi ? x2 : p0, n3 = hi ? x3 : p1;
+        x0 = n0; x1 = n1; x2 = n2; x3 = n3;
+      }
+      float4* op = reinterpret_cast<float4*>(o + hf * 4);
+      float4 v = make_float4(x0, x1, x2, x3);
+      if (accum) { const float4 pv = *op; v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w; }
+#ifdef VOX_NO_STORE
+      if (v.x == 123456.f) *op = v;
+#else
+      *op = v;
+#endif
     }
   }
 }
 
-struct VxPlan { bool ok; int C, gw, dil, tiles; size_t lds; };
+struct VxPlan { bool ok; int C, td, dil, tiles; size_t lds; };
 
 static VxPlan vx_plan(const n3d_conv_geom* g) {
   VxPlan p; p.ok = false;
   if (g->depthwise || g->k != 3 || g->stride != 1 || g->Ci != g->Co || (g->Ci != 4 && g->Ci != 8)) return p;
   if (!(g->dil == 1 || g->dil == 2) || g->pad != g->dil) return p;
   const int W = g->Wi, H = g->Hi, D = g->Di;
-  int gw;
-  if (W % 64 == 0) gw = 64; else if (W == 32) gw = 32; else if (W == 16) gw = 16; else return p;
-  const int th = 4 * (64 / gw);
-  if (D % 4 != 0 || H % th != 0) return p;
-  p.ok = true; p.C = g->Ci; p.gw = gw; p.dil = g->dil;
-  p.tiles = (W / gw) * (H / th) * (D / 4);
-  p.lds = (size_t)(g->Ci / 4) * (4 + 2 * g->dil) * (th + 2 * g->dil) * (gw + 2 * g->dil) * 16;
+  if (W % 16 != 0 || H % 4 != 0) return p;
+  const int64_t groups = (int64_t)g->B * D * (H / 4) * (W / 16);
+  // tile depth: as deep as possible while keeping >= ~8 single-wave workgroups per CU
+  int td = 1;
+  if (D % 4 == 0 && groups / 4 >= 2048 && g->Ci == 4) td = 4;
+  else if (D % 2 == 0 && groups / 2 >= 2048) td = 2;
+  p.ok = true; p.C = g->Ci; p.td = td; p.dil = g->dil;
+  p.tiles = (W / 16) * (H / 4) * (D / td);
+  const int Q = g->Ci / 4;
+  p.lds = ((size_t)Q * (td + 2 * g->dil) * (4 + 2 * g->dil) * (16 + 2 * g->dil) + (size_t)27 * g->Ci * Q) * 16;
   return p;
 }
 
-template <int C, int GW, int DIL>
-static int launch_vox_t(const VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_vox64_kernel<C, GW, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((conv_vox64_kernel<C, GW, DIL>), dim3(p.tiles, B), dim3(256), p.lds, s, a);
+template <int C, int TD, int DIL>
+static int launch_vox_t(VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
+  hipLaunchKernelGGL((conv_vox64_kernel<C, TD, DIL>), dim3(p.tiles, B), dim3(64), p.lds, s, a);
   return 1;
 }
 
 template <int C>
-static int launch_vox_c(const VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
+static int launch_vox_c(VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
   if (p.dil == 1) {
-    if (p.gw == 64) return launch_vox_t<C, 64, 1>(a, p, B, s);
-    if (p.gw == 32) return launch_vox_t<C, 32, 1>(a, p, B, s);
-    return launch_vox_t<C, 16, 1>(a, p, B, s);
+    if (p.td == 4) return launch_vox_t<C, 4, 1>(a, p, B, s);
+    if (p.td == 2) return launch_vox_t<C, 2, 1>(a, p, B, s);
+    return launch_vox_t<C, 1, 1>(a, p, B, s);
   }
-  if (p.gw == 64) return launch_vox_t<C, 64, 2>(a, p, B, s);
-  if (p.gw == 32) return launch_vox_t<C, 32, 2>(a, p, B, s);
-  return launch_vox_t<C, 16, 2>(a, p, B, s);
+  if (p.td == 4) return launch_vox_t<C, 4, 2>(a, p, B, s);
+  if (p.td == 2) return launch_vox_t<C, 2, 2>(a, p, B, s);
+  return launch_vox_t<C, 1, 2>(a, p, B, s);
 }
 
 // ------------------------------------------------------------------------------------------------

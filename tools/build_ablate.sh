@@ -1,0 +1,11 @@
+#!/bin/bash
+# builds ablation variants of libn3d into tools/bin (scratch; never used by the product)
+set -e
+cd "$(dirname "$0")/.."
+SRC=nas_3d_unet_amd/csrc
+for v in base NO_STORE NO_MFMA NO_LOAD; do
+  D=""; [ $v != base ] && D="-DVOX_$v"
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast $D -shared -o tools/bin/libn3d_$v.so $SRC/n3d_core.hip $SRC/elementwise.hip $SRC/conv_generic.hip $SRC/conv_mfma.hip &
+done
+wait
+/opt/rocm/bin/hipcc -O2 tools/conv_bench.cpp -o tools/bin/conv_bench -ldl
