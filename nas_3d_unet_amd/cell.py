@@ -1,7 +1,7 @@
 """MI355X-native drop-in for the reference's ``cell`` module (cell.py:8-82): MixedOp and Cell."""
-import torch
 import torch.nn as nn
 
+from . import fused
 from .prim_ops import OPS, ConvOps, DownOps, NormOps, UpOps
 
 
@@ -18,7 +18,11 @@ class MixedOp(nn.Module):
 
     def forward(self, x, alpha1, alpha2):
         weights = alpha1 if self.stride == 1 else alpha2
-        return sum(w * op(x) for w, op in zip(weights, self._ops))
+        if getattr(self, "_segs", None) is None:
+            self._segs = [fused._single_segment(op) for op in self._ops]
+            self._plist = [p for seg in self._segs for p in seg.params()]
+        # one autograd node: every primitive's epilogue accumulates w_k * op_k(x) into the same buffer
+        return fused.MixedOpFn.apply(self._segs, x, weights, *self._plist)
 
 
 class Cell(nn.Module):
@@ -43,12 +47,9 @@ class Cell(nn.Module):
         return self.n_nodes * self.c_node
 
     def forward(self, x0, x1, alpha1, alpha2):
-        xs = [self.preprocess0(x0), self.preprocess1(x1)]
-        e = 0
-        for _ in range(self.n_nodes):
-            acc = 0
-            for x in list(xs):
-                acc = acc + self._ops[e](x, alpha1[e], alpha2[e])
-                e += 1
-            xs.append(acc)
-        return torch.cat(xs[-self.n_nodes:], dim=1)
+        """x0, x1: cell inputs; alpha1 / alpha2: full (n_edges, n_prims) weight matrices for the stride-1 /
+        stride-2 edges, both indexed by the global edge counter (cell.py:76-80).  Runs as one fused launch
+        program (fused.py); the result is the channel concat of the n_nodes node outputs."""
+        if getattr(self, "_plan", None) is None:
+            self._plan = fused.supernet_plan(self)
+        return fused.CellFn.apply(self._plan, x0, x1, alpha1, alpha2, *self._plan.params)

@@ -1,0 +1,222 @@
+"""Cell-level autograd Functions: one autograd node per MixedOp / Cell / SearchedCell.
+
+The reference builds a cell out of Python-level tensor algebra -- ``w * op(x)``, ``sum(...)``,
+``torch.cat(dim=1)`` (cell.py:29-32,76-82; searched.py:45-51) -- which costs one extra full pass
+(and one launch) per term.  Here the whole cell is one launch program:
+  * every primitive's normalise / ReLU / alpha-weight epilogue ACCUMULATES straight into its node's
+    channel slice of the cell output buffer (zero-copy concat, fused weighted sum);
+  * backward walks the DAG in reverse, data-gradient kernels accumulate into the producers'
+    gradient slices, and dalpha[e][k] = <d node, op_k(x)> falls out of the epilogue's reduction pass.
+Numerics: the accumulation order is the reference's left-to-right order.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import kernels as K
+from . import programs as P
+from ._lib import ACCUMULATE
+
+
+def _single_segment(op):
+    if op._segments is None:
+        op._segments = op._build_segments()
+    if len(op._segments) != 1:
+        raise P.N3DError("fused cells need single-segment primitives, got ops_order=%s" % "_".join(op.ops_list))
+    return op._segments[0]
+
+
+def _slice_view(buf_view, k, cn):
+    """View of channels [k*cn, (k+1)*cn) of a (B, n*cn, D, H, W) NDHWC buffer."""
+    t = buf_view.t[:, k * cn:(k + 1) * cn]
+    return K.View(t, buf_view.ld)
+
+
+def _copy_into(src, dst):
+    """dst = src through the identity epilogue kernel (both pitched views)."""
+    K.affine_act(src, None, None, None, dst, 0)
+
+
+class _Plan:
+    """Static description of a cell: edges = (node, input index, [(segment, alpha_col)], alpha matrix id, row)."""
+
+    def __init__(self, pre0, pre1, n_nodes, c_node, edges, params):
+        self.pre0, self.pre1, self.n_nodes, self.c_node, self.edges, self.params = pre0, pre1, n_nodes, c_node, edges, params
+        self.index = {id(p): i for i, p in enumerate(params)}
+
+
+def searched_plan(cell):
+    edges = []
+    for node in range(cell.n_nodes):
+        for e in (2 * node, 2 * node + 1):
+            edges.append((node, cell.genolist[e][1], [(_single_segment(cell._ops[e]), 0)], 0, e))
+    return _Plan(_single_segment(cell.preprocess0), _single_segment(cell.preprocess1), cell.n_nodes, cell.c_node, edges,
+                 list(cell.parameters()))
+
+
+def supernet_plan(cell):
+    edges = []
+    e = 0
+    for node in range(cell.n_nodes):
+        for i in range(node + 2):
+            mixed = cell._ops[e]
+            segs = [(_single_segment(op), k) for k, op in enumerate(mixed._ops)]
+            edges.append((node, i, segs, 1 if mixed.stride == 1 else 2, e))
+            e += 1
+    return _Plan(_single_segment(cell.preprocess0), _single_segment(cell.preprocess1), cell.n_nodes, cell.c_node, edges,
+                 list(cell.parameters()))
+
+
+def _run_forward(plan, x0, x1, alpha1, alpha2):
+    """Returns (cell output tensor, saved state)."""
+    st = P.Saved()
+    x0v, x1v = K.as_view(x0, "x0"), K.as_view(x1, "x1")
+    p0, st.s_pre0 = P.seg_forward(plan.pre0, x0v)
+    p1, st.s_pre1 = P.seg_forward(plan.pre1, x1v)
+    xs = [p0, p1]
+    cn, nn = plan.c_node, plan.n_nodes
+    out = None
+    started = [False] * nn
+    st.saved = []
+    for node, idx, segs, amat, row in plan.edges:
+        xin = xs[idx]
+        for seg, col in segs:
+            if out is None:
+                shp = seg.weight.out_shape(xin)
+                out = K.as_view(K.empty_ndhwc(shp[0], nn * cn, shp[2], shp[3], shp[4], xin.t.device))
+                nodes = [_slice_view(out, k, cn) for k in range(nn)]
+                xs.extend(nodes)
+            arow = None
+            if amat:
+                a = alpha1 if amat == 1 else alpha2
+                arow = a[row]
+            _, s = P.seg_forward(seg, xin, None, nodes[node], started[node], arow, col)
+            started[node] = True
+            st.saved.append(s)
+    st.xs, st.out = xs, out
+    return out.t, st
+
+
+def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha):
+    cn, nn = plan.c_node, plan.n_nodes
+    dv = K.as_view(dout, "grad_output")
+    out = st.out
+    dev = out.t.device
+    # private, writable copy of the incoming gradient: node slices receive further contributions
+    dcat = K.as_view(K.empty_ndhwc(out.B, nn * cn, out.D, out.H, out.W, dev))
+    _copy_into(dv, dcat)
+    dnodes = [_slice_view(dcat, k, cn) for k in range(nn)]
+    p0, p1 = st.xs[0], st.xs[1]
+    dpre = [K.as_view(K.empty_ndhwc(p0.B, p0.C, p0.D, p0.H, p0.W, dev)), K.as_view(K.empty_ndhwc(p1.B, p1.C, p1.D, p1.H, p1.W, dev))]
+    pre_started = [False, False]
+    grads = [None] * len(plan.params)
+    da1 = torch.zeros_like(alpha1) if (want_dalpha and alpha1 is not None) else None
+    da2 = torch.zeros_like(alpha2) if (want_dalpha and alpha2 is not None) else None
+
+    def put(seg, glist):
+        for p, g in zip(seg.params(), glist):
+            if g is not None and getattr(p, "_n3d_grad", None) is None:
+                grads[plan.index[id(p)]] = g
+
+    # reverse order over edges / primitives (saved states were appended in forward order)
+    flat = []
+    for node, idx, segs, amat, row in plan.edges:
+        for seg, col in segs:
+            flat.append((node, idx, seg, col, amat, row))
+    for (node, idx, seg, col, amat, row), s in zip(reversed(flat), reversed(st.saved)):
+        if idx >= 2:
+            target, acc = dnodes[idx - 2], True
+        else:
+            target, acc = dpre[idx], pre_started[idx]
+            pre_started[idx] = True
+        arow = dal = None
+        if amat:
+            a = alpha1 if amat == 1 else alpha2
+            arow = a[row]
+            d = da1 if amat == 1 else da2
+            dal = d[row] if d is not None else None
+        _, gl = P.seg_backward(seg, s, dnodes[node], True, target, acc, arow, col, dal)
+        put(seg, gl)
+    dx = [None, None]
+    for i, (seg, s, need) in enumerate(((plan.pre0, st.s_pre0, need_x0), (plan.pre1, st.s_pre1, need_x1))):
+        if not pre_started[i]:
+            dpre[i].t.zero_()
+        d, gl = P.seg_backward(seg, s, dpre[i], need)
+        put(seg, gl)
+        dx[i] = d
+    return dx[0], dx[1], da1, da2, grads
+
+
+class SearchedCellFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, x0, x1, *params):
+        out, st = _run_forward(plan, x0, x1, None, None)
+        ctx.plan, ctx.st = plan, st
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx0, dx1, _, _, grads = _run_backward(ctx.plan, ctx.st, dout, None, None, ctx.needs_input_grad[1],
+                                              ctx.needs_input_grad[2], False)
+        ctx.st = None
+        return (None, dx0, dx1) + tuple(g if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(grads))
+
+
+class CellFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, x0, x1, alpha1, alpha2, *params):
+        a1 = alpha1.detach().contiguous()
+        a2 = alpha2.detach().contiguous()
+        out, st = _run_forward(plan, x0, x1, a1, a2)
+        ctx.plan, ctx.st, ctx.a1, ctx.a2 = plan, st, a1, a2
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        want = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        dx0, dx1, da1, da2, grads = _run_backward(ctx.plan, ctx.st, dout, ctx.a1, ctx.a2, ctx.needs_input_grad[1],
+                                                  ctx.needs_input_grad[2], want)
+        ctx.st = None
+        return (None, dx0, dx1, da1 if ctx.needs_input_grad[3] else None, da2 if ctx.needs_input_grad[4] else None) + \
+            tuple(g if ctx.needs_input_grad[5 + i] else None for i, g in enumerate(grads))
+
+
+class MixedOpFn(torch.autograd.Function):
+    """sum_k w_k * op_k(x) for one edge (cell.py:24-33) as a single autograd node."""
+
+    @staticmethod
+    def forward(ctx, segs, x, weights, *params):
+        xv = K.as_view(x, "input")
+        w = weights.detach().contiguous()
+        out = None
+        saved = []
+        for k, seg in enumerate(segs):
+            if out is None:
+                shp = seg.weight.out_shape(xv)
+                out = K.as_view(K.empty_ndhwc(*shp, xv.t.device))
+            _, s = P.seg_forward(seg, xv, None, out, k > 0, w, k)
+            saved.append(s)
+        ctx.segs, ctx.saved, ctx.w, ctx.xv = segs, saved, w, xv
+        plist = []
+        for seg in segs:
+            plist += seg.params()
+        ctx.index = {id(p): i for i, p in enumerate(plist)}
+        ctx.nparams = len(plist)
+        return out.t
+
+    @staticmethod
+    def backward(ctx, dout):
+        dv = K.as_view(dout, "grad_output")
+        xv = ctx.xv
+        need_dx = ctx.needs_input_grad[1]
+        dx = K.as_view(K.empty_ndhwc(xv.B, xv.C, xv.D, xv.H, xv.W, xv.t.device)) if need_dx else None
+        dalpha = torch.zeros_like(ctx.w) if ctx.needs_input_grad[2] else None
+        grads = [None] * ctx.nparams
+        for k, (seg, s) in enumerate(zip(ctx.segs, ctx.saved)):
+            _, gl = P.seg_backward(seg, s, dv, need_dx, dx, k > 0, ctx.w, k, dalpha)
+            for p, g in zip(seg.params(), gl):
+                if g is not None and getattr(p, "_n3d_grad", None) is None:
+                    grads[ctx.index[id(p)]] = g
+        ctx.saved = None
+        return (None, dx.t if need_dx else None, dalpha) + tuple(g if ctx.needs_input_grad[3 + i] else None
+                                                                   for i, g in enumerate(grads))

@@ -1,7 +1,7 @@
 """Searched network (build-side counterpart of the reference's searched.py:10-111)."""
-import torch
 import torch.nn as nn
 
+from . import fused
 from .genotype import Genotype  # noqa: F401  (re-exported like the reference module does)
 from .prim_ops import OPS, ConvOps
 
@@ -23,11 +23,11 @@ class SearchedCell(nn.Module):
         return self.n_nodes * self.c_node
 
     def forward(self, x0, x1):
-        xs = [self.preprocess0(x0), self.preprocess1(x1)]
-        for node in range(self.n_nodes):
-            a, b = 2 * node, 2 * node + 1
-            xs.append(0 + self._ops[a](xs[self.genolist[a][1]]) + self._ops[b](xs[self.genolist[b][1]]))
-        return torch.cat(xs[-self.n_nodes:], dim=1)
+        """node k = op[2k](xs[i]) + op[2k+1](xs[j]); output = concat of the nodes -- as one fused launch
+        program: the second op's epilogue accumulates into the first one's slice of the output buffer."""
+        if getattr(self, "_plan", None) is None:
+            self._plan = fused.searched_plan(self)
+        return fused.SearchedCellFn.apply(self._plan, x0, x1, *self._plan.params)
 
 
 class SearchedNet(nn.Module):
