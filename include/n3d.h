@@ -43,6 +43,7 @@ extern "C" {
 #define N3D_ACCUMULATE 4  /* destination += result instead of = result */
 #define N3D_POOL_MAX 8    /* pooling type (prim_ops.py:160-163) */
 #define N3D_NO_MFMA 16    /* force the generic VALU kernels (A/B testing) */
+#define N3D_PREPACKED 32  /* `ws` already holds this conv's packed weights (written by n3d_pack_batch) */
 
 /* Geometry of a (possibly strided / dilated) 3-D convolution, torch Conv3d semantics:
  * o = floor((i + 2*pad - dil*(k-1) - 1)/stride) + 1.  "i side" is what the window slides over.
@@ -74,6 +75,26 @@ int n3d_conv_stats_rows(const n3d_conv_geom* g, int transposed, int flags);
 /* rows per sample written by n3d_channel_stats / n3d_affine_act_bwd_reduce for N voxels, C channels */
 int n3d_stats_rows(int64_t N, int C);
 
+/* Batched weight packing: the conv kernels read weights from a kernel-friendly packed copy.  By default each
+ * conv call packs into its workspace (one tiny extra launch); a trainer instead packs ALL weights of the net
+ * with one launch per step (n3d_pack_batch) and passes N3D_PREPACKED + the packed slot as `ws`.
+ * n3d_conv_pack_info: layout id / padded channel count / float count of the packed form that the kernel
+ * selected for (geometry, forward or data-gradient) expects. */
+typedef struct n3d_pack_job {
+  const float* w; float* dst;
+  int32_t Co, Ci, taps, data_grad, layout, cdp;
+} n3d_pack_job;
+int n3d_conv_pack_info(const n3d_conv_geom* g, int data_grad, int flags, int32_t* layout, int32_t* cdp, int64_t* floats);
+int n3d_pack_batch(const n3d_pack_job* jobs /* host array */, int njobs, void* stream);
+
+/* Deferred weight-gradient reduction: n3d_conv(T)_bwd_weight leave their partial slabs in `ws` and describe the
+ * remaining fixed-order reduction in *deferred; n3d_wgrad_finalize_batch then finishes many convs in one launch. */
+typedef struct n3d_final_job {
+  const float* partial; const float* pbias; float* dw; float* dbias;
+  int32_t nchunks, ntiles, tci, tco, ci_t, co_t, Co, Ci, taps, pad_;
+} n3d_final_job;
+int n3d_wgrad_finalize_batch(const n3d_final_job* jobs /* host array */, int njobs, void* stream);
+
 /* y[o side] = conv(x[i side]) + bias */
 int n3d_conv_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias,
                  float* y, int64_t yld, int flags, const float* in_gate, double* stats,
@@ -86,7 +107,7 @@ int n3d_conv_bwd_data(const n3d_conv_geom* g, const float* dy, int64_t dyld, con
 /* dw (native layout) = sum x * dy, dbias = sum dy (either may be NULL) */
 int n3d_conv_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld,
                         float* dw, float* dbias, int flags, const float* in_gate,
-                        void* ws, size_t ws_bytes, void* stream);
+                        void* ws, size_t ws_bytes, n3d_final_job* deferred /* NULL: finish now */, void* stream);
 /* transposed convolution y[i side] = convT(x[o side]) + bias; same kernels with the roles swapped */
 int n3d_convT_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias,
                   float* y, int64_t yld, int flags, const float* in_gate, double* stats,
@@ -94,7 +115,8 @@ int n3d_convT_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const flo
 int n3d_convT_bwd_data(const n3d_conv_geom* g, const float* dy, int64_t dyld, const float* w,
                        float* dx, int64_t dxld, int flags, void* ws, size_t ws_bytes, void* stream);
 int n3d_convT_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld,
-                         float* dw, float* dbias, int flags, void* ws, size_t ws_bytes, void* stream);
+                         float* dw, float* dbias, int flags, void* ws, size_t ws_bytes,
+                         n3d_final_job* deferred /* NULL: finish now */, void* stream);
 
 /* ---- per-(sample,channel) statistics and the normalise / activate / weighted-sum epilogue ----------
  * n3d_channel_stats: stats[b][row][c] = partial (sum x, sum x^2) over the N voxels (GroupNorm of a tensor
@@ -113,10 +135,13 @@ int n3d_affine_act(const float* raw, int64_t rld, const float* a, const float* b
 int n3d_affine_act_bwd_reduce(const float* dout, int64_t dld, const float* raw, int64_t rld, const float* a,
                               const float* b, int B, int64_t N, int C, int flags, double* sums, void* stream);
 /* GroupNorm backward coefficients: dgamma, dbeta (summed over b), dalpha = sum Sz (if not NULL),
- * and the per-(b,c) affine draw = A*g + Bc + Cc*raw.  wptr: the MixedOp weight (NULL -> 1). */
+ * and the per-(b,c) affine draw = A*g + Bc + Cc*raw.  wptr: the MixedOp weight (NULL -> 1).
+ * If dbias_conv != NULL (needs the forward statistics rows fstats/frows of the same raw tensor) it also
+ * writes the gradient of the bias of the conv that produced raw:  sum_v draw = A*S1 + N*Bc + Cc*sum(raw). */
 int n3d_gn_bwd_coeffs(const double* sums, int rows, const float* gamma, const float* mean_rstd,
                       const float* wptr, int B, int C, int G, int64_t N, float* dgamma, float* dbeta,
-                      float* dalpha, float* A, float* Bc, float* Cc, void* stream);
+                      float* dalpha, float* A, float* Bc, float* Cc, const double* fstats, int frows,
+                      float* dbias_conv, void* stream);
 /* plain (no norm) epilogue backward coefficients: A = w, Bc = Cc = 0, dalpha = sum Sz */
 int n3d_plain_bwd_coeffs(const double* sums, int rows, const float* wptr, int B, int C, float* dalpha,
                          float* A, void* stream);

@@ -26,6 +26,17 @@ class ConvGeom(C.Structure):
                 ("B", "Di", "Hi", "Wi", "Ci", "Do", "Ho", "Wo", "Co", "k", "stride", "dil", "pad", "depthwise")]
 
 
+class PackJob(C.Structure):
+    """n3d_pack_job (include/n3d.h)"""
+    _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p)] + [(n, C.c_int32) for n in ("Co", "Ci", "taps", "data_grad", "layout", "cdp")]
+
+
+class FinalJob(C.Structure):
+    """n3d_final_job (include/n3d.h)"""
+    _fields_ = [("partial", C.c_void_p), ("pbias", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("nchunks", "ntiles", "tci", "tco", "ci_t", "co_t", "Co", "Ci", "taps", "pad_")]
+
+
 _p = C.c_void_p
 _i = C.c_int
 _i64 = C.c_int64
@@ -44,15 +55,18 @@ PROTOTYPES = {
     "n3d_stats_rows": (_i, [_i64, _i]),
     "n3d_conv_fwd": (_i, [_gp, _p, _i64, _p, _p, _p, _i64, _i, _p, _p, _p, _sz, _p]),
     "n3d_conv_bwd_data": (_i, [_gp, _p, _i64, _p, _p, _i64, _i, _p, _i64, _p, _p, _sz, _p]),
-    "n3d_conv_bwd_weight": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i, _p, _p, _sz, _p]),
+    "n3d_conv_bwd_weight": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i, _p, _p, _sz, C.POINTER(FinalJob), _p]),
+    "n3d_conv_pack_info": (_i, [_gp, _i, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "n3d_pack_batch": (_i, [C.POINTER(PackJob), _i, _p]),
+    "n3d_wgrad_finalize_batch": (_i, [C.POINTER(FinalJob), _i, _p]),
     "n3d_convT_fwd": (_i, [_gp, _p, _i64, _p, _p, _p, _i64, _i, _p, _p, _p, _sz, _p]),
     "n3d_convT_bwd_data": (_i, [_gp, _p, _i64, _p, _p, _i64, _i, _p, _sz, _p]),
-    "n3d_convT_bwd_weight": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i, _p, _sz, _p]),
+    "n3d_convT_bwd_weight": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i, _p, _sz, C.POINTER(FinalJob), _p]),
     "n3d_channel_stats": (_i, [_p, _i64, _i, _i64, _i, _p, _p]),
     "n3d_gn_coeffs": (_i, [_p, _i, _p, _p, _i, _i, _i, _i64, _f, _p, _p, _p, _p]),
     "n3d_affine_act": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i, _i64, _i, _i, _p]),
     "n3d_affine_act_bwd_reduce": (_i, [_p, _i64, _p, _i64, _p, _p, _i, _i64, _i, _i, _p, _p]),
-    "n3d_gn_bwd_coeffs": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p, _p]),
+    "n3d_gn_bwd_coeffs": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
     "n3d_plain_bwd_coeffs": (_i, [_p, _i, _p, _i, _i, _p, _p, _p]),
     "n3d_affine_act_bwd_apply": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i, _i64, _i, _i, _p]),
     "n3d_se_gate_fwd": (_i, [_p, _i, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),
@@ -68,7 +82,7 @@ PROTOTYPES = {
 }
 
 # flags (include/n3d.h)
-RELU_IN, RELU, ACCUMULATE, POOL_MAX, NO_MFMA = 1, 2, 4, 8, 16
+RELU_IN, RELU, ACCUMULATE, POOL_MAX, NO_MFMA, PREPACKED = 1, 2, 4, 8, 16, 32
 
 _lib = None
 

@@ -482,6 +482,70 @@ __global__ void channel_sum_final_kernel(const float* __restrict__ partial, int 
   out[c] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// batched weight packing / batched weight-gradient reduction: jobs travel BY VALUE in the kernel
+// arguments (graph-capturable, no device-side table to maintain); blockIdx.y selects the job.
+// layouts: 0 generic [tap][cs][cdp]; 1 gemm16 [tap][cs/16][kk][cd][j]; 2 vox64 [tap][cd][cs] (flipped for data grad)
+// ------------------------------------------------------------------------------------------------
+#define N3D_PACK_JOBS 64
+#define N3D_FINAL_JOBS 40
+struct PackJobs { n3d_pack_job j[N3D_PACK_JOBS]; };
+struct FinalJobs { n3d_final_job j[N3D_FINAL_JOBS]; };
+
+__global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
+  const n3d_pack_job jb = jobs.j[blockIdx.y];
+  const int Co = jb.Co, Ci = jb.Ci, taps = jb.taps;
+  const int Cs = jb.data_grad ? Co : Ci, Cd = jb.data_grad ? Ci : Co;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (jb.layout == 0) {
+    const int Cdp = jb.cdp;
+    if (i >= taps * Cs * Cdp) return;
+    const int cd = i % Cdp, cs = (i / Cdp) % Cs, tap = i / (Cdp * Cs);
+    float v = 0.f;
+    if (cd < Cd) {
+      const int co = jb.data_grad ? cs : cd, ci = jb.data_grad ? cd : cs;
+      v = jb.w[((int64_t)co * Ci + ci) * taps + tap];
+    }
+    jb.dst[i] = v;
+  } else if (jb.layout == 1) {
+    if (i >= taps * Cs * Cd) return;
+    const int j = i & 3, cd = (i >> 2) % Cd, rest = (i >> 2) / Cd;
+    const int kk = rest & 3, c16 = (rest >> 2) % (Cs / 16), tap = (rest >> 2) / (Cs / 16);
+    const int cs = c16 * 16 + kk * 4 + j;
+    const int co = jb.data_grad ? cs : cd, ci = jb.data_grad ? cd : cs;
+    jb.dst[i] = jb.w[((int64_t)co * Ci + ci) * taps + tap];
+  } else {
+    const int C = Co;
+    if (i >= 27 * C * C) return;
+    const int cs = i % C, cd = (i / C) % C, tap = i / (C * C);
+    const int co = jb.data_grad ? cs : cd, ci = jb.data_grad ? cd : cs, t2 = jb.data_grad ? 26 - tap : tap;
+    jb.dst[i] = jb.w[((int64_t)co * C + ci) * 27 + t2];
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_final_batch_kernel(FinalJobs jobs) {
+  const n3d_final_job jb = jobs.j[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int nw = jb.Co * jb.Ci * jb.taps;
+  const int T = jb.ci_t * jb.co_t;
+  if (i < nw) {
+    if (jb.dw) {
+      const int tap = i % jb.taps, ci = (i / jb.taps) % jb.Ci, co = i / (jb.taps * jb.Ci);
+      const int tile = (tap * jb.tci + ci / jb.ci_t) * jb.tco + co / jb.co_t;
+      const int q = (ci % jb.ci_t) * jb.co_t + (co % jb.co_t);
+      float s = 0.f;
+      for (int c = 0; c < jb.nchunks; ++c) s += jb.partial[((int64_t)c * jb.ntiles + tile) * T + q];
+      jb.dw[i] = s;
+    }
+  } else if (i < nw + jb.Co && jb.dbias) {
+    const int co = i - nw;
+    float s = 0.f;
+    for (int c = 0; c < jb.nchunks; ++c) s += jb.pbias[((int64_t)c * jb.tco + co / jb.co_t) * jb.co_t + co % jb.co_t];
+    jb.dbias[co] = s;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side launch helpers shared with the C ABI
 // ------------------------------------------------------------------------------------------------
@@ -557,6 +621,7 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
                   int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate, double* stats,
                   void* ws, size_t ws_bytes, hipStream_t s);
 int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags);
+int mfma_pack_layout(const n3d_conv_geom* g, bool data_grad, int flags);  // 1 gemm16, 2 vox64, 0 none
 int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                    float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s);
 }
@@ -634,7 +699,8 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
   float* wp = (float*)ws;
   a.wp = wp;
   const int total = taps * a.Cs * a.Cdp;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g->Co, g->Ci, taps, a.Cdp, data_grad ? 1 : 0);
+  if (!(flags & N3D_PREPACKED))
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g->Co, g->Ci, taps, a.Cdp, data_grad ? 1 : 0);
   launch_gather(a, g->B, s);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
@@ -669,8 +735,15 @@ int n3d_convT_bwd_data(const n3d_conv_geom* g, const float* dy, int64_t dyld, co
   return run_gather(g, false, dy, dyld, w, nullptr, dx, dxld, flags & ~N3D_RELU_IN, nullptr, nullptr, 0, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
+static void fill_job(n3d_final_job* j, const float* partial, const float* pbias, float* dw, float* dbias, int nch, int ntl, int tci, int tco,
+                     int ci_t, int co_t, int Co, int Ci, int taps) {
+  j->partial = partial; j->pbias = pbias; j->dw = dw; j->dbias = dbias; j->nchunks = nch; j->ntiles = ntl; j->tci = tci; j->tco = tco;
+  j->ci_t = ci_t; j->co_t = co_t; j->Co = Co; j->Ci = Ci; j->taps = taps; j->pad_ = 0;
+}
+
 static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, float* dw, float* dbias, int flags,
-                     const float* in_gate, void* ws, size_t ws_bytes, void* stream, bool transposed) {
+                     const float* in_gate, void* ws, size_t ws_bytes, void* stream, bool transposed, n3d_final_job* deferred) {
+  if (deferred) deferred->nchunks = 0;  // 0 = nothing deferred
   hipStream_t s = (hipStream_t)stream;
   const int taps = g->k * g->k * g->k;
   const int64_t No = (int64_t)g->Do * g->Ho * g->Wo;
@@ -706,8 +779,12 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     if (g->Ci % 16 == 0 && g->Co % 16 == 0 && (1024 + nt16) * (256 + 16) <= avail &&
         mfma_wgrad_try(g, x, xld, dy, dyld, flags, in_gate, wsf, pb, (1024 + nt16) * 256, &nch, &ntl, s) == 1) {
       const int nout = g->Co * g->Ci * taps + g->Co;
-      hipLaunchKernelGGL(conv_wgrad_final_kernel, dim3((unsigned)cdiv(nout, 256)), dim3(256), 0, s, wsf, pb, nch, ntl, g->Ci / 16, g->Co / 16,
-                         16, 16, g->Co, g->Ci, taps, dw, transposed ? nullptr : dbias);
+      if (deferred) {
+        fill_job(deferred, wsf, pb, dw, transposed ? nullptr : dbias, nch, ntl, g->Ci / 16, g->Co / 16, 16, 16, g->Co, g->Ci, taps);
+      } else {
+        hipLaunchKernelGGL(conv_wgrad_final_kernel, dim3((unsigned)cdiv(nout, 256)), dim3(256), 0, s, wsf, pb, nch, ntl, g->Ci / 16,
+                           g->Co / 16, 16, 16, g->Co, g->Ci, taps, dw, transposed ? nullptr : dbias);
+      }
       N3D_LAUNCH_CHECK();
       return N3D_OK;
     }
@@ -727,29 +804,86 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   else if (p.ci_t == 4 && p.co_t == 8) launch_wgrad_t<4, 8>(a, p, s);
   else launch_wgrad_t<4, 4>(a, p, s);
   const int nout = g->Co * g->Ci * taps + g->Co;
-  hipLaunchKernelGGL(conv_wgrad_final_kernel, dim3((unsigned)cdiv(nout, 256)), dim3(256), 0, s, a.partial, a.pbias, p.nchunks, p.ntiles, p.tci,
-                     p.tco, p.ci_t, p.co_t, g->Co, g->Ci, taps, dw, transposed ? nullptr : dbias);
+  if (deferred) {
+    fill_job(deferred, a.partial, a.pbias, dw, transposed ? nullptr : dbias, p.nchunks, p.ntiles, p.tci, p.tco, p.ci_t, p.co_t, g->Co, g->Ci, taps);
+  } else {
+    hipLaunchKernelGGL(conv_wgrad_final_kernel, dim3((unsigned)cdiv(nout, 256)), dim3(256), 0, s, a.partial, a.pbias, p.nchunks, p.ntiles,
+                       p.tci, p.tco, p.ci_t, p.co_t, g->Co, g->Ci, taps, dw, transposed ? nullptr : dbias);
+  }
   N3D_LAUNCH_CHECK();
-  (void)transposed;
   return N3D_OK;
 }
 
 int n3d_conv_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, float* dw, float* dbias, int flags,
-                        const float* in_gate, void* ws, size_t ws_bytes, void* stream) {
+                        const float* in_gate, void* ws, size_t ws_bytes, n3d_final_job* deferred, void* stream) {
   if (int e = check_geom(g, "conv_bwd_weight")) return e;
   N3D_CHECK_ARG(x && dy && (dw || dbias), "conv_bwd_weight: bad pointers");
-  return run_wgrad(g, x, xld, dy, dyld, dw, dbias, flags, in_gate, ws, ws_bytes, stream, false);
+  return run_wgrad(g, x, xld, dy, dyld, dw, dbias, flags, in_gate, ws, ws_bytes, stream, false, deferred);
+}
+
+int n3d_conv_pack_info(const n3d_conv_geom* g, int data_grad, int flags, int32_t* layout, int32_t* cdp, int64_t* floats) {
+  if (int e = check_geom(g, "conv_pack_info")) return e;
+  N3D_CHECK_ARG(layout && cdp && floats, "conv_pack_info: null outputs");
+  const int taps = g->k * g->k * g->k;
+  const int Cs = data_grad ? g->Co : g->Ci, Cd = data_grad ? g->Ci : g->Co;
+  if (g->depthwise) { *layout = -1; *cdp = 0; *floats = 0; return N3D_OK; }  // depthwise kernels read native weights
+  const int ml = mfma_pack_layout(g, data_grad != 0, flags);
+  if (ml == 2) { *layout = 2; *cdp = Cd; *floats = (int64_t)27 * Cd * Cs; return N3D_OK; }
+  if (ml == 1) { *layout = 1; *cdp = Cd; *floats = (int64_t)taps * Cs * Cd; return N3D_OK; }
+  const int cot = pick_cot(Cd);
+  *layout = 0; *cdp = (int)align_up(Cd, cot); *floats = (int64_t)taps * Cs * (*cdp);
+  return N3D_OK;
+}
+
+int n3d_pack_batch(const n3d_pack_job* jobs, int njobs, void* stream) {
+  N3D_CHECK_ARG(jobs && njobs >= 0, "pack_batch: bad args");
+  for (int base = 0; base < njobs; base += N3D_PACK_JOBS) {
+    const int n = njobs - base < N3D_PACK_JOBS ? njobs - base : N3D_PACK_JOBS;
+    PackJobs pj;
+    int maxel = 0;
+    for (int i = 0; i < n; ++i) {
+      pj.j[i] = jobs[base + i];
+      const n3d_pack_job& q = pj.j[i];
+      const int Cs = q.data_grad ? q.Co : q.Ci, Cd = q.data_grad ? q.Ci : q.Co;
+      const int el = q.layout == 0 ? q.taps * Cs * q.cdp : (q.layout == 1 ? q.taps * Cs * Cd : 27 * q.Co * q.Co);
+      if (el > maxel) maxel = el;
+    }
+    for (int i = n; i < N3D_PACK_JOBS; ++i) pj.j[i] = pj.j[0];
+    hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)cdiv(maxel, 256), n), dim3(256), 0, (hipStream_t)stream, pj);
+  }
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_wgrad_finalize_batch(const n3d_final_job* jobs, int njobs, void* stream) {
+  N3D_CHECK_ARG(jobs && njobs >= 0, "wgrad_finalize_batch: bad args");
+  for (int base = 0; base < njobs; base += N3D_FINAL_JOBS) {
+    const int n = njobs - base < N3D_FINAL_JOBS ? njobs - base : N3D_FINAL_JOBS;
+    FinalJobs fj;
+    int maxel = 0;
+    for (int i = 0; i < n; ++i) {
+      fj.j[i] = jobs[base + i];
+      const int el = fj.j[i].Co * fj.j[i].Ci * fj.j[i].taps + fj.j[i].Co;
+      if (el > maxel) maxel = el;
+    }
+    for (int i = n; i < N3D_FINAL_JOBS; ++i) fj.j[i] = fj.j[0];
+    hipLaunchKernelGGL(wgrad_final_batch_kernel, dim3((unsigned)cdiv(maxel, 256), n), dim3(256), 0, (hipStream_t)stream, fj);
+  }
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
 }
 
 
 int n3d_convT_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, float* dw, float* dbias, int flags,
-                         void* ws, size_t ws_bytes, void* stream) {
+                         void* ws, size_t ws_bytes, n3d_final_job* deferred, void* stream) {
   if (int e = check_geom(g, "convT_bwd_weight")) return e;
   N3D_CHECK_ARG(x && dy && (dw || dbias) && xld >= g->Co && dyld >= g->Ci, "convT_bwd_weight: bad pointers/pitches");
   // kernel roles: i-side tensor = dy (Ci channels), o-side tensor = x (Co channels); see run_wgrad
   if (dw) {
-    int e = run_wgrad(g, dy, dyld, x, xld, dw, nullptr, flags & ~N3D_RELU_IN, nullptr, ws, ws_bytes, stream, true);
+    int e = run_wgrad(g, dy, dyld, x, xld, dw, nullptr, flags & ~N3D_RELU_IN, nullptr, ws, ws_bytes, stream, true, deferred);
     if (e) return e;
+  } else if (deferred) {
+    deferred->nchunks = 0;
   }
   if (dbias) {
     // bias gradient = per-channel sum of dy over the i side

@@ -81,40 +81,32 @@ __global__ __launch_bounds__(256, 2) void conv_gemm16_kernel(MfArgs a) {
   const bool relu_in = a.flags & N3D_RELU_IN;
   const float4* __restrict__ wp4 = reinterpret_cast<const float4*>(a.wp);
 
-  int cur_tap = -1;
-  const float* sp[MT];
-  bool sok[MT];
-  for (int g = (KSPLIT == 4 ? wave : 0); g < ngroups; g += (KSPLIT == 4 ? 4 : 1)) {
+  // K loop, software-pipelined by hand: the operands of group g+step are requested before the MFMAs of group g
+  // issue, so each wave keeps one group of global loads in flight behind its matrix work.
+  auto load_group = [&](int g, float4 (&av)[MT], float4 (&bv)[NT]) {
     const int tap = g / c16n, c16 = g - tap * c16n;
-    if (tap != cur_tap) {
-      cur_tap = tap;
-      const int kw = tap % k, kh = (tap / k) % k, kd = tap / (k * k);
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        int nd = rd[t] * a.sn + a.off + kd * a.dt, nh = rh[t] * a.sn + a.off + kh * a.dt, nw = rw[t] * a.sn + a.off + kw * a.dt;
-        bool ok = rvalid[t];
-        if (a.den == 2) { ok = ok && !((nd | nh | nw) & 1); nd >>= 1; nh >>= 1; nw >>= 1; }
-        ok = ok && nd >= 0 && nd < a.Ds && nh >= 0 && nh < a.Hs && nw >= 0 && nw < a.Ws;
-        sok[t] = ok;
-        sp[t] = a.src + ((int64_t)rb[t] * Ns + ((int64_t)nd * a.Hs + nh) * a.Ws + nw) * a.sld + kk * 4;
-      }
-    }
-    float4 av[MT];
+    const int kw = tap % k, kh = (tap / k) % k, kd = tap / (k * k);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      av[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (sok[t]) {
-        av[t] = *reinterpret_cast<const float4*>(sp[t] + c16 * 16);
-        if (relu_in) { av[t].x = fmaxf(av[t].x, 0.f); av[t].y = fmaxf(av[t].y, 0.f); av[t].z = fmaxf(av[t].z, 0.f); av[t].w = fmaxf(av[t].w, 0.f); }
-        if (a.in_gate) {
-          const float4 gq = *reinterpret_cast<const float4*>(a.in_gate + (int64_t)rb[t] * a.Cs + c16 * 16 + kk * 4);
-          av[t].x *= gq.x; av[t].y *= gq.y; av[t].z *= gq.z; av[t].w *= gq.w;
-        }
+      int nd = rd[t] * a.sn + a.off + kd * a.dt, nh = rh[t] * a.sn + a.off + kh * a.dt, nw = rw[t] * a.sn + a.off + kw * a.dt;
+      bool ok = rvalid[t];
+      if (a.den == 2) { ok = ok && !((nd | nh | nw) & 1); nd >>= 1; nh >>= 1; nw >>= 1; }
+      ok = ok && nd >= 0 && nd < a.Ds && nh >= 0 && nh < a.Hs && nw >= 0 && nw < a.Ws;
+      // clamped address + select instead of a branch: the load is always issued
+      const int cd_ = min(max(nd, 0), a.Ds - 1), ch_ = min(max(nh, 0), a.Hs - 1), cw_ = min(max(nw, 0), a.Ws - 1);
+      const float* sp = a.src + ((int64_t)rb[t] * Ns + ((int64_t)cd_ * a.Hs + ch_) * a.Ws + cw_) * a.sld + kk * 4 + c16 * 16;
+      float4 v = *reinterpret_cast<const float4*>(sp);
+      if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (a.in_gate) {
+        const float4 gq = *reinterpret_cast<const float4*>(a.in_gate + (int64_t)rb[t] * a.Cs + c16 * 16 + kk * 4);
+        v.x *= gq.x; v.y *= gq.y; v.z *= gq.z; v.w *= gq.w;
       }
+      av[t] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float4 bv[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) bv[n] = wp4[((int64_t)g * 4 + kk) * a.Cd + n0 + n * 16 + m];
+  };
+  auto mfma_group = [&](const float4 (&av)[MT], const float4 (&bv)[NT]) {
     // two accumulator chains per tile (x,z / y,w): a dependent 16x16x4 MFMA has 40 cycles latency vs 32 issue
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -130,6 +122,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm16_kernel(MfArgs a) {
         acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].z, bv[n].z, acc[t][n], 0, 0, 0);
         acc2[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].w, bv[n].w, acc2[t][n], 0, 0, 0);
       }
+  };
+  {
+    const int g0 = (KSPLIT == 4 ? wave : 0), step = (KSPLIT == 4 ? 4 : 1);
+    float4 avA[MT], bvA[NT], avB[MT], bvB[NT];
+    if (g0 < ngroups) load_group(g0, avA, bvA);
+    for (int g = g0; g < ngroups; g += 2 * step) {
+      const bool hasB = g + step < ngroups;
+      if (hasB) load_group(g + step, avB, bvB);
+      mfma_group(avA, bvA);
+      if (g + 2 * step < ngroups) load_group(g + 2 * step, avA, bvA);
+      if (hasB) mfma_group(avB, bvB);
+    }
   }
 #pragma unroll
   for (int t = 0; t < MT; ++t)
@@ -562,6 +566,13 @@ static G16Plan g16_plan(const n3d_conv_geom* g, bool data_grad) {
   return p;
 }
 
+int mfma_pack_layout(const n3d_conv_geom* g, bool data_grad, int flags) {
+  if (flags & N3D_NO_MFMA) return 0;
+  if (vx_plan(g).ok) return 2;
+  if (g16_plan(g, data_grad).ok) return 1;
+  return 0;
+}
+
 int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags) {
   if (flags & N3D_NO_MFMA) return 0;
   {
@@ -590,13 +601,14 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
     VxPlan v = vx_plan(g);
     if (v.ok) {
       if (in_gate || relu_src || out_gate || (flags & N3D_RELU_IN) || sld % 4 != 0 || dld % 4 != 0 || !aligned16(src) || !aligned16(dst)) {
-        if (stats) { set_error("conv(vox64): unsupported extras with statistics"); return N3D_ERR_UNSUPPORTED; }
+        if (stats || (flags & N3D_PREPACKED)) { set_error("conv(vox64): gate / relu extras are not supported on this shape with statistics or pre-packed weights"); return N3D_ERR_UNSUPPORTED; }
         return 0;
       }
       const size_t need = (size_t)27 * v.C * v.C * 4;
       if (!ws || ws_bytes < need) { set_error("conv(vox64): workspace too small"); return N3D_ERR_WORKSPACE; }
       float* wq = (float*)ws;
-      hipLaunchKernelGGL(pack_vox_kernel, dim3((unsigned)cdiv(27 * v.C * v.C, 256)), dim3(256), 0, s, w, wq, v.C, data_grad ? 1 : 0);
+      if (!(flags & N3D_PREPACKED))
+        hipLaunchKernelGGL(pack_vox_kernel, dim3((unsigned)cdiv(27 * v.C * v.C, 256)), dim3(256), 0, s, w, wq, v.C, data_grad ? 1 : 0);
       VxArgs a;
       a.src = src; a.sld = sld; a.dst = dst; a.dld = dld; a.wq = wq; a.bias = bias; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.flags = flags;
       a.stats = stats; a.rows_per_sample = v.tiles;
@@ -608,7 +620,10 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
   }
   G16Plan p = g16_plan(g, data_grad);
   if (!p.ok) return 0;
-  if (sld % 4 != 0 || !aligned16(src)) return 0;
+  if (sld % 4 != 0 || !aligned16(src)) {
+    if (flags & N3D_PREPACKED) { set_error("conv(gemm16): misaligned source with pre-packed weights"); return N3D_ERR_UNSUPPORTED; }
+    return 0;
+  }
   const int taps = g->k * g->k * g->k;
   MfArgs a;
   a.src = src; a.sld = sld; a.dst = dst; a.dld = dld; a.bias = bias; a.k = g->k; a.flags = flags; a.B = g->B;
@@ -627,7 +642,8 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
   float* wp = (float*)ws;
   a.wp = wp;
   const int total = taps * a.Cs * a.Cd;
-  hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g->Co, g->Ci, taps, data_grad ? 1 : 0);
+  if (!(flags & N3D_PREPACKED))
+    hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g->Co, g->Ci, taps, data_grad ? 1 : 0);
   const int64_t M = (int64_t)g->B * Nd;
   if (p.ksplit == 4) launch_g16<1, 1, 4>(a, M, s);
   else if (p.nt == 2) launch_g16<2, 2, 1>(a, M, s);

@@ -206,16 +206,19 @@ __global__ __launch_bounds__(256) void gn_bwd_coeffs_kernel(const double* __rest
                                                             const float* __restrict__ mean_rstd, const float* __restrict__ wptr, int B,
                                                             int C, int G, double count, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ dalpha, float* __restrict__ A,
-                                                            float* __restrict__ Bc, float* __restrict__ Cc) {
+                                                            float* __restrict__ Bc, float* __restrict__ Cc,
+                                                            const double* __restrict__ fstats, int frows, float* __restrict__ dbias_conv) {
   __shared__ double part[256];
   __shared__ double tot[192];
+  __shared__ double ftot[128];
   __shared__ double gc[64 * 2];
   __shared__ double zred[64];
   const int t = threadIdx.x;
   const int cg = C / G;
   const double w = wptr ? (double)*wptr : 1.0;
-  double dg = 0, db = 0, dz = 0;
+  double dg = 0, db = 0, dz = 0, dbc = 0;
   for (int b = 0; b < B; ++b) {
+    if (dbias_conv) reduce_rows(fstats + (int64_t)b * frows * C * 2, frows, C * 2, part, ftot);
     reduce_rows(sums + (int64_t)b * rows * C * 3, rows, C * 3, part, tot);
     if (t < G) {
       const double mean = mean_rstd[(b * G + t) * 2], rstd = mean_rstd[(b * G + t) * 2 + 1];
@@ -237,15 +240,18 @@ __global__ __launch_bounds__(256) void gn_bwd_coeffs_kernel(const double* __rest
       db += w * S1;
       dz += Sz;
       const double c1 = gc[g * 2], c2 = gc[g * 2 + 1];
-      A[b * C + t] = (float)(rstd * (double)gamma[t] * w);
-      Bc[b * C + t] = (float)(-rstd * c1 + rstd * rstd * c2 * mean);
-      Cc[b * C + t] = (float)(-rstd * rstd * c2);
+      const double Av = rstd * (double)gamma[t] * w, Bv = -rstd * c1 + rstd * rstd * c2 * mean, Cv = -rstd * rstd * c2;
+      A[b * C + t] = (float)Av;
+      Bc[b * C + t] = (float)Bv;
+      Cc[b * C + t] = (float)Cv;
+      if (dbias_conv) dbc += Av * S1 + count * Bv + Cv * ftot[t * 2];
     }
     __syncthreads();
   }
   if (t < C) {
     if (dgamma) dgamma[t] = (float)dg;
     if (dbeta) dbeta[t] = (float)db;
+    if (dbias_conv) dbias_conv[t] = (float)dbc;
   }
   if (dalpha) {
     if (t < 64) zred[t] = (t < C) ? dz : 0.0;
@@ -675,10 +681,12 @@ int n3d_affine_act_bwd_reduce(const float* dout, int64_t dld, const float* raw, 
 }
 
 int n3d_gn_bwd_coeffs(const double* sums, int rows, const float* gamma, const float* mean_rstd, const float* wptr, int B, int C, int G,
-                      int64_t N, float* dgamma, float* dbeta, float* dalpha, float* A, float* Bc, float* Cc, void* stream) {
+                      int64_t N, float* dgamma, float* dbeta, float* dalpha, float* A, float* Bc, float* Cc, const double* fstats, int frows,
+                      float* dbias_conv, void* stream) {
   N3D_CHECK_ARG(sums && gamma && mean_rstd && A && Bc && Cc && C <= 64 && C % G == 0, "gn_bwd_coeffs: bad args");
+  N3D_CHECK_ARG(!dbias_conv || (fstats && frows >= 1), "gn_bwd_coeffs: dbias_conv needs the forward statistics rows");
   hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, rows, gamma, mean_rstd, wptr, B, C, G, (double)N,
-                     dgamma, dbeta, dalpha, A, Bc, Cc);
+                     dgamma, dbeta, dalpha, A, Bc, Cc, fstats, frows, dbias_conv);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

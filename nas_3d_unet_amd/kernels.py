@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACCUMULATE, POOL_MAX, RELU, RELU_IN, ConvGeom, N3DError, check
+from ._lib import ACCUMULATE, POOL_MAX, PREPACKED, RELU, RELU_IN, ConvGeom, FinalJob, N3DError, PackJob, check
 
 __all__ = ["View", "as_view", "empty_ndhwc", "stream_ptr", "conv_geom", "ptr"]
 
@@ -107,6 +107,92 @@ def _ws(g, device):
     return torch.empty(max(int(n), 256), dtype=torch.uint8, device=device), int(n)
 
 
+class StepContext:
+    """Per-trainer launch batching (no reference counterpart; removes ~225 tiny launches per step):
+      * every conv weight of the net is packed into its kernel layout by ONE n3d_pack_batch launch at the
+        start of a step (first pass records the jobs, later passes hand the packed slot to the conv call);
+      * the fixed-order reductions of all weight-gradient partial slabs run as ONE n3d_wgrad_finalize_batch
+        launch at the end of backward."""
+
+    def __init__(self, device):
+        self.device = device
+        self.pending = {}      # key -> (weight, Co, Ci, taps, data_grad, layout, cdp, floats)
+        self.slots = {}        # key -> (ptr, bytes)
+        self.frozen = False
+        self.buf = None
+        self.jobs = None
+        self.final = []
+        self.keep = []
+
+    # ---- weight packing
+    def slot(self, w, g, data_grad, flags):
+        lay, cdp, fl = C.c_int32(), C.c_int32(), C.c_int64()
+        check(_lib.load().n3d_conv_pack_info(C.byref(g), 1 if data_grad else 0, flags, C.byref(lay), C.byref(cdp), C.byref(fl)),
+              "n3d_conv_pack_info")
+        if lay.value < 0:
+            return None
+        key = (w.data_ptr(), bool(data_grad), lay.value, cdp.value)
+        if key in self.slots:
+            return self.slots[key]
+        if not self.frozen:
+            self.pending[key] = (w, g.Co, g.Ci, g.k ** 3, 1 if data_grad else 0, lay.value, cdp.value, fl.value)
+        return None
+
+    def freeze(self):
+        total = sum((v[7] + 63) // 64 * 64 for v in self.pending.values())
+        self.buf = torch.empty(max(total, 64), dtype=torch.float32, device=self.device)
+        arr = (PackJob * max(len(self.pending), 1))()
+        off = 0
+        for i, (key, (w, Co, Ci, taps, dg, lay, cdp, fl)) in enumerate(self.pending.items()):
+            dst = self.buf.data_ptr() + off * 4
+            arr[i] = PackJob(w.data_ptr(), dst, Co, Ci, taps, dg, lay, cdp)
+            self.slots[key] = (dst, fl * 4)
+            off += (fl + 63) // 64 * 64
+        self.jobs, self.njobs = arr, len(self.pending)
+        self.frozen = True
+
+    def pack_all(self):
+        if self.frozen and self.njobs:
+            check(_lib.load().n3d_pack_batch(self.jobs, self.njobs, stream_ptr()), "n3d_pack_batch")
+
+    # ---- deferred weight-gradient reductions
+    def flush_final(self):
+        if self.final:
+            arr = (FinalJob * len(self.final))(*self.final)
+            check(_lib.load().n3d_wgrad_finalize_batch(arr, len(self.final), stream_ptr()), "n3d_wgrad_finalize_batch")
+        self.final, self.keep = [], []
+
+
+_ctx = None
+
+
+class step_context:
+    """with step_context(ctx): conv calls use ctx's packed-weight slots and defer their wgrad reductions."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        global _ctx
+        self.prev, _ctx = _ctx, self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        global _ctx
+        _ctx = self.prev
+        return False
+
+
+def _packed(w, g, data_grad, flags, device):
+    """(ws tensor or None, ws ptr, ws bytes, flags) for a forward / data-gradient conv call."""
+    if _ctx is not None:
+        sl = _ctx.slot(w, g, data_grad, flags)
+        if sl is not None:
+            return None, C.c_void_p(sl[0]), sl[1], flags | PREPACKED
+    ws, n = _ws(g, device)
+    return ws, ptr(ws), n, flags
+
+
 # ------------------------------------------------------------------------------------------ convs
 def conv_stats_rows(g, transposed, flags=0):
     return int(_lib.load().n3d_conv_stats_rows(C.byref(g), 1 if transposed else 0, flags))
@@ -117,38 +203,43 @@ def stats_rows(N, Cc):
 
 
 def conv_fwd(g, x: View, w, bias, y: View, flags=0, in_gate=None, stats=None, transposed=False):
-    ws, n = _ws(g, x.t.device)
+    ws, wsp, n, flags = _packed(w, g, transposed, flags, x.t.device)
     fn = _lib.load().n3d_convT_fwd if transposed else _lib.load().n3d_conv_fwd
-    check(fn(C.byref(g), x.p, x.ld, ptr(w), ptr(bias), y.p, y.ld, flags, ptr(in_gate), ptr(stats), ptr(ws), n,
+    check(fn(C.byref(g), x.p, x.ld, ptr(w), ptr(bias), y.p, y.ld, flags, ptr(in_gate), ptr(stats), wsp, n,
              stream_ptr()), "n3d_convT_fwd" if transposed else "n3d_conv_fwd")
 
 
 def conv_bwd_data(g, dy: View, w, dx: View, flags=0, relu_src: View | None = None, out_gate=None, transposed=False):
-    ws, n = _ws(g, dy.t.device)
+    ws, wsp, n, flags = _packed(w, g, not transposed, flags, dy.t.device)
     lib = _lib.load()
     if transposed:
         if relu_src is not None or out_gate is not None:
             raise N3DError("convT_bwd_data: relu/gate epilogue not supported")
-        check(lib.n3d_convT_bwd_data(C.byref(g), dy.p, dy.ld, ptr(w), dx.p, dx.ld, flags, ptr(ws), n, stream_ptr()),
+        check(lib.n3d_convT_bwd_data(C.byref(g), dy.p, dy.ld, ptr(w), dx.p, dx.ld, flags, wsp, n, stream_ptr()),
               "n3d_convT_bwd_data")
     else:
         check(lib.n3d_conv_bwd_data(C.byref(g), dy.p, dy.ld, ptr(w), dx.p, dx.ld, flags,
                                     relu_src.p if relu_src is not None else None,
-                                    relu_src.ld if relu_src is not None else 0, ptr(out_gate), ptr(ws), n,
+                                    relu_src.ld if relu_src is not None else 0, ptr(out_gate), wsp, n,
                                     stream_ptr()), "n3d_conv_bwd_data")
 
 
 def conv_bwd_weight(g, x: View, dy: View, dw, dbias, flags=0, in_gate=None, transposed=False):
     ws, n = _ws(g, x.t.device)
     lib = _lib.load()
+    job = FinalJob() if (_ctx is not None and not g.depthwise) else None
+    jp = C.byref(job) if job is not None else None
     if transposed:
         if in_gate is not None:
             raise N3DError("convT_bwd_weight: gate not supported")
-        check(lib.n3d_convT_bwd_weight(C.byref(g), x.p, x.ld, dy.p, dy.ld, ptr(dw), ptr(dbias), flags, ptr(ws), n,
+        check(lib.n3d_convT_bwd_weight(C.byref(g), x.p, x.ld, dy.p, dy.ld, ptr(dw), ptr(dbias), flags, ptr(ws), n, jp,
                                        stream_ptr()), "n3d_convT_bwd_weight")
     else:
         check(lib.n3d_conv_bwd_weight(C.byref(g), x.p, x.ld, dy.p, dy.ld, ptr(dw), ptr(dbias), flags, ptr(in_gate),
-                                      ptr(ws), n, stream_ptr()), "n3d_conv_bwd_weight")
+                                      ptr(ws), n, jp, stream_ptr()), "n3d_conv_bwd_weight")
+    if job is not None and job.nchunks > 0:
+        _ctx.final.append(job)
+        _ctx.keep.append(ws)  # the partial slabs live in ws until StepContext.flush_final()
 
 
 # ------------------------------------------------------------------------------------------ epilogue
@@ -192,17 +283,19 @@ def grad_target(p):
     return t if t is not None else torch.empty_like(p)
 
 
-def gn_bwd_coeffs(sums, rows, gamma, mean_rstd, wptr, B, Cc, G, N, dalpha_ptr=None, beta=None):
+def gn_bwd_coeffs(sums, rows, gamma, mean_rstd, wptr, B, Cc, G, N, dalpha_ptr=None, beta=None, fstats=None, frows=0,
+                  conv_bias=None):
     dev = sums.device
     dgamma = grad_target(gamma) if isinstance(gamma, torch.nn.Parameter) else torch.empty((Cc,), dtype=torch.float32, device=dev)
     dbeta = grad_target(beta) if isinstance(beta, torch.nn.Parameter) else torch.empty((Cc,), dtype=torch.float32, device=dev)
     A = torch.empty((B, Cc), dtype=torch.float32, device=dev)
     Bc = torch.empty((B, Cc), dtype=torch.float32, device=dev)
     Cc_ = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+    dcb = grad_target(conv_bias) if (conv_bias is not None and fstats is not None) else None
     check(_lib.load().n3d_gn_bwd_coeffs(ptr(sums), rows, ptr(gamma), ptr(mean_rstd), wptr, B, Cc, G, N, ptr(dgamma),
-                                        ptr(dbeta), dalpha_ptr, ptr(A), ptr(Bc), ptr(Cc_), stream_ptr()),
-          "n3d_gn_bwd_coeffs")
-    return dgamma, dbeta, A, Bc, Cc_
+                                        ptr(dbeta), dalpha_ptr, ptr(A), ptr(Bc), ptr(Cc_), ptr(fstats), frows, ptr(dcb),
+                                        stream_ptr()), "n3d_gn_bwd_coeffs")
+    return dgamma, dbeta, A, Bc, Cc_, dcb
 
 
 def plain_bwd_coeffs(sums, rows, wptr, B, Cc, device, dalpha_ptr=None, want_A=True):

@@ -37,6 +37,11 @@ class WeightProgram:
     def params(self):
         return []
 
+    def norm_fed_bias(self):
+        """bias Parameter of the conv whose output is the segment's raw tensor (its gradient can then be
+        derived from the GroupNorm backward sums instead of a reduction over the tensor), or None"""
+        return None
+
     def out_shape(self, x):
         raise NotImplementedError
 
@@ -52,7 +57,7 @@ class IdentityW(WeightProgram):
             raise N3DError("identity weight op with act-before-weight / dropout is not supported")
         return x, None, 0, None
 
-    def bwd(self, saved, draw, need_dx, dx_out, dx_acc):
+    def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
         if not need_dx:
             return None, []
         if dx_out is None:
@@ -81,7 +86,7 @@ class PoolW(WeightProgram):
         s.x = x
         return y, None, 0, s
 
-    def bwd(self, saved, draw, need_dx, dx_out, dx_acc):
+    def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
         if not need_dx:
             return None, []
         x = saved.x
@@ -124,6 +129,9 @@ class DenseConvW(WeightProgram):
     def params(self):
         return [self.m.weight, self.m.bias]
 
+    def norm_fed_bias(self):
+        return self.m.bias
+
     def geom(self, x):
         w = self.m.weight
         if self.transposed:
@@ -162,11 +170,11 @@ class DenseConvW(WeightProgram):
         s.x, s.g, s.relu_in, s.gate = x, g, relu_in, gate
         return y, stats, rows, s
 
-    def bwd(self, saved, draw, need_dx, dx_out, dx_acc):
+    def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
         x, g = saved.x, saved.g
         w = self.m.weight
         dw = K.grad_target(w)
-        db = K.grad_target(self.m.bias)
+        db = None if skip_bias else K.grad_target(self.m.bias)
         if dw is not None or db is not None:
             K.conv_bwd_weight(g, x, draw, dw, db, RELU_IN if saved.relu_in else 0, saved.gate, self.transposed)
         dx = None
@@ -196,6 +204,9 @@ class DepthSepW(WeightProgram):
 
     def params(self):
         return [self.dm.weight, self.dm.bias, self.pm.weight, self.pm.bias]
+
+    def norm_fed_bias(self):
+        return self.pm.bias
 
     def dgeom(self, x):
         c = x.C
@@ -233,11 +244,11 @@ class DepthSepW(WeightProgram):
         s.x, s.mid, s.gd, s.gp = x, mid, gd, gp
         return y, stats, rows, s
 
-    def bwd(self, saved, draw, need_dx, dx_out, dx_acc):
+    def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
         x, mid, gd, gp = saved.x, saved.mid, saved.gd, saved.gp
         pw, pb, dwt, dbs = self.pm.weight, self.pm.bias, self.dm.weight, self.dm.bias
         g_pw = K.grad_target(pw)
-        g_pb = K.grad_target(pb)
+        g_pb = None if skip_bias else K.grad_target(pb)
         if g_pw is not None or g_pb is not None:
             K.conv_bwd_weight(gp, mid, draw, g_pw, g_pb, 0, None, False)
         dmid = K.as_view(K.empty_ndhwc(mid.B, mid.C, mid.D, mid.H, mid.W, x.t.device))
@@ -289,6 +300,9 @@ class SEConvW(WeightProgram):
     def params(self):
         return self.gate.params() + self.conv.params()
 
+    def norm_fed_bias(self):
+        return self.conv.m.bias
+
     def out_shape(self, x):
         return self.conv.out_shape(x)
 
@@ -303,9 +317,9 @@ class SEConvW(WeightProgram):
         s.x, s.mean, s.hidden, s.gate, s.cs = x, mean, hidden, g, cs
         return y, stats, rows, s
 
-    def bwd(self, saved, draw, need_dx, dx_out, dx_acc):
+    def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
         x = saved.x
-        du_t, cg = self.conv.bwd(saved.cs, draw, True, None, False)
+        du_t, cg = self.conv.bwd(saved.cs, draw, True, None, False, skip_bias)
         du = K.as_view(du_t)
         sums, rows = K.affine_act_bwd_reduce(du, x, None, None, 0)
         fc = self.gate.fc
@@ -367,6 +381,7 @@ def seg_forward(seg, x, drop_gate=None, out=None, accumulate=False, alpha_row=No
         G = group_count(cn)
         s.a, s.b, s.mr = K.gn_coeffs(stats, rows, seg.norm.weight, seg.norm.bias, raw.B, cn, G, raw.N, seg.norm.eps)
         s.kind, s.G = "gn", G
+        s.fstats, s.frows = stats, rows
     elif seg.se_gate is not None:
         s.mean, s.hidden, s.a = seg.se_gate.fwd(raw)
         s.kind = "se"
@@ -392,8 +407,11 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
     extra = []
     if s.kind == "gn":
         sums, rows = K.affine_act_bwd_reduce(dout, raw, s.a, s.b, fl)
-        dgamma, dbeta, A, Bc, Cc = K.gn_bwd_coeffs(sums, rows, seg.norm.weight, s.mr, wp, raw.B, raw.C, s.G, raw.N, dap,
-                                                   seg.norm.bias)
+        cbias = seg.weight.norm_fed_bias()
+        if cbias is not None and not cbias.requires_grad:
+            cbias = None
+        dgamma, dbeta, A, Bc, Cc, dcb = K.gn_bwd_coeffs(sums, rows, seg.norm.weight, s.mr, wp, raw.B, raw.C, s.G, raw.N, dap,
+                                                        seg.norm.bias, s.fstats, s.frows, cbias)
         if isinstance(seg.weight, IdentityW) and need_dx:
             # the raw tensor is the input itself: write dx directly
             if dx_out is None:
@@ -403,7 +421,15 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
             return dx_out.t, [dgamma, dbeta]
         draw = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
         K.affine_act_bwd_apply(dout, raw, s.a, s.b, A, Bc, Cc, draw, fl)
-        extra = [dgamma, dbeta]
+        dx, wg = seg.weight.bwd(s.ws, draw, need_dx, dx_out, dx_acc, dcb is not None)
+        wg = list(wg)
+        if dcb is not None:
+            # the conv bias gradient came out of the GroupNorm backward sums: put it in the bias slot
+            plist = seg.weight.params()
+            for i, p in enumerate(plist):
+                if p is cbias:
+                    wg[i] = dcb
+        return dx, wg + [dgamma, dbeta]
     elif s.kind == "se":
         sums, rows = K.affine_act_bwd_reduce(dout, raw, s.a, None, 0)
         fc = seg.se_gate.fc

@@ -72,14 +72,20 @@ class Trainer:
         self._graph = None
         self._static_x = self._static_t = self._static_loss = None
         self._comm_stream = torch.cuda.Stream(device=self.device) if self.world > 1 else None
+        self.ctx = K.StepContext(self.device)  # batched weight packing + deferred wgrad reductions
         if self.world > 1:
             dist.broadcast(self.fp.flat, src=0, group=self.pg)
 
     # -- pieces ---------------------------------------------------------------------------------
     def _fwd_bwd(self, x, t):
-        p = self.model(x)
-        loss = self.loss_fn(p, t)
-        loss.backward()
+        with K.step_context(self.ctx):
+            self.ctx.pack_all()            # one launch packs every conv weight for this step
+            p = self.model(x)
+            loss = self.loss_fn(p, t)
+            loss.backward()
+            self.ctx.flush_final()         # one launch finishes every weight-gradient reduction
+        if not self.ctx.frozen:
+            self.ctx.freeze()              # first pass only recorded which weights / layouts are needed
         return loss.detach()
 
     def _allreduce(self):

@@ -1,0 +1,29 @@
+"""GPU: the trainer's batched mechanics (flat parameters + in-place gradients, one-launch weight
+packing, deferred weight-gradient reductions, fused Adam, HIP-graph replay) must reproduce the
+reference's training trajectory: losses of 3 Adam steps vs the golden vectors (torch.optim.Adam on
+the reference modules) and vs the same net stepped eagerly with torch.optim.Adam."""
+import numpy as np
+import pytest
+import torch
+
+import golden_common as gc
+from test_gpu_nets import build_net
+from _util import dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("key,kind,gname,depth,size,batch,adam", [c for c in gc.net_cases() if c[6] and c[1] == "searched"])
+def test_trainer_matches_reference_adam(golden, graph, key, kind, gname, depth, size, batch, adam):
+    from nas_3d_unet_amd.train import Trainer
+    g = golden("nets")
+    net, head = build_net(kind, gname, depth)
+    xn, tn = gc.net_batch(key, batch, size)
+    x, t = dev(xn), dev(tn)
+    tr = Trainer(net, graph=graph)
+    losses = [float(tr.step(x, t)) for _ in range(adam)]
+    np.testing.assert_allclose(losses, g[key + "/adam_losses"], rtol=0, atol=2e-4)
+    for n, q in net.named_parameters():
+        ref = float(g[key + "/adam%d/pnorm/%s" % (adam, n)])
+        assert abs(float(q.detach().double().norm()) - ref) <= 5e-4 * max(ref, 1e-3), n
