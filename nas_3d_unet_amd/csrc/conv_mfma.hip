@@ -46,7 +46,7 @@ __global__ void pack16_kernel(const float* __restrict__ w, float* __restrict__ w
 }
 
 template <int MT, int NT, int KSPLIT>
-__global__ __launch_bounds__(256, 2) void conv_gemm16_kernel(MfArgs a) {
+__global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) void conv_gemm16_kernel(MfArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, kk = lane >> 4;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm16_kernel(MfArgs a) {
       }
   };
   {
-    const int g0 = (KSPLIT == 4 ? wave : 0), step = (KSPLIT == 4 ? 4 : 1);
+    const int g0 = (KSPLIT > 1 ? wave : 0), step = (KSPLIT > 1 ? KSPLIT : 1);
     float4 avA[MT], bvA[NT], avB[MT], bvB[NT];
     if (g0 < ngroups) load_group(g0, avA, bvA);
     for (int g = g0; g < ngroups; g += 2 * step) {
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm16_kernel(MfArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[t][n] += acc2[t][n];
 
-  if (KSPLIT == 4) {
-    // reduce the four K-slices through LDS into wave 0
+  if (KSPLIT > 1) {
+    // reduce the K-slices through LDS into wave 0
     f32x4* l4 = reinterpret_cast<f32x4*>(lds);
     if (wave > 0) {
 #pragma unroll
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm16_kernel(MfArgs a) {
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-      for (int w = 0; w < 3; ++w)
+      for (int w = 0; w < KSPLIT - 1; ++w)
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm16_kernel(MfArgs a) {
   }
   if (a.stats) {
     // all rows of a block belong to one sample (host guarantees Nd % ROWS_PER_BLOCK == 0)
-    double* red = reinterpret_cast<double*>(lds + (KSPLIT == 4 ? 3 * MT * NT * 256 : 0));
-    if (KSPLIT == 4) __syncthreads();
+    double* red = reinterpret_cast<double*>(lds + (KSPLIT > 1 ? (KSPLIT - 1) * MT * NT * 256 : 0));
+    if (KSPLIT > 1) __syncthreads();
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       double s = csum[n], q = csq[n];
@@ -560,7 +560,8 @@ static G16Plan g16_plan(const n3d_conv_geom* g, bool data_grad) {
   const int64_t Nd = data_grad ? (int64_t)g->Di * g->Hi * g->Wi : (int64_t)g->Do * g->Ho * g->Wo;
   const int64_t M = (int64_t)g->B * Nd;
   const int64_t tiles = cdiv(M, 16) * (Cd / 16);
-  if (tiles <= 1024) { p.mt = 1; p.nt = 1; p.ksplit = 4; p.rows_per_block = 16; }
+  if (tiles <= 256) { p.mt = 1; p.nt = 1; p.ksplit = 16; p.rows_per_block = 16; }
+  else if (tiles <= 1024) { p.mt = 1; p.nt = 1; p.ksplit = 4; p.rows_per_block = 16; }
   else { p.mt = 2; p.nt = (Cd % 32 == 0) ? 2 : 1; p.ksplit = 1; p.rows_per_block = 128; }
   p.ok = true;
   return p;
@@ -590,8 +591,8 @@ template <int MT, int NT, int KS>
 static void launch_g16(const MfArgs& a, int64_t M, hipStream_t s) {
   constexpr int RPB = 16 * MT * (KS == 1 ? 4 : 1);
   dim3 grid((unsigned)cdiv(M, RPB), (unsigned)(a.Cd / (16 * NT)));
-  size_t shm = (KS == 4 ? (size_t)3 * MT * NT * 256 * sizeof(float) : 0) + (size_t)4 * NT * 16 * 2 * sizeof(double);
-  hipLaunchKernelGGL((conv_gemm16_kernel<MT, NT, KS>), grid, dim3(256), shm, s, a);
+  size_t shm = (KS > 1 ? (size_t)(KS - 1) * MT * NT * 256 * sizeof(float) : 0) + (size_t)16 * NT * 16 * 2 * sizeof(double);
+  hipLaunchKernelGGL((conv_gemm16_kernel<MT, NT, KS>), grid, dim3(KS == 16 ? 1024 : 256), shm, s, a);
 }
 
 int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
@@ -645,7 +646,8 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
   if (!(flags & N3D_PREPACKED))
     hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g->Co, g->Ci, taps, data_grad ? 1 : 0);
   const int64_t M = (int64_t)g->B * Nd;
-  if (p.ksplit == 4) launch_g16<1, 1, 4>(a, M, s);
+  if (p.ksplit == 16) launch_g16<1, 1, 16>(a, M, s);
+  else if (p.ksplit == 4) launch_g16<1, 1, 4>(a, M, s);
   else if (p.nt == 2) launch_g16<2, 2, 1>(a, M, s);
   else launch_g16<2, 1, 1>(a, M, s);
   hipError_t e = hipGetLastError();

@@ -96,8 +96,9 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(const double* __restrict
   __shared__ double tot[192];
   __shared__ double mr[64 * 2];
   const int b = blockIdx.x;
-  reduce_rows(stats + (int64_t)b * rows * C * 2, rows, C * 2, part, tot);
   const int t = threadIdx.x;
+  const float gam_t = (t < C) ? gamma[t] : 0.f, bet_t = (t < C) ? beta[t] : 0.f;  // issued before the row loads
+  reduce_rows(stats + (int64_t)b * rows * C * 2, rows, C * 2, part, tot);
   const int cg = C / G;
   if (t < G) {
     double s = 0, ss = 0;
@@ -114,9 +115,9 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(const double* __restrict
   if (t < C) {
     const int g = t / cg;
     const float rstd = (float)mr[g * 2 + 1], mean = (float)mr[g * 2];
-    const float av = gamma[t] * rstd;
+    const float av = gam_t * rstd;
     a[b * C + t] = av;
-    bb[b * C + t] = beta[t] - mean * av;
+    bb[b * C + t] = bet_t - mean * av;
   }
 }
 
@@ -201,66 +202,93 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(const float* __r
   block_reduce_to_row<3>(vals, m.cpb, row, lds);
 }
 
-// GroupNorm backward coefficients; one block, loops over samples (B is small)
-__global__ __launch_bounds__(256) void gn_bwd_coeffs_kernel(const double* __restrict__ sums, int rows, const float* __restrict__ gamma,
+// GroupNorm backward coefficients.  One workgroup of 256*BP threads: thread (bl = tid/256, t = tid%256) works on
+// sample b = b0 + bl, so up to BP = 4 samples go through the dependent-load chain (rows -> group sums ->
+// coefficients) side by side instead of one after the other; per-channel sums over samples meet in LDS.
+#define GNB_BP 4
+__device__ __forceinline__ void reduce_rows_b(const double* __restrict__ rows, int nrows, int ncol, double* lds_part /*[256]*/,
+                                              double* lds_out /*[ncol]*/, int t, bool active) {
+  const int nrl = 256 / ncol > 0 ? 256 / ncol : 1;
+  const int q = t % ncol, rl = t / ncol;
+  double s = 0;
+  if (active && rl < nrl)
+    for (int r = rl; r < nrows; r += nrl) s += rows[(int64_t)r * ncol + q];
+  lds_part[t] = s;
+  __syncthreads();
+  if (t < ncol) {
+    double a = 0;
+    for (int r = 0; r < nrl; ++r) a += lds_part[r * ncol + t];
+    lds_out[t] = a;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffs_kernel(const double* __restrict__ sums, int rows, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_rstd, const float* __restrict__ wptr, int B,
                                                             int C, int G, double count, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ dalpha, float* __restrict__ A,
                                                             float* __restrict__ Bc, float* __restrict__ Cc,
                                                             const double* __restrict__ fstats, int frows, float* __restrict__ dbias_conv) {
-  __shared__ double part[256];
-  __shared__ double tot[192];
-  __shared__ double ftot[128];
-  __shared__ double gc[64 * 2];
-  __shared__ double zred[64];
-  const int t = threadIdx.x;
+  __shared__ double part[GNB_BP][256];
+  __shared__ double tot[GNB_BP][192];
+  __shared__ double ftot[GNB_BP][128];
+  __shared__ double gc[GNB_BP][64 * 2];
+  __shared__ double acc4[GNB_BP][4][64];  // per-sample dgamma, dbeta, dz, dbias contributions
+  const int bl = threadIdx.x >> 8, t = threadIdx.x & 255;
   const int cg = C / G;
   const double w = wptr ? (double)*wptr : 1.0;
+  // independent loads first: they overlap the row reductions
+  const double gam = (t < C) ? (double)gamma[t] : 0.0;
   double dg = 0, db = 0, dz = 0, dbc = 0;
-  for (int b = 0; b < B; ++b) {
-    if (dbias_conv) reduce_rows(fstats + (int64_t)b * frows * C * 2, frows, C * 2, part, ftot);
-    reduce_rows(sums + (int64_t)b * rows * C * 3, rows, C * 3, part, tot);
+  for (int b0 = 0; b0 < B; b0 += GNB_BP) {
+    const int b = b0 + bl;
+    const bool act = b < B;
+    const int bb = act ? b : B - 1;
+    const int gq = (t < C) ? t / cg : 0;
+    const double mean_c = mean_rstd[(bb * G + gq) * 2], rstd_c = mean_rstd[(bb * G + gq) * 2 + 1];
+    if (dbias_conv) reduce_rows_b(fstats + (int64_t)bb * frows * C * 2, frows, C * 2, part[bl], ftot[bl], t, act);
+    reduce_rows_b(sums + (int64_t)bb * rows * C * 3, rows, C * 3, part[bl], tot[bl], t, act);
     if (t < G) {
-      const double mean = mean_rstd[(b * G + t) * 2], rstd = mean_rstd[(b * G + t) * 2 + 1];
+      const double mean = mean_rstd[(bb * G + t) * 2], rstd = mean_rstd[(bb * G + t) * 2 + 1];
       double c1 = 0, c2 = 0;
       for (int c = t * cg; c < (t + 1) * cg; ++c) {
-        const double S1 = tot[c * 3], S2 = tot[c * 3 + 1];
-        c1 += (double)gamma[c] * w * S1;
-        c2 += (double)gamma[c] * w * rstd * (S2 - mean * S1);
+        const double S1 = tot[bl][c * 3], S2 = tot[bl][c * 3 + 1];
+        const double gm = (double)gamma[c];
+        c1 += gm * w * S1;
+        c2 += gm * w * rstd * (S2 - mean * S1);
       }
       const double n = count * cg;
-      gc[t * 2] = c1 / n; gc[t * 2 + 1] = c2 / n;
+      gc[bl][t * 2] = c1 / n; gc[bl][t * 2 + 1] = c2 / n;
     }
     __syncthreads();
-    if (t < C) {
-      const int g = t / cg;
-      const double mean = mean_rstd[(b * G + g) * 2], rstd = mean_rstd[(b * G + g) * 2 + 1];
-      const double S1 = tot[t * 3], S2 = tot[t * 3 + 1], Sz = tot[t * 3 + 2];
-      dg += w * rstd * (S2 - mean * S1);
+    if (t < C && act) {
+      const double S1 = tot[bl][t * 3], S2 = tot[bl][t * 3 + 1], Sz = tot[bl][t * 3 + 2];
+      dg += w * rstd_c * (S2 - mean_c * S1);
       db += w * S1;
       dz += Sz;
-      const double c1 = gc[g * 2], c2 = gc[g * 2 + 1];
-      const double Av = rstd * (double)gamma[t] * w, Bv = -rstd * c1 + rstd * rstd * c2 * mean, Cv = -rstd * rstd * c2;
+      const double c1 = gc[bl][gq * 2], c2 = gc[bl][gq * 2 + 1];
+      const double Av = rstd_c * gam * w, Bv = -rstd_c * c1 + rstd_c * rstd_c * c2 * mean_c, Cv = -rstd_c * rstd_c * c2;
       A[b * C + t] = (float)Av;
       Bc[b * C + t] = (float)Bv;
       Cc[b * C + t] = (float)Cv;
-      if (dbias_conv) dbc += Av * S1 + count * Bv + Cv * ftot[t * 2];
+      if (dbias_conv) dbc += Av * S1 + count * Bv + Cv * ftot[bl][t * 2];
     }
     __syncthreads();
   }
-  if (t < C) {
-    if (dgamma) dgamma[t] = (float)dg;
-    if (dbeta) dbeta[t] = (float)db;
-    if (dbias_conv) dbias_conv[t] = (float)dbc;
+  if (t < 64) { acc4[bl][0][t] = (t < C) ? dg : 0.0; acc4[bl][1][t] = (t < C) ? db : 0.0; acc4[bl][2][t] = (t < C) ? dz : 0.0; acc4[bl][3][t] = (t < C) ? dbc : 0.0; }
+  __syncthreads();
+  if (bl == 0 && t < C) {
+    double a0 = 0, a1 = 0, a3 = 0;
+    for (int k = 0; k < GNB_BP; ++k) { a0 += acc4[k][0][t]; a1 += acc4[k][1][t]; a3 += acc4[k][3][t]; }
+    if (dgamma) dgamma[t] = (float)a0;
+    if (dbeta) dbeta[t] = (float)a1;
+    if (dbias_conv) dbias_conv[t] = (float)a3;
   }
-  if (dalpha) {
-    if (t < 64) zred[t] = (t < C) ? dz : 0.0;
-    __syncthreads();
-    if (t == 0) {
-      double s = 0;
-      for (int i = 0; i < 64; ++i) s += zred[i];
-      *dalpha = (float)s;
-    }
+  if (dalpha && threadIdx.x == 0) {
+    double sdz = 0;
+    for (int k = 0; k < GNB_BP; ++k)
+      for (int i = 0; i < 64; ++i) sdz += acc4[k][2][i];
+    *dalpha = (float)sdz;
   }
 }
 
@@ -685,8 +713,8 @@ int n3d_gn_bwd_coeffs(const double* sums, int rows, const float* gamma, const fl
                       float* dbias_conv, void* stream) {
   N3D_CHECK_ARG(sums && gamma && mean_rstd && A && Bc && Cc && C <= 64 && C % G == 0, "gn_bwd_coeffs: bad args");
   N3D_CHECK_ARG(!dbias_conv || (fstats && frows >= 1), "gn_bwd_coeffs: dbias_conv needs the forward statistics rows");
-  hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, rows, gamma, mean_rstd, wptr, B, C, G, (double)N,
-                     dgamma, dbeta, dalpha, A, Bc, Cc, fstats, frows, dbias_conv);
+  hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(1), dim3(256 * GNB_BP), 0, (hipStream_t)stream, sums, rows, gamma, mean_rstd, wptr, B, C, G,
+                     (double)N, dgamma, dbeta, dalpha, A, Bc, Cc, fstats, frows, dbias_conv);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

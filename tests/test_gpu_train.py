@@ -26,4 +26,6 @@ def test_trainer_matches_reference_adam(golden, graph, key, kind, gname, depth, 
     np.testing.assert_allclose(losses, g[key + "/adam_losses"], rtol=0, atol=2e-4)
     for n, q in net.named_parameters():
         ref = float(g[key + "/adam%d/pnorm/%s" % (adam, n)])
-        assert abs(float(q.detach().double().norm()) - ref) <= 5e-4 * max(ref, 1e-3), n
+        # Adam moves every element by ~lr per step whatever the gradient's size, so an element whose gradient is
+        # fp32 noise (e.g. a conv bias ahead of a GroupNorm) may legitimately end up to adam*lr away
+        assert abs(float(q.detach().double().norm()) - ref) <= 5e-4 * ref + adam * 1e-3, n
