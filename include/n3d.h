@@ -124,24 +124,39 @@ int n3d_convT_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, co
 int n3d_channel_stats(const float* x, int64_t ld, int B, int64_t N, int C, double* stats, void* stream);
 /* GroupNorm(G, C) statistics -> per-(b,c) affine y = a*x + b; mean_rstd[b][g] = (mean, rstd) (prim_ops.py:56-58) */
 int n3d_gn_coeffs(const double* stats, int rows, const float* gamma, const float* beta, int B, int C, int G,
-                  int64_t N, float eps, float* a, float* b, float* mean_rstd, void* stream);
+                  int64_t N, float eps, float* a, float* b, float* mean_rstd, double* sumraw /* [B][C] or NULL */,
+                  void* stream);
 /* out (+)= w * act(a[b,c]*raw + b[b,c]);  a,b NULL -> identity affine; wptr NULL -> 1.
  * This is GroupNorm-apply + ReLU (prim_ops.py:75-80) fused with the MixedOp weighting and the node
  * sum (cell.py:29-32,81; searched.py:50). */
 int n3d_affine_act(const float* raw, int64_t rld, const float* a, const float* b, const float* wptr,
                    float* out, int64_t old_, int B, int64_t N, int C, int flags, void* stream);
+/* Fused form for small tensors (rows <= n3d_fused_max_rows()): the GroupNorm coefficients are computed from the
+ * statistics rows in every workgroup's prologue (no separate n3d_gn_coeffs launch); a / b / mean_rstd are also
+ * stored for the backward pass. */
+int n3d_fused_max_rows(void);
+int n3d_affine_act_gn(const float* raw, int64_t rld, const double* stats, int rows, const float* gamma,
+                      const float* beta, int G, float eps, const float* wptr, float* out, int64_t old_, int B,
+                      int64_t N, int C, int flags, float* a_out, float* b_out, float* mean_rstd_out,
+                      double* sumraw /* [B][C] per-channel sum of raw, or NULL */, void* stream);
 /* backward, pass 1: sums[b][row][c] = partial (S1 = sum g, S2 = sum g*raw, Sz = sum dout*z),
  * g = dout * act'(a*raw+b), z = act(a*raw+b) */
 int n3d_affine_act_bwd_reduce(const float* dout, int64_t dld, const float* raw, int64_t rld, const float* a,
                               const float* b, int B, int64_t N, int C, int flags, double* sums, void* stream);
 /* GroupNorm backward coefficients: dgamma, dbeta (summed over b), dalpha = sum Sz (if not NULL),
  * and the per-(b,c) affine draw = A*g + Bc + Cc*raw.  wptr: the MixedOp weight (NULL -> 1).
- * If dbias_conv != NULL (needs the forward statistics rows fstats/frows of the same raw tensor) it also
+ * If dbias_conv != NULL (needs sumraw[b][c] = sum_v raw, saved by the forward coefficient kernels) it also
  * writes the gradient of the bias of the conv that produced raw:  sum_v draw = A*S1 + N*Bc + Cc*sum(raw). */
 int n3d_gn_bwd_coeffs(const double* sums, int rows, const float* gamma, const float* mean_rstd,
                       const float* wptr, int B, int C, int G, int64_t N, float* dgamma, float* dbeta,
-                      float* dalpha, float* A, float* Bc, float* Cc, const double* fstats, int frows,
+                      float* dalpha, float* A, float* Bc, float* Cc, const double* sumraw,
                       float* dbias_conv, void* stream);
+/* n3d_gn_bwd_coeffs + n3d_affine_act_bwd_apply in one launch for small tensors (rows <= n3d_fused_max_rows()) */
+int n3d_affine_act_bwd_apply_gn(const float* dout, int64_t dld, const float* raw, int64_t rld, const float* a,
+                                const float* b, const double* sums, int rows, const float* gamma,
+                                const float* mean_rstd, const float* wptr, const double* sumraw,
+                                float* draw, int64_t drld, int B, int64_t N, int C, int G, int flags, float* dgamma,
+                                float* dbeta, float* dalpha, float* dbias_conv, void* stream);
 /* plain (no norm) epilogue backward coefficients: A = w, Bc = Cc = 0, dalpha = sum Sz */
 int n3d_plain_bwd_coeffs(const double* sums, int rows, const float* wptr, int B, int C, float* dalpha,
                          float* A, void* stream);

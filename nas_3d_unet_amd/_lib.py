@@ -63,10 +63,14 @@ PROTOTYPES = {
     "n3d_convT_bwd_data": (_i, [_gp, _p, _i64, _p, _p, _i64, _i, _p, _sz, _p]),
     "n3d_convT_bwd_weight": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i, _p, _sz, C.POINTER(FinalJob), _p]),
     "n3d_channel_stats": (_i, [_p, _i64, _i, _i64, _i, _p, _p]),
-    "n3d_gn_coeffs": (_i, [_p, _i, _p, _p, _i, _i, _i, _i64, _f, _p, _p, _p, _p]),
+    "n3d_gn_coeffs": (_i, [_p, _i, _p, _p, _i, _i, _i, _i64, _f, _p, _p, _p, _p, _p]),
     "n3d_affine_act": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i, _i64, _i, _i, _p]),
+    "n3d_fused_max_rows": (_i, []),
+    "n3d_affine_act_gn": (_i, [_p, _i64, _p, _i, _p, _p, _i, _f, _p, _p, _i64, _i, _i64, _i, _i, _p, _p, _p, _p, _p]),
+    "n3d_affine_act_bwd_apply_gn": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i64, _i, _i64, _i, _i, _i,
+                                         _p, _p, _p, _p, _p]),
     "n3d_affine_act_bwd_reduce": (_i, [_p, _i64, _p, _i64, _p, _p, _i, _i64, _i, _i, _p, _p]),
-    "n3d_gn_bwd_coeffs": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p]),
+    "n3d_gn_bwd_coeffs": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "n3d_plain_bwd_coeffs": (_i, [_p, _i, _p, _i, _i, _p, _p, _p]),
     "n3d_affine_act_bwd_apply": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i, _i64, _i, _i, _p]),
     "n3d_se_gate_fwd": (_i, [_p, _i, _i64, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p]),

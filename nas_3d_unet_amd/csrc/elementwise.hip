@@ -91,7 +91,8 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ rows, int
 
 __global__ __launch_bounds__(256) void gn_coeffs_kernel(const double* __restrict__ stats, int rows, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int C, int G, double count, float eps,
-                                                        float* __restrict__ a, float* __restrict__ bb, float* __restrict__ mean_rstd) {
+                                                        float* __restrict__ a, float* __restrict__ bb, float* __restrict__ mean_rstd,
+                                                        double* __restrict__ sumraw) {
   __shared__ double part[256];
   __shared__ double tot[192];
   __shared__ double mr[64 * 2];
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(const double* __restrict
     const float av = gam_t * rstd;
     a[b * C + t] = av;
     bb[b * C + t] = bet_t - mean * av;
+    if (sumraw) sumraw[b * C + t] = tot[t * 2];
   }
 }
 
@@ -228,10 +230,9 @@ __global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffs_kernel(const doubl
                                                             int C, int G, double count, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ dalpha, float* __restrict__ A,
                                                             float* __restrict__ Bc, float* __restrict__ Cc,
-                                                            const double* __restrict__ fstats, int frows, float* __restrict__ dbias_conv) {
+                                                            const double* __restrict__ sumraw, float* __restrict__ dbias_conv) {
   __shared__ double part[GNB_BP][256];
   __shared__ double tot[GNB_BP][192];
-  __shared__ double ftot[GNB_BP][128];
   __shared__ double gc[GNB_BP][64 * 2];
   __shared__ double acc4[GNB_BP][4][64];  // per-sample dgamma, dbeta, dz, dbias contributions
   const int bl = threadIdx.x >> 8, t = threadIdx.x & 255;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffs_kernel(const doubl
     const int bb = act ? b : B - 1;
     const int gq = (t < C) ? t / cg : 0;
     const double mean_c = mean_rstd[(bb * G + gq) * 2], rstd_c = mean_rstd[(bb * G + gq) * 2 + 1];
-    if (dbias_conv) reduce_rows_b(fstats + (int64_t)bb * frows * C * 2, frows, C * 2, part[bl], ftot[bl], t, act);
+    const double sraw = (dbias_conv && t < C) ? sumraw[bb * C + t] : 0.0;
     reduce_rows_b(sums + (int64_t)bb * rows * C * 3, rows, C * 3, part[bl], tot[bl], t, act);
     if (t < G) {
       const double mean = mean_rstd[(bb * G + t) * 2], rstd = mean_rstd[(bb * G + t) * 2 + 1];
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffs_kernel(const doubl
       A[b * C + t] = (float)Av;
       Bc[b * C + t] = (float)Bv;
       Cc[b * C + t] = (float)Cv;
-      if (dbias_conv) dbc += Av * S1 + count * Bv + Cv * ftot[bl][t * 2];
+      if (dbias_conv) dbc += Av * S1 + count * Bv + Cv * sraw;
     }
     __syncthreads();
   }
@@ -346,6 +347,217 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __re
     const int64_t v = v0 + (int64_t)it * m.vpb;
     if (v >= N) break;
     const float4 dq = *reinterpret_cast<const float4*>(db + v * dld);
+    const float4 rq = *reinterpret_cast<const float4*>(rb + v * rld);
+    const float d[4] = {dq.x, dq.y, dq.z, dq.w};
+    const float r[4] = {rq.x, rq.y, rq.z, rq.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float g = d[j];
+      if (RELU) { const float z = fmaf(av[j], r[j], bv[j]); g = z > 0.f ? g : 0.f; }
+      o[j] = fmaf(Av[j], g, fmaf(Cv[j], r[j], Bv[j]));
+    }
+    float4* op = reinterpret_cast<float4*>(ob + v * drld);
+    if (ACC) { const float4 p = *op; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+    *op = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Fused-prologue variants for small tensors (the deep U-net levels, where a step is launch-latency bound):
+// every workgroup recomputes its sample's GroupNorm coefficients from the partial-statistics rows in its
+// prologue (a few hundred doubles), so the separate coefficient kernel -- one launch and one dependent
+// memory round trip per op -- disappears.  Workgroup (0, b) also stores the coefficients for the backward pass.
+// ------------------------------------------------------------------------------------------------
+template <bool RELU, bool ACC>
+__global__ __launch_bounds__(256) void affine_act_gn_kernel(const float* __restrict__ raw, int64_t rld, const double* __restrict__ stats, int rows,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int G, double count,
+                                                            float eps, const float* __restrict__ wptr, float* __restrict__ out, int64_t old_,
+                                                            int64_t N, int C, EwMap m, float* __restrict__ a_out, float* __restrict__ b_out,
+                                                            float* __restrict__ mr_out, double* __restrict__ sumraw) {
+  __shared__ double part[256];
+  __shared__ double tot[128];
+  __shared__ float ab[2][64];
+  const int b = blockIdx.y;
+  const int t = threadIdx.x;
+  const float gam_t = (t < C) ? gamma[t] : 0.f, bet_t = (t < C) ? beta[t] : 0.f;
+  const float w = wptr ? *wptr : 1.0f;
+  reduce_rows(stats + (int64_t)b * rows * C * 2, rows, C * 2, part, tot);
+  const int cg = C / G;
+  if (t < C) {
+    const int g = t / cg;
+    double s = 0, ss = 0;
+    for (int c = g * cg; c < (g + 1) * cg; ++c) { s += tot[c * 2]; ss += tot[c * 2 + 1]; }
+    const double n = count * cg;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const float av = gam_t * (float)rstd;
+    const float bv = bet_t - (float)mean * av;
+    ab[0][t] = av; ab[1][t] = bv;
+    if (blockIdx.x == 0) {
+      a_out[b * C + t] = av; b_out[b * C + t] = bv;
+      if (sumraw) sumraw[b * C + t] = tot[t * 2];
+      if (t % cg == 0) { mr_out[(b * G + g) * 2] = (float)mean; mr_out[(b * G + g) * 2 + 1] = (float)rstd; }
+    }
+  }
+  __syncthreads();
+  const int c4 = t % m.cpb, vl = t / m.cpb;
+  if (vl >= m.vpb) return;
+  const float4 av = make_float4(ab[0][c4 * 4], ab[0][c4 * 4 + 1], ab[0][c4 * 4 + 2], ab[0][c4 * 4 + 3]);
+  const float4 bv = make_float4(ab[1][c4 * 4], ab[1][c4 * 4 + 1], ab[1][c4 * 4 + 2], ab[1][c4 * 4 + 3]);
+  const float* rb = raw + (int64_t)b * N * rld + c4 * 4;
+  float* ob = out + (int64_t)b * N * old_ + c4 * 4;
+  const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+#pragma unroll 4
+  for (int it = 0; it < m.iters; ++it) {
+    const int64_t v = v0 + (int64_t)it * m.vpb;
+    if (v >= N) break;
+    const float4 q = *reinterpret_cast<const float4*>(rb + v * rld);
+    float4 z;
+    z.x = fmaf(av.x, q.x, bv.x); z.y = fmaf(av.y, q.y, bv.y); z.z = fmaf(av.z, q.z, bv.z); z.w = fmaf(av.w, q.w, bv.w);
+    if (RELU) { z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f); }
+    float4* op = reinterpret_cast<float4*>(ob + v * old_);
+    if (ACC) {
+      float4 o = *op;
+      o.x = fmaf(w, z.x, o.x); o.y = fmaf(w, z.y, o.y); o.z = fmaf(w, z.z, o.z); o.w = fmaf(w, z.w, o.w);
+      *op = o;
+    } else {
+      z.x *= w; z.y *= w; z.z *= w; z.w *= w;
+      *op = z;
+    }
+  }
+}
+
+// backward pass 2 with the GroupNorm-backward coefficients computed in the prologue (per workgroup, for its sample);
+// workgroup (0,0) additionally covers all samples (B <= 4) to emit dgamma / dbeta / dalpha / conv-bias gradient.
+// All global loads of the prologue (parameter vectors and every partial row this workgroup needs) are issued
+// before the first use, so the prologue costs ONE memory round trip; everything after it is LDS work.
+#define GNF_MAXB 4
+template <bool RELU, bool ACC>
+__global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* __restrict__ dout, int64_t dld, const float* __restrict__ raw,
+                                                                  int64_t rld, const float* __restrict__ a, const float* __restrict__ bb,
+                                                                  const double* __restrict__ sums, int rows, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean_rstd, const float* __restrict__ wptr,
+                                                                  const double* __restrict__ sumraw, int B, int G, double count,
+                                                                  float* __restrict__ draw, int64_t drld, int64_t N, int C, EwMap m,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dalpha,
+                                                                  float* __restrict__ dbias_conv) {
+  __shared__ double part[256];
+  __shared__ double tot[192];
+  __shared__ double gc[64 * 2];
+  __shared__ double gsh[64];
+  __shared__ double zred[64];
+  __shared__ float coef[3][64];
+  const int t = threadIdx.x;
+  const int cg = C / G;
+  const bool leader = (blockIdx.x == 0 && blockIdx.y == 0);
+  const int nb = leader ? B : 1;
+  // ---- load phase (no dependent loads): parameters, group statistics, this thread's share of the partial rows
+  const double w = wptr ? (double)*wptr : 1.0;
+  const double gam = (t < C) ? (double)gamma[t] : 0.0;
+  const int gq = (t < C) ? t / cg : 0;
+  double mean_c[GNF_MAXB], rstd_c[GNF_MAXB], ps[GNF_MAXB], pf[GNF_MAXB];
+  const int ncol3 = C * 3;
+  const int nrl3 = 256 / ncol3 > 0 ? 256 / ncol3 : 1;
+  const int q3 = t % ncol3, rl3 = t / ncol3;
+  const bool want_f = leader && dbias_conv;
+#pragma unroll
+  for (int k = 0; k < GNF_MAXB; ++k) {
+    ps[k] = 0; pf[k] = 0; mean_c[k] = 0; rstd_c[k] = 1;
+    if (k < nb) {
+      const int b = leader ? ((int)blockIdx.y + 1 + k) % B : (int)blockIdx.y;
+      mean_c[k] = mean_rstd[(b * G + gq) * 2]; rstd_c[k] = mean_rstd[(b * G + gq) * 2 + 1];
+      if (want_f && t < C) pf[k] = sumraw[b * C + t];
+    }
+  }
+  if (rl3 < nrl3)
+    for (int r = rl3; r < rows; r += nrl3) {
+#pragma unroll
+      for (int k = 0; k < GNF_MAXB; ++k)
+        if (k < nb) {
+          const int b = leader ? ((int)blockIdx.y + 1 + k) % B : (int)blockIdx.y;
+          ps[k] += sums[((int64_t)b * rows + r) * ncol3 + q3];
+        }
+    }
+  if (t < C) gsh[t] = gam;
+  // ---- LDS phase, sample by sample (the leader's own sample comes last so that coef[] ends up its own)
+  double dg = 0, db = 0, dz = 0, dbc = 0;
+#pragma unroll
+  for (int k = 0; k < GNF_MAXB; ++k) {
+    if (k < nb) {
+      part[t] = ps[k];
+      __syncthreads();
+      if (t < ncol3) {
+        double acc = 0;
+        for (int r = 0; r < nrl3; ++r) acc += part[r * ncol3 + t];
+        tot[t] = acc;
+      }
+      __syncthreads();
+      if (t < C && (t % cg) == 0) {
+        // one thread per group: mean_c / rstd_c of this thread ARE the group's
+        double c1 = 0, c2 = 0;
+        for (int c = t; c < t + cg; ++c) {
+          const double S1 = tot[c * 3], S2 = tot[c * 3 + 1];
+          c1 += gsh[c] * w * S1;
+          c2 += gsh[c] * w * rstd_c[k] * (S2 - mean_c[k] * S1);
+        }
+        const double n = count * cg;
+        gc[gq * 2] = c1 / n; gc[gq * 2 + 1] = c2 / n;
+      }
+      __syncthreads();
+      if (t < C) {
+        const double S1 = tot[t * 3], S2 = tot[t * 3 + 1], Sz = tot[t * 3 + 2];
+        const double c1 = gc[gq * 2], c2 = gc[gq * 2 + 1];
+        const double rs = rstd_c[k], mn = mean_c[k];
+        const double Av = rs * gam * w, Bv = -rs * c1 + rs * rs * c2 * mn, Cv = -rs * rs * c2;
+        coef[0][t] = (float)Av; coef[1][t] = (float)Bv; coef[2][t] = (float)Cv;
+        if (leader) {
+          dg += w * rs * (S2 - mn * S1);
+          db += w * S1;
+          dz += Sz;
+          if (dbias_conv) dbc += Av * S1 + count * Bv + Cv * pf[k];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (leader) {
+    if (t < C) {
+      if (dgamma) dgamma[t] = (float)dg;
+      if (dbeta) dbeta[t] = (float)db;
+      if (dbias_conv) dbias_conv[t] = (float)dbc;
+    }
+    if (dalpha) {
+      if (t < 64) zred[t] = (t < C) ? dz : 0.0;
+      __syncthreads();
+      if (t == 0) {
+        double sdz = 0;
+        for (int i = 0; i < 64; ++i) sdz += zred[i];
+        *dalpha = (float)sdz;
+      }
+    }
+  }
+  const int b = blockIdx.y;
+  const int c4 = t % m.cpb, vl = t / m.cpb;
+  if (vl >= m.vpb) return;
+  float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0}, Av[4], Bv[4], Cv[4];
+  const int co = b * C + c4 * 4;
+  if (a) { const float4 q = *reinterpret_cast<const float4*>(a + co); av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w; }
+  if (bb) { const float4 q = *reinterpret_cast<const float4*>(bb + co); bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { Av[j] = coef[0][c4 * 4 + j]; Bv[j] = coef[1][c4 * 4 + j]; Cv[j] = coef[2][c4 * 4 + j]; }
+  const float* dbp = dout + (int64_t)b * N * dld + c4 * 4;
+  const float* rb = raw + (int64_t)b * N * rld + c4 * 4;
+  float* ob = draw + (int64_t)b * N * drld + c4 * 4;
+  const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+#pragma unroll 2
+  for (int it = 0; it < m.iters; ++it) {
+    const int64_t v = v0 + (int64_t)it * m.vpb;
+    if (v >= N) break;
+    const float4 dq = *reinterpret_cast<const float4*>(dbp + v * dld);
     const float4 rq = *reinterpret_cast<const float4*>(rb + v * rld);
     const float d[4] = {dq.x, dq.y, dq.z, dq.w};
     const float r[4] = {rq.x, rq.y, rq.z, rq.w};
@@ -670,10 +882,10 @@ int n3d_channel_stats(const float* x, int64_t ld, int B, int64_t N, int C, doubl
 }
 
 int n3d_gn_coeffs(const double* stats, int rows, const float* gamma, const float* beta, int B, int C, int G, int64_t N, float eps,
-                  float* a, float* b, float* mean_rstd, void* stream) {
+                  float* a, float* b, float* mean_rstd, double* sumraw, void* stream) {
   N3D_CHECK_ARG(stats && gamma && beta && a && b && C <= 64 && G >= 1 && C % G == 0 && rows >= 1, "gn_coeffs: bad args");
   hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, stats, rows, gamma, beta, C, G, (double)N, eps, a, b,
-                     mean_rstd);
+                     mean_rstd, sumraw);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -709,12 +921,12 @@ int n3d_affine_act_bwd_reduce(const float* dout, int64_t dld, const float* raw, 
 }
 
 int n3d_gn_bwd_coeffs(const double* sums, int rows, const float* gamma, const float* mean_rstd, const float* wptr, int B, int C, int G,
-                      int64_t N, float* dgamma, float* dbeta, float* dalpha, float* A, float* Bc, float* Cc, const double* fstats, int frows,
+                      int64_t N, float* dgamma, float* dbeta, float* dalpha, float* A, float* Bc, float* Cc, const double* sumraw,
                       float* dbias_conv, void* stream) {
   N3D_CHECK_ARG(sums && gamma && mean_rstd && A && Bc && Cc && C <= 64 && C % G == 0, "gn_bwd_coeffs: bad args");
-  N3D_CHECK_ARG(!dbias_conv || (fstats && frows >= 1), "gn_bwd_coeffs: dbias_conv needs the forward statistics rows");
+  N3D_CHECK_ARG(!dbias_conv || sumraw, "gn_bwd_coeffs: dbias_conv needs the forward per-channel sums");
   hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(1), dim3(256 * GNB_BP), 0, (hipStream_t)stream, sums, rows, gamma, mean_rstd, wptr, B, C, G,
-                     (double)N, dgamma, dbeta, dalpha, A, Bc, Cc, fstats, frows, dbias_conv);
+                     (double)N, dgamma, dbeta, dalpha, A, Bc, Cc, sumraw, dbias_conv);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -837,6 +1049,48 @@ int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
                      beta2, eps, weight_decay, grad_scale, step_ptr);
   if (inc_step) hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_ptr);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+// fused variants: statistics rows -> coefficients in the kernel prologue (rows <= N3D_FUSED_MAX_ROWS)
+int n3d_fused_max_rows(void) { return 64; }
+
+int n3d_affine_act_gn(const float* raw, int64_t rld, const double* stats, int rows, const float* gamma, const float* beta, int G, float eps,
+                      const float* wptr, float* out, int64_t old_, int B, int64_t N, int C, int flags, float* a_out, float* b_out,
+                      float* mean_rstd_out, double* sumraw, void* stream) {
+  N3D_CHECK_ARG(raw && out && stats && gamma && beta && a_out && b_out && mean_rstd_out && C <= 64 && C % G == 0 && rows >= 1 && rows <= 64,
+                "affine_act_gn: bad args");
+  if (int e = check_vec(raw, rld, C, "affine_act_gn(raw)")) return e;
+  if (int e = check_vec(out, old_, C, "affine_act_gn(out)")) return e;
+  EwMap m = ew_map(N, C);
+  dim3 grid(m.rows, B), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bool relu = flags & N3D_RELU, acc = flags & N3D_ACCUMULATE;
+#define N3D_AAG(R, A_) hipLaunchKernelGGL((affine_act_gn_kernel<R, A_>), grid, blk, 0, s, raw, rld, stats, rows, gamma, beta, G, (double)N, eps, wptr, out, old_, N, C, m, a_out, b_out, mean_rstd_out, sumraw)
+  if (relu && acc) N3D_AAG(true, true); else if (relu) N3D_AAG(true, false); else if (acc) N3D_AAG(false, true); else N3D_AAG(false, false);
+#undef N3D_AAG
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_affine_act_bwd_apply_gn(const float* dout, int64_t dld, const float* raw, int64_t rld, const float* a, const float* b,
+                                const double* sums, int rows, const float* gamma, const float* mean_rstd, const float* wptr,
+                                const double* sumraw, float* draw, int64_t drld, int B, int64_t N, int C, int G, int flags,
+                                float* dgamma, float* dbeta, float* dalpha, float* dbias_conv, void* stream) {
+  N3D_CHECK_ARG(dout && raw && draw && sums && gamma && mean_rstd && C <= 64 && C % G == 0 && rows >= 1 && rows <= 64 && B <= GNF_MAXB,
+                "affine_act_bwd_apply_gn: bad args (needs rows <= 64, B <= 4)");
+  N3D_CHECK_ARG(!dbias_conv || sumraw, "affine_act_bwd_apply_gn: dbias_conv needs the forward per-channel sums");
+  if (int e = check_vec(dout, dld, C, "bwd_apply_gn(dout)")) return e;
+  if (int e = check_vec(raw, rld, C, "bwd_apply_gn(raw)")) return e;
+  if (int e = check_vec(draw, drld, C, "bwd_apply_gn(draw)")) return e;
+  EwMap m = ew_map(N, C);
+  dim3 grid(m.rows, B), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bool relu = flags & N3D_RELU, acc = flags & N3D_ACCUMULATE;
+#define N3D_ABG(R, A_) hipLaunchKernelGGL((affine_bwd_apply_gn_kernel<R, A_>), grid, blk, 0, s, dout, dld, raw, rld, a, b, sums, rows, gamma, mean_rstd, wptr, sumraw, B, G, (double)N, draw, drld, N, C, m, dgamma, dbeta, dalpha, dbias_conv)
+  if (relu && acc) N3D_ABG(true, true); else if (relu) N3D_ABG(true, false); else if (acc) N3D_ABG(false, true); else N3D_ABG(false, false);
+#undef N3D_ABG
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

@@ -255,14 +255,50 @@ def gn_coeffs(stats, rows, gamma, beta, B, Cc, G, N, eps=1e-5):
     a = torch.empty((B, Cc), dtype=torch.float32, device=dev)
     b = torch.empty((B, Cc), dtype=torch.float32, device=dev)
     mr = torch.empty((B, G, 2), dtype=torch.float32, device=dev)
+    sr = torch.empty((B, Cc), dtype=torch.float64, device=dev)
     check(_lib.load().n3d_gn_coeffs(ptr(stats), rows, ptr(gamma), ptr(beta), B, Cc, G, N, eps, ptr(a), ptr(b), ptr(mr),
-                                    stream_ptr()), "n3d_gn_coeffs")
-    return a, b, mr
+                                    ptr(sr), stream_ptr()), "n3d_gn_coeffs")
+    return a, b, mr, sr
 
 
 def affine_act(raw: View, a, b, wptr, out: View, flags=0):
     check(_lib.load().n3d_affine_act(raw.p, raw.ld, ptr(a), ptr(b), wptr, out.p, out.ld, raw.B, raw.N, raw.C, flags,
                                      stream_ptr()), "n3d_affine_act")
+
+
+_FUSED_MAX_ROWS = None
+
+
+def fused_max_rows():
+    global _FUSED_MAX_ROWS
+    if _FUSED_MAX_ROWS is None:
+        _FUSED_MAX_ROWS = int(_lib.load().n3d_fused_max_rows())
+    return _FUSED_MAX_ROWS
+
+
+def affine_act_gn(raw: View, stats, rows, gamma, beta, G, eps, wptr, out: View, flags=0):
+    """GroupNorm coefficients + normalise/activate/accumulate in one launch (small tensors)."""
+    dev = raw.t.device
+    a = torch.empty((raw.B, raw.C), dtype=torch.float32, device=dev)
+    b = torch.empty((raw.B, raw.C), dtype=torch.float32, device=dev)
+    mr = torch.empty((raw.B, G, 2), dtype=torch.float32, device=dev)
+    sr = torch.empty((raw.B, raw.C), dtype=torch.float64, device=dev)
+    check(_lib.load().n3d_affine_act_gn(raw.p, raw.ld, ptr(stats), rows, ptr(gamma), ptr(beta), G, eps, wptr, out.p, out.ld,
+                                        raw.B, raw.N, raw.C, flags, ptr(a), ptr(b), ptr(mr), ptr(sr), stream_ptr()),
+          "n3d_affine_act_gn")
+    return a, b, mr, sr
+
+
+def affine_act_bwd_apply_gn(dout: View, raw: View, a, b, sums, rows, gamma, beta, mean_rstd, wptr, sumraw, conv_bias,
+                            draw: View, G, flags=0, dalpha_ptr=None):
+    dgamma = grad_target(gamma)
+    dbeta = grad_target(beta)
+    dcb = grad_target(conv_bias) if (conv_bias is not None and sumraw is not None) else None
+    check(_lib.load().n3d_affine_act_bwd_apply_gn(dout.p, dout.ld, raw.p, raw.ld, ptr(a), ptr(b), ptr(sums), rows, ptr(gamma),
+                                                  ptr(mean_rstd), wptr, ptr(sumraw), draw.p, draw.ld, raw.B, raw.N,
+                                                  raw.C, G, flags, ptr(dgamma), ptr(dbeta), dalpha_ptr, ptr(dcb),
+                                                  stream_ptr()), "n3d_affine_act_bwd_apply_gn")
+    return dgamma, dbeta, dcb
 
 
 def affine_act_bwd_reduce(dout: View, raw: View, a, b, flags=0):
@@ -283,17 +319,16 @@ def grad_target(p):
     return t if t is not None else torch.empty_like(p)
 
 
-def gn_bwd_coeffs(sums, rows, gamma, mean_rstd, wptr, B, Cc, G, N, dalpha_ptr=None, beta=None, fstats=None, frows=0,
-                  conv_bias=None):
+def gn_bwd_coeffs(sums, rows, gamma, mean_rstd, wptr, B, Cc, G, N, dalpha_ptr=None, beta=None, sumraw=None, conv_bias=None):
     dev = sums.device
     dgamma = grad_target(gamma) if isinstance(gamma, torch.nn.Parameter) else torch.empty((Cc,), dtype=torch.float32, device=dev)
     dbeta = grad_target(beta) if isinstance(beta, torch.nn.Parameter) else torch.empty((Cc,), dtype=torch.float32, device=dev)
     A = torch.empty((B, Cc), dtype=torch.float32, device=dev)
     Bc = torch.empty((B, Cc), dtype=torch.float32, device=dev)
     Cc_ = torch.empty((B, Cc), dtype=torch.float32, device=dev)
-    dcb = grad_target(conv_bias) if (conv_bias is not None and fstats is not None) else None
+    dcb = grad_target(conv_bias) if (conv_bias is not None and sumraw is not None) else None
     check(_lib.load().n3d_gn_bwd_coeffs(ptr(sums), rows, ptr(gamma), ptr(mean_rstd), wptr, B, Cc, G, N, ptr(dgamma),
-                                        ptr(dbeta), dalpha_ptr, ptr(A), ptr(Bc), ptr(Cc_), ptr(fstats), frows, ptr(dcb),
+                                        ptr(dbeta), dalpha_ptr, ptr(A), ptr(Bc), ptr(Cc_), ptr(sumraw), ptr(dcb),
                                         stream_ptr()), "n3d_gn_bwd_coeffs")
     return dgamma, dbeta, A, Bc, Cc_, dcb
 

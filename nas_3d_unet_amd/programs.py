@@ -379,9 +379,16 @@ def seg_forward(seg, x, drop_gate=None, out=None, accumulate=False, alpha_row=No
             stats, rows = K.channel_stats(raw)
         cn = raw.C
         G = group_count(cn)
-        s.a, s.b, s.mr = K.gn_coeffs(stats, rows, seg.norm.weight, seg.norm.bias, raw.B, cn, G, raw.N, seg.norm.eps)
         s.kind, s.G = "gn", G
-        s.fstats, s.frows = stats, rows
+        if rows <= K.fused_max_rows():
+            # small tensor: coefficients are computed in the epilogue kernel's prologue (one launch less)
+            if out is None:
+                out = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
+                accumulate = False
+            fl = (RELU if seg.relu_out else 0) | (ACCUMULATE if accumulate else 0)
+            s.a, s.b, s.mr, s.sumraw = K.affine_act_gn(raw, stats, rows, seg.norm.weight, seg.norm.bias, G, seg.norm.eps, wp, out, fl)
+            return out, s
+        s.a, s.b, s.mr, s.sumraw = K.gn_coeffs(stats, rows, seg.norm.weight, seg.norm.bias, raw.B, cn, G, raw.N, seg.norm.eps)
     elif seg.se_gate is not None:
         s.mean, s.hidden, s.a = seg.se_gate.fwd(raw)
         s.kind = "se"
@@ -410,17 +417,27 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
         cbias = seg.weight.norm_fed_bias()
         if cbias is not None and not cbias.requires_grad:
             cbias = None
-        dgamma, dbeta, A, Bc, Cc, dcb = K.gn_bwd_coeffs(sums, rows, seg.norm.weight, s.mr, wp, raw.B, raw.C, s.G, raw.N, dap,
-                                                        seg.norm.bias, s.fstats, s.frows, cbias)
-        if isinstance(seg.weight, IdentityW) and need_dx:
-            # the raw tensor is the input itself: write dx directly
+        ident = isinstance(seg.weight, IdentityW)
+        if ident and not need_dx:
+            ident = False
+        if ident:
+            # the raw tensor is the input itself: the apply pass writes dx directly
             if dx_out is None:
                 dx_out = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
                 dx_acc = False
-            K.affine_act_bwd_apply(dout, raw, s.a, s.b, A, Bc, Cc, dx_out, fl | (ACCUMULATE if dx_acc else 0))
+            target, tfl = dx_out, fl | (ACCUMULATE if dx_acc else 0)
+        else:
+            target, tfl = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device)), fl
+        if rows <= K.fused_max_rows() and raw.B <= 4:
+            dgamma, dbeta, dcb = K.affine_act_bwd_apply_gn(dout, raw, s.a, s.b, sums, rows, seg.norm.weight, seg.norm.bias, s.mr, wp,
+                                                           s.sumraw, cbias, target, s.G, tfl, dap)
+        else:
+            dgamma, dbeta, A, Bc, Cc, dcb = K.gn_bwd_coeffs(sums, rows, seg.norm.weight, s.mr, wp, raw.B, raw.C, s.G, raw.N, dap,
+                                                            seg.norm.bias, s.sumraw, cbias)
+            K.affine_act_bwd_apply(dout, raw, s.a, s.b, A, Bc, Cc, target, tfl)
+        if ident:
             return dx_out.t, [dgamma, dbeta]
-        draw = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
-        K.affine_act_bwd_apply(dout, raw, s.a, s.b, A, Bc, Cc, draw, fl)
+        draw = target
         dx, wg = seg.weight.bwd(s.ws, draw, need_dx, dx_out, dx_acc, dcb is not None)
         wg = list(wg)
         if dcb is not None:
