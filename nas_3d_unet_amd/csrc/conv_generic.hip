@@ -20,6 +20,7 @@ struct GatherArgs {
   const float* relu_src; int64_t rld;
   const float* out_gate;
   double* stats;
+  FastDiv fWd, fHd;
 };
 
 // pack native (Co, Ci, k^3) weights into wp[tap][cs][cdp]; transpose=0: cs=ci, cd=co (forward);
@@ -45,8 +46,11 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd, Ns = (int64_t)a.Ds * a.Hs * a.Ws;
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool valid = v < Nd;
-  const int64_t vv = valid ? v : 0;
-  const int w_ = (int)(vv % a.Wd), h_ = (int)((vv / a.Wd) % a.Hd), d_ = (int)(vv / ((int64_t)a.Wd * a.Hd));
+  const uint32_t vv = valid ? (uint32_t)v : 0u;
+  uint32_t qw, rw_, qd, rh_;
+  a.fWd.divmod(vv, qw, rw_);
+  a.fHd.divmod(qw, qd, rh_);
+  const int w_ = (int)rw_, h_ = (int)rh_, d_ = (int)qd;
   float acc[CO_T];
 #pragma unroll
   for (int j = 0; j < CO_T; ++j) {
@@ -192,6 +196,7 @@ struct WgradArgs {
   float* pbias;     // [nchunks][tco][CO_T]
   int tci, tco;
   int64_t chunk;
+  FastDiv fNo, fWo, fHo;
 };
 
 template <int CI_T, int CO_T>
@@ -217,9 +222,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int j = 0; j < CO_T; ++j) bacc[j] = 0.f;
   for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-    const int b = (int)(i / No);
-    const int64_t o = i % No;
-    const int ow = (int)(o % a.Wo), oh = (int)((o / a.Wo) % a.Ho), od = (int)(o / ((int64_t)a.Wo * a.Ho));
+    uint32_t ub, uo, q1, uw, ud, uh;
+    a.fNo.divmod((uint32_t)i, ub, uo);
+    a.fWo.divmod(uo, q1, uw);
+    a.fHo.divmod(q1, ud, uh);
+    const int b = (int)ub, ow = (int)uw, oh = (int)uh, od = (int)ud;
     float dyv[CO_T];
     const float* dp = a.dy + i * a.dyld + cot * CO_T;
     if (covec) {
@@ -311,6 +318,7 @@ struct DwArgs {
   const float* w;   // native (C,1,k,k,k)
   const float* bias;
   int k, sn, off, dt, den, flags;
+  FastDiv fcpb, fWd, fHd;
 };
 
 __global__ __launch_bounds__(256) void dw_gather_kernel(DwArgs a) {
@@ -319,9 +327,13 @@ __global__ __launch_bounds__(256) void dw_gather_kernel(DwArgs a) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= Nd * cpb) return;
   const int b = blockIdx.y;
-  const int c4 = (int)(idx % cpb);
-  const int64_t v = idx / cpb;
-  const int w_ = (int)(v % a.Wd), h_ = (int)((v / a.Wd) % a.Hd), d_ = (int)(v / ((int64_t)a.Wd * a.Hd));
+  uint32_t uv, uc, q1, uw, ud, uh;
+  a.fcpb.divmod((uint32_t)idx, uv, uc);
+  a.fWd.divmod(uv, q1, uw);
+  a.fHd.divmod(q1, ud, uh);
+  const int c4 = (int)uc;
+  const int64_t v = uv;
+  const int w_ = (int)uw, h_ = (int)uh, d_ = (int)ud;
   const int k = a.k, taps = k * k * k;
   float acc[4];
 #pragma unroll
@@ -360,6 +372,7 @@ struct DwWgradArgs {
   int B, C, k, stride, pad;
   float* partial;  // [nchunks][27+1][C]
   int64_t chunk;   // flattened (b,o) voxels per block
+  FastDiv fNo, fWo, fHo;
 };
 
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
@@ -378,9 +391,11 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
     for (int j = 0; j < 4; ++j) acc[q][j] = 0.f;
   if (vl < vpb) {
     for (int64_t i = i0 + vl; i < i1; i += vpb) {
-      const int b = (int)(i / No);
-      const int64_t o = i % No;
-      const int ow = (int)(o % a.Wo), oh = (int)((o / a.Wo) % a.Ho), od = (int)(o / ((int64_t)a.Wo * a.Ho));
+      uint32_t ub, uo, q1, uw, ud, uh;
+      a.fNo.divmod((uint32_t)i, ub, uo);
+      a.fWo.divmod(uo, q1, uw);
+      a.fHo.divmod(q1, ud, uh);
+      const int b = (int)ub, ow = (int)uw, oh = (int)uh, od = (int)ud;
       const float4 g = *reinterpret_cast<const float4*>(a.dy + i * a.dyld + c4 * 4);
       acc[27][0] += g.x; acc[27][1] += g.y; acc[27][2] += g.z; acc[27][3] += g.w;
       const float* xb = a.x + (int64_t)b * Ni * a.xld + c4 * 4;
@@ -676,6 +691,7 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
     else { a.src = src; a.sld = sld; a.Ds = g->Do; a.Hs = g->Ho; a.Ws = g->Wo; a.dst = dst; a.dld = dld; a.Dd = g->Di; a.Hd = g->Hi; a.Wd = g->Wi;
       a.sn = 1; a.off = g->pad; a.dt = -g->dil; a.den = g->stride; }
     const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
+    a.fcpb = FastDiv((uint32_t)(a.C / 4)); a.fWd = FastDiv((uint32_t)a.Wd); a.fHd = FastDiv((uint32_t)a.Hd);
     hipLaunchKernelGGL(dw_gather_kernel, dim3((unsigned)cdiv(Nd * (a.C / 4), 256), g->B), dim3(256), 0, s, a);
     N3D_LAUNCH_CHECK();
     return N3D_OK;
@@ -692,6 +708,7 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
     a.sn = g->stride; a.off = -g->pad; a.dt = g->dil; a.den = 1; }
   else { a.Ds = g->Do; a.Hs = g->Ho; a.Ws = g->Wo; a.Cs = g->Co; a.Dd = g->Di; a.Hd = g->Hi; a.Wd = g->Wi; a.Cd = g->Ci;
     a.sn = 1; a.off = g->pad; a.dt = -g->dil; a.den = g->stride; }
+  a.fWd = FastDiv((uint32_t)a.Wd); a.fHd = FastDiv((uint32_t)a.Hd);
   const int cot = pick_cot(a.Cd);
   a.Cdp = (int)align_up(a.Cd, cot);
   const size_t need = (size_t)taps * a.Cs * a.Cdp * 4;
@@ -757,6 +774,7 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     DwWgradArgs a;
     a.x = x; a.xld = xld; a.Di = g->Di; a.Hi = g->Hi; a.Wi = g->Wi; a.dy = dy; a.dyld = dyld; a.Do = g->Do; a.Ho = g->Ho; a.Wo = g->Wo;
     a.B = g->B; a.C = g->Ci; a.k = 3; a.stride = g->stride; a.pad = g->pad; a.partial = wsf;
+    a.fNo = FastDiv((uint32_t)No); a.fWo = FastDiv((uint32_t)g->Wo); a.fHo = FastDiv((uint32_t)g->Ho);
     const int64_t total = (int64_t)g->B * No;
     int64_t nch = cdiv(total, 2048);
     if (nch > 512) nch = 512;
@@ -796,6 +814,8 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   a.dy = dy; a.dyld = dyld; a.Do = g->Do; a.Ho = g->Ho; a.Wo = g->Wo; a.Co = g->Co;
   a.B = g->B; a.k = g->k; a.stride = g->stride; a.dil = g->dil; a.pad = g->pad; a.flags = flags; a.in_gate = in_gate;
   a.partial = wsf; a.pbias = wsf + p.partial_floats; a.tci = p.tci; a.tco = p.tco; a.chunk = p.chunk;
+  a.fNo = FastDiv((uint32_t)No); a.fWo = FastDiv((uint32_t)g->Wo); a.fHo = FastDiv((uint32_t)g->Ho);
+  N3D_CHECK_ARG((int64_t)g->B * No < (1ll << 31), "conv_bwd_weight: tensor too large for 32-bit voxel indexing");
   N3D_CHECK_ARG(g->Ci % 4 == 0 && xld % 4 == 0 && aligned16(x), "conv_bwd_weight: i-side tensor needs C %% 4 == 0 and 16-byte alignment");
   if (p.ci_t == 8 && p.co_t == 16) launch_wgrad_t<8, 16>(a, p, s);
   else if (p.ci_t == 8 && p.co_t == 8) launch_wgrad_t<8, 8>(a, p, s);

@@ -28,6 +28,7 @@ struct MfArgs {
   const float* out_gate;
   double* stats;
   int rows_per_sample;
+  FastDiv fNd, fWd, fHd, fC16;
 };
 
 // Wp[tap][c16][kk][cd][j] <- w native (Co, Ci, taps); transpose=0: cs=ci, cd=co; transpose=1: cs=co, cd=ci
@@ -64,10 +65,12 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
   for (int t = 0; t < MT; ++t) {
     const int64_t i = row0 + t * 16 + m;
     rvalid[t] = i < Mtot;
-    const int64_t ii = rvalid[t] ? i : 0;
-    rb[t] = (int)(ii / Nd);
-    const int64_t v = ii % Nd;
-    rw[t] = (int)(v % a.Wd); rh[t] = (int)((v / a.Wd) % a.Hd); rd[t] = (int)(v / ((int64_t)a.Wd * a.Hd));
+    const uint32_t ii = rvalid[t] ? (uint32_t)i : 0u;
+    uint32_t ub, uv, q1, uw, ud, uh;
+    a.fNd.divmod(ii, ub, uv);
+    a.fWd.divmod(uv, q1, uw);
+    a.fHd.divmod(q1, ud, uh);
+    rb[t] = (int)ub; rw[t] = (int)uw; rh[t] = (int)uh; rd[t] = (int)ud;
   }
   f32x4 acc[MT][NT], acc2[MT][NT];
 #pragma unroll
@@ -84,8 +87,9 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
   // K loop, software-pipelined by hand: the operands of group g+step are requested before the MFMAs of group g
   // issue, so each wave keeps one group of global loads in flight behind its matrix work.
   auto load_group = [&](int g, float4 (&av)[MT], float4 (&bv)[NT]) {
-    const int tap = g / c16n, c16 = g - tap * c16n;
-    const int kw = tap % k, kh = (tap / k) % k, kd = tap / (k * k);
+    const int tap = (int)a.fC16.div((uint32_t)g), c16 = g - tap * c16n;
+    // k is 1 or 3: constant divisors
+    const int kd = (k == 3) ? tap / 9 : 0, kh = (k == 3) ? (tap % 9) / 3 : 0, kw = (k == 3) ? tap % 3 : 0;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       int nd = rd[t] * a.sn + a.off + kd * a.dt, nh = rh[t] * a.sn + a.off + kh * a.dt, nw = rw[t] * a.sn + a.off + kw * a.dt;
@@ -123,7 +127,19 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
         acc2[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].w, bv[n].w, acc2[t][n], 0, 0, 0);
       }
   };
-  {
+  if (KSPLIT == 16 && ngroups <= 16 * 8) {
+    // tiny GEMM: every operand this wave will ever need is requested up front (<= 8 groups, 16 float4 per lane),
+    // so the whole K loop costs one memory round trip
+    float4 avs[8][MT], bvs[8][NT];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int g = wave + i * 16;
+      load_group(g < ngroups ? g : ngroups - 1, avs[i], bvs[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (wave + i * 16 < ngroups) mfma_group(avs[i], bvs[i]);
+  } else {
     const int g0 = (KSPLIT > 1 ? wave : 0), step = (KSPLIT > 1 ? KSPLIT : 1);
     float4 avA[MT], bvA[NT], avB[MT], bvB[NT];
     if (g0 < ngroups) load_group(g0, avA, bvA);
@@ -173,7 +189,7 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
       for (int r = 0; r < 4; ++r) {
         const int64_t i = row0 + t * 16 + kk * 4 + r;
         if (i >= Mtot) continue;
-        const int b = (int)(i / Nd);
+        const int b = (int)a.fNd.div((uint32_t)i);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const int c = n0 + n * 16 + m;
@@ -206,9 +222,11 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
       const int q2 = threadIdx.x & 1, col = (threadIdx.x >> 1) & 15, n = threadIdx.x >> 5;
       double s = 0;
       for (int w = 0; w < nw; ++w) s += red[((w * NT + n) * 16 + col) * 2 + q2];
-      const int64_t first = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
-      const int b = (int)(first / Nd);
-      const int row = (int)((first % Nd) / ROWS_PER_BLOCK);
+      const uint32_t first = (uint32_t)blockIdx.x * ROWS_PER_BLOCK;
+      uint32_t ub2, ur2;
+      a.fNd.divmod(first, ub2, ur2);
+      const int b = (int)ub2;
+      const int row = (int)(ur2 / ROWS_PER_BLOCK);
       a.stats[(((int64_t)b * a.rows_per_sample + row) * a.Cd + n0 + n * 16 + col) * 2 + q2] = s;
     }
   }
@@ -228,6 +246,7 @@ struct Wg16Args {
   float* pbias;    // [nchunks][tco][16]
   int tci, tco;
   int64_t chunk;   // voxels (flattened b,o) per workgroup, multiple of 16
+  FastDiv fNo, fWo, fHo, fTco, fTci;
 };
 
 __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wg16Args a) {
@@ -236,8 +255,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wg16Args a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, kk = lane >> 4;
   const int tile = blockIdx.x;
-  const int cot = tile % a.tco, cit = (tile / a.tco) % a.tci, tap = tile / (a.tco * a.tci);
-  const int kw = tap % a.k, kh = (tap / a.k) % a.k, kd = tap / (a.k * a.k);
+  uint32_t t1, ucot, utap, ucit;
+  a.fTco.divmod((uint32_t)tile, t1, ucot);
+  a.fTci.divmod(t1, utap, ucit);
+  const int cot = (int)ucot, cit = (int)ucit, tap = (int)utap;
+  const int kd = (a.k == 3) ? tap / 9 : 0, kh = (a.k == 3) ? (tap % 9) / 3 : 0, kw = (a.k == 3) ? tap % 3 : 0;
   const int64_t No = (int64_t)a.Do * a.Ho * a.Wo, Ni = (int64_t)a.Di * a.Hi * a.Wi;
   const int64_t total = (int64_t)a.B * No;
   const int64_t c0 = (int64_t)blockIdx.y * a.chunk;
@@ -249,27 +271,40 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wg16Args a) {
   float bsum = 0.f;
   // this lane's voxel walks i = c0 + wave*4 + kk, step 16
   int64_t i = c0 + wave * 4 + kk;
-  int b = (int)(i / No);
-  int64_t o = i % No;
-  int ow = (int)(o % a.Wo), oh = (int)((o / a.Wo) % a.Ho), od = (int)(o / ((int64_t)a.Wo * a.Ho));
-  for (; i - kk - wave * 4 < c1; i += 16) {
-    float av = 0.f, bv = 0.f;
-    if (i < c1) {
-      bv = a.dy[i * a.dyld + cot * 16 + m];
+  uint32_t ub, uo, q1, uw, ud, uh;
+  a.fNo.divmod((uint32_t)i, ub, uo);
+  a.fWo.divmod(uo, q1, uw);
+  a.fHo.divmod(q1, ud, uh);
+  int b = (int)ub, ow = (int)uw, oh = (int)uh, od = (int)ud;
+  // four voxel steps per iteration: all eight loads are requested before the first MFMA consumes them
+  for (; i - kk - wave * 4 < c1; i += 64) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t iu = i + 16 * u;
+      const bool in = iu < c1;
+      const int64_t ic = in ? iu : c0;
+      bv[u] = a.dy[ic * a.dyld + cot * 16 + m];
       const int id = od * a.stride - a.pad + kd * a.dil, ih = oh * a.stride - a.pad + kh * a.dil, iw = ow * a.stride - a.pad + kw * a.dil;
-      if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi) {
-        av = a.x[((int64_t)b * Ni + ((int64_t)id * a.Hi + ih) * a.Wi + iw) * a.xld + cit * 16 + m];
-        if (relu_in) av = fmaxf(av, 0.f);
-        if (a.in_gate) av *= a.in_gate[(int64_t)b * a.Ci + cit * 16 + m];
+      const bool ok = in && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+      const int cd_ = min(max(id, 0), a.Di - 1), ch_ = min(max(ih, 0), a.Hi - 1), cw_ = min(max(iw, 0), a.Wi - 1);
+      const int bc = min(b, a.B - 1);
+      float xv = a.x[((int64_t)bc * Ni + ((int64_t)cd_ * a.Hi + ch_) * a.Wi + cw_) * a.xld + cit * 16 + m];
+      if (relu_in) xv = fmaxf(xv, 0.f);
+      if (a.in_gate) xv *= a.in_gate[(int64_t)bc * a.Ci + cit * 16 + m];
+      av[u] = ok ? xv : 0.f;
+      if (!in) bv[u] = 0.f;
+      // advance this lane's voxel by 16
+      ow += 16;
+      while (ow >= a.Wo) {
+        ow -= a.Wo;
+        if (++oh >= a.Ho) { oh = 0; if (++od >= a.Do) { od = 0; ++b; } }
       }
     }
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-    bsum += bv;
-    // advance this lane's voxel by 16
-    ow += 16;
-    while (ow >= a.Wo) {
-      ow -= a.Wo;
-      if (++oh >= a.Ho) { oh = 0; if (++od >= a.Do) { od = 0; ++b; } }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+      bsum += bv[u];
     }
   }
   if (wave > 0) l4[(wave - 1) * 64 + lane] = acc;
@@ -634,6 +669,8 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
   else { a.Ds = g->Do; a.Hs = g->Ho; a.Ws = g->Wo; a.Cs = g->Co; a.Dd = g->Di; a.Hd = g->Hi; a.Wd = g->Wi; a.Cd = g->Ci;
     a.sn = 1; a.off = g->pad; a.dt = -g->dil; a.den = g->stride; }
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
+  if ((int64_t)g->B * Nd >= (1ll << 31)) return 0;  // 32-bit voxel indexing
+  a.fNd = FastDiv((uint32_t)Nd); a.fWd = FastDiv((uint32_t)a.Wd); a.fHd = FastDiv((uint32_t)a.Hd); a.fC16 = FastDiv((uint32_t)(a.Cs / 16));
   if (stats) {
     if (Nd % p.rows_per_block != 0) { set_error("conv(mfma): statistics requested for a shape whose n3d_conv_stats_rows() is -1"); return N3D_ERR_INVALID; }
     a.rows_per_sample = (int)(Nd / p.rows_per_block);
@@ -678,6 +715,9 @@ int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const fl
   nch = cdiv(total, chunk);
   if ((size_t)nch * ntiles * 256 > avail_floats) return 0;
   a.chunk = chunk; a.partial = partial; a.pbias = pbias;
+  if (total + 64 >= (1ll << 31)) return 0;
+  a.fNo = FastDiv((uint32_t)No); a.fWo = FastDiv((uint32_t)g->Wo); a.fHo = FastDiv((uint32_t)g->Ho);
+  a.fTco = FastDiv((uint32_t)a.tco); a.fTci = FastDiv((uint32_t)a.tci);
   hipLaunchKernelGGL(conv_wgrad16_kernel, dim3(ntiles, (unsigned)nch), dim3(256), 0, s, a);
   *nchunks_out = (int)nch; *ntiles_out = ntiles;
   return 1;

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
   __shared__ double lds[4 * 64 * 8];
   const int b = blockIdx.y;
   const int t = threadIdx.x;
-  const int c4 = t % m.cpb, vl = t / m.cpb;
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   const bool active = vl < m.vpb;
   const int64_t v0 = (int64_t)blockIdx.x * m.vpc;
   float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
                                                          float* __restrict__ out, int64_t old_, int64_t N, int C, EwMap m) {
   const int b = blockIdx.y;
   const int t = threadIdx.x;
-  const int c4 = t % m.cpb, vl = t / m.cpb;
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   if (vl >= m.vpb) return;
   float4 av = make_float4(1, 1, 1, 1), bv = make_float4(0, 0, 0, 0);
   if (a) av = *reinterpret_cast<const float4*>(a + b * C + c4 * 4);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(const float* __r
   __shared__ double lds[4 * 64 * 12];
   const int b = blockIdx.y;
   const int t = threadIdx.x;
-  const int c4 = t % m.cpb, vl = t / m.cpb;
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   const bool active = vl < m.vpb;
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, sz[4] = {0, 0, 0, 0};
   if (active) {
@@ -179,21 +179,32 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(const float* __r
     const float* db = dout + (int64_t)b * N * dld + c4 * 4;
     const float* rb = raw + (int64_t)b * N * rld + c4 * 4;
     const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
-    for (int it = 0; it < m.iters; ++it) {
-      const int64_t v = v0 + (int64_t)it * m.vpb;
-      if (v >= N) break;
-      const float4 dq = *reinterpret_cast<const float4*>(db + v * dld);
-      const float4 rq = *reinterpret_cast<const float4*>(rb + v * rld);
-      const float d[4] = {dq.x, dq.y, dq.z, dq.w};
-      const float r[4] = {rq.x, rq.y, rq.z, rq.w};
+    for (int it0 = 0; it0 < m.iters; it0 += 4) {
+      float4 dq[4], rq[4];
+      bool ok[4];
+      // request up to 8 independent 16-byte loads before the first use
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float z = fmaf(av[j], r[j], bv[j]);
-        float g = d[j];
-        if (RELU) { g = z > 0.f ? g : 0.f; z = fmaxf(z, 0.f); }
-        s1[j] += g;
-        s2[j] = fmaf(g, r[j], s2[j]);
-        sz[j] = fmaf(d[j], z, sz[j]);
+      for (int u = 0; u < 4; ++u) {
+        const int64_t v = v0 + (int64_t)(it0 + u) * m.vpb;
+        ok[u] = (it0 + u < m.iters) && v < N;
+        const int64_t vc = ok[u] ? v : 0;
+        dq[u] = *reinterpret_cast<const float4*>(db + vc * dld);
+        rq[u] = *reinterpret_cast<const float4*>(rb + vc * rld);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        const float d[4] = {dq[u].x, dq[u].y, dq[u].z, dq[u].w};
+        const float r[4] = {rq[u].x, rq[u].y, rq[u].z, rq[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float z = fmaf(av[j], r[j], bv[j]);
+          float g = d[j];
+          if (RELU) { g = z > 0.f ? g : 0.f; z = fmaxf(z, 0.f); }
+          s1[j] += g;
+          s2[j] = fmaf(g, r[j], s2[j]);
+          sz[j] = fmaf(d[j], z, sz[j]);
+        }
       }
     }
   }
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __re
                                                                int64_t N, int C, EwMap m) {
   const int b = blockIdx.y;
   const int t = threadIdx.x;
-  const int c4 = t % m.cpb, vl = t / m.cpb;
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   if (vl >= m.vpb) return;
   float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0}, Av[4] = {1, 1, 1, 1}, Bv[4] = {0, 0, 0, 0}, Cv[4] = {0, 0, 0, 0};
   const int co = b * C + c4 * 4;
@@ -404,7 +415,7 @@ __global__ __launch_bounds__(256) void affine_act_gn_kernel(const float* __restr
     }
   }
   __syncthreads();
-  const int c4 = t % m.cpb, vl = t / m.cpb;
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   if (vl >= m.vpb) return;
   const float4 av = make_float4(ab[0][c4 * 4], ab[0][c4 * 4 + 1], ab[0][c4 * 4 + 2], ab[0][c4 * 4 + 3]);
   const float4 bv = make_float4(ab[1][c4 * 4], ab[1][c4 * 4 + 1], ab[1][c4 * 4 + 2], ab[1][c4 * 4 + 3]);
@@ -541,7 +552,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* _
     }
   }
   const int b = blockIdx.y;
-  const int c4 = t % m.cpb, vl = t / m.cpb;
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   if (vl >= m.vpb) return;
   float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0}, Av[4], Bv[4], Cv[4];
   const int co = b * C + c4 * 4;

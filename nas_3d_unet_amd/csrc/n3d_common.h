@@ -36,6 +36,26 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Division by a launch-time constant without the ~40-200 instruction integer-division sequences hipcc emits
+// for runtime divisors (index decoding used to dominate the small kernels).  Exact for 0 <= n < 2^31.
+struct FastDiv {
+  uint32_t d, m, s;
+#ifdef __HIPCC__
+  __host__ __device__
+#endif
+  FastDiv() : d(1), m(0x80000000u), s(0) {}
+  explicit FastDiv(uint32_t dd) {
+    d = dd ? dd : 1;
+    s = 0;
+    while ((1ull << s) < d) ++s;
+    m = (uint32_t)(((1ull << (31 + s)) + d - 1) / d);
+  }
+#ifdef __HIPCC__
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return (uint32_t)(((uint64_t)n * m) >> (31 + s)); }
+  __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const { q = div(n); r = n - q * d; }
+#endif
+};
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---------------------------------------------------------------------------------------------
@@ -51,6 +71,7 @@ struct EwMap {
   int iters;    // iterations per block
   int64_t vpc;  // voxels per block (chunk)
   int rows;     // blocks (partial rows) per sample
+  FastDiv fcpb; // thread -> (voxel lane, channel quad) without a runtime division
 };
 
 static inline EwMap ew_map(int64_t N, int C) {
@@ -65,6 +86,7 @@ static inline EwMap ew_map(int64_t N, int C) {
   m.iters = (int)it;
   m.vpc = (int64_t)m.vpb * m.iters;
   m.rows = (int)cdiv(N, m.vpc);
+  m.fcpb = FastDiv((uint32_t)m.cpb);
   return m;
 }
 
