@@ -51,6 +51,56 @@ class FlatParams:
                     weight_decay, grad_scale, True)
 
 
+class GradSync:
+    """Bucketed mean all-reduce of one flat gradient buffer (works with RCCL on GPUs and gloo on CPU tensors).
+
+    xGMI is point-to-point (7 links per GPU) and the whole payload is 2-7 MB (searched net) / 27 MB
+    (supernet), so the collective is latency-bound: a few large buckets, never one call per tensor."""
+
+    def __init__(self, flat_grad, process_group=None, n_buckets=2, comm_stream=None):
+        self.g = flat_grad
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        n = flat_grad.numel()
+        nb = max(1, min(n_buckets, n // 4 if n >= 4 else 1))
+        self.edges = [n * i // nb // 4 * 4 for i in range(nb)] + [n]
+        self.comm_stream = comm_stream
+
+    def all_reduce(self):
+        """sum-reduce every bucket; callers divide by world size (folded into the Adam kernel)."""
+        if self.world == 1:
+            return
+        if self.comm_stream is not None:
+            cs = self.comm_stream
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                for a, b in zip(self.edges[:-1], self.edges[1:]):
+                    dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.pg)
+            torch.cuda.current_stream().wait_stream(cs)
+        else:
+            for a, b in zip(self.edges[:-1], self.edges[1:]):
+                dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.pg)
+
+
+def flatten_params(params, device=None):
+    """(flat parameter tensor, flat gradient tensor): re-homes every parameter (and its .grad) as a view."""
+    params = list(params)
+    device = device if device is not None else params[0].device
+    offs, n = [], 0
+    for p in params:
+        offs.append(n)
+        n += (p.numel() + 3) // 4 * 4
+    flat = torch.zeros(n, dtype=torch.float32, device=device)
+    grad = torch.zeros(n, dtype=torch.float32, device=device)
+    with torch.no_grad():
+        for p, o in zip(params, offs):
+            v = flat[o:o + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = grad[o:o + p.numel()].view(p.shape)
+    return flat, grad, offs
+
+
 class Trainer:
     """One searched-net (or any model built from nas_3d_unet_amd ops) training step.
 
@@ -73,6 +123,7 @@ class Trainer:
         self._static_x = self._static_t = self._static_loss = None
         self._comm_stream = torch.cuda.Stream(device=self.device) if self.world > 1 else None
         self.ctx = K.StepContext(self.device)  # batched weight packing + deferred wgrad reductions
+        self.sync = GradSync(self.fp.grad, self.pg, self.n_buckets, self._comm_stream)
         if self.world > 1:
             dist.broadcast(self.fp.flat, src=0, group=self.pg)
 
@@ -89,17 +140,7 @@ class Trainer:
         return loss.detach()
 
     def _allreduce(self):
-        """Bucketed all-reduce of the flat gradient buffer on the side stream (xGMI ring/tree is
-        latency-bound at these sizes (2-7 MB): few large buckets, not one per tensor)."""
-        n = self.fp.numel
-        nb = self.n_buckets
-        edges = [n * i // nb // 4 * 4 for i in range(nb)] + [n]
-        cs = self._comm_stream
-        cs.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(cs):
-            for i in range(nb):
-                dist.all_reduce(self.fp.grad[edges[i]:edges[i + 1]], op=dist.ReduceOp.SUM, group=self.pg)
-        torch.cuda.current_stream().wait_stream(cs)
+        self.sync.all_reduce()
 
     def _update(self):
         self.fp.adam(self.lr, self.betas, self.eps, 0.0, 1.0 / self.world)
@@ -141,3 +182,81 @@ class Trainer:
             if self.world == 1:
                 self._update()
         self._graph = g
+
+
+class SearchTrainer:
+    """Supernet search step, first-order DARTS as in the reference (search.py:211-238):
+    architecture pass on the validation batch (Adam on the four alpha matrices), then weight pass on the
+    training batch (Adam on the kernel weights); both Adam instances use torch defaults (search.py:103-104).
+
+    Exact-equivalent savings over the reference: the architecture pass does not compute weight gradients
+    (the reference computes and discards them, search.py:231) and the weight pass does not compute alpha
+    gradients -- requires_grad is switched per pass, so the corresponding kernels are simply not launched."""
+
+    def __init__(self, shell, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph=True):
+        self.model = shell
+        self.loss_fn = WeightedDiceLoss()
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.device = next(shell.parameters()).device
+        self.kparams = list(shell.kernel.parameters())
+        self.aparams = list(shell.alphas())
+        self.fp = FlatParams(self.kparams, self.device)
+        self.aflat, self.agrad, _ = flatten_params(self.aparams, self.device)
+        self.a_m = torch.zeros_like(self.aflat)
+        self.a_v = torch.zeros_like(self.aflat)
+        self.a_step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.ctx = K.StepContext(self.device)
+        self.use_graph = graph
+        self._graph = None
+
+    def _pass(self, x, t, arch):
+        for p in self.kparams:
+            p.requires_grad_(not arch)
+        for p in self.aparams:
+            p.requires_grad_(arch)
+        if arch:
+            self.agrad.zero_()  # alpha gradients arrive through autograd accumulation (softmax backward)
+        with K.step_context(self.ctx):
+            self.ctx.pack_all()
+            loss = self.loss_fn(self.model(x), t)
+            loss.backward()
+            self.ctx.flush_final()
+        if not self.ctx.frozen and not arch:
+            self.ctx.freeze()
+        if arch:
+            K.adam_step(self.aflat, self.agrad, self.a_m, self.a_v, self.a_step, self.lr, self.betas[0], self.betas[1], self.eps)
+        else:
+            self.fp.adam(self.lr, self.betas, self.eps)
+        return loss.detach()
+
+    def _both(self, x, t, vx, vt):
+        la = self._pass(vx, vt, True)
+        lw = self._pass(x, t, False)
+        return la, lw
+
+    def step(self, x, t, val_x, val_t):
+        """returns (architecture-pass loss, weight-pass loss) as device scalars"""
+        if not self.use_graph:
+            return self._both(x, t, val_x, val_t)
+        if self._graph is None:
+            self._sx, self._st, self._svx, self._svt = x.clone(), t.clone(), val_x.clone(), val_t.clone()
+            keep = (self.fp.flat.clone(), self.aflat.clone())
+            s = torch.cuda.Stream(device=self.device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    self._both(self._sx, self._st, self._svx, self._svt)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            # undo the warm-up updates (weights, alphas, Adam moments and step counters)
+            self.fp.flat.copy_(keep[0]); self.aflat.copy_(keep[1])
+            for z in (self.fp.exp_avg, self.fp.exp_avg_sq, self.a_m, self.a_v):
+                z.zero_()
+            self.fp.step.zero_(); self.a_step.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._losses = self._both(self._sx, self._st, self._svx, self._svt)
+            self._graph = g
+        self._sx.copy_(x); self._st.copy_(t); self._svx.copy_(val_x); self._svt.copy_(val_t)
+        self._graph.replay()
+        return self._losses
