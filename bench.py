@@ -46,12 +46,13 @@ def synthetic_batch(batch, size, seed):
     return x.astype(np.float32), np.broadcast_to(t, (batch,) + t.shape).copy()
 
 
-def conv_kernel_roofline(device, batch, size, iters=20):
-    """Time the dominant kernel -- the 3x3x3 stride-1 conv at C=4 on (batch, 4, size^3), the shape of
-    up-cell 4 (43 % of the net's FLOPs) -- with HIP events on the launch stream."""
-    import ctypes as C
-    from nas_3d_unet_amd import _lib, kernels as K
-    lib = _lib.load()
+def conv_kernel_roofline(device, batch, size, iters=40):
+    """Time the dominant FLOP kernel -- the 3x3x3 stride-1 conv at C=4 on (batch, 4, size^3), the shape of up-cell 4
+    (43 % of the net's FLOPs; the same kernel serves its data gradient) -- with HIP events on the launch stream.
+    The launches are replayed from a HIP graph with pre-packed weights, so the figure is kernel time plus the
+    ~1.7 us dependent-launch boundary, not host launch cost.  Algorithmic FLOPs = 2*B*S^3*C*C*27 per launch,
+    algorithmic bytes = input + output tensor."""
+    from nas_3d_unet_amd import kernels as K
     c = 4
     x = K.as_view(K.empty_ndhwc(batch, c, size, size, size, device).normal_())
     y = K.as_view(K.empty_ndhwc(batch, c, size, size, size, device))
@@ -60,29 +61,62 @@ def conv_kernel_roofline(device, batch, size, iters=20):
     g = K.conv_geom(batch, size, size, size, c, c, 3, 1, 1, 1)
     rows = K.conv_stats_rows(g, False)
     stats = torch.empty((batch, rows, c, 2), dtype=torch.float64, device=device)
+    ctx = K.StepContext(device)
+    with K.step_context(ctx):
+        K.conv_fwd(g, x, w, b, y, 0, None, stats, False)   # records the pack job
+        ctx.freeze()
+        ctx.pack_all()
+        K.conv_fwd(g, x, w, b, y, 0, None, stats, False)   # pre-packed path
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph):
+                for _ in range(iters):
+                    K.conv_fwd(g, x, w, b, y, 0, None, stats, False)
     stream = torch.cuda.current_stream()
-    for _ in range(3):
-        K.conv_fwd(g, x, w, b, y, 0, None, stats, False)
+    graph.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
     e0.record(stream)
-    for _ in range(iters):
-        K.conv_fwd(g, x, w, b, y, 0, None, stats, False)
+    for _ in range(reps):
+        graph.replay()
     e1.record(stream)
     e1.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    sec = e0.elapsed_time(e1) * 1e-3 / (iters * reps)
     flops = 2.0 * batch * size ** 3 * c * c * 27
     bytes_ = 2.0 * batch * size ** 3 * c * 4
     ach = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": "conv3x3x3 s1 d1 C=4 fwd (incl. weight pack + GN-stats epilogue)",
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_vox64.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"bound": "mfma", "kernel": "conv_vox64_kernel<4,4,1>: 3x3x3 s1 d1 conv, C=4, (%d,4,%d^3), GN-stats epilogue" % (batch, size),
             "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
-            "us_per_launch": round(sec * 1e6, 2), "algorithmic_gbs": round(bytes_ / sec / 1e9, 1), "traffic": None}
+            "us_per_launch": round(sec * 1e6, 2), "algorithmic_flop_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
+            "algorithmic_gbs": round(bytes_ / sec / 1e9, 1), "traffic": traffic}
+
+
+def usable_cores():
+    """cores this process may really use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def cpu_baseline(batch, size, budget_s=25.0):
     """The CPU oracle (functional torch-CPU restatement, proven equal to the reference by the golden
     tests) timed on this box's host cores: forward + Dice + backward at the same batch."""
     from oracle import ref_path as orc
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     P = orc.make_params(orc.searched_param_specs(orc.DEFAULT_CFG, orc.G_CONV), requires_grad=True)
     xn, tn = synthetic_batch(batch, size, 99)
@@ -96,7 +130,7 @@ def cpu_baseline(batch, size, budget_s=25.0):
     one()  # warm-up
     times = []
     t_all = time.perf_counter()
-    while len(times) < 5 and (time.perf_counter() - t_all) < budget_s:
+    while len(times) < 7 and (time.perf_counter() - t_all) < budget_s:
         t0 = time.perf_counter()
         one()
         times.append(time.perf_counter() - t0)

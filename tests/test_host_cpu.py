@@ -1,0 +1,133 @@
+"""CPU-only tests of the host side: C-ABI symbol coverage, module surface / state-dict parity, segment
+building, error behaviour, genotype decoding.  No kernel is launched here."""
+import importlib
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import golden_common as gc
+from oracle import ref_path as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nas_3d_unet_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "n3d.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(n3d_[a-zA-Z0-9_]+)\s*\(", hdr))
+    declared -= {"n3d_conv_geom", "n3d_pack_job", "n3d_final_job"}
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libn3d.so does not export %s" % name
+    assert declared == set(_lib.PROTOTYPES), (declared ^ set(_lib.PROTOTYPES))
+    assert lib.n3d_version() >= 1
+    assert isinstance(lib.n3d_last_error(), bytes)
+
+
+def test_registry_surface(golden):
+    from nas_3d_unet_amd import prim_ops
+    g = golden("small")
+    assert list(prim_ops.OPS.keys()) == list(g["registry/OPS"])
+    assert prim_ops.DownOps == list(g["registry/DownOps"])
+    assert prim_ops.UpOps == list(g["registry/UpOps"])
+    assert prim_ops.NormOps == list(g["registry/NormOps"])
+
+
+def test_state_dict_inventory_matches_reference(golden):
+    from nas_3d_unet_amd import nas, searched
+    g = golden("small")
+    for gname in ("G_CONV", "G_ALL"):
+        m = searched.SearchedNet(4, 4, 3, 4, 3, True, searched.Genotype(*getattr(orc, gname)))
+        mine = {k: str(tuple(v.shape)) for k, v in m.state_dict().items()}
+        ref = dict(zip(g["inventory/searched/%s/names" % gname], g["inventory/searched/%s/shapes" % gname]))
+        assert mine == ref
+    m = nas.ShellNet(4, 4, 3, 4, 3, False, True)
+    mine = {k: str(tuple(v.shape)) for k, v in m.state_dict().items()}
+    assert mine == dict(zip(g["inventory/supernet/names"], g["inventory/supernet/shapes"]))
+    assert [n for n, _ in m._alphas] == ["alpha2_down", "alpha2_up", "alpha1_down", "alpha1_up"]
+
+
+def test_segment_building_and_errors():
+    from nas_3d_unet_amd import prim_ops
+    from nas_3d_unet_amd._lib import N3DError
+    op = prim_ops.ConvOps(4, 8, ops_order="weight_norm_act")
+    segs = op._build_segments()
+    assert len(segs) == 1 and segs[0].norm is op.norm and segs[0].relu_out and not segs[0].relu_in
+    op = prim_ops.ConvOps(4, 8, kernel_size=1, ops_order="act_weight_norm")
+    segs = op._build_segments()
+    assert len(segs) == 1 and segs[0].relu_in and not segs[0].relu_out and segs[0].norm is op.norm
+    op = prim_ops.ConvOps(4, 8, ops_order="norm_weight_act")       # not a canonical order: two segments
+    assert len(op._build_segments()) == 2
+    assert len(prim_ops.SEConvOp(8, 8)._build_segments()) == 1      # stride 1: forced to 'weight'
+    assert prim_ops.SEConvOp(8, 8).norm is None and prim_ops.SEConvOp(8, 8, stride=2).norm is not None
+    with pytest.raises(Warning):
+        prim_ops.ConvOps(4, 4, ops_order="weight_bogus")(torch.zeros(1, 4, 2, 2, 2))
+    with pytest.raises(NotImplementedError):
+        prim_ops.PoolingOp(4, 4, "median")
+    with pytest.raises(N3DError):                                    # no CPU fallback
+        prim_ops.OPS["conv"](4)(torch.zeros(1, 4, 4, 4, 4))
+    # group rule and padding formula of the reference
+    assert [prim_ops.P.group_count(c) for c in (4, 8, 12, 16, 32, 64)] == [1, 1, 1, 1, 2, 4]
+    assert [prim_ops._padding(3, s, d) for s, d in ((1, 1), (1, 2), (2, 1), (2, 2))] == [1, 2, 1, 2]
+    assert prim_ops._padding(1, 1, 1) == 0 and prim_ops._padding(1, 2, 1) == 0
+
+
+@pytest.mark.parametrize("key", gc.geno_cases())
+def test_genotype_parser(golden, key):
+    from nas_3d_unet_amd.genotype import GenoParser
+    g = golden("small")
+    p = GenoParser(3)
+    a1 = gc.case_alpha_matrix(key + "/a1", 9, 5)
+    gd = p.parse(a1, gc.case_alpha_matrix(key + "/a2d", 9, 6), True)
+    gu = p.parse(a1, gc.case_alpha_matrix(key + "/a2u", 9, 4), False)
+    assert [n for n, _ in gd] == list(g[key + "/down_names"]) and [i for _, i in gd] == list(g[key + "/down_idx"])
+    assert [n for n, _ in gu] == list(g[key + "/up_names"]) and [i for _, i in gu] == list(g[key + "/up_idx"])
+
+
+def test_fresh_shellnet_genotype_is_the_degenerate_one():
+    from nas_3d_unet_amd import nas
+    gene = nas.ShellNet(4, 4, 3, 2, 3, False, True).get_gene()   # zero alphas
+    assert [n for n, _ in gene.down][:3] == ["avg_pool", "avg_pool", "avg_pool"]
+    assert gene.up[0][0] == "identity"
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference sources only exist in the build container")
+def test_dropin_under_the_reference_network_files():
+    """The reference's nas.py / searched.py, UNCHANGED, import this repo's prim_ops / cell:
+    the nets build, and their state_dicts equal those built on the reference's own modules."""
+    import nas_3d_unet_amd.cell, nas_3d_unet_amd.genotype, nas_3d_unet_amd.prim_ops
+    saved = {k: sys.modules.get(k) for k in ("prim_ops", "cell", "genotype", "nas", "searched")}
+    sys.path.insert(0, "/root/reference")
+    try:
+        for k in saved:
+            sys.modules.pop(k, None)
+        ref_nas = importlib.import_module("nas")
+        ref_searched = importlib.import_module("searched")
+        ref_sd = {k: tuple(v.shape) for k, v in ref_nas.ShellNet(4, 4, 3, 4, 3, False, True).state_dict().items()}
+        ref_sd2 = {k: tuple(v.shape) for k, v in
+                   ref_searched.SearchedNet(4, 4, 3, 4, 3, True, ref_searched.Genotype(*orc.G_ALL)).state_dict().items()}
+        for k in saved:
+            sys.modules.pop(k, None)
+        sys.modules["prim_ops"] = nas_3d_unet_amd.prim_ops
+        sys.modules["cell"] = nas_3d_unet_amd.cell
+        sys.modules["genotype"] = nas_3d_unet_amd.genotype
+        drop_nas = importlib.import_module("nas")
+        drop_searched = importlib.import_module("searched")
+        assert drop_nas.Cell is nas_3d_unet_amd.cell.Cell
+        m = drop_nas.ShellNet(4, 4, 3, 4, 3, False, True)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == ref_sd
+        m2 = drop_searched.SearchedNet(4, 4, 3, 4, 3, True, drop_searched.Genotype(*orc.G_ALL))
+        assert {k: tuple(v.shape) for k, v in m2.state_dict().items()} == ref_sd2
+        assert isinstance(m2.down_cells[0]._ops[0], nas_3d_unet_amd.prim_ops.SEConvOp)
+    finally:
+        sys.path.remove("/root/reference")
+        for k, v in saved.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
