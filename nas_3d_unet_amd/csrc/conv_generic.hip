@@ -39,7 +39,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   wp[i] = v;
 }
 
-template <int CO_T, int SV>
+template <int CO_T, int SV, int CSQ>
 __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
   __shared__ double red[4][CO_T * 2];
   const int b = blockIdx.z, cot = blockIdx.y;
@@ -61,6 +61,96 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
   const float* gate = a.in_gate ? a.in_gate + (int64_t)b * a.Cs : nullptr;
   const bool relu_in = a.flags & N3D_RELU_IN;
   const int k = a.k;
+  // Weights: every lane of the block needs the same [tap][cs][CO_T] tile.  Scalar (SMEM) loads serialise on one
+  // memory latency per tap (measured: ~0.7 us per tap, 22 us per k3 conv whatever its size), so the small-Cs path
+  // stages the tile once in LDS (<= 27*12*16 floats) and reads it back with broadcast ds_read_b128.
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  if (SV == 4 && CSQ > 0) {
+    const int ntile = k * k * k * CSQ * 4 * CO_T;
+    for (int i = threadIdx.x; i < ntile; i += 256) {
+      const int co = i % CO_T, r = i / CO_T;  // r = tap*Cs + cs
+      wlds[i] = a.wp[(int64_t)r * a.Cdp + cot * CO_T + co];
+    }
+    __syncthreads();
+  }
+  if (SV == 4 && CSQ > 0) {
+    // Few input channels (Cs = 4*CSQ <= 12): the loads of a whole (kh, kw) plane of taps (CSQ <= 2) or of one kw row
+    // (CSQ == 3) are issued back to back from clamped addresses, then consumed -- no branch between a load and the
+    // next one, so a thread pays one memory latency per plane instead of one per tap.
+    constexpr int RB = (CSQ <= 2) ? 3 : 1;   // kh rows per batch
+    const float relu_floor = relu_in ? 0.f : -INFINITY;
+    float gv[CSQ > 0 ? CSQ * 4 : 1];
+#pragma unroll
+    for (int e = 0; e < CSQ * 4; ++e) gv[e] = gate ? gate[e] : 1.f;
+    for (int kd = 0; kd < k; ++kd) {
+      int nd = d_ * a.sn + a.off + kd * a.dt;
+      bool okd = valid;
+      if (a.den == 2) { okd = okd && !(nd & 1); nd >>= 1; }
+      okd = okd && nd >= 0 && nd < a.Ds;
+      const int cd_ = min(max(nd, 0), a.Ds - 1);
+      for (int kh0 = 0; kh0 < k; kh0 += RB) {
+        float4 xq[RB][3][CSQ > 0 ? CSQ : 1];
+        bool okv[RB][3];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int kh = kh0 + r;
+          int nh = h_ * a.sn + a.off + kh * a.dt;
+          bool okh = okd && kh < k;
+          if (a.den == 2) { okh = okh && !(nh & 1); nh >>= 1; }
+          okh = okh && nh >= 0 && nh < a.Hs;
+          const int ch_ = min(max(nh, 0), a.Hs - 1);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            int nw = w_ * a.sn + a.off + kw * a.dt;
+            bool ok = okh && kw < k;
+            if (a.den == 2) { ok = ok && !(nw & 1); nw >>= 1; }
+            ok = ok && nw >= 0 && nw < a.Ws;
+            okv[r][kw] = ok;
+            const int cw_ = min(max(nw, 0), a.Ws - 1);
+            const float* xs = srcb + (((int64_t)cd_ * a.Hs + ch_) * a.Ws + cw_) * a.sld;
+#pragma unroll
+            for (int q = 0; q < CSQ; ++q) xq[r][kw][q] = *reinterpret_cast<const float4*>(xs + q * 4);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int kh = kh0 + r;
+          if (kh >= k) continue;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            if (kw >= k) continue;
+            const int tap = (kd * k + kh) * k + kw;
+            const float* wr = wlds + tap * (CSQ * 4) * CO_T;
+            const bool ok = okv[r][kw];
+            // branch-free operand preparation (a uniform branch here would fence every LDS weight read behind a wait)
+            float xe[CSQ > 0 ? CSQ * 4 : 1];
+#pragma unroll
+            for (int q = 0; q < CSQ; ++q) {
+              const float xv[4] = {xq[r][kw][q].x, xq[r][kw][q].y, xq[r][kw][q].z, xq[r][kw][q].w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float x = ok ? xv[j] : 0.f;
+                x = fmaxf(x, relu_floor);
+                xe[q * 4 + j] = x * gv[q * 4 + j];
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < CSQ * 4; ++e) {
+              const float4* wrow = reinterpret_cast<const float4*>(wr + e * CO_T);
+#pragma unroll
+              for (int c4 = 0; c4 < CO_T / 4; ++c4) {
+                const float4 wv = wrow[c4];
+                acc[c4 * 4 + 0] = fmaf(xe[e], wv.x, acc[c4 * 4 + 0]);
+                acc[c4 * 4 + 1] = fmaf(xe[e], wv.y, acc[c4 * 4 + 1]);
+                acc[c4 * 4 + 2] = fmaf(xe[e], wv.z, acc[c4 * 4 + 2]);
+                acc[c4 * 4 + 3] = fmaf(xe[e], wv.w, acc[c4 * 4 + 3]);
+              }
+            }
+          }
+        }
+      }
+    }
+  } else
   for (int kd = 0; kd < k; ++kd) {
     int nd = d_ * a.sn + a.off + kd * a.dt;
     bool okd = true;
@@ -81,17 +171,25 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
         if (ok) {
           const float* xs = srcb + (((int64_t)nd * a.Hs + nh) * a.Ws + nw) * a.sld;
           if (SV == 4) {
-            for (int c4 = 0; c4 < a.Cs; c4 += 4) {
-              float4 q = *reinterpret_cast<const float4*>(xs + c4);
-              float xv[4] = {q.x, q.y, q.z, q.w};
+            // four 16-byte loads in flight per step
+            for (int c16 = 0; c16 < a.Cs; c16 += 16) {
+              float4 q4[4];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                float x = xv[j];
-                if (relu_in) x = fmaxf(x, 0.f);
-                if (gate) x *= gate[c4 + j];
-                const float* wrow = wr + (int64_t)(c4 + j) * a.Cdp;
+              for (int u = 0; u < 4; ++u) q4[u] = *reinterpret_cast<const float4*>(xs + min(c16 + u * 4, a.Cs - 4));
 #pragma unroll
-                for (int co = 0; co < CO_T; ++co) acc[co] = fmaf(x, wrow[co], acc[co]);
+              for (int u = 0; u < 4; ++u) {
+                const int c4 = c16 + u * 4;
+                if (c4 >= a.Cs) break;
+                const float xv[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  float x = xv[j];
+                  if (relu_in) x = fmaxf(x, 0.f);
+                  if (gate) x *= gate[c4 + j];
+                  const float* wrow = wr + (int64_t)(c4 + j) * a.Cdp;
+#pragma unroll
+                  for (int co = 0; co < CO_T; ++co) acc[co] = fmaf(x, wrow[co], acc[co]);
+                }
               }
             }
           } else {
@@ -169,8 +267,12 @@ static void launch_gather_t(const GatherArgs& a, int B, hipStream_t s) {
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
   dim3 grid((unsigned)cdiv(Nd, 256), (unsigned)(a.Cdp / CO_T), (unsigned)B);
   const bool vec = (a.Cs % 4 == 0) && (a.sld % 4 == 0) && aligned16(a.src);
-  if (vec) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((conv_gather_kernel<CO_T, 1>), grid, dim3(256), 0, s, a);
+  const size_t wbytes = (size_t)a.k * a.k * a.k * a.Cs * CO_T * sizeof(float);
+  if (!vec) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 1, 0>), grid, dim3(256), 0, s, a);
+  else if (a.Cs == 4) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4, 1>), grid, dim3(256), wbytes, s, a);
+  else if (a.Cs == 8) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4, 2>), grid, dim3(256), wbytes, s, a);
+  else if (a.Cs == 12) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4, 3>), grid, dim3(256), wbytes, s, a);
+  else hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4, 0>), grid, dim3(256), 0, s, a);
 }
 
 static void launch_gather(const GatherArgs& a, int B, hipStream_t s) {

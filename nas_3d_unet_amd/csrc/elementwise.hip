@@ -12,11 +12,13 @@ namespace n3d {
 // ------------------------------------------------------------------------------------------------
 template <int NV>
 __device__ __forceinline__ void block_reduce_to_row(double (&vals)[NV * 4], int cpb, double* __restrict__ row,
-                                                    double* lds /* [4 waves][cpb max 64][NV*4] */) {
+                                                    double* lds /* [4 waves][cpb max 64][NV*4] */, bool wave_done = false) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  if (!wave_done) {
 #pragma unroll
-  for (int q = 0; q < NV * 4; ++q) vals[q] = wave_sum_strided(vals[q], cpb);
+    for (int q = 0; q < NV * 4; ++q) vals[q] = wave_sum_strided(vals[q], cpb);
+  }
   // the class of lane l (< cpb) in this wave is (wave*64 + l) % cpb
   if (lane < cpb) {
     const int c4 = (wave * 64 + lane) % cpb;
@@ -208,11 +210,19 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(const float* __r
       }
     }
   }
+  // the wave-level stage runs in fp32 (<= 64 lanes x <= 4 partials each), the cross-wave / cross-row stages in fp64
   double vals[12];
+  if (is_pow2(m.cpb)) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { vals[j] = s1[j]; vals[4 + j] = s2[j]; vals[8 + j] = sz[j]; }
+    for (int j = 0; j < 4; ++j) {
+      vals[j] = wave_classsum_f(s1[j], m.cpb); vals[4 + j] = wave_classsum_f(s2[j], m.cpb); vals[8 + j] = wave_classsum_f(sz[j], m.cpb);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { vals[j] = s1[j]; vals[4 + j] = s2[j]; vals[8 + j] = sz[j]; }
+  }
   double* row = sums + ((int64_t)b * gridDim.x + blockIdx.x) * C * 3;
-  block_reduce_to_row<3>(vals, m.cpb, row, lds);
+  block_reduce_to_row<3>(vals, m.cpb, row, lds, is_pow2(m.cpb));
 }
 
 // GroupNorm backward coefficients.  One workgroup of 256*BP threads: thread (bl = tid/256, t = tid%256) works on

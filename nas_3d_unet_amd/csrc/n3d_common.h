@@ -91,8 +91,53 @@ static inline EwMap ew_map(int64_t N, int C) {
 }
 
 #ifdef __HIPCC__
-// sum over the lanes of a wave that share (lane % cpb); result valid in lanes < cpb
+// ---- cross-lane sums.  A lone wave issues ~1 instruction per 4-5 cycles, so on the small tensors of the deep
+// U-net levels kernel time IS the dynamic instruction count: reductions use DPP row operations (1 instruction per
+// step and 32-bit half) instead of ds_bpermute sequences (~8 instructions per step).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float swz16_f(float v) {  // lane i <- lane i ^ 16 (ds_swizzle bit mode: xor 0x10, and 0x1f)
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+__device__ __forceinline__ double swz16_d(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_ds_swizzle((int)(b & 0xffffffffll), 0x401F);
+  const int hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), 0x401F);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// every lane ends up with the sum over the lanes of its class (lane % cpb), cpb a power of two <= 64
+__device__ __forceinline__ float wave_classsum_f(float v, int cpb) {
+  if (cpb <= 1) v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (cpb <= 2) v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (cpb <= 4) v += dpp_f<0x124>(v);   // row_ror:4
+  if (cpb <= 8) v += dpp_f<0x128>(v);   // row_ror:8
+  if (cpb <= 16) v += swz16_f(v);
+  if (cpb <= 32) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_classsum_d(double v, int cpb) {
+  if (cpb <= 1) v += dpp_d<0xB1>(v);
+  if (cpb <= 2) v += dpp_d<0x4E>(v);
+  if (cpb <= 4) v += dpp_d<0x124>(v);
+  if (cpb <= 8) v += dpp_d<0x128>(v);
+  if (cpb <= 16) v += swz16_d(v);
+  if (cpb <= 32) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ bool is_pow2(int x) { return (x & (x - 1)) == 0; }
+
+// sum over the lanes of a wave that share (lane % cpb); result valid in lanes < cpb (any cpb <= 64)
 __device__ __forceinline__ double wave_sum_strided(double v, int cpb) {
+  if (is_pow2(cpb)) return wave_classsum_d(v, cpb);
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
@@ -105,6 +150,7 @@ __device__ __forceinline__ double wave_sum_strided(double v, int cpb) {
   return v;
 }
 __device__ __forceinline__ float wave_sum_strided_f(float v, int cpb) {
+  if (is_pow2(cpb)) return wave_classsum_f(v, cpb);
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) {
@@ -116,16 +162,8 @@ __device__ __forceinline__ float wave_sum_strided_f(float v, int cpb) {
   }
   return v;
 }
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
-  return v;
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
-  return v;
-}
+__device__ __forceinline__ float wave_sum_f(float v) { return wave_classsum_f(v, 1); }
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_classsum_d(v, 1); }
 #endif
 
 }  // namespace n3d

@@ -22,7 +22,9 @@ int main(int argc, char** argv) {
   err_t lerr = (err_t)dlsym(h, "n3d_last_error");
   int C = atoi(argv[2]), D = atoi(argv[3]), H = atoi(argv[4]), W = atoi(argv[5]), dil = atoi(argv[6]), B = atoi(argv[7]), iters = atoi(argv[8]);
   int flags = argc > 9 ? atoi(argv[9]) : 0;
-  n3d_conv_geom g = {B, D, H, W, C, D, H, W, C, 3, 1, dil, dil, 0};
+  int stride = argc > 10 ? atoi(argv[10]) : 1;
+  int Do = (D + 2 * dil - dil * 2 - 1) / stride + 1, Ho = (H + 2 * dil - dil * 2 - 1) / stride + 1, Wo = (W + 2 * dil - dil * 2 - 1) / stride + 1;
+  n3d_conv_geom g = {B, D, H, W, C, Do, Ho, Wo, C, 3, stride, dil, dil, 0};
   size_t n = (size_t)B * D * H * W * C;
   float *x, *y, *w, *bias; void* ws; double* stats;
   hipMalloc(&x, n * 4); hipMalloc(&y, n * 4); hipMalloc(&w, C * C * 27 * 4); hipMalloc(&bias, C * 4);
