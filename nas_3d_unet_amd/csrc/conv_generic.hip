@@ -642,24 +642,34 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
 }
 
 __global__ __launch_bounds__(256) void wgrad_final_batch_kernel(FinalJobs jobs) {
+  // 32 outputs x 8 chunk segments per workgroup: the slab rows are summed 8-way in parallel and combined in LDS
+  // in a fixed order (deterministic), instead of one thread walking up to 512 slabs.
+  __shared__ float seg[8][32];
   const n3d_final_job jb = jobs.j[blockIdx.y];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int oi = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + oi;
   const int nw = jb.Co * jb.Ci * jb.taps;
   const int T = jb.ci_t * jb.co_t;
+  float s = 0.f;
   if (i < nw) {
     if (jb.dw) {
       const int tap = i % jb.taps, ci = (i / jb.taps) % jb.Ci, co = i / (jb.taps * jb.Ci);
       const int tile = (tap * jb.tci + ci / jb.ci_t) * jb.tco + co / jb.co_t;
       const int q = (ci % jb.ci_t) * jb.co_t + (co % jb.co_t);
-      float s = 0.f;
-      for (int c = 0; c < jb.nchunks; ++c) s += jb.partial[((int64_t)c * jb.ntiles + tile) * T + q];
-      jb.dw[i] = s;
+      for (int c = sg; c < jb.nchunks; c += 8) s += jb.partial[((int64_t)c * jb.ntiles + tile) * T + q];
     }
   } else if (i < nw + jb.Co && jb.dbias) {
     const int co = i - nw;
-    float s = 0.f;
-    for (int c = 0; c < jb.nchunks; ++c) s += jb.pbias[((int64_t)c * jb.tco + co / jb.co_t) * jb.co_t + co % jb.co_t];
-    jb.dbias[co] = s;
+    for (int c = sg; c < jb.nchunks; c += 8) s += jb.pbias[((int64_t)c * jb.tco + co / jb.co_t) * jb.co_t + co % jb.co_t];
+  }
+  seg[sg][oi] = s;
+  __syncthreads();
+  if (sg == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += seg[k][oi];
+    if (i < nw) { if (jb.dw) jb.dw[i] = tot; }
+    else if (i < nw + jb.Co && jb.dbias) jb.dbias[i - nw] = tot;
   }
 }
 
@@ -739,6 +749,8 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
                   void* ws, size_t ws_bytes, hipStream_t s);
 int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags);
 int mfma_pack_layout(const n3d_conv_geom* g, bool data_grad, int flags);  // 1 gemm16, 2 vox64, 0 none
+int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
+                  float* partial, size_t avail_floats, int* nchunks_out, hipStream_t s);
 int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                    float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s);
 }
@@ -757,6 +769,10 @@ size_t n3d_conv_workspace_bytes(const n3d_conv_geom* g) {
     WgradPlan p1 = wgrad_plan(g->B, No, g->Ci, g->Co, taps);
     WgradPlan p2 = wgrad_plan(g->B, No, g->Co, g->Ci, taps);  // transposed roles
     size_t a = (p1.partial_floats + p1.pbias_floats) * 4, b = (p2.partial_floats + p2.pbias_floats) * 4;
+    if (g->k == 3 && g->Ci == g->Co && (g->Ci == 4 || g->Ci == 8)) {  // vox64 weight-gradient slabs: <= 1024 workgroups
+      const size_t c = (size_t)1024 * 27 * g->Ci * g->Ci * 4;
+      if (c > a) a = c;
+    }
     if (g->Ci % 16 == 0 && g->Co % 16 == 0) {  // MFMA weight-gradient slabs (conv_mfma.hip)
       const size_t nt = (size_t)taps * (g->Ci / 16) * (g->Co / 16);
       const size_t c = (1024 + nt) * (256 + 16) * 4;
@@ -892,6 +908,22 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   // dense: the kernel computes G[co'][ci'][tap] = sum dyK[o][co'] * xK[i(o,tap)][ci'] with xK on the i side.
   // forward conv: xK = x (Ci), dyK = dy (Co), dw native (Co,Ci,k^3) = G.
   // transposed conv (weight (CinT=Co_geom, CoutT=Ci_geom)): xK = dy_T (i side, Ci), dyK = x_T (o side, Co): same G layout.
+  if (!dbias || transposed) {
+    // vox64 weight gradient (3x3x3 stride 1, C = 4 / 8); it does not produce the bias gradient, which the callers on the
+    // hot path obtain analytically from the GroupNorm backward sums (n3d_gn_bwd_coeffs)
+    int nch = 0;
+    if (vox_wgrad_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, s) == 1) {
+      const int C = g->Ci, nout = C * C * taps;
+      if (deferred) {
+        fill_job(deferred, wsf, nullptr, dw, nullptr, nch, taps, 1, 1, C, C, C, C, taps);
+      } else {
+        hipLaunchKernelGGL(conv_wgrad_final_kernel, dim3((unsigned)cdiv(nout, 256)), dim3(256), 0, s, wsf, (const float*)nullptr, nch, taps, 1, 1,
+                           C, C, C, C, taps, dw, (float*)nullptr);
+      }
+      N3D_LAUNCH_CHECK();
+      return N3D_OK;
+    }
+  }
   if (!(flags & N3D_NO_MFMA) && xld % 4 == 0 && dyld % 4 == 0) {
     int nch = 0, ntl = 0;
     const size_t nt16 = (size_t)taps * (g->Ci / 16) * (g->Co / 16);
@@ -989,7 +1021,7 @@ int n3d_wgrad_finalize_batch(const n3d_final_job* jobs, int njobs, void* stream)
       if (el > maxel) maxel = el;
     }
     for (int i = n; i < N3D_FINAL_JOBS; ++i) fj.j[i] = fj.j[0];
-    hipLaunchKernelGGL(wgrad_final_batch_kernel, dim3((unsigned)cdiv(maxel, 256), n), dim3(256), 0, (hipStream_t)stream, fj);
+    hipLaunchKernelGGL(wgrad_final_batch_kernel, dim3((unsigned)cdiv(maxel, 32), n), dim3(256), 0, (hipStream_t)stream, fj);
   }
   N3D_LAUNCH_CHECK();
   return N3D_OK;

@@ -583,6 +583,179 @@ static int launch_vox_c(VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// vox64 weight gradient: 3x3x3 stride-1 (dilation 1/2) conv with C = 4 or 8:
+//   dW[tap][ci][co] = sum_v X[v + (tap-1)*dil][ci] * dY[v][co].
+// v_mfma_f32_4x4x1_16b_f32 again, now with the 16 blocks = 16 consecutive W voxels: block b multiplies the column
+// X[v_b + tap][ci 0..3] by the row dY[v_b][co 0..3]; the hardware accumulates one 4x4 tile per block over
+// successive issues (= over voxels), and the 16 block tiles are added with DPP class sums at the very end.
+//   A operand: ds_read_b32 from the LDS halo tile of X (16 voxels x 16 B contiguous -> conflict free);
+//   B operand: dY straight from HBM, one dword per lane and 16-voxel row, reused by all taps of the wave.
+// The 27 taps are split over the 4 waves (7/7/7/6), so each wave keeps 7*Q*Q accumulator tiles (28 / 112 VGPRs);
+// a workgroup walks several 4x4x16 tiles of one column before it reduces, which amortises the reduction and
+// keeps the number of partial slabs (= workgroups) at a few hundred.  Compared with the VALU kernel this is ~8x
+// fewer instructions per voxel, which is what matters at these sizes (a lone wave issues ~1 instruction / 4 cycles).
+// ------------------------------------------------------------------------------------------------
+struct VwArgs {
+  const float* x; int64_t xld;
+  const float* dy; int64_t dyld;
+  float* partial;       // [workgroup][27][C*C]
+  int D, H, W, dchunk;  // dchunk: planes per workgroup (multiple of 4)
+};
+
+template <int C, int DIL>
+__global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
+  constexpr int Q = C / 4, TD = 4, GH = 4, GW = 16;
+  constexpr int LD = TD + 2 * DIL, LH = GH + 2 * DIL, LW = GW + 2 * DIL;
+  constexpr int PLANE = LH * LW, QSTRIDE = LD * PLANE, NVOX = LD * PLANE;
+  extern __shared__ __attribute__((aligned(16))) float4 wtile[];  // [Q][LD][LH][LW]
+  const float* tf = reinterpret_cast<const float*>(wtile);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const int tw_n = a.W / GW, th_n = a.H / GH;
+  int bx = blockIdx.x;
+  const int w0 = (bx % tw_n) * GW; bx /= tw_n;
+  const int h0 = (bx % th_n) * GH;
+  const int dbeg = (bx / th_n) * a.dchunk;
+  const int64_t N = (int64_t)a.D * a.H * a.W;
+  const float* xb = a.x + (int64_t)b * N * a.xld;
+  const float* dyb = a.dy + (int64_t)b * N * a.dyld;
+  const int blk = lane >> 2, i4 = lane & 3;
+  const int tap0 = wave * 7;
+  // LDS float offset of this lane's A element for tap t (relative to the row base), and tap validity
+  int toff[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = (tap0 + t < 27) ? tap0 + t : 26;
+    const int kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
+    toff[t] = ((kd * DIL) * PLANE + (kh * DIL) * LW + kw * DIL + blk) * 4 + i4;
+  }
+  f32x4 acc[7][Q][Q];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int qa = 0; qa < Q; ++qa)
+#pragma unroll
+      for (int qb = 0; qb < Q; ++qb) acc[t][qa][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int d0 = dbeg; d0 < dbeg + a.dchunk; d0 += TD) {
+    // ---- stage the X halo tile (branch-free clamped loads, all in flight at once)
+    {
+      constexpr int NFI = (NVOX + 255) / 256;
+      float4 fv[NFI][Q];
+#pragma unroll
+      for (int i = 0; i < NFI; ++i) {
+        const int idx = (tid + i * 256 < NVOX) ? tid + i * 256 : NVOX - 1;
+        const int wx = idx % LW, hy = (idx / LW) % LH, dz = idx / PLANE;
+        const int gd = d0 - DIL + dz, gh = h0 - DIL + hy, gw = w0 - DIL + wx;
+        const bool inb = gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+        const int cd_ = min(max(gd, 0), a.D - 1), ch_ = min(max(gh, 0), a.H - 1), cw_ = min(max(gw, 0), a.W - 1);
+        const float* p = xb + (((int64_t)cd_ * a.H + ch_) * a.W + cw_) * a.xld;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(p + q * 4);
+          fv[i][q] = inb ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      __syncthreads();  // previous tile fully consumed
+#pragma unroll
+      for (int i = 0; i < NFI; ++i) {
+        const int idx = tid + i * 256;
+        if (idx < NVOX) {
+#pragma unroll
+          for (int q = 0; q < Q; ++q) wtile[q * QSTRIDE + idx] = fv[i][q];
+        }
+      }
+      __syncthreads();
+    }
+    // ---- 16 rows of 16 voxels: row r = (g, hh) -> output plane d0+g, row h0+hh.
+    // All dY values of the tile are requested first (one memory round trip per tile); no branch inside the MFMA
+    // loop (the 28th "tap" of wave 3 runs on a clamped address and is dropped at the end), so the compiler can
+    // batch the LDS reads ahead of the MFMAs.
+    float bvs[TD * GH][Q];
+#pragma unroll
+    for (int r = 0; r < TD * GH; ++r) {
+      const int g = r >> 2, hh = r & 3;
+      const float* dp = dyb + (((int64_t)(d0 + g) * a.H + h0 + hh) * a.W + w0 + blk) * a.dyld + i4;
+#pragma unroll
+      for (int qb = 0; qb < Q; ++qb) bvs[r][qb] = dp[qb * 4];
+    }
+#pragma unroll
+    for (int r = 0; r < TD * GH; ++r) {
+      const int g = r >> 2, hh = r & 3;
+      const int rbase = (g * PLANE + hh * LW) * 4;
+      float avs[7][Q];
+#pragma unroll
+      for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int qa = 0; qa < Q; ++qa) avs[t][qa] = tf[qa * QSTRIDE * 4 + rbase + toff[t]];
+#pragma unroll
+      for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int qa = 0; qa < Q; ++qa)
+#pragma unroll
+          for (int qb = 0; qb < Q; ++qb) acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(avs[t][qa], bvs[r][qb], acc[t][qa][qb], 0, 0, 0);
+    }
+  }
+  // ---- add the 16 block tiles (lanes with equal lane&3) and write this workgroup's slab
+  float* out = a.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 27) * (C * C);
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    if (tap0 + t < 27) {
+#pragma unroll
+      for (int qa = 0; qa < Q; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < Q; ++qb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sum = wave_classsum_f(acc[t][qa][qb][r], 4);
+            // D[blk][row r = ci][col lane&3 = co]
+            if (lane < 4) out[(tap0 + t) * (C * C) + (qa * 4 + r) * C + qb * 4 + lane] = sum;
+          }
+    }
+  }
+}
+
+struct VwPlan { bool ok; int C, dil, dchunk, tiles; size_t lds; };
+
+static VwPlan vw_plan(const n3d_conv_geom* g) {
+  VwPlan p; p.ok = false;
+  if (g->depthwise || g->k != 3 || g->stride != 1 || g->Ci != g->Co || (g->Ci != 4 && g->Ci != 8)) return p;
+  if (!(g->dil == 1 || g->dil == 2) || g->pad != g->dil) return p;
+  const int W = g->Wi, H = g->Hi, D = g->Di;
+  if (W % 16 != 0 || H % 4 != 0 || D % 4 != 0) return p;
+  const int columns = g->B * (H / 4) * (W / 16);
+  int nd = D / 4, dsplit = 1;
+  while (columns * dsplit < 384 && dsplit * 2 <= nd && nd % (dsplit * 2) == 0) dsplit *= 2;
+  p.ok = true; p.C = g->Ci; p.dil = g->dil; p.dchunk = D / dsplit;
+  p.tiles = (W / 16) * (H / 4) * dsplit;
+  p.lds = (size_t)(g->Ci / 4) * (4 + 2 * g->dil) * (4 + 2 * g->dil) * (16 + 2 * g->dil) * 16;
+  return p;
+}
+
+// returns 1 if handled: partial slabs laid out for conv_wgrad_final (ci_t = co_t = C, tci = tco = 1, ntiles = 27)
+int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
+                  float* partial, size_t avail_floats, int* nchunks_out, hipStream_t s) {
+  if ((flags & (N3D_RELU_IN | N3D_NO_MFMA)) || in_gate) return 0;
+  VwPlan p = vw_plan(g);
+  if (!p.ok || xld % 4 != 0 || !aligned16(x)) return 0;
+  const int nwg = p.tiles * g->B;
+  if ((size_t)nwg * 27 * p.C * p.C > avail_floats) return 0;
+  VwArgs a;
+  a.x = x; a.xld = xld; a.dy = dy; a.dyld = dyld; a.partial = partial; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.dchunk = p.dchunk;
+  dim3 grid(p.tiles, g->B);
+  if (p.C == 4) {
+    if (p.dil == 1) hipLaunchKernelGGL((vox_wgrad_kernel<4, 1>), grid, dim3(256), p.lds, s, a);
+    else hipLaunchKernelGGL((vox_wgrad_kernel<4, 2>), grid, dim3(256), p.lds, s, a);
+  } else {
+    if (p.dil == 1) hipLaunchKernelGGL((vox_wgrad_kernel<8, 1>), grid, dim3(256), p.lds, s, a);
+    else hipLaunchKernelGGL((vox_wgrad_kernel<8, 2>), grid, dim3(256), p.lds, s, a);
+  }
+  *nchunks_out = nwg;
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 struct G16Plan { int mt, nt, ksplit, rows_per_block; bool ok; };

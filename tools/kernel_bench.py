@@ -55,5 +55,7 @@ for (C, S) in ((64, 4), (32, 8), (16, 16), (8, 32), (4, 64)):
     bench("affine_act_bwd_reduce (E2)", lambda: K.affine_act_bwd_reduce(d, x, a, b, K.RELU))
     if r3 <= K.fused_max_rows():
         bench("affine_act_bwd_apply_gn (E3 fused)", lambda: K.affine_act_bwd_apply_gn(d, x, a, b, sums, r3, torch.nn.Parameter(gam), torch.nn.Parameter(bet), mr, None, sr, None, y, G, K.RELU))
+    gp, bp = torch.nn.Parameter(gam), torch.nn.Parameter(bet)
+    bench("gn_bwd_coeffs", lambda: K.gn_bwd_coeffs(sums, r3, gp, mr, None, B, C, G, S ** 3, None, bp, sr, None))
     A = torch.ones((B, C), device=dev)
     bench("affine_act_bwd_apply (E3)", lambda: K.affine_act_bwd_apply(d, x, a, b, A, A, A, y, K.RELU))
