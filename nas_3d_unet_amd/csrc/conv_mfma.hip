@@ -86,21 +86,32 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
 
   // K loop, software-pipelined by hand: the operands of group g+step are requested before the MFMAs of group g
   // issue, so each wave keeps one group of global loads in flight behind its matrix work.
+  // per-lane 32-bit voxel index math (tensors on this path are < 2^31 voxels); one 64-bit multiply-add per load
+  const float relu_floor = relu_in ? 0.f : -INFINITY;
+  int rbase[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) rbase[t] = rb[t] * a.Ds;
   auto load_group = [&](int g, float4 (&av)[MT], float4 (&bv)[NT]) {
     const int tap = (int)a.fC16.div((uint32_t)g), c16 = g - tap * c16n;
     // k is 1 or 3: constant divisors
     const int kd = (k == 3) ? tap / 9 : 0, kh = (k == 3) ? (tap % 9) / 3 : 0, kw = (k == 3) ? tap % 3 : 0;
+    const int od = a.off + kd * a.dt, oh = a.off + kh * a.dt, ow = a.off + kw * a.dt;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      int nd = rd[t] * a.sn + a.off + kd * a.dt, nh = rh[t] * a.sn + a.off + kh * a.dt, nw = rw[t] * a.sn + a.off + kw * a.dt;
+      int nd = rd[t] * a.sn + od, nh = rh[t] * a.sn + oh, nw = rw[t] * a.sn + ow;
       bool ok = rvalid[t];
       if (a.den == 2) { ok = ok && !((nd | nh | nw) & 1); nd >>= 1; nh >>= 1; nw >>= 1; }
-      ok = ok && nd >= 0 && nd < a.Ds && nh >= 0 && nh < a.Hs && nw >= 0 && nw < a.Ws;
-      // clamped address + select instead of a branch: the load is always issued
-      const int cd_ = min(max(nd, 0), a.Ds - 1), ch_ = min(max(nh, 0), a.Hs - 1), cw_ = min(max(nw, 0), a.Ws - 1);
-      const float* sp = a.src + ((int64_t)rb[t] * Ns + ((int64_t)cd_ * a.Hs + ch_) * a.Ws + cw_) * a.sld + kk * 4 + c16 * 16;
+      // unsigned compares fold the two-sided range tests
+      ok = ok && (unsigned)nd < (unsigned)a.Ds && (unsigned)nh < (unsigned)a.Hs && (unsigned)nw < (unsigned)a.Ws;
+      const int idx = ok ? ((rbase[t] + nd) * a.Hs + nh) * a.Ws + nw : 0;   // voxel 0 is always a legal address
+      const float* sp = a.src + (int64_t)idx * a.sld + kk * 4 + c16 * 16;
+#ifdef VOX_NO_LOAD
+      float4 v = make_float4((float)idx, 1.f, 2.f, 3.f);
+      (void)sp;
+#else
       float4 v = *reinterpret_cast<const float4*>(sp);
-      if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+#endif
+      v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
       if (a.in_gate) {
         const float4 gq = *reinterpret_cast<const float4*>(a.in_gate + (int64_t)rb[t] * a.Cs + c16 * 16 + kk * 4);
         v.x *= gq.x; v.y *= gq.y; v.z *= gq.z; v.w *= gq.w;
@@ -108,9 +119,19 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
       av[t] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int n = 0; n < NT; ++n) bv[n] = wp4[((int64_t)g * 4 + kk) * a.Cd + n0 + n * 16 + m];
+    for (int n = 0; n < NT; ++n) {
+#ifdef VOX_NO_LOAD
+      bv[n] = make_float4((float)g, 1.f, (float)m, 3.f);
+#else
+      bv[n] = wp4[((int64_t)g * 4 + kk) * a.Cd + n0 + n * 16 + m];
+#endif
+    }
   };
   auto mfma_group = [&](const float4 (&av)[MT], const float4 (&bv)[NT]) {
+#ifdef VOX_NO_MFMA
+    acc[0][0][0] += av[0].x * bv[0].x + av[0].y * bv[0].y + av[0].z * bv[0].z + av[0].w * bv[0].w;
+    return;
+#endif
     // two accumulator chains per tile (x,z / y,w): a dependent 16x16x4 MFMA has 40 cycles latency vs 32 issue
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -391,34 +412,49 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
     float4 wv[NWI];
 #pragma unroll
     for (int i = 0; i < NWI; ++i) { const int idx = lane + i * 64; wv[i] = wq4[idx < NW4 ? idx : NW4 - 1]; }
-    constexpr int NFI = (NVOX + 63) / 64;
-    float4 fv[NFI][Q];
+    // position-major fill: lane l owns the in-plane positions l and l+64 (< LH*LW) of EVERY plane, so the
+    // (hy, wx) decode, bounds tests and clamps are done once per position and each plane costs one add
+    // (VALU issue is a co-bottleneck of this kernel: 2.6 VALU per MFMA before this change).
+    constexpr int NPOS = (PLANE + 63) / 64;
+    float4 fv[NPOS][LD][Q];
+    bool okp[NPOS];
+    int lpos[NPOS];
 #pragma unroll
-    for (int i = 0; i < NFI; ++i) {
-      const int idx = (lane + i * 64 < NVOX) ? lane + i * 64 : NVOX - 1;
-      const int wx = idx % LW, hy = (idx / LW) % LH, dz = idx / PLANE;
-      const int gd = d0 - DIL + dz, gh = h0 - DIL + hy, gw = w0 - DIL + wx;
-      const bool inb = gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-      const int cd_ = min(max(gd, 0), a.D - 1), ch_ = min(max(gh, 0), a.H - 1), cw_ = min(max(gw, 0), a.W - 1);
-      const float* p = srcb + (((int64_t)cd_ * a.H + ch_) * a.W + cw_) * a.sld;
+    for (int i = 0; i < NPOS; ++i) {
+      const int pos = (lane + i * 64 < PLANE) ? lane + i * 64 : PLANE - 1;
+      lpos[i] = pos;
+      const int wx = pos % LW, hy = pos / LW;
+      const int gh = h0 - DIL + hy, gw = w0 - DIL + wx;
+      okp[i] = gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      const int ch_ = min(max(gh, 0), a.H - 1), cw_ = min(max(gw, 0), a.W - 1);
+      const float* prow = srcb + ((int64_t)ch_ * a.W + cw_) * a.sld;
+      const int64_t pstride = (int64_t)a.H * a.W * a.sld;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) {
+      for (int dz = 0; dz < LD; ++dz) {
+        const int gd = d0 - DIL + dz;
+        const bool inb = okp[i] && gd >= 0 && gd < a.D;
+        const int cd_ = min(max(gd, 0), a.D - 1);
+        const float* p = prow + cd_ * pstride;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
 #ifdef VOX_NO_LOAD
-        float4 v = make_float4(1.f, 1.f, 1.f, 1.f);
+          float4 v = make_float4(1.f, 1.f, 1.f, 1.f);
 #else
-        float4 v = *reinterpret_cast<const float4*>(p + q * 4);
+          float4 v = *reinterpret_cast<const float4*>(p + q * 4);
 #endif
-        fv[i][q] = inb ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+          fv[i][dz][q] = inb ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < NWI; ++i) { const int idx = lane + i * 64; if (idx < NW4) wl[idx] = wv[i]; }
 #pragma unroll
-    for (int i = 0; i < NFI; ++i) {
-      const int idx = lane + i * 64;
-      if (idx < NVOX) {
+    for (int i = 0; i < NPOS; ++i) {
+      if (lane + i * 64 < PLANE) {
 #pragma unroll
-        for (int q = 0; q < Q; ++q) tile[q * QSTRIDE + idx] = fv[i][q];
+        for (int dz = 0; dz < LD; ++dz)
+#pragma unroll
+          for (int q = 0; q < Q; ++q) tile[q * QSTRIDE + dz * PLANE + lpos[i]] = fv[i][dz][q];
       }
     }
   }

@@ -79,8 +79,18 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ rows, int
   // ncol <= 256 guaranteed by callers (C <= 64, NV <= 3 -> 192)
   const int q = t % ncol, rl = t / ncol;
   double s = 0;
-  if (rl < nrl)
-    for (int r = rl; r < nrows; r += nrl) s += rows[(int64_t)r * ncol + q];
+  if (rl < nrl) {
+    // a rolled "load; add" loop pays one memory latency per row: keep 8 independent loads in flight instead
+    int r = rl;
+    for (; r + 7 * nrl < nrows; r += 8 * nrl) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = rows[(int64_t)(r + u * nrl) * ncol + q];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < nrows; r += nrl) s += rows[(int64_t)r * ncol + q];
+  }
   lds_part[t] = s;
   __syncthreads();
   if (t < ncol) {
@@ -234,8 +244,17 @@ __device__ __forceinline__ void reduce_rows_b(const double* __restrict__ rows, i
   const int nrl = 256 / ncol > 0 ? 256 / ncol : 1;
   const int q = t % ncol, rl = t / ncol;
   double s = 0;
-  if (active && rl < nrl)
-    for (int r = rl; r < nrows; r += nrl) s += rows[(int64_t)r * ncol + q];
+  if (active && rl < nrl) {
+    int r = rl;
+    for (; r + 7 * nrl < nrows; r += 8 * nrl) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = rows[(int64_t)(r + u * nrl) * ncol + q];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < nrows; r += nrl) s += rows[(int64_t)r * ncol + q];
+  }
   lds_part[t] = s;
   __syncthreads();
   if (t < ncol) {
