@@ -323,64 +323,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int j = 0; j < CO_T; ++j) acc[i][j] = 0.f;
 #pragma unroll
   for (int j = 0; j < CO_T; ++j) bacc[j] = 0.f;
-  // two voxels per thread per iteration: both voxels' loads (dy and the tap-shifted x) are requested before any
-  // of them is consumed, from clamped addresses (no branch between a load and the next)
-  for (int64_t i = i0 + threadIdx.x; i < i1; i += 512) {
-    float dyv[2][CO_T], xv[2][CI_T];
-    bool okx[2];
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    uint32_t ub, uo, q1, uw, ud, uh;
+    a.fNo.divmod((uint32_t)i, ub, uo);
+    a.fWo.divmod(uo, q1, uw);
+    a.fHo.divmod(q1, ud, uh);
+    const int b = (int)ub, ow = (int)uw, oh = (int)uh, od = (int)ud;
+    float dyv[CO_T];
+    const float* dp = a.dy + i * a.dyld + cot * CO_T;
+    if (covec) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int64_t iu = i + 256 * u;
-      const bool in = iu < i1;
-      const int64_t ic = in ? iu : i0;
-      uint32_t ub, uo, q1, uw, ud, uh;
-      a.fNo.divmod((uint32_t)ic, ub, uo);
-      a.fWo.divmod(uo, q1, uw);
-      a.fHo.divmod(q1, ud, uh);
-      const int b = (int)ub, ow = (int)uw, oh = (int)uh, od = (int)ud;
-      const float* dp = a.dy + ic * a.dyld + cot * CO_T;
-      if (covec) {
-#pragma unroll
-        for (int j = 0; j < CO_T; j += 4) {
-          const float4 q = *reinterpret_cast<const float4*>(dp + j);
-          dyv[u][j] = q.x; dyv[u][j + 1] = q.y; dyv[u][j + 2] = q.z; dyv[u][j + 3] = q.w;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < CO_T; ++j) dyv[u][j] = (cot * CO_T + j < a.Co) ? dp[j] : 0.f;
+      for (int j = 0; j < CO_T; j += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(dp + j);
+        dyv[j] = q.x; dyv[j + 1] = q.y; dyv[j + 2] = q.z; dyv[j + 3] = q.w;
       }
-      if (!in) {
+    } else {
 #pragma unroll
-        for (int j = 0; j < CO_T; ++j) dyv[u][j] = 0.f;
-      }
-      const int id = od * a.stride - a.pad + kd * a.dil, ih = oh * a.stride - a.pad + kh * a.dil, iw = ow * a.stride - a.pad + kw * a.dil;
-      okx[u] = in && (unsigned)id < (unsigned)a.Di && (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
-      const int64_t vi = okx[u] ? (int64_t)b * Ni + ((int64_t)id * a.Hi + ih) * a.Wi + iw : 0;
-      const float* xp = a.x + vi * a.xld + cit * CI_T;
+      for (int j = 0; j < CO_T; ++j) dyv[j] = (cot * CO_T + j < a.Co) ? dp[j] : 0.f;
+    }
+    if (do_bias) {
 #pragma unroll
-      for (int c = 0; c < CI_T; c += 4) {
-        const float4 q = *reinterpret_cast<const float4*>(xp + c);
-        xv[u][c] = q.x; xv[u][c + 1] = q.y; xv[u][c + 2] = q.z; xv[u][c + 3] = q.w;
-      }
+      for (int j = 0; j < CO_T; ++j) bacc[j] += dyv[j];
+    }
+    const int id = od * a.stride - a.pad + kd * a.dil, ih = oh * a.stride - a.pad + kh * a.dil, iw = ow * a.stride - a.pad + kw * a.dil;
+    if (id < 0 || id >= a.Di || ih < 0 || ih >= a.Hi || iw < 0 || iw >= a.Wi) continue;
+    const float* xp = a.x + ((int64_t)b * Ni + ((int64_t)id * a.Hi + ih) * a.Wi + iw) * a.xld + cit * CI_T;
+    float xv[CI_T];
 #pragma unroll
-      for (int c = 0; c < CI_T; ++c) {
-        float x = okx[u] ? xv[u][c] : 0.f;
-        if (relu_in) x = fmaxf(x, 0.f);
-        if (a.in_gate) x *= a.in_gate[(int64_t)b * a.Ci + cit * CI_T + c];
-        xv[u][c] = x;
-      }
+    for (int c = 0; c < CI_T; c += 4) {
+      const float4 q = *reinterpret_cast<const float4*>(xp + c);
+      xv[c] = q.x; xv[c + 1] = q.y; xv[c + 2] = q.z; xv[c + 3] = q.w;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (do_bias) {
-#pragma unroll
-        for (int j = 0; j < CO_T; ++j) bacc[j] += dyv[u][j];
-      }
-#pragma unroll
-      for (int c = 0; c < CI_T; ++c)
-#pragma unroll
-        for (int j = 0; j < CO_T; ++j) acc[c][j] = fmaf(xv[u][c], dyv[u][j], acc[c][j]);
+    for (int c = 0; c < CI_T; ++c) {
+      if (relu_in) xv[c] = fmaxf(xv[c], 0.f);
+      if (a.in_gate) xv[c] *= a.in_gate[(int64_t)b * a.Ci + cit * CI_T + c];
     }
+#pragma unroll
+    for (int c = 0; c < CI_T; ++c)
+#pragma unroll
+      for (int j = 0; j < CO_T; ++j) acc[c][j] = fmaf(xv[c], dyv[j], acc[c][j]);
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -682,15 +664,7 @@ __global__ __launch_bounds__(256) void wgrad_final_batch_kernel(FinalJobs jobs) 
       const int tap = i % jb.taps, ci = (i / jb.taps) % jb.Ci, co = i / (jb.taps * jb.Ci);
       const int tile = (tap * jb.tci + ci / jb.ci_t) * jb.tco + co / jb.co_t;
       const int q = (ci % jb.ci_t) * jb.co_t + (co % jb.co_t);
-      int c = sg;
-      for (; c + 56 < jb.nchunks; c += 64) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = jb.partial[((int64_t)(c + 8 * u) * jb.ntiles + tile) * T + q];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-      }
-      for (; c < jb.nchunks; c += 8) s += jb.partial[((int64_t)c * jb.ntiles + tile) * T + q];
+      for (int c = sg; c < jb.nchunks; c += 8) s += jb.partial[((int64_t)c * jb.ntiles + tile) * T + q];
     }
   } else if (i < nw + jb.Co && jb.dbias) {
     const int co = i - nw;
