@@ -11,6 +11,7 @@
 //
 // The same kernel is the data-gradient / transposed-conv kernel through the gather map
 //   src coordinate = (dst*sn + off + tap*dt) / den   (valid iff divisible and in range).
+#include <stdlib.h>
 #include "n3d_common.h"
 
 namespace n3d {
@@ -233,8 +234,8 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       double s = csum[n], q = csq[n];
-      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      s = xsum32_d(xsum16_d(s));
+      q = xsum32_d(xsum16_d(q));
       if (writer && kk == 0) { red[((wave * NT + n) * 16 + m) * 2] = s; red[((wave * NT + n) * 16 + m) * 2 + 1] = q; }
     }
     __syncthreads();
@@ -330,8 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wg16Args a) {
   }
   if (wave > 0) l4[(wave - 1) * 64 + lane] = acc;
   if (do_bias) {
-    bsum += __shfl_xor(bsum, 16, 64);
-    bsum += __shfl_xor(bsum, 32, 64);
+    bsum = xsum32_f(xsum16_f(bsum));
     if (kk == 0) lb[wave][m] = bsum;
   }
   __syncthreads();
@@ -365,6 +365,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wg16Args a) {
 // accumulator chains) -- 54 + 27 LDS reads per 432 MFMAs at C = 4.
 // The data gradient is the same kernel on spatially flipped, channel-transposed weights (pack kernel).
 // ------------------------------------------------------------------------------------------------
+__device__ float4 n3d_zero_page[1];  // zero-initialised; source of the conv zero padding for LDS-DMA fills
+static const void* zero_page_ptr() {
+  static thread_local const void* p = nullptr;
+  static thread_local int dev = -1;
+  int d = 0; hipGetDevice(&d);
+  if (!p || d != dev) { void* q = nullptr; hipGetSymbolAddress(&q, HIP_SYMBOL(n3d_zero_page)); p = q; dev = d; }
+  return p;
+}
+
 struct VxArgs {
   const float* src; int64_t sld;
   float* dst; int64_t dld;
@@ -372,6 +381,8 @@ struct VxArgs {
   const float* bias;
   int D, H, W, flags;
   double* stats; int rows_per_sample;
+  int tiles;            // tiles per sample
+  const void* zero_page; // 16 zero bytes in device memory
 };
 
 // Wq[tap][cd][cs]; forward: cd=co, cs=ci, tap'=tap; data gradient: cd=ci, cs=co, tap'=26-tap
@@ -383,201 +394,266 @@ __global__ void pack_vox_kernel(const float* __restrict__ w, float* __restrict__
   wq[i] = w[((int64_t)co * C + ci) * 27 + t2];
 }
 
+#ifdef VOX_STAMP
+// debug build only (tools/build_ablate.sh): per-workgroup phase stamps of the vox64 kernel
+__device__ unsigned long long vox_stamp_buf[8192 * 8];
+__device__ unsigned long long vox_stamp_buf2[8192 * 8];
+#define VSTAMP_NW(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) vox_stamp_buf2[blockIdx.x * 8 + (k)] = clock64(); } while (0)
+#define VSTAMP(k)                                                                                          \
+  do {                                                                                                     \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 8192)                                                             \
+      vox_stamp_buf[blockIdx.x * 8 + (k)] = (k) >= 6 ? wall_clock64() : clock64(); \
+  } while (0)
+extern "C" int n3d_debug_vox_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vox_stamp_buf), (size_t)n * 8);
+}
+extern "C" int n3d_debug_vox_stamps2(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vox_stamp_buf2), (size_t)n * 8);
+}
+#else
+#define VSTAMP(k)
+#define VSTAMP_NW(k)
+#endif
+
 template <int C, int TD, int DIL>
 __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
   constexpr int Q = C / 4, GH = 4, GW = 16;
   constexpr int LD = TD + 2 * DIL, LH = GH + 2 * DIL, LW = GW + 2 * DIL;
-  constexpr int PLANE = LH * LW, QSTRIDE = LD * PLANE, NVOX = LD * PLANE;
-  constexpr int NW4 = 27 * C * Q;  // float4 count of the packed weights
-  extern __shared__ __attribute__((aligned(16))) float4 vlds[];  // tile [Q][LD][LH][LW], then weights [27][C][Q]
+  constexpr int PLANE = LH * LW, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64, QSTRIDE = LD * PSTRIDE;
+  constexpr int NW4 = 27 * C * Q, NWI = (NW4 + 63) / 64;  // float4 count of the packed weights
+  extern __shared__ __attribute__((aligned(16))) float4 vlds[];  // tile [Q][LD][PSTRIDE >= LH*LW], then weights [27][C][Q]
   float4* tile = vlds;
   float4* wl = vlds + Q * QSTRIDE;
   const int lane = threadIdx.x;
-  const int b = blockIdx.y;
+  // XCD-aware placement: workgroup ids are dealt round-robin to the 8 XCDs (private L2 each); remap so that every
+  // XCD works on one contiguous run of tiles (a D-slab of one sample) and the halo re-reads of neighbouring tiles
+  // hit that XCD's L2 instead of being fetched from HBM once per XCD.
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int b = wg / a.tiles;
+  const int tile_id = wg - b * a.tiles;
   const int tw_n = a.W / GW, th_n = a.H / GH;
-  int bx = blockIdx.x;
+  int bx = tile_id;
   const int w0 = (bx % tw_n) * GW; bx /= tw_n;
   const int h0 = (bx % th_n) * GH;
   const int d0 = (bx / th_n) * TD;
   const int64_t N = (int64_t)a.D * a.H * a.W;
   const float* srcb = a.src + (int64_t)b * N * a.sld;
   const int j = lane & 3, blk = lane >> 2;
+  VSTAMP(6);
+  VSTAMP(0);
 
-  // ---- stage weights and the halo tile (zero padding outside the volume); same wave reads them: no barrier.
-  // All global loads are issued back to back (clamped addresses + select, no branches) so that the
-  // wave pays ONE memory latency for the whole tile, then the LDS writes follow.
+  // ---- stage weights and the halo tile with LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS, no VGPR staging, no
+  // ds_write traffic -- the register-staged fill spent ~1 us in ds_write_b128 issue with 8 waves per CU).  One
+  // instruction fills 64 consecutive float4 slots from 64 per-lane addresses: lane l owns the in-plane positions
+  // l, l+64, .. of every plane (plane stride padded to a multiple of 64); positions outside the volume (zero
+  // padding) and pad slots read a 16-byte zero page instead.  Same wave reads what it wrote: vmcnt(0), no barrier.
   {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
     const float4* __restrict__ wq4 = reinterpret_cast<const float4*>(a.wq);
-    constexpr int NWI = (NW4 + 63) / 64;
-    float4 wv[NWI];
+    const float4* zp = reinterpret_cast<const float4*>(a.zero_page);
 #pragma unroll
-    for (int i = 0; i < NWI; ++i) { const int idx = lane + i * 64; wv[i] = wq4[idx < NW4 ? idx : NW4 - 1]; }
-    // position-major fill: lane l owns the in-plane positions l and l+64 (< LH*LW) of EVERY plane, so the
-    // (hy, wx) decode, bounds tests and clamps are done once per position and each plane costs one add
-    // (VALU issue is a co-bottleneck of this kernel: 2.6 VALU per MFMA before this change).
-    constexpr int NPOS = (PLANE + 63) / 64;
-    float4 fv[NPOS][LD][Q];
-    bool okp[NPOS];
-    int lpos[NPOS];
+    for (int i = 0; i < NWI; ++i) {
+      const int idx = lane + i * 64;
+#ifndef VOX_NO_LOAD
+      __builtin_amdgcn_global_load_lds((gptr_t)(idx < NW4 ? wq4 + idx : zp), (lptr_t)(wl + i * 64), 16, 0, 0);
+#endif
+    }
+    const int64_t pstride = (int64_t)a.H * a.W * a.sld;
 #pragma unroll
     for (int i = 0; i < NPOS; ++i) {
-      const int pos = (lane + i * 64 < PLANE) ? lane + i * 64 : PLANE - 1;
-      lpos[i] = pos;
+      const int pos = lane + i * 64;
       const int wx = pos % LW, hy = pos / LW;
       const int gh = h0 - DIL + hy, gw = w0 - DIL + wx;
-      okp[i] = gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-      const int ch_ = min(max(gh, 0), a.H - 1), cw_ = min(max(gw, 0), a.W - 1);
-      const float* prow = srcb + ((int64_t)ch_ * a.W + cw_) * a.sld;
-      const int64_t pstride = (int64_t)a.H * a.W * a.sld;
+      const bool okp = pos < PLANE && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      const float* prow = srcb + ((int64_t)gh * a.W + gw) * a.sld;
 #pragma unroll
       for (int dz = 0; dz < LD; ++dz) {
         const int gd = d0 - DIL + dz;
-        const bool inb = okp[i] && gd >= 0 && gd < a.D;
-        const int cd_ = min(max(gd, 0), a.D - 1);
-        const float* p = prow + cd_ * pstride;
+        const bool inb = okp && gd >= 0 && gd < a.D;
+        const float* p = prow + gd * pstride;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-#ifdef VOX_NO_LOAD
-          float4 v = make_float4(1.f, 1.f, 1.f, 1.f);
-#else
-          float4 v = *reinterpret_cast<const float4*>(p + q * 4);
+#ifndef VOX_NO_LOAD
+          __builtin_amdgcn_global_load_lds((gptr_t)(inb ? reinterpret_cast<const float4*>(p + q * 4) : zp),
+                                           (lptr_t)(tile + q * QSTRIDE + dz * PSTRIDE + i * 64), 16, 0, 0);
 #endif
-          fv[i][dz][q] = inb ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
     }
-#pragma unroll
-    for (int i = 0; i < NWI; ++i) { const int idx = lane + i * 64; if (idx < NW4) wl[idx] = wv[i]; }
-#pragma unroll
-    for (int i = 0; i < NPOS; ++i) {
-      if (lane + i * 64 < PLANE) {
-#pragma unroll
-        for (int dz = 0; dz < LD; ++dz)
-#pragma unroll
-          for (int q = 0; q < Q; ++q) tile[q * QSTRIDE + dz * PLANE + lpos[i]] = fv[i][dz][q];
-      }
-    }
+    VSTAMP(1);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_barrier();  // single-wave workgroup: orders the LDS writes above before the reads below
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  VSTAMP(2);
 
-  const int hh = lane >> 4, ww = lane & 15;
+  // lane -> voxel: row hh = lane/16; odd rows are rotated by LW % 16 voxels so that the fixed 16-lane groups a
+  // ds_read_b128 is serviced in ({0-3,12-15,20-27}, ...: 8 lanes of an even row + 8 of the next odd row) fall on
+  // 64 distinct banks with the (16 + 2*DIL)-float4 row pitch (2-way conflicts on every A read otherwise)
+  const int hh = lane >> 4, ww = ((lane & 15) - (hh & 1) * (LW % 16)) & 15;
+  // accumulators: the WEIGHTS are the MFMA A operand (row i = output channel) and the voxels the B operand
+  // (column j = voxel), so lane l ends up with all four channels of ITS OWN voxel in the four accumulator
+  // registers: the epilogue is one float4 store per lane, no cross-lane transpose.
   f32x4 acc[TD][Q];
 #pragma unroll
-  for (int g = 0; g < TD; ++g)
+  for (int hf = 0; hf < Q; ++hf) {
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) { const float4 t = *reinterpret_cast<const float4*>(a.bias + hf * 4); bv = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+    for (int g = 0; g < TD; ++g) acc[g][hf] = bv;
+  }
+  float* dstb = a.dst + (int64_t)b * N * a.dld;
+  const bool accum = a.flags & N3D_ACCUMULATE;
+  const int64_t vox_off = ((int64_t)(h0 + hh) * a.W + w0 + ww);
+  float cs[Q][4], cq[Q][4];  // per-lane GroupNorm partial sums of the lane's voxels, per channel
+#pragma unroll
+  for (int hf = 0; hf < Q; ++hf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[hf][r] = cq[hf][r] = 0.f;
+  // finished output plane g: statistics (of the convolution result itself) + one 16-byte store per lane and half
+  auto emit_plane = [&](int g) {
+    float* o = dstb + (((int64_t)(d0 + g) * a.H * a.W) + vox_off) * a.dld;
 #pragma unroll
     for (int hf = 0; hf < Q; ++hf) {
-      const float bv = a.bias ? a.bias[hf * 4 + j] : 0.f;
-      acc[g][hf] = (f32x4){bv, bv, bv, bv};
-    }
-#ifdef VOX_NO_MFMA
-#pragma unroll 1
-  for (int t9 = 0; t9 < 0; ++t9) {
+      const f32x4 v = acc[g][hf];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { cs[hf][r] += v[r]; cq[hf][r] = fmaf(v[r], v[r], cq[hf][r]); }
+      float4* op = reinterpret_cast<float4*>(o + hf * 4);
+      float4 w4 = make_float4(v[0], v[1], v[2], v[3]);
+      if (accum) { const float4 pv = *op; w4.x += pv.x; w4.y += pv.y; w4.z += pv.z; w4.w += pv.w; }
+#ifdef VOX_NO_STORE
+      if (w4.x == 123456.f) *op = w4;
 #else
-#pragma unroll
-  for (int t9 = 0; t9 < 9; ++t9) {
+      *op = w4;
 #endif
-    const int kh = t9 / 3, kw = t9 % 3;
-    float4 wr[3][Q][Q];  // [kd][half][quad]
+    }
+  };
+#ifndef VOX_NO_MFMA
+  if constexpr (Q == 1) {
+    // C = 4: all 27 weight quads live in registers (108 VGPRs) and the loop is INPUT-PLANE major: plane dz feeds
+    // the output planes dz, dz-DIL, dz-2*DIL, and an output plane is stored as soon as its last input plane is
+    // done -- its store latency and epilogue VALU work overlap the partner wave's MFMAs instead of forming a tail.
+    float4 wr[27];
 #pragma unroll
-    for (int kd = 0; kd < 3; ++kd)
+    for (int t = 0; t < 27; ++t) wr[t] = wl[t * 4 + j];
+    f32x4 acc2[TD];
 #pragma unroll
-      for (int hf = 0; hf < Q; ++hf)
-#pragma unroll
-        for (int q = 0; q < Q; ++q) wr[kd][hf][q] = wl[((kd * 9 + t9) * C + hf * 4 + j) * Q + q];
-    const int base = (hh + kh * DIL) * LW + (ww + kw * DIL);
-    // all input planes of this (kh,kw) are requested up front: LD*Q ds_read_b128 in flight, the MFMAs of
-    // plane dz start as soon as its read has landed (counted lgkmcnt waits)
-    float4 av[LD][Q];
-#pragma unroll
-    for (int dz = 0; dz < LD; ++dz)
-#pragma unroll
-      for (int q = 0; q < Q; ++q) av[dz][q] = tile[q * QSTRIDE + dz * PLANE + base];
+    for (int g = 0; g < TD; ++g) acc2[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dz = 0; dz < LD; ++dz) {
+      float4 av[9];
 #pragma unroll
-      for (int q = 0; q < Q; ++q) {
+      for (int t9 = 0; t9 < 9; ++t9) av[t9] = tile[dz * PSTRIDE + (hh + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL)];
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float ae = e == 0 ? av[dz][q].x : (e == 1 ? av[dz][q].y : (e == 2 ? av[dz][q].z : av[dz][q].w));
+          const float xe = e == 0 ? av[t9].x : (e == 1 ? av[t9].y : (e == 2 ? av[t9].z : av[t9].w));
 #pragma unroll
           for (int kd = 0; kd < 3; ++kd) {
             const int g = dz - kd * DIL;
             if (g >= 0 && g < TD) {
+              const float4 wv = wr[kd * 9 + t9];
+              const float we = e == 0 ? wv.x : (e == 1 ? wv.y : (e == 2 ? wv.z : wv.w));
+              // two accumulator chains per output plane (even / odd input channel): a dependent 4x4x1 chain
+              // issues one MFMA per ~15 cycles, and the first / last input planes feed a single output plane
+              if (e & 1) acc2[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(we, xe, acc2[g], 0, 0, 0);
+              else acc[g][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(we, xe, acc[g][0], 0, 0, 0);
+            }
+          }
+        }
+      }
+      VSTAMP_NW(dz < 7 ? dz : 7);
+      if (dz - 2 * DIL >= 0) {
+        acc[dz - 2 * DIL][0] += acc2[dz - 2 * DIL];
+        emit_plane(dz - 2 * DIL);
+      }
+    }
+  } else {
+    // C = 8: (kh,kw) outer with the three kd weight sets in registers, input plane inner (every A read feeds up
+    // to 3 output planes on independent accumulator chains)
 #pragma unroll
-              for (int hf = 0; hf < Q; ++hf) {
-                const float4 wv = wr[kd][hf][q];
-                const float be = e == 0 ? wv.x : (e == 1 ? wv.y : (e == 2 ? wv.z : wv.w));
-                acc[g][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(ae, be, acc[g][hf], 0, 0, 0);
+    for (int t9 = 0; t9 < 9; ++t9) {
+      const int kh = t9 / 3, kw = t9 % 3;
+      float4 wr[3][Q][Q];  // [kd][half][quad]
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int hf = 0; hf < Q; ++hf)
+#pragma unroll
+          for (int q = 0; q < Q; ++q) wr[kd][hf][q] = wl[((kd * 9 + t9) * C + hf * 4 + j) * Q + q];
+      const int base = (hh + kh * DIL) * LW + (ww + kw * DIL);
+      float4 av[LD][Q];
+#pragma unroll
+      for (int dz = 0; dz < LD; ++dz)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) av[dz][q] = tile[q * QSTRIDE + dz * PSTRIDE + base];
+#pragma unroll
+      for (int dz = 0; dz < LD; ++dz) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xe = e == 0 ? av[dz][q].x : (e == 1 ? av[dz][q].y : (e == 2 ? av[dz][q].z : av[dz][q].w));
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+              const int g = dz - kd * DIL;
+              if (g >= 0 && g < TD) {
+#pragma unroll
+                for (int hf = 0; hf < Q; ++hf) {
+                  const float4 wv = wr[kd][hf][q];
+                  const float we = e == 0 ? wv.x : (e == 1 ? wv.y : (e == 2 ? wv.z : wv.w));
+                  acc[g][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(we, xe, acc[g][hf], 0, 0, 0);
+                }
               }
             }
           }
         }
       }
     }
+#pragma unroll
+    for (int g = 0; g < TD; ++g) emit_plane(g);
   }
-
-  // ---- epilogue: lane (blk, j) holds channel 4*half + j of voxels 4*blk + r (r = register) of each group.
-  // GroupNorm statistics are taken in that layout (one channel per lane); for the store the 4x4 block held
-  // by each lane quad is transposed with two DPP butterfly stages so that lane (blk, i) owns all four
-  // channels of voxel 4*blk + i and issues ONE 16-byte store (a wave writes 4 rows x 256 contiguous bytes).
-  float* dstb = a.dst + (int64_t)b * N * a.dld;
-  const bool accum = a.flags & N3D_ACCUMULATE;
-  if (a.stats) {
-#pragma unroll
-    for (int hf = 0; hf < Q; ++hf) {
-      float cs = 0.f, cq = 0.f;
-#pragma unroll
-      for (int g = 0; g < TD; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float v = acc[g][hf][r]; cs += v; cq = fmaf(v, v, cq); }
-      double sm = cs, q2 = cq;
-#pragma unroll
-      for (int off = 4; off < 64; off <<= 1) { sm += __shfl_xor(sm, off, 64); q2 += __shfl_xor(q2, off, 64); }
-      if (lane < 4) {
-        double* o = a.stats + (((int64_t)b * a.rows_per_sample + blockIdx.x) * C + hf * 4 + lane) * 2;
-        o[0] = sm; o[1] = q2;
-      }
-    }
-  }
-  const int vr = lane;  // after the transpose this lane owns voxel `lane` of the group
-  const int64_t vox_off = ((int64_t)(h0 + (vr >> 4)) * a.W + w0 + (vr & 15));
-#pragma unroll
-  for (int g = 0; g < TD; ++g) {
-    float* o = dstb + (((int64_t)(d0 + g) * a.H * a.W) + vox_off) * a.dld;
-#pragma unroll
-    for (int hf = 0; hf < Q; ++hf) {
-      float x0 = acc[g][hf][0], x1 = acc[g][hf][1], x2 = acc[g][hf][2], x3 = acc[g][hf][3];
-      // stage 1: exchange with lane^1 (quad_perm [1,0,3,2] = 0xB1)
-      {
-        const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x0), 0xB1, 0xF, 0xF, true));
-        const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x1), 0xB1, 0xF, 0xF, true));
-        const float p2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x2), 0xB1, 0xF, 0xF, true));
-        const float p3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x3), 0xB1, 0xF, 0xF, true));
-        const bool odd = j & 1;
-        const float n0 = odd ? p1 : x0, n1 = odd ? x1 : p0, n2 = odd ? p3 : x2, n3 = odd ? x3 : p2;
-        x0 = n0; x1 = n1; x2 = n2; x3 = n3;
-      }
-      // stage 2: exchange with lane^2 (quad_perm [2,3,0,1] = 0x4E)
-      {
-        const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x0), 0x4E, 0xF, 0xF, true));
-        const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x1), 0x4E, 0xF, 0xF, true));
-        const float p2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x2), 0x4E, 0xF, 0xF, true));
-        const float p3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x3), 0x4E, 0xF, 0xF, true));
-        const bool hi = j & 2;
-        const float n0 = hi ? p2 : x0, n1 = hi ? p3 : x1, n2 = hi ? x2 : p0, n3 = hi ? x3 : p1;
-        x0 = n0; x1 = n1; x2 = n2; x3 = n3;
-      }
-      float4* op = reinterpret_cast<float4*>(o + hf * 4);
-      float4 v = make_float4(x0, x1, x2, x3);
-      if (accum) { const float4 pv = *op; v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w; }
-#ifdef VOX_NO_STORE
-      if (v.x == 123456.f) *op = v;
 #else
-      *op = v;
+#pragma unroll
+  for (int g = 0; g < TD; ++g) emit_plane(g);
 #endif
+  VSTAMP(3);
+  // ---- GroupNorm partial row of this tile: 8 per-lane sums (4 channels x {sum, sum of squares}) per half are
+  // folded with a halving butterfly (lane^1 keeps channels {0,1} | {2,3}, lane^2 keeps one of the two), then one
+  // class sum over the 16 lanes that ended up with the same channel.  fp32 tree, rows are added in fp64 downstream.
+  if (a.stats) {
+    const bool odd = lane & 1, hi = lane & 2;
+#pragma unroll
+    for (int hf = 0; hf < Q; ++hf) {
+      float u[2], uq[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float keep = odd ? cs[hf][2 + k] : cs[hf][k], send = odd ? cs[hf][k] : cs[hf][2 + k];
+        u[k] = keep + dpp_f<0xB1>(send);
+        const float keepq = odd ? cq[hf][2 + k] : cq[hf][k], sendq = odd ? cq[hf][k] : cq[hf][2 + k];
+        uq[k] = keepq + dpp_f<0xB1>(sendq);
+      }
+      float v1 = (hi ? u[1] : u[0]) + dpp_f<0x4E>(hi ? u[0] : u[1]);
+      float v2 = (hi ? uq[1] : uq[0]) + dpp_f<0x4E>(hi ? uq[0] : uq[1]);
+      v1 = wave_classsum_f(v1, 4); v2 = wave_classsum_f(v2, 4);
+      if (lane < 4) {
+        const int ch = (lane & 1) * 2 + (lane >> 1);
+        double* o = a.stats + (((int64_t)b * a.rows_per_sample + tile_id) * C + hf * 4 + ch) * 2;
+        reinterpret_cast<double2*>(o)[0] = make_double2((double)v1, (double)v2);
+      }
     }
   }
+  VSTAMP(4);
+  VSTAMP(5);
+#ifdef VOX_STAMP
+  if (threadIdx.x == 0 && blockIdx.x < 8192)
+    vox_stamp_buf[blockIdx.x * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+#endif
 }
 
 struct VxPlan { bool ok; int C, td, dil, tiles; size_t lds; };
@@ -593,16 +669,22 @@ static VxPlan vx_plan(const n3d_conv_geom* g) {
   int td = 1;
   if (D % 4 == 0 && groups / 4 >= 2048 && g->Ci == 4) td = 4;
   else if (D % 2 == 0 && groups / 2 >= 2048) td = 2;
+#if defined(VOX_STAMP) || defined(VOX_TUNE)
+  if (getenv("VOX_TD")) td = atoi(getenv("VOX_TD"));
+#endif
   p.ok = true; p.C = g->Ci; p.td = td; p.dil = g->dil;
   p.tiles = (W / 16) * (H / 4) * (D / td);
   const int Q = g->Ci / 4;
-  p.lds = ((size_t)Q * (td + 2 * g->dil) * (4 + 2 * g->dil) * (16 + 2 * g->dil) + (size_t)27 * g->Ci * Q) * 16;
+  const size_t pstride = ((size_t)(4 + 2 * g->dil) * (16 + 2 * g->dil) + 63) / 64 * 64;
+  p.lds = ((size_t)Q * (td + 2 * g->dil) * pstride + ((size_t)27 * g->Ci * Q + 63) / 64 * 64) * 16;
   return p;
 }
 
 template <int C, int TD, int DIL>
 static int launch_vox_t(VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
-  hipLaunchKernelGGL((conv_vox64_kernel<C, TD, DIL>), dim3(p.tiles, B), dim3(64), p.lds, s, a);
+  a.tiles = p.tiles;
+  a.zero_page = zero_page_ptr();
+  hipLaunchKernelGGL((conv_vox64_kernel<C, TD, DIL>), dim3(p.tiles * B), dim3(64), p.lds, s, a);
   return 1;
 }
 

@@ -92,8 +92,8 @@ static inline EwMap ew_map(int64_t N, int C) {
 
 #ifdef __HIPCC__
 // ---- cross-lane sums.  A lone wave issues ~1 instruction per 4-5 cycles, so on the small tensors of the deep
-// U-net levels kernel time IS the dynamic instruction count: reductions use DPP row operations (1 instruction per
-// step and 32-bit half) instead of ds_bpermute sequences (~8 instructions per step).
+// U-net levels kernel time IS the dynamic instruction count: reductions use DPP row operations and permlane swaps
+// (1-2 VALU instructions per step and 32-bit half) instead of ds_bpermute sequences (~8 instructions + an LDS trip).
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
@@ -105,14 +105,33 @@ __device__ __forceinline__ double dpp_d(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ float swz16_f(float v) {  // lane i <- lane i ^ 16 (ds_swizzle bit mode: xor 0x10, and 0x1f)
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+// lane i + lane i^16, and lane i + lane i^32, in every lane: gfx950's v_permlane16_swap / v_permlane32_swap exchange
+// row pairs / wave halves between two VGPRs inside the VALU (a ds_swizzle or ds_bpermute pays an LDS round trip)
+__device__ __forceinline__ float xsum16_f(float v) {
+  const int x = __builtin_bit_cast(int, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
 }
-__device__ __forceinline__ double swz16_d(double v) {
+__device__ __forceinline__ float xsum32_f(float v) {
+  const int x = __builtin_bit_cast(int, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+__device__ __forceinline__ double xsum16_d(double v) {
   const long long b = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_ds_swizzle((int)(b & 0xffffffffll), 0x401F);
-  const int hi = __builtin_amdgcn_ds_swizzle((int)(b >> 32), 0x401F);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+  const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __builtin_bit_cast(double, ((long long)(int)rh[0] << 32) | (unsigned int)rl[0]) +
+         __builtin_bit_cast(double, ((long long)(int)rh[1] << 32) | (unsigned int)rl[1]);
+}
+__device__ __forceinline__ double xsum32_d(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __builtin_bit_cast(double, ((long long)(int)rh[0] << 32) | (unsigned int)rl[0]) +
+         __builtin_bit_cast(double, ((long long)(int)rh[1] << 32) | (unsigned int)rl[1]);
 }
 // every lane ends up with the sum over the lanes of its class (lane % cpb), cpb a power of two <= 64
 __device__ __forceinline__ float wave_classsum_f(float v, int cpb) {
@@ -120,8 +139,8 @@ __device__ __forceinline__ float wave_classsum_f(float v, int cpb) {
   if (cpb <= 2) v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
   if (cpb <= 4) v += dpp_f<0x124>(v);   // row_ror:4
   if (cpb <= 8) v += dpp_f<0x128>(v);   // row_ror:8
-  if (cpb <= 16) v += swz16_f(v);
-  if (cpb <= 32) v += __shfl_xor(v, 32, 64);
+  if (cpb <= 16) v = xsum16_f(v);
+  if (cpb <= 32) v = xsum32_f(v);
   return v;
 }
 __device__ __forceinline__ double wave_classsum_d(double v, int cpb) {
@@ -129,8 +148,8 @@ __device__ __forceinline__ double wave_classsum_d(double v, int cpb) {
   if (cpb <= 2) v += dpp_d<0x4E>(v);
   if (cpb <= 4) v += dpp_d<0x124>(v);
   if (cpb <= 8) v += dpp_d<0x128>(v);
-  if (cpb <= 16) v += swz16_d(v);
-  if (cpb <= 32) v += __shfl_xor(v, 32, 64);
+  if (cpb <= 16) v = xsum16_d(v);
+  if (cpb <= 32) v = xsum32_d(v);
   return v;
 }
 __device__ __forceinline__ bool is_pow2(int x) { return (x & (x - 1)) == 0; }
