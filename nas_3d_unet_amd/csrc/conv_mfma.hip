@@ -79,6 +79,40 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
 #pragma unroll
     for (int n = 0; n < NT; ++n) { acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
+  // epilogue operands of the writer wave (bias, ReLU mask source, output gate, previous output) are requested
+  // here, ahead of the K loop, so the epilogue never waits on memory
+  const bool writer = (KSPLIT == 1) || (wave == 0);
+  const bool accum = a.flags & N3D_ACCUMULATE;
+  float e_bias[NT], e_relu[MT][4][NT], e_gate[MT][4][NT], e_prev[MT][4][NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) e_bias[n] = 0.f;
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { e_relu[t][r][n] = 1.f; e_gate[t][r][n] = 1.f; e_prev[t][r][n] = 0.f; }
+  if (writer) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) if (a.bias) e_bias[n] = a.bias[n0 + n * 16 + m];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t i = row0 + t * 16 + kk * 4 + r;
+        if (i < Mtot) {
+          const int b = (int)a.fNd.div((uint32_t)i);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const int c = n0 + n * 16 + m;
+            if (a.relu_src) e_relu[t][r][n] = a.relu_src[i * a.rld + c];
+            if (a.out_gate) e_gate[t][r][n] = a.out_gate[(int64_t)b * a.Cd + c];
+            if (accum) e_prev[t][r][n] = a.dst[i * a.dld + c];
+          }
+        }
+      }
+  }
+
   const int k = a.k, taps = k * k * k;
   const int c16n = a.Cs >> 4;
   const int ngroups = taps * c16n;
@@ -199,38 +233,45 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
   }
 
   // ---- epilogue: D layout -> lane holds column n = lane&15, rows 4*(lane>>4) + r
-  const bool writer = (KSPLIT == 1) || (wave == 0);
   float csum[NT], csq[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) { csum[n] = 0.f; csq[n] = 0.f; }
   if (writer) {
-    const bool accum = a.flags & N3D_ACCUMULATE;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t i = row0 + t * 16 + kk * 4 + r;
         if (i >= Mtot) continue;
-        const int b = (int)a.fNd.div((uint32_t)i);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const int c = n0 + n * 16 + m;
-          float v = acc[t][n][r];
-          if (a.bias) v += a.bias[c];
-          if (a.relu_src) { if (!(a.relu_src[i * a.rld + c] > 0.f)) v = 0.f; }
-          if (a.out_gate) v *= a.out_gate[(int64_t)b * a.Cd + c];
-          float* o = a.dst + i * a.dld + c;
-          if (accum) v += *o;
-          *o = v;
+          float v = acc[t][n][r] + e_bias[n];
+          if (!(e_relu[t][r][n] > 0.f)) v = 0.f;
+          v = v * e_gate[t][r][n] + e_prev[t][r][n];
+          a.dst[i * a.dld + c] = v;
           csum[n] += v; csq[n] = fmaf(v, v, csq[n]);
         }
       }
     }
   }
-  if (a.stats) {
+  if (a.stats && KSPLIT > 1) {
+    // only wave 0 holds data: its lanes kk == 0 write the block's partial row directly (no LDS, no barrier)
+    if (wave == 0) {
+      const uint32_t first = (uint32_t)blockIdx.x * ROWS_PER_BLOCK;
+      uint32_t ub2, ur2;
+      a.fNd.divmod(first, ub2, ur2);
+      const int row = (int)(ur2 / ROWS_PER_BLOCK);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const double s = xsum32_d(xsum16_d((double)csum[n])), q = xsum32_d(xsum16_d((double)csq[n]));
+        if (kk == 0)
+          *reinterpret_cast<double2*>(a.stats + (((int64_t)ub2 * a.rows_per_sample + row) * a.Cd + n0 + n * 16 + m) * 2) = make_double2(s, q);
+      }
+    }
+  } else if (a.stats) {
     // all rows of a block belong to one sample (host guarantees Nd % ROWS_PER_BLOCK == 0)
-    double* red = reinterpret_cast<double*>(lds + (KSPLIT > 1 ? (KSPLIT - 1) * MT * NT * 256 : 0));
-    if (KSPLIT > 1) __syncthreads();
+    double* red = reinterpret_cast<double*>(lds);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       double s = csum[n], q = csq[n];
@@ -416,6 +457,14 @@ extern "C" int n3d_debug_vox_stamps2(unsigned long long* host, int n) {
 #define VSTAMP_NW(k)
 #endif
 
+#ifdef VOX_NO_LDSREAD
+#define TILE_RD(idx) make_float4(__builtin_bit_cast(float, (idx) + lane), 1.f, 2.f, __builtin_bit_cast(float, lane))
+#define WL_RD(idx) make_float4(__builtin_bit_cast(float, (idx) * 3 + lane), 1.5f, 2.5f, __builtin_bit_cast(float, lane * 7))
+#else
+#define TILE_RD(idx) tile[idx]
+#define WL_RD(idx) wl[idx]
+#endif
+
 template <int C, int TD, int DIL>
 __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
   constexpr int Q = C / 4, GH = 4, GW = 16;
@@ -446,6 +495,25 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
   const int j = lane & 3, blk = lane >> 2;
   VSTAMP(6);
   VSTAMP(0);
+
+  // lane -> voxel: row hh = lane/16; odd rows are rotated by LW % 16 voxels so that the fixed 16-lane groups a
+  // ds_read_b128 is serviced in ({0-3,12-15,20-27}, ...: 8 lanes of an even row + 8 of the next odd row) fall on
+  // 64 distinct banks with the (16 + 2*DIL)-float4 row pitch (2-way conflicts on every A read otherwise)
+  const int hh = lane >> 4, ww = ((lane & 15) - (hh & 1) * (LW % 16)) & 15;
+  // bias and (accumulate mode) the previous output values are ordinary global loads: issued BEFORE the LDS-DMA
+  // fill so that the single vmcnt(0) below covers them (a load after the fill would add a second memory latency)
+  float* dstb = a.dst + (int64_t)b * N * a.dld;
+  const bool accum = a.flags & N3D_ACCUMULATE;
+  const int64_t vox_off = ((int64_t)(h0 + hh) * a.W + w0 + ww);
+  float4 biasv[Q], prevv[TD][Q];
+#pragma unroll
+  for (int hf = 0; hf < Q; ++hf) {
+    biasv[hf] = a.bias ? *reinterpret_cast<const float4*>(a.bias + hf * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < TD; ++g)
+      prevv[g][hf] = accum ? *reinterpret_cast<const float4*>(dstb + (((int64_t)(d0 + g) * a.H * a.W) + vox_off) * a.dld + hf * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
   // ---- stage weights and the halo tile with LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS, no VGPR staging, no
   // ds_write traffic -- the register-staged fill spent ~1 us in ds_write_b128 issue with 8 waves per CU).  One
@@ -491,24 +559,16 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   VSTAMP(2);
 
-  // lane -> voxel: row hh = lane/16; odd rows are rotated by LW % 16 voxels so that the fixed 16-lane groups a
-  // ds_read_b128 is serviced in ({0-3,12-15,20-27}, ...: 8 lanes of an even row + 8 of the next odd row) fall on
-  // 64 distinct banks with the (16 + 2*DIL)-float4 row pitch (2-way conflicts on every A read otherwise)
-  const int hh = lane >> 4, ww = ((lane & 15) - (hh & 1) * (LW % 16)) & 15;
   // accumulators: the WEIGHTS are the MFMA A operand (row i = output channel) and the voxels the B operand
   // (column j = voxel), so lane l ends up with all four channels of ITS OWN voxel in the four accumulator
   // registers: the epilogue is one float4 store per lane, no cross-lane transpose.
   f32x4 acc[TD][Q];
 #pragma unroll
   for (int hf = 0; hf < Q; ++hf) {
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias) { const float4 t = *reinterpret_cast<const float4*>(a.bias + hf * 4); bv = (f32x4){t.x, t.y, t.z, t.w}; }
+    const f32x4 bv = {biasv[hf].x, biasv[hf].y, biasv[hf].z, biasv[hf].w};
 #pragma unroll
     for (int g = 0; g < TD; ++g) acc[g][hf] = bv;
   }
-  float* dstb = a.dst + (int64_t)b * N * a.dld;
-  const bool accum = a.flags & N3D_ACCUMULATE;
-  const int64_t vox_off = ((int64_t)(h0 + hh) * a.W + w0 + ww);
   float cs[Q][4], cq[Q][4];  // per-lane GroupNorm partial sums of the lane's voxels, per channel
 #pragma unroll
   for (int hf = 0; hf < Q; ++hf)
@@ -524,7 +584,7 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
       for (int r = 0; r < 4; ++r) { cs[hf][r] += v[r]; cq[hf][r] = fmaf(v[r], v[r], cq[hf][r]); }
       float4* op = reinterpret_cast<float4*>(o + hf * 4);
       float4 w4 = make_float4(v[0], v[1], v[2], v[3]);
-      if (accum) { const float4 pv = *op; w4.x += pv.x; w4.y += pv.y; w4.z += pv.z; w4.w += pv.w; }
+      { const float4 pv = prevv[g][hf]; w4.x += pv.x; w4.y += pv.y; w4.z += pv.z; w4.w += pv.w; }
 #ifdef VOX_NO_STORE
       if (w4.x == 123456.f) *op = w4;
 #else
@@ -537,17 +597,31 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
     // C = 4: all 27 weight quads live in registers (108 VGPRs) and the loop is INPUT-PLANE major: plane dz feeds
     // the output planes dz, dz-DIL, dz-2*DIL, and an output plane is stored as soon as its last input plane is
     // done -- its store latency and epilogue VALU work overlap the partner wave's MFMAs instead of forming a tail.
+    // weight quads are fetched from LDS one kd-slab ahead of the first input plane that needs them (kd = 0 before
+    // plane 0, kd = 1 during plane 0, ...) so the start of the MFMA phase is not one 45-read LDS burst per wave
     float4 wr[27];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) wr[t] = wl[t * 4 + j];
+    for (int t = 0; t < 9; ++t) wr[t] = WL_RD(t * 4 + j);
     f32x4 acc2[TD];
 #pragma unroll
     for (int g = 0; g < TD; ++g) acc2[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the nine A reads of plane dz+1 are issued before the MFMAs of plane dz (register double buffer)
+    float4 avb[2][9];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) avb[0][t9] = TILE_RD((hh + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL));
 #pragma unroll
     for (int dz = 0; dz < LD; ++dz) {
-      float4 av[9];
+      if (dz + 1 < LD) {
 #pragma unroll
-      for (int t9 = 0; t9 < 9; ++t9) av[t9] = tile[dz * PSTRIDE + (hh + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL)];
+        for (int t9 = 0; t9 < 9; ++t9)
+          avb[(dz + 1) & 1][t9] = TILE_RD((dz + 1) * PSTRIDE + (hh + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL));
+      }
+      if (dz == 0 || dz == DIL) {
+        const int kd = dz / DIL + 1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[kd * 9 + t] = WL_RD((kd * 9 + t) * 4 + j);
+      }
+      const float4* av = avb[dz & 1];
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9) {
 #pragma unroll

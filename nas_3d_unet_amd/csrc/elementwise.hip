@@ -423,6 +423,18 @@ __global__ __launch_bounds__(256) void affine_act_gn_kernel(const float* __restr
   const int t = threadIdx.x;
   const float gam_t = (t < C) ? gamma[t] : 0.f, bet_t = (t < C) ? beta[t] : 0.f;
   const float w = wptr ? *wptr : 1.0f;
+  // the first iteration's operands are requested before the prologue: its memory round trip overlaps the
+  // coefficient computation instead of following it
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
+  const float* rb = raw + (int64_t)b * N * rld + c4 * 4;
+  float* ob = out + (int64_t)b * N * old_ + c4 * 4;
+  const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+  const bool act0 = vl < m.vpb && v0 < N;
+  float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), o0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (act0) {
+    q0 = *reinterpret_cast<const float4*>(rb + v0 * rld);
+    if (ACC) o0 = *reinterpret_cast<const float4*>(ob + v0 * old_);
+  }
   reduce_rows(stats + (int64_t)b * rows * C * 2, rows, C * 2, part, tot);
   const int cg = C / G;
   if (t < C) {
@@ -444,30 +456,46 @@ __global__ __launch_bounds__(256) void affine_act_gn_kernel(const float* __restr
     }
   }
   __syncthreads();
-  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
-  if (vl >= m.vpb) return;
+  if (!act0) return;
   const float4 av = make_float4(ab[0][c4 * 4], ab[0][c4 * 4 + 1], ab[0][c4 * 4 + 2], ab[0][c4 * 4 + 3]);
   const float4 bv = make_float4(ab[1][c4 * 4], ab[1][c4 * 4 + 1], ab[1][c4 * 4 + 2], ab[1][c4 * 4 + 3]);
-  const float* rb = raw + (int64_t)b * N * rld + c4 * 4;
-  float* ob = out + (int64_t)b * N * old_ + c4 * 4;
-  const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
-#pragma unroll 4
-  for (int it = 0; it < m.iters; ++it) {
-    const int64_t v = v0 + (int64_t)it * m.vpb;
-    if (v >= N) break;
-    const float4 q = *reinterpret_cast<const float4*>(rb + v * rld);
+  // iterations 1.. are requested before iteration 0 is finished (loads first, then math and stores)
+  constexpr int PF = 3;
+  float4 qn[PF], on[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int64_t v = v0 + (int64_t)(i + 1) * m.vpb;
+    const bool ok = (i + 1) < m.iters && v < N;
+    const int64_t vc = ok ? v : v0;
+    qn[i] = *reinterpret_cast<const float4*>(rb + vc * rld);
+    if (ACC) on[i] = *reinterpret_cast<const float4*>(ob + vc * old_);
+  }
+  auto emit = [&](int64_t v, const float4 q, float4 o) {
     float4 z;
     z.x = fmaf(av.x, q.x, bv.x); z.y = fmaf(av.y, q.y, bv.y); z.z = fmaf(av.z, q.z, bv.z); z.w = fmaf(av.w, q.w, bv.w);
     if (RELU) { z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f); }
     float4* op = reinterpret_cast<float4*>(ob + v * old_);
     if (ACC) {
-      float4 o = *op;
       o.x = fmaf(w, z.x, o.x); o.y = fmaf(w, z.y, o.y); o.z = fmaf(w, z.z, o.z); o.w = fmaf(w, z.w, o.w);
       *op = o;
     } else {
       z.x *= w; z.y *= w; z.z *= w; z.w *= w;
       *op = z;
     }
+  };
+  emit(v0, q0, o0);
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int64_t v = v0 + (int64_t)(i + 1) * m.vpb;
+    if ((i + 1) < m.iters && v < N) emit(v, qn[i], on[i]);
+  }
+  for (int it = PF + 1; it < m.iters; ++it) {
+    const int64_t v = v0 + (int64_t)it * m.vpb;
+    if (v >= N) break;
+    const float4 q = *reinterpret_cast<const float4*>(rb + v * rld);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACC) o = *reinterpret_cast<const float4*>(ob + v * old_);
+    emit(v, q, o);
   }
 }
 
@@ -495,7 +523,23 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* _
   const int cg = C / G;
   const bool leader = (blockIdx.x == 0 && blockIdx.y == 0);
   const int nb = leader ? B : 1;
-  // ---- load phase (no dependent loads): parameters, group statistics, this thread's share of the partial rows
+  // ---- load phase (no dependent loads): the first iteration's tensor operands and forward coefficients, then
+  // parameters, group statistics and this thread's share of the partial rows
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
+  const float* dbp = dout + (int64_t)blockIdx.y * N * dld + c4 * 4;
+  const float* rb = raw + (int64_t)blockIdx.y * N * rld + c4 * 4;
+  float* ob = draw + (int64_t)blockIdx.y * N * drld + c4 * 4;
+  const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+  const bool act0 = vl < m.vpb && v0 < N;
+  float4 dq0 = make_float4(0.f, 0.f, 0.f, 0.f), rq0 = dq0, pq0 = dq0, aq = make_float4(1.f, 1.f, 1.f, 1.f), bq = dq0;
+  if (act0) {
+    dq0 = *reinterpret_cast<const float4*>(dbp + v0 * dld);
+    rq0 = *reinterpret_cast<const float4*>(rb + v0 * rld);
+    if (ACC) pq0 = *reinterpret_cast<const float4*>(ob + v0 * drld);
+    const int co = (int)blockIdx.y * C + c4 * 4;
+    if (a) aq = *reinterpret_cast<const float4*>(a + co);
+    if (bb) bq = *reinterpret_cast<const float4*>(bb + co);
+  }
   const double w = wptr ? (double)*wptr : 1.0;
   const double gam = (t < C) ? (double)gamma[t] : 0.0;
   const int gq = (t < C) ? t / cg : 0;
@@ -580,25 +624,24 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* _
       }
     }
   }
-  const int b = blockIdx.y;
-  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
-  if (vl >= m.vpb) return;
-  float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0}, Av[4], Bv[4], Cv[4];
-  const int co = b * C + c4 * 4;
-  if (a) { const float4 q = *reinterpret_cast<const float4*>(a + co); av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w; }
-  if (bb) { const float4 q = *reinterpret_cast<const float4*>(bb + co); bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w; }
+  if (!act0) return;
+  const float av[4] = {aq.x, aq.y, aq.z, aq.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
+  float Av[4], Bv[4], Cv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) { Av[j] = coef[0][c4 * 4 + j]; Bv[j] = coef[1][c4 * 4 + j]; Cv[j] = coef[2][c4 * 4 + j]; }
-  const float* dbp = dout + (int64_t)b * N * dld + c4 * 4;
-  const float* rb = raw + (int64_t)b * N * rld + c4 * 4;
-  float* ob = draw + (int64_t)b * N * drld + c4 * 4;
-  const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
-#pragma unroll 2
-  for (int it = 0; it < m.iters; ++it) {
-    const int64_t v = v0 + (int64_t)it * m.vpb;
-    if (v >= N) break;
-    const float4 dq = *reinterpret_cast<const float4*>(dbp + v * dld);
-    const float4 rq = *reinterpret_cast<const float4*>(rb + v * rld);
+  // iterations 1.. are requested before iteration 0 is finished (loads first, then math and stores)
+  constexpr int PF = 3;
+  float4 dn[PF], rn[PF], pn[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int64_t v = v0 + (int64_t)(i + 1) * m.vpb;
+    const bool ok = (i + 1) < m.iters && v < N;
+    const int64_t vc = ok ? v : v0;
+    dn[i] = *reinterpret_cast<const float4*>(dbp + vc * dld);
+    rn[i] = *reinterpret_cast<const float4*>(rb + vc * rld);
+    if (ACC) pn[i] = *reinterpret_cast<const float4*>(ob + vc * drld);
+  }
+  auto emit = [&](int64_t v, const float4 dq, const float4 rq, const float4 pq) {
     const float d[4] = {dq.x, dq.y, dq.z, dq.w};
     const float r[4] = {rq.x, rq.y, rq.z, rq.w};
     float o[4];
@@ -608,9 +651,23 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* _
       if (RELU) { const float z = fmaf(av[j], r[j], bv[j]); g = z > 0.f ? g : 0.f; }
       o[j] = fmaf(Av[j], g, fmaf(Cv[j], r[j], Bv[j]));
     }
-    float4* op = reinterpret_cast<float4*>(ob + v * drld);
-    if (ACC) { const float4 p = *op; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
-    *op = make_float4(o[0], o[1], o[2], o[3]);
+    if (ACC) { o[0] += pq.x; o[1] += pq.y; o[2] += pq.z; o[3] += pq.w; }
+    *reinterpret_cast<float4*>(ob + v * drld) = make_float4(o[0], o[1], o[2], o[3]);
+  };
+  emit(v0, dq0, rq0, pq0);
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int64_t v = v0 + (int64_t)(i + 1) * m.vpb;
+    if ((i + 1) < m.iters && v < N) emit(v, dn[i], rn[i], pn[i]);
+  }
+  for (int it = PF + 1; it < m.iters; ++it) {
+    const int64_t v = v0 + (int64_t)it * m.vpb;
+    if (v >= N) break;
+    const float4 dq = *reinterpret_cast<const float4*>(dbp + v * dld);
+    const float4 rq = *reinterpret_cast<const float4*>(rb + v * rld);
+    float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACC) pq = *reinterpret_cast<const float4*>(ob + v * drld);
+    emit(v, dq, rq, pq);
   }
 }
 

@@ -1,0 +1,5 @@
+#!/bin/bash
+# rocprofv3 kernel trace of a short bench run (run on the GPU box): tools/profile_step.sh <outdir-name>
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$1 -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/$1.log 2>&1
+tail -1 gpurun_out/$1.log | cut -c1-200
