@@ -419,6 +419,7 @@ __global__ __launch_bounds__(256) void affine_act_gn_kernel(const float* __restr
   __shared__ double part[256];
   __shared__ double tot[128];
   __shared__ float ab[2][64];
+  __shared__ __attribute__((aligned(16))) float abw[4][2][64];
   const int b = blockIdx.y;
   const int t = threadIdx.x;
   const float gam_t = (t < C) ? gamma[t] : 0.f, bet_t = (t < C) ? beta[t] : 0.f;
@@ -435,30 +436,74 @@ __global__ __launch_bounds__(256) void affine_act_gn_kernel(const float* __restr
     q0 = *reinterpret_cast<const float4*>(rb + v0 * rld);
     if (ACC) o0 = *reinterpret_cast<const float4*>(ob + v0 * old_);
   }
-  reduce_rows(stats + (int64_t)b * rows * C * 2, rows, C * 2, part, tot);
   const int cg = C / G;
-  if (t < C) {
-    const int g = t / cg;
+  float4 av, bv;
+  if (is_pow2(C) && cg <= 16) {
+    // wave-level prologue, no workgroup barrier: each wave redundantly sums the partial rows (lane = row slot x
+    // channel), folds them with DPP / permlane sums, derives its group's mean and rstd, and hands the per-channel
+    // coefficients to its own lanes through a private LDS strip (LDS operations of one wave execute in order).
+    const int lane = t & 63, wave = t >> 6;
+    const int c = lane & (C - 1), rs = lane / C, nslots = 64 / C;
+    const float gam = gamma[c], bet = beta[c];
+    const double2* st2 = reinterpret_cast<const double2*>(stats + (int64_t)b * rows * C * 2);
     double s = 0, ss = 0;
-    for (int c = g * cg; c < (g + 1) * cg; ++c) { s += tot[c * 2]; ss += tot[c * 2 + 1]; }
+    {
+      int r = rs;
+      for (; r + 3 * nslots < rows; r += 4 * nslots) {
+        double2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = st2[(int64_t)(r + u * nslots) * C + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s += v[u].x; ss += v[u].y; }
+      }
+      for (; r < rows; r += nslots) { const double2 v = st2[(int64_t)r * C + c]; s += v.x; ss += v.y; }
+    }
+    s = wave_classsum_d(s, C); ss = wave_classsum_d(ss, C);
+    const double gs = wave_groupsum_d(s, cg), gss = wave_groupsum_d(ss, cg);
     const double n = count * cg;
-    const double mean = s / n;
-    double var = ss / n - mean * mean;
+    const double mean = gs / n;
+    double var = gss / n - mean * mean;
     if (var < 0) var = 0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
-    const float av = gam_t * (float)rstd;
-    const float bv = bet_t - (float)mean * av;
-    ab[0][t] = av; ab[1][t] = bv;
-    if (blockIdx.x == 0) {
-      a_out[b * C + t] = av; b_out[b * C + t] = bv;
-      if (sumraw) sumraw[b * C + t] = tot[t * 2];
-      if (t % cg == 0) { mr_out[(b * G + g) * 2] = (float)mean; mr_out[(b * G + g) * 2 + 1] = (float)rstd; }
+    const float a1 = gam * (float)rstd;
+    const float b1 = bet - (float)mean * a1;
+    if (lane < C) { abw[wave][0][lane] = a1; abw[wave][1][lane] = b1; }
+    if (blockIdx.x == 0 && wave == 0 && lane < C) {
+      a_out[b * C + c] = a1; b_out[b * C + c] = b1;
+      if (sumraw) sumraw[b * C + c] = s;
+      if (c % cg == 0) { const int g = c / cg; mr_out[(b * G + g) * 2] = (float)mean; mr_out[(b * G + g) * 2 + 1] = (float)rstd; }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!act0) return;
+    av = *reinterpret_cast<const float4*>(&abw[wave][0][c4 * 4]);
+    bv = *reinterpret_cast<const float4*>(&abw[wave][1][c4 * 4]);
+  } else {
+    reduce_rows(stats + (int64_t)b * rows * C * 2, rows, C * 2, part, tot);
+    if (t < C) {
+      const int g = t / cg;
+      double s = 0, ss = 0;
+      for (int c = g * cg; c < (g + 1) * cg; ++c) { s += tot[c * 2]; ss += tot[c * 2 + 1]; }
+      const double n = count * cg;
+      const double mean = s / n;
+      double var = ss / n - mean * mean;
+      if (var < 0) var = 0;
+      const double rstd = 1.0 / sqrt(var + (double)eps);
+      const float a1 = gam_t * (float)rstd;
+      const float b1 = bet_t - (float)mean * a1;
+      ab[0][t] = a1; ab[1][t] = b1;
+      if (blockIdx.x == 0) {
+        a_out[b * C + t] = a1; b_out[b * C + t] = b1;
+        if (sumraw) sumraw[b * C + t] = tot[t * 2];
+        if (t % cg == 0) { mr_out[(b * G + g) * 2] = (float)mean; mr_out[(b * G + g) * 2 + 1] = (float)rstd; }
+      }
+    }
+    __syncthreads();
+    if (!act0) return;
+    av = make_float4(ab[0][c4 * 4], ab[0][c4 * 4 + 1], ab[0][c4 * 4 + 2], ab[0][c4 * 4 + 3]);
+    bv = make_float4(ab[1][c4 * 4], ab[1][c4 * 4 + 1], ab[1][c4 * 4 + 2], ab[1][c4 * 4 + 3]);
   }
-  __syncthreads();
-  if (!act0) return;
-  const float4 av = make_float4(ab[0][c4 * 4], ab[0][c4 * 4 + 1], ab[0][c4 * 4 + 2], ab[0][c4 * 4 + 3]);
-  const float4 bv = make_float4(ab[1][c4 * 4], ab[1][c4 * 4 + 1], ab[1][c4 * 4 + 2], ab[1][c4 * 4 + 3]);
   // iterations 1.. are requested before iteration 0 is finished (loads first, then math and stores)
   constexpr int PF = 3;
   float4 qn[PF], on[PF];
@@ -519,6 +564,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* _
   __shared__ double gsh[64];
   __shared__ double zred[64];
   __shared__ float coef[3][64];
+  __shared__ __attribute__((aligned(16))) float coefw[4][3][64];
   const int t = threadIdx.x;
   const int cg = C / G;
   const bool leader = (blockIdx.x == 0 && blockIdx.y == 0);
@@ -540,95 +586,163 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* _
     if (a) aq = *reinterpret_cast<const float4*>(a + co);
     if (bb) bq = *reinterpret_cast<const float4*>(bb + co);
   }
-  const double w = wptr ? (double)*wptr : 1.0;
-  const double gam = (t < C) ? (double)gamma[t] : 0.0;
-  const int gq = (t < C) ? t / cg : 0;
-  double mean_c[GNF_MAXB], rstd_c[GNF_MAXB], ps[GNF_MAXB], pf[GNF_MAXB];
-  const int ncol3 = C * 3;
-  const int nrl3 = 256 / ncol3 > 0 ? 256 / ncol3 : 1;
-  const int q3 = t % ncol3, rl3 = t / ncol3;
-  const bool want_f = leader && dbias_conv;
-#pragma unroll
-  for (int k = 0; k < GNF_MAXB; ++k) {
-    ps[k] = 0; pf[k] = 0; mean_c[k] = 0; rstd_c[k] = 1;
-    if (k < nb) {
-      const int b = leader ? ((int)blockIdx.y + 1 + k) % B : (int)blockIdx.y;
-      mean_c[k] = mean_rstd[(b * G + gq) * 2]; rstd_c[k] = mean_rstd[(b * G + gq) * 2 + 1];
-      if (want_f && t < C) pf[k] = sumraw[b * C + t];
-    }
-  }
-  if (rl3 < nrl3)
-    for (int r = rl3; r < rows; r += nrl3) {
-#pragma unroll
-      for (int k = 0; k < GNF_MAXB; ++k)
-        if (k < nb) {
-          const int b = leader ? ((int)blockIdx.y + 1 + k) % B : (int)blockIdx.y;
-          ps[k] += sums[((int64_t)b * rows + r) * ncol3 + q3];
-        }
-    }
-  if (t < C) gsh[t] = gam;
-  // ---- LDS phase, sample by sample (the leader's own sample comes last so that coef[] ends up its own)
-  double dg = 0, db = 0, dz = 0, dbc = 0;
-#pragma unroll
-  for (int k = 0; k < GNF_MAXB; ++k) {
-    if (k < nb) {
-      part[t] = ps[k];
-      __syncthreads();
-      if (t < ncol3) {
-        double acc = 0;
-        for (int r = 0; r < nrl3; ++r) acc += part[r * ncol3 + t];
-        tot[t] = acc;
-      }
-      __syncthreads();
-      if (t < C && (t % cg) == 0) {
-        // one thread per group: mean_c / rstd_c of this thread ARE the group's
-        double c1 = 0, c2 = 0;
-        for (int c = t; c < t + cg; ++c) {
-          const double S1 = tot[c * 3], S2 = tot[c * 3 + 1];
-          c1 += gsh[c] * w * S1;
-          c2 += gsh[c] * w * rstd_c[k] * (S2 - mean_c[k] * S1);
-        }
-        const double n = count * cg;
-        gc[gq * 2] = c1 / n; gc[gq * 2 + 1] = c2 / n;
-      }
-      __syncthreads();
-      if (t < C) {
-        const double S1 = tot[t * 3], S2 = tot[t * 3 + 1], Sz = tot[t * 3 + 2];
-        const double c1 = gc[gq * 2], c2 = gc[gq * 2 + 1];
-        const double rs = rstd_c[k], mn = mean_c[k];
-        const double Av = rs * gam * w, Bv = -rs * c1 + rs * rs * c2 * mn, Cv = -rs * rs * c2;
-        coef[0][t] = (float)Av; coef[1][t] = (float)Bv; coef[2][t] = (float)Cv;
-        if (leader) {
-          dg += w * rs * (S2 - mn * S1);
-          db += w * S1;
-          dz += Sz;
-          if (dbias_conv) dbc += Av * S1 + count * Bv + Cv * pf[k];
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if (leader) {
-    if (t < C) {
-      if (dgamma) dgamma[t] = (float)dg;
-      if (dbeta) dbeta[t] = (float)db;
-      if (dbias_conv) dbias_conv[t] = (float)dbc;
-    }
-    if (dalpha) {
-      if (t < 64) zred[t] = (t < C) ? dz : 0.0;
-      __syncthreads();
-      if (t == 0) {
-        double sdz = 0;
-        for (int i = 0; i < 64; ++i) sdz += zred[i];
-        *dalpha = (float)sdz;
-      }
-    }
-  }
-  if (!act0) return;
-  const float av[4] = {aq.x, aq.y, aq.z, aq.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
   float Av[4], Bv[4], Cv[4];
+  if (is_pow2(C) && cg <= 16) {
+    // wave-level prologue (no workgroup barrier): lane = row slot x channel; partial rows -> class sums over the
+    // row slots -> DPP group sums -> GroupNorm-backward coefficients, redundantly in every wave.  Wave 0 of the
+    // leader workgroup walks all B samples to emit dgamma / dbeta / dalpha / conv-bias gradient.
+    const int lane = t & 63, wave = t >> 6;
+    const int c = lane & (C - 1), rs = lane / C, nslots = 64 / C;
+    const int gq = c / cg;
+    const double w = wptr ? (double)*wptr : 1.0;
+    const double gam = (double)gamma[c];
+    const bool lead_w = leader && wave == 0;
+    const int nbw = lead_w ? B : 1;
+    double dg = 0, db = 0, dz = 0, dbc = 0;
+    for (int k = 0; k < nbw; ++k) {
+      const int b = lead_w ? ((int)blockIdx.y + 1 + k) % B : (int)blockIdx.y;  // own sample last
+      const double mn = mean_rstd[(b * G + gq) * 2], rsd = mean_rstd[(b * G + gq) * 2 + 1];
+      const double pf = (lead_w && dbias_conv) ? sumraw[b * C + c] : 0.0;
+      const double* sb = sums + (int64_t)b * rows * C * 3 + c * 3;
+      double S1 = 0, S2 = 0, Sz = 0;
+      {
+        int r = rs;
+        for (; r + 3 * nslots < rows; r += 4 * nslots) {
+          double v[4][3];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { Av[j] = coef[0][c4 * 4 + j]; Bv[j] = coef[1][c4 * 4 + j]; Cv[j] = coef[2][c4 * 4 + j]; }
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) v[u][q] = sb[(int64_t)(r + u * nslots) * C * 3 + q];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { S1 += v[u][0]; S2 += v[u][1]; Sz += v[u][2]; }
+        }
+        for (; r < rows; r += nslots) { S1 += sb[(int64_t)r * C * 3]; S2 += sb[(int64_t)r * C * 3 + 1]; Sz += sb[(int64_t)r * C * 3 + 2]; }
+      }
+      S1 = wave_classsum_d(S1, C); S2 = wave_classsum_d(S2, C);
+      if (dalpha) Sz = wave_classsum_d(Sz, C);
+      const double n = count * cg;
+      const double c1 = wave_groupsum_d(gam * w * S1, cg) / n;
+      const double c2 = wave_groupsum_d(gam * w * rsd * (S2 - mn * S1), cg) / n;
+      const double A1 = rsd * gam * w, B1 = -rsd * c1 + rsd * rsd * c2 * mn, C1 = -rsd * rsd * c2;
+      if (k == nbw - 1 && lane < C) { coefw[wave][0][lane] = (float)A1; coefw[wave][1][lane] = (float)B1; coefw[wave][2][lane] = (float)C1; }
+      if (lead_w) {
+        dg += w * rsd * (S2 - mn * S1);
+        db += w * S1;
+        dz += Sz;
+        if (dbias_conv) dbc += A1 * S1 + count * B1 + C1 * pf;
+      }
+    }
+    if (lead_w) {
+      if (lane < C) {
+        if (dgamma) dgamma[c] = (float)dg;
+        if (dbeta) dbeta[c] = (float)db;
+        if (dbias_conv) dbias_conv[c] = (float)dbc;
+      }
+      if (dalpha) {
+        const double sdz = wave_sum_d(lane < C ? dz : 0.0);
+        if (lane == 0) *dalpha = (float)sdz;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!act0) return;
+    const float4 qa = *reinterpret_cast<const float4*>(&coefw[wave][0][c4 * 4]);
+    const float4 qb = *reinterpret_cast<const float4*>(&coefw[wave][1][c4 * 4]);
+    const float4 qc = *reinterpret_cast<const float4*>(&coefw[wave][2][c4 * 4]);
+    Av[0] = qa.x; Av[1] = qa.y; Av[2] = qa.z; Av[3] = qa.w;
+    Bv[0] = qb.x; Bv[1] = qb.y; Bv[2] = qb.z; Bv[3] = qb.w;
+    Cv[0] = qc.x; Cv[1] = qc.y; Cv[2] = qc.z; Cv[3] = qc.w;
+  } else {
+    const double w = wptr ? (double)*wptr : 1.0;
+    const double gam = (t < C) ? (double)gamma[t] : 0.0;
+    const int gq = (t < C) ? t / cg : 0;
+    double mean_c[GNF_MAXB], rstd_c[GNF_MAXB], ps[GNF_MAXB], pf[GNF_MAXB];
+    const int ncol3 = C * 3;
+    const int nrl3 = 256 / ncol3 > 0 ? 256 / ncol3 : 1;
+    const int q3 = t % ncol3, rl3 = t / ncol3;
+    const bool want_f = leader && dbias_conv;
+  #pragma unroll
+    for (int k = 0; k < GNF_MAXB; ++k) {
+      ps[k] = 0; pf[k] = 0; mean_c[k] = 0; rstd_c[k] = 1;
+      if (k < nb) {
+        const int b = leader ? ((int)blockIdx.y + 1 + k) % B : (int)blockIdx.y;
+        mean_c[k] = mean_rstd[(b * G + gq) * 2]; rstd_c[k] = mean_rstd[(b * G + gq) * 2 + 1];
+        if (want_f && t < C) pf[k] = sumraw[b * C + t];
+      }
+    }
+    if (rl3 < nrl3)
+      for (int r = rl3; r < rows; r += nrl3) {
+  #pragma unroll
+        for (int k = 0; k < GNF_MAXB; ++k)
+          if (k < nb) {
+            const int b = leader ? ((int)blockIdx.y + 1 + k) % B : (int)blockIdx.y;
+            ps[k] += sums[((int64_t)b * rows + r) * ncol3 + q3];
+          }
+      }
+    if (t < C) gsh[t] = gam;
+    // ---- LDS phase, sample by sample (the leader's own sample comes last so that coef[] ends up its own)
+    double dg = 0, db = 0, dz = 0, dbc = 0;
+  #pragma unroll
+    for (int k = 0; k < GNF_MAXB; ++k) {
+      if (k < nb) {
+        part[t] = ps[k];
+        __syncthreads();
+        if (t < ncol3) {
+          double acc = 0;
+          for (int r = 0; r < nrl3; ++r) acc += part[r * ncol3 + t];
+          tot[t] = acc;
+        }
+        __syncthreads();
+        if (t < C && (t % cg) == 0) {
+          // one thread per group: mean_c / rstd_c of this thread ARE the group's
+          double c1 = 0, c2 = 0;
+          for (int c = t; c < t + cg; ++c) {
+            const double S1 = tot[c * 3], S2 = tot[c * 3 + 1];
+            c1 += gsh[c] * w * S1;
+            c2 += gsh[c] * w * rstd_c[k] * (S2 - mean_c[k] * S1);
+          }
+          const double n = count * cg;
+          gc[gq * 2] = c1 / n; gc[gq * 2 + 1] = c2 / n;
+        }
+        __syncthreads();
+        if (t < C) {
+          const double S1 = tot[t * 3], S2 = tot[t * 3 + 1], Sz = tot[t * 3 + 2];
+          const double c1 = gc[gq * 2], c2 = gc[gq * 2 + 1];
+          const double rs = rstd_c[k], mn = mean_c[k];
+          const double Av = rs * gam * w, Bv = -rs * c1 + rs * rs * c2 * mn, Cv = -rs * rs * c2;
+          coef[0][t] = (float)Av; coef[1][t] = (float)Bv; coef[2][t] = (float)Cv;
+          if (leader) {
+            dg += w * rs * (S2 - mn * S1);
+            db += w * S1;
+            dz += Sz;
+            if (dbias_conv) dbc += Av * S1 + count * Bv + Cv * pf[k];
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (leader) {
+      if (t < C) {
+        if (dgamma) dgamma[t] = (float)dg;
+        if (dbeta) dbeta[t] = (float)db;
+        if (dbias_conv) dbias_conv[t] = (float)dbc;
+      }
+      if (dalpha) {
+        if (t < 64) zred[t] = (t < C) ? dz : 0.0;
+        __syncthreads();
+        if (t == 0) {
+          double sdz = 0;
+          for (int i = 0; i < 64; ++i) sdz += zred[i];
+          *dalpha = (float)sdz;
+        }
+      }
+    }
+    if (!act0) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { Av[j] = coef[0][c4 * 4 + j]; Bv[j] = coef[1][c4 * 4 + j]; Cv[j] = coef[2][c4 * 4 + j]; }
+  }
+  const float av[4] = {aq.x, aq.y, aq.z, aq.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w};
   // iterations 1.. are requested before iteration 0 is finished (loads first, then math and stores)
   constexpr int PF = 3;
   float4 dn[PF], rn[PF], pn[PF];

@@ -153,6 +153,14 @@ __device__ __forceinline__ double wave_classsum_d(double v, int cpb) {
   return v;
 }
 __device__ __forceinline__ bool is_pow2(int x) { return (x & (x - 1)) == 0; }
+// every lane ends up with the sum over its aligned group of cg consecutive lanes (cg = 1, 2, 4, 8 or 16): DPP only
+__device__ __forceinline__ double wave_groupsum_d(double v, int cg) {
+  if (cg >= 2) v += dpp_d<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (cg >= 4) v += dpp_d<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (cg >= 8) v += dpp_d<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of each 8
+  if (cg >= 16) v += dpp_d<0x140>(v);  // row_mirror: lane i <-> 15 - i of each 16
+  return v;
+}
 
 // sum over the lanes of a wave that share (lane % cpb); result valid in lanes < cpb (any cpb <= 64)
 __device__ __forceinline__ double wave_sum_strided(double v, int cpb) {
