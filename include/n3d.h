@@ -108,6 +108,15 @@ int n3d_conv_bwd_data(const n3d_conv_geom* g, const float* dy, int64_t dyld, con
 int n3d_conv_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld,
                         float* dw, float* dbias, int flags, const float* in_gate,
                         void* ws, size_t ws_bytes, n3d_final_job* deferred /* NULL: finish now */, void* stream);
+
+/* Data gradient AND weight gradient of one convolution: exactly n3d_conv_bwd_data(...) followed by
+ * n3d_conv_bwd_weight(...) (same arguments, same results), but issued as ONE launch when both halves are small
+ * MFMA problems (channel counts multiples of 16 on the 2^3..8^3 levels), where each half alone leaves most of the
+ * chip idle.  Replaces the autograd backward of nn.Conv3d (prim_ops.py:109-110) on those levels. */
+int n3d_conv_bwd_both(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, const float* w, float* dx,
+                      int64_t dxld, int flags_data, const float* relu_src, int64_t rld, const float* out_gate, void* ws_data,
+                      size_t ws_data_bytes, float* dw, float* dbias, int flags_weight, const float* in_gate, void* ws_weight,
+                      size_t ws_weight_bytes, n3d_final_job* deferred, void* stream);
 /* transposed convolution y[i side] = convT(x[o side]) + bias; same kernels with the roles swapped */
 int n3d_convT_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias,
                   float* y, int64_t yld, int flags, const float* in_gate, double* stats,

@@ -759,9 +759,22 @@ int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags);
 int mfma_pack_layout(const n3d_conv_geom* g, bool data_grad, int flags);  // 1 gemm16, 2 vox64, 0 none
 int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                   float* partial, size_t avail_floats, int* nchunks_out, hipStream_t s);
+struct Wg16Args;
 int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
-                   float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s);
+                   float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s,
+                   Wg16Args* prepared = nullptr);
+int mfma_bwd_dual_try(const n3d_conv_geom* g, const float* dy, int64_t dyld, const float* wp_packed, float* dx, int64_t dxld, int flags_d,
+                      const float* relu_src, int64_t rld, const float* out_gate, const float* x, int64_t xld, int flags_w,
+                      const float* in_gate, float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out,
+                      hipStream_t s);
+void mfma_pack16(const float* w, float* wp, int Co, int Ci, int taps, int data_grad, hipStream_t s);
 }
+
+// request to fold the data gradient into the weight-gradient launch (n3d_conv_bwd_both)
+struct DualReq {
+  const float* w; float* dx; int64_t dxld; int flags; const float* relu_src; int64_t rld; const float* out_gate;
+  void* ws; size_t ws_bytes; bool done;
+};
 
 extern "C" {
 
@@ -885,7 +898,8 @@ static void fill_job(n3d_final_job* j, const float* partial, const float* pbias,
 }
 
 static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, float* dw, float* dbias, int flags,
-                     const float* in_gate, void* ws, size_t ws_bytes, void* stream, bool transposed, n3d_final_job* deferred) {
+                     const float* in_gate, void* ws, size_t ws_bytes, void* stream, bool transposed, n3d_final_job* deferred,
+                     DualReq* dual = nullptr) {
   if (deferred) deferred->nchunks = 0;  // 0 = nothing deferred
   hipStream_t s = (hipStream_t)stream;
   const int taps = g->k * g->k * g->k;
@@ -936,8 +950,18 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     int nch = 0, ntl = 0;
     const size_t nt16 = (size_t)taps * (g->Ci / 16) * (g->Co / 16);
     float* pb = wsf + (1024 + nt16) * 256;
-    if (g->Ci % 16 == 0 && g->Co % 16 == 0 && (1024 + nt16) * (256 + 16) <= avail &&
-        mfma_wgrad_try(g, x, xld, dy, dyld, flags, in_gate, wsf, pb, (1024 + nt16) * 256, &nch, &ntl, s) == 1) {
+    int handled = 0;
+    if (g->Ci % 16 == 0 && g->Co % 16 == 0 && (1024 + nt16) * (256 + 16) <= avail) {
+      if (dual && !transposed && dual->ws && dual->ws_bytes >= (size_t)taps * g->Ci * g->Co * 4) {
+        if (!(dual->flags & N3D_PREPACKED)) mfma_pack16(dual->w, (float*)dual->ws, g->Co, g->Ci, taps, 1, s);
+        handled = mfma_bwd_dual_try(g, dy, dyld, (const float*)dual->ws, dual->dx, dual->dxld, dual->flags, dual->relu_src, dual->rld,
+                                    dual->out_gate, x, xld, flags, in_gate, wsf, pb, (1024 + nt16) * 256, &nch, &ntl, s);
+        if (handled < 0) return handled;
+        if (handled == 1) dual->done = true;
+      }
+      if (!handled) handled = mfma_wgrad_try(g, x, xld, dy, dyld, flags, in_gate, wsf, pb, (1024 + nt16) * 256, &nch, &ntl, s);
+    }
+    if (handled == 1) {
       const int nout = g->Co * g->Ci * taps + g->Co;
       if (deferred) {
         fill_job(deferred, wsf, pb, dw, transposed ? nullptr : dbias, nch, ntl, g->Ci / 16, g->Co / 16, 16, 16, g->Co, g->Ci, taps);
@@ -981,6 +1005,19 @@ int n3d_conv_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, con
   if (int e = check_geom(g, "conv_bwd_weight")) return e;
   N3D_CHECK_ARG(x && dy && (dw || dbias), "conv_bwd_weight: bad pointers");
   return run_wgrad(g, x, xld, dy, dyld, dw, dbias, flags, in_gate, ws, ws_bytes, stream, false, deferred);
+}
+
+int n3d_conv_bwd_both(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, const float* w, float* dx,
+                      int64_t dxld, int flags_data, const float* relu_src, int64_t rld, const float* out_gate, void* ws_data,
+                      size_t ws_data_bytes, float* dw, float* dbias, int flags_weight, const float* in_gate, void* ws_weight,
+                      size_t ws_weight_bytes, n3d_final_job* deferred, void* stream) {
+  if (int e = check_geom(g, "conv_bwd_both")) return e;
+  N3D_CHECK_ARG(x && dy && w && dx && (dw || dbias) && dyld >= g->Co && dxld >= g->Ci, "conv_bwd_both: bad pointers/pitches");
+  DualReq rq = {w, dx, dxld, flags_data & ~N3D_RELU_IN, relu_src, rld, out_gate, ws_data, ws_data_bytes, false};
+  if (int e = run_wgrad(g, x, xld, dy, dyld, dw, dbias, flags_weight, in_gate, ws_weight, ws_weight_bytes, stream, false, deferred, &rq)) return e;
+  if (rq.done) return N3D_OK;
+  return run_gather(g, true, dy, dyld, w, nullptr, dx, dxld, flags_data & ~N3D_RELU_IN, nullptr, relu_src, rld, out_gate, nullptr, ws_data,
+                    ws_data_bytes, stream);
 }
 
 int n3d_conv_pack_info(const n3d_conv_geom* g, int data_grad, int flags, int32_t* layout, int32_t* cdp, int64_t* floats) {

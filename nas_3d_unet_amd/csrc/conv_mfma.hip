@@ -48,16 +48,15 @@ __global__ void pack16_kernel(const float* __restrict__ w, float* __restrict__ w
 }
 
 template <int MT, int NT, int KSPLIT>
-__global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) void conv_gemm16_kernel(MfArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const int by, float* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, kk = lane >> 4;
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd, Ns = (int64_t)a.Ds * a.Hs * a.Ws;
   const int64_t Mtot = (int64_t)a.B * Nd;
   constexpr int ROWS_PER_WAVE = 16 * MT;
   constexpr int ROWS_PER_BLOCK = ROWS_PER_WAVE * (KSPLIT == 1 ? 4 : 1);
-  const int64_t row0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (KSPLIT == 1 ? wave * ROWS_PER_WAVE : 0);
-  const int n0 = blockIdx.y * 16 * NT;
+  const int64_t row0 = (int64_t)bx * ROWS_PER_BLOCK + (KSPLIT == 1 ? wave * ROWS_PER_WAVE : 0);
+  const int n0 = by * 16 * NT;
 
   // A-side rows of this lane (voxel m of each M tile)
   int rb[MT], rd[MT], rh[MT], rw[MT];
@@ -258,7 +257,7 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
   if (a.stats && KSPLIT > 1) {
     // only wave 0 holds data: its lanes kk == 0 write the block's partial row directly (no LDS, no barrier)
     if (wave == 0) {
-      const uint32_t first = (uint32_t)blockIdx.x * ROWS_PER_BLOCK;
+      const uint32_t first = (uint32_t)bx * ROWS_PER_BLOCK;
       uint32_t ub2, ur2;
       a.fNd.divmod(first, ub2, ur2);
       const int row = (int)(ur2 / ROWS_PER_BLOCK);
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
       const int q2 = threadIdx.x & 1, col = (threadIdx.x >> 1) & 15, n = threadIdx.x >> 5;
       double s = 0;
       for (int w = 0; w < nw; ++w) s += red[((w * NT + n) * 16 + col) * 2 + q2];
-      const uint32_t first = (uint32_t)blockIdx.x * ROWS_PER_BLOCK;
+      const uint32_t first = (uint32_t)bx * ROWS_PER_BLOCK;
       uint32_t ub2, ur2;
       a.fNd.divmod(first, ub2, ur2);
       const int b = (int)ub2;
@@ -293,6 +292,12 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
       a.stats[(((int64_t)b * a.rows_per_sample + row) * a.Cd + n0 + n * 16 + col) * 2 + q2] = s;
     }
   }
+}
+
+template <int MT, int NT, int KSPLIT>
+__global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) void conv_gemm16_kernel(MfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  gemm16_body<MT, NT, KSPLIT>(a, blockIdx.x, blockIdx.y, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -312,12 +317,12 @@ struct Wg16Args {
   FastDiv fNo, fWo, fHo, fTco, fTci;
 };
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wg16Args a) {
-  __shared__ f32x4 l4[3 * 64];
-  __shared__ float lb[4][16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// body for one (tile, chunk) unit executed by 256 threads (tid = 0..255); `active` = false units only take part in
+// the workgroup barrier (the dual backward kernel packs four units into one 1024-thread workgroup)
+__device__ __forceinline__ void wgrad16_body(const Wg16Args& a, const int tile, const int cy, const int ntiles, const int tid,
+                                             const bool active, f32x4* l4 /*[3*64]*/, float (*lb)[16] /*[4][16]*/) {
+  const int lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, kk = lane >> 4;
-  const int tile = blockIdx.x;
   uint32_t t1, ucot, utap, ucit;
   a.fTco.divmod((uint32_t)tile, t1, ucot);
   a.fTci.divmod(t1, utap, ucit);
@@ -325,9 +330,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wg16Args a) {
   const int kd = (a.k == 3) ? tap / 9 : 0, kh = (a.k == 3) ? (tap % 9) / 3 : 0, kw = (a.k == 3) ? tap % 3 : 0;
   const int64_t No = (int64_t)a.Do * a.Ho * a.Wo, Ni = (int64_t)a.Di * a.Hi * a.Wi;
   const int64_t total = (int64_t)a.B * No;
-  const int64_t c0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t c0 = (int64_t)cy * a.chunk;
   int64_t c1 = c0 + a.chunk;
   if (c1 > total) c1 = total;
+  if (!active) c1 = c0;  // no work
   const bool relu_in = a.flags & N3D_RELU_IN;
   const bool do_bias = (tap == 0 && cit == 0);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -376,14 +382,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wg16Args a) {
     if (kk == 0) lb[wave][m] = bsum;
   }
   __syncthreads();
-  if (wave == 0) {
+  if (wave == 0 && active) {
     acc += l4[lane]; acc += l4[64 + lane]; acc += l4[128 + lane];
-    const int ntiles = gridDim.x;
-    float* p = a.partial + ((int64_t)blockIdx.y * ntiles + tile) * 256;
+    float* p = a.partial + ((int64_t)cy * ntiles + tile) * 256;
     // D: rows (ci) 4*kk + r, column (co) m  ->  q = ci*16 + co
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[(kk * 4 + r) * 16 + m] = acc[r];
-    if (do_bias && lane < 16) a.pbias[((int64_t)blockIdx.y * a.tco + cot) * 16 + lane] = lb[0][lane] + lb[1][lane] + lb[2][lane] + lb[3][lane];
+    if (do_bias && lane < 16) a.pbias[((int64_t)cy * a.tco + cot) * 16 + lane] = lb[0][lane] + lb[1][lane] + lb[2][lane] + lb[3][lane];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wg16Args a) {
+  __shared__ f32x4 l4[3 * 64];
+  __shared__ float lb[4][16];
+  wgrad16_body(a, blockIdx.x, blockIdx.y, gridDim.x, threadIdx.x, true, l4, lb);
+}
+
+// Backward of one deep-level conv in ONE launch: workgroups [0, nA) run the data-gradient GEMM (K split over the 16
+// waves), workgroups [nA, ..) each run four (tap, channel tile, chunk) units of the weight gradient.  Both halves
+// only read the same d(raw) tensor, so nothing orders them; on the 2^3 .. 8^3 levels either half alone leaves most
+// of the chip idle and costs a full launch + memory round trip.
+struct DualArgs { MfArgs d; Wg16Args w; int nA, gxA, ntilesB, nB; };
+
+__global__ __launch_bounds__(1024, 4) void conv_bwd16_dual_kernel(DualArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int L = blockIdx.x;
+  if (L < q.nA) {
+    gemm16_body<1, 1, 16>(q.d, L % q.gxA, L / q.gxA, lds);
+  } else {
+    f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+    float (*lb)[16] = reinterpret_cast<float (*)[16]>(lds + 4 * 3 * 64 * 4);
+    const int sub = threadIdx.x >> 8;
+    const int unit = (L - q.nA) * 4 + sub;
+    const bool active = unit < q.nB;
+    const int u = active ? unit : 0;
+    wgrad16_body(q.w, u % q.ntilesB, u / q.ntilesB, q.ntilesB, threadIdx.x & 255, active, l4 + sub * 3 * 64, lb + sub * 4);
   }
 }
 
@@ -995,6 +1028,10 @@ static void launch_g16(const MfArgs& a, int64_t M, hipStream_t s) {
   hipLaunchKernelGGL((conv_gemm16_kernel<MT, NT, KS>), grid, dim3(KS == 16 ? 1024 : 256), shm, s, a);
 }
 
+void mfma_pack16(const float* w, float* wp, int Co, int Ci, int taps, int data_grad, hipStream_t s) {
+  hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)cdiv((int64_t)taps * Co * Ci, 256)), dim3(256), 0, s, w, wp, Co, Ci, taps, data_grad);
+}
+
 int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
                   int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate, double* stats,
                   void* ws, size_t ws_bytes, hipStream_t s) {
@@ -1059,7 +1096,8 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
 
 // returns 1 if handled
 int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
-                   float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s) {
+                   float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s,
+                   Wg16Args* prepared) {
   if (g->depthwise || g->Ci % 16 != 0 || g->Co % 16 != 0) return 0;
   const int taps = g->k * g->k * g->k;
   const int64_t No = (int64_t)g->Do * g->Ho * g->Wo;
@@ -1083,8 +1121,44 @@ int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const fl
   if (total + 64 >= (1ll << 31)) return 0;
   a.fNo = FastDiv((uint32_t)No); a.fWo = FastDiv((uint32_t)g->Wo); a.fHo = FastDiv((uint32_t)g->Ho);
   a.fTco = FastDiv((uint32_t)a.tco); a.fTci = FastDiv((uint32_t)a.tci);
-  hipLaunchKernelGGL(conv_wgrad16_kernel, dim3(ntiles, (unsigned)nch), dim3(256), 0, s, a);
   *nchunks_out = (int)nch; *ntiles_out = ntiles;
+  if (prepared) { *prepared = a; return 1; }
+  hipLaunchKernelGGL(conv_wgrad16_kernel, dim3(ntiles, (unsigned)nch), dim3(256), 0, s, a);
+  return 1;
+}
+
+// Data gradient + weight gradient of a non-transposed conv whose channel counts are multiples of 16 and whose data
+// gradient is a tiny GEMM (K-split plan), in one launch.  Returns 1 if launched, 0 if the shape does not qualify.
+int mfma_bwd_dual_try(const n3d_conv_geom* g, const float* dy, int64_t dyld, const float* wp_packed, float* dx, int64_t dxld, int flags_d,
+                      const float* relu_src, int64_t rld, const float* out_gate, const float* x, int64_t xld, int flags_w,
+                      const float* in_gate, float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out,
+                      hipStream_t s) {
+  if (vx_plan(g).ok) return 0;
+  const G16Plan p = g16_plan(g, true);
+  if (!p.ok || p.ksplit != 16) return 0;
+  if (dyld % 4 != 0 || !aligned16(dy)) return 0;
+  MfArgs a;
+  a.src = dy; a.sld = dyld; a.dst = dx; a.dld = dxld; a.bias = nullptr; a.k = g->k; a.flags = flags_d; a.B = g->B;
+  a.in_gate = nullptr; a.relu_src = relu_src; a.rld = rld; a.out_gate = out_gate; a.stats = nullptr; a.rows_per_sample = 0;
+  a.Ds = g->Do; a.Hs = g->Ho; a.Ws = g->Wo; a.Cs = g->Co; a.Dd = g->Di; a.Hd = g->Hi; a.Wd = g->Wi; a.Cd = g->Ci;
+  a.sn = 1; a.off = g->pad; a.dt = -g->dil; a.den = g->stride;
+  const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
+  if ((int64_t)g->B * Nd >= (1ll << 31)) return 0;
+  a.fNd = FastDiv((uint32_t)Nd); a.fWd = FastDiv((uint32_t)a.Wd); a.fHd = FastDiv((uint32_t)a.Hd); a.fC16 = FastDiv((uint32_t)(a.Cs / 16));
+  a.wp = wp_packed;
+  DualArgs q;
+  q.d = a;
+  if (!mfma_wgrad_try(g, x, xld, dy, dyld, flags_w, in_gate, partial, pbias, avail_floats, nchunks_out, ntiles_out, s, &q.w)) return 0;
+  const int64_t M = (int64_t)g->B * Nd;
+  q.gxA = (int)cdiv(M, 16);
+  q.nA = q.gxA * (a.Cd / 16);
+  q.ntilesB = *ntiles_out;
+  q.nB = *ntiles_out * *nchunks_out;
+  const size_t shm_a = (size_t)15 * 256 * sizeof(float) + (size_t)16 * 16 * 2 * sizeof(double);
+  const size_t shm_b = (size_t)4 * 3 * 64 * 16 + (size_t)4 * 4 * 16 * 4;
+  hipLaunchKernelGGL(conv_bwd16_dual_kernel, dim3((unsigned)(q.nA + cdiv(q.nB, 4))), dim3(1024), shm_a > shm_b ? shm_a : shm_b, s, q);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("conv(bwd dual) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
   return 1;
 }
 

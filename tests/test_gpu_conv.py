@@ -120,6 +120,16 @@ def test_conv_family(cin, cout, k, stride, dil, transposed, B, shape):
     assert_close(dx.t, xc2.grad, 5e-5, "dx relu-mask+gate")
     K.conv_bwd_weight(g, x, dy, dw, None, K.RELU_IN, gate, False)
     assert_close(dw, wc2.grad, 1e-4, "dw relu+gate")
+    # ---------------- combined backward (one launch on the deep-level shapes): same results as the two calls
+    dx3 = K.as_view(K.empty_ndhwc(B, cin, *shape, dev))
+    dw3, db3 = torch.zeros_like(w), torch.zeros_like(b)
+    K.conv_bwd_both(g, x, dy, w, dx3, dw3, db3, 0, None, None, 0, None)
+    assert_close(dx3.t, xc.grad, 5e-5, "dx (both)")
+    assert_close(dw3, wc.grad, 1e-4, "dw (both)")
+    assert_close(db3, bc.grad, 1e-4, "db (both)")
+    K.conv_bwd_both(g, x, dy, w, dx3, dw3, None, K.ACCUMULATE, x, gate, K.RELU_IN, gate)
+    assert_close(dx3.t, xc.grad + xc2.grad, 5e-5, "dx (both, accumulate + relu-mask + gate)")
+    assert_close(dw3, wc2.grad, 1e-4, "dw (both, relu + gate)")
 
 
 @pytest.mark.parametrize("c,stride,transposed,shape", [(4, 1, False, (6, 8, 10)), (8, 2, False, (8, 8, 8)), (16, 2, True, (4, 4, 6)),
