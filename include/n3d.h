@@ -117,6 +117,12 @@ int n3d_conv_bwd_both(const n3d_conv_geom* g, const float* x, int64_t xld, const
                       int64_t dxld, int flags_data, const float* relu_src, int64_t rld, const float* out_gate, void* ws_data,
                       size_t ws_data_bytes, float* dw, float* dbias, int flags_weight, const float* in_gate, void* ws_weight,
                       size_t ws_weight_bytes, n3d_final_job* deferred, void* stream);
+
+/* The same for nn.ConvTranspose3d (prim_ops.py:100-102): n3d_convT_bwd_data + n3d_convT_bwd_weight (weight gradient
+ * only; the bias gradient of a transposed conv is a plain channel sum the hot path derives from the GroupNorm sums). */
+int n3d_convT_bwd_both(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, const float* w, float* dx,
+                       int64_t dxld, int flags_data, void* ws_data, size_t ws_data_bytes, float* dw, int flags_weight, void* ws_weight,
+                       size_t ws_weight_bytes, n3d_final_job* deferred, void* stream);
 /* transposed convolution y[i side] = convT(x[o side]) + bias; same kernels with the roles swapped */
 int n3d_convT_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias,
                   float* y, int64_t yld, int flags, const float* in_gate, double* stats,

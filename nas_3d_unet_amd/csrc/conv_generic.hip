@@ -763,10 +763,10 @@ struct Wg16Args;
 int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                    float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s,
                    Wg16Args* prepared = nullptr);
-int mfma_bwd_dual_try(const n3d_conv_geom* g, const float* dy, int64_t dyld, const float* wp_packed, float* dx, int64_t dxld, int flags_d,
-                      const float* relu_src, int64_t rld, const float* out_gate, const float* x, int64_t xld, int flags_w,
-                      const float* in_gate, float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out,
-                      hipStream_t s);
+int mfma_bwd_dual_try(const n3d_conv_geom* g, bool transposed, const float* dy, int64_t dyld, const float* wp_packed, float* dx,
+                      int64_t dxld, int flags_d, const float* relu_src, int64_t rld, const float* out_gate, const float* x, int64_t xld,
+                      int flags_w, const float* in_gate, float* partial, float* pbias, size_t avail_floats, int* nchunks_out,
+                      int* ntiles_out, hipStream_t s);
 void mfma_pack16(const float* w, float* wp, int Co, int Ci, int taps, int data_grad, hipStream_t s);
 }
 
@@ -952,10 +952,14 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     float* pb = wsf + (1024 + nt16) * 256;
     int handled = 0;
     if (g->Ci % 16 == 0 && g->Co % 16 == 0 && (1024 + nt16) * (256 + 16) <= avail) {
-      if (dual && !transposed && dual->ws && dual->ws_bytes >= (size_t)taps * g->Ci * g->Co * 4) {
-        if (!(dual->flags & N3D_PREPACKED)) mfma_pack16(dual->w, (float*)dual->ws, g->Co, g->Ci, taps, 1, s);
-        handled = mfma_bwd_dual_try(g, dy, dyld, (const float*)dual->ws, dual->dx, dual->dxld, dual->flags, dual->relu_src, dual->rld,
-                                    dual->out_gate, x, xld, flags, in_gate, wsf, pb, (1024 + nt16) * 256, &nch, &ntl, s);
+      if (dual && dual->ws && dual->ws_bytes >= (size_t)taps * g->Ci * g->Co * 4) {
+        if (!(dual->flags & N3D_PREPACKED)) mfma_pack16(dual->w, (float*)dual->ws, g->Co, g->Ci, taps, transposed ? 0 : 1, s);
+        // run_wgrad's (x, dy) are kernel roles (i side, o side); a transposed conv's output gradient sits on the i side
+        const float* true_dy = transposed ? x : dy; const int64_t true_dyld = transposed ? xld : dyld;
+        const float* true_x = transposed ? dy : x; const int64_t true_xld = transposed ? dyld : xld;
+        handled = mfma_bwd_dual_try(g, transposed, true_dy, true_dyld, (const float*)dual->ws, dual->dx, dual->dxld, dual->flags,
+                                    dual->relu_src, dual->rld, dual->out_gate, true_x, true_xld, flags, in_gate, wsf, pb,
+                                    (1024 + nt16) * 256, &nch, &ntl, s);
         if (handled < 0) return handled;
         if (handled == 1) dual->done = true;
       }
@@ -1017,6 +1021,20 @@ int n3d_conv_bwd_both(const n3d_conv_geom* g, const float* x, int64_t xld, const
   if (int e = run_wgrad(g, x, xld, dy, dyld, dw, dbias, flags_weight, in_gate, ws_weight, ws_weight_bytes, stream, false, deferred, &rq)) return e;
   if (rq.done) return N3D_OK;
   return run_gather(g, true, dy, dyld, w, nullptr, dx, dxld, flags_data & ~N3D_RELU_IN, nullptr, relu_src, rld, out_gate, nullptr, ws_data,
+                    ws_data_bytes, stream);
+}
+
+int n3d_convT_bwd_both(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, const float* w, float* dx,
+                       int64_t dxld, int flags_data, void* ws_data, size_t ws_data_bytes, float* dw, int flags_weight, void* ws_weight,
+                       size_t ws_weight_bytes, n3d_final_job* deferred, void* stream) {
+  if (int e = check_geom(g, "convT_bwd_both")) return e;
+  N3D_CHECK_ARG(x && dy && w && dx && dw && xld >= g->Co && dyld >= g->Ci && dxld >= g->Co, "convT_bwd_both: bad pointers/pitches");
+  DualReq rq = {w, dx, dxld, flags_data & ~N3D_RELU_IN, nullptr, 0, nullptr, ws_data, ws_data_bytes, false};
+  if (int e = run_wgrad(g, dy, dyld, x, xld, dw, nullptr, flags_weight & ~N3D_RELU_IN, nullptr, ws_weight, ws_weight_bytes, stream, true,
+                        deferred, &rq))
+    return e;
+  if (rq.done) return N3D_OK;
+  return run_gather(g, false, dy, dyld, w, nullptr, dx, dxld, flags_data & ~N3D_RELU_IN, nullptr, nullptr, 0, nullptr, nullptr, ws_data,
                     ws_data_bytes, stream);
 }
 

@@ -1129,26 +1129,33 @@ int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const fl
 
 // Data gradient + weight gradient of a non-transposed conv whose channel counts are multiples of 16 and whose data
 // gradient is a tiny GEMM (K-split plan), in one launch.  Returns 1 if launched, 0 if the shape does not qualify.
-int mfma_bwd_dual_try(const n3d_conv_geom* g, const float* dy, int64_t dyld, const float* wp_packed, float* dx, int64_t dxld, int flags_d,
-                      const float* relu_src, int64_t rld, const float* out_gate, const float* x, int64_t xld, int flags_w,
-                      const float* in_gate, float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out,
-                      hipStream_t s) {
+int mfma_bwd_dual_try(const n3d_conv_geom* g, bool transposed, const float* dy, int64_t dyld, const float* wp_packed, float* dx,
+                      int64_t dxld, int flags_d, const float* relu_src, int64_t rld, const float* out_gate, const float* x, int64_t xld,
+                      int flags_w, const float* in_gate, float* partial, float* pbias, size_t avail_floats, int* nchunks_out,
+                      int* ntiles_out, hipStream_t s) {
+  // transposed conv: its data gradient is the FORWARD gather of the geometry (dy lives on the i side), and the weight
+  // gradient kernel sees dy as its i-side operand and x as its o-side operand (roles swapped by the caller's convention)
+  const bool dgrad_is_data_grad = !transposed;
   if (vx_plan(g).ok) return 0;
-  const G16Plan p = g16_plan(g, true);
+  const G16Plan p = g16_plan(g, dgrad_is_data_grad);
   if (!p.ok || p.ksplit != 16) return 0;
   if (dyld % 4 != 0 || !aligned16(dy)) return 0;
   MfArgs a;
   a.src = dy; a.sld = dyld; a.dst = dx; a.dld = dxld; a.bias = nullptr; a.k = g->k; a.flags = flags_d; a.B = g->B;
   a.in_gate = nullptr; a.relu_src = relu_src; a.rld = rld; a.out_gate = out_gate; a.stats = nullptr; a.rows_per_sample = 0;
-  a.Ds = g->Do; a.Hs = g->Ho; a.Ws = g->Wo; a.Cs = g->Co; a.Dd = g->Di; a.Hd = g->Hi; a.Wd = g->Wi; a.Cd = g->Ci;
-  a.sn = 1; a.off = g->pad; a.dt = -g->dil; a.den = g->stride;
+  if (!dgrad_is_data_grad) { a.Ds = g->Di; a.Hs = g->Hi; a.Ws = g->Wi; a.Cs = g->Ci; a.Dd = g->Do; a.Hd = g->Ho; a.Wd = g->Wo; a.Cd = g->Co;
+    a.sn = g->stride; a.off = -g->pad; a.dt = g->dil; a.den = 1; }
+  else { a.Ds = g->Do; a.Hs = g->Ho; a.Ws = g->Wo; a.Cs = g->Co; a.Dd = g->Di; a.Hd = g->Hi; a.Wd = g->Wi; a.Cd = g->Ci;
+    a.sn = 1; a.off = g->pad; a.dt = -g->dil; a.den = g->stride; }
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
   if ((int64_t)g->B * Nd >= (1ll << 31)) return 0;
   a.fNd = FastDiv((uint32_t)Nd); a.fWd = FastDiv((uint32_t)a.Wd); a.fHd = FastDiv((uint32_t)a.Hd); a.fC16 = FastDiv((uint32_t)(a.Cs / 16));
   a.wp = wp_packed;
   DualArgs q;
   q.d = a;
-  if (!mfma_wgrad_try(g, x, xld, dy, dyld, flags_w, in_gate, partial, pbias, avail_floats, nchunks_out, ntiles_out, s, &q.w)) return 0;
+  const int wok = transposed ? mfma_wgrad_try(g, dy, dyld, x, xld, flags_w, in_gate, partial, pbias, avail_floats, nchunks_out, ntiles_out, s, &q.w)
+                             : mfma_wgrad_try(g, x, xld, dy, dyld, flags_w, in_gate, partial, pbias, avail_floats, nchunks_out, ntiles_out, s, &q.w);
+  if (!wok) return 0;
   const int64_t M = (int64_t)g->B * Nd;
   q.gxA = (int)cdiv(M, 16);
   q.nA = q.gxA * (a.Cd / 16);

@@ -269,12 +269,21 @@ def conv_bwd_weight(g, x: View, dy: View, dw, dbias, flags=0, in_gate=None, tran
 
 
 def conv_bwd_both(g, x: View, dy: View, w, dx: View, dw, dbias, flags_data=0, relu_src: View | None = None, out_gate=None,
-                  flags_weight=0, in_gate=None):
-    """conv_bwd_data + conv_bwd_weight of a non-transposed conv; one launch where libn3d can fold them."""
-    wsd, wspd, nd, flags_data = _packed(w, g, True, flags_data, dy.t.device)
+                  flags_weight=0, in_gate=None, transposed=False):
+    """conv_bwd_data + conv_bwd_weight of one conv; one launch where libn3d can fold them."""
+    wsd, wspd, nd, flags_data = _packed(w, g, not transposed, flags_data, dy.t.device)
     ws, n = _ws(g, x.t.device)
     job = FinalJob() if (_ctx is not None and not g.depthwise) else None
     jp = C.byref(job) if job is not None else None
+    if transposed:
+        if relu_src is not None or out_gate is not None or in_gate is not None or dbias is not None:
+            raise N3DError("convT_bwd_both: relu / gate / bias-gradient extras are not supported")
+        check(_lib.load().n3d_convT_bwd_both(C.byref(g), x.p, x.ld, dy.p, dy.ld, ptr(w), dx.p, dx.ld, flags_data, wspd, nd,
+                                             ptr(dw), flags_weight, ptr(ws), n, jp, stream_ptr()), "n3d_convT_bwd_both")
+        if job is not None and job.nchunks > 0:
+            _ctx.final.append(job)
+            _ctx.keep.append(ws)
+        return
     check(_lib.load().n3d_conv_bwd_both(C.byref(g), x.p, x.ld, dy.p, dy.ld, ptr(w), dx.p, dx.ld, flags_data,
                                         relu_src.p if relu_src is not None else None,
                                         relu_src.ld if relu_src is not None else 0, ptr(out_gate), wspd, nd,

@@ -175,6 +175,13 @@ class DenseConvW(WeightProgram):
         w = self.m.weight
         dw = K.grad_target(w)
         db = None if skip_bias else K.grad_target(self.m.bias)
+        if (need_dx and saved.pre is None and self.transposed and dw is not None and db is None
+                and g.Ci % 16 == 0 and g.Co % 16 == 0):
+            if dx_out is None:
+                dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+                dx_acc = False
+            K.conv_bwd_both(g, x, draw, w, dx_out, dw, None, ACCUMULATE if dx_acc else 0, None, None, 0, None, True)
+            return dx_out.t, [dw, db]
         if (need_dx and saved.pre is None and not self.transposed and (dw is not None or db is not None)
                 and g.Ci % 16 == 0 and g.Co % 16 == 0):
             # deep levels: data gradient and weight gradient in one launch where libn3d can fold them

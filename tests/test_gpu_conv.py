@@ -106,6 +106,11 @@ def test_conv_family(cin, cout, k, stride, dil, transposed, B, shape):
     K.conv_bwd_weight(g, x, dy, dw2, None, 0, None, transposed)
     assert_close(dw2, wc.grad, 1e-4, "dw (no bias)")
     if transposed:
+        dx3 = K.as_view(K.empty_ndhwc(B, cin, *shape, dev))
+        dw3 = torch.zeros_like(w)
+        K.conv_bwd_both(g, x, dy, w, dx3, dw3, None, 0, None, None, 0, None, True)
+        assert_close(dx3.t, xc.grad, 5e-5, "dx (both, transposed)")
+        assert_close(dw3, wc.grad, 1e-4, "dw (both, transposed)")
         return
     # ---------------- fused extras (non-transposed): relu on load + input gate
     gate = torch.from_numpy(gate_n).to(dev)
