@@ -404,16 +404,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(Wg16Args a) {
 // of the chip idle and costs a full launch + memory round trip.
 struct DualArgs { MfArgs d; Wg16Args w; int nA, gxA, ntilesB, nB; };
 
-__global__ __launch_bounds__(1024, 4) void conv_bwd16_dual_kernel(DualArgs q) {
+template <int KS>
+__global__ __launch_bounds__(KS == 16 ? 1024 : 256, KS == 16 ? 4 : 2) void conv_bwd16_dual_kernel(DualArgs q) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int UNITS = KS == 16 ? 4 : 1;  // weight-gradient units (256 threads each) per workgroup
   const int L = blockIdx.x;
   if (L < q.nA) {
-    gemm16_body<1, 1, 16>(q.d, L % q.gxA, L / q.gxA, lds);
+    gemm16_body<1, 1, KS>(q.d, L % q.gxA, L / q.gxA, lds);
   } else {
     f32x4* l4 = reinterpret_cast<f32x4*>(lds);
-    float (*lb)[16] = reinterpret_cast<float (*)[16]>(lds + 4 * 3 * 64 * 4);
+    float (*lb)[16] = reinterpret_cast<float (*)[16]>(lds + UNITS * 3 * 64 * 4);
     const int sub = threadIdx.x >> 8;
-    const int unit = (L - q.nA) * 4 + sub;
+    const int unit = (L - q.nA) * UNITS + sub;
     const bool active = unit < q.nB;
     const int u = active ? unit : 0;
     wgrad16_body(q.w, u % q.ntilesB, u / q.ntilesB, q.ntilesB, threadIdx.x & 255, active, l4 + sub * 3 * 64, lb + sub * 4);
@@ -1138,7 +1140,7 @@ int mfma_bwd_dual_try(const n3d_conv_geom* g, bool transposed, const float* dy, 
   const bool dgrad_is_data_grad = !transposed;
   if (vx_plan(g).ok) return 0;
   const G16Plan p = g16_plan(g, dgrad_is_data_grad);
-  if (!p.ok || p.ksplit != 16) return 0;
+  if (!p.ok || p.ksplit == 1) return 0;
   if (dyld % 4 != 0 || !aligned16(dy)) return 0;
   MfArgs a;
   a.src = dy; a.sld = dyld; a.dst = dx; a.dld = dxld; a.bias = nullptr; a.k = g->k; a.flags = flags_d; a.B = g->B;
@@ -1161,9 +1163,13 @@ int mfma_bwd_dual_try(const n3d_conv_geom* g, bool transposed, const float* dy, 
   q.nA = q.gxA * (a.Cd / 16);
   q.ntilesB = *ntiles_out;
   q.nB = *ntiles_out * *nchunks_out;
-  const size_t shm_a = (size_t)15 * 256 * sizeof(float) + (size_t)16 * 16 * 2 * sizeof(double);
-  const size_t shm_b = (size_t)4 * 3 * 64 * 16 + (size_t)4 * 4 * 16 * 4;
-  hipLaunchKernelGGL(conv_bwd16_dual_kernel, dim3((unsigned)(q.nA + cdiv(q.nB, 4))), dim3(1024), shm_a > shm_b ? shm_a : shm_b, s, q);
+  const int units = p.ksplit == 16 ? 4 : 1;
+  const size_t shm_a = (size_t)(p.ksplit - 1) * 256 * sizeof(float) + (size_t)16 * 16 * 2 * sizeof(double);
+  const size_t shm_b = (size_t)units * (3 * 64 * 16 + 4 * 16 * 4);
+  const size_t shm = shm_a > shm_b ? shm_a : shm_b;
+  const dim3 grid((unsigned)(q.nA + cdiv(q.nB, units)));
+  if (p.ksplit == 16) hipLaunchKernelGGL(conv_bwd16_dual_kernel<16>, grid, dim3(1024), shm, s, q);
+  else hipLaunchKernelGGL(conv_bwd16_dual_kernel<4>, grid, dim3(256), shm, s, q);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("conv(bwd dual) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
   return 1;
