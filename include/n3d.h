@@ -172,6 +172,35 @@ int n3d_affine_act_bwd_apply_gn(const float* dout, int64_t dld, const float* raw
                                 const float* mean_rstd, const float* wptr, const double* sumraw,
                                 float* draw, int64_t drld, int B, int64_t N, int C, int G, int flags, float* dgamma,
                                 float* dbeta, float* dalpha, float* dbias_conv, void* stream);
+/* ---- node-level pair epilogues: a searched-cell node is op_a(x_i) + op_b(x_j) (searched.py:45-50); both ops end in
+ * GroupNorm -> [ReLU] -> weighted sum on tensors of one shape and share the node gradient in backward.  One launch
+ * does the work of two n3d_affine_act_gn / n3d_affine_act_bwd_reduce / n3d_affine_act_bwd_apply_gn calls (same
+ * results; the node buffer is written once, the node gradient read once).  Requirements: rows <= n3d_fused_max_rows(),
+ * C a power of two <= 64, C / G <= 16, B <= 4 for the backward apply; otherwise N3D_ERR_UNSUPPORTED (call the single
+ * forms). */
+typedef struct n3d_gn_fwd_term {
+  const float* raw; int64_t rld;          /* conv output (pitched NDHWC) */
+  const double* stats; int32_t rows;      /* [B][rows][C][2] partial (sum, sum of squares) */
+  int32_t relu;                           /* 1: ReLU after the norm */
+  const float* gamma; const float* beta;  /* GroupNorm affine */
+  const float* wptr;                      /* optional scalar weight (MixedOp alpha), NULL = 1 */
+  float* a_out; float* b_out; float* mean_rstd_out; double* sumraw;  /* saved for backward, as n3d_affine_act_gn */
+} n3d_gn_fwd_term;
+int n3d_affine_act_gn2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int G, float eps, float* out, int64_t old_, int B,
+                       int64_t N, int C, int flags /* N3D_ACCUMULATE */, void* stream);
+
+typedef struct n3d_gn_bwd_term {
+  const float* raw; int64_t rld; const float* a; const float* b;   /* forward operands / coefficients */
+  double* sums; int32_t rows;             /* [B][rows][C][3]: written by n3d_affine_act_bwd_reduce2, read by ..._apply_gn2 */
+  int32_t relu;
+  const float* gamma; const float* mean_rstd; const float* wptr; const double* sumraw;
+  float* draw; int64_t drld;              /* d(raw), output of the apply pass */
+  float* dgamma; float* dbeta; float* dalpha; float* dbias_conv;   /* parameter gradients (dalpha / dbias_conv may be NULL) */
+} n3d_gn_bwd_term;
+int n3d_affine_act_bwd_reduce2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N,
+                               int C, void* stream);
+int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N,
+                                 int C, int G, void* stream);
 /* plain (no norm) epilogue backward coefficients: A = w, Bc = Cc = 0, dalpha = sum Sz */
 int n3d_plain_bwd_coeffs(const double* sums, int rows, const float* wptr, int B, int C, float* dalpha,
                          float* A, void* stream);

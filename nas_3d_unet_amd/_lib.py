@@ -37,6 +37,21 @@ class FinalJob(C.Structure):
                [(n, C.c_int32) for n in ("nchunks", "ntiles", "tci", "tco", "ci_t", "co_t", "Co", "Ci", "taps", "pad_")]
 
 
+class GnFwdTerm(C.Structure):
+    """n3d_gn_fwd_term (include/n3d.h)"""
+    _fields_ = [("raw", C.c_void_p), ("rld", C.c_int64), ("stats", C.c_void_p), ("rows", C.c_int32), ("relu", C.c_int32),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("wptr", C.c_void_p), ("a_out", C.c_void_p), ("b_out", C.c_void_p),
+                ("mean_rstd_out", C.c_void_p), ("sumraw", C.c_void_p)]
+
+
+class GnBwdTerm(C.Structure):
+    """n3d_gn_bwd_term (include/n3d.h)"""
+    _fields_ = [("raw", C.c_void_p), ("rld", C.c_int64), ("a", C.c_void_p), ("b", C.c_void_p), ("sums", C.c_void_p),
+                ("rows", C.c_int32), ("relu", C.c_int32), ("gamma", C.c_void_p), ("mean_rstd", C.c_void_p), ("wptr", C.c_void_p),
+                ("sumraw", C.c_void_p), ("draw", C.c_void_p), ("drld", C.c_int64), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("dalpha", C.c_void_p), ("dbias_conv", C.c_void_p)]
+
+
 _p = C.c_void_p
 _i = C.c_int
 _i64 = C.c_int64
@@ -72,6 +87,9 @@ PROTOTYPES = {
     "n3d_affine_act_gn": (_i, [_p, _i64, _p, _i, _p, _p, _i, _f, _p, _p, _i64, _i, _i64, _i, _i, _p, _p, _p, _p, _p]),
     "n3d_affine_act_bwd_apply_gn": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i64, _i, _i64, _i, _i, _i,
                                          _p, _p, _p, _p, _p]),
+    "n3d_affine_act_gn2": (_i, [C.POINTER(GnFwdTerm), C.POINTER(GnFwdTerm), _i, _f, _p, _i64, _i, _i64, _i, _i, _p]),
+    "n3d_affine_act_bwd_reduce2": (_i, [_p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _p]),
+    "n3d_affine_act_bwd_apply_gn2": (_i, [_p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _i, _p]),
     "n3d_affine_act_bwd_reduce": (_i, [_p, _i64, _p, _i64, _p, _p, _i, _i64, _i, _i, _p, _p]),
     "n3d_gn_bwd_coeffs": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "n3d_plain_bwd_coeffs": (_i, [_p, _i, _p, _i, _i, _p, _p, _p]),

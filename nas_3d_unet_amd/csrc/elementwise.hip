@@ -786,6 +786,320 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// Node-level pair kernels.  A searched-cell node is  op_a(x_i) + op_b(x_j)  (searched.py:45-50): both ops end in the
+// same GroupNorm -> ReLU -> weighted-sum epilogue on tensors of one shape, and in backward both consume the same
+// node gradient.  One launch handles both terms: forward out = term0 + term1 written once (no read-modify-write
+// of the node buffer), backward reads the node gradient once for both reductions / both gradient tensors.
+// Wave-level prologues only (C a power of two, group width <= 16); the host falls back to two single launches.
+// ------------------------------------------------------------------------------------------------
+struct GnFwdTerm {
+  const float* raw; int64_t rld; const double* stats; int rows; const float* gamma; const float* beta; const float* wptr;
+  float* a_out; float* b_out; float* mr_out; double* sumraw; int relu;
+};
+
+// forward GroupNorm coefficients of sample b, computed redundantly by one wave; the wave's lanes < C publish them
+// in its private LDS strip (strip[0][c] = a, strip[1][c] = b)
+__device__ __forceinline__ void gn_fwd_prologue_wave(const GnFwdTerm& t, const int b, const int C, const int G, const double count, const float eps,
+                                                     const bool store, float (*strip)[64]) {
+  const int lane = threadIdx.x & 63;
+  const int cg = C / G;
+  const int c = lane & (C - 1), rs = lane / C, nslots = 64 / C;
+  const float gam = t.gamma[c], bet = t.beta[c];
+  const double2* st2 = reinterpret_cast<const double2*>(t.stats + (int64_t)b * t.rows * C * 2);
+  double s = 0, ss = 0;
+  int r = rs;
+  for (; r + 3 * nslots < t.rows; r += 4 * nslots) {
+    double2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = st2[(int64_t)(r + u * nslots) * C + c];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s += v[u].x; ss += v[u].y; }
+  }
+  for (; r < t.rows; r += nslots) { const double2 v = st2[(int64_t)r * C + c]; s += v.x; ss += v.y; }
+  s = wave_classsum_d(s, C); ss = wave_classsum_d(ss, C);
+  const double gs = wave_groupsum_d(s, cg), gss = wave_groupsum_d(ss, cg);
+  const double n = count * cg;
+  const double mean = gs / n;
+  double var = gss / n - mean * mean;
+  if (var < 0) var = 0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const float a1 = gam * (float)rstd;
+  const float b1 = bet - (float)mean * a1;
+  if (lane < C) { strip[0][lane] = a1; strip[1][lane] = b1; }
+  if (store && lane < C) {
+    t.a_out[b * C + c] = a1; t.b_out[b * C + c] = b1;
+    if (t.sumraw) t.sumraw[b * C + c] = s;
+    if (c % cg == 0) { const int g = c / cg; t.mr_out[(b * G + g) * 2] = (float)mean; t.mr_out[(b * G + g) * 2 + 1] = (float)rstd; }
+  }
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwdTerm t1, int G, double count, float eps, float* __restrict__ out,
+                                                             int64_t old_, int64_t N, int C, EwMap m) {
+  __shared__ __attribute__((aligned(16))) float abw[4][2][2][64];  // [wave][term][a|b][channel]
+  const int b = blockIdx.y, t = threadIdx.x, wave = t >> 6;
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
+  const float* r0 = t0.raw + (int64_t)b * N * t0.rld + c4 * 4;
+  const float* r1 = t1.raw + (int64_t)b * N * t1.rld + c4 * 4;
+  float* ob = out + (int64_t)b * N * old_ + c4 * 4;
+  const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+  const bool act0 = vl < m.vpb && v0 < N;
+  constexpr int PF = 4;   // iterations requested up front (the first one ahead of the prologues)
+  float4 q0[PF], q1[PF], on[PF];
+  const float w0 = t0.wptr ? *t0.wptr : 1.0f, w1 = t1.wptr ? *t1.wptr : 1.0f;
+  if (act0) {
+    q0[0] = *reinterpret_cast<const float4*>(r0 + v0 * t0.rld);
+    q1[0] = *reinterpret_cast<const float4*>(r1 + v0 * t1.rld);
+    if (ACC) on[0] = *reinterpret_cast<const float4*>(ob + v0 * old_);
+  }
+  const bool store = blockIdx.x == 0 && wave == 0;
+  gn_fwd_prologue_wave(t0, b, C, G, count, eps, store, abw[wave][0]);
+  gn_fwd_prologue_wave(t1, b, C, G, count, eps, store, abw[wave][1]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (!act0) return;
+  const float4 a0 = *reinterpret_cast<const float4*>(&abw[wave][0][0][c4 * 4]), b0 = *reinterpret_cast<const float4*>(&abw[wave][0][1][c4 * 4]);
+  const float4 a1 = *reinterpret_cast<const float4*>(&abw[wave][1][0][c4 * 4]), b1 = *reinterpret_cast<const float4*>(&abw[wave][1][1][c4 * 4]);
+  const float f0 = t0.relu ? 0.f : -INFINITY, f1 = t1.relu ? 0.f : -INFINITY;
+#pragma unroll
+  for (int i = 1; i < PF; ++i) {
+    const int64_t v = v0 + (int64_t)i * m.vpb;
+    const int64_t vc = (i < m.iters && v < N) ? v : v0;
+    q0[i] = *reinterpret_cast<const float4*>(r0 + vc * t0.rld);
+    q1[i] = *reinterpret_cast<const float4*>(r1 + vc * t1.rld);
+    if (ACC) on[i] = *reinterpret_cast<const float4*>(ob + vc * old_);
+  }
+  auto emit = [&](int64_t v, const float4 x0, const float4 x1, const float4 o) {
+    float4 z;
+    // term0 first, then term1, then (accumulate mode) the previous content: the reference's left-to-right sum
+    z.x = w0 * fmaxf(fmaf(a0.x, x0.x, b0.x), f0); z.y = w0 * fmaxf(fmaf(a0.y, x0.y, b0.y), f0);
+    z.z = w0 * fmaxf(fmaf(a0.z, x0.z, b0.z), f0); z.w = w0 * fmaxf(fmaf(a0.w, x0.w, b0.w), f0);
+    if (ACC) { z.x += o.x; z.y += o.y; z.z += o.z; z.w += o.w; }
+    z.x = fmaf(w1, fmaxf(fmaf(a1.x, x1.x, b1.x), f1), z.x); z.y = fmaf(w1, fmaxf(fmaf(a1.y, x1.y, b1.y), f1), z.y);
+    z.z = fmaf(w1, fmaxf(fmaf(a1.z, x1.z, b1.z), f1), z.z); z.w = fmaf(w1, fmaxf(fmaf(a1.w, x1.w, b1.w), f1), z.w);
+    *reinterpret_cast<float4*>(ob + v * old_) = z;
+  };
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int64_t v = v0 + (int64_t)i * m.vpb;
+    if (i < m.iters && v < N) emit(v, q0[i], q1[i], on[i]);
+  }
+  for (int it = PF; it < m.iters; ++it) {
+    const int64_t v = v0 + (int64_t)it * m.vpb;
+    if (v >= N) break;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACC) o = *reinterpret_cast<const float4*>(ob + v * old_);
+    emit(v, *reinterpret_cast<const float4*>(r0 + v * t0.rld), *reinterpret_cast<const float4*>(r1 + v * t1.rld), o);
+  }
+}
+
+// backward pass 1 for two ops that share the node gradient dout: sums0 / sums1 rows as affine_bwd_reduce_kernel
+struct BwdRedTerm { const float* raw; int64_t rld; const float* a; const float* b; double* sums; int relu; };
+
+__global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const float* __restrict__ dout, int64_t dld, BwdRedTerm t0, BwdRedTerm t1, int64_t N,
+                                                                 int C, EwMap m) {
+  __shared__ double lds[4 * 64 * 12];
+  const int b = blockIdx.y;
+  const int t = threadIdx.x;
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
+  const bool active = vl < m.vpb;
+  float s1[2][4], s2[2][4], sz[2][4];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s1[k][j] = s2[k][j] = sz[k][j] = 0.f;
+  if (active) {
+    float4 av[2], bv[2];
+    av[0] = *reinterpret_cast<const float4*>(t0.a + b * C + c4 * 4); bv[0] = *reinterpret_cast<const float4*>(t0.b + b * C + c4 * 4);
+    av[1] = *reinterpret_cast<const float4*>(t1.a + b * C + c4 * 4); bv[1] = *reinterpret_cast<const float4*>(t1.b + b * C + c4 * 4);
+    const float thr[2] = {t0.relu ? 0.f : -INFINITY, t1.relu ? 0.f : -INFINITY};
+    const float* db = dout + (int64_t)b * N * dld + c4 * 4;
+    const float* rb0 = t0.raw + (int64_t)b * N * t0.rld + c4 * 4;
+    const float* rb1 = t1.raw + (int64_t)b * N * t1.rld + c4 * 4;
+    const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+    for (int it0 = 0; it0 < m.iters; it0 += 4) {
+      float4 dq[4], rq[2][4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t v = v0 + (int64_t)(it0 + u) * m.vpb;
+        ok[u] = (it0 + u < m.iters) && v < N;
+        const int64_t vc = ok[u] ? v : 0;
+        dq[u] = *reinterpret_cast<const float4*>(db + vc * dld);
+        rq[0][u] = *reinterpret_cast<const float4*>(rb0 + vc * t0.rld);
+        rq[1][u] = *reinterpret_cast<const float4*>(rb1 + vc * t1.rld);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        const float d[4] = {dq[u].x, dq[u].y, dq[u].z, dq[u].w};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float r[4] = {rq[k][u].x, rq[k][u].y, rq[k][u].z, rq[k][u].w};
+          const float a4[4] = {av[k].x, av[k].y, av[k].z, av[k].w}, b4[4] = {bv[k].x, bv[k].y, bv[k].z, bv[k].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float z = fmaf(a4[j], r[j], b4[j]);
+            const float g = z > thr[k] ? d[j] : 0.f;
+            z = fmaxf(z, thr[k]);
+            s1[k][j] += g;
+            s2[k][j] = fmaf(g, r[j], s2[k][j]);
+            sz[k][j] = fmaf(d[j], z, sz[k][j]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    double vals[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      vals[j] = wave_classsum_f(s1[k][j], m.cpb); vals[4 + j] = wave_classsum_f(s2[k][j], m.cpb); vals[8 + j] = wave_classsum_f(sz[k][j], m.cpb);
+    }
+    double* row = (k == 0 ? t0.sums : t1.sums) + ((int64_t)b * gridDim.x + blockIdx.x) * C * 3;
+    if (k == 1) __syncthreads();
+    block_reduce_to_row<3>(vals, m.cpb, row, lds, true);
+  }
+}
+
+struct GnBwdTerm {
+  const float* raw; int64_t rld; const float* a; const float* b; const double* sums; int rows; const float* gamma; const float* mean_rstd;
+  const float* wptr; const double* sumraw; float* draw; int64_t drld; float* dgamma; float* dbeta; float* dalpha; float* dbias_conv; int relu;
+};
+
+// GroupNorm-backward coefficients of one term, wave level (see affine_bwd_apply_gn_kernel); strip[0..2][c] = A, B, C
+__device__ __forceinline__ void gn_bwd_prologue_wave(const GnBwdTerm& t, const int B, const int C, const int G, const double count, const bool lead_w,
+                                                     float (*strip)[64]) {
+  const int lane = threadIdx.x & 63;
+  const int cg = C / G;
+  const int c = lane & (C - 1), rs = lane / C, nslots = 64 / C;
+  const int gq = c / cg;
+  const double w = t.wptr ? (double)*t.wptr : 1.0;
+  const double gam = (double)t.gamma[c];
+  const int nbw = lead_w ? B : 1;
+  double dg = 0, db = 0, dz = 0, dbc = 0;
+  for (int k = 0; k < nbw; ++k) {
+    const int b = lead_w ? ((int)blockIdx.y + 1 + k) % B : (int)blockIdx.y;  // own sample last
+    const double mn = t.mean_rstd[(b * G + gq) * 2], rsd = t.mean_rstd[(b * G + gq) * 2 + 1];
+    const double pf = (lead_w && t.dbias_conv) ? t.sumraw[b * C + c] : 0.0;
+    const double* sb = t.sums + (int64_t)b * t.rows * C * 3 + c * 3;
+    double S1 = 0, S2 = 0, Sz = 0;
+    int r = rs;
+    for (; r + 3 * nslots < t.rows; r += 4 * nslots) {
+      double v[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[u][q] = sb[(int64_t)(r + u * nslots) * C * 3 + q];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { S1 += v[u][0]; S2 += v[u][1]; Sz += v[u][2]; }
+    }
+    for (; r < t.rows; r += nslots) { S1 += sb[(int64_t)r * C * 3]; S2 += sb[(int64_t)r * C * 3 + 1]; Sz += sb[(int64_t)r * C * 3 + 2]; }
+    S1 = wave_classsum_d(S1, C); S2 = wave_classsum_d(S2, C);
+    if (t.dalpha) Sz = wave_classsum_d(Sz, C);
+    const double n = count * cg;
+    const double c1 = wave_groupsum_d(gam * w * S1, cg) / n;
+    const double c2 = wave_groupsum_d(gam * w * rsd * (S2 - mn * S1), cg) / n;
+    const double A1 = rsd * gam * w, B1 = -rsd * c1 + rsd * rsd * c2 * mn, C1 = -rsd * rsd * c2;
+    if (k == nbw - 1 && lane < C) { strip[0][lane] = (float)A1; strip[1][lane] = (float)B1; strip[2][lane] = (float)C1; }
+    if (lead_w) {
+      dg += w * rsd * (S2 - mn * S1);
+      db += w * S1;
+      dz += Sz;
+      if (t.dbias_conv) dbc += A1 * S1 + count * B1 + C1 * pf;
+    }
+  }
+  if (lead_w) {
+    if (lane < C) {
+      if (t.dgamma) t.dgamma[c] = (float)dg;
+      if (t.dbeta) t.dbeta[c] = (float)db;
+      if (t.dbias_conv) t.dbias_conv[c] = (float)dbc;
+    }
+    if (t.dalpha) {
+      const double sdz = wave_sum_d(lane < C ? dz : 0.0);
+      if (lane == 0) *t.dalpha = (float)sdz;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* __restrict__ dout, int64_t dld, GnBwdTerm t0, GnBwdTerm t1, int B, int G,
+                                                                   double count, int64_t N, int C, EwMap m) {
+  __shared__ __attribute__((aligned(16))) float cw[4][2][3][64];  // [wave][term][A|B|C][channel]
+  const int t = threadIdx.x, wave = t >> 6;
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
+  const int by = blockIdx.y;
+  const float* dbp = dout + (int64_t)by * N * dld + c4 * 4;
+  const float* rb0 = t0.raw + (int64_t)by * N * t0.rld + c4 * 4;
+  const float* rb1 = t1.raw + (int64_t)by * N * t1.rld + c4 * 4;
+  float* o0 = t0.draw + (int64_t)by * N * t0.drld + c4 * 4;
+  float* o1 = t1.draw + (int64_t)by * N * t1.drld + c4 * 4;
+  const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+  const bool act0 = vl < m.vpb && v0 < N;
+  constexpr int PF = 4;
+  float4 dq[PF], r0[PF], r1[PF];
+  float4 fa[2], fb[2];
+  fa[0] = fa[1] = make_float4(1.f, 1.f, 1.f, 1.f); fb[0] = fb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (act0) {
+    dq[0] = *reinterpret_cast<const float4*>(dbp + v0 * dld);
+    r0[0] = *reinterpret_cast<const float4*>(rb0 + v0 * t0.rld);
+    r1[0] = *reinterpret_cast<const float4*>(rb1 + v0 * t1.rld);
+    const int co = by * C + c4 * 4;
+    fa[0] = *reinterpret_cast<const float4*>(t0.a + co); fb[0] = *reinterpret_cast<const float4*>(t0.b + co);
+    fa[1] = *reinterpret_cast<const float4*>(t1.a + co); fb[1] = *reinterpret_cast<const float4*>(t1.b + co);
+  }
+  const bool lead_w = blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
+  gn_bwd_prologue_wave(t0, B, C, G, count, lead_w, cw[wave][0]);
+  gn_bwd_prologue_wave(t1, B, C, G, count, lead_w, cw[wave][1]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (!act0) return;
+  float4 cA[2], cB[2], cC[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    cA[k] = *reinterpret_cast<const float4*>(&cw[wave][k][0][c4 * 4]);
+    cB[k] = *reinterpret_cast<const float4*>(&cw[wave][k][1][c4 * 4]);
+    cC[k] = *reinterpret_cast<const float4*>(&cw[wave][k][2][c4 * 4]);
+  }
+  const float thr[2] = {t0.relu ? 0.f : -INFINITY, t1.relu ? 0.f : -INFINITY};
+#pragma unroll
+  for (int i = 1; i < PF; ++i) {
+    const int64_t v = v0 + (int64_t)i * m.vpb;
+    const int64_t vc = (i < m.iters && v < N) ? v : v0;
+    dq[i] = *reinterpret_cast<const float4*>(dbp + vc * dld);
+    r0[i] = *reinterpret_cast<const float4*>(rb0 + vc * t0.rld);
+    r1[i] = *reinterpret_cast<const float4*>(rb1 + vc * t1.rld);
+  }
+  auto one = [&](const int k, const float4 d4, const float4 r4, float* op) {
+    const float d[4] = {d4.x, d4.y, d4.z, d4.w}, r[4] = {r4.x, r4.y, r4.z, r4.w};
+    const float a4[4] = {fa[k].x, fa[k].y, fa[k].z, fa[k].w}, b4[4] = {fb[k].x, fb[k].y, fb[k].z, fb[k].w};
+    const float A4[4] = {cA[k].x, cA[k].y, cA[k].z, cA[k].w}, B4[4] = {cB[k].x, cB[k].y, cB[k].z, cB[k].w}, C4[4] = {cC[k].x, cC[k].y, cC[k].z, cC[k].w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float z = fmaf(a4[j], r[j], b4[j]);
+      const float g = z > thr[k] ? d[j] : 0.f;
+      o[j] = fmaf(A4[j], g, fmaf(C4[j], r[j], B4[j]));
+    }
+    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+  };
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int64_t v = v0 + (int64_t)i * m.vpb;
+    if (i < m.iters && v < N) { one(0, dq[i], r0[i], o0 + v * t0.drld); one(1, dq[i], r1[i], o1 + v * t1.drld); }
+  }
+  for (int it = PF; it < m.iters; ++it) {
+    const int64_t v = v0 + (int64_t)it * m.vpb;
+    if (v >= N) break;
+    const float4 d4 = *reinterpret_cast<const float4*>(dbp + v * dld);
+    one(0, d4, *reinterpret_cast<const float4*>(rb0 + v * t0.rld), o0 + v * t0.drld);
+    one(1, d4, *reinterpret_cast<const float4*>(rb1 + v * t1.rld), o1 + v * t1.drld);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // SE gate
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const double* __restrict__ stats, int rows, double count, const float* __restrict__ w1,
@@ -1138,6 +1452,73 @@ int n3d_gn_bwd_coeffs(const double* sums, int rows, const float* gamma, const fl
   N3D_CHECK_ARG(!dbias_conv || sumraw, "gn_bwd_coeffs: dbias_conv needs the forward per-channel sums");
   hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(1), dim3(256 * GNB_BP), 0, (hipStream_t)stream, sums, rows, gamma, mean_rstd, wptr, B, C, G,
                      (double)N, dgamma, dbeta, dalpha, A, Bc, Cc, sumraw, dbias_conv);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+static bool pair_shape_ok(int C, int G) { return C >= 4 && C <= 64 && (C & (C - 1)) == 0 && G >= 1 && C % G == 0 && C / G <= 16; }
+
+int n3d_affine_act_gn2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int G, float eps, float* out, int64_t old_, int B,
+                       int64_t N, int C, int flags, void* stream) {
+  N3D_CHECK_ARG(t0 && t1 && out && B > 0 && N > 0, "affine_act_gn2: bad args");
+  if (!pair_shape_ok(C, G) || t0->rows < 1 || t1->rows < 1 || t0->rows > n3d_fused_max_rows() || t1->rows > n3d_fused_max_rows())
+    N3D_UNSUPPORTED("affine_act_gn2: shape not supported by the pair kernel (C=%d G=%d rows=%d/%d)", C, G, t0->rows, t1->rows);
+  GnFwdTerm k[2];
+  const n3d_gn_fwd_term* ts[2] = {t0, t1};
+  for (int i = 0; i < 2; ++i) {
+    const n3d_gn_fwd_term* t = ts[i];
+    N3D_CHECK_ARG(t->raw && t->stats && t->gamma && t->beta && t->a_out && t->b_out && t->mean_rstd_out, "affine_act_gn2: null term pointer");
+    if (int e = check_vec(t->raw, t->rld, C, "affine_act_gn2(raw)")) return e;
+    k[i] = GnFwdTerm{t->raw, t->rld, t->stats, t->rows, t->gamma, t->beta, t->wptr, t->a_out, t->b_out, t->mean_rstd_out, t->sumraw, t->relu};
+  }
+  if (int e = check_vec(out, old_, C, "affine_act_gn2(out)")) return e;
+  EwMap m = ew_map(N, C);
+  dim3 grid(m.rows, B), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, out, old_, N, C, m);
+  else hipLaunchKernelGGL((affine_act_gn2_kernel<false>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, out, old_, N, C, m);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_affine_act_bwd_reduce2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N,
+                               int C, void* stream) {
+  N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0 && C <= 64, "affine_act_bwd_reduce2: bad args");
+  if (int e = check_vec(dout, dld, C, "bwd_reduce2(dout)")) return e;
+  EwMap m = ew_map(N, C);
+  if ((m.cpb & (m.cpb - 1)) != 0) N3D_UNSUPPORTED("affine_act_bwd_reduce2: C / 4 must be a power of two");
+  BwdRedTerm k[2];
+  const n3d_gn_bwd_term* ts[2] = {t0, t1};
+  for (int i = 0; i < 2; ++i) {
+    const n3d_gn_bwd_term* t = ts[i];
+    N3D_CHECK_ARG(t->raw && t->a && t->b && t->sums, "affine_act_bwd_reduce2: null term pointer");
+    if (int e = check_vec(t->raw, t->rld, C, "bwd_reduce2(raw)")) return e;
+    k[i] = BwdRedTerm{t->raw, t->rld, t->a, t->b, t->sums, t->relu};
+  }
+  hipLaunchKernelGGL(affine_bwd_reduce2_kernel, dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, k[0], k[1], N, C, m);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N,
+                                 int C, int G, void* stream) {
+  N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0, "affine_act_bwd_apply_gn2: bad args");
+  if (!pair_shape_ok(C, G) || t0->rows < 1 || t1->rows < 1 || t0->rows > n3d_fused_max_rows() || t1->rows > n3d_fused_max_rows())
+    N3D_UNSUPPORTED("affine_act_bwd_apply_gn2: shape not supported by the pair kernel (C=%d G=%d rows=%d/%d)", C, G, t0->rows, t1->rows);
+  if (int e = check_vec(dout, dld, C, "bwd_apply_gn2(dout)")) return e;
+  GnBwdTerm k[2];
+  const n3d_gn_bwd_term* ts[2] = {t0, t1};
+  for (int i = 0; i < 2; ++i) {
+    const n3d_gn_bwd_term* t = ts[i];
+    N3D_CHECK_ARG(t->raw && t->a && t->b && t->sums && t->gamma && t->mean_rstd && t->draw, "affine_act_bwd_apply_gn2: null term pointer");
+    N3D_CHECK_ARG(!t->dbias_conv || t->sumraw, "affine_act_bwd_apply_gn2: dbias_conv needs the forward per-channel sums");
+    if (int e = check_vec(t->raw, t->rld, C, "bwd_apply_gn2(raw)")) return e;
+    if (int e = check_vec(t->draw, t->drld, C, "bwd_apply_gn2(draw)")) return e;
+    k[i] = GnBwdTerm{t->raw, t->rld, t->a, t->b, t->sums, t->rows, t->gamma, t->mean_rstd, t->wptr, t->sumraw, t->draw, t->drld,
+                     t->dgamma, t->dbeta, t->dalpha, t->dbias_conv, t->relu};
+  }
+  EwMap m = ew_map(N, C);
+  hipLaunchKernelGGL(affine_bwd_apply_gn2_kernel, dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, k[0], k[1], B, G, (double)N, N, C, m);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

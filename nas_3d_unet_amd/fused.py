@@ -40,9 +40,10 @@ def _copy_into(src, dst):
 class _Plan:
     """Static description of a cell: edges = (node, input index, [(segment, alpha_col)], alpha matrix id, row)."""
 
-    def __init__(self, pre0, pre1, n_nodes, c_node, edges, params):
+    def __init__(self, pre0, pre1, n_nodes, c_node, edges, params, pairs=False):
         self.pre0, self.pre1, self.n_nodes, self.c_node, self.edges, self.params = pre0, pre1, n_nodes, c_node, edges, params
         self.index = {id(p): i for i, p in enumerate(params)}
+        self.pairs = pairs  # searched cell: node k = exactly two single-primitive edges (2k, 2k+1)
 
 
 def searched_plan(cell):
@@ -51,7 +52,7 @@ def searched_plan(cell):
         for e in (2 * node, 2 * node + 1):
             edges.append((node, cell.genolist[e][1], [(_single_segment(cell._ops[e]), 0)], 0, e))
     return _Plan(_single_segment(cell.preprocess0), _single_segment(cell.preprocess1), cell.n_nodes, cell.c_node, edges,
-                 list(cell.parameters()))
+                 list(cell.parameters()), pairs=True)
 
 
 def supernet_plan(cell):
@@ -78,6 +79,20 @@ def _run_forward(plan, x0, x1, alpha1, alpha2):
     out = None
     started = [False] * nn
     st.saved = []
+    if plan.pairs:
+        # searched cell: each node is one pair (both weight ops, then ONE epilogue launch writing the node slice)
+        for node in range(nn):
+            (_, i0, segs0, _, _), (_, i1, segs1, _, _) = plan.edges[2 * node], plan.edges[2 * node + 1]
+            seg0, seg1 = segs0[0][0], segs1[0][0]
+            if out is None:
+                shp = seg0.weight.out_shape(xs[i0])
+                out = K.as_view(K.empty_ndhwc(shp[0], nn * cn, shp[2], shp[3], shp[4], xs[i0].t.device))
+                nodes = [_slice_view(out, k, cn) for k in range(nn)]
+                xs.extend(nodes)
+            s0, s1 = P.pair_forward(seg0, xs[i0], seg1, xs[i1], nodes[node])
+            st.saved.extend([s0, s1])
+        st.xs, st.out = xs, out
+        return out.t, st
     for node, idx, segs, amat, row in plan.edges:
         xin = xs[idx]
         for seg, col in segs:
@@ -118,12 +133,34 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha)
             if g is not None and getattr(p, "_n3d_grad", None) is None:
                 grads[plan.index[id(p)]] = g
 
+    def tgt(idx):
+        if idx >= 2:
+            return dnodes[idx - 2], True
+        t, acc = dpre[idx], pre_started[idx]
+        pre_started[idx] = True
+        return t, acc
+
+    if plan.pairs:
+        # searched cell: nodes in reverse; each node's two epilogue backwards share their launches (P.pair_backward)
+        for node in reversed(range(nn)):
+            (_, i0, segs0, _, _), (_, i1, segs1, _, _) = plan.edges[2 * node], plan.edges[2 * node + 1]
+            seg0, seg1 = segs0[0][0], segs1[0][0]
+            s0, s1 = st.saved[2 * node], st.saved[2 * node + 1]
+            t1, a1 = tgt(i1)   # second edge first: same accumulation order as the unpaired reverse walk
+            t0, a0 = tgt(i0)
+            (_, g0), (_, g1) = P.pair_backward(seg0, s0, seg1, s1, dnodes[node], (True, t0, a0), (True, t1, a1))
+            put(seg1, g1)
+            put(seg0, g0)
+        flat = []
+    else:
+        flat = None
     # reverse order over edges / primitives (saved states were appended in forward order)
-    flat = []
-    for node, idx, segs, amat, row in plan.edges:
-        for seg, col in segs:
-            flat.append((node, idx, seg, col, amat, row))
-    for (node, idx, seg, col, amat, row), s in zip(reversed(flat), reversed(st.saved)):
+    if flat is None:
+        flat = []
+        for node, idx, segs, amat, row in plan.edges:
+            for seg, col in segs:
+                flat.append((node, idx, seg, col, amat, row))
+    for (node, idx, seg, col, amat, row), s in zip(reversed(flat), reversed(st.saved if not plan.pairs else [])):
         if idx >= 2:
             target, acc = dnodes[idx - 2], True
         else:

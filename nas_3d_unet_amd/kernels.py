@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACCUMULATE, POOL_MAX, PREPACKED, RELU, RELU_IN, ConvGeom, FinalJob, N3DError, PackJob, check
+from ._lib import GnFwdTerm, GnBwdTerm, ACCUMULATE, POOL_MAX, PREPACKED, RELU, RELU_IN, ConvGeom, FinalJob, N3DError, PackJob, check
 
 __all__ = ["View", "as_view", "empty_ndhwc", "stream_ptr", "conv_geom", "ptr"]
 
@@ -351,6 +351,70 @@ def affine_act_bwd_apply_gn(dout: View, raw: View, a, b, sums, rows, gamma, beta
                                                   raw.C, G, flags, ptr(dgamma), ptr(dbeta), dalpha_ptr, ptr(dcb),
                                                   stream_ptr()), "n3d_affine_act_bwd_apply_gn")
     return dgamma, dbeta, dcb
+
+
+def _vp(t):
+    """raw device address (int or None) of a tensor / ctypes pointer, for structure fields"""
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        return t.data_ptr()
+    return t.value if hasattr(t, "value") else t
+
+
+def pair_ok(Cc, G, rows0, rows1, B):
+    """shapes the node-level pair kernels accept (include/n3d.h, n3d_affine_act_gn2)"""
+    return (4 <= Cc <= 64 and (Cc & (Cc - 1)) == 0 and Cc % G == 0 and Cc // G <= 16 and 1 <= rows0 <= fused_max_rows()
+            and 1 <= rows1 <= fused_max_rows() and B <= 4)
+
+
+def affine_act_gn2(terms, G, eps, out: View, flags=0):
+    """Two GroupNorm -> [ReLU] -> weighted-sum epilogues into one output: terms = [(raw, stats, rows, gamma, beta, wptr, relu)] * 2.
+    Returns [(a, b, mean_rstd, sumraw)] * 2 (saved for backward)."""
+    raw0 = terms[0][0]
+    dev = raw0.t.device
+    B, Cc = raw0.B, raw0.C
+    # one allocation for both terms' saved coefficients
+    fbuf = torch.empty((2, 2 * B * Cc + 2 * B * G), dtype=torch.float32, device=dev)
+    dbuf = torch.empty((2, B * Cc), dtype=torch.float64, device=dev)
+    ts, saved = [], []
+    for i, (raw, stats, rows, gamma, beta, wptr, relu) in enumerate(terms):
+        a = fbuf[i, :B * Cc].view(B, Cc)
+        b = fbuf[i, B * Cc:2 * B * Cc].view(B, Cc)
+        mr = fbuf[i, 2 * B * Cc:].view(B, G, 2)
+        sr = dbuf[i].view(B, Cc)
+        ts.append(GnFwdTerm(raw.p.value, raw.ld, stats.data_ptr(), rows, 1 if relu else 0, gamma.data_ptr(), beta.data_ptr(),
+                            _vp(wptr), a.data_ptr(), b.data_ptr(), mr.data_ptr(), sr.data_ptr()))
+        saved.append((a, b, mr, sr))
+    check(_lib.load().n3d_affine_act_gn2(C.byref(ts[0]), C.byref(ts[1]), G, eps, out.p, out.ld, B, raw0.N, Cc, flags, stream_ptr()),
+          "n3d_affine_act_gn2")
+    return saved
+
+
+def affine_act_bwd_gn2(dout: View, terms, G):
+    """Backward of affine_act_gn2: terms = [dict(raw, a, b, mr, sumraw, gamma, beta, wptr, relu, conv_bias, draw, dalpha_ptr)] * 2.
+    Two launches (reduce, apply) for both ops.  Returns [(dgamma, dbeta, dconv_bias | None)] * 2."""
+    raw0 = terms[0]["raw"]
+    dev = raw0.t.device
+    B, Cc, N = raw0.B, raw0.C, raw0.N
+    rows = stats_rows(N, Cc)
+    sums = torch.empty((2, B, rows, Cc, 3), dtype=torch.float64, device=dev)
+    ts, outs = [], []
+    for i, t in enumerate(terms):
+        dgamma, dbeta = grad_target(t["gamma"]), grad_target(t["beta"])
+        cb = t.get("conv_bias")
+        dcb = grad_target(cb) if (cb is not None and t["sumraw"] is not None) else None
+        raw, draw = t["raw"], t["draw"]
+        ts.append(GnBwdTerm(raw.p.value, raw.ld, t["a"].data_ptr(), t["b"].data_ptr(), sums[i].data_ptr(), rows, 1 if t["relu"] else 0,
+                            t["gamma"].data_ptr(), t["mr"].data_ptr(), _vp(t.get("wptr")), _vp(t["sumraw"]), draw.p.value, draw.ld,
+                            _vp(dgamma), _vp(dbeta), _vp(t.get("dalpha_ptr")), _vp(dcb)))
+        outs.append((dgamma, dbeta, dcb))
+    lib = _lib.load()
+    check(lib.n3d_affine_act_bwd_reduce2(dout.p, dout.ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, stream_ptr()),
+          "n3d_affine_act_bwd_reduce2")
+    check(lib.n3d_affine_act_bwd_apply_gn2(dout.p, dout.ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, G, stream_ptr()),
+          "n3d_affine_act_bwd_apply_gn2")
+    return outs
 
 
 def affine_act_bwd_reduce(dout: View, raw: View, a, b, flags=0):

@@ -383,10 +383,15 @@ def _wptr(alpha_row, k):
 
 def seg_forward(seg, x, drop_gate=None, out=None, accumulate=False, alpha_row=None, alpha_k=0):
     """Run one segment.  x/out: kernels.View.  Returns (out_view, saved)."""
-    s = Saved()
-    wp = _wptr(alpha_row, alpha_k)
     want_stats = seg.norm is not None and seg.weight.produces_stats
     raw, stats, rows, ws = seg.weight.fwd(x, seg.relu_in, drop_gate, want_stats)
+    return _seg_epilogue_forward(seg, raw, stats, rows, ws, out, accumulate, alpha_row, alpha_k)
+
+
+def _seg_epilogue_forward(seg, raw, stats, rows, ws, out, accumulate, alpha_row, alpha_k):
+    """[norm] -> [ReLU] -> weighted accumulation of a segment whose weight op has produced `raw`"""
+    s = Saved()
+    wp = _wptr(alpha_row, alpha_k)
     s.ws, s.raw = ws, raw
     s.a = s.b = s.mr = None
     s.kind = "plain"
@@ -417,6 +422,77 @@ def seg_forward(seg, x, drop_gate=None, out=None, accumulate=False, alpha_row=No
     fl = (RELU if seg.relu_out else 0) | (ACCUMULATE if accumulate else 0)
     K.affine_act(raw, s.a, s.b, wp, out, fl)
     return out, s
+
+
+def _pairable_fwd(seg):
+    return (seg.norm is not None and seg.weight.produces_stats and seg.se_gate is None)
+
+
+def pair_forward(segA, xA, segB, xB, out):
+    """Node of a searched cell: out = segA(xA) + segB(xB) (searched.py:45-50), `out` a View that is overwritten.
+    Both weight ops run first; if both epilogues are small GroupNorm epilogues of one shape they share ONE launch
+    (n3d_affine_act_gn2), otherwise the two ordinary epilogues run one after the other.  Returns (savedA, savedB)."""
+    res = []
+    for seg, x in ((segA, xA), (segB, xB)):
+        want_stats = seg.norm is not None and seg.weight.produces_stats
+        raw, stats, rows, ws = seg.weight.fwd(x, seg.relu_in, None, want_stats)
+        if seg.norm is not None and stats is None:
+            stats, rows = K.channel_stats(raw)
+        res.append((raw, stats, rows, ws))
+    (rawA, stA, rowsA, wsA), (rawB, stB, rowsB, wsB) = res
+    G = group_count(rawA.C)
+    if (_pairable_fwd(segA) and _pairable_fwd(segB) and rawA.C == rawB.C and rawA.N == rawB.N
+            and segA.norm.eps == segB.norm.eps and K.pair_ok(rawA.C, G, rowsA, rowsB, rawA.B)):
+        terms = [(rawA, stA, rowsA, segA.norm.weight, segA.norm.bias, None, segA.relu_out),
+                 (rawB, stB, rowsB, segB.norm.weight, segB.norm.bias, None, segB.relu_out)]
+        sv = K.affine_act_gn2(terms, G, segA.norm.eps, out, 0)
+        saved = []
+        for (raw, _, _, ws), (a, b, mr, sr) in zip(res, sv):
+            s = Saved()
+            s.ws, s.raw, s.kind, s.G = ws, raw, "gn", G
+            s.a, s.b, s.mr, s.sumraw = a, b, mr, sr
+            saved.append(s)
+        return saved[0], saved[1]
+    _, sA = _seg_epilogue_forward(segA, rawA, stA, rowsA, wsA, out, False, None, 0)
+    _, sB = _seg_epilogue_forward(segB, rawB, stB, rowsB, wsB, out, True, None, 0)
+    return sA, sB
+
+
+def pair_backward(segA, sA, segB, sB, dout, argsA, argsB):
+    """Backward of pair_forward.  argsX = (need_dx, dx_out, dx_acc).  Returns ((dxA, gradsA), (dxB, gradsB)) with
+    grads ordered like segX.params()."""
+    pair = (sA.kind == "gn" and sB.kind == "gn" and not isinstance(segA.weight, IdentityW) and not isinstance(segB.weight, IdentityW)
+            and sA.raw.C == sB.raw.C and sA.raw.N == sB.raw.N)
+    if pair:
+        raw = sA.raw
+        rows = K.stats_rows(raw.N, raw.C)
+        pair = K.pair_ok(raw.C, sA.G, rows, rows, raw.B)
+    if not pair:
+        rb = seg_backward(segB, sB, dout, *argsB)
+        ra = seg_backward(segA, sA, dout, *argsA)
+        return ra, rb
+    terms = []
+    for seg, s in ((segA, sA), (segB, sB)):
+        cbias = seg.weight.norm_fed_bias()
+        if cbias is not None and not cbias.requires_grad:
+            cbias = None
+        raw = s.raw
+        terms.append(dict(raw=raw, a=s.a, b=s.b, mr=s.mr, sumraw=s.sumraw, gamma=seg.norm.weight, beta=seg.norm.bias, wptr=None,
+                          relu=seg.relu_out, conv_bias=cbias,
+                          draw=K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))))
+    outs = K.affine_act_bwd_gn2(dout, terms, sA.G)
+    results = []
+    # weight-op backward in reverse forward order (B then A), as the unpaired path does
+    for seg, s, t, (dgamma, dbeta, dcb), args in ((segB, sB, terms[1], outs[1], argsB), (segA, sA, terms[0], outs[0], argsA)):
+        need_dx, dx_out, dx_acc = args
+        dx, wg = seg.weight.bwd(s.ws, t["draw"], need_dx, dx_out, dx_acc, dcb is not None)
+        wg = list(wg)
+        if dcb is not None:
+            for i, p in enumerate(seg.weight.params()):
+                if p is t["conv_bias"]:
+                    wg[i] = dcb
+        results.append((dx, wg + [dgamma, dbeta]))
+    return results[1], results[0]
 
 
 def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_row=None, alpha_k=0, dalpha=None):
