@@ -1,0 +1,69 @@
+"""GPU parity of the node-level pair kernels (n3d_affine_act_gn2 / _bwd_reduce2 / _bwd_apply_gn2) against the two
+single-op launches they replace, and against the torch-CPU formula of the reference node
+  relu(GN_a(raw_a)) + [relu](GN_b(raw_b))   (searched.py:45-50 with prim_ops.py:56-63,75-80)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def group_count(c):
+    return 1 if c % 16 else c // 16
+
+
+@pytest.mark.parametrize("C,shape,B,relu_b", [(4, (8, 8, 16), 2, True), (8, (4, 8, 8), 2, False), (16, (4, 4, 8), 3, True),
+                                               (32, (4, 4, 4), 2, True), (64, (2, 2, 2), 2, True)])
+def test_pair_forward_backward(C, shape, B, relu_b):
+    from nas_3d_unet_amd import kernels as K
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(C)
+    G = group_count(C)
+    raws = [rng.standard_normal((B, C) + shape).astype(np.float32) * 1.5 + 0.3 for _ in range(2)]
+    gam = [rng.standard_normal(C).astype(np.float32) * 0.5 + 1.0 for _ in range(2)]
+    bet = [rng.standard_normal(C).astype(np.float32) * 0.2 for _ in range(2)]
+    dnode = rng.standard_normal((B, C) + shape).astype(np.float32)
+    relus = [True, relu_b]
+    # ---- torch CPU reference
+    rc = [torch.from_numpy(r).requires_grad_(True) for r in raws]
+    gc = [torch.from_numpy(g).requires_grad_(True) for g in gam]
+    bc = [torch.from_numpy(b).requires_grad_(True) for b in bet]
+    terms = []
+    for k in range(2):
+        z = F.group_norm(rc[k], G, gc[k], bc[k], 1e-5)
+        terms.append(F.relu(z) if relus[k] else z)
+    yc = terms[0] + terms[1]
+    (yc * torch.from_numpy(dnode)).sum().backward()
+    # ---- HIP pair kernels
+    rv = [K.as_view(torch.from_numpy(r).to(dev)) for r in raws]
+    gp = [torch.nn.Parameter(torch.from_numpy(g).to(dev)) for g in gam]
+    bp = [torch.nn.Parameter(torch.from_numpy(b).to(dev)) for b in bet]
+    stats = [K.channel_stats(v) for v in rv]
+    assert K.pair_ok(C, G, stats[0][1], stats[1][1], B)
+    out = K.as_view(K.empty_ndhwc(B, C, *shape, dev))
+    sv = K.affine_act_gn2([(rv[k], stats[k][0], stats[k][1], gp[k], bp[k], None, relus[k]) for k in range(2)], G, 1e-5, out, 0)
+    assert_close(out.t, yc, 2e-5, "node output")
+    dv = K.as_view(torch.from_numpy(dnode).to(dev))
+    draws = [K.as_view(K.empty_ndhwc(B, C, *shape, dev)) for _ in range(2)]
+    tl = [dict(raw=rv[k], a=sv[k][0], b=sv[k][1], mr=sv[k][2], sumraw=sv[k][3], gamma=gp[k], beta=bp[k], wptr=None, relu=relus[k],
+               conv_bias=None, draw=draws[k]) for k in range(2)]
+    outs = K.affine_act_bwd_gn2(dv, tl, G)
+    for k in range(2):
+        assert_close(draws[k].t, rc[k].grad, 1e-4, "d raw %d" % k)
+        assert_close(outs[k][0], gc[k].grad, 1e-4, "dgamma %d" % k)
+        assert_close(outs[k][1], bc[k].grad, 1e-4, "dbeta %d" % k)
+    # ---- and against the single-op launches (same arithmetic, different launch grouping)
+    out1 = K.as_view(K.empty_ndhwc(B, C, *shape, dev))
+    for k in range(2):
+        K.affine_act_gn(rv[k], stats[k][0], stats[k][1], gp[k], bp[k], G, 1e-5, None, out1, (K.RELU if relus[k] else 0) | (K.ACCUMULATE if k else 0))
+    assert torch.equal(out1.t, out.t), "pair forward differs from the two single launches"
+
+
+def test_pair_rejects_unsupported_shape():
+    from nas_3d_unet_amd import kernels as K
+    assert not K.pair_ok(12, 1, 4, 4, 2)     # C not a power of two
+    assert not K.pair_ok(16, 1, 1000, 4, 2)  # too many partial rows for the fused prologue
+    assert K.pair_ok(64, 4, 1, 1, 2)
