@@ -49,7 +49,7 @@ class GnBwdTerm(C.Structure):
     _fields_ = [("raw", C.c_void_p), ("rld", C.c_int64), ("a", C.c_void_p), ("b", C.c_void_p), ("sums", C.c_void_p),
                 ("rows", C.c_int32), ("relu", C.c_int32), ("gamma", C.c_void_p), ("mean_rstd", C.c_void_p), ("wptr", C.c_void_p),
                 ("sumraw", C.c_void_p), ("draw", C.c_void_p), ("drld", C.c_int64), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
-                ("dalpha", C.c_void_p), ("dbias_conv", C.c_void_p)]
+                ("dalpha", C.c_void_p), ("dbias_conv", C.c_void_p), ("cA", C.c_void_p), ("cB", C.c_void_p), ("cC", C.c_void_p)]
 
 
 _p = C.c_void_p
@@ -87,6 +87,10 @@ PROTOTYPES = {
     "n3d_affine_act_gn": (_i, [_p, _i64, _p, _i, _p, _p, _i, _f, _p, _p, _i64, _i, _i64, _i, _i, _p, _p, _p, _p, _p]),
     "n3d_affine_act_bwd_apply_gn": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i64, _i, _i64, _i, _i, _i,
                                          _p, _p, _p, _p, _p]),
+    "n3d_gn_coeffs2": (_i, [C.POINTER(GnFwdTerm), C.POINTER(GnFwdTerm), _i, _i, _i, _i64, _f, _p]),
+    "n3d_affine_act2": (_i, [C.POINTER(GnFwdTerm), C.POINTER(GnFwdTerm), _p, _i64, _i, _i64, _i, _i, _p]),
+    "n3d_gn_bwd_coeffs2": (_i, [C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i, _i, _i64, _p]),
+    "n3d_affine_act_bwd_apply2": (_i, [_p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _p]),
     "n3d_affine_act_gn2": (_i, [C.POINTER(GnFwdTerm), C.POINTER(GnFwdTerm), _i, _f, _p, _i64, _i, _i64, _i, _i, _p]),
     "n3d_affine_act_bwd_reduce2": (_i, [_p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _p]),
     "n3d_affine_act_bwd_apply_gn2": (_i, [_p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _i, _p]),

@@ -101,17 +101,18 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ rows, int
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void gn_coeffs_kernel(const double* __restrict__ stats, int rows, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, int C, int G, double count, float eps,
-                                                        float* __restrict__ a, float* __restrict__ bb, float* __restrict__ mean_rstd,
-                                                        double* __restrict__ sumraw) {
+struct GnCoefArgs { const double* stats; int rows; const float* gamma; const float* beta; float* a; float* bb; float* mean_rstd; double* sumraw; };
+
+// grid (B, terms): blockIdx.y selects the op (two ops of a searched-cell node share one launch)
+__global__ __launch_bounds__(256) void gn_coeffs_kernel(GnCoefArgs q0, GnCoefArgs q1, int C, int G, double count, float eps) {
   __shared__ double part[256];
   __shared__ double tot[192];
   __shared__ double mr[64 * 2];
+  const GnCoefArgs q = blockIdx.y ? q1 : q0;
   const int b = blockIdx.x;
   const int t = threadIdx.x;
-  const float gam_t = (t < C) ? gamma[t] : 0.f, bet_t = (t < C) ? beta[t] : 0.f;  // issued before the row loads
-  reduce_rows(stats + (int64_t)b * rows * C * 2, rows, C * 2, part, tot);
+  const float gam_t = (t < C) ? q.gamma[t] : 0.f, bet_t = (t < C) ? q.beta[t] : 0.f;  // issued before the row loads
+  reduce_rows(q.stats + (int64_t)b * q.rows * C * 2, q.rows, C * 2, part, tot);
   const int cg = C / G;
   if (t < G) {
     double s = 0, ss = 0;
@@ -122,16 +123,16 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(const double* __restrict
     if (var < 0) var = 0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
     mr[t * 2] = mean; mr[t * 2 + 1] = rstd;
-    if (mean_rstd) { mean_rstd[(b * G + t) * 2] = (float)mean; mean_rstd[(b * G + t) * 2 + 1] = (float)rstd; }
+    if (q.mean_rstd) { q.mean_rstd[(b * G + t) * 2] = (float)mean; q.mean_rstd[(b * G + t) * 2 + 1] = (float)rstd; }
   }
   __syncthreads();
   if (t < C) {
     const int g = t / cg;
     const float rstd = (float)mr[g * 2 + 1], mean = (float)mr[g * 2];
     const float av = gam_t * rstd;
-    a[b * C + t] = av;
-    bb[b * C + t] = bet_t - mean * av;
-    if (sumraw) sumraw[b * C + t] = tot[t * 2];
+    q.a[b * C + t] = av;
+    q.bb[b * C + t] = bet_t - mean * av;
+    if (q.sumraw) q.sumraw[b * C + t] = tot[t * 2];
   }
 }
 
@@ -265,12 +266,19 @@ __device__ __forceinline__ void reduce_rows_b(const double* __restrict__ rows, i
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffs_kernel(const double* __restrict__ sums, int rows, const float* __restrict__ gamma,
-                                                            const float* __restrict__ mean_rstd, const float* __restrict__ wptr, int B,
-                                                            int C, int G, double count, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, float* __restrict__ dalpha, float* __restrict__ A,
-                                                            float* __restrict__ Bc, float* __restrict__ Cc,
-                                                            const double* __restrict__ sumraw, float* __restrict__ dbias_conv) {
+struct GnBwdCoefArgs {
+  const double* sums; int rows; const float* gamma; const float* mean_rstd; const float* wptr; float* dgamma; float* dbeta; float* dalpha;
+  float* A; float* Bc; float* Cc; const double* sumraw; float* dbias_conv;
+};
+
+// grid (terms): blockIdx.x selects the op
+__global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffs_kernel(GnBwdCoefArgs q0, GnBwdCoefArgs q1, int B, int C, int G, double count) {
+  const GnBwdCoefArgs q = blockIdx.x ? q1 : q0;
+  const double* __restrict__ sums = q.sums; const int rows = q.rows; const float* __restrict__ gamma = q.gamma;
+  const float* __restrict__ mean_rstd = q.mean_rstd; const float* __restrict__ wptr = q.wptr;
+  float* __restrict__ dgamma = q.dgamma; float* __restrict__ dbeta = q.dbeta; float* __restrict__ dalpha = q.dalpha;
+  float* __restrict__ A = q.A; float* __restrict__ Bc = q.Bc; float* __restrict__ Cc = q.Cc;
+  const double* __restrict__ sumraw = q.sumraw; float* __restrict__ dbias_conv = q.dbias_conv;
   __shared__ double part[GNB_BP][256];
   __shared__ double tot[GNB_BP][192];
   __shared__ double gc[GNB_BP][64 * 2];
@@ -833,7 +841,8 @@ __device__ __forceinline__ void gn_fwd_prologue_wave(const GnFwdTerm& t, const i
   }
 }
 
-template <bool ACC>
+// PRE: the GroupNorm coefficients were computed by n3d_gn_coeffs2 (large tensors): a_out / b_out are inputs, no prologue
+template <bool ACC, bool PRE>
 __global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwdTerm t1, int G, double count, float eps, float* __restrict__ out,
                                                              int64_t old_, int64_t N, int C, EwMap m) {
   __shared__ __attribute__((aligned(16))) float abw[4][2][2][64];  // [wave][term][a|b][channel]
@@ -852,15 +861,23 @@ __global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwd
     q1[0] = *reinterpret_cast<const float4*>(r1 + v0 * t1.rld);
     if (ACC) on[0] = *reinterpret_cast<const float4*>(ob + v0 * old_);
   }
-  const bool store = blockIdx.x == 0 && wave == 0;
-  gn_fwd_prologue_wave(t0, b, C, G, count, eps, store, abw[wave][0]);
-  gn_fwd_prologue_wave(t1, b, C, G, count, eps, store, abw[wave][1]);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (!act0) return;
-  const float4 a0 = *reinterpret_cast<const float4*>(&abw[wave][0][0][c4 * 4]), b0 = *reinterpret_cast<const float4*>(&abw[wave][0][1][c4 * 4]);
-  const float4 a1 = *reinterpret_cast<const float4*>(&abw[wave][1][0][c4 * 4]), b1 = *reinterpret_cast<const float4*>(&abw[wave][1][1][c4 * 4]);
+  float4 a0, b0, a1, b1;
+  if (PRE) {
+    if (!act0) return;
+    const int co = b * C + c4 * 4;
+    a0 = *reinterpret_cast<const float4*>(t0.a_out + co); b0 = *reinterpret_cast<const float4*>(t0.b_out + co);
+    a1 = *reinterpret_cast<const float4*>(t1.a_out + co); b1 = *reinterpret_cast<const float4*>(t1.b_out + co);
+  } else {
+    const bool store = blockIdx.x == 0 && wave == 0;
+    gn_fwd_prologue_wave(t0, b, C, G, count, eps, store, abw[wave][0]);
+    gn_fwd_prologue_wave(t1, b, C, G, count, eps, store, abw[wave][1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!act0) return;
+    a0 = *reinterpret_cast<const float4*>(&abw[wave][0][0][c4 * 4]); b0 = *reinterpret_cast<const float4*>(&abw[wave][0][1][c4 * 4]);
+    a1 = *reinterpret_cast<const float4*>(&abw[wave][1][0][c4 * 4]); b1 = *reinterpret_cast<const float4*>(&abw[wave][1][1][c4 * 4]);
+  }
   const float f0 = t0.relu ? 0.f : -INFINITY, f1 = t1.relu ? 0.f : -INFINITY;
 #pragma unroll
   for (int i = 1; i < PF; ++i) {
@@ -967,6 +984,7 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const float* __
 struct GnBwdTerm {
   const float* raw; int64_t rld; const float* a; const float* b; const double* sums; int rows; const float* gamma; const float* mean_rstd;
   const float* wptr; const double* sumraw; float* draw; int64_t drld; float* dgamma; float* dbeta; float* dalpha; float* dbias_conv; int relu;
+  const float* cA; const float* cB; const float* cC;   // PRE variant: coefficients from n3d_gn_bwd_coeffs2
 };
 
 // GroupNorm-backward coefficients of one term, wave level (see affine_bwd_apply_gn_kernel); strip[0..2][c] = A, B, C
@@ -1024,6 +1042,7 @@ __device__ __forceinline__ void gn_bwd_prologue_wave(const GnBwdTerm& t, const i
   }
 }
 
+template <bool PRE>
 __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* __restrict__ dout, int64_t dld, GnBwdTerm t0, GnBwdTerm t1, int B, int G,
                                                                    double count, int64_t N, int C, EwMap m) {
   __shared__ __attribute__((aligned(16))) float cw[4][2][3][64];  // [wave][term][A|B|C][channel]
@@ -1049,19 +1068,26 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
     fa[0] = *reinterpret_cast<const float4*>(t0.a + co); fb[0] = *reinterpret_cast<const float4*>(t0.b + co);
     fa[1] = *reinterpret_cast<const float4*>(t1.a + co); fb[1] = *reinterpret_cast<const float4*>(t1.b + co);
   }
-  const bool lead_w = blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
-  gn_bwd_prologue_wave(t0, B, C, G, count, lead_w, cw[wave][0]);
-  gn_bwd_prologue_wave(t1, B, C, G, count, lead_w, cw[wave][1]);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (!act0) return;
   float4 cA[2], cB[2], cC[2];
+  if (PRE) {
+    if (!act0) return;
+    const int co = by * C + c4 * 4;
+    cA[0] = *reinterpret_cast<const float4*>(t0.cA + co); cB[0] = *reinterpret_cast<const float4*>(t0.cB + co); cC[0] = *reinterpret_cast<const float4*>(t0.cC + co);
+    cA[1] = *reinterpret_cast<const float4*>(t1.cA + co); cB[1] = *reinterpret_cast<const float4*>(t1.cB + co); cC[1] = *reinterpret_cast<const float4*>(t1.cC + co);
+  } else {
+    const bool lead_w = blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
+    gn_bwd_prologue_wave(t0, B, C, G, count, lead_w, cw[wave][0]);
+    gn_bwd_prologue_wave(t1, B, C, G, count, lead_w, cw[wave][1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!act0) return;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    cA[k] = *reinterpret_cast<const float4*>(&cw[wave][k][0][c4 * 4]);
-    cB[k] = *reinterpret_cast<const float4*>(&cw[wave][k][1][c4 * 4]);
-    cC[k] = *reinterpret_cast<const float4*>(&cw[wave][k][2][c4 * 4]);
+    for (int k = 0; k < 2; ++k) {
+      cA[k] = *reinterpret_cast<const float4*>(&cw[wave][k][0][c4 * 4]);
+      cB[k] = *reinterpret_cast<const float4*>(&cw[wave][k][1][c4 * 4]);
+      cC[k] = *reinterpret_cast<const float4*>(&cw[wave][k][2][c4 * 4]);
+    }
   }
   const float thr[2] = {t0.relu ? 0.f : -INFINITY, t1.relu ? 0.f : -INFINITY};
 #pragma unroll
@@ -1409,8 +1435,8 @@ int n3d_channel_stats(const float* x, int64_t ld, int B, int64_t N, int C, doubl
 int n3d_gn_coeffs(const double* stats, int rows, const float* gamma, const float* beta, int B, int C, int G, int64_t N, float eps,
                   float* a, float* b, float* mean_rstd, double* sumraw, void* stream) {
   N3D_CHECK_ARG(stats && gamma && beta && a && b && C <= 64 && G >= 1 && C % G == 0 && rows >= 1, "gn_coeffs: bad args");
-  hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, stats, rows, gamma, beta, C, G, (double)N, eps, a, b,
-                     mean_rstd, sumraw);
+  const GnCoefArgs q{stats, rows, gamma, beta, a, b, mean_rstd, sumraw};
+  hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B, 1), dim3(256), 0, (hipStream_t)stream, q, q, C, G, (double)N, eps);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -1450,8 +1476,8 @@ int n3d_gn_bwd_coeffs(const double* sums, int rows, const float* gamma, const fl
                       float* dbias_conv, void* stream) {
   N3D_CHECK_ARG(sums && gamma && mean_rstd && A && Bc && Cc && C <= 64 && C % G == 0, "gn_bwd_coeffs: bad args");
   N3D_CHECK_ARG(!dbias_conv || sumraw, "gn_bwd_coeffs: dbias_conv needs the forward per-channel sums");
-  hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(1), dim3(256 * GNB_BP), 0, (hipStream_t)stream, sums, rows, gamma, mean_rstd, wptr, B, C, G,
-                     (double)N, dgamma, dbeta, dalpha, A, Bc, Cc, sumraw, dbias_conv);
+  const GnBwdCoefArgs q{sums, rows, gamma, mean_rstd, wptr, dgamma, dbeta, dalpha, A, Bc, Cc, sumraw, dbias_conv};
+  hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(1), dim3(256 * GNB_BP), 0, (hipStream_t)stream, q, q, B, C, G, (double)N);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -1475,8 +1501,8 @@ int n3d_affine_act_gn2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int
   EwMap m = ew_map(N, C);
   dim3 grid(m.rows, B), blk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, out, old_, N, C, m);
-  else hipLaunchKernelGGL((affine_act_gn2_kernel<false>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, out, old_, N, C, m);
+  if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true, false>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, out, old_, N, C, m);
+  else hipLaunchKernelGGL((affine_act_gn2_kernel<false, false>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, out, old_, N, C, m);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -1515,10 +1541,81 @@ int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const n3d_gn_bw
     if (int e = check_vec(t->raw, t->rld, C, "bwd_apply_gn2(raw)")) return e;
     if (int e = check_vec(t->draw, t->drld, C, "bwd_apply_gn2(draw)")) return e;
     k[i] = GnBwdTerm{t->raw, t->rld, t->a, t->b, t->sums, t->rows, t->gamma, t->mean_rstd, t->wptr, t->sumraw, t->draw, t->drld,
-                     t->dgamma, t->dbeta, t->dalpha, t->dbias_conv, t->relu};
+                     t->dgamma, t->dbeta, t->dalpha, t->dbias_conv, t->relu, nullptr, nullptr, nullptr};
   }
   EwMap m = ew_map(N, C);
-  hipLaunchKernelGGL(affine_bwd_apply_gn2_kernel, dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, k[0], k[1], B, G, (double)N, N, C, m);
+  hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, k[0], k[1], B, G, (double)N, N, C, m);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_gn_coeffs2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int B, int C, int G, int64_t N, float eps, void* stream) {
+  N3D_CHECK_ARG(t0 && t1 && C <= 64 && G >= 1 && C % G == 0, "gn_coeffs2: bad args");
+  GnCoefArgs q[2];
+  const n3d_gn_fwd_term* ts[2] = {t0, t1};
+  for (int i = 0; i < 2; ++i) {
+    const n3d_gn_fwd_term* t = ts[i];
+    N3D_CHECK_ARG(t->stats && t->gamma && t->beta && t->a_out && t->b_out && t->rows >= 1, "gn_coeffs2: null term pointer");
+    q[i] = GnCoefArgs{t->stats, t->rows, t->gamma, t->beta, t->a_out, t->b_out, t->mean_rstd_out, t->sumraw};
+  }
+  hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B, 2), dim3(256), 0, (hipStream_t)stream, q[0], q[1], C, G, (double)N, eps);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_affine_act2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, float* out, int64_t old_, int B, int64_t N, int C, int flags,
+                    void* stream) {
+  N3D_CHECK_ARG(t0 && t1 && out && B > 0 && N > 0 && C <= 64, "affine_act2: bad args");
+  GnFwdTerm k[2];
+  const n3d_gn_fwd_term* ts[2] = {t0, t1};
+  for (int i = 0; i < 2; ++i) {
+    const n3d_gn_fwd_term* t = ts[i];
+    N3D_CHECK_ARG(t->raw && t->a_out && t->b_out, "affine_act2: null term pointer");
+    if (int e = check_vec(t->raw, t->rld, C, "affine_act2(raw)")) return e;
+    k[i] = GnFwdTerm{t->raw, t->rld, nullptr, 0, nullptr, nullptr, t->wptr, t->a_out, t->b_out, nullptr, nullptr, t->relu};
+  }
+  if (int e = check_vec(out, old_, C, "affine_act2(out)")) return e;
+  EwMap m = ew_map(N, C);
+  dim3 grid(m.rows, B), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true, true>), grid, blk, 0, s, k[0], k[1], 1, (double)N, 0.f, out, old_, N, C, m);
+  else hipLaunchKernelGGL((affine_act_gn2_kernel<false, true>), grid, blk, 0, s, k[0], k[1], 1, (double)N, 0.f, out, old_, N, C, m);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_gn_bwd_coeffs2(const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int C, int G, int64_t N, void* stream) {
+  N3D_CHECK_ARG(t0 && t1 && C <= 64 && G >= 1 && C % G == 0, "gn_bwd_coeffs2: bad args");
+  GnBwdCoefArgs q[2];
+  const n3d_gn_bwd_term* ts[2] = {t0, t1};
+  for (int i = 0; i < 2; ++i) {
+    const n3d_gn_bwd_term* t = ts[i];
+    N3D_CHECK_ARG(t->sums && t->gamma && t->mean_rstd && t->cA && t->cB && t->cC && t->rows >= 1, "gn_bwd_coeffs2: null term pointer");
+    N3D_CHECK_ARG(!t->dbias_conv || t->sumraw, "gn_bwd_coeffs2: dbias_conv needs the forward per-channel sums");
+    q[i] = GnBwdCoefArgs{t->sums, t->rows, t->gamma, t->mean_rstd, t->wptr, t->dgamma, t->dbeta, t->dalpha, t->cA, t->cB, t->cC, t->sumraw,
+                         t->dbias_conv};
+  }
+  hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(2), dim3(256 * GNB_BP), 0, (hipStream_t)stream, q[0], q[1], B, C, G, (double)N);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_affine_act_bwd_apply2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N, int C,
+                              void* stream) {
+  N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0 && C <= 64, "affine_act_bwd_apply2: bad args");
+  if (int e = check_vec(dout, dld, C, "bwd_apply2(dout)")) return e;
+  GnBwdTerm k[2];
+  const n3d_gn_bwd_term* ts[2] = {t0, t1};
+  for (int i = 0; i < 2; ++i) {
+    const n3d_gn_bwd_term* t = ts[i];
+    N3D_CHECK_ARG(t->raw && t->a && t->b && t->cA && t->cB && t->cC && t->draw, "affine_act_bwd_apply2: null term pointer");
+    if (int e = check_vec(t->raw, t->rld, C, "bwd_apply2(raw)")) return e;
+    if (int e = check_vec(t->draw, t->drld, C, "bwd_apply2(draw)")) return e;
+    k[i] = GnBwdTerm{t->raw, t->rld, t->a, t->b, nullptr, 0, nullptr, nullptr, nullptr, nullptr, t->draw, t->drld, nullptr, nullptr, nullptr,
+                     nullptr, t->relu, t->cA, t->cB, t->cC};
+  }
+  EwMap m = ew_map(N, C);
+  hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<true>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, k[0], k[1], B, 1, (double)N, N, C, m);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

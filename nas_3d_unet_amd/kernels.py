@@ -363,9 +363,14 @@ def _vp(t):
 
 
 def pair_ok(Cc, G, rows0, rows1, B):
-    """shapes the node-level pair kernels accept (include/n3d.h, n3d_affine_act_gn2)"""
+    """shapes the FUSED node-level pair kernels accept (include/n3d.h, n3d_affine_act_gn2)"""
     return (4 <= Cc <= 64 and (Cc & (Cc - 1)) == 0 and Cc % G == 0 and Cc // G <= 16 and 1 <= rows0 <= fused_max_rows()
             and 1 <= rows1 <= fused_max_rows() and B <= 4)
+
+
+def pair_shape_ok(Cc):
+    """shapes every pair kernel accepts (the variants with separately computed coefficients have no row limit)"""
+    return 4 <= Cc <= 64 and (Cc & (Cc - 1)) == 0
 
 
 def affine_act_gn2(terms, G, eps, out: View, flags=0):
@@ -386,8 +391,14 @@ def affine_act_gn2(terms, G, eps, out: View, flags=0):
         ts.append(GnFwdTerm(raw.p.value, raw.ld, stats.data_ptr(), rows, 1 if relu else 0, gamma.data_ptr(), beta.data_ptr(),
                             _vp(wptr), a.data_ptr(), b.data_ptr(), mr.data_ptr(), sr.data_ptr()))
         saved.append((a, b, mr, sr))
-    check(_lib.load().n3d_affine_act_gn2(C.byref(ts[0]), C.byref(ts[1]), G, eps, out.p, out.ld, B, raw0.N, Cc, flags, stream_ptr()),
-          "n3d_affine_act_gn2")
+    lib = _lib.load()
+    if pair_ok(Cc, G, terms[0][2], terms[1][2], B):
+        check(lib.n3d_affine_act_gn2(C.byref(ts[0]), C.byref(ts[1]), G, eps, out.p, out.ld, B, raw0.N, Cc, flags, stream_ptr()),
+              "n3d_affine_act_gn2")
+    else:
+        # large tensors: coefficients of both ops in one launch, then the two-term epilogue
+        check(lib.n3d_gn_coeffs2(C.byref(ts[0]), C.byref(ts[1]), B, Cc, G, raw0.N, eps, stream_ptr()), "n3d_gn_coeffs2")
+        check(lib.n3d_affine_act2(C.byref(ts[0]), C.byref(ts[1]), out.p, out.ld, B, raw0.N, Cc, flags, stream_ptr()), "n3d_affine_act2")
     return saved
 
 
@@ -400,6 +411,8 @@ def affine_act_bwd_gn2(dout: View, terms, G):
     rows = stats_rows(N, Cc)
     sums = torch.empty((2, B, rows, Cc, 3), dtype=torch.float64, device=dev)
     ts, outs = [], []
+    fused = pair_ok(Cc, G, rows, rows, B)
+    coef = None if fused else torch.empty((2, 3, B, Cc), dtype=torch.float32, device=dev)
     for i, t in enumerate(terms):
         dgamma, dbeta = grad_target(t["gamma"]), grad_target(t["beta"])
         cb = t.get("conv_bias")
@@ -407,13 +420,19 @@ def affine_act_bwd_gn2(dout: View, terms, G):
         raw, draw = t["raw"], t["draw"]
         ts.append(GnBwdTerm(raw.p.value, raw.ld, t["a"].data_ptr(), t["b"].data_ptr(), sums[i].data_ptr(), rows, 1 if t["relu"] else 0,
                             t["gamma"].data_ptr(), t["mr"].data_ptr(), _vp(t.get("wptr")), _vp(t["sumraw"]), draw.p.value, draw.ld,
-                            _vp(dgamma), _vp(dbeta), _vp(t.get("dalpha_ptr")), _vp(dcb)))
+                            _vp(dgamma), _vp(dbeta), _vp(t.get("dalpha_ptr")), _vp(dcb),
+                            *([None] * 3 if fused else [coef[i, j].data_ptr() for j in range(3)])))
         outs.append((dgamma, dbeta, dcb))
     lib = _lib.load()
     check(lib.n3d_affine_act_bwd_reduce2(dout.p, dout.ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, stream_ptr()),
           "n3d_affine_act_bwd_reduce2")
-    check(lib.n3d_affine_act_bwd_apply_gn2(dout.p, dout.ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, G, stream_ptr()),
-          "n3d_affine_act_bwd_apply_gn2")
+    if fused:
+        check(lib.n3d_affine_act_bwd_apply_gn2(dout.p, dout.ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, G, stream_ptr()),
+              "n3d_affine_act_bwd_apply_gn2")
+    else:
+        check(lib.n3d_gn_bwd_coeffs2(C.byref(ts[0]), C.byref(ts[1]), B, Cc, G, N, stream_ptr()), "n3d_gn_bwd_coeffs2")
+        check(lib.n3d_affine_act_bwd_apply2(dout.p, dout.ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, stream_ptr()),
+              "n3d_affine_act_bwd_apply2")
     return outs
 
 

@@ -442,7 +442,7 @@ def pair_forward(segA, xA, segB, xB, out):
     (rawA, stA, rowsA, wsA), (rawB, stB, rowsB, wsB) = res
     G = group_count(rawA.C)
     if (_pairable_fwd(segA) and _pairable_fwd(segB) and rawA.C == rawB.C and rawA.N == rawB.N
-            and segA.norm.eps == segB.norm.eps and K.pair_ok(rawA.C, G, rowsA, rowsB, rawA.B)):
+            and segA.norm.eps == segB.norm.eps and K.pair_shape_ok(rawA.C)):
         terms = [(rawA, stA, rowsA, segA.norm.weight, segA.norm.bias, None, segA.relu_out),
                  (rawB, stB, rowsB, segB.norm.weight, segB.norm.bias, None, segB.relu_out)]
         sv = K.affine_act_gn2(terms, G, segA.norm.eps, out, 0)
@@ -464,9 +464,7 @@ def pair_backward(segA, sA, segB, sB, dout, argsA, argsB):
     pair = (sA.kind == "gn" and sB.kind == "gn" and not isinstance(segA.weight, IdentityW) and not isinstance(segB.weight, IdentityW)
             and sA.raw.C == sB.raw.C and sA.raw.N == sB.raw.N)
     if pair:
-        raw = sA.raw
-        rows = K.stats_rows(raw.N, raw.C)
-        pair = K.pair_ok(raw.C, sA.G, rows, rows, raw.B)
+        pair = K.pair_shape_ok(sA.raw.C)
     if not pair:
         rb = seg_backward(segB, sB, dout, *argsB)
         ra = seg_backward(segA, sA, dout, *argsA)

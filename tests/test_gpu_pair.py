@@ -16,7 +16,8 @@ def group_count(c):
 
 
 @pytest.mark.parametrize("C,shape,B,relu_b", [(4, (8, 8, 16), 2, True), (8, (4, 8, 8), 2, False), (16, (4, 4, 8), 3, True),
-                                               (32, (4, 4, 4), 2, True), (64, (2, 2, 2), 2, True)])
+                                               (32, (4, 4, 4), 2, True), (64, (2, 2, 2), 2, True),
+                                               (4, (32, 32, 32), 2, True), (8, (16, 32, 32), 5, False)])  # last two: > 64 partial rows
 def test_pair_forward_backward(C, shape, B, relu_b):
     from nas_3d_unet_amd import kernels as K
     dev = torch.device("cuda")
@@ -42,7 +43,7 @@ def test_pair_forward_backward(C, shape, B, relu_b):
     gp = [torch.nn.Parameter(torch.from_numpy(g).to(dev)) for g in gam]
     bp = [torch.nn.Parameter(torch.from_numpy(b).to(dev)) for b in bet]
     stats = [K.channel_stats(v) for v in rv]
-    assert K.pair_ok(C, G, stats[0][1], stats[1][1], B)
+    assert K.pair_shape_ok(C)
     out = K.as_view(K.empty_ndhwc(B, C, *shape, dev))
     sv = K.affine_act_gn2([(rv[k], stats[k][0], stats[k][1], gp[k], bp[k], None, relus[k]) for k in range(2)], G, 1e-5, out, 0)
     assert_close(out.t, yc, 2e-5, "node output")
@@ -58,7 +59,12 @@ def test_pair_forward_backward(C, shape, B, relu_b):
     # ---- and against the single-op launches (same arithmetic, different launch grouping)
     out1 = K.as_view(K.empty_ndhwc(B, C, *shape, dev))
     for k in range(2):
-        K.affine_act_gn(rv[k], stats[k][0], stats[k][1], gp[k], bp[k], G, 1e-5, None, out1, (K.RELU if relus[k] else 0) | (K.ACCUMULATE if k else 0))
+        fl = (K.RELU if relus[k] else 0) | (K.ACCUMULATE if k else 0)
+        if stats[k][1] <= K.fused_max_rows():
+            K.affine_act_gn(rv[k], stats[k][0], stats[k][1], gp[k], bp[k], G, 1e-5, None, out1, fl)
+        else:
+            a, b, _, _ = K.gn_coeffs(stats[k][0], stats[k][1], gp[k], bp[k], B, C, G, rv[k].N)
+            K.affine_act(rv[k], a, b, None, out1, fl)
     assert torch.equal(out1.t, out.t), "pair forward differs from the two single launches"
 
 
