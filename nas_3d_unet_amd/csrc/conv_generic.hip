@@ -650,25 +650,26 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
 }
 
 __global__ __launch_bounds__(256) void wgrad_final_batch_kernel(FinalJobs jobs) {
-  // 32 outputs x 8 chunk segments per workgroup: the slab rows are summed 8-way in parallel and combined in LDS
-  // in a fixed order (deterministic), instead of one thread walking up to 512 slabs.
+  // A workgroup owns 32 consecutive SLAB positions (tile-major, the order the partial slabs are stored in) and sums
+  // them over the chunks 8-way in parallel: every slab row is read as one contiguous 128-byte piece (reading in
+  // weight-tensor order instead walks the slabs with a multi-KB stride per lane).  The 32 sums are combined in
+  // LDS in a fixed order (deterministic) and scattered to the native (Co, Ci, taps) weight layout.
   __shared__ float seg[8][32];
   const n3d_final_job jb = jobs.j[blockIdx.y];
   const int oi = threadIdx.x & 31, sg = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + oi;
-  const int nw = jb.Co * jb.Ci * jb.taps;
   const int T = jb.ci_t * jb.co_t;
+  const int nslab = jb.ntiles * T;
+  const int nb = jb.tco * jb.co_t;
+  const int p = blockIdx.x * 32 + oi;
+  if (blockIdx.x * 32 >= nslab + nb) return;
   float s = 0.f;
-  if (i < nw) {
+  if (p < nslab) {
     if (jb.dw) {
-      const int tap = i % jb.taps, ci = (i / jb.taps) % jb.Ci, co = i / (jb.taps * jb.Ci);
-      const int tile = (tap * jb.tci + ci / jb.ci_t) * jb.tco + co / jb.co_t;
-      const int q = (ci % jb.ci_t) * jb.co_t + (co % jb.co_t);
-      for (int c = sg; c < jb.nchunks; c += 8) s += jb.partial[((int64_t)c * jb.ntiles + tile) * T + q];
+      const int64_t cs = nslab;
+      for (int c = sg; c < jb.nchunks; c += 8) s += jb.partial[c * cs + p];
     }
-  } else if (i < nw + jb.Co && jb.dbias) {
-    const int co = i - nw;
-    for (int c = sg; c < jb.nchunks; c += 8) s += jb.pbias[((int64_t)c * jb.tco + co / jb.co_t) * jb.co_t + co % jb.co_t];
+  } else if (p < nslab + nb && jb.dbias) {
+    for (int c = sg; c < jb.nchunks; c += 8) s += jb.pbias[(int64_t)c * nb + (p - nslab)];
   }
   seg[sg][oi] = s;
   __syncthreads();
@@ -676,8 +677,17 @@ __global__ __launch_bounds__(256) void wgrad_final_batch_kernel(FinalJobs jobs) 
     float tot = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) tot += seg[k][oi];
-    if (i < nw) { if (jb.dw) jb.dw[i] = tot; }
-    else if (i < nw + jb.Co && jb.dbias) jb.dbias[i - nw] = tot;
+    if (p < nslab) {
+      if (jb.dw) {
+        const int tile = p / T, q = p - tile * T;
+        const int cot = tile % jb.tco, cit = (tile / jb.tco) % jb.tci, tap = tile / (jb.tco * jb.tci);
+        const int ci = cit * jb.ci_t + q / jb.co_t, co = cot * jb.co_t + q % jb.co_t;
+        if (ci < jb.Ci && co < jb.Co) jb.dw[((int64_t)co * jb.Ci + ci) * jb.taps + tap] = tot;
+      }
+    } else if (p < nslab + nb && jb.dbias) {
+      const int co = p - nslab;
+      if (co < jb.Co) jb.dbias[co] = tot;
+    }
   }
 }
 
@@ -699,7 +709,9 @@ static WgradPlan wgrad_plan(int B, int64_t No, int Ci, int Co, int taps) {
   p.tco = (int)cdiv(Co, p.co_t);
   p.ntiles = taps * p.tci * p.tco;
   const int64_t total = (int64_t)B * No;
-  int64_t nch = cdiv(total, 4096);
+  // short chunks: the voxel loop of the kernel is a dependent load -> FMA chain (one memory latency per
+  // iteration), so per-thread trip count, not block count, sets the kernel time on these small problems
+  int64_t nch = cdiv(total, 512);
   // keep the grid around a few thousand blocks
   while (nch * p.ntiles > 8192 && nch > 1) nch = (nch + 1) / 2;
   if (nch > 512) nch = 512;
@@ -1080,7 +1092,7 @@ int n3d_wgrad_finalize_batch(const n3d_final_job* jobs, int njobs, void* stream)
     int maxel = 0;
     for (int i = 0; i < n; ++i) {
       fj.j[i] = jobs[base + i];
-      const int el = fj.j[i].Co * fj.j[i].Ci * fj.j[i].taps + fj.j[i].Co;
+      const int el = fj.j[i].ntiles * fj.j[i].ci_t * fj.j[i].co_t + fj.j[i].tco * fj.j[i].co_t;
       if (el > maxel) maxel = el;
     }
     for (int i = n; i < N3D_FINAL_JOBS; ++i) fj.j[i] = fj.j[0];
