@@ -616,7 +616,9 @@ __global__ void channel_sum_final_kernel(const float* __restrict__ partial, int 
 #define N3D_PACK_JOBS 64
 #define N3D_FINAL_JOBS 40
 struct PackJobs { n3d_pack_job j[N3D_PACK_JOBS]; };
-struct FinalJobs { n3d_final_job j[N3D_FINAL_JOBS]; };
+// start[k] = first workgroup of job k in the flattened grid (only the workgroups a job needs are launched: a
+// (max elements, jobs) grid spends its time dispatching empty workgroups)
+struct FinalJobs { n3d_final_job j[N3D_FINAL_JOBS]; int start[N3D_FINAL_JOBS + 1]; int n; };
 
 __global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
   const n3d_pack_job jb = jobs.j[blockIdx.y];
@@ -649,24 +651,68 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
   }
 }
 
+#define N3D_FINAL_DIRECT_MAX 16  // jobs with at most this many chunks: one thread sums all chunks of its slab position
+
+__device__ __forceinline__ void final_store(const n3d_final_job& jb, const int p, const int nslab, const int nb, const int T, const float tot) {
+  if (p < nslab) {
+    if (jb.dw) {
+      const int tile = p / T, q = p - tile * T;
+      const int cot = tile % jb.tco, cit = (tile / jb.tco) % jb.tci, tap = tile / (jb.tco * jb.tci);
+      const int ci = cit * jb.ci_t + q / jb.co_t, co = cot * jb.co_t + q % jb.co_t;
+      if (ci < jb.Ci && co < jb.Co) jb.dw[((int64_t)co * jb.Ci + ci) * jb.taps + tap] = tot;
+    }
+  } else if (p < nslab + nb && jb.dbias) {
+    const int co = p - nslab;
+    if (co < jb.Co) jb.dbias[co] = tot;
+  }
+}
+
 __global__ __launch_bounds__(256) void wgrad_final_batch_kernel(FinalJobs jobs) {
-  // A workgroup owns 32 consecutive SLAB positions (tile-major, the order the partial slabs are stored in) and sums
-  // them over the chunks 8-way in parallel: every slab row is read as one contiguous 128-byte piece (reading in
-  // weight-tensor order instead walks the slabs with a multi-KB stride per lane).  The 32 sums are combined in
-  // LDS in a fixed order (deterministic) and scattered to the native (Co, Ci, taps) weight layout.
+  // Slab positions are walked in the order the partial slabs are stored in (tile-major), so every slab row is read
+  // as contiguous pieces (reading in weight-tensor order walks the slabs with a multi-KB stride per lane); sums are
+  // formed in a fixed order (deterministic) and scattered to the native (Co, Ci, taps) weight layout.
   __shared__ float seg[8][32];
-  const n3d_final_job jb = jobs.j[blockIdx.y];
-  const int oi = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  int jx = 0;
+  while (jx + 1 < jobs.n && (int)blockIdx.x >= jobs.start[jx + 1]) ++jx;
+  const n3d_final_job jb = jobs.j[jx];
+  const int lb = blockIdx.x - jobs.start[jx];
   const int T = jb.ci_t * jb.co_t;
   const int nslab = jb.ntiles * T;
   const int nb = jb.tco * jb.co_t;
-  const int p = blockIdx.x * 32 + oi;
-  if (blockIdx.x * 32 >= nslab + nb) return;
+  const int64_t cs = nslab;
+  if (jb.nchunks <= N3D_FINAL_DIRECT_MAX) {
+    // few chunks: 256 positions per workgroup, all rows of a position requested up front
+    const int p = lb * 256 + threadIdx.x;
+    float v[N3D_FINAL_DIRECT_MAX];
+    float s = 0.f;
+    if (p < nslab) {
+      if (!jb.dw) return;
+#pragma unroll
+      for (int c = 0; c < N3D_FINAL_DIRECT_MAX; ++c) v[c] = jb.partial[(c < jb.nchunks ? c : 0) * cs + p];
+#pragma unroll
+      for (int c = 0; c < N3D_FINAL_DIRECT_MAX; ++c) s += (c < jb.nchunks) ? v[c] : 0.f;
+    } else if (p < nslab + nb && jb.dbias) {
+      for (int c = 0; c < jb.nchunks; ++c) s += jb.pbias[(int64_t)c * nb + (p - nslab)];
+    }
+    final_store(jb, p, nslab, nb, T, s);
+    return;
+  }
+  // many chunks: 32 positions x 8 chunk segments per workgroup, segments combined in LDS
+  const int oi = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int p = lb * 32 + oi;
   float s = 0.f;
   if (p < nslab) {
     if (jb.dw) {
-      const int64_t cs = nslab;
-      for (int c = sg; c < jb.nchunks; c += 8) s += jb.partial[c * cs + p];
+      // eight slab rows in flight per step (a rolled load -> add loop pays one memory latency per row)
+      int c = sg;
+      for (; c + 56 < jb.nchunks; c += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = jb.partial[(c + 8 * u) * cs + p];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; c < jb.nchunks; c += 8) s += jb.partial[c * cs + p];
     }
   } else if (p < nslab + nb && jb.dbias) {
     for (int c = sg; c < jb.nchunks; c += 8) s += jb.pbias[(int64_t)c * nb + (p - nslab)];
@@ -677,17 +723,7 @@ __global__ __launch_bounds__(256) void wgrad_final_batch_kernel(FinalJobs jobs) 
     float tot = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) tot += seg[k][oi];
-    if (p < nslab) {
-      if (jb.dw) {
-        const int tile = p / T, q = p - tile * T;
-        const int cot = tile % jb.tco, cit = (tile / jb.tco) % jb.tci, tap = tile / (jb.tco * jb.tci);
-        const int ci = cit * jb.ci_t + q / jb.co_t, co = cot * jb.co_t + q % jb.co_t;
-        if (ci < jb.Ci && co < jb.Co) jb.dw[((int64_t)co * jb.Ci + ci) * jb.taps + tap] = tot;
-      }
-    } else if (p < nslab + nb && jb.dbias) {
-      const int co = p - nslab;
-      if (co < jb.Co) jb.dbias[co] = tot;
-    }
+    final_store(jb, p, nslab, nb, T, tot);
   }
 }
 
@@ -1089,14 +1125,17 @@ int n3d_wgrad_finalize_batch(const n3d_final_job* jobs, int njobs, void* stream)
   for (int base = 0; base < njobs; base += N3D_FINAL_JOBS) {
     const int n = njobs - base < N3D_FINAL_JOBS ? njobs - base : N3D_FINAL_JOBS;
     FinalJobs fj;
-    int maxel = 0;
+    int nblk = 0;
     for (int i = 0; i < n; ++i) {
       fj.j[i] = jobs[base + i];
       const int el = fj.j[i].ntiles * fj.j[i].ci_t * fj.j[i].co_t + fj.j[i].tco * fj.j[i].co_t;
-      if (el > maxel) maxel = el;
+      fj.start[i] = nblk;
+      nblk += (int)cdiv(el, fj.j[i].nchunks <= N3D_FINAL_DIRECT_MAX ? 256 : 32);
     }
-    for (int i = n; i < N3D_FINAL_JOBS; ++i) fj.j[i] = fj.j[0];
-    hipLaunchKernelGGL(wgrad_final_batch_kernel, dim3((unsigned)cdiv(maxel, 32), n), dim3(256), 0, (hipStream_t)stream, fj);
+    for (int i = n; i < N3D_FINAL_JOBS; ++i) { fj.j[i] = fj.j[0]; fj.start[i] = nblk; }
+    fj.start[N3D_FINAL_JOBS] = nblk;
+    fj.n = n;
+    if (nblk > 0) hipLaunchKernelGGL(wgrad_final_batch_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, fj);
   }
   N3D_LAUNCH_CHECK();
   return N3D_OK;
