@@ -615,16 +615,20 @@ __global__ void channel_sum_final_kernel(const float* __restrict__ partial, int 
 // ------------------------------------------------------------------------------------------------
 #define N3D_PACK_JOBS 64
 #define N3D_FINAL_JOBS 40
-struct PackJobs { n3d_pack_job j[N3D_PACK_JOBS]; };
+struct PackJobs { n3d_pack_job j[N3D_PACK_JOBS]; int start[N3D_PACK_JOBS + 1]; int n; };
 // start[k] = first workgroup of job k in the flattened grid (only the workgroups a job needs are launched: a
 // (max elements, jobs) grid spends its time dispatching empty workgroups)
 struct FinalJobs { n3d_final_job j[N3D_FINAL_JOBS]; int start[N3D_FINAL_JOBS + 1]; int n; };
 
 __global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
-  const n3d_pack_job jb = jobs.j[blockIdx.y];
+  // flattened grid: start[k] = first workgroup of job k; binary search (each probe is a dependent scalar load)
+  int jx = 0;
+  for (int step = 32; step >= 1; step >>= 1)
+    if (jx + step < jobs.n && (int)blockIdx.x >= jobs.start[jx + step]) jx += step;
+  const n3d_pack_job jb = jobs.j[jx];
   const int Co = jb.Co, Ci = jb.Ci, taps = jb.taps;
   const int Cs = jb.data_grad ? Co : Ci, Cd = jb.data_grad ? Ci : Co;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = (blockIdx.x - jobs.start[jx]) * 256 + threadIdx.x;
   if (jb.layout == 0) {
     const int Cdp = jb.cdp;
     if (i >= taps * Cs * Cdp) return;
@@ -672,8 +676,9 @@ __global__ __launch_bounds__(256) void wgrad_final_batch_kernel(FinalJobs jobs) 
   // as contiguous pieces (reading in weight-tensor order walks the slabs with a multi-KB stride per lane); sums are
   // formed in a fixed order (deterministic) and scattered to the native (Co, Ci, taps) weight layout.
   __shared__ float seg[8][32];
-  int jx = 0;
-  while (jx + 1 < jobs.n && (int)blockIdx.x >= jobs.start[jx + 1]) ++jx;
+  int jx = 0;  // binary search over the job start offsets (each probe is a dependent scalar load)
+  for (int step = 32; step >= 1; step >>= 1)
+    if (jx + step < jobs.n && (int)blockIdx.x >= jobs.start[jx + step]) jx += step;
   const n3d_final_job jb = jobs.j[jx];
   const int lb = blockIdx.x - jobs.start[jx];
   const int T = jb.ci_t * jb.co_t;
@@ -1105,16 +1110,19 @@ int n3d_pack_batch(const n3d_pack_job* jobs, int njobs, void* stream) {
   for (int base = 0; base < njobs; base += N3D_PACK_JOBS) {
     const int n = njobs - base < N3D_PACK_JOBS ? njobs - base : N3D_PACK_JOBS;
     PackJobs pj;
-    int maxel = 0;
+    int nblk = 0;
     for (int i = 0; i < n; ++i) {
       pj.j[i] = jobs[base + i];
       const n3d_pack_job& q = pj.j[i];
       const int Cs = q.data_grad ? q.Co : q.Ci, Cd = q.data_grad ? q.Ci : q.Co;
       const int el = q.layout == 0 ? q.taps * Cs * q.cdp : (q.layout == 1 ? q.taps * Cs * Cd : 27 * q.Co * q.Co);
-      if (el > maxel) maxel = el;
+      pj.start[i] = nblk;
+      nblk += (int)cdiv(el, 256);
     }
-    for (int i = n; i < N3D_PACK_JOBS; ++i) pj.j[i] = pj.j[0];
-    hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)cdiv(maxel, 256), n), dim3(256), 0, (hipStream_t)stream, pj);
+    for (int i = n; i < N3D_PACK_JOBS; ++i) { pj.j[i] = pj.j[0]; pj.start[i] = nblk; }
+    pj.start[N3D_PACK_JOBS] = nblk;
+    pj.n = n;
+    if (nblk > 0) hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, pj);
   }
   N3D_LAUNCH_CHECK();
   return N3D_OK;
