@@ -21,6 +21,8 @@ struct GatherArgs {
   const float* out_gate;
   double* stats;
   FastDiv fWd, fHd;
+  int cls;            // 1: parity-class mode (den == 2, even output dims): workgroup = one output parity class
+  FastDiv fWh, fHh;   // Wd / 2, Hd / 2
 };
 
 // pack native (Co, Ci, k^3) weights into wp[tap][cs][cdp]; transpose=0: cs=ci, cd=co (forward);
@@ -44,13 +46,40 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
   __shared__ double red[4][CO_T * 2];
   const int b = blockIdx.z, cot = blockIdx.y;
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd, Ns = (int64_t)a.Ds * a.Hs * a.Ws;
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool valid = v < Nd;
-  const uint32_t vv = valid ? (uint32_t)v : 0u;
-  uint32_t qw, rw_, qd, rh_;
-  a.fWd.divmod(vv, qw, rw_);
-  a.fHd.divmod(qw, qd, rh_);
-  const int w_ = (int)rw_, h_ = (int)rh_, d_ = (int)qd;
+  // den == 2 (transposed conv forward / strided conv data gradient): an output voxel only receives the taps whose
+  // source index (o + off + k*dt) is even.  In class mode a workgroup serves ONE output parity class, so the valid
+  // tap set is uniform and the other taps (19 of 27 on average, 26 of 27 for dilation 2 off-lattice classes) are
+  // skipped instead of being loaded and masked.
+  int64_t v;
+  bool valid;
+  int w_, h_, d_;
+  int kmd = (1 << a.k) - 1, kmh = kmd, kmw = kmd;  // valid-tap bit masks per dimension (uniform); 1x1x1 convs: tap 0 only
+  if (a.cls) {
+    const int cls = blockIdx.x & 7;
+    const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
+    const int64_t jv = (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x;
+    valid = jv < (Nd >> 3);
+    uint32_t qw, rw_, qd, rh_;
+    a.fWh.divmod(valid ? (uint32_t)jv : 0u, qw, rw_);
+    a.fHh.divmod(qw, qd, rh_);
+    w_ = 2 * (int)rw_ + pw; h_ = 2 * (int)rh_ + ph; d_ = 2 * (int)qd + pd;
+    v = ((int64_t)d_ * a.Hd + h_) * a.Wd + w_;
+    kmd = kmh = kmw = 0;
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      kmd |= (((pd + a.off + kk * a.dt) & 1) == 0) << kk;
+      kmh |= (((ph + a.off + kk * a.dt) & 1) == 0) << kk;
+      kmw |= (((pw + a.off + kk * a.dt) & 1) == 0) << kk;
+    }
+  } else {
+    v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    valid = v < Nd;
+    const uint32_t vv = valid ? (uint32_t)v : 0u;
+    uint32_t qw, rw_, qd, rh_;
+    a.fWd.divmod(vv, qw, rw_);
+    a.fHd.divmod(qw, qd, rh_);
+    w_ = (int)rw_; h_ = (int)rh_; d_ = (int)qd;
+  }
   float acc[CO_T];
 #pragma unroll
   for (int j = 0; j < CO_T; ++j) {
@@ -66,10 +95,23 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
   // stages the tile once in LDS (<= 27*12*16 floats) and reads it back with broadcast ds_read_b128.
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   if (SV == 4 && CSQ > 0) {
+    // eight weight elements per thread requested before the first LDS store (a rolled load -> store loop pays one
+    // memory latency per trip: 7 - 21 trips for a 3x3x3 tile)
     const int ntile = k * k * k * CSQ * 4 * CO_T;
-    for (int i = threadIdx.x; i < ntile; i += 256) {
-      const int co = i % CO_T, r = i / CO_T;  // r = tap*Cs + cs
-      wlds[i] = a.wp[(int64_t)r * a.Cdp + cot * CO_T + co];
+    for (int i0 = threadIdx.x; i0 < ntile; i0 += 256 * 8) {
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        const int ic = i < ntile ? i : 0;
+        const int co = ic % CO_T, r = ic / CO_T;  // r = tap*Cs + cs
+        wv[u] = a.wp[(int64_t)r * a.Cdp + cot * CO_T + co];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        if (i < ntile) wlds[i] = wv[u];
+      }
     }
     __syncthreads();
   }
@@ -83,6 +125,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
 #pragma unroll
     for (int e = 0; e < CSQ * 4; ++e) gv[e] = gate ? gate[e] : 1.f;
     for (int kd = 0; kd < k; ++kd) {
+      if (!((kmd >> kd) & 1)) continue;  // uniform: no tap of this plane reaches this parity class
       int nd = d_ * a.sn + a.off + kd * a.dt;
       bool okd = valid;
       if (a.den == 2) { okd = okd && !(nd & 1); nd >>= 1; }
@@ -94,6 +137,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
           const int kh = kh0 + r;
+          if (!((kmh >> kh) & 1)) continue;  // uniform
           int nh = h_ * a.sn + a.off + kh * a.dt;
           bool okh = okd && kh < k;
           if (a.den == 2) { okh = okh && !(nh & 1); nh >>= 1; }
@@ -101,6 +145,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
           const int ch_ = min(max(nh, 0), a.Hs - 1);
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
+            if (!((kmw >> kw) & 1)) continue;  // uniform
             int nw = w_ * a.sn + a.off + kw * a.dt;
             bool ok = okh && kw < k;
             if (a.den == 2) { ok = ok && !(nw & 1); nw >>= 1; }
@@ -115,10 +160,10 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
           const int kh = kh0 + r;
-          if (kh >= k) continue;
+          if (kh >= k || !((kmh >> kh) & 1)) continue;
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
-            if (kw >= k) continue;
+            if (kw >= k || !((kmw >> kw) & 1)) continue;
             const int tap = (kd * k + kh) * k + kw;
             const float* wr = wlds + tap * (CSQ * 4) * CO_T;
             const bool ok = okv[r][kw];
@@ -240,9 +285,10 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int j = 0; j < CO_T; ++j) {
+      // fp32 DPP tree over the 64 lanes of a wave (as the MFMA kernels do); waves and rows are added in fp64
       const float val = valid ? acc[j] : 0.f;
-      const double s = wave_sum_d((double)val), ss = wave_sum_d((double)val * (double)val);
-      if (lane == 0) { red[wave][j * 2] = s; red[wave][j * 2 + 1] = ss; }
+      const float s = wave_sum_f(val), ss = wave_sum_f(val * val);
+      if (lane == 0) { red[wave][j * 2] = (double)s; red[wave][j * 2 + 1] = (double)ss; }
     }
     __syncthreads();
     if (threadIdx.x < CO_T * 2) {
@@ -262,11 +308,18 @@ static int pick_cot(int Cd) {
   return 4;
 }
 
+// parity-class mode of the gather kernel: den == 2, 3x3x3, even output dims, small-Cs vector path
+static bool gather_class_mode(int den, int k, int Dd, int Hd, int Wd, int Cs, bool vec) {
+  return den == 2 && k == 3 && Dd % 2 == 0 && Hd % 2 == 0 && Wd % 2 == 0 && vec && (Cs == 4 || Cs == 8 || Cs == 12);
+}
+
 template <int CO_T>
-static void launch_gather_t(const GatherArgs& a, int B, hipStream_t s) {
+static void launch_gather_t(GatherArgs a, int B, hipStream_t s) {
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
-  dim3 grid((unsigned)cdiv(Nd, 256), (unsigned)(a.Cdp / CO_T), (unsigned)B);
   const bool vec = (a.Cs % 4 == 0) && (a.sld % 4 == 0) && aligned16(a.src);
+  a.cls = gather_class_mode(a.den, a.k, a.Dd, a.Hd, a.Wd, a.Cs, vec) ? 1 : 0;
+  a.fWh = FastDiv((uint32_t)(a.Wd / 2 > 0 ? a.Wd / 2 : 1)); a.fHh = FastDiv((uint32_t)(a.Hd / 2 > 0 ? a.Hd / 2 : 1));
+  dim3 grid((unsigned)(a.cls ? 8 * cdiv(Nd / 8, 256) : cdiv(Nd, 256)), (unsigned)(a.Cdp / CO_T), (unsigned)B);
   const size_t wbytes = (size_t)a.k * a.k * a.k * a.Cs * CO_T * sizeof(float);
   if (!vec) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 1, 0>), grid, dim3(256), 0, s, a);
   else if (a.Cs == 4) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4, 1>), grid, dim3(256), wbytes, s, a);
@@ -866,6 +919,9 @@ int n3d_conv_stats_rows(const n3d_conv_geom* g, int transposed, int flags) {
   if (r > 0) return r;
   if (r < 0) return 0;  // the kernel for this shape cannot emit statistics: use n3d_channel_stats
   const int64_t Nd = transposed ? (int64_t)g->Di * g->Hi * g->Wi : (int64_t)g->Do * g->Ho * g->Wo;
+  // transposed forward runs the gather kernel with den = stride; its parity-class mode has 8 row groups
+  // (activation tensors on this path are 16-byte aligned pitched views, which the class mode requires)
+  if (transposed && gather_class_mode(g->stride, g->k, g->Di, g->Hi, g->Wi, g->Co, true)) return (int)(8 * cdiv(Nd / 8, 256));
   return (int)cdiv(Nd, 256);
 }
 
@@ -910,6 +966,10 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
   const int total = taps * a.Cs * a.Cdp;
   if (!(flags & N3D_PREPACKED))
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g->Co, g->Ci, taps, a.Cdp, data_grad ? 1 : 0);
+  if (stats && gather_class_mode(a.den, a.k, a.Dd, a.Hd, a.Wd, a.Cs, true) && !((a.Cs % 4 == 0) && (a.sld % 4 == 0) && aligned16(a.src))) {
+    set_error("conv: statistics on this shape need a 16-byte aligned source (n3d_conv_stats_rows assumed the parity-class kernel)");
+    return N3D_ERR_UNSUPPORTED;
+  }
   launch_gather(a, g->B, s);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
