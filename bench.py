@@ -139,6 +139,36 @@ def cpu_baseline(batch, size, budget_s=25.0):
             "sample": "%d timed fwd+bwd iterations of the same net at batch %d, 4x%d^3 fp32 (median %.3f s)" % (len(times), batch, size, med)}
 
 
+def search_step_bench(args, device):
+    """BASELINE configs[2]: nas.py supernet search step (search.py:211-238): architecture pass on a validation batch
+    (Adam on the alphas) + weight pass on a training batch (Adam on the kernel weights), batch 2 each, one GPU."""
+    from nas_3d_unet_amd import nas
+    from nas_3d_unet_amd.train import SearchTrainer
+    torch.manual_seed(1234)
+    net = nas.ShellNet(CFG["in_channels"], CFG["init_n_kernels"], CFG["out_channels"], CFG["depth"], CFG["n_nodes"], False,
+                       CFG["channel_change"]).to(device)
+    net.train()
+    tr = SearchTrainer(net, graph=not args.no_graph)
+    xn, tn = synthetic_batch(args.batch, args.size, 1234)
+    vxn, vtn = synthetic_batch(args.batch, args.size, 4321)
+    x, t, vx, vt = (torch.from_numpy(a).to(device) for a in (xn, tn, vxn, vtn))
+    for _ in range(args.warmup):
+        tr.step(x, t, vx, vt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        la, lw = tr.step(x, t, vx, vt)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "supernet search steps/sec (arch pass + weight pass, each fwd + Dice + bwd + Adam)", "value": round(args.steps / dt, 3),
+        "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "patches_per_s": round(2 * args.batch * args.steps / dt, 2),
+        "config": {"workload": "nas.py ShellNet search step, train batch=%d + val batch=%d 4x%d^3 fp32" % (args.batch, args.batch, args.size),
+                   "hip_graph": not args.no_graph, "loss_arch": round(float(la), 5), "loss_weight": round(float(lw), 5)}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,6 +179,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--workload", choices=["train", "search"], default="train",
+                    help="train: searched-net train step (BASELINE configs[1], the contract default); "
+                         "search: supernet search step, arch pass + weight pass (configs[2]; informational, N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,6 +197,8 @@ def main():
     from nas_3d_unet_amd import _lib, searched
     from nas_3d_unet_amd.train import Trainer
     _lib.require_device()
+    if args.workload == "search":
+        return search_step_bench(args, device)
 
     torch.manual_seed(1234)  # same random-init weights on every rank (then broadcast anyway)
     net = searched.SearchedNet(CFG["in_channels"], CFG["init_n_kernels"], CFG["out_channels"], CFG["depth"],

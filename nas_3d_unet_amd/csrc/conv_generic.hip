@@ -533,7 +533,8 @@ struct DwWgradArgs {
   const float* x; int64_t xld; int Di, Hi, Wi;
   const float* dy; int64_t dyld; int Do, Ho, Wo;
   int B, C, k, stride, pad;
-  float* partial;  // [nchunks][27+1][C]
+  float* partial;  // [nchunks][27][C]  (the layout n3d_wgrad_finalize_batch reads with ci_t = 1, co_t = C)
+  float* pbias;    // [nchunks][C]
   int64_t chunk;   // flattened (b,o) voxels per block
   FastDiv fNo, fWo, fHo;
 };
@@ -562,25 +563,39 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
       const float4 g = *reinterpret_cast<const float4*>(a.dy + i * a.dyld + c4 * 4);
       acc[27][0] += g.x; acc[27][1] += g.y; acc[27][2] += g.z; acc[27][3] += g.w;
       const float* xb = a.x + (int64_t)b * Ni * a.xld + c4 * 4;
+      // one kd plane at a time: its nine loads are issued from clamped addresses before the first use (a branch per
+      // tap serialises on one memory latency per tap: 27 per voxel)
 #pragma unroll
       for (int kd = 0; kd < 3; ++kd) {
         const int id = od * a.stride - a.pad + kd;
+        const bool okd = id >= 0 && id < a.Di;
+        const int cd_ = min(max(id, 0), a.Di - 1);
+        float4 q[3][3];
+        bool ok[3][3];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
           const int ih = oh * a.stride - a.pad + kh;
+          const bool okh = okd && ih >= 0 && ih < a.Hi;
+          const int ch_ = min(max(ih, 0), a.Hi - 1);
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
             const int iw = ow * a.stride - a.pad + kw;
-            if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi) {
-              const float4 q = *reinterpret_cast<const float4*>(xb + (((int64_t)id * a.Hi + ih) * a.Wi + iw) * a.xld);
-              const int tap = (kd * 3 + kh) * 3 + kw;
-              acc[tap][0] = fmaf(q.x, g.x, acc[tap][0]);
-              acc[tap][1] = fmaf(q.y, g.y, acc[tap][1]);
-              acc[tap][2] = fmaf(q.z, g.z, acc[tap][2]);
-              acc[tap][3] = fmaf(q.w, g.w, acc[tap][3]);
-            }
+            ok[kh][kw] = okh && iw >= 0 && iw < a.Wi;
+            const int cw_ = min(max(iw, 0), a.Wi - 1);
+            q[kh][kw] = *reinterpret_cast<const float4*>(xb + (((int64_t)cd_ * a.Hi + ch_) * a.Wi + cw_) * a.xld);
           }
         }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int tap = (kd * 3 + kh) * 3 + kw;
+            const float m = ok[kh][kw] ? 1.f : 0.f;
+            acc[tap][0] = fmaf(q[kh][kw].x * m, g.x, acc[tap][0]);
+            acc[tap][1] = fmaf(q[kh][kw].y * m, g.y, acc[tap][1]);
+            acc[tap][2] = fmaf(q[kh][kw].z * m, g.z, acc[tap][2]);
+            acc[tap][3] = fmaf(q[kh][kw].w * m, g.w, acc[tap][3]);
+          }
       }
     }
   }
@@ -603,21 +618,10 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
     const int j = i % 4, q = (i / 4) % 28, cls = i / (4 * 28);
     float s = 0.f;
     for (int w = 0; w < 4; ++w) s += dyn[((w * cpb + cls) * 28 + q) * 4 + j];
-    a.partial[((int64_t)blockIdx.x * 28 + q) * a.C + cls * 4 + j] = s;
+    if (q < 27) a.partial[((int64_t)blockIdx.x * 27 + q) * a.C + cls * 4 + j] = s;
+    else a.pbias[(int64_t)blockIdx.x * a.C + cls * 4 + j] = s;
   }
 }
-
-__global__ __launch_bounds__(256) void dw_wgrad_final_kernel(const float* __restrict__ partial, int nchunks, int C, float* __restrict__ dw,
-                                                             float* __restrict__ dbias) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 28 * C) return;
-  const int c = i % C, q = i / C;
-  float s = 0.f;
-  for (int k = 0; k < nchunks; ++k) s += partial[((int64_t)k * 28 + q) * C + c];
-  if (q < 27) { if (dw) dw[c * 27 + q] = s; }
-  else if (dbias) dbias[c] = s;
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // per-channel sum over all (b, voxel): bias gradient of a transposed convolution
@@ -891,7 +895,7 @@ size_t n3d_conv_workspace_bytes(const n3d_conv_geom* g) {
   // weight-gradient partial slabs (dense) or depthwise partials
   const int64_t No = (int64_t)g->Do * g->Ho * g->Wo, Ni = (int64_t)g->Di * g->Hi * g->Wi;
   if (g->depthwise) {
-    bytes += align_up((size_t)512 * 28 * g->Ci * 4, 256);
+    bytes += align_up((size_t)1024 * 28 * g->Ci * 4, 256);
   } else {
     WgradPlan p1 = wgrad_plan(g->B, No, g->Ci, g->Co, taps);
     WgradPlan p2 = wgrad_plan(g->B, No, g->Co, g->Ci, taps);  // transposed roles
@@ -1029,14 +1033,20 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     a.B = g->B; a.C = g->Ci; a.k = 3; a.stride = g->stride; a.pad = g->pad; a.partial = wsf;
     a.fNo = FastDiv((uint32_t)No); a.fWo = FastDiv((uint32_t)g->Wo); a.fHo = FastDiv((uint32_t)g->Ho);
     const int64_t total = (int64_t)g->B * No;
-    int64_t nch = cdiv(total, 2048);
-    if (nch > 512) nch = 512;
+    // short chunks (the voxel loop is a dependent load -> FMA chain), bounded by the slab workspace
+    int64_t nch = cdiv(total, 512);
+    if (nch > 1024) nch = 1024;
     a.chunk = cdiv(total, nch);
     const int nchunks = (int)cdiv(total, a.chunk);
     if ((size_t)nchunks * 28 * a.C > avail) { set_error("dw wgrad: workspace too small"); return N3D_ERR_WORKSPACE; }
+    a.pbias = wsf + (size_t)nchunks * 27 * a.C;
     const int cpb = a.C / 4;
     hipLaunchKernelGGL(dw_wgrad_kernel, dim3(nchunks), dim3(256), (size_t)4 * cpb * 28 * 4 * sizeof(float), s, a);
-    hipLaunchKernelGGL(dw_wgrad_final_kernel, dim3((unsigned)cdiv(28 * a.C, 256)), dim3(256), 0, s, wsf, nchunks, a.C, dw, dbias);
+    // fixed-order slab reduction through the common finalize: one "tile" per tap, ci_t = 1, co_t = C, Ci = 1
+    n3d_final_job job;
+    fill_job(&job, a.partial, a.pbias, dw, dbias, nchunks, 27, 1, 1, 1, a.C, a.C, 1, 27);
+    if (deferred) *deferred = job;
+    else if (int e = n3d_wgrad_finalize_batch(&job, 1, stream)) return e;
     N3D_LAUNCH_CHECK();
     return N3D_OK;
   }

@@ -252,7 +252,7 @@ def conv_bwd_data(g, dy: View, w, dx: View, flags=0, relu_src: View | None = Non
 def conv_bwd_weight(g, x: View, dy: View, dw, dbias, flags=0, in_gate=None, transposed=False):
     ws, n = _ws(g, x.t.device)
     lib = _lib.load()
-    job = FinalJob() if (_ctx is not None and not g.depthwise) else None
+    job = FinalJob() if _ctx is not None else None
     jp = C.byref(job) if job is not None else None
     sp = _side_launch_ptr([x.t, dy.t, ws, in_gate]) if job is not None else stream_ptr()
     if transposed:
