@@ -539,6 +539,9 @@ struct DwWgradArgs {
   FastDiv fNo, fWo, fHo;
 };
 
+// POW2: C / 4 is a power of two (every depthwise op of the reference: C = 4 .. 64) -> DPP / permlane class sums, fully
+// unrolled so the 28 x 4 accumulators stay in registers (the generic strided sums made the compiler spill them)
+template <bool POW2>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
   extern __shared__ float dyn[];
   const int cpb = a.C / 4, vpb = 256 / cpb;
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
 #pragma unroll
   for (int q = 0; q < 28; ++q)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[q][j] = wave_sum_strided_f(acc[q][j], cpb);
+    for (int j = 0; j < 4; ++j) acc[q][j] = POW2 ? wave_classsum_f(acc[q][j], cpb) : wave_sum_strided_f(acc[q][j], cpb);
   if (lane < cpb) {
     const int cls = (wave * 64 + lane) % cpb;
 #pragma unroll
@@ -1041,7 +1044,8 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     if ((size_t)nchunks * 28 * a.C > avail) { set_error("dw wgrad: workspace too small"); return N3D_ERR_WORKSPACE; }
     a.pbias = wsf + (size_t)nchunks * 27 * a.C;
     const int cpb = a.C / 4;
-    hipLaunchKernelGGL(dw_wgrad_kernel, dim3(nchunks), dim3(256), (size_t)4 * cpb * 28 * 4 * sizeof(float), s, a);
+    if ((cpb & (cpb - 1)) == 0) hipLaunchKernelGGL(dw_wgrad_kernel<true>, dim3(nchunks), dim3(256), (size_t)4 * cpb * 28 * 4 * sizeof(float), s, a);
+    else hipLaunchKernelGGL(dw_wgrad_kernel<false>, dim3(nchunks), dim3(256), (size_t)4 * cpb * 28 * 4 * sizeof(float), s, a);
     // fixed-order slab reduction through the common finalize: one "tile" per tap, ci_t = 1, co_t = C, Ci = 1
     n3d_final_job job;
     fill_job(&job, a.partial, a.pbias, dw, dbias, nchunks, 27, 1, 1, 1, a.C, a.C, 1, 27);
