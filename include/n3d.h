@@ -258,6 +258,8 @@ int n3d_ndhwc_to_ncdhw(const float* src, int64_t sld, float* dst, int B, int C, 
  * step_ptr: device int32 holding the number of steps already taken; if inc_step != 0 a second tiny
  * launch increments it after the update (graph-replay safe).  grad_scale multiplies g (DP mean). */
 int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  const float* lr_ptr /* if not NULL the learning rate is read from this device float instead of
+                  `lr`: a captured graph then follows the ReduceLROnPlateau schedule (train.py:50,77) */,
                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t* step_ptr,
                   int inc_step, void* stream);
 

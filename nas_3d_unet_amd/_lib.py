@@ -107,7 +107,7 @@ PROTOTYPES = {
     "n3d_dice_bwd": (_i, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i, _i, _i64, _f, _p, _p, _p, _i64, _i64, _i64, _p]),
     "n3d_ncdhw_to_ndhwc": (_i, [_p, _p, _i64, _i, _i, _i64, _p]),
     "n3d_ndhwc_to_ncdhw": (_i, [_p, _i64, _p, _i, _i, _i64, _p]),
-    "n3d_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _i, _p]),
+    "n3d_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _f, _p, _i, _p]),
 }
 
 # flags (include/n3d.h)

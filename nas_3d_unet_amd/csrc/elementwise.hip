@@ -1383,9 +1383,10 @@ __global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const float* __rest
 // Adam (torch.optim.Adam, amsgrad=False, maximize=False)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                   int64_t n, float lr, float b1, float b2, float eps, float wd, float gscale,
-                                                   const int32_t* __restrict__ step_ptr) {
+                                                   int64_t n, float lr_imm, const float* __restrict__ lr_ptr, float b1, float b2, float eps,
+                                                   float wd, float gscale, const int32_t* __restrict__ step_ptr) {
   const int step = *step_ptr + 1;
+  const float lr = lr_ptr ? *lr_ptr : lr_imm;
   const double bc1 = 1.0 - pow((double)b1, (double)step);
   const double bc2 = 1.0 - pow((double)b2, (double)step);
   const float step_size = (float)((double)lr / bc1);
@@ -1729,14 +1730,14 @@ int n3d_ndhwc_to_ncdhw(const float* src, int64_t sld, float* dst, int B, int C, 
   return N3D_OK;
 }
 
-int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, float grad_scale, int32_t* step_ptr, int inc_step, void* stream) {
+int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, const float* lr_ptr, float beta1,
+                  float beta2, float eps, float weight_decay, float grad_scale, int32_t* step_ptr, int inc_step, void* stream) {
   N3D_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_ptr && n > 0, "adam_step: bad args");
   int64_t blocks = cdiv(n, 256 * 4);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                     beta2, eps, weight_decay, grad_scale, step_ptr);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, lr_ptr,
+                     beta1, beta2, eps, weight_decay, grad_scale, step_ptr);
   if (inc_step) hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_ptr);
   N3D_LAUNCH_CHECK();
   return N3D_OK;

@@ -556,9 +556,10 @@ def dice_bwd(p, t, smooth, sums, dloss, dp):
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
-              grad_scale=1.0, inc_step=True):
-    check(_lib.load().n3d_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, beta1, beta2,
-                                    eps, weight_decay, grad_scale, ptr(step_t), 1 if inc_step else 0, stream_ptr()),
+              grad_scale=1.0, inc_step=True, lr_dev=None):
+    """lr_dev: optional 1-element device tensor holding the learning rate (read by the kernel; survives graph replay)"""
+    check(_lib.load().n3d_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, ptr(lr_dev),
+                                    beta1, beta2, eps, weight_decay, grad_scale, ptr(step_t), 1 if inc_step else 0, stream_ptr()),
           "n3d_adam_step")
 
 

@@ -46,9 +46,47 @@ class FlatParams:
                 p._n3d_grad = g  # backward kernels write here (programs.py / kernels.grad_target)
                 p.grad = g
 
-    def adam(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    def adam(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, lr_dev=None):
         K.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step, lr, betas[0], betas[1], eps,
-                    weight_decay, grad_scale, True)
+                    weight_decay, grad_scale, True, lr_dev)
+
+
+class PlateauLR:
+    """Host logic of torch.optim.lr_scheduler.ReduceLROnPlateau as the reference uses it
+    (`ReduceLROnPlateau(optim, factor=0.5)`, train.py:50; search.py:105-106; stepped once per epoch with the validation
+    loss, train.py:77; search.py:155-156): mode 'min', relative threshold 1e-4, patience 10, cooldown 0, min_lr 0,
+    eps 1e-8.  `set_lr(new_lr)` is called when the rate changes; the trainers keep the rate in a device scalar that
+    the Adam kernel reads, so a captured HIP graph follows the schedule without re-capture."""
+
+    def __init__(self, get_lr, set_lr, factor=0.5, patience=10, threshold=1e-4, cooldown=0, min_lr=0.0, eps=1e-8):
+        if factor >= 1.0:
+            raise ValueError("Factor should be < 1.0.")
+        self.get_lr, self.set_lr = get_lr, set_lr
+        self.factor, self.patience, self.threshold, self.cooldown, self.min_lr, self.eps = factor, patience, threshold, cooldown, min_lr, eps
+        self.best = float("inf")
+        self.num_bad_epochs = 0
+        self.cooldown_counter = 0
+        self.last_epoch = 0
+
+    def step(self, metric):
+        current = float(metric)
+        self.last_epoch += 1
+        if current < self.best * (1.0 - self.threshold):
+            self.best = current
+            self.num_bad_epochs = 0
+        else:
+            self.num_bad_epochs += 1
+        if self.cooldown_counter > 0:
+            self.cooldown_counter -= 1
+            self.num_bad_epochs = 0
+        if self.num_bad_epochs > self.patience:
+            old = self.get_lr()
+            new = max(old * self.factor, self.min_lr)
+            if old - new > self.eps:
+                self.set_lr(new)
+            self.cooldown_counter = self.cooldown
+            self.num_bad_epochs = 0
+        return self.get_lr()
 
 
 class GradSync:
@@ -123,6 +161,8 @@ class Trainer:
         self._static_x = self._static_t = self._static_loss = None
         self._comm_stream = torch.cuda.Stream(device=self.device) if self.world > 1 else None
         self.ctx = K.StepContext(self.device)  # batched weight packing + deferred wgrad reductions
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)  # read by the Adam kernel
+        self.scheduler = PlateauLR(lambda: self.lr, self.set_lr)  # train.py:50: ReduceLROnPlateau(factor=0.5)
         self.sync = GradSync(self.fp.grad, self.pg, self.n_buckets, self._comm_stream)
         if self.world > 1:
             dist.broadcast(self.fp.flat, src=0, group=self.pg)
@@ -143,7 +183,12 @@ class Trainer:
         self.sync.all_reduce()
 
     def _update(self):
-        self.fp.adam(self.lr, self.betas, self.eps, 0.0, 1.0 / self.world)
+        self.fp.adam(self.lr, self.betas, self.eps, 0.0, 1.0 / self.world, self.lr_dev)
+
+    def set_lr(self, lr):
+        """new learning rate for the following steps (also inside an already captured graph)"""
+        self.lr = float(lr)
+        self.lr_dev.fill_(self.lr)
 
     # -- public ---------------------------------------------------------------------------------
     def step(self, x, t):
@@ -208,6 +253,20 @@ class SearchTrainer:
         self.ctx = K.StepContext(self.device)
         self.use_graph = graph
         self._graph = None
+        # two learning rates (search.py:103-106): alphas ("shell") and kernel weights, each on its own plateau schedule
+        self.lr_shell, self.lr_kernel = float(lr), float(lr)
+        self.lr_shell_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)
+        self.lr_kernel_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)
+        self.shell_scheduler = PlateauLR(lambda: self.lr_shell, self.set_shell_lr)
+        self.kernel_scheduler = PlateauLR(lambda: self.lr_kernel, self.set_kernel_lr)
+
+    def set_shell_lr(self, lr):
+        self.lr_shell = float(lr)
+        self.lr_shell_dev.fill_(self.lr_shell)
+
+    def set_kernel_lr(self, lr):
+        self.lr_kernel = float(lr)
+        self.lr_kernel_dev.fill_(self.lr_kernel)
 
     def _pass(self, x, t, arch):
         for p in self.kparams:
@@ -224,9 +283,10 @@ class SearchTrainer:
         if not self.ctx.frozen and not arch:
             self.ctx.freeze()
         if arch:
-            K.adam_step(self.aflat, self.agrad, self.a_m, self.a_v, self.a_step, self.lr, self.betas[0], self.betas[1], self.eps)
+            K.adam_step(self.aflat, self.agrad, self.a_m, self.a_v, self.a_step, self.lr_shell, self.betas[0], self.betas[1], self.eps,
+                        lr_dev=self.lr_shell_dev)
         else:
-            self.fp.adam(self.lr, self.betas, self.eps)
+            self.fp.adam(self.lr_kernel, self.betas, self.eps, lr_dev=self.lr_kernel_dev)
         return loss.detach()
 
     def _both(self, x, t, vx, vt):

@@ -29,3 +29,30 @@ def test_trainer_matches_reference_adam(golden, graph, key, kind, gname, depth, 
         # Adam moves every element by ~lr per step whatever the gradient's size, so an element whose gradient is
         # fp32 noise (e.g. a conv bias ahead of a GroupNorm) may legitimately end up to adam*lr away
         assert abs(float(q.detach().double().norm()) - ref) <= 5e-4 * ref + adam * 1e-3, n
+
+
+def test_lr_schedule_follows_through_graph_replay():
+    """ReduceLROnPlateau (train.py:50,77): a halved learning rate must take effect inside an already captured HIP graph
+    (the Adam kernel reads the rate from a device scalar).  Checked against the same trainer run eagerly."""
+    from nas_3d_unet_amd.train import Trainer
+    key, kind, gname, depth, size, batch, adam = [c for c in gc.net_cases() if c[6] and c[1] == "searched"][0]
+    xn, tn = gc.net_batch(key, batch, size)
+    x, t = dev(xn), dev(tn)
+    out = []
+    for graph in (False, True):
+        net, _ = build_net(kind, gname, depth)
+        tr = Trainer(net, graph=graph)
+        tr.step(x, t)
+        tr.step(x, t)
+        tr.set_lr(tr.lr * 0.5)
+        tr.step(x, t)
+        l = float(tr.step(x, t))
+        out.append((l, torch.cat([p.detach().flatten() for p in net.parameters()]).double().cpu()))
+    assert abs(out[0][0] - out[1][0]) < 2e-5
+    assert float((out[0][1] - out[1][1]).abs().max()) < 2e-5
+    # and the schedule really changed the trajectory
+    net, _ = build_net(kind, gname, depth)
+    tr = Trainer(net, graph=True)
+    for _ in range(4):
+        l_const = float(tr.step(x, t))
+    assert abs(l_const - out[1][0]) > 1e-6

@@ -131,3 +131,23 @@ def test_dropin_under_the_reference_network_files():
             sys.modules.pop(k, None)
             if v is not None:
                 sys.modules[k] = v
+
+
+def test_plateau_lr_matches_torch_scheduler():
+    """PlateauLR = host logic of ReduceLROnPlateau(optim, factor=0.5) (train.py:50,77; search.py:105-106,155-156)"""
+    import numpy as np
+    import torch
+    from nas_3d_unet_amd.train import PlateauLR
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        losses = np.abs(1.0 / (1 + 0.05 * np.arange(120)) + 0.02 * rng.standard_normal(120)) if trial % 2 else np.full(60, 0.5) + 1e-6 * rng.standard_normal(60)
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p])
+        ref = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5)
+        state = {"lr": 1e-3}
+        mine = PlateauLR(lambda: state["lr"], lambda v: state.__setitem__("lr", v))
+        for l in losses:
+            ref.step(float(l))
+            mine.step(float(l))
+            assert abs(opt.param_groups[0]["lr"] - state["lr"]) < 1e-15
+        assert state["lr"] < 1e-3  # the sequences are long enough to trigger at least one reduction
