@@ -186,8 +186,10 @@ typedef struct n3d_gn_fwd_term {
   const float* wptr;                      /* optional scalar weight (MixedOp alpha), NULL = 1 */
   float* a_out; float* b_out; float* mean_rstd_out; double* sumraw;  /* saved for backward, as n3d_affine_act_gn */
 } n3d_gn_fwd_term;
-int n3d_affine_act_gn2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int G, float eps, float* out, int64_t old_, int B,
-                       int64_t N, int C, int flags /* N3D_ACCUMULATE */, void* stream);
+int n3d_affine_act_gn2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int G, float eps, float* out, int64_t old_,
+                       float* out1 /* NULL: out = term0 + term1 (a node); else two independent outputs (the two preprocess
+                       ops of a cell, cell.py:47-50): term0 -> out, term1 -> out1 */, int64_t old1, int B, int64_t N, int C,
+                       int flags /* N3D_ACCUMULATE */, void* stream);
 
 typedef struct n3d_gn_bwd_term {
   const float* raw; int64_t rld; const float* a; const float* b;   /* forward operands / coefficients */
@@ -198,21 +200,22 @@ typedef struct n3d_gn_bwd_term {
   float* dgamma; float* dbeta; float* dalpha; float* dbias_conv;   /* parameter gradients (dalpha / dbias_conv may be NULL) */
   float* cA; float* cB; float* cC;        /* [B][C] draw = cA*g + cB + cC*raw: written by n3d_gn_bwd_coeffs2, read by n3d_affine_act_bwd_apply2 */
 } n3d_gn_bwd_term;
-int n3d_affine_act_bwd_reduce2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N,
-                               int C, void* stream);
-int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N,
-                                 int C, int G, void* stream);
+/* dout1: NULL = both terms share the output gradient dout (a node); else the gradient of term1's own output */
+int n3d_affine_act_bwd_reduce2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
+                               const n3d_gn_bwd_term* t1, int B, int64_t N, int C, void* stream);
+int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
+                                 const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* stream);
 /* the same pairing for tensors with more partial rows than the fused prologues accept (the 32^3 / 64^3 levels):
  * n3d_gn_coeffs2 = two n3d_gn_coeffs in one launch (fills a_out, b_out, mean_rstd_out, sumraw of both terms);
  * n3d_affine_act2 = two n3d_affine_act into one output (reads a_out / b_out as the coefficients; stats unused);
  * n3d_gn_bwd_coeffs2 = two n3d_gn_bwd_coeffs (fills cA / cB / cC and the parameter gradients);
  * n3d_affine_act_bwd_apply2 = two n3d_affine_act_bwd_apply reading the node gradient once. */
 int n3d_gn_coeffs2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int B, int C, int G, int64_t N, float eps, void* stream);
-int n3d_affine_act2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, float* out, int64_t old_, int B, int64_t N, int C, int flags,
-                    void* stream);
+int n3d_affine_act2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, float* out, int64_t old_, float* out1, int64_t old1, int B,
+                    int64_t N, int C, int flags, void* stream);
 int n3d_gn_bwd_coeffs2(const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int C, int G, int64_t N, void* stream);
-int n3d_affine_act_bwd_apply2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N, int C,
-                              void* stream);
+int n3d_affine_act_bwd_apply2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
+                              const n3d_gn_bwd_term* t1, int B, int64_t N, int C, void* stream);
 /* plain (no norm) epilogue backward coefficients: A = w, Bc = Cc = 0, dalpha = sum Sz */
 int n3d_plain_bwd_coeffs(const double* sums, int rows, const float* wptr, int B, int C, float* dalpha,
                          float* A, void* stream);

@@ -844,7 +844,7 @@ __device__ __forceinline__ void gn_fwd_prologue_wave(const GnFwdTerm& t, const i
 // PRE: the GroupNorm coefficients were computed by n3d_gn_coeffs2 (large tensors): a_out / b_out are inputs, no prologue
 template <bool ACC, bool PRE>
 __global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwdTerm t1, int G, double count, float eps, float* __restrict__ out,
-                                                             int64_t old_, int64_t N, int C, EwMap m) {
+                                                             int64_t old_, float* __restrict__ out1, int64_t old1, int64_t N, int C, EwMap m) {
   __shared__ __attribute__((aligned(16))) float abw[4][2][2][64];  // [wave][term][a|b][channel]
   const int b = blockIdx.y, t = threadIdx.x, wave = t >> 6;
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
@@ -893,6 +893,15 @@ __global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwd
     z.x = w0 * fmaxf(fmaf(a0.x, x0.x, b0.x), f0); z.y = w0 * fmaxf(fmaf(a0.y, x0.y, b0.y), f0);
     z.z = w0 * fmaxf(fmaf(a0.z, x0.z, b0.z), f0); z.w = w0 * fmaxf(fmaf(a0.w, x0.w, b0.w), f0);
     if (ACC) { z.x += o.x; z.y += o.y; z.z += o.z; z.w += o.w; }
+    if (out1) {
+      // two independent outputs (the two preprocess ops of a cell): term 1 goes to its own tensor
+      *reinterpret_cast<float4*>(ob + v * old_) = z;
+      float4 y;
+      y.x = w1 * fmaxf(fmaf(a1.x, x1.x, b1.x), f1); y.y = w1 * fmaxf(fmaf(a1.y, x1.y, b1.y), f1);
+      y.z = w1 * fmaxf(fmaf(a1.z, x1.z, b1.z), f1); y.w = w1 * fmaxf(fmaf(a1.w, x1.w, b1.w), f1);
+      *reinterpret_cast<float4*>(out1 + (int64_t)b * N * old1 + c4 * 4 + v * old1) = y;
+      return;
+    }
     z.x = fmaf(w1, fmaxf(fmaf(a1.x, x1.x, b1.x), f1), z.x); z.y = fmaf(w1, fmaxf(fmaf(a1.y, x1.y, b1.y), f1), z.y);
     z.z = fmaf(w1, fmaxf(fmaf(a1.z, x1.z, b1.z), f1), z.z); z.w = fmaf(w1, fmaxf(fmaf(a1.w, x1.w, b1.w), f1), z.w);
     *reinterpret_cast<float4*>(ob + v * old_) = z;
@@ -914,8 +923,10 @@ __global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwd
 // backward pass 1 for two ops that share the node gradient dout: sums0 / sums1 rows as affine_bwd_reduce_kernel
 struct BwdRedTerm { const float* raw; int64_t rld; const float* a; const float* b; double* sums; int relu; };
 
-__global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const float* __restrict__ dout, int64_t dld, BwdRedTerm t0, BwdRedTerm t1, int64_t N,
-                                                                 int C, EwMap m) {
+// TWO: the second op has its own output gradient (independent outputs); otherwise both share dout (a node)
+template <bool TWO>
+__global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const float* __restrict__ dout, int64_t dld, const float* __restrict__ dout1,
+                                                                 int64_t dld1, BwdRedTerm t0, BwdRedTerm t1, int64_t N, int C, EwMap m) {
   __shared__ double lds[4 * 64 * 12];
   const int b = blockIdx.y;
   const int t = threadIdx.x;
@@ -932,11 +943,12 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const float* __
     av[1] = *reinterpret_cast<const float4*>(t1.a + b * C + c4 * 4); bv[1] = *reinterpret_cast<const float4*>(t1.b + b * C + c4 * 4);
     const float thr[2] = {t0.relu ? 0.f : -INFINITY, t1.relu ? 0.f : -INFINITY};
     const float* db = dout + (int64_t)b * N * dld + c4 * 4;
+    const float* db1 = TWO ? dout1 + (int64_t)b * N * dld1 + c4 * 4 : nullptr;
     const float* rb0 = t0.raw + (int64_t)b * N * t0.rld + c4 * 4;
     const float* rb1 = t1.raw + (int64_t)b * N * t1.rld + c4 * 4;
     const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
     for (int it0 = 0; it0 < m.iters; it0 += 4) {
-      float4 dq[4], rq[2][4];
+      float4 dq[4], dq1[TWO ? 4 : 1], rq[2][4];
       bool ok[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -944,15 +956,17 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const float* __
         ok[u] = (it0 + u < m.iters) && v < N;
         const int64_t vc = ok[u] ? v : 0;
         dq[u] = *reinterpret_cast<const float4*>(db + vc * dld);
+        if (TWO) dq1[TWO ? u : 0] = *reinterpret_cast<const float4*>(db1 + vc * dld1);
         rq[0][u] = *reinterpret_cast<const float4*>(rb0 + vc * t0.rld);
         rq[1][u] = *reinterpret_cast<const float4*>(rb1 + vc * t1.rld);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (!ok[u]) continue;
-        const float d[4] = {dq[u].x, dq[u].y, dq[u].z, dq[u].w};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+          const float4 dk = (TWO && k) ? dq1[TWO ? u : 0] : dq[u];
+          const float d[4] = {dk.x, dk.y, dk.z, dk.w};
           const float r[4] = {rq[k][u].x, rq[k][u].y, rq[k][u].z, rq[k][u].w};
           const float a4[4] = {av[k].x, av[k].y, av[k].z, av[k].w}, b4[4] = {bv[k].x, bv[k].y, bv[k].z, bv[k].w};
 #pragma unroll
@@ -1042,14 +1056,16 @@ __device__ __forceinline__ void gn_bwd_prologue_wave(const GnBwdTerm& t, const i
   }
 }
 
-template <bool PRE>
-__global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* __restrict__ dout, int64_t dld, GnBwdTerm t0, GnBwdTerm t1, int B, int G,
-                                                                   double count, int64_t N, int C, EwMap m) {
+template <bool PRE, bool TWO>
+__global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* __restrict__ dout, int64_t dld, const float* __restrict__ dout1,
+                                                                   int64_t dld1, GnBwdTerm t0, GnBwdTerm t1, int B, int G, double count, int64_t N,
+                                                                   int C, EwMap m) {
   __shared__ __attribute__((aligned(16))) float cw[4][2][3][64];  // [wave][term][A|B|C][channel]
   const int t = threadIdx.x, wave = t >> 6;
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   const int by = blockIdx.y;
   const float* dbp = dout + (int64_t)by * N * dld + c4 * 4;
+  const float* dbp1 = TWO ? dout1 + (int64_t)by * N * dld1 + c4 * 4 : nullptr;  // TWO: second op has its own output gradient
   const float* rb0 = t0.raw + (int64_t)by * N * t0.rld + c4 * 4;
   const float* rb1 = t1.raw + (int64_t)by * N * t1.rld + c4 * 4;
   float* o0 = t0.draw + (int64_t)by * N * t0.drld + c4 * 4;
@@ -1057,11 +1073,12 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
   const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
   const bool act0 = vl < m.vpb && v0 < N;
   constexpr int PF = 4;
-  float4 dq[PF], r0[PF], r1[PF];
+  float4 dq[PF], dq1[TWO ? PF : 1], r0[PF], r1[PF];
   float4 fa[2], fb[2];
   fa[0] = fa[1] = make_float4(1.f, 1.f, 1.f, 1.f); fb[0] = fb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (act0) {
     dq[0] = *reinterpret_cast<const float4*>(dbp + v0 * dld);
+    if (TWO) dq1[0] = *reinterpret_cast<const float4*>(dbp1 + v0 * dld1);
     r0[0] = *reinterpret_cast<const float4*>(rb0 + v0 * t0.rld);
     r1[0] = *reinterpret_cast<const float4*>(rb1 + v0 * t1.rld);
     const int co = by * C + c4 * 4;
@@ -1095,6 +1112,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
     const int64_t v = v0 + (int64_t)i * m.vpb;
     const int64_t vc = (i < m.iters && v < N) ? v : v0;
     dq[i] = *reinterpret_cast<const float4*>(dbp + vc * dld);
+    if (TWO) dq1[TWO ? i : 0] = *reinterpret_cast<const float4*>(dbp1 + vc * dld1);
     r0[i] = *reinterpret_cast<const float4*>(rb0 + vc * t0.rld);
     r1[i] = *reinterpret_cast<const float4*>(rb1 + vc * t1.rld);
   }
@@ -1114,14 +1132,15 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
 #pragma unroll
   for (int i = 0; i < PF; ++i) {
     const int64_t v = v0 + (int64_t)i * m.vpb;
-    if (i < m.iters && v < N) { one(0, dq[i], r0[i], o0 + v * t0.drld); one(1, dq[i], r1[i], o1 + v * t1.drld); }
+    if (i < m.iters && v < N) { one(0, dq[i], r0[i], o0 + v * t0.drld); one(1, TWO ? dq1[TWO ? i : 0] : dq[i], r1[i], o1 + v * t1.drld); }
   }
   for (int it = PF; it < m.iters; ++it) {
     const int64_t v = v0 + (int64_t)it * m.vpb;
     if (v >= N) break;
     const float4 d4 = *reinterpret_cast<const float4*>(dbp + v * dld);
+    const float4 e4 = TWO ? *reinterpret_cast<const float4*>(dbp1 + v * dld1) : d4;
     one(0, d4, *reinterpret_cast<const float4*>(rb0 + v * t0.rld), o0 + v * t0.drld);
-    one(1, d4, *reinterpret_cast<const float4*>(rb1 + v * t1.rld), o1 + v * t1.drld);
+    one(1, e4, *reinterpret_cast<const float4*>(rb1 + v * t1.rld), o1 + v * t1.drld);
   }
 }
 
@@ -1485,8 +1504,8 @@ int n3d_gn_bwd_coeffs(const double* sums, int rows, const float* gamma, const fl
 
 static bool pair_shape_ok(int C, int G) { return C >= 4 && C <= 64 && (C & (C - 1)) == 0 && G >= 1 && C % G == 0 && C / G <= 16; }
 
-int n3d_affine_act_gn2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int G, float eps, float* out, int64_t old_, int B,
-                       int64_t N, int C, int flags, void* stream) {
+int n3d_affine_act_gn2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int G, float eps, float* out, int64_t old_, float* out1,
+                       int64_t old1, int B, int64_t N, int C, int flags, void* stream) {
   N3D_CHECK_ARG(t0 && t1 && out && B > 0 && N > 0, "affine_act_gn2: bad args");
   if (!pair_shape_ok(C, G) || t0->rows < 1 || t1->rows < 1 || t0->rows > n3d_fused_max_rows() || t1->rows > n3d_fused_max_rows())
     N3D_UNSUPPORTED("affine_act_gn2: shape not supported by the pair kernel (C=%d G=%d rows=%d/%d)", C, G, t0->rows, t1->rows);
@@ -1499,17 +1518,18 @@ int n3d_affine_act_gn2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int
     k[i] = GnFwdTerm{t->raw, t->rld, t->stats, t->rows, t->gamma, t->beta, t->wptr, t->a_out, t->b_out, t->mean_rstd_out, t->sumraw, t->relu};
   }
   if (int e = check_vec(out, old_, C, "affine_act_gn2(out)")) return e;
+  if (out1) { if (int e = check_vec(out1, old1, C, "affine_act_gn2(out1)")) return e; }
   EwMap m = ew_map(N, C);
   dim3 grid(m.rows, B), blk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true, false>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, out, old_, N, C, m);
-  else hipLaunchKernelGGL((affine_act_gn2_kernel<false, false>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, out, old_, N, C, m);
+  if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true, false>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, out, old_, out1, old1, N, C, m);
+  else hipLaunchKernelGGL((affine_act_gn2_kernel<false, false>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, out, old_, out1, old1, N, C, m);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
 
-int n3d_affine_act_bwd_reduce2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N,
-                               int C, void* stream) {
+int n3d_affine_act_bwd_reduce2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
+                               const n3d_gn_bwd_term* t1, int B, int64_t N, int C, void* stream) {
   N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0 && C <= 64, "affine_act_bwd_reduce2: bad args");
   if (int e = check_vec(dout, dld, C, "bwd_reduce2(dout)")) return e;
   EwMap m = ew_map(N, C);
@@ -1522,13 +1542,15 @@ int n3d_affine_act_bwd_reduce2(const float* dout, int64_t dld, const n3d_gn_bwd_
     if (int e = check_vec(t->raw, t->rld, C, "bwd_reduce2(raw)")) return e;
     k[i] = BwdRedTerm{t->raw, t->rld, t->a, t->b, t->sums, t->relu};
   }
-  hipLaunchKernelGGL(affine_bwd_reduce2_kernel, dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, k[0], k[1], N, C, m);
+  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_reduce2(dout1)")) return e; }
+  if (dout1) hipLaunchKernelGGL(affine_bwd_reduce2_kernel<true>, dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], N, C, m);
+  else hipLaunchKernelGGL(affine_bwd_reduce2_kernel<false>, dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], N, C, m);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
 
-int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N,
-                                 int C, int G, void* stream) {
+int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
+                                 const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* stream) {
   N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0, "affine_act_bwd_apply_gn2: bad args");
   if (!pair_shape_ok(C, G) || t0->rows < 1 || t1->rows < 1 || t0->rows > n3d_fused_max_rows() || t1->rows > n3d_fused_max_rows())
     N3D_UNSUPPORTED("affine_act_bwd_apply_gn2: shape not supported by the pair kernel (C=%d G=%d rows=%d/%d)", C, G, t0->rows, t1->rows);
@@ -1545,7 +1567,9 @@ int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const n3d_gn_bw
                      t->dgamma, t->dbeta, t->dalpha, t->dbias_conv, t->relu, nullptr, nullptr, nullptr};
   }
   EwMap m = ew_map(N, C);
-  hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, k[0], k[1], B, G, (double)N, N, C, m);
+  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_apply_gn2(dout1)")) return e; }
+  if (dout1) hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, true>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
+  else hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, false>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -1564,8 +1588,8 @@ int n3d_gn_coeffs2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int B, 
   return N3D_OK;
 }
 
-int n3d_affine_act2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, float* out, int64_t old_, int B, int64_t N, int C, int flags,
-                    void* stream) {
+int n3d_affine_act2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, float* out, int64_t old_, float* out1, int64_t old1, int B,
+                    int64_t N, int C, int flags, void* stream) {
   N3D_CHECK_ARG(t0 && t1 && out && B > 0 && N > 0 && C <= 64, "affine_act2: bad args");
   GnFwdTerm k[2];
   const n3d_gn_fwd_term* ts[2] = {t0, t1};
@@ -1576,11 +1600,12 @@ int n3d_affine_act2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, float*
     k[i] = GnFwdTerm{t->raw, t->rld, nullptr, 0, nullptr, nullptr, t->wptr, t->a_out, t->b_out, nullptr, nullptr, t->relu};
   }
   if (int e = check_vec(out, old_, C, "affine_act2(out)")) return e;
+  if (out1) { if (int e = check_vec(out1, old1, C, "affine_act2(out1)")) return e; }
   EwMap m = ew_map(N, C);
   dim3 grid(m.rows, B), blk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true, true>), grid, blk, 0, s, k[0], k[1], 1, (double)N, 0.f, out, old_, N, C, m);
-  else hipLaunchKernelGGL((affine_act_gn2_kernel<false, true>), grid, blk, 0, s, k[0], k[1], 1, (double)N, 0.f, out, old_, N, C, m);
+  if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true, true>), grid, blk, 0, s, k[0], k[1], 1, (double)N, 0.f, out, old_, out1, old1, N, C, m);
+  else hipLaunchKernelGGL((affine_act_gn2_kernel<false, true>), grid, blk, 0, s, k[0], k[1], 1, (double)N, 0.f, out, old_, out1, old1, N, C, m);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -1601,8 +1626,8 @@ int n3d_gn_bwd_coeffs2(const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int
   return N3D_OK;
 }
 
-int n3d_affine_act_bwd_apply2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N, int C,
-                              void* stream) {
+int n3d_affine_act_bwd_apply2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
+                              const n3d_gn_bwd_term* t1, int B, int64_t N, int C, void* stream) {
   N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0 && C <= 64, "affine_act_bwd_apply2: bad args");
   if (int e = check_vec(dout, dld, C, "bwd_apply2(dout)")) return e;
   GnBwdTerm k[2];
@@ -1616,7 +1641,9 @@ int n3d_affine_act_bwd_apply2(const float* dout, int64_t dld, const n3d_gn_bwd_t
                      nullptr, t->relu, t->cA, t->cB, t->cC};
   }
   EwMap m = ew_map(N, C);
-  hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<true>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, k[0], k[1], B, 1, (double)N, N, C, m);
+  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_apply2(dout1)")) return e; }
+  if (dout1) hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<true, true>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], B, 1, (double)N, N, C, m);
+  else hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<true, false>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], B, 1, (double)N, N, C, m);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

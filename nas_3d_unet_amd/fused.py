@@ -72,8 +72,15 @@ def _run_forward(plan, x0, x1, alpha1, alpha2):
     """Returns (cell output tensor, saved state)."""
     st = P.Saved()
     x0v, x1v = K.as_view(x0, "x0"), K.as_view(x1, "x1")
-    p0, st.s_pre0 = P.seg_forward(plan.pre0, x0v)
-    p1, st.s_pre1 = P.seg_forward(plan.pre1, x1v)
+    # the two preprocess ops (cell.py:47-50) are independent and of one output shape: paired epilogue launch
+    shp = plan.pre1.weight.out_shape(x1v)
+    p0 = K.as_view(K.empty_ndhwc(*shp, x1v.t.device))
+    p1 = K.as_view(K.empty_ndhwc(*shp, x1v.t.device))
+    if tuple(plan.pre0.weight.out_shape(x0v)) == tuple(shp) and plan.pre0.dropout is None and plan.pre1.dropout is None:
+        st.s_pre0, st.s_pre1 = P.pair_forward(plan.pre0, x0v, plan.pre1, x1v, p0, p1)
+    else:
+        p0, st.s_pre0 = P.seg_forward(plan.pre0, x0v)
+        p1, st.s_pre1 = P.seg_forward(plan.pre1, x1v)
     xs = [p0, p1]
     cn, nn = plan.c_node, plan.n_nodes
     out = None
@@ -174,14 +181,14 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha)
             dal = d[row] if d is not None else None
         _, gl = P.seg_backward(seg, s, dnodes[node], True, target, acc, arow, col, dal)
         put(seg, gl)
-    dx = [None, None]
-    for i, (seg, s, need) in enumerate(((plan.pre0, st.s_pre0, need_x0), (plan.pre1, st.s_pre1, need_x1))):
+    for i in range(2):
         if not pre_started[i]:
             dpre[i].t.zero_()
-        d, gl = P.seg_backward(seg, s, dpre[i], need)
-        put(seg, gl)
-        dx[i] = d
-    return dx[0], dx[1], da1, da2, grads
+    (d0, g0), (d1, g1) = P.pair_backward(plan.pre0, st.s_pre0, plan.pre1, st.s_pre1, dpre[0], (need_x0, None, False), (need_x1, None, False),
+                                         dpre[1])
+    put(plan.pre0, g0)
+    put(plan.pre1, g1)
+    return d0, d1, da1, da2, grads
 
 
 class SearchedCellFn(torch.autograd.Function):

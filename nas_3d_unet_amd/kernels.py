@@ -373,7 +373,7 @@ def pair_shape_ok(Cc):
     return 4 <= Cc <= 64 and (Cc & (Cc - 1)) == 0
 
 
-def affine_act_gn2(terms, G, eps, out: View, flags=0):
+def affine_act_gn2(terms, G, eps, out: View, flags=0, out1: View | None = None):
     """Two GroupNorm -> [ReLU] -> weighted-sum epilogues into one output: terms = [(raw, stats, rows, gamma, beta, wptr, relu)] * 2.
     Returns [(a, b, mean_rstd, sumraw)] * 2 (saved for backward)."""
     raw0 = terms[0][0]
@@ -392,17 +392,19 @@ def affine_act_gn2(terms, G, eps, out: View, flags=0):
                             _vp(wptr), a.data_ptr(), b.data_ptr(), mr.data_ptr(), sr.data_ptr()))
         saved.append((a, b, mr, sr))
     lib = _lib.load()
+    o1p, o1ld = (out1.p, out1.ld) if out1 is not None else (None, 0)
     if pair_ok(Cc, G, terms[0][2], terms[1][2], B):
-        check(lib.n3d_affine_act_gn2(C.byref(ts[0]), C.byref(ts[1]), G, eps, out.p, out.ld, B, raw0.N, Cc, flags, stream_ptr()),
-              "n3d_affine_act_gn2")
+        check(lib.n3d_affine_act_gn2(C.byref(ts[0]), C.byref(ts[1]), G, eps, out.p, out.ld, o1p, o1ld, B, raw0.N, Cc, flags,
+                                     stream_ptr()), "n3d_affine_act_gn2")
     else:
         # large tensors: coefficients of both ops in one launch, then the two-term epilogue
         check(lib.n3d_gn_coeffs2(C.byref(ts[0]), C.byref(ts[1]), B, Cc, G, raw0.N, eps, stream_ptr()), "n3d_gn_coeffs2")
-        check(lib.n3d_affine_act2(C.byref(ts[0]), C.byref(ts[1]), out.p, out.ld, B, raw0.N, Cc, flags, stream_ptr()), "n3d_affine_act2")
+        check(lib.n3d_affine_act2(C.byref(ts[0]), C.byref(ts[1]), out.p, out.ld, o1p, o1ld, B, raw0.N, Cc, flags, stream_ptr()),
+              "n3d_affine_act2")
     return saved
 
 
-def affine_act_bwd_gn2(dout: View, terms, G):
+def affine_act_bwd_gn2(dout: View, terms, G, dout1: View | None = None):
     """Backward of affine_act_gn2: terms = [dict(raw, a, b, mr, sumraw, gamma, beta, wptr, relu, conv_bias, draw, dalpha_ptr)] * 2.
     Two launches (reduce, apply) for both ops.  Returns [(dgamma, dbeta, dconv_bias | None)] * 2."""
     raw0 = terms[0]["raw"]
@@ -424,14 +426,15 @@ def affine_act_bwd_gn2(dout: View, terms, G):
                             *([None] * 3 if fused else [coef[i, j].data_ptr() for j in range(3)])))
         outs.append((dgamma, dbeta, dcb))
     lib = _lib.load()
-    check(lib.n3d_affine_act_bwd_reduce2(dout.p, dout.ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, stream_ptr()),
+    d1p, d1ld = (dout1.p, dout1.ld) if dout1 is not None else (None, 0)
+    check(lib.n3d_affine_act_bwd_reduce2(dout.p, dout.ld, d1p, d1ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, stream_ptr()),
           "n3d_affine_act_bwd_reduce2")
     if fused:
-        check(lib.n3d_affine_act_bwd_apply_gn2(dout.p, dout.ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, G, stream_ptr()),
+        check(lib.n3d_affine_act_bwd_apply_gn2(dout.p, dout.ld, d1p, d1ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, G, stream_ptr()),
               "n3d_affine_act_bwd_apply_gn2")
     else:
         check(lib.n3d_gn_bwd_coeffs2(C.byref(ts[0]), C.byref(ts[1]), B, Cc, G, N, stream_ptr()), "n3d_gn_bwd_coeffs2")
-        check(lib.n3d_affine_act_bwd_apply2(dout.p, dout.ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, stream_ptr()),
+        check(lib.n3d_affine_act_bwd_apply2(dout.p, dout.ld, d1p, d1ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, stream_ptr()),
               "n3d_affine_act_bwd_apply2")
     return outs
 

@@ -428,8 +428,9 @@ def _pairable_fwd(seg):
     return (seg.norm is not None and seg.weight.produces_stats and seg.se_gate is None)
 
 
-def pair_forward(segA, xA, segB, xB, out):
+def pair_forward(segA, xA, segB, xB, out, outB=None):
     """Node of a searched cell: out = segA(xA) + segB(xB) (searched.py:45-50), `out` a View that is overwritten.
+    With `outB` the two ops are independent (the two preprocess ops of a cell, cell.py:47-50): segA -> out, segB -> outB.
     Both weight ops run first; if both epilogues are small GroupNorm epilogues of one shape they share ONE launch
     (n3d_affine_act_gn2), otherwise the two ordinary epilogues run one after the other.  Returns (savedA, savedB)."""
     res = []
@@ -445,7 +446,7 @@ def pair_forward(segA, xA, segB, xB, out):
             and segA.norm.eps == segB.norm.eps and K.pair_shape_ok(rawA.C)):
         terms = [(rawA, stA, rowsA, segA.norm.weight, segA.norm.bias, None, segA.relu_out),
                  (rawB, stB, rowsB, segB.norm.weight, segB.norm.bias, None, segB.relu_out)]
-        sv = K.affine_act_gn2(terms, G, segA.norm.eps, out, 0)
+        sv = K.affine_act_gn2(terms, G, segA.norm.eps, out, 0, outB)
         saved = []
         for (raw, _, _, ws), (a, b, mr, sr) in zip(res, sv):
             s = Saved()
@@ -454,19 +455,22 @@ def pair_forward(segA, xA, segB, xB, out):
             saved.append(s)
         return saved[0], saved[1]
     _, sA = _seg_epilogue_forward(segA, rawA, stA, rowsA, wsA, out, False, None, 0)
-    _, sB = _seg_epilogue_forward(segB, rawB, stB, rowsB, wsB, out, True, None, 0)
+    if outB is not None:
+        _, sB = _seg_epilogue_forward(segB, rawB, stB, rowsB, wsB, outB, False, None, 0)
+    else:
+        _, sB = _seg_epilogue_forward(segB, rawB, stB, rowsB, wsB, out, True, None, 0)
     return sA, sB
 
 
-def pair_backward(segA, sA, segB, sB, dout, argsA, argsB):
+def pair_backward(segA, sA, segB, sB, dout, argsA, argsB, doutB=None):
     """Backward of pair_forward.  argsX = (need_dx, dx_out, dx_acc).  Returns ((dxA, gradsA), (dxB, gradsB)) with
-    grads ordered like segX.params()."""
+    grads ordered like segX.params().  doutB: gradient of segB's own output (independent-outputs mode)."""
     pair = (sA.kind == "gn" and sB.kind == "gn" and not isinstance(segA.weight, IdentityW) and not isinstance(segB.weight, IdentityW)
             and sA.raw.C == sB.raw.C and sA.raw.N == sB.raw.N)
     if pair:
         pair = K.pair_shape_ok(sA.raw.C)
     if not pair:
-        rb = seg_backward(segB, sB, dout, *argsB)
+        rb = seg_backward(segB, sB, doutB if doutB is not None else dout, *argsB)
         ra = seg_backward(segA, sA, dout, *argsA)
         return ra, rb
     terms = []
@@ -478,7 +482,7 @@ def pair_backward(segA, sA, segB, sB, dout, argsA, argsB):
         terms.append(dict(raw=raw, a=s.a, b=s.b, mr=s.mr, sumraw=s.sumraw, gamma=seg.norm.weight, beta=seg.norm.bias, wptr=None,
                           relu=seg.relu_out, conv_bias=cbias,
                           draw=K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))))
-    outs = K.affine_act_bwd_gn2(dout, terms, sA.G)
+    outs = K.affine_act_bwd_gn2(dout, terms, sA.G, doutB)
     results = []
     # weight-op backward in reverse forward order (B then A), as the unpaired path does
     for seg, s, t, (dgamma, dbeta, dcb), args in ((segB, sB, terms[1], outs[1], argsB), (segA, sA, terms[0], outs[0], argsA)):
