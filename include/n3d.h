@@ -123,6 +123,26 @@ int n3d_conv_bwd_both(const n3d_conv_geom* g, const float* x, int64_t xld, const
 int n3d_convT_bwd_both(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, const float* w, float* dx,
                        int64_t dxld, int flags_data, void* ws_data, size_t ws_data_bytes, float* dw, int flags_weight, void* ws_weight,
                        size_t ws_weight_bytes, n3d_final_job* deferred, void* stream);
+
+/* ---- two independent convolutions in one launch: the two ops of a searched-cell node (searched.py:45-50) or a cell's
+ * two preprocess convs (cell.py:47-50).  Exactly the two single calls described by the structures (same arguments,
+ * same results, same fallbacks); ONE launch when both are small MFMA problems of the same K-split plan (channel
+ * counts multiples of 16 on the 2^3..16^3 levels), where each alone leaves most of the chip idle. */
+typedef struct n3d_conv_fwd_call {     /* arguments of n3d_conv_fwd / n3d_convT_fwd */
+  const n3d_conv_geom* g; int32_t transposed; int32_t flags;
+  const float* x; int64_t xld; const float* w; const float* bias; float* y; int64_t yld;
+  const float* in_gate; double* stats; void* ws; size_t ws_bytes;
+} n3d_conv_fwd_call;
+int n3d_conv_fwd2(const n3d_conv_fwd_call* c0, const n3d_conv_fwd_call* c1, void* stream);
+
+typedef struct n3d_conv_bwd_call {     /* arguments of n3d_conv_bwd_both / n3d_convT_bwd_both */
+  const n3d_conv_geom* g; int32_t transposed; int32_t flags_data; int32_t flags_weight; int32_t pad_;
+  const float* x; int64_t xld; const float* dy; int64_t dyld; const float* w; float* dx; int64_t dxld;
+  const float* relu_src; int64_t rld; const float* out_gate; void* ws_data; size_t ws_data_bytes;
+  float* dw; float* dbias; const float* in_gate; void* ws_weight; size_t ws_weight_bytes; n3d_final_job* deferred;
+} n3d_conv_bwd_call;
+/* the two data gradients must not alias (dx of c0 != dx of c1) for the one-launch form; aliasing falls back to two launches */
+int n3d_conv_bwd_both2(const n3d_conv_bwd_call* c0, const n3d_conv_bwd_call* c1, void* stream);
 /* transposed convolution y[i side] = convT(x[o side]) + bias; same kernels with the roles swapped */
 int n3d_convT_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias,
                   float* y, int64_t yld, int flags, const float* in_gate, double* stats,

@@ -52,6 +52,22 @@ class GnBwdTerm(C.Structure):
                 ("dalpha", C.c_void_p), ("dbias_conv", C.c_void_p), ("cA", C.c_void_p), ("cB", C.c_void_p), ("cC", C.c_void_p)]
 
 
+class ConvFwdCall(C.Structure):
+    """n3d_conv_fwd_call (include/n3d.h)"""
+    _fields_ = [("g", C.POINTER(ConvGeom)), ("transposed", C.c_int32), ("flags", C.c_int32), ("x", C.c_void_p), ("xld", C.c_int64),
+                ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("yld", C.c_int64), ("in_gate", C.c_void_p),
+                ("stats", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+
+
+class ConvBwdCall(C.Structure):
+    """n3d_conv_bwd_call (include/n3d.h)"""
+    _fields_ = [("g", C.POINTER(ConvGeom)), ("transposed", C.c_int32), ("flags_data", C.c_int32), ("flags_weight", C.c_int32),
+                ("pad_", C.c_int32), ("x", C.c_void_p), ("xld", C.c_int64), ("dy", C.c_void_p), ("dyld", C.c_int64), ("w", C.c_void_p),
+                ("dx", C.c_void_p), ("dxld", C.c_int64), ("relu_src", C.c_void_p), ("rld", C.c_int64), ("out_gate", C.c_void_p),
+                ("ws_data", C.c_void_p), ("ws_data_bytes", C.c_size_t), ("dw", C.c_void_p), ("dbias", C.c_void_p),
+                ("in_gate", C.c_void_p), ("ws_weight", C.c_void_p), ("ws_weight_bytes", C.c_size_t), ("deferred", C.POINTER(FinalJob))]
+
+
 _p = C.c_void_p
 _i = C.c_int
 _i64 = C.c_int64
@@ -71,6 +87,8 @@ PROTOTYPES = {
     "n3d_conv_fwd": (_i, [_gp, _p, _i64, _p, _p, _p, _i64, _i, _p, _p, _p, _sz, _p]),
     "n3d_conv_bwd_data": (_i, [_gp, _p, _i64, _p, _p, _i64, _i, _p, _i64, _p, _p, _sz, _p]),
     "n3d_conv_bwd_weight": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i, _p, _p, _sz, C.POINTER(FinalJob), _p]),
+    "n3d_conv_fwd2": (_i, [C.POINTER(ConvFwdCall), C.POINTER(ConvFwdCall), _p]),
+    "n3d_conv_bwd_both2": (_i, [C.POINTER(ConvBwdCall), C.POINTER(ConvBwdCall), _p]),
     "n3d_convT_bwd_both": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i64, _i, _p, _sz, _p, _i, _p, _sz, C.POINTER(FinalJob), _p]),
     "n3d_conv_bwd_both": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i64, _i, _p, _i64, _p, _p, _sz, _p, _p, _i, _p, _p, _sz,
                                 C.POINTER(FinalJob), _p]),

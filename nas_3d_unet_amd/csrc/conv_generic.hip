@@ -876,10 +876,22 @@ struct Wg16Args;
 int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                    float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s,
                    Wg16Args* prepared = nullptr);
+struct DualArgs;
 int mfma_bwd_dual_try(const n3d_conv_geom* g, bool transposed, const float* dy, int64_t dyld, const float* wp_packed, float* dx,
                       int64_t dxld, int flags_d, const float* relu_src, int64_t rld, const float* out_gate, const float* x, int64_t xld,
                       int flags_w, const float* in_gate, float* partial, float* pbias, size_t avail_floats, int* nchunks_out,
-                      int* ntiles_out, hipStream_t s);
+                      int* ntiles_out, hipStream_t s, DualArgs* prepared = nullptr, int* ksplit_out = nullptr);
+int mfma_bwd_quad_ok(const n3d_conv_geom* g0, bool t0, const n3d_conv_geom* g1, bool t1);
+struct BwdOne {  // one conv's backward operands for the quad launch (same layout as in conv_mfma.hip)
+  const n3d_conv_geom* g; bool transposed; const float* dy; int64_t dyld; const float* wp; float* dx; int64_t dxld; int flags_d;
+  const float* relu_src; int64_t rld; const float* out_gate; const float* x; int64_t xld; int flags_w; const float* in_gate;
+  float* partial; float* pbias; size_t avail; int nch, ntl;
+};
+int mfma_bwd_quad_try(BwdOne* c0, BwdOne* c1, hipStream_t s);
+int mfma_conv_pair_try(const n3d_conv_geom* g0, bool dg0, const float* src0, int64_t sld0, const float* w0, const float* bias0, float* dst0,
+                       int64_t dld0, int flags0, const float* gate0, double* stats0, void* ws0, size_t wsb0, const n3d_conv_geom* g1, bool dg1,
+                       const float* src1, int64_t sld1, const float* w1, const float* bias1, float* dst1, int64_t dld1, int flags1,
+                       const float* gate1, double* stats1, void* ws1, size_t wsb1, hipStream_t s);
 void mfma_pack16(const float* w, float* wp, int Co, int Ci, int taps, int data_grad, hipStream_t s);
 }
 
@@ -1163,6 +1175,96 @@ int n3d_convT_bwd_both(const n3d_conv_geom* g, const float* x, int64_t xld, cons
   if (rq.done) return N3D_OK;
   return run_gather(g, false, dy, dyld, w, nullptr, dx, dxld, flags_data & ~N3D_RELU_IN, nullptr, nullptr, 0, nullptr, nullptr, ws_data,
                     ws_data_bytes, stream);
+}
+
+int n3d_conv_fwd2(const n3d_conv_fwd_call* c0, const n3d_conv_fwd_call* c1, void* stream) {
+  N3D_CHECK_ARG(c0 && c1 && c0->g && c1->g, "conv_fwd2: bad args");
+  const n3d_conv_fwd_call* cs[2] = {c0, c1};
+  for (int i = 0; i < 2; ++i) {
+    if (int e = check_geom(cs[i]->g, "conv_fwd2")) return e;
+    N3D_CHECK_ARG(cs[i]->x && cs[i]->w && cs[i]->y, "conv_fwd2: null pointers");
+  }
+  if (!((c0->flags | c1->flags) & N3D_NO_MFMA) && !c0->g->depthwise && !c1->g->depthwise) {
+    // forward conv = gather with data_grad=false; transposed forward = gather with data_grad=true (run_gather convention)
+    const int r = mfma_conv_pair_try(c0->g, c0->transposed != 0, c0->x, c0->xld, c0->w, c0->bias, c0->y, c0->yld, c0->flags, c0->in_gate,
+                                     c0->stats, c0->ws, c0->ws_bytes, c1->g, c1->transposed != 0, c1->x, c1->xld, c1->w, c1->bias, c1->y,
+                                     c1->yld, c1->flags, c1->in_gate, c1->stats, c1->ws, c1->ws_bytes, (hipStream_t)stream);
+    if (r < 0) return r;
+    if (r == 1) return N3D_OK;
+  }
+  for (int i = 0; i < 2; ++i) {
+    const n3d_conv_fwd_call* c = cs[i];
+    const int e = c->transposed ? n3d_convT_fwd(c->g, c->x, c->xld, c->w, c->bias, c->y, c->yld, c->flags, c->in_gate, c->stats, c->ws, c->ws_bytes, stream)
+                                : n3d_conv_fwd(c->g, c->x, c->xld, c->w, c->bias, c->y, c->yld, c->flags, c->in_gate, c->stats, c->ws, c->ws_bytes, stream);
+    if (e) return e;
+  }
+  return N3D_OK;
+}
+
+int n3d_conv_bwd_both2(const n3d_conv_bwd_call* c0, const n3d_conv_bwd_call* c1, void* stream) {
+  N3D_CHECK_ARG(c0 && c1 && c0->g && c1->g, "conv_bwd_both2: bad args");
+  const n3d_conv_bwd_call* cs[2] = {c0, c1};
+  hipStream_t s = (hipStream_t)stream;
+  bool quad = true;
+  for (int i = 0; i < 2; ++i) {
+    const n3d_conv_bwd_call* c = cs[i];
+    if (int e = check_geom(c->g, "conv_bwd_both2")) return e;
+    N3D_CHECK_ARG(c->x && c->dy && c->w && c->dx && c->dw, "conv_bwd_both2: null pointers");
+    if (c->transposed && (c->dbias || c->relu_src || c->out_gate || c->in_gate)) N3D_UNSUPPORTED("conv_bwd_both2: transposed conv with bias / relu / gate extras");
+    quad = quad && !((c->flags_data | c->flags_weight) & N3D_NO_MFMA) && c->xld % 4 == 0 && c->dyld % 4 == 0 && c->ws_data && c->ws_weight;
+  }
+  // the two data gradients must not touch the same memory (both may accumulate into one input gradient)
+  quad = quad && c0->dx != c1->dx && mfma_bwd_quad_ok(c0->g, c0->transposed != 0, c1->g, c1->transposed != 0);
+  BwdOne b[2];
+  if (quad) {
+    for (int i = 0; i < 2 && quad; ++i) {
+      const n3d_conv_bwd_call* c = cs[i];
+      const n3d_conv_geom* g = c->g;
+      const int taps = g->k * g->k * g->k;
+      const size_t skip = align_up(packed_floats(g) * 4, 256);
+      if (c->ws_weight_bytes <= skip || c->ws_data_bytes < (size_t)taps * g->Ci * g->Co * 4) { quad = false; break; }
+      float* wsf = (float*)((char*)c->ws_weight + skip);
+      const size_t avail = (c->ws_weight_bytes - skip) / 4;
+      const size_t nt16 = (size_t)taps * (g->Ci / 16) * (g->Co / 16);
+      if ((1024 + nt16) * (256 + 16) > avail) { quad = false; break; }
+      b[i] = BwdOne{g, c->transposed != 0, c->dy, c->dyld, (const float*)c->ws_data, c->dx, c->dxld, c->flags_data & ~N3D_RELU_IN,
+                    c->relu_src, c->rld, c->out_gate, c->x, c->xld, c->transposed ? (c->flags_weight & ~N3D_RELU_IN) : c->flags_weight,
+                    c->in_gate, wsf, wsf + (1024 + nt16) * 256, (1024 + nt16) * 256, 0, 0};
+    }
+  }
+  if (quad) {
+    for (int i = 0; i < 2; ++i) {
+      const n3d_conv_bwd_call* c = cs[i];
+      if (!(c->flags_data & N3D_PREPACKED))
+        mfma_pack16(c->w, (float*)c->ws_data, c->g->Co, c->g->Ci, c->g->k * c->g->k * c->g->k, c->transposed ? 0 : 1, s);
+    }
+    const int r = mfma_bwd_quad_try(&b[0], &b[1], s);
+    if (r < 0) return r;
+    if (r == 1) {
+      for (int i = 0; i < 2; ++i) {
+        const n3d_conv_bwd_call* c = cs[i];
+        const n3d_conv_geom* g = c->g;
+        const int taps = g->k * g->k * g->k;
+        n3d_final_job job;
+        fill_job(&job, b[i].partial, b[i].pbias, c->dw, c->transposed ? nullptr : c->dbias, b[i].nch, b[i].ntl, g->Ci / 16, g->Co / 16, 16, 16, g->Co,
+                 g->Ci, taps);
+        if (c->deferred) *c->deferred = job;
+        else if (int e = n3d_wgrad_finalize_batch(&job, 1, stream)) return e;
+      }
+      return N3D_OK;
+    }
+  }
+  for (int i = 0; i < 2; ++i) {
+    const n3d_conv_bwd_call* c = cs[i];
+    const int e = c->transposed
+                      ? n3d_convT_bwd_both(c->g, c->x, c->xld, c->dy, c->dyld, c->w, c->dx, c->dxld, c->flags_data, c->ws_data, c->ws_data_bytes, c->dw,
+                                           c->flags_weight, c->ws_weight, c->ws_weight_bytes, c->deferred, stream)
+                      : n3d_conv_bwd_both(c->g, c->x, c->xld, c->dy, c->dyld, c->w, c->dx, c->dxld, c->flags_data, c->relu_src, c->rld, c->out_gate,
+                                          c->ws_data, c->ws_data_bytes, c->dw, c->dbias, c->flags_weight, c->in_gate, c->ws_weight,
+                                          c->ws_weight_bytes, c->deferred, stream);
+    if (e) return e;
+  }
+  return N3D_OK;
 }
 
 int n3d_conv_pack_info(const n3d_conv_geom* g, int data_grad, int flags, int32_t* layout, int32_t* cdp, int64_t* floats) {

@@ -423,6 +423,41 @@ __global__ __launch_bounds__(KS == 16 ? 1024 : 256, KS == 16 ? 4 : 2) void conv_
 }
 
 
+// Two independent small convolutions in ONE launch (the two ops of a searched-cell node, or a cell's two preprocess
+// convs): forward pair = two K-split GEMMs, backward "quad" = two (data gradient + weight gradient) duals.  On the
+// 2^3 .. 16^3 levels each problem alone occupies a fraction of the chip and costs a full launch + memory round trip.
+struct PairArgs { MfArgs a0, a1; int n0, gx0, gx1; };
+
+template <int KS>
+__global__ __launch_bounds__(KS == 16 ? 1024 : 256, KS == 16 ? 4 : 2) void conv_gemm16_pair_kernel(PairArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int L = blockIdx.x;
+  if (L < q.n0) gemm16_body<1, 1, KS>(q.a0, L % q.gx0, L / q.gx0, lds);
+  else gemm16_body<1, 1, KS>(q.a1, (L - q.n0) % q.gx1, (L - q.n0) / q.gx1, lds);
+}
+
+struct QuadArgs { DualArgs q0, q1; int n0; };
+
+template <int KS>
+__global__ __launch_bounds__(KS == 16 ? 1024 : 256, KS == 16 ? 4 : 2) void conv_bwd16_quad_kernel(QuadArgs z) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int UNITS = KS == 16 ? 4 : 1;
+  const bool second = (int)blockIdx.x >= z.n0;
+  const DualArgs& q = second ? z.q1 : z.q0;
+  const int L = second ? blockIdx.x - z.n0 : blockIdx.x;
+  if (L < q.nA) {
+    gemm16_body<1, 1, KS>(q.d, L % q.gxA, L / q.gxA, lds);
+  } else {
+    f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+    float (*lb)[16] = reinterpret_cast<float (*)[16]>(lds + UNITS * 3 * 64 * 4);
+    const int sub = threadIdx.x >> 8;
+    const int unit = (L - q.nA) * UNITS + sub;
+    const bool active = unit < q.nB;
+    const int u = active ? unit : 0;
+    wgrad16_body(q.w, u % q.ntilesB, u / q.ntilesB, q.ntilesB, threadIdx.x & 255, active, l4 + sub * 3 * 64, lb + sub * 4);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // vox64 family -- the FLOP-heavy shallow levels: 3x3x3 stride-1 (dilation 1 or 2) convolution with C = 4 or 8
 // channels on 16^3 .. 128^3 volumes (up-cells 3/4 and their data gradients: > 60 % of the net's FLOPs).
@@ -1034,6 +1069,10 @@ void mfma_pack16(const float* w, float* wp, int Co, int Ci, int taps, int data_g
   hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)cdiv((int64_t)taps * Co * Ci, 256)), dim3(256), 0, s, w, wp, Co, Ci, taps, data_grad);
 }
 
+int g16_prepare(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
+                int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate, double* stats,
+                void* ws, size_t ws_bytes, hipStream_t s, MfArgs* out, G16Plan* plan);
+
 int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
                   int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate, double* stats,
                   void* ws, size_t ws_bytes, hipStream_t s) {
@@ -1058,6 +1097,28 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
       return 1;
     }
   }
+  MfArgs a;
+  G16Plan p;
+  {
+    const int r = g16_prepare(g, data_grad, src, sld, w, bias, dst, dld, flags, in_gate, relu_src, rld, out_gate, stats, ws, ws_bytes, s, &a, &p);
+    if (r <= 0) return r;
+  }
+  const int64_t M = (int64_t)g->B * a.Dd * a.Hd * a.Wd;
+  if (p.ksplit == 16) launch_g16<1, 1, 16>(a, M, s);
+  else if (p.ksplit == 4) launch_g16<1, 1, 4>(a, M, s);
+  else if (p.nt == 2) launch_g16<2, 2, 1>(a, M, s);
+  else launch_g16<2, 1, 1>(a, M, s);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("conv(mfma) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+  return 1;
+}
+
+// fills the arguments of the gemm16 family for one conv (packing the weights unless pre-packed); 1 = ready, 0 = shape not
+// served by gemm16, < 0 error
+int g16_prepare(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
+                int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate, double* stats,
+                void* ws, size_t ws_bytes, hipStream_t s, MfArgs* out, G16Plan* plan) {
+  if (vx_plan(g).ok) return 0;
   G16Plan p = g16_plan(g, data_grad);
   if (!p.ok) return 0;
   if (sld % 4 != 0 || !aligned16(src)) {
@@ -1086,13 +1147,36 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
   const int total = taps * a.Cs * a.Cd;
   if (!(flags & N3D_PREPACKED))
     hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g->Co, g->Ci, taps, data_grad ? 1 : 0);
-  const int64_t M = (int64_t)g->B * Nd;
-  if (p.ksplit == 16) launch_g16<1, 1, 16>(a, M, s);
-  else if (p.ksplit == 4) launch_g16<1, 1, 4>(a, M, s);
-  else if (p.nt == 2) launch_g16<2, 2, 1>(a, M, s);
-  else launch_g16<2, 1, 1>(a, M, s);
+  *out = a; *plan = p;
+  return 1;
+}
+
+// two forward-type convs (forward, or transposed forward) of the K-split gemm16 family in one launch; 1 = launched,
+// 0 = not applicable (nothing launched, nothing packed), < 0 error
+int mfma_conv_pair_try(const n3d_conv_geom* g0, bool dg0, const float* src0, int64_t sld0, const float* w0, const float* bias0, float* dst0,
+                       int64_t dld0, int flags0, const float* gate0, double* stats0, void* ws0, size_t wsb0, const n3d_conv_geom* g1, bool dg1,
+                       const float* src1, int64_t sld1, const float* w1, const float* bias1, float* dst1, int64_t dld1, int flags1,
+                       const float* gate1, double* stats1, void* ws1, size_t wsb1, hipStream_t s) {
+  // decide before touching anything (g16_prepare packs weights)
+  if (vx_plan(g0).ok || vx_plan(g1).ok) return 0;
+  const G16Plan p0 = g16_plan(g0, dg0), p1 = g16_plan(g1, dg1);
+  if (!p0.ok || !p1.ok || p0.ksplit != p1.ksplit || p0.ksplit == 1) return 0;
+  if (sld0 % 4 != 0 || !aligned16(src0) || sld1 % 4 != 0 || !aligned16(src1)) return 0;
+  PairArgs q;
+  G16Plan t0, t1;
+  int r = g16_prepare(g0, dg0, src0, sld0, w0, bias0, dst0, dld0, flags0, gate0, nullptr, 0, nullptr, stats0, ws0, wsb0, s, &q.a0, &t0);
+  if (r <= 0) return r < 0 ? r : N3D_ERR_INVALID;
+  r = g16_prepare(g1, dg1, src1, sld1, w1, bias1, dst1, dld1, flags1, gate1, nullptr, 0, nullptr, stats1, ws1, wsb1, s, &q.a1, &t1);
+  if (r <= 0) return r < 0 ? r : N3D_ERR_INVALID;
+  const int64_t M0 = (int64_t)g0->B * q.a0.Dd * q.a0.Hd * q.a0.Wd, M1 = (int64_t)g1->B * q.a1.Dd * q.a1.Hd * q.a1.Wd;
+  q.gx0 = (int)cdiv(M0, 16); q.gx1 = (int)cdiv(M1, 16);
+  q.n0 = q.gx0 * (q.a0.Cd / 16);
+  const int n1 = q.gx1 * (q.a1.Cd / 16);
+  const size_t shm = (size_t)(p0.ksplit - 1) * 256 * sizeof(float) + (size_t)16 * 16 * 2 * sizeof(double);
+  if (p0.ksplit == 16) hipLaunchKernelGGL(conv_gemm16_pair_kernel<16>, dim3((unsigned)(q.n0 + n1)), dim3(1024), shm, s, q);
+  else hipLaunchKernelGGL(conv_gemm16_pair_kernel<4>, dim3((unsigned)(q.n0 + n1)), dim3(256), shm, s, q);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { set_error("conv(mfma) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+  if (e != hipSuccess) { set_error("conv(pair) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
   return 1;
 }
 
@@ -1134,7 +1218,7 @@ int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const fl
 int mfma_bwd_dual_try(const n3d_conv_geom* g, bool transposed, const float* dy, int64_t dyld, const float* wp_packed, float* dx,
                       int64_t dxld, int flags_d, const float* relu_src, int64_t rld, const float* out_gate, const float* x, int64_t xld,
                       int flags_w, const float* in_gate, float* partial, float* pbias, size_t avail_floats, int* nchunks_out,
-                      int* ntiles_out, hipStream_t s) {
+                      int* ntiles_out, hipStream_t s, DualArgs* prepared, int* ksplit_out) {
   // transposed conv: its data gradient is the FORWARD gather of the geometry (dy lives on the i side), and the weight
   // gradient kernel sees dy as its i-side operand and x as its o-side operand (roles swapped by the caller's convention)
   const bool dgrad_is_data_grad = !transposed;
@@ -1163,6 +1247,7 @@ int mfma_bwd_dual_try(const n3d_conv_geom* g, bool transposed, const float* dy, 
   q.nA = q.gxA * (a.Cd / 16);
   q.ntilesB = *ntiles_out;
   q.nB = *ntiles_out * *nchunks_out;
+  if (prepared) { *prepared = q; *ksplit_out = p.ksplit; return 1; }
   const int units = p.ksplit == 16 ? 4 : 1;
   const size_t shm_a = (size_t)(p.ksplit - 1) * 256 * sizeof(float) + (size_t)16 * 16 * 2 * sizeof(double);
   const size_t shm_b = (size_t)units * (3 * 64 * 16 + 4 * 16 * 4);
@@ -1174,5 +1259,46 @@ int mfma_bwd_dual_try(const n3d_conv_geom* g, bool transposed, const float* dy, 
   if (e != hipSuccess) { set_error("conv(bwd dual) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
   return 1;
 }
+
+// can the backward of these two convs share one launch?  (pure function of the geometries)
+int mfma_bwd_quad_ok(const n3d_conv_geom* g0, bool t0, const n3d_conv_geom* g1, bool t1) {
+  if (vx_plan(g0).ok || vx_plan(g1).ok) return 0;
+  if (g0->depthwise || g1->depthwise || g0->Ci % 16 || g0->Co % 16 || g1->Ci % 16 || g1->Co % 16) return 0;
+  const G16Plan p0 = g16_plan(g0, !t0), p1 = g16_plan(g1, !t1);
+  return p0.ok && p1.ok && p0.ksplit == p1.ksplit && p0.ksplit != 1;
+}
+
+struct BwdOne {  // one conv's backward operands for the quad launch
+  const n3d_conv_geom* g; bool transposed; const float* dy; int64_t dyld; const float* wp; float* dx; int64_t dxld; int flags_d;
+  const float* relu_src; int64_t rld; const float* out_gate; const float* x; int64_t xld; int flags_w; const float* in_gate;
+  float* partial; float* pbias; size_t avail; int nch, ntl;
+};
+
+int mfma_bwd_quad_try(BwdOne* c0, BwdOne* c1, hipStream_t s) {
+  QuadArgs z;
+  int k0 = 0, k1 = 0;
+  BwdOne* cs[2] = {c0, c1};
+  DualArgs* qs[2] = {&z.q0, &z.q1};
+  int* ks[2] = {&k0, &k1};
+  for (int i = 0; i < 2; ++i) {
+    BwdOne* c = cs[i];
+    const int r = mfma_bwd_dual_try(c->g, c->transposed, c->dy, c->dyld, c->wp, c->dx, c->dxld, c->flags_d, c->relu_src, c->rld, c->out_gate,
+                                    c->x, c->xld, c->flags_w, c->in_gate, c->partial, c->pbias, c->avail, &c->nch, &c->ntl, s, qs[i], ks[i]);
+    if (r != 1) return r;
+  }
+  if (k0 != k1) return 0;
+  const int units = k0 == 16 ? 4 : 1;
+  z.n0 = z.q0.nA + (int)cdiv(z.q0.nB, units);
+  const int n1 = z.q1.nA + (int)cdiv(z.q1.nB, units);
+  const size_t shm_a = (size_t)(k0 - 1) * 256 * sizeof(float) + (size_t)16 * 16 * 2 * sizeof(double);
+  const size_t shm_b = (size_t)units * (3 * 64 * 16 + 4 * 16 * 4);
+  const size_t shm = shm_a > shm_b ? shm_a : shm_b;
+  if (k0 == 16) hipLaunchKernelGGL(conv_bwd16_quad_kernel<16>, dim3((unsigned)(z.n0 + n1)), dim3(1024), shm, s, z);
+  else hipLaunchKernelGGL(conv_bwd16_quad_kernel<4>, dim3((unsigned)(z.n0 + n1)), dim3(256), shm, s, z);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("conv(bwd quad) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+  return 1;
+}
+
 
 }  // namespace n3d

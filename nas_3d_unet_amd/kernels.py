@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import GnFwdTerm, GnBwdTerm, ACCUMULATE, POOL_MAX, PREPACKED, RELU, RELU_IN, ConvGeom, FinalJob, N3DError, PackJob, check
+from ._lib import ConvBwdCall, ConvFwdCall, GnFwdTerm, GnBwdTerm, ACCUMULATE, POOL_MAX, PREPACKED, RELU, RELU_IN, ConvGeom, FinalJob, N3DError, PackJob, check
 
 __all__ = ["View", "as_view", "empty_ndhwc", "stream_ptr", "conv_geom", "ptr"]
 
@@ -266,6 +266,39 @@ def conv_bwd_weight(g, x: View, dy: View, dw, dbias, flags=0, in_gate=None, tran
     if job is not None and job.nchunks > 0:
         _ctx.final.append(job)
         _ctx.keep.append(ws)  # the partial slabs live in ws until StepContext.flush_final()
+
+
+def conv_fwd2(calls):
+    """Two forward convs, one launch where libn3d can fold them.  calls = [(g, x, w, bias, y, flags, in_gate, stats, transposed)] * 2"""
+    cs, keep = [], []
+    for (g, x, w, bias, y, flags, in_gate, stats, transposed) in calls:
+        ws, wsp, n, flags = _packed(w, g, transposed, flags, x.t.device)
+        keep.append((ws, g))
+        cs.append(ConvFwdCall(C.pointer(g), 1 if transposed else 0, flags, x.p.value, x.ld, w.data_ptr(), _vp(bias), y.p.value, y.ld,
+                              _vp(in_gate), _vp(stats), wsp.value if hasattr(wsp, "value") else wsp, n))
+    check(_lib.load().n3d_conv_fwd2(C.byref(cs[0]), C.byref(cs[1]), stream_ptr()), "n3d_conv_fwd2")
+
+
+def conv_bwd_both2(calls):
+    """Backward (data + weight gradient) of two convs, one launch where libn3d can fold them.
+    calls = [(g, x, dy, w, dx, dw, dbias, flags_data, relu_src, out_gate, flags_weight, in_gate, transposed)] * 2"""
+    cs, keep, jobs = [], [], []
+    for (g, x, dy, w, dx, dw, dbias, flags_data, relu_src, out_gate, flags_weight, in_gate, transposed) in calls:
+        wsd, wspd, nd, flags_data = _packed(w, g, not transposed, flags_data, dy.t.device)
+        ws, n = _ws(g, x.t.device)
+        job = FinalJob() if _ctx is not None else None
+        keep.append((wsd, ws, g))
+        jobs.append((job, ws))
+        cs.append(ConvBwdCall(C.pointer(g), 1 if transposed else 0, flags_data, flags_weight, 0, x.p.value, x.ld, dy.p.value, dy.ld,
+                              w.data_ptr(), dx.p.value, dx.ld, relu_src.p.value if relu_src is not None else None,
+                              relu_src.ld if relu_src is not None else 0, _vp(out_gate),
+                              wspd.value if hasattr(wspd, "value") else wspd, nd, _vp(dw), _vp(dbias), _vp(in_gate), ws.data_ptr(), n,
+                              C.pointer(job) if job is not None else None))
+    check(_lib.load().n3d_conv_bwd_both2(C.byref(cs[0]), C.byref(cs[1]), stream_ptr()), "n3d_conv_bwd_both2")
+    for job, ws in jobs:
+        if job is not None and job.nchunks > 0:
+            _ctx.final.append(job)
+            _ctx.keep.append(ws)
 
 
 def conv_bwd_both(g, x: View, dy: View, w, dx: View, dw, dbias, flags_data=0, relu_src: View | None = None, out_gate=None,

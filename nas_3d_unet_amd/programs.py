@@ -151,7 +151,8 @@ class DenseConvW(WeightProgram):
         g = self.geom(x)
         return (g.B, g.Ci, g.Di, g.Hi, g.Wi) if self.transposed else (g.B, g.Co, g.Do, g.Ho, g.Wo)
 
-    def fwd(self, x, relu_in, gate, want_stats):
+    def fwd_prepare(self, x, relu_in, gate, want_stats):
+        """everything of fwd() except the conv launch: returns (call tuple for K.conv_fwd2, (y, stats, rows, saved))"""
         s = Saved()
         s.pre = None
         if self.transposed and (relu_in or gate is not None):
@@ -166,9 +167,31 @@ class DenseConvW(WeightProgram):
             rows = K.conv_stats_rows(g, self.transposed)
             if rows > 0:  # 0: this shape's kernel cannot emit statistics -> seg_forward runs n3d_channel_stats
                 stats = torch.empty((x.B, rows, shp[1], 2), dtype=torch.float64, device=x.t.device)
-        K.conv_fwd(g, x, self.m.weight, self.m.bias, y, RELU_IN if relu_in else 0, gate, stats, self.transposed)
         s.x, s.g, s.relu_in, s.gate = x, g, relu_in, gate
-        return y, stats, rows, s
+        call = (g, x, self.m.weight, self.m.bias, y, RELU_IN if relu_in else 0, gate, stats, self.transposed)
+        return call, (y, stats, rows, s)
+
+    def fwd(self, x, relu_in, gate, want_stats):
+        call, res = self.fwd_prepare(x, relu_in, gate, want_stats)
+        g, xx, w, b, y, fl, gt, stats, tr = call
+        K.conv_fwd(g, xx, w, b, y, fl, gt, stats, tr)
+        return res
+
+    def bwd_call(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias):
+        """call tuple for K.conv_bwd_both2 if this backward is a plain (data + weight gradient) pair candidate, else None"""
+        x, g = saved.x, saved.g
+        dw = K.grad_target(self.m.weight)
+        db = None if skip_bias else K.grad_target(self.m.bias)
+        if not (need_dx and saved.pre is None and dw is not None and g.Ci % 16 == 0 and g.Co % 16 == 0):
+            return None
+        if self.transposed and (db is not None or saved.relu_in or saved.gate is not None):
+            return None
+        if dx_out is None:
+            dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+            dx_acc = False
+        call = (g, x, draw, self.m.weight, dx_out, dw, db, ACCUMULATE if dx_acc else 0, x if saved.relu_in else None, saved.gate,
+                RELU_IN if saved.relu_in else 0, saved.gate, self.transposed)
+        return call, dx_out, [dw, db]
 
     def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
         x, g = saved.x, saved.g
@@ -434,12 +457,25 @@ def pair_forward(segA, xA, segB, xB, out, outB=None):
     Both weight ops run first; if both epilogues are small GroupNorm epilogues of one shape they share ONE launch
     (n3d_affine_act_gn2), otherwise the two ordinary epilogues run one after the other.  Returns (savedA, savedB)."""
     res = []
-    for seg, x in ((segA, xA), (segB, xB)):
-        want_stats = seg.norm is not None and seg.weight.produces_stats
-        raw, stats, rows, ws = seg.weight.fwd(x, seg.relu_in, None, want_stats)
-        if seg.norm is not None and stats is None:
-            stats, rows = K.channel_stats(raw)
-        res.append((raw, stats, rows, ws))
+    if isinstance(segA.weight, DenseConvW) and isinstance(segB.weight, DenseConvW):
+        # both weight ops are plain convs: one launch where libn3d can fold them (n3d_conv_fwd2)
+        calls = []
+        for seg, x in ((segA, xA), (segB, xB)):
+            call, r = seg.weight.fwd_prepare(x, seg.relu_in, None, seg.norm is not None)
+            calls.append(call)
+            res.append(list(r))
+        K.conv_fwd2(calls)
+        for seg, r in zip((segA, segB), res):
+            if seg.norm is not None and r[1] is None:
+                r[1], r[2] = K.channel_stats(r[0])
+        res = [tuple(r) for r in res]
+    else:
+        for seg, x in ((segA, xA), (segB, xB)):
+            want_stats = seg.norm is not None and seg.weight.produces_stats
+            raw, stats, rows, ws = seg.weight.fwd(x, seg.relu_in, None, want_stats)
+            if seg.norm is not None and stats is None:
+                stats, rows = K.channel_stats(raw)
+            res.append((raw, stats, rows, ws))
     (rawA, stA, rowsA, wsA), (rawB, stB, rowsB, wsB) = res
     G = group_count(rawA.C)
     if (_pairable_fwd(segA) and _pairable_fwd(segB) and rawA.C == rawB.C and rawA.N == rawB.N
@@ -484,10 +520,21 @@ def pair_backward(segA, sA, segB, sB, dout, argsA, argsB, doutB=None):
                           draw=K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))))
     outs = K.affine_act_bwd_gn2(dout, terms, sA.G, doutB)
     results = []
+    order = ((segB, sB, terms[1], outs[1], argsB), (segA, sA, terms[0], outs[0], argsA))
+    # both weight ops plain convs of the deep levels with distinct input-gradient targets: one backward launch for both
+    pre = None
+    if all(isinstance(o[0].weight, DenseConvW) for o in order):
+        cands = [o[0].weight.bwd_call(o[1].ws, o[2]["draw"], o[4][0], o[4][1], o[4][2], o[3][2] is not None) for o in order]
+        if all(c is not None for c in cands) and cands[0][1].p.value != cands[1][1].p.value:
+            K.conv_bwd_both2([c[0] for c in cands])
+            pre = [(c[1].t, c[2]) for c in cands]
     # weight-op backward in reverse forward order (B then A), as the unpaired path does
-    for seg, s, t, (dgamma, dbeta, dcb), args in ((segB, sB, terms[1], outs[1], argsB), (segA, sA, terms[0], outs[0], argsA)):
+    for k, (seg, s, t, (dgamma, dbeta, dcb), args) in enumerate(order):
         need_dx, dx_out, dx_acc = args
-        dx, wg = seg.weight.bwd(s.ws, t["draw"], need_dx, dx_out, dx_acc, dcb is not None)
+        if pre is not None:
+            dx, wg = pre[k]
+        else:
+            dx, wg = seg.weight.bwd(s.ws, t["draw"], need_dx, dx_out, dx_acc, dcb is not None)
         wg = list(wg)
         if dcb is not None:
             for i, p in enumerate(seg.weight.params()):
