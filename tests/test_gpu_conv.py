@@ -167,3 +167,56 @@ def test_depthwise_family(c, stride, transposed, shape):
     K.conv_bwd_weight(g, x, dy, dw, db, 0, None, transposed)
     assert_close(dw, wc.grad, 1e-4, "dw")
     assert_close(db, bc.grad, 1e-4, "db")
+
+
+@pytest.mark.parametrize("specA,specB", [
+    ((64, 64, 3, 1, 1, False, (4, 4, 4)), (64, 64, 3, 1, 2, False, (4, 4, 4))),      # both K-split-16 GEMMs: one launch
+    ((32, 32, 3, 2, 1, True, (4, 4, 4)), (32, 32, 3, 1, 1, False, (8, 8, 8))),       # transposed + plain
+    ((16, 16, 3, 1, 1, False, (16, 16, 16)), (16, 16, 3, 1, 2, False, (16, 16, 16))),  # K-split-4 plan
+    ((96, 32, 1, 2, 1, False, (8, 8, 8)), (48, 32, 1, 1, 1, False, (4, 4, 4))),      # the two preprocess convs of a cell
+    ((8, 8, 3, 1, 1, False, (8, 8, 16)), (64, 64, 3, 1, 1, False, (4, 4, 4))),       # not foldable: falls back to two launches
+])
+def test_conv_pairs_match_single_calls(specA, specB):
+    """n3d_conv_fwd2 / n3d_conv_bwd_both2 == the two single calls (and torch CPU), whatever launch grouping libn3d picks."""
+    from nas_3d_unet_amd import kernels as K
+    from nas_3d_unet_amd.prim_ops import _padding
+    dev = torch.device("cuda")
+    B = 2
+    fwd_calls, bwd_calls, refs, outs = [], [], [], []
+    for si, (cin, cout, k, stride, dil, transposed, shape) in enumerate((specA, specB)):
+        pad = _padding(k, stride, dil)
+        xn = _mk((B, cin) + shape, 11 + si)
+        wn = _mk((cin, cout, k, k, k) if transposed else (cout, cin, k, k, k), 21 + si, 1.0 / np.sqrt(cin * k ** 3))
+        bn = _mk((cout,), 31 + si, 0.1)
+        xc, wc, bc = (torch.from_numpy(a).requires_grad_(True) for a in (xn, wn, bn))
+        if transposed:
+            yc = F.conv_transpose3d(xc, wc, bc, stride=stride, padding=pad, output_padding=0 if stride == 1 else 1, dilation=dil)
+            g = K.conv_geom(B, yc.shape[2], yc.shape[3], yc.shape[4], cout, cin, k, stride, dil, pad)
+        else:
+            yc = F.conv3d(xc, wc, bc, stride=stride, padding=pad, dilation=dil)
+            g = K.conv_geom(B, shape[0], shape[1], shape[2], cin, cout, k, stride, dil, pad)
+        rn = _mk(tuple(yc.shape), 41 + si)
+        (yc * torch.from_numpy(rn)).sum().backward()
+        x = K.as_view(torch.from_numpy(xn).to(dev))
+        w, b = torch.from_numpy(wn).to(dev), torch.from_numpy(bn).to(dev)
+        y = K.as_view(K.empty_ndhwc(B, yc.shape[1], yc.shape[2], yc.shape[3], yc.shape[4], dev))
+        rows = K.conv_stats_rows(g, transposed)
+        stats = torch.zeros((B, rows, yc.shape[1], 2), dtype=torch.float64, device=dev) if rows > 0 else None
+        fwd_calls.append((g, x, w, b, y, 0, None, stats, transposed))
+        dy = K.as_view(torch.from_numpy(rn).to(dev))
+        dx = K.as_view(K.empty_ndhwc(B, cin, *shape, dev))
+        dw = torch.zeros_like(w)
+        db = None if transposed else torch.zeros_like(b)
+        bwd_calls.append((g, x, dy, w, dx, dw, db, 0, None, None, 0, None, transposed))
+        refs.append((yc.detach(), xc.grad, wc.grad, bc.grad))
+        outs.append((y, stats, dx, dw, db))
+    K.conv_fwd2(fwd_calls)
+    K.conv_bwd_both2(bwd_calls)
+    for (yc, dxc, dwc, dbc), (y, stats, dx, dw, db) in zip(refs, outs):
+        assert_close(y.t, yc, 2e-5, "y (pair)")
+        if stats is not None:
+            assert_close(stats.sum(dim=1).cpu().numpy()[..., 0], yc.double().sum(dim=(2, 3, 4)).numpy(), 1e-5, "stats (pair)")
+        assert_close(dx.t, dxc, 5e-5, "dx (pair)")
+        assert_close(dw, dwc, 1e-4, "dw (pair)")
+        if db is not None:
+            assert_close(db, dbc, 1e-4, "db (pair)")
