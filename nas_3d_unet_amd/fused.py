@@ -18,6 +18,9 @@ from . import programs as P
 from ._lib import ACCUMULATE
 
 
+REUSE_GRAD_OUTPUT = False  # see _run_backward; switched on by the trainers for the duration of their backward pass
+
+
 def _single_segment(op):
     if op._segments is None:
         op._segments = op._build_segments()
@@ -124,9 +127,15 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha)
     dv = K.as_view(dout, "grad_output")
     out = st.out
     dev = out.t.device
-    # private, writable copy of the incoming gradient: node slices receive further contributions
-    dcat = K.as_view(K.empty_ndhwc(out.B, nn * cn, out.D, out.H, out.W, dev))
-    _copy_into(dv, dcat)
+    # node slices of the incoming gradient receive further contributions.  A trainer that owns the whole backward
+    # (train.Trainer / SearchTrainer set REUSE_GRAD_OUTPUT) lets the cell accumulate straight into autograd's buffer: it is
+    # either this cell's consumer's freshly returned dx or autograd's own accumulation buffer, and nobody reads it again.
+    # Stand-alone use keeps the private copy (autograd forbids modifying grad_output in general).
+    if REUSE_GRAD_OUTPUT and dv.t is dout and dv.ld == nn * cn:
+        dcat = dv
+    else:
+        dcat = K.as_view(K.empty_ndhwc(out.B, nn * cn, out.D, out.H, out.W, dev))
+        _copy_into(dv, dcat)
     dnodes = [_slice_view(dcat, k, cn) for k in range(nn)]
     p0, p1 = st.xs[0], st.xs[1]
     dpre = [K.as_view(K.empty_ndhwc(p0.B, p0.C, p0.D, p0.H, p0.W, dev)), K.as_view(K.empty_ndhwc(p1.B, p1.C, p1.D, p1.H, p1.W, dev))]

@@ -17,6 +17,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from . import fused as _fused
 from . import kernels as K
 from .loss import WeightedDiceLoss
 
@@ -173,7 +174,11 @@ class Trainer:
             self.ctx.pack_all()            # one launch packs every conv weight for this step
             p = self.model(x)
             loss = self.loss_fn(p, t)
-            loss.backward()
+            prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True   # this backward is all ours (no hooks, no retain)
+            try:
+                loss.backward()
+            finally:
+                _fused.REUSE_GRAD_OUTPUT = prev
             self.ctx.flush_final()         # one launch finishes every weight-gradient reduction
         if not self.ctx.frozen:
             self.ctx.freeze()              # first pass only recorded which weights / layouts are needed
@@ -278,7 +283,11 @@ class SearchTrainer:
         with K.step_context(self.ctx):
             self.ctx.pack_all()
             loss = self.loss_fn(self.model(x), t)
-            loss.backward()
+            prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True
+            try:
+                loss.backward()
+            finally:
+                _fused.REUSE_GRAD_OUTPUT = prev
             self.ctx.flush_final()
         if not self.ctx.frozen and not arch:
             self.ctx.freeze()
