@@ -277,6 +277,17 @@ int n3d_dice_bwd(const float* p, int64_t psb, int64_t psc, int64_t psv, const fl
 int n3d_ncdhw_to_ndhwc(const float* src, float* dst, int64_t dld, int B, int C, int64_t N, void* stream);
 int n3d_ndhwc_to_ncdhw(const float* src, int64_t sld, float* dst, int B, int C, int64_t N, void* stream);
 
+/* ---- on-device data step (the work of the reference's generator just ahead of the hot path, train.py:117-119):
+ * patch crop with zero padding (patches.py:99-115,152-169) + one cube isometry per patch (augment.py:73-131; the same
+ * for data and truth) + label expansion to three binary channels (generator.py:230-248, including its quirk that the
+ * inclusive "WT" channel is labels {1,2}).  out[b][i] = vol[corner + src(i)], src_a(i) = i[perm[a]] or P-1-i[perm[a]]
+ * (flip[a]); zero outside the volume.  vol: (Cv, X, Y, Z) contiguous fp32; truth: (X, Y, Z) uint8 labels {0,1,2,4} or
+ * NULL; x_out: pitched NDHWC (B, Cv, P, P, P); t_out: (B, 3, P, P, P) contiguous fp32 or NULL.  descs: HOST array. */
+#define N3D_PATCH_MAX_BATCH 64
+typedef struct n3d_patch_desc { int32_t corner[3]; int32_t perm[3]; int32_t flip[3]; } n3d_patch_desc;
+int n3d_patch_batch(const float* vol, int Cv, const uint8_t* truth, int X, int Y, int Z, const n3d_patch_desc* descs, int B, int P,
+                    int inclusive, float* x_out, int64_t xld, float* t_out, void* stream);
+
 /* ---- flat Adam (train.py:49,128; search.py:103-104,228,238): torch.optim.Adam defaults ------------
  * step_ptr: device int32 holding the number of steps already taken; if inc_step != 0 a second tiny
  * launch increments it after the update (graph-replay safe).  grad_scale multiplies g (DP mean). */

@@ -68,6 +68,11 @@ class ConvBwdCall(C.Structure):
                 ("in_gate", C.c_void_p), ("ws_weight", C.c_void_p), ("ws_weight_bytes", C.c_size_t), ("deferred", C.POINTER(FinalJob))]
 
 
+class PatchDesc(C.Structure):
+    """n3d_patch_desc (include/n3d.h)"""
+    _fields_ = [("corner", C.c_int32 * 3), ("perm", C.c_int32 * 3), ("flip", C.c_int32 * 3)]
+
+
 _p = C.c_void_p
 _i = C.c_int
 _i64 = C.c_int64
@@ -125,6 +130,7 @@ PROTOTYPES = {
     "n3d_dice_bwd": (_i, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i, _i, _i64, _f, _p, _p, _p, _i64, _i64, _i64, _p]),
     "n3d_ncdhw_to_ndhwc": (_i, [_p, _p, _i64, _i, _i, _i64, _p]),
     "n3d_ndhwc_to_ncdhw": (_i, [_p, _i64, _p, _i, _i, _i64, _p]),
+    "n3d_patch_batch": (_i, [_p, _i, _p, _i, _i, _i, C.POINTER(PatchDesc), _i, _i, _i, _p, _i64, _p, _p]),
     "n3d_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _f, _p, _i, _p]),
 }
 

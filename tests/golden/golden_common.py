@@ -125,3 +125,36 @@ def dice_cases():
 
 def geno_cases():
     return ["geno/%d" % i for i in range(8)]
+
+
+# ---- data step (patch crop + cube isometry + label expansion) ---------------------------------
+DATASTEP_PATCH = (6, 6, 6)
+
+
+def permutation_keys():
+    """the 48 keys ((rotate_y, rotate_z), flip_x, flip_y, flip_z, transpose) of augment.py:73-92, in a fixed order"""
+    import itertools
+    return sorted(itertools.product(itertools.combinations_with_replacement(range(2), 2), range(2), range(2), range(2), range(2)))
+
+
+def datastep_cube():
+    """(2, 5, 5, 5) float32 cube with distinct entries"""
+    return np.arange(2 * 5 * 5 * 5, dtype=np.float32).reshape(2, 5, 5, 5) * 0.5 - 7.0
+
+
+def datastep_volume():
+    """(4, 11, 9, 10) float32 image and (1, 11, 9, 10) uint8 truth with BraTS labels {0, 1, 2, 4}"""
+    rng = np.random.default_rng(77)
+    vol = rng.standard_normal((4, 11, 9, 10)).astype(np.float32)
+    truth = rng.choice(np.array([0, 0, 1, 2, 4], dtype=np.uint8), size=(1, 11, 9, 10))
+    return vol, truth
+
+
+def datastep_corners():
+    """patch corners inside, partly outside (both sides) and mostly outside the volume"""
+    return [(0, 0, 0), (5, 3, 4), (-2, 1, 6), (7, -3, -1), (-4, -4, -4), (9, 7, 8), (2, 2, 2), (-1, 5, -2)]
+
+
+def datastep_batch_keys():
+    ks = permutation_keys()
+    return [ks[i] for i in (0, 5, 11, 17, 23, 30, 41, 47)]
