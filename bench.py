@@ -231,7 +231,7 @@ def main():
         patches = world * args.batch * args.steps
         value = patches / dt
         out = {
-            "metric": "4x64^3 patches/sec (train step: fwd + Dice + bwd + Adam%s)" % (" + RCCL all-reduce" if world > 1 else ""),
+            "metric": "4x%d^3 patches/sec (train step: fwd + Dice + bwd + Adam%s)" % (args.size, " + RCCL all-reduce" if world > 1 else ""),
             "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
