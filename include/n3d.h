@@ -288,6 +288,17 @@ typedef struct n3d_patch_desc { int32_t corner[3]; int32_t perm[3]; int32_t flip
 int n3d_patch_batch(const float* vol, int Cv, const uint8_t* truth, int X, int Y, int Z, const n3d_patch_desc* descs, int B, int P,
                     int inclusive, float* x_out, int64_t xld, float* t_out, void* stream);
 
+/* ---- step after the hot path (prediction.py:120-170): stitch the per-patch predictions into the brain-wide volume with
+ * mean blending (patches.py:172-207) and fuse the three sigmoid channels into one label volume.
+ * n3d_stitch: patches element (b, c, voxel v = (lx*P+ly)*P+lz) at patches[b*sb + c*sc + v*sv] (any of the layouts the
+ * net produces); corners: DEVICE int32 [B][3] on the brain-wide grid (may be negative / hang over the border);
+ * out: float64 (C, FX, FY, FZ) full image, the (X,Y,Z) brain-wide box is written at offset (ox,oy,oz); voxels of the box
+ * no patch covers become 0.  Sums run in list order in fp64 like the reference's.  1 <= C <= 4.
+ * n3d_tumor_labels: pred float64 (3, N) -> uint8 labels {0,1,2,4} (inclusive: TC/WT/ET channels; else NCR-NET/ED/ET). */
+int n3d_stitch(const float* patches, int64_t sb, int64_t sc, int64_t sv, int C, int P, const int32_t* corners, int B, int X, int Y, int Z,
+               double* out, int FX, int FY, int FZ, int ox, int oy, int oz, void* stream);
+int n3d_tumor_labels(const double* pred, int64_t N, double threshold, int inclusive, uint8_t* out, void* stream);
+
 /* ---- flat Adam (train.py:49,128; search.py:103-104,228,238): torch.optim.Adam defaults ------------
  * step_ptr: device int32 holding the number of steps already taken; if inc_step != 0 a second tiny
  * launch increments it after the update (graph-replay safe).  grad_scale multiplies g (DP mean). */

@@ -131,6 +131,8 @@ PROTOTYPES = {
     "n3d_ncdhw_to_ndhwc": (_i, [_p, _p, _i64, _i, _i, _i64, _p]),
     "n3d_ndhwc_to_ncdhw": (_i, [_p, _i64, _p, _i, _i, _i64, _p]),
     "n3d_patch_batch": (_i, [_p, _i, _p, _i, _i, _i, C.POINTER(PatchDesc), _i, _i, _i, _p, _i64, _p, _p]),
+    "n3d_stitch": (_i, [_p, _i64, _i64, _i64, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "n3d_tumor_labels": (_i, [_p, _i64, C.c_double, _i, _p, _p]),
     "n3d_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _f, _p, _i, _p]),
 }
 

@@ -158,3 +158,24 @@ def datastep_corners():
 def datastep_batch_keys():
     ks = permutation_keys()
     return [ks[i] for i in (0, 5, 11, 17, 23, 30, 41, 47)]
+
+
+# ---- stitching + label fusion -----------------------------------------------------------------
+def poststep_patches():
+    """12 (3, 6, 6, 6) float32 patches on a (3, 13, 11, 12) brain-wide grid: overlapping, some hanging over the border on
+    either side, one voxel region covered by nothing"""
+    rng = np.random.default_rng(91)
+    corners = [(0, 0, 0), (4, 0, 0), (7, 0, 0), (0, 5, 0), (4, 5, 0), (7, 5, 0), (0, 0, 6), (4, 0, 6), (-2, 3, 7), (9, 7, 8), (3, -1, -3), (5, 4, 5)]
+    patches = [rng.uniform(0, 1, (3, 6, 6, 6)).astype(np.float32) for _ in corners]
+    return patches, corners, (3, 13, 11, 12)
+
+
+def poststep_pred():
+    """(3, 9, 8, 7) probabilities incl. exact ties and values exactly at the threshold"""
+    rng = np.random.default_rng(92)
+    p = rng.uniform(0, 1, (3, 9, 8, 7))
+    p[:, 0, 0, :] = 0.5
+    p[0, 1, :, 0] = p[1, 1, :, 0] = 0.75   # ties between channels 0 and 1 above the threshold
+    p[1, 2, :, 1] = p[2, 2, :, 1] = 0.9
+    p[:, 3, 3, :] = 0.8                    # all three above the threshold
+    return p

@@ -1,0 +1,21 @@
+"""CPU: the post-step oracle (oracle/post_step.py) against the golden vectors of the reference's own stitch / get_tumor_pred."""
+import numpy as np
+
+import golden_common as gc
+from oracle import post_step as ps
+
+
+def test_stitch_oracle(golden):
+    g = golden("poststep")
+    patches, corners, shape = gc.poststep_patches()
+    out = ps.stitch(patches, corners, shape)
+    assert out.dtype == np.float64 and np.array_equal(out, g["stitch/out"])
+    assert (g["stitch/out"] == 0).any()  # the case really contains voxels no patch covers
+
+
+def test_tumor_labels_oracle(golden):
+    g = golden("poststep")
+    pred = gc.poststep_pred()
+    assert np.array_equal(ps.tumor_labels(pred, 0.5, True), g["tumor/inclusive"])
+    assert np.array_equal(ps.tumor_labels(pred, 0.5, False), g["tumor/exclusive"])
+    assert np.array_equal(ps.tumor_labels(pred, 0.3, False), g["tumor/exclusive_t03"])
