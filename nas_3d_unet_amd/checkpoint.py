@@ -1,0 +1,104 @@
+"""Checkpoint / genotype interoperability with the reference; host logic only.
+
+The reference saves `torch.save({...})` dictionaries (train.py:85-93: epoch, history, model_param, optim, scheduler,
+best_loss; search.py:166-176 adds geno_count, optim_shell / optim_kernel, shell_scheduler / kernel_scheduler) and reads
+them back in check_resume (train.py:52-67; search.py:108-127); the genotype travels as a pickled `(str(gene), count)`
+that is `eval`ed (search.py:189-194; train.py:36-38).  Module state-dicts need no conversion (same keys and shapes).
+What does need one is the optimizer: the trainers keep Adam's moments in flat buffers with ONE step counter, torch's
+Adam keeps per-parameter tensors -- `adam_state_dict` / `load_adam_state_dict` translate both ways, and the plateau
+schedulers export / import torch's ReduceLROnPlateau field names.
+"""
+from __future__ import annotations
+
+import pickle
+
+import torch
+
+from .genotype import Genotype
+
+
+# ------------------------------------------------------------------------------------------------ Adam
+def adam_state_dict(fp, lr, betas=(0.9, 0.999), eps=1e-8):
+    """torch.optim.Adam(params).state_dict() equivalent of a train.FlatParams (params in `fp.params` order)."""
+    step = int(fp.step.item())
+    state = {}
+    for i, (p, o) in enumerate(zip(fp.params, fp.offsets)):
+        n = p.numel()
+        if step > 0:
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": fp.exp_avg[o:o + n].view(p.shape).clone(),
+                        "exp_avg_sq": fp.exp_avg_sq[o:o + n].view(p.shape).clone()}
+    group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
+             "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+             "params": list(range(len(fp.params)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def load_adam_state_dict(fp, sd):
+    """inverse of adam_state_dict; returns the learning rate stored in the checkpoint"""
+    steps = set()
+    fp.exp_avg.zero_()
+    fp.exp_avg_sq.zero_()
+    for i, (p, o) in enumerate(zip(fp.params, fp.offsets)):
+        st = sd["state"].get(i)
+        if st is None:
+            continue
+        n = p.numel()
+        fp.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1).to(fp.exp_avg.device))
+        fp.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1).to(fp.exp_avg.device))
+        steps.add(int(float(st["step"])))
+    if len(steps) > 1:
+        raise ValueError("checkpoint has different Adam step counts per parameter: %s" % sorted(steps))
+    fp.step.fill_(steps.pop() if steps else 0)
+    return float(sd["param_groups"][0]["lr"])
+
+
+# ------------------------------------------------------------------------------------------------ scheduler
+_SCHED_FIELDS = ("factor", "patience", "threshold", "cooldown", "eps", "best", "num_bad_epochs", "cooldown_counter", "last_epoch")
+
+
+def scheduler_state_dict(s):
+    """ReduceLROnPlateau.state_dict() field names for a train.PlateauLR"""
+    d = {k: getattr(s, k) for k in _SCHED_FIELDS}
+    d.update({"mode": "min", "threshold_mode": "rel", "min_lrs": [s.min_lr], "mode_worse": float("inf"), "_last_lr": [s.get_lr()]})
+    return d
+
+
+def load_scheduler_state_dict(s, d):
+    for k in _SCHED_FIELDS:
+        if k in d:
+            setattr(s, k, d[k])
+    if "min_lrs" in d:
+        s.min_lr = d["min_lrs"][0]
+
+
+# ------------------------------------------------------------------------------------------------ train.py:85-93 / 52-67
+def train_state_dicts(trainer, epoch, history, best_loss):
+    return {"epoch": epoch, "history": history, "model_param": trainer.model.state_dict(),
+            "optim": adam_state_dict(trainer.fp, trainer.lr, trainer.betas, trainer.eps),
+            "scheduler": scheduler_state_dict(trainer.scheduler), "best_loss": best_loss}
+
+
+def load_train_state_dicts(trainer, sd, new_lr=False):
+    """returns (next epoch, history, best_loss) like check_resume"""
+    trainer.model.load_state_dict(sd["model_param"])   # parameters are views of the flat buffer: copied in place
+    if not new_lr:
+        trainer.set_lr(load_adam_state_dict(trainer.fp, sd["optim"]))
+        load_scheduler_state_dict(trainer.scheduler, sd["scheduler"])
+    return sd["epoch"] + 1, sd["history"], sd["best_loss"]
+
+
+# ------------------------------------------------------------------------------------------------ genotype pickle
+def save_genotype(path, gene, count=1):
+    """search.py:189-194: pickle of (str(gene), count)"""
+    with open(path, "wb") as f:
+        pickle.dump((str(gene), count), f)
+
+
+def load_genotype(path):
+    """train.py:36-38: gene = eval(pickle.load(f)[0]) -- evaluated with only `Genotype` in scope"""
+    with open(path, "rb") as f:
+        text = pickle.load(f)[0]
+    gene = eval(text, {"__builtins__": {}}, {"Genotype": Genotype})
+    if not isinstance(gene, Genotype):
+        raise ValueError("not a Genotype: %r" % (text,))
+    return gene

@@ -151,3 +151,51 @@ def test_plateau_lr_matches_torch_scheduler():
             mine.step(float(l))
             assert abs(opt.param_groups[0]["lr"] - state["lr"]) < 1e-15
         assert state["lr"] < 1e-3  # the sequences are long enough to trigger at least one reduction
+
+
+def test_checkpoint_interop_with_torch_adam_and_scheduler(tmp_path):
+    """the trainer's flat Adam state and plateau scheduler round-trip through torch.optim.Adam /
+    ReduceLROnPlateau state-dicts in the reference's checkpoint layout (train.py:85-93, 52-67)."""
+    import torch
+    from nas_3d_unet_amd import checkpoint as ck, searched
+    from nas_3d_unet_amd.train import Trainer
+    gene = searched.Genotype(down=[("down_conv", 0), ("down_dil_conv", 1), ("down_conv", 1), ("conv", 2), ("dil_conv", 2), ("conv", 3)],
+                             up=[("conv", 0), ("up_conv", 1), ("up_conv", 1), ("dil_conv", 2), ("conv", 3), ("up_dil_conv", 1)])
+    net = searched.SearchedNet(4, 4, 3, 2, 3, True, gene)
+    tr = Trainer(net, graph=False)                       # construction only: no kernel runs on the CPU
+    g = torch.Generator().manual_seed(0)
+    tr.fp.exp_avg.copy_(torch.randn(tr.fp.numel, generator=g))
+    tr.fp.exp_avg_sq.copy_(torch.rand(tr.fp.numel, generator=g))
+    tr.fp.step.fill_(7)
+    tr.set_lr(2.5e-4)
+    tr.scheduler.best, tr.scheduler.num_bad_epochs, tr.scheduler.last_epoch = 0.31, 4, 12
+    sd = ck.train_state_dicts(tr, epoch=12, history={"loss": [0.5]}, best_loss=0.31)
+    assert set(sd) == {"epoch", "history", "model_param", "optim", "scheduler", "best_loss"}
+    path = tmp_path / "last.pth"
+    torch.save(sd, path)
+    sd2 = torch.load(path, weights_only=False)
+    # the reference side: plain torch objects accept the dictionaries
+    ref_net = searched.SearchedNet(4, 4, 3, 2, 3, True, gene)
+    ref_net.load_state_dict(sd2["model_param"])
+    opt = torch.optim.Adam(ref_net.parameters())
+    opt.load_state_dict(sd2["optim"])
+    sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5)
+    sch.load_state_dict(sd2["scheduler"])
+    assert opt.param_groups[0]["lr"] == 2.5e-4 and sch.best == 0.31 and sch.num_bad_epochs == 4
+    p0 = list(ref_net.parameters())[3]
+    o = tr.fp.offsets[3]
+    assert torch.equal(opt.state[p0]["exp_avg"], tr.fp.exp_avg[o:o + p0.numel()].view(p0.shape))
+    assert float(opt.state[p0]["step"]) == 7
+    # and back: a checkpoint written by torch objects resumes the trainer
+    tr2 = Trainer(searched.SearchedNet(4, 4, 3, 2, 3, True, gene), graph=False)
+    back = {"epoch": 12, "history": {}, "model_param": ref_net.state_dict(), "optim": opt.state_dict(), "scheduler": sch.state_dict(), "best_loss": 0.31}
+    epoch, _, best = ck.load_train_state_dicts(tr2, back)
+    assert epoch == 13 and best == 0.31 and tr2.lr == 2.5e-4 and int(tr2.fp.step) == 7
+    for p, o in zip(tr.fp.params, tr.fp.offsets):   # (the flat buffers pad every tensor to a multiple of 4 elements)
+        n = p.numel()
+        assert torch.equal(tr2.fp.exp_avg[o:o + n], tr.fp.exp_avg[o:o + n]) and torch.equal(tr2.fp.exp_avg_sq[o:o + n], tr.fp.exp_avg_sq[o:o + n])
+    assert torch.equal(tr2.fp.flat, tr.fp.flat) and tr2.scheduler.num_bad_epochs == 4
+    # genotype pickle (search.py:189-194, train.py:36-38)
+    gp = tmp_path / "best_genotype.pkl"
+    ck.save_genotype(gp, gene, 3)
+    assert ck.load_genotype(gp) == gene
