@@ -179,3 +179,10 @@ def poststep_pred():
     p[1, 2, :, 1] = p[2, 2, :, 1] = 0.9
     p[:, 3, 3, :] = 0.8                    # all three above the threshold
     return p
+
+
+def patching_cases():
+    """(img_shape, patch_shape, overlap, both_ps) for patches.patching"""
+    return [((155, 173, 140), (64, 64, 64), None, False), ((155, 173, 140), (64, 64, 64), 16, False),
+            ((155, 173, 140), (64, 64, 64), (8, 16, 32), True), ((60, 64, 130), (64, 64, 64), None, False),
+            ((128, 128, 128), (128, 128, 128), 0, True), ((200, 90, 65), (128, 128, 128), 32, False)]

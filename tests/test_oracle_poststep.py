@@ -19,3 +19,11 @@ def test_tumor_labels_oracle(golden):
     assert np.array_equal(ps.tumor_labels(pred, 0.5, True), g["tumor/inclusive"])
     assert np.array_equal(ps.tumor_labels(pred, 0.5, False), g["tumor/exclusive"])
     assert np.array_equal(ps.tumor_labels(pred, 0.3, False), g["tumor/exclusive_t03"])
+
+
+def test_patching_strategies_match_reference(golden):
+    """host logic of predict.patching (patches.py:9-70) against the reference's own corner lists"""
+    from nas_3d_unet_amd.predict import patching
+    g = golden("poststep")
+    for i, (img, patch, overlap, both) in enumerate(gc.patching_cases()):
+        assert np.array_equal(patching(img, patch, overlap=overlap, both_ps=both), g["patching/%d" % i]), (img, patch, overlap, both)
