@@ -535,16 +535,20 @@ extern "C" int n3d_debug_vox_stamps2(unsigned long long* host, int n) {
 #define WL_RD(idx) wl[idx]
 #endif
 
-template <int C, int TD, int DIL>
-__global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
-  constexpr int Q = C / 4, GH = 4, GW = 16;
+// NW = waves per workgroup (1 or 2).  With NW = 2 the workgroup owns an 8-row tile: each wave computes its own 4 rows
+// from ONE shared halo tile (6 x 10 x 18 positions instead of 2 x 6 x 6 x 18), which cuts the LDS-DMA instructions
+// per output voxel by 29 % -- the fill is bound by the texture-address path (16 cycles per 1 KiB instruction per CU).
+// The two waves split the fill chunk-wise and meet at ONE workgroup barrier before the MFMA phase.
+template <int C, int TD, int DIL, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv_vox64_kernel(VxArgs a) {
+  constexpr int Q = C / 4, GH = 4 * NW, GW = 16;
   constexpr int LD = TD + 2 * DIL, LH = GH + 2 * DIL, LW = GW + 2 * DIL;
   constexpr int PLANE = LH * LW, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64, QSTRIDE = LD * PSTRIDE;
   constexpr int NW4 = 27 * C * Q, NWI = (NW4 + 63) / 64;  // float4 count of the packed weights
   extern __shared__ __attribute__((aligned(16))) float4 vlds[];  // tile [Q][LD][PSTRIDE >= LH*LW], then weights [27][C][Q]
   float4* tile = vlds;
   float4* wl = vlds + Q * QSTRIDE;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // XCD-aware placement: workgroup ids are dealt round-robin to the 8 XCDs (private L2 each); remap so that every
   // XCD works on one contiguous run of tiles (a D-slab of one sample) and the halo re-reads of neighbouring tiles
   // hit that XCD's L2 instead of being fetched from HBM once per XCD.
@@ -570,11 +574,12 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
   // ds_read_b128 is serviced in ({0-3,12-15,20-27}, ...: 8 lanes of an even row + 8 of the next odd row) fall on
   // 64 distinct banks with the (16 + 2*DIL)-float4 row pitch (2-way conflicts on every A read otherwise)
   const int hh = lane >> 4, ww = ((lane & 15) - (hh & 1) * (LW % 16)) & 15;
+  const int hrow = 4 * wave + hh;  // row inside the workgroup's tile
   // bias and (accumulate mode) the previous output values are ordinary global loads: issued BEFORE the LDS-DMA
   // fill so that the single vmcnt(0) below covers them (a load after the fill would add a second memory latency)
   float* dstb = a.dst + (int64_t)b * N * a.dld;
   const bool accum = a.flags & N3D_ACCUMULATE;
-  const int64_t vox_off = ((int64_t)(h0 + hh) * a.W + w0 + ww);
+  const int64_t vox_off = ((int64_t)(h0 + 4 * wave + hh) * a.W + w0 + ww);
   float4 biasv[Q], prevv[TD][Q];
 #pragma unroll
   for (int hf = 0; hf < Q; ++hf) {
@@ -599,7 +604,8 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
     for (int i = 0; i < NWI; ++i) {
       const int idx = lane + i * 64;
 #ifndef VOX_NO_LOAD
-      __builtin_amdgcn_global_load_lds((gptr_t)(idx < NW4 ? wq4 + idx : zp), (lptr_t)(wl + i * 64), 16, 0, 0);
+      if (NW == 1 || (i % NW) == wave)
+        __builtin_amdgcn_global_load_lds((gptr_t)(idx < NW4 ? wq4 + idx : zp), (lptr_t)(wl + i * 64), 16, 0, 0);
 #endif
     }
     const int64_t pstride = (int64_t)a.H * a.W * a.sld;
@@ -610,8 +616,12 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
       const int gh = h0 - DIL + hy, gw = w0 - DIL + wx;
       const bool okp = pos < PLANE && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
       const float* prow = srcb + ((int64_t)gh * a.W + gw) * a.sld;
+      // the workgroup's waves take alternate planes (dz = m*NW + wave: no branch, only the plane address and the LDS
+      // destination depend on the wave)
+      static_assert(LD % NW == 0, "tile depth must split evenly over the waves");
 #pragma unroll
-      for (int dz = 0; dz < LD; ++dz) {
+      for (int m = 0; m < LD / NW; ++m) {
+        const int dz = m * NW + (NW > 1 ? wave : 0);
         const int gd = d0 - DIL + dz;
         const bool inb = okp && gd >= 0 && gd < a.D;
         const float* p = prow + gd * pstride;
@@ -627,6 +637,7 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
     VSTAMP(1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (NW > 1) __syncthreads();  // each wave reads rows the other wave's DMA filled
   VSTAMP(2);
 
   // accumulators: the WEIGHTS are the MFMA A operand (row i = output channel) and the voxels the B operand
@@ -645,8 +656,10 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) cs[hf][r] = cq[hf][r] = 0.f;
   // finished output plane g: statistics (of the convolution result itself) + one 16-byte store per lane and half
+  float* const o_plane0 = dstb + ((int64_t)d0 * a.H * a.W + vox_off) * a.dld;
+  const int64_t o_pstride = (int64_t)a.H * a.W * a.dld;
   auto emit_plane = [&](int g) {
-    float* o = dstb + (((int64_t)(d0 + g) * a.H * a.W) + vox_off) * a.dld;
+    float* o = o_plane0 + g * o_pstride;
 #pragma unroll
     for (int hf = 0; hf < Q; ++hf) {
       const f32x4 v = acc[g][hf];
@@ -678,13 +691,13 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
     // the nine A reads of plane dz+1 are issued before the MFMAs of plane dz (register double buffer)
     float4 avb[2][9];
 #pragma unroll
-    for (int t9 = 0; t9 < 9; ++t9) avb[0][t9] = TILE_RD((hh + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL));
+    for (int t9 = 0; t9 < 9; ++t9) avb[0][t9] = TILE_RD((hrow + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL));
 #pragma unroll
     for (int dz = 0; dz < LD; ++dz) {
       if (dz + 1 < LD) {
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9)
-          avb[(dz + 1) & 1][t9] = TILE_RD((dz + 1) * PSTRIDE + (hh + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL));
+          avb[(dz + 1) & 1][t9] = TILE_RD((dz + 1) * PSTRIDE + (hrow + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL));
       }
       if (dz == 0 || dz == DIL) {
         const int kd = dz / DIL + 1;
@@ -730,7 +743,7 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
         for (int hf = 0; hf < Q; ++hf)
 #pragma unroll
           for (int q = 0; q < Q; ++q) wr[kd][hf][q] = wl[((kd * 9 + t9) * C + hf * 4 + j) * Q + q];
-      const int base = (hh + kh * DIL) * LW + (ww + kw * DIL);
+      const int base = (hrow + kh * DIL) * LW + (ww + kw * DIL);
       float4 av[LD][Q];
 #pragma unroll
       for (int dz = 0; dz < LD; ++dz)
@@ -787,7 +800,7 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
       v1 = wave_classsum_f(v1, 4); v2 = wave_classsum_f(v2, 4);
       if (lane < 4) {
         const int ch = (lane & 1) * 2 + (lane >> 1);
-        double* o = a.stats + (((int64_t)b * a.rows_per_sample + tile_id) * C + hf * 4 + ch) * 2;
+        double* o = a.stats + (((int64_t)b * a.rows_per_sample + tile_id * NW + wave) * C + hf * 4 + ch) * 2;
         reinterpret_cast<double2*>(o)[0] = make_double2((double)v1, (double)v2);
       }
     }
@@ -800,7 +813,7 @@ __global__ __launch_bounds__(64, 2) void conv_vox64_kernel(VxArgs a) {
 #endif
 }
 
-struct VxPlan { bool ok; int C, td, dil, tiles; size_t lds; };
+struct VxPlan { bool ok; int C, td, dil, tiles, nw; size_t lds; };
 
 static VxPlan vx_plan(const n3d_conv_geom* g) {
   VxPlan p; p.ok = false;
@@ -817,9 +830,13 @@ static VxPlan vx_plan(const n3d_conv_geom* g) {
   if (getenv("VOX_TD")) td = atoi(getenv("VOX_TD"));
 #endif
   p.ok = true; p.C = g->Ci; p.td = td; p.dil = g->dil;
-  p.tiles = (W / 16) * (H / 4) * (D / td);
+  // two waves per workgroup on an 8-row tile (shared halo): pays for dilation 2, whose +-2 halo makes the single-wave
+  // tile 8 x 8 x 20 positions for 256 outputs (measured at (2,4,64^3): 12.8 -> 8.0 us); for dilation 1 it is neutral at
+  // 64^3 and 4 % slower at 128^3, so those keep one wave per workgroup
+  p.nw = (g->Ci == 4 && td == 4 && H % 8 == 0 && g->dil == 2) ? 2 : 1;
+  p.tiles = (W / 16) * (H / (4 * p.nw)) * (D / td);
   const int Q = g->Ci / 4;
-  const size_t pstride = ((size_t)(4 + 2 * g->dil) * (16 + 2 * g->dil) + 63) / 64 * 64;
+  const size_t pstride = ((size_t)(4 * p.nw + 2 * g->dil) * (16 + 2 * g->dil) + 63) / 64 * 64;
   p.lds = ((size_t)Q * (td + 2 * g->dil) * pstride + ((size_t)27 * g->Ci * Q + 63) / 64 * 64) * 16;
   return p;
 }
@@ -828,7 +845,10 @@ template <int C, int TD, int DIL>
 static int launch_vox_t(VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
   a.tiles = p.tiles;
   a.zero_page = zero_page_ptr();
-  hipLaunchKernelGGL((conv_vox64_kernel<C, TD, DIL>), dim3(p.tiles * B), dim3(64), p.lds, s, a);
+  if constexpr (C == 4 && TD == 4) {
+    if (p.nw == 2) { hipLaunchKernelGGL((conv_vox64_kernel<C, TD, DIL, 2>), dim3(p.tiles * B), dim3(128), p.lds, s, a); return 1; }
+  }
+  hipLaunchKernelGGL((conv_vox64_kernel<C, TD, DIL, 1>), dim3(p.tiles * B), dim3(64), p.lds, s, a);
   return 1;
 }
 
@@ -1048,7 +1068,7 @@ int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags) {
   if (flags & N3D_NO_MFMA) return 0;
   {
     VxPlan v = vx_plan(g);
-    if (v.ok) return v.tiles;
+    if (v.ok) return v.tiles * v.nw;  // one partial row per wave
   }
   G16Plan p = g16_plan(g, data_grad);
   if (!p.ok) return 0;
@@ -1090,7 +1110,7 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
         hipLaunchKernelGGL(pack_vox_kernel, dim3((unsigned)cdiv(27 * v.C * v.C, 256)), dim3(256), 0, s, w, wq, v.C, data_grad ? 1 : 0);
       VxArgs a;
       a.src = src; a.sld = sld; a.dst = dst; a.dld = dld; a.wq = wq; a.bias = bias; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.flags = flags;
-      a.stats = stats; a.rows_per_sample = v.tiles;
+      a.stats = stats; a.rows_per_sample = v.tiles * v.nw;
       if (v.C == 4) launch_vox_c<4>(a, v, g->B, s); else launch_vox_c<8>(a, v, g->B, s);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) { set_error("conv(vox64) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }

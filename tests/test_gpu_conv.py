@@ -45,6 +45,8 @@ CASES = [
     (8, 8, 3, 1, 2, False, 1, (8, 16, 16)),
     (4, 4, 3, 1, 2, False, 1, (4, 16, 16)),
     (8, 8, 3, 1, 1, False, 1, (4, 4, 64)),
+    (4, 4, 3, 1, 2, False, 2, (64, 64, 64)),     # dilation 2 at full size: two waves per workgroup on a shared 8-row halo tile
+    (4, 4, 3, 1, 1, False, 2, (64, 64, 64)),     # the roofline shape itself (TD = 4 tiles, XCD-ordered)
 ]
 
 
