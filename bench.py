@@ -71,7 +71,7 @@ def conv_kernel_roofline(device, batch, size, iters=40):
         side = torch.cuda.Stream(device=device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 for _ in range(iters):
                     K.conv_fwd(g, x, w, b, y, 0, None, stats, False)
     stream = torch.cuda.current_stream()
@@ -187,8 +187,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("N3D_FORCE_DP") == "1":   # (N3D_FORCE_DP: 1-rank RCCL group, exercises the N > 1 code path)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local)
@@ -247,7 +248,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.size)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -14,6 +14,8 @@ MI355X-first mechanics (none of which the reference has):
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -104,10 +106,11 @@ class GradSync:
         nb = max(1, min(n_buckets, n // 4 if n >= 4 else 1))
         self.edges = [n * i // nb // 4 * 4 for i in range(nb)] + [n]
         self.comm_stream = comm_stream
+        self.force = dist.is_initialized() and os.environ.get("N3D_FORCE_DP") == "1"  # see Trainer.dp_path
 
     def all_reduce(self):
         """sum-reduce every bucket; callers divide by world size (folded into the Adam kernel)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.comm_stream is not None:
             cs = self.comm_stream
@@ -147,7 +150,7 @@ class Trainer:
     no host sync).  With graph=True the first call captures, later calls replay."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph=True, process_group=None,
-                 n_buckets=2, params=None):
+                 n_buckets=1, params=None):
         self.model = model
         self.loss_fn = WeightedDiceLoss()
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -157,10 +160,13 @@ class Trainer:
         self.use_graph = graph
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        # N3D_FORCE_DP=1: take the multi-GPU code path (eager all-reduce on the comm stream + eager Adam after the graph)
+        # even in a 1-rank group -- lets a single-GPU box exercise exactly what N > 1 runs
+        self.dp_path = self.world > 1 or (dist.is_initialized() and os.environ.get("N3D_FORCE_DP") == "1")
         self.n_buckets = max(1, n_buckets)
         self._graph = None
         self._static_x = self._static_t = self._static_loss = None
-        self._comm_stream = torch.cuda.Stream(device=self.device) if self.world > 1 else None
+        self._comm_stream = torch.cuda.Stream(device=self.device) if self.dp_path else None
         self.ctx = K.StepContext(self.device)  # batched weight packing + deferred wgrad reductions
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)  # read by the Adam kernel
         self.scheduler = PlateauLR(lambda: self.lr, self.set_lr)  # train.py:50: ReduceLROnPlateau(factor=0.5)
@@ -199,7 +205,7 @@ class Trainer:
     def step(self, x, t):
         if not self.use_graph:
             loss = self._fwd_bwd(x, t)
-            if self.world > 1:
+            if self.dp_path:
                 self._allreduce()
             self._update()
             return loss
@@ -208,7 +214,7 @@ class Trainer:
         self._static_x.copy_(x)
         self._static_t.copy_(t)
         self._graph.replay()
-        if self.world > 1:
+        if self.dp_path:
             self._allreduce()
             self._update()
         return self._static_loss
@@ -227,9 +233,9 @@ class Trainer:
         torch.cuda.synchronize()
         self.fp.flat.copy_(keep)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):  # RCCL's watchdog thread may touch the runtime meanwhile
             self._static_loss = self._fwd_bwd(self._static_x, self._static_t)
-            if self.world == 1:
+            if not self.dp_path:
                 self._update()
         self._graph = g
 
@@ -323,7 +329,7 @@ class SearchTrainer:
                 z.zero_()
             self.fp.step.zero_(); self.a_step.zero_()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):  # RCCL's watchdog thread may touch the runtime meanwhile
                 self._losses = self._both(self._sx, self._st, self._svx, self._svt)
             self._graph = g
         self._sx.copy_(x); self._st.copy_(t); self._svx.copy_(val_x); self._svt.copy_(val_t)
