@@ -813,6 +813,220 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64_kernel(VxArgs a) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// vox_s2: the same 4x4x1-MFMA scheme for the STRIDE-2 3x3x3 convs with C = 4 / 8 (down_conv / down_dil_conv forward
+// and the data gradient of up_conv / up_dil_conv, which is a strided gather of dy):
+//   out[o] = bias + sum_tap W[tap] . x[2*o - pad + tap*dil]          (pad == dil)
+// One wave = one workgroup = TD x 4 x 16 output voxels; the (2*TD-1+2*dil) x (7+2*dil) x (31+2*dil) input region is
+// filled by LDS-DMA.  Lanes read the tile with a voxel stride of 2, so the fill DE-INTERLEAVES each row by W parity
+// (the per-lane source address of the DMA is free): row = [even w | odd w], and the 16 lanes of a row read 16
+// consecutive float4 again; odd tile rows are rotated so that the fixed 16-lane groups of ds_read_b128 hit 64
+// distinct banks.  Loop: (kh,kw) outer with the three kd weight sets in registers, input plane inner.
+// ------------------------------------------------------------------------------------------------
+struct Vs2Args {
+  const float* src; int64_t sld; int D, H, W;      // input tensor
+  float* dst; int64_t dld; int oD, oH, oW;         // output tensor (= ceil(in / 2))
+  const float* wq; const float* bias; int flags;
+  double* stats; int rows_per_sample; int tiles; const void* zero_page;
+};
+
+template <int C, int TD, int DIL>
+__global__ __launch_bounds__(64, 2) void conv_vox_s2_kernel(Vs2Args a) {
+  constexpr int Q = C / 4;
+  constexpr int LD = 2 * (TD - 1) + 2 * DIL + 1, LH = 7 + 2 * DIL, LW = 31 + 2 * DIL;
+  constexpr int HW = (LW + 1) / 2, RW = 2 * HW;              // half-row (one W parity) and row pitch in float4
+  constexpr int PLANE = LH * RW, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64, QSTRIDE = LD * PSTRIDE;
+  constexpr int NW4 = 27 * C * Q, NWI = (NW4 + 63) / 64;
+  constexpr int ROT = ((2 * RW * 4) % 64) / 4;               // voxels odd lane rows are rotated by (bank-conflict-free reads)
+  extern __shared__ __attribute__((aligned(16))) float4 vlds[];
+  float4* tile = vlds;
+  float4* wl = vlds + Q * QSTRIDE;
+  const int lane = threadIdx.x;
+  int wg = blockIdx.x;
+  {  // XCD-aware placement (see conv_vox64_kernel)
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int b = wg / a.tiles;
+  const int tile_id = wg - b * a.tiles;
+  const int tw_n = a.oW / 16, th_n = a.oH / 4;
+  int bx = tile_id;
+  const int w0 = (bx % tw_n) * 16; bx /= tw_n;
+  const int h0 = (bx % th_n) * 4;
+  const int d0 = (bx / th_n) * TD;
+  const int64_t Ns = (int64_t)a.D * a.H * a.W, Nd = (int64_t)a.oD * a.oH * a.oW;
+  const float* srcb = a.src + (int64_t)b * Ns * a.sld;
+  float* dstb = a.dst + (int64_t)b * Nd * a.dld;
+  const int j = lane & 3;
+  const int hh = lane >> 4, ww = ((lane & 15) - (hh & 1) * ROT) & 15;
+  const bool accum = a.flags & N3D_ACCUMULATE;
+  const int64_t vox_off = ((int64_t)(h0 + hh) * a.oW + w0 + ww);
+  float4 biasv[Q], prevv[TD][Q];
+#pragma unroll
+  for (int hf = 0; hf < Q; ++hf) {
+    biasv[hf] = a.bias ? *reinterpret_cast<const float4*>(a.bias + hf * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < TD; ++g)
+      prevv[g][hf] = accum ? *reinterpret_cast<const float4*>(dstb + (((int64_t)(d0 + g) * a.oH * a.oW) + vox_off) * a.dld + hf * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const float4* __restrict__ wq4 = reinterpret_cast<const float4*>(a.wq);
+    const float4* zp = reinterpret_cast<const float4*>(a.zero_page);
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      const int idx = lane + i * 64;
+      __builtin_amdgcn_global_load_lds((gptr_t)(idx < NW4 ? wq4 + idx : zp), (lptr_t)(wl + i * 64), 16, 0, 0);
+    }
+    const int64_t pstride = (int64_t)a.H * a.W * a.sld;
+    const int id0 = 2 * d0 - DIL, ih0 = 2 * h0 - DIL, iw0 = 2 * w0 - DIL;
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+      const int pos = lane + i * 64;                       // LDS slot in the plane: [row][parity][half]
+      const int row = pos / RW, rem = pos - row * RW;
+      const int par = rem / HW, half = rem - par * HW;
+      const int wx = 2 * half + par;                       // local input w
+      const int gh = ih0 + row, gw = iw0 + wx;
+      const bool okp = pos < PLANE && wx < LW && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      const float* prow = srcb + ((int64_t)gh * a.W + gw) * a.sld;
+#pragma unroll
+      for (int dz = 0; dz < LD; ++dz) {
+        const int gd = id0 + dz;
+        const bool inb = okp && gd >= 0 && gd < a.D;
+        const float* p = prow + gd * pstride;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          __builtin_amdgcn_global_load_lds((gptr_t)(inb ? reinterpret_cast<const float4*>(p + q * 4) : zp),
+                                           (lptr_t)(tile + q * QSTRIDE + dz * PSTRIDE + i * 64), 16, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  f32x4 acc[TD][Q];
+#pragma unroll
+  for (int hf = 0; hf < Q; ++hf) {
+    const f32x4 bv = {biasv[hf].x, biasv[hf].y, biasv[hf].z, biasv[hf].w};
+#pragma unroll
+    for (int g = 0; g < TD; ++g) acc[g][hf] = bv;
+  }
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9) {
+    const int kh = t9 / 3, kw = t9 % 3;
+    float4 wr[3][Q][Q];  // [kd][half][quad]
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int hf = 0; hf < Q; ++hf)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) wr[kd][hf][q] = wl[((kd * 9 + t9) * C + hf * 4 + j) * Q + q];
+    // input voxel (2*hh + kh*DIL, 2*ww + kw*DIL): W parity and half index are wave-uniform / lane-linear
+    const int base = (2 * hh + kh * DIL) * RW + ((kw * DIL) & 1) * HW + ww + ((kw * DIL) >> 1);
+    float4 av[LD][Q];
+#pragma unroll
+    for (int dz = 0; dz < LD; ++dz)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) av[dz][q] = tile[q * QSTRIDE + dz * PSTRIDE + base];
+#pragma unroll
+    for (int dz = 0; dz < LD; ++dz) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xe = e == 0 ? av[dz][q].x : (e == 1 ? av[dz][q].y : (e == 2 ? av[dz][q].z : av[dz][q].w));
+#pragma unroll
+          for (int kd = 0; kd < 3; ++kd) {
+            const int g2 = dz - kd * DIL;                 // = 2 * output plane
+            if (g2 >= 0 && (g2 & 1) == 0 && (g2 >> 1) < TD) {
+#pragma unroll
+              for (int hf = 0; hf < Q; ++hf) {
+                const float4 wv = wr[kd][hf][q];
+                const float we = e == 0 ? wv.x : (e == 1 ? wv.y : (e == 2 ? wv.z : wv.w));
+                acc[g2 >> 1][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(we, xe, acc[g2 >> 1][hf], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- epilogue: statistics of the convolution result + one 16-byte store per lane and half
+  float cs[Q][4], cq[Q][4];
+#pragma unroll
+  for (int hf = 0; hf < Q; ++hf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[hf][r] = cq[hf][r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < TD; ++g) {
+    float* o = dstb + (((int64_t)(d0 + g) * a.oH * a.oW) + vox_off) * a.dld;
+#pragma unroll
+    for (int hf = 0; hf < Q; ++hf) {
+      const f32x4 v = acc[g][hf];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { cs[hf][r] += v[r]; cq[hf][r] = fmaf(v[r], v[r], cq[hf][r]); }
+      const float4 pv = prevv[g][hf];
+      *reinterpret_cast<float4*>(o + hf * 4) = make_float4(v[0] + pv.x, v[1] + pv.y, v[2] + pv.z, v[3] + pv.w);
+    }
+  }
+  if (a.stats) {
+    const bool odd = lane & 1, hi = lane & 2;
+#pragma unroll
+    for (int hf = 0; hf < Q; ++hf) {
+      float u[2], uq[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float keep = odd ? cs[hf][2 + k] : cs[hf][k], send = odd ? cs[hf][k] : cs[hf][2 + k];
+        u[k] = keep + dpp_f<0xB1>(send);
+        const float keepq = odd ? cq[hf][2 + k] : cq[hf][k], sendq = odd ? cq[hf][k] : cq[hf][2 + k];
+        uq[k] = keepq + dpp_f<0xB1>(sendq);
+      }
+      float v1 = (hi ? u[1] : u[0]) + dpp_f<0x4E>(hi ? u[0] : u[1]);
+      float v2 = (hi ? uq[1] : uq[0]) + dpp_f<0x4E>(hi ? uq[0] : uq[1]);
+      v1 = wave_classsum_f(v1, 4); v2 = wave_classsum_f(v2, 4);
+      if (lane < 4) {
+        const int ch = (lane & 1) * 2 + (lane >> 1);
+        double* o = a.stats + (((int64_t)b * a.rows_per_sample + tile_id) * C + hf * 4 + ch) * 2;
+        reinterpret_cast<double2*>(o)[0] = make_double2((double)v1, (double)v2);
+      }
+    }
+  }
+}
+
+struct Vs2Plan { bool ok; int C, td, dil, tiles; size_t lds; };
+
+// forward-type gathers only (conv forward with stride 2; data gradient of a stride-2 transposed conv)
+static Vs2Plan vs2_plan(const n3d_conv_geom* g, bool data_grad) {
+  Vs2Plan p; p.ok = false;
+  if (data_grad || g->depthwise || g->k != 3 || g->stride != 2 || g->Ci != g->Co || (g->Ci != 4 && g->Ci != 8)) return p;
+  if (!(g->dil == 1 || g->dil == 2) || g->pad != g->dil) return p;
+  if (g->Wo % 16 != 0 || g->Ho % 4 != 0) return p;
+  p.C = g->Ci; p.dil = g->dil;
+  p.td = (g->Ci == 4 && g->Do % 2 == 0) ? 2 : 1;
+  p.tiles = (g->Wo / 16) * (g->Ho / 4) * (g->Do / p.td);
+  const int Q = g->Ci / 4;
+  const int LD = 2 * (p.td - 1) + 2 * g->dil + 1, LH = 7 + 2 * g->dil, LW = 31 + 2 * g->dil;
+  const size_t pstride = ((size_t)LH * 2 * ((LW + 1) / 2) + 63) / 64 * 64;
+  p.lds = ((size_t)Q * LD * pstride + ((size_t)27 * g->Ci * Q + 63) / 64 * 64) * 16;
+  p.ok = p.lds <= 160 * 1024;
+  return p;
+}
+
+template <int C, int TD, int DIL>
+static void launch_vs2_t(Vs2Args& a, const Vs2Plan& p, int B, hipStream_t s) {
+  hipLaunchKernelGGL((conv_vox_s2_kernel<C, TD, DIL>), dim3(p.tiles * B), dim3(64), p.lds, s, a);
+}
+
+static void launch_vs2(Vs2Args& a, const Vs2Plan& p, int B, hipStream_t s) {
+  if (p.C == 4) {
+    if (p.td == 2) { if (p.dil == 1) launch_vs2_t<4, 2, 1>(a, p, B, s); else launch_vs2_t<4, 2, 2>(a, p, B, s); }
+    else { if (p.dil == 1) launch_vs2_t<4, 1, 1>(a, p, B, s); else launch_vs2_t<4, 1, 2>(a, p, B, s); }
+  } else {
+    if (p.dil == 1) launch_vs2_t<8, 1, 1>(a, p, B, s); else launch_vs2_t<8, 1, 2>(a, p, B, s);
+  }
+}
+
 struct VxPlan { bool ok; int C, td, dil, tiles, nw; size_t lds; };
 
 static VxPlan vx_plan(const n3d_conv_geom* g) {
@@ -1059,7 +1273,7 @@ static G16Plan g16_plan(const n3d_conv_geom* g, bool data_grad) {
 
 int mfma_pack_layout(const n3d_conv_geom* g, bool data_grad, int flags) {
   if (flags & N3D_NO_MFMA) return 0;
-  if (vx_plan(g).ok) return 2;
+  if (vx_plan(g).ok || vs2_plan(g, data_grad).ok) return 2;
   if (g16_plan(g, data_grad).ok) return 1;
   return 0;
 }
@@ -1069,6 +1283,8 @@ int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags) {
   {
     VxPlan v = vx_plan(g);
     if (v.ok) return v.tiles * v.nw;  // one partial row per wave
+    Vs2Plan v2 = vs2_plan(g, data_grad);
+    if (v2.ok) return v2.tiles;
   }
   G16Plan p = g16_plan(g, data_grad);
   if (!p.ok) return 0;
@@ -1097,6 +1313,25 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
                   int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate, double* stats,
                   void* ws, size_t ws_bytes, hipStream_t s) {
   {
+    Vs2Plan v2 = vs2_plan(g, data_grad);
+    if (v2.ok) {
+      if (in_gate || relu_src || out_gate || (flags & N3D_RELU_IN) || sld % 4 != 0 || dld % 4 != 0 || !aligned16(src) || !aligned16(dst)) {
+        if (stats || (flags & N3D_PREPACKED)) { set_error("conv(vox_s2): gate / relu extras are not supported on this shape with statistics or pre-packed weights"); return N3D_ERR_UNSUPPORTED; }
+        return 0;
+      }
+      const size_t need = (size_t)27 * v2.C * v2.C * 4;
+      if (!ws || ws_bytes < need) { set_error("conv(vox_s2): workspace too small"); return N3D_ERR_WORKSPACE; }
+      float* wq = (float*)ws;
+      if (!(flags & N3D_PREPACKED))
+        hipLaunchKernelGGL(pack_vox_kernel, dim3((unsigned)cdiv(27 * v2.C * v2.C, 256)), dim3(256), 0, s, w, wq, v2.C, 0);
+      Vs2Args a;
+      a.src = src; a.sld = sld; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.dst = dst; a.dld = dld; a.oD = g->Do; a.oH = g->Ho; a.oW = g->Wo;
+      a.wq = wq; a.bias = bias; a.flags = flags; a.stats = stats; a.rows_per_sample = v2.tiles; a.tiles = v2.tiles; a.zero_page = zero_page_ptr();
+      launch_vs2(a, v2, g->B, s);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) { set_error("conv(vox_s2) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+      return 1;
+    }
     VxPlan v = vx_plan(g);
     if (v.ok) {
       if (in_gate || relu_src || out_gate || (flags & N3D_RELU_IN) || sld % 4 != 0 || dld % 4 != 0 || !aligned16(src) || !aligned16(dst)) {

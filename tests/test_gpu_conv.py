@@ -45,6 +45,14 @@ CASES = [
     (8, 8, 3, 1, 2, False, 1, (8, 16, 16)),
     (4, 4, 3, 1, 2, False, 1, (4, 16, 16)),
     (8, 8, 3, 1, 1, False, 1, (4, 4, 64)),
+    # vox_s2 (stride-2 MFMA kernel, parity-deinterleaved LDS tile): forward of strided convs, data gradient of transposed ones
+    (8, 8, 3, 2, 1, False, 2, (8, 8, 32)),
+    (8, 8, 3, 2, 2, False, 2, (4, 8, 32)),
+    (4, 4, 3, 2, 1, False, 2, (8, 16, 32)),
+    (4, 4, 3, 2, 2, False, 1, (6, 8, 64)),
+    (8, 8, 3, 2, 1, True, 2, (4, 4, 16)),
+    (4, 4, 3, 2, 2, True, 2, (4, 8, 16)),
+    (4, 4, 3, 2, 1, True, 1, (32, 32, 32)),
     (4, 4, 3, 1, 2, False, 2, (64, 64, 64)),     # dilation 2 at full size: two waves per workgroup on a shared 8-row halo tile
     (4, 4, 3, 1, 1, False, 2, (64, 64, 64)),     # the roofline shape itself (TD = 4 tiles, XCD-ordered)
 ]
