@@ -710,7 +710,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
     const int C = Co;
     if (i >= 27 * C * C) return;
     const int cs = i % C, cd = (i / C) % C, tap = i / (C * C);
-    const int co = jb.data_grad ? cs : cd, ci = jb.data_grad ? cd : cs, t2 = jb.data_grad ? 26 - tap : tap;
+    // layout 2: vox64 / vox_s2 (data gradient: channels transposed + taps flipped); layout 3: vox_up (channels transposed only)
+    const int co = jb.data_grad ? cs : cd, ci = jb.data_grad ? cd : cs, t2 = (jb.data_grad && jb.layout == 2) ? 26 - tap : tap;
     jb.dst[i] = jb.w[((int64_t)co * C + ci) * 27 + t2];
   }
 }
@@ -1274,7 +1275,7 @@ int n3d_conv_pack_info(const n3d_conv_geom* g, int data_grad, int flags, int32_t
   const int Cs = data_grad ? g->Co : g->Ci, Cd = data_grad ? g->Ci : g->Co;
   if (g->depthwise) { *layout = -1; *cdp = 0; *floats = 0; return N3D_OK; }  // depthwise kernels read native weights
   const int ml = mfma_pack_layout(g, data_grad != 0, flags);
-  if (ml == 2) { *layout = 2; *cdp = Cd; *floats = (int64_t)27 * Cd * Cs; return N3D_OK; }
+  if (ml == 2 || ml == 3) { *layout = ml; *cdp = Cd; *floats = (int64_t)27 * Cd * Cs; return N3D_OK; }
   if (ml == 1) { *layout = 1; *cdp = Cd; *floats = (int64_t)taps * Cs * Cd; return N3D_OK; }
   const int cot = pick_cot(Cd);
   *layout = 0; *cdp = (int)align_up(Cd, cot); *floats = (int64_t)taps * Cs * (*cdp);

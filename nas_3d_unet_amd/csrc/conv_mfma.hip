@@ -501,7 +501,9 @@ __global__ void pack_vox_kernel(const float* __restrict__ w, float* __restrict__
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 27 * C * C) return;
   const int cs = i % C, cd = (i / C) % C, tap = i / (C * C);
-  const int co = data_grad ? cs : cd, ci = data_grad ? cd : cs, t2 = data_grad ? 26 - tap : tap;
+  // data_grad: 0 forward; 1 stride-1 data gradient (channels transposed, taps flipped); 2 gather form of the stride-2
+  // data gradient / transposed forward (channels transposed, taps as they are: the gather map carries the direction)
+  const int co = data_grad ? cs : cd, ci = data_grad ? cd : cs, t2 = data_grad == 1 ? 26 - tap : tap;
   wq[i] = w[((int64_t)co * C + ci) * 27 + t2];
 }
 
@@ -1027,6 +1029,212 @@ static void launch_vs2(Vs2Args& a, const Vs2Plan& p, int B, hipStream_t s) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// vox_up: stride-2 3x3x3 TRANSPOSED conv forward (up_conv / up_dil_conv) and the data gradient of the stride-2 convs,
+// C = 4 / 8: the output grid is twice the source grid, out[o] = bias + sum_k W[k] . x[(o + pad - k*dil) / 2] over the taps
+// whose index is even.  A wave owns 4 x 16 SOURCE voxels j of one source plane and produces all 8 output parity
+// classes (2*j + p) of them from one LDS halo tile (3 x 6 x 18): per dimension a source shift s feeds
+//   dil = 1:  s =  0 -> (p = 0, k = 1) and (p = 1, k = 2);  s = +1 -> (p = 1, k = 0)
+//   dil = 2:  s in {-1, 0, +1} -> (p = 0, k = 1 - s)         (odd outputs receive the bias only)
+// so the 27 taps are spread over 8 accumulator sets (27 * Cin * Cout/4 MFMAs per 64 source voxels, none wasted).
+// The generic gather walked every tap for every output voxel and masked 19 of 27.
+// ------------------------------------------------------------------------------------------------
+struct VupArgs {
+  const float* src; int64_t sld; int D, H, W;      // source tensor (the small grid)
+  float* dst; int64_t dld;                         // output tensor (2D x 2H x 2W)
+  const float* wq; const float* bias; int flags;
+  double* stats; int rows_per_sample; int tiles; const void* zero_page;
+};
+
+__host__ __device__ constexpr int vup_count(int dil, int s) { return dil == 2 ? 1 : (s == 0 ? 2 : (s == 1 ? 1 : 0)); }
+__host__ __device__ constexpr int vup_p(int dil, int s, int i) { return dil == 2 ? 0 : (s == 0 ? i : 1); }
+__host__ __device__ constexpr int vup_k(int dil, int s, int i) { return dil == 2 ? 1 - s : (s == 0 ? 1 + i : 0); }
+
+template <int C, int DIL>
+__global__ __launch_bounds__(64, 2) void conv_vox_up_kernel(VupArgs a) {
+  constexpr int Q = C / 4;
+  constexpr int LD = 3, LH = 6, LW = 18;
+  constexpr int PLANE = LH * LW, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64, QSTRIDE = LD * PSTRIDE;
+  constexpr int NW4 = 27 * C * Q, NWI = (NW4 + 63) / 64;
+  extern __shared__ __attribute__((aligned(16))) float4 vlds[];
+  float4* tile = vlds;
+  float4* wl = vlds + Q * QSTRIDE;
+  const int lane = threadIdx.x;
+  int wg = blockIdx.x;
+  {  // XCD-aware placement (see conv_vox64_kernel)
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int b = wg / a.tiles;
+  const int tile_id = wg - b * a.tiles;
+  const int tw_n = a.W / 16, th_n = a.H / 4;
+  int bx = tile_id;
+  const int w0 = (bx % tw_n) * 16; bx /= tw_n;
+  const int h0 = (bx % th_n) * 4;
+  const int d0 = bx / th_n;
+  const int64_t Ns = (int64_t)a.D * a.H * a.W;
+  const int oH = 2 * a.H, oW = 2 * a.W;
+  const float* srcb = a.src + (int64_t)b * Ns * a.sld;
+  float* dstb = a.dst + (int64_t)b * 8 * Ns * a.dld;
+  const int j = lane & 3;
+  const int hh = lane >> 4, ww = ((lane & 15) - (hh & 1) * (LW % 16)) & 15;   // bank-conflict-free row rotation (vox64)
+  const bool accum = a.flags & N3D_ACCUMULATE;
+  // output voxel of class (pd, ph, pw): (2*d0 + pd, 2*(h0+hh) + ph, 2*(w0+ww) + pw)
+  const int64_t obase = (((int64_t)(2 * d0) * oH + 2 * (h0 + hh)) * oW + 2 * (w0 + ww)) * a.dld;
+  auto ooff = [&](int cls) { return (((int64_t)(cls >> 2) * oH + ((cls >> 1) & 1)) * oW + (cls & 1)) * a.dld; };
+  float4 biasv[Q], prevv[8][Q];
+#pragma unroll
+  for (int hf = 0; hf < Q; ++hf) {
+    biasv[hf] = a.bias ? *reinterpret_cast<const float4*>(a.bias + hf * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int cls = 0; cls < 8; ++cls)
+      prevv[cls][hf] = accum ? *reinterpret_cast<const float4*>(dstb + obase + ooff(cls) + hf * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const float4* __restrict__ wq4 = reinterpret_cast<const float4*>(a.wq);
+    const float4* zp = reinterpret_cast<const float4*>(a.zero_page);
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      const int idx = lane + i * 64;
+      __builtin_amdgcn_global_load_lds((gptr_t)(idx < NW4 ? wq4 + idx : zp), (lptr_t)(wl + i * 64), 16, 0, 0);
+    }
+    const int64_t pstride = (int64_t)a.H * a.W * a.sld;
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+      const int pos = lane + i * 64;
+      const int wx = pos % LW, hy = pos / LW;
+      const int gh = h0 - 1 + hy, gw = w0 - 1 + wx;
+      const bool okp = pos < PLANE && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      const float* prow = srcb + ((int64_t)gh * a.W + gw) * a.sld;
+#pragma unroll
+      for (int dz = 0; dz < LD; ++dz) {
+        const int gd = d0 - 1 + dz;
+        const bool inb = okp && gd >= 0 && gd < a.D;
+        const float* p = prow + gd * pstride;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          __builtin_amdgcn_global_load_lds((gptr_t)(inb ? reinterpret_cast<const float4*>(p + q * 4) : zp),
+                                           (lptr_t)(tile + q * QSTRIDE + dz * PSTRIDE + i * 64), 16, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  f32x4 acc[8][Q];
+#pragma unroll
+  for (int hf = 0; hf < Q; ++hf) {
+    const f32x4 bv = {biasv[hf].x, biasv[hf].y, biasv[hf].z, biasv[hf].w};
+#pragma unroll
+    for (int cls = 0; cls < 8; ++cls) acc[cls][hf] = bv;
+  }
+#pragma unroll
+  for (int sd = -1; sd <= 1; ++sd) {
+    if (vup_count(DIL, sd) == 0) continue;
+    // the source positions of this plane that feed anything are requested first, then consumed
+    float4 av[3][3][Q];
+#pragma unroll
+    for (int sh = -1; sh <= 1; ++sh)
+#pragma unroll
+      for (int sw = -1; sw <= 1; ++sw)
+        if (vup_count(DIL, sh) > 0 && vup_count(DIL, sw) > 0) {
+#pragma unroll
+          for (int q = 0; q < Q; ++q) av[sh + 1][sw + 1][q] = tile[q * QSTRIDE + (1 + sd) * PSTRIDE + (hh + 1 + sh) * LW + (ww + 1 + sw)];
+        }
+#pragma unroll
+    for (int sh = -1; sh <= 1; ++sh)
+#pragma unroll
+      for (int sw = -1; sw <= 1; ++sw) {
+        if (vup_count(DIL, sh) == 0 || vup_count(DIL, sw) == 0) continue;
+#pragma unroll
+        for (int id = 0; id < vup_count(DIL, sd); ++id)
+#pragma unroll
+          for (int ih = 0; ih < vup_count(DIL, sh); ++ih)
+#pragma unroll
+            for (int iw = 0; iw < vup_count(DIL, sw); ++iw) {
+              const int cls = vup_p(DIL, sd, id) * 4 + vup_p(DIL, sh, ih) * 2 + vup_p(DIL, sw, iw);
+              const int tap = vup_k(DIL, sd, id) * 9 + vup_k(DIL, sh, ih) * 3 + vup_k(DIL, sw, iw);
+              float4 wr[Q][Q];
+#pragma unroll
+              for (int hf = 0; hf < Q; ++hf)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) wr[hf][q] = wl[(tap * C + hf * 4 + j) * Q + q];
+#pragma unroll
+              for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float4 x4 = av[sh + 1][sw + 1][q];
+                  const float xe = e == 0 ? x4.x : (e == 1 ? x4.y : (e == 2 ? x4.z : x4.w));
+#pragma unroll
+                  for (int hf = 0; hf < Q; ++hf) {
+                    const float4 wv = wr[hf][q];
+                    const float we = e == 0 ? wv.x : (e == 1 ? wv.y : (e == 2 ? wv.z : wv.w));
+                    acc[cls][hf] = __builtin_amdgcn_mfma_f32_4x4x1f32(we, xe, acc[cls][hf], 0, 0, 0);
+                  }
+                }
+            }
+      }
+  }
+  // ---- epilogue: 8 stores of 16 bytes per lane and half (the two W classes of a lane are adjacent voxels)
+  float cs[Q][4], cq[Q][4];
+#pragma unroll
+  for (int hf = 0; hf < Q; ++hf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[hf][r] = cq[hf][r] = 0.f;
+#pragma unroll
+  for (int cls = 0; cls < 8; ++cls) {
+    float* o = dstb + obase + ooff(cls);
+#pragma unroll
+    for (int hf = 0; hf < Q; ++hf) {
+      const f32x4 v = acc[cls][hf];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { cs[hf][r] += v[r]; cq[hf][r] = fmaf(v[r], v[r], cq[hf][r]); }
+      const float4 pv = prevv[cls][hf];
+      *reinterpret_cast<float4*>(o + hf * 4) = make_float4(v[0] + pv.x, v[1] + pv.y, v[2] + pv.z, v[3] + pv.w);
+    }
+  }
+  if (a.stats) {
+    const bool odd = lane & 1, hi = lane & 2;
+#pragma unroll
+    for (int hf = 0; hf < Q; ++hf) {
+      float u[2], uq[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float keep = odd ? cs[hf][2 + k] : cs[hf][k], send = odd ? cs[hf][k] : cs[hf][2 + k];
+        u[k] = keep + dpp_f<0xB1>(send);
+        const float keepq = odd ? cq[hf][2 + k] : cq[hf][k], sendq = odd ? cq[hf][k] : cq[hf][2 + k];
+        uq[k] = keepq + dpp_f<0xB1>(sendq);
+      }
+      float v1 = (hi ? u[1] : u[0]) + dpp_f<0x4E>(hi ? u[0] : u[1]);
+      float v2 = (hi ? uq[1] : uq[0]) + dpp_f<0x4E>(hi ? uq[0] : uq[1]);
+      v1 = wave_classsum_f(v1, 4); v2 = wave_classsum_f(v2, 4);
+      if (lane < 4) {
+        const int ch = (lane & 1) * 2 + (lane >> 1);
+        double* o = a.stats + (((int64_t)b * a.rows_per_sample + tile_id) * C + hf * 4 + ch) * 2;
+        reinterpret_cast<double2*>(o)[0] = make_double2((double)v1, (double)v2);
+      }
+    }
+  }
+}
+
+struct VupPlan { bool ok; int C, dil, tiles; size_t lds; };
+
+// gather form with den = 2 only (transposed conv forward with stride 2; data gradient of a stride-2 conv) on exactly doubled grids
+static VupPlan vup_plan(const n3d_conv_geom* g, bool data_grad) {
+  VupPlan p; p.ok = false;
+  if (!data_grad || g->depthwise || g->k != 3 || g->stride != 2 || g->Ci != g->Co || (g->Ci != 4 && g->Ci != 8)) return p;
+  if (!(g->dil == 1 || g->dil == 2) || g->pad != g->dil) return p;
+  if (g->Di != 2 * g->Do || g->Hi != 2 * g->Ho || g->Wi != 2 * g->Wo) return p;
+  if (g->Wo % 16 != 0 || g->Ho % 4 != 0) return p;
+  p.C = g->Ci; p.dil = g->dil;
+  p.tiles = (g->Wo / 16) * (g->Ho / 4) * g->Do;
+  const int Q = g->Ci / 4;
+  p.lds = ((size_t)Q * 3 * 128 + ((size_t)27 * g->Ci * Q + 63) / 64 * 64) * 16;
+  p.ok = true;
+  return p;
+}
+
 struct VxPlan { bool ok; int C, td, dil, tiles, nw; size_t lds; };
 
 static VxPlan vx_plan(const n3d_conv_geom* g) {
@@ -1273,6 +1481,7 @@ static G16Plan g16_plan(const n3d_conv_geom* g, bool data_grad) {
 
 int mfma_pack_layout(const n3d_conv_geom* g, bool data_grad, int flags) {
   if (flags & N3D_NO_MFMA) return 0;
+  if (vup_plan(g, data_grad).ok) return 3;   // vox layout, channels transposed, taps not flipped
   if (vx_plan(g).ok || vs2_plan(g, data_grad).ok) return 2;
   if (g16_plan(g, data_grad).ok) return 1;
   return 0;
@@ -1285,6 +1494,8 @@ int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags) {
     if (v.ok) return v.tiles * v.nw;  // one partial row per wave
     Vs2Plan v2 = vs2_plan(g, data_grad);
     if (v2.ok) return v2.tiles;
+    VupPlan v3 = vup_plan(g, data_grad);
+    if (v3.ok) return v3.tiles;
   }
   G16Plan p = g16_plan(g, data_grad);
   if (!p.ok) return 0;
@@ -1330,6 +1541,28 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
       launch_vs2(a, v2, g->B, s);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) { set_error("conv(vox_s2) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+      return 1;
+    }
+    VupPlan v3 = vup_plan(g, data_grad);
+    if (v3.ok) {
+      if (in_gate || relu_src || out_gate || (flags & N3D_RELU_IN) || sld % 4 != 0 || dld % 4 != 0 || !aligned16(src) || !aligned16(dst)) {
+        if (stats || (flags & N3D_PREPACKED)) { set_error("conv(vox_up): gate / relu extras are not supported on this shape with statistics or pre-packed weights"); return N3D_ERR_UNSUPPORTED; }
+        return 0;
+      }
+      const size_t need = (size_t)27 * v3.C * v3.C * 4;
+      if (!ws || ws_bytes < need) { set_error("conv(vox_up): workspace too small"); return N3D_ERR_WORKSPACE; }
+      float* wq = (float*)ws;
+      if (!(flags & N3D_PREPACKED))
+        hipLaunchKernelGGL(pack_vox_kernel, dim3((unsigned)cdiv(27 * v3.C * v3.C, 256)), dim3(256), 0, s, w, wq, v3.C, 2);
+      VupArgs a;
+      a.src = src; a.sld = sld; a.D = g->Do; a.H = g->Ho; a.W = g->Wo; a.dst = dst; a.dld = dld;
+      a.wq = wq; a.bias = bias; a.flags = flags; a.stats = stats; a.rows_per_sample = v3.tiles; a.tiles = v3.tiles; a.zero_page = zero_page_ptr();
+      if (v3.C == 4) { if (v3.dil == 1) hipLaunchKernelGGL((conv_vox_up_kernel<4, 1>), dim3(v3.tiles * g->B), dim3(64), v3.lds, s, a);
+                       else hipLaunchKernelGGL((conv_vox_up_kernel<4, 2>), dim3(v3.tiles * g->B), dim3(64), v3.lds, s, a); }
+      else { if (v3.dil == 1) hipLaunchKernelGGL((conv_vox_up_kernel<8, 1>), dim3(v3.tiles * g->B), dim3(64), v3.lds, s, a);
+             else hipLaunchKernelGGL((conv_vox_up_kernel<8, 2>), dim3(v3.tiles * g->B), dim3(64), v3.lds, s, a); }
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) { set_error("conv(vox_up) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
       return 1;
     }
     VxPlan v = vx_plan(g);
