@@ -18,6 +18,7 @@ from . import programs as P
 from ._lib import ACCUMULATE
 
 
+PAIR_SUPERNET_TERMS = True  # pair the GroupNorm-type terms of a supernet node (False: one epilogue launch per primitive)
 REUSE_GRAD_OUTPUT = False  # see _run_backward; switched on by the trainers for the duration of their backward pass
 
 
@@ -71,6 +72,15 @@ def supernet_plan(cell):
                  list(cell.parameters()))
 
 
+def _flat_terms(plan):
+    """(node, input index, segment, alpha column, alpha matrix id, alpha row) of every primitive, in forward order"""
+    flat = []
+    for node, idx, segs, amat, row in plan.edges:
+        for seg, col in segs:
+            flat.append((node, idx, seg, col, amat, row))
+    return flat
+
+
 def _run_forward(plan, x0, x1, alpha1, alpha2):
     """Returns (cell output tensor, saved state)."""
     st = P.Saved()
@@ -103,21 +113,38 @@ def _run_forward(plan, x0, x1, alpha1, alpha2):
             st.saved.extend([s0, s1])
         st.xs, st.out = xs, out
         return out.t, st
-    for node, idx, segs, amat, row in plan.edges:
-        xin = xs[idx]
-        for seg, col in segs:
+    # supernet cell (cell.py:76-81): node = sum over its edges of sum_k alpha[e][k] * op_k(x_e).  The terms of a node whose
+    # epilogue is GroupNorm -> [ReLU] -> weighted sum (the conv-type primitives) are taken two at a time: one epilogue
+    # launch per pair (P.pair_forward), the other primitives (identity, pools, stride-1 SE) keep their own.
+    flat = _flat_terms(plan)
+    st.saved = [None] * len(flat)
+    for node in range(nn):
+        pend = None
+        for fi, (nd, idx, seg, col, amat, row) in enumerate(flat):
+            if nd != node:
+                continue
+            xin = xs[idx]
             if out is None:
                 shp = seg.weight.out_shape(xin)
                 out = K.as_view(K.empty_ndhwc(shp[0], nn * cn, shp[2], shp[3], shp[4], xin.t.device))
                 nodes = [_slice_view(out, k, cn) for k in range(nn)]
                 xs.extend(nodes)
-            arow = None
-            if amat:
-                a = alpha1 if amat == 1 else alpha2
-                arow = a[row]
-            _, s = P.seg_forward(seg, xin, None, nodes[node], started[node], arow, col)
+            arow = (alpha1 if amat == 1 else alpha2)[row] if amat else None
+            if PAIR_SUPERNET_TERMS and P.gn_pairable(seg):
+                if pend is None:
+                    pend = (fi, seg, xin, arow, col)
+                    continue
+                fa, sa_, xa, aa, ca = pend
+                pend = None
+                st.saved[fa], st.saved[fi] = P.pair_forward(sa_, xa, seg, xin, nodes[node], None, started[node], (aa, ca), (arow, col))
+                started[node] = True
+                continue
+            _, st.saved[fi] = P.seg_forward(seg, xin, None, nodes[node], started[node], arow, col)
             started[node] = True
-            st.saved.append(s)
+        if pend is not None:
+            fa, sa_, xa, aa, ca = pend
+            _, st.saved[fa] = P.seg_forward(sa_, xa, None, nodes[node], started[node], aa, ca)
+            started[node] = True
     st.xs, st.out = xs, out
     return out.t, st
 
@@ -170,26 +197,49 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha)
         flat = []
     else:
         flat = None
-    # reverse order over edges / primitives (saved states were appended in forward order)
+    # supernet cell: reverse order over primitives (saved states are in forward order); the GroupNorm-type terms of a
+    # node share their epilogue-backward launches two at a time (they all consume the same node gradient)
     if flat is None:
-        flat = []
-        for node, idx, segs, amat, row in plan.edges:
-            for seg, col in segs:
-                flat.append((node, idx, seg, col, amat, row))
-    for (node, idx, seg, col, amat, row), s in zip(reversed(flat), reversed(st.saved if not plan.pairs else [])):
-        if idx >= 2:
-            target, acc = dnodes[idx - 2], True
-        else:
-            target, acc = dpre[idx], pre_started[idx]
-            pre_started[idx] = True
-        arow = dal = None
-        if amat:
-            a = alpha1 if amat == 1 else alpha2
-            arow = a[row]
+        flat = _flat_terms(plan)
+
+        def alpha_of(amat, row):
+            if not amat:
+                return None, None
             d = da1 if amat == 1 else da2
-            dal = d[row] if d is not None else None
-        _, gl = P.seg_backward(seg, s, dnodes[node], True, target, acc, arow, col, dal)
-        put(seg, gl)
+            return (alpha1 if amat == 1 else alpha2)[row], (d[row] if d is not None else None)
+
+        pend = None
+        for fi in reversed(range(len(flat))):
+            node, idx, seg, col, amat, row = flat[fi]
+            if pend is not None and pend[0] != node:   # node boundary: flush the unpaired term
+                _, pn, pseg, ps, pcol, parow, pdal = pend
+                target, acc = tgt(flat[pn][1])
+                _, gl = P.seg_backward(pseg, ps, dnodes[pend[0]], True, target, acc, parow, pcol, pdal)
+                put(pseg, gl)
+                pend = None
+            arow, dal = alpha_of(amat, row)
+            s = st.saved[fi]
+            if PAIR_SUPERNET_TERMS and P.gn_pairable(seg) and s.kind == "gn":
+                if pend is None:
+                    pend = (node, fi, seg, s, col, arow, dal)
+                    continue
+                _, pn, pseg, ps, pcol, parow, pdal = pend
+                pend = None
+                tb, ab = tgt(flat[pn][1])     # the later term (in forward order) first, like the unpaired reverse walk
+                ta, aa = tgt(idx)
+                (_, ga), (_, gb) = P.pair_backward(seg, s, pseg, ps, dnodes[node], (True, ta, aa), (True, tb, ab), None,
+                                                  (arow, col, dal), (parow, pcol, pdal))
+                put(pseg, gb)
+                put(seg, ga)
+                continue
+            target, acc = tgt(idx)
+            _, gl = P.seg_backward(seg, s, dnodes[node], True, target, acc, arow, col, dal)
+            put(seg, gl)
+        if pend is not None:
+            _, pn, pseg, ps, pcol, parow, pdal = pend
+            target, acc = tgt(flat[pn][1])
+            _, gl = P.seg_backward(pseg, ps, dnodes[pend[0]], True, target, acc, parow, pcol, pdal)
+            put(pseg, gl)
     for i in range(2):
         if not pre_started[i]:
             dpre[i].t.zero_()

@@ -451,9 +451,16 @@ def _pairable_fwd(seg):
     return (seg.norm is not None and seg.weight.produces_stats and seg.se_gate is None)
 
 
-def pair_forward(segA, xA, segB, xB, out, outB=None):
+def gn_pairable(seg):
+    """segment whose epilogue can share a launch with another one of the same output shape (see pair_forward)"""
+    return _pairable_fwd(seg) and not isinstance(seg.weight, IdentityW) and seg.dropout is None
+
+
+def pair_forward(segA, xA, segB, xB, out, outB=None, accumulate=False, alphaA=None, alphaB=None):
     """Node of a searched cell: out = segA(xA) + segB(xB) (searched.py:45-50), `out` a View that is overwritten.
     With `outB` the two ops are independent (the two preprocess ops of a cell, cell.py:47-50): segA -> out, segB -> outB.
+    Supernet nodes (cell.py:76-81) use it too: alphaX = (alpha row tensor, column) is the MixedOp weight of the term and
+    `accumulate` adds the pair to what the node buffer already holds.
     Both weight ops run first; if both epilogues are small GroupNorm epilogues of one shape they share ONE launch
     (n3d_affine_act_gn2), otherwise the two ordinary epilogues run one after the other.  Returns (savedA, savedB)."""
     res = []
@@ -480,9 +487,11 @@ def pair_forward(segA, xA, segB, xB, out, outB=None):
     G = group_count(rawA.C)
     if (_pairable_fwd(segA) and _pairable_fwd(segB) and rawA.C == rawB.C and rawA.N == rawB.N
             and segA.norm.eps == segB.norm.eps and K.pair_shape_ok(rawA.C)):
-        terms = [(rawA, stA, rowsA, segA.norm.weight, segA.norm.bias, None, segA.relu_out),
-                 (rawB, stB, rowsB, segB.norm.weight, segB.norm.bias, None, segB.relu_out)]
-        sv = K.affine_act_gn2(terms, G, segA.norm.eps, out, 0, outB)
+        wpA = _wptr(*alphaA) if alphaA is not None else None
+        wpB = _wptr(*alphaB) if alphaB is not None else None
+        terms = [(rawA, stA, rowsA, segA.norm.weight, segA.norm.bias, wpA, segA.relu_out),
+                 (rawB, stB, rowsB, segB.norm.weight, segB.norm.bias, wpB, segB.relu_out)]
+        sv = K.affine_act_gn2(terms, G, segA.norm.eps, out, ACCUMULATE if accumulate else 0, outB)
         saved = []
         for (raw, _, _, ws), (a, b, mr, sr) in zip(res, sv):
             s = Saved()
@@ -490,32 +499,38 @@ def pair_forward(segA, xA, segB, xB, out, outB=None):
             s.a, s.b, s.mr, s.sumraw = a, b, mr, sr
             saved.append(s)
         return saved[0], saved[1]
-    _, sA = _seg_epilogue_forward(segA, rawA, stA, rowsA, wsA, out, False, None, 0)
+    aA, kA = alphaA if alphaA is not None else (None, 0)
+    aB, kB = alphaB if alphaB is not None else (None, 0)
+    _, sA = _seg_epilogue_forward(segA, rawA, stA, rowsA, wsA, out, accumulate, aA, kA)
     if outB is not None:
-        _, sB = _seg_epilogue_forward(segB, rawB, stB, rowsB, wsB, outB, False, None, 0)
+        _, sB = _seg_epilogue_forward(segB, rawB, stB, rowsB, wsB, outB, False, aB, kB)
     else:
-        _, sB = _seg_epilogue_forward(segB, rawB, stB, rowsB, wsB, out, True, None, 0)
+        _, sB = _seg_epilogue_forward(segB, rawB, stB, rowsB, wsB, out, True, aB, kB)
     return sA, sB
 
 
-def pair_backward(segA, sA, segB, sB, dout, argsA, argsB, doutB=None):
+def pair_backward(segA, sA, segB, sB, dout, argsA, argsB, doutB=None, alphaA=None, alphaB=None):
     """Backward of pair_forward.  argsX = (need_dx, dx_out, dx_acc).  Returns ((dxA, gradsA), (dxB, gradsB)) with
-    grads ordered like segX.params().  doutB: gradient of segB's own output (independent-outputs mode)."""
+    grads ordered like segX.params().  doutB: gradient of segB's own output (independent-outputs mode).
+    alphaX = (alpha row, column, dalpha row | None): MixedOp weight of the term and where its gradient <dout, z> goes."""
+    aA = alphaA if alphaA is not None else (None, 0, None)
+    aB = alphaB if alphaB is not None else (None, 0, None)
     pair = (sA.kind == "gn" and sB.kind == "gn" and not isinstance(segA.weight, IdentityW) and not isinstance(segB.weight, IdentityW)
             and sA.raw.C == sB.raw.C and sA.raw.N == sB.raw.N)
     if pair:
         pair = K.pair_shape_ok(sA.raw.C)
     if not pair:
-        rb = seg_backward(segB, sB, doutB if doutB is not None else dout, *argsB)
-        ra = seg_backward(segA, sA, dout, *argsA)
+        rb = seg_backward(segB, sB, doutB if doutB is not None else dout, *argsB, aB[0], aB[1], aB[2])
+        ra = seg_backward(segA, sA, dout, *argsA, aA[0], aA[1], aA[2])
         return ra, rb
     terms = []
-    for seg, s in ((segA, sA), (segB, sB)):
+    for seg, s, al in ((segA, sA, aA), (segB, sB, aB)):
         cbias = seg.weight.norm_fed_bias()
         if cbias is not None and not cbias.requires_grad:
             cbias = None
         raw = s.raw
-        terms.append(dict(raw=raw, a=s.a, b=s.b, mr=s.mr, sumraw=s.sumraw, gamma=seg.norm.weight, beta=seg.norm.bias, wptr=None,
+        terms.append(dict(raw=raw, a=s.a, b=s.b, mr=s.mr, sumraw=s.sumraw, gamma=seg.norm.weight, beta=seg.norm.bias,
+                          wptr=_wptr(al[0], al[1]), dalpha_ptr=(C.c_void_p(al[2].data_ptr() + 4 * al[1]) if al[2] is not None else None),
                           relu=seg.relu_out, conv_bias=cbias,
                           draw=K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))))
     outs = K.affine_act_bwd_gn2(dout, terms, sA.G, doutB)
