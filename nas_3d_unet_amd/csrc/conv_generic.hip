@@ -485,7 +485,17 @@ struct DwArgs {
 };
 
 __global__ __launch_bounds__(256) void dw_gather_kernel(DwArgs a) {
+  // k = 3, dilation 1 (check_geom).  Branch-free: the weights of all channel quads are staged once in LDS as float4
+  // [c4][tap] (one broadcast ds_read_b128 per tap), and the nine source loads of a kd plane are issued from clamped
+  // addresses before their first use -- the rolled tap loop with `continue`s paid one memory latency per tap (27).
+  extern __shared__ __attribute__((aligned(16))) float4 dwl[];   // [C/4][27]
   const int cpb = a.C / 4;
+  for (int i = threadIdx.x; i < cpb * 27; i += 256) {
+    const int c4 = i / 27, tap = i - c4 * 27;
+    const float* wc = a.w + (int64_t)c4 * 4 * 27 + tap;
+    dwl[i] = make_float4(wc[0], wc[27], wc[54], wc[81]);
+  }
+  __syncthreads();
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd, Ns = (int64_t)a.Ds * a.Hs * a.Ws;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= Nd * cpb) return;
@@ -497,36 +507,53 @@ __global__ __launch_bounds__(256) void dw_gather_kernel(DwArgs a) {
   const int c4 = (int)uc;
   const int64_t v = uv;
   const int w_ = (int)uw, h_ = (int)uh, d_ = (int)ud;
-  const int k = a.k, taps = k * k * k;
-  float acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = a.bias ? a.bias[c4 * 4 + j] : 0.f;
+  float4* op = reinterpret_cast<float4*>(a.dst + ((int64_t)b * Nd + v) * a.dld + c4 * 4);
+  const bool accum = a.flags & N3D_ACCUMULATE;
+  float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (accum) prev = *op;
+  float4 acc = a.bias ? *reinterpret_cast<const float4*>(a.bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float* srcb = a.src + (int64_t)b * Ns * a.sld + c4 * 4;
-  const float* wc = a.w + (int64_t)c4 * 4 * taps;
-  for (int kd = 0; kd < k; ++kd) {
+  const float4* wq = dwl + c4 * 27;
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd) {
     int nd = d_ * a.sn + a.off + kd * a.dt;
-    if (a.den == 2) { if (nd & 1) continue; nd >>= 1; }
-    if (nd < 0 || nd >= a.Ds) continue;
-    for (int kh = 0; kh < k; ++kh) {
+    bool okd = true;
+    if (a.den == 2) { okd = !(nd & 1); nd >>= 1; }
+    okd = okd && nd >= 0 && nd < a.Ds;
+    const int cd_ = min(max(nd, 0), a.Ds - 1);
+    float4 q[3][3];
+    float m[3][3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
       int nh = h_ * a.sn + a.off + kh * a.dt;
-      if (a.den == 2) { if (nh & 1) continue; nh >>= 1; }
-      if (nh < 0 || nh >= a.Hs) continue;
-      for (int kw = 0; kw < k; ++kw) {
+      bool okh = okd;
+      if (a.den == 2) { okh = okh && !(nh & 1); nh >>= 1; }
+      okh = okh && nh >= 0 && nh < a.Hs;
+      const int ch_ = min(max(nh, 0), a.Hs - 1);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
         int nw = w_ * a.sn + a.off + kw * a.dt;
-        if (a.den == 2) { if (nw & 1) continue; nw >>= 1; }
-        if (nw < 0 || nw >= a.Ws) continue;
-        const int tap = (kd * k + kh) * k + kw;
-        const float4 q = *reinterpret_cast<const float4*>(srcb + (((int64_t)nd * a.Hs + nh) * a.Ws + nw) * a.sld);
-        acc[0] = fmaf(q.x, wc[tap], acc[0]);
-        acc[1] = fmaf(q.y, wc[taps + tap], acc[1]);
-        acc[2] = fmaf(q.z, wc[2 * taps + tap], acc[2]);
-        acc[3] = fmaf(q.w, wc[3 * taps + tap], acc[3]);
+        bool ok = okh;
+        if (a.den == 2) { ok = ok && !(nw & 1); nw >>= 1; }
+        ok = ok && nw >= 0 && nw < a.Ws;
+        const int cw_ = min(max(nw, 0), a.Ws - 1);
+        m[kh][kw] = ok ? 1.f : 0.f;
+        q[kh][kw] = *reinterpret_cast<const float4*>(srcb + (((int64_t)cd_ * a.Hs + ch_) * a.Ws + cw_) * a.sld);
       }
     }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float4 wv = wq[(kd * 3 + kh) * 3 + kw];
+        const float mm = m[kh][kw];
+        acc.x = fmaf(q[kh][kw].x * mm, wv.x, acc.x);
+        acc.y = fmaf(q[kh][kw].y * mm, wv.y, acc.y);
+        acc.z = fmaf(q[kh][kw].z * mm, wv.z, acc.z);
+        acc.w = fmaf(q[kh][kw].w * mm, wv.w, acc.w);
+      }
   }
-  float4* op = reinterpret_cast<float4*>(a.dst + ((int64_t)b * Nd + v) * a.dld + c4 * 4);
-  if (a.flags & N3D_ACCUMULATE) { const float4 p = *op; acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w; }
-  *op = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *op = make_float4(acc.x + prev.x, acc.y + prev.y, acc.z + prev.z, acc.w + prev.w);
 }
 
 struct DwWgradArgs {
@@ -960,7 +987,7 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
       a.sn = 1; a.off = g->pad; a.dt = -g->dil; a.den = g->stride; }
     const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
     a.fcpb = FastDiv((uint32_t)(a.C / 4)); a.fWd = FastDiv((uint32_t)a.Wd); a.fHd = FastDiv((uint32_t)a.Hd);
-    hipLaunchKernelGGL(dw_gather_kernel, dim3((unsigned)cdiv(Nd * (a.C / 4), 256), g->B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dw_gather_kernel, dim3((unsigned)cdiv(Nd * (a.C / 4), 256), g->B), dim3(256), (size_t)(a.C / 4) * 27 * sizeof(float4), s, a);
     N3D_LAUNCH_CHECK();
     return N3D_OK;
   }
