@@ -83,6 +83,11 @@ def _flat_terms(plan):
 
 def _run_forward(plan, x0, x1, alpha1, alpha2):
     """Returns (cell output tensor, saved state)."""
+    with K.stats_cache():
+        return _run_forward_impl(plan, x0, x1, alpha1, alpha2)
+
+
+def _run_forward_impl(plan, x0, x1, alpha1, alpha2):
     st = P.Saved()
     x0v, x1v = K.as_view(x0, "x0"), K.as_view(x1, "x1")
     # the two preprocess ops (cell.py:47-50) are independent and of one output shape: paired epilogue launch

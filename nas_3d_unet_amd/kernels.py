@@ -328,7 +328,36 @@ def conv_bwd_both(g, x: View, dy: View, w, dx: View, dw, dbias, flags_data=0, re
 
 
 # ------------------------------------------------------------------------------------------ epilogue
+_stats_cache = None
+
+
+class stats_cache:
+    """with stats_cache(): channel statistics of one tensor are computed once -- inside a supernet cell the same input
+    feeds several primitives that each need them (identity's GroupNorm, the SE gates).  Only valid while the tensors do
+    not change: fused._run_forward holds it for one cell forward, whose inputs are complete before they are read."""
+
+    def __enter__(self):
+        global _stats_cache
+        self.prev, _stats_cache = _stats_cache, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _stats_cache
+        _stats_cache = self.prev
+        return False
+
+
 def channel_stats(x: View):
+    if _stats_cache is not None:
+        key = (x.p.value, x.ld, x.B, x.C, x.N)
+        hit = _stats_cache.get(key)
+        if hit is None:
+            hit = _stats_cache[key] = (_channel_stats(x), x.t)   # the tensor reference keeps its address from being reused
+        return hit[0]
+    return _channel_stats(x)
+
+
+def _channel_stats(x: View):
     rows = stats_rows(x.N, x.C)
     st = torch.empty((x.B, rows, x.C, 2), dtype=torch.float64, device=x.t.device)
     check(_lib.load().n3d_channel_stats(x.p, x.ld, x.B, x.N, x.C, ptr(st), stream_ptr()), "n3d_channel_stats")
