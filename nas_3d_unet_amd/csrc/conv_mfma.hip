@@ -1304,29 +1304,43 @@ struct VwArgs {
   const float* dy; int64_t dyld;
   float* partial;       // [workgroup][27][C*C]
   int D, H, W, dchunk;  // dchunk: planes per workgroup (multiple of 4)
+  const void* zero_page;
 };
 
 template <int C, int DIL>
 __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
   constexpr int Q = C / 4, TD = 4, GH = 4, GW = 16;
   constexpr int LD = TD + 2 * DIL, LH = GH + 2 * DIL, LW = GW + 2 * DIL;
-  constexpr int PLANE = LH * LW, QSTRIDE = LD * PLANE, NVOX = LD * PLANE;
-  extern __shared__ __attribute__((aligned(16))) float4 wtile[];  // [Q][LD][LH][LW]
-  const float* tf = reinterpret_cast<const float*>(wtile);
+  constexpr int PLANE = LH * LW, NVOX = LD * PLANE;
+  // One staged tile = the X halo tile ([Q][NVOX] float4) followed by the dY tile ([TD*GH rows][16 voxels][Q] float4), filled
+  // by LDS-DMA in 1 KiB chunks that the four waves share; two such buffers, so the DMA of tile k+1 runs under the
+  // MFMAs of tile k (ONE barrier per tile).  Both operands come from LDS: no ordinary global load sits in the loop,
+  // whose wait would also drain the prefetch (VMEM counters retire in order).
+  constexpr int NXC = (Q * NVOX + 63) / 64;            // chunks of the X tile
+  constexpr int NYC = (TD * GH * GW * Q + 63) / 64;    // chunks of the dY tile
+  constexpr int NCH = (NXC + NYC + 3) / 4 * 4;         // padded to a multiple of the 4 waves
+  constexpr int BUF = NCH * 64;                        // float4 per buffer
+  extern __shared__ __attribute__((aligned(16))) float4 wtile[];  // [2][BUF]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y;
+  // XCD-aware order of the workgroups (see conv_vox64_kernel); the slab index stays the physical workgroup id
+  int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  {
+    const int nwg = gridDim.x * gridDim.y, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int b = wg / (int)gridDim.x;
   const int tw_n = a.W / GW, th_n = a.H / GH;
-  int bx = blockIdx.x;
+  int bx = wg - b * (int)gridDim.x;
   const int w0 = (bx % tw_n) * GW; bx /= tw_n;
   const int h0 = (bx % th_n) * GH;
   const int dbeg = (bx / th_n) * a.dchunk;
   const int64_t N = (int64_t)a.D * a.H * a.W;
   const float* xb = a.x + (int64_t)b * N * a.xld;
   const float* dyb = a.dy + (int64_t)b * N * a.dyld;
+  const float4* zp = reinterpret_cast<const float4*>(a.zero_page);
   const int blk = lane >> 2, i4 = lane & 3;
   const int tap0 = wave * 7;
-  // LDS float offset of this lane's A element for tap t (relative to the row base), and tap validity
   int toff[7];
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
@@ -1342,63 +1356,60 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
 #pragma unroll
       for (int qb = 0; qb < Q; ++qb) acc[t][qa][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int d0 = dbeg; d0 < dbeg + a.dchunk; d0 += TD) {
-    // ---- stage the X halo tile (branch-free clamped loads, all in flight at once)
-    {
-      constexpr int NFI = (NVOX + 255) / 256;
-      float4 fv[NFI][Q];
-#pragma unroll
-      for (int i = 0; i < NFI; ++i) {
-        const int idx = (tid + i * 256 < NVOX) ? tid + i * 256 : NVOX - 1;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // stage tile `d0` into buffer `buf`: this wave's chunks are wave, wave+4, ...
+  auto stage = [&](int d0, float4* buf) {
+#pragma unroll 1
+    for (int m = 0; m < NCH / 4; ++m) {   // rolled: the address arithmetic of 4-12 chunks unrolled spills at C = 8
+      const int c = m * 4 + wave;                       // uniform
+      const int slot = c * 64 + lane;
+      const float4* srcp = zp;
+      if (c < NXC) {
+        // X tile: slot = q * NVOX + idx, idx = (dz * LH + hy) * LW + wx
+        const int q = slot / NVOX, idx = slot - q * NVOX;
         const int wx = idx % LW, hy = (idx / LW) % LH, dz = idx / PLANE;
         const int gd = d0 - DIL + dz, gh = h0 - DIL + hy, gw = w0 - DIL + wx;
-        const bool inb = gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-        const int cd_ = min(max(gd, 0), a.D - 1), ch_ = min(max(gh, 0), a.H - 1), cw_ = min(max(gw, 0), a.W - 1);
-        const float* p = xb + (((int64_t)cd_ * a.H + ch_) * a.W + cw_) * a.xld;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-          const float4 v = *reinterpret_cast<const float4*>(p + q * 4);
-          fv[i][q] = inb ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool inb = slot < Q * NVOX && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+        if (inb) srcp = reinterpret_cast<const float4*>(xb + (((int64_t)gd * a.H + gh) * a.W + gw) * a.xld + q * 4);
+      } else {
+        // dY tile: slot' = (row * 16 + voxel) * Q + q, row = g * GH + hh
+        const int sl = slot - NXC * 64;
+        const int q = sl % Q, vx = (sl / Q) % GW, row = sl / (Q * GW);
+        if (row < TD * GH) {
+          const int g = row / GH, hh = row - g * GH;
+          srcp = reinterpret_cast<const float4*>(dyb + (((int64_t)(d0 + g) * a.H + h0 + hh) * a.W + w0 + vx) * a.dyld + q * 4);
         }
       }
-      __syncthreads();  // previous tile fully consumed
-#pragma unroll
-      for (int i = 0; i < NFI; ++i) {
-        const int idx = tid + i * 256;
-        if (idx < NVOX) {
-#pragma unroll
-          for (int q = 0; q < Q; ++q) wtile[q * QSTRIDE + idx] = fv[i][q];
-        }
-      }
-      __syncthreads();
+      __builtin_amdgcn_global_load_lds((gptr_t)srcp, (lptr_t)(buf + c * 64), 16, 0, 0);
     }
-    // ---- 16 rows of 16 voxels: row r = (g, hh) -> output plane d0+g, row h0+hh.
-    // All dY values of the tile are requested first (one memory round trip per tile); no branch inside the MFMA
-    // loop (the 28th "tap" of wave 3 runs on a clamped address and is dropped at the end), so the compiler can
-    // batch the LDS reads ahead of the MFMAs.
-    float bvs[TD * GH][Q];
-#pragma unroll
-    for (int r = 0; r < TD * GH; ++r) {
-      const int g = r >> 2, hh = r & 3;
-      const float* dp = dyb + (((int64_t)(d0 + g) * a.H + h0 + hh) * a.W + w0 + blk) * a.dyld + i4;
-#pragma unroll
-      for (int qb = 0; qb < Q; ++qb) bvs[r][qb] = dp[qb * 4];
-    }
+  };
+  const int ntile = a.dchunk / TD;
+  stage(dbeg, wtile);
+  for (int k = 0; k < ntile; ++k) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile k landed for every wave; everyone is done with the buffer tile k+1 is about to overwrite
+    if (k + 1 < ntile) stage(dbeg + (k + 1) * TD, wtile + ((k + 1) & 1) * BUF);
+    const float* tf = reinterpret_cast<const float*>(wtile + (k & 1) * BUF);
+    const float* yf = tf + NXC * 64 * 4;
+    // ---- 16 rows of 16 voxels: row r = (g, hh) -> output plane d0+g, row h0+hh
 #pragma unroll
     for (int r = 0; r < TD * GH; ++r) {
       const int g = r >> 2, hh = r & 3;
       const int rbase = (g * PLANE + hh * LW) * 4;
-      float avs[7][Q];
+      float avs[7][Q], bvs[Q];
+#pragma unroll
+      for (int qb = 0; qb < Q; ++qb) bvs[qb] = yf[((r * GW + blk) * Q + qb) * 4 + i4];
 #pragma unroll
       for (int t = 0; t < 7; ++t)
 #pragma unroll
-        for (int qa = 0; qa < Q; ++qa) avs[t][qa] = tf[qa * QSTRIDE * 4 + rbase + toff[t]];
+        for (int qa = 0; qa < Q; ++qa) avs[t][qa] = tf[qa * NVOX * 4 + rbase + toff[t]];
 #pragma unroll
       for (int t = 0; t < 7; ++t)
 #pragma unroll
         for (int qa = 0; qa < Q; ++qa)
 #pragma unroll
-          for (int qb = 0; qb < Q; ++qb) acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(avs[t][qa], bvs[r][qb], acc[t][qa][qb], 0, 0, 0);
+          for (int qb = 0; qb < Q; ++qb) acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(avs[t][qa], bvs[qb], acc[t][qa][qb], 0, 0, 0);
     }
   }
   // ---- add the 16 block tiles (lanes with equal lane&3) and write this workgroup's slab
@@ -1433,7 +1444,11 @@ static VwPlan vw_plan(const n3d_conv_geom* g) {
   while (columns * dsplit < 384 && dsplit * 2 <= nd && nd % (dsplit * 2) == 0) dsplit *= 2;
   p.ok = true; p.C = g->Ci; p.dil = g->dil; p.dchunk = D / dsplit;
   p.tiles = (W / 16) * (H / 4) * dsplit;
-  p.lds = (size_t)(g->Ci / 4) * (4 + 2 * g->dil) * (4 + 2 * g->dil) * (16 + 2 * g->dil) * 16;
+  {
+    const size_t Qn = g->Ci / 4, nvox = (size_t)(4 + 2 * g->dil) * (4 + 2 * g->dil) * (16 + 2 * g->dil);
+    const size_t nxc = (Qn * nvox + 63) / 64, nyc = (4 * 4 * 16 * Qn + 63) / 64, nch = (nxc + nyc + 3) / 4 * 4;
+    p.lds = 2 * nch * 64 * 16;   // two staged tiles (X halo tile + dY tile each)
+  }
   return p;
 }
 
@@ -1447,6 +1462,7 @@ int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const flo
   if ((size_t)nwg * 27 * p.C * p.C > avail_floats) return 0;
   VwArgs a;
   a.x = x; a.xld = xld; a.dy = dy; a.dyld = dyld; a.partial = partial; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.dchunk = p.dchunk;
+  a.zero_page = zero_page_ptr();
   dim3 grid(p.tiles, g->B);
   if (p.C == 4) {
     if (p.dil == 1) hipLaunchKernelGGL((vox_wgrad_kernel<4, 1>), grid, dim3(256), p.lds, s, a);
