@@ -900,6 +900,8 @@ int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags);
 int mfma_pack_layout(const n3d_conv_geom* g, bool data_grad, int flags);  // 1 gemm16, 2 vox64, 0 none
 int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                   float* partial, size_t avail_floats, int* nchunks_out, hipStream_t s);
+int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
+                     float* partial, size_t avail_floats, int* nchunks_out, hipStream_t s);
 struct Wg16Args;
 int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                    float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s,
@@ -1101,7 +1103,10 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     // vox64 weight gradient (3x3x3 stride 1, C = 4 / 8); it does not produce the bias gradient, which the callers on the
     // hot path obtain analytically from the GroupNorm backward sums (n3d_gn_bwd_coeffs)
     int nch = 0;
-    if (vox_wgrad_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, s) == 1) {
+    int hv = vox_wgrad_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, s);
+    if (hv == 0) hv = vox_wgrad_s2_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, s);
+    if (hv < 0) return hv;
+    if (hv == 1) {
       const int C = g->Ci, nout = C * C * taps;
       if (deferred) {
         fill_job(deferred, wsf, nullptr, dw, nullptr, nch, taps, 1, 1, C, C, C, C, taps);

@@ -1431,6 +1431,175 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// vox_wgrad_s2: weight gradient of the STRIDE-2 3x3x3 convs with C = 4 / 8 (and, with the operand roles swapped by the
+// caller, of the stride-2 transposed convs):  dW[tap][ci][co] = sum_o X[2*o - pad + tap*dil][ci] * dY[o][co].
+// Same scheme as vox_wgrad_kernel (4x4x1 MFMA, taps split over 4 waves, double-buffered LDS-DMA staging); the tile
+// walks TD = 2 planes of the SMALL grid, the X region is (3 + 2*dil) x (7 + 2*dil) x (31 + 2*dil) voxels of the big grid,
+// stored with every row de-interleaved by W parity so that the 16 blocks of an MFMA read 16 consecutive voxels.
+// The generic kernel gave every tap its own workgroups, i.e. re-read dY 27 times.
+// ------------------------------------------------------------------------------------------------
+struct Vw2Args {
+  const float* x; int64_t xld; int D, H, W;        // big grid (conv input / transposed-conv output gradient)
+  const float* dy; int64_t dyld; int oD, oH, oW;   // small grid
+  float* partial; int dchunk; const void* zero_page;
+};
+
+template <int C, int DIL>
+__global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
+  constexpr int Q = C / 4, TD = 2, GH = 4, GW = 16;
+  constexpr int LD = 2 * (TD - 1) + 2 * DIL + 1, LH = 7 + 2 * DIL, LW = 31 + 2 * DIL;
+  constexpr int HW = (LW + 1) / 2, RW = 2 * HW, PLANE = LH * RW, NVOX = LD * PLANE;
+  constexpr int NXC = (Q * NVOX + 63) / 64, NYC = (TD * GH * GW * Q + 63) / 64, NCH = (NXC + NYC + 3) / 4 * 4, BUF = NCH * 64;
+  extern __shared__ __attribute__((aligned(16))) float4 wtile[];  // [2][BUF]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  {
+    const int nwg = gridDim.x * gridDim.y, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int b = wg / (int)gridDim.x;
+  const int tw_n = a.oW / GW, th_n = a.oH / GH;
+  int bx = wg - b * (int)gridDim.x;
+  const int w0 = (bx % tw_n) * GW; bx /= tw_n;
+  const int h0 = (bx % th_n) * GH;
+  const int dbeg = (bx / th_n) * a.dchunk;
+  const int64_t Nx = (int64_t)a.D * a.H * a.W, Ny = (int64_t)a.oD * a.oH * a.oW;
+  const float* xb = a.x + (int64_t)b * Nx * a.xld;
+  const float* dyb = a.dy + (int64_t)b * Ny * a.dyld;
+  const float4* zp = reinterpret_cast<const float4*>(a.zero_page);
+  const int blk = lane >> 2, i4 = lane & 3;
+  const int tap0 = wave * 7;
+  int toff[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = (tap0 + t < 27) ? tap0 + t : 26;
+    const int kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
+    // X voxel (2g + kd*DIL, 2hh + kh*DIL, 2blk + kw*DIL): W parity and half index
+    toff[t] = ((kd * DIL) * PLANE + (kh * DIL) * RW + ((kw * DIL) & 1) * HW + ((kw * DIL) >> 1) + blk) * 4 + i4;
+  }
+  f32x4 acc[7][Q][Q];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int qa = 0; qa < Q; ++qa)
+#pragma unroll
+      for (int qb = 0; qb < Q; ++qb) acc[t][qa][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto stage = [&](int d0, float4* buf) {
+    const int id0 = 2 * d0 - DIL, ih0 = 2 * h0 - DIL, iw0 = 2 * w0 - DIL;
+#pragma unroll 1
+    for (int m = 0; m < NCH / 4; ++m) {
+      const int c = m * 4 + wave;
+      const int slot = c * 64 + lane;
+      const float4* srcp = zp;
+      if (c < NXC) {
+        // X tile: slot = q * NVOX + (dz * LH + row) * RW + par * HW + half
+        const int q = slot / NVOX, idx = slot - q * NVOX;
+        const int dz = idx / PLANE, rem = idx - dz * PLANE;
+        const int row = rem / RW, r2 = rem - row * RW;
+        const int par = r2 / HW, half = r2 - par * HW;
+        const int wx = 2 * half + par;
+        const int gd = id0 + dz, gh = ih0 + row, gw = iw0 + wx;
+        const bool inb = slot < Q * NVOX && wx < LW && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+        if (inb) srcp = reinterpret_cast<const float4*>(xb + (((int64_t)gd * a.H + gh) * a.W + gw) * a.xld + q * 4);
+      } else {
+        const int sl = slot - NXC * 64;
+        const int q = sl % Q, vx = (sl / Q) % GW, row = sl / (Q * GW);
+        if (row < TD * GH) {
+          const int g = row / GH, hh = row - g * GH;
+          srcp = reinterpret_cast<const float4*>(dyb + (((int64_t)(d0 + g) * a.oH + h0 + hh) * a.oW + w0 + vx) * a.dyld + q * 4);
+        }
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)srcp, (lptr_t)(buf + c * 64), 16, 0, 0);
+    }
+  };
+  const int ntile = a.dchunk / TD;
+  stage(dbeg, wtile);
+  for (int k = 0; k < ntile; ++k) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (k + 1 < ntile) stage(dbeg + (k + 1) * TD, wtile + ((k + 1) & 1) * BUF);
+    const float* tf = reinterpret_cast<const float*>(wtile + (k & 1) * BUF);
+    const float* yf = tf + NXC * 64 * 4;
+#pragma unroll
+    for (int r = 0; r < TD * GH; ++r) {
+      const int g = r >> 2, hh = r & 3;
+      const int rbase = ((2 * g) * PLANE + (2 * hh) * RW) * 4;
+      float avs[7][Q], bvs[Q];
+#pragma unroll
+      for (int qb = 0; qb < Q; ++qb) bvs[qb] = yf[((r * GW + blk) * Q + qb) * 4 + i4];
+#pragma unroll
+      for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int qa = 0; qa < Q; ++qa) avs[t][qa] = tf[qa * NVOX * 4 + rbase + toff[t]];
+#pragma unroll
+      for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int qa = 0; qa < Q; ++qa)
+#pragma unroll
+          for (int qb = 0; qb < Q; ++qb) acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(avs[t][qa], bvs[qb], acc[t][qa][qb], 0, 0, 0);
+    }
+  }
+  float* out = a.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 27) * (C * C);
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    if (tap0 + t < 27) {
+#pragma unroll
+      for (int qa = 0; qa < Q; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < Q; ++qb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sum = wave_classsum_f(acc[t][qa][qb][r], 4);
+            if (lane < 4) out[(tap0 + t) * (C * C) + (qa * 4 + r) * C + qb * 4 + lane] = sum;
+          }
+    }
+  }
+}
+
+// returns 1 if handled (slab layout as vox_wgrad_try: ci_t = co_t = C, tci = tco = 1, ntiles = 27)
+int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
+                     float* partial, size_t avail_floats, int* nchunks_out, hipStream_t s) {
+  if ((flags & (N3D_RELU_IN | N3D_NO_MFMA)) || in_gate) return 0;
+  if (g->depthwise || g->k != 3 || g->stride != 2 || g->Ci != g->Co || (g->Ci != 4 && g->Ci != 8)) return 0;
+  if (!(g->dil == 1 || g->dil == 2) || g->pad != g->dil) return 0;
+  if (g->Wo % 16 != 0 || g->Ho % 4 != 0 || g->Do % 2 != 0) return 0;
+  // small problems (16^3 outputs) leave this tile scheme with a few dozen long-running workgroups: the per-tap generic
+  // kernel is faster there (measured 8.7 vs 12.7 us at (2,8,16^3)); from 32^3 outputs on it is 2x faster and reads dY once
+  if ((int64_t)g->B * g->Do * g->Ho * g->Wo < 32768) return 0;
+  if (xld % 4 != 0 || dyld % 4 != 0 || !aligned16(x) || !aligned16(dy)) return 0;
+  const int columns = g->B * (g->Ho / 4) * (g->Wo / 16);
+  int nd = g->Do / 2, dsplit = 1;
+  while (columns * dsplit < 384 && dsplit * 2 <= nd && nd % (dsplit * 2) == 0) dsplit *= 2;
+  const int tiles = (g->Wo / 16) * (g->Ho / 4) * dsplit;
+  const int nwg = tiles * g->B;
+  if ((size_t)nwg * 27 * g->Ci * g->Ci > avail_floats) return 0;
+  const size_t Qn = g->Ci / 4;
+  const size_t LDn = 2 + 2 * g->dil + 1, LHn = 7 + 2 * g->dil, LWn = 31 + 2 * g->dil;
+  const size_t nvox = LDn * LHn * 2 * ((LWn + 1) / 2);
+  const size_t nxc = (Qn * nvox + 63) / 64, nyc = (2 * 4 * 16 * Qn + 63) / 64, nch = (nxc + nyc + 3) / 4 * 4;
+  const size_t lds = 2 * nch * 64 * 16;
+  if (lds > 160 * 1024) return 0;
+  Vw2Args a;
+  a.x = x; a.xld = xld; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.dy = dy; a.dyld = dyld; a.oD = g->Do; a.oH = g->Ho; a.oW = g->Wo;
+  a.partial = partial; a.dchunk = g->Do / dsplit; a.zero_page = zero_page_ptr();
+  dim3 grid(tiles, g->B);
+  if (g->Ci == 4) {
+    if (g->dil == 1) hipLaunchKernelGGL((vox_wgrad_s2_kernel<4, 1>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((vox_wgrad_s2_kernel<4, 2>), grid, dim3(256), lds, s, a);
+  } else {
+    if (g->dil == 1) hipLaunchKernelGGL((vox_wgrad_s2_kernel<8, 1>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((vox_wgrad_s2_kernel<8, 2>), grid, dim3(256), lds, s, a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("conv(vox_wgrad_s2) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+  *nchunks_out = nwg;
+  return 1;
+}
+
 struct VwPlan { bool ok; int C, dil, dchunk, tiles; size_t lds; };
 
 static VwPlan vw_plan(const n3d_conv_geom* g) {

@@ -53,6 +53,8 @@ CASES = [
     (8, 8, 3, 2, 1, True, 2, (4, 4, 16)),
     (4, 4, 3, 2, 2, True, 2, (4, 8, 16)),
     (4, 4, 3, 2, 1, True, 1, (32, 32, 32)),
+    (8, 8, 3, 2, 1, False, 2, (32, 32, 64)),     # large enough for the stride-2 MFMA weight gradient (>= 32768 output voxels)
+    (4, 4, 3, 2, 2, False, 2, (32, 32, 64)),
     (4, 4, 3, 1, 2, False, 2, (64, 64, 64)),     # dilation 2 at full size: two waves per workgroup on a shared 8-row halo tile
     (4, 4, 3, 1, 1, False, 2, (64, 64, 64)),     # the roofline shape itself (TD = 4 tiles, XCD-ordered)
 ]
