@@ -1078,8 +1078,10 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     a.B = g->B; a.C = g->Ci; a.k = 3; a.stride = g->stride; a.pad = g->pad; a.partial = wsf;
     a.fNo = FastDiv((uint32_t)No); a.fWo = FastDiv((uint32_t)g->Wo); a.fHo = FastDiv((uint32_t)g->Ho);
     const int64_t total = (int64_t)g->B * No;
-    // short chunks (the voxel loop is a dependent load -> FMA chain), bounded by the slab workspace
-    int64_t nch = cdiv(total, 512);
+    // short chunks (the voxel loop is a dependent load -> FMA chain): about two trips per thread -- a workgroup covers
+    // 256 / (C/4) voxels per trip, so wide channel counts need far smaller chunks than 512 voxels; bounded by the slab workspace
+    const int64_t vpb = 256 / (a.C / 4) > 0 ? 256 / (a.C / 4) : 1;
+    int64_t nch = cdiv(total, 2 * vpb < 512 ? 2 * vpb : 512);
     if (nch > 1024) nch = 1024;
     a.chunk = cdiv(total, nch);
     const int nchunks = (int)cdiv(total, a.chunk);
