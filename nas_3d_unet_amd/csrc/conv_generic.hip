@@ -568,10 +568,12 @@ struct DwWgradArgs {
 
 // POW2: C / 4 is a power of two (every depthwise op of the reference: C = 4 .. 64) -> DPP / permlane class sums, fully
 // unrolled so the 28 x 4 accumulators stay in registers (the generic strided sums made the compiler spill them)
-template <bool POW2>
+// CPB: C / 4 when it is a power of two (compile-time, so the 112 class sums are straight-line DPP code), 0 = generic
+template <int CPB>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
+  constexpr bool POW2 = CPB > 0;
   extern __shared__ float dyn[];
-  const int cpb = a.C / 4, vpb = 256 / cpb;
+  const int cpb = CPB > 0 ? CPB : a.C / 4, vpb = 256 / cpb;
   const int t = threadIdx.x, c4 = t % cpb, vl = t / cpb;
   const int64_t No = (int64_t)a.Do * a.Ho * a.Wo, Ni = (int64_t)a.Di * a.Hi * a.Wi;
   const int64_t total = (int64_t)a.B * No;
@@ -1088,8 +1090,15 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     if ((size_t)nchunks * 28 * a.C > avail) { set_error("dw wgrad: workspace too small"); return N3D_ERR_WORKSPACE; }
     a.pbias = wsf + (size_t)nchunks * 27 * a.C;
     const int cpb = a.C / 4;
-    if ((cpb & (cpb - 1)) == 0) hipLaunchKernelGGL(dw_wgrad_kernel<true>, dim3(nchunks), dim3(256), (size_t)4 * cpb * 28 * 4 * sizeof(float), s, a);
-    else hipLaunchKernelGGL(dw_wgrad_kernel<false>, dim3(nchunks), dim3(256), (size_t)4 * cpb * 28 * 4 * sizeof(float), s, a);
+    const size_t shm = (size_t)4 * cpb * 28 * 4 * sizeof(float);
+    switch (cpb) {
+      case 1: hipLaunchKernelGGL(dw_wgrad_kernel<1>, dim3(nchunks), dim3(256), shm, s, a); break;
+      case 2: hipLaunchKernelGGL(dw_wgrad_kernel<2>, dim3(nchunks), dim3(256), shm, s, a); break;
+      case 4: hipLaunchKernelGGL(dw_wgrad_kernel<4>, dim3(nchunks), dim3(256), shm, s, a); break;
+      case 8: hipLaunchKernelGGL(dw_wgrad_kernel<8>, dim3(nchunks), dim3(256), shm, s, a); break;
+      case 16: hipLaunchKernelGGL(dw_wgrad_kernel<16>, dim3(nchunks), dim3(256), shm, s, a); break;
+      default: hipLaunchKernelGGL(dw_wgrad_kernel<0>, dim3(nchunks), dim3(256), shm, s, a); break;
+    }
     // fixed-order slab reduction through the common finalize: one "tile" per tap, ci_t = 1, co_t = C, Ci = 1
     n3d_final_job job;
     fill_job(&job, a.partial, a.pbias, dw, dbias, nchunks, 27, 1, 1, 1, a.C, a.C, 1, 27);
