@@ -1,55 +1,59 @@
-"""MI355X-native drop-in for the reference's ``cell`` module (cell.py:8-82): MixedOp and Cell."""
+"""MI355X-native drop-in for the reference's ``cell`` module (`MixedOp` cell.py:8-33, `Cell` :35-82): same class names,
+constructor arguments, forward signatures and `_ops` / `preprocess*` attribute names."""
 import torch.nn as nn
 
 from . import fused
 from .prim_ops import OPS, ConvOps, DownOps, NormOps, UpOps
 
 
+def edge_kinds(n_nodes, downward):
+    """(stride, transposed) of every edge in the cell's edge order: node k has k + 2 inputs (the two cell inputs, then the
+    earlier nodes).  Down cell: the edges from the two cell inputs reduce (stride 2); up cell: only the edge from the second
+    cell input expands (stride-2 transposed primitives)."""
+    kinds = []
+    for n_inputs in range(2, n_nodes + 2):
+        for src in range(n_inputs):
+            strided = src < 2 if downward else src == 1
+            kinds.append((2 if strided else 1, not downward))
+    return kinds
+
+
 class MixedOp(nn.Module):
-    """DARTS continuous relaxation: sum_k w_k * op_k(x) over the edge's primitive list (cell.py:9-33)."""
+    """DARTS relaxation of one edge: sum_k w_k * op_k(x) over the primitive list the stride selects."""
 
     def __init__(self, channels, stride, transposed=False):
         super().__init__()
-        self._ops = nn.ModuleList()
         self.stride = stride
-        names = NormOps if stride == 1 else (UpOps if transposed else DownOps)
-        for name in names:
-            self._ops.append(OPS[name](channels))
+        prims = NormOps if stride == 1 else (UpOps if transposed else DownOps)
+        self._ops = nn.ModuleList(OPS[p](channels) for p in prims)
+        self._segs = None
 
     def forward(self, x, alpha1, alpha2):
-        weights = alpha1 if self.stride == 1 else alpha2
-        if getattr(self, "_segs", None) is None:
+        if self._segs is None:
             self._segs = [fused._single_segment(op) for op in self._ops]
             self._plist = [p for seg in self._segs for p in seg.params()]
-        # one autograd node: every primitive's epilogue accumulates w_k * op_k(x) into the same buffer
-        return fused.MixedOpFn.apply(self._segs, x, weights, *self._plist)
+        # one autograd node; every primitive's epilogue accumulates w_k * op_k(x) into the same buffer
+        return fused.MixedOpFn.apply(self._segs, x, alpha1 if self.stride == 1 else alpha2, *self._plist)
 
 
 class Cell(nn.Module):
-    """Supernet cell: n_nodes nodes, node n has n+2 incoming MixedOp edges (cell.py:36-82)."""
+    """Supernet cell.  alpha1 / alpha2 are the full (n_edges, n_prims) matrices of the stride-1 / stride-2 edges, both
+    indexed by the cell-wide edge counter (so each matrix has rows that are never read)."""
 
     def __init__(self, n_nodes, c0, c1, c_node, downward=True):
         super().__init__()
-        self.n_nodes = n_nodes
-        self.c_node = c_node
+        self.n_nodes, self.c_node = n_nodes, c_node
         self.preprocess0 = ConvOps(c0, c_node, kernel_size=1, stride=2 if downward else 1, ops_order="act_weight_norm")
         self.preprocess1 = ConvOps(c1, c_node, kernel_size=1, ops_order="act_weight_norm")
-        self._ops = nn.ModuleList()
-        for n_in in range(2, 2 + n_nodes):
-            for i in range(n_in):
-                if downward:
-                    self._ops.append(MixedOp(c_node, stride=2 if i <= 1 else 1))
-                else:
-                    self._ops.append(MixedOp(c_node, stride=2 if i == 1 else 1, transposed=True))
+        self._ops = nn.ModuleList(MixedOp(c_node, stride=s, transposed=t) for s, t in edge_kinds(n_nodes, downward))
+        self._plan = None
 
     @property
     def out_channels(self):
-        return self.n_nodes * self.c_node
+        return self.c_node * self.n_nodes
 
     def forward(self, x0, x1, alpha1, alpha2):
-        """x0, x1: cell inputs; alpha1 / alpha2: full (n_edges, n_prims) weight matrices for the stride-1 /
-        stride-2 edges, both indexed by the global edge counter (cell.py:76-80).  Runs as one fused launch
-        program (fused.py); the result is the channel concat of the n_nodes node outputs."""
-        if getattr(self, "_plan", None) is None:
+        # one launch program per cell (fused.py); the result is the channel concatenation of the node outputs
+        if self._plan is None:
             self._plan = fused.supernet_plan(self)
         return fused.CellFn.apply(self._plan, x0, x1, alpha1, alpha2, *self._plan.params)

@@ -1,0 +1,50 @@
+"""U-shaped wiring shared by the supernet (nas.KernelNet) and the searched net (searched.SearchedNet).
+
+The reference builds the same encoder / decoder twice (nas.py:25-78 and searched.py:66-111): two stems, `depth` down
+cells whose node width doubles when `channel_change`, `depth + 1` up cells fed by a stack of skip tensors, a 1x1x1 head.
+Here it is one channel plan and one routing function; the two nets differ only in the cell type and in what a cell call
+passes along (alpha matrices or nothing)."""
+import torch.nn as nn
+
+from .prim_ops import ConvOps
+
+
+def cell_specs(init_n_kernels, depth, n_nodes, channel_change):
+    """([(c0, c1, c_node, downward)] for the down cells then the up cells, channels entering the head)"""
+    wide = n_nodes * init_n_kernels          # both stems emit n_nodes * init_n_kernels channels
+    specs, pending = [], [wide, wide]        # `pending`: channel counts of the skip tensors, in push order
+    prev2, prev1, node_c = wide, wide, init_n_kernels
+    for _ in range(depth):
+        if channel_change:
+            node_c *= 2
+        specs.append((prev2, prev1, node_c, True))
+        prev2, prev1 = prev1, n_nodes * node_c
+        pending.append(prev1)
+    pending.pop()                            # the deepest output goes straight into the first up cell
+    for _ in range(depth + 1):
+        specs.append((pending.pop(), prev1, node_c, False))
+        prev1 = n_nodes * node_c
+        if channel_change:
+            node_c //= 2
+    return specs, prev1
+
+
+def build_stems_and_head(net, in_channels, init_n_kernels, out_channels, n_nodes, head_in, head_dropout):
+    """registers stem0 / stem1 / last_conv on `net` under the reference's attribute names (state-dict parity)"""
+    wide = n_nodes * init_n_kernels
+    net.stem0 = ConvOps(in_channels, wide, kernel_size=1, ops_order="weight_norm")
+    net.stem1 = ConvOps(in_channels, wide, kernel_size=3, stride=2, ops_order="weight_norm")
+    return nn.Sequential(ConvOps(head_in, out_channels, kernel_size=1, dropout_rate=head_dropout, ops_order="weight"), nn.Sigmoid())
+
+
+def route(net, x, call_down, call_up):
+    """stems -> down cells (every output is kept as a skip) -> up cells (each takes the latest remaining skip) -> head"""
+    older, newer = net.stem0(x), net.stem1(x)
+    kept = [older, newer]
+    for cell in net.down_cells:
+        older, newer = newer, call_down(cell, older, newer)
+        kept.append(newer)
+    kept.pop()
+    for cell in net.up_cells:
+        newer = call_up(cell, kept.pop(), newer)
+    return net.last_conv(newer)
