@@ -154,7 +154,9 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2):
     return out.t, st
 
 
-def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha):
+def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets=None, own_dout=False):
+    """dx_targets = ((View | None, accumulate), (View | None, accumulate)): where the gradients of the two cell inputs go
+    (NetFn passes the producers' gradient buffers); own_dout: `dout` is a private buffer the cell may accumulate into."""
     cn, nn = plan.c_node, plan.n_nodes
     dv = K.as_view(dout, "grad_output")
     out = st.out
@@ -163,7 +165,7 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha)
     # (train.Trainer / SearchTrainer set REUSE_GRAD_OUTPUT) lets the cell accumulate straight into autograd's buffer: it is
     # either this cell's consumer's freshly returned dx or autograd's own accumulation buffer, and nobody reads it again.
     # Stand-alone use keeps the private copy (autograd forbids modifying grad_output in general).
-    if REUSE_GRAD_OUTPUT and dv.t is dout and dv.ld == nn * cn:
+    if (REUSE_GRAD_OUTPUT or own_dout) and dv.t is dout and dv.ld == nn * cn:
         dcat = dv
     else:
         dcat = K.as_view(K.empty_ndhwc(out.B, nn * cn, out.D, out.H, out.W, dev))
@@ -248,7 +250,8 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha)
     for i in range(2):
         if not pre_started[i]:
             dpre[i].t.zero_()
-    (d0, g0), (d1, g1) = P.pair_backward(plan.pre0, st.s_pre0, plan.pre1, st.s_pre1, dpre[0], (need_x0, None, False), (need_x1, None, False),
+    (t0, acc0), (t1, acc1) = dx_targets if dx_targets is not None else ((None, False), (None, False))
+    (d0, g0), (d1, g1) = P.pair_backward(plan.pre0, st.s_pre0, plan.pre1, st.s_pre1, dpre[0], (need_x0, t0, acc0), (need_x1, t1, acc1),
                                          dpre[1])
     put(plan.pre0, g0)
     put(plan.pre1, g1)
@@ -328,3 +331,105 @@ class MixedOpFn(torch.autograd.Function):
         ctx.saved = None
         return (None, dx.t if need_dx else None, dalpha) + tuple(g if ctx.needs_input_grad[3 + i] else None
                                                                    for i, g in enumerate(grads))
+
+
+# =================================================================================================
+# whole-net autograd node
+# =================================================================================================
+WHOLE_NET = True  # nets run stems + cells as ONE autograd node (NetFn); False: one node per stem / cell
+
+
+class _NetPlan:
+    """Stems and cells of a U-shaped net in execution order, with the wiring of unet.route as index triples."""
+
+    def __init__(self, net, supernet):
+        self.supernet = supernet
+        self.stem0, self.stem1 = _single_segment(net.stem0), _single_segment(net.stem1)
+        make = supernet_plan if supernet else searched_plan
+        cells = list(net.down_cells) + list(net.up_cells)
+        for c in cells:
+            if c._plan is None:
+                c._plan = make(c)
+        self.cells = [c._plan for c in cells]
+        self.n_down = len(net.down_cells)
+        # activations: 0 = stem0, 1 = stem1, 2 + k = cell k.  wiring[k] = (x0 index, x1 index, output index)
+        self.wiring = []
+        older, newer, kept = 0, 1, [0, 1]
+        for k in range(self.n_down):
+            self.wiring.append((older, newer, 2 + k))
+            older, newer = newer, 2 + k
+            kept.append(newer)
+        kept.pop()
+        for k in range(self.n_down, len(cells)):
+            self.wiring.append((kept.pop(), newer, 2 + k))
+            newer = 2 + k
+        self.params = self.stem0.params() + self.stem1.params()
+        self.offsets = []
+        for pl in self.cells:
+            self.offsets.append(len(self.params))
+            self.params = self.params + pl.params
+
+
+def net_plan(net, supernet):
+    return _NetPlan(net, supernet)
+
+
+class NetFn(torch.autograd.Function):
+    """Stems + every cell of a SearchedNet / KernelNet as one autograd node (nas.py:54-77, searched.py:93-110).
+
+    With one node per cell, autograd sums the gradients of every activation that feeds two or three consumers (each cell
+    output is the next cell's x1, the one after's x0 and possibly a skip) with separate add kernels.  Here the backward walk
+    owns the gradient buffers: the first consumer to run writes, later ones accumulate in their data-gradient kernels."""
+
+    @staticmethod
+    def forward(ctx, nplan, x, a1d, a1u, a2d, a2u, *params):
+        xv = K.as_view(x, "input")
+        al = [a.detach().contiguous() if a is not None else None for a in (a1d, a1u, a2d, a2u)]
+        s0, st0 = P.seg_forward(nplan.stem0, xv)
+        s1, st1 = P.seg_forward(nplan.stem1, xv)
+        acts, states = [s0.t, s1.t], []
+        for k, (i0, i1, _) in enumerate(nplan.wiring):
+            a1, a2 = (al[0], al[2]) if k < nplan.n_down else (al[1], al[3])
+            out, st = _run_forward(nplan.cells[k], acts[i0], acts[i1], a1, a2)
+            acts.append(out)
+            states.append(st)
+        ctx.nplan, ctx.al, ctx.st0, ctx.st1, ctx.states = nplan, al, st0, st1, states
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, dout):
+        nplan, al = ctx.nplan, ctx.al
+        want_da = any(ctx.needs_input_grad[2:6])
+        n_acts = 2 + len(nplan.cells)
+        gbuf = [None] * n_acts
+        gbuf[-1] = dout
+        grads = [None] * len(nplan.params)
+        das = [None] * 4
+        for k in reversed(range(len(nplan.cells))):
+            i0, i1, io = nplan.wiring[k]
+            down = k < nplan.n_down
+            a1, a2 = (al[0], al[2]) if down else (al[1], al[3])
+            targets = tuple((K.as_view(gbuf[i], "grad") if gbuf[i] is not None else None, gbuf[i] is not None) for i in (i0, i1))
+            d0, d1, da1, da2, gl = _run_backward(nplan.cells[k], ctx.states[k], gbuf[io], a1, a2, True, True, want_da, targets,
+                                                 own_dout=gbuf[io] is not dout)
+            ctx.states[k] = None
+            gbuf[io] = None
+            gbuf[i0], gbuf[i1] = d0, d1
+            for j, g in enumerate(gl):
+                grads[nplan.offsets[k] + j] = g
+            for slot, d in ((0 if down else 1, da1), (2 if down else 3, da2)):
+                if d is not None:
+                    das[slot] = d if das[slot] is None else das[slot].add_(d)
+        need_x = ctx.needs_input_grad[1]
+        dx = None
+        n0 = len(nplan.stem0.params())
+        for seg, st, g, off in ((nplan.stem1, ctx.st1, gbuf[1], n0), (nplan.stem0, ctx.st0, gbuf[0], 0)):
+            d, gl = P.seg_backward(seg, st, K.as_view(g, "grad"), need_x)
+            for j, (p, gg) in enumerate(zip(seg.params(), gl)):
+                if gg is not None and getattr(p, "_n3d_grad", None) is None:
+                    grads[off + j] = gg
+            if need_x:
+                dx = d if dx is None else dx + d
+        ctx.st0 = ctx.st1 = ctx.states = None
+        return (None, dx) + tuple(d if ctx.needs_input_grad[2 + i] else None for i, d in enumerate(das)) + \
+            tuple(g if ctx.needs_input_grad[6 + i] else None for i, g in enumerate(grads))

@@ -25,8 +25,7 @@ class KernelNet(nn.Module):
 
     def forward(self, x, alpha1_down, alpha1_up, alpha2_down, alpha2_up):
         # the down cells share (alpha1_down, alpha2_down), the up cells (alpha1_up, alpha2_up)
-        return unet.route(self, x, lambda cell, skip, cur: cell(skip, cur, alpha1_down, alpha2_down),
-                          lambda cell, skip, cur: cell(skip, cur, alpha1_up, alpha2_up))
+        return unet.run(self, x, (alpha1_down, alpha1_up, alpha2_down, alpha2_up))
 
 
 class ShellNet(nn.Module):

@@ -6,6 +6,7 @@ Here it is one channel plan and one routing function; the two nets differ only i
 passes along (alpha matrices or nothing)."""
 import torch.nn as nn
 
+from . import fused
 from .prim_ops import ConvOps
 
 
@@ -35,6 +36,22 @@ def build_stems_and_head(net, in_channels, init_n_kernels, out_channels, n_nodes
     net.stem0 = ConvOps(in_channels, wide, kernel_size=1, ops_order="weight_norm")
     net.stem1 = ConvOps(in_channels, wide, kernel_size=3, stride=2, ops_order="weight_norm")
     return nn.Sequential(ConvOps(head_in, out_channels, kernel_size=1, dropout_rate=head_dropout, ops_order="weight"), nn.Sigmoid())
+
+
+def run(net, x, alphas=None):
+    """Forward of either net.  alphas: None (searched net) or (alpha1_down, alpha1_up, alpha2_down, alpha2_up), already
+    softmaxed.  Stems and cells run as one autograd node (fused.NetFn) unless fused.WHOLE_NET is off."""
+    if not fused.WHOLE_NET:
+        if alphas is None:
+            plain = lambda cell, skip, cur: cell(skip, cur)
+            return route(net, x, plain, plain)
+        a1d, a1u, a2d, a2u = alphas
+        return route(net, x, lambda cell, skip, cur: cell(skip, cur, a1d, a2d), lambda cell, skip, cur: cell(skip, cur, a1u, a2u))
+    plan = getattr(net, "_net_plan", None)
+    if plan is None:
+        plan = net._net_plan = fused.net_plan(net, supernet=alphas is not None)
+    body = fused.NetFn.apply(plan, x, *(alphas if alphas is not None else (None,) * 4), *plan.params)
+    return net.last_conv(body)
 
 
 def route(net, x, call_down, call_up):
