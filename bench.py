@@ -46,6 +46,12 @@ def synthetic_batch(batch, size, seed):
     return x.astype(np.float32), np.broadcast_to(t, (batch,) + t.shape).copy()
 
 
+def to_patch_layout(x):
+    """(B, C, D, H, W) logical shape in NDHWC storage -- what the data step (datastep.patch_batch / n3d_patch_batch) hands the
+    net, so the step does not start with a layout conversion"""
+    return x.contiguous(memory_format=torch.channels_last_3d)
+
+
 def conv_kernel_roofline(device, batch, size, iters=40):
     """Time the dominant FLOP kernel -- the 3x3x3 stride-1 conv at C=4 on (batch, 4, size^3), the shape of up-cell 4
     (43 % of the net's FLOPs; the same kernel serves its data gradient) -- with HIP events on the launch stream.
@@ -152,6 +158,7 @@ def search_step_bench(args, device):
     xn, tn = synthetic_batch(args.batch, args.size, 1234)
     vxn, vtn = synthetic_batch(args.batch, args.size, 4321)
     x, t, vx, vt = (torch.from_numpy(a).to(device) for a in (xn, tn, vxn, vtn))
+    x, vx = to_patch_layout(x), to_patch_layout(vx)
     for _ in range(args.warmup):
         tr.step(x, t, vx, vt)
     torch.cuda.synchronize()
@@ -166,7 +173,7 @@ def search_step_bench(args, device):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "patches_per_s": round(2 * args.batch * args.steps / dt, 2),
         "config": {"workload": "nas.py ShellNet search step, train batch=%d + val batch=%d 4x%d^3 fp32" % (args.batch, args.batch, args.size),
-                   "hip_graph": not args.no_graph, "loss_arch": round(float(la), 5), "loss_weight": round(float(lw), 5)}}), flush=True)
+                   "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "loss_arch": round(float(la), 5), "loss_weight": round(float(lw), 5)}}), flush=True)
 
 
 def main():
@@ -208,7 +215,7 @@ def main():
     trainer = Trainer(net, graph=not args.no_graph)
 
     xn, tn = synthetic_batch(args.batch, args.size, 1234 + rank)
-    x, t = torch.from_numpy(xn).to(device), torch.from_numpy(tn).to(device)
+    x, t = to_patch_layout(torch.from_numpy(xn).to(device)), torch.from_numpy(tn).to(device)
 
     for _ in range(args.warmup):
         loss = trainer.step(x, t)
@@ -238,7 +245,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "searched.py SearchedNet/G_conv train step, batch=%d 4x%d^3 fp32 per GPU" % (args.batch, args.size),
                        "global_batch": world * args.batch, "patch": [4, args.size, args.size, args.size],
-                       "parallelism": "dp%d" % world, "hip_graph": not args.no_graph, "final_loss": round(final_loss, 5)},
+                       "parallelism": "dp%d" % world, "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "final_loss": round(final_loss, 5)},
             "whole_net": {"tflops_fwd_bwd": round(value * FLOP_FWD_BWD_PER_PATCH / 1e12, 3),
                           "algorithmic_gbs": round(value * 3 * BYTES_FWD_PER_PATCH / 1e9, 1),
                           "hbm_frac_of_8TBs": round(value * 3 * BYTES_FWD_PER_PATCH / 1e9 / world / PEAK_HBM_GBS, 4)},

@@ -665,5 +665,5 @@ def run_segment(seg, x, training):
         # the (B, C) mask is generated by torch's RNG and folded into the conv as an input gate.
         p = seg.dropout.p
         B, Cc = x.shape[0], x.shape[1]
-        gate = (torch.rand((B, Cc), device=x.device) >= p).to(torch.float32) * (1.0 / (1.0 - p))
+        gate = torch.empty((B, Cc), dtype=torch.float32, device=x.device).bernoulli_(1.0 - p).div_(1.0 - p)  # torch's own recipe
     return SegmentFn.apply(seg, gate, x, *seg.params())

@@ -169,6 +169,7 @@ class Trainer:
         self._comm_stream = torch.cuda.Stream(device=self.device) if self.dp_path else None
         self.ctx = K.StepContext(self.device)  # batched weight packing + deferred wgrad reductions
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)  # read by the Adam kernel
+        self._one = torch.ones((), dtype=torch.float32, device=self.device)
         self.scheduler = PlateauLR(lambda: self.lr, self.set_lr)  # train.py:50: ReduceLROnPlateau(factor=0.5)
         self.sync = GradSync(self.fp.grad, self.pg, self.n_buckets, self._comm_stream)
         if self.world > 1:
@@ -182,7 +183,7 @@ class Trainer:
             loss = self.loss_fn(p, t)
             prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True   # this backward is all ours (no hooks, no retain)
             try:
-                loss.backward()
+                loss.backward(self._one)  # seed gradient kept resident: no fill launch per step
             finally:
                 _fused.REUSE_GRAD_OUTPUT = prev
             self.ctx.flush_final()         # one launch finishes every weight-gradient reduction
@@ -261,6 +262,7 @@ class SearchTrainer:
         self.a_m = torch.zeros_like(self.aflat)
         self.a_v = torch.zeros_like(self.aflat)
         self.a_step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._one = torch.ones((), dtype=torch.float32, device=self.device)
         self.ctx = K.StepContext(self.device)
         self.use_graph = graph
         self._graph = None
@@ -291,7 +293,7 @@ class SearchTrainer:
             loss = self.loss_fn(self.model(x), t)
             prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True
             try:
-                loss.backward()
+                loss.backward(self._one)  # seed gradient kept resident: no fill launch per step
             finally:
                 _fused.REUSE_GRAD_OUTPUT = prev
             self.ctx.flush_final()
