@@ -7,7 +7,8 @@ The reference builds a cell out of Python-level tensor algebra -- ``w * op(x)``,
     channel slice of the cell output buffer (zero-copy concat, fused weighted sum);
   * backward walks the DAG in reverse, data-gradient kernels accumulate into the producers'
     gradient slices, and dalpha[e][k] = <d node, op_k(x)> falls out of the epilogue's reduction pass.
-Numerics: the accumulation order is the reference's left-to-right order.
+Numerics: a searched cell accumulates in the reference's left-to-right order; a supernet node in the fixed order of
+_node_units (terms grouped so that launches can be shared), i.e. the same sum with a different fp32 rounding order.
 """
 from __future__ import annotations
 
@@ -81,6 +82,41 @@ def _flat_terms(plan):
     return flat
 
 
+def _node_units(plan):
+    """Launch schedule of a supernet cell: per node a list of units, each one term index or a pair of term indices into
+    _flat_terms(plan).  GroupNorm-type terms share their epilogue launches two at a time (P.pair_forward / pair_backward).
+    The plain-conv terms are paired with each other, partners taken from DIFFERENT edges where the node has more than one:
+    then the two convs also share one launch forward (n3d_conv_fwd2) and, having distinct input-gradient targets, one
+    launch backward (n3d_conv_bwd_both2).  The remaining GroupNorm-type terms (depthwise-separable, stride-2 SE convs)
+    pair in order; identity, pooling and stride-1 SE terms stay single."""
+    if getattr(plan, "_units", None) is not None:
+        return plan._units
+    flat = _flat_terms(plan)
+    units = []
+    for node in range(plan.n_nodes):
+        mine = [fi for fi, t in enumerate(flat) if t[0] == node]
+        pairable = [fi for fi in mine if PAIR_SUPERNET_TERMS and P.gn_pairable(flat[fi][2])]
+        dense = [fi for fi in pairable if isinstance(flat[fi][2].weight, P.DenseConvW)]
+        # position of the term among its edge's dense terms first, edge second: neighbours come from different edges
+        rank, seen = {}, {}
+        for fi in dense:
+            e = flat[fi][5]
+            rank[fi] = seen.get(e, 0)
+            seen[e] = rank[fi] + 1
+        dense.sort(key=lambda fi: (rank[fi], fi))
+        rest = [fi for fi in pairable if fi not in rank]
+        u = []
+        for group in (dense, rest):
+            for i in range(0, len(group) - 1, 2):
+                u.append((group[i], group[i + 1]))
+            if len(group) % 2:
+                u.append((group[-1],))
+        u.extend((fi,) for fi in mine if fi not in pairable)
+        units.append(u)
+    plan._units = units
+    return units
+
+
 def _run_forward(plan, x0, x1, alpha1, alpha2):
     """Returns (cell output tensor, saved state)."""
     with K.stats_cache():
@@ -118,37 +154,29 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2):
             st.saved.extend([s0, s1])
         st.xs, st.out = xs, out
         return out.t, st
-    # supernet cell (cell.py:76-81): node = sum over its edges of sum_k alpha[e][k] * op_k(x_e).  The terms of a node whose
-    # epilogue is GroupNorm -> [ReLU] -> weighted sum (the conv-type primitives) are taken two at a time: one epilogue
-    # launch per pair (P.pair_forward), the other primitives (identity, pools, stride-1 SE) keep their own.
+    # supernet cell (cell.py:76-81): node = sum over its edges of sum_k alpha[e][k] * op_k(x_e), accumulated unit by unit
+    # in the order of _node_units (a fixed order, but not the reference's left-to-right one: fp32 rounding differs)
     flat = _flat_terms(plan)
     st.saved = [None] * len(flat)
-    for node in range(nn):
-        pend = None
-        for fi, (nd, idx, seg, col, amat, row) in enumerate(flat):
-            if nd != node:
-                continue
-            xin = xs[idx]
-            if out is None:
-                shp = seg.weight.out_shape(xin)
-                out = K.as_view(K.empty_ndhwc(shp[0], nn * cn, shp[2], shp[3], shp[4], xin.t.device))
-                nodes = [_slice_view(out, k, cn) for k in range(nn)]
-                xs.extend(nodes)
-            arow = (alpha1 if amat == 1 else alpha2)[row] if amat else None
-            if PAIR_SUPERNET_TERMS and P.gn_pairable(seg):
-                if pend is None:
-                    pend = (fi, seg, xin, arow, col)
-                    continue
-                fa, sa_, xa, aa, ca = pend
-                pend = None
-                st.saved[fa], st.saved[fi] = P.pair_forward(sa_, xa, seg, xin, nodes[node], None, started[node], (aa, ca), (arow, col))
-                started[node] = True
-                continue
-            _, st.saved[fi] = P.seg_forward(seg, xin, None, nodes[node], started[node], arow, col)
-            started[node] = True
-        if pend is not None:
-            fa, sa_, xa, aa, ca = pend
-            _, st.saved[fa] = P.seg_forward(sa_, xa, None, nodes[node], started[node], aa, ca)
+    for node, units in enumerate(_node_units(plan)):
+        for unit in units:
+            args = []
+            for fi in unit:
+                _, idx, seg, col, amat, row = flat[fi]
+                xin = xs[idx]
+                if out is None:
+                    shp = seg.weight.out_shape(xin)
+                    out = K.as_view(K.empty_ndhwc(shp[0], nn * cn, shp[2], shp[3], shp[4], xin.t.device))
+                    nodes = [_slice_view(out, k, cn) for k in range(nn)]
+                    xs.extend(nodes)
+                arow = (alpha1 if amat == 1 else alpha2)[row] if amat else None
+                args.append((seg, xin, arow, col))
+            if len(unit) == 2:
+                (sa_, xa, aa, ca), (sb_, xb, ab, cb) = args
+                st.saved[unit[0]], st.saved[unit[1]] = P.pair_forward(sa_, xa, sb_, xb, nodes[node], None, started[node], (aa, ca), (ab, cb))
+            else:
+                (sa_, xa, aa, ca), = args
+                _, st.saved[unit[0]] = P.seg_forward(sa_, xa, None, nodes[node], started[node], aa, ca)
             started[node] = True
     st.xs, st.out = xs, out
     return out.t, st
@@ -215,38 +243,33 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
             d = da1 if amat == 1 else da2
             return (alpha1 if amat == 1 else alpha2)[row], (d[row] if d is not None else None)
 
-        pend = None
-        for fi in reversed(range(len(flat))):
-            node, idx, seg, col, amat, row = flat[fi]
-            if pend is not None and pend[0] != node:   # node boundary: flush the unpaired term
-                _, pn, pseg, ps, pcol, parow, pdal = pend
-                target, acc = tgt(flat[pn][1])
-                _, gl = P.seg_backward(pseg, ps, dnodes[pend[0]], True, target, acc, parow, pcol, pdal)
-                put(pseg, gl)
-                pend = None
-            arow, dal = alpha_of(amat, row)
-            s = st.saved[fi]
-            if PAIR_SUPERNET_TERMS and P.gn_pairable(seg) and s.kind == "gn":
-                if pend is None:
-                    pend = (node, fi, seg, s, col, arow, dal)
-                    continue
-                _, pn, pseg, ps, pcol, parow, pdal = pend
-                pend = None
-                tb, ab = tgt(flat[pn][1])     # the later term (in forward order) first, like the unpaired reverse walk
-                ta, aa = tgt(idx)
-                (_, ga), (_, gb) = P.pair_backward(seg, s, pseg, ps, dnodes[node], (True, ta, aa), (True, tb, ab), None,
-                                                  (arow, col, dal), (parow, pcol, pdal))
-                put(pseg, gb)
-                put(seg, ga)
-                continue
-            target, acc = tgt(idx)
-            _, gl = P.seg_backward(seg, s, dnodes[node], True, target, acc, arow, col, dal)
-            put(seg, gl)
-        if pend is not None:
-            _, pn, pseg, ps, pcol, parow, pdal = pend
-            target, acc = tgt(flat[pn][1])
-            _, gl = P.seg_backward(pseg, ps, dnodes[pend[0]], True, target, acc, parow, pcol, pdal)
-            put(pseg, gl)
+        all_units = _node_units(plan)
+        for node in reversed(range(nn)):
+            for unit in reversed(all_units[node]):
+                if len(unit) == 2:
+                    fa, fb = unit
+                    _, ia, sega, cola, amata, rowa = flat[fa]
+                    _, ib, segb, colb, amatb, rowb = flat[fb]
+                    sa, sb = st.saved[fa], st.saved[fb]
+                    (arowa, dala), (arowb, dalb) = alpha_of(amata, rowa), alpha_of(amatb, rowb)
+                    if sa.kind == "gn" and sb.kind == "gn":
+                        tb, ab = tgt(ib)     # the later term first, like the unpaired reverse walk
+                        ta, aa = tgt(ia)
+                        (_, ga), (_, gb) = P.pair_backward(sega, sa, segb, sb, dnodes[node], (True, ta, aa), (True, tb, ab), None,
+                                                          (arowa, cola, dala), (arowb, colb, dalb))
+                        put(segb, gb)
+                        put(sega, ga)
+                        continue
+                    todo = ((ib, segb, sb, colb, arowb, dalb), (ia, sega, sa, cola, arowa, dala))
+                else:
+                    fi, = unit
+                    _, idx, seg, col, amat, row = flat[fi]
+                    arow, dal = alpha_of(amat, row)
+                    todo = ((idx, seg, st.saved[fi], col, arow, dal),)
+                for idx, seg, s, col, arow, dal in todo:
+                    target, acc = tgt(idx)
+                    _, gl = P.seg_backward(seg, s, dnodes[node], True, target, acc, arow, col, dal)
+                    put(seg, gl)
     for i in range(2):
         if not pre_started[i]:
             dpre[i].t.zero_()
