@@ -143,6 +143,10 @@ typedef struct n3d_conv_bwd_call {     /* arguments of n3d_conv_bwd_both / n3d_c
 } n3d_conv_bwd_call;
 /* the two data gradients must not alias (dx of c0 != dx of c1) for the one-launch form; aliasing falls back to two launches */
 int n3d_conv_bwd_both2(const n3d_conv_bwd_call* c0, const n3d_conv_bwd_call* c1, void* stream);
+/* Data gradients only of two convs (the architecture pass of the search step computes no weight gradients, search.py:223-231;
+ * the reference runs loss.backward() through every conv's input there): fields x, dw, dbias, in_gate, ws_weight, deferred and
+ * flags_weight of the calls are ignored.  One launch where both fit the small-tensor MFMA kernel and dx of c0 != dx of c1. */
+int n3d_conv_bwd_data2(const n3d_conv_bwd_call* c0, const n3d_conv_bwd_call* c1, void* stream);
 /* transposed convolution y[i side] = convT(x[o side]) + bias; same kernels with the roles swapped */
 int n3d_convT_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias,
                   float* y, int64_t yld, int flags, const float* in_gate, double* stats,

@@ -923,7 +923,7 @@ int mfma_bwd_quad_try(BwdOne* c0, BwdOne* c1, hipStream_t s);
 int mfma_conv_pair_try(const n3d_conv_geom* g0, bool dg0, const float* src0, int64_t sld0, const float* w0, const float* bias0, float* dst0,
                        int64_t dld0, int flags0, const float* gate0, double* stats0, void* ws0, size_t wsb0, const n3d_conv_geom* g1, bool dg1,
                        const float* src1, int64_t sld1, const float* w1, const float* bias1, float* dst1, int64_t dld1, int flags1,
-                       const float* gate1, double* stats1, void* ws1, size_t wsb1, hipStream_t s);
+                       const float* gate1, double* stats1, void* ws1, size_t wsb1, hipStream_t s, const PairExtras* x0, const PairExtras* x1);
 void mfma_pack16(const float* w, float* wp, int Co, int Ci, int taps, int data_grad, hipStream_t s);
 }
 
@@ -1232,7 +1232,7 @@ int n3d_conv_fwd2(const n3d_conv_fwd_call* c0, const n3d_conv_fwd_call* c1, void
     // forward conv = gather with data_grad=false; transposed forward = gather with data_grad=true (run_gather convention)
     const int r = mfma_conv_pair_try(c0->g, c0->transposed != 0, c0->x, c0->xld, c0->w, c0->bias, c0->y, c0->yld, c0->flags, c0->in_gate,
                                      c0->stats, c0->ws, c0->ws_bytes, c1->g, c1->transposed != 0, c1->x, c1->xld, c1->w, c1->bias, c1->y,
-                                     c1->yld, c1->flags, c1->in_gate, c1->stats, c1->ws, c1->ws_bytes, (hipStream_t)stream);
+                                     c1->yld, c1->flags, c1->in_gate, c1->stats, c1->ws, c1->ws_bytes, (hipStream_t)stream, nullptr, nullptr);
     if (r < 0) return r;
     if (r == 1) return N3D_OK;
   }
@@ -1240,6 +1240,37 @@ int n3d_conv_fwd2(const n3d_conv_fwd_call* c0, const n3d_conv_fwd_call* c1, void
     const n3d_conv_fwd_call* c = cs[i];
     const int e = c->transposed ? n3d_convT_fwd(c->g, c->x, c->xld, c->w, c->bias, c->y, c->yld, c->flags, c->in_gate, c->stats, c->ws, c->ws_bytes, stream)
                                 : n3d_conv_fwd(c->g, c->x, c->xld, c->w, c->bias, c->y, c->yld, c->flags, c->in_gate, c->stats, c->ws, c->ws_bytes, stream);
+    if (e) return e;
+  }
+  return N3D_OK;
+}
+
+int n3d_conv_bwd_data2(const n3d_conv_bwd_call* c0, const n3d_conv_bwd_call* c1, void* stream) {
+  N3D_CHECK_ARG(c0 && c1 && c0->g && c1->g, "conv_bwd_data2: bad args");
+  const n3d_conv_bwd_call* cs[2] = {c0, c1};
+  bool pair = c0->dx != c1->dx;  // both may accumulate into one input gradient: then they must run one after the other
+  for (int i = 0; i < 2; ++i) {
+    const n3d_conv_bwd_call* c = cs[i];
+    if (int e = check_geom(c->g, "conv_bwd_data2")) return e;
+    N3D_CHECK_ARG(c->dy && c->w && c->dx, "conv_bwd_data2: null pointers");
+    if (c->transposed && (c->relu_src || c->out_gate)) N3D_UNSUPPORTED("conv_bwd_data2: transposed conv with relu / gate extras");
+    pair = pair && !(c->flags_data & N3D_NO_MFMA) && !c->g->depthwise;
+  }
+  if (pair) {
+    // data gradient of a conv = gather with data_grad=true, of a transposed conv = gather with data_grad=false (run_gather convention)
+    const PairExtras x0{c0->relu_src, c0->rld, c0->out_gate}, x1{c1->relu_src, c1->rld, c1->out_gate};
+    const int r = mfma_conv_pair_try(c0->g, !c0->transposed, c0->dy, c0->dyld, c0->w, nullptr, c0->dx, c0->dxld, c0->flags_data & ~N3D_RELU_IN, nullptr,
+                                     nullptr, c0->ws_data, c0->ws_data_bytes, c1->g, !c1->transposed, c1->dy, c1->dyld, c1->w, nullptr, c1->dx,
+                                     c1->dxld, c1->flags_data & ~N3D_RELU_IN, nullptr, nullptr, c1->ws_data, c1->ws_data_bytes, (hipStream_t)stream,
+                                     &x0, &x1);
+    if (r < 0) return r;
+    if (r == 1) return N3D_OK;
+  }
+  for (int i = 0; i < 2; ++i) {
+    const n3d_conv_bwd_call* c = cs[i];
+    const int e = c->transposed ? n3d_convT_bwd_data(c->g, c->dy, c->dyld, c->w, c->dx, c->dxld, c->flags_data, c->ws_data, c->ws_data_bytes, stream)
+                                : n3d_conv_bwd_data(c->g, c->dy, c->dyld, c->w, c->dx, c->dxld, c->flags_data, c->relu_src, c->rld, c->out_gate,
+                                                    c->ws_data, c->ws_data_bytes, stream);
     if (e) return e;
   }
   return N3D_OK;

@@ -51,7 +51,7 @@ template <int MT, int NT, int KSPLIT>
 __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const int by, float* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, kk = lane >> 4;
-  const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd, Ns = (int64_t)a.Ds * a.Hs * a.Ws;
+  const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
   const int64_t Mtot = (int64_t)a.B * Nd;
   constexpr int ROWS_PER_WAVE = 16 * MT;
   constexpr int ROWS_PER_BLOCK = ROWS_PER_WAVE * (KSPLIT == 1 ? 4 : 1);
@@ -480,8 +480,13 @@ __device__ float4 n3d_zero_page[1];  // zero-initialised; source of the conv zer
 static const void* zero_page_ptr() {
   static thread_local const void* p = nullptr;
   static thread_local int dev = -1;
-  int d = 0; hipGetDevice(&d);
-  if (!p || d != dev) { void* q = nullptr; hipGetSymbolAddress(&q, HIP_SYMBOL(n3d_zero_page)); p = q; dev = d; }
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) return nullptr;
+  if (!p || d != dev) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(n3d_zero_page)) != hipSuccess) return nullptr;  // callers fall back to the kernels without LDS-DMA
+    p = q; dev = d;
+  }
   return p;
 }
 
@@ -568,7 +573,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64_kernel(VxArgs a) {
   const int d0 = (bx / th_n) * TD;
   const int64_t N = (int64_t)a.D * a.H * a.W;
   const float* srcb = a.src + (int64_t)b * N * a.sld;
-  const int j = lane & 3, blk = lane >> 2;
+  const int j = lane & 3;
   VSTAMP(6);
   VSTAMP(0);
 
@@ -1267,6 +1272,7 @@ template <int C, int TD, int DIL>
 static int launch_vox_t(VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
   a.tiles = p.tiles;
   a.zero_page = zero_page_ptr();
+  if (!a.zero_page) return 0;
   if constexpr (C == 4 && TD == 4) {
     if (p.nw == 2) { hipLaunchKernelGGL((conv_vox64_kernel<C, TD, DIL, 2>), dim3(p.tiles * B), dim3(128), p.lds, s, a); return 1; }
   }
@@ -1586,6 +1592,7 @@ int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   Vw2Args a;
   a.x = x; a.xld = xld; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.dy = dy; a.dyld = dyld; a.oD = g->Do; a.oH = g->Ho; a.oW = g->Wo;
   a.partial = partial; a.dchunk = g->Do / dsplit; a.zero_page = zero_page_ptr();
+  if (!a.zero_page) return 0;
   dim3 grid(tiles, g->B);
   if (g->Ci == 4) {
     if (g->dil == 1) hipLaunchKernelGGL((vox_wgrad_s2_kernel<4, 1>), grid, dim3(256), lds, s, a);
@@ -1632,6 +1639,7 @@ int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const flo
   VwArgs a;
   a.x = x; a.xld = xld; a.dy = dy; a.dyld = dyld; a.partial = partial; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.dchunk = p.dchunk;
   a.zero_page = zero_page_ptr();
+  if (!a.zero_page) return 0;
   dim3 grid(p.tiles, g->B);
   if (p.C == 4) {
     if (p.dil == 1) hipLaunchKernelGGL((vox_wgrad_kernel<4, 1>), grid, dim3(256), p.lds, s, a);
@@ -1723,6 +1731,7 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
       Vs2Args a;
       a.src = src; a.sld = sld; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.dst = dst; a.dld = dld; a.oD = g->Do; a.oH = g->Ho; a.oW = g->Wo;
       a.wq = wq; a.bias = bias; a.flags = flags; a.stats = stats; a.rows_per_sample = v2.tiles; a.tiles = v2.tiles; a.zero_page = zero_page_ptr();
+      if (!a.zero_page) { set_error("conv(vox_s2): zero page symbol unavailable"); return N3D_ERR_HIP; }
       launch_vs2(a, v2, g->B, s);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) { set_error("conv(vox_s2) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
@@ -1742,6 +1751,7 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
       VupArgs a;
       a.src = src; a.sld = sld; a.D = g->Do; a.H = g->Ho; a.W = g->Wo; a.dst = dst; a.dld = dld;
       a.wq = wq; a.bias = bias; a.flags = flags; a.stats = stats; a.rows_per_sample = v3.tiles; a.tiles = v3.tiles; a.zero_page = zero_page_ptr();
+      if (!a.zero_page) { set_error("conv(vox_up): zero page symbol unavailable"); return N3D_ERR_HIP; }
       if (v3.C == 4) { if (v3.dil == 1) hipLaunchKernelGGL((conv_vox_up_kernel<4, 1>), dim3(v3.tiles * g->B), dim3(64), v3.lds, s, a);
                        else hipLaunchKernelGGL((conv_vox_up_kernel<4, 2>), dim3(v3.tiles * g->B), dim3(64), v3.lds, s, a); }
       else { if (v3.dil == 1) hipLaunchKernelGGL((conv_vox_up_kernel<8, 1>), dim3(v3.tiles * g->B), dim3(64), v3.lds, s, a);
@@ -1764,7 +1774,8 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
       VxArgs a;
       a.src = src; a.sld = sld; a.dst = dst; a.dld = dld; a.wq = wq; a.bias = bias; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.flags = flags;
       a.stats = stats; a.rows_per_sample = v.tiles * v.nw;
-      if (v.C == 4) launch_vox_c<4>(a, v, g->B, s); else launch_vox_c<8>(a, v, g->B, s);
+      const int launched = v.C == 4 ? launch_vox_c<4>(a, v, g->B, s) : launch_vox_c<8>(a, v, g->B, s);
+      if (!launched) { set_error("conv(vox64): zero page symbol unavailable"); return N3D_ERR_HIP; }
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) { set_error("conv(vox64) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
       return 1;
@@ -1829,7 +1840,7 @@ int g16_prepare(const n3d_conv_geom* g, bool data_grad, const float* src, int64_
 int mfma_conv_pair_try(const n3d_conv_geom* g0, bool dg0, const float* src0, int64_t sld0, const float* w0, const float* bias0, float* dst0,
                        int64_t dld0, int flags0, const float* gate0, double* stats0, void* ws0, size_t wsb0, const n3d_conv_geom* g1, bool dg1,
                        const float* src1, int64_t sld1, const float* w1, const float* bias1, float* dst1, int64_t dld1, int flags1,
-                       const float* gate1, double* stats1, void* ws1, size_t wsb1, hipStream_t s) {
+                       const float* gate1, double* stats1, void* ws1, size_t wsb1, hipStream_t s, const PairExtras* x0, const PairExtras* x1) {
   // decide before touching anything (g16_prepare packs weights)
   if (vx_plan(g0).ok || vx_plan(g1).ok) return 0;
   const G16Plan p0 = g16_plan(g0, dg0), p1 = g16_plan(g1, dg1);
@@ -1837,9 +1848,12 @@ int mfma_conv_pair_try(const n3d_conv_geom* g0, bool dg0, const float* src0, int
   if (sld0 % 4 != 0 || !aligned16(src0) || sld1 % 4 != 0 || !aligned16(src1)) return 0;
   PairArgs q;
   G16Plan t0, t1;
-  int r = g16_prepare(g0, dg0, src0, sld0, w0, bias0, dst0, dld0, flags0, gate0, nullptr, 0, nullptr, stats0, ws0, wsb0, s, &q.a0, &t0);
+  // x0 / x1: the data-gradient extras of a conv (ReLU mask source of the input, per-(b,c) output gate); NULL for a forward conv
+  int r = g16_prepare(g0, dg0, src0, sld0, w0, bias0, dst0, dld0, flags0, gate0, x0 ? x0->relu_src : nullptr, x0 ? x0->rld : 0,
+                      x0 ? x0->out_gate : nullptr, stats0, ws0, wsb0, s, &q.a0, &t0);
   if (r <= 0) return r < 0 ? r : N3D_ERR_INVALID;
-  r = g16_prepare(g1, dg1, src1, sld1, w1, bias1, dst1, dld1, flags1, gate1, nullptr, 0, nullptr, stats1, ws1, wsb1, s, &q.a1, &t1);
+  r = g16_prepare(g1, dg1, src1, sld1, w1, bias1, dst1, dld1, flags1, gate1, x1 ? x1->relu_src : nullptr, x1 ? x1->rld : 0,
+                  x1 ? x1->out_gate : nullptr, stats1, ws1, wsb1, s, &q.a1, &t1);
   if (r <= 0) return r < 0 ? r : N3D_ERR_INVALID;
   const int64_t M0 = (int64_t)g0->B * q.a0.Dd * q.a0.Hd * q.a0.Wd, M1 = (int64_t)g1->B * q.a1.Dd * q.a1.Hd * q.a1.Wd;
   q.gx0 = (int)cdiv(M0, 16); q.gx1 = (int)cdiv(M1, 16);

@@ -193,4 +193,8 @@ __device__ __forceinline__ float wave_sum_f(float v) { return wave_classsum_f(v,
 __device__ __forceinline__ double wave_sum_d(double v) { return wave_classsum_d(v, 1); }
 #endif
 
+// data-gradient extras of one conv in a paired MFMA launch (conv_mfma.hip, mfma_conv_pair_try): ReLU mask source of the
+// conv input (and its pitch), per-(b,c) gate applied to the result
+struct PairExtras { const float* relu_src; int64_t rld; const float* out_gate; };
+
 }  // namespace n3d

@@ -301,6 +301,19 @@ def conv_bwd_both2(calls):
             _ctx.keep.append(ws)
 
 
+def conv_bwd_data2(calls):
+    """Data gradients of two convs, one launch where libn3d can fold them (distinct dx targets, small-tensor MFMA shapes).
+    calls = [(g, dy, w, dx, flags, relu_src, out_gate, transposed)] * 2, arguments as conv_bwd_data."""
+    cs, keep = [], []
+    for (g, dy, w, dx, flags, relu_src, out_gate, transposed) in calls:
+        ws, wsp, n, flags = _packed(w, g, not transposed, flags, dy.t.device)
+        keep.append((ws, g))
+        cs.append(ConvBwdCall(C.pointer(g), 1 if transposed else 0, flags, 0, 0, None, 0, dy.p.value, dy.ld, w.data_ptr(), dx.p.value, dx.ld,
+                              relu_src.p.value if relu_src is not None else None, relu_src.ld if relu_src is not None else 0,
+                              _vp(out_gate), wsp.value if hasattr(wsp, "value") else wsp, n, None, None, None, None, 0, None))
+    check(_lib.load().n3d_conv_bwd_data2(C.byref(cs[0]), C.byref(cs[1]), stream_ptr()), "n3d_conv_bwd_data2")
+
+
 def conv_bwd_both(g, x: View, dy: View, w, dx: View, dw, dbias, flags_data=0, relu_src: View | None = None, out_gate=None,
                   flags_weight=0, in_gate=None, transposed=False):
     """conv_bwd_data + conv_bwd_weight of one conv; one launch where libn3d can fold them."""

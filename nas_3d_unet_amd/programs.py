@@ -193,6 +193,20 @@ class DenseConvW(WeightProgram):
                 RELU_IN if saved.relu_in else 0, saved.gate, self.transposed)
         return call, dx_out, [dw, db]
 
+    def bwd_data_call(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias):
+        """call tuple for K.conv_bwd_data2 if this backward is a data gradient only (frozen weights: the architecture pass of
+        the search step), else None"""
+        x, g = saved.x, saved.g
+        if not need_dx or saved.pre is not None or self.m.weight.requires_grad or self.m.bias.requires_grad:
+            return None
+        if self.transposed and (saved.relu_in or saved.gate is not None):
+            return None
+        if dx_out is None:
+            dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+            dx_acc = False
+        call = (g, draw, self.m.weight, dx_out, ACCUMULATE if dx_acc else 0, x if saved.relu_in else None, saved.gate, self.transposed)
+        return call, dx_out, [None, None]
+
     def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
         x, g = saved.x, saved.g
         w = self.m.weight
@@ -543,6 +557,11 @@ def pair_backward(segA, sA, segB, sB, dout, argsA, argsB, doutB=None, alphaA=Non
         if all(c is not None for c in cands) and cands[0][1].p.value != cands[1][1].p.value:
             K.conv_bwd_both2([c[0] for c in cands])
             pre = [(c[1].t, c[2]) for c in cands]
+        else:
+            cands = [o[0].weight.bwd_data_call(o[1].ws, o[2]["draw"], o[4][0], o[4][1], o[4][2], o[3][2] is not None) for o in order]
+            if all(c is not None for c in cands) and cands[0][1].p.value != cands[1][1].p.value:
+                K.conv_bwd_data2([c[0] for c in cands])
+                pre = [(c[1].t, c[2]) for c in cands]
     # weight-op backward in reverse forward order (B then A), as the unpaired path does
     for k, (seg, s, t, (dgamma, dbeta, dcb), args) in enumerate(order):
         need_dx, dx_out, dx_acc = args

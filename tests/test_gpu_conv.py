@@ -232,3 +232,17 @@ def test_conv_pairs_match_single_calls(specA, specB):
         assert_close(dw, dwc, 1e-4, "dw (pair)")
         if db is not None:
             assert_close(db, dbc, 1e-4, "db (pair)")
+    # data gradients only (n3d_conv_bwd_data2), accumulating into a pre-filled target behind the ReLU mask of the conv input
+    # where the single call supports it: == what the two single calls give
+    pair, single = [], []
+    for (g, x, dy, w, dx, dw, db, _, _, _, _, _, transposed) in bwd_calls:
+        mask_src = None if transposed else x
+        base = torch.from_numpy(_mk(tuple(dx.t.shape), 77)).to(dev)
+        t2 = K.as_view(K.empty_ndhwc(*dx.t.shape, dev)); t2.t.copy_(base)
+        t1 = K.as_view(K.empty_ndhwc(*dx.t.shape, dev)); t1.t.copy_(base)
+        pair.append((g, dy, w, t2, K.ACCUMULATE, mask_src, None, transposed))
+        K.conv_bwd_data(g, dy, w, t1, K.ACCUMULATE, mask_src, None, transposed)
+        single.append(t1)
+    K.conv_bwd_data2(pair)
+    for c, t1 in zip(pair, single):
+        assert_close(c[3].t, t1.t.cpu().numpy(), 1e-6, "dx (data-gradient pair)")
