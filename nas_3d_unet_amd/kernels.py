@@ -210,7 +210,7 @@ class step_context:
 
 def _packed(w, g, data_grad, flags, device):
     """(ws tensor or None, ws ptr, ws bytes, flags) for a forward / data-gradient conv call."""
-    if _ctx is not None:
+    if _ctx is not None and not getattr(w, "_n3d_nopack", False):  # temporaries (zero-padded weights) are packed by the call itself
         sl = _ctx.slot(w, g, data_grad, flags)
         if sl is not None:
             return None, C.c_void_p(sl[0]), sl[1], flags | PREPACKED
@@ -249,10 +249,11 @@ def conv_bwd_data(g, dy: View, w, dx: View, flags=0, relu_src: View | None = Non
                                     stream_ptr()), "n3d_conv_bwd_data")
 
 
-def conv_bwd_weight(g, x: View, dy: View, dw, dbias, flags=0, in_gate=None, transposed=False):
+def conv_bwd_weight(g, x: View, dy: View, dw, dbias, flags=0, in_gate=None, transposed=False, defer=True):
+    """defer=False: dw is complete when the call returns to the stream (no batched reduction at the end of backward)"""
     ws, n = _ws(g, x.t.device)
     lib = _lib.load()
-    job = FinalJob() if _ctx is not None else None
+    job = FinalJob() if (_ctx is not None and defer) else None
     jp = C.byref(job) if job is not None else None
     sp = _side_launch_ptr([x.t, dy.t, ws, in_gate]) if job is not None else stream_ptr()
     if transposed:

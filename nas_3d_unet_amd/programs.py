@@ -132,8 +132,8 @@ class DenseConvW(WeightProgram):
     def norm_fed_bias(self):
         return self.m.bias
 
-    def geom(self, x):
-        w = self.m.weight
+    def geom(self, x, w=None):
+        w = self.m.weight if w is None else w
         if self.transposed:
             cin_t, cout_t = w.shape[0], w.shape[1]
             if x.C != cin_t:
@@ -159,8 +159,16 @@ class DenseConvW(WeightProgram):
             s.pre = (x, relu_in, gate)
             x = _materialise_pre(x, relu_in, gate)
             relu_in, gate = False, None
-        g = self.geom(x)
-        shp = self.out_shape(x)
+        w = self.m.weight
+        s.wpad = None
+        if x.C % 4 != 0 and not self.transposed:
+            # 1-3 input modalities at the stems (or any conv input whose channel count is not a multiple of 4): the kernels
+            # read channels four at a time, so input and weight get zero channels up to the next multiple (copies only)
+            s.cin = x.C
+            x, w = self._pad_input_channels(x)
+            s.wpad = w
+        g = self.geom(x, w)
+        shp = (g.B, g.Ci, g.Di, g.Hi, g.Wi) if self.transposed else (g.B, g.Co, g.Do, g.Ho, g.Wo)
         y = K.as_view(K.empty_ndhwc(*shp, x.t.device))
         stats, rows = None, 0
         if want_stats:
@@ -168,8 +176,18 @@ class DenseConvW(WeightProgram):
             if rows > 0:  # 0: this shape's kernel cannot emit statistics -> seg_forward runs n3d_channel_stats
                 stats = torch.empty((x.B, rows, shp[1], 2), dtype=torch.float64, device=x.t.device)
         s.x, s.g, s.relu_in, s.gate = x, g, relu_in, gate
-        call = (g, x, self.m.weight, self.m.bias, y, RELU_IN if relu_in else 0, gate, stats, self.transposed)
+        call = (g, x, w, self.m.bias, y, RELU_IN if relu_in else 0, gate, stats, self.transposed)
         return call, (y, stats, rows, s)
+
+    def _pad_input_channels(self, x):
+        c4 = (x.C + 3) // 4 * 4
+        xp = K.as_view(K.zeros_ndhwc(x.B, c4, x.D, x.H, x.W, x.t.device))
+        xp.t[:, :x.C].copy_(x.t)
+        w = self.m.weight
+        wp = torch.zeros((w.shape[0], c4) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+        wp[:, :x.C].copy_(w.detach())
+        wp._n3d_nopack = True
+        return xp, wp
 
     def fwd(self, x, relu_in, gate, want_stats):
         call, res = self.fwd_prepare(x, relu_in, gate, want_stats)
@@ -182,7 +200,7 @@ class DenseConvW(WeightProgram):
         x, g = saved.x, saved.g
         dw = K.grad_target(self.m.weight)
         db = None if skip_bias else K.grad_target(self.m.bias)
-        if not (need_dx and saved.pre is None and dw is not None and g.Ci % 16 == 0 and g.Co % 16 == 0):
+        if not (need_dx and saved.pre is None and saved.wpad is None and dw is not None and g.Ci % 16 == 0 and g.Co % 16 == 0):
             return None
         if self.transposed and (db is not None or saved.relu_in or saved.gate is not None):
             return None
@@ -197,7 +215,7 @@ class DenseConvW(WeightProgram):
         """call tuple for K.conv_bwd_data2 if this backward is a data gradient only (frozen weights: the architecture pass of
         the search step), else None"""
         x, g = saved.x, saved.g
-        if not need_dx or saved.pre is not None or self.m.weight.requires_grad or self.m.bias.requires_grad:
+        if not need_dx or saved.pre is not None or saved.wpad is not None or self.m.weight.requires_grad or self.m.bias.requires_grad:
             return None
         if self.transposed and (saved.relu_in or saved.gate is not None):
             return None
@@ -207,8 +225,34 @@ class DenseConvW(WeightProgram):
         call = (g, draw, self.m.weight, dx_out, ACCUMULATE if dx_acc else 0, x if saved.relu_in else None, saved.gate, self.transposed)
         return call, dx_out, [None, None]
 
+    def _bwd_padded(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias):
+        """backward of a conv whose input channels were zero-padded (fwd_prepare): gradients of the padded tensors, real slices out"""
+        x, g, wp, cin = saved.x, saved.g, saved.wpad, saved.cin
+        dw = K.grad_target(self.m.weight)
+        db = None if skip_bias else K.grad_target(self.m.bias)
+        if dw is not None or db is not None:
+            dwp = torch.empty_like(wp) if dw is not None else None
+            K.conv_bwd_weight(g, x, draw, dwp, db, RELU_IN if saved.relu_in else 0, saved.gate, False, defer=False)
+            if dw is not None:
+                dw.copy_(dwp[:, :cin])
+        dx = None
+        if need_dx:
+            dxp = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+            K.conv_bwd_data(g, draw, wp, dxp, 0, x if saved.relu_in else None, saved.gate, False)
+            if dx_out is None:
+                dx_out = K.as_view(K.empty_ndhwc(x.B, cin, x.D, x.H, x.W, x.t.device))
+                dx_acc = False
+            if dx_acc:
+                dx_out.t.add_(dxp.t[:, :cin])
+            else:
+                dx_out.t.copy_(dxp.t[:, :cin])
+            dx = dx_out.t
+        return dx, [dw, db]
+
     def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
         x, g = saved.x, saved.g
+        if saved.wpad is not None:
+            return self._bwd_padded(saved, draw, need_dx, dx_out, dx_acc, skip_bias)
         w = self.m.weight
         dw = K.grad_target(w)
         db = None if skip_bias else K.grad_target(self.m.bias)

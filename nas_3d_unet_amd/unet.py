@@ -27,6 +27,12 @@ def cell_specs(init_n_kernels, depth, n_nodes, channel_change):
         prev1 = n_nodes * node_c
         if channel_change:
             node_c //= 2
+    widths = sorted({wide} | {spec[2] for spec in specs})
+    if any(c % 4 for c in widths):
+        # the kernels move channels four at a time (16-byte NDHWC vectors); only a conv INPUT may have another count
+        raise NotImplementedError("nas_3d_unet_amd: every feature-map channel count must be a multiple of 4; init_n_kernels=%d, n_nodes=%d, "
+                                  "depth=%d give stems of %d and cell nodes of %s channels (config.yml's 4 / 3 / 4: 12 and 4..64)"
+                                  % (init_n_kernels, n_nodes, depth, wide, sorted({spec[2] for spec in specs})))
     return specs, prev1
 
 

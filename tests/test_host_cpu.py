@@ -199,3 +199,23 @@ def test_checkpoint_interop_with_torch_adam_and_scheduler(tmp_path):
     gp = tmp_path / "best_genotype.pkl"
     ck.save_genotype(gp, gene, 3)
     assert ck.load_genotype(gp) == gene
+
+
+def test_channel_plan_matches_oracle_and_rejects_unsupported_widths():
+    """unet.cell_specs: the (c0, c1, c_node, downward) plan equals the oracle's restatement of nas.py:33-49 / searched.py:74-90,
+    and widths the 4-channel-vector kernels cannot run fail at construction with an explanation"""
+    import pytest
+    from nas_3d_unet_amd import unet
+    from oracle import ref_path as orc
+    for cfg in (orc.DEFAULT_CFG, orc.NetCfg(4, 8, 3, 3, 2, True), orc.NetCfg(1, 4, 1, 2, 4, False)):
+        specs, head_in = unet.cell_specs(cfg.init_n_kernels, cfg.depth, cfg.n_nodes, cfg.channel_change)
+        P = orc.supernet_param_specs(cfg)
+        names = dict(P) if not isinstance(P, dict) else P
+        for k, (c0, c1, cn, down) in enumerate(specs):
+            pre = ("kernel.down_cells.%d." % k) if down else ("kernel.up_cells.%d." % (k - cfg.depth))
+            assert tuple(names[pre + "preprocess0.conv.weight"])[:2] == (cn, c0), (k, specs[k])
+            assert tuple(names[pre + "preprocess1.conv.weight"])[:2] == (cn, c1), (k, specs[k])
+        assert tuple(names["kernel.last_conv.0.conv.weight"])[:2] == (cfg.out_channels, head_in)
+    for bad in ((2, 3, 3, True), (5, 3, 3, True), (6, 2, 3, False)):
+        with pytest.raises(NotImplementedError, match="multiple of 4"):
+            unet.cell_specs(*bad)

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Hyper-parameter sweep against the CPU oracle (GPU box): network widths / depths / node counts / channel counts other than
+config.yml's, searched net and supernet, one forward + backward each: loss, probabilities and every parameter gradient.
+A limit finder for the shape-specialised kernels' fallbacks -- tests/ pins the default configuration."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+from _util import fill_module
+from nas_3d_unet_amd import loss, nas, searched
+from oracle import ref_path as orc
+
+dev = torch.device("cuda")
+
+
+def genotype_for(n_nodes, flavour):
+    """a legal genotype for any node count: every node takes inputs (k % 2) and (k + 1) (its predecessor or a cell input)"""
+    down_s2 = ["down_conv", "down_dil_conv", "down_dep_conv", "down_se_conv", "max_pool", "avg_pool"]
+    up_s2 = ["up_conv", "up_dil_conv", "up_dep_conv", "up_se_conv"]
+    s1 = ["conv", "dil_conv", "dep_conv", "se_conv", "identity"]
+    if flavour == "conv":
+        down_s2, up_s2, s1 = down_s2[:2], up_s2[:2], s1[:2]
+    down, up = [], []
+    for k in range(n_nodes):
+        for j, idx in enumerate((k % 2, k + 1)):
+            n = 2 * k + j
+            down.append((down_s2[n % len(down_s2)] if idx < 2 else s1[n % len(s1)], idx))
+            up.append((up_s2[n % len(up_s2)] if idx == 1 else s1[n % len(s1)], idx))
+    return orc.Genotype(down, up)
+
+
+def check(tag, cfg, net, P, fwd, B=2, size=32):
+    rng = np.random.default_rng(17)
+    xn = rng.standard_normal((B, cfg.in_channels, size, size, size)).astype(np.float32)
+    tn = (rng.uniform(0, 1, (B, cfg.out_channels, size, size, size)) < 0.3).astype(np.float32)
+    pr = fwd(torch.from_numpy(xn))
+    lr = orc.dice_loss(pr, torch.from_numpy(tn))
+    lr.backward()
+    p = net(torch.from_numpy(xn).to(dev))
+    l = loss.WeightedDiceLoss()(p, torch.from_numpy(tn).to(dev))
+    l.backward()
+    bad = []
+    if abs(float(l) - float(lr)) > 5e-6:
+        bad.append("loss %.7f vs %.7f" % (float(l), float(lr)))
+    dp = float((p.detach().cpu() - pr.detach()).abs().max())
+    if dp > 3e-5:
+        bad.append("probs %.2e" % dp)
+    total = float(torch.sqrt(sum((q.grad.double() ** 2).sum() for q in P.values() if q.grad is not None)))
+    worst = 0.0
+    for n, q in net.named_parameters():
+        ref = P[n].grad
+        if ref is None:
+            ref = torch.zeros_like(P[n])
+        if q.grad is None:
+            bad.append("no grad for " + n)
+            continue
+        d = float((q.grad.cpu() - ref).abs().max())
+        lim = 3e-4 * float(ref.abs().max()) + 2e-5 * total
+        worst = max(worst, d / lim)
+        if d > lim:
+            bad.append("%s %.2e > %.2e" % (n, d, lim))
+    print("%-58s %s (loss %.5f, worst grad err / limit %.2f)" % (tag, "OK" if not bad else "MISMATCH " + "; ".join(bad[:4]), float(l), worst), flush=True)
+    return not bad
+
+
+def run_searched(cfg, flavour):
+    gene = genotype_for(cfg.n_nodes, flavour)
+    net = searched.SearchedNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, cfg.channel_change,
+                               searched.Genotype(list(gene.down), list(gene.up)))
+    fill_module(net)
+    net.last_conv[0].dropout = None
+    net.last_conv[0]._segments = None
+    net = net.to(dev)
+    P = orc.make_params(orc.searched_param_specs(cfg, gene), requires_grad=True)
+    return check("searched/%s %s" % (flavour, tuple(cfg)), cfg, net, P, lambda x: orc.searched_forward(P, x, gene, cfg))
+
+
+def run_supernet(cfg):
+    net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)
+    fill_module(net)
+    net.kernel.last_conv[0].dropout = None
+    net.kernel.last_conv[0]._segments = None
+    net = net.to(dev)
+    P = orc.make_params(orc.supernet_param_specs(cfg), requires_grad=True)
+    return check("supernet %s" % (tuple(cfg),), cfg, net, P, lambda x: orc.supernet_forward(P, x, cfg))
+
+
+C = orc.NetCfg
+ok = True
+for cfg in (C(4, 4, 3, 4, 3, True), C(4, 2, 3, 4, 3, True), C(4, 6, 3, 3, 3, True), C(4, 8, 3, 3, 3, True), C(4, 16, 3, 2, 3, True),
+            C(4, 4, 3, 4, 3, False), C(1, 4, 1, 3, 3, True), C(3, 5, 4, 3, 3, True), C(4, 4, 3, 3, 2, True), C(4, 4, 3, 3, 4, True),
+            C(2, 12, 2, 2, 2, False)):
+    for flavour in ("conv", "all"):
+        try:
+            ok &= run_searched(cfg, flavour)
+        except Exception as e:  # noqa: BLE001 -- a sweep: report and go on
+            ok = False
+            print("searched/%s %s RAISED %s: %s" % (flavour, tuple(cfg), type(e).__name__, str(e)[:200]), flush=True)
+for cfg in (C(4, 4, 3, 3, 3, True), C(4, 2, 3, 3, 2, True), C(4, 8, 3, 2, 3, False), C(3, 5, 2, 2, 4, True)):
+    try:
+        ok &= run_supernet(cfg)
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        print("supernet %s RAISED %s: %s" % (tuple(cfg), type(e).__name__, str(e)[:200]), flush=True)
+print("ALL OK" if ok else "FAILURES")
