@@ -240,6 +240,17 @@ int n3d_affine_act2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, float*
 int n3d_gn_bwd_coeffs2(const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int C, int G, int64_t N, void* stream);
 int n3d_affine_act_bwd_apply2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
                               const n3d_gn_bwd_term* t1, int B, int64_t N, int C, void* stream);
+/* N-term forms for a supernet node (cell.py:76-81: node = sum over its edges of sum_k alpha[e][k] * op_k(x_e); 8-16 of the
+ * 10-22 terms end in a GroupNorm).  `terms`: array of n <= N3D_MAX_GROUP_TERMS descriptors, C a power of two in 4..64.
+ * n3d_gn_coeffsN: n x n3d_gn_coeffs in one launch.  n3d_affine_actN: out (+)= sum_k w_k * act_k(a_k * raw_k + b_k) in term
+ * order, one pass over the node buffer.  Backward: n3d_affine_act_bwd_reduceN (fills sums of every term; all terms read the
+ * same node gradient), n3d_gn_bwd_coeffsN (cA / cB / cC and the parameter gradients), n3d_affine_act_bwd_applyN (every draw). */
+#define N3D_MAX_GROUP_TERMS 8
+int n3d_gn_coeffsN(const n3d_gn_fwd_term* terms, int n, int B, int C, int G, int64_t N, float eps, void* stream);
+int n3d_affine_actN(const n3d_gn_fwd_term* terms, int n, float* out, int64_t old_, int B, int64_t N, int C, int flags, void* stream);
+int n3d_affine_act_bwd_reduceN(const float* dout, int64_t dld, const n3d_gn_bwd_term* terms, int n, int B, int64_t N, int C, void* stream);
+int n3d_gn_bwd_coeffsN(const n3d_gn_bwd_term* terms, int n, int B, int C, int G, int64_t N, void* stream);
+int n3d_affine_act_bwd_applyN(const float* dout, int64_t dld, const n3d_gn_bwd_term* terms, int n, int B, int64_t N, int C, void* stream);
 /* plain (no norm) epilogue backward coefficients: A = w, Bc = Cc = 0, dalpha = sum Sz */
 int n3d_plain_bwd_coeffs(const double* sums, int rows, const float* wptr, int B, int C, float* dalpha,
                          float* A, void* stream);

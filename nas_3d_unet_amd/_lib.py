@@ -115,6 +115,11 @@ PROTOTYPES = {
     "n3d_affine_act2": (_i, [C.POINTER(GnFwdTerm), C.POINTER(GnFwdTerm), _p, _i64, _p, _i64, _i, _i64, _i, _i, _p]),
     "n3d_gn_bwd_coeffs2": (_i, [C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i, _i, _i64, _p]),
     "n3d_affine_act_bwd_apply2": (_i, [_p, _i64, _p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _p]),
+    "n3d_gn_coeffsN": (_i, [C.POINTER(GnFwdTerm), _i, _i, _i, _i, _i64, C.c_float, _p]),
+    "n3d_affine_actN": (_i, [C.POINTER(GnFwdTerm), _i, _p, _i64, _i, _i64, _i, _i, _p]),
+    "n3d_affine_act_bwd_reduceN": (_i, [_p, _i64, C.POINTER(GnBwdTerm), _i, _i, _i64, _i, _p]),
+    "n3d_gn_bwd_coeffsN": (_i, [C.POINTER(GnBwdTerm), _i, _i, _i, _i, _i64, _p]),
+    "n3d_affine_act_bwd_applyN": (_i, [_p, _i64, C.POINTER(GnBwdTerm), _i, _i, _i64, _i, _p]),
     "n3d_affine_act_gn2": (_i, [C.POINTER(GnFwdTerm), C.POINTER(GnFwdTerm), _i, _f, _p, _i64, _p, _i64, _i, _i64, _i, _i, _p]),
     "n3d_affine_act_bwd_reduce2": (_i, [_p, _i64, _p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _p]),
     "n3d_affine_act_bwd_apply_gn2": (_i, [_p, _i64, _p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _i, _p]),

@@ -103,12 +103,10 @@ __device__ __forceinline__ void reduce_rows(const double* __restrict__ rows, int
 
 struct GnCoefArgs { const double* stats; int rows; const float* gamma; const float* beta; float* a; float* bb; float* mean_rstd; double* sumraw; };
 
-// grid (B, terms): blockIdx.y selects the op (two ops of a searched-cell node share one launch)
-__global__ __launch_bounds__(256) void gn_coeffs_kernel(GnCoefArgs q0, GnCoefArgs q1, int C, int G, double count, float eps) {
+__device__ __forceinline__ void gn_coeffs_body(const GnCoefArgs q, int C, int G, double count, float eps) {
   __shared__ double part[256];
   __shared__ double tot[192];
   __shared__ double mr[64 * 2];
-  const GnCoefArgs q = blockIdx.y ? q1 : q0;
   const int b = blockIdx.x;
   const int t = threadIdx.x;
   const float gam_t = (t < C) ? q.gamma[t] : 0.f, bet_t = (t < C) ? q.beta[t] : 0.f;  // issued before the row loads
@@ -134,6 +132,21 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(GnCoefArgs q0, GnCoefArg
     q.bb[b * C + t] = bet_t - mean * av;
     if (q.sumraw) q.sumraw[b * C + t] = tot[t * 2];
   }
+}
+// grid (B, terms): blockIdx.y selects the op (two ops of a searched-cell node share one launch)
+__global__ __launch_bounds__(256) void gn_coeffs_kernel(GnCoefArgs q0, GnCoefArgs q1, int C, int G, double count, float eps) {
+  gn_coeffs_body(blockIdx.y ? q1 : q0, C, G, count, eps);
+}
+// up to N3D_MAX_GROUP_TERMS ops of a supernet node in one launch: grid (B, terms).  The descriptors live in the kernel
+// arguments; the switch keeps every access to them statically indexed (a dynamic index would turn into dependent scalar loads)
+#define N3D_PICK8(arr, i, dst)                                                                                     \
+  switch (i) { case 0: dst = arr[0]; break; case 1: dst = arr[1]; break; case 2: dst = arr[2]; break; case 3: dst = arr[3]; break; \
+               case 4: dst = arr[4]; break; case 5: dst = arr[5]; break; case 6: dst = arr[6]; break; default: dst = arr[7]; break; }
+struct GnCoefArgsN { GnCoefArgs q[8]; };
+__global__ __launch_bounds__(256) void gn_coeffsN_kernel(GnCoefArgsN qs, int C, int G, double count, float eps) {
+  GnCoefArgs q;
+  N3D_PICK8(qs.q, blockIdx.y, q);
+  gn_coeffs_body(q, C, G, count, eps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -271,9 +284,7 @@ struct GnBwdCoefArgs {
   float* A; float* Bc; float* Cc; const double* sumraw; float* dbias_conv;
 };
 
-// grid (terms): blockIdx.x selects the op
-__global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffs_kernel(GnBwdCoefArgs q0, GnBwdCoefArgs q1, int B, int C, int G, double count) {
-  const GnBwdCoefArgs q = blockIdx.x ? q1 : q0;
+__device__ __forceinline__ void gn_bwd_coeffs_body(const GnBwdCoefArgs q, int B, int C, int G, double count) {
   const double* __restrict__ sums = q.sums; const int rows = q.rows; const float* __restrict__ gamma = q.gamma;
   const float* __restrict__ mean_rstd = q.mean_rstd; const float* __restrict__ wptr = q.wptr;
   float* __restrict__ dgamma = q.dgamma; float* __restrict__ dbeta = q.dbeta; float* __restrict__ dalpha = q.dalpha;
@@ -339,6 +350,16 @@ __global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffs_kernel(GnBwdCoefAr
       for (int i = 0; i < 64; ++i) sdz += acc4[k][2][i];
     *dalpha = (float)sdz;
   }
+}
+// grid (terms): blockIdx.x selects the op
+__global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffs_kernel(GnBwdCoefArgs q0, GnBwdCoefArgs q1, int B, int C, int G, double count) {
+  gn_bwd_coeffs_body(blockIdx.x ? q1 : q0, B, C, G, count);
+}
+struct GnBwdCoefArgsN { GnBwdCoefArgs q[8]; };
+__global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffsN_kernel(GnBwdCoefArgsN qs, int B, int C, int G, double count) {
+  GnBwdCoefArgs q;
+  N3D_PICK8(qs.q, blockIdx.x, q);
+  gn_bwd_coeffs_body(q, B, C, G, count);
 }
 
 __global__ __launch_bounds__(256) void plain_bwd_coeffs_kernel(const double* __restrict__ sums, int rows, const float* __restrict__ wptr,
@@ -1145,6 +1166,155 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// N-term epilogues of a supernet node (cell.py:76-81: a node sums 10-22 weighted primitives; 8-16 of them end in a GroupNorm).
+// Coefficients come from gn_coeffsN / gn_bwd_coeffsN.  Forward: ONE pass writes (or accumulates into) the node buffer for up
+// to 8 terms, in term order.  Backward: the per-term reductions and d(raw) passes are independent, so the launch is simply
+// batched over blockIdx.z.
+// ------------------------------------------------------------------------------------------------
+struct FwdTermN { const float* raw[8]; int64_t rld[8]; const float* a[8]; const float* b[8]; const float* wptr[8]; int relu[8]; int n; };
+
+template <bool ACC>
+__global__ __launch_bounds__(256) void affine_actN_kernel(FwdTermN ts, float* __restrict__ out, int64_t old_, int64_t N, int C, EwMap m) {
+  const int b = blockIdx.y, t = threadIdx.x;
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
+  if (vl >= m.vpb) return;
+  const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+  if (v0 >= N) return;
+  const int co = b * C + c4 * 4;
+  float4 av[8], bv[8];
+  float w[8], fl[8];
+  const float* rb[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < ts.n) {
+      av[k] = *reinterpret_cast<const float4*>(ts.a[k] + co);
+      bv[k] = *reinterpret_cast<const float4*>(ts.b[k] + co);
+      w[k] = ts.wptr[k] ? *ts.wptr[k] : 1.0f;
+      fl[k] = ts.relu[k] ? 0.f : -INFINITY;
+      rb[k] = ts.raw[k] + (int64_t)b * N * ts.rld[k] + c4 * 4;
+    }
+  }
+  float* ob = out + (int64_t)b * N * old_ + c4 * 4;
+  for (int it = 0; it < m.iters; ++it) {
+    const int64_t v = v0 + (int64_t)it * m.vpb;
+    if (v >= N) break;
+    float4 q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < ts.n) q[k] = *reinterpret_cast<const float4*>(rb[k] + v * ts.rld[k]);
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACC) z = *reinterpret_cast<const float4*>(ob + v * old_);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < ts.n) {
+        z.x = fmaf(w[k], fmaxf(fmaf(av[k].x, q[k].x, bv[k].x), fl[k]), z.x); z.y = fmaf(w[k], fmaxf(fmaf(av[k].y, q[k].y, bv[k].y), fl[k]), z.y);
+        z.z = fmaf(w[k], fmaxf(fmaf(av[k].z, q[k].z, bv[k].z), fl[k]), z.z); z.w = fmaf(w[k], fmaxf(fmaf(av[k].w, q[k].w, bv[k].w), fl[k]), z.w);
+      }
+    }
+    *reinterpret_cast<float4*>(ob + v * old_) = z;
+  }
+}
+
+struct BwdRedTermN { BwdRedTerm t[8]; };
+// grid (rows, B, terms): the reduction pass of affine_bwd_reduce2_kernel for term blockIdx.z
+__global__ __launch_bounds__(256) void affine_bwd_reduceN_kernel(const float* __restrict__ dout, int64_t dld, BwdRedTermN ts, int64_t N, int C,
+                                                                 EwMap m) {
+  __shared__ double lds[4 * 64 * 12];
+  BwdRedTerm tm;
+  N3D_PICK8(ts.t, blockIdx.z, tm);
+  const int b = blockIdx.y;
+  const int t = threadIdx.x;
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
+  const bool active = vl < m.vpb;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, sz[4] = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const float4 av = *reinterpret_cast<const float4*>(tm.a + b * C + c4 * 4), bv = *reinterpret_cast<const float4*>(tm.b + b * C + c4 * 4);
+    const float a4[4] = {av.x, av.y, av.z, av.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
+    const float thr = tm.relu ? 0.f : -INFINITY;
+    const float* db = dout + (int64_t)b * N * dld + c4 * 4;
+    const float* rb = tm.raw + (int64_t)b * N * tm.rld + c4 * 4;
+    const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+    for (int it0 = 0; it0 < m.iters; it0 += 4) {
+      float4 dq[4], rq[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t v = v0 + (int64_t)(it0 + u) * m.vpb;
+        ok[u] = (it0 + u < m.iters) && v < N;
+        const int64_t vc = ok[u] ? v : 0;
+        dq[u] = *reinterpret_cast<const float4*>(db + vc * dld);
+        rq[u] = *reinterpret_cast<const float4*>(rb + vc * tm.rld);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        const float d[4] = {dq[u].x, dq[u].y, dq[u].z, dq[u].w}, r[4] = {rq[u].x, rq[u].y, rq[u].z, rq[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float z = fmaf(a4[j], r[j], b4[j]);
+          const float g = z > thr ? d[j] : 0.f;
+          z = fmaxf(z, thr);
+          s1[j] += g;
+          s2[j] = fmaf(g, r[j], s2[j]);
+          sz[j] = fmaf(d[j], z, sz[j]);
+        }
+      }
+    }
+  }
+  double vals[12];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    vals[j] = wave_classsum_f(s1[j], m.cpb); vals[4 + j] = wave_classsum_f(s2[j], m.cpb); vals[8 + j] = wave_classsum_f(sz[j], m.cpb);
+  }
+  double* row = tm.sums + ((int64_t)b * gridDim.x + blockIdx.x) * C * 3;
+  block_reduce_to_row<3>(vals, m.cpb, row, lds, true);
+}
+
+struct BwdApplyTerm { const float* raw; int64_t rld; const float* a; const float* b; const float* cA; const float* cB; const float* cC;
+                      float* draw; int64_t drld; int relu; };
+struct BwdApplyTermN { BwdApplyTerm t[8]; };
+// grid (rows, B, terms): draw = cA * g + cB + cC * raw of term blockIdx.z (g = dout behind the term's ReLU mask)
+__global__ __launch_bounds__(256) void affine_bwd_applyN_kernel(const float* __restrict__ dout, int64_t dld, BwdApplyTermN ts, int64_t N, int C,
+                                                                EwMap m) {
+  BwdApplyTerm tm;
+  N3D_PICK8(ts.t, blockIdx.z, tm);
+  const int b = blockIdx.y, t = threadIdx.x;
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
+  if (vl >= m.vpb) return;
+  const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+  if (v0 >= N) return;
+  const int co = b * C + c4 * 4;
+  const float* db = dout + (int64_t)b * N * dld + c4 * 4;
+  const float* rb = tm.raw + (int64_t)b * N * tm.rld + c4 * 4;
+  float* ob = tm.draw + (int64_t)b * N * tm.drld + c4 * 4;
+  // the first voxel's operands are requested together with the coefficients
+  float4 d0 = *reinterpret_cast<const float4*>(db + v0 * dld), r0 = *reinterpret_cast<const float4*>(rb + v0 * tm.rld);
+  const float4 fa = *reinterpret_cast<const float4*>(tm.a + co), fb = *reinterpret_cast<const float4*>(tm.b + co);
+  const float4 qA = *reinterpret_cast<const float4*>(tm.cA + co), qB = *reinterpret_cast<const float4*>(tm.cB + co), qC = *reinterpret_cast<const float4*>(tm.cC + co);
+  const float a4[4] = {fa.x, fa.y, fa.z, fa.w}, b4[4] = {fb.x, fb.y, fb.z, fb.w};
+  const float A4[4] = {qA.x, qA.y, qA.z, qA.w}, B4[4] = {qB.x, qB.y, qB.z, qB.w}, C4[4] = {qC.x, qC.y, qC.z, qC.w};
+  const float thr = tm.relu ? 0.f : -INFINITY;
+  for (int it = 0; it < m.iters; ++it) {
+    const int64_t v = v0 + (int64_t)it * m.vpb;
+    if (v >= N) break;
+    const int64_t vn = v + m.vpb;
+    const bool more = it + 1 < m.iters && vn < N;
+    float4 d1 = d0, r1 = r0;
+    if (more) { d1 = *reinterpret_cast<const float4*>(db + vn * dld); r1 = *reinterpret_cast<const float4*>(rb + vn * tm.rld); }
+    const float d[4] = {d0.x, d0.y, d0.z, d0.w}, r[4] = {r0.x, r0.y, r0.z, r0.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float z = fmaf(a4[j], r[j], b4[j]);
+      const float g = z > thr ? d[j] : 0.f;
+      o[j] = fmaf(A4[j], g, fmaf(C4[j], r[j], B4[j]));
+    }
+    *reinterpret_cast<float4*>(ob + v * tm.drld) = make_float4(o[0], o[1], o[2], o[3]);
+    d0 = d1; r0 = r1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // SE gate
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const double* __restrict__ stats, int rows, double count, const float* __restrict__ w1,
@@ -1644,6 +1814,98 @@ int n3d_affine_act_bwd_apply2(const float* dout, int64_t dld, const float* dout1
   if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_apply2(dout1)")) return e; }
   if (dout1) hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<true, true>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], B, 1, (double)N, N, C, m);
   else hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<true, false>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], B, 1, (double)N, N, C, m);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+// ---- N-term forms (supernet nodes) -----------------------------------------------------------------
+static int check_group(int n, int C, const char* who) {
+  if (n < 1 || n > N3D_MAX_GROUP_TERMS) { set_error("%s: 1..%d terms, got %d", who, N3D_MAX_GROUP_TERMS, n); return N3D_ERR_INVALID; }
+  if (C < 4 || C > 64 || (C & (C - 1)) != 0) { set_error("%s: C must be a power of two in 4..64 (C=%d)", who, C); return N3D_ERR_UNSUPPORTED; }
+  return N3D_OK;
+}
+
+int n3d_gn_coeffsN(const n3d_gn_fwd_term* terms, int n, int B, int C, int G, int64_t N, float eps, void* stream) {
+  N3D_CHECK_ARG(terms && B > 0 && N > 0 && G >= 1 && C % G == 0, "gn_coeffsN: bad args");
+  if (int e = check_group(n, C, "gn_coeffsN")) return e;
+  GnCoefArgsN qs;
+  for (int i = 0; i < 8; ++i) {
+    const n3d_gn_fwd_term* t = &terms[i < n ? i : 0];
+    N3D_CHECK_ARG(t->stats && t->gamma && t->beta && t->a_out && t->b_out && t->rows >= 1, "gn_coeffsN: null term pointer");
+    qs.q[i] = GnCoefArgs{t->stats, t->rows, t->gamma, t->beta, t->a_out, t->b_out, t->mean_rstd_out, t->sumraw};
+  }
+  hipLaunchKernelGGL(gn_coeffsN_kernel, dim3(B, n), dim3(256), 0, (hipStream_t)stream, qs, C, G, (double)N, eps);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_affine_actN(const n3d_gn_fwd_term* terms, int n, float* out, int64_t old_, int B, int64_t N, int C, int flags, void* stream) {
+  N3D_CHECK_ARG(terms && out && B > 0 && N > 0, "affine_actN: bad args");
+  if (int e = check_group(n, C, "affine_actN")) return e;
+  FwdTermN ts;
+  ts.n = n;
+  for (int i = 0; i < 8; ++i) {
+    const n3d_gn_fwd_term* t = &terms[i < n ? i : 0];
+    N3D_CHECK_ARG(t->raw && t->a_out && t->b_out, "affine_actN: null term pointer");
+    if (int e = check_vec(t->raw, t->rld, C, "affine_actN(raw)")) return e;
+    ts.raw[i] = t->raw; ts.rld[i] = t->rld; ts.a[i] = t->a_out; ts.b[i] = t->b_out; ts.wptr[i] = t->wptr; ts.relu[i] = t->relu;
+  }
+  if (int e = check_vec(out, old_, C, "affine_actN(out)")) return e;
+  EwMap m = ew_map(N, C);
+  dim3 grid(m.rows, B), blk(256);
+  if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL(affine_actN_kernel<true>, grid, blk, 0, (hipStream_t)stream, ts, out, old_, N, C, m);
+  else hipLaunchKernelGGL(affine_actN_kernel<false>, grid, blk, 0, (hipStream_t)stream, ts, out, old_, N, C, m);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_affine_act_bwd_reduceN(const float* dout, int64_t dld, const n3d_gn_bwd_term* terms, int n, int B, int64_t N, int C, void* stream) {
+  N3D_CHECK_ARG(dout && terms && B > 0 && N > 0, "affine_act_bwd_reduceN: bad args");
+  if (int e = check_group(n, C, "affine_act_bwd_reduceN")) return e;
+  if (int e = check_vec(dout, dld, C, "bwd_reduceN(dout)")) return e;
+  BwdRedTermN ts;
+  for (int i = 0; i < 8; ++i) {
+    const n3d_gn_bwd_term* t = &terms[i < n ? i : 0];
+    N3D_CHECK_ARG(t->raw && t->a && t->b && t->sums, "affine_act_bwd_reduceN: null term pointer");
+    if (int e = check_vec(t->raw, t->rld, C, "bwd_reduceN(raw)")) return e;
+    ts.t[i] = BwdRedTerm{t->raw, t->rld, t->a, t->b, t->sums, t->relu};
+  }
+  EwMap m = ew_map(N, C);
+  hipLaunchKernelGGL(affine_bwd_reduceN_kernel, dim3(m.rows, B, n), dim3(256), 0, (hipStream_t)stream, dout, dld, ts, N, C, m);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_gn_bwd_coeffsN(const n3d_gn_bwd_term* terms, int n, int B, int C, int G, int64_t N, void* stream) {
+  N3D_CHECK_ARG(terms && B > 0 && N > 0 && G >= 1 && C % G == 0, "gn_bwd_coeffsN: bad args");
+  if (int e = check_group(n, C, "gn_bwd_coeffsN")) return e;
+  GnBwdCoefArgsN qs;
+  for (int i = 0; i < 8; ++i) {
+    const n3d_gn_bwd_term* t = &terms[i < n ? i : 0];
+    N3D_CHECK_ARG(t->sums && t->gamma && t->mean_rstd && t->cA && t->cB && t->cC && t->rows >= 1, "gn_bwd_coeffsN: null term pointer");
+    N3D_CHECK_ARG(!t->dbias_conv || t->sumraw, "gn_bwd_coeffsN: dbias_conv needs the forward per-channel sums");
+    qs.q[i] = GnBwdCoefArgs{t->sums, t->rows, t->gamma, t->mean_rstd, t->wptr, t->dgamma, t->dbeta, t->dalpha, t->cA, t->cB, t->cC, t->sumraw,
+                            t->dbias_conv};
+  }
+  hipLaunchKernelGGL(gn_bwd_coeffsN_kernel, dim3(n), dim3(256 * GNB_BP), 0, (hipStream_t)stream, qs, B, C, G, (double)N);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_affine_act_bwd_applyN(const float* dout, int64_t dld, const n3d_gn_bwd_term* terms, int n, int B, int64_t N, int C, void* stream) {
+  N3D_CHECK_ARG(dout && terms && B > 0 && N > 0, "affine_act_bwd_applyN: bad args");
+  if (int e = check_group(n, C, "affine_act_bwd_applyN")) return e;
+  if (int e = check_vec(dout, dld, C, "bwd_applyN(dout)")) return e;
+  BwdApplyTermN ts;
+  for (int i = 0; i < 8; ++i) {
+    const n3d_gn_bwd_term* t = &terms[i < n ? i : 0];
+    N3D_CHECK_ARG(t->raw && t->a && t->b && t->cA && t->cB && t->cC && t->draw, "affine_act_bwd_applyN: null term pointer");
+    if (int e = check_vec(t->raw, t->rld, C, "bwd_applyN(raw)")) return e;
+    if (int e = check_vec(t->draw, t->drld, C, "bwd_applyN(draw)")) return e;
+    ts.t[i] = BwdApplyTerm{t->raw, t->rld, t->a, t->b, t->cA, t->cB, t->cC, t->draw, t->drld, t->relu};
+  }
+  EwMap m = ew_map(N, C);
+  hipLaunchKernelGGL(affine_bwd_applyN_kernel, dim3(m.rows, B, n), dim3(256), 0, (hipStream_t)stream, dout, dld, ts, N, C, m);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

@@ -20,6 +20,7 @@ from ._lib import ACCUMULATE
 
 
 PAIR_SUPERNET_TERMS = True  # pair the GroupNorm-type terms of a supernet node (False: one epilogue launch per primitive)
+GROUP_SUPERNET_TERMS = True  # ... and take them up to eight at a time where a node has three or more (P.group_forward)
 REUSE_GRAD_OUTPUT = False  # see _run_backward; switched on by the trainers for the duration of their backward pass
 
 
@@ -106,11 +107,17 @@ def _node_units(plan):
         dense.sort(key=lambda fi: (rank[fi], fi))
         rest = [fi for fi in pairable if fi not in rank]
         u = []
-        for group in (dense, rest):
-            for i in range(0, len(group) - 1, 2):
-                u.append((group[i], group[i + 1]))
-            if len(group) % 2:
-                u.append((group[-1],))
+        if GROUP_SUPERNET_TERMS and K.group_shape_ok(plan.c_node) and len(pairable) >= 3 and len({flat[fi][2].norm.eps for fi in pairable}) == 1:
+            # N-term groups: all coefficients in one launch and one pass over the node buffer (backward: three launches per group)
+            both = dense + rest
+            for i in range(0, len(both), K.MAX_GROUP_TERMS):
+                u.append(tuple(both[i:i + K.MAX_GROUP_TERMS]))
+        else:
+            for group in (dense, rest):
+                for i in range(0, len(group) - 1, 2):
+                    u.append((group[i], group[i + 1]))
+                if len(group) % 2:
+                    u.append((group[-1],))
         u.extend((fi,) for fi in mine if fi not in pairable)
         units.append(u)
     plan._units = units
@@ -171,7 +178,10 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2):
                     xs.extend(nodes)
                 arow = (alpha1 if amat == 1 else alpha2)[row] if amat else None
                 args.append((seg, xin, arow, col))
-            if len(unit) == 2:
+            if len(unit) >= 3:
+                for fi, sv in zip(unit, P.group_forward(args, nodes[node], started[node])):
+                    st.saved[fi] = sv
+            elif len(unit) == 2:
                 (sa_, xa, aa, ca), (sb_, xb, ab, cb) = args
                 st.saved[unit[0]], st.saved[unit[1]] = P.pair_forward(sa_, xa, sb_, xb, nodes[node], None, started[node], (aa, ca), (ab, cb))
             else:
@@ -246,6 +256,18 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
         all_units = _node_units(plan)
         for node in reversed(range(nn)):
             for unit in reversed(all_units[node]):
+                if len(unit) >= 3:
+                    # targets are claimed in reverse term order, like the unpaired reverse walk
+                    terms = []
+                    for fi in reversed(unit):
+                        _, idx, seg, col, amat, row = flat[fi]
+                        arow, dal = alpha_of(amat, row)
+                        target, acc = tgt(idx)
+                        terms.append((seg, st.saved[fi], (True, target, acc), (arow, col, dal)))
+                    terms.reverse()
+                    for (seg, _, _, _), (_, gl) in zip(terms, P.group_backward(terms, dnodes[node])):
+                        put(seg, gl)
+                    continue
                 if len(unit) == 2:
                     fa, fb = unit
                     _, ia, sega, cola, amata, rowa = flat[fa]

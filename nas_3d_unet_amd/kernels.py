@@ -515,6 +515,68 @@ def affine_act_bwd_gn2(dout: View, terms, G, dout1: View | None = None):
     return outs
 
 
+MAX_GROUP_TERMS = 8  # N3D_MAX_GROUP_TERMS
+
+
+def group_shape_ok(Cc):
+    """channel counts the N-term epilogues accept (include/n3d.h, n3d_affine_actN)"""
+    return 4 <= Cc <= 64 and (Cc & (Cc - 1)) == 0
+
+
+def affine_act_gnN(terms, G, eps, out: View, flags=0):
+    """GroupNorm -> [ReLU] -> weighted sum of up to 8 terms into one output, two launches (all coefficients, then one pass over
+    the output): terms = [(raw, stats, rows, gamma, beta, wptr, relu)].  Returns [(a, b, mean_rstd, sumraw)] (saved for backward)."""
+    n = len(terms)
+    raw0 = terms[0][0]
+    dev = raw0.t.device
+    B, Cc = raw0.B, raw0.C
+    fbuf = torch.empty((n, 2 * B * Cc + 2 * B * G), dtype=torch.float32, device=dev)
+    dbuf = torch.empty((n, B * Cc), dtype=torch.float64, device=dev)
+    arr = (GnFwdTerm * n)()
+    saved = []
+    for i, (raw, stats, rows, gamma, beta, wptr, relu) in enumerate(terms):
+        a = fbuf[i, :B * Cc].view(B, Cc)
+        b = fbuf[i, B * Cc:2 * B * Cc].view(B, Cc)
+        mr = fbuf[i, 2 * B * Cc:].view(B, G, 2)
+        sr = dbuf[i].view(B, Cc)
+        arr[i] = GnFwdTerm(raw.p.value, raw.ld, stats.data_ptr(), rows, 1 if relu else 0, gamma.data_ptr(), beta.data_ptr(),
+                           _vp(wptr), a.data_ptr(), b.data_ptr(), mr.data_ptr(), sr.data_ptr())
+        saved.append((a, b, mr, sr))
+    lib = _lib.load()
+    check(lib.n3d_gn_coeffsN(arr, n, B, Cc, G, raw0.N, eps, stream_ptr()), "n3d_gn_coeffsN")
+    check(lib.n3d_affine_actN(arr, n, out.p, out.ld, B, raw0.N, Cc, flags, stream_ptr()), "n3d_affine_actN")
+    return saved
+
+
+def affine_act_bwd_gnN(dout: View, terms, G):
+    """Backward of affine_act_gnN, three launches for all terms (reductions, coefficients + parameter gradients, d(raw)):
+    terms = [dict(raw, a, b, mr, sumraw, gamma, beta, wptr, relu, conv_bias, draw, dalpha_ptr)].
+    Returns [(dgamma, dbeta, dconv_bias | None)]."""
+    n = len(terms)
+    raw0 = terms[0]["raw"]
+    dev = raw0.t.device
+    B, Cc, N = raw0.B, raw0.C, raw0.N
+    rows = stats_rows(N, Cc)
+    sums = torch.empty((n, B, rows, Cc, 3), dtype=torch.float64, device=dev)
+    coef = torch.empty((n, 3, B, Cc), dtype=torch.float32, device=dev)
+    arr = (GnBwdTerm * n)()
+    outs = []
+    for i, t in enumerate(terms):
+        dgamma, dbeta = grad_target(t["gamma"]), grad_target(t["beta"])
+        cb = t.get("conv_bias")
+        dcb = grad_target(cb) if (cb is not None and t["sumraw"] is not None) else None
+        raw, draw = t["raw"], t["draw"]
+        arr[i] = GnBwdTerm(raw.p.value, raw.ld, t["a"].data_ptr(), t["b"].data_ptr(), sums[i].data_ptr(), rows, 1 if t["relu"] else 0,
+                           t["gamma"].data_ptr(), t["mr"].data_ptr(), _vp(t.get("wptr")), _vp(t["sumraw"]), draw.p.value, draw.ld,
+                           _vp(dgamma), _vp(dbeta), _vp(t.get("dalpha_ptr")), _vp(dcb), *[coef[i, j].data_ptr() for j in range(3)])
+        outs.append((dgamma, dbeta, dcb))
+    lib = _lib.load()
+    check(lib.n3d_affine_act_bwd_reduceN(dout.p, dout.ld, arr, n, B, N, Cc, stream_ptr()), "n3d_affine_act_bwd_reduceN")
+    check(lib.n3d_gn_bwd_coeffsN(arr, n, B, Cc, G, N, stream_ptr()), "n3d_gn_bwd_coeffsN")
+    check(lib.n3d_affine_act_bwd_applyN(dout.p, dout.ld, arr, n, B, N, Cc, stream_ptr()), "n3d_affine_act_bwd_applyN")
+    return outs
+
+
 def affine_act_bwd_reduce(dout: View, raw: View, a, b, flags=0):
     rows = stats_rows(raw.N, raw.C)
     sums = torch.empty((raw.B, rows, raw.C, 3), dtype=torch.float64, device=raw.t.device)

@@ -581,45 +581,112 @@ def pair_backward(segA, sA, segB, sB, dout, argsA, argsB, doutB=None, alphaA=Non
         rb = seg_backward(segB, sB, doutB if doutB is not None else dout, *argsB, aB[0], aB[1], aB[2])
         ra = seg_backward(segA, sA, dout, *argsA, aA[0], aA[1], aA[2])
         return ra, rb
-    terms = []
-    for seg, s, al in ((segA, sA, aA), (segB, sB, aB)):
-        cbias = seg.weight.norm_fed_bias()
-        if cbias is not None and not cbias.requires_grad:
-            cbias = None
-        raw = s.raw
-        terms.append(dict(raw=raw, a=s.a, b=s.b, mr=s.mr, sumraw=s.sumraw, gamma=seg.norm.weight, beta=seg.norm.bias,
-                          wptr=_wptr(al[0], al[1]), dalpha_ptr=(C.c_void_p(al[2].data_ptr() + 4 * al[1]) if al[2] is not None else None),
-                          relu=seg.relu_out, conv_bias=cbias,
-                          draw=K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))))
+    terms = [_gn_bwd_term(segA, sA, aA), _gn_bwd_term(segB, sB, aB)]
     outs = K.affine_act_bwd_gn2(dout, terms, sA.G, doutB)
-    results = []
-    order = ((segB, sB, terms[1], outs[1], argsB), (segA, sA, terms[0], outs[0], argsA))
-    # both weight ops plain convs of the deep levels with distinct input-gradient targets: one backward launch for both
-    pre = None
-    if all(isinstance(o[0].weight, DenseConvW) for o in order):
-        cands = [o[0].weight.bwd_call(o[1].ws, o[2]["draw"], o[4][0], o[4][1], o[4][2], o[3][2] is not None) for o in order]
-        if all(c is not None for c in cands) and cands[0][1].p.value != cands[1][1].p.value:
-            K.conv_bwd_both2([c[0] for c in cands])
-            pre = [(c[1].t, c[2]) for c in cands]
-        else:
-            cands = [o[0].weight.bwd_data_call(o[1].ws, o[2]["draw"], o[4][0], o[4][1], o[4][2], o[3][2] is not None) for o in order]
-            if all(c is not None for c in cands) and cands[0][1].p.value != cands[1][1].p.value:
-                K.conv_bwd_data2([c[0] for c in cands])
-                pre = [(c[1].t, c[2]) for c in cands]
     # weight-op backward in reverse forward order (B then A), as the unpaired path does
-    for k, (seg, s, t, (dgamma, dbeta, dcb), args) in enumerate(order):
-        need_dx, dx_out, dx_acc = args
-        if pre is not None:
-            dx, wg = pre[k]
-        else:
-            dx, wg = seg.weight.bwd(s.ws, t["draw"], need_dx, dx_out, dx_acc, dcb is not None)
-        wg = list(wg)
-        if dcb is not None:
-            for i, p in enumerate(seg.weight.params()):
-                if p is t["conv_bias"]:
-                    wg[i] = dcb
-        results.append((dx, wg + [dgamma, dbeta]))
+    order = ((segB, sB, terms[1], outs[1], argsB), (segA, sA, terms[0], outs[0], argsA))
+    results = _weight_backward(order)
     return results[1], results[0]
+
+
+def _gn_bwd_term(seg, s, alpha):
+    """descriptor of one GroupNorm-type term for K.affine_act_bwd_gn2 / affine_act_bwd_gnN; alpha = (row, column, dalpha row | None)"""
+    cbias = seg.weight.norm_fed_bias()
+    if cbias is not None and not cbias.requires_grad:
+        cbias = None
+    raw = s.raw
+    return dict(raw=raw, a=s.a, b=s.b, mr=s.mr, sumraw=s.sumraw, gamma=seg.norm.weight, beta=seg.norm.bias,
+                wptr=_wptr(alpha[0], alpha[1]), dalpha_ptr=(C.c_void_p(alpha[2].data_ptr() + 4 * alpha[1]) if alpha[2] is not None else None),
+                relu=seg.relu_out, conv_bias=cbias,
+                draw=K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device)))
+
+
+def _weight_backward(order):
+    """Weight-op backwards of GroupNorm-type terms whose d(raw) is ready.  order = [(seg, saved, term dict, (dgamma, dbeta,
+    dconv_bias), (need_dx, dx_out, dx_acc))] in execution order.  Two neighbouring plain convs with distinct input-gradient
+    targets share one launch (data + weight gradients: n3d_conv_bwd_both2; frozen weights: n3d_conv_bwd_data2).
+    Returns [(dx, grads ordered like seg.params())] in the same order."""
+    results = []
+    i = 0
+    while i < len(order):
+        pre = None
+        if i + 1 < len(order) and isinstance(order[i][0].weight, DenseConvW) and isinstance(order[i + 1][0].weight, DenseConvW):
+            two = order[i:i + 2]
+            cands = [o[0].weight.bwd_call(o[1].ws, o[2]["draw"], o[4][0], o[4][1], o[4][2], o[3][2] is not None) for o in two]
+            if all(c is not None for c in cands) and cands[0][1].p.value != cands[1][1].p.value:
+                K.conv_bwd_both2([c[0] for c in cands])
+                pre = [(c[1].t, c[2]) for c in cands]
+            else:
+                cands = [o[0].weight.bwd_data_call(o[1].ws, o[2]["draw"], o[4][0], o[4][1], o[4][2], o[3][2] is not None) for o in two]
+                if all(c is not None for c in cands) and cands[0][1].p.value != cands[1][1].p.value:
+                    K.conv_bwd_data2([c[0] for c in cands])
+                    pre = [(c[1].t, c[2]) for c in cands]
+        for k in range(2 if pre is not None else 1):
+            seg, s, t, (dgamma, dbeta, dcb), (need_dx, dx_out, dx_acc) = order[i + k]
+            if pre is not None:
+                dx, wg = pre[k]
+            else:
+                dx, wg = seg.weight.bwd(s.ws, t["draw"], need_dx, dx_out, dx_acc, dcb is not None)
+            wg = list(wg)
+            if dcb is not None:
+                for j, p in enumerate(seg.weight.params()):
+                    if p is t["conv_bias"]:
+                        wg[j] = dcb
+            results.append((dx, wg + [dgamma, dbeta]))
+        i += 2 if pre is not None else 1
+    return results
+
+
+def group_ok(segs):
+    """terms whose epilogues can run as ONE N-term group (K.affine_act_gnN): GroupNorm-type, one eps, 3..8 of them"""
+    return (3 <= len(segs) <= K.MAX_GROUP_TERMS and all(gn_pairable(g) for g in segs)
+            and all(g.norm.eps == segs[0].norm.eps for g in segs))
+
+
+def group_forward(terms, out, accumulate):
+    """Supernet node (cell.py:76-81): out (+)= sum_k alpha_k * GN_k(op_k(x_k)) for 3..8 GroupNorm-type terms.
+    terms = [(segment, input View, alpha row | None, alpha column)].  The weight ops run first (two neighbouring plain convs in one
+    launch), then all GroupNorm coefficients in one launch and ONE pass over `out`.  Returns the saved states, in term order."""
+    res = []
+    i = 0
+    while i < len(terms):
+        if i + 1 < len(terms) and isinstance(terms[i][0].weight, DenseConvW) and isinstance(terms[i + 1][0].weight, DenseConvW):
+            calls, rr = [], []
+            for seg, x, _, _ in terms[i:i + 2]:
+                call, r = seg.weight.fwd_prepare(x, seg.relu_in, None, True)
+                calls.append(call)
+                rr.append(list(r))
+            K.conv_fwd2(calls)
+            res.extend(rr)
+            i += 2
+        else:
+            seg, x, _, _ = terms[i]
+            res.append(list(seg.weight.fwd(x, seg.relu_in, None, seg.weight.produces_stats)))
+            i += 1
+    for r in res:
+        if r[1] is None:
+            r[1], r[2] = K.channel_stats(r[0])
+    raw0 = res[0][0]
+    G = group_count(raw0.C)
+    tl = [(r[0], r[1], r[2], seg.norm.weight, seg.norm.bias, _wptr(arow, col) if arow is not None else None, seg.relu_out)
+          for r, (seg, _, arow, col) in zip(res, terms)]
+    sv = K.affine_act_gnN(tl, G, terms[0][0].norm.eps, out, ACCUMULATE if accumulate else 0)
+    saved = []
+    for (raw, _, _, ws), (a, b, mr, sr) in zip(res, sv):
+        s = Saved()
+        s.ws, s.raw, s.kind, s.G = ws, raw, "gn", G
+        s.a, s.b, s.mr, s.sumraw = a, b, mr, sr
+        saved.append(s)
+    return saved
+
+
+def group_backward(terms, dout):
+    """Backward of group_forward.  terms = [(segment, saved, (need_dx, dx_out, dx_acc), (alpha row, column, dalpha row | None))] in
+    forward order; dout: View of the node gradient all of them consume.  Returns [(dx, grads)] in forward order."""
+    tds = [_gn_bwd_term(seg, s, al if al is not None else (None, 0, None)) for seg, s, _, al in terms]
+    outs = K.affine_act_bwd_gnN(dout, tds, terms[0][1].G)
+    order = [(seg, s, td, o, args) for (seg, s, args, _), td, o in zip(terms, tds, outs)][::-1]
+    return _weight_backward(order)[::-1]
 
 
 def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_row=None, alpha_k=0, dalpha=None):
