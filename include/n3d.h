@@ -243,7 +243,8 @@ int n3d_affine_act_bwd_apply2(const float* dout, int64_t dld, const float* dout1
 /* N-term forms for a supernet node (cell.py:76-81: node = sum over its edges of sum_k alpha[e][k] * op_k(x_e); 8-16 of the
  * 10-22 terms end in a GroupNorm).  `terms`: array of n <= N3D_MAX_GROUP_TERMS descriptors, C a power of two in 4..64.
  * n3d_gn_coeffsN: n x n3d_gn_coeffs in one launch.  n3d_affine_actN: out (+)= sum_k w_k * act_k(a_k * raw_k + b_k) in term
- * order, one pass over the node buffer.  Backward: n3d_affine_act_bwd_reduceN (fills sums of every term; all terms read the
+ * order, one pass over the node buffer; a_k = a_out, b_k = b_out of the term, NULL meaning 1 / 0, so the node's other
+ * primitives (SE gate: a = gate; pooling, identity-with-norm) ride in the same pass.  Backward: n3d_affine_act_bwd_reduceN (fills sums of every term; all terms read the
  * same node gradient), n3d_gn_bwd_coeffsN (cA / cB / cC and the parameter gradients), n3d_affine_act_bwd_applyN (every draw). */
 #define N3D_MAX_GROUP_TERMS 8
 int n3d_gn_coeffsN(const n3d_gn_fwd_term* terms, int n, int B, int C, int G, int64_t N, float eps, void* stream);

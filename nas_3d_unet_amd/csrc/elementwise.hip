@@ -1187,8 +1187,8 @@ __global__ __launch_bounds__(256) void affine_actN_kernel(FwdTermN ts, float* __
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     if (k < ts.n) {
-      av[k] = *reinterpret_cast<const float4*>(ts.a[k] + co);
-      bv[k] = *reinterpret_cast<const float4*>(ts.b[k] + co);
+      av[k] = ts.a[k] ? *reinterpret_cast<const float4*>(ts.a[k] + co) : make_float4(1.f, 1.f, 1.f, 1.f);
+      bv[k] = ts.b[k] ? *reinterpret_cast<const float4*>(ts.b[k] + co) : make_float4(0.f, 0.f, 0.f, 0.f);
       w[k] = ts.wptr[k] ? *ts.wptr[k] : 1.0f;
       fl[k] = ts.relu[k] ? 0.f : -INFINITY;
       rb[k] = ts.raw[k] + (int64_t)b * N * ts.rld[k] + c4 * 4;
@@ -1846,7 +1846,7 @@ int n3d_affine_actN(const n3d_gn_fwd_term* terms, int n, float* out, int64_t old
   ts.n = n;
   for (int i = 0; i < 8; ++i) {
     const n3d_gn_fwd_term* t = &terms[i < n ? i : 0];
-    N3D_CHECK_ARG(t->raw && t->a_out && t->b_out, "affine_actN: null term pointer");
+    N3D_CHECK_ARG(t->raw, "affine_actN: null term pointer");  // a_out / b_out may be NULL: scale 1 / shift 0
     if (int e = check_vec(t->raw, t->rld, C, "affine_actN(raw)")) return e;
     ts.raw[i] = t->raw; ts.rld[i] = t->rld; ts.a[i] = t->a_out; ts.b[i] = t->b_out; ts.wptr[i] = t->wptr; ts.relu[i] = t->relu;
   }

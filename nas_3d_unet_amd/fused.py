@@ -124,6 +124,23 @@ def _node_units(plan):
     return units
 
 
+def _node_fwd_units(plan):
+    """Forward launch schedule of a supernet cell.  With N-term groups the forward pass of a node takes ALL its primitives up
+    to eight at a time (P.group_forward: the pass over the node buffer does not care what produced a term's scale / shift),
+    in the order of _node_units followed by the primitives that stay single in backward."""
+    if getattr(plan, "_fwd_units", None) is not None:
+        return plan._fwd_units
+    units = _node_units(plan)
+    if GROUP_SUPERNET_TERMS and K.group_shape_ok(plan.c_node):
+        out = []
+        for u in units:
+            every = [fi for unit in u for fi in unit]
+            out.append([tuple(every[i:i + K.MAX_GROUP_TERMS]) for i in range(0, len(every), K.MAX_GROUP_TERMS)])
+        units = out
+    plan._fwd_units = units
+    return units
+
+
 def _run_forward(plan, x0, x1, alpha1, alpha2):
     """Returns (cell output tensor, saved state)."""
     with K.stats_cache():
@@ -165,7 +182,8 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2):
     # in the order of _node_units (a fixed order, but not the reference's left-to-right one: fp32 rounding differs)
     flat = _flat_terms(plan)
     st.saved = [None] * len(flat)
-    for node, units in enumerate(_node_units(plan)):
+    grouped = GROUP_SUPERNET_TERMS and K.group_shape_ok(plan.c_node)
+    for node, units in enumerate(_node_fwd_units(plan)):
         for unit in units:
             args = []
             for fi in unit:
@@ -178,7 +196,7 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2):
                     xs.extend(nodes)
                 arow = (alpha1 if amat == 1 else alpha2)[row] if amat else None
                 args.append((seg, xin, arow, col))
-            if len(unit) >= 3:
+            if grouped and len(unit) >= 2:
                 for fi, sv in zip(unit, P.group_forward(args, nodes[node], started[node])):
                     st.saved[fi] = sv
             elif len(unit) == 2:

@@ -523,9 +523,9 @@ def group_shape_ok(Cc):
     return 4 <= Cc <= 64 and (Cc & (Cc - 1)) == 0
 
 
-def affine_act_gnN(terms, G, eps, out: View, flags=0):
-    """GroupNorm -> [ReLU] -> weighted sum of up to 8 terms into one output, two launches (all coefficients, then one pass over
-    the output): terms = [(raw, stats, rows, gamma, beta, wptr, relu)].  Returns [(a, b, mean_rstd, sumraw)] (saved for backward)."""
+def gn_coeffsN(terms, G, eps):
+    """GroupNorm coefficients of up to 8 tensors of one shape in ONE launch: terms = [(raw, stats, rows, gamma, beta)].
+    Returns [(a, b, mean_rstd, sumraw)] (what affine_actN reads and backward needs)."""
     n = len(terms)
     raw0 = terms[0][0]
     dev = raw0.t.device
@@ -534,18 +534,26 @@ def affine_act_gnN(terms, G, eps, out: View, flags=0):
     dbuf = torch.empty((n, B * Cc), dtype=torch.float64, device=dev)
     arr = (GnFwdTerm * n)()
     saved = []
-    for i, (raw, stats, rows, gamma, beta, wptr, relu) in enumerate(terms):
+    for i, (raw, stats, rows, gamma, beta) in enumerate(terms):
         a = fbuf[i, :B * Cc].view(B, Cc)
         b = fbuf[i, B * Cc:2 * B * Cc].view(B, Cc)
         mr = fbuf[i, 2 * B * Cc:].view(B, G, 2)
         sr = dbuf[i].view(B, Cc)
-        arr[i] = GnFwdTerm(raw.p.value, raw.ld, stats.data_ptr(), rows, 1 if relu else 0, gamma.data_ptr(), beta.data_ptr(),
-                           _vp(wptr), a.data_ptr(), b.data_ptr(), mr.data_ptr(), sr.data_ptr())
+        arr[i] = GnFwdTerm(raw.p.value, raw.ld, stats.data_ptr(), rows, 0, gamma.data_ptr(), beta.data_ptr(), None, a.data_ptr(),
+                           b.data_ptr(), mr.data_ptr(), sr.data_ptr())
         saved.append((a, b, mr, sr))
-    lib = _lib.load()
-    check(lib.n3d_gn_coeffsN(arr, n, B, Cc, G, raw0.N, eps, stream_ptr()), "n3d_gn_coeffsN")
-    check(lib.n3d_affine_actN(arr, n, out.p, out.ld, B, raw0.N, Cc, flags, stream_ptr()), "n3d_affine_actN")
+    check(_lib.load().n3d_gn_coeffsN(arr, n, B, Cc, G, raw0.N, eps, stream_ptr()), "n3d_gn_coeffsN")
     return saved
+
+
+def affine_actN(terms, out: View, flags=0):
+    """out (+)= sum_k w_k * act_k(a_k * raw_k + b_k) for up to 8 terms in one pass: terms = [(raw, a | None, b | None, wptr, relu)]."""
+    n = len(terms)
+    raw0 = terms[0][0]
+    arr = (GnFwdTerm * n)()
+    for i, (raw, a, b, wptr, relu) in enumerate(terms):
+        arr[i] = GnFwdTerm(raw.p.value, raw.ld, None, 0, 1 if relu else 0, None, None, _vp(wptr), _vp(a), _vp(b), None, None)
+    check(_lib.load().n3d_affine_actN(arr, n, out.p, out.ld, raw0.B, raw0.N, raw0.C, flags, stream_ptr()), "n3d_affine_actN")
 
 
 def affine_act_bwd_gnN(dout: View, terms, G):

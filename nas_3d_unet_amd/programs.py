@@ -638,22 +638,23 @@ def _weight_backward(order):
 
 
 def group_ok(segs):
-    """terms whose epilogues can run as ONE N-term group (K.affine_act_gnN): GroupNorm-type, one eps, 3..8 of them"""
+    """terms whose BACKWARD epilogues can run as one N-term group (K.affine_act_bwd_gnN): GroupNorm-type, one eps, 3..8 of them"""
     return (3 <= len(segs) <= K.MAX_GROUP_TERMS and all(gn_pairable(g) for g in segs)
             and all(g.norm.eps == segs[0].norm.eps for g in segs))
 
 
 def group_forward(terms, out, accumulate):
-    """Supernet node (cell.py:76-81): out (+)= sum_k alpha_k * GN_k(op_k(x_k)) for 3..8 GroupNorm-type terms.
-    terms = [(segment, input View, alpha row | None, alpha column)].  The weight ops run first (two neighbouring plain convs in one
-    launch), then all GroupNorm coefficients in one launch and ONE pass over `out`.  Returns the saved states, in term order."""
+    """Supernet node (cell.py:76-81): out (+)= sum_k alpha_k * op_k(x_k) for up to 8 primitives of any kind (GroupNorm-type
+    convs, identity-with-norm, SE gates, pooling).  terms = [(segment, input View, alpha row | None, alpha column)].
+    The weight ops run first (two neighbouring plain convs in one launch), then the coefficients -- all GroupNorm ones in one
+    launch, one per SE gate -- and ONE pass over `out` for everything.  Returns the saved states, in term order."""
     res = []
     i = 0
     while i < len(terms):
         if i + 1 < len(terms) and isinstance(terms[i][0].weight, DenseConvW) and isinstance(terms[i + 1][0].weight, DenseConvW):
             calls, rr = [], []
             for seg, x, _, _ in terms[i:i + 2]:
-                call, r = seg.weight.fwd_prepare(x, seg.relu_in, None, True)
+                call, r = seg.weight.fwd_prepare(x, seg.relu_in, None, seg.norm is not None)
                 calls.append(call)
                 rr.append(list(r))
             K.conv_fwd2(calls)
@@ -661,22 +662,31 @@ def group_forward(terms, out, accumulate):
             i += 2
         else:
             seg, x, _, _ = terms[i]
-            res.append(list(seg.weight.fwd(x, seg.relu_in, None, seg.weight.produces_stats)))
+            res.append(list(seg.weight.fwd(x, seg.relu_in, None, seg.norm is not None and seg.weight.produces_stats)))
             i += 1
-    for r in res:
-        if r[1] is None:
-            r[1], r[2] = K.channel_stats(r[0])
-    raw0 = res[0][0]
-    G = group_count(raw0.C)
-    tl = [(r[0], r[1], r[2], seg.norm.weight, seg.norm.bias, _wptr(arow, col) if arow is not None else None, seg.relu_out)
-          for r, (seg, _, arow, col) in zip(res, terms)]
-    sv = K.affine_act_gnN(tl, G, terms[0][0].norm.eps, out, ACCUMULATE if accumulate else 0)
-    saved = []
-    for (raw, _, _, ws), (a, b, mr, sr) in zip(res, sv):
+    saved, gn = [], []
+    for r, (seg, _, _, _) in zip(res, terms):
         s = Saved()
-        s.ws, s.raw, s.kind, s.G = ws, raw, "gn", G
-        s.a, s.b, s.mr, s.sumraw = a, b, mr, sr
+        s.ws, s.raw = r[3], r[0]
+        s.a = s.b = s.mr = None
+        s.kind = "plain"
+        if seg.norm is not None:
+            if r[1] is None:
+                r[1], r[2] = K.channel_stats(r[0])
+            s.kind, s.G = "gn", group_count(r[0].C)
+            gn.append((s, (r[0], r[1], r[2], seg.norm.weight, seg.norm.bias)))
+        elif seg.se_gate is not None:
+            s.mean, s.hidden, s.a = seg.se_gate.fwd(r[0])
+            s.kind = "se"
         saved.append(s)
+    if gn:
+        eps = [seg.norm.eps for seg, _, _, _ in terms if seg.norm is not None]
+        if any(e != eps[0] for e in eps):
+            raise N3DError("group_forward: GroupNorm terms of one node with different eps")
+        for (s, _), (a, b, mr, sr) in zip(gn, K.gn_coeffsN([g[1] for g in gn], gn[0][0].G, eps[0])):
+            s.a, s.b, s.mr, s.sumraw = a, b, mr, sr
+    tl = [(s.raw, s.a, s.b, _wptr(arow, col) if arow is not None else None, seg.relu_out) for s, (seg, _, arow, col) in zip(saved, terms)]
+    K.affine_actN(tl, out, ACCUMULATE if accumulate else 0)
     return saved
 
 
