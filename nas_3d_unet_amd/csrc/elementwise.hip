@@ -1228,7 +1228,8 @@ __global__ __launch_bounds__(256) void affine_bwd_reduceN_kernel(const float* __
   const bool active = vl < m.vpb;
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, sz[4] = {0.f, 0.f, 0.f, 0.f};
   if (active) {
-    const float4 av = *reinterpret_cast<const float4*>(tm.a + b * C + c4 * 4), bv = *reinterpret_cast<const float4*>(tm.b + b * C + c4 * 4);
+    const float4 av = tm.a ? *reinterpret_cast<const float4*>(tm.a + b * C + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bv = tm.b ? *reinterpret_cast<const float4*>(tm.b + b * C + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float a4[4] = {av.x, av.y, av.z, av.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
     const float thr = tm.relu ? 0.f : -INFINITY;
     const float* db = dout + (int64_t)b * N * dld + c4 * 4;
@@ -1866,7 +1867,7 @@ int n3d_affine_act_bwd_reduceN(const float* dout, int64_t dld, const n3d_gn_bwd_
   BwdRedTermN ts;
   for (int i = 0; i < 8; ++i) {
     const n3d_gn_bwd_term* t = &terms[i < n ? i : 0];
-    N3D_CHECK_ARG(t->raw && t->a && t->b && t->sums, "affine_act_bwd_reduceN: null term pointer");
+    N3D_CHECK_ARG(t->raw && t->sums, "affine_act_bwd_reduceN: null term pointer");  // a / b may be NULL: scale 1 / shift 0
     if (int e = check_vec(t->raw, t->rld, C, "bwd_reduceN(raw)")) return e;
     ts.t[i] = BwdRedTerm{t->raw, t->rld, t->a, t->b, t->sums, t->relu};
   }

@@ -272,7 +272,26 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
             return (alpha1 if amat == 1 else alpha2)[row], (d[row] if d is not None else None)
 
         all_units = _node_units(plan)
+        batch_reduce = GROUP_SUPERNET_TERMS and K.group_shape_ok(cn)
         for node in reversed(range(nn)):
+            # the primitives that stay single (identity, SE gates, pooling) all start with a reduction pass over the same node
+            # gradient: those passes run up to eight per launch
+            pre = {}
+            if batch_reduce:
+                want = []
+                for unit in all_units[node]:
+                    if len(unit) == 1:
+                        fi, = unit
+                        _, _, seg, _, amat, row = flat[fi]
+                        s = st.saved[fi]
+                        if P.needs_reduce(seg, s, alpha_of(amat, row)[1]):
+                            want.append((fi, (s.raw, s.a if s.kind != "plain" else None, s.b if s.kind == "gn" else None,
+                                              seg.relu_out and s.kind != "se")))
+                for i in range(0, len(want), K.MAX_GROUP_TERMS):
+                    chunk = want[i:i + K.MAX_GROUP_TERMS]
+                    if len(chunk) >= 2:
+                        for (fi, _), r in zip(chunk, K.affine_act_bwd_reduceN(dnodes[node], [c[1] for c in chunk])):
+                            pre[fi] = r
             for unit in reversed(all_units[node]):
                 if len(unit) >= 3:
                     # targets are claimed in reverse term order, like the unpaired reverse walk
@@ -308,7 +327,8 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
                     todo = ((idx, seg, st.saved[fi], col, arow, dal),)
                 for idx, seg, s, col, arow, dal in todo:
                     target, acc = tgt(idx)
-                    _, gl = P.seg_backward(seg, s, dnodes[node], True, target, acc, arow, col, dal)
+                    _, gl = P.seg_backward(seg, s, dnodes[node], True, target, acc, arow, col, dal,
+                                           pre.get(unit[0]) if len(unit) == 1 else None)
                     put(seg, gl)
     for i in range(2):
         if not pre_started[i]:

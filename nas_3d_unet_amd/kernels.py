@@ -585,6 +585,20 @@ def affine_act_bwd_gnN(dout: View, terms, G):
     return outs
 
 
+def affine_act_bwd_reduceN(dout: View, terms):
+    """affine_act_bwd_reduce of up to 8 terms that consume the same gradient, one launch: terms = [(raw, a | None, b | None, relu)].
+    Returns [(sums, rows)]."""
+    n = len(terms)
+    raw0 = terms[0][0]
+    rows = stats_rows(raw0.N, raw0.C)
+    sums = torch.empty((n, raw0.B, rows, raw0.C, 3), dtype=torch.float64, device=raw0.t.device)
+    arr = (GnBwdTerm * n)()
+    for i, (raw, a, b, relu) in enumerate(terms):
+        arr[i] = GnBwdTerm(raw.p.value, raw.ld, _vp(a), _vp(b), sums[i].data_ptr(), rows, 1 if relu else 0, *([None] * 4), None, 0, *([None] * 7))
+    check(_lib.load().n3d_affine_act_bwd_reduceN(dout.p, dout.ld, arr, n, raw0.B, raw0.N, raw0.C, stream_ptr()), "n3d_affine_act_bwd_reduceN")
+    return [(sums[i], rows) for i in range(n)]
+
+
 def affine_act_bwd_reduce(dout: View, raw: View, a, b, flags=0):
     rows = stats_rows(raw.N, raw.C)
     sums = torch.empty((raw.B, rows, raw.C, 3), dtype=torch.float64, device=raw.t.device)

@@ -699,17 +699,23 @@ def group_backward(terms, dout):
     return _weight_backward(order)[::-1]
 
 
-def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_row=None, alpha_k=0, dalpha=None):
+def needs_reduce(seg, s, dalpha):
+    """does seg_backward start with the reduction pass over (dout, raw)?  (callers may batch those passes: pre_sums)"""
+    return s.kind in ("gn", "se") or dalpha is not None
+
+
+def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_row=None, alpha_k=0, dalpha=None, pre_sums=None):
     """Backward of one segment.  dout: View of d(out).  Returns (dx tensor | None, [param grads])
     with param grads ordered like seg.params().  If `dalpha` (a float tensor) is given,
-    dalpha[alpha_k] = <dout, z> is written (MixedOp architecture gradient, cell.py:29-32)."""
+    dalpha[alpha_k] = <dout, z> is written (MixedOp architecture gradient, cell.py:29-32).
+    pre_sums = (sums, rows): the reduction pass was already done (K.affine_act_bwd_reduceN over several terms of a node)."""
     wp = _wptr(alpha_row, alpha_k)
     dap = C.c_void_p(dalpha.data_ptr() + 4 * alpha_k) if dalpha is not None else None
     raw = s.raw
     fl = RELU if seg.relu_out else 0
     extra = []
     if s.kind == "gn":
-        sums, rows = K.affine_act_bwd_reduce(dout, raw, s.a, s.b, fl)
+        sums, rows = pre_sums if pre_sums is not None else K.affine_act_bwd_reduce(dout, raw, s.a, s.b, fl)
         cbias = seg.weight.norm_fed_bias()
         if cbias is not None and not cbias.requires_grad:
             cbias = None
@@ -744,7 +750,7 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
                     wg[i] = dcb
         return dx, wg + [dgamma, dbeta]
     elif s.kind == "se":
-        sums, rows = K.affine_act_bwd_reduce(dout, raw, s.a, None, 0)
+        sums, rows = pre_sums if pre_sums is not None else K.affine_act_bwd_reduce(dout, raw, s.a, None, 0)
         fc = seg.se_gate.fc
         dw1, db1, dw2, db2, A, Bc = K.se_gate_bwd(sums, rows, wp, s.mean, s.hidden, s.a, fc[0].weight, fc[2].weight,
                                                   raw.B, raw.C, raw.N, dap, fc)
@@ -760,7 +766,7 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
         if seg.relu_out or wp is not None or dap is not None:
             sums, rows = (None, 0)
             if dap is not None:
-                sums, rows = K.affine_act_bwd_reduce(dout, raw, None, None, fl)
+                sums, rows = pre_sums if pre_sums is not None else K.affine_act_bwd_reduce(dout, raw, None, None, fl)
             A = K.plain_bwd_coeffs(sums, rows, wp, raw.B, raw.C, raw.t.device, dap, want_A=True)
             draw = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
             K.affine_act_bwd_apply(dout, raw, None, None, A, None, None, draw, fl)
