@@ -271,6 +271,18 @@ int n3d_se_gate_bwd(const double* sums, int rows, const float* wptr, const float
                     const float* gate, const float* w1, const float* w2, int B, int C, int64_t N,
                     float* dw1, float* db1, float* dw2, float* db2, float* dalpha, float* A, float* Bc,
                     void* stream);
+/* the gates of up to N3D_MAX_GROUP_TERMS SE primitives of a supernet node (one per stride-1 edge, cell.py:76-81) in one launch.
+ * `sums`: forward = the [B][rows][C][2] channel statistics of the gate input, backward = the [B][rows][C][3] reduction rows
+ * of n3d_affine_act_bwd_reduce(N); other fields as the arguments of n3d_se_gate_fwd / n3d_se_gate_bwd. */
+typedef struct n3d_se_term {
+  const double* sums; int32_t rows; int32_t pad_;
+  const float* w1; const float* b1; const float* w2; const float* b2;
+  float* mean; float* hidden; float* gate;      /* forward outputs, backward inputs */
+  const float* wptr; float* dw1; float* db1; float* dw2; float* db2; float* dalpha; float* A; float* Bc;   /* backward only */
+} n3d_se_term;
+int n3d_se_gate_fwdN(const n3d_se_term* terms, int n, int64_t N, int B, int C, void* stream);
+int n3d_se_gate_bwdN(const n3d_se_term* terms, int n, int64_t N, int B, int C, void* stream);
+
 
 /* ---- 2x2x2 pooling, stride 2 (prim_ops.py:160-163) ------------------------------------------------ */
 int n3d_pool2_fwd(const float* x, int64_t xld, float* y, int64_t yld, int B, int Di, int Hi, int Wi, int C,

@@ -52,6 +52,14 @@ class GnBwdTerm(C.Structure):
                 ("dalpha", C.c_void_p), ("dbias_conv", C.c_void_p), ("cA", C.c_void_p), ("cB", C.c_void_p), ("cC", C.c_void_p)]
 
 
+class SeTerm(C.Structure):
+    """n3d_se_term (include/n3d.h)"""
+    _fields_ = [("sums", C.c_void_p), ("rows", C.c_int32), ("pad_", C.c_int32), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p),
+                ("b2", C.c_void_p), ("mean", C.c_void_p), ("hidden", C.c_void_p), ("gate", C.c_void_p), ("wptr", C.c_void_p),
+                ("dw1", C.c_void_p), ("db1", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p), ("dalpha", C.c_void_p),
+                ("A", C.c_void_p), ("Bc", C.c_void_p)]
+
+
 class ConvFwdCall(C.Structure):
     """n3d_conv_fwd_call (include/n3d.h)"""
     _fields_ = [("g", C.POINTER(ConvGeom)), ("transposed", C.c_int32), ("flags", C.c_int32), ("x", C.c_void_p), ("xld", C.c_int64),
@@ -115,6 +123,8 @@ PROTOTYPES = {
     "n3d_affine_act2": (_i, [C.POINTER(GnFwdTerm), C.POINTER(GnFwdTerm), _p, _i64, _p, _i64, _i, _i64, _i, _i, _p]),
     "n3d_gn_bwd_coeffs2": (_i, [C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i, _i, _i64, _p]),
     "n3d_affine_act_bwd_apply2": (_i, [_p, _i64, _p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _p]),
+    "n3d_se_gate_fwdN": (_i, [C.POINTER(SeTerm), _i, _i64, _i, _i, _p]),
+    "n3d_se_gate_bwdN": (_i, [C.POINTER(SeTerm), _i, _i64, _i, _i, _p]),
     "n3d_gn_coeffsN": (_i, [C.POINTER(GnFwdTerm), _i, _i, _i, _i, _i64, C.c_float, _p]),
     "n3d_affine_actN": (_i, [C.POINTER(GnFwdTerm), _i, _p, _i64, _i, _i64, _i, _i, _p]),
     "n3d_affine_act_bwd_reduceN": (_i, [_p, _i64, C.POINTER(GnBwdTerm), _i, _i, _i64, _i, _p]),

@@ -1318,9 +1318,9 @@ __global__ __launch_bounds__(256) void affine_bwd_applyN_kernel(const float* __r
 // ------------------------------------------------------------------------------------------------
 // SE gate
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const double* __restrict__ stats, int rows, double count, const float* __restrict__ w1,
-                                                          const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
-                                                          int C, float* __restrict__ mean, float* __restrict__ hidden, float* __restrict__ gate) {
+__device__ __forceinline__ void se_gate_fwd_body(const double* __restrict__ stats, int rows, double count, const float* __restrict__ w1,
+                                                 const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                 int C, float* __restrict__ mean, float* __restrict__ hidden, float* __restrict__ gate) {
   __shared__ double part[256];
   __shared__ double tot[192];
   __shared__ float hsh;
@@ -1342,13 +1342,29 @@ __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const double* __restri
     gate[b * C + t] = 1.0f / (1.0f + __expf(-pre));
   }
 }
+__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const double* __restrict__ stats, int rows, double count, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          int C, float* __restrict__ mean, float* __restrict__ hidden, float* __restrict__ gate) {
+  se_gate_fwd_body(stats, rows, count, w1, b1, w2, b2, C, mean, hidden, gate);
+}
+// the SE gates of up to 8 primitives of a supernet node: grid (B, gates) forward, grid (gates) backward
+struct SeTerm {
+  const double* sums; int rows; const float* w1; const float* b1; const float* w2; const float* b2; float* mean; float* hidden; float* gate;
+  const float* wptr; float* dw1; float* db1; float* dw2; float* db2; float* dalpha; float* A; float* Bc;
+};
+struct SeTermN { SeTerm t[8]; };
+__global__ __launch_bounds__(256) void se_gate_fwdN_kernel(SeTermN ts, double count, int C) {
+  SeTerm q;
+  N3D_PICK8(ts.t, blockIdx.y, q);
+  se_gate_fwd_body(q.sums, q.rows, count, q.w1, q.b1, q.w2, q.b2, C, q.mean, q.hidden, q.gate);
+}
 
-__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const double* __restrict__ sums, int rows, const float* __restrict__ wptr,
-                                                          const float* __restrict__ mean, const float* __restrict__ hidden,
-                                                          const float* __restrict__ gate, const float* __restrict__ w1,
-                                                          const float* __restrict__ w2, int B, int C, double count, float* __restrict__ dw1,
-                                                          float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
-                                                          float* __restrict__ dalpha, float* __restrict__ A, float* __restrict__ Bc) {
+__device__ __forceinline__ void se_gate_bwd_body(const double* __restrict__ sums, int rows, const float* __restrict__ wptr,
+                                                 const float* __restrict__ mean, const float* __restrict__ hidden,
+                                                 const float* __restrict__ gate, const float* __restrict__ w1,
+                                                 const float* __restrict__ w2, int B, int C, double count, float* __restrict__ dw1,
+                                                 float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
+                                                 float* __restrict__ dalpha, float* __restrict__ A, float* __restrict__ Bc) {
   __shared__ double part[256];
   __shared__ double tot[192];
   __shared__ double red[64];
@@ -1395,6 +1411,19 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const double* __restri
       *dalpha = (float)s;
     }
   }
+}
+__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const double* __restrict__ sums, int rows, const float* __restrict__ wptr,
+                                                          const float* __restrict__ mean, const float* __restrict__ hidden,
+                                                          const float* __restrict__ gate, const float* __restrict__ w1,
+                                                          const float* __restrict__ w2, int B, int C, double count, float* __restrict__ dw1,
+                                                          float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
+                                                          float* __restrict__ dalpha, float* __restrict__ A, float* __restrict__ Bc) {
+  se_gate_bwd_body(sums, rows, wptr, mean, hidden, gate, w1, w2, B, C, count, dw1, db1, dw2, db2, dalpha, A, Bc);
+}
+__global__ __launch_bounds__(256) void se_gate_bwdN_kernel(SeTermN ts, int B, int C, double count) {
+  SeTerm q;
+  N3D_PICK8(ts.t, blockIdx.x, q);
+  se_gate_bwd_body(q.sums, q.rows, q.wptr, q.mean, q.hidden, q.gate, q.w1, q.w2, B, C, count, q.dw1, q.db1, q.dw2, q.db2, q.dalpha, q.A, q.Bc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1952,6 +1981,39 @@ int n3d_se_gate_bwd(const double* sums, int rows, const float* wptr, const float
   N3D_CHECK_ARG(sums && mean && hidden && gate && w1 && w2 && dw1 && db1 && dw2 && db2 && A && Bc && C <= 64, "se_gate_bwd: bad args");
   hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, rows, wptr, mean, hidden, gate, w1, w2, B, C,
                      (double)N, dw1, db1, dw2, db2, dalpha, A, Bc);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+static int se_terms(const n3d_se_term* terms, int n, bool bwd, SeTermN* out, const char* who) {
+  if (n < 1 || n > N3D_MAX_GROUP_TERMS) { set_error("%s: 1..%d gates, got %d", who, N3D_MAX_GROUP_TERMS, n); return N3D_ERR_INVALID; }
+  for (int i = 0; i < 8; ++i) {
+    const n3d_se_term* t = &terms[i < n ? i : 0];
+    if (!(t->sums && t->rows >= 1 && t->w1 && t->w2 && t->mean && t->hidden && t->gate) || (!bwd && !(t->b1 && t->b2)) ||
+        (bwd && !(t->dw1 && t->db1 && t->dw2 && t->db2 && t->A && t->Bc))) {
+      set_error("%s: null pointer in gate %d", who, i);
+      return N3D_ERR_INVALID;
+    }
+    out->t[i] = SeTerm{t->sums, t->rows, t->w1, t->b1, t->w2, t->b2, t->mean, t->hidden, t->gate, t->wptr, t->dw1, t->db1, t->dw2, t->db2,
+                       t->dalpha, t->A, t->Bc};
+  }
+  return N3D_OK;
+}
+
+int n3d_se_gate_fwdN(const n3d_se_term* terms, int n, int64_t N, int B, int C, void* stream) {
+  N3D_CHECK_ARG(terms && B > 0 && N > 0 && C >= 1 && C <= 64, "se_gate_fwdN: bad args");
+  SeTermN ts;
+  if (int e = se_terms(terms, n, false, &ts, "se_gate_fwdN")) return e;
+  hipLaunchKernelGGL(se_gate_fwdN_kernel, dim3(B, n), dim3(256), 0, (hipStream_t)stream, ts, (double)N, C);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_se_gate_bwdN(const n3d_se_term* terms, int n, int64_t N, int B, int C, void* stream) {
+  N3D_CHECK_ARG(terms && B > 0 && N > 0 && C >= 1 && C <= 64, "se_gate_bwdN: bad args");
+  SeTermN ts;
+  if (int e = se_terms(terms, n, true, &ts, "se_gate_bwdN")) return e;
+  hipLaunchKernelGGL(se_gate_bwdN_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, ts, B, C, (double)N);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

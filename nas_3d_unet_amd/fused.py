@@ -276,7 +276,7 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
         for node in reversed(range(nn)):
             # the primitives that stay single (identity, SE gates, pooling) all start with a reduction pass over the same node
             # gradient: those passes run up to eight per launch
-            pre = {}
+            pre, pre_se = {}, {}
             if batch_reduce:
                 want = []
                 for unit in all_units[node]:
@@ -292,6 +292,21 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
                     if len(chunk) >= 2:
                         for (fi, _), r in zip(chunk, K.affine_act_bwd_reduceN(dnodes[node], [c[1] for c in chunk])):
                             pre[fi] = r
+                # ... and the SE gates among them share one gate-backward launch
+                gates = [fi for fi, _ in want if fi in pre and st.saved[fi].kind == "se"]
+                for i in range(0, len(gates), K.MAX_GROUP_TERMS):
+                    chunk = gates[i:i + K.MAX_GROUP_TERMS]
+                    if len(chunk) >= 2:
+                        tds = []
+                        for fi in chunk:
+                            _, _, seg, col, amat, row = flat[fi]
+                            arow, dal = alpha_of(amat, row)
+                            s = st.saved[fi]
+                            tds.append(dict(sums=pre[fi][0], rows=pre[fi][1], wptr=P._wptr(arow, col), mean=s.mean, hidden=s.hidden, gate=s.a,
+                                            fc=seg.se_gate.fc, dalpha_ptr=(dal.data_ptr() + 4 * col) if dal is not None else None))
+                        raw = st.saved[chunk[0]].raw
+                        for fi, r in zip(chunk, K.se_gate_bwdN(tds, raw.N, raw.B, raw.C)):
+                            pre_se[fi] = r
             for unit in reversed(all_units[node]):
                 if len(unit) >= 3:
                     # targets are claimed in reverse term order, like the unpaired reverse walk
@@ -328,7 +343,7 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
                 for idx, seg, s, col, arow, dal in todo:
                     target, acc = tgt(idx)
                     _, gl = P.seg_backward(seg, s, dnodes[node], True, target, acc, arow, col, dal,
-                                           pre.get(unit[0]) if len(unit) == 1 else None)
+                                           pre.get(unit[0]) if len(unit) == 1 else None, pre_se.get(unit[0]) if len(unit) == 1 else None)
                     put(seg, gl)
     for i in range(2):
         if not pre_started[i]:

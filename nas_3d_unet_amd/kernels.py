@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvBwdCall, ConvFwdCall, GnFwdTerm, GnBwdTerm, ACCUMULATE, POOL_MAX, PREPACKED, RELU, RELU_IN, ConvGeom, FinalJob, N3DError, PackJob, check
+from ._lib import ConvBwdCall, ConvFwdCall, GnFwdTerm, GnBwdTerm, SeTerm, ACCUMULATE, POOL_MAX, PREPACKED, RELU, RELU_IN, ConvGeom, FinalJob, N3DError, PackJob, check
 
 __all__ = ["View", "as_view", "empty_ndhwc", "stream_ptr", "conv_geom", "ptr"]
 
@@ -672,6 +672,45 @@ def se_gate_bwd(sums, rows, wptr, mean, hidden, gate, w1, w2, B, Cc, N, dalpha_p
                                       N, ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), dalpha_ptr, ptr(A), ptr(Bc),
                                       stream_ptr()), "n3d_se_gate_bwd")
     return dw1, db1, dw2, db2, A, Bc
+
+
+def se_gate_fwdN(terms, N, B, Cc):
+    """se_gate_fwd of up to 8 gates in one launch: terms = [(stats, rows, fc)].  Returns [(mean, hidden, gate)]."""
+    n = len(terms)
+    dev = terms[0][0].device
+    buf = torch.empty((n, 2 * B * Cc + B), dtype=torch.float32, device=dev)
+    arr = (SeTerm * n)()
+    out = []
+    for i, (stats, rows, fc) in enumerate(terms):
+        mean, gate, hidden = buf[i, :B * Cc].view(B, Cc), buf[i, B * Cc:2 * B * Cc].view(B, Cc), buf[i, 2 * B * Cc:]
+        arr[i] = SeTerm(stats.data_ptr(), rows, 0, fc[0].weight.data_ptr(), fc[0].bias.data_ptr(), fc[2].weight.data_ptr(),
+                        fc[2].bias.data_ptr(), mean.data_ptr(), hidden.data_ptr(), gate.data_ptr(), *([None] * 8))
+        out.append((mean, hidden, gate))
+    check(_lib.load().n3d_se_gate_fwdN(arr, n, N, B, Cc, stream_ptr()), "n3d_se_gate_fwdN")
+    return out
+
+
+def se_gate_bwdN(terms, N, B, Cc):
+    """se_gate_bwd of up to 8 gates in one launch: terms = [dict(sums, rows, wptr, mean, hidden, gate, fc, dalpha_ptr)].
+    Returns [(dw1, db1, dw2, db2, A, Bc)]."""
+    n = len(terms)
+    dev = terms[0]["sums"].device
+    coef = torch.empty((n, 2, B, Cc), dtype=torch.float32, device=dev)
+    arr = (SeTerm * n)()
+    out = []
+    for i, t in enumerate(terms):
+        fc = t["fc"]
+        dw1, db1, dw2, db2 = (grad_target(fc[0].weight), grad_target(fc[0].bias), grad_target(fc[2].weight), grad_target(fc[2].bias))
+        dw1 = dw1 if dw1 is not None else torch.empty((1, Cc), dtype=torch.float32, device=dev)
+        db1 = db1 if db1 is not None else torch.empty((1,), dtype=torch.float32, device=dev)
+        dw2 = dw2 if dw2 is not None else torch.empty((Cc, 1), dtype=torch.float32, device=dev)
+        db2 = db2 if db2 is not None else torch.empty((Cc,), dtype=torch.float32, device=dev)
+        arr[i] = SeTerm(t["sums"].data_ptr(), t["rows"], 0, fc[0].weight.data_ptr(), None, fc[2].weight.data_ptr(), None,
+                        t["mean"].data_ptr(), t["hidden"].data_ptr(), t["gate"].data_ptr(), _vp(t.get("wptr")), dw1.data_ptr(),
+                        db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), _vp(t.get("dalpha_ptr")), coef[i, 0].data_ptr(), coef[i, 1].data_ptr())
+        out.append((dw1, db1, dw2, db2, coef[i, 0], coef[i, 1]))
+    check(_lib.load().n3d_se_gate_bwdN(arr, n, N, B, Cc, stream_ptr()), "n3d_se_gate_bwdN")
+    return out
 
 
 def pool2_fwd(x: View, y: View, is_max):

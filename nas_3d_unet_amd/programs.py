@@ -664,7 +664,7 @@ def group_forward(terms, out, accumulate):
             seg, x, _, _ = terms[i]
             res.append(list(seg.weight.fwd(x, seg.relu_in, None, seg.norm is not None and seg.weight.produces_stats)))
             i += 1
-    saved, gn = [], []
+    saved, gn, se = [], [], []
     for r, (seg, _, _, _) in zip(res, terms):
         s = Saved()
         s.ws, s.raw = r[3], r[0]
@@ -676,9 +676,17 @@ def group_forward(terms, out, accumulate):
             s.kind, s.G = "gn", group_count(r[0].C)
             gn.append((s, (r[0], r[1], r[2], seg.norm.weight, seg.norm.bias)))
         elif seg.se_gate is not None:
-            s.mean, s.hidden, s.a = seg.se_gate.fwd(r[0])
             s.kind = "se"
+            se.append((s, seg.se_gate.fc, r[0]))
         saved.append(s)
+    if len(se) == 1:
+        s, fc, raw = se[0]
+        s.mean, s.hidden, s.a = SEGate(fc).fwd(raw)
+    elif se:
+        raw0 = se[0][2]
+        sts = [K.channel_stats(raw) for _, _, raw in se]
+        for (s, _, _), (mean, hidden, gate) in zip(se, K.se_gate_fwdN([(st, rows, fc) for (st, rows), (_, fc, _) in zip(sts, se)], raw0.N, raw0.B, raw0.C)):
+            s.mean, s.hidden, s.a = mean, hidden, gate
     if gn:
         eps = [seg.norm.eps for seg, _, _, _ in terms if seg.norm is not None]
         if any(e != eps[0] for e in eps):
@@ -704,11 +712,12 @@ def needs_reduce(seg, s, dalpha):
     return s.kind in ("gn", "se") or dalpha is not None
 
 
-def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_row=None, alpha_k=0, dalpha=None, pre_sums=None):
+def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_row=None, alpha_k=0, dalpha=None, pre_sums=None, pre_se=None):
     """Backward of one segment.  dout: View of d(out).  Returns (dx tensor | None, [param grads])
     with param grads ordered like seg.params().  If `dalpha` (a float tensor) is given,
     dalpha[alpha_k] = <dout, z> is written (MixedOp architecture gradient, cell.py:29-32).
-    pre_sums = (sums, rows): the reduction pass was already done (K.affine_act_bwd_reduceN over several terms of a node)."""
+    pre_sums = (sums, rows): the reduction pass was already done (K.affine_act_bwd_reduceN over several terms of a node);
+    pre_se = (dw1, db1, dw2, db2, A, Bc): so was the SE gate backward (K.se_gate_bwdN)."""
     wp = _wptr(alpha_row, alpha_k)
     dap = C.c_void_p(dalpha.data_ptr() + 4 * alpha_k) if dalpha is not None else None
     raw = s.raw
@@ -752,8 +761,11 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
     elif s.kind == "se":
         sums, rows = pre_sums if pre_sums is not None else K.affine_act_bwd_reduce(dout, raw, s.a, None, 0)
         fc = seg.se_gate.fc
-        dw1, db1, dw2, db2, A, Bc = K.se_gate_bwd(sums, rows, wp, s.mean, s.hidden, s.a, fc[0].weight, fc[2].weight,
-                                                  raw.B, raw.C, raw.N, dap, fc)
+        if pre_se is not None:
+            dw1, db1, dw2, db2, A, Bc = pre_se
+        else:
+            dw1, db1, dw2, db2, A, Bc = K.se_gate_bwd(sums, rows, wp, s.mean, s.hidden, s.a, fc[0].weight, fc[2].weight,
+                                                      raw.B, raw.C, raw.N, dap, fc)
         dx = None
         if need_dx:
             if dx_out is None:
