@@ -319,7 +319,8 @@ class DepthSepW(WeightProgram):
         co = self.pm.weight.shape[0]
         return (g.B, co, g.Di, g.Hi, g.Wi) if self.transposed else (g.B, co, g.Do, g.Ho, g.Wo)
 
-    def fwd(self, x, relu_in, gate, want_stats):
+    def fwd_depth(self, x, relu_in, gate):
+        """first stage: the depthwise conv.  Returns the saved state (s.mid = its output)"""
         s = Saved()
         s.pre = None
         if relu_in or gate is not None:
@@ -330,26 +331,49 @@ class DepthSepW(WeightProgram):
         mid = K.as_view(K.empty_ndhwc(*mid_shape, x.t.device))
         K.conv_fwd(gd, x, self.dm.weight, self.dm.bias, mid, 0, None, None, self.transposed)
         co = self.pm.weight.shape[0]
-        gp = K.conv_geom(mid.B, mid.D, mid.H, mid.W, mid.C, co, 1, 1, 1, 0)
-        y = K.as_view(K.empty_ndhwc(mid.B, co, mid.D, mid.H, mid.W, x.t.device))
+        s.x, s.mid, s.gd = x, mid, gd
+        s.gp = K.conv_geom(mid.B, mid.D, mid.H, mid.W, mid.C, co, 1, 1, 1, 0)
+        return s
+
+    def point_call(self, s, want_stats):
+        """second stage, the 1x1x1 conv, as a call tuple for K.conv_fwd / K.conv_fwd2 (two of them fold into one launch) and
+        its (y, stats, rows)"""
+        mid, gp = s.mid, s.gp
+        co = self.pm.weight.shape[0]
+        y = K.as_view(K.empty_ndhwc(mid.B, co, mid.D, mid.H, mid.W, mid.t.device))
         stats, rows = None, 0
         if want_stats:
             rows = K.conv_stats_rows(gp, False)
             if rows > 0:
-                stats = torch.empty((x.B, rows, co, 2), dtype=torch.float64, device=x.t.device)
-        K.conv_fwd(gp, mid, self.pm.weight, self.pm.bias, y, 0, None, stats, False)
-        s.x, s.mid, s.gd, s.gp = x, mid, gd, gp
+                stats = torch.empty((mid.B, rows, co, 2), dtype=torch.float64, device=mid.t.device)
+        return (gp, mid, self.pm.weight, self.pm.bias, y, 0, None, stats, False), (y, stats, rows)
+
+    def fwd(self, x, relu_in, gate, want_stats):
+        s = self.fwd_depth(x, relu_in, gate)
+        call, (y, stats, rows) = self.point_call(s, want_stats)
+        K.conv_fwd(*call)
         return y, stats, rows, s
 
-    def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
-        x, mid, gd, gp = saved.x, saved.mid, saved.gd, saved.gp
-        pw, pb, dwt, dbs = self.pm.weight, self.pm.bias, self.dm.weight, self.dm.bias
+    def point_bwd_call(self, saved, draw, skip_bias):
+        """backward of the 1x1x1 conv as a call tuple for K.conv_bwd_both2 (weights trainable) or K.conv_bwd_data2 (frozen), or
+        None when its shape has no folded kernel.  Returns (kind, call, dmid, [g_pw, g_pb])"""
+        mid, gp = saved.mid, saved.gp
+        if gp.Ci % 16 != 0 or gp.Co % 16 != 0:
+            return None
+        pw, pb = self.pm.weight, self.pm.bias
         g_pw = K.grad_target(pw)
         g_pb = None if skip_bias else K.grad_target(pb)
-        if g_pw is not None or g_pb is not None:
-            K.conv_bwd_weight(gp, mid, draw, g_pw, g_pb, 0, None, False)
-        dmid = K.as_view(K.empty_ndhwc(mid.B, mid.C, mid.D, mid.H, mid.W, x.t.device))
-        K.conv_bwd_data(gp, draw, pw, dmid, 0, None, None, False)
+        dmid = K.as_view(K.empty_ndhwc(mid.B, mid.C, mid.D, mid.H, mid.W, mid.t.device))
+        if g_pw is not None:
+            return "both", (gp, mid, draw, pw, dmid, g_pw, g_pb, 0, None, None, 0, None, False), dmid, [g_pw, g_pb]
+        if g_pb is None:
+            return "data", (gp, draw, pw, dmid, 0, None, None, False), dmid, [None, None]
+        return None
+
+    def bwd_depth(self, saved, dmid, need_dx, dx_out, dx_acc):
+        """backward of the depthwise conv given d(mid).  Returns (dx, [g_dw, g_db])"""
+        x, gd = saved.x, saved.gd
+        dwt, dbs = self.dm.weight, self.dm.bias
         g_dw = K.grad_target(dwt)
         g_db = K.grad_target(dbs)
         if g_dw is not None or g_db is not None:
@@ -367,6 +391,23 @@ class DepthSepW(WeightProgram):
                     dx_acc = False
                 K.conv_bwd_data(gd, dmid, dwt, dx_out, ACCUMULATE if dx_acc else 0, None, None, self.transposed)
                 dx = dx_out.t
+        return dx, [g_dw, g_db]
+
+    def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
+        mid, gp = saved.mid, saved.gp
+        c = self.point_bwd_call(saved, draw, skip_bias)
+        if c is not None and c[0] == "both":
+            K.conv_bwd_both(*c[1][:12])          # data + weight gradient of the 1x1x1 conv in one launch
+            dmid, (g_pw, g_pb) = c[2], c[3]
+        else:
+            pw, pb = self.pm.weight, self.pm.bias
+            g_pw = K.grad_target(pw)
+            g_pb = None if skip_bias else K.grad_target(pb)
+            if g_pw is not None or g_pb is not None:
+                K.conv_bwd_weight(gp, mid, draw, g_pw, g_pb, 0, None, False)
+            dmid = K.as_view(K.empty_ndhwc(mid.B, mid.C, mid.D, mid.H, mid.W, mid.t.device))
+            K.conv_bwd_data(gp, draw, pw, dmid, 0, None, None, False)
+        dx, (g_dw, g_db) = self.bwd_depth(saved, dmid, need_dx, dx_out, dx_acc)
         return dx, [g_dw, g_db, g_pw, g_pb]
 
 
@@ -621,6 +662,17 @@ def _weight_backward(order):
                 if all(c is not None for c in cands) and cands[0][1].p.value != cands[1][1].p.value:
                     K.conv_bwd_data2([c[0] for c in cands])
                     pre = [(c[1].t, c[2]) for c in cands]
+        if (pre is None and i + 1 < len(order) and isinstance(order[i][0].weight, DepthSepW)
+                and isinstance(order[i + 1][0].weight, DepthSepW)):
+            # two depthwise-separable primitives: their 1x1x1 convs' backward in one launch, then the depthwise stages
+            two = order[i:i + 2]
+            cands = [o[0].weight.point_bwd_call(o[1].ws, o[2]["draw"], o[3][2] is not None) for o in two]
+            if all(c is not None for c in cands) and cands[0][0] == cands[1][0]:
+                (K.conv_bwd_both2 if cands[0][0] == "both" else K.conv_bwd_data2)([c[1] for c in cands])
+                pre = []
+                for o, c in zip(two, cands):
+                    dx, gdw = o[0].weight.bwd_depth(o[1].ws, c[2], o[4][0], o[4][1], o[4][2])
+                    pre.append((dx, gdw + c[3]))
         for k in range(2 if pre is not None else 1):
             seg, s, t, (dgamma, dbeta, dcb), (need_dx, dx_out, dx_acc) = order[i + k]
             if pre is not None:
@@ -657,6 +709,17 @@ def group_forward(terms, out, accumulate):
                 call, r = seg.weight.fwd_prepare(x, seg.relu_in, None, seg.norm is not None)
                 calls.append(call)
                 rr.append(list(r))
+            K.conv_fwd2(calls)
+            res.extend(rr)
+            i += 2
+        elif i + 1 < len(terms) and isinstance(terms[i][0].weight, DepthSepW) and isinstance(terms[i + 1][0].weight, DepthSepW):
+            # two depthwise-separable primitives: the depthwise stages one after the other, the two 1x1x1 convs in one launch
+            calls, rr = [], []
+            for seg, x, _, _ in terms[i:i + 2]:
+                ws = seg.weight.fwd_depth(x, seg.relu_in, None)
+                call, (y, stats, rows) = seg.weight.point_call(ws, seg.norm is not None)
+                calls.append(call)
+                rr.append([y, stats, rows, ws])
             K.conv_fwd2(calls)
             res.extend(rr)
             i += 2
