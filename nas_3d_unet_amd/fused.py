@@ -106,6 +106,7 @@ def _node_units(plan):
             seen[e] = rank[fi] + 1
         dense.sort(key=lambda fi: (rank[fi], fi))
         rest = [fi for fi in pairable if fi not in rank]
+        rest.sort(key=lambda fi: (not isinstance(flat[fi][2].weight, P.DepthSepW), fi))   # depthwise-separable terms side by side
         u = []
         if GROUP_SUPERNET_TERMS and K.group_shape_ok(plan.c_node) and len(pairable) >= 3 and len({flat[fi][2].norm.eps for fi in pairable}) == 1:
             # N-term groups: all coefficients in one launch and one pass over the node buffer (backward: three launches per group)
