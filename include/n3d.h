@@ -48,6 +48,8 @@ extern "C" {
 /* Geometry of a (possibly strided / dilated) 3-D convolution, torch Conv3d semantics:
  * o = floor((i + 2*pad - dil*(k-1) - 1)/stride) + 1.  "i side" is what the window slides over.
  * For a transposed convolution the i side is its OUTPUT and the o side its INPUT. */
+#define N3D_MAX_GROUP_TERMS 8   /* terms / jobs per batched launch (the N-term entry points below) */
+
 typedef struct n3d_conv_geom {
   int32_t B;
   int32_t Di, Hi, Wi, Ci;
@@ -134,6 +136,16 @@ typedef struct n3d_conv_fwd_call {     /* arguments of n3d_conv_fwd / n3d_convT_
   const float* in_gate; double* stats; void* ws; size_t ws_bytes;
 } n3d_conv_fwd_call;
 int n3d_conv_fwd2(const n3d_conv_fwd_call* c0, const n3d_conv_fwd_call* c1, void* stream);
+
+/* The depthwise 3x3x3 convs of up to N3D_MAX_GROUP_TERMS primitives of a supernet node (one depthwise-separable primitive per
+ * edge, cell.py:76-81) in ONE launch.  A job is one gather pass: data_grad = 0: dst[o side] = conv(src[i side]) + bias
+ * (n3d_conv_fwd, or the data gradient of a transposed conv); data_grad = 1: dst[i side] (+)= conv^T(src[o side]) (n3d_conv_bwd_data,
+ * or n3d_convT_fwd).  All jobs share batch, channel count and destination shape; destinations must not alias. */
+typedef struct n3d_dw_job {
+  const n3d_conv_geom* g; int32_t data_grad; int32_t flags /* N3D_ACCUMULATE */;
+  const float* src; int64_t sld; const float* w; const float* bias; float* dst; int64_t dld;
+} n3d_dw_job;
+int n3d_dwconv_batch(const n3d_dw_job* jobs, int n, void* stream);
 
 typedef struct n3d_conv_bwd_call {     /* arguments of n3d_conv_bwd_both / n3d_convT_bwd_both */
   const n3d_conv_geom* g; int32_t transposed; int32_t flags_data; int32_t flags_weight; int32_t pad_;
@@ -246,7 +258,6 @@ int n3d_affine_act_bwd_apply2(const float* dout, int64_t dld, const float* dout1
  * order, one pass over the node buffer; a_k = a_out, b_k = b_out of the term, NULL meaning 1 / 0, so the node's other
  * primitives (SE gate: a = gate; pooling, identity-with-norm) ride in the same pass.  Backward: n3d_affine_act_bwd_reduceN (fills sums of every term; all terms read the
  * same node gradient; a / b NULL = 1 / 0 as in n3d_affine_act_bwd_reduce, so the other primitives' reductions ride along), n3d_gn_bwd_coeffsN (cA / cB / cC and the parameter gradients), n3d_affine_act_bwd_applyN (every draw). */
-#define N3D_MAX_GROUP_TERMS 8
 int n3d_gn_coeffsN(const n3d_gn_fwd_term* terms, int n, int B, int C, int G, int64_t N, float eps, void* stream);
 int n3d_affine_actN(const n3d_gn_fwd_term* terms, int n, float* out, int64_t old_, int B, int64_t N, int C, int flags, void* stream);
 int n3d_affine_act_bwd_reduceN(const float* dout, int64_t dld, const n3d_gn_bwd_term* terms, int n, int B, int64_t N, int C, void* stream);

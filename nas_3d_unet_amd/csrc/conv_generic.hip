@@ -484,7 +484,7 @@ struct DwArgs {
   FastDiv fcpb, fWd, fHd;
 };
 
-__global__ __launch_bounds__(256) void dw_gather_kernel(DwArgs a) {
+__device__ __forceinline__ void dw_gather_body(const DwArgs& a) {
   // k = 3, dilation 1 (check_geom).  Branch-free: the weights of all channel quads are staged once in LDS as float4
   // [c4][tap] (one broadcast ds_read_b128 per tap), and the nine source loads of a kd plane are issued from clamped
   // addresses before their first use -- the rolled tap loop with `continue`s paid one memory latency per tap (27).
@@ -554,6 +554,16 @@ __global__ __launch_bounds__(256) void dw_gather_kernel(DwArgs a) {
       }
   }
   *op = make_float4(acc.x + prev.x, acc.y + prev.y, acc.z + prev.z, acc.w + prev.w);
+}
+__global__ __launch_bounds__(256) void dw_gather_kernel(DwArgs a) { dw_gather_body(a); }
+// the depthwise convs of up to 8 primitives of a supernet node (one per edge, cell.py:76-81) in one launch: grid.z = job; all
+// jobs share the output shape and channel count (blockIdx.x covers the output voxels), their sources may differ in shape
+struct DwArgsN { DwArgs j[8]; };
+__global__ __launch_bounds__(256) void dw_gatherN_kernel(DwArgsN js) {
+  DwArgs a;
+  switch (blockIdx.z) { case 0: a = js.j[0]; break; case 1: a = js.j[1]; break; case 2: a = js.j[2]; break; case 3: a = js.j[3]; break;
+                        case 4: a = js.j[4]; break; case 5: a = js.j[5]; break; case 6: a = js.j[6]; break; default: a = js.j[7]; break; }
+  dw_gather_body(a);
 }
 
 struct DwWgradArgs {
@@ -976,6 +986,18 @@ int n3d_conv_stats_rows(const n3d_conv_geom* g, int transposed, int flags) {
   return (int)cdiv(Nd, 256);
 }
 
+static DwArgs dw_args(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
+                      int64_t dld, int flags) {
+  DwArgs a;
+  a.C = g->Ci; a.w = w; a.bias = bias; a.k = g->k; a.flags = flags;
+  if (!data_grad) { a.src = src; a.sld = sld; a.Ds = g->Di; a.Hs = g->Hi; a.Ws = g->Wi; a.dst = dst; a.dld = dld; a.Dd = g->Do; a.Hd = g->Ho; a.Wd = g->Wo;
+    a.sn = g->stride; a.off = -g->pad; a.dt = g->dil; a.den = 1; }
+  else { a.src = src; a.sld = sld; a.Ds = g->Do; a.Hs = g->Ho; a.Ws = g->Wo; a.dst = dst; a.dld = dld; a.Dd = g->Di; a.Hd = g->Hi; a.Wd = g->Wi;
+    a.sn = 1; a.off = g->pad; a.dt = -g->dil; a.den = g->stride; }
+  a.fcpb = FastDiv((uint32_t)(a.C / 4)); a.fWd = FastDiv((uint32_t)a.Wd); a.fHd = FastDiv((uint32_t)a.Hd);
+  return a;
+}
+
 static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
                       int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate,
                       double* stats, void* ws, size_t ws_bytes, void* stream) {
@@ -983,14 +1005,8 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
   if (g->depthwise) {
     N3D_CHECK_ARG(!in_gate && !relu_src && !out_gate && !stats && !(flags & N3D_RELU_IN), "depthwise conv: gate/relu/stats not supported");
     N3D_CHECK_ARG(sld % 4 == 0 && dld % 4 == 0 && aligned16(src) && aligned16(dst), "depthwise conv: needs 16-byte aligned pitched rows");
-    DwArgs a;
-    a.C = g->Ci; a.w = w; a.bias = bias; a.k = g->k; a.flags = flags;
-    if (!data_grad) { a.src = src; a.sld = sld; a.Ds = g->Di; a.Hs = g->Hi; a.Ws = g->Wi; a.dst = dst; a.dld = dld; a.Dd = g->Do; a.Hd = g->Ho; a.Wd = g->Wo;
-      a.sn = g->stride; a.off = -g->pad; a.dt = g->dil; a.den = 1; }
-    else { a.src = src; a.sld = sld; a.Ds = g->Do; a.Hs = g->Ho; a.Ws = g->Wo; a.dst = dst; a.dld = dld; a.Dd = g->Di; a.Hd = g->Hi; a.Wd = g->Wi;
-      a.sn = 1; a.off = g->pad; a.dt = -g->dil; a.den = g->stride; }
+    DwArgs a = dw_args(g, data_grad, src, sld, w, bias, dst, dld, flags);
     const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
-    a.fcpb = FastDiv((uint32_t)(a.C / 4)); a.fWd = FastDiv((uint32_t)a.Wd); a.fHd = FastDiv((uint32_t)a.Hd);
     hipLaunchKernelGGL(dw_gather_kernel, dim3((unsigned)cdiv(Nd * (a.C / 4), 256), g->B), dim3(256), (size_t)(a.C / 4) * 27 * sizeof(float4), s, a);
     N3D_LAUNCH_CHECK();
     return N3D_OK;
@@ -1219,6 +1235,28 @@ int n3d_convT_bwd_both(const n3d_conv_geom* g, const float* x, int64_t xld, cons
   if (rq.done) return N3D_OK;
   return run_gather(g, false, dy, dyld, w, nullptr, dx, dxld, flags_data & ~N3D_RELU_IN, nullptr, nullptr, 0, nullptr, nullptr, ws_data,
                     ws_data_bytes, stream);
+}
+
+int n3d_dwconv_batch(const n3d_dw_job* jobs, int n, void* stream) {
+  N3D_CHECK_ARG(jobs && n >= 1 && n <= N3D_MAX_GROUP_TERMS, "dwconv_batch: 1..8 jobs");
+  DwArgsN js;
+  int64_t Nd0 = 0;
+  int C0 = 0, B0 = 0;
+  for (int i = 0; i < 8; ++i) {
+    const n3d_dw_job* q = &jobs[i < n ? i : 0];
+    N3D_CHECK_ARG(q->g && q->src && q->w && q->dst, "dwconv_batch: null pointers");
+    if (int e = check_geom(q->g, "dwconv_batch")) return e;
+    N3D_CHECK_ARG(q->g->depthwise, "dwconv_batch: depthwise geometries only");
+    N3D_CHECK_ARG(q->sld % 4 == 0 && q->dld % 4 == 0 && aligned16(q->src) && aligned16(q->dst), "dwconv_batch: needs 16-byte aligned pitched rows");
+    js.j[i] = dw_args(q->g, q->data_grad != 0, q->src, q->sld, q->w, q->bias, q->dst, q->dld, q->flags);
+    const int64_t Nd = (int64_t)js.j[i].Dd * js.j[i].Hd * js.j[i].Wd;
+    if (i == 0) { Nd0 = Nd; C0 = js.j[i].C; B0 = q->g->B; }
+    N3D_CHECK_ARG(Nd == Nd0 && js.j[i].C == C0 && q->g->B == B0, "dwconv_batch: the jobs must share output shape, channel count and batch");
+  }
+  hipLaunchKernelGGL(dw_gatherN_kernel, dim3((unsigned)cdiv(Nd0 * (C0 / 4), 256), B0, n), dim3(256), (size_t)(C0 / 4) * 27 * sizeof(float4),
+                     (hipStream_t)stream, js);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
 }
 
 int n3d_conv_fwd2(const n3d_conv_fwd_call* c0, const n3d_conv_fwd_call* c1, void* stream) {

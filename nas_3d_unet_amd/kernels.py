@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvBwdCall, ConvFwdCall, GnFwdTerm, GnBwdTerm, SeTerm, ACCUMULATE, POOL_MAX, PREPACKED, RELU, RELU_IN, ConvGeom, FinalJob, N3DError, PackJob, check
+from ._lib import ConvBwdCall, ConvFwdCall, DwJob, GnFwdTerm, GnBwdTerm, SeTerm, ACCUMULATE, POOL_MAX, PREPACKED, RELU, RELU_IN, ConvGeom, FinalJob, N3DError, PackJob, check
 
 __all__ = ["View", "as_view", "empty_ndhwc", "stream_ptr", "conv_geom", "ptr"]
 
@@ -300,6 +300,16 @@ def conv_bwd_both2(calls):
         if job is not None and job.nchunks > 0:
             _ctx.final.append(job)
             _ctx.keep.append(ws)
+
+
+def dwconv_batch(jobs):
+    """Depthwise gather passes of up to 8 primitives in one launch: jobs = [(g, data_grad, src View, w, bias | None, dst View, flags)];
+    data_grad False: dst = conv(src) + bias, True: dst (+)= conv^T(src).  Same batch, channels and destination shape; distinct dsts."""
+    n = len(jobs)
+    arr = (DwJob * n)()
+    for i, (g, data_grad, src, w, bias, dst, flags) in enumerate(jobs):
+        arr[i] = DwJob(C.pointer(g), 1 if data_grad else 0, flags, src.p.value, src.ld, w.data_ptr(), _vp(bias), dst.p.value, dst.ld)
+    check(_lib.load().n3d_dwconv_batch(arr, n, stream_ptr()), "n3d_dwconv_batch")
 
 
 def conv_bwd_data2(calls):

@@ -319,8 +319,9 @@ class DepthSepW(WeightProgram):
         co = self.pm.weight.shape[0]
         return (g.B, co, g.Di, g.Hi, g.Wi) if self.transposed else (g.B, co, g.Do, g.Ho, g.Wo)
 
-    def fwd_depth(self, x, relu_in, gate):
-        """first stage: the depthwise conv.  Returns the saved state (s.mid = its output)"""
+    def fwd_depth(self, x, relu_in, gate, launch=True):
+        """first stage: the depthwise conv.  Returns the saved state (s.mid = its output); launch=False leaves the launch to the
+        caller (s.job is the K.dwconv_batch job)"""
         s = Saved()
         s.pre = None
         if relu_in or gate is not None:
@@ -329,7 +330,9 @@ class DepthSepW(WeightProgram):
         gd = self.dgeom(x)
         mid_shape = (gd.B, gd.Ci, gd.Di, gd.Hi, gd.Wi) if self.transposed else (gd.B, gd.Co, gd.Do, gd.Ho, gd.Wo)
         mid = K.as_view(K.empty_ndhwc(*mid_shape, x.t.device))
-        K.conv_fwd(gd, x, self.dm.weight, self.dm.bias, mid, 0, None, None, self.transposed)
+        s.job = (gd, self.transposed, x, self.dm.weight, self.dm.bias, mid, 0)
+        if launch:
+            K.conv_fwd(gd, x, self.dm.weight, self.dm.bias, mid, 0, None, None, self.transposed)
         co = self.pm.weight.shape[0]
         s.x, s.mid, s.gd = x, mid, gd
         s.gp = K.conv_geom(mid.B, mid.D, mid.H, mid.W, mid.C, co, 1, 1, 1, 0)
@@ -370,8 +373,35 @@ class DepthSepW(WeightProgram):
             return "data", (gp, draw, pw, dmid, 0, None, None, False), dmid, [None, None]
         return None
 
-    def bwd_depth(self, saved, dmid, need_dx, dx_out, dx_acc):
-        """backward of the depthwise conv given d(mid).  Returns (dx, [g_dw, g_db])"""
+    def bwd_point(self, saved, draw, skip_bias):
+        """backward of the 1x1x1 conv alone.  Returns (dmid, [g_pw, g_pb])"""
+        mid, gp = saved.mid, saved.gp
+        c = self.point_bwd_call(saved, draw, skip_bias)
+        if c is not None and c[0] == "both":
+            K.conv_bwd_both(*c[1][:12])          # data + weight gradient of the 1x1x1 conv in one launch
+            return c[2], c[3]
+        pw, pb = self.pm.weight, self.pm.bias
+        g_pw = K.grad_target(pw)
+        g_pb = None if skip_bias else K.grad_target(pb)
+        if g_pw is not None or g_pb is not None:
+            K.conv_bwd_weight(gp, mid, draw, g_pw, g_pb, 0, None, False)
+        dmid = K.as_view(K.empty_ndhwc(mid.B, mid.C, mid.D, mid.H, mid.W, mid.t.device))
+        K.conv_bwd_data(gp, draw, pw, dmid, 0, None, None, False)
+        return dmid, [g_pw, g_pb]
+
+    def depth_data_job(self, saved, dmid, dx_out, dx_acc):
+        """the depthwise data gradient as a K.dwconv_batch job (None: this op needs the materialised-input path).
+        Returns (job, dx_out)"""
+        if saved.pre is not None:
+            return None
+        x = saved.x
+        if dx_out is None:
+            dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+            dx_acc = False
+        return (saved.gd, not self.transposed, dmid, self.dm.weight, None, dx_out, ACCUMULATE if dx_acc else 0), dx_out
+
+    def bwd_depth(self, saved, dmid, need_dx, dx_out, dx_acc, data=True):
+        """backward of the depthwise conv given d(mid).  Returns (dx, [g_dw, g_db]); data=False: weight gradient only"""
         x, gd = saved.x, saved.gd
         dwt, dbs = self.dm.weight, self.dm.bias
         g_dw = K.grad_target(dwt)
@@ -379,7 +409,7 @@ class DepthSepW(WeightProgram):
         if g_dw is not None or g_db is not None:
             K.conv_bwd_weight(gd, x, dmid, g_dw, g_db, 0, None, self.transposed)
         dx = None
-        if need_dx:
+        if need_dx and data:
             if saved.pre is not None:
                 du = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
                 K.conv_bwd_data(gd, dmid, dwt, du, 0, None, None, self.transposed)
@@ -394,19 +424,7 @@ class DepthSepW(WeightProgram):
         return dx, [g_dw, g_db]
 
     def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
-        mid, gp = saved.mid, saved.gp
-        c = self.point_bwd_call(saved, draw, skip_bias)
-        if c is not None and c[0] == "both":
-            K.conv_bwd_both(*c[1][:12])          # data + weight gradient of the 1x1x1 conv in one launch
-            dmid, (g_pw, g_pb) = c[2], c[3]
-        else:
-            pw, pb = self.pm.weight, self.pm.bias
-            g_pw = K.grad_target(pw)
-            g_pb = None if skip_bias else K.grad_target(pb)
-            if g_pw is not None or g_pb is not None:
-                K.conv_bwd_weight(gp, mid, draw, g_pw, g_pb, 0, None, False)
-            dmid = K.as_view(K.empty_ndhwc(mid.B, mid.C, mid.D, mid.H, mid.W, mid.t.device))
-            K.conv_bwd_data(gp, draw, pw, dmid, 0, None, None, False)
+        dmid, (g_pw, g_pb) = self.bwd_point(saved, draw, skip_bias)
         dx, (g_dw, g_db) = self.bwd_depth(saved, dmid, need_dx, dx_out, dx_acc)
         return dx, [g_dw, g_db, g_pw, g_pb]
 
@@ -662,18 +680,38 @@ def _weight_backward(order):
                 if all(c is not None for c in cands) and cands[0][1].p.value != cands[1][1].p.value:
                     K.conv_bwd_data2([c[0] for c in cands])
                     pre = [(c[1].t, c[2]) for c in cands]
+        npre = 2
         if (pre is None and i + 1 < len(order) and isinstance(order[i][0].weight, DepthSepW)
                 and isinstance(order[i + 1][0].weight, DepthSepW)):
-            # two depthwise-separable primitives: their 1x1x1 convs' backward in one launch, then the depthwise stages
-            two = order[i:i + 2]
-            cands = [o[0].weight.point_bwd_call(o[1].ws, o[2]["draw"], o[3][2] is not None) for o in two]
-            if all(c is not None for c in cands) and cands[0][0] == cands[1][0]:
-                (K.conv_bwd_both2 if cands[0][0] == "both" else K.conv_bwd_data2)([c[1] for c in cands])
-                pre = []
-                for o, c in zip(two, cands):
-                    dx, gdw = o[0].weight.bwd_depth(o[1].ws, c[2], o[4][0], o[4][1], o[4][2])
-                    pre.append((dx, gdw + c[3]))
-        for k in range(2 if pre is not None else 1):
+            # a run of depthwise-separable primitives: the 1x1x1 convs' backward two per launch, the depthwise weight gradients
+            # one by one, the depthwise data gradients (distinct targets) in one launch
+            j = i
+            while j < len(order) and isinstance(order[j][0].weight, DepthSepW):
+                j += 1
+            run = order[i:j]
+            cands = [o[0].weight.point_bwd_call(o[1].ws, o[2]["draw"], o[3][2] is not None) for o in run]
+            dmids, gpw = [None] * len(run), [None] * len(run)
+            k = 0
+            while k < len(run):
+                if k + 1 < len(run) and cands[k] is not None and cands[k + 1] is not None and cands[k][0] == cands[k + 1][0]:
+                    (K.conv_bwd_both2 if cands[k][0] == "both" else K.conv_bwd_data2)([cands[k][1], cands[k + 1][1]])
+                    for q in (k, k + 1):
+                        dmids[q], gpw[q] = cands[q][2], cands[q][3]
+                    k += 2
+                else:
+                    dmids[k], gpw[k] = run[k][0].weight.bwd_point(run[k][1].ws, run[k][2]["draw"], run[k][3][2] is not None)
+                    k += 1
+            jobs = [o[0].weight.depth_data_job(o[1].ws, dm, o[4][1], o[4][2]) if o[4][0] else None for o, dm in zip(run, dmids)]
+            batch = (all(jb is not None for jb in jobs) and len({jb[1].p.value for jb in jobs}) == len(jobs)
+                     and len({(jb[1].B, jb[1].C, jb[1].N) for jb in jobs}) == 1)
+            pre = []
+            for o, dm, gp_, jb in zip(run, dmids, gpw, jobs):
+                dx, gdw = o[0].weight.bwd_depth(o[1].ws, dm, o[4][0], o[4][1], o[4][2], data=not batch)
+                pre.append((jb[1].t if batch else dx, gdw + gp_))
+            if batch:
+                K.dwconv_batch([jb[0] for jb in jobs])
+            npre = len(run)
+        for k in range(npre if pre is not None else 1):
             seg, s, t, (dgamma, dbeta, dcb), (need_dx, dx_out, dx_acc) = order[i + k]
             if pre is not None:
                 dx, wg = pre[k]
@@ -685,7 +723,7 @@ def _weight_backward(order):
                     if p is t["conv_bias"]:
                         wg[j] = dcb
             results.append((dx, wg + [dgamma, dbeta]))
-        i += 2 if pre is not None else 1
+        i += npre if pre is not None else 1
     return results
 
 
@@ -713,16 +751,20 @@ def group_forward(terms, out, accumulate):
             res.extend(rr)
             i += 2
         elif i + 1 < len(terms) and isinstance(terms[i][0].weight, DepthSepW) and isinstance(terms[i + 1][0].weight, DepthSepW):
-            # two depthwise-separable primitives: the depthwise stages one after the other, the two 1x1x1 convs in one launch
-            calls, rr = [], []
-            for seg, x, _, _ in terms[i:i + 2]:
-                ws = seg.weight.fwd_depth(x, seg.relu_in, None)
-                call, (y, stats, rows) = seg.weight.point_call(ws, seg.norm is not None)
-                calls.append(call)
-                rr.append([y, stats, rows, ws])
-            K.conv_fwd2(calls)
-            res.extend(rr)
-            i += 2
+            # a run of depthwise-separable primitives: all depthwise stages in one launch, the 1x1x1 convs two per launch
+            j = i
+            while j < len(terms) and isinstance(terms[j][0].weight, DepthSepW):
+                j += 1
+            run = terms[i:j]
+            wss = [seg.weight.fwd_depth(x, seg.relu_in, None, launch=False) for seg, x, _, _ in run]
+            K.dwconv_batch([ws.job for ws in wss])
+            pcs = [seg.weight.point_call(ws, seg.norm is not None) for (seg, _, _, _), ws in zip(run, wss)]
+            for k in range(0, len(run) - 1, 2):
+                K.conv_fwd2([pcs[k][0], pcs[k + 1][0]])
+            if len(run) % 2:
+                K.conv_fwd(*pcs[-1][0])
+            res.extend([y, stats, rows, ws] for (_, (y, stats, rows)), ws in zip(pcs, wss))
+            i = j
         else:
             seg, x, _, _ = terms[i]
             res.append(list(seg.weight.fwd(x, seg.relu_in, None, seg.norm is not None and seg.weight.produces_stats)))
