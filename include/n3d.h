@@ -266,6 +266,9 @@ int n3d_affine_act_bwd_applyN(const float* dout, int64_t dld, const n3d_gn_bwd_t
 /* plain (no norm) epilogue backward coefficients: A = w, Bc = Cc = 0, dalpha = sum Sz */
 int n3d_plain_bwd_coeffs(const double* sums, int rows, const float* wptr, int B, int C, float* dalpha,
                          float* A, void* stream);
+/* the same for up to N3D_MAX_GROUP_TERMS primitives of a node in one launch (A or dalpha of a term may be NULL) */
+typedef struct n3d_plain_coef_term { const double* sums; int32_t rows; int32_t pad_; const float* wptr; float* dalpha; float* A; } n3d_plain_coef_term;
+int n3d_plain_bwd_coeffsN(const n3d_plain_coef_term* terms, int n, int B, int C, void* stream);
 /* backward, pass 2: draw (+)= A[b,c]*g + Bc[b,c] + Cc[b,c]*raw   (Bc, Cc may be NULL) */
 int n3d_affine_act_bwd_apply(const float* dout, int64_t dld, const float* raw, int64_t rld, const float* a,
                              const float* b, const float* A, const float* Bc, const float* Cc, float* draw,
@@ -300,6 +303,9 @@ int n3d_pool2_fwd(const float* x, int64_t xld, float* y, int64_t yld, int B, int
                   int flags, void* stream);
 int n3d_pool2_bwd(const float* dy, int64_t dyld, const float* x, int64_t xld, float* dx, int64_t dxld, int B,
                   int Di, int Hi, int Wi, int C, int flags, void* stream);
+/* dx (+)= w * pool^T(dy): the MixedOp weight of a pooling primitive (cell.py:29-32) folded into its backward (wptr NULL = 1) */
+int n3d_pool2_bwd_scaled(const float* dy, int64_t dyld, const float* x, int64_t xld, float* dx, int64_t dxld, int B, int Di, int Hi,
+                         int Wi, int C, int flags, const float* wptr, void* stream);
 
 /* ---- sigmoid head + Dice loss (nas.py:52, searched.py:93, loss.py:12-14) --------------------------
  * element (b,c,v) of p / t / dp is at  ptr[b*sb + c*sc + v*sv]  (works for NCDHW and NDHWC).

@@ -60,6 +60,11 @@ class SeTerm(C.Structure):
                 ("A", C.c_void_p), ("Bc", C.c_void_p)]
 
 
+class PlainCoefTerm(C.Structure):
+    """n3d_plain_coef_term (include/n3d.h)"""
+    _fields_ = [("sums", C.c_void_p), ("rows", C.c_int32), ("pad_", C.c_int32), ("wptr", C.c_void_p), ("dalpha", C.c_void_p), ("A", C.c_void_p)]
+
+
 class DwJob(C.Structure):
     """n3d_dw_job (include/n3d.h)"""
     _fields_ = [("g", C.POINTER(ConvGeom)), ("data_grad", C.c_int32), ("flags", C.c_int32), ("src", C.c_void_p), ("sld", C.c_int64),
@@ -129,6 +134,8 @@ PROTOTYPES = {
     "n3d_affine_act2": (_i, [C.POINTER(GnFwdTerm), C.POINTER(GnFwdTerm), _p, _i64, _p, _i64, _i, _i64, _i, _i, _p]),
     "n3d_gn_bwd_coeffs2": (_i, [C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i, _i, _i64, _p]),
     "n3d_affine_act_bwd_apply2": (_i, [_p, _i64, _p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _p]),
+    "n3d_plain_bwd_coeffsN": (_i, [C.POINTER(PlainCoefTerm), _i, _i, _i, _p]),
+    "n3d_pool2_bwd_scaled": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _i, _i, _i, _p, _p]),
     "n3d_dwconv_batch": (_i, [C.POINTER(DwJob), _i, _p]),
     "n3d_se_gate_fwdN": (_i, [C.POINTER(SeTerm), _i, _i64, _i, _i, _p]),
     "n3d_se_gate_bwdN": (_i, [C.POINTER(SeTerm), _i, _i64, _i, _i, _p]),

@@ -362,8 +362,8 @@ __global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffsN_kernel(GnBwdCoefA
   gn_bwd_coeffs_body(q, B, C, G, count);
 }
 
-__global__ __launch_bounds__(256) void plain_bwd_coeffs_kernel(const double* __restrict__ sums, int rows, const float* __restrict__ wptr,
-                                                               int B, int C, float* __restrict__ dalpha, float* __restrict__ A) {
+__device__ __forceinline__ void plain_bwd_coeffs_body(const double* __restrict__ sums, int rows, const float* __restrict__ wptr,
+                                                      int B, int C, float* __restrict__ dalpha, float* __restrict__ A) {
   __shared__ double part[256];
   __shared__ double tot[192];
   __shared__ double zred[64];
@@ -387,6 +387,17 @@ __global__ __launch_bounds__(256) void plain_bwd_coeffs_kernel(const double* __r
       *dalpha = (float)s;
     }
   }
+}
+__global__ __launch_bounds__(256) void plain_bwd_coeffs_kernel(const double* __restrict__ sums, int rows, const float* __restrict__ wptr,
+                                                               int B, int C, float* __restrict__ dalpha, float* __restrict__ A) {
+  plain_bwd_coeffs_body(sums, rows, wptr, B, C, dalpha, A);
+}
+struct PlainCoefArgs { const double* sums; int rows; const float* wptr; float* dalpha; float* A; };
+struct PlainCoefArgsN { PlainCoefArgs q[8]; };
+__global__ __launch_bounds__(256) void plain_bwd_coeffsN_kernel(PlainCoefArgsN qs, int B, int C) {
+  PlainCoefArgs q;
+  N3D_PICK8(qs.q, blockIdx.x, q);
+  plain_bwd_coeffs_body(q.sums, q.rows, q.wptr, B, C, q.dalpha, q.A);
 }
 
 // backward pass 2
@@ -1465,7 +1476,8 @@ __global__ __launch_bounds__(256) void pool2_fwd_kernel(const float* __restrict_
 // (d,h,w) scan order, the choice torch's max_pool3d backward makes)
 template <bool MAX, bool ACC>
 __global__ __launch_bounds__(256) void pool2_bwd_kernel(const float* __restrict__ dy, int64_t dyld, const float* __restrict__ x, int64_t xld,
-                                                        float* __restrict__ dx, int64_t dxld, int Di, int Hi, int Wi, int C) {
+                                                        float* __restrict__ dx, int64_t dxld, int Di, int Hi, int Wi, int C,
+                                                        const float* __restrict__ wptr) {
   const int Do = Di / 2, Ho = Hi / 2, Wo = Wi / 2;
   const int cpb = C / 4;
   const int64_t total = (int64_t)Do * Ho * Wo * cpb;
@@ -1479,7 +1491,8 @@ __global__ __launch_bounds__(256) void pool2_bwd_kernel(const float* __restrict_
   const int d_o = v / Ho;
   const int64_t vo = ((int64_t)d_o * Ho + ho) * Wo + wo;
   const float4 gq = *reinterpret_cast<const float4*>(dy + ((int64_t)b * Do * Ho * Wo + vo) * dyld + c4 * 4);
-  const float g[4] = {gq.x, gq.y, gq.z, gq.w};
+  const float wsc = wptr ? *wptr : 1.0f;   // MixedOp weight of the pooling primitive: dx (+)= w * pool^T(dy)
+  const float g[4] = {gq.x * wsc, gq.y * wsc, gq.z * wsc, gq.w * wsc};
   const float* xb = x ? x + (int64_t)b * Di * Hi * Wi * xld + c4 * 4 : nullptr;
   float* db = dx + (int64_t)b * Di * Hi * Wi * dxld + c4 * 4;
   int arg[4] = {0, 0, 0, 0};
@@ -1948,6 +1961,19 @@ int n3d_plain_bwd_coeffs(const double* sums, int rows, const float* wptr, int B,
   return N3D_OK;
 }
 
+int n3d_plain_bwd_coeffsN(const n3d_plain_coef_term* terms, int n, int B, int C, void* stream) {
+  N3D_CHECK_ARG(terms && n >= 1 && n <= N3D_MAX_GROUP_TERMS && B > 0 && C >= 1 && C <= 64, "plain_bwd_coeffsN: bad args");
+  PlainCoefArgsN qs;
+  for (int i = 0; i < 8; ++i) {
+    const n3d_plain_coef_term* t = &terms[i < n ? i : 0];
+    N3D_CHECK_ARG((!t->dalpha || (t->sums && t->rows >= 1)) && (t->dalpha || t->A), "plain_bwd_coeffsN: null term pointer");
+    qs.q[i] = PlainCoefArgs{t->sums, t->rows, t->wptr, t->dalpha, t->A};
+  }
+  hipLaunchKernelGGL(plain_bwd_coeffsN_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, qs, B, C);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
 int n3d_affine_act_bwd_apply(const float* dout, int64_t dld, const float* raw, int64_t rld, const float* a, const float* b, const float* A,
                              const float* Bc, const float* Cc, float* draw, int64_t drld, int B, int64_t N, int C, int flags,
                              void* stream) {
@@ -2032,6 +2058,11 @@ int n3d_pool2_fwd(const float* x, int64_t xld, float* y, int64_t yld, int B, int
 
 int n3d_pool2_bwd(const float* dy, int64_t dyld, const float* x, int64_t xld, float* dx, int64_t dxld, int B, int Di, int Hi, int Wi, int C,
                   int flags, void* stream) {
+  return n3d_pool2_bwd_scaled(dy, dyld, x, xld, dx, dxld, B, Di, Hi, Wi, C, flags, nullptr, stream);
+}
+
+int n3d_pool2_bwd_scaled(const float* dy, int64_t dyld, const float* x, int64_t xld, float* dx, int64_t dxld, int B, int Di, int Hi, int Wi,
+                         int C, int flags, const float* wptr, void* stream) {
   const bool mx = flags & N3D_POOL_MAX, acc = flags & N3D_ACCUMULATE;
   N3D_CHECK_ARG(dy && dx && (!mx || x), "pool2_bwd: bad args");
   if (int e = check_vec(dy, dyld, C, "pool2_bwd(dy)")) return e;
@@ -2040,10 +2071,10 @@ int n3d_pool2_bwd(const float* dy, int64_t dyld, const float* x, int64_t xld, fl
   const int64_t total = (int64_t)(Di / 2) * (Hi / 2) * (Wi / 2) * (C / 4);
   dim3 grid((unsigned)cdiv(total, 256), B), blk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (mx && acc) hipLaunchKernelGGL((pool2_bwd_kernel<true, true>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C);
-  else if (mx) hipLaunchKernelGGL((pool2_bwd_kernel<true, false>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C);
-  else if (acc) hipLaunchKernelGGL((pool2_bwd_kernel<false, true>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C);
-  else hipLaunchKernelGGL((pool2_bwd_kernel<false, false>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C);
+  if (mx && acc) hipLaunchKernelGGL((pool2_bwd_kernel<true, true>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C, wptr);
+  else if (mx) hipLaunchKernelGGL((pool2_bwd_kernel<true, false>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C, wptr);
+  else if (acc) hipLaunchKernelGGL((pool2_bwd_kernel<false, true>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C, wptr);
+  else hipLaunchKernelGGL((pool2_bwd_kernel<false, false>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C, wptr);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

@@ -277,7 +277,7 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
         for node in reversed(range(nn)):
             # the primitives that stay single (identity, SE gates, pooling) all start with a reduction pass over the same node
             # gradient: those passes run up to eight per launch
-            pre, pre_se = {}, {}
+            pre, pre_se, pre_da = {}, {}, set()
             if batch_reduce:
                 want = []
                 for unit in all_units[node]:
@@ -293,6 +293,19 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
                     if len(chunk) >= 2:
                         for (fi, _), r in zip(chunk, K.affine_act_bwd_reduceN(dnodes[node], [c[1] for c in chunk])):
                             pre[fi] = r
+                # ... the pooling primitives' dalpha = <d node, pooled> come out of one launch
+                pools = [fi for fi, _ in want if fi in pre and isinstance(flat[fi][2].weight, P.PoolW) and not flat[fi][2].relu_out]
+                for i in range(0, len(pools), K.MAX_GROUP_TERMS):
+                    chunk = pools[i:i + K.MAX_GROUP_TERMS]
+                    if len(chunk) >= 2:
+                        tds = []
+                        for fi in chunk:
+                            _, _, _, col, amat, row = flat[fi]
+                            dal = alpha_of(amat, row)[1]
+                            tds.append((pre[fi][0], pre[fi][1], dal.data_ptr() + 4 * col))
+                        raw = st.saved[chunk[0]].raw
+                        K.plain_dalphaN(tds, raw.B, raw.C)
+                        pre_da.update(chunk)
                 # ... and the SE gates among them share one gate-backward launch
                 gates = [fi for fi, _ in want if fi in pre and st.saved[fi].kind == "se"]
                 for i in range(0, len(gates), K.MAX_GROUP_TERMS):
@@ -344,7 +357,8 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
                 for idx, seg, s, col, arow, dal in todo:
                     target, acc = tgt(idx)
                     _, gl = P.seg_backward(seg, s, dnodes[node], True, target, acc, arow, col, dal,
-                                           pre.get(unit[0]) if len(unit) == 1 else None, pre_se.get(unit[0]) if len(unit) == 1 else None)
+                                           pre.get(unit[0]) if len(unit) == 1 else None, pre_se.get(unit[0]) if len(unit) == 1 else None,
+                                           len(unit) == 1 and unit[0] in pre_da)
                     put(seg, gl)
     for i in range(2):
         if not pre_started[i]:

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvBwdCall, ConvFwdCall, DwJob, GnFwdTerm, GnBwdTerm, SeTerm, ACCUMULATE, POOL_MAX, PREPACKED, RELU, RELU_IN, ConvGeom, FinalJob, N3DError, PackJob, check
+from ._lib import ConvBwdCall, ConvFwdCall, DwJob, GnFwdTerm, GnBwdTerm, PlainCoefTerm, SeTerm, ACCUMULATE, POOL_MAX, PREPACKED, RELU, RELU_IN, ConvGeom, FinalJob, N3DError, PackJob, check
 
 __all__ = ["View", "as_view", "empty_ndhwc", "stream_ptr", "conv_geom", "ptr"]
 
@@ -728,10 +728,21 @@ def pool2_fwd(x: View, y: View, is_max):
                                     stream_ptr()), "n3d_pool2_fwd")
 
 
-def pool2_bwd(dy: View, x: View, dx: View, is_max, accumulate=False):
+def pool2_bwd(dy: View, x: View, dx: View, is_max, accumulate=False, wptr=None):
+    """dx (+)= w * pool^T(dy); wptr: device scalar (the MixedOp weight of the pooling primitive) or None = 1"""
     fl = (POOL_MAX if is_max else 0) | (ACCUMULATE if accumulate else 0)
-    check(_lib.load().n3d_pool2_bwd(dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.B, x.D, x.H, x.W, x.C, fl, stream_ptr()),
-          "n3d_pool2_bwd")
+    check(_lib.load().n3d_pool2_bwd_scaled(dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.B, x.D, x.H, x.W, x.C, fl, wptr, stream_ptr()),
+          "n3d_pool2_bwd_scaled")
+
+
+def plain_dalphaN(terms, B, Cc):
+    """dalpha = <dout, z> of up to 8 un-normalised primitives from their reduction rows, one launch:
+    terms = [(sums, rows, dalpha_ptr)]"""
+    n = len(terms)
+    arr = (PlainCoefTerm * n)()
+    for i, (sums, rows, dap) in enumerate(terms):
+        arr[i] = PlainCoefTerm(sums.data_ptr(), rows, 0, None, _vp(dap), None)
+    check(_lib.load().n3d_plain_bwd_coeffsN(arr, n, B, Cc, stream_ptr()), "n3d_plain_bwd_coeffsN")
 
 
 # ------------------------------------------------------------------------------------------ dice / adam

@@ -86,14 +86,15 @@ class PoolW(WeightProgram):
         s.x = x
         return y, None, 0, s
 
-    def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
+    def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False, scale=None):
+        """scale: device scalar pointer multiplying the gradient (the primitive's MixedOp weight) or None"""
         if not need_dx:
             return None, []
         x = saved.x
         if dx_out is None:
             dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
             dx_acc = False
-        K.pool2_bwd(draw, x, dx_out, self.is_max, dx_acc)
+        K.pool2_bwd(draw, x, dx_out, self.is_max, dx_acc, scale)
         return dx_out.t, []
 
 
@@ -702,14 +703,20 @@ def _weight_backward(order):
                     dmids[k], gpw[k] = run[k][0].weight.bwd_point(run[k][1].ws, run[k][2]["draw"], run[k][3][2] is not None)
                     k += 1
             jobs = [o[0].weight.depth_data_job(o[1].ws, dm, o[4][1], o[4][2]) if o[4][0] else None for o, dm in zip(run, dmids)]
-            batch = (all(jb is not None for jb in jobs) and len({jb[1].p.value for jb in jobs}) == len(jobs)
-                     and len({(jb[1].B, jb[1].C, jb[1].N) for jb in jobs}) == 1)
+            # batches: jobs of one destination shape (a down / up cell node mixes stride-2 and stride-1 edges), distinct targets
+            shapes = {}
+            if len({jb[1].p.value for jb in jobs if jb is not None}) == sum(jb is not None for jb in jobs):
+                for q, jb in enumerate(jobs):
+                    if jb is not None:
+                        shapes.setdefault((jb[1].B, jb[1].C, jb[1].D, jb[1].H, jb[1].W), []).append(q)
+            batched = {q for qs in shapes.values() if len(qs) >= 2 for q in qs}
             pre = []
-            for o, dm, gp_, jb in zip(run, dmids, gpw, jobs):
-                dx, gdw = o[0].weight.bwd_depth(o[1].ws, dm, o[4][0], o[4][1], o[4][2], data=not batch)
-                pre.append((jb[1].t if batch else dx, gdw + gp_))
-            if batch:
-                K.dwconv_batch([jb[0] for jb in jobs])
+            for q, (o, dm, gp_, jb) in enumerate(zip(run, dmids, gpw, jobs)):
+                dx, gdw = o[0].weight.bwd_depth(o[1].ws, dm, o[4][0], o[4][1], o[4][2], data=q not in batched)
+                pre.append((jb[1].t if q in batched else dx, gdw + gp_))
+            for qs in shapes.values():
+                if len(qs) >= 2:
+                    K.dwconv_batch([jobs[q][0] for q in qs])
             npre = len(run)
         for k in range(npre if pre is not None else 1):
             seg, s, t, (dgamma, dbeta, dcb), (need_dx, dx_out, dx_acc) = order[i + k]
@@ -817,12 +824,14 @@ def needs_reduce(seg, s, dalpha):
     return s.kind in ("gn", "se") or dalpha is not None
 
 
-def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_row=None, alpha_k=0, dalpha=None, pre_sums=None, pre_se=None):
+def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_row=None, alpha_k=0, dalpha=None, pre_sums=None, pre_se=None,
+                 pre_dalpha=False):
     """Backward of one segment.  dout: View of d(out).  Returns (dx tensor | None, [param grads])
     with param grads ordered like seg.params().  If `dalpha` (a float tensor) is given,
     dalpha[alpha_k] = <dout, z> is written (MixedOp architecture gradient, cell.py:29-32).
     pre_sums = (sums, rows): the reduction pass was already done (K.affine_act_bwd_reduceN over several terms of a node);
-    pre_se = (dw1, db1, dw2, db2, A, Bc): so was the SE gate backward (K.se_gate_bwdN)."""
+    pre_se = (dw1, db1, dw2, db2, A, Bc): so was the SE gate backward (K.se_gate_bwdN); pre_dalpha: so was dalpha of an
+    un-normalised primitive (K.plain_dalphaN)."""
     wp = _wptr(alpha_row, alpha_k)
     dap = C.c_void_p(dalpha.data_ptr() + 4 * alpha_k) if dalpha is not None else None
     raw = s.raw
@@ -880,6 +889,13 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
             dx = dx_out.t
         return dx, [dw1, db1, dw2, db2]
     else:
+        if isinstance(seg.weight, PoolW) and not seg.relu_out:
+            # pooling: dx (+)= w * pool^T(dout) in the pooling backward itself; dalpha = <dout, pooled> from the reduction rows
+            if dap is not None and not pre_dalpha:
+                sums, rows = pre_sums if pre_sums is not None else K.affine_act_bwd_reduce(dout, raw, None, None, 0)
+                K.plain_bwd_coeffs(sums, rows, wp, raw.B, raw.C, raw.t.device, dap, want_A=False)
+            dx, wg = seg.weight.bwd(s.ws, dout, need_dx, dx_out, dx_acc, scale=wp)
+            return dx, list(wg) + extra
         if seg.relu_out or wp is not None or dap is not None:
             sums, rows = (None, 0)
             if dap is not None:
