@@ -24,6 +24,11 @@ GROUP_SUPERNET_TERMS = True  # ... and take them up to eight at a time where a n
 REUSE_GRAD_OUTPUT = False  # see _run_backward; switched on by the trainers for the duration of their backward pass
 
 
+def _grouping(c_node):
+    """are the N-term launches of a supernet node in use?  (both switches on, channel count the group kernels take)"""
+    return PAIR_SUPERNET_TERMS and GROUP_SUPERNET_TERMS and K.group_shape_ok(c_node)
+
+
 def _single_segment(op):
     if op._segments is None:
         op._segments = op._build_segments()
@@ -108,7 +113,7 @@ def _node_units(plan):
         rest = [fi for fi in pairable if fi not in rank]
         rest.sort(key=lambda fi: (not isinstance(flat[fi][2].weight, P.DepthSepW), fi))   # depthwise-separable terms side by side
         u = []
-        if GROUP_SUPERNET_TERMS and K.group_shape_ok(plan.c_node) and len(pairable) >= 3 and len({flat[fi][2].norm.eps for fi in pairable}) == 1:
+        if _grouping(plan.c_node) and len(pairable) >= 3 and len({flat[fi][2].norm.eps for fi in pairable}) == 1:
             # N-term groups: all coefficients in one launch and one pass over the node buffer (backward: three launches per group)
             both = dense + rest
             for i in range(0, len(both), K.MAX_GROUP_TERMS):
@@ -132,7 +137,7 @@ def _node_fwd_units(plan):
     if getattr(plan, "_fwd_units", None) is not None:
         return plan._fwd_units
     units = _node_units(plan)
-    if GROUP_SUPERNET_TERMS and K.group_shape_ok(plan.c_node):
+    if _grouping(plan.c_node):
         out = []
         for u in units:
             every = [fi for unit in u for fi in unit]
@@ -183,7 +188,7 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2):
     # in the order of _node_units (a fixed order, but not the reference's left-to-right one: fp32 rounding differs)
     flat = _flat_terms(plan)
     st.saved = [None] * len(flat)
-    grouped = GROUP_SUPERNET_TERMS and K.group_shape_ok(plan.c_node)
+    grouped = _grouping(plan.c_node)
     for node, units in enumerate(_node_fwd_units(plan)):
         for unit in units:
             args = []
@@ -273,7 +278,7 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
             return (alpha1 if amat == 1 else alpha2)[row], (d[row] if d is not None else None)
 
         all_units = _node_units(plan)
-        batch_reduce = GROUP_SUPERNET_TERMS and K.group_shape_ok(cn)
+        batch_reduce = _grouping(cn)
         for node in reversed(range(nn)):
             # the primitives that stay single (identity, SE gates, pooling) all start with a reduction pass over the same node
             # gradient: those passes run up to eight per launch
