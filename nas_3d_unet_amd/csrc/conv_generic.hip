@@ -338,6 +338,136 @@ static void launch_gather(const GatherArgs& a, int B, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 1x1x1 stride-1 convs with few channels on the large levels (stems, the preprocess convs of the outer cells, their data
+// gradients): pure streaming.  One thread owns four voxels (coalesced: voxel = base + i*256 + lane), the [Cs][Cd] weight
+// tile sits in LDS and every broadcast read of it feeds four voxels, a workgroup writes ONE statistics row for its 1024
+// voxels.  The generic gather kernel spends a workgroup (weight staging, barrier, block reduction) on every 256 voxels.
+// ------------------------------------------------------------------------------------------------
+struct K1Args {
+  const float* src; int64_t sld; float* dst; int64_t dld; const float* wp; int Cdp; const float* bias;
+  int flags; const float* relu_src; int64_t rld; double* stats; int64_t N;
+};
+constexpr int K1_VPB = 1024;   // voxels per workgroup
+
+// EXTRA: the data-gradient extras (accumulate into dst, ReLU mask source) are in use -- they cost 8 * CDQ registers per voxel
+template <int CSQ, int CDQ, bool EXTRA>   // Cs = 4 * CSQ, Cd = 4 * CDQ
+__global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
+  constexpr int VPT = EXTRA ? 2 : K1_VPB / 256;   // data-gradient form: no statistics rows to agree on, fewer registers per voxel
+  __shared__ __attribute__((aligned(16))) float4 wl[CSQ * 4 * CDQ];
+  __shared__ double red[4][CDQ * 8];
+  const int t = threadIdx.x, b = blockIdx.y;
+  for (int i = t; i < CSQ * 4 * CDQ; i += 256) {
+    const int cs = i / CDQ, q = i - cs * CDQ;
+    wl[i] = *reinterpret_cast<const float4*>(a.wp + (int64_t)cs * a.Cdp + q * 4);
+  }
+  const int64_t base = (int64_t)blockIdx.x * (VPT * 256) + t;
+  const float* sb = a.src + (int64_t)b * a.N * a.sld;
+  float* db = a.dst + (int64_t)b * a.N * a.dld;
+  const bool accum = EXTRA && (a.flags & N3D_ACCUMULATE);
+  const float floor_ = (a.flags & N3D_RELU_IN) ? 0.f : -INFINITY;
+  float4 x[VPT][CSQ], prev[EXTRA ? VPT : 1][CDQ], msk[EXTRA ? VPT : 1][CDQ];
+  bool ok[VPT];
+  // every global operand is requested before the first use
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int64_t v = base + i * 256;
+    ok[i] = v < a.N;
+    const int64_t vc = ok[i] ? v : a.N - 1;
+#pragma unroll
+    for (int q = 0; q < CSQ; ++q) x[i][q] = *reinterpret_cast<const float4*>(sb + vc * a.sld + q * 4);
+    if constexpr (EXTRA) {
+#pragma unroll
+      for (int q = 0; q < CDQ; ++q) {
+        prev[i][q] = accum ? *reinterpret_cast<const float4*>(db + vc * a.dld + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        msk[i][q] = a.relu_src ? *reinterpret_cast<const float4*>(a.relu_src + ((int64_t)b * a.N + vc) * a.rld + q * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+      }
+    }
+  }
+  float4 acc[VPT][CDQ];
+#pragma unroll
+  for (int q = 0; q < CDQ; ++q) {
+    const float4 bq = a.bias ? *reinterpret_cast<const float4*>(a.bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) acc[i][q] = bq;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int cs = 0; cs < CSQ * 4; ++cs) {
+    float xv[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const float4 xq = x[i][cs >> 2];
+      xv[i] = fmaxf((cs & 3) == 0 ? xq.x : ((cs & 3) == 1 ? xq.y : ((cs & 3) == 2 ? xq.z : xq.w)), floor_);
+    }
+#pragma unroll
+    for (int q = 0; q < CDQ; ++q) {
+      const float4 w = wl[cs * CDQ + q];
+#pragma unroll
+      for (int i = 0; i < VPT; ++i) {
+        acc[i][q].x = fmaf(xv[i], w.x, acc[i][q].x); acc[i][q].y = fmaf(xv[i], w.y, acc[i][q].y);
+        acc[i][q].z = fmaf(xv[i], w.z, acc[i][q].z); acc[i][q].w = fmaf(xv[i], w.w, acc[i][q].w);
+      }
+    }
+  }
+  float s1[CDQ * 4], s2[CDQ * 4];
+#pragma unroll
+  for (int j = 0; j < CDQ * 4; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+#pragma unroll
+    for (int q = 0; q < CDQ; ++q) {
+      float4 r = acc[i][q];
+      if constexpr (EXTRA) {
+        if (a.relu_src) {
+          r.x = msk[i][q].x > 0.f ? r.x : 0.f; r.y = msk[i][q].y > 0.f ? r.y : 0.f; r.z = msk[i][q].z > 0.f ? r.z : 0.f; r.w = msk[i][q].w > 0.f ? r.w : 0.f;
+        }
+        r.x += prev[i][q].x; r.y += prev[i][q].y; r.z += prev[i][q].z; r.w += prev[i][q].w;
+      }
+      if (ok[i]) {
+        *reinterpret_cast<float4*>(db + (base + i * 256) * a.dld + q * 4) = r;
+        s1[q * 4] += r.x; s1[q * 4 + 1] += r.y; s1[q * 4 + 2] += r.z; s1[q * 4 + 3] += r.w;
+        s2[q * 4] = fmaf(r.x, r.x, s2[q * 4]); s2[q * 4 + 1] = fmaf(r.y, r.y, s2[q * 4 + 1]);
+        s2[q * 4 + 2] = fmaf(r.z, r.z, s2[q * 4 + 2]); s2[q * 4 + 3] = fmaf(r.w, r.w, s2[q * 4 + 3]);
+      }
+    }
+  }
+  if (a.stats) {
+    const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+    for (int j = 0; j < CDQ * 4; ++j) {
+      const float s = wave_sum_f(s1[j]), ss = wave_sum_f(s2[j]);
+      if (lane == 0) { red[wave][j * 2] = (double)s; red[wave][j * 2 + 1] = (double)ss; }
+    }
+    __syncthreads();
+    if (t < CDQ * 8)
+      a.stats[(((int64_t)b * gridDim.x + blockIdx.x) * (CDQ * 4)) * 2 + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+  }
+}
+
+// shapes the 1x1x1 streaming kernel takes (the statistics row count depends on it: n3d_conv_stats_rows)
+static bool k1_shape_ok(const n3d_conv_geom* g, bool data_grad) {
+  if (g->k != 1 || g->stride != 1 || g->depthwise) return false;
+  const int Cs = data_grad ? g->Co : g->Ci, Cd = data_grad ? g->Ci : g->Co;
+  const int64_t N = (int64_t)g->Di * g->Hi * g->Wi;
+  // register budget: (Cs/4) * (Cd/4) <= 6 covers the nets' shapes (4->12, 12->4, 12->8, 24->4 and their data gradients)
+  return Cs % 4 == 0 && Cs >= 4 && Cs <= 24 && Cd % 4 == 0 && Cd >= 4 && Cd <= 12 && (Cs / 4) * (Cd / 4) <= 6 && N >= 32768;
+}
+
+template <int CSQ, bool EXTRA>
+static void launch_k1_e(const K1Args& a, int Cd, dim3 grid, hipStream_t s) {
+  switch (Cd / 4) {
+    case 1: hipLaunchKernelGGL((conv_k1_kernel<CSQ, 1, EXTRA>), grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((conv_k1_kernel<CSQ, 2, EXTRA>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((conv_k1_kernel<CSQ, 3, EXTRA>), grid, dim3(256), 0, s, a); break;
+  }
+}
+template <int CSQ>
+static void launch_k1_c(const K1Args& a, int Cd, dim3 grid, hipStream_t s) {
+  if ((a.flags & N3D_ACCUMULATE) || a.relu_src) launch_k1_e<CSQ, true>(a, Cd, grid, s);
+  else launch_k1_e<CSQ, false>(a, Cd, grid, s);
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient: dW[co][ci][tap] = sum_{b,o} dy[b,o,co] * f(x[b, o*s - pad + tap*dil, ci])
 // one block = (chunk of flattened (b,o), one (tap, ci tile, co tile)); per-thread register outer
 // products, wave reduction, partial slabs, then a fixed-order final reduction (deterministic).
@@ -983,6 +1113,7 @@ int n3d_conv_stats_rows(const n3d_conv_geom* g, int transposed, int flags) {
   // transposed forward runs the gather kernel with den = stride; its parity-class mode has 8 row groups
   // (activation tensors on this path are 16-byte aligned pitched views, which the class mode requires)
   if (transposed && gather_class_mode(g->stride, g->k, g->Di, g->Hi, g->Wi, g->Co, true)) return (int)(8 * cdiv(Nd / 8, 256));
+  if (k1_shape_ok(g, transposed != 0)) return (int)cdiv(Nd, K1_VPB);   // the 1x1x1 streaming kernel: one row per 1024 voxels
   return (int)cdiv(Nd, 256);
 }
 
@@ -1036,6 +1167,32 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
   if (stats && gather_class_mode(a.den, a.k, a.Dd, a.Hd, a.Wd, a.Cs, true) && !((a.Cs % 4 == 0) && (a.sld % 4 == 0) && aligned16(a.src))) {
     set_error("conv: statistics on this shape need a 16-byte aligned source (n3d_conv_stats_rows assumed the parity-class kernel)");
     return N3D_ERR_UNSUPPORTED;
+  }
+  if (k1_shape_ok(g, data_grad)) {
+    const bool fits = !in_gate && !out_gate && sld % 4 == 0 && dld % 4 == 0 && aligned16(src) && aligned16(dst) && aligned16(a.wp) &&
+                      (!bias || aligned16(bias)) && (!relu_src || (rld % 4 == 0 && aligned16(relu_src))) && a.Cdp % 4 == 0;
+    if (fits) {
+      K1Args q;
+      q.src = src; q.sld = sld; q.dst = dst; q.dld = dld; q.wp = a.wp; q.Cdp = a.Cdp; q.bias = bias; q.flags = flags; q.relu_src = relu_src;
+      q.rld = rld; q.stats = stats; q.N = (int64_t)a.Dd * a.Hd * a.Wd;
+      const bool extra = (flags & N3D_ACCUMULATE) || relu_src;
+      N3D_CHECK_ARG(!(extra && stats), "conv(1x1x1): statistics together with accumulate / relu mask are not supported");
+      const dim3 grid((unsigned)cdiv(q.N, extra ? 512 : K1_VPB), (unsigned)g->B);
+      switch (a.Cs / 4) {
+        case 1: launch_k1_c<1>(q, a.Cd, grid, s); break;
+        case 2: launch_k1_c<2>(q, a.Cd, grid, s); break;
+        case 3: launch_k1_c<3>(q, a.Cd, grid, s); break;
+        case 4: launch_k1_c<4>(q, a.Cd, grid, s); break;
+        case 5: launch_k1_c<5>(q, a.Cd, grid, s); break;
+        default: launch_k1_c<6>(q, a.Cd, grid, s); break;
+      }
+      N3D_LAUNCH_CHECK();
+      return N3D_OK;
+    }
+    if (stats) {
+      set_error("conv: statistics on this 1x1x1 shape need the streaming kernel (no gates, 16-byte aligned rows): n3d_conv_stats_rows assumed it");
+      return N3D_ERR_UNSUPPORTED;
+    }
   }
   launch_gather(a, g->B, s);
   N3D_LAUNCH_CHECK();
