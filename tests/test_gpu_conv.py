@@ -57,6 +57,11 @@ CASES = [
     (4, 4, 3, 2, 2, False, 2, (32, 32, 64)),
     (4, 4, 3, 1, 2, False, 2, (64, 64, 64)),     # dilation 2 at full size: two waves per workgroup on a shared 8-row halo tile
     (4, 4, 3, 1, 1, False, 2, (64, 64, 64)),     # the roofline shape itself (TD = 4 tiles, XCD-ordered)
+    # 1x1x1 streaming kernel (>= 32768 voxels, few channels): stems / outer preprocess convs and their data gradients
+    (4, 12, 1, 1, 1, False, 2, (32, 32, 32)),
+    (12, 4, 1, 1, 1, False, 2, (32, 33, 32)),    # ragged: the last workgroup is partial
+    (12, 8, 1, 1, 1, False, 1, (32, 32, 40)),
+    (24, 4, 1, 1, 1, False, 2, (32, 32, 32)),
 ]
 
 
