@@ -346,6 +346,9 @@ static void launch_gather(const GatherArgs& a, int B, hipStream_t s) {
 struct K1Args {
   const float* src; int64_t sld; float* dst; int64_t dld; const float* wp; int Cdp; const float* bias;
   int flags; const float* relu_src; int64_t rld; double* stats; int64_t N;
+  // up: the data gradient of a stride-2 1x1x1 conv -- destination voxel (d,h,w) takes source voxel (d/2,h/2,w/2) when all three
+  // are even and nothing otherwise; Ns = source voxels per sample
+  int up, Wd, Hd; int64_t Ns; FastDiv fWd, fHd;
 };
 constexpr int K1_VPB = 1024;   // voxels per workgroup
 
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
     wl[i] = *reinterpret_cast<const float4*>(a.wp + (int64_t)cs * a.Cdp + q * 4);
   }
   const int64_t base = (int64_t)blockIdx.x * (VPT * 256) + t;
-  const float* sb = a.src + (int64_t)b * a.N * a.sld;
+  const float* sb = a.src + (int64_t)b * (EXTRA && a.up ? a.Ns : a.N) * a.sld;
   float* db = a.dst + (int64_t)b * a.N * a.dld;
   const bool accum = EXTRA && (a.flags & N3D_ACCUMULATE);
   const float floor_ = (a.flags & N3D_RELU_IN) ? 0.f : -INFINITY;
@@ -373,8 +376,23 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
     const int64_t v = base + i * 256;
     ok[i] = v < a.N;
     const int64_t vc = ok[i] ? v : a.N - 1;
+    int64_t vs = vc;
+    bool hit = true;
+    if constexpr (EXTRA) {
+      if (a.up) {
+        uint32_t q1, uw, ud, uh;
+        a.fWd.divmod((uint32_t)vc, q1, uw);
+        a.fHd.divmod(q1, ud, uh);
+        hit = !((uw | uh | ud) & 1u);
+        vs = ((int64_t)(ud >> 1) * (a.Hd >> 1) + (uh >> 1)) * (a.Wd >> 1) + (uw >> 1);
+        if (!hit) vs = 0;
+      }
+    }
 #pragma unroll
-    for (int q = 0; q < CSQ; ++q) x[i][q] = *reinterpret_cast<const float4*>(sb + vc * a.sld + q * 4);
+    for (int q = 0; q < CSQ; ++q) {
+      x[i][q] = *reinterpret_cast<const float4*>(sb + vs * a.sld + q * 4);
+      if (EXTRA && !hit) x[i][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if constexpr (EXTRA) {
 #pragma unroll
       for (int q = 0; q < CDQ; ++q) {
@@ -446,7 +464,9 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
 
 // shapes the 1x1x1 streaming kernel takes (the statistics row count depends on it: n3d_conv_stats_rows)
 static bool k1_shape_ok(const n3d_conv_geom* g, bool data_grad) {
-  if (g->k != 1 || g->stride != 1 || g->depthwise) return false;
+  if (g->k != 1 || g->depthwise) return false;
+  // stride 2: only the data gradient (zero-upsampling form), even input dims, no bias
+  if (g->stride != 1 && !(g->stride == 2 && data_grad && g->pad == 0 && g->Di % 2 == 0 && g->Hi % 2 == 0 && g->Wi % 2 == 0)) return false;
   const int Cs = data_grad ? g->Co : g->Ci, Cd = data_grad ? g->Ci : g->Co;
   const int64_t N = (int64_t)g->Di * g->Hi * g->Wi;
   // register budget: (Cs/4) * (Cd/4) <= 6 covers the nets' shapes (4->12, 12->4, 12->8, 24->4 and their data gradients)
@@ -463,7 +483,7 @@ static void launch_k1_e(const K1Args& a, int Cd, dim3 grid, hipStream_t s) {
 }
 template <int CSQ>
 static void launch_k1_c(const K1Args& a, int Cd, dim3 grid, hipStream_t s) {
-  if ((a.flags & N3D_ACCUMULATE) || a.relu_src) launch_k1_e<CSQ, true>(a, Cd, grid, s);
+  if ((a.flags & N3D_ACCUMULATE) || a.relu_src || a.up) launch_k1_e<CSQ, true>(a, Cd, grid, s);
   else launch_k1_e<CSQ, false>(a, Cd, grid, s);
 }
 
@@ -1113,7 +1133,7 @@ int n3d_conv_stats_rows(const n3d_conv_geom* g, int transposed, int flags) {
   // transposed forward runs the gather kernel with den = stride; its parity-class mode has 8 row groups
   // (activation tensors on this path are 16-byte aligned pitched views, which the class mode requires)
   if (transposed && gather_class_mode(g->stride, g->k, g->Di, g->Hi, g->Wi, g->Co, true)) return (int)(8 * cdiv(Nd / 8, 256));
-  if (k1_shape_ok(g, transposed != 0)) return (int)cdiv(Nd, K1_VPB);   // the 1x1x1 streaming kernel: one row per 1024 voxels
+  if (g->stride == 1 && k1_shape_ok(g, transposed != 0)) return (int)cdiv(Nd, K1_VPB);   // the 1x1x1 streaming kernel: one row per 1024 voxels
   return (int)cdiv(Nd, 256);
 }
 
@@ -1170,12 +1190,14 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
   }
   if (k1_shape_ok(g, data_grad)) {
     const bool fits = !in_gate && !out_gate && sld % 4 == 0 && dld % 4 == 0 && aligned16(src) && aligned16(dst) && aligned16(a.wp) &&
-                      (!bias || aligned16(bias)) && (!relu_src || (rld % 4 == 0 && aligned16(relu_src))) && a.Cdp % 4 == 0;
+                      (!bias || aligned16(bias)) && (!relu_src || (rld % 4 == 0 && aligned16(relu_src))) && a.Cdp % 4 == 0 &&
+                      !(a.den == 2 && (bias || stats));   // the zero-upsampling form carries neither
     if (fits) {
       K1Args q;
       q.src = src; q.sld = sld; q.dst = dst; q.dld = dld; q.wp = a.wp; q.Cdp = a.Cdp; q.bias = bias; q.flags = flags; q.relu_src = relu_src;
       q.rld = rld; q.stats = stats; q.N = (int64_t)a.Dd * a.Hd * a.Wd;
-      const bool extra = (flags & N3D_ACCUMULATE) || relu_src;
+      q.up = a.den == 2 ? 1 : 0; q.Wd = a.Wd; q.Hd = a.Hd; q.Ns = (int64_t)a.Ds * a.Hs * a.Ws; q.fWd = a.fWd; q.fHd = a.fHd;
+      const bool extra = (flags & N3D_ACCUMULATE) || relu_src || q.up;
       N3D_CHECK_ARG(!(extra && stats), "conv(1x1x1): statistics together with accumulate / relu mask are not supported");
       const dim3 grid((unsigned)cdiv(q.N, extra ? 512 : K1_VPB), (unsigned)g->B);
       switch (a.Cs / 4) {
@@ -1189,7 +1211,7 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
       N3D_LAUNCH_CHECK();
       return N3D_OK;
     }
-    if (stats) {
+    if (stats && g->stride == 1) {
       set_error("conv: statistics on this 1x1x1 shape need the streaming kernel (no gates, 16-byte aligned rows): n3d_conv_stats_rows assumed it");
       return N3D_ERR_UNSUPPORTED;
     }

@@ -62,6 +62,7 @@ CASES = [
     (12, 4, 1, 1, 1, False, 2, (32, 33, 32)),    # ragged: the last workgroup is partial
     (12, 8, 1, 1, 1, False, 1, (32, 32, 40)),
     (24, 4, 1, 1, 1, False, 2, (32, 32, 32)),
+    (12, 8, 1, 2, 1, False, 2, (32, 32, 64)),    # stride 2: its data gradient is the zero-upsampling form of the same kernel
 ]
 
 
