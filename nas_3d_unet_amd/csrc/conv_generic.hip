@@ -487,6 +487,109 @@ static void launch_k1_c(const K1Args& a, int Cd, dim3 grid, hipStream_t s) {
   else launch_k1_e<CSQ, false>(a, Cd, grid, s);
 }
 
+// weight gradient of the same 1x1x1 convs (stride 1 or 2): dW[co][ci] = sum_v f(x[i(v)][ci]) * dy[v][co], dbias = sum_v dy[v].
+// A thread streams output voxels (coalesced over the workgroup), keeps the whole Ci x Co outer product in registers and the
+// workgroup leaves ONE partial slab ([Ci][Co] + [Co]) for the common fixed-order finalize.  The tiled generic kernel reads dy
+// once per input-channel tile and x in 16-byte pieces of 48-byte voxels.
+struct K1WgArgs {
+  const float* x; int64_t xld; const float* dy; int64_t dyld; float* partial; float* pbias; int64_t total, chunk; int flags;
+  int stride, Wo, Ho, Wi, Hi; int64_t No, Ni; FastDiv fNo, fWo, fHo;
+};
+constexpr int K1W_CHUNK = 2048;   // output voxels per workgroup
+
+template <int CIQ, int COQ>
+__global__ __launch_bounds__(256) void conv_k1_wgrad_kernel(K1WgArgs a) {
+  constexpr int CI = CIQ * 4, CO = COQ * 4, NV = CI * CO + CO;
+  __shared__ float red[4][NV];
+  const int t = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * a.chunk;
+  int64_t i1 = i0 + a.chunk;
+  if (i1 > a.total) i1 = a.total;
+  const float floor_ = (a.flags & N3D_RELU_IN) ? 0.f : -INFINITY;
+  float acc[CI][CO], accb[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) accb[c] = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[ci][c] = 0.f;
+  for (int64_t i = i0 + t; i < i1; i += 512) {
+    // two voxels in flight per trip
+    float4 xq[2][CIQ], gq[2][COQ];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t v = i + u * 256;
+      ok[u] = v < i1;
+      const int64_t vc = ok[u] ? v : i;
+      int64_t xi = vc;
+      if (a.stride == 2) {
+        uint32_t ub, uo, q1, uw, ud, uh;
+        a.fNo.divmod((uint32_t)vc, ub, uo);
+        a.fWo.divmod(uo, q1, uw);
+        a.fHo.divmod(q1, ud, uh);
+        xi = (int64_t)ub * a.Ni + ((int64_t)(2 * ud) * a.Hi + 2 * uh) * a.Wi + 2 * uw;
+      }
+#pragma unroll
+      for (int q = 0; q < CIQ; ++q) xq[u][q] = *reinterpret_cast<const float4*>(a.x + xi * a.xld + q * 4);
+#pragma unroll
+      for (int q = 0; q < COQ; ++q) gq[u][q] = *reinterpret_cast<const float4*>(a.dy + vc * a.dyld + q * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!ok[u]) continue;
+      float g[CO];
+#pragma unroll
+      for (int q = 0; q < COQ; ++q) { g[q * 4] = gq[u][q].x; g[q * 4 + 1] = gq[u][q].y; g[q * 4 + 2] = gq[u][q].z; g[q * 4 + 3] = gq[u][q].w; }
+#pragma unroll
+      for (int c = 0; c < CO; ++c) accb[c] += g[c];
+#pragma unroll
+      for (int q = 0; q < CIQ; ++q) {
+        const float xv[4] = {fmaxf(xq[u][q].x, floor_), fmaxf(xq[u][q].y, floor_), fmaxf(xq[u][q].z, floor_), fmaxf(xq[u][q].w, floor_)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < CO; ++c) acc[q * 4 + e][c] = fmaf(xv[e], g[c], acc[q * 4 + e][c]);
+      }
+    }
+  }
+  const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+  for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      const float sv = wave_sum_f(acc[ci][c]);
+      if (lane == 0) red[wave][ci * CO + c] = sv;
+    }
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const float sv = wave_sum_f(accb[c]);
+    if (lane == 0) red[wave][CI * CO + c] = sv;
+  }
+  __syncthreads();
+  for (int j = t; j < NV; j += 256) {
+    const float sv = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    if (j < CI * CO) a.partial[(int64_t)blockIdx.x * (CI * CO) + j] = sv;
+    else a.pbias[(int64_t)blockIdx.x * CO + (j - CI * CO)] = sv;
+  }
+}
+
+static bool k1_wgrad_shape_ok(const n3d_conv_geom* g) {
+  if (g->k != 1 || g->depthwise || g->pad != 0 || (g->stride != 1 && g->stride != 2)) return false;
+  const int64_t total = (int64_t)g->B * g->Do * g->Ho * g->Wo;
+  return g->Ci % 4 == 0 && g->Ci >= 4 && g->Ci <= 24 && g->Co % 4 == 0 && g->Co >= 4 && g->Co <= 12 && (g->Ci / 4) * (g->Co / 4) <= 6 &&
+         total >= 32768 && total < (1ll << 31);
+}
+
+template <int CIQ>
+static void launch_k1_wgrad_c(const K1WgArgs& a, int Co, int nchunks, hipStream_t s) {
+  switch (Co / 4) {
+    case 1: hipLaunchKernelGGL((conv_k1_wgrad_kernel<CIQ, 1>), dim3(nchunks), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((conv_k1_wgrad_kernel<CIQ, 2>), dim3(nchunks), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((conv_k1_wgrad_kernel<CIQ, 3>), dim3(nchunks), dim3(256), 0, s, a); break;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight gradient: dW[co][ci][tap] = sum_{b,o} dy[b,o,co] * f(x[b, o*s - pad + tap*dil, ci])
 // one block = (chunk of flattened (b,o), one (tap, ci tile, co tile)); per-thread register outer
@@ -1350,6 +1453,41 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
       } else {
         hipLaunchKernelGGL(conv_wgrad_final_kernel, dim3((unsigned)cdiv(nout, 256)), dim3(256), 0, s, wsf, pb, nch, ntl, g->Ci / 16,
                            g->Co / 16, 16, 16, g->Co, g->Ci, taps, dw, transposed ? nullptr : dbias);
+      }
+      N3D_LAUNCH_CHECK();
+      return N3D_OK;
+    }
+  }
+  if (!transposed && !in_gate && k1_wgrad_shape_ok(g) && xld % 4 == 0 && dyld % 4 == 0 && aligned16(x) && aligned16(dy)) {
+    // 1x1x1 streaming weight gradient (large levels, few channels)
+    const int64_t total = (int64_t)g->B * No;
+    const size_t nslab = (size_t)g->Ci * g->Co;
+    // 2048 voxels per workgroup, more when the slab workspace (sized for the tiled kernel) or 1024 workgroups would be exceeded
+    int64_t maxc = (int64_t)(avail / (nslab + g->Co));
+    if (maxc > 1024) maxc = 1024;
+    int64_t chunk = K1W_CHUNK;
+    if (maxc >= 1 && cdiv(total, chunk) > maxc) chunk = (cdiv(total, maxc) + 255) / 256 * 256;
+    const int nchunks = (int)cdiv(total, chunk);
+    if (maxc >= 64 && (size_t)nchunks * (nslab + g->Co) <= avail) {
+      K1WgArgs q;
+      q.x = x; q.xld = xld; q.dy = dy; q.dyld = dyld; q.partial = wsf; q.pbias = wsf + (size_t)nchunks * nslab; q.total = total;
+      q.chunk = chunk; q.flags = flags; q.stride = g->stride; q.Wo = g->Wo; q.Ho = g->Ho; q.Wi = g->Wi; q.Hi = g->Hi; q.No = No;
+      q.Ni = (int64_t)g->Di * g->Hi * g->Wi; q.fNo = FastDiv((uint32_t)No); q.fWo = FastDiv((uint32_t)g->Wo); q.fHo = FastDiv((uint32_t)g->Ho);
+      switch (g->Ci / 4) {
+        case 1: launch_k1_wgrad_c<1>(q, g->Co, nchunks, s); break;
+        case 2: launch_k1_wgrad_c<2>(q, g->Co, nchunks, s); break;
+        case 3: launch_k1_wgrad_c<3>(q, g->Co, nchunks, s); break;
+        case 4: launch_k1_wgrad_c<4>(q, g->Co, nchunks, s); break;
+        case 5: launch_k1_wgrad_c<5>(q, g->Co, nchunks, s); break;
+        default: launch_k1_wgrad_c<6>(q, g->Co, nchunks, s); break;
+      }
+      // one "tile" holding the whole [Ci][Co] slab: ci_t = Ci, co_t = Co
+      if (deferred) {
+        fill_job(deferred, q.partial, q.pbias, dw, dbias, nchunks, 1, 1, 1, g->Ci, g->Co, g->Co, g->Ci, 1);
+      } else {
+        const int nout = g->Co * g->Ci + g->Co;
+        hipLaunchKernelGGL(conv_wgrad_final_kernel, dim3((unsigned)cdiv(nout, 256)), dim3(256), 0, s, q.partial, q.pbias, nchunks, 1, 1, 1, g->Ci,
+                           g->Co, g->Co, g->Ci, 1, dw, dbias);
       }
       N3D_LAUNCH_CHECK();
       return N3D_OK;
