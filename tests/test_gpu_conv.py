@@ -143,6 +143,22 @@ def test_conv_family(cin, cout, k, stride, dil, transposed, B, shape):
     assert_close(dx.t, xc2.grad, 5e-5, "dx relu-mask+gate")
     K.conv_bwd_weight(g, x, dy, dw, None, K.RELU_IN, gate, False)
     assert_close(dw, wc2.grad, 1e-4, "dw relu+gate")
+    # ---------------- ReLU on load alone (the preprocess convs, 'act_weight_norm'): the 1x1x1 streaming kernels take this form
+    if k == 1:
+        xc3 = torch.from_numpy(xn).requires_grad_(True)
+        wc3 = torch.from_numpy(wn).requires_grad_(True)
+        yc3 = F.conv3d(F.relu(xc3), wc3, None, stride=stride, padding=pad, dilation=dil)
+        (yc3 * torch.from_numpy(rn)).sum().backward()
+        K.conv_fwd(g, x, w, None, y, K.RELU_IN, None, None, False)
+        assert_close(y.t, yc3, 2e-5, "y relu")
+        dx4 = K.as_view(torch.from_numpy(_mk((B, cin) + shape, 9)).to(dev))
+        base = dx4.t.clone()
+        K.conv_bwd_data(g, dy, w, dx4, K.ACCUMULATE, x, None, False)
+        assert_close(dx4.t, base.cpu() + xc3.grad, 5e-5, "dx relu-mask + accumulate")
+        dw4, db4 = torch.zeros_like(w), torch.zeros_like(b)
+        K.conv_bwd_weight(g, x, dy, dw4, db4, K.RELU_IN, None, False)
+        assert_close(dw4, wc3.grad, 1e-4, "dw relu")
+        assert_close(db4, bc.grad, 1e-4, "db relu")
     # ---------------- combined backward (one launch on the deep-level shapes): same results as the two calls
     dx3 = K.as_view(K.empty_ndhwc(B, cin, *shape, dev))
     dw3, db3 = torch.zeros_like(w), torch.zeros_like(b)
