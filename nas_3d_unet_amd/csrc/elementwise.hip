@@ -1555,12 +1555,20 @@ __global__ __launch_bounds__(256) void dice_finalize_kernel(const double* __rest
   __shared__ double ratio[256];
   const int t = threadIdx.x;
   double acc = 0;
-  for (int i = t; i < BC; i += 256) {
+  // one wave per (b, c) row: lanes stride over the partial rows (a single thread walking them pays one memory latency per
+  // row: 64 rows at 64^3, 512 at 128^3), fixed-order lane sum
+  const int wave = t >> 6, lane = t & 63;
+  for (int i = wave; i < BC; i += 4) {
     double s[3] = {0, 0, 0};
-    for (int r = 0; r < rows; ++r)
+    for (int r = lane; r < rows; r += 64)
+#pragma unroll
       for (int k = 0; k < 3; ++k) s[k] += partial[((int64_t)i * rows + r) * 3 + k];
-    sums[i * 3] = s[0]; sums[i * 3 + 1] = s[1]; sums[i * 3 + 2] = s[2];
-    acc += (2.0 * s[0] + smooth) / (s[1] + s[2] + smooth);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = wave_sum_d(s[k]);
+    if (lane == 0) {
+      sums[i * 3] = s[0]; sums[i * 3 + 1] = s[1]; sums[i * 3 + 2] = s[2];
+      acc += (2.0 * s[0] + smooth) / (s[1] + s[2] + smooth);
+    }
   }
   ratio[t] = acc;
   __syncthreads();
