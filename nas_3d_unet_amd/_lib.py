@@ -112,6 +112,7 @@ PROTOTYPES = {
     "n3d_conv_bwd_data": (_i, [_gp, _p, _i64, _p, _p, _i64, _i, _p, _i64, _p, _p, _sz, _p]),
     "n3d_conv_bwd_weight": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i, _p, _p, _sz, C.POINTER(FinalJob), _p]),
     "n3d_conv_fwd2": (_i, [C.POINTER(ConvFwdCall), C.POINTER(ConvFwdCall), _p]),
+    "n3d_conv_fwdN": (_i, [C.POINTER(ConvFwdCall), _i, _p]),
     "n3d_conv_bwd_both2": (_i, [C.POINTER(ConvBwdCall), C.POINTER(ConvBwdCall), _p]),
     "n3d_conv_bwd_data2": (_i, [C.POINTER(ConvBwdCall), C.POINTER(ConvBwdCall), _p]),
     "n3d_convT_bwd_both": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i64, _i, _p, _sz, _p, _i, _p, _sz, C.POINTER(FinalJob), _p]),

@@ -1183,6 +1183,9 @@ struct BwdOne {  // one conv's backward operands for the quad launch (same layou
   float* partial; float* pbias; size_t avail; int nch, ntl;
 };
 int mfma_bwd_quad_try(BwdOne* c0, BwdOne* c1, hipStream_t s);
+int mfma_conv_multi_try(int n, const n3d_conv_geom* const* g, const bool* dg, const float* const* src, const int64_t* sld, const float* const* w,
+                        const float* const* bias, float* const* dst, const int64_t* dld, const int* flags, const float* const* gate,
+                        double* const* stats, void* const* ws, const size_t* wsb, hipStream_t s);
 int mfma_conv_pair_try(const n3d_conv_geom* g0, bool dg0, const float* src0, int64_t sld0, const float* w0, const float* bias0, float* dst0,
                        int64_t dld0, int flags0, const float* gate0, double* stats0, void* ws0, size_t wsb0, const n3d_conv_geom* g1, bool dg1,
                        const float* src1, int64_t sld1, const float* w1, const float* bias1, float* dst1, int64_t dld1, int flags1,
@@ -1593,6 +1596,39 @@ int n3d_conv_fwd2(const n3d_conv_fwd_call* c0, const n3d_conv_fwd_call* c1, void
   }
   for (int i = 0; i < 2; ++i) {
     const n3d_conv_fwd_call* c = cs[i];
+    const int e = c->transposed ? n3d_convT_fwd(c->g, c->x, c->xld, c->w, c->bias, c->y, c->yld, c->flags, c->in_gate, c->stats, c->ws, c->ws_bytes, stream)
+                                : n3d_conv_fwd(c->g, c->x, c->xld, c->w, c->bias, c->y, c->yld, c->flags, c->in_gate, c->stats, c->ws, c->ws_bytes, stream);
+    if (e) return e;
+  }
+  return N3D_OK;
+}
+
+int n3d_conv_fwdN(const n3d_conv_fwd_call* calls, int n, void* stream) {
+  N3D_CHECK_ARG(calls && n >= 1 && n <= 4, "conv_fwdN: 1..4 calls");
+  if (n >= 3) {
+    const n3d_conv_geom* g[4]; bool dg[4]; const float* src[4]; int64_t sld[4]; const float* w[4]; const float* bias[4]; float* dst[4];
+    int64_t dld[4]; int flags[4]; const float* gate[4]; double* stats[4]; void* ws[4]; size_t wsb[4];
+    bool mf = true;
+    for (int i = 0; i < n; ++i) {
+      const n3d_conv_fwd_call* c = &calls[i];
+      N3D_CHECK_ARG(c->g && c->x && c->w && c->y, "conv_fwdN: null pointers");
+      if (int e = check_geom(c->g, "conv_fwdN")) return e;
+      mf = mf && !(c->flags & N3D_NO_MFMA) && !c->g->depthwise;
+      g[i] = c->g; dg[i] = c->transposed != 0; src[i] = c->x; sld[i] = c->xld; w[i] = c->w; bias[i] = c->bias; dst[i] = c->y; dld[i] = c->yld;
+      flags[i] = c->flags; gate[i] = c->in_gate; stats[i] = c->stats; ws[i] = c->ws; wsb[i] = c->ws_bytes;
+    }
+    if (mf) {
+      const int r = mfma_conv_multi_try(n, g, dg, src, sld, w, bias, dst, dld, flags, gate, stats, ws, wsb, (hipStream_t)stream);
+      if (r < 0) return r;
+      if (r == 1) return N3D_OK;
+    }
+  }
+  // two at a time (one launch each where foldable), a leftover alone
+  int i = 0;
+  for (; i + 1 < n; i += 2)
+    if (int e = n3d_conv_fwd2(&calls[i], &calls[i + 1], stream)) return e;
+  if (i < n) {
+    const n3d_conv_fwd_call* c = &calls[i];
     const int e = c->transposed ? n3d_convT_fwd(c->g, c->x, c->xld, c->w, c->bias, c->y, c->yld, c->flags, c->in_gate, c->stats, c->ws, c->ws_bytes, stream)
                                 : n3d_conv_fwd(c->g, c->x, c->xld, c->w, c->bias, c->y, c->yld, c->flags, c->in_gate, c->stats, c->ws, c->ws_bytes, stream);
     if (e) return e;

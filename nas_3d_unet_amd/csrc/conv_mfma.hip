@@ -436,6 +436,26 @@ __global__ __launch_bounds__(KS == 16 ? 1024 : 256, KS == 16 ? 4 : 2) void conv_
   else gemm16_body<1, 1, KS>(q.a1, (L - q.n0) % q.gx1, (L - q.n0) / q.gx1, lds);
 }
 
+// up to four independent small convs in one launch (the plain-conv primitives of a supernet node, cell.py:76-81): the
+// descriptor of the workgroup's conv is copied out of the kernel arguments by a switch (static indexing), one body
+struct MultiArgs { MfArgs a[4]; int start[5]; int gx[4]; };
+
+template <int KS>
+__global__ __launch_bounds__(KS == 16 ? 1024 : 256, KS == 16 ? 4 : 2) void conv_gemm16_multi_kernel(MultiArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int L = blockIdx.x;
+  const int k = (L >= q.start[1]) + (L >= q.start[2]) + (L >= q.start[3]);
+  MfArgs a;
+  int s0, gx;
+  switch (k) {
+    case 0: a = q.a[0]; s0 = q.start[0]; gx = q.gx[0]; break;
+    case 1: a = q.a[1]; s0 = q.start[1]; gx = q.gx[1]; break;
+    case 2: a = q.a[2]; s0 = q.start[2]; gx = q.gx[2]; break;
+    default: a = q.a[3]; s0 = q.start[3]; gx = q.gx[3]; break;
+  }
+  gemm16_body<1, 1, KS>(a, (L - s0) % gx, (L - s0) / gx, lds);
+}
+
 struct QuadArgs { DualArgs q0, q1; int n0; };
 
 template <int KS>
@@ -1864,6 +1884,44 @@ int mfma_conv_pair_try(const n3d_conv_geom* g0, bool dg0, const float* src0, int
   else hipLaunchKernelGGL(conv_gemm16_pair_kernel<4>, dim3((unsigned)(q.n0 + n1)), dim3(256), shm, s, q);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("conv(pair) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+  return 1;
+}
+
+// n = 3 or 4 forward-type convs (no data-gradient extras) in one launch; 1 = launched, 0 = not foldable (nothing touched)
+int mfma_conv_multi_try(int n, const n3d_conv_geom* const* g, const bool* dg, const float* const* src, const int64_t* sld, const float* const* w,
+                        const float* const* bias, float* const* dst, const int64_t* dld, const int* flags, const float* const* gate,
+                        double* const* stats, void* const* ws, const size_t* wsb, hipStream_t s) {
+  if (n < 3 || n > 4) return 0;
+  int ksplit = 0;
+  for (int i = 0; i < n; ++i) {
+    if (vx_plan(g[i]).ok) return 0;
+    const G16Plan p = g16_plan(g[i], dg[i]);
+    if (!p.ok || p.ksplit == 1 || (i > 0 && p.ksplit != ksplit)) return 0;
+    ksplit = p.ksplit;
+    if (sld[i] % 4 != 0 || !aligned16(src[i])) return 0;
+  }
+  MultiArgs q;
+  int total = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (i < n) {
+      G16Plan t;
+      const int r = g16_prepare(g[i], dg[i], src[i], sld[i], w[i], bias[i], dst[i], dld[i], flags[i], gate[i], nullptr, 0, nullptr, stats[i],
+                                ws[i], wsb[i], s, &q.a[i], &t);
+      if (r <= 0) return r < 0 ? r : N3D_ERR_INVALID;
+      const int64_t M = (int64_t)g[i]->B * q.a[i].Dd * q.a[i].Hd * q.a[i].Wd;
+      q.gx[i] = (int)cdiv(M, 16);
+      q.start[i] = total;
+      total += q.gx[i] * (q.a[i].Cd / 16);
+    } else {
+      q.a[i] = q.a[0]; q.gx[i] = 1; q.start[i] = 0x7fffffff;   // never selected
+    }
+  }
+  q.start[4] = total;
+  const size_t shm = (size_t)(ksplit - 1) * 256 * sizeof(float) + (size_t)16 * 16 * 2 * sizeof(double);
+  if (ksplit == 16) hipLaunchKernelGGL(conv_gemm16_multi_kernel<16>, dim3((unsigned)total), dim3(1024), shm, s, q);
+  else hipLaunchKernelGGL(conv_gemm16_multi_kernel<4>, dim3((unsigned)total), dim3(256), shm, s, q);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("conv(multi) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
   return 1;
 }
 

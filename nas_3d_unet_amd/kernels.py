@@ -280,6 +280,19 @@ def conv_fwd2(calls):
     check(_lib.load().n3d_conv_fwd2(C.byref(cs[0]), C.byref(cs[1]), stream_ptr()), "n3d_conv_fwd2")
 
 
+def conv_fwdN(calls):
+    """Up to four forward convs, as few launches as libn3d can fold them into.  calls as conv_fwd2."""
+    n = len(calls)
+    arr = (ConvFwdCall * n)()
+    keep = []
+    for i, (g, x, w, bias, y, flags, in_gate, stats, transposed) in enumerate(calls):
+        ws, wsp, nb, flags = _packed(w, g, transposed, flags, x.t.device)
+        keep.append((ws, g))
+        arr[i] = ConvFwdCall(C.pointer(g), 1 if transposed else 0, flags, x.p.value, x.ld, w.data_ptr(), _vp(bias), y.p.value, y.ld,
+                             _vp(in_gate), _vp(stats), wsp.value if hasattr(wsp, "value") else wsp, nb)
+    check(_lib.load().n3d_conv_fwdN(arr, n, stream_ptr()), "n3d_conv_fwdN")
+
+
 def conv_bwd_both2(calls):
     """Backward (data + weight gradient) of two convs, one launch where libn3d can fold them.
     calls = [(g, x, dy, w, dx, dw, dbias, flags_data, relu_src, out_gate, flags_weight, in_gate, transposed)] * 2"""

@@ -749,14 +749,18 @@ def group_forward(terms, out, accumulate):
     i = 0
     while i < len(terms):
         if i + 1 < len(terms) and isinstance(terms[i][0].weight, DenseConvW) and isinstance(terms[i + 1][0].weight, DenseConvW):
+            # a run of plain convs: up to four per launch
+            j = i
+            while j < len(terms) and j < i + 4 and isinstance(terms[j][0].weight, DenseConvW):
+                j += 1
             calls, rr = [], []
-            for seg, x, _, _ in terms[i:i + 2]:
+            for seg, x, _, _ in terms[i:j]:
                 call, r = seg.weight.fwd_prepare(x, seg.relu_in, None, seg.norm is not None)
                 calls.append(call)
                 rr.append(list(r))
-            K.conv_fwd2(calls)
+            K.conv_fwdN(calls)
             res.extend(rr)
-            i += 2
+            i = j
         elif i + 1 < len(terms) and isinstance(terms[i][0].weight, DepthSepW) and isinstance(terms[i + 1][0].weight, DepthSepW):
             # a run of depthwise-separable primitives: all depthwise stages in one launch, the 1x1x1 convs two per launch
             j = i

@@ -268,3 +268,34 @@ def test_conv_pairs_match_single_calls(specA, specB):
     K.conv_bwd_data2(pair)
     for c, t1 in zip(pair, single):
         assert_close(c[3].t, t1.t.cpu().numpy(), 1e-6, "dx (data-gradient pair)")
+
+
+@pytest.mark.parametrize("specs", [
+    [(64, 64, 3, 1, 1, (4, 4, 4)), (64, 64, 3, 1, 2, (4, 4, 4)), (64, 64, 3, 1, 1, (4, 4, 4)), (64, 64, 3, 1, 2, (4, 4, 4))],   # one launch
+    [(32, 32, 3, 1, 1, (8, 8, 8)), (32, 32, 3, 1, 2, (8, 8, 8)), (32, 32, 3, 2, 1, (16, 16, 16))],                            # three
+    [(16, 16, 3, 1, 1, (16, 16, 16)), (8, 8, 3, 1, 1, (8, 8, 16)), (64, 64, 3, 1, 1, (4, 4, 4))],                             # not foldable
+])
+def test_conv_fwdN_matches_torch(specs):
+    """n3d_conv_fwdN (up to four forward convs, as few launches as they fold into) against torch CPU, statistics included"""
+    from nas_3d_unet_amd import kernels as K
+    from nas_3d_unet_amd.prim_ops import _padding
+    dev = torch.device("cuda")
+    B = 2
+    calls, refs, outs = [], [], []
+    for si, (cin, cout, k, stride, dil, shape) in enumerate(specs):
+        pad = _padding(k, stride, dil)
+        xn, wn, bn = _mk((B, cin) + shape, 50 + si), _mk((cout, cin, k, k, k), 60 + si, 1.0 / np.sqrt(cin * k ** 3)), _mk((cout,), 70 + si, 0.1)
+        yc = F.conv3d(torch.from_numpy(xn), torch.from_numpy(wn), torch.from_numpy(bn), stride=stride, padding=pad, dilation=dil)
+        g = K.conv_geom(B, shape[0], shape[1], shape[2], cin, cout, k, stride, dil, pad)
+        x = K.as_view(torch.from_numpy(xn).to(dev))
+        y = K.as_view(K.empty_ndhwc(B, cout, yc.shape[2], yc.shape[3], yc.shape[4], dev))
+        rows = K.conv_stats_rows(g, False)
+        stats = torch.zeros((B, rows, cout, 2), dtype=torch.float64, device=dev) if rows > 0 else None
+        calls.append((g, x, torch.from_numpy(wn).to(dev), torch.from_numpy(bn).to(dev), y, 0, None, stats, False))
+        refs.append(yc)
+        outs.append((y, stats))
+    K.conv_fwdN(calls)
+    for yc, (y, stats) in zip(refs, outs):
+        assert_close(y.t, yc, 2e-5, "y (fwdN)")
+        if stats is not None:
+            assert_close(stats.sum(dim=1).cpu().numpy()[..., 0], yc.double().sum(dim=(2, 3, 4)).numpy(), 1e-5, "stats (fwdN)")
