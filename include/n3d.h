@@ -176,6 +176,8 @@ int n3d_convT_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, co
  * n3d_channel_stats: stats[b][row][c] = partial (sum x, sum x^2) over the N voxels (GroupNorm of a tensor
  *   that no conv of ours produced: IdentityOp prim_ops.py:170-174; SE mean prim_ops.py:149). */
 int n3d_channel_stats(const float* x, int64_t ld, int B, int64_t N, int C, double* stats, void* stream);
+/* the same for up to N3D_MAX_GROUP_TERMS tensors of one (B, N, C) shape in one launch: xs / lds / stats are host arrays of n entries */
+int n3d_channel_statsN(const float* const* xs, const int64_t* lds, double* const* stats, int n, int B, int64_t N, int C, void* stream);
 /* GroupNorm(G, C) statistics -> per-(b,c) affine y = a*x + b; mean_rstd[b][g] = (mean, rstd) (prim_ops.py:56-58) */
 int n3d_gn_coeffs(const double* stats, int rows, const float* gamma, const float* beta, int B, int C, int G,
                   int64_t N, float eps, float* a, float* b, float* mean_rstd, double* sumraw /* [B][C] or NULL */,

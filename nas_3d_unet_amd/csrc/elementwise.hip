@@ -44,8 +44,8 @@ __device__ __forceinline__ void block_reduce_to_row(double (&vals)[NV * 4], int 
 // ------------------------------------------------------------------------------------------------
 // channel statistics
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, int64_t ld, int64_t N, int C,
-                                                            EwMap m, double* __restrict__ stats) {
+__device__ __forceinline__ void channel_stats_body(const float* __restrict__ x, int64_t ld, int64_t N, int C, const EwMap& m,
+                                                   double* __restrict__ stats) {
   __shared__ double lds[4 * 64 * 8];
   const int b = blockIdx.y;
   const int t = threadIdx.x;
@@ -69,6 +69,22 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
   for (int j = 0; j < 4; ++j) { vals[j] = s[j]; vals[4 + j] = ss[j]; }
   double* row = stats + ((int64_t)b * gridDim.x + blockIdx.x) * C * 2;
   block_reduce_to_row<2>(vals, m.cpb, row, lds);
+}
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, int64_t ld, int64_t N, int C,
+                                                            EwMap m, double* __restrict__ stats) {
+  channel_stats_body(x, ld, N, C, m, stats);
+}
+// up to 8 tensors of one shape in one launch (grid.z = tensor): the inputs of a supernet node's primitives
+struct StatsJobN { const float* x[8]; int64_t ld[8]; double* stats[8]; };
+__global__ __launch_bounds__(256) void channel_statsN_kernel(StatsJobN js, int64_t N, int C, EwMap m) {
+  const float* x; int64_t ld; double* st;
+  switch (blockIdx.z) {
+    case 0: x = js.x[0]; ld = js.ld[0]; st = js.stats[0]; break; case 1: x = js.x[1]; ld = js.ld[1]; st = js.stats[1]; break;
+    case 2: x = js.x[2]; ld = js.ld[2]; st = js.stats[2]; break; case 3: x = js.x[3]; ld = js.ld[3]; st = js.stats[3]; break;
+    case 4: x = js.x[4]; ld = js.ld[4]; st = js.stats[4]; break; case 5: x = js.x[5]; ld = js.ld[5]; st = js.stats[5]; break;
+    case 6: x = js.x[6]; ld = js.ld[6]; st = js.stats[6]; break; default: x = js.x[7]; ld = js.ld[7]; st = js.stats[7]; break;
+  }
+  channel_stats_body(x, ld, N, C, m, st);
 }
 
 // sum partial rows: out[q] for q < ncol, executed by a whole 256-thread block; result in lds_out
@@ -1669,6 +1685,21 @@ int n3d_channel_stats(const float* x, int64_t ld, int B, int64_t N, int C, doubl
   if (int e = check_vec(x, ld, C, "channel_stats")) return e;
   EwMap m = ew_map(N, C);
   hipLaunchKernelGGL(channel_stats_kernel, dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, x, ld, N, C, m, stats);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_channel_statsN(const float* const* xs, const int64_t* lds, double* const* stats, int n, int B, int64_t N, int C, void* stream) {
+  N3D_CHECK_ARG(xs && lds && stats && n >= 1 && n <= 8 && B > 0 && N > 0, "channel_statsN: bad args");
+  StatsJobN js;
+  for (int i = 0; i < 8; ++i) {
+    const int k = i < n ? i : 0;
+    N3D_CHECK_ARG(xs[k] && stats[k], "channel_statsN: null pointers");
+    if (int e = check_vec(xs[k], lds[k], C, "channel_statsN(x)")) return e;
+    js.x[i] = xs[k]; js.ld[i] = lds[k]; js.stats[i] = stats[k];
+  }
+  EwMap m = ew_map(N, C);
+  hipLaunchKernelGGL(channel_statsN_kernel, dim3(m.rows, B, n), dim3(256), 0, (hipStream_t)stream, js, N, C, m);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

@@ -394,6 +394,41 @@ def channel_stats(x: View):
     return _channel_stats(x)
 
 
+def channel_statsN(xs):
+    """channel_stats of several tensors (cache honoured); the ones still missing that share a shape go out in one launch"""
+    out = [None] * len(xs)
+    todo = {}
+    for i, x in enumerate(xs):
+        key = (x.p.value, x.ld, x.B, x.C, x.N)
+        hit = _stats_cache.get(key) if _stats_cache is not None else None
+        if hit is not None:
+            out[i] = hit[0]
+        else:
+            todo.setdefault((x.B, x.C, x.N), {}).setdefault(key, []).append(i)
+    for (B, Cc, N), keys in todo.items():
+        group = list(keys.items())
+        for g0 in range(0, len(group), 8):
+            chunk = group[g0:g0 + 8]
+            views = [xs[idx[0]] for _, idx in chunk]
+            if len(chunk) == 1:
+                res = [_channel_stats(views[0])]
+            else:
+                rows = stats_rows(N, Cc)
+                st = torch.empty((len(chunk), B, rows, Cc, 2), dtype=torch.float64, device=views[0].t.device)
+                n = len(chunk)
+                xp = (C.c_void_p * n)(*[v.p.value for v in views])
+                lp = (C.c_int64 * n)(*[v.ld for v in views])
+                sp = (C.c_void_p * n)(*[st[k].data_ptr() for k in range(n)])
+                check(_lib.load().n3d_channel_statsN(xp, lp, sp, n, B, N, Cc, stream_ptr()), "n3d_channel_statsN")
+                res = [(st[k], rows) for k in range(n)]
+            for (key, idx), r, v in zip(chunk, res, views):
+                if _stats_cache is not None:
+                    _stats_cache[key] = (r, v.t)
+                for i in idx:
+                    out[i] = r
+    return out
+
+
 def _channel_stats(x: View):
     rows = stats_rows(x.N, x.C)
     st = torch.empty((x.B, rows, x.C, 2), dtype=torch.float64, device=x.t.device)

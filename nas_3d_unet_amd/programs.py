@@ -780,6 +780,10 @@ def group_forward(terms, out, accumulate):
             seg, x, _, _ = terms[i]
             res.append(list(seg.weight.fwd(x, seg.relu_in, None, seg.norm is not None and seg.weight.produces_stats)))
             i += 1
+    # the channel statistics still missing (conv outputs whose kernel emitted none, GroupNorm / SE-gate inputs) in one launch
+    need = [r[0] for r, (seg, _, _, _) in zip(res, terms) if (seg.norm is not None and r[1] is None) or (seg.norm is None and seg.se_gate is not None)]
+    if len(need) >= 2:
+        K.channel_statsN(need)   # fills the statistics cache; the per-term calls below hit it
     saved, gn, se = [], [], []
     for r, (seg, _, _, _) in zip(res, terms):
         s = Saved()
