@@ -463,25 +463,36 @@ class SEConvW(WeightProgram):
     def out_shape(self, x):
         return self.conv.out_shape(x)
 
+    def fwd_prepare(self, x, gate3, want_stats):
+        """everything of fwd() but the gate and the conv launch: gate3 = (mean, hidden, gate) of SEGate.fwd(x) (or of a batched
+        K.se_gate_fwdN).  Returns (call tuple for K.conv_fwd / conv_fwdN, [y, stats, rows, saved])"""
+        mean, hidden, g = gate3
+        u = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+        K.affine_act(x, g, None, None, u, 0)
+        call, (y, stats, rows, cs) = self.conv.fwd_prepare(u, False, None, want_stats)
+        s = Saved()
+        s.x, s.mean, s.hidden, s.gate, s.cs = x, mean, hidden, g, cs
+        return call, [y, stats, rows, s]
+
     def fwd(self, x, relu_in, gate, want_stats):
         if relu_in or gate is not None:
             raise N3DError("SE conv with act-before-weight / dropout is not supported")
-        mean, hidden, g = self.gate.fwd(x)
-        u = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
-        K.affine_act(x, g, None, None, u, 0)
-        y, stats, rows, cs = self.conv.fwd(u, False, None, want_stats)
-        s = Saved()
-        s.x, s.mean, s.hidden, s.gate, s.cs = x, mean, hidden, g, cs
-        return y, stats, rows, s
+        call, r = self.fwd_prepare(x, self.gate.fwd(x), want_stats)
+        g, xx, w, b, y, fl, gt, stats, tr = call
+        K.conv_fwd(g, xx, w, b, y, fl, gt, stats, tr)
+        return tuple(r)
 
-    def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
+    def bwd_tail(self, saved, du, cg, need_dx, dx_out, dx_acc, pre=None):
+        """backward behind the conv: du = d(x * gate).  pre = ((sums, rows) | None, se_gate_bwd outputs | None) when those passes
+        already ran batched.  Returns (dx, grads)"""
         x = saved.x
-        du_t, cg = self.conv.bwd(saved.cs, draw, True, None, False, skip_bias)
-        du = K.as_view(du_t)
-        sums, rows = K.affine_act_bwd_reduce(du, x, None, None, 0)
         fc = self.gate.fc
-        dw1, db1, dw2, db2, A, Bc = K.se_gate_bwd(sums, rows, None, saved.mean, saved.hidden, saved.gate, fc[0].weight,
-                                                  fc[2].weight, x.B, x.C, x.N, None, fc)
+        if pre is not None and pre[1] is not None:
+            dw1, db1, dw2, db2, A, Bc = pre[1]
+        else:
+            sums, rows = pre[0] if pre is not None and pre[0] is not None else K.affine_act_bwd_reduce(du, x, None, None, 0)
+            dw1, db1, dw2, db2, A, Bc = K.se_gate_bwd(sums, rows, None, saved.mean, saved.hidden, saved.gate, fc[0].weight,
+                                                      fc[2].weight, x.B, x.C, x.N, None, fc)
         dx = None
         if need_dx:
             if dx_out is None:
@@ -490,6 +501,10 @@ class SEConvW(WeightProgram):
             K.affine_act_bwd_apply(du, x, None, None, A, Bc, None, dx_out, ACCUMULATE if dx_acc else 0)
             dx = dx_out.t
         return dx, [dw1, db1, dw2, db2] + cg
+
+    def bwd(self, saved, draw, need_dx, dx_out, dx_acc, skip_bias=False):
+        du_t, cg = self.conv.bwd(saved.cs, draw, True, None, False, skip_bias)
+        return self.bwd_tail(saved, K.as_view(du_t), cg, need_dx, dx_out, dx_acc)
 
 
 # =================================================================================================
@@ -682,6 +697,44 @@ def _weight_backward(order):
                     K.conv_bwd_data2([c[0] for c in cands])
                     pre = [(c[1].t, c[2]) for c in cands]
         npre = 2
+        if pre is None and i + 1 < len(order) and isinstance(order[i][0].weight, SEConvW) and isinstance(order[i + 1][0].weight, SEConvW):
+            # a run of stride-2 SE convs: conv backwards two per launch, the gate backwards in one launch
+            j = i
+            while j < len(order) and isinstance(order[j][0].weight, SEConvW):
+                j += 1
+            run = order[i:j]
+            dus, cgs = [None] * len(run), [None] * len(run)
+            k = 0
+            while k < len(run):
+                done = False
+                if k + 1 < len(run):
+                    two = run[k:k + 2]
+                    for kind, fn in (("bwd_call", K.conv_bwd_both2), ("bwd_data_call", K.conv_bwd_data2)):
+                        cands = [getattr(o[0].weight.conv, kind)(o[1].ws.cs, o[2]["draw"], True, None, False, o[3][2] is not None) for o in two]
+                        if all(c is not None for c in cands):
+                            fn([c[0] for c in cands])
+                            for q, c in zip((k, k + 1), cands):
+                                dus[q], cgs[q] = c[1], list(c[2])
+                            done = True
+                            break
+                if done:
+                    k += 2
+                    continue
+                o = run[k]
+                du_t, cg = o[0].weight.conv.bwd(o[1].ws.cs, o[2]["draw"], True, None, False, o[3][2] is not None)
+                dus[k], cgs[k] = K.as_view(du_t), list(cg)
+                k += 1
+            red = [K.affine_act_bwd_reduce(du, o[1].ws.x, None, None, 0) for o, du in zip(run, dus)]
+            x0 = run[0][1].ws.x
+            gpre = [None] * len(run)
+            if len({(o[1].ws.x.B, o[1].ws.x.C, o[1].ws.x.N) for o in run}) == 1:
+                tds = [dict(sums=r[0], rows=r[1], wptr=None, mean=o[1].ws.mean, hidden=o[1].ws.hidden, gate=o[1].ws.gate,
+                            fc=o[0].weight.gate.fc, dalpha_ptr=None) for o, r in zip(run, red)]
+                gpre = K.se_gate_bwdN(tds, x0.N, x0.B, x0.C)
+            pre = []
+            for o, du, cg, r, gp_ in zip(run, dus, cgs, red, gpre):
+                pre.append(o[0].weight.bwd_tail(o[1].ws, du, cg, o[4][0], o[4][1], o[4][2], (r, gp_)))
+            npre = len(run)
         if (pre is None and i + 1 < len(order) and isinstance(order[i][0].weight, DepthSepW)
                 and isinstance(order[i + 1][0].weight, DepthSepW)):
             # a run of depthwise-separable primitives: the 1x1x1 convs' backward two per launch, the depthwise weight gradients
@@ -746,9 +799,34 @@ def group_forward(terms, out, accumulate):
     The weight ops run first (two neighbouring plain convs in one launch), then the coefficients -- all GroupNorm ones in one
     launch, one per SE gate -- and ONE pass over `out` for everything.  Returns the saved states, in term order."""
     res = []
+    # the gates of the stride-2 SE convs of this chunk: their input statistics in one launch, the gates in one launch
+    sec = [k for k, t in enumerate(terms) if isinstance(t[0].weight, SEConvW)]
+    gates = {}
+    if len(sec) >= 2:
+        sts = K.channel_statsN([terms[k][1] for k in sec])
+        x0 = terms[sec[0]][1]
+        if len({(terms[k][1].B, terms[k][1].C, terms[k][1].N) for k in sec}) == 1:
+            for k, g3 in zip(sec, K.se_gate_fwdN([(st, rows, terms[k][0].weight.gate.fc) for k, (st, rows) in zip(sec, sts)], x0.N, x0.B, x0.C)):
+                gates[k] = g3
     i = 0
     while i < len(terms):
-        if i + 1 < len(terms) and isinstance(terms[i][0].weight, DenseConvW) and isinstance(terms[i + 1][0].weight, DenseConvW):
+        if isinstance(terms[i][0].weight, SEConvW) and (i in gates or (i + 1 < len(terms) and isinstance(terms[i + 1][0].weight, SEConvW))):
+            # a run of stride-2 SE convs: x * gate each, then the convs up to four per launch
+            j = i
+            while j < len(terms) and j < i + 4 and isinstance(terms[j][0].weight, SEConvW):
+                j += 1
+            calls = []
+            for k in range(i, j):
+                seg, x, _, _ = terms[k]
+                if seg.relu_in:
+                    raise N3DError("SE conv with act-before-weight is not supported")
+                g3 = gates[k] if k in gates else seg.weight.gate.fwd(x)
+                call, r = seg.weight.fwd_prepare(x, g3, seg.norm is not None)
+                calls.append(call)
+                res.append(r)
+            K.conv_fwdN(calls)
+            i = j
+        elif i + 1 < len(terms) and isinstance(terms[i][0].weight, DenseConvW) and isinstance(terms[i + 1][0].weight, DenseConvW):
             # a run of plain convs: up to four per launch
             j = i
             while j < len(terms) and j < i + 4 and isinstance(terms[j][0].weight, DenseConvW):
