@@ -311,6 +311,12 @@ int n3d_pool2_bwd(const float* dy, int64_t dyld, const float* x, int64_t xld, fl
 /* dx (+)= w * pool^T(dy): the MixedOp weight of a pooling primitive (cell.py:29-32) folded into its backward (wptr NULL = 1) */
 int n3d_pool2_bwd_scaled(const float* dy, int64_t dyld, const float* x, int64_t xld, float* dx, int64_t dxld, int B, int Di, int Hi,
                          int Wi, int C, int flags, const float* wptr, void* stream);
+/* average AND max pooling of one tensor (both primitives sit on every stride-2 edge of a down cell, prim_ops.py:29-30; cell.py:16-22):
+ * forward in one pass over x; backward dx (+)= w_avg * avgpool^T(dy) + w_max * maxpool^T(dy) in one pass over dx */
+int n3d_pool2_fwd_both(const float* x, int64_t xld, float* y_avg, int64_t yald, float* y_max, int64_t ymld, int B, int Di, int Hi, int Wi,
+                       int C, void* stream);
+int n3d_pool2_bwd_both(const float* dy, int64_t dyld, const float* x, int64_t xld, float* dx, int64_t dxld, int B, int Di, int Hi, int Wi,
+                       int C, int flags, const float* w_avg, const float* w_max, void* stream);
 
 /* ---- sigmoid head + Dice loss (nas.py:52, searched.py:93, loss.py:12-14) --------------------------
  * element (b,c,v) of p / t / dp is at  ptr[b*sb + c*sc + v*sv]  (works for NCDHW and NDHWC).

@@ -136,6 +136,8 @@ PROTOTYPES = {
     "n3d_gn_bwd_coeffs2": (_i, [C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i, _i, _i64, _p]),
     "n3d_affine_act_bwd_apply2": (_i, [_p, _i64, _p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _p]),
     "n3d_plain_bwd_coeffsN": (_i, [C.POINTER(PlainCoefTerm), _i, _i, _i, _p]),
+    "n3d_pool2_fwd_both": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _i, _i, _p]),
+    "n3d_pool2_bwd_both": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "n3d_pool2_bwd_scaled": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _i, _i, _i, _p, _p]),
     "n3d_dwconv_batch": (_i, [C.POINTER(DwJob), _i, _p]),
     "n3d_se_gate_fwdN": (_i, [C.POINTER(SeTerm), _i, _i64, _i, _i, _p]),

@@ -1488,6 +1488,85 @@ __global__ __launch_bounds__(256) void pool2_fwd_kernel(const float* __restrict_
   *reinterpret_cast<float4*>(y + ((int64_t)b * Do * Ho * Wo + vo) * yld + c4 * 4) = acc;
 }
 
+// average AND max pooling of one tensor in one pass (a stride-2 edge of a down cell carries both primitives, prim_ops.py:29-30)
+__global__ __launch_bounds__(256) void pool2_fwd_both_kernel(const float* __restrict__ x, int64_t xld, float* __restrict__ ya, int64_t yald,
+                                                             float* __restrict__ ym, int64_t ymld, int Di, int Hi, int Wi, int C) {
+  const int Do = Di / 2, Ho = Hi / 2, Wo = Wi / 2;
+  const int cpb = C / 4;
+  const int64_t total = (int64_t)Do * Ho * Wo * cpb;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int b = blockIdx.y;
+  const int c4 = idx % cpb;
+  int64_t v = idx / cpb;
+  const int wo = v % Wo; v /= Wo;
+  const int ho = v % Ho;
+  const int d_o = v / Ho;
+  const float* xb = x + (int64_t)b * Di * Hi * Wi * xld + c4 * 4;
+  float4 q[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int64_t vi = ((int64_t)(2 * d_o + (k >> 2)) * Hi + (2 * ho + ((k >> 1) & 1))) * Wi + (2 * wo + (k & 1));
+    q[k] = *reinterpret_cast<const float4*>(xb + vi * xld);
+  }
+  float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sm = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {   // same summation / comparison order as the two single kernels
+    sa.x += q[k].x; sa.y += q[k].y; sa.z += q[k].z; sa.w += q[k].w;
+    sm.x = fmaxf(sm.x, q[k].x); sm.y = fmaxf(sm.y, q[k].y); sm.z = fmaxf(sm.z, q[k].z); sm.w = fmaxf(sm.w, q[k].w);
+  }
+  sa.x *= 0.125f; sa.y *= 0.125f; sa.z *= 0.125f; sa.w *= 0.125f;
+  const int64_t vo = (int64_t)b * Do * Ho * Wo + ((int64_t)d_o * Ho + ho) * Wo + wo;
+  *reinterpret_cast<float4*>(ya + vo * yald + c4 * 4) = sa;
+  *reinterpret_cast<float4*>(ym + vo * ymld + c4 * 4) = sm;
+}
+
+// dx (+)= w_avg * avgpool^T(dy) + w_max * maxpool^T(dy): both pooling backwards of an edge in one pass over dx
+template <bool ACC>
+__global__ __launch_bounds__(256) void pool2_bwd_both_kernel(const float* __restrict__ dy, int64_t dyld, const float* __restrict__ x, int64_t xld,
+                                                             float* __restrict__ dx, int64_t dxld, int Di, int Hi, int Wi, int C,
+                                                             const float* __restrict__ wa, const float* __restrict__ wm) {
+  const int Do = Di / 2, Ho = Hi / 2, Wo = Wi / 2;
+  const int cpb = C / 4;
+  const int64_t total = (int64_t)Do * Ho * Wo * cpb;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int b = blockIdx.y;
+  const int c4 = idx % cpb;
+  int64_t v = idx / cpb;
+  const int wo = v % Wo; v /= Wo;
+  const int ho = v % Ho;
+  const int d_o = v / Ho;
+  const int64_t vo = ((int64_t)d_o * Ho + ho) * Wo + wo;
+  const float4 gq = *reinterpret_cast<const float4*>(dy + ((int64_t)b * Do * Ho * Wo + vo) * dyld + c4 * 4);
+  const float sa = (wa ? *wa : 1.0f) * 0.125f, sm = wm ? *wm : 1.0f;
+  const float g[4] = {gq.x, gq.y, gq.z, gq.w};
+  const float* xb = x + (int64_t)b * Di * Hi * Wi * xld + c4 * 4;
+  float* db = dx + (int64_t)b * Di * Hi * Wi * dxld + c4 * 4;
+  int arg[4] = {0, 0, 0, 0};
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  float4 prev[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int64_t vi = ((int64_t)(2 * d_o + (k >> 2)) * Hi + (2 * ho + ((k >> 1) & 1))) * Wi + (2 * wo + (k & 1));
+    const float4 q = *reinterpret_cast<const float4*>(xb + vi * xld);
+    if (ACC) prev[k] = *reinterpret_cast<const float4*>(db + vi * dxld);
+    const float qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (qq[j] > best[j] || qq[j] != qq[j]) { best[j] = qq[j]; arg[j] = k; }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int64_t vi = ((int64_t)(2 * d_o + (k >> 2)) * Hi + (2 * ho + ((k >> 1) & 1))) * Wi + (2 * wo + (k & 1));
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = g[j] * sa + (arg[j] == k ? g[j] * sm : 0.f);
+    if (ACC) { o[0] += prev[k].x; o[1] += prev[k].y; o[2] += prev[k].z; o[3] += prev[k].w; }
+    *reinterpret_cast<float4*>(db + vi * dxld) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // one thread per OUTPUT voxel quad: routes dy to its 8 inputs (avg: /8; max: first arg-max in
 // (d,h,w) scan order, the choice torch's max_pool3d backward makes)
 template <bool MAX, bool ACC>
@@ -2091,6 +2170,33 @@ int n3d_pool2_fwd(const float* x, int64_t xld, float* y, int64_t yld, int B, int
   dim3 grid((unsigned)cdiv(total, 256), B), blk(256);
   if (flags & N3D_POOL_MAX) hipLaunchKernelGGL((pool2_fwd_kernel<true>), grid, blk, 0, (hipStream_t)stream, x, xld, y, yld, Di, Hi, Wi, C);
   else hipLaunchKernelGGL((pool2_fwd_kernel<false>), grid, blk, 0, (hipStream_t)stream, x, xld, y, yld, Di, Hi, Wi, C);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_pool2_fwd_both(const float* x, int64_t xld, float* y_avg, int64_t yald, float* y_max, int64_t ymld, int B, int Di, int Hi, int Wi, int C,
+                       void* stream) {
+  N3D_CHECK_ARG(x && y_avg && y_max && Di % 2 == 0 && Hi % 2 == 0 && Wi % 2 == 0, "pool2_fwd_both: bad args / odd spatial dims");
+  if (int e = check_vec(x, xld, C, "pool2_fwd_both(x)")) return e;
+  if (int e = check_vec(y_avg, yald, C, "pool2_fwd_both(y_avg)")) return e;
+  if (int e = check_vec(y_max, ymld, C, "pool2_fwd_both(y_max)")) return e;
+  const int64_t total = (int64_t)(Di / 2) * (Hi / 2) * (Wi / 2) * (C / 4);
+  hipLaunchKernelGGL(pool2_fwd_both_kernel, dim3((unsigned)cdiv(total, 256), B), dim3(256), 0, (hipStream_t)stream, x, xld, y_avg, yald, y_max, ymld,
+                     Di, Hi, Wi, C);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_pool2_bwd_both(const float* dy, int64_t dyld, const float* x, int64_t xld, float* dx, int64_t dxld, int B, int Di, int Hi, int Wi, int C,
+                       int flags, const float* w_avg, const float* w_max, void* stream) {
+  N3D_CHECK_ARG(dy && x && dx && Di % 2 == 0 && Hi % 2 == 0 && Wi % 2 == 0, "pool2_bwd_both: bad args / odd spatial dims");
+  if (int e = check_vec(dy, dyld, C, "pool2_bwd_both(dy)")) return e;
+  if (int e = check_vec(dx, dxld, C, "pool2_bwd_both(dx)")) return e;
+  if (int e = check_vec(x, xld, C, "pool2_bwd_both(x)")) return e;
+  const int64_t total = (int64_t)(Di / 2) * (Hi / 2) * (Wi / 2) * (C / 4);
+  dim3 grid((unsigned)cdiv(total, 256), B), blk(256);
+  if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL(pool2_bwd_both_kernel<true>, grid, blk, 0, (hipStream_t)stream, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C, w_avg, w_max);
+  else hipLaunchKernelGGL(pool2_bwd_both_kernel<false>, grid, blk, 0, (hipStream_t)stream, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C, w_avg, w_max);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

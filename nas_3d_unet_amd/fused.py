@@ -326,7 +326,28 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
                         raw = st.saved[chunk[0]].raw
                         for fi, r in zip(chunk, K.se_gate_bwdN(tds, raw.N, raw.B, raw.C)):
                             pre_se[fi] = r
-            for unit in reversed(all_units[node]):
+            rev = list(reversed(all_units[node]))
+            skip = set()
+            for ui, unit in enumerate(rev):
+                if ui in skip:
+                    continue
+                # the average and the max pooling of one edge (two single units next to each other): one pass over the input gradient
+                if len(unit) == 1 and ui + 1 < len(rev) and len(rev[ui + 1]) == 1:
+                    fb, fa = unit[0], rev[ui + 1][0]      # fb later in forward order
+                    (_, ia, sega, cola, amata, rowa), (_, ib, segb, colb, amatb, rowb) = flat[fa], flat[fb]
+                    if (isinstance(sega.weight, P.PoolW) and isinstance(segb.weight, P.PoolW) and ia == ib and sega.weight.is_max != segb.weight.is_max
+                            and not (sega.relu_out or segb.relu_out)):
+                        wps = {}
+                        for fi, seg, col, amat, row in ((fa, sega, cola, amata, rowa), (fb, segb, colb, amatb, rowb)):
+                            arow, dal = alpha_of(amat, row)
+                            if dal is not None and fi not in pre_da:
+                                sums, rows = pre[fi] if fi in pre else K.affine_act_bwd_reduce(dnodes[node], st.saved[fi].raw, None, None, 0)
+                                K.plain_bwd_coeffs(sums, rows, None, st.saved[fi].raw.B, st.saved[fi].raw.C, dev, dal.data_ptr() + 4 * col, want_A=False)
+                            wps[seg.weight.is_max] = P._wptr(arow, col)
+                        target, acc = tgt(ia)
+                        K.pool2_bwd_both(dnodes[node], st.saved[fa].ws.x, target, acc, wps[False], wps[True])
+                        skip.add(ui + 1)
+                        continue
                 if len(unit) >= 3:
                     # targets are claimed in reverse term order, like the unpaired reverse walk
                     terms = []

@@ -783,6 +783,17 @@ def pool2_bwd(dy: View, x: View, dx: View, is_max, accumulate=False, wptr=None):
           "n3d_pool2_bwd_scaled")
 
 
+def pool2_fwd_both(x: View, y_avg: View, y_max: View):
+    check(_lib.load().n3d_pool2_fwd_both(x.p, x.ld, y_avg.p, y_avg.ld, y_max.p, y_max.ld, x.B, x.D, x.H, x.W, x.C, stream_ptr()),
+          "n3d_pool2_fwd_both")
+
+
+def pool2_bwd_both(dy: View, x: View, dx: View, accumulate, w_avg=None, w_max=None):
+    """dx (+)= w_avg * avgpool^T(dy) + w_max * maxpool^T(dy); w_*: device scalar pointers or None = 1"""
+    check(_lib.load().n3d_pool2_bwd_both(dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.B, x.D, x.H, x.W, x.C, ACCUMULATE if accumulate else 0,
+                                         w_avg, w_max, stream_ptr()), "n3d_pool2_bwd_both")
+
+
 def plain_dalphaN(terms, B, Cc):
     """dalpha = <dout, z> of up to 8 un-normalised primitives from their reduction rows, one launch:
     terms = [(sums, rows, dalpha_ptr)]"""

@@ -826,6 +826,21 @@ def group_forward(terms, out, accumulate):
                 res.append(r)
             K.conv_fwdN(calls)
             i = j
+        elif (i + 1 < len(terms) and isinstance(terms[i][0].weight, PoolW) and isinstance(terms[i + 1][0].weight, PoolW)
+              and terms[i][0].weight.is_max != terms[i + 1][0].weight.is_max and terms[i][1].p.value == terms[i + 1][1].p.value
+              and not (terms[i][0].relu_in or terms[i + 1][0].relu_in)):
+            # the average and the max pooling of one edge: one pass over the input
+            x = terms[i][1]
+            if x.D % 2 or x.H % 2 or x.W % 2:
+                raise N3DError("pool2: spatial dims must be even, got %s" % ((x.D, x.H, x.W),))
+            ys = [K.as_view(K.empty_ndhwc(x.B, x.C, x.D // 2, x.H // 2, x.W // 2, x.t.device)) for _ in range(2)]
+            a_first = not terms[i][0].weight.is_max
+            K.pool2_fwd_both(x, ys[0] if a_first else ys[1], ys[1] if a_first else ys[0])
+            for y in ys:
+                ws = Saved()
+                ws.x = x
+                res.append([y, None, 0, ws])
+            i += 2
         elif i + 1 < len(terms) and isinstance(terms[i][0].weight, DenseConvW) and isinstance(terms[i + 1][0].weight, DenseConvW):
             # a run of plain convs: up to four per launch
             j = i
