@@ -1193,6 +1193,145 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Whole GroupNorm-epilogue backward of a searched-cell node on the small levels (<= 2048 channel quads per group) in ONE
+// launch: reduction pass, coefficient math and d(raw) pass of BOTH terms, one workgroup per GroupNorm group, every element
+// held in registers between the passes (the reduce2 + apply_gn2 pair re-reads all three tensors and pays two launches).
+// Thread t owns the quads e = t + i*1024 (i < QPT) of the group's [B][N][cg/4] quads; samples start on wave boundaries
+// (N * cg/4 a multiple of 64), so a wave-level class sum never mixes samples.  Sums: fp32 per lane and per wave (DPP tree),
+// fp64 across waves in a fixed order, coefficients in fp64 as the two-launch path does.
+// ------------------------------------------------------------------------------------------------
+template <int QPT>
+__global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __restrict__ dout, int64_t dld, GnBwdTerm t0, GnBwdTerm t1, int B,
+                                                            int N, int C, int G, double count) {
+  __shared__ float red[QPT * 16][2][32];   // [slot = i*16 + wave][term][(S1 | S2) x 16 channels]
+  __shared__ double tot[4][2][32];         // [b][term][(S1 | S2) x 16 channels]
+  __shared__ float fco[4][2][2][16];       // forward a | b of (sample, term, channel): staged once, read twice per element
+  __shared__ float coef[4][2][3][16];      // [b][term][A | B | C][channel]
+  __shared__ double contrib[4][2][3][16];  // [b][term][dgamma | dbeta | dbias][channel]
+  const int g = blockIdx.x, cg = C / G, cpg4 = cg >> 2;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int per_b = N * cpg4, total = B * per_b;
+  const int q = t % cpg4;                  // the channel quad of every element of this thread
+  const int c0 = g * cg + q * 4;
+  const float thr0 = t0.relu ? 0.f : -INFINITY, thr1 = t1.relu ? 0.f : -INFINITY;
+  if (t < B * 2 * 2 * 16) {
+    const int b = t >> 6, k = (t >> 5) & 1, ab = (t >> 4) & 1, c = t & 15;
+    const GnBwdTerm& tm = k ? t1 : t0;
+    fco[b][k][ab][c] = c < cg ? (ab ? tm.b : tm.a)[b * C + g * cg + c] : 0.f;
+  }
+  float4 d4[QPT], r0[QPT], r1[QPT];
+  bool ok[QPT];
+  int bi[QPT];
+  int64_t vox[QPT];
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const int e = t + i * 1024;
+    ok[i] = e < total;
+    const int ec = ok[i] ? e : 0;
+    bi[i] = ec / per_b;
+    vox[i] = (int64_t)bi[i] * N + (ec - bi[i] * per_b) / cpg4;
+    d4[i] = *reinterpret_cast<const float4*>(dout + vox[i] * dld + c0);
+    r0[i] = *reinterpret_cast<const float4*>(t0.raw + vox[i] * t0.rld + c0);
+    r1[i] = *reinterpret_cast<const float4*>(t1.raw + vox[i] * t1.rld + c0);
+  }
+  __syncthreads();
+  // ---- pass 1: S1 = sum g, S2 = sum g * raw per (sample, channel), g = dout behind the term's ReLU mask
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const float d[4] = {d4[i].x, d4[i].y, d4[i].z, d4[i].w};
+    const float ra[2][4] = {{r0[i].x, r0[i].y, r0[i].z, r0[i].w}, {r1[i].x, r1[i].y, r1[i].z, r1[i].w}};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float thr = k ? thr1 : thr0;
+      const float4 fa = *reinterpret_cast<const float4*>(&fco[bi[i]][k][0][q * 4]), fb = *reinterpret_cast<const float4*>(&fco[bi[i]][k][1][q * 4]);
+      const float aa[4] = {fa.x, fa.y, fa.z, fa.w}, bb[4] = {fb.x, fb.y, fb.z, fb.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float z = fmaf(aa[j], ra[k][j], bb[j]);
+        const float gm = (ok[i] && z > thr) ? d[j] : 0.f;
+        const float s1 = wave_classsum_f(gm, cpg4), s2 = wave_classsum_f(gm * ra[k][j], cpg4);
+        if (lane < cpg4) { red[i * 16 + wave][k][q * 4 + j] = s1; red[i * 16 + wave][k][16 + q * 4 + j] = s2; }
+      }
+    }
+  }
+  __syncthreads();
+  // fixed-order sum of the wave slots of each sample: slot s covers the quads [64 s, 64 s + 64), a sample per_b / 64 of them
+  if (t < B * 2 * 32) {
+    const int b = t >> 6, k = (t >> 5) & 1, idx = t & 31;
+    double s = 0;
+    if ((idx & 15) < cg) {
+      const int spb = per_b >> 6, s0 = b * spb;
+      for (int sl = s0; sl < s0 + spb; ++sl) s += (double)red[sl][k][idx];
+    }
+    tot[b][k][idx] = s;
+  }
+  __syncthreads();
+  // ---- coefficients of d(raw) = A * g + B + C * raw and the per-sample parameter-gradient contributions
+  if (t < B * 2 * 16) {
+    const int b = t >> 5, k = (t >> 4) & 1, c = t & 15;
+    if (c < cg) {
+      const GnBwdTerm& tm = k ? t1 : t0;
+      const double w = tm.wptr ? (double)*tm.wptr : 1.0;
+      const double mn = tm.mean_rstd[(b * G + g) * 2], rsd = tm.mean_rstd[(b * G + g) * 2 + 1];
+      double c1 = 0, c2 = 0;
+      for (int cc = 0; cc < cg; ++cc) {
+        const double gm = (double)tm.gamma[g * cg + cc];
+        const double S1 = tot[b][k][cc], S2 = tot[b][k][16 + cc];
+        c1 += gm * w * S1;
+        c2 += gm * w * rsd * (S2 - mn * S1);
+      }
+      const double n = count * cg;
+      c1 /= n; c2 /= n;
+      const double gam = (double)tm.gamma[g * cg + c];
+      const double S1 = tot[b][k][c], S2 = tot[b][k][16 + c];
+      const double Av = rsd * gam * w, Bv = -rsd * c1 + rsd * rsd * c2 * mn, Cv = -rsd * rsd * c2;
+      coef[b][k][0][c] = (float)Av; coef[b][k][1][c] = (float)Bv; coef[b][k][2][c] = (float)Cv;
+      contrib[b][k][0][c] = w * rsd * (S2 - mn * S1);
+      contrib[b][k][1][c] = w * S1;
+      contrib[b][k][2][c] = tm.dbias_conv ? Av * S1 + count * Bv + Cv * tm.sumraw[b * C + g * cg + c] : 0.0;
+    }
+  }
+  __syncthreads();
+  // ---- pass 2: d(raw) of both terms from the registers
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    if (!ok[i]) continue;
+    const float d[4] = {d4[i].x, d4[i].y, d4[i].z, d4[i].w};
+    const float ra[2][4] = {{r0[i].x, r0[i].y, r0[i].z, r0[i].w}, {r1[i].x, r1[i].y, r1[i].z, r1[i].w}};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float thr = k ? thr1 : thr0;
+      const float4 fa = *reinterpret_cast<const float4*>(&fco[bi[i]][k][0][q * 4]), fb = *reinterpret_cast<const float4*>(&fco[bi[i]][k][1][q * 4]);
+      const float4 qA = *reinterpret_cast<const float4*>(&coef[bi[i]][k][0][q * 4]), qB = *reinterpret_cast<const float4*>(&coef[bi[i]][k][1][q * 4]),
+                   qC = *reinterpret_cast<const float4*>(&coef[bi[i]][k][2][q * 4]);
+      const float aa[4] = {fa.x, fa.y, fa.z, fa.w}, bb[4] = {fb.x, fb.y, fb.z, fb.w};
+      const float A4[4] = {qA.x, qA.y, qA.z, qA.w}, B4[4] = {qB.x, qB.y, qB.z, qB.w}, C4[4] = {qC.x, qC.y, qC.z, qC.w};
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float z = fmaf(aa[j], ra[k][j], bb[j]);
+        const float gm = z > thr ? d[j] : 0.f;
+        o[j] = fmaf(A4[j], gm, fmaf(C4[j], ra[k][j], B4[j]));
+      }
+      float* op = (k ? t1.draw + vox[i] * t1.drld : t0.draw + vox[i] * t0.drld) + c0;
+      *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  // ---- parameter gradients: sums over the samples in sample order
+  if (t < 2 * 16) {
+    const int k = t >> 4, c = t & 15;
+    if (c < cg) {
+      const GnBwdTerm& tm = k ? t1 : t0;
+      double dg = 0, db = 0, dbc = 0;
+      for (int b = 0; b < B; ++b) { dg += contrib[b][k][0][c]; db += contrib[b][k][1][c]; dbc += contrib[b][k][2][c]; }
+      if (tm.dgamma) tm.dgamma[g * cg + c] = (float)dg;
+      if (tm.dbeta) tm.dbeta[g * cg + c] = (float)db;
+      if (tm.dbias_conv) tm.dbias_conv[g * cg + c] = (float)dbc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // N-term epilogues of a supernet node (cell.py:76-81: a node sums 10-22 weighted primitives; 8-16 of them end in a GroupNorm).
 // Coefficients come from gn_coeffsN / gn_bwd_coeffsN.  Forward: ONE pass writes (or accumulates into) the node buffer for up
 // to 8 terms, in term order.  Backward: the per-term reductions and d(raw) passes are independent, so the launch is simply
@@ -1901,6 +2040,42 @@ int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const float* do
   if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_apply_gn2(dout1)")) return e; }
   if (dout1) hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, true>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
   else hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, false>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+// 1 if n3d_affine_act_bwd_small2 takes this shape: the group's quads fit one 1024-thread workgroup two deep, samples start on
+// wave boundaries
+int n3d_bwd_small2_ok(int B, int64_t N, int C, int G) {
+  if (!pair_shape_ok(C, G) || B < 1 || B > 4 || N < 1 || N > 4096) return 0;
+  const int cpg4 = (C / G) / 4;
+  if (cpg4 < 1) return 0;
+  const int64_t per_b = N * cpg4;
+  // two quads per thread at most: four deep (4096 quads) measured slower than the two-launch path (18 vs 16 us)
+  return (per_b % 64 == 0 && (int64_t)B * per_b <= 2048) ? 1 : 0;
+}
+
+int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N, int C,
+                              int G, void* stream) {
+  N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0, "affine_act_bwd_small2: bad args");
+  if (!n3d_bwd_small2_ok(B, N, C, G)) N3D_UNSUPPORTED("affine_act_bwd_small2: shape not supported (B=%d N=%lld C=%d G=%d)", B, (long long)N, C, G);
+  if (int e = check_vec(dout, dld, C, "bwd_small2(dout)")) return e;
+  GnBwdTerm k[2];
+  const n3d_gn_bwd_term* ts[2] = {t0, t1};
+  for (int i = 0; i < 2; ++i) {
+    const n3d_gn_bwd_term* t = ts[i];
+    N3D_CHECK_ARG(t->raw && t->a && t->b && t->gamma && t->mean_rstd && t->draw, "affine_act_bwd_small2: null term pointer");
+    N3D_CHECK_ARG(!t->dalpha, "affine_act_bwd_small2: MixedOp weight gradients are not produced here (use the reduce2 / apply_gn2 pair)");
+    N3D_CHECK_ARG(!t->dbias_conv || t->sumraw, "affine_act_bwd_small2: dbias_conv needs the forward per-channel sums");
+    if (int e = check_vec(t->raw, t->rld, C, "bwd_small2(raw)")) return e;
+    if (int e = check_vec(t->draw, t->drld, C, "bwd_small2(draw)")) return e;
+    k[i] = GnBwdTerm{t->raw, t->rld, t->a, t->b, nullptr, 0, t->gamma, t->mean_rstd, t->wptr, t->sumraw, t->draw, t->drld,
+                     t->dgamma, t->dbeta, nullptr, t->dbias_conv, t->relu, nullptr, nullptr, nullptr};
+  }
+  const int64_t quads = (int64_t)B * N * ((C / G) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (quads <= 1024) hipLaunchKernelGGL(gn_bwd_small2_kernel<1>, dim3(G), dim3(1024), 0, s, dout, dld, k[0], k[1], B, (int)N, C, G, (double)N);
+  else hipLaunchKernelGGL(gn_bwd_small2_kernel<2>, dim3(G), dim3(1024), 0, s, dout, dld, k[0], k[1], B, (int)N, C, G, (double)N);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

@@ -538,12 +538,32 @@ def affine_act_gn2(terms, G, eps, out: View, flags=0, out1: View | None = None):
     return saved
 
 
+SMALL_NODE_BACKWARD = True   # the one-launch epilogue backward of a node on the small levels (n3d_affine_act_bwd_small2)
+
+
 def affine_act_bwd_gn2(dout: View, terms, G, dout1: View | None = None):
     """Backward of affine_act_gn2: terms = [dict(raw, a, b, mr, sumraw, gamma, beta, wptr, relu, conv_bias, draw, dalpha_ptr)] * 2.
     Two launches (reduce, apply) for both ops.  Returns [(dgamma, dbeta, dconv_bias | None)] * 2."""
     raw0 = terms[0]["raw"]
     dev = raw0.t.device
     B, Cc, N = raw0.B, raw0.C, raw0.N
+    lib = _lib.load()
+    if (SMALL_NODE_BACKWARD and dout1 is None and all(t.get("dalpha_ptr") is None for t in terms)
+            and lib.n3d_bwd_small2_ok(B, N, Cc, G)):
+        # small levels: reduction, coefficients, parameter gradients and both d(raw) in ONE launch
+        ts, outs = [], []
+        for t in terms:
+            dgamma, dbeta = grad_target(t["gamma"]), grad_target(t["beta"])
+            cb = t.get("conv_bias")
+            dcb = grad_target(cb) if (cb is not None and t["sumraw"] is not None) else None
+            raw, draw = t["raw"], t["draw"]
+            ts.append(GnBwdTerm(raw.p.value, raw.ld, t["a"].data_ptr(), t["b"].data_ptr(), None, 0, 1 if t["relu"] else 0,
+                                t["gamma"].data_ptr(), t["mr"].data_ptr(), _vp(t.get("wptr")), _vp(t["sumraw"]), draw.p.value, draw.ld,
+                                _vp(dgamma), _vp(dbeta), None, _vp(dcb), None, None, None))
+            outs.append((dgamma, dbeta, dcb))
+        check(lib.n3d_affine_act_bwd_small2(dout.p, dout.ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, G, stream_ptr()),
+              "n3d_affine_act_bwd_small2")
+        return outs
     rows = stats_rows(N, Cc)
     sums = torch.empty((2, B, rows, Cc, 3), dtype=torch.float64, device=dev)
     ts, outs = [], []
