@@ -246,7 +246,7 @@ int n3d_affine_act_bwd_reduce2(const float* dout, int64_t dld, const float* dout
                                const n3d_gn_bwd_term* t1, int B, int64_t N, int C, void* stream);
 int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
                                  const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* stream);
-/* Small levels (n3d_bwd_small2_ok: B <= 4, B * N * (C/G)/4 <= 2048 channel quads per group, N * (C/G)/4 a multiple of 64): the
+/* Small levels (n3d_bwd_small2_ok: B <= 4, B * roundup(N * (C/G)/4, 64) <= 2048 channel quads per group): the
  * whole epilogue backward of a node whose terms carry no MixedOp weight gradient -- reduction, coefficients, parameter
  * gradients and both d(raw) -- in ONE launch, one workgroup per GroupNorm group, elements held in registers between the passes.
  * Same outputs as n3d_affine_act_bwd_reduce2 + n3d_affine_act_bwd_apply_gn2 (sums / dalpha of the terms are not used). */

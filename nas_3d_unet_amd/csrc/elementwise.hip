@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
 // launch: reduction pass, coefficient math and d(raw) pass of BOTH terms, one workgroup per GroupNorm group, every element
 // held in registers between the passes (the reduce2 + apply_gn2 pair re-reads all three tensors and pays two launches).
 // Thread t owns the quads e = t + i*1024 (i < QPT) of the group's [B][N][cg/4] quads; samples start on wave boundaries
-// (N * cg/4 a multiple of 64), so a wave-level class sum never mixes samples.  Sums: fp32 per lane and per wave (DPP tree),
+// (padded with idle lanes where N * cg/4 is not a multiple of 64), so a wave-level class sum never mixes samples.  Sums: fp32 per lane and per wave (DPP tree),
 // fp64 across waves in a fixed order, coefficients in fp64 as the two-launch path does.
 // ------------------------------------------------------------------------------------------------
 template <int QPT>
@@ -1210,7 +1210,8 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __rest
   __shared__ double contrib[4][2][3][16];  // [b][term][dgamma | dbeta | dbias][channel]
   const int g = blockIdx.x, cg = C / G, cpg4 = cg >> 2;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int per_b = N * cpg4, total = B * per_b;
+  // a sample's quads occupy a whole number of waves (padded with idle lanes when N * cg/4 is not a multiple of 64: the 2^3 level)
+  const int real_b = N * cpg4, per_b = (real_b + 63) & ~63, total = B * per_b;
   const int q = t % cpg4;                  // the channel quad of every element of this thread
   const int c0 = g * cg + q * 4;
   const float thr0 = t0.relu ? 0.f : -INFINITY, thr1 = t1.relu ? 0.f : -INFINITY;
@@ -1226,10 +1227,10 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     const int e = t + i * 1024;
-    ok[i] = e < total;
-    const int ec = ok[i] ? e : 0;
-    bi[i] = ec / per_b;
-    vox[i] = (int64_t)bi[i] * N + (ec - bi[i] * per_b) / cpg4;
+    const int eb = e / per_b, er = e - eb * per_b;
+    ok[i] = e < total && er < real_b;
+    bi[i] = ok[i] ? eb : 0;
+    vox[i] = (int64_t)bi[i] * N + (ok[i] ? er : 0) / cpg4;
     d4[i] = *reinterpret_cast<const float4*>(dout + vox[i] * dld + c0);
     r0[i] = *reinterpret_cast<const float4*>(t0.raw + vox[i] * t0.rld + c0);
     r1[i] = *reinterpret_cast<const float4*>(t1.raw + vox[i] * t1.rld + c0);
@@ -2050,9 +2051,9 @@ int n3d_bwd_small2_ok(int B, int64_t N, int C, int G) {
   if (!pair_shape_ok(C, G) || B < 1 || B > 4 || N < 1 || N > 4096) return 0;
   const int cpg4 = (C / G) / 4;
   if (cpg4 < 1) return 0;
-  const int64_t per_b = N * cpg4;
+  const int64_t per_b = (N * cpg4 + 63) / 64 * 64;   // a sample's quads are padded to whole waves
   // two quads per thread at most: four deep (4096 quads) measured slower than the two-launch path (18 vs 16 us)
-  return (per_b % 64 == 0 && (int64_t)B * per_b <= 2048) ? 1 : 0;
+  return ((int64_t)B * per_b <= 2048) ? 1 : 0;
 }
 
 int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N, int C,
@@ -2072,7 +2073,7 @@ int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const n3d_gn_bwd_t
     k[i] = GnBwdTerm{t->raw, t->rld, t->a, t->b, nullptr, 0, t->gamma, t->mean_rstd, t->wptr, t->sumraw, t->draw, t->drld,
                      t->dgamma, t->dbeta, nullptr, t->dbias_conv, t->relu, nullptr, nullptr, nullptr};
   }
-  const int64_t quads = (int64_t)B * N * ((C / G) / 4);
+  const int64_t quads = (int64_t)B * ((N * ((C / G) / 4) + 63) / 64 * 64);
   hipStream_t s = (hipStream_t)stream;
   if (quads <= 1024) hipLaunchKernelGGL(gn_bwd_small2_kernel<1>, dim3(G), dim3(1024), 0, s, dout, dld, k[0], k[1], B, (int)N, C, G, (double)N);
   else hipLaunchKernelGGL(gn_bwd_small2_kernel<2>, dim3(G), dim3(1024), 0, s, dout, dld, k[0], k[1], B, (int)N, C, G, (double)N);
