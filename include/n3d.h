@@ -251,8 +251,8 @@ int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const float* do
  * gradients and both d(raw) -- in ONE launch, one workgroup per GroupNorm group, elements held in registers between the passes.
  * Same outputs as n3d_affine_act_bwd_reduce2 + n3d_affine_act_bwd_apply_gn2 (sums / dalpha of the terms are not used). */
 int n3d_bwd_small2_ok(int B, int64_t N, int C, int G);
-int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N, int C,
-                              int G, void* stream);
+int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const float* dout1 /* as in ..._reduce2 */, int64_t dld1, const n3d_gn_bwd_term* t0,
+                              const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* stream);
 /* the same pairing for tensors with more partial rows than the fused prologues accept (the 32^3 / 64^3 levels):
  * n3d_gn_coeffs2 = two n3d_gn_coeffs in one launch (fills a_out, b_out, mean_rstd_out, sumraw of both terms);
  * n3d_affine_act2 = two n3d_affine_act into one output (reads a_out / b_out as the coefficients; stats unused);

@@ -1200,9 +1200,10 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
 // (padded with idle lanes where N * cg/4 is not a multiple of 64), so a wave-level class sum never mixes samples.  Sums: fp32 per lane and per wave (DPP tree),
 // fp64 across waves in a fixed order, coefficients in fp64 as the two-launch path does.
 // ------------------------------------------------------------------------------------------------
-template <int QPT>
-__global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __restrict__ dout, int64_t dld, GnBwdTerm t0, GnBwdTerm t1, int B,
-                                                            int N, int C, int G, double count) {
+// TWO: term 1 has its own output gradient dout1 (the two preprocess ops of a cell, independent outputs of one shape)
+template <int QPT, bool TWO>
+__global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __restrict__ dout, int64_t dld, const float* __restrict__ dout1,
+                                                            int64_t dld1, GnBwdTerm t0, GnBwdTerm t1, int B, int N, int C, int G, double count) {
   __shared__ float red[QPT * 16][2][32];   // [slot = i*16 + wave][term][(S1 | S2) x 16 channels]
   __shared__ double tot[4][2][32];         // [b][term][(S1 | S2) x 16 channels]
   __shared__ float fco[4][2][2][16];       // forward a | b of (sample, term, channel): staged once, read twice per element
@@ -1220,7 +1221,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __rest
     const GnBwdTerm& tm = k ? t1 : t0;
     fco[b][k][ab][c] = c < cg ? (ab ? tm.b : tm.a)[b * C + g * cg + c] : 0.f;
   }
-  float4 d4[QPT], r0[QPT], r1[QPT];
+  float4 d4[QPT], e4[TWO ? QPT : 1], r0[QPT], r1[QPT];
   bool ok[QPT];
   int bi[QPT];
   int64_t vox[QPT];
@@ -1232,6 +1233,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __rest
     bi[i] = ok[i] ? eb : 0;
     vox[i] = (int64_t)bi[i] * N + (ok[i] ? er : 0) / cpg4;
     d4[i] = *reinterpret_cast<const float4*>(dout + vox[i] * dld + c0);
+    if (TWO) e4[TWO ? i : 0] = *reinterpret_cast<const float4*>(dout1 + vox[i] * dld1 + c0);
     r0[i] = *reinterpret_cast<const float4*>(t0.raw + vox[i] * t0.rld + c0);
     r1[i] = *reinterpret_cast<const float4*>(t1.raw + vox[i] * t1.rld + c0);
   }
@@ -1239,7 +1241,8 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __rest
   // ---- pass 1: S1 = sum g, S2 = sum g * raw per (sample, channel), g = dout behind the term's ReLU mask
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
-    const float d[4] = {d4[i].x, d4[i].y, d4[i].z, d4[i].w};
+    const float4 e4i = TWO ? e4[TWO ? i : 0] : d4[i];
+    const float dd[2][4] = {{d4[i].x, d4[i].y, d4[i].z, d4[i].w}, {e4i.x, e4i.y, e4i.z, e4i.w}};
     const float ra[2][4] = {{r0[i].x, r0[i].y, r0[i].z, r0[i].w}, {r1[i].x, r1[i].y, r1[i].z, r1[i].w}};
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -1249,7 +1252,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float z = fmaf(aa[j], ra[k][j], bb[j]);
-        const float gm = (ok[i] && z > thr) ? d[j] : 0.f;
+        const float gm = (ok[i] && z > thr) ? dd[k][j] : 0.f;
         const float s1 = wave_classsum_f(gm, cpg4), s2 = wave_classsum_f(gm * ra[k][j], cpg4);
         if (lane < cpg4) { red[i * 16 + wave][k][q * 4 + j] = s1; red[i * 16 + wave][k][16 + q * 4 + j] = s2; }
       }
@@ -1297,7 +1300,8 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     if (!ok[i]) continue;
-    const float d[4] = {d4[i].x, d4[i].y, d4[i].z, d4[i].w};
+    const float4 e4i = TWO ? e4[TWO ? i : 0] : d4[i];
+    const float dd[2][4] = {{d4[i].x, d4[i].y, d4[i].z, d4[i].w}, {e4i.x, e4i.y, e4i.z, e4i.w}};
     const float ra[2][4] = {{r0[i].x, r0[i].y, r0[i].z, r0[i].w}, {r1[i].x, r1[i].y, r1[i].z, r1[i].w}};
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -1311,7 +1315,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float z = fmaf(aa[j], ra[k][j], bb[j]);
-        const float gm = z > thr ? d[j] : 0.f;
+        const float gm = z > thr ? dd[k][j] : 0.f;
         o[j] = fmaf(A4[j], gm, fmaf(C4[j], ra[k][j], B4[j]));
       }
       float* op = (k ? t1.draw + vox[i] * t1.drld : t0.draw + vox[i] * t0.drld) + c0;
@@ -2056,9 +2060,10 @@ int n3d_bwd_small2_ok(int B, int64_t N, int C, int G) {
   return ((int64_t)B * per_b <= 2048) ? 1 : 0;
 }
 
-int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int64_t N, int C,
-                              int G, void* stream) {
+int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
+                              const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* stream) {
   N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0, "affine_act_bwd_small2: bad args");
+  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_small2(dout1)")) return e; }
   if (!n3d_bwd_small2_ok(B, N, C, G)) N3D_UNSUPPORTED("affine_act_bwd_small2: shape not supported (B=%d N=%lld C=%d G=%d)", B, (long long)N, C, G);
   if (int e = check_vec(dout, dld, C, "bwd_small2(dout)")) return e;
   GnBwdTerm k[2];
@@ -2075,8 +2080,13 @@ int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const n3d_gn_bwd_t
   }
   const int64_t quads = (int64_t)B * ((N * ((C / G) / 4) + 63) / 64 * 64);
   hipStream_t s = (hipStream_t)stream;
-  if (quads <= 1024) hipLaunchKernelGGL(gn_bwd_small2_kernel<1>, dim3(G), dim3(1024), 0, s, dout, dld, k[0], k[1], B, (int)N, C, G, (double)N);
-  else hipLaunchKernelGGL(gn_bwd_small2_kernel<2>, dim3(G), dim3(1024), 0, s, dout, dld, k[0], k[1], B, (int)N, C, G, (double)N);
+  if (quads <= 1024) {
+    if (dout1) hipLaunchKernelGGL((gn_bwd_small2_kernel<1, true>), dim3(G), dim3(1024), 0, s, dout, dld, dout1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
+    else hipLaunchKernelGGL((gn_bwd_small2_kernel<1, false>), dim3(G), dim3(1024), 0, s, dout, dld, dout1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
+  } else {
+    if (dout1) hipLaunchKernelGGL((gn_bwd_small2_kernel<2, true>), dim3(G), dim3(1024), 0, s, dout, dld, dout1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
+    else hipLaunchKernelGGL((gn_bwd_small2_kernel<2, false>), dim3(G), dim3(1024), 0, s, dout, dld, dout1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
+  }
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

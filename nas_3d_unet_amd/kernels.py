@@ -548,8 +548,7 @@ def affine_act_bwd_gn2(dout: View, terms, G, dout1: View | None = None):
     dev = raw0.t.device
     B, Cc, N = raw0.B, raw0.C, raw0.N
     lib = _lib.load()
-    if (SMALL_NODE_BACKWARD and dout1 is None and all(t.get("dalpha_ptr") is None for t in terms)
-            and lib.n3d_bwd_small2_ok(B, N, Cc, G)):
+    if (SMALL_NODE_BACKWARD and all(t.get("dalpha_ptr") is None for t in terms) and lib.n3d_bwd_small2_ok(B, N, Cc, G)):
         # small levels: reduction, coefficients, parameter gradients and both d(raw) in ONE launch
         ts, outs = [], []
         for t in terms:
@@ -561,7 +560,8 @@ def affine_act_bwd_gn2(dout: View, terms, G, dout1: View | None = None):
                                 t["gamma"].data_ptr(), t["mr"].data_ptr(), _vp(t.get("wptr")), _vp(t["sumraw"]), draw.p.value, draw.ld,
                                 _vp(dgamma), _vp(dbeta), None, _vp(dcb), None, None, None))
             outs.append((dgamma, dbeta, dcb))
-        check(lib.n3d_affine_act_bwd_small2(dout.p, dout.ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, G, stream_ptr()),
+        d1p, d1ld = (dout1.p, dout1.ld) if dout1 is not None else (None, 0)
+        check(lib.n3d_affine_act_bwd_small2(dout.p, dout.ld, d1p, d1ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, G, stream_ptr()),
               "n3d_affine_act_bwd_small2")
         return outs
     rows = stats_rows(N, Cc)
