@@ -45,6 +45,10 @@ extern "C" {
 #define N3D_NO_MFMA 16    /* force the generic VALU kernels (A/B testing) */
 #define N3D_PREPACKED 32  /* `ws` already holds this conv's packed weights (written by n3d_pack_batch) */
 
+/* storage type of an activation tensor (entry points that take a dtype argument; all others are fp32) */
+#define N3D_F32 0
+#define N3D_BF16 1        /* bfloat16 storage, fp32 arithmetic: BASELINE configs[4] (4x128^3 patches, HBM-bound levels) */
+
 /* Geometry of a (possibly strided / dilated) 3-D convolution, torch Conv3d semantics:
  * o = floor((i + 2*pad - dil*(k-1) - 1)/stride) + 1.  "i side" is what the window slides over.
  * For a transposed convolution the i side is its OUTPUT and the o side its INPUT. */
@@ -335,6 +339,34 @@ int n3d_dice_fwd(const float* p, int64_t psb, int64_t psc, int64_t psv, const fl
 int n3d_dice_bwd(const float* p, int64_t psb, int64_t psc, int64_t psv, const float* t, int64_t tsb, int64_t tsc,
                  int64_t tsv, int B, int C, int64_t N, float smooth, const double* sums, const float* dloss,
                  float* dp, int64_t dsb, int64_t dsc, int64_t dsv, void* stream);
+
+/* ---- fused head: Dropout3d -> Conv3d(k=1) -> Sigmoid (nas.py:50-52, searched.py:91-93) and, optionally in the same passes,
+ * the Dice loss on its output (loss.py:12-14).  x: (B, Ci, N voxels) pitched NDHWC of dtype x_dtype; w: (Co, Ci) = the
+ * Conv3d weight (Co, Ci, 1, 1, 1); gate: (B, Ci) Dropout3d gate (0 or 1/(1-p) per sample and channel; prim_ops.py:66,72-73)
+ * or NULL.  Ci in {4, 8, 12, 16, 24, 32}, Co <= 4, otherwise N3D_ERR_UNSUPPORTED.  p / logits / t / dp are fp32 with element
+ * (b, c, v) at ptr[b*sb + c*sc + v*sv] (NCDHW or NDHWC).
+ * n3d_dropout3d_gate: draws the gate on the device: gate[i] = u(seed, counter, i) >= p ? 1/(1-p) : 0 with u =
+ *   n3d_dropout3d_uniform (splitmix64, host-callable); state = device uint32[3] {seed_lo, seed_hi, counter}; the launch
+ *   increments the counter, so a captured HIP graph draws a new mask on every replay.
+ * n3d_head_fwd: p = sigmoid(conv(x * gate) + bias) (logits optionally stored too); with t != NULL also
+ *   sums[b][c] = (sum p*t, sum p, sum t) and *loss = 1 - mean_bc (2*sum pt + smooth) / (sum p + sum t + smooth);
+ *   partial: double[B][Co][n3d_head_rows(N)][3] scratch.
+ * n3d_head_bwd: one pass writes dx (+)= and the weight / bias gradient slabs.  Either dp (gradient w.r.t. p) is given, or
+ *   (t, sums [, dloss]) and the Dice gradient is formed on the fly.  p is recomputed from x, nothing saved is read.
+ *   ws: n3d_head_workspace_bytes(); deferred as in n3d_conv_bwd_weight. */
+typedef struct n3d_head {
+  const void* x; int64_t xld; int32_t x_dtype; int32_t B; int32_t Ci; int32_t Co; int64_t N;
+  const float* w; const float* bias; const float* gate;
+} n3d_head;
+float n3d_dropout3d_uniform(uint64_t seed, uint32_t counter, uint32_t index);
+int n3d_dropout3d_gate(uint32_t* state, float p, int B, int C, float* gate, void* stream);
+int n3d_head_rows(int64_t N);
+size_t n3d_head_workspace_bytes(const n3d_head* h);
+int n3d_head_fwd(const n3d_head* h, float* p, int64_t psb, int64_t psc, int64_t psv, float* logits, const float* t, int64_t tsb,
+                 int64_t tsc, int64_t tsv, float smooth, double* partial, double* sums, float* loss, void* stream);
+int n3d_head_bwd(const n3d_head* h, const float* dp, int64_t dsb, int64_t dsc, int64_t dsv, const float* t, int64_t tsb, int64_t tsc,
+                 int64_t tsv, float smooth, const double* sums, const float* dloss, void* dx, int64_t dxld, int dx_dtype, int flags,
+                 float* dw, float* dbias, void* ws, size_t ws_bytes, n3d_final_job* deferred, void* stream);
 
 /* ---- layout: NCDHW <-> NDHWC (caller tensors arrive NCDHW: train.py:118-119) ---------------------- */
 int n3d_ncdhw_to_ndhwc(const float* src, float* dst, int64_t dld, int B, int C, int64_t N, void* stream);

@@ -87,6 +87,12 @@ class ConvBwdCall(C.Structure):
                 ("in_gate", C.c_void_p), ("ws_weight", C.c_void_p), ("ws_weight_bytes", C.c_size_t), ("deferred", C.POINTER(FinalJob))]
 
 
+class Head(C.Structure):
+    """n3d_head (include/n3d.h)"""
+    _fields_ = [("x", C.c_void_p), ("xld", C.c_int64), ("x_dtype", C.c_int32), ("B", C.c_int32), ("Ci", C.c_int32), ("Co", C.c_int32),
+                ("N", C.c_int64), ("w", C.c_void_p), ("bias", C.c_void_p), ("gate", C.c_void_p)]
+
+
 class PatchDesc(C.Structure):
     """n3d_patch_desc (include/n3d.h)"""
     _fields_ = [("corner", C.c_int32 * 3), ("perm", C.c_int32 * 3), ("flip", C.c_int32 * 3)]
@@ -164,6 +170,13 @@ PROTOTYPES = {
     "n3d_dice_rows": (_i, [_i64]),
     "n3d_dice_fwd": (_i, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i, _i, _i64, _f, _p, _p, _p, _p]),
     "n3d_dice_bwd": (_i, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _i, _i, _i64, _f, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "n3d_dropout3d_uniform": (C.c_float, [C.c_uint64, C.c_uint32, C.c_uint32]),
+    "n3d_dropout3d_gate": (_i, [_p, _f, _i, _i, _p, _p]),
+    "n3d_head_rows": (_i, [_i64]),
+    "n3d_head_workspace_bytes": (_sz, [C.POINTER(Head)]),
+    "n3d_head_fwd": (_i, [C.POINTER(Head), _p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i64, _f, _p, _p, _p, _p]),
+    "n3d_head_bwd": (_i, [C.POINTER(Head), _p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _f, _p, _p, _p, _i64, _i, _i, _p, _p, _p, _sz,
+                          C.POINTER(FinalJob), _p]),
     "n3d_ncdhw_to_ndhwc": (_i, [_p, _p, _i64, _i, _i, _i64, _p]),
     "n3d_ndhwc_to_ncdhw": (_i, [_p, _i64, _p, _i, _i, _i64, _p]),
     "n3d_patch_batch": (_i, [_p, _i, _p, _i, _i, _i, C.POINTER(PatchDesc), _i, _i, _i, _p, _i64, _p, _p]),
@@ -174,6 +187,7 @@ PROTOTYPES = {
 
 # flags (include/n3d.h)
 RELU_IN, RELU, ACCUMULATE, POOL_MAX, NO_MFMA, PREPACKED = 1, 2, 4, 8, 16, 32
+F32, BF16 = 0, 1   # N3D_F32 / N3D_BF16
 
 _lib = None
 

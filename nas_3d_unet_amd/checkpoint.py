@@ -34,7 +34,9 @@ def adam_state_dict(fp, lr, betas=(0.9, 0.999), eps=1e-8):
 
 
 def load_adam_state_dict(fp, sd):
-    """inverse of adam_state_dict; returns the learning rate stored in the checkpoint"""
+    """inverse of adam_state_dict; returns the learning rate stored in the checkpoint.
+    Limit: the flat Adam keeps ONE step counter, so every parameter with state must be at the same step (true for every
+    checkpoint the reference writes: all parameters receive a gradient in every step); otherwise ValueError."""
     steps = set()
     fp.exp_avg.zero_()
     fp.exp_avg_sq.zero_()
@@ -87,6 +89,28 @@ def load_train_state_dicts(trainer, sd, new_lr=False):
     return sd["epoch"] + 1, sd["history"], sd["best_loss"]
 
 
+# ------------------------------------------------------------------------------------------------ search.py:166-176 / 108-127
+def search_state_dicts(trainer, epoch, geno_count, history, best_loss):
+    """the reference's search checkpoint: two optimizers, two schedulers (the reference stores the KERNEL scheduler under
+    both scheduler keys, search.py:174; here each key holds its own scheduler)"""
+    return {"epoch": epoch, "geno_count": geno_count, "history": history, "model_param": trainer.model.state_dict(),
+            "optim_shell": adam_state_dict(trainer.afp, trainer.lr_shell, trainer.betas, trainer.eps),
+            "optim_kernel": adam_state_dict(trainer.fp, trainer.lr_kernel, trainer.betas, trainer.eps),
+            "kernel_scheduler": scheduler_state_dict(trainer.kernel_scheduler),
+            "shell_scheduler": scheduler_state_dict(trainer.shell_scheduler), "best_loss": best_loss}
+
+
+def load_search_state_dicts(trainer, sd, new_lr=False):
+    """returns (next epoch, geno_count, history, best_loss) like search.py's check_resume"""
+    trainer.model.load_state_dict(sd["model_param"])   # kernel weights and alphas are views of the flat buffers: copied in place
+    if not new_lr:
+        trainer.set_shell_lr(load_adam_state_dict(trainer.afp, sd["optim_shell"]))
+        trainer.set_kernel_lr(load_adam_state_dict(trainer.fp, sd["optim_kernel"]))
+        load_scheduler_state_dict(trainer.shell_scheduler, sd["shell_scheduler"])
+        load_scheduler_state_dict(trainer.kernel_scheduler, sd["kernel_scheduler"])
+    return sd["epoch"] + 1, sd["geno_count"], sd["history"], sd["best_loss"]
+
+
 # ------------------------------------------------------------------------------------------------ genotype pickle
 def save_genotype(path, gene, count=1):
     """search.py:189-194: pickle of (str(gene), count)"""
@@ -94,11 +118,26 @@ def save_genotype(path, gene, count=1):
         pickle.dump((str(gene), count), f)
 
 
+class _StrTupleUnpickler(pickle.Unpickler):
+    """a genotype file holds (str, int): no class needs to be importable, so none is"""
+
+    def find_class(self, module, name):
+        raise pickle.UnpicklingError("genotype file references %s.%s: only a (str, count) tuple is accepted" % (module, name))
+
+
 def load_genotype(path):
-    """train.py:36-38: gene = eval(pickle.load(f)[0]) -- evaluated with only `Genotype` in scope"""
+    """train.py:36-38 does `eval(pickle.load(f)[0])`; here the pickle may only contain builtin containers / str / int and
+    the text is parsed as a literal `Genotype(down=[...], up=[...])` call (ast), never evaluated"""
+    import ast
     with open(path, "rb") as f:
-        text = pickle.load(f)[0]
-    gene = eval(text, {"__builtins__": {}}, {"Genotype": Genotype})
-    if not isinstance(gene, Genotype):
+        text = _StrTupleUnpickler(f).load()[0]
+    try:
+        call = ast.parse(text.strip(), mode="eval").body
+        if not (isinstance(call, ast.Call) and isinstance(call.func, ast.Name) and call.func.id == "Genotype"):
+            raise ValueError
+        args = [ast.literal_eval(a) for a in call.args]
+        kw = {k.arg: ast.literal_eval(k.value) for k in call.keywords}
+        gene = Genotype(*args, **kw)
+    except (ValueError, SyntaxError, TypeError):
         raise ValueError("not a Genotype: %r" % (text,))
     return gene

@@ -1,0 +1,379 @@
+// Fused network head (nas.py:50-52, searched.py:91-93) and its Dice loss (loss.py:12-14):
+//   p = sigmoid(conv1x1x1(Dropout3d(x)) + bias)            one pass over x, one write of p
+//   Dice partial sums (sum p*t, sum p, sum t per (b, c))     in the same pass when the target is given
+// and the whole backward -- d loss / d p from the Dice sums, sigmoid', data gradient, weight and bias gradient -- in ONE
+// pass over (x, t) that writes dx.  The reference runs Dropout3d, Conv3d, Sigmoid, four reductions and their autograd
+// counterparts as separate full-tensor passes; here the head is HBM-bound streaming work: forward reads Ci and writes
+// Co channels per voxel, backward reads Ci (+ Co target channels) and writes Ci.
+// Dropout3d(p) zeroes whole channels per sample and rescales by 1/(1-p) (prim_ops.py:66,72-73): a (B, Ci) gate applied
+// to x on load.  The gate is either supplied or drawn on the device by n3d_dropout3d_gate from a counter-based generator
+// (seed + step counter in device memory, so a captured HIP graph draws a fresh mask on every replay).
+#include "n3d_common.h"
+
+namespace n3d {
+
+constexpr int HEAD_CHUNK = 2048;   // voxels per workgroup (8 per thread)
+constexpr int HEAD_COMAX = 4;      // output channels computed per voxel (weights zero-padded)
+
+// splitmix64 of (seed, counter, element): uniform in [0,1) with 24 bits
+__host__ __device__ inline float head_uniform(uint64_t seed, uint32_t counter, uint32_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (((uint64_t)counter << 20) + idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ void dropout3d_gate_kernel(uint32_t* __restrict__ state, float p, int n, float* __restrict__ gate) {
+  __shared__ uint32_t st[3];
+  if (threadIdx.x < 3) st[threadIdx.x] = state[threadIdx.x];
+  __syncthreads();
+  const uint64_t seed = ((uint64_t)st[1] << 32) | st[0];
+  const float keep = 1.0f / (1.0f - p);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) gate[i] = head_uniform(seed, st[2], (uint32_t)i) >= p ? keep : 0.f;
+  if (threadIdx.x == 0) state[2] = st[2] + 1;
+}
+
+struct HeadFwdArgs {
+  const void* x; int64_t xld; int64_t N;
+  const float* w; const float* bias; const float* gate;
+  float* p; int64_t psb, psc, psv; float* logits;
+  const float* t; int64_t tsb, tsc, tsv;
+  double* partial; int rows; int Ci, Co;
+};
+
+// thread = voxel; lanes walk consecutive voxels (x: Ci * sizeof(TX) contiguous bytes per voxel, p / t: strided per channel)
+template <typename TX, int CIQ>
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
+  constexpr int CI = CIQ * 4;
+  __shared__ float wsm[HEAD_COMAX][CI];
+  __shared__ double red[HEAD_COMAX * 3][4];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  for (int i = tid; i < HEAD_COMAX * CI; i += 256) {
+    const int co = i / CI, ci = i - co * CI;
+    wsm[co][ci] = co < a.Co ? a.w[co * CI + ci] * (a.gate ? a.gate[b * CI + ci] : 1.f) : 0.f;
+  }
+  __syncthreads();
+  float bias[HEAD_COMAX];
+#pragma unroll
+  for (int co = 0; co < HEAD_COMAX; ++co) bias[co] = co < a.Co ? a.bias[co] : 0.f;
+  const TX* xb = reinterpret_cast<const TX*>(a.x) + (int64_t)b * a.N * a.xld;
+  float spt[HEAD_COMAX], sp[HEAD_COMAX], st[HEAD_COMAX];
+#pragma unroll
+  for (int co = 0; co < HEAD_COMAX; ++co) spt[co] = sp[co] = st[co] = 0.f;
+  const int64_t v0 = (int64_t)blockIdx.x * HEAD_CHUNK;
+#pragma unroll 2
+  for (int k = 0; k < HEAD_CHUNK / 256; ++k) {
+    const int64_t v = v0 + tid + k * 256;
+    if (v >= a.N) break;
+    float4 xq[CIQ];
+#pragma unroll
+    for (int q = 0; q < CIQ; ++q) xq[q] = ld4(xb + v * a.xld + q * 4);
+    float tv[HEAD_COMAX];
+#pragma unroll
+    for (int co = 0; co < HEAD_COMAX; ++co) tv[co] = (a.t && co < a.Co) ? a.t[b * a.tsb + co * a.tsc + v * a.tsv] : 0.f;
+    float z[HEAD_COMAX];
+#pragma unroll
+    for (int co = 0; co < HEAD_COMAX; ++co) {
+      float s = bias[co];
+#pragma unroll
+      for (int q = 0; q < CIQ; ++q) {
+        s = fmaf(wsm[co][q * 4 + 0], xq[q].x, s); s = fmaf(wsm[co][q * 4 + 1], xq[q].y, s);
+        s = fmaf(wsm[co][q * 4 + 2], xq[q].z, s); s = fmaf(wsm[co][q * 4 + 3], xq[q].w, s);
+      }
+      z[co] = s;
+    }
+#pragma unroll
+    for (int co = 0; co < HEAD_COMAX; ++co) {
+      if (co < a.Co) {
+        const float pr = 1.0f / (1.0f + expf(-z[co]));
+        a.p[b * a.psb + co * a.psc + v * a.psv] = pr;
+        if (a.logits) a.logits[b * a.psb + co * a.psc + v * a.psv] = z[co];
+        spt[co] = fmaf(pr, tv[co], spt[co]); sp[co] += pr; st[co] += tv[co];
+      }
+    }
+  }
+  if (!a.partial) return;
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int co = 0; co < HEAD_COMAX; ++co) {
+    const double d0 = wave_sum_d(spt[co]), d1 = wave_sum_d(sp[co]), d2 = wave_sum_d(st[co]);
+    if (lane == 0) { red[co * 3][wave] = d0; red[co * 3 + 1][wave] = d1; red[co * 3 + 2][wave] = d2; }
+  }
+  __syncthreads();
+  if (tid < a.Co * 3) {
+    const int co = tid / 3, k = tid - co * 3;
+    a.partial[(((int64_t)b * a.Co + co) * a.rows + blockIdx.x) * 3 + k] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+  }
+}
+
+// same arithmetic as dice_finalize_kernel (elementwise.hip): one wave per (b, c), fixed-order sums
+__global__ __launch_bounds__(256) void head_dice_finalize_kernel(const double* __restrict__ partial, int rows, int BC, double smooth,
+                                                                 double* __restrict__ sums, float* __restrict__ loss) {
+  __shared__ double ratio[256];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  double acc = 0;
+  for (int i = wave; i < BC; i += 4) {
+    double s[3] = {0, 0, 0};
+    for (int r = lane; r < rows; r += 64)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s[k] += partial[((int64_t)i * rows + r) * 3 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = wave_sum_d(s[k]);
+    if (lane == 0) {
+      sums[i * 3] = s[0]; sums[i * 3 + 1] = s[1]; sums[i * 3 + 2] = s[2];
+      acc += (2.0 * s[0] + smooth) / (s[1] + s[2] + smooth);
+    }
+  }
+  ratio[t] = acc;
+  __syncthreads();
+  if (t == 0) {
+    double s = 0;
+    for (int i = 0; i < 256; ++i) s += ratio[i];
+    *loss = (float)(1.0 - s / BC);
+  }
+}
+
+struct HeadBwdArgs {
+  const void* x; int64_t xld; int64_t N;
+  const float* w; const float* bias; const float* gate;
+  const float* dp; int64_t dsb, dsc, dsv;
+  const float* t; int64_t tsb, tsc, tsv;
+  const double* sums; const float* dloss; double smooth; int BC;
+  void* dx; int64_t dxld; int accumulate;
+  float* partial; float* pbias; int chunks_per_sample; int Ci, Co;
+};
+
+// thread = voxel.  d logit = dp * p * (1 - p) with p recomputed from x (no saved activations are read);
+// dx[ci] = gate[ci] * sum_co W[co][ci] * dlogit[co];  dW[co][ci] = gate[ci] * sum_v dlogit[co] * x[ci];  dbias[co] = sum_v dlogit[co]
+template <typename TX, typename TD, int CIQ>
+__global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
+  constexpr int CI = CIQ * 4, NV = HEAD_COMAX * CI + HEAD_COMAX;
+  __shared__ float wsm[HEAD_COMAX][CI];
+  __shared__ float gsm[CI];
+  __shared__ float red[4][NV];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  for (int i = tid; i < HEAD_COMAX * CI; i += 256) {
+    const int co = i / CI, ci = i - co * CI;
+    wsm[co][ci] = co < a.Co ? a.w[co * CI + ci] * (a.gate ? a.gate[b * CI + ci] : 1.f) : 0.f;
+  }
+  if (tid < CI) gsm[tid] = a.gate ? a.gate[b * CI + tid] : 1.f;
+  __syncthreads();
+  float bias[HEAD_COMAX], k2[HEAD_COMAX], k0[HEAD_COMAX];
+#pragma unroll
+  for (int co = 0; co < HEAD_COMAX; ++co) {
+    bias[co] = co < a.Co ? a.bias[co] : 0.f;
+    k2[co] = k0[co] = 0.f;
+    if (a.sums && co < a.Co) {
+      // d loss / d p = -(1/BC) * (2 t den - num) / den^2   (loss.py:13-14), as n3d_dice_bwd
+      const int i = b * a.Co + co;
+      const double num = 2.0 * a.sums[i * 3] + a.smooth, den = a.sums[i * 3 + 1] + a.sums[i * 3 + 2] + a.smooth;
+      const double gl = a.dloss ? (double)*a.dloss : 1.0;
+      k2[co] = (float)(-gl / a.BC * 2.0 / den);
+      k0[co] = (float)(gl / a.BC * num / (den * den));
+    }
+  }
+  const TX* xb = reinterpret_cast<const TX*>(a.x) + (int64_t)b * a.N * a.xld;
+  TD* dxb = reinterpret_cast<TD*>(a.dx) + (int64_t)b * a.N * a.dxld;
+  float acc[HEAD_COMAX][CI], accb[HEAD_COMAX];
+#pragma unroll
+  for (int co = 0; co < HEAD_COMAX; ++co) {
+    accb[co] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) acc[co][ci] = 0.f;
+  }
+  const int64_t v0 = (int64_t)blockIdx.x * HEAD_CHUNK;
+  for (int k = 0; k < HEAD_CHUNK / 256; ++k) {
+    const int64_t v = v0 + tid + k * 256;
+    if (v >= a.N) break;
+    float4 xq[CIQ];
+#pragma unroll
+    for (int q = 0; q < CIQ; ++q) xq[q] = ld4(xb + v * a.xld + q * 4);
+    float gp[HEAD_COMAX];
+#pragma unroll
+    for (int co = 0; co < HEAD_COMAX; ++co) {
+      gp[co] = 0.f;
+      if (co < a.Co) gp[co] = a.sums ? fmaf(k2[co], a.t[b * a.tsb + co * a.tsc + v * a.tsv], k0[co]) : a.dp[b * a.dsb + co * a.dsc + v * a.dsv];
+    }
+    float4 prevq[CIQ];
+    if (a.accumulate) {
+#pragma unroll
+      for (int q = 0; q < CIQ; ++q) prevq[q] = ld4(dxb + v * a.dxld + q * 4);
+    }
+    float dl[HEAD_COMAX];
+#pragma unroll
+    for (int co = 0; co < HEAD_COMAX; ++co) {
+      float s = bias[co];
+#pragma unroll
+      for (int q = 0; q < CIQ; ++q) {
+        s = fmaf(wsm[co][q * 4 + 0], xq[q].x, s); s = fmaf(wsm[co][q * 4 + 1], xq[q].y, s);
+        s = fmaf(wsm[co][q * 4 + 2], xq[q].z, s); s = fmaf(wsm[co][q * 4 + 3], xq[q].w, s);
+      }
+      const float pr = 1.0f / (1.0f + expf(-s));
+      dl[co] = gp[co] * pr * (1.0f - pr);
+      accb[co] += dl[co];
+    }
+#pragma unroll
+    for (int q = 0; q < CIQ; ++q) {
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+      const float xe[4] = {xq[q].x, xq[q].y, xq[q].z, xq[q].w};
+#pragma unroll
+      for (int co = 0; co < HEAD_COMAX; ++co) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = fmaf(wsm[co][q * 4 + e], dl[co], o[e]);      // wsm already carries the gate
+          acc[co][q * 4 + e] = fmaf(dl[co], xe[e], acc[co][q * 4 + e]);
+        }
+      }
+      float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+      if (a.accumulate) { ov.x += prevq[q].x; ov.y += prevq[q].y; ov.z += prevq[q].z; ov.w += prevq[q].w; }
+      st4(dxb + v * a.dxld + q * 4, ov);
+    }
+  }
+  if (!a.partial) return;
+  // block sums -> one partial slab [ci][co] (+ bias row) per workgroup; the common fixed-order finalize adds the slabs
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int co = 0; co < HEAD_COMAX; ++co) {
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+      const float s = wave_sum_f(acc[co][ci]);
+      if (lane == 0) red[wave][ci * HEAD_COMAX + co] = s;
+    }
+    const float sb = wave_sum_f(accb[co]);
+    if (lane == 0) red[wave][HEAD_COMAX * CI + co] = sb;
+  }
+  __syncthreads();
+  const int chunk = b * a.chunks_per_sample + blockIdx.x;
+  for (int i = tid; i < NV; i += 256) {
+    const float s = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (i < HEAD_COMAX * CI) {
+      const int ci = i / HEAD_COMAX, co = i - ci * HEAD_COMAX;
+      if (co < a.Co) a.partial[(int64_t)chunk * (CI * a.Co) + ci * a.Co + co] = s * gsm[ci];
+    } else {
+      const int co = i - HEAD_COMAX * CI;
+      if (co < a.Co) a.pbias[(int64_t)chunk * a.Co + co] = s;
+    }
+  }
+}
+
+template <typename TX>
+static bool launch_head_fwd(const HeadFwdArgs& a, int B, hipStream_t s) {
+  const dim3 grid((unsigned)a.rows, (unsigned)B), blk(256);
+  switch (a.Ci / 4) {
+    case 1: hipLaunchKernelGGL((head_fwd_kernel<TX, 1>), grid, blk, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((head_fwd_kernel<TX, 2>), grid, blk, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((head_fwd_kernel<TX, 3>), grid, blk, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((head_fwd_kernel<TX, 4>), grid, blk, 0, s, a); break;
+    case 6: hipLaunchKernelGGL((head_fwd_kernel<TX, 6>), grid, blk, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((head_fwd_kernel<TX, 8>), grid, blk, 0, s, a); break;
+    default: return false;
+  }
+  return true;
+}
+
+template <typename TX, typename TD>
+static bool launch_head_bwd(const HeadBwdArgs& a, int B, hipStream_t s) {
+  const dim3 grid((unsigned)a.chunks_per_sample, (unsigned)B), blk(256);
+  switch (a.Ci / 4) {
+    case 1: hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 1>), grid, blk, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 2>), grid, blk, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 3>), grid, blk, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 4>), grid, blk, 0, s, a); break;
+    case 6: hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 6>), grid, blk, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 8>), grid, blk, 0, s, a); break;
+    default: return false;
+  }
+  return true;
+}
+
+static int check_head(const n3d_head* h, const char* what) {
+  N3D_CHECK_ARG(h && h->x && h->w && h->bias && h->B > 0 && h->N > 0, "%s: bad args", what);
+  const int q = h->Ci / 4;
+  if (h->Ci % 4 != 0 || !(q == 1 || q == 2 || q == 3 || q == 4 || q == 6 || q == 8) || h->Co < 1 || h->Co > HEAD_COMAX)
+    N3D_UNSUPPORTED("%s: Ci in {4,8,12,16,24,32} and Co <= %d are built (Ci=%d Co=%d)", what, HEAD_COMAX, h->Ci, h->Co);
+  N3D_CHECK_ARG(h->x_dtype == N3D_F32 || h->x_dtype == N3D_BF16, "%s: unknown dtype %d", what, h->x_dtype);
+  const int esz = h->x_dtype == N3D_BF16 ? 2 : 4;
+  N3D_CHECK_ARG(h->xld >= h->Ci && h->xld % 4 == 0 && (reinterpret_cast<uintptr_t>(h->x) % (4 * esz)) == 0, "%s: x needs ld %% 4 == 0 and quad alignment", what);
+  return 0;
+}
+
+}  // namespace n3d
+
+using namespace n3d;
+
+extern "C" {
+
+float n3d_dropout3d_uniform(uint64_t seed, uint32_t counter, uint32_t index) { return head_uniform(seed, counter, index); }
+
+int n3d_dropout3d_gate(uint32_t* state, float p, int B, int C, float* gate, void* stream) {
+  N3D_CHECK_ARG(state && gate && B > 0 && C > 0 && p >= 0.f && p < 1.f, "dropout3d_gate: bad args");
+  hipLaunchKernelGGL(dropout3d_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, p, B * C, gate);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_head_rows(int64_t N) { return (int)cdiv(N, HEAD_CHUNK); }
+
+size_t n3d_head_workspace_bytes(const n3d_head* h) {
+  if (!h || h->N <= 0 || h->B <= 0) return 0;
+  return (size_t)h->B * cdiv(h->N, HEAD_CHUNK) * ((size_t)h->Ci * h->Co + h->Co) * sizeof(float);
+}
+
+int n3d_head_fwd(const n3d_head* h, float* p, int64_t psb, int64_t psc, int64_t psv, float* logits, const float* t, int64_t tsb,
+                 int64_t tsc, int64_t tsv, float smooth, double* partial, double* sums, float* loss, void* stream) {
+  if (int e = check_head(h, "head_fwd")) return e;
+  N3D_CHECK_ARG(p, "head_fwd: no output");
+  N3D_CHECK_ARG(!t || (partial && sums && loss), "head_fwd: the Dice mode needs partial / sums / loss");
+  HeadFwdArgs a;
+  a.x = h->x; a.xld = h->xld; a.N = h->N; a.w = h->w; a.bias = h->bias; a.gate = h->gate;
+  a.p = p; a.psb = psb; a.psc = psc; a.psv = psv; a.logits = logits;
+  a.t = t; a.tsb = tsb; a.tsc = tsc; a.tsv = tsv; a.partial = t ? partial : nullptr; a.rows = (int)cdiv(h->N, HEAD_CHUNK);
+  a.Ci = h->Ci; a.Co = h->Co;
+  hipStream_t s = (hipStream_t)stream;
+  const bool ok = h->x_dtype == N3D_BF16 ? launch_head_fwd<bf16_t>(a, h->B, s) : launch_head_fwd<float>(a, h->B, s);
+  if (!ok) N3D_UNSUPPORTED("head_fwd: Ci=%d", h->Ci);
+  if (t) hipLaunchKernelGGL(head_dice_finalize_kernel, dim3(1), dim3(256), 0, s, partial, a.rows, h->B * h->Co, (double)smooth, sums, loss);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_head_bwd(const n3d_head* h, const float* dp, int64_t dsb, int64_t dsc, int64_t dsv, const float* t, int64_t tsb, int64_t tsc,
+                 int64_t tsv, float smooth, const double* sums, const float* dloss, void* dx, int64_t dxld, int dx_dtype, int flags,
+                 float* dw, float* dbias, void* ws, size_t ws_bytes, n3d_final_job* deferred, void* stream) {
+  if (deferred) deferred->nchunks = 0;
+  if (int e = check_head(h, "head_bwd")) return e;
+  N3D_CHECK_ARG(dx && dxld >= h->Ci && dxld % 4 == 0, "head_bwd: bad dx");
+  N3D_CHECK_ARG((dp != nullptr) != (t != nullptr && sums != nullptr), "head_bwd: give either dp or (t, sums)");
+  N3D_CHECK_ARG(dx_dtype == N3D_F32 || dx_dtype == N3D_BF16, "head_bwd: unknown dx dtype");
+  const bool want_w = dw || dbias;
+  const int cps = (int)cdiv(h->N, HEAD_CHUNK);
+  const size_t need = n3d_head_workspace_bytes(h);
+  if (want_w && (!ws || ws_bytes < need)) { set_error("head_bwd: workspace too small (%zu < %zu)", ws_bytes, need); return N3D_ERR_WORKSPACE; }
+  HeadBwdArgs a;
+  a.x = h->x; a.xld = h->xld; a.N = h->N; a.w = h->w; a.bias = h->bias; a.gate = h->gate;
+  a.dp = dp; a.dsb = dsb; a.dsc = dsc; a.dsv = dsv; a.t = t; a.tsb = tsb; a.tsc = tsc; a.tsv = tsv;
+  a.sums = dp ? nullptr : sums; a.dloss = dloss; a.smooth = (double)smooth; a.BC = h->B * h->Co;
+  a.dx = dx; a.dxld = dxld; a.accumulate = (flags & N3D_ACCUMULATE) ? 1 : 0;
+  const int nchunks = h->B * cps;
+  a.partial = want_w ? (float*)ws : nullptr;
+  a.pbias = want_w ? (float*)ws + (size_t)nchunks * h->Ci * h->Co : nullptr;
+  a.chunks_per_sample = cps; a.Ci = h->Ci; a.Co = h->Co;
+  hipStream_t s = (hipStream_t)stream;
+  bool ok;
+  if (h->x_dtype == N3D_BF16) ok = dx_dtype == N3D_BF16 ? launch_head_bwd<bf16_t, bf16_t>(a, h->B, s) : launch_head_bwd<bf16_t, float>(a, h->B, s);
+  else ok = dx_dtype == N3D_BF16 ? launch_head_bwd<float, bf16_t>(a, h->B, s) : launch_head_bwd<float, float>(a, h->B, s);
+  if (!ok) N3D_UNSUPPORTED("head_bwd: Ci=%d", h->Ci);
+  N3D_LAUNCH_CHECK();
+  if (want_w) {
+    // one "tile" holding the whole [Ci][Co] slab per chunk (layout of n3d_final_job: position = ci * co_t + co)
+    n3d_final_job job;
+    job.partial = a.partial; job.pbias = a.pbias; job.dw = dw; job.dbias = dbias; job.nchunks = nchunks; job.ntiles = 1; job.tci = 1; job.tco = 1;
+    job.ci_t = h->Ci; job.co_t = h->Co; job.Co = h->Co; job.Ci = h->Ci; job.taps = 1; job.pad_ = 0;
+    if (deferred) *deferred = job;
+    else if (int e = n3d_wgrad_finalize_batch(&job, 1, stream)) return e;
+  }
+  return N3D_OK;
+}
+
+}  // extern "C"

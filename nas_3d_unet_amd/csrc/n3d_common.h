@@ -91,6 +91,33 @@ static inline EwMap ew_map(int64_t N, int C) {
 }
 
 #ifdef __HIPCC__
+// ---- activation storage types.  fp32 is the reference's arithmetic; bf16 is the STORAGE format of the HBM-bound
+// levels in the bf16 configuration (BASELINE configs[4]): every kernel converts on load / store and computes in fp32.
+// A "quad" is four consecutive channels of one voxel: 16 bytes in fp32, 8 bytes in bf16.
+typedef uint16_t bf16_t;
+typedef __bf16 n3d_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float n3d_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
+                     __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {   // round-to-nearest-even (v_cvt_pk_bf16_f32)
+  const n3d_f32x2 f = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, n3d_bf16x2));
+}
+__device__ __forceinline__ void st4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, const float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return __builtin_bit_cast(float, (uint32_t)*p << 16); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = (bf16_t)(pack_bf16x2(v, 0.f) & 0xffffu); }
+#endif
+
+#ifdef __HIPCC__
 // ---- cross-lane sums.  A lone wave issues ~1 instruction per 4-5 cycles, so on the small tensors of the deep
 // U-net levels kernel time IS the dynamic instruction count: reductions use DPP row operations and permlane swaps
 // (1-2 VALU instructions per step and 32-bit half) instead of ds_bpermute sequences (~8 instructions + an LDS trip).

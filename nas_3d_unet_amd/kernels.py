@@ -52,13 +52,15 @@ def zeros_ndhwc(B, Cc, D, H, W, device, dtype=torch.float32):
 
 
 class View:
-    """Pitched NDHWC view of a logical (B, C, D, H, W) fp32 device tensor."""
-    __slots__ = ("t", "p", "ld", "B", "C", "D", "H", "W", "N")
+    """Pitched NDHWC view of a logical (B, C, D, H, W) device tensor (fp32, or bf16 storage: dt = N3D_F32 / N3D_BF16;
+    the pitch counts elements)."""
+    __slots__ = ("t", "p", "ld", "B", "C", "D", "H", "W", "N", "dt")
 
     def __init__(self, t, ld):
         self.t = t
         self.p = C.c_void_p(t.data_ptr())
         self.ld = int(ld)
+        self.dt = _lib.BF16 if t.dtype == torch.bfloat16 else _lib.F32
         self.B, self.C, self.D, self.H, self.W = (int(s) for s in t.shape)
         self.N = self.D * self.H * self.W
 
@@ -92,19 +94,20 @@ def _pitch_of(t):
     return ld
 
 
-def as_view(t, what="tensor"):
-    """Validate (or repack with a copy) a logical (B,C,D,H,W) tensor into a pitched NDHWC view."""
+def as_view(t, what="tensor", bf16_ok=False):
+    """Validate (or repack with a copy) a logical (B,C,D,H,W) tensor into a pitched NDHWC view.  bf16_ok: the caller's
+    kernels take bf16 storage too (the entry points with a dtype argument)."""
     if not isinstance(t, torch.Tensor) or t.dim() != 5:
         raise N3DError("%s: expected a 5-D (B,C,D,H,W) tensor" % what)
     if not t.is_cuda:
         raise N3DError("%s is on %s: the nas_3d_unet_amd ops only run on a HIP (gfx950) device; "
                        "there is no CPU fallback" % (what, t.device))
-    if t.dtype != torch.float32:
+    if t.dtype != torch.float32 and not (bf16_ok and t.dtype == torch.bfloat16):
         raise N3DError("%s: fp32 expected, got %s" % (what, t.dtype))
     ld = _pitch_of(t)
-    if ld is None or (t.data_ptr() % 16 != 0) or (ld % 4 != 0 and t.shape[1] % 4 == 0):
+    if ld is None or (t.data_ptr() % (4 * t.element_size()) != 0) or (ld % 4 != 0 and t.shape[1] % 4 == 0):
         B, Cc, D, H, W = t.shape
-        n = empty_ndhwc(B, Cc, D, H, W, t.device)
+        n = empty_ndhwc(B, Cc, D, H, W, t.device, t.dtype)
         n.copy_(t)  # layout plumbing (strided copy); arithmetic stays in libn3d
         t, ld = n, Cc
     return View(t, ld)
@@ -863,6 +866,62 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_t, lr=1e-3, beta1=0.9, beta
     check(_lib.load().n3d_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, ptr(lr_dev),
                                     beta1, beta2, eps, weight_decay, grad_scale, ptr(step_t), 1 if inc_step else 0, stream_ptr()),
           "n3d_adam_step")
+
+
+# ------------------------------------------------------------------------------------------ fused head
+def dropout3d_gate(state, p, B, Cc):
+    """(B, C) Dropout3d gate drawn on the device from `state` (uint32[3]: seed_lo, seed_hi, counter; the counter advances)"""
+    gate = torch.empty((B, Cc), dtype=torch.float32, device=state.device)
+    check(_lib.load().n3d_dropout3d_gate(ptr(state), float(p), B, Cc, ptr(gate), stream_ptr()), "n3d_dropout3d_gate")
+    return gate
+
+
+def _head_desc(x: View, w, bias, gate):
+    return _lib.Head(x.p.value, x.ld, x.dt, x.B, x.C, int(w.shape[0]), x.N, w.data_ptr(), bias.data_ptr(), _vp(gate))
+
+
+def head_fwd(x: View, w, bias, gate, t=None, smooth=1e-6, want_logits=False):
+    """p = sigmoid(conv1x1x1(x * gate) + bias) as a contiguous (B, Co, D, H, W) tensor; with a target t also the Dice sums
+    and loss from the same pass.  Returns (p, logits | None, sums | None, loss | None)."""
+    lib = _lib.load()
+    h = _head_desc(x, w, bias, gate)
+    dev = x.t.device
+    Co = int(w.shape[0])
+    p = torch.empty((x.B, Co, x.D, x.H, x.W), dtype=torch.float32, device=dev)
+    logits = torch.empty_like(p) if want_logits else None
+    sums = loss = partial = None
+    ts = (0, 0, 0)
+    if t is not None:
+        ts = _bcv_strides(t)
+        rows = int(lib.n3d_head_rows(x.N))
+        partial = torch.empty((x.B, Co, rows, 3), dtype=torch.float64, device=dev)
+        sums = torch.empty((x.B, Co, 3), dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+    check(lib.n3d_head_fwd(C.byref(h), ptr(p), Co * x.N, x.N, 1, ptr(logits), ptr(t), ts[0], ts[1], ts[2], float(smooth), ptr(partial),
+                           ptr(sums), ptr(loss), stream_ptr()), "n3d_head_fwd")
+    return p, logits, sums, loss
+
+
+def head_bwd(x: View, w, bias, gate, dx: View, dw, dbias, dp=None, t=None, sums=None, dloss=None, smooth=1e-6, accumulate=False):
+    """backward of head_fwd in one pass: dx (+)=, dw, dbias.  Either dp (gradient w.r.t. p, any uniform strides) or
+    (t, sums[, dloss]) for the fused Dice gradient."""
+    lib = _lib.load()
+    h = _head_desc(x, w, bias, gate)
+    ws = None
+    n = 0
+    job = None
+    if dw is not None or dbias is not None:
+        n = int(lib.n3d_head_workspace_bytes(C.byref(h)))
+        ws = torch.empty(max(n, 256), dtype=torch.uint8, device=x.t.device)
+        job = FinalJob() if _ctx is not None else None
+    ds = _bcv_strides(dp) if dp is not None else (0, 0, 0)
+    ts = _bcv_strides(t) if t is not None else (0, 0, 0)
+    check(lib.n3d_head_bwd(C.byref(h), ptr(dp), ds[0], ds[1], ds[2], ptr(t), ts[0], ts[1], ts[2], float(smooth), ptr(sums), ptr(dloss),
+                           dx.p, dx.ld, dx.dt, ACCUMULATE if accumulate else 0, ptr(dw), ptr(dbias), ptr(ws), n,
+                           C.byref(job) if job is not None else None, stream_ptr()), "n3d_head_bwd")
+    if job is not None and job.nchunks > 0:
+        _ctx.final.append(job)
+        _ctx.keep.append(ws)
 
 
 def ncdhw_to_ndhwc(src):

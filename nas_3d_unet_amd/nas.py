@@ -27,6 +27,9 @@ class KernelNet(nn.Module):
         # the down cells share (alpha1_down, alpha2_down), the up cells (alpha1_up, alpha2_up)
         return unet.run(self, x, (alpha1_down, alpha1_up, alpha2_down, alpha2_up))
 
+    def forward_loss(self, x, t, alpha1_down, alpha1_up, alpha2_down, alpha2_up, smooth=1e-6):
+        return unet.run_loss(self, x, t, (alpha1_down, alpha1_up, alpha2_down, alpha2_up), smooth)
+
 
 class ShellNet(nn.Module):
     """Architecture parameters around a KernelNet: four zero-initialised alpha matrices, one row per edge."""
@@ -50,6 +53,10 @@ class ShellNet(nn.Module):
 
     def forward(self, x):
         return self.kernel(x, *self._soft())
+
+    def forward_loss(self, x, t, smooth=1e-6):
+        """(Dice loss, probabilities) with the loss formed inside the head's launches (search.py:224-226,233-235)"""
+        return self.kernel.forward_loss(x, t, *self._soft(), smooth=smooth)
 
     def get_gene(self):
         a1d, a1u, a2d, a2u = (a.detach().cpu().numpy() for a in self._soft())

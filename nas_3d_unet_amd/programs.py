@@ -1038,12 +1038,58 @@ class SegmentFn(torch.autograd.Function):
         return (None, None, dx) + tuple(out)
 
 
+# Dropout3d (prim_ops.py:66,72-73): a (B, C) gate of 0 / 1/(1-p) folded into the conv as an input scale.  The gate is drawn on
+# the device by n3d_dropout3d_gate from a counter-based generator whose state (seed, step counter) lives in device memory next
+# to the nn.Dropout3d module, so a captured HIP graph draws a fresh mask on every replay and no torch RNG kernel runs.
+_forced_gate = None
+_drop_serial = [0]
+
+
+class forced_dropout_gate:
+    """with forced_dropout_gate(g): every Dropout3d inside uses the given (B, C) gate tensor (parity tests feed the mask
+    the CPU oracle used).  g = None: dropout off."""
+
+    def __init__(self, gate):
+        self.gate = gate
+
+    def __enter__(self):
+        global _forced_gate
+        self.prev, _forced_gate = _forced_gate, (self.gate,)
+        return self
+
+    def __exit__(self, *exc):
+        global _forced_gate
+        _forced_gate = self.prev
+        return False
+
+
+def dropout_state(drop, device, seed=None):
+    """device int32[3] {seed_lo, seed_hi, counter} of an nn.Dropout3d, created on first use from torch's seed, the process
+    rank (data-parallel ranks must not share masks) and a per-module serial number; seed != None re-seeds it"""
+    st = getattr(drop, "_n3d_state", None)
+    if st is None or st.device != device or seed is not None:
+        if seed is None:
+            import torch.distributed as dist
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+            _drop_serial[0] += 1
+            seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (rank * 4096 + _drop_serial[0])) & 0xFFFFFFFFFFFFFFFF
+        words = [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, 0]
+        st = torch.tensor([w - (1 << 32) if w >= (1 << 31) else w for w in words], dtype=torch.int32, device=device)
+        drop._n3d_state = st
+    return st
+
+
+def draw_gate(drop, training, B, Cc, device):
+    """the Dropout3d gate of this call: None (inactive), the forced one, or a fresh draw"""
+    if _forced_gate is not None:
+        return _forced_gate[0]
+    if drop is None or not training or drop.p <= 0:
+        return None
+    return K.dropout3d_gate(dropout_state(drop, device), drop.p, B, Cc)
+
+
 def run_segment(seg, x, training):
     gate = None
-    if seg.dropout is not None and training and seg.dropout.p > 0:
-        # Dropout3d zeroes whole channels per sample and rescales by 1/(1-p) (prim_ops.py:66,72-73);
-        # the (B, C) mask is generated by torch's RNG and folded into the conv as an input gate.
-        p = seg.dropout.p
-        B, Cc = x.shape[0], x.shape[1]
-        gate = torch.empty((B, Cc), dtype=torch.float32, device=x.device).bernoulli_(1.0 - p).div_(1.0 - p)  # torch's own recipe
+    if seg.dropout is not None:
+        gate = draw_gate(seg.dropout, training, x.shape[0], x.shape[1], x.device)
     return SegmentFn.apply(seg, gate, x, *seg.params())

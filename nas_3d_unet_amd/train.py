@@ -15,6 +15,7 @@ MI355X-first mechanics (none of which the reference has):
 from __future__ import annotations
 
 import os
+import types
 
 import torch
 import torch.distributed as dist
@@ -22,6 +23,14 @@ import torch.distributed as dist
 from . import fused as _fused
 from . import kernels as K
 from .loss import WeightedDiceLoss
+
+
+def _loss_of(model, loss_fn, x, t):
+    """Dice loss of the model on (x, t): through the model's fused head + loss path when it has one"""
+    fl = getattr(model, "forward_loss", None)
+    if fl is not None and isinstance(loss_fn, WeightedDiceLoss):
+        return fl(x, t, loss_fn.smooth)[0]
+    return loss_fn(model(x), t)
 
 
 class FlatParams:
@@ -182,8 +191,7 @@ class Trainer:
     def _fwd_bwd(self, x, t):
         with K.step_context(self.ctx):
             self.ctx.pack_all()            # one launch packs every conv weight for this step
-            p = self.model(x)
-            loss = self.loss_fn(p, t)
+            loss = _loss_of(self.model, self.loss_fn, x, t)
             prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True   # this backward is all ours (no hooks, no retain)
             try:
                 loss.backward(self._one)  # seed gradient kept resident: no fill launch per step
@@ -215,6 +223,14 @@ class Trainer:
             return loss
         if self._graph is None:
             self._capture(x, t)
+        if x.shape != self._static_x.shape or t.shape != self._static_t.shape:
+            # a batch of another shape (the reference's generator yields a smaller last batch of an epoch): the captured
+            # graph is for one shape only, so this step runs eagerly (same kernels, same update)
+            loss = self._fwd_bwd(x, t)
+            if self.dp_path:
+                self._allreduce()
+            self._update()
+            return loss
         self._static_x.copy_(x)
         self._static_t.copy_(t)
         self._graph.replay()
@@ -261,10 +277,12 @@ class SearchTrainer:
         self.kparams = list(shell.kernel.parameters())
         self.aparams = list(shell.alphas())
         self.fp = FlatParams(self.kparams, self.device)
-        self.aflat, self.agrad, _ = flatten_params(self.aparams, self.device)
+        self.aflat, self.agrad, aoffs = flatten_params(self.aparams, self.device)
         self.a_m = torch.zeros_like(self.aflat)
         self.a_v = torch.zeros_like(self.aflat)
         self.a_step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # the alphas' Adam state in the shape checkpoint.adam_state_dict reads (optim_shell, search.py:103)
+        self.afp = types.SimpleNamespace(params=self.aparams, offsets=aoffs, exp_avg=self.a_m, exp_avg_sq=self.a_v, step=self.a_step)
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
         self.ctx = K.StepContext(self.device)
         self.use_graph = graph
@@ -284,7 +302,7 @@ class SearchTrainer:
         self.lr_kernel = float(lr)
         self.lr_kernel_dev.fill_(self.lr_kernel)
 
-    def _pass(self, x, t, arch):
+    def _pass(self, x, t, arch, update=True):
         for p in self.kparams:
             p.requires_grad_(not arch)
         for p in self.aparams:
@@ -293,7 +311,7 @@ class SearchTrainer:
             self.agrad.zero_()  # alpha gradients arrive through autograd accumulation (softmax backward)
         with K.step_context(self.ctx):
             self.ctx.pack_all()
-            loss = self.loss_fn(self.model(x), t)
+            loss = _loss_of(self.model, self.loss_fn, x, t)
             prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True
             try:
                 loss.backward(self._one)  # seed gradient kept resident: no fill launch per step
@@ -302,6 +320,8 @@ class SearchTrainer:
             self.ctx.flush_final()
         if not self.ctx.frozen and not arch:
             self.ctx.freeze()
+        if not update:
+            return loss.detach()
         if arch:
             K.adam_step(self.aflat, self.agrad, self.a_m, self.a_v, self.a_step, self.lr_shell, self.betas[0], self.betas[1], self.eps,
                         lr_dev=self.lr_shell_dev)
@@ -309,9 +329,9 @@ class SearchTrainer:
             self.fp.adam(self.lr_kernel, self.betas, self.eps, lr_dev=self.lr_kernel_dev)
         return loss.detach()
 
-    def _both(self, x, t, vx, vt):
-        la = self._pass(vx, vt, True)
-        lw = self._pass(x, t, False)
+    def _both(self, x, t, vx, vt, update=True):
+        la = self._pass(vx, vt, True, update)
+        lw = self._pass(x, t, False, update)
         return la, lw
 
     def step(self, x, t, val_x, val_t):
@@ -320,23 +340,21 @@ class SearchTrainer:
             return self._both(x, t, val_x, val_t)
         if self._graph is None:
             self._sx, self._st, self._svx, self._svt = x.clone(), t.clone(), val_x.clone(), val_t.clone()
-            keep = (self.fp.flat.clone(), self.aflat.clone())
+            # warm-up on a side stream (allocator + lazy module state) WITHOUT the optimizer launches: weights, alphas,
+            # Adam moments and step counters -- possibly just loaded from a checkpoint (search.py:108-127) -- stay untouched
             s = torch.cuda.Stream(device=self.device)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 for _ in range(2):
-                    self._both(self._sx, self._st, self._svx, self._svt)
+                    self._both(self._sx, self._st, self._svx, self._svt, update=False)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
-            # undo the warm-up updates (weights, alphas, Adam moments and step counters)
-            self.fp.flat.copy_(keep[0]); self.aflat.copy_(keep[1])
-            for z in (self.fp.exp_avg, self.fp.exp_avg_sq, self.a_m, self.a_v):
-                z.zero_()
-            self.fp.step.zero_(); self.a_step.zero_()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):  # RCCL's watchdog thread may touch the runtime meanwhile
                 self._losses = self._both(self._sx, self._st, self._svx, self._svt)
             self._graph = g
+        if any(a.shape != b.shape for a, b in ((x, self._sx), (t, self._st), (val_x, self._svx), (val_t, self._svt))):
+            return self._both(x, t, val_x, val_t)   # remainder batch of an epoch: eager step (the graph is for one shape)
         self._sx.copy_(x); self._st.copy_(t); self._svx.copy_(val_x); self._svt.copy_(val_t)
         self._graph.replay()
         return self._losses

@@ -6,7 +6,7 @@ Here it is one channel plan and one routing function; the two nets differ only i
 passes along (alpha matrices or nothing)."""
 import torch.nn as nn
 
-from . import fused
+from . import fused, head as _head
 from .prim_ops import ConvOps
 
 
@@ -44,24 +44,33 @@ def build_stems_and_head(net, in_channels, init_n_kernels, out_channels, n_nodes
     return nn.Sequential(ConvOps(head_in, out_channels, kernel_size=1, dropout_rate=head_dropout, ops_order="weight"), nn.Sigmoid())
 
 
-def run(net, x, alphas=None):
-    """Forward of either net.  alphas: None (searched net) or (alpha1_down, alpha1_up, alpha2_down, alpha2_up), already
+def body(net, x, alphas=None):
+    """Everything ahead of the head.  alphas: None (searched net) or (alpha1_down, alpha1_up, alpha2_down, alpha2_up), already
     softmaxed.  Stems and cells run as one autograd node (fused.NetFn) unless fused.WHOLE_NET is off."""
     if not fused.WHOLE_NET:
         if alphas is None:
             plain = lambda cell, skip, cur: cell(skip, cur)
-            return route(net, x, plain, plain)
+            return route(net, x, plain, plain, head=False)
         a1d, a1u, a2d, a2u = alphas
-        return route(net, x, lambda cell, skip, cur: cell(skip, cur, a1d, a2d), lambda cell, skip, cur: cell(skip, cur, a1u, a2u))
+        return route(net, x, lambda cell, skip, cur: cell(skip, cur, a1d, a2d), lambda cell, skip, cur: cell(skip, cur, a1u, a2u), head=False)
     plan = getattr(net, "_net_plan", None)
     if plan is None:
         plan = net._net_plan = fused.net_plan(net, supernet=alphas is not None)
-    body = fused.NetFn.apply(plan, x, *(alphas if alphas is not None else (None,) * 4), *plan.params)
-    return net.last_conv(body)
+    return fused.NetFn.apply(plan, x, *(alphas if alphas is not None else (None,) * 4), *plan.params)
 
 
-def route(net, x, call_down, call_up):
-    """stems -> down cells (every output is kept as a skip) -> up cells (each takes the latest remaining skip) -> head"""
+def run(net, x, alphas=None):
+    """Forward of either net: probabilities (B, n_out, D, H, W).  The head (Dropout3d -> 1x1x1 conv -> sigmoid) is one launch."""
+    return _head.run(net.last_conv, body(net, x, alphas))
+
+
+def run_loss(net, x, t, alphas=None, smooth=1e-6):
+    """(Dice loss, probabilities): forward with the loss of loss.py:12-14 formed inside the head's passes (the trainers' path)"""
+    return _head.run_loss(net.last_conv, body(net, x, alphas), t, smooth)
+
+
+def route(net, x, call_down, call_up, head=True):
+    """stems -> down cells (every output is kept as a skip) -> up cells (each takes the latest remaining skip) [-> head]"""
     older, newer = net.stem0(x), net.stem1(x)
     kept = [older, newer]
     for cell in net.down_cells:
@@ -70,4 +79,4 @@ def route(net, x, call_down, call_up):
     kept.pop()
     for cell in net.up_cells:
         newer = call_up(cell, kept.pop(), newer)
-    return net.last_conv(newer)
+    return net.last_conv(newer) if head else newer

@@ -119,6 +119,34 @@ def net_batch(key, batch, size):
     return x, t
 
 
+def case_drop_gate(key, batch, channels, p):
+    """Dropout3d gate (prim_ops.py:66,72-73): Bernoulli(1 - p) per (sample, channel), kept channels scaled by 1/(1-p)"""
+    keep = _rng(key, 9).uniform(0, 1, (batch, channels)) >= p
+    return (keep / (1.0 - p)).astype(np.float32)
+
+
+def net2_cases():
+    """second group of whole-net cases (nets2.npz): (key, kind, genotype name, depth, patch size, batch, options)
+    options: drop = head Dropout3d rate applied with case_drop_gate (train-mode head); wshare = normal_w_share (nas.py:109-113)"""
+    return [
+        ("net2/searched/G_CONV/d4s32/drop", "searched", "G_CONV", 4, 32, 2, dict(drop=0.5)),
+        ("net2/supernet/d2s16/drop", "supernet", None, 2, 16, 2, dict(drop=0.1)),
+        ("net2/supernet/d2s16/wshare", "supernet", None, 2, 16, 2, dict(wshare=True)),
+        ("net2/supernet/d4s64", "supernet", None, 4, 64, 1, dict()),
+    ]
+
+
+def search_cases():
+    """search-step trajectories (search.py:211-238 written out with the reference modules and torch.optim.Adam):
+    (key, depth, patch size, batch, steps)"""
+    return [("search/d4s32", 4, 32, 2, 2)]
+
+
+def search_batches(key, batch, size):
+    (x, t), (vx, vt) = net_batch(key + "/train", batch, size), net_batch(key + "/val", batch, size)
+    return x, t, vx, vt
+
+
 def dice_cases():
     return [("dice/a", (2, 3, 4, 6, 8)), ("dice/b", (1, 3, 16, 16, 16)), ("dice/c", (3, 3, 2, 2, 2))]
 

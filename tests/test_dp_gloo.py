@@ -31,6 +31,10 @@ def _worker(rank, world, port, out):
         with torch.no_grad():
             flat.add_(1.0)
     dist.broadcast(flat, src=0)
+    # after the broadcast every rank holds rank 0's weights (= the closed-form fill)
+    fresh = orc.make_params(orc.searched_param_specs(cfg, orc.G_ALL))
+    bcast_err = max(float((p.detach() - q).abs().max()) for p, q in zip(params, fresh.values()))
+    torch.save({"bcast": bcast_err}, out + ".bcast%d" % rank)
     rng = np.random.default_rng(5)
     xs = rng.standard_normal((2 * world, 4, 16, 16, 16)).astype(np.float32)
     ts = (rng.uniform(0, 1, (2 * world, 3, 16, 16, 16)) < 0.3).astype(np.float32)
@@ -50,17 +54,25 @@ def _worker(rank, world, port, out):
         worst = 0.0
         for (n, q), p in zip(Q.items(), params):
             worst = max(worst, float((q.grad.double() - p.grad.double()).norm()) / tot)
-        torch.save({"worst": worst, "bcast": float((flat - torch.cat([q.detach().flatten() for q in Q.values()])[:0].new_zeros(1)).abs().max())}, out)
+        torch.save({"worst": worst}, out)
     dist.barrier()
     dist.destroy_process_group()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_dp_two_ranks_equals_global_batch(tmp_path):
     out = str(tmp_path / "res.pt")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     res = torch.load(out)
     assert res["worst"] < 1e-5, res
+    for rank in range(2):
+        assert torch.load(out + ".bcast%d" % rank)["bcast"] == 0.0
 
 
 def test_gradsync_single_process_is_noop():

@@ -1,0 +1,144 @@
+"""GPU: the fused head (Dropout3d -> 1x1x1 conv -> sigmoid [-> Dice], nas.py:50-52 / searched.py:91-93 / loss.py:12-14)
+through the C ABI (n3d_head_fwd / n3d_head_bwd / n3d_dropout3d_gate) against torch fp32 on the CPU and the reference's
+golden Dice vectors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_common as gc
+from _util import assert_close, dev
+from oracle import ref_path as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(x, w, b, gate, t, smooth=1e-6):
+    x = x.clone().requires_grad_(True)
+    w = w.clone().requires_grad_(True)
+    b = b.clone().requires_grad_(True)
+    u = x * gate[:, :, None, None, None] if gate is not None else x
+    logits = F.conv3d(u, w, b)
+    p = torch.sigmoid(logits)
+    loss = orc.dice_loss(p, t, smooth)
+    loss.backward()
+    return p.detach(), logits.detach(), loss.detach(), x.grad, w.grad, b.grad
+
+
+@pytest.mark.parametrize("ci,co,shape,batch,use_gate", [(12, 3, (8, 12, 16), 2, True), (12, 3, (32, 32, 32), 2, False), (4, 1, (4, 6, 10), 3, True),
+                                                       (24, 2, (6, 6, 6), 1, True), (32, 4, (4, 8, 8), 5, False), (8, 3, (5, 3, 7), 2, True)])
+@pytest.mark.parametrize("mode", ["dice", "plain"])
+def test_head_matches_torch(ci, co, shape, batch, use_gate, mode):
+    from nas_3d_unet_amd import kernels as K
+    rng = np.random.default_rng(ci * 100 + co)
+    xn = rng.standard_normal((batch, ci) + shape).astype(np.float32)
+    wn = (rng.standard_normal((co, ci, 1, 1, 1)) * 0.4).astype(np.float32)
+    bn = rng.standard_normal(co).astype(np.float32) * 0.2
+    tn = (rng.uniform(0, 1, (batch, co) + shape) < 0.3).astype(np.float32)
+    gn = ((rng.uniform(0, 1, (batch, ci)) >= 0.5) / 0.5).astype(np.float32) if use_gate else None
+    pr, lr, lossr, dxr, dwr, dbr = _reference(torch.from_numpy(xn), torch.from_numpy(wn), torch.from_numpy(bn),
+                                              torch.from_numpy(gn) if use_gate else None, torch.from_numpy(tn))
+    xv = K.as_view(dev(xn))
+    w, b, t = dev(wn), dev(bn), dev(tn)
+    gate = dev(gn) if use_gate else None
+    p, logits, sums, loss = K.head_fwd(xv, w, b, gate, t if mode == "dice" else None, want_logits=True)
+    assert_close(p, pr, 2e-6, "p")
+    assert_close(logits, lr, 2e-6, "logits")
+    dx = K.as_view(K.empty_ndhwc(batch, ci, *shape, xv.t.device))
+    dw, db = torch.empty_like(w), torch.empty_like(b)
+    if mode == "dice":
+        assert abs(float(loss) - float(lossr)) < 1e-6
+        K.head_bwd(xv, w, b, gate, dx, dw, db, t=t, sums=sums)
+    else:
+        # d loss / d p computed on the host from the reference probabilities
+        pq = pr.clone().requires_grad_(True)
+        orc.dice_loss(pq, torch.from_numpy(tn)).backward()
+        K.head_bwd(xv, w, b, gate, dx, dw, db, dp=pq.grad.cuda())
+    assert_close(dx.t, dxr, 2e-5, "dx")
+    assert_close(dw, dwr, 2e-5, "dw")
+    assert_close(db, dbr, 2e-5, "db")
+    # accumulate mode: dx += ...
+    K.head_bwd(xv, w, b, gate, dx, None, None, t=t, sums=sums, accumulate=True) if mode == "dice" else None
+    if mode == "dice":
+        assert_close(dx.t, 2 * dxr, 2e-5, "dx accumulate")
+
+
+def test_head_bf16_storage():
+    """bf16 storage of the head input / its gradient (BASELINE configs[4]): same kernels, conversions on load / store.
+    Reference: fp32 torch on the bf16-rounded input; dx compared after rounding to bf16 (one ulp = 2^-8 relative)."""
+    from nas_3d_unet_amd import kernels as K
+    rng = np.random.default_rng(5)
+    batch, ci, co, shape = 2, 12, 3, (8, 16, 16)
+    xb = torch.from_numpy(rng.standard_normal((batch, ci) + shape).astype(np.float32)).bfloat16()
+    wn = (rng.standard_normal((co, ci, 1, 1, 1)) * 0.4).astype(np.float32)
+    bn = rng.standard_normal(co).astype(np.float32) * 0.2
+    tn = (rng.uniform(0, 1, (batch, co) + shape) < 0.3).astype(np.float32)
+    pr, lr, lossr, dxr, dwr, dbr = _reference(xb.float(), torch.from_numpy(wn), torch.from_numpy(bn), None, torch.from_numpy(tn))
+    xd = K.empty_ndhwc(batch, ci, *shape, torch.device("cuda"), torch.bfloat16)
+    xd.copy_(xb.cuda())
+    xv = K.as_view(xd, bf16_ok=True)
+    w, b, t = dev(wn), dev(bn), dev(tn)
+    p, _, sums, loss = K.head_fwd(xv, w, b, None, t)
+    assert_close(p, pr, 2e-6, "p")
+    assert abs(float(loss) - float(lossr)) < 1e-6
+    dx = K.as_view(K.empty_ndhwc(batch, ci, *shape, xv.t.device, torch.bfloat16), bf16_ok=True)
+    dw, db = torch.empty_like(w), torch.empty_like(b)
+    K.head_bwd(xv, w, b, None, dx, dw, db, t=t, sums=sums)
+    assert_close(dw, dwr, 2e-5, "dw")
+    assert_close(dx.t.float(), dxr, 2.0 ** -8, "dx (bf16)")
+    assert torch.equal(dx.t.cpu(), dxr.bfloat16()) or float((dx.t.float().cpu() - dxr.bfloat16().float()).abs().max()) <= float(dxr.abs().max()) * 2.0 ** -7
+
+
+@pytest.mark.parametrize("key,shape", gc.dice_cases())
+def test_dice_loss_golden(golden, key, shape):
+    """WeightedDiceLoss on the GPU (n3d_dice_fwd / n3d_dice_bwd) against the reference's own loss and d loss / d p"""
+    from nas_3d_unet_amd import loss
+    g = golden("small")
+    p = dev(gc.case_probs(key, shape), True)
+    t = dev(gc.case_targets(key, shape))
+    l = loss.WeightedDiceLoss()(p, t)
+    l.backward()
+    assert abs(float(l) - float(g[key + "/loss"])) < 1e-6
+    assert_close(p.grad, g[key + "/dp"], 1e-5, key + " dp")
+    # the same loss through NDHWC-strided probabilities (what the op-by-op head emits)
+    p2 = dev(gc.case_probs(key, shape)).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    l2 = loss.WeightedDiceLoss()(p2, t)
+    l2.backward()
+    assert abs(float(l2) - float(g[key + "/loss"])) < 1e-6
+    assert_close(p2.grad, g[key + "/dp"], 1e-5, key + " dp (NDHWC)")
+
+
+def test_dropout_gate_generator():
+    """n3d_dropout3d_gate: values are exactly {0, 1/(1-p)}, equal to the host-callable generator n3d_dropout3d_uniform for
+    the same (seed, counter, index), the counter advances per launch, keep rate ~ 1 - p"""
+    from nas_3d_unet_amd import _lib, kernels as K
+    lib = _lib.load()
+    seed = 0x1234567887654321
+    st = torch.tensor([0x87654321 - (1 << 32), 0x12345678, 0], dtype=torch.int32, device="cuda")
+    B, Cc, p = 64, 12, 0.5
+    g0 = K.dropout3d_gate(st, p, B, Cc).cpu().numpy().ravel()
+    g1 = K.dropout3d_gate(st, p, B, Cc).cpu().numpy().ravel()
+    assert int(st[2]) == 2
+    for counter, got in ((0, g0), (1, g1)):
+        want = np.array([2.0 if lib.n3d_dropout3d_uniform(C.c_uint64(seed), counter, i) >= p else 0.0 for i in range(B * Cc)], dtype=np.float32)
+        assert np.array_equal(got, want)
+    assert not np.array_equal(g0, g1)
+    assert 0.4 < (g0 > 0).mean() < 0.6
+
+
+def test_train_mode_head_draws_fresh_masks_under_graph_replay():
+    """Trainer(graph=True) with the head Dropout3d active: the mask comes from device state, so consecutive replays see
+    different masks (losses differ run to run while the weights are frozen by lr = 0) and the step stays finite"""
+    from test_gpu_nets import build_net
+    from nas_3d_unet_amd.train import Trainer
+    net, head = build_net("searched", "G_CONV", 2, keep_dropout=True)
+    net.train()
+    rng = np.random.default_rng(3)
+    x = dev(rng.standard_normal((2, 4, 16, 16, 16)).astype(np.float32))
+    t = dev((rng.uniform(0, 1, (2, 3, 16, 16, 16)) < 0.3).astype(np.float32))
+    tr = Trainer(net, lr=0.0, graph=True)
+    losses = [float(tr.step(x, t)) for _ in range(6)]
+    assert all(np.isfinite(losses))
+    assert len({round(l, 7) for l in losses}) >= 3, losses

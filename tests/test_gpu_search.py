@@ -51,3 +51,116 @@ def test_search_step_matches_oracle(graph):
         assert np.abs(mine - P[n].detach().numpy()).max() <= 2.5e-3, n
     gene = net.get_gene()
     assert len(gene.down) == 6 and len(gene.up) == 6
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_search_trajectory_depth4_matches_reference(golden, graph):
+    """BASELINE configs[2] as benchmarked -- depth-4 supernet through SearchTrainer (HIP-graph replay) -- against the trajectory
+    recorded from the reference modules + torch.optim.Adam (tests/golden/make_golden.py gen_nets2): the ALPHA GRADIENTS after
+    each architecture pass element by element, both losses per step, the kernel-weight gradient norms of the weight pass."""
+    import golden_common as gc
+    from nas_3d_unet_amd import nas
+    from nas_3d_unet_amd.train import SearchTrainer
+    g = golden("nets2")
+    key, depth, size, batch, steps = gc.search_cases()[0]
+    cfg = orc.DEFAULT_CFG._replace(depth=depth)
+    net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)
+    fill_module(net)
+    net.kernel.last_conv[0].dropout = None
+    net = net.cuda()
+    tr = SearchTrainer(net, graph=graph)
+    x, t, vx, vt = (torch.from_numpy(a).cuda() for a in gc.search_batches(key, batch, size))
+    for step in range(steps):
+        la, lw = tr.step(x, t, vx, vt)
+        np.testing.assert_allclose([float(la), float(lw)], g["%s/step%d/losses" % (key, step)], rtol=0, atol=2e-5)
+        for n in ("alpha2_down", "alpha2_up", "alpha1_down", "alpha1_up"):
+            ref = g["%s/step%d/dalpha/%s" % (key, step, n)]
+            mine = getattr(net, n).grad.detach().cpu().numpy()   # the arch pass's gradient (the weight pass leaves it alone)
+            # step 0: same weights on both sides; step 1: after one Adam step of lr-sized moves driven by fp32-noise-level
+            # differences, so a looser bound
+            tol = (5e-4 if step == 0 else 5e-3) * np.abs(ref).max()
+            assert np.abs(mine - ref).max() <= tol, (n, step, np.abs(mine - ref).max(), np.abs(ref).max())
+            # rows no edge uses have an exactly zero gradient (cell.py:79-80)
+            assert np.array_equal(mine[np.abs(ref).max(axis=1) == 0], np.zeros_like(mine[np.abs(ref).max(axis=1) == 0]))
+        total = float(g["%s/step%d/gnorm_total" % (key, step)])
+        for n, q in net.kernel.named_parameters():
+            ref = float(g["%s/step%d/gnorm/kernel.%s" % (key, step, n)])
+            mine = float(q.grad.double().norm())
+            assert abs(mine - ref) <= (1e-3 if step == 0 else 1e-2) * ref + 2e-4 * total, (n, step, mine, ref)
+
+
+def test_search_step_with_shared_normal_alphas_matches_oracle():
+    """normal_w_share=True (nas.py:109-113): alpha1_up IS alpha1_down, so its gradient collects the stride-1 edges of both the
+    down and the up cells.  One search step through SearchTrainer against the oracle + torch.optim.Adam."""
+    from nas_3d_unet_amd import nas
+    from nas_3d_unet_amd.train import SearchTrainer
+    cfg = orc.DEFAULT_CFG._replace(depth=2)
+    rng = np.random.default_rng(19)
+    mk = lambda: (rng.standard_normal((2, 4, 16, 16, 16)).astype(np.float32), (rng.uniform(0, 1, (2, 3, 16, 16, 16)) < 0.3).astype(np.float32))
+    (xn, tn), (vxn, vtn) = mk(), mk()
+    P = orc.make_params(orc.supernet_param_specs(cfg, True), requires_grad=True)
+    anames = [n for n in ("alpha2_down", "alpha2_up", "alpha1_down") if n in P]
+    la = orc.dice_loss(orc.supernet_forward(P, torch.from_numpy(vxn), cfg, normal_w_share=True), torch.from_numpy(vtn))
+    la.backward()
+    net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, True, cfg.channel_change)
+    assert net.alpha1_up is net.alpha1_down and len(list(net.alphas())) == 3
+    fill_module(net)
+    net.kernel.last_conv[0].dropout = None
+    net = net.cuda()
+    tr = SearchTrainer(net, graph=False)
+    la_hip, _ = tr.step(*(torch.from_numpy(a).cuda() for a in (xn, tn, vxn, vtn)))
+    assert abs(float(la_hip) - float(la)) < 5e-6
+    for n in anames:
+        ref = P[n].grad.numpy()
+        mine = getattr(net, n).grad.cpu().numpy()
+        assert np.abs(mine - ref).max() <= 5e-4 * np.abs(ref).max(), n
+
+
+def test_search_trainer_resumes_loaded_adam_state_in_graph_mode():
+    """the first graph-mode step must not wipe optimizer state loaded before it (the resume path of
+    search.py:108-127).  Load moments + step counters, take one graph step, compare with the same step taken eagerly."""
+    from nas_3d_unet_amd import nas
+    from nas_3d_unet_amd.train import SearchTrainer
+    cfg = orc.DEFAULT_CFG._replace(depth=2)
+    rng = np.random.default_rng(23)
+    mk = lambda: (rng.standard_normal((2, 4, 16, 16, 16)).astype(np.float32), (rng.uniform(0, 1, (2, 3, 16, 16, 16)) < 0.3).astype(np.float32))
+    (xn, tn), (vxn, vtn) = mk(), mk()
+    batches = [torch.from_numpy(a).cuda() for a in (xn, tn, vxn, vtn)]
+    res = []
+    for graph in (False, True):
+        net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)
+        fill_module(net)
+        net.kernel.last_conv[0].dropout = None
+        tr = SearchTrainer(net.cuda(), graph=graph)
+        gen = torch.Generator().manual_seed(1)
+        tr.fp.exp_avg.copy_(torch.randn(tr.fp.numel, generator=gen) * 1e-3)
+        tr.fp.exp_avg_sq.copy_(torch.rand(tr.fp.numel, generator=gen) * 1e-5)
+        tr.a_m.copy_(torch.randn(tr.a_m.numel(), generator=gen) * 1e-3)
+        tr.a_v.copy_(torch.rand(tr.a_v.numel(), generator=gen) * 1e-5)
+        tr.fp.step.fill_(40); tr.a_step.fill_(40)
+        tr.step(*batches)
+        assert int(tr.fp.step) == 41 and int(tr.a_step) == 41
+        res.append((tr.fp.flat.clone(), tr.aflat.clone(), tr.fp.exp_avg.clone(), tr.a_m.clone()))
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= 1e-6 + 1e-5 * float(a.abs().max())
+
+
+def test_search_trainer_remainder_batch_runs_eagerly():
+    """a last batch of another size must not be broadcast into the captured batch"""
+    from nas_3d_unet_amd import nas
+    from nas_3d_unet_amd.train import SearchTrainer
+    cfg = orc.DEFAULT_CFG._replace(depth=2)
+    rng = np.random.default_rng(29)
+    mk = lambda b: (torch.from_numpy(rng.standard_normal((b, 4, 16, 16, 16)).astype(np.float32)).cuda(),
+                    torch.from_numpy((rng.uniform(0, 1, (b, 3, 16, 16, 16)) < 0.3).astype(np.float32)).cuda())
+    (x, t), (vx, vt), (x1, t1), (vx1, vt1) = mk(2), mk(2), mk(1), mk(1)
+    out = []
+    for graph in (True, False):
+        net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)
+        fill_module(net)
+        net.kernel.last_conv[0].dropout = None
+        tr = SearchTrainer(net.cuda(), graph=graph)
+        tr.step(x, t, vx, vt)
+        la, lw = tr.step(x1, t1, vx1, vt1)
+        out.append((float(la), float(lw)))
+    np.testing.assert_allclose(out[0], out[1], rtol=0, atol=2e-6)

@@ -56,3 +56,41 @@ def test_lr_schedule_follows_through_graph_replay():
     for _ in range(4):
         l_const = float(tr.step(x, t))
     assert abs(l_const - out[1][0]) > 1e-6
+
+
+def test_remainder_batch_runs_eagerly():
+    """the reference's generator yields a smaller last batch; the captured graph is for one shape, so that step
+    must run eagerly instead of broadcasting the sample into the captured batch"""
+    from nas_3d_unet_amd.train import Trainer
+    key, kind, gname, depth, size, batch, adam = [c for c in gc.net_cases() if c[6] and c[1] == "searched"][0]
+    xn, tn = gc.net_batch(key, batch, size)
+    x, t = dev(xn), dev(tn)
+    out = []
+    for graph in (True, False):
+        net, _ = build_net(kind, gname, depth)
+        tr = Trainer(net, graph=graph)
+        tr.step(x, t)
+        out.append(float(tr.step(x[:1], t[:1])))
+        out.append(float(tr.step(x, t)))
+    np.testing.assert_allclose(out[:2], out[2:], rtol=0, atol=2e-6)
+
+
+def test_data_parallel_property_on_the_hip_path():
+    """SURVEY 5.8 / 8(e) on ONE GPU through the HIP kernels: the gradient of a batch of 4 equals the mean of the gradients of
+    its two halves (GroupNorm / SE are per sample, Dice is a mean over (b, c) rows) -- what the all-reduce relies on."""
+    from nas_3d_unet_amd.train import Trainer
+    rng = np.random.default_rng(31)
+    xn = rng.standard_normal((4, 4, 32, 32, 32)).astype(np.float32)
+    tn = (rng.uniform(0, 1, (4, 3, 32, 32, 32)) < 0.3).astype(np.float32)
+    for gname in ("G_CONV", "G_ALL"):
+        net, _ = build_net("searched", gname, 4)
+        tr = Trainer(net, graph=False)
+        tr._fwd_bwd(dev(xn), dev(tn))
+        whole = tr.fp.grad.clone()
+        tr._fwd_bwd(dev(xn[:2]), dev(tn[:2]))
+        half = tr.fp.grad.clone()
+        tr._fwd_bwd(dev(xn[2:]), dev(tn[2:]))
+        half += tr.fp.grad
+        half *= 0.5
+        tot = float(whole.double().norm())
+        assert float((whole - half).double().norm()) <= 2e-5 * tot, gname

@@ -219,3 +219,71 @@ def test_channel_plan_matches_oracle_and_rejects_unsupported_widths():
     for bad in ((2, 3, 3, True), (5, 3, 3, True), (6, 2, 3, False)):
         with pytest.raises(NotImplementedError, match="multiple of 4"):
             unet.cell_specs(*bad)
+
+
+def test_search_checkpoint_interop_with_torch_adam(tmp_path):
+    """search.py:166-176 / 108-127: optim_shell / optim_kernel / both schedulers / geno_count round-trip through torch objects"""
+    import torch
+    from collections import Counter
+    from nas_3d_unet_amd import checkpoint as ck, nas
+    from nas_3d_unet_amd.train import SearchTrainer
+    tr = SearchTrainer(nas.ShellNet(4, 4, 3, 2, 3, False, True), graph=False)    # construction only: no kernel runs on the CPU
+    g = torch.Generator().manual_seed(0)
+    tr.fp.exp_avg.copy_(torch.randn(tr.fp.numel, generator=g)); tr.fp.exp_avg_sq.copy_(torch.rand(tr.fp.numel, generator=g))
+    tr.a_m.copy_(torch.randn(tr.a_m.numel(), generator=g)); tr.a_v.copy_(torch.rand(tr.a_v.numel(), generator=g))
+    tr.fp.step.fill_(9); tr.a_step.fill_(9)
+    tr.set_shell_lr(5e-4); tr.set_kernel_lr(2.5e-4)
+    tr.shell_scheduler.num_bad_epochs, tr.kernel_scheduler.num_bad_epochs = 3, 5
+    sd = ck.search_state_dicts(tr, epoch=4, geno_count=Counter({"g": 2}), history={"loss": [0.6]}, best_loss=0.4)
+    assert set(sd) == {"epoch", "geno_count", "history", "model_param", "optim_shell", "optim_kernel", "kernel_scheduler", "shell_scheduler", "best_loss"}
+    path = tmp_path / "last.pth"
+    torch.save(sd, path)
+    sd2 = torch.load(path, weights_only=False)
+    ref = nas.ShellNet(4, 4, 3, 2, 3, False, True)
+    ref.load_state_dict(sd2["model_param"])
+    osh, okn = torch.optim.Adam(ref.alphas()), torch.optim.Adam(ref.kernel.parameters())
+    osh.load_state_dict(sd2["optim_shell"]); okn.load_state_dict(sd2["optim_kernel"])
+    assert osh.param_groups[0]["lr"] == 5e-4 and okn.param_groups[0]["lr"] == 2.5e-4
+    a0 = list(ref.alphas())[1]
+    o = tr.afp.offsets[1]
+    assert torch.equal(osh.state[a0]["exp_avg"], tr.a_m[o:o + a0.numel()].view(a0.shape)) and float(osh.state[a0]["step"]) == 9
+    tr2 = SearchTrainer(nas.ShellNet(4, 4, 3, 2, 3, False, True), graph=False)
+    back = dict(sd2, optim_shell=osh.state_dict(), optim_kernel=okn.state_dict())
+    epoch, gc_, _, best = ck.load_search_state_dicts(tr2, back)
+    assert epoch == 5 and gc_["g"] == 2 and best == 0.4 and tr2.lr_shell == 5e-4 and tr2.lr_kernel == 2.5e-4
+    assert int(tr2.a_step) == 9 and int(tr2.fp.step) == 9 and tr2.shell_scheduler.num_bad_epochs == 3 and tr2.kernel_scheduler.num_bad_epochs == 5
+    for p, o in zip(tr.aparams, tr.afp.offsets):
+        n = p.numel()
+        assert torch.equal(tr2.a_m[o:o + n], tr.a_m[o:o + n]) and torch.equal(tr2.a_v[o:o + n], tr.a_v[o:o + n])
+    assert torch.equal(tr2.fp.exp_avg, tr.fp.exp_avg) or all(
+        torch.equal(tr2.fp.exp_avg[o:o + p.numel()], tr.fp.exp_avg[o:o + p.numel()]) for p, o in zip(tr.fp.params, tr.fp.offsets))
+
+
+def test_genotype_file_is_parsed_not_evaluated(tmp_path):
+    """a genotype file is data -- no class lookup while unpickling, no eval of its text"""
+    import pickle
+    import pytest
+    from nas_3d_unet_amd import checkpoint as ck
+    bad = tmp_path / "bad.pkl"
+    with open(bad, "wb") as f:
+        pickle.dump(("__import__('os').system('true')", 1), f)
+    with pytest.raises(ValueError):
+        ck.load_genotype(bad)
+    with open(bad, "wb") as f:
+        pickle.dump((pytest.raises, 1), f)     # needs a class / function lookup
+    with pytest.raises(pickle.UnpicklingError):
+        ck.load_genotype(bad)
+
+
+def test_dropout_gate_host_generator_is_uniform():
+    """the counter-based generator behind n3d_dropout3d_gate (host-callable twin n3d_dropout3d_uniform): values in [0, 1),
+    deterministic, mean 1/2, different counters give different streams"""
+    import ctypes as C
+    import numpy as np
+    from nas_3d_unet_amd import _lib
+    lib = _lib.load()
+    u0 = np.array([lib.n3d_dropout3d_uniform(C.c_uint64(77), 0, i) for i in range(4000)])
+    u1 = np.array([lib.n3d_dropout3d_uniform(C.c_uint64(77), 1, i) for i in range(4000)])
+    assert u0.min() >= 0.0 and u0.max() < 1.0 and abs(u0.mean() - 0.5) < 0.02 and abs((u0 < 0.1).mean() - 0.1) < 0.02
+    assert not np.array_equal(u0, u1)
+    assert lib.n3d_dropout3d_uniform(C.c_uint64(77), 0, 5) == u0[5]

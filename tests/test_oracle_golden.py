@@ -205,3 +205,62 @@ def test_genotype(golden, key):
     gu = orc.parse_genotype(a1, gc.case_alpha_matrix(key + "/a2u", 9, 4), 3, False)
     assert [n for n, _ in gd] == list(g[key + "/down_names"]) and [i for _, i in gd] == list(g[key + "/down_idx"])
     assert [n for n, _ in gu] == list(g[key + "/up_names"]) and [i for _, i in gu] == list(g[key + "/up_idx"])
+
+
+def _net2_forward(kind, gname, depth, opt, P, x, key, batch):
+    cfg = orc.DEFAULT_CFG._replace(depth=depth)
+    gate = T(gc.case_drop_gate(key, batch, cfg.n_nodes * cfg.init_n_kernels, opt["drop"])) if opt.get("drop") else None
+    if kind == "searched":
+        return orc.searched_forward(P, x, getattr(orc, gname), cfg, drop_mask=gate, return_logits=True)
+    return orc.supernet_forward(P, x, cfg, drop_mask=gate, return_logits=True, normal_w_share=bool(opt.get("wshare")))
+
+
+@pytest.mark.parametrize("key,kind,gname,depth,size,batch,opt", [c for c in gc.net2_cases() if c[4] <= 32])
+def test_nets2(golden, key, kind, gname, depth, size, batch, opt):
+    """train-mode head with a known Dropout3d mask (prim_ops.py:66,72-73) and the shared-alpha supernet (nas.py:109-113)"""
+    g = golden("nets2")
+    cfg = orc.DEFAULT_CFG._replace(depth=depth)
+    specs = orc.searched_param_specs(cfg, getattr(orc, gname)) if kind == "searched" else orc.supernet_param_specs(cfg, bool(opt.get("wshare")))
+    P = orc.make_params(specs, requires_grad=True)
+    xn, tn = gc.net_batch(key, batch, size)
+    p, logits = _net2_forward(kind, gname, depth, opt, P, T(xn), key, batch)
+    loss = orc.dice_loss(p, T(tn))
+    loss.backward()
+    c = size // 2
+    s = slice(c - 3, c + 3)
+    assert abs(float(loss) - float(g[key + "/loss"])) < 2e-6
+    close(logits.detach()[:, :, s, s, s], g[key + "/logits_crop"], rtol=1e-4)
+    close(p.detach()[:, :, s, s, s], g[key + "/probs_crop"], rtol=1e-4)
+    total = float(g[key + "/gnorm_total"])
+    for n, q in P.items():
+        ref = float(g[key + "/gnorm/" + n])
+        assert abs(float(q.grad.double().norm()) - ref) <= 1e-4 * total + 1e-3 * ref, n
+        gk = key + "/grad/" + n
+        if gk in g.files:
+            d = np.abs(q.grad.numpy().astype(np.float64) - g[gk]).max()
+            assert d <= 1e-4 * max(ref, 1e-4 * total), (n, d)
+
+
+def test_search_trajectory(golden):
+    """search step (search.py:211-238) on the oracle: alpha gradients after each architecture pass, both losses, alphas
+    after the update, against the trajectory recorded from the reference modules + torch.optim.Adam"""
+    g = golden("nets2")
+    key, depth, size, batch, steps = gc.search_cases()[0]
+    cfg = orc.DEFAULT_CFG._replace(depth=depth)
+    P = orc.make_params(orc.supernet_param_specs(cfg), requires_grad=True)
+    x, t, vx, vt = (T(a) for a in gc.search_batches(key, batch, size))
+    anames = ("alpha2_down", "alpha2_up", "alpha1_down", "alpha1_up")
+    oa = torch.optim.Adam([P[n] for n in anames])
+    ok = torch.optim.Adam([v for n, v in P.items() if n.startswith("kernel.")])
+    for step in range(steps):
+        oa.zero_grad()
+        la = orc.dice_loss(orc.supernet_forward(P, vx, cfg), vt)
+        la.backward()
+        for n in anames:
+            close(P[n].grad, g["%s/step%d/dalpha/%s" % (key, step, n)], rtol=2e-3 if step else 2e-4)
+        oa.step()
+        ok.zero_grad()
+        lw = orc.dice_loss(orc.supernet_forward(P, x, cfg), t)
+        lw.backward()
+        ok.step()
+        np.testing.assert_allclose([float(la), float(lw)], g["%s/step%d/losses" % (key, step)], rtol=0, atol=2e-5)
