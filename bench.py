@@ -154,7 +154,7 @@ def search_step_bench(args, device):
     net = nas.ShellNet(CFG["in_channels"], CFG["init_n_kernels"], CFG["out_channels"], CFG["depth"], CFG["n_nodes"], False,
                        CFG["channel_change"]).to(device)
     net.train()
-    tr = SearchTrainer(net, graph=not args.no_graph)
+    tr = SearchTrainer(net, graph=not args.no_graph, comm=args.comm)
     xn, tn = synthetic_batch(args.batch, args.size, 1234)
     vxn, vtn = synthetic_batch(args.batch, args.size, 4321)
     x, t, vx, vt = (torch.from_numpy(a).to(device) for a in (xn, tn, vxn, vtn))
@@ -186,6 +186,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--buckets", type=int, default=None, help="gradient buckets of the data-parallel exchange (default: N3D_DP_BUCKETS or 1); "
+                    ">= 2: all-reduce of a bucket on a side stream under the backward of the next one")
+    ap.add_argument("--comm", choices=["torch", "rccl"], default=None, help="all-reduce through torch.distributed (default) or the C ABI's n3d_comm_*")
     ap.add_argument("--workload", choices=["train", "search"], default="train",
                     help="train: searched-net train step (BASELINE configs[1], the contract default); "
                          "search: supernet search step, arch pass + weight pass (configs[2]; informational, N=1 only)")
@@ -212,7 +215,7 @@ def main():
     net = searched.SearchedNet(CFG["in_channels"], CFG["init_n_kernels"], CFG["out_channels"], CFG["depth"],
                                CFG["n_nodes"], CFG["channel_change"], searched.Genotype(**G_CONV)).to(device)
     net.train()  # head Dropout3d(0.5) active, as in training (searched.py:91-93)
-    trainer = Trainer(net, graph=not args.no_graph)
+    trainer = Trainer(net, graph=not args.no_graph, n_buckets=args.buckets, comm=args.comm)
 
     xn, tn = synthetic_batch(args.batch, args.size, 1234 + rank)
     x, t = to_patch_layout(torch.from_numpy(xn).to(device)), torch.from_numpy(tn).to(device)
@@ -245,7 +248,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "searched.py SearchedNet/G_conv train step, batch=%d 4x%d^3 fp32 per GPU" % (args.batch, args.size),
                        "global_batch": world * args.batch, "patch": [4, args.size, args.size, args.size],
-                       "parallelism": "dp%d" % world, "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "final_loss": round(final_loss, 5)},
+                       "parallelism": "dp%d" % world, "dp_buckets": len(trainer.sync.ranges) if trainer.dp_path else None, "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "final_loss": round(final_loss, 5)},
             "whole_net": {"tflops_fwd_bwd": round(value * FLOP_FWD_BWD_PER_PATCH / 1e12, 3),
                           "algorithmic_gbs": round(value * 3 * BYTES_FWD_PER_PATCH / 1e9, 1),
                           "hbm_frac_of_8TBs": round(value * 3 * BYTES_FWD_PER_PATCH / 1e9 / world / PEAK_HBM_GBS, 4)},

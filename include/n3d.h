@@ -394,6 +394,19 @@ int n3d_stitch(const float* patches, int64_t sb, int64_t sc, int64_t sv, int C, 
                double* out, int FX, int FY, int FZ, int ox, int oy, int oz, void* stream);
 int n3d_tumor_labels(const double* pred, int64_t N, double threshold, int inclusive, uint8_t* out, void* stream);
 
+/* ---- RCCL exchange step of data-parallel training (no reference counterpart: config.yml:54 `multi_gpus` is never read;
+ * SURVEY 8(e)).  One process per GPU; the hot path's only exchange is a SUM all-reduce of the flat fp32 gradient buffer, in
+ * place, stream-ordered on `stream` (a side HIP stream lets it run under the backward kernels of the next bucket).
+ * RCCL is bound with dlopen at first use (the copy already in the process -- torch's -- wins).
+ * n3d_comm_unique_id: rank 0 fills 128 bytes (ncclUniqueId) that the host distributes out of band;
+ * n3d_comm_init: ncclCommInitRank on the CURRENT HIP device (collective: every rank calls it). */
+#define N3D_COMM_ID_BYTES 128
+int n3d_comm_available(void);
+int n3d_comm_unique_id(void* id_out /* N3D_COMM_ID_BYTES */);
+int n3d_comm_init(const void* id, int world, int rank, void** comm_out);
+int n3d_comm_allreduce_sum(void* comm, float* buf, int64_t n, void* stream);
+int n3d_comm_destroy(void* comm);
+
 /* ---- flat Adam (train.py:49,128; search.py:103-104,228,238): torch.optim.Adam defaults ------------
  * step_ptr: device int32 holding the number of steps already taken; if inc_step != 0 a second tiny
  * launch increments it after the update (graph-replay safe).  grad_scale multiplies g (DP mean). */

@@ -476,6 +476,10 @@ class MixedOpFn(torch.autograd.Function):
 # whole-net autograd node
 # =================================================================================================
 WHOLE_NET = True  # nets run stems + cells as ONE autograd node (NetFn); False: one node per stem / cell
+# data-parallel trainers: called as CELL_DONE_HOOK(k) inside NetFn.backward when every parameter gradient of cell k (k = index
+# into down_cells + up_cells; -1 = the stems, i.e. the end) has been launched -- the point where a gradient bucket can be handed
+# to the all-reduce while the backward of the remaining cells goes on (train.Trainer)
+CELL_DONE_HOOK = None
 
 
 class _NetPlan:
@@ -559,6 +563,8 @@ class NetFn(torch.autograd.Function):
             for slot, d in ((0 if down else 1, da1), (2 if down else 3, da2)):
                 if d is not None:
                     das[slot] = d if das[slot] is None else das[slot].add_(d)
+            if CELL_DONE_HOOK is not None:
+                CELL_DONE_HOOK(k)
         need_x = ctx.needs_input_grad[1]
         dx = None
         n0 = len(nplan.stem0.params())
@@ -570,5 +576,7 @@ class NetFn(torch.autograd.Function):
             if need_x:
                 dx = d if dx is None else dx + d
         ctx.st0 = ctx.st1 = ctx.states = None
+        if CELL_DONE_HOOK is not None:
+            CELL_DONE_HOOK(-1)
         return (None, dx) + tuple(d if ctx.needs_input_grad[2 + i] else None for i, d in enumerate(das)) + \
             tuple(g if ctx.needs_input_grad[6 + i] else None for i, g in enumerate(grads))

@@ -8,9 +8,12 @@ MI355X-first mechanics (none of which the reference has):
     launch updates everything (n3d_adam_step);
   * forward + backward (+ Adam) of a fixed-shape step is captured once into a HIP graph and
     replayed, which removes the per-kernel host launch cost (~300 launches per step);
-  * data parallel: one process per GPU, the flat gradient buffer is all-reduced with RCCL
-    (torch.distributed backend "nccl") in a few large buckets, issued on a side stream as soon as
-    the backward graph segment that fills the bucket has been enqueued.
+  * data parallel: one process per GPU, parameters broadcast once, per step a SUM all-reduce of the flat gradient
+    buffer over RCCL (torch.distributed backend "nccl", or the C ABI's n3d_comm_* with N3D_COMM=rccl), the mean folded
+    into the Adam kernel.  Default: ONE bucket issued from the step's own stream after the captured forward + backward
+    graph (7.3 MB is latency-bound on xGMI and a stream hop costs more than it hides on one GPU).  n_buckets >= 2:
+    the step runs without autograd as graph segments split at cell boundaries of the backward pass; the bucket a segment
+    completes is all-reduced on a side HIP stream while the next segment's backward kernels run.
 """
 from __future__ import annotations
 
@@ -102,35 +105,84 @@ class PlateauLR:
 
 
 class GradSync:
-    """Bucketed mean all-reduce of one flat gradient buffer (works with RCCL on GPUs and gloo on CPU tensors).
+    """Bucketed SUM all-reduce of one flat gradient buffer (RCCL on GPUs, gloo on CPU tensors); callers divide by the world
+    size (folded into the Adam kernel).
 
-    xGMI is point-to-point (7 links per GPU) and the whole payload is 2-7 MB (searched net) / 27 MB
-    (supernet), so the collective is latency-bound: a few large buckets, never one call per tensor."""
+    xGMI is point-to-point (7 links per GPU) and the whole payload is 2-7 MB (searched net) / 27 MB (supernet), so the
+    collective is latency-bound: a few large buckets, never one call per tensor.  `ranges`: the buckets as (begin, end)
+    element ranges in ISSUE order (default: n_buckets equal slices).  backend "torch" = torch.distributed.all_reduce;
+    "rccl" = the C ABI's n3d_comm_allreduce_sum on a communicator of its own (unique id exchanged through the process group)."""
 
-    def __init__(self, flat_grad, process_group=None, n_buckets=2, comm_stream=None):
+    def __init__(self, flat_grad, process_group=None, n_buckets=2, comm_stream=None, ranges=None, backend=None):
         self.g = flat_grad
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         n = flat_grad.numel()
         nb = max(1, min(n_buckets, n // 4 if n >= 4 else 1))
         self.edges = [n * i // nb // 4 * 4 for i in range(nb)] + [n]
+        self.ranges = list(ranges) if ranges is not None else list(zip(self.edges[:-1], self.edges[1:]))
         self.comm_stream = comm_stream
         self.force = dist.is_initialized() and os.environ.get("N3D_FORCE_DP") == "1"  # see Trainer.dp_path
+        self.active = self.world > 1 or self.force
+        self.backend = backend or os.environ.get("N3D_COMM", "torch")
+        self._comm = None
+        if self.backend == "rccl" and self.active and flat_grad.is_cuda:
+            self._init_rccl()
+
+    def _init_rccl(self):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        rank = dist.get_rank(self.pg)
+        buf = (C.c_char * 128)()
+        if rank == 0:
+            _lib.check(lib.n3d_comm_unique_id(buf), "n3d_comm_unique_id")
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=0, group=self.pg)   # the 128-byte id travels out of band
+        comm = C.c_void_p()
+        idb = (C.c_char * 128).from_buffer_copy(box[0])
+        _lib.check(lib.n3d_comm_init(idb, self.world, rank, C.byref(comm)), "n3d_comm_init")
+        self._comm = comm
+
+    def reduce_range(self, i):
+        """SUM all-reduce of bucket i on the CURRENT stream"""
+        if not self.active:
+            return
+        a, b = self.ranges[i]
+        if b <= a:
+            return
+        if self._comm is not None:
+            from . import _lib
+            import ctypes as C
+            _lib.check(_lib.load().n3d_comm_allreduce_sum(self._comm, C.c_void_p(self.g.data_ptr() + 4 * a), b - a,
+                                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "n3d_comm_allreduce_sum")
+        else:
+            dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.pg)
 
     def all_reduce(self):
-        """sum-reduce every bucket; callers divide by world size (folded into the Adam kernel)."""
-        if self.world == 1 and not self.force:
+        """sum-reduce every bucket, in issue order"""
+        if not self.active:
             return
         if self.comm_stream is not None:
             cs = self.comm_stream
             cs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cs):
-                for a, b in zip(self.edges[:-1], self.edges[1:]):
-                    dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.pg)
+                for i in range(len(self.ranges)):
+                    self.reduce_range(i)
             torch.cuda.current_stream().wait_stream(cs)
         else:
-            for a, b in zip(self.edges[:-1], self.edges[1:]):
-                dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.pg)
+            for i in range(len(self.ranges)):
+                self.reduce_range(i)
+
+
+class _Ctx:
+    """stand-in for an autograd context when a Function's forward / backward are called directly (Trainer's pipeline)"""
+
+    def __init__(self, needs):
+        self.needs_input_grad = needs
+
+    def mark_non_differentiable(self, *a):
+        pass
 
 
 def flatten_params(params, device=None):
@@ -156,10 +208,11 @@ class Trainer:
     """One searched-net (or any model built from nas_3d_unet_amd ops) training step.
 
     step(x, t): x (B,4,S,S,S), t (B,3,S,S,S) fp32 device tensors -> loss (0-d device tensor,
-    no host sync).  With graph=True the first call captures, later calls replay."""
+    no host sync).  With graph=True the first call captures, later calls replay.
+    n_buckets >= 2 (data parallel only): bucketed gradient exchange overlapped with backward, see the module docstring."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph=True, process_group=None,
-                 n_buckets=1, params=None):
+                 n_buckets=None, params=None, comm=None):
         self.model = model
         self.loss_fn = WeightedDiceLoss()
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -169,23 +222,69 @@ class Trainer:
         self.use_graph = graph
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
-        # N3D_FORCE_DP=1: take the multi-GPU code path (eager all-reduce on the comm stream + eager Adam after the graph)
-        # even in a 1-rank group -- lets a single-GPU box exercise exactly what N > 1 runs
+        # N3D_FORCE_DP=1: take the multi-GPU code path (all-reduce + eager Adam after the graph) even in a 1-rank group --
+        # lets a single-GPU box exercise exactly what N > 1 runs
         self.dp_path = self.world > 1 or (dist.is_initialized() and os.environ.get("N3D_FORCE_DP") == "1")
+        if n_buckets is None:
+            n_buckets = int(os.environ.get("N3D_DP_BUCKETS", "1"))
         self.n_buckets = max(1, n_buckets)
         self._graph = None
+        self._segments = None
         self._static_x = self._static_t = self._static_loss = None
-        # one bucket = nothing to overlap: the collective is issued from the step's own stream (a hop through a second
-        # stream costs two cross-stream waits, ~0.3 ms per step around a graph launch); N3D_COMM_STREAM=1 restores the hop
-        want_cs = self.dp_path and (self.n_buckets > 1 or os.environ.get("N3D_COMM_STREAM") == "1")
-        self._comm_stream = torch.cuda.Stream(device=self.device) if want_cs else None
         self.ctx = K.StepContext(self.device)  # batched weight packing + deferred wgrad reductions
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)  # read by the Adam kernel
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
         self.scheduler = PlateauLR(lambda: self.lr, self.set_lr)  # train.py:50: ReduceLROnPlateau(factor=0.5)
-        self.sync = GradSync(self.fp.grad, self.pg, self.n_buckets, self._comm_stream)
+        self._buckets = self._bucket_plan() if (self.dp_path and self.n_buckets > 1) else None
+        # one bucket = nothing to overlap: the collective is issued from the step's own stream (a hop through a second
+        # stream costs two cross-stream waits around a graph launch); N3D_COMM_STREAM=1 restores the hop
+        want_cs = self.dp_path and (self._buckets is not None or os.environ.get("N3D_COMM_STREAM") == "1")
+        self._comm_stream = torch.cuda.Stream(device=self.device) if (want_cs and self.device.type == "cuda") else None
+        ranges = [r for _, r in self._buckets] if self._buckets is not None else None
+        self.sync = GradSync(self.fp.grad, self.pg, 1, self._comm_stream, ranges, comm)
         if self.world > 1:
             dist.broadcast(self.fp.flat, src=0, group=self.pg)
+
+    # -- bucket plan ------------------------------------------------------------------------------
+    def _bucket_plan(self):
+        """[(cell index whose backward completes the bucket (-1 = the stems, i.e. the end), (begin, end) flat range)] in issue
+        order, or None when the model is not a stems / down_cells / up_cells / last_conv net with a fusable head.
+        Backward finishes the head first, then the cells last to first, then the stems, and `model.parameters()` lists
+        stems, cells, head -- so what is complete after cell k is the TAIL of the flat buffer starting at cell k's first
+        parameter.  Bucket j closes at the first point of the backward walk where at least thresholds[j] of the gradient
+        bytes are complete; the last bucket closes at the end."""
+        m = self.model
+        if not all(hasattr(m, a) for a in ("stem0", "stem1", "down_cells", "up_cells", "last_conv")):
+            return None
+        off = {id(p): (o, o + (p.numel() + 3) // 4 * 4) for p, o in zip(self.fp.params, self.fp.offsets)}
+        cells = list(m.down_cells) + list(m.up_cells)
+        order = [m.stem0, m.stem1] + cells + [m.last_conv]
+        spans, pos = [], 0
+        for mod in order:
+            ps = list(mod.parameters())
+            if not ps or any(id(q) not in off for q in ps):
+                return None
+            lo, hi = min(off[id(q)][0] for q in ps), max(off[id(q)][1] for q in ps)
+            if lo != pos:
+                return None          # not the contiguous stems / cells / head order: keep the single bucket
+            spans.append((lo, hi))
+            pos = hi
+        total = self.fp.numel
+        if pos != total:
+            return None
+        n = self.n_buckets
+        thresholds = [0.85] if n == 2 else [0.4 + (0.92 - 0.4) * j / (n - 2) for j in range(n - 1)]
+        plan, end, j = [], total, 0
+        for k in reversed(range(len(cells))):
+            if j >= len(thresholds):
+                break
+            start = spans[2 + k][0]
+            if (total - start) / total >= thresholds[j] and start < end and k > 0:
+                plan.append((k, (start, end)))
+                end = start
+                j += 1
+        plan.append((-1, (0, end)))
+        return plan if len(plan) > 1 else None
 
     # -- pieces ---------------------------------------------------------------------------------
     def _fwd_bwd(self, x, t):
@@ -202,6 +301,55 @@ class Trainer:
             self.ctx.freeze()              # first pass only recorded which weights / layouts are needed
         return loss.detach()
 
+    def _pipeline(self, x, t, on_bucket):
+        """forward + Dice + backward WITHOUT autograd: fused.NetFn and head.HeadDiceFn are called directly, so the backward walk
+        is one Python function on this thread and can hand over gradient buckets on the way: on_bucket(j) is called as soon as
+        every gradient of self._buckets[j] has been launched (its deferred weight-gradient reductions included)."""
+        from . import head as _head, programs as _P
+        m = self.model
+        plan = getattr(m, "_net_plan", None)
+        if plan is None:
+            plan = m._net_plan = _fused.net_plan(m, supernet=False)
+        op = m.last_conv[0]
+        closes = {k: j for j, (k, _) in enumerate(self._buckets)}
+
+        def hook(k):
+            j = closes.get(k)
+            if j is not None:
+                self.ctx.flush_final()
+                on_bucket(j)
+
+        with torch.no_grad(), K.step_context(self.ctx):
+            self.ctx.pack_all()
+            nctx = _Ctx((False, False) + (False,) * 4 + (True,) * len(plan.params))
+            body = _fused.NetFn.forward(nctx, plan, x, None, None, None, None, *plan.params)
+            gate = _P.draw_gate(op.dropout, op.training, body.shape[0], body.shape[1], body.device)
+            hctx = _Ctx((False, False, True, False, True, True))
+            loss, _ = _head.HeadDiceFn.forward(hctx, gate, float(self.loss_fn.smooth), body, t, op.conv.weight, op.conv.bias)
+            dbody = _head.HeadDiceFn.backward(hctx, self._one, None)[2]
+            prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True
+            prev_hook, _fused.CELL_DONE_HOOK = _fused.CELL_DONE_HOOK, hook
+            try:
+                _fused.NetFn.backward(nctx, dbody)
+            finally:
+                _fused.REUSE_GRAD_OUTPUT, _fused.CELL_DONE_HOOK = prev, prev_hook
+        if not self.ctx.frozen:
+            self.ctx.freeze()
+        return loss
+
+    def _pipeline_ok(self, x):
+        from . import head as _head
+        m = self.model
+        return (self._buckets is not None and _fused.WHOLE_NET and isinstance(self.loss_fn, WeightedDiceLoss)
+                and not hasattr(m, "kernel") and _head.fusable(m.last_conv, torch.empty((1, m.last_conv[0].conv.weight.shape[1], 1, 1, 1), device="meta")))
+
+    def _reduce_on_side(self, j):
+        """bucket j is complete on the current stream: all-reduce it on the comm stream"""
+        cs = self._comm_stream
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            self.sync.reduce_range(j)
+
     def _allreduce(self):
         self.sync.all_reduce()
 
@@ -213,26 +361,37 @@ class Trainer:
         self.lr = float(lr)
         self.lr_dev.fill_(self.lr)
 
-    # -- public ---------------------------------------------------------------------------------
-    def step(self, x, t):
-        if not self.use_graph:
+    def _eager(self, x, t):
+        if self.dp_path and self._pipeline_ok(x):
+            loss = self._pipeline(x, t, self._reduce_on_side)
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        else:
             loss = self._fwd_bwd(x, t)
             if self.dp_path:
                 self._allreduce()
-            self._update()
-            return loss
-        if self._graph is None:
+        self._update()
+        return loss
+
+    # -- public ---------------------------------------------------------------------------------
+    def step(self, x, t):
+        if not self.use_graph:
+            return self._eager(x, t)
+        if self._graph is None and self._segments is None:
             self._capture(x, t)
         if x.shape != self._static_x.shape or t.shape != self._static_t.shape:
             # a batch of another shape (the reference's generator yields a smaller last batch of an epoch): the captured
             # graph is for one shape only, so this step runs eagerly (same kernels, same update)
-            loss = self._fwd_bwd(x, t)
-            if self.dp_path:
-                self._allreduce()
-            self._update()
-            return loss
+            return self._eager(x, t)
         self._static_x.copy_(x)
         self._static_t.copy_(t)
+        if self._segments is not None:
+            # bucketed exchange: segment j's graph completes bucket j; its all-reduce runs on the comm stream under segment j+1
+            for j, g in enumerate(self._segments):
+                g.replay()
+                self._reduce_on_side(j)
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+            self._update()
+            return self._static_loss
         self._graph.replay()
         if self.dp_path:
             self._allreduce()
@@ -242,22 +401,47 @@ class Trainer:
     def _capture(self, x, t):
         self._static_x = x.clone()
         self._static_t = t.clone()
-        # warm-up on a side stream (allocator + lazy module state), restoring the weights afterwards
-        keep = self.fp.flat.clone()
+        segmented = self.dp_path and self._pipeline_ok(x)
+        # warm-up on a side stream (allocator + lazy module state); no optimizer launch, the weights stay as they are
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
-                self._fwd_bwd(self._static_x, self._static_t)
+                if segmented:
+                    self._pipeline(self._static_x, self._static_t, lambda j: None)
+                else:
+                    self._fwd_bwd(self._static_x, self._static_t)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self.fp.flat.copy_(keep)
+        if segmented:
+            return self._capture_segments(s)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):  # RCCL's watchdog thread may touch the runtime meanwhile
             self._static_loss = self._fwd_bwd(self._static_x, self._static_t)
             if not self.dp_path:
                 self._update()
         self._graph = g
+
+    def _capture_segments(self, s):
+        """one HIP graph per gradient bucket: the capture is closed and the next one opened inside the backward walk, at the
+        point where the bucket is complete (all graphs share one memory pool; they are only ever replayed in this order)"""
+        pool = torch.cuda.graph_pool_handle()
+        graphs = [torch.cuda.CUDAGraph()]
+        last = len(self._buckets) - 1
+
+        def on_bucket(j):
+            graphs[-1].capture_end()
+            if j < last:
+                graphs.append(torch.cuda.CUDAGraph())
+                graphs[-1].capture_begin(pool=pool, capture_error_mode="thread_local")
+
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            graphs[0].capture_begin(pool=pool, capture_error_mode="thread_local")
+            self._static_loss = self._pipeline(self._static_x, self._static_t, on_bucket)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._segments = graphs
 
 
 class SearchTrainer:
@@ -269,7 +453,7 @@ class SearchTrainer:
     (the reference computes and discards them, search.py:231) and the weight pass does not compute alpha
     gradients -- requires_grad is switched per pass, so the corresponding kernels are simply not launched."""
 
-    def __init__(self, shell, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph=True):
+    def __init__(self, shell, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph=True, process_group=None, comm=None):
         self.model = shell
         self.loss_fn = WeightedDiceLoss()
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -293,6 +477,17 @@ class SearchTrainer:
         self.lr_kernel_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)
         self.shell_scheduler = PlateauLR(lambda: self.lr_shell, self.set_shell_lr)
         self.kernel_scheduler = PlateauLR(lambda: self.lr_kernel, self.set_kernel_lr)
+        # data parallel: two exchanges per step -- the alpha gradients (180 floats) after the architecture pass,
+        # the kernel-weight gradients (27.4 MB) after the weight pass; weights and alphas broadcast once from rank 0
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        self.dp_path = self.world > 1 or (dist.is_initialized() and os.environ.get("N3D_FORCE_DP") == "1")
+        self.sync_alpha = GradSync(self.agrad, self.pg, 1, None, None, "torch")      # tiny: always through torch.distributed
+        self.sync_kernel = GradSync(self.fp.grad, self.pg, 1, None, None, comm)
+        self._graphs = None
+        if self.world > 1:
+            dist.broadcast(self.fp.flat, src=0, group=self.pg)
+            dist.broadcast(self.aflat, src=0, group=self.pg)
 
     def set_shell_lr(self, lr):
         self.lr_shell = float(lr)
@@ -320,14 +515,21 @@ class SearchTrainer:
             self.ctx.flush_final()
         if not self.ctx.frozen and not arch:
             self.ctx.freeze()
-        if not update:
-            return loss.detach()
-        if arch:
-            K.adam_step(self.aflat, self.agrad, self.a_m, self.a_v, self.a_step, self.lr_shell, self.betas[0], self.betas[1], self.eps,
-                        lr_dev=self.lr_shell_dev)
-        else:
-            self.fp.adam(self.lr_kernel, self.betas, self.eps, lr_dev=self.lr_kernel_dev)
+        if update:
+            self._update(arch)
         return loss.detach()
+
+    def _update(self, arch):
+        """exchange (data parallel) + Adam of the pass that just ran"""
+        if arch:
+            if self.dp_path:
+                self.sync_alpha.all_reduce()
+            K.adam_step(self.aflat, self.agrad, self.a_m, self.a_v, self.a_step, self.lr_shell, self.betas[0], self.betas[1], self.eps,
+                        grad_scale=1.0 / self.world, lr_dev=self.lr_shell_dev)
+        else:
+            if self.dp_path:
+                self.sync_kernel.all_reduce()
+            self.fp.adam(self.lr_kernel, self.betas, self.eps, 0.0, 1.0 / self.world, self.lr_kernel_dev)
 
     def _both(self, x, t, vx, vt, update=True):
         la = self._pass(vx, vt, True, update)
@@ -338,7 +540,7 @@ class SearchTrainer:
         """returns (architecture-pass loss, weight-pass loss) as device scalars"""
         if not self.use_graph:
             return self._both(x, t, val_x, val_t)
-        if self._graph is None:
+        if self._graph is None and self._graphs is None:
             self._sx, self._st, self._svx, self._svt = x.clone(), t.clone(), val_x.clone(), val_t.clone()
             # warm-up on a side stream (allocator + lazy module state) WITHOUT the optimizer launches: weights, alphas,
             # Adam moments and step counters -- possibly just loaded from a checkpoint (search.py:108-127) -- stay untouched
@@ -349,12 +551,28 @@ class SearchTrainer:
                     self._both(self._sx, self._st, self._svx, self._svt, update=False)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):  # RCCL's watchdog thread may touch the runtime meanwhile
-                self._losses = self._both(self._sx, self._st, self._svx, self._svt)
-            self._graph = g
+            if self.dp_path:
+                # one graph per pass (forward + backward only); the exchange and Adam of each pass run eagerly behind it
+                pool = torch.cuda.graph_pool_handle()
+                ga, gw = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
+                    la = self._pass(self._svx, self._svt, True, update=False)
+                with torch.cuda.graph(gw, pool=pool, capture_error_mode="thread_local"):
+                    lw = self._pass(self._sx, self._st, False, update=False)
+                self._losses, self._graphs = (la, lw), (ga, gw)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # RCCL's watchdog thread may touch the runtime meanwhile
+                    self._losses = self._both(self._sx, self._st, self._svx, self._svt)
+                self._graph = g
         if any(a.shape != b.shape for a, b in ((x, self._sx), (t, self._st), (val_x, self._svx), (val_t, self._svt))):
             return self._both(x, t, val_x, val_t)   # remainder batch of an epoch: eager step (the graph is for one shape)
         self._sx.copy_(x); self._st.copy_(t); self._svx.copy_(val_x); self._svt.copy_(val_t)
+        if self._graphs is not None:
+            self._graphs[0].replay()
+            self._update(True)
+            self._graphs[1].replay()
+            self._update(False)
+            return self._losses
         self._graph.replay()
         return self._losses

@@ -1,0 +1,102 @@
+"""GPU: the data-parallel code paths in a 1-rank RCCL group on one GPU (what N > 1 runs, minus the peers): single-bucket and
+bucketed-overlap schedules of Trainer (graph segments split inside the backward walk), the C ABI's n3d_comm_* wrapper, and
+SearchTrainer's two exchanges -- each against the plain single-GPU trainer on the same inputs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from test_gpu_nets import build_net
+from _util import dev, fill_module
+from oracle import ref_path as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def one_rank_group():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["N3D_FORCE_DP"] = "1"
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    yield
+    dist.destroy_process_group()
+    os.environ.pop("N3D_FORCE_DP", None)
+
+
+def _losses_and_weights(tr, x, t, n=3):
+    losses = [float(tr.step(x, t)) for _ in range(n)]
+    return losses, tr.fp.flat.clone()
+
+
+@pytest.mark.parametrize("graph", [True, False])
+@pytest.mark.parametrize("buckets,comm", [(1, "torch"), (2, "torch"), (3, "torch"), (2, "rccl"), (1, "rccl")])
+def test_trainer_dp_schedules_match_single_gpu(one_rank_group, graph, buckets, comm):
+    from nas_3d_unet_amd.train import Trainer
+    rng = np.random.default_rng(41)
+    x = dev(rng.standard_normal((2, 4, 32, 32, 32)).astype(np.float32))
+    t = dev((rng.uniform(0, 1, (2, 3, 32, 32, 32)) < 0.3).astype(np.float32))
+    os.environ.pop("N3D_FORCE_DP")
+    try:
+        net, _ = build_net("searched", "G_CONV", 4)
+        ref = Trainer(net, graph=graph)
+        assert not ref.dp_path
+        lr_, wr = _losses_and_weights(ref, x, t)
+    finally:
+        os.environ["N3D_FORCE_DP"] = "1"
+    net, _ = build_net("searched", "G_CONV", 4)
+    tr = Trainer(net, graph=graph, n_buckets=buckets, comm=comm)
+    assert tr.dp_path and len(tr.sync.ranges) == buckets and (comm != "rccl" or tr.sync._comm is not None)
+    l, w = _losses_and_weights(tr, x, t)
+    if graph and buckets > 1:
+        assert tr._segments is not None and len(tr._segments) == buckets
+    np.testing.assert_allclose(l, lr_, rtol=0, atol=2e-6)
+    assert float((w - wr).abs().max()) <= 2e-6
+
+
+def test_search_trainer_dp_matches_single_gpu(one_rank_group):
+    from nas_3d_unet_amd import nas
+    from nas_3d_unet_amd.train import SearchTrainer
+    cfg = orc.DEFAULT_CFG._replace(depth=2)
+    rng = np.random.default_rng(43)
+    mk = lambda: (dev(rng.standard_normal((2, 4, 16, 16, 16)).astype(np.float32)), dev((rng.uniform(0, 1, (2, 3, 16, 16, 16)) < 0.3).astype(np.float32)))
+    (x, t), (vx, vt) = mk(), mk()
+    out = []
+    for dp in (False, True):
+        if not dp:
+            os.environ.pop("N3D_FORCE_DP")
+        try:
+            net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)
+            fill_module(net)
+            net.kernel.last_conv[0].dropout = None
+            tr = SearchTrainer(net.cuda(), graph=True)
+            assert tr.dp_path == dp
+            ls = [tuple(float(v) for v in tr.step(x, t, vx, vt)) for _ in range(3)]
+            out.append((ls, tr.fp.flat.clone(), tr.aflat.clone()))
+        finally:
+            os.environ["N3D_FORCE_DP"] = "1"
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=2e-6)
+    assert float((out[0][1] - out[1][1]).abs().max()) <= 2e-6 and float((out[0][2] - out[1][2]).abs().max()) <= 2e-6
+
+
+def test_comm_wrapper_allreduce_one_rank():
+    """n3d_comm_* through the C ABI alone (no torch.distributed): unique id -> init -> in-place SUM all-reduce -> destroy"""
+    import ctypes as C
+    from nas_3d_unet_amd import _lib
+    lib = _lib.load()
+    assert lib.n3d_comm_available() == 1
+    idb = (C.c_char * 128)()
+    _lib.check(lib.n3d_comm_unique_id(idb), "unique_id")
+    comm = C.c_void_p()
+    _lib.check(lib.n3d_comm_init(idb, 1, 0, C.byref(comm)), "init")
+    g = torch.arange(1000, dtype=torch.float32, device="cuda")
+    _lib.check(lib.n3d_comm_allreduce_sum(comm, C.c_void_p(g.data_ptr()), g.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "allreduce")
+    torch.cuda.synchronize()
+    assert torch.equal(g.cpu(), torch.arange(1000, dtype=torch.float32))
+    _lib.check(lib.n3d_comm_destroy(comm), "destroy")
