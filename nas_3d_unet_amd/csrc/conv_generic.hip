@@ -1814,8 +1814,24 @@ int n3d_convT_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, co
     if (nblk > 256) nblk = 256;
     const int64_t chunk = cdiv(total, nblk);
     nblk = cdiv(total, chunk);
-    // the slab region is free again once run_wgrad's final kernel has been enqueued (stream order)
     if (!ws || ws_bytes < skip + (size_t)nblk * g->Ci * 4) { set_error("convT_bwd_weight: workspace too small"); return N3D_ERR_WORKSPACE; }
+    if (deferred && deferred->nchunks > 0) {
+      // the weight-gradient slabs of this call stay in `ws` until the caller's batched finalize: the channel sums must not
+      // land on them.  They go behind the slabs if there is room, otherwise the slabs are finalized now.
+      const float* end = deferred->partial + (size_t)deferred->nchunks * deferred->ntiles * deferred->ci_t * deferred->co_t;
+      if (deferred->pbias) {
+        const float* e2 = deferred->pbias + (size_t)deferred->nchunks * deferred->tco * deferred->co_t;
+        if (e2 > end) end = e2;
+      }
+      float* behind = (float*)(((uintptr_t)end + 255) & ~(uintptr_t)255);
+      if ((char*)behind + (size_t)nblk * g->Ci * 4 <= (char*)ws + ws_bytes && (char*)behind >= (char*)wsf) {
+        wsf = behind;
+      } else {
+        if (int e = n3d_wgrad_finalize_batch(deferred, 1, stream)) return e;
+        deferred->nchunks = 0;
+      }
+    }
+    // (not deferred: the slab region is free again once run_wgrad's final kernel has been enqueued -- stream order)
     hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)nblk), dim3(256), (size_t)4 * (g->Ci / 4) * 4 * sizeof(float), s, dy, dyld, total, g->Ci,
                        chunk, wsf);
     hipLaunchKernelGGL(channel_sum_final_kernel, dim3((unsigned)cdiv(g->Ci, 256)), dim3(256), 0, s, wsf, (int)nblk, g->Ci, dbias);

@@ -94,3 +94,26 @@ def test_data_parallel_property_on_the_hip_path():
         half *= 0.5
         tot = float(whole.double().norm())
         assert float((whole - half).double().norm()) <= 2e-5 * tot, gname
+
+
+@pytest.mark.parametrize("gname", ["G_ALL", "G_CONV"])
+def test_trainer_gradients_equal_autograd_gradients(gname):
+    """The trainer's launch batching (pre-packed weights, weight-gradient slabs finalized in ONE launch at the end of backward,
+    gradients written in place into the flat buffer) must not change any gradient: every parameter against the plain
+    autograd path of the same net.  (Round 2 found the channel sums of a transposed depthwise conv's bias gradient landing
+    on its still-pending weight-gradient slabs.)"""
+    from nas_3d_unet_amd import loss
+    from nas_3d_unet_amd.train import Trainer
+    rng = np.random.default_rng(37)
+    x = dev(rng.standard_normal((2, 4, 32, 32, 32)).astype(np.float32))
+    t = dev((rng.uniform(0, 1, (2, 3, 32, 32, 32)) < 0.3).astype(np.float32))
+    net, _ = build_net("searched", gname, 4)
+    loss.WeightedDiceLoss()(net(x), t).backward()
+    ref = {n: p.grad.clone() for n, p in net.named_parameters()}
+    tot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in ref.values())))
+    net2, _ = build_net("searched", gname, 4)
+    tr = Trainer(net2, graph=False)
+    for _ in range(2):     # second pass: frozen context (pre-packed weights)
+        tr._fwd_bwd(x, t)
+        for n, p in net2.named_parameters():
+            assert float((p.grad - ref[n]).double().norm()) <= 1e-5 * tot, n
