@@ -118,12 +118,22 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(batch, size, budget_s=25.0):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(batch, size, budget_s=22.0):
     """The CPU oracle (functional torch-CPU restatement, proven equal to the reference by the golden
-    tests) timed on this box's host cores: forward + Dice + backward at the same batch."""
+    tests) timed on this box's host cores: forward + Dice + backward at the same batch, once with every usable core and once
+    with ONE thread, both on a bounded sample."""
     from oracle import ref_path as orc
     cores = usable_cores()
-    torch.set_num_threads(cores)
     P = orc.make_params(orc.searched_param_specs(orc.DEFAULT_CFG, orc.G_CONV), requires_grad=True)
     xn, tn = synthetic_batch(batch, size, 99)
     x, t = torch.from_numpy(xn), torch.from_numpy(tn)
@@ -133,16 +143,24 @@ def cpu_baseline(batch, size, budget_s=25.0):
             q.grad = None
         l = orc.dice_loss(orc.searched_forward(P, x, orc.G_CONV), t)
         l.backward()
-    one()  # warm-up
-    times = []
-    t_all = time.perf_counter()
-    while len(times) < 7 and (time.perf_counter() - t_all) < budget_s:
-        t0 = time.perf_counter()
-        one()
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return {"value": round(batch / med, 3), "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": "%d timed fwd+bwd iterations of the same net at batch %d, 4x%d^3 fp32 (median %.3f s)" % (len(times), batch, size, med)}
+
+    def timed(threads, max_iters, budget):
+        torch.set_num_threads(threads)
+        one()  # warm-up
+        times, t_all = [], time.perf_counter()
+        while len(times) < max_iters and (time.perf_counter() - t_all) < budget:
+            t0 = time.perf_counter()
+            one()
+            times.append(time.perf_counter() - t0)
+        return float(np.median(times)), len(times)
+
+    med, n = timed(cores, 7, budget_s * 0.5)
+    med1, n1 = timed(1, 2, budget_s * 0.5)
+    torch.set_num_threads(cores)
+    return {"value": round(batch / med, 3), "unit": "patches/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "one_thread": {"value": round(batch / med1, 3), "unit": "patches/s", "cores": 1,
+                           "sample": "%d timed fwd+bwd iterations, median %.2f s" % (n1, med1)},
+            "sample": "%d timed fwd+bwd iterations of the same net at batch %d, 4x%d^3 fp32 (median %.3f s)" % (n, batch, size, med)}
 
 
 def search_step_bench(args, device):
