@@ -201,6 +201,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=2, help="patches per GPU")
     ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: the reference's arithmetic and storage (the contract default); bf16: bf16 STORAGE of the HBM-bound levels' "
+                         "activations, fp32 arithmetic (BASELINE configs[4], quoted at --size 128)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -233,7 +236,7 @@ def main():
     net = searched.SearchedNet(CFG["in_channels"], CFG["init_n_kernels"], CFG["out_channels"], CFG["depth"],
                                CFG["n_nodes"], CFG["channel_change"], searched.Genotype(**G_CONV)).to(device)
     net.train()  # head Dropout3d(0.5) active, as in training (searched.py:91-93)
-    trainer = Trainer(net, graph=not args.no_graph, n_buckets=args.buckets, comm=args.comm)
+    trainer = Trainer(net, graph=not args.no_graph, n_buckets=args.buckets, comm=args.comm, storage="bf16" if args.dtype == "bf16" else None)
 
     xn, tn = synthetic_batch(args.batch, args.size, 1234 + rank)
     x, t = to_patch_layout(torch.from_numpy(xn).to(device)), torch.from_numpy(tn).to(device)
@@ -263,8 +266,8 @@ def main():
             "metric": "4x%d^3 patches/sec (train step: fwd + Dice + bwd + Adam%s)" % (args.size, " + RCCL all-reduce" if world > 1 else ""),
             "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "searched.py SearchedNet/G_conv train step, batch=%d 4x%d^3 fp32 per GPU" % (args.batch, args.size),
+            "vs_baseline": None, "dtype": "f32" if args.dtype == "f32" else "bf16 storage (levels with <= 8 channels per node, stems, head input) / f32 arithmetic", "data": "synthetic",
+            "config": {"workload": "searched.py SearchedNet/G_conv train step, batch=%d 4x%d^3 %s per GPU" % (args.batch, args.size, "fp32" if args.dtype == "f32" else "bf16-storage"),
                        "global_batch": world * args.batch, "patch": [4, args.size, args.size, args.size],
                        "parallelism": "dp%d" % world, "dp_buckets": len(trainer.sync.ranges) if trainer.dp_path else None, "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "final_loss": round(final_loss, 5)},
             "whole_net": {"tflops_fwd_bwd": round(value * FLOP_FWD_BWD_PER_PATCH / 1e12, 3),

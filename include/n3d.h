@@ -44,6 +44,15 @@ extern "C" {
 #define N3D_POOL_MAX 8    /* pooling type (prim_ops.py:160-163) */
 #define N3D_NO_MFMA 16    /* force the generic VALU kernels (A/B testing) */
 #define N3D_PREPACKED 32  /* `ws` already holds this conv's packed weights (written by n3d_pack_batch) */
+/* storage types (bf16 configuration, BASELINE configs[4]): activation pointers are declared `float*` for the fp32 path; with one of
+ * these flags the tensor holds bfloat16 elements instead (pitches then count bf16 elements, 4-channel groups must be 8-byte aligned)
+ * and the kernel converts on load / store, computing in fp32.  Conv family: SRC = the first activation tensor of the call (x; dy of a
+ * data gradient; x of a weight gradient), DST = the second (y; dx and relu_src of a data gradient; dy of a weight gradient).
+ * Epilogue family (n3d_channel_stats / n3d_affine_act*): every activation tensor of one call shares ONE type, N3D_ACT_BF16 (or the
+ * `dtype` field of the term structures). */
+#define N3D_SRC_BF16 64
+#define N3D_DST_BF16 128
+#define N3D_ACT_BF16 64
 
 /* storage type of an activation tensor (entry points that take a dtype argument; all others are fp32) */
 #define N3D_F32 0
@@ -180,6 +189,8 @@ int n3d_convT_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, co
  * n3d_channel_stats: stats[b][row][c] = partial (sum x, sum x^2) over the N voxels (GroupNorm of a tensor
  *   that no conv of ours produced: IdentityOp prim_ops.py:170-174; SE mean prim_ops.py:149). */
 int n3d_channel_stats(const float* x, int64_t ld, int B, int64_t N, int C, double* stats, void* stream);
+/* the same with a storage type (N3D_F32 / N3D_BF16) */
+int n3d_channel_stats_t(const void* x, int64_t ld, int dtype, int B, int64_t N, int C, double* stats, void* stream);
 /* the same for up to N3D_MAX_GROUP_TERMS tensors of one (B, N, C) shape in one launch: xs / lds / stats are host arrays of n entries */
 int n3d_channel_statsN(const float* const* xs, const int64_t* lds, double* const* stats, int n, int B, int64_t N, int C, void* stream);
 /* GroupNorm(G, C) statistics -> per-(b,c) affine y = a*x + b; mean_rstd[b][g] = (mean, rstd) (prim_ops.py:56-58) */
@@ -230,6 +241,7 @@ typedef struct n3d_gn_fwd_term {
   const float* gamma; const float* beta;  /* GroupNorm affine */
   const float* wptr;                      /* optional scalar weight (MixedOp alpha), NULL = 1 */
   float* a_out; float* b_out; float* mean_rstd_out; double* sumraw;  /* saved for backward, as n3d_affine_act_gn */
+  int32_t dtype; int32_t pad_;            /* storage of raw (N3D_F32 / N3D_BF16); entry points with a `flags` argument use N3D_ACT_BF16 */
 } n3d_gn_fwd_term;
 int n3d_affine_act_gn2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int G, float eps, float* out, int64_t old_,
                        float* out1 /* NULL: out = term0 + term1 (a node); else two independent outputs (the two preprocess
@@ -244,6 +256,7 @@ typedef struct n3d_gn_bwd_term {
   float* draw; int64_t drld;              /* d(raw), output of the apply pass */
   float* dgamma; float* dbeta; float* dalpha; float* dbias_conv;   /* parameter gradients (dalpha / dbias_conv may be NULL) */
   float* cA; float* cB; float* cC;        /* [B][C] draw = cA*g + cB + cC*raw: written by n3d_gn_bwd_coeffs2, read by n3d_affine_act_bwd_apply2 */
+  int32_t dtype; int32_t pad_;            /* storage of raw / draw and of the output gradient(s) of the call (N3D_F32 / N3D_BF16) */
 } n3d_gn_bwd_term;
 /* dout1: NULL = both terms share the output gradient dout (a node); else the gradient of term1's own output */
 int n3d_affine_act_bwd_reduce2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,

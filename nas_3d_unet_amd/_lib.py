@@ -41,7 +41,7 @@ class GnFwdTerm(C.Structure):
     """n3d_gn_fwd_term (include/n3d.h)"""
     _fields_ = [("raw", C.c_void_p), ("rld", C.c_int64), ("stats", C.c_void_p), ("rows", C.c_int32), ("relu", C.c_int32),
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("wptr", C.c_void_p), ("a_out", C.c_void_p), ("b_out", C.c_void_p),
-                ("mean_rstd_out", C.c_void_p), ("sumraw", C.c_void_p)]
+                ("mean_rstd_out", C.c_void_p), ("sumraw", C.c_void_p), ("dtype", C.c_int32), ("pad_", C.c_int32)]
 
 
 class GnBwdTerm(C.Structure):
@@ -49,7 +49,8 @@ class GnBwdTerm(C.Structure):
     _fields_ = [("raw", C.c_void_p), ("rld", C.c_int64), ("a", C.c_void_p), ("b", C.c_void_p), ("sums", C.c_void_p),
                 ("rows", C.c_int32), ("relu", C.c_int32), ("gamma", C.c_void_p), ("mean_rstd", C.c_void_p), ("wptr", C.c_void_p),
                 ("sumraw", C.c_void_p), ("draw", C.c_void_p), ("drld", C.c_int64), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
-                ("dalpha", C.c_void_p), ("dbias_conv", C.c_void_p), ("cA", C.c_void_p), ("cB", C.c_void_p), ("cC", C.c_void_p)]
+                ("dalpha", C.c_void_p), ("dbias_conv", C.c_void_p), ("cA", C.c_void_p), ("cB", C.c_void_p), ("cC", C.c_void_p),
+                ("dtype", C.c_int32), ("pad_", C.c_int32)]
 
 
 class SeTerm(C.Structure):
@@ -131,6 +132,7 @@ PROTOTYPES = {
     "n3d_convT_bwd_data": (_i, [_gp, _p, _i64, _p, _p, _i64, _i, _p, _sz, _p]),
     "n3d_convT_bwd_weight": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i, _p, _sz, C.POINTER(FinalJob), _p]),
     "n3d_channel_stats": (_i, [_p, _i64, _i, _i64, _i, _p, _p]),
+    "n3d_channel_stats_t": (_i, [_p, _i64, _i, _i, _i64, _i, _p, _p]),
     "n3d_gn_coeffs": (_i, [_p, _i, _p, _p, _i, _i, _i, _i64, _f, _p, _p, _p, _p, _p]),
     "n3d_affine_act": (_i, [_p, _i64, _p, _p, _p, _p, _i64, _i, _i64, _i, _i, _p]),
     "n3d_fused_max_rows": (_i, []),
@@ -193,6 +195,7 @@ PROTOTYPES = {
 # flags (include/n3d.h)
 RELU_IN, RELU, ACCUMULATE, POOL_MAX, NO_MFMA, PREPACKED = 1, 2, 4, 8, 16, 32
 F32, BF16 = 0, 1   # N3D_F32 / N3D_BF16
+SRC_BF16, DST_BF16, ACT_BF16 = 64, 128, 64   # storage flags of the conv / epilogue families
 
 _lib = None
 

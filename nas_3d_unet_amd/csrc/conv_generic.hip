@@ -10,14 +10,14 @@
 namespace n3d {
 
 struct GatherArgs {
-  const float* src; int64_t sld; int Ds, Hs, Ws, Cs;
-  float* dst; int64_t dld; int Dd, Hd, Wd, Cd;
+  const void* src; int64_t sld; int Ds, Hs, Ws, Cs;   // TS elements (fp32 or bf16 storage)
+  void* dst; int64_t dld; int Dd, Hd, Wd, Cd;         // TD elements
   const float* wp; int Cdp;
   const float* bias;
   int k, sn, off, dt, den;
   int flags;
   const float* in_gate;
-  const float* relu_src; int64_t rld;
+  const void* relu_src; int64_t rld;                  // TD elements (the tensor whose gradient dst is)
   const float* out_gate;
   double* stats;
   FastDiv fWd, fHd;
@@ -41,7 +41,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   wp[i] = v;
 }
 
-template <int CO_T, int SV, int CSQ>
+template <int CO_T, int SV, int CSQ, typename TS = float, typename TD = float>
 __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
   __shared__ double red[4][CO_T * 2];
   const int b = blockIdx.z, cot = blockIdx.y;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
     const int c = cot * CO_T + j;
     acc[j] = (a.bias && c < a.Cd) ? a.bias[c] : 0.f;
   }
-  const float* srcb = a.src + (int64_t)b * Ns * a.sld;
+  const TS* srcb = reinterpret_cast<const TS*>(a.src) + (int64_t)b * Ns * a.sld;
   const float* gate = a.in_gate ? a.in_gate + (int64_t)b * a.Cs : nullptr;
   const bool relu_in = a.flags & N3D_RELU_IN;
   const int k = a.k;
@@ -152,9 +152,9 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
             ok = ok && nw >= 0 && nw < a.Ws;
             okv[r][kw] = ok;
             const int cw_ = min(max(nw, 0), a.Ws - 1);
-            const float* xs = srcb + (((int64_t)cd_ * a.Hs + ch_) * a.Ws + cw_) * a.sld;
+            const TS* xs = srcb + (((int64_t)cd_ * a.Hs + ch_) * a.Ws + cw_) * a.sld;
 #pragma unroll
-            for (int q = 0; q < CSQ; ++q) xq[r][kw][q] = *reinterpret_cast<const float4*>(xs + q * 4);
+            for (int q = 0; q < CSQ; ++q) xq[r][kw][q] = ld4(xs + q * 4);
           }
         }
 #pragma unroll
@@ -214,13 +214,13 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
         const int tap = (kd * k + kh) * k + kw;
         const float* wr = a.wp + (int64_t)tap * a.Cs * a.Cdp + cot * CO_T;
         if (ok) {
-          const float* xs = srcb + (((int64_t)nd * a.Hs + nh) * a.Ws + nw) * a.sld;
+          const TS* xs = srcb + (((int64_t)nd * a.Hs + nh) * a.Ws + nw) * a.sld;
           if (SV == 4) {
             // four 16-byte loads in flight per step
             for (int c16 = 0; c16 < a.Cs; c16 += 16) {
               float4 q4[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) q4[u] = *reinterpret_cast<const float4*>(xs + min(c16 + u * 4, a.Cs - 4));
+              for (int u = 0; u < 4; ++u) q4[u] = ld4(xs + min(c16 + u * 4, a.Cs - 4));
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 const int c4 = c16 + u * 4;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
             }
           } else {
             for (int c = 0; c < a.Cs; ++c) {
-              float x = xs[c];
+              float x = ld1(xs + c);
               if (relu_in) x = fmaxf(x, 0.f);
               if (gate) x *= gate[c];
               const float* wrow = wr + (int64_t)c * a.Cdp;
@@ -255,30 +255,29 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
   const int c0 = cot * CO_T;
   if (valid) {
     if (a.relu_src) {
-      const float* rs = a.relu_src + ((int64_t)b * Nd + v) * a.rld + c0;
+      const TD* rs = reinterpret_cast<const TD*>(a.relu_src) + ((int64_t)b * Nd + v) * a.rld + c0;
 #pragma unroll
       for (int j = 0; j < CO_T; ++j)
-        if (c0 + j < a.Cd && !(rs[j] > 0.f)) acc[j] = 0.f;
+        if (c0 + j < a.Cd && !(ld1(rs + j) > 0.f)) acc[j] = 0.f;
     }
     if (a.out_gate) {
 #pragma unroll
       for (int j = 0; j < CO_T; ++j)
         if (c0 + j < a.Cd) acc[j] *= a.out_gate[(int64_t)b * a.Cd + c0 + j];
     }
-    float* o = a.dst + ((int64_t)b * Nd + v) * a.dld + c0;
+    TD* o = reinterpret_cast<TD*>(a.dst) + ((int64_t)b * Nd + v) * a.dld + c0;
     const bool accum = a.flags & N3D_ACCUMULATE;
-    if (CO_T % 4 == 0 && (a.Cd % 4 == 0) && (a.dld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0)) {
+    if (CO_T % 4 == 0 && (a.Cd % 4 == 0) && (a.dld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.dst) & (4 * sizeof(TD) - 1)) == 0)) {
 #pragma unroll
       for (int j = 0; j < CO_T; j += 4) {
-        float4* op = reinterpret_cast<float4*>(o + j);
         float4 r = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
-        if (accum) { const float4 p = *op; r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w; acc[j] = r.x; acc[j + 1] = r.y; acc[j + 2] = r.z; acc[j + 3] = r.w; }
-        *op = r;
+        if (accum) { const float4 p = ld4(o + j); r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w; acc[j] = r.x; acc[j + 1] = r.y; acc[j + 2] = r.z; acc[j + 3] = r.w; }
+        st4(o + j, r);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < CO_T; ++j)
-        if (c0 + j < a.Cd) { if (accum) acc[j] += o[j]; o[j] = acc[j]; }
+        if (c0 + j < a.Cd) { if (accum) acc[j] += ld1(o + j); st1(o + j, acc[j]); }
     }
   }
   if (a.stats) {
@@ -313,28 +312,38 @@ static bool gather_class_mode(int den, int k, int Dd, int Hd, int Wd, int Cs, bo
   return den == 2 && k == 3 && Dd % 2 == 0 && Hd % 2 == 0 && Wd % 2 == 0 && vec && (Cs == 4 || Cs == 8 || Cs == 12);
 }
 
-template <int CO_T>
+template <int CO_T, typename TS = float, typename TD = float>
 static void launch_gather_t(GatherArgs a, int B, hipStream_t s) {
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
-  const bool vec = (a.Cs % 4 == 0) && (a.sld % 4 == 0) && aligned16(a.src);
+  const bool vec = (a.Cs % 4 == 0) && (a.sld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.src) & (4 * sizeof(TS) - 1)) == 0);
   a.cls = gather_class_mode(a.den, a.k, a.Dd, a.Hd, a.Wd, a.Cs, vec) ? 1 : 0;
   a.fWh = FastDiv((uint32_t)(a.Wd / 2 > 0 ? a.Wd / 2 : 1)); a.fHh = FastDiv((uint32_t)(a.Hd / 2 > 0 ? a.Hd / 2 : 1));
   dim3 grid((unsigned)(a.cls ? 8 * cdiv(Nd / 8, 256) : cdiv(Nd, 256)), (unsigned)(a.Cdp / CO_T), (unsigned)B);
   const size_t wbytes = (size_t)a.k * a.k * a.k * a.Cs * CO_T * sizeof(float);
-  if (!vec) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 1, 0>), grid, dim3(256), 0, s, a);
-  else if (a.Cs == 4) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4, 1>), grid, dim3(256), wbytes, s, a);
-  else if (a.Cs == 8) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4, 2>), grid, dim3(256), wbytes, s, a);
-  else if (a.Cs == 12) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4, 3>), grid, dim3(256), wbytes, s, a);
-  else hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4, 0>), grid, dim3(256), 0, s, a);
+  if (!vec) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 1, 0, TS, TD>), grid, dim3(256), 0, s, a);
+  else if (a.Cs == 4) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4, 1, TS, TD>), grid, dim3(256), wbytes, s, a);
+  else if (a.Cs == 8) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4, 2, TS, TD>), grid, dim3(256), wbytes, s, a);
+  else if (a.Cs == 12) hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4, 3, TS, TD>), grid, dim3(256), wbytes, s, a);
+  else hipLaunchKernelGGL((conv_gather_kernel<CO_T, 4, 0, TS, TD>), grid, dim3(256), 0, s, a);
 }
 
-static void launch_gather(const GatherArgs& a, int B, hipStream_t s) {
+template <typename TS, typename TD>
+static void launch_gather_d(const GatherArgs& a, int B, hipStream_t s) {
   switch (pick_cot(a.Cd)) {
-    case 16: launch_gather_t<16>(a, B, s); break;
-    case 12: launch_gather_t<12>(a, B, s); break;
-    case 8: launch_gather_t<8>(a, B, s); break;
-    default: launch_gather_t<4>(a, B, s); break;
+    case 16: launch_gather_t<16, TS, TD>(a, B, s); break;
+    case 12: launch_gather_t<12, TS, TD>(a, B, s); break;
+    case 8: launch_gather_t<8, TS, TD>(a, B, s); break;
+    default: launch_gather_t<4, TS, TD>(a, B, s); break;
   }
+}
+
+// storage types of the source / destination tensors: flags N3D_SRC_BF16 / N3D_DST_BF16
+static void launch_gather(const GatherArgs& a, int B, hipStream_t s) {
+  const bool sb = a.flags & N3D_SRC_BF16, db = a.flags & N3D_DST_BF16;
+  if (sb && db) launch_gather_d<bf16_t, bf16_t>(a, B, s);
+  else if (sb) launch_gather_d<bf16_t, float>(a, B, s);
+  else if (db) launch_gather_d<float, bf16_t>(a, B, s);
+  else launch_gather_d<float, float>(a, B, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -344,8 +353,8 @@ static void launch_gather(const GatherArgs& a, int B, hipStream_t s) {
 // voxels.  The generic gather kernel spends a workgroup (weight staging, barrier, block reduction) on every 256 voxels.
 // ------------------------------------------------------------------------------------------------
 struct K1Args {
-  const float* src; int64_t sld; float* dst; int64_t dld; const float* wp; int Cdp; const float* bias;
-  int flags; const float* relu_src; int64_t rld; double* stats; int64_t N;
+  const void* src; int64_t sld; void* dst; int64_t dld; const float* wp; int Cdp; const float* bias;   // src: TS elements, dst / relu_src: TD
+  int flags; const void* relu_src; int64_t rld; double* stats; int64_t N;
   // up: the data gradient of a stride-2 1x1x1 conv -- destination voxel (d,h,w) takes source voxel (d/2,h/2,w/2) when all three
   // are even and nothing otherwise; Ns = source voxels per sample
   int up, Wd, Hd; int64_t Ns; FastDiv fWd, fHd;
@@ -353,7 +362,7 @@ struct K1Args {
 constexpr int K1_VPB = 1024;   // voxels per workgroup
 
 // EXTRA: the data-gradient extras (accumulate into dst, ReLU mask source) are in use -- they cost 8 * CDQ registers per voxel
-template <int CSQ, int CDQ, bool EXTRA>   // Cs = 4 * CSQ, Cd = 4 * CDQ
+template <int CSQ, int CDQ, bool EXTRA, typename TS = float, typename TD = float>   // Cs = 4 * CSQ, Cd = 4 * CDQ
 __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
   constexpr int VPT = EXTRA ? 2 : K1_VPB / 256;   // data-gradient form: no statistics rows to agree on, fewer registers per voxel
   __shared__ __attribute__((aligned(16))) float4 wl[CSQ * 4 * CDQ];
@@ -364,8 +373,8 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
     wl[i] = *reinterpret_cast<const float4*>(a.wp + (int64_t)cs * a.Cdp + q * 4);
   }
   const int64_t base = (int64_t)blockIdx.x * (VPT * 256) + t;
-  const float* sb = a.src + (int64_t)b * (EXTRA && a.up ? a.Ns : a.N) * a.sld;
-  float* db = a.dst + (int64_t)b * a.N * a.dld;
+  const TS* sb = reinterpret_cast<const TS*>(a.src) + (int64_t)b * (EXTRA && a.up ? a.Ns : a.N) * a.sld;
+  TD* db = reinterpret_cast<TD*>(a.dst) + (int64_t)b * a.N * a.dld;
   const bool accum = EXTRA && (a.flags & N3D_ACCUMULATE);
   const float floor_ = (a.flags & N3D_RELU_IN) ? 0.f : -INFINITY;
   float4 x[VPT][CSQ], prev[EXTRA ? VPT : 1][CDQ], msk[EXTRA ? VPT : 1][CDQ];
@@ -390,14 +399,14 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
     }
 #pragma unroll
     for (int q = 0; q < CSQ; ++q) {
-      x[i][q] = *reinterpret_cast<const float4*>(sb + vs * a.sld + q * 4);
+      x[i][q] = ld4(sb + vs * a.sld + q * 4);
       if (EXTRA && !hit) x[i][q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if constexpr (EXTRA) {
 #pragma unroll
       for (int q = 0; q < CDQ; ++q) {
-        prev[i][q] = accum ? *reinterpret_cast<const float4*>(db + vc * a.dld + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        msk[i][q] = a.relu_src ? *reinterpret_cast<const float4*>(a.relu_src + ((int64_t)b * a.N + vc) * a.rld + q * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        prev[i][q] = accum ? ld4(db + vc * a.dld + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        msk[i][q] = a.relu_src ? ld4(reinterpret_cast<const TD*>(a.relu_src) + ((int64_t)b * a.N + vc) * a.rld + q * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
       }
     }
   }
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
         r.x += prev[i][q].x; r.y += prev[i][q].y; r.z += prev[i][q].z; r.w += prev[i][q].w;
       }
       if (ok[i]) {
-        *reinterpret_cast<float4*>(db + (base + i * 256) * a.dld + q * 4) = r;
+        st4(db + (base + i * 256) * a.dld + q * 4, r);
         s1[q * 4] += r.x; s1[q * 4 + 1] += r.y; s1[q * 4 + 2] += r.z; s1[q * 4 + 3] += r.w;
         s2[q * 4] = fmaf(r.x, r.x, s2[q * 4]); s2[q * 4 + 1] = fmaf(r.y, r.y, s2[q * 4 + 1]);
         s2[q * 4 + 2] = fmaf(r.z, r.z, s2[q * 4 + 2]); s2[q * 4 + 3] = fmaf(r.w, r.w, s2[q * 4 + 3]);
@@ -473,18 +482,26 @@ static bool k1_shape_ok(const n3d_conv_geom* g, bool data_grad) {
   return Cs % 4 == 0 && Cs >= 4 && Cs <= 24 && Cd % 4 == 0 && Cd >= 4 && Cd <= 12 && (Cs / 4) * (Cd / 4) <= 6 && N >= 32768;
 }
 
-template <int CSQ, bool EXTRA>
+template <int CSQ, bool EXTRA, typename TS, typename TD>
 static void launch_k1_e(const K1Args& a, int Cd, dim3 grid, hipStream_t s) {
   switch (Cd / 4) {
-    case 1: hipLaunchKernelGGL((conv_k1_kernel<CSQ, 1, EXTRA>), grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((conv_k1_kernel<CSQ, 2, EXTRA>), grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((conv_k1_kernel<CSQ, 3, EXTRA>), grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((conv_k1_kernel<CSQ, 1, EXTRA, TS, TD>), grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((conv_k1_kernel<CSQ, 2, EXTRA, TS, TD>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((conv_k1_kernel<CSQ, 3, EXTRA, TS, TD>), grid, dim3(256), 0, s, a); break;
   }
+}
+template <int CSQ, typename TS, typename TD>
+static void launch_k1_d(const K1Args& a, int Cd, dim3 grid, hipStream_t s) {
+  if ((a.flags & N3D_ACCUMULATE) || a.relu_src || a.up) launch_k1_e<CSQ, true, TS, TD>(a, Cd, grid, s);
+  else launch_k1_e<CSQ, false, TS, TD>(a, Cd, grid, s);
 }
 template <int CSQ>
 static void launch_k1_c(const K1Args& a, int Cd, dim3 grid, hipStream_t s) {
-  if ((a.flags & N3D_ACCUMULATE) || a.relu_src || a.up) launch_k1_e<CSQ, true>(a, Cd, grid, s);
-  else launch_k1_e<CSQ, false>(a, Cd, grid, s);
+  const bool sb = a.flags & N3D_SRC_BF16, db = a.flags & N3D_DST_BF16;
+  if (sb && db) launch_k1_d<CSQ, bf16_t, bf16_t>(a, Cd, grid, s);
+  else if (sb) launch_k1_d<CSQ, bf16_t, float>(a, Cd, grid, s);
+  else if (db) launch_k1_d<CSQ, float, bf16_t>(a, Cd, grid, s);
+  else launch_k1_d<CSQ, float, float>(a, Cd, grid, s);
 }
 
 // weight gradient of the same 1x1x1 convs (stride 1 or 2): dW[co][ci] = sum_v f(x[i(v)][ci]) * dy[v][co], dbias = sum_v dy[v].
@@ -492,12 +509,12 @@ static void launch_k1_c(const K1Args& a, int Cd, dim3 grid, hipStream_t s) {
 // workgroup leaves ONE partial slab ([Ci][Co] + [Co]) for the common fixed-order finalize.  The tiled generic kernel reads dy
 // once per input-channel tile and x in 16-byte pieces of 48-byte voxels.
 struct K1WgArgs {
-  const float* x; int64_t xld; const float* dy; int64_t dyld; float* partial; float* pbias; int64_t total, chunk; int flags;
+  const void* x; int64_t xld; const void* dy; int64_t dyld; float* partial; float* pbias; int64_t total, chunk; int flags;   // x: TS elements, dy: TD elements
   int stride, Wo, Ho, Wi, Hi; int64_t No, Ni; FastDiv fNo, fWo, fHo;
 };
 constexpr int K1W_CHUNK = 2048;   // output voxels per workgroup
 
-template <int CIQ, int COQ>
+template <int CIQ, int COQ, typename TS = float, typename TD = float>
 __global__ __launch_bounds__(256) void conv_k1_wgrad_kernel(K1WgArgs a) {
   constexpr int CI = CIQ * 4, CO = COQ * 4, NV = CI * CO + CO;
   __shared__ float red[4][NV];
@@ -531,9 +548,9 @@ __global__ __launch_bounds__(256) void conv_k1_wgrad_kernel(K1WgArgs a) {
         xi = (int64_t)ub * a.Ni + ((int64_t)(2 * ud) * a.Hi + 2 * uh) * a.Wi + 2 * uw;
       }
 #pragma unroll
-      for (int q = 0; q < CIQ; ++q) xq[u][q] = *reinterpret_cast<const float4*>(a.x + xi * a.xld + q * 4);
+      for (int q = 0; q < CIQ; ++q) xq[u][q] = ld4(reinterpret_cast<const TS*>(a.x) + xi * a.xld + q * 4);
 #pragma unroll
-      for (int q = 0; q < COQ; ++q) gq[u][q] = *reinterpret_cast<const float4*>(a.dy + vc * a.dyld + q * 4);
+      for (int q = 0; q < COQ; ++q) gq[u][q] = ld4(reinterpret_cast<const TD*>(a.dy) + vc * a.dyld + q * 4);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -581,13 +598,21 @@ static bool k1_wgrad_shape_ok(const n3d_conv_geom* g) {
          total >= 32768 && total < (1ll << 31);
 }
 
+template <int CIQ, typename TS, typename TD>
+static void launch_k1_wgrad_d(const K1WgArgs& a, int Co, int nchunks, hipStream_t s) {
+  switch (Co / 4) {
+    case 1: hipLaunchKernelGGL((conv_k1_wgrad_kernel<CIQ, 1, TS, TD>), dim3(nchunks), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((conv_k1_wgrad_kernel<CIQ, 2, TS, TD>), dim3(nchunks), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((conv_k1_wgrad_kernel<CIQ, 3, TS, TD>), dim3(nchunks), dim3(256), 0, s, a); break;
+  }
+}
 template <int CIQ>
 static void launch_k1_wgrad_c(const K1WgArgs& a, int Co, int nchunks, hipStream_t s) {
-  switch (Co / 4) {
-    case 1: hipLaunchKernelGGL((conv_k1_wgrad_kernel<CIQ, 1>), dim3(nchunks), dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((conv_k1_wgrad_kernel<CIQ, 2>), dim3(nchunks), dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((conv_k1_wgrad_kernel<CIQ, 3>), dim3(nchunks), dim3(256), 0, s, a); break;
-  }
+  const bool sb = a.flags & N3D_SRC_BF16, db = a.flags & N3D_DST_BF16;
+  if (sb && db) launch_k1_wgrad_d<CIQ, bf16_t, bf16_t>(a, Co, nchunks, s);
+  else if (sb) launch_k1_wgrad_d<CIQ, bf16_t, float>(a, Co, nchunks, s);
+  else if (db) launch_k1_wgrad_d<CIQ, float, bf16_t>(a, Co, nchunks, s);
+  else launch_k1_wgrad_d<CIQ, float, float>(a, Co, nchunks, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -596,8 +621,8 @@ static void launch_k1_wgrad_c(const K1WgArgs& a, int Co, int nchunks, hipStream_
 // products, wave reduction, partial slabs, then a fixed-order final reduction (deterministic).
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
-  const float* x; int64_t xld; int Di, Hi, Wi, Ci;
-  const float* dy; int64_t dyld; int Do, Ho, Wo, Co;
+  const void* x; int64_t xld; int Di, Hi, Wi, Ci;      // TS elements
+  const void* dy; int64_t dyld; int Do, Ho, Wo, Co;    // TD elements
   int B, k, stride, dil, pad, flags;
   const float* in_gate;
   float* partial;   // [nchunks][ntiles][CI_T*CO_T]
@@ -607,7 +632,7 @@ struct WgradArgs {
   FastDiv fNo, fWo, fHo;
 };
 
-template <int CI_T, int CO_T>
+template <int CI_T, int CO_T, typename TS = float, typename TD = float>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   __shared__ float red[4][CI_T * CO_T + CO_T];
   const int tile = blockIdx.y;
@@ -620,7 +645,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   if (i1 > total) i1 = total;
   const bool relu_in = a.flags & N3D_RELU_IN;
   const bool do_bias = (tap == 0 && cit == 0);
-  const bool covec = (a.Co % 4 == 0) && (a.dyld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.dy) & 15) == 0);
+  const bool covec = (a.Co % 4 == 0) && (a.dyld % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.dy) & (4 * sizeof(TD) - 1)) == 0);
   float acc[CI_T][CO_T];
   float bacc[CO_T];
 #pragma unroll
@@ -636,16 +661,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     a.fHo.divmod(q1, ud, uh);
     const int b = (int)ub, ow = (int)uw, oh = (int)uh, od = (int)ud;
     float dyv[CO_T];
-    const float* dp = a.dy + i * a.dyld + cot * CO_T;
+    const TD* dp = reinterpret_cast<const TD*>(a.dy) + i * a.dyld + cot * CO_T;
     if (covec) {
 #pragma unroll
       for (int j = 0; j < CO_T; j += 4) {
-        const float4 q = *reinterpret_cast<const float4*>(dp + j);
+        const float4 q = ld4(dp + j);
         dyv[j] = q.x; dyv[j + 1] = q.y; dyv[j + 2] = q.z; dyv[j + 3] = q.w;
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < CO_T; ++j) dyv[j] = (cot * CO_T + j < a.Co) ? dp[j] : 0.f;
+      for (int j = 0; j < CO_T; ++j) dyv[j] = (cot * CO_T + j < a.Co) ? ld1(dp + j) : 0.f;
     }
     if (do_bias) {
 #pragma unroll
@@ -653,11 +678,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
     const int id = od * a.stride - a.pad + kd * a.dil, ih = oh * a.stride - a.pad + kh * a.dil, iw = ow * a.stride - a.pad + kw * a.dil;
     if (id < 0 || id >= a.Di || ih < 0 || ih >= a.Hi || iw < 0 || iw >= a.Wi) continue;
-    const float* xp = a.x + ((int64_t)b * Ni + ((int64_t)id * a.Hi + ih) * a.Wi + iw) * a.xld + cit * CI_T;
+    const TS* xp = reinterpret_cast<const TS*>(a.x) + ((int64_t)b * Ni + ((int64_t)id * a.Hi + ih) * a.Wi + iw) * a.xld + cit * CI_T;
     float xv[CI_T];
 #pragma unroll
     for (int c = 0; c < CI_T; c += 4) {
-      const float4 q = *reinterpret_cast<const float4*>(xp + c);
+      const float4 q = ld4(xp + c);
       xv[c] = q.x; xv[c + 1] = q.y; xv[c + 2] = q.z; xv[c + 3] = q.w;
     }
 #pragma unroll
@@ -921,7 +946,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
 // ------------------------------------------------------------------------------------------------
 // per-channel sum over all (b, voxel): bias gradient of a transposed convolution
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, int64_t ld, int64_t total, int C, int64_t chunk,
+template <typename TX>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const TX* __restrict__ x, int64_t ld, int64_t total, int C, int64_t chunk,
                                                           float* __restrict__ partial /*[nblk][C]*/) {
   extern __shared__ float dyn[];
   const int cpb = C / 4, vpb = 256 / cpb;
@@ -932,7 +958,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
   float acc[4] = {0, 0, 0, 0};
   if (vl < vpb)
     for (int64_t i = i0 + vl; i < i1; i += vpb) {
-      const float4 q = *reinterpret_cast<const float4*>(x + i * ld + c4 * 4);
+      const float4 q = ld4(x + i * ld + c4 * 4);
       acc[0] += q.x; acc[1] += q.y; acc[2] += q.z; acc[3] += q.w;
     }
   const int wave = t >> 6, lane = t & 63;
@@ -1119,7 +1145,12 @@ static WgradPlan wgrad_plan(int B, int64_t No, int Ci, int Co, int taps) {
 
 template <int CI_T, int CO_T>
 static void launch_wgrad_t(const WgradArgs& a, const WgradPlan& p, hipStream_t s) {
-  hipLaunchKernelGGL((conv_wgrad_kernel<CI_T, CO_T>), dim3(p.nchunks, p.ntiles), dim3(256), 0, s, a);
+  const bool sb = a.flags & N3D_SRC_BF16, db = a.flags & N3D_DST_BF16;
+  const dim3 grid(p.nchunks, p.ntiles);
+  if (sb && db) hipLaunchKernelGGL((conv_wgrad_kernel<CI_T, CO_T, bf16_t, bf16_t>), grid, dim3(256), 0, s, a);
+  else if (sb) hipLaunchKernelGGL((conv_wgrad_kernel<CI_T, CO_T, bf16_t, float>), grid, dim3(256), 0, s, a);
+  else if (db) hipLaunchKernelGGL((conv_wgrad_kernel<CI_T, CO_T, float, bf16_t>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<CI_T, CO_T, float, float>), grid, dim3(256), 0, s, a);
 }
 
 }  // namespace n3d
@@ -1127,6 +1158,9 @@ static void launch_wgrad_t(const WgradArgs& a, const WgradPlan& p, hipStream_t s
 using namespace n3d;
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// 4-channel groups of a tensor are loaded with one access: 16-byte aligned for fp32, 8-byte for bf16 storage
+static bool aligned_quad(const void* p, bool bf16) { return (reinterpret_cast<uintptr_t>(p) & (bf16 ? 7 : 15)) == 0; }
+#define N3D_ANY_BF16 (N3D_SRC_BF16 | N3D_DST_BF16)
 
 static size_t packed_floats(const n3d_conv_geom* g) {
   const int taps = g->k * g->k * g->k;
@@ -1259,7 +1293,9 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
                       int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate,
                       double* stats, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  const bool sb16 = flags & N3D_SRC_BF16, db16 = flags & N3D_DST_BF16;
   if (g->depthwise) {
+    if (flags & N3D_ANY_BF16) N3D_UNSUPPORTED("depthwise conv: bf16 storage is not built");
     N3D_CHECK_ARG(!in_gate && !relu_src && !out_gate && !stats && !(flags & N3D_RELU_IN), "depthwise conv: gate/relu/stats not supported");
     N3D_CHECK_ARG(sld % 4 == 0 && dld % 4 == 0 && aligned16(src) && aligned16(dst), "depthwise conv: needs 16-byte aligned pitched rows");
     DwArgs a = dw_args(g, data_grad, src, sld, w, bias, dst, dld, flags);
@@ -1290,13 +1326,13 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
   const int total = taps * a.Cs * a.Cdp;
   if (!(flags & N3D_PREPACKED))
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, w, wp, g->Co, g->Ci, taps, a.Cdp, data_grad ? 1 : 0);
-  if (stats && gather_class_mode(a.den, a.k, a.Dd, a.Hd, a.Wd, a.Cs, true) && !((a.Cs % 4 == 0) && (a.sld % 4 == 0) && aligned16(a.src))) {
+  if (stats && gather_class_mode(a.den, a.k, a.Dd, a.Hd, a.Wd, a.Cs, true) && !((a.Cs % 4 == 0) && (a.sld % 4 == 0) && aligned_quad(a.src, sb16))) {
     set_error("conv: statistics on this shape need a 16-byte aligned source (n3d_conv_stats_rows assumed the parity-class kernel)");
     return N3D_ERR_UNSUPPORTED;
   }
   if (k1_shape_ok(g, data_grad)) {
-    const bool fits = !in_gate && !out_gate && sld % 4 == 0 && dld % 4 == 0 && aligned16(src) && aligned16(dst) && aligned16(a.wp) &&
-                      (!bias || aligned16(bias)) && (!relu_src || (rld % 4 == 0 && aligned16(relu_src))) && a.Cdp % 4 == 0 &&
+    const bool fits = !in_gate && !out_gate && sld % 4 == 0 && dld % 4 == 0 && aligned_quad(src, sb16) && aligned_quad(dst, db16) && aligned16(a.wp) &&
+                      (!bias || aligned16(bias)) && (!relu_src || (rld % 4 == 0 && aligned_quad(relu_src, db16))) && a.Cdp % 4 == 0 &&
                       !(a.den == 2 && (bias || stats));   // the zero-upsampling form carries neither
     if (fits) {
       K1Args q;
@@ -1373,7 +1409,9 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   if (!ws || ws_bytes <= skip) { set_error("conv_bwd_weight: workspace too small"); return N3D_ERR_WORKSPACE; }
   float* wsf = (float*)((char*)ws + skip);
   const size_t avail = (ws_bytes - skip) / 4;
+  const bool sb16 = flags & N3D_SRC_BF16, db16 = flags & N3D_DST_BF16;   // storage of the kernel-role x / dy tensors
   if (g->depthwise) {
+    if (flags & N3D_ANY_BF16) N3D_UNSUPPORTED("depthwise weight gradient: bf16 storage is not built");
     // conv-side roles: X on the i side, DY on the o side (callers of the transposed form pass them swapped)
     N3D_CHECK_ARG(!in_gate && !(flags & N3D_RELU_IN), "depthwise wgrad: gate/relu not supported");
     DwWgradArgs a;
@@ -1411,7 +1449,7 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   // dense: the kernel computes G[co'][ci'][tap] = sum dyK[o][co'] * xK[i(o,tap)][ci'] with xK on the i side.
   // forward conv: xK = x (Ci), dyK = dy (Co), dw native (Co,Ci,k^3) = G.
   // transposed conv (weight (CinT=Co_geom, CoutT=Ci_geom)): xK = dy_T (i side, Ci), dyK = x_T (o side, Co): same G layout.
-  if (!dbias || transposed) {
+  if ((!dbias || transposed) && !(flags & N3D_ANY_BF16)) {
     // vox64 weight gradient (3x3x3 stride 1, C = 4 / 8); it does not produce the bias gradient, which the callers on the
     // hot path obtain analytically from the GroupNorm backward sums (n3d_gn_bwd_coeffs)
     int nch = 0;
@@ -1430,7 +1468,7 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
       return N3D_OK;
     }
   }
-  if (!(flags & N3D_NO_MFMA) && xld % 4 == 0 && dyld % 4 == 0) {
+  if (!(flags & (N3D_NO_MFMA | N3D_ANY_BF16)) && xld % 4 == 0 && dyld % 4 == 0) {
     int nch = 0, ntl = 0;
     const size_t nt16 = (size_t)taps * (g->Ci / 16) * (g->Co / 16);
     float* pb = wsf + (1024 + nt16) * 256;
@@ -1461,7 +1499,7 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
       return N3D_OK;
     }
   }
-  if (!transposed && !in_gate && k1_wgrad_shape_ok(g) && xld % 4 == 0 && dyld % 4 == 0 && aligned16(x) && aligned16(dy)) {
+  if (!transposed && !in_gate && k1_wgrad_shape_ok(g) && xld % 4 == 0 && dyld % 4 == 0 && aligned_quad(x, sb16) && aligned_quad(dy, db16)) {
     // 1x1x1 streaming weight gradient (large levels, few channels)
     const int64_t total = (int64_t)g->B * No;
     const size_t nslab = (size_t)g->Ci * g->Co;
@@ -1505,7 +1543,7 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   a.partial = wsf; a.pbias = wsf + p.partial_floats; a.tci = p.tci; a.tco = p.tco; a.chunk = p.chunk;
   a.fNo = FastDiv((uint32_t)No); a.fWo = FastDiv((uint32_t)g->Wo); a.fHo = FastDiv((uint32_t)g->Ho);
   N3D_CHECK_ARG((int64_t)g->B * No < (1ll << 31), "conv_bwd_weight: tensor too large for 32-bit voxel indexing");
-  N3D_CHECK_ARG(g->Ci % 4 == 0 && xld % 4 == 0 && aligned16(x), "conv_bwd_weight: i-side tensor needs C %% 4 == 0 and 16-byte alignment");
+  N3D_CHECK_ARG(g->Ci % 4 == 0 && xld % 4 == 0 && aligned_quad(x, sb16), "conv_bwd_weight: i-side tensor needs C %% 4 == 0 and quad alignment");
   if (p.ci_t == 8 && p.co_t == 16) launch_wgrad_t<8, 16>(a, p, s);
   else if (p.ci_t == 8 && p.co_t == 8) launch_wgrad_t<8, 8>(a, p, s);
   else if (p.ci_t == 8 && p.co_t == 4) launch_wgrad_t<8, 4>(a, p, s);
@@ -1798,7 +1836,9 @@ int n3d_convT_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, co
   N3D_CHECK_ARG(x && dy && (dw || dbias) && xld >= g->Co && dyld >= g->Ci, "convT_bwd_weight: bad pointers/pitches");
   // kernel roles: i-side tensor = dy (Ci channels), o-side tensor = x (Co channels); see run_wgrad
   if (dw) {
-    int e = run_wgrad(g, dy, dyld, x, xld, dw, nullptr, flags & ~N3D_RELU_IN, nullptr, ws, ws_bytes, stream, true, deferred);
+    // the storage flags follow the tensors into their swapped roles
+    const int rf = (flags & ~(N3D_RELU_IN | N3D_SRC_BF16 | N3D_DST_BF16)) | ((flags & N3D_SRC_BF16) ? N3D_DST_BF16 : 0) | ((flags & N3D_DST_BF16) ? N3D_SRC_BF16 : 0);
+    int e = run_wgrad(g, dy, dyld, x, xld, dw, nullptr, rf, nullptr, ws, ws_bytes, stream, true, deferred);
     if (e) return e;
   } else if (deferred) {
     deferred->nchunks = 0;
@@ -1806,7 +1846,7 @@ int n3d_convT_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, co
   if (dbias) {
     // bias gradient = per-channel sum of dy over the i side
     hipStream_t s = (hipStream_t)stream;
-    N3D_CHECK_ARG(g->Ci % 4 == 0 && dyld % 4 == 0 && aligned16(dy) && g->Ci <= 256, "convT_bwd_weight: dy needs C %% 4 == 0");
+    N3D_CHECK_ARG(g->Ci % 4 == 0 && dyld % 4 == 0 && aligned_quad(dy, flags & N3D_DST_BF16) && g->Ci <= 256, "convT_bwd_weight: dy needs C %% 4 == 0");
     const size_t skip = align_up(packed_floats(g) * 4, 256);
     float* wsf = (float*)((char*)ws + skip);
     const int64_t total = (int64_t)g->B * g->Di * g->Hi * g->Wi;
@@ -1832,8 +1872,14 @@ int n3d_convT_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, co
       }
     }
     // (not deferred: the slab region is free again once run_wgrad's final kernel has been enqueued -- stream order)
-    hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)nblk), dim3(256), (size_t)4 * (g->Ci / 4) * 4 * sizeof(float), s, dy, dyld, total, g->Ci,
-                       chunk, wsf);
+    // dy is the SECOND activation tensor of a transposed weight-gradient call... but the kernel roles are swapped (see above):
+    // the caller's dy (Ci channels, i side) carries the N3D_DST_BF16 flag
+    if (flags & N3D_DST_BF16)
+      hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), (size_t)4 * (g->Ci / 4) * 4 * sizeof(float), s,
+                         reinterpret_cast<const bf16_t*>(dy), dyld, total, g->Ci, chunk, wsf);
+    else
+      hipLaunchKernelGGL(channel_sum_kernel<float>, dim3((unsigned)nblk), dim3(256), (size_t)4 * (g->Ci / 4) * 4 * sizeof(float), s, dy, dyld, total, g->Ci,
+                         chunk, wsf);
     hipLaunchKernelGGL(channel_sum_final_kernel, dim3((unsigned)cdiv(g->Ci, 256)), dim3(256), 0, s, wsf, (int)nblk, g->Ci, dbias);
     N3D_LAUNCH_CHECK();
   }

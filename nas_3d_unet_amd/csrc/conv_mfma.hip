@@ -1693,7 +1693,7 @@ static G16Plan g16_plan(const n3d_conv_geom* g, bool data_grad) {
 }
 
 int mfma_pack_layout(const n3d_conv_geom* g, bool data_grad, int flags) {
-  if (flags & N3D_NO_MFMA) return 0;
+  if (flags & (N3D_NO_MFMA | N3D_SRC_BF16 | N3D_DST_BF16)) return 0;
   if (vup_plan(g, data_grad).ok) return 3;   // vox layout, channels transposed, taps not flipped
   if (vx_plan(g).ok || vs2_plan(g, data_grad).ok) return 2;
   if (g16_plan(g, data_grad).ok) return 1;
@@ -1701,7 +1701,7 @@ int mfma_pack_layout(const n3d_conv_geom* g, bool data_grad, int flags) {
 }
 
 int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags) {
-  if (flags & N3D_NO_MFMA) return 0;
+  if (flags & (N3D_NO_MFMA | N3D_SRC_BF16 | N3D_DST_BF16)) return 0;   // bf16 storage: the streaming / gather kernels (conv_generic.hip)
   {
     VxPlan v = vx_plan(g);
     if (v.ok) return v.tiles * v.nw;  // one partial row per wave
@@ -1736,6 +1736,7 @@ int g16_prepare(const n3d_conv_geom* g, bool data_grad, const float* src, int64_
 int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
                   int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate, double* stats,
                   void* ws, size_t ws_bytes, hipStream_t s) {
+  if (flags & (N3D_SRC_BF16 | N3D_DST_BF16)) return 0;
   {
     Vs2Plan v2 = vs2_plan(g, data_grad);
     if (v2.ok) {
@@ -1862,6 +1863,7 @@ int mfma_conv_pair_try(const n3d_conv_geom* g0, bool dg0, const float* src0, int
                        const float* src1, int64_t sld1, const float* w1, const float* bias1, float* dst1, int64_t dld1, int flags1,
                        const float* gate1, double* stats1, void* ws1, size_t wsb1, hipStream_t s, const PairExtras* x0, const PairExtras* x1) {
   // decide before touching anything (g16_prepare packs weights)
+  if ((flags0 | flags1) & (N3D_SRC_BF16 | N3D_DST_BF16)) return 0;
   if (vx_plan(g0).ok || vx_plan(g1).ok) return 0;
   const G16Plan p0 = g16_plan(g0, dg0), p1 = g16_plan(g1, dg1);
   if (!p0.ok || !p1.ok || p0.ksplit != p1.ksplit || p0.ksplit == 1) return 0;

@@ -2,6 +2,8 @@
 // weighted-sum epilogue and its backward, SE gate, pooling, Dice, layout, Adam.
 // All are HBM-bound streaming passes: 16-byte accesses, lane-consecutive addresses, >= 256 blocks
 // where the tensor is large enough, partial rows + a tiny finalize kernel instead of atomics.
+#include <type_traits>
+
 #include "n3d_common.h"
 
 namespace n3d {
@@ -44,7 +46,8 @@ __device__ __forceinline__ void block_reduce_to_row(double (&vals)[NV * 4], int 
 // ------------------------------------------------------------------------------------------------
 // channel statistics
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void channel_stats_body(const float* __restrict__ x, int64_t ld, int64_t N, int C, const EwMap& m,
+template <typename T>
+__device__ __forceinline__ void channel_stats_body(const T* __restrict__ x, int64_t ld, int64_t N, int C, const EwMap& m,
                                                    double* __restrict__ stats) {
   __shared__ double lds[4 * 64 * 8];
   const int b = blockIdx.y;
@@ -54,11 +57,11 @@ __device__ __forceinline__ void channel_stats_body(const float* __restrict__ x, 
   const int64_t v0 = (int64_t)blockIdx.x * m.vpc;
   float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
   if (active) {
-    const float* xb = x + (int64_t)b * N * ld + c4 * 4;
+    const T* xb = x + (int64_t)b * N * ld + c4 * 4;
     for (int it = 0; it < m.iters; ++it) {
       const int64_t v = v0 + (int64_t)it * m.vpb + vl;
       if (v < N) {
-        const float4 q = *reinterpret_cast<const float4*>(xb + v * ld);
+        const float4 q = ld4(xb + v * ld);
         s[0] += q.x; s[1] += q.y; s[2] += q.z; s[3] += q.w;
         ss[0] += q.x * q.x; ss[1] += q.y * q.y; ss[2] += q.z * q.z; ss[3] += q.w * q.w;
       }
@@ -70,7 +73,8 @@ __device__ __forceinline__ void channel_stats_body(const float* __restrict__ x, 
   double* row = stats + ((int64_t)b * gridDim.x + blockIdx.x) * C * 2;
   block_reduce_to_row<2>(vals, m.cpb, row, lds);
 }
-__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, int64_t ld, int64_t N, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, int64_t ld, int64_t N, int C,
                                                             EwMap m, double* __restrict__ stats) {
   channel_stats_body(x, ld, N, C, m, stats);
 }
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void channel_statsN_kernel(StatsJobN js, int64
     case 4: x = js.x[4]; ld = js.ld[4]; st = js.stats[4]; break; case 5: x = js.x[5]; ld = js.ld[5]; st = js.stats[5]; break;
     case 6: x = js.x[6]; ld = js.ld[6]; st = js.stats[6]; break; default: x = js.x[7]; ld = js.ld[7]; st = js.stats[7]; break;
   }
-  channel_stats_body(x, ld, N, C, m, st);
+  channel_stats_body<float>(x, ld, N, C, m, st);
 }
 
 // sum partial rows: out[q] for q < ncol, executed by a whole 256-thread block; result in lds_out
@@ -168,44 +172,44 @@ __global__ __launch_bounds__(256) void gn_coeffsN_kernel(GnCoefArgsN qs, int C, 
 // ------------------------------------------------------------------------------------------------
 // epilogue forward: out (+)= w * act(a*raw + b)
 // ------------------------------------------------------------------------------------------------
-template <bool RELU, bool ACC>
-__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ raw, int64_t rld, const float* __restrict__ a,
+template <bool RELU, bool ACC, typename T = float>
+__global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ raw, int64_t rld, const float* __restrict__ a,
                                                          const float* __restrict__ bb, const float* __restrict__ wptr,
-                                                         float* __restrict__ out, int64_t old_, int64_t N, int C, EwMap m) {
+                                                         T* __restrict__ out, int64_t old_, int64_t N, int C, EwMap m) {
   const int b = blockIdx.y;
   const int t = threadIdx.x;
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   if (vl >= m.vpb) return;
   float4 av = make_float4(1, 1, 1, 1), bv = make_float4(0, 0, 0, 0);
-  if (a) av = *reinterpret_cast<const float4*>(a + b * C + c4 * 4);
-  if (bb) bv = *reinterpret_cast<const float4*>(bb + b * C + c4 * 4);
+  if (a) av = ld4(a + b * C + c4 * 4);
+  if (bb) bv = ld4(bb + b * C + c4 * 4);
   const float w = wptr ? *wptr : 1.0f;
-  const float* rb = raw + (int64_t)b * N * rld + c4 * 4;
-  float* ob = out + (int64_t)b * N * old_ + c4 * 4;
+  const T* rb = raw + (int64_t)b * N * rld + c4 * 4;
+  T* ob = out + (int64_t)b * N * old_ + c4 * 4;
   const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
 #pragma unroll 4
   for (int it = 0; it < m.iters; ++it) {
     const int64_t v = v0 + (int64_t)it * m.vpb;
     if (v >= N) break;
-    const float4 q = *reinterpret_cast<const float4*>(rb + v * rld);
+    const float4 q = ld4(rb + v * rld);
     float4 z;
     z.x = fmaf(av.x, q.x, bv.x); z.y = fmaf(av.y, q.y, bv.y); z.z = fmaf(av.z, q.z, bv.z); z.w = fmaf(av.w, q.w, bv.w);
     if (RELU) { z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f); }
-    float4* op = reinterpret_cast<float4*>(ob + v * old_);
+    T* op = ob + v * old_;
     if (ACC) {
-      float4 o = *op;
+      float4 o = ld4(op);
       o.x = fmaf(w, z.x, o.x); o.y = fmaf(w, z.y, o.y); o.z = fmaf(w, z.z, o.z); o.w = fmaf(w, z.w, o.w);
-      *op = o;
+      st4(op, o);
     } else {
       z.x *= w; z.y *= w; z.z *= w; z.w *= w;
-      *op = z;
+      st4(op, z);
     }
   }
 }
 
 // backward pass 1
-template <bool RELU>
-__global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(const float* __restrict__ dout, int64_t dld, const float* __restrict__ raw,
+template <bool RELU, typename T = float>
+__global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ raw,
                                                                 int64_t rld, const float* __restrict__ a, const float* __restrict__ bb,
                                                                 int64_t N, int C, EwMap m, double* __restrict__ sums) {
   __shared__ double lds[4 * 64 * 12];
@@ -216,10 +220,10 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(const float* __r
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, sz[4] = {0, 0, 0, 0};
   if (active) {
     float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0};
-    if (a) { const float4 q = *reinterpret_cast<const float4*>(a + b * C + c4 * 4); av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w; }
-    if (bb) { const float4 q = *reinterpret_cast<const float4*>(bb + b * C + c4 * 4); bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w; }
-    const float* db = dout + (int64_t)b * N * dld + c4 * 4;
-    const float* rb = raw + (int64_t)b * N * rld + c4 * 4;
+    if (a) { const float4 q = ld4(a + b * C + c4 * 4); av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w; }
+    if (bb) { const float4 q = ld4(bb + b * C + c4 * 4); bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w; }
+    const T* db = dout + (int64_t)b * N * dld + c4 * 4;
+    const T* rb = raw + (int64_t)b * N * rld + c4 * 4;
     const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
     for (int it0 = 0; it0 < m.iters; it0 += 4) {
       float4 dq[4], rq[4];
@@ -230,8 +234,8 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(const float* __r
         const int64_t v = v0 + (int64_t)(it0 + u) * m.vpb;
         ok[u] = (it0 + u < m.iters) && v < N;
         const int64_t vc = ok[u] ? v : 0;
-        dq[u] = *reinterpret_cast<const float4*>(db + vc * dld);
-        rq[u] = *reinterpret_cast<const float4*>(rb + vc * rld);
+        dq[u] = ld4(db + vc * dld);
+        rq[u] = ld4(rb + vc * rld);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -417,11 +421,11 @@ __global__ __launch_bounds__(256) void plain_bwd_coeffsN_kernel(PlainCoefArgsN q
 }
 
 // backward pass 2
-template <bool RELU, bool ACC>
-__global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __restrict__ dout, int64_t dld, const float* __restrict__ raw,
+template <bool RELU, bool ACC, typename T = float>
+__global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ raw,
                                                                int64_t rld, const float* __restrict__ a, const float* __restrict__ bb,
                                                                const float* __restrict__ A, const float* __restrict__ Bc,
-                                                               const float* __restrict__ Cc, float* __restrict__ draw, int64_t drld,
+                                                               const float* __restrict__ Cc, T* __restrict__ draw, int64_t drld,
                                                                int64_t N, int C, EwMap m) {
   const int b = blockIdx.y;
   const int t = threadIdx.x;
@@ -429,21 +433,21 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __re
   if (vl >= m.vpb) return;
   float av[4] = {1, 1, 1, 1}, bv[4] = {0, 0, 0, 0}, Av[4] = {1, 1, 1, 1}, Bv[4] = {0, 0, 0, 0}, Cv[4] = {0, 0, 0, 0};
   const int co = b * C + c4 * 4;
-  if (a) { const float4 q = *reinterpret_cast<const float4*>(a + co); av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w; }
-  if (bb) { const float4 q = *reinterpret_cast<const float4*>(bb + co); bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w; }
-  if (A) { const float4 q = *reinterpret_cast<const float4*>(A + co); Av[0] = q.x; Av[1] = q.y; Av[2] = q.z; Av[3] = q.w; }
-  if (Bc) { const float4 q = *reinterpret_cast<const float4*>(Bc + co); Bv[0] = q.x; Bv[1] = q.y; Bv[2] = q.z; Bv[3] = q.w; }
-  if (Cc) { const float4 q = *reinterpret_cast<const float4*>(Cc + co); Cv[0] = q.x; Cv[1] = q.y; Cv[2] = q.z; Cv[3] = q.w; }
-  const float* db = dout + (int64_t)b * N * dld + c4 * 4;
-  const float* rb = raw + (int64_t)b * N * rld + c4 * 4;
-  float* ob = draw + (int64_t)b * N * drld + c4 * 4;
+  if (a) { const float4 q = ld4(a + co); av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w; }
+  if (bb) { const float4 q = ld4(bb + co); bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w; }
+  if (A) { const float4 q = ld4(A + co); Av[0] = q.x; Av[1] = q.y; Av[2] = q.z; Av[3] = q.w; }
+  if (Bc) { const float4 q = ld4(Bc + co); Bv[0] = q.x; Bv[1] = q.y; Bv[2] = q.z; Bv[3] = q.w; }
+  if (Cc) { const float4 q = ld4(Cc + co); Cv[0] = q.x; Cv[1] = q.y; Cv[2] = q.z; Cv[3] = q.w; }
+  const T* db = dout + (int64_t)b * N * dld + c4 * 4;
+  const T* rb = raw + (int64_t)b * N * rld + c4 * 4;
+  T* ob = draw + (int64_t)b * N * drld + c4 * 4;
   const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
 #pragma unroll 2
   for (int it = 0; it < m.iters; ++it) {
     const int64_t v = v0 + (int64_t)it * m.vpb;
     if (v >= N) break;
-    const float4 dq = *reinterpret_cast<const float4*>(db + v * dld);
-    const float4 rq = *reinterpret_cast<const float4*>(rb + v * rld);
+    const float4 dq = ld4(db + v * dld);
+    const float4 rq = ld4(rb + v * rld);
     const float d[4] = {dq.x, dq.y, dq.z, dq.w};
     const float r[4] = {rq.x, rq.y, rq.z, rq.w};
     float o[4];
@@ -453,9 +457,9 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __re
       if (RELU) { const float z = fmaf(av[j], r[j], bv[j]); g = z > 0.f ? g : 0.f; }
       o[j] = fmaf(Av[j], g, fmaf(Cv[j], r[j], Bv[j]));
     }
-    float4* op = reinterpret_cast<float4*>(ob + v * drld);
-    if (ACC) { const float4 p = *op; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
-    *op = make_float4(o[0], o[1], o[2], o[3]);
+    T* op = ob + v * drld;
+    if (ACC) { const float4 p = ld4(op); o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+    st4(op, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
@@ -466,10 +470,10 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const float* __re
 // prologue (a few hundred doubles), so the separate coefficient kernel -- one launch and one dependent
 // memory round trip per op -- disappears.  Workgroup (0, b) also stores the coefficients for the backward pass.
 // ------------------------------------------------------------------------------------------------
-template <bool RELU, bool ACC>
-__global__ __launch_bounds__(256) void affine_act_gn_kernel(const float* __restrict__ raw, int64_t rld, const double* __restrict__ stats, int rows,
+template <bool RELU, bool ACC, typename T = float>
+__global__ __launch_bounds__(256) void affine_act_gn_kernel(const T* __restrict__ raw, int64_t rld, const double* __restrict__ stats, int rows,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int G, double count,
-                                                            float eps, const float* __restrict__ wptr, float* __restrict__ out, int64_t old_,
+                                                            float eps, const float* __restrict__ wptr, T* __restrict__ out, int64_t old_,
                                                             int64_t N, int C, EwMap m, float* __restrict__ a_out, float* __restrict__ b_out,
                                                             float* __restrict__ mr_out, double* __restrict__ sumraw) {
   __shared__ double part[256];
@@ -483,14 +487,14 @@ __global__ __launch_bounds__(256) void affine_act_gn_kernel(const float* __restr
   // the first iteration's operands are requested before the prologue: its memory round trip overlaps the
   // coefficient computation instead of following it
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
-  const float* rb = raw + (int64_t)b * N * rld + c4 * 4;
-  float* ob = out + (int64_t)b * N * old_ + c4 * 4;
+  const T* rb = raw + (int64_t)b * N * rld + c4 * 4;
+  T* ob = out + (int64_t)b * N * old_ + c4 * 4;
   const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
   const bool act0 = vl < m.vpb && v0 < N;
   float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), o0 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (act0) {
-    q0 = *reinterpret_cast<const float4*>(rb + v0 * rld);
-    if (ACC) o0 = *reinterpret_cast<const float4*>(ob + v0 * old_);
+    q0 = ld4(rb + v0 * rld);
+    if (ACC) o0 = ld4(ob + v0 * old_);
   }
   const int cg = C / G;
   float4 av, bv;
@@ -533,8 +537,8 @@ __global__ __launch_bounds__(256) void affine_act_gn_kernel(const float* __restr
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!act0) return;
-    av = *reinterpret_cast<const float4*>(&abw[wave][0][c4 * 4]);
-    bv = *reinterpret_cast<const float4*>(&abw[wave][1][c4 * 4]);
+    av = ld4(&abw[wave][0][c4 * 4]);
+    bv = ld4(&abw[wave][1][c4 * 4]);
   } else {
     reduce_rows(stats + (int64_t)b * rows * C * 2, rows, C * 2, part, tot);
     if (t < C) {
@@ -568,20 +572,20 @@ __global__ __launch_bounds__(256) void affine_act_gn_kernel(const float* __restr
     const int64_t v = v0 + (int64_t)(i + 1) * m.vpb;
     const bool ok = (i + 1) < m.iters && v < N;
     const int64_t vc = ok ? v : v0;
-    qn[i] = *reinterpret_cast<const float4*>(rb + vc * rld);
-    if (ACC) on[i] = *reinterpret_cast<const float4*>(ob + vc * old_);
+    qn[i] = ld4(rb + vc * rld);
+    if (ACC) on[i] = ld4(ob + vc * old_);
   }
   auto emit = [&](int64_t v, const float4 q, float4 o) {
     float4 z;
     z.x = fmaf(av.x, q.x, bv.x); z.y = fmaf(av.y, q.y, bv.y); z.z = fmaf(av.z, q.z, bv.z); z.w = fmaf(av.w, q.w, bv.w);
     if (RELU) { z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f); }
-    float4* op = reinterpret_cast<float4*>(ob + v * old_);
+    T* op = ob + v * old_;
     if (ACC) {
       o.x = fmaf(w, z.x, o.x); o.y = fmaf(w, z.y, o.y); o.z = fmaf(w, z.z, o.z); o.w = fmaf(w, z.w, o.w);
-      *op = o;
+      st4(op, o);
     } else {
       z.x *= w; z.y *= w; z.z *= w; z.w *= w;
-      *op = z;
+      st4(op, z);
     }
   };
   emit(v0, q0, o0);
@@ -593,9 +597,9 @@ __global__ __launch_bounds__(256) void affine_act_gn_kernel(const float* __restr
   for (int it = PF + 1; it < m.iters; ++it) {
     const int64_t v = v0 + (int64_t)it * m.vpb;
     if (v >= N) break;
-    const float4 q = *reinterpret_cast<const float4*>(rb + v * rld);
+    const float4 q = ld4(rb + v * rld);
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ACC) o = *reinterpret_cast<const float4*>(ob + v * old_);
+    if (ACC) o = ld4(ob + v * old_);
     emit(v, q, o);
   }
 }
@@ -605,13 +609,13 @@ __global__ __launch_bounds__(256) void affine_act_gn_kernel(const float* __restr
 // All global loads of the prologue (parameter vectors and every partial row this workgroup needs) are issued
 // before the first use, so the prologue costs ONE memory round trip; everything after it is LDS work.
 #define GNF_MAXB 4
-template <bool RELU, bool ACC>
-__global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* __restrict__ dout, int64_t dld, const float* __restrict__ raw,
+template <bool RELU, bool ACC, typename T = float>
+__global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ raw,
                                                                   int64_t rld, const float* __restrict__ a, const float* __restrict__ bb,
                                                                   const double* __restrict__ sums, int rows, const float* __restrict__ gamma,
                                                                   const float* __restrict__ mean_rstd, const float* __restrict__ wptr,
                                                                   const double* __restrict__ sumraw, int B, int G, double count,
-                                                                  float* __restrict__ draw, int64_t drld, int64_t N, int C, EwMap m,
+                                                                  T* __restrict__ draw, int64_t drld, int64_t N, int C, EwMap m,
                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dalpha,
                                                                   float* __restrict__ dbias_conv) {
   __shared__ double part[256];
@@ -628,19 +632,19 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* _
   // ---- load phase (no dependent loads): the first iteration's tensor operands and forward coefficients, then
   // parameters, group statistics and this thread's share of the partial rows
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
-  const float* dbp = dout + (int64_t)blockIdx.y * N * dld + c4 * 4;
-  const float* rb = raw + (int64_t)blockIdx.y * N * rld + c4 * 4;
-  float* ob = draw + (int64_t)blockIdx.y * N * drld + c4 * 4;
+  const T* dbp = dout + (int64_t)blockIdx.y * N * dld + c4 * 4;
+  const T* rb = raw + (int64_t)blockIdx.y * N * rld + c4 * 4;
+  T* ob = draw + (int64_t)blockIdx.y * N * drld + c4 * 4;
   const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
   const bool act0 = vl < m.vpb && v0 < N;
   float4 dq0 = make_float4(0.f, 0.f, 0.f, 0.f), rq0 = dq0, pq0 = dq0, aq = make_float4(1.f, 1.f, 1.f, 1.f), bq = dq0;
   if (act0) {
-    dq0 = *reinterpret_cast<const float4*>(dbp + v0 * dld);
-    rq0 = *reinterpret_cast<const float4*>(rb + v0 * rld);
-    if (ACC) pq0 = *reinterpret_cast<const float4*>(ob + v0 * drld);
+    dq0 = ld4(dbp + v0 * dld);
+    rq0 = ld4(rb + v0 * rld);
+    if (ACC) pq0 = ld4(ob + v0 * drld);
     const int co = (int)blockIdx.y * C + c4 * 4;
-    if (a) aq = *reinterpret_cast<const float4*>(a + co);
-    if (bb) bq = *reinterpret_cast<const float4*>(bb + co);
+    if (a) aq = ld4(a + co);
+    if (bb) bq = ld4(bb + co);
   }
   float Av[4], Bv[4], Cv[4];
   if (is_pow2(C) && cg <= 16) {
@@ -703,9 +707,9 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* _
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!act0) return;
-    const float4 qa = *reinterpret_cast<const float4*>(&coefw[wave][0][c4 * 4]);
-    const float4 qb = *reinterpret_cast<const float4*>(&coefw[wave][1][c4 * 4]);
-    const float4 qc = *reinterpret_cast<const float4*>(&coefw[wave][2][c4 * 4]);
+    const float4 qa = ld4(&coefw[wave][0][c4 * 4]);
+    const float4 qb = ld4(&coefw[wave][1][c4 * 4]);
+    const float4 qc = ld4(&coefw[wave][2][c4 * 4]);
     Av[0] = qa.x; Av[1] = qa.y; Av[2] = qa.z; Av[3] = qa.w;
     Bv[0] = qb.x; Bv[1] = qb.y; Bv[2] = qb.z; Bv[3] = qb.w;
     Cv[0] = qc.x; Cv[1] = qc.y; Cv[2] = qc.z; Cv[3] = qc.w;
@@ -807,9 +811,9 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* _
     const int64_t v = v0 + (int64_t)(i + 1) * m.vpb;
     const bool ok = (i + 1) < m.iters && v < N;
     const int64_t vc = ok ? v : v0;
-    dn[i] = *reinterpret_cast<const float4*>(dbp + vc * dld);
-    rn[i] = *reinterpret_cast<const float4*>(rb + vc * rld);
-    if (ACC) pn[i] = *reinterpret_cast<const float4*>(ob + vc * drld);
+    dn[i] = ld4(dbp + vc * dld);
+    rn[i] = ld4(rb + vc * rld);
+    if (ACC) pn[i] = ld4(ob + vc * drld);
   }
   auto emit = [&](int64_t v, const float4 dq, const float4 rq, const float4 pq) {
     const float d[4] = {dq.x, dq.y, dq.z, dq.w};
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* _
       o[j] = fmaf(Av[j], g, fmaf(Cv[j], r[j], Bv[j]));
     }
     if (ACC) { o[0] += pq.x; o[1] += pq.y; o[2] += pq.z; o[3] += pq.w; }
-    *reinterpret_cast<float4*>(ob + v * drld) = make_float4(o[0], o[1], o[2], o[3]);
+    st4(ob + v * drld, make_float4(o[0], o[1], o[2], o[3]));
   };
   emit(v0, dq0, rq0, pq0);
 #pragma unroll
@@ -833,10 +837,10 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const float* _
   for (int it = PF + 1; it < m.iters; ++it) {
     const int64_t v = v0 + (int64_t)it * m.vpb;
     if (v >= N) break;
-    const float4 dq = *reinterpret_cast<const float4*>(dbp + v * dld);
-    const float4 rq = *reinterpret_cast<const float4*>(rb + v * rld);
+    const float4 dq = ld4(dbp + v * dld);
+    const float4 rq = ld4(rb + v * rld);
     float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ACC) pq = *reinterpret_cast<const float4*>(ob + v * drld);
+    if (ACC) pq = ld4(ob + v * drld);
     emit(v, dq, rq, pq);
   }
 }
@@ -890,31 +894,31 @@ __device__ __forceinline__ void gn_fwd_prologue_wave(const GnFwdTerm& t, const i
 }
 
 // PRE: the GroupNorm coefficients were computed by n3d_gn_coeffs2 (large tensors): a_out / b_out are inputs, no prologue
-template <bool ACC, bool PRE>
-__global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwdTerm t1, int G, double count, float eps, float* __restrict__ out,
-                                                             int64_t old_, float* __restrict__ out1, int64_t old1, int64_t N, int C, EwMap m) {
+template <bool ACC, bool PRE, typename T = float>
+__global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwdTerm t1, int G, double count, float eps, T* __restrict__ out,
+                                                             int64_t old_, T* __restrict__ out1, int64_t old1, int64_t N, int C, EwMap m) {
   __shared__ __attribute__((aligned(16))) float abw[4][2][2][64];  // [wave][term][a|b][channel]
   const int b = blockIdx.y, t = threadIdx.x, wave = t >> 6;
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
-  const float* r0 = t0.raw + (int64_t)b * N * t0.rld + c4 * 4;
-  const float* r1 = t1.raw + (int64_t)b * N * t1.rld + c4 * 4;
-  float* ob = out + (int64_t)b * N * old_ + c4 * 4;
+  const T* r0 = reinterpret_cast<const T*>(t0.raw) + (int64_t)b * N * t0.rld + c4 * 4;
+  const T* r1 = reinterpret_cast<const T*>(t1.raw) + (int64_t)b * N * t1.rld + c4 * 4;
+  T* ob = out + (int64_t)b * N * old_ + c4 * 4;
   const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
   const bool act0 = vl < m.vpb && v0 < N;
   constexpr int PF = 4;   // iterations requested up front (the first one ahead of the prologues)
   float4 q0[PF], q1[PF], on[PF];
   const float w0 = t0.wptr ? *t0.wptr : 1.0f, w1 = t1.wptr ? *t1.wptr : 1.0f;
   if (act0) {
-    q0[0] = *reinterpret_cast<const float4*>(r0 + v0 * t0.rld);
-    q1[0] = *reinterpret_cast<const float4*>(r1 + v0 * t1.rld);
-    if (ACC) on[0] = *reinterpret_cast<const float4*>(ob + v0 * old_);
+    q0[0] = ld4(r0 + v0 * t0.rld);
+    q1[0] = ld4(r1 + v0 * t1.rld);
+    if (ACC) on[0] = ld4(ob + v0 * old_);
   }
   float4 a0, b0, a1, b1;
   if (PRE) {
     if (!act0) return;
     const int co = b * C + c4 * 4;
-    a0 = *reinterpret_cast<const float4*>(t0.a_out + co); b0 = *reinterpret_cast<const float4*>(t0.b_out + co);
-    a1 = *reinterpret_cast<const float4*>(t1.a_out + co); b1 = *reinterpret_cast<const float4*>(t1.b_out + co);
+    a0 = ld4(t0.a_out + co); b0 = ld4(t0.b_out + co);
+    a1 = ld4(t1.a_out + co); b1 = ld4(t1.b_out + co);
   } else {
     const bool store = blockIdx.x == 0 && wave == 0;
     gn_fwd_prologue_wave(t0, b, C, G, count, eps, store, abw[wave][0]);
@@ -923,17 +927,17 @@ __global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwd
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!act0) return;
-    a0 = *reinterpret_cast<const float4*>(&abw[wave][0][0][c4 * 4]); b0 = *reinterpret_cast<const float4*>(&abw[wave][0][1][c4 * 4]);
-    a1 = *reinterpret_cast<const float4*>(&abw[wave][1][0][c4 * 4]); b1 = *reinterpret_cast<const float4*>(&abw[wave][1][1][c4 * 4]);
+    a0 = ld4(&abw[wave][0][0][c4 * 4]); b0 = ld4(&abw[wave][0][1][c4 * 4]);
+    a1 = ld4(&abw[wave][1][0][c4 * 4]); b1 = ld4(&abw[wave][1][1][c4 * 4]);
   }
   const float f0 = t0.relu ? 0.f : -INFINITY, f1 = t1.relu ? 0.f : -INFINITY;
 #pragma unroll
   for (int i = 1; i < PF; ++i) {
     const int64_t v = v0 + (int64_t)i * m.vpb;
     const int64_t vc = (i < m.iters && v < N) ? v : v0;
-    q0[i] = *reinterpret_cast<const float4*>(r0 + vc * t0.rld);
-    q1[i] = *reinterpret_cast<const float4*>(r1 + vc * t1.rld);
-    if (ACC) on[i] = *reinterpret_cast<const float4*>(ob + vc * old_);
+    q0[i] = ld4(r0 + vc * t0.rld);
+    q1[i] = ld4(r1 + vc * t1.rld);
+    if (ACC) on[i] = ld4(ob + vc * old_);
   }
   auto emit = [&](int64_t v, const float4 x0, const float4 x1, const float4 o) {
     float4 z;
@@ -943,16 +947,16 @@ __global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwd
     if (ACC) { z.x += o.x; z.y += o.y; z.z += o.z; z.w += o.w; }
     if (out1) {
       // two independent outputs (the two preprocess ops of a cell): term 1 goes to its own tensor
-      *reinterpret_cast<float4*>(ob + v * old_) = z;
+      st4(ob + v * old_, z);
       float4 y;
       y.x = w1 * fmaxf(fmaf(a1.x, x1.x, b1.x), f1); y.y = w1 * fmaxf(fmaf(a1.y, x1.y, b1.y), f1);
       y.z = w1 * fmaxf(fmaf(a1.z, x1.z, b1.z), f1); y.w = w1 * fmaxf(fmaf(a1.w, x1.w, b1.w), f1);
-      *reinterpret_cast<float4*>(out1 + (int64_t)b * N * old1 + c4 * 4 + v * old1) = y;
+      st4(out1 + (int64_t)b * N * old1 + c4 * 4 + v * old1, y);
       return;
     }
     z.x = fmaf(w1, fmaxf(fmaf(a1.x, x1.x, b1.x), f1), z.x); z.y = fmaf(w1, fmaxf(fmaf(a1.y, x1.y, b1.y), f1), z.y);
     z.z = fmaf(w1, fmaxf(fmaf(a1.z, x1.z, b1.z), f1), z.z); z.w = fmaf(w1, fmaxf(fmaf(a1.w, x1.w, b1.w), f1), z.w);
-    *reinterpret_cast<float4*>(ob + v * old_) = z;
+    st4(ob + v * old_, z);
   };
 #pragma unroll
   for (int i = 0; i < PF; ++i) {
@@ -963,8 +967,8 @@ __global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwd
     const int64_t v = v0 + (int64_t)it * m.vpb;
     if (v >= N) break;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ACC) o = *reinterpret_cast<const float4*>(ob + v * old_);
-    emit(v, *reinterpret_cast<const float4*>(r0 + v * t0.rld), *reinterpret_cast<const float4*>(r1 + v * t1.rld), o);
+    if (ACC) o = ld4(ob + v * old_);
+    emit(v, ld4(r0 + v * t0.rld), ld4(r1 + v * t1.rld), o);
   }
 }
 
@@ -972,8 +976,8 @@ __global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwd
 struct BwdRedTerm { const float* raw; int64_t rld; const float* a; const float* b; double* sums; int relu; };
 
 // TWO: the second op has its own output gradient (independent outputs); otherwise both share dout (a node)
-template <bool TWO>
-__global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const float* __restrict__ dout, int64_t dld, const float* __restrict__ dout1,
+template <bool TWO, typename T = float>
+__global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ dout1,
                                                                  int64_t dld1, BwdRedTerm t0, BwdRedTerm t1, int64_t N, int C, EwMap m) {
   __shared__ double lds[4 * 64 * 12];
   const int b = blockIdx.y;
@@ -987,13 +991,13 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const float* __
     for (int j = 0; j < 4; ++j) s1[k][j] = s2[k][j] = sz[k][j] = 0.f;
   if (active) {
     float4 av[2], bv[2];
-    av[0] = *reinterpret_cast<const float4*>(t0.a + b * C + c4 * 4); bv[0] = *reinterpret_cast<const float4*>(t0.b + b * C + c4 * 4);
-    av[1] = *reinterpret_cast<const float4*>(t1.a + b * C + c4 * 4); bv[1] = *reinterpret_cast<const float4*>(t1.b + b * C + c4 * 4);
+    av[0] = ld4(t0.a + b * C + c4 * 4); bv[0] = ld4(t0.b + b * C + c4 * 4);
+    av[1] = ld4(t1.a + b * C + c4 * 4); bv[1] = ld4(t1.b + b * C + c4 * 4);
     const float thr[2] = {t0.relu ? 0.f : -INFINITY, t1.relu ? 0.f : -INFINITY};
-    const float* db = dout + (int64_t)b * N * dld + c4 * 4;
-    const float* db1 = TWO ? dout1 + (int64_t)b * N * dld1 + c4 * 4 : nullptr;
-    const float* rb0 = t0.raw + (int64_t)b * N * t0.rld + c4 * 4;
-    const float* rb1 = t1.raw + (int64_t)b * N * t1.rld + c4 * 4;
+    const T* db = dout + (int64_t)b * N * dld + c4 * 4;
+    const T* db1 = TWO ? dout1 + (int64_t)b * N * dld1 + c4 * 4 : nullptr;
+    const T* rb0 = reinterpret_cast<const T*>(t0.raw) + (int64_t)b * N * t0.rld + c4 * 4;
+    const T* rb1 = reinterpret_cast<const T*>(t1.raw) + (int64_t)b * N * t1.rld + c4 * 4;
     const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
     for (int it0 = 0; it0 < m.iters; it0 += 4) {
       float4 dq[4], dq1[TWO ? 4 : 1], rq[2][4];
@@ -1003,10 +1007,10 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const float* __
         const int64_t v = v0 + (int64_t)(it0 + u) * m.vpb;
         ok[u] = (it0 + u < m.iters) && v < N;
         const int64_t vc = ok[u] ? v : 0;
-        dq[u] = *reinterpret_cast<const float4*>(db + vc * dld);
-        if (TWO) dq1[TWO ? u : 0] = *reinterpret_cast<const float4*>(db1 + vc * dld1);
-        rq[0][u] = *reinterpret_cast<const float4*>(rb0 + vc * t0.rld);
-        rq[1][u] = *reinterpret_cast<const float4*>(rb1 + vc * t1.rld);
+        dq[u] = ld4(db + vc * dld);
+        if (TWO) dq1[TWO ? u : 0] = ld4(db1 + vc * dld1);
+        rq[0][u] = ld4(rb0 + vc * t0.rld);
+        rq[1][u] = ld4(rb1 + vc * t1.rld);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -1104,20 +1108,20 @@ __device__ __forceinline__ void gn_bwd_prologue_wave(const GnBwdTerm& t, const i
   }
 }
 
-template <bool PRE, bool TWO>
-__global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* __restrict__ dout, int64_t dld, const float* __restrict__ dout1,
+template <bool PRE, bool TWO, typename T = float>
+__global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ dout1,
                                                                    int64_t dld1, GnBwdTerm t0, GnBwdTerm t1, int B, int G, double count, int64_t N,
                                                                    int C, EwMap m) {
   __shared__ __attribute__((aligned(16))) float cw[4][2][3][64];  // [wave][term][A|B|C][channel]
   const int t = threadIdx.x, wave = t >> 6;
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   const int by = blockIdx.y;
-  const float* dbp = dout + (int64_t)by * N * dld + c4 * 4;
-  const float* dbp1 = TWO ? dout1 + (int64_t)by * N * dld1 + c4 * 4 : nullptr;  // TWO: second op has its own output gradient
-  const float* rb0 = t0.raw + (int64_t)by * N * t0.rld + c4 * 4;
-  const float* rb1 = t1.raw + (int64_t)by * N * t1.rld + c4 * 4;
-  float* o0 = t0.draw + (int64_t)by * N * t0.drld + c4 * 4;
-  float* o1 = t1.draw + (int64_t)by * N * t1.drld + c4 * 4;
+  const T* dbp = dout + (int64_t)by * N * dld + c4 * 4;
+  const T* dbp1 = TWO ? dout1 + (int64_t)by * N * dld1 + c4 * 4 : nullptr;  // TWO: second op has its own output gradient
+  const T* rb0 = reinterpret_cast<const T*>(t0.raw) + (int64_t)by * N * t0.rld + c4 * 4;
+  const T* rb1 = reinterpret_cast<const T*>(t1.raw) + (int64_t)by * N * t1.rld + c4 * 4;
+  T* o0 = reinterpret_cast<T*>(t0.draw) + (int64_t)by * N * t0.drld + c4 * 4;
+  T* o1 = reinterpret_cast<T*>(t1.draw) + (int64_t)by * N * t1.drld + c4 * 4;
   const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
   const bool act0 = vl < m.vpb && v0 < N;
   constexpr int PF = 4;
@@ -1125,20 +1129,20 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
   float4 fa[2], fb[2];
   fa[0] = fa[1] = make_float4(1.f, 1.f, 1.f, 1.f); fb[0] = fb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (act0) {
-    dq[0] = *reinterpret_cast<const float4*>(dbp + v0 * dld);
-    if (TWO) dq1[0] = *reinterpret_cast<const float4*>(dbp1 + v0 * dld1);
-    r0[0] = *reinterpret_cast<const float4*>(rb0 + v0 * t0.rld);
-    r1[0] = *reinterpret_cast<const float4*>(rb1 + v0 * t1.rld);
+    dq[0] = ld4(dbp + v0 * dld);
+    if (TWO) dq1[0] = ld4(dbp1 + v0 * dld1);
+    r0[0] = ld4(rb0 + v0 * t0.rld);
+    r1[0] = ld4(rb1 + v0 * t1.rld);
     const int co = by * C + c4 * 4;
-    fa[0] = *reinterpret_cast<const float4*>(t0.a + co); fb[0] = *reinterpret_cast<const float4*>(t0.b + co);
-    fa[1] = *reinterpret_cast<const float4*>(t1.a + co); fb[1] = *reinterpret_cast<const float4*>(t1.b + co);
+    fa[0] = ld4(t0.a + co); fb[0] = ld4(t0.b + co);
+    fa[1] = ld4(t1.a + co); fb[1] = ld4(t1.b + co);
   }
   float4 cA[2], cB[2], cC[2];
   if (PRE) {
     if (!act0) return;
     const int co = by * C + c4 * 4;
-    cA[0] = *reinterpret_cast<const float4*>(t0.cA + co); cB[0] = *reinterpret_cast<const float4*>(t0.cB + co); cC[0] = *reinterpret_cast<const float4*>(t0.cC + co);
-    cA[1] = *reinterpret_cast<const float4*>(t1.cA + co); cB[1] = *reinterpret_cast<const float4*>(t1.cB + co); cC[1] = *reinterpret_cast<const float4*>(t1.cC + co);
+    cA[0] = ld4(t0.cA + co); cB[0] = ld4(t0.cB + co); cC[0] = ld4(t0.cC + co);
+    cA[1] = ld4(t1.cA + co); cB[1] = ld4(t1.cB + co); cC[1] = ld4(t1.cC + co);
   } else {
     const bool lead_w = blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
     gn_bwd_prologue_wave(t0, B, C, G, count, lead_w, cw[wave][0]);
@@ -1149,9 +1153,9 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
     if (!act0) return;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      cA[k] = *reinterpret_cast<const float4*>(&cw[wave][k][0][c4 * 4]);
-      cB[k] = *reinterpret_cast<const float4*>(&cw[wave][k][1][c4 * 4]);
-      cC[k] = *reinterpret_cast<const float4*>(&cw[wave][k][2][c4 * 4]);
+      cA[k] = ld4(&cw[wave][k][0][c4 * 4]);
+      cB[k] = ld4(&cw[wave][k][1][c4 * 4]);
+      cC[k] = ld4(&cw[wave][k][2][c4 * 4]);
     }
   }
   const float thr[2] = {t0.relu ? 0.f : -INFINITY, t1.relu ? 0.f : -INFINITY};
@@ -1159,12 +1163,12 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
   for (int i = 1; i < PF; ++i) {
     const int64_t v = v0 + (int64_t)i * m.vpb;
     const int64_t vc = (i < m.iters && v < N) ? v : v0;
-    dq[i] = *reinterpret_cast<const float4*>(dbp + vc * dld);
-    if (TWO) dq1[TWO ? i : 0] = *reinterpret_cast<const float4*>(dbp1 + vc * dld1);
-    r0[i] = *reinterpret_cast<const float4*>(rb0 + vc * t0.rld);
-    r1[i] = *reinterpret_cast<const float4*>(rb1 + vc * t1.rld);
+    dq[i] = ld4(dbp + vc * dld);
+    if (TWO) dq1[TWO ? i : 0] = ld4(dbp1 + vc * dld1);
+    r0[i] = ld4(rb0 + vc * t0.rld);
+    r1[i] = ld4(rb1 + vc * t1.rld);
   }
-  auto one = [&](const int k, const float4 d4, const float4 r4, float* op) {
+  auto one = [&](const int k, const float4 d4, const float4 r4, T* op) {
     const float d[4] = {d4.x, d4.y, d4.z, d4.w}, r[4] = {r4.x, r4.y, r4.z, r4.w};
     const float a4[4] = {fa[k].x, fa[k].y, fa[k].z, fa[k].w}, b4[4] = {fb[k].x, fb[k].y, fb[k].z, fb[k].w};
     const float A4[4] = {cA[k].x, cA[k].y, cA[k].z, cA[k].w}, B4[4] = {cB[k].x, cB[k].y, cB[k].z, cB[k].w}, C4[4] = {cC[k].x, cC[k].y, cC[k].z, cC[k].w};
@@ -1175,7 +1179,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
       const float g = z > thr[k] ? d[j] : 0.f;
       o[j] = fmaf(A4[j], g, fmaf(C4[j], r[j], B4[j]));
     }
-    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+    st4(op, make_float4(o[0], o[1], o[2], o[3]));
   };
 #pragma unroll
   for (int i = 0; i < PF; ++i) {
@@ -1185,10 +1189,10 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
   for (int it = PF; it < m.iters; ++it) {
     const int64_t v = v0 + (int64_t)it * m.vpb;
     if (v >= N) break;
-    const float4 d4 = *reinterpret_cast<const float4*>(dbp + v * dld);
-    const float4 e4 = TWO ? *reinterpret_cast<const float4*>(dbp1 + v * dld1) : d4;
-    one(0, d4, *reinterpret_cast<const float4*>(rb0 + v * t0.rld), o0 + v * t0.drld);
-    one(1, e4, *reinterpret_cast<const float4*>(rb1 + v * t1.rld), o1 + v * t1.drld);
+    const float4 d4 = ld4(dbp + v * dld);
+    const float4 e4 = TWO ? ld4(dbp1 + v * dld1) : d4;
+    one(0, d4, ld4(rb0 + v * t0.rld), o0 + v * t0.drld);
+    one(1, e4, ld4(rb1 + v * t1.rld), o1 + v * t1.drld);
   }
 }
 
@@ -1201,8 +1205,8 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const float* 
 // fp64 across waves in a fixed order, coefficients in fp64 as the two-launch path does.
 // ------------------------------------------------------------------------------------------------
 // TWO: term 1 has its own output gradient dout1 (the two preprocess ops of a cell, independent outputs of one shape)
-template <int QPT, bool TWO>
-__global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __restrict__ dout, int64_t dld, const float* __restrict__ dout1,
+template <int QPT, bool TWO, typename T = float>
+__global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ dout1,
                                                             int64_t dld1, GnBwdTerm t0, GnBwdTerm t1, int B, int N, int C, int G, double count) {
   __shared__ float red[QPT * 16][2][32];   // [slot = i*16 + wave][term][(S1 | S2) x 16 channels]
   __shared__ double tot[4][2][32];         // [b][term][(S1 | S2) x 16 channels]
@@ -1232,10 +1236,10 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __rest
     ok[i] = e < total && er < real_b;
     bi[i] = ok[i] ? eb : 0;
     vox[i] = (int64_t)bi[i] * N + (ok[i] ? er : 0) / cpg4;
-    d4[i] = *reinterpret_cast<const float4*>(dout + vox[i] * dld + c0);
-    if (TWO) e4[TWO ? i : 0] = *reinterpret_cast<const float4*>(dout1 + vox[i] * dld1 + c0);
-    r0[i] = *reinterpret_cast<const float4*>(t0.raw + vox[i] * t0.rld + c0);
-    r1[i] = *reinterpret_cast<const float4*>(t1.raw + vox[i] * t1.rld + c0);
+    d4[i] = ld4(dout + vox[i] * dld + c0);
+    if (TWO) e4[TWO ? i : 0] = ld4(dout1 + vox[i] * dld1 + c0);
+    r0[i] = ld4(reinterpret_cast<const T*>(t0.raw) + vox[i] * t0.rld + c0);
+    r1[i] = ld4(reinterpret_cast<const T*>(t1.raw) + vox[i] * t1.rld + c0);
   }
   __syncthreads();
   // ---- pass 1: S1 = sum g, S2 = sum g * raw per (sample, channel), g = dout behind the term's ReLU mask
@@ -1247,7 +1251,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const float thr = k ? thr1 : thr0;
-      const float4 fa = *reinterpret_cast<const float4*>(&fco[bi[i]][k][0][q * 4]), fb = *reinterpret_cast<const float4*>(&fco[bi[i]][k][1][q * 4]);
+      const float4 fa = ld4(&fco[bi[i]][k][0][q * 4]), fb = ld4(&fco[bi[i]][k][1][q * 4]);
       const float aa[4] = {fa.x, fa.y, fa.z, fa.w}, bb[4] = {fb.x, fb.y, fb.z, fb.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1306,9 +1310,9 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const float thr = k ? thr1 : thr0;
-      const float4 fa = *reinterpret_cast<const float4*>(&fco[bi[i]][k][0][q * 4]), fb = *reinterpret_cast<const float4*>(&fco[bi[i]][k][1][q * 4]);
-      const float4 qA = *reinterpret_cast<const float4*>(&coef[bi[i]][k][0][q * 4]), qB = *reinterpret_cast<const float4*>(&coef[bi[i]][k][1][q * 4]),
-                   qC = *reinterpret_cast<const float4*>(&coef[bi[i]][k][2][q * 4]);
+      const float4 fa = ld4(&fco[bi[i]][k][0][q * 4]), fb = ld4(&fco[bi[i]][k][1][q * 4]);
+      const float4 qA = ld4(&coef[bi[i]][k][0][q * 4]), qB = ld4(&coef[bi[i]][k][1][q * 4]),
+                   qC = ld4(&coef[bi[i]][k][2][q * 4]);
       const float aa[4] = {fa.x, fa.y, fa.z, fa.w}, bb[4] = {fb.x, fb.y, fb.z, fb.w};
       const float A4[4] = {qA.x, qA.y, qA.z, qA.w}, B4[4] = {qB.x, qB.y, qB.z, qB.w}, C4[4] = {qC.x, qC.y, qC.z, qC.w};
       float o[4];
@@ -1318,8 +1322,8 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const float* __rest
         const float gm = z > thr ? dd[k][j] : 0.f;
         o[j] = fmaf(A4[j], gm, fmaf(C4[j], ra[k][j], B4[j]));
       }
-      float* op = (k ? t1.draw + vox[i] * t1.drld : t0.draw + vox[i] * t0.drld) + c0;
-      *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+      T* op = (k ? reinterpret_cast<T*>(t1.draw) + vox[i] * t1.drld : reinterpret_cast<T*>(t0.draw) + vox[i] * t0.drld) + c0;
+      st4(op, make_float4(o[0], o[1], o[2], o[3]));
     }
   }
   // ---- parameter gradients: sums over the samples in sample order
@@ -1358,8 +1362,8 @@ __global__ __launch_bounds__(256) void affine_actN_kernel(FwdTermN ts, float* __
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     if (k < ts.n) {
-      av[k] = ts.a[k] ? *reinterpret_cast<const float4*>(ts.a[k] + co) : make_float4(1.f, 1.f, 1.f, 1.f);
-      bv[k] = ts.b[k] ? *reinterpret_cast<const float4*>(ts.b[k] + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+      av[k] = ts.a[k] ? ld4(ts.a[k] + co) : make_float4(1.f, 1.f, 1.f, 1.f);
+      bv[k] = ts.b[k] ? ld4(ts.b[k] + co) : make_float4(0.f, 0.f, 0.f, 0.f);
       w[k] = ts.wptr[k] ? *ts.wptr[k] : 1.0f;
       fl[k] = ts.relu[k] ? 0.f : -INFINITY;
       rb[k] = ts.raw[k] + (int64_t)b * N * ts.rld[k] + c4 * 4;
@@ -1372,9 +1376,9 @@ __global__ __launch_bounds__(256) void affine_actN_kernel(FwdTermN ts, float* __
     float4 q[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (k < ts.n) q[k] = *reinterpret_cast<const float4*>(rb[k] + v * ts.rld[k]);
+      if (k < ts.n) q[k] = ld4(rb[k] + v * ts.rld[k]);
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ACC) z = *reinterpret_cast<const float4*>(ob + v * old_);
+    if (ACC) z = ld4(ob + v * old_);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (k < ts.n) {
@@ -1382,7 +1386,7 @@ __global__ __launch_bounds__(256) void affine_actN_kernel(FwdTermN ts, float* __
         z.z = fmaf(w[k], fmaxf(fmaf(av[k].z, q[k].z, bv[k].z), fl[k]), z.z); z.w = fmaf(w[k], fmaxf(fmaf(av[k].w, q[k].w, bv[k].w), fl[k]), z.w);
       }
     }
-    *reinterpret_cast<float4*>(ob + v * old_) = z;
+    st4(ob + v * old_, z);
   }
 }
 
@@ -1399,8 +1403,8 @@ __global__ __launch_bounds__(256) void affine_bwd_reduceN_kernel(const float* __
   const bool active = vl < m.vpb;
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, sz[4] = {0.f, 0.f, 0.f, 0.f};
   if (active) {
-    const float4 av = tm.a ? *reinterpret_cast<const float4*>(tm.a + b * C + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-    const float4 bv = tm.b ? *reinterpret_cast<const float4*>(tm.b + b * C + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 av = tm.a ? ld4(tm.a + b * C + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bv = tm.b ? ld4(tm.b + b * C + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float a4[4] = {av.x, av.y, av.z, av.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
     const float thr = tm.relu ? 0.f : -INFINITY;
     const float* db = dout + (int64_t)b * N * dld + c4 * 4;
@@ -1414,8 +1418,8 @@ __global__ __launch_bounds__(256) void affine_bwd_reduceN_kernel(const float* __
         const int64_t v = v0 + (int64_t)(it0 + u) * m.vpb;
         ok[u] = (it0 + u < m.iters) && v < N;
         const int64_t vc = ok[u] ? v : 0;
-        dq[u] = *reinterpret_cast<const float4*>(db + vc * dld);
-        rq[u] = *reinterpret_cast<const float4*>(rb + vc * tm.rld);
+        dq[u] = ld4(db + vc * dld);
+        rq[u] = ld4(rb + vc * tm.rld);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -1460,9 +1464,9 @@ __global__ __launch_bounds__(256) void affine_bwd_applyN_kernel(const float* __r
   const float* rb = tm.raw + (int64_t)b * N * tm.rld + c4 * 4;
   float* ob = tm.draw + (int64_t)b * N * tm.drld + c4 * 4;
   // the first voxel's operands are requested together with the coefficients
-  float4 d0 = *reinterpret_cast<const float4*>(db + v0 * dld), r0 = *reinterpret_cast<const float4*>(rb + v0 * tm.rld);
-  const float4 fa = *reinterpret_cast<const float4*>(tm.a + co), fb = *reinterpret_cast<const float4*>(tm.b + co);
-  const float4 qA = *reinterpret_cast<const float4*>(tm.cA + co), qB = *reinterpret_cast<const float4*>(tm.cB + co), qC = *reinterpret_cast<const float4*>(tm.cC + co);
+  float4 d0 = ld4(db + v0 * dld), r0 = ld4(rb + v0 * tm.rld);
+  const float4 fa = ld4(tm.a + co), fb = ld4(tm.b + co);
+  const float4 qA = ld4(tm.cA + co), qB = ld4(tm.cB + co), qC = ld4(tm.cC + co);
   const float a4[4] = {fa.x, fa.y, fa.z, fa.w}, b4[4] = {fb.x, fb.y, fb.z, fb.w};
   const float A4[4] = {qA.x, qA.y, qA.z, qA.w}, B4[4] = {qB.x, qB.y, qB.z, qB.w}, C4[4] = {qC.x, qC.y, qC.z, qC.w};
   const float thr = tm.relu ? 0.f : -INFINITY;
@@ -1472,7 +1476,7 @@ __global__ __launch_bounds__(256) void affine_bwd_applyN_kernel(const float* __r
     const int64_t vn = v + m.vpb;
     const bool more = it + 1 < m.iters && vn < N;
     float4 d1 = d0, r1 = r0;
-    if (more) { d1 = *reinterpret_cast<const float4*>(db + vn * dld); r1 = *reinterpret_cast<const float4*>(rb + vn * tm.rld); }
+    if (more) { d1 = ld4(db + vn * dld); r1 = ld4(rb + vn * tm.rld); }
     const float d[4] = {d0.x, d0.y, d0.z, d0.w}, r[4] = {r0.x, r0.y, r0.z, r0.w};
     float o[4];
 #pragma unroll
@@ -1481,7 +1485,7 @@ __global__ __launch_bounds__(256) void affine_bwd_applyN_kernel(const float* __r
       const float g = z > thr ? d[j] : 0.f;
       o[j] = fmaf(A4[j], g, fmaf(C4[j], r[j], B4[j]));
     }
-    *reinterpret_cast<float4*>(ob + v * tm.drld) = make_float4(o[0], o[1], o[2], o[3]);
+    st4(ob + v * tm.drld, make_float4(o[0], o[1], o[2], o[3]));
     d0 = d1; r0 = r1;
   }
 }
@@ -1623,13 +1627,13 @@ __global__ __launch_bounds__(256) void pool2_fwd_kernel(const float* __restrict_
 #pragma unroll
       for (int kw = 0; kw < 2; ++kw) {
         const int64_t vi = ((int64_t)(2 * d_o + kd) * Hi + (2 * ho + kh)) * Wi + (2 * wo + kw);
-        const float4 q = *reinterpret_cast<const float4*>(xb + vi * xld);
+        const float4 q = ld4(xb + vi * xld);
         if (MAX) { acc.x = fmaxf(acc.x, q.x); acc.y = fmaxf(acc.y, q.y); acc.z = fmaxf(acc.z, q.z); acc.w = fmaxf(acc.w, q.w); }
         else { acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
       }
   if (!MAX) { acc.x *= 0.125f; acc.y *= 0.125f; acc.z *= 0.125f; acc.w *= 0.125f; }
   const int64_t vo = ((int64_t)d_o * Ho + ho) * Wo + wo;
-  *reinterpret_cast<float4*>(y + ((int64_t)b * Do * Ho * Wo + vo) * yld + c4 * 4) = acc;
+  st4(y + ((int64_t)b * Do * Ho * Wo + vo) * yld + c4 * 4, acc);
 }
 
 // average AND max pooling of one tensor in one pass (a stride-2 edge of a down cell carries both primitives, prim_ops.py:29-30)
@@ -1651,7 +1655,7 @@ __global__ __launch_bounds__(256) void pool2_fwd_both_kernel(const float* __rest
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int64_t vi = ((int64_t)(2 * d_o + (k >> 2)) * Hi + (2 * ho + ((k >> 1) & 1))) * Wi + (2 * wo + (k & 1));
-    q[k] = *reinterpret_cast<const float4*>(xb + vi * xld);
+    q[k] = ld4(xb + vi * xld);
   }
   float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sm = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
@@ -1661,8 +1665,8 @@ __global__ __launch_bounds__(256) void pool2_fwd_both_kernel(const float* __rest
   }
   sa.x *= 0.125f; sa.y *= 0.125f; sa.z *= 0.125f; sa.w *= 0.125f;
   const int64_t vo = (int64_t)b * Do * Ho * Wo + ((int64_t)d_o * Ho + ho) * Wo + wo;
-  *reinterpret_cast<float4*>(ya + vo * yald + c4 * 4) = sa;
-  *reinterpret_cast<float4*>(ym + vo * ymld + c4 * 4) = sm;
+  st4(ya + vo * yald + c4 * 4, sa);
+  st4(ym + vo * ymld + c4 * 4, sm);
 }
 
 // dx (+)= w_avg * avgpool^T(dy) + w_max * maxpool^T(dy): both pooling backwards of an edge in one pass over dx
@@ -1682,7 +1686,7 @@ __global__ __launch_bounds__(256) void pool2_bwd_both_kernel(const float* __rest
   const int ho = v % Ho;
   const int d_o = v / Ho;
   const int64_t vo = ((int64_t)d_o * Ho + ho) * Wo + wo;
-  const float4 gq = *reinterpret_cast<const float4*>(dy + ((int64_t)b * Do * Ho * Wo + vo) * dyld + c4 * 4);
+  const float4 gq = ld4(dy + ((int64_t)b * Do * Ho * Wo + vo) * dyld + c4 * 4);
   const float sa = (wa ? *wa : 1.0f) * 0.125f, sm = wm ? *wm : 1.0f;
   const float g[4] = {gq.x, gq.y, gq.z, gq.w};
   const float* xb = x + (int64_t)b * Di * Hi * Wi * xld + c4 * 4;
@@ -1693,8 +1697,8 @@ __global__ __launch_bounds__(256) void pool2_bwd_both_kernel(const float* __rest
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int64_t vi = ((int64_t)(2 * d_o + (k >> 2)) * Hi + (2 * ho + ((k >> 1) & 1))) * Wi + (2 * wo + (k & 1));
-    const float4 q = *reinterpret_cast<const float4*>(xb + vi * xld);
-    if (ACC) prev[k] = *reinterpret_cast<const float4*>(db + vi * dxld);
+    const float4 q = ld4(xb + vi * xld);
+    if (ACC) prev[k] = ld4(db + vi * dxld);
     const float qq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1707,7 +1711,7 @@ __global__ __launch_bounds__(256) void pool2_bwd_both_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = g[j] * sa + (arg[j] == k ? g[j] * sm : 0.f);
     if (ACC) { o[0] += prev[k].x; o[1] += prev[k].y; o[2] += prev[k].z; o[3] += prev[k].w; }
-    *reinterpret_cast<float4*>(db + vi * dxld) = make_float4(o[0], o[1], o[2], o[3]);
+    st4(db + vi * dxld, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
@@ -1729,7 +1733,7 @@ __global__ __launch_bounds__(256) void pool2_bwd_kernel(const float* __restrict_
   const int ho = v % Ho;
   const int d_o = v / Ho;
   const int64_t vo = ((int64_t)d_o * Ho + ho) * Wo + wo;
-  const float4 gq = *reinterpret_cast<const float4*>(dy + ((int64_t)b * Do * Ho * Wo + vo) * dyld + c4 * 4);
+  const float4 gq = ld4(dy + ((int64_t)b * Do * Ho * Wo + vo) * dyld + c4 * 4);
   const float wsc = wptr ? *wptr : 1.0f;   // MixedOp weight of the pooling primitive: dx (+)= w * pool^T(dy)
   const float g[4] = {gq.x * wsc, gq.y * wsc, gq.z * wsc, gq.w * wsc};
   const float* xb = x ? x + (int64_t)b * Di * Hi * Wi * xld + c4 * 4 : nullptr;
@@ -1740,7 +1744,7 @@ __global__ __launch_bounds__(256) void pool2_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int64_t vi = ((int64_t)(2 * d_o + (k >> 2)) * Hi + (2 * ho + ((k >> 1) & 1))) * Wi + (2 * wo + (k & 1));
-      const float4 q = *reinterpret_cast<const float4*>(xb + vi * xld);
+      const float4 q = ld4(xb + vi * xld);
       const float qq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -1890,26 +1894,40 @@ using namespace n3d;
 // ================================================================================================
 // C ABI
 // ================================================================================================
+// dispatch on the storage type of a call's activation tensors: f receives a null pointer of the element type
+template <typename F>
+static void with_act_type(bool bf16, F&& f) {
+  if (bf16) f(static_cast<bf16_t*>(nullptr));
+  else f(static_cast<float*>(nullptr));
+}
+#define N3D_T(tag) std::remove_pointer_t<decltype(tag)>
+
 extern "C" {
 
 int n3d_stats_rows(int64_t N, int C) { return ew_map(N, C).rows; }
 int n3d_dice_rows(int64_t N) { return (int)cdiv(N, DICE_CHUNK); }
 
-static int check_vec(const void* p, int64_t ld, int C, const char* what) {
-  if (C % 4 != 0 || ld % 4 != 0 || !aligned16(p) || C > 64 * 4) {
+static int check_vec(const void* p, int64_t ld, int C, const char* what, bool bf16 = false) {
+  if (C % 4 != 0 || ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p) & (bf16 ? 7 : 15)) != 0 || C > 64 * 4) {
     set_error("%s: needs C %% 4 == 0, ld %% 4 == 0, 16-byte aligned base (C=%d ld=%lld)", what, C, (long long)ld);
     return N3D_ERR_UNSUPPORTED;
   }
   return 0;
 }
 
-int n3d_channel_stats(const float* x, int64_t ld, int B, int64_t N, int C, double* stats, void* stream) {
-  N3D_CHECK_ARG(x && stats && B > 0 && N > 0 && C > 0 && C <= 64, "channel_stats: bad args");
-  if (int e = check_vec(x, ld, C, "channel_stats")) return e;
+int n3d_channel_stats_t(const void* x, int64_t ld, int dtype, int B, int64_t N, int C, double* stats, void* stream) {
+  N3D_CHECK_ARG(x && stats && B > 0 && N > 0 && C > 0 && C <= 64 && (dtype == N3D_F32 || dtype == N3D_BF16), "channel_stats: bad args");
+  if (int e = check_vec(x, ld, C, "channel_stats", dtype == N3D_BF16)) return e;
   EwMap m = ew_map(N, C);
-  hipLaunchKernelGGL(channel_stats_kernel, dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, x, ld, N, C, m, stats);
+  with_act_type(dtype == N3D_BF16, [&](auto* tag) {
+    using T = N3D_T(tag);
+    hipLaunchKernelGGL(channel_stats_kernel<T>, dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, (const T*)x, ld, N, C, m, stats);
+  });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
+}
+int n3d_channel_stats(const float* x, int64_t ld, int B, int64_t N, int C, double* stats, void* stream) {
+  return n3d_channel_stats_t(x, ld, N3D_F32, B, N, C, stats, stream);
 }
 
 int n3d_channel_statsN(const float* const* xs, const int64_t* lds, double* const* stats, int n, int B, int64_t N, int C, void* stream) {
@@ -1939,16 +1957,21 @@ int n3d_gn_coeffs(const double* stats, int rows, const float* gamma, const float
 int n3d_affine_act(const float* raw, int64_t rld, const float* a, const float* b, const float* wptr, float* out, int64_t old_, int B,
                    int64_t N, int C, int flags, void* stream) {
   N3D_CHECK_ARG(raw && out && B > 0 && N > 0, "affine_act: bad args");
-  if (int e = check_vec(raw, rld, C, "affine_act(raw)")) return e;
-  if (int e = check_vec(out, old_, C, "affine_act(out)")) return e;
+  const bool bf = flags & N3D_ACT_BF16;
+  if (int e = check_vec(raw, rld, C, "affine_act(raw)", bf)) return e;
+  if (int e = check_vec(out, old_, C, "affine_act(out)", bf)) return e;
   EwMap m = ew_map(N, C);
   dim3 grid(m.rows, B), blk(256);
   hipStream_t s = (hipStream_t)stream;
   const bool relu = flags & N3D_RELU, acc = flags & N3D_ACCUMULATE;
-  if (relu && acc) hipLaunchKernelGGL((affine_act_kernel<true, true>), grid, blk, 0, s, raw, rld, a, b, wptr, out, old_, N, C, m);
-  else if (relu) hipLaunchKernelGGL((affine_act_kernel<true, false>), grid, blk, 0, s, raw, rld, a, b, wptr, out, old_, N, C, m);
-  else if (acc) hipLaunchKernelGGL((affine_act_kernel<false, true>), grid, blk, 0, s, raw, rld, a, b, wptr, out, old_, N, C, m);
-  else hipLaunchKernelGGL((affine_act_kernel<false, false>), grid, blk, 0, s, raw, rld, a, b, wptr, out, old_, N, C, m);
+  with_act_type(bf, [&](auto* tag) {
+    using T = N3D_T(tag);
+    const T* r = (const T*)raw; T* o = (T*)out;
+    if (relu && acc) hipLaunchKernelGGL((affine_act_kernel<true, true, T>), grid, blk, 0, s, r, rld, a, b, wptr, o, old_, N, C, m);
+    else if (relu) hipLaunchKernelGGL((affine_act_kernel<true, false, T>), grid, blk, 0, s, r, rld, a, b, wptr, o, old_, N, C, m);
+    else if (acc) hipLaunchKernelGGL((affine_act_kernel<false, true, T>), grid, blk, 0, s, r, rld, a, b, wptr, o, old_, N, C, m);
+    else hipLaunchKernelGGL((affine_act_kernel<false, false, T>), grid, blk, 0, s, r, rld, a, b, wptr, o, old_, N, C, m);
+  });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -1956,12 +1979,16 @@ int n3d_affine_act(const float* raw, int64_t rld, const float* a, const float* b
 int n3d_affine_act_bwd_reduce(const float* dout, int64_t dld, const float* raw, int64_t rld, const float* a, const float* b, int B,
                               int64_t N, int C, int flags, double* sums, void* stream) {
   N3D_CHECK_ARG(dout && raw && sums && C <= 64, "affine_act_bwd_reduce: bad args");
-  if (int e = check_vec(dout, dld, C, "bwd_reduce(dout)")) return e;
-  if (int e = check_vec(raw, rld, C, "bwd_reduce(raw)")) return e;
+  const bool bf = flags & N3D_ACT_BF16;
+  if (int e = check_vec(dout, dld, C, "bwd_reduce(dout)", bf)) return e;
+  if (int e = check_vec(raw, rld, C, "bwd_reduce(raw)", bf)) return e;
   EwMap m = ew_map(N, C);
   dim3 grid(m.rows, B), blk(256);
-  if (flags & N3D_RELU) hipLaunchKernelGGL((affine_bwd_reduce_kernel<true>), grid, blk, 0, (hipStream_t)stream, dout, dld, raw, rld, a, b, N, C, m, sums);
-  else hipLaunchKernelGGL((affine_bwd_reduce_kernel<false>), grid, blk, 0, (hipStream_t)stream, dout, dld, raw, rld, a, b, N, C, m, sums);
+  with_act_type(bf, [&](auto* tag) {
+    using T = N3D_T(tag);
+    if (flags & N3D_RELU) hipLaunchKernelGGL((affine_bwd_reduce_kernel<true, T>), grid, blk, 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)raw, rld, a, b, N, C, m, sums);
+    else hipLaunchKernelGGL((affine_bwd_reduce_kernel<false, T>), grid, blk, 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)raw, rld, a, b, N, C, m, sums);
+  });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -1989,24 +2016,29 @@ int n3d_affine_act_gn2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int
   for (int i = 0; i < 2; ++i) {
     const n3d_gn_fwd_term* t = ts[i];
     N3D_CHECK_ARG(t->raw && t->stats && t->gamma && t->beta && t->a_out && t->b_out && t->mean_rstd_out, "affine_act_gn2: null term pointer");
-    if (int e = check_vec(t->raw, t->rld, C, "affine_act_gn2(raw)")) return e;
+    if (int e = check_vec(t->raw, t->rld, C, "affine_act_gn2(raw)", flags & N3D_ACT_BF16)) return e;
     k[i] = GnFwdTerm{t->raw, t->rld, t->stats, t->rows, t->gamma, t->beta, t->wptr, t->a_out, t->b_out, t->mean_rstd_out, t->sumraw, t->relu};
   }
-  if (int e = check_vec(out, old_, C, "affine_act_gn2(out)")) return e;
-  if (out1) { if (int e = check_vec(out1, old1, C, "affine_act_gn2(out1)")) return e; }
+  const bool bf = flags & N3D_ACT_BF16;
+  if (int e = check_vec(out, old_, C, "affine_act_gn2(out)", bf)) return e;
+  if (out1) { if (int e = check_vec(out1, old1, C, "affine_act_gn2(out1)", bf)) return e; }
   EwMap m = ew_map(N, C);
   dim3 grid(m.rows, B), blk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true, false>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, out, old_, out1, old1, N, C, m);
-  else hipLaunchKernelGGL((affine_act_gn2_kernel<false, false>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, out, old_, out1, old1, N, C, m);
+  with_act_type(bf, [&](auto* tag) {
+    using T = N3D_T(tag);
+    if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true, false, T>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, (T*)out, old_, (T*)out1, old1, N, C, m);
+    else hipLaunchKernelGGL((affine_act_gn2_kernel<false, false, T>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, (T*)out, old_, (T*)out1, old1, N, C, m);
+  });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
 
 int n3d_affine_act_bwd_reduce2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
                                const n3d_gn_bwd_term* t1, int B, int64_t N, int C, void* stream) {
-  N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0 && C <= 64, "affine_act_bwd_reduce2: bad args");
-  if (int e = check_vec(dout, dld, C, "bwd_reduce2(dout)")) return e;
+  N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0 && C <= 64 && t0->dtype == t1->dtype, "affine_act_bwd_reduce2: bad args");
+  const bool bf = t0->dtype == N3D_BF16;
+  if (int e = check_vec(dout, dld, C, "bwd_reduce2(dout)", bf)) return e;
   EwMap m = ew_map(N, C);
   if ((m.cpb & (m.cpb - 1)) != 0) N3D_UNSUPPORTED("affine_act_bwd_reduce2: C / 4 must be a power of two");
   BwdRedTerm k[2];
@@ -2014,12 +2046,15 @@ int n3d_affine_act_bwd_reduce2(const float* dout, int64_t dld, const float* dout
   for (int i = 0; i < 2; ++i) {
     const n3d_gn_bwd_term* t = ts[i];
     N3D_CHECK_ARG(t->raw && t->a && t->b && t->sums, "affine_act_bwd_reduce2: null term pointer");
-    if (int e = check_vec(t->raw, t->rld, C, "bwd_reduce2(raw)")) return e;
+    if (int e = check_vec(t->raw, t->rld, C, "bwd_reduce2(raw)", bf)) return e;
     k[i] = BwdRedTerm{t->raw, t->rld, t->a, t->b, t->sums, t->relu};
   }
-  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_reduce2(dout1)")) return e; }
-  if (dout1) hipLaunchKernelGGL(affine_bwd_reduce2_kernel<true>, dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], N, C, m);
-  else hipLaunchKernelGGL(affine_bwd_reduce2_kernel<false>, dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], N, C, m);
+  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_reduce2(dout1)", bf)) return e; }
+  with_act_type(bf, [&](auto* tag) {
+    using T = N3D_T(tag);
+    if (dout1) hipLaunchKernelGGL((affine_bwd_reduce2_kernel<true, T>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], N, C, m);
+    else hipLaunchKernelGGL((affine_bwd_reduce2_kernel<false, T>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], N, C, m);
+  });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2029,22 +2064,27 @@ int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const float* do
   N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0, "affine_act_bwd_apply_gn2: bad args");
   if (!pair_shape_ok(C, G) || t0->rows < 1 || t1->rows < 1 || t0->rows > n3d_fused_max_rows() || t1->rows > n3d_fused_max_rows())
     N3D_UNSUPPORTED("affine_act_bwd_apply_gn2: shape not supported by the pair kernel (C=%d G=%d rows=%d/%d)", C, G, t0->rows, t1->rows);
-  if (int e = check_vec(dout, dld, C, "bwd_apply_gn2(dout)")) return e;
+  N3D_CHECK_ARG(t0->dtype == t1->dtype, "affine_act_bwd_apply_gn2: both terms must share one storage type");
+  const bool bf = t0->dtype == N3D_BF16;
+  if (int e = check_vec(dout, dld, C, "bwd_apply_gn2(dout)", bf)) return e;
   GnBwdTerm k[2];
   const n3d_gn_bwd_term* ts[2] = {t0, t1};
   for (int i = 0; i < 2; ++i) {
     const n3d_gn_bwd_term* t = ts[i];
     N3D_CHECK_ARG(t->raw && t->a && t->b && t->sums && t->gamma && t->mean_rstd && t->draw, "affine_act_bwd_apply_gn2: null term pointer");
     N3D_CHECK_ARG(!t->dbias_conv || t->sumraw, "affine_act_bwd_apply_gn2: dbias_conv needs the forward per-channel sums");
-    if (int e = check_vec(t->raw, t->rld, C, "bwd_apply_gn2(raw)")) return e;
-    if (int e = check_vec(t->draw, t->drld, C, "bwd_apply_gn2(draw)")) return e;
+    if (int e = check_vec(t->raw, t->rld, C, "bwd_apply_gn2(raw)", bf)) return e;
+    if (int e = check_vec(t->draw, t->drld, C, "bwd_apply_gn2(draw)", bf)) return e;
     k[i] = GnBwdTerm{t->raw, t->rld, t->a, t->b, t->sums, t->rows, t->gamma, t->mean_rstd, t->wptr, t->sumraw, t->draw, t->drld,
                      t->dgamma, t->dbeta, t->dalpha, t->dbias_conv, t->relu, nullptr, nullptr, nullptr};
   }
   EwMap m = ew_map(N, C);
-  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_apply_gn2(dout1)")) return e; }
-  if (dout1) hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, true>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
-  else hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, false>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
+  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_apply_gn2(dout1)", bf)) return e; }
+  with_act_type(bf, [&](auto* tag) {
+    using T = N3D_T(tag);
+    if (dout1) hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, true, T>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
+    else hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, false, T>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
+  });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2062,10 +2102,11 @@ int n3d_bwd_small2_ok(int B, int64_t N, int C, int G) {
 
 int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
                               const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* stream) {
-  N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0, "affine_act_bwd_small2: bad args");
-  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_small2(dout1)")) return e; }
+  N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0 && t0->dtype == t1->dtype, "affine_act_bwd_small2: bad args");
+  const bool bf = t0->dtype == N3D_BF16;
+  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_small2(dout1)", bf)) return e; }
   if (!n3d_bwd_small2_ok(B, N, C, G)) N3D_UNSUPPORTED("affine_act_bwd_small2: shape not supported (B=%d N=%lld C=%d G=%d)", B, (long long)N, C, G);
-  if (int e = check_vec(dout, dld, C, "bwd_small2(dout)")) return e;
+  if (int e = check_vec(dout, dld, C, "bwd_small2(dout)", bf)) return e;
   GnBwdTerm k[2];
   const n3d_gn_bwd_term* ts[2] = {t0, t1};
   for (int i = 0; i < 2; ++i) {
@@ -2073,20 +2114,24 @@ int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const float* dout1
     N3D_CHECK_ARG(t->raw && t->a && t->b && t->gamma && t->mean_rstd && t->draw, "affine_act_bwd_small2: null term pointer");
     N3D_CHECK_ARG(!t->dalpha, "affine_act_bwd_small2: MixedOp weight gradients are not produced here (use the reduce2 / apply_gn2 pair)");
     N3D_CHECK_ARG(!t->dbias_conv || t->sumraw, "affine_act_bwd_small2: dbias_conv needs the forward per-channel sums");
-    if (int e = check_vec(t->raw, t->rld, C, "bwd_small2(raw)")) return e;
-    if (int e = check_vec(t->draw, t->drld, C, "bwd_small2(draw)")) return e;
+    if (int e = check_vec(t->raw, t->rld, C, "bwd_small2(raw)", bf)) return e;
+    if (int e = check_vec(t->draw, t->drld, C, "bwd_small2(draw)", bf)) return e;
     k[i] = GnBwdTerm{t->raw, t->rld, t->a, t->b, nullptr, 0, t->gamma, t->mean_rstd, t->wptr, t->sumraw, t->draw, t->drld,
                      t->dgamma, t->dbeta, nullptr, t->dbias_conv, t->relu, nullptr, nullptr, nullptr};
   }
   const int64_t quads = (int64_t)B * ((N * ((C / G) / 4) + 63) / 64 * 64);
   hipStream_t s = (hipStream_t)stream;
-  if (quads <= 1024) {
-    if (dout1) hipLaunchKernelGGL((gn_bwd_small2_kernel<1, true>), dim3(G), dim3(1024), 0, s, dout, dld, dout1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
-    else hipLaunchKernelGGL((gn_bwd_small2_kernel<1, false>), dim3(G), dim3(1024), 0, s, dout, dld, dout1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
-  } else {
-    if (dout1) hipLaunchKernelGGL((gn_bwd_small2_kernel<2, true>), dim3(G), dim3(1024), 0, s, dout, dld, dout1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
-    else hipLaunchKernelGGL((gn_bwd_small2_kernel<2, false>), dim3(G), dim3(1024), 0, s, dout, dld, dout1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
-  }
+  with_act_type(bf, [&](auto* tag) {
+    using T = N3D_T(tag);
+    const T* d0 = (const T*)dout; const T* d1 = (const T*)dout1;
+    if (quads <= 1024) {
+      if (dout1) hipLaunchKernelGGL((gn_bwd_small2_kernel<1, true, T>), dim3(G), dim3(1024), 0, s, d0, dld, d1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
+      else hipLaunchKernelGGL((gn_bwd_small2_kernel<1, false, T>), dim3(G), dim3(1024), 0, s, d0, dld, d1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
+    } else {
+      if (dout1) hipLaunchKernelGGL((gn_bwd_small2_kernel<2, true, T>), dim3(G), dim3(1024), 0, s, d0, dld, d1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
+      else hipLaunchKernelGGL((gn_bwd_small2_kernel<2, false, T>), dim3(G), dim3(1024), 0, s, d0, dld, d1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
+    }
+  });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2113,16 +2158,20 @@ int n3d_affine_act2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, float*
   for (int i = 0; i < 2; ++i) {
     const n3d_gn_fwd_term* t = ts[i];
     N3D_CHECK_ARG(t->raw && t->a_out && t->b_out, "affine_act2: null term pointer");
-    if (int e = check_vec(t->raw, t->rld, C, "affine_act2(raw)")) return e;
+    if (int e = check_vec(t->raw, t->rld, C, "affine_act2(raw)", flags & N3D_ACT_BF16)) return e;
     k[i] = GnFwdTerm{t->raw, t->rld, nullptr, 0, nullptr, nullptr, t->wptr, t->a_out, t->b_out, nullptr, nullptr, t->relu};
   }
-  if (int e = check_vec(out, old_, C, "affine_act2(out)")) return e;
-  if (out1) { if (int e = check_vec(out1, old1, C, "affine_act2(out1)")) return e; }
+  const bool bf = flags & N3D_ACT_BF16;
+  if (int e = check_vec(out, old_, C, "affine_act2(out)", bf)) return e;
+  if (out1) { if (int e = check_vec(out1, old1, C, "affine_act2(out1)", bf)) return e; }
   EwMap m = ew_map(N, C);
   dim3 grid(m.rows, B), blk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true, true>), grid, blk, 0, s, k[0], k[1], 1, (double)N, 0.f, out, old_, out1, old1, N, C, m);
-  else hipLaunchKernelGGL((affine_act_gn2_kernel<false, true>), grid, blk, 0, s, k[0], k[1], 1, (double)N, 0.f, out, old_, out1, old1, N, C, m);
+  with_act_type(bf, [&](auto* tag) {
+    using T = N3D_T(tag);
+    if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true, true, T>), grid, blk, 0, s, k[0], k[1], 1, (double)N, 0.f, (T*)out, old_, (T*)out1, old1, N, C, m);
+    else hipLaunchKernelGGL((affine_act_gn2_kernel<false, true, T>), grid, blk, 0, s, k[0], k[1], 1, (double)N, 0.f, (T*)out, old_, (T*)out1, old1, N, C, m);
+  });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2145,22 +2194,26 @@ int n3d_gn_bwd_coeffs2(const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int
 
 int n3d_affine_act_bwd_apply2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
                               const n3d_gn_bwd_term* t1, int B, int64_t N, int C, void* stream) {
-  N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0 && C <= 64, "affine_act_bwd_apply2: bad args");
-  if (int e = check_vec(dout, dld, C, "bwd_apply2(dout)")) return e;
+  N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0 && C <= 64 && t0->dtype == t1->dtype, "affine_act_bwd_apply2: bad args");
+  const bool bf = t0->dtype == N3D_BF16;
+  if (int e = check_vec(dout, dld, C, "bwd_apply2(dout)", bf)) return e;
   GnBwdTerm k[2];
   const n3d_gn_bwd_term* ts[2] = {t0, t1};
   for (int i = 0; i < 2; ++i) {
     const n3d_gn_bwd_term* t = ts[i];
     N3D_CHECK_ARG(t->raw && t->a && t->b && t->cA && t->cB && t->cC && t->draw, "affine_act_bwd_apply2: null term pointer");
-    if (int e = check_vec(t->raw, t->rld, C, "bwd_apply2(raw)")) return e;
-    if (int e = check_vec(t->draw, t->drld, C, "bwd_apply2(draw)")) return e;
+    if (int e = check_vec(t->raw, t->rld, C, "bwd_apply2(raw)", bf)) return e;
+    if (int e = check_vec(t->draw, t->drld, C, "bwd_apply2(draw)", bf)) return e;
     k[i] = GnBwdTerm{t->raw, t->rld, t->a, t->b, nullptr, 0, nullptr, nullptr, nullptr, nullptr, t->draw, t->drld, nullptr, nullptr, nullptr,
                      nullptr, t->relu, t->cA, t->cB, t->cC};
   }
   EwMap m = ew_map(N, C);
-  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_apply2(dout1)")) return e; }
-  if (dout1) hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<true, true>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], B, 1, (double)N, N, C, m);
-  else hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<true, false>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, dout, dld, dout1, dld1, k[0], k[1], B, 1, (double)N, N, C, m);
+  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_apply2(dout1)", bf)) return e; }
+  with_act_type(bf, [&](auto* tag) {
+    using T = N3D_T(tag);
+    if (dout1) hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<true, true, T>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], B, 1, (double)N, N, C, m);
+    else hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<true, false, T>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], B, 1, (double)N, N, C, m);
+  });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2282,17 +2335,22 @@ int n3d_affine_act_bwd_apply(const float* dout, int64_t dld, const float* raw, i
                              const float* Bc, const float* Cc, float* draw, int64_t drld, int B, int64_t N, int C, int flags,
                              void* stream) {
   N3D_CHECK_ARG(dout && raw && draw, "affine_act_bwd_apply: bad args");
-  if (int e = check_vec(dout, dld, C, "bwd_apply(dout)")) return e;
-  if (int e = check_vec(raw, rld, C, "bwd_apply(raw)")) return e;
-  if (int e = check_vec(draw, drld, C, "bwd_apply(draw)")) return e;
+  const bool bf = flags & N3D_ACT_BF16;
+  if (int e = check_vec(dout, dld, C, "bwd_apply(dout)", bf)) return e;
+  if (int e = check_vec(raw, rld, C, "bwd_apply(raw)", bf)) return e;
+  if (int e = check_vec(draw, drld, C, "bwd_apply(draw)", bf)) return e;
   EwMap m = ew_map(N, C);
   dim3 grid(m.rows, B), blk(256);
   hipStream_t s = (hipStream_t)stream;
   const bool relu = flags & N3D_RELU, acc = flags & N3D_ACCUMULATE;
-  if (relu && acc) hipLaunchKernelGGL((affine_bwd_apply_kernel<true, true>), grid, blk, 0, s, dout, dld, raw, rld, a, b, A, Bc, Cc, draw, drld, N, C, m);
-  else if (relu) hipLaunchKernelGGL((affine_bwd_apply_kernel<true, false>), grid, blk, 0, s, dout, dld, raw, rld, a, b, A, Bc, Cc, draw, drld, N, C, m);
-  else if (acc) hipLaunchKernelGGL((affine_bwd_apply_kernel<false, true>), grid, blk, 0, s, dout, dld, raw, rld, a, b, A, Bc, Cc, draw, drld, N, C, m);
-  else hipLaunchKernelGGL((affine_bwd_apply_kernel<false, false>), grid, blk, 0, s, dout, dld, raw, rld, a, b, A, Bc, Cc, draw, drld, N, C, m);
+  with_act_type(bf, [&](auto* tag) {
+    using T = N3D_T(tag);
+    const T* d = (const T*)dout; const T* r = (const T*)raw; T* o = (T*)draw;
+    if (relu && acc) hipLaunchKernelGGL((affine_bwd_apply_kernel<true, true, T>), grid, blk, 0, s, d, dld, r, rld, a, b, A, Bc, Cc, o, drld, N, C, m);
+    else if (relu) hipLaunchKernelGGL((affine_bwd_apply_kernel<true, false, T>), grid, blk, 0, s, d, dld, r, rld, a, b, A, Bc, Cc, o, drld, N, C, m);
+    else if (acc) hipLaunchKernelGGL((affine_bwd_apply_kernel<false, true, T>), grid, blk, 0, s, d, dld, r, rld, a, b, A, Bc, Cc, o, drld, N, C, m);
+    else hipLaunchKernelGGL((affine_bwd_apply_kernel<false, false, T>), grid, blk, 0, s, d, dld, r, rld, a, b, A, Bc, Cc, o, drld, N, C, m);
+  });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2465,15 +2523,19 @@ int n3d_affine_act_gn(const float* raw, int64_t rld, const double* stats, int ro
                       float* mean_rstd_out, double* sumraw, void* stream) {
   N3D_CHECK_ARG(raw && out && stats && gamma && beta && a_out && b_out && mean_rstd_out && C <= 64 && C % G == 0 && rows >= 1 && rows <= 64,
                 "affine_act_gn: bad args");
-  if (int e = check_vec(raw, rld, C, "affine_act_gn(raw)")) return e;
-  if (int e = check_vec(out, old_, C, "affine_act_gn(out)")) return e;
+  const bool bf = flags & N3D_ACT_BF16;
+  if (int e = check_vec(raw, rld, C, "affine_act_gn(raw)", bf)) return e;
+  if (int e = check_vec(out, old_, C, "affine_act_gn(out)", bf)) return e;
   EwMap m = ew_map(N, C);
   dim3 grid(m.rows, B), blk(256);
   hipStream_t s = (hipStream_t)stream;
   const bool relu = flags & N3D_RELU, acc = flags & N3D_ACCUMULATE;
-#define N3D_AAG(R, A_) hipLaunchKernelGGL((affine_act_gn_kernel<R, A_>), grid, blk, 0, s, raw, rld, stats, rows, gamma, beta, G, (double)N, eps, wptr, out, old_, N, C, m, a_out, b_out, mean_rstd_out, sumraw)
-  if (relu && acc) N3D_AAG(true, true); else if (relu) N3D_AAG(true, false); else if (acc) N3D_AAG(false, true); else N3D_AAG(false, false);
+  with_act_type(bf, [&](auto* tag) {
+    using T = N3D_T(tag);
+#define N3D_AAG(R, A_) hipLaunchKernelGGL((affine_act_gn_kernel<R, A_, T>), grid, blk, 0, s, (const T*)raw, rld, stats, rows, gamma, beta, G, (double)N, eps, wptr, (T*)out, old_, N, C, m, a_out, b_out, mean_rstd_out, sumraw)
+    if (relu && acc) N3D_AAG(true, true); else if (relu) N3D_AAG(true, false); else if (acc) N3D_AAG(false, true); else N3D_AAG(false, false);
 #undef N3D_AAG
+  });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2485,16 +2547,20 @@ int n3d_affine_act_bwd_apply_gn(const float* dout, int64_t dld, const float* raw
   N3D_CHECK_ARG(dout && raw && draw && sums && gamma && mean_rstd && C <= 64 && C % G == 0 && rows >= 1 && rows <= 64 && B <= GNF_MAXB,
                 "affine_act_bwd_apply_gn: bad args (needs rows <= 64, B <= 4)");
   N3D_CHECK_ARG(!dbias_conv || sumraw, "affine_act_bwd_apply_gn: dbias_conv needs the forward per-channel sums");
-  if (int e = check_vec(dout, dld, C, "bwd_apply_gn(dout)")) return e;
-  if (int e = check_vec(raw, rld, C, "bwd_apply_gn(raw)")) return e;
-  if (int e = check_vec(draw, drld, C, "bwd_apply_gn(draw)")) return e;
+  const bool bf = flags & N3D_ACT_BF16;
+  if (int e = check_vec(dout, dld, C, "bwd_apply_gn(dout)", bf)) return e;
+  if (int e = check_vec(raw, rld, C, "bwd_apply_gn(raw)", bf)) return e;
+  if (int e = check_vec(draw, drld, C, "bwd_apply_gn(draw)", bf)) return e;
   EwMap m = ew_map(N, C);
   dim3 grid(m.rows, B), blk(256);
   hipStream_t s = (hipStream_t)stream;
   const bool relu = flags & N3D_RELU, acc = flags & N3D_ACCUMULATE;
-#define N3D_ABG(R, A_) hipLaunchKernelGGL((affine_bwd_apply_gn_kernel<R, A_>), grid, blk, 0, s, dout, dld, raw, rld, a, b, sums, rows, gamma, mean_rstd, wptr, sumraw, B, G, (double)N, draw, drld, N, C, m, dgamma, dbeta, dalpha, dbias_conv)
-  if (relu && acc) N3D_ABG(true, true); else if (relu) N3D_ABG(true, false); else if (acc) N3D_ABG(false, true); else N3D_ABG(false, false);
+  with_act_type(bf, [&](auto* tag) {
+    using T = N3D_T(tag);
+#define N3D_ABG(R, A_) hipLaunchKernelGGL((affine_bwd_apply_gn_kernel<R, A_, T>), grid, blk, 0, s, (const T*)dout, dld, (const T*)raw, rld, a, b, sums, rows, gamma, mean_rstd, wptr, sumraw, B, G, (double)N, (T*)draw, drld, N, C, m, dgamma, dbeta, dalpha, dbias_conv)
+    if (relu && acc) N3D_ABG(true, true); else if (relu) N3D_ABG(true, false); else if (acc) N3D_ABG(false, true); else N3D_ABG(false, false);
 #undef N3D_ABG
+  });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

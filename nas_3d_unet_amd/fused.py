@@ -55,6 +55,7 @@ class _Plan:
         self.pre0, self.pre1, self.n_nodes, self.c_node, self.edges, self.params = pre0, pre1, n_nodes, c_node, edges, params
         self.index = {id(p): i for i, p in enumerate(params)}
         self.pairs = pairs  # searched cell: node k = exactly two single-primitive edges (2k, 2k+1)
+        self.dt = torch.float32  # storage type of the cell's activations (bf16 configuration: set by _NetPlan)
 
 
 def searched_plan(cell):
@@ -149,7 +150,7 @@ def _node_fwd_units(plan):
 
 def _run_forward(plan, x0, x1, alpha1, alpha2):
     """Returns (cell output tensor, saved state)."""
-    with K.stats_cache():
+    with K.stats_cache(), K.storage(plan.dt):
         return _run_forward_impl(plan, x0, x1, alpha1, alpha2)
 
 
@@ -219,6 +220,11 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2):
 def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets=None, own_dout=False):
     """dx_targets = ((View | None, accumulate), (View | None, accumulate)): where the gradients of the two cell inputs go
     (NetFn passes the producers' gradient buffers); own_dout: `dout` is a private buffer the cell may accumulate into."""
+    with K.storage(plan.dt):
+        return _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, own_dout)
+
+
+def _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, own_dout):
     cn, nn = plan.c_node, plan.n_nodes
     dv = K.as_view(dout, "grad_output")
     out = st.out
@@ -230,11 +236,11 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
     if (REUSE_GRAD_OUTPUT or own_dout) and dv.t is dout and dv.ld == nn * cn:
         dcat = dv
     else:
-        dcat = K.as_view(K.empty_ndhwc(out.B, nn * cn, out.D, out.H, out.W, dev))
+        dcat = K.like(out)
         _copy_into(dv, dcat)
     dnodes = [_slice_view(dcat, k, cn) for k in range(nn)]
     p0, p1 = st.xs[0], st.xs[1]
-    dpre = [K.as_view(K.empty_ndhwc(p0.B, p0.C, p0.D, p0.H, p0.W, dev)), K.as_view(K.empty_ndhwc(p1.B, p1.C, p1.D, p1.H, p1.W, dev))]
+    dpre = [K.like(p0), K.like(p1)]
     pre_started = [False, False]
     grads = [None] * len(plan.params)
     da1 = torch.zeros_like(alpha1) if (want_dalpha and alpha1 is not None) else None
@@ -459,7 +465,7 @@ class MixedOpFn(torch.autograd.Function):
         dv = K.as_view(dout, "grad_output")
         xv = ctx.xv
         need_dx = ctx.needs_input_grad[1]
-        dx = K.as_view(K.empty_ndhwc(xv.B, xv.C, xv.D, xv.H, xv.W, xv.t.device)) if need_dx else None
+        dx = K.like(xv) if need_dx else None
         dalpha = torch.zeros_like(ctx.w) if ctx.needs_input_grad[2] else None
         grads = [None] * ctx.nparams
         for k, (seg, s) in enumerate(zip(ctx.segs, ctx.saved)):
@@ -475,6 +481,7 @@ class MixedOpFn(torch.autograd.Function):
 # =================================================================================================
 # whole-net autograd node
 # =================================================================================================
+BF16_MAX_NODE_WIDTH = 8  # bf16 configuration: cells with at most this many channels per node store their activations in bf16
 WHOLE_NET = True  # nets run stems + cells as ONE autograd node (NetFn); False: one node per stem / cell
 # data-parallel trainers: called as CELL_DONE_HOOK(k) inside NetFn.backward when every parameter gradient of cell k (k = index
 # into down_cells + up_cells; -1 = the stems, i.e. the end) has been launched -- the point where a gradient bucket can be handed
@@ -494,6 +501,13 @@ class _NetPlan:
             if c._plan is None:
                 c._plan = make(c)
         self.cells = [c._plan for c in cells]
+        # storage policy (BASELINE configs[4]): with net._n3d_storage == "bf16" the stems and the cells of the HBM-bound levels
+        # (node width <= 8: the 128^3 .. 32^3 tensors, ~94 % of a step's bytes) keep their activations and activation
+        # gradients in bf16; the deep cells (16 .. 64 channels on <= 32^3 voxels, latency-bound, L2-resident) stay fp32
+        bf = getattr(net, "_n3d_storage", "fp32") == "bf16"
+        for pl in self.cells:
+            pl.dt = torch.bfloat16 if (bf and pl.c_node <= BF16_MAX_NODE_WIDTH) else torch.float32
+        self.stem_dt = torch.bfloat16 if bf else torch.float32
         self.n_down = len(net.down_cells)
         # activations: 0 = stem0, 1 = stem1, 2 + k = cell k.  wiring[k] = (x0 index, x1 index, output index)
         self.wiring = []
@@ -528,8 +542,9 @@ class NetFn(torch.autograd.Function):
     def forward(ctx, nplan, x, a1d, a1u, a2d, a2u, *params):
         xv = K.as_view(x, "input")
         al = [a.detach().contiguous() if a is not None else None for a in (a1d, a1u, a2d, a2u)]
-        s0, st0 = P.seg_forward(nplan.stem0, xv)
-        s1, st1 = P.seg_forward(nplan.stem1, xv)
+        with K.storage(nplan.stem_dt):
+            s0, st0 = P.seg_forward(nplan.stem0, xv)
+            s1, st1 = P.seg_forward(nplan.stem1, xv)
         acts, states = [s0.t, s1.t], []
         for k, (i0, i1, _) in enumerate(nplan.wiring):
             a1, a2 = (al[0], al[2]) if k < nplan.n_down else (al[1], al[3])

@@ -42,13 +42,60 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def empty_ndhwc(B, Cc, D, H, W, device, dtype=torch.float32):
-    """Dense NDHWC storage presented with the reference's logical (B, C, D, H, W) shape."""
-    return torch.empty((B, D, H, W, Cc), device=device, dtype=dtype).permute(0, 4, 1, 2, 3)
+# Storage type of NEW forward activations (conv outputs, node buffers): fp32, or bf16 inside `with storage(torch.bfloat16)` --
+# the bf16 configuration (BASELINE configs[4]) switches it per cell (fused._Plan.dt).  Gradient buffers never consult it: they
+# take the type of the forward tensor they belong to (`like`).
+_act_dtype = torch.float32
 
 
-def zeros_ndhwc(B, Cc, D, H, W, device, dtype=torch.float32):
-    return torch.zeros((B, D, H, W, Cc), device=device, dtype=dtype).permute(0, 4, 1, 2, 3)
+class storage:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _act_dtype
+        self.prev, _act_dtype = _act_dtype, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global _act_dtype
+        _act_dtype = self.prev
+        return False
+
+
+def empty_ndhwc(B, Cc, D, H, W, device, dtype=None):
+    """Dense NDHWC storage presented with the reference's logical (B, C, D, H, W) shape (dtype None: the current storage type)."""
+    return torch.empty((B, D, H, W, Cc), device=device, dtype=dtype if dtype is not None else _act_dtype).permute(0, 4, 1, 2, 3)
+
+
+def zeros_ndhwc(B, Cc, D, H, W, device, dtype=None):
+    return torch.zeros((B, D, H, W, Cc), device=device, dtype=dtype if dtype is not None else _act_dtype).permute(0, 4, 1, 2, 3)
+
+
+def like(v):
+    """fresh dense View of the shape and storage type of View v (gradient buffers, temporaries)"""
+    return View(empty_ndhwc(v.B, v.C, v.D, v.H, v.W, v.t.device, v.t.dtype), v.C)
+
+
+def _need_f32(what, *views):
+    for v in views:
+        if v is not None and v.dt != _lib.F32:
+            raise N3DError("%s: bf16 storage is not built for this kernel family (fp32 tensors only)" % what)
+
+
+def _cflags(flags, src, dst):
+    """conv-family storage flags: src / dst = the first / second activation tensor of the call"""
+    return flags | (_lib.SRC_BF16 if src.dt == _lib.BF16 else 0) | (_lib.DST_BF16 if dst.dt == _lib.BF16 else 0)
+
+
+def _aflag(v):
+    return _lib.ACT_BF16 if v.dt == _lib.BF16 else 0
+
+
+def _same_dt(what, *views):
+    dts = {v.dt for v in views if v is not None}
+    if len(dts) > 1:
+        raise N3DError("%s: the activation tensors of one epilogue call must share a storage type" % what)
 
 
 class View:
@@ -94,9 +141,9 @@ def _pitch_of(t):
     return ld
 
 
-def as_view(t, what="tensor", bf16_ok=False):
-    """Validate (or repack with a copy) a logical (B,C,D,H,W) tensor into a pitched NDHWC view.  bf16_ok: the caller's
-    kernels take bf16 storage too (the entry points with a dtype argument)."""
+def as_view(t, what="tensor", bf16_ok=True):
+    """Validate (or repack with a copy) a logical (B,C,D,H,W) tensor into a pitched NDHWC view (fp32 or bf16 storage; the
+    kernel families without bf16 support check for themselves)."""
     if not isinstance(t, torch.Tensor) or t.dim() != 5:
         raise N3DError("%s: expected a 5-D (B,C,D,H,W) tensor" % what)
     if not t.is_cuda:
@@ -222,7 +269,10 @@ def _packed(w, g, data_grad, flags, device):
 
 
 # ------------------------------------------------------------------------------------------ convs
-def conv_stats_rows(g, transposed, flags=0):
+def conv_stats_rows(g, transposed, flags=0, x=None, y=None):
+    """x / y: the call's input / output views (their storage types select the kernel, hence the row count)"""
+    if x is not None and y is not None:
+        flags = _cflags(flags, x, y)
     return int(_lib.load().n3d_conv_stats_rows(C.byref(g), 1 if transposed else 0, flags))
 
 
@@ -231,6 +281,7 @@ def stats_rows(N, Cc):
 
 
 def conv_fwd(g, x: View, w, bias, y: View, flags=0, in_gate=None, stats=None, transposed=False):
+    flags = _cflags(flags, x, y)
     ws, wsp, n, flags = _packed(w, g, transposed, flags, x.t.device)
     fn = _lib.load().n3d_convT_fwd if transposed else _lib.load().n3d_conv_fwd
     check(fn(C.byref(g), x.p, x.ld, ptr(w), ptr(bias), y.p, y.ld, flags, ptr(in_gate), ptr(stats), wsp, n,
@@ -238,6 +289,9 @@ def conv_fwd(g, x: View, w, bias, y: View, flags=0, in_gate=None, stats=None, tr
 
 
 def conv_bwd_data(g, dy: View, w, dx: View, flags=0, relu_src: View | None = None, out_gate=None, transposed=False):
+    flags = _cflags(flags, dy, dx)
+    if relu_src is not None and relu_src.dt != dx.dt:
+        raise N3DError("conv_bwd_data: the ReLU mask source must have the gradient's storage type")
     ws, wsp, n, flags = _packed(w, g, not transposed, flags, dy.t.device)
     lib = _lib.load()
     if transposed:
@@ -254,6 +308,7 @@ def conv_bwd_data(g, dy: View, w, dx: View, flags=0, relu_src: View | None = Non
 
 def conv_bwd_weight(g, x: View, dy: View, dw, dbias, flags=0, in_gate=None, transposed=False, defer=True):
     """defer=False: dw is complete when the call returns to the stream (no batched reduction at the end of backward)"""
+    flags = _cflags(flags, x, dy)
     ws, n = _ws(g, x.t.device)
     lib = _lib.load()
     job = FinalJob() if (_ctx is not None and defer) else None
@@ -276,6 +331,7 @@ def conv_fwd2(calls):
     """Two forward convs, one launch where libn3d can fold them.  calls = [(g, x, w, bias, y, flags, in_gate, stats, transposed)] * 2"""
     cs, keep = [], []
     for (g, x, w, bias, y, flags, in_gate, stats, transposed) in calls:
+        flags = _cflags(flags, x, y)
         ws, wsp, n, flags = _packed(w, g, transposed, flags, x.t.device)
         keep.append((ws, g))
         cs.append(ConvFwdCall(C.pointer(g), 1 if transposed else 0, flags, x.p.value, x.ld, w.data_ptr(), _vp(bias), y.p.value, y.ld,
@@ -289,6 +345,7 @@ def conv_fwdN(calls):
     arr = (ConvFwdCall * n)()
     keep = []
     for i, (g, x, w, bias, y, flags, in_gate, stats, transposed) in enumerate(calls):
+        flags = _cflags(flags, x, y)
         ws, wsp, nb, flags = _packed(w, g, transposed, flags, x.t.device)
         keep.append((ws, g))
         arr[i] = ConvFwdCall(C.pointer(g), 1 if transposed else 0, flags, x.p.value, x.ld, w.data_ptr(), _vp(bias), y.p.value, y.ld,
@@ -301,6 +358,7 @@ def conv_bwd_both2(calls):
     calls = [(g, x, dy, w, dx, dw, dbias, flags_data, relu_src, out_gate, flags_weight, in_gate, transposed)] * 2"""
     cs, keep, jobs = [], [], []
     for (g, x, dy, w, dx, dw, dbias, flags_data, relu_src, out_gate, flags_weight, in_gate, transposed) in calls:
+        _need_f32("conv_bwd_both2", x, dy, dx)
         wsd, wspd, nd, flags_data = _packed(w, g, not transposed, flags_data, dy.t.device)
         ws, n = _ws(g, x.t.device)
         job = FinalJob() if _ctx is not None else None
@@ -324,6 +382,7 @@ def dwconv_batch(jobs):
     n = len(jobs)
     arr = (DwJob * n)()
     for i, (g, data_grad, src, w, bias, dst, flags) in enumerate(jobs):
+        _need_f32("dwconv_batch", src, dst)
         arr[i] = DwJob(C.pointer(g), 1 if data_grad else 0, flags, src.p.value, src.ld, w.data_ptr(), _vp(bias), dst.p.value, dst.ld)
     check(_lib.load().n3d_dwconv_batch(arr, n, stream_ptr()), "n3d_dwconv_batch")
 
@@ -333,6 +392,7 @@ def conv_bwd_data2(calls):
     calls = [(g, dy, w, dx, flags, relu_src, out_gate, transposed)] * 2, arguments as conv_bwd_data."""
     cs, keep = [], []
     for (g, dy, w, dx, flags, relu_src, out_gate, transposed) in calls:
+        _need_f32("conv_bwd_data2", dy, dx)
         ws, wsp, n, flags = _packed(w, g, not transposed, flags, dy.t.device)
         keep.append((ws, g))
         cs.append(ConvBwdCall(C.pointer(g), 1 if transposed else 0, flags, 0, 0, None, 0, dy.p.value, dy.ld, w.data_ptr(), dx.p.value, dx.ld,
@@ -344,6 +404,7 @@ def conv_bwd_data2(calls):
 def conv_bwd_both(g, x: View, dy: View, w, dx: View, dw, dbias, flags_data=0, relu_src: View | None = None, out_gate=None,
                   flags_weight=0, in_gate=None, transposed=False):
     """conv_bwd_data + conv_bwd_weight of one conv; one launch where libn3d can fold them."""
+    _need_f32("conv_bwd_both", x, dy, dx)
     wsd, wspd, nd, flags_data = _packed(w, g, not transposed, flags_data, dy.t.device)
     ws, n = _ws(g, x.t.device)
     job = FinalJob() if (_ctx is not None and not g.depthwise) else None
@@ -399,6 +460,7 @@ def channel_stats(x: View):
 
 def channel_statsN(xs):
     """channel_stats of several tensors (cache honoured); the ones still missing that share a shape go out in one launch"""
+    _need_f32("channel_statsN", *xs)
     out = [None] * len(xs)
     todo = {}
     for i, x in enumerate(xs):
@@ -435,7 +497,7 @@ def channel_statsN(xs):
 def _channel_stats(x: View):
     rows = stats_rows(x.N, x.C)
     st = torch.empty((x.B, rows, x.C, 2), dtype=torch.float64, device=x.t.device)
-    check(_lib.load().n3d_channel_stats(x.p, x.ld, x.B, x.N, x.C, ptr(st), stream_ptr()), "n3d_channel_stats")
+    check(_lib.load().n3d_channel_stats_t(x.p, x.ld, x.dt, x.B, x.N, x.C, ptr(st), stream_ptr()), "n3d_channel_stats_t")
     return st, rows
 
 
@@ -451,6 +513,8 @@ def gn_coeffs(stats, rows, gamma, beta, B, Cc, G, N, eps=1e-5):
 
 
 def affine_act(raw: View, a, b, wptr, out: View, flags=0):
+    _same_dt("affine_act", raw, out)
+    flags |= _aflag(raw)
     check(_lib.load().n3d_affine_act(raw.p, raw.ld, ptr(a), ptr(b), wptr, out.p, out.ld, raw.B, raw.N, raw.C, flags,
                                      stream_ptr()), "n3d_affine_act")
 
@@ -467,6 +531,8 @@ def fused_max_rows():
 
 def affine_act_gn(raw: View, stats, rows, gamma, beta, G, eps, wptr, out: View, flags=0):
     """GroupNorm coefficients + normalise/activate/accumulate in one launch (small tensors)."""
+    _same_dt("affine_act_gn", raw, out)
+    flags |= _aflag(raw)
     dev = raw.t.device
     a = torch.empty((raw.B, raw.C), dtype=torch.float32, device=dev)
     b = torch.empty((raw.B, raw.C), dtype=torch.float32, device=dev)
@@ -483,6 +549,8 @@ def affine_act_bwd_apply_gn(dout: View, raw: View, a, b, sums, rows, gamma, beta
     dgamma = grad_target(gamma)
     dbeta = grad_target(beta)
     dcb = grad_target(conv_bias) if (conv_bias is not None and sumraw is not None) else None
+    _same_dt("affine_act_bwd_apply_gn", dout, raw, draw)
+    flags |= _aflag(raw)
     check(_lib.load().n3d_affine_act_bwd_apply_gn(dout.p, dout.ld, raw.p, raw.ld, ptr(a), ptr(b), ptr(sums), rows, ptr(gamma),
                                                   ptr(mean_rstd), wptr, ptr(sumraw), draw.p, draw.ld, raw.B, raw.N,
                                                   raw.C, G, flags, ptr(dgamma), ptr(dbeta), dalpha_ptr, ptr(dcb),
@@ -514,6 +582,8 @@ def affine_act_gn2(terms, G, eps, out: View, flags=0, out1: View | None = None):
     """Two GroupNorm -> [ReLU] -> weighted-sum epilogues into one output: terms = [(raw, stats, rows, gamma, beta, wptr, relu)] * 2.
     Returns [(a, b, mean_rstd, sumraw)] * 2 (saved for backward)."""
     raw0 = terms[0][0]
+    _same_dt("affine_act_gn2", raw0, terms[1][0], out, out1)
+    flags |= _aflag(raw0)
     dev = raw0.t.device
     B, Cc = raw0.B, raw0.C
     # one allocation for both terms' saved coefficients
@@ -526,7 +596,7 @@ def affine_act_gn2(terms, G, eps, out: View, flags=0, out1: View | None = None):
         mr = fbuf[i, 2 * B * Cc:].view(B, G, 2)
         sr = dbuf[i].view(B, Cc)
         ts.append(GnFwdTerm(raw.p.value, raw.ld, stats.data_ptr(), rows, 1 if relu else 0, gamma.data_ptr(), beta.data_ptr(),
-                            _vp(wptr), a.data_ptr(), b.data_ptr(), mr.data_ptr(), sr.data_ptr()))
+                            _vp(wptr), a.data_ptr(), b.data_ptr(), mr.data_ptr(), sr.data_ptr(), raw.dt, 0))
         saved.append((a, b, mr, sr))
     lib = _lib.load()
     o1p, o1ld = (out1.p, out1.ld) if out1 is not None else (None, 0)
@@ -548,6 +618,7 @@ def affine_act_bwd_gn2(dout: View, terms, G, dout1: View | None = None):
     """Backward of affine_act_gn2: terms = [dict(raw, a, b, mr, sumraw, gamma, beta, wptr, relu, conv_bias, draw, dalpha_ptr)] * 2.
     Two launches (reduce, apply) for both ops.  Returns [(dgamma, dbeta, dconv_bias | None)] * 2."""
     raw0 = terms[0]["raw"]
+    _same_dt("affine_act_bwd_gn2", raw0, terms[1]["raw"], terms[0]["draw"], terms[1]["draw"], dout, dout1)
     dev = raw0.t.device
     B, Cc, N = raw0.B, raw0.C, raw0.N
     lib = _lib.load()
@@ -561,7 +632,7 @@ def affine_act_bwd_gn2(dout: View, terms, G, dout1: View | None = None):
             raw, draw = t["raw"], t["draw"]
             ts.append(GnBwdTerm(raw.p.value, raw.ld, t["a"].data_ptr(), t["b"].data_ptr(), None, 0, 1 if t["relu"] else 0,
                                 t["gamma"].data_ptr(), t["mr"].data_ptr(), _vp(t.get("wptr")), _vp(t["sumraw"]), draw.p.value, draw.ld,
-                                _vp(dgamma), _vp(dbeta), None, _vp(dcb), None, None, None))
+                                _vp(dgamma), _vp(dbeta), None, _vp(dcb), None, None, None, raw.dt, 0))
             outs.append((dgamma, dbeta, dcb))
         d1p, d1ld = (dout1.p, dout1.ld) if dout1 is not None else (None, 0)
         check(lib.n3d_affine_act_bwd_small2(dout.p, dout.ld, d1p, d1ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, G, stream_ptr()),
@@ -580,7 +651,7 @@ def affine_act_bwd_gn2(dout: View, terms, G, dout1: View | None = None):
         ts.append(GnBwdTerm(raw.p.value, raw.ld, t["a"].data_ptr(), t["b"].data_ptr(), sums[i].data_ptr(), rows, 1 if t["relu"] else 0,
                             t["gamma"].data_ptr(), t["mr"].data_ptr(), _vp(t.get("wptr")), _vp(t["sumraw"]), draw.p.value, draw.ld,
                             _vp(dgamma), _vp(dbeta), _vp(t.get("dalpha_ptr")), _vp(dcb),
-                            *([None] * 3 if fused else [coef[i, j].data_ptr() for j in range(3)])))
+                            *([None] * 3 if fused else [coef[i, j].data_ptr() for j in range(3)]), raw.dt, 0))
         outs.append((dgamma, dbeta, dcb))
     lib = _lib.load()
     d1p, d1ld = (dout1.p, dout1.ld) if dout1 is not None else (None, 0)
@@ -609,6 +680,7 @@ def gn_coeffsN(terms, G, eps):
     Returns [(a, b, mean_rstd, sumraw)] (what affine_actN reads and backward needs)."""
     n = len(terms)
     raw0 = terms[0][0]
+    _need_f32("gn_coeffsN / affine_actN", *[t[0] for t in terms])
     dev = raw0.t.device
     B, Cc = raw0.B, raw0.C
     fbuf = torch.empty((n, 2 * B * Cc + 2 * B * G), dtype=torch.float32, device=dev)
@@ -631,6 +703,7 @@ def affine_actN(terms, out: View, flags=0):
     """out (+)= sum_k w_k * act_k(a_k * raw_k + b_k) for up to 8 terms in one pass: terms = [(raw, a | None, b | None, wptr, relu)]."""
     n = len(terms)
     raw0 = terms[0][0]
+    _need_f32("affine_actN", out, *[t[0] for t in terms])
     arr = (GnFwdTerm * n)()
     for i, (raw, a, b, wptr, relu) in enumerate(terms):
         arr[i] = GnFwdTerm(raw.p.value, raw.ld, None, 0, 1 if relu else 0, None, None, _vp(wptr), _vp(a), _vp(b), None, None)
@@ -643,6 +716,7 @@ def affine_act_bwd_gnN(dout: View, terms, G):
     Returns [(dgamma, dbeta, dconv_bias | None)]."""
     n = len(terms)
     raw0 = terms[0]["raw"]
+    _need_f32("affine_act_bwd_gnN", dout, *[t["raw"] for t in terms])
     dev = raw0.t.device
     B, Cc, N = raw0.B, raw0.C, raw0.N
     rows = stats_rows(N, Cc)
@@ -671,6 +745,7 @@ def affine_act_bwd_reduceN(dout: View, terms):
     Returns [(sums, rows)]."""
     n = len(terms)
     raw0 = terms[0][0]
+    _need_f32("affine_act_bwd_reduceN", dout, *[t[0] for t in terms])
     rows = stats_rows(raw0.N, raw0.C)
     sums = torch.empty((n, raw0.B, rows, raw0.C, 3), dtype=torch.float64, device=raw0.t.device)
     arr = (GnBwdTerm * n)()
@@ -681,6 +756,8 @@ def affine_act_bwd_reduceN(dout: View, terms):
 
 
 def affine_act_bwd_reduce(dout: View, raw: View, a, b, flags=0):
+    _same_dt("affine_act_bwd_reduce", dout, raw)
+    flags |= _aflag(raw)
     rows = stats_rows(raw.N, raw.C)
     sums = torch.empty((raw.B, rows, raw.C, 3), dtype=torch.float64, device=raw.t.device)
     check(_lib.load().n3d_affine_act_bwd_reduce(dout.p, dout.ld, raw.p, raw.ld, ptr(a), ptr(b), raw.B, raw.N, raw.C,
@@ -720,6 +797,8 @@ def plain_bwd_coeffs(sums, rows, wptr, B, Cc, device, dalpha_ptr=None, want_A=Tr
 
 
 def affine_act_bwd_apply(dout: View, raw: View, a, b, A, Bc, Cc_, draw: View, flags=0):
+    _same_dt("affine_act_bwd_apply", dout, raw, draw)
+    flags |= _aflag(raw)
     check(_lib.load().n3d_affine_act_bwd_apply(dout.p, dout.ld, raw.p, raw.ld, ptr(a), ptr(b), ptr(A), ptr(Bc), ptr(Cc_),
                                                draw.p, draw.ld, raw.B, raw.N, raw.C, flags, stream_ptr()),
           "n3d_affine_act_bwd_apply")
@@ -795,6 +874,7 @@ def se_gate_bwdN(terms, N, B, Cc):
 
 
 def pool2_fwd(x: View, y: View, is_max):
+    _need_f32("pool2_fwd", x, y)
     check(_lib.load().n3d_pool2_fwd(x.p, x.ld, y.p, y.ld, x.B, x.D, x.H, x.W, x.C, POOL_MAX if is_max else 0,
                                     stream_ptr()), "n3d_pool2_fwd")
 
@@ -802,17 +882,20 @@ def pool2_fwd(x: View, y: View, is_max):
 def pool2_bwd(dy: View, x: View, dx: View, is_max, accumulate=False, wptr=None):
     """dx (+)= w * pool^T(dy); wptr: device scalar (the MixedOp weight of the pooling primitive) or None = 1"""
     fl = (POOL_MAX if is_max else 0) | (ACCUMULATE if accumulate else 0)
+    _need_f32("pool2_bwd", dy, x, dx)
     check(_lib.load().n3d_pool2_bwd_scaled(dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.B, x.D, x.H, x.W, x.C, fl, wptr, stream_ptr()),
           "n3d_pool2_bwd_scaled")
 
 
 def pool2_fwd_both(x: View, y_avg: View, y_max: View):
+    _need_f32("pool2_fwd_both", x, y_avg, y_max)
     check(_lib.load().n3d_pool2_fwd_both(x.p, x.ld, y_avg.p, y_avg.ld, y_max.p, y_max.ld, x.B, x.D, x.H, x.W, x.C, stream_ptr()),
           "n3d_pool2_fwd_both")
 
 
 def pool2_bwd_both(dy: View, x: View, dx: View, accumulate, w_avg=None, w_max=None):
     """dx (+)= w_avg * avgpool^T(dy) + w_max * maxpool^T(dy); w_*: device scalar pointers or None = 1"""
+    _need_f32("pool2_bwd_both", dy, x, dx)
     check(_lib.load().n3d_pool2_bwd_both(dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.B, x.D, x.H, x.W, x.C, ACCUMULATE if accumulate else 0,
                                          w_avg, w_max, stream_ptr()), "n3d_pool2_bwd_both")
 

@@ -80,7 +80,7 @@ class PoolW(WeightProgram):
             raise N3DError("pooling with act-before-weight / dropout is not supported")
         if x.D % 2 or x.H % 2 or x.W % 2:
             raise N3DError("pool2: spatial dims must be even, got %s" % ((x.D, x.H, x.W),))
-        y = K.as_view(K.empty_ndhwc(x.B, x.C, x.D // 2, x.H // 2, x.W // 2, x.t.device))
+        y = K.as_view(K.empty_ndhwc(x.B, x.C, x.D // 2, x.H // 2, x.W // 2, x.t.device, x.t.dtype))
         K.pool2_fwd(x, y, self.is_max)
         s = Saved()
         s.x = x
@@ -92,7 +92,7 @@ class PoolW(WeightProgram):
             return None, []
         x = saved.x
         if dx_out is None:
-            dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+            dx_out = K.like(x)
             dx_acc = False
         K.pool2_bwd(draw, x, dx_out, self.is_max, dx_acc, scale)
         return dx_out.t, []
@@ -100,7 +100,7 @@ class PoolW(WeightProgram):
 
 def _materialise_pre(x, relu_in, gate):
     """u = relu?(x) * gate  as a real tensor (rare orders only)."""
-    u = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+    u = K.like(x)
     K.affine_act(x, gate, None, None, u, RELU if (relu_in and gate is None) else 0)
     if relu_in and gate is not None:
         # relu(x)*gate with a possibly negative gate: do it in two passes
@@ -112,7 +112,7 @@ def _materialise_pre(x, relu_in, gate):
 def _pre_backward(x, relu_in, gate, du, dx_out, dx_acc):
     """dx (+)= du * gate * [x > 0]"""
     if dx_out is None:
-        dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+        dx_out = K.like(x)
         dx_acc = False
     fl = (RELU if relu_in else 0) | (ACCUMULATE if dx_acc else 0)
     K.affine_act_bwd_apply(du, x, None, None, gate, None, None, dx_out, fl)
@@ -173,7 +173,7 @@ class DenseConvW(WeightProgram):
         y = K.as_view(K.empty_ndhwc(*shp, x.t.device))
         stats, rows = None, 0
         if want_stats:
-            rows = K.conv_stats_rows(g, self.transposed)
+            rows = K.conv_stats_rows(g, self.transposed, 0, x, y)
             if rows > 0:  # 0: this shape's kernel cannot emit statistics -> seg_forward runs n3d_channel_stats
                 stats = torch.empty((x.B, rows, shp[1], 2), dtype=torch.float64, device=x.t.device)
         s.x, s.g, s.relu_in, s.gate = x, g, relu_in, gate
@@ -206,7 +206,7 @@ class DenseConvW(WeightProgram):
         if self.transposed and (db is not None or saved.relu_in or saved.gate is not None):
             return None
         if dx_out is None:
-            dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+            dx_out = K.like(x)
             dx_acc = False
         call = (g, x, draw, self.m.weight, dx_out, dw, db, ACCUMULATE if dx_acc else 0, x if saved.relu_in else None, saved.gate,
                 RELU_IN if saved.relu_in else 0, saved.gate, self.transposed)
@@ -221,7 +221,7 @@ class DenseConvW(WeightProgram):
         if self.transposed and (saved.relu_in or saved.gate is not None):
             return None
         if dx_out is None:
-            dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+            dx_out = K.like(x)
             dx_acc = False
         call = (g, draw, self.m.weight, dx_out, ACCUMULATE if dx_acc else 0, x if saved.relu_in else None, saved.gate, self.transposed)
         return call, dx_out, [None, None]
@@ -238,10 +238,10 @@ class DenseConvW(WeightProgram):
                 dw.copy_(dwp[:, :cin])
         dx = None
         if need_dx:
-            dxp = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+            dxp = K.like(x)
             K.conv_bwd_data(g, draw, wp, dxp, 0, x if saved.relu_in else None, saved.gate, False)
             if dx_out is None:
-                dx_out = K.as_view(K.empty_ndhwc(x.B, cin, x.D, x.H, x.W, x.t.device))
+                dx_out = K.as_view(K.empty_ndhwc(x.B, cin, x.D, x.H, x.W, x.t.device, x.t.dtype))
                 dx_acc = False
             if dx_acc:
                 dx_out.t.add_(dxp.t[:, :cin])
@@ -260,7 +260,7 @@ class DenseConvW(WeightProgram):
         if (need_dx and saved.pre is None and self.transposed and dw is not None and db is None
                 and g.Ci % 16 == 0 and g.Co % 16 == 0):
             if dx_out is None:
-                dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+                dx_out = K.like(x)
                 dx_acc = False
             K.conv_bwd_both(g, x, draw, w, dx_out, dw, None, ACCUMULATE if dx_acc else 0, None, None, 0, None, True)
             return dx_out.t, [dw, db]
@@ -268,7 +268,7 @@ class DenseConvW(WeightProgram):
                 and g.Ci % 16 == 0 and g.Co % 16 == 0):
             # deep levels: data gradient and weight gradient in one launch where libn3d can fold them
             if dx_out is None:
-                dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+                dx_out = K.like(x)
                 dx_acc = False
             K.conv_bwd_both(g, x, draw, w, dx_out, dw, db, ACCUMULATE if dx_acc else 0, x if saved.relu_in else None, saved.gate,
                             RELU_IN if saved.relu_in else 0, saved.gate)
@@ -278,13 +278,13 @@ class DenseConvW(WeightProgram):
         dx = None
         if need_dx:
             if saved.pre is not None:
-                du = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+                du = K.like(x)
                 K.conv_bwd_data(g, draw, w, du, 0, None, None, self.transposed)
                 x0, r0, g0 = saved.pre
                 dx = _pre_backward(x0, r0, g0, du, dx_out, dx_acc).t
             else:
                 if dx_out is None:
-                    dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+                    dx_out = K.like(x)
                     dx_acc = False
                 K.conv_bwd_data(g, draw, w, dx_out, ACCUMULATE if dx_acc else 0, x if saved.relu_in else None, saved.gate,
                                 self.transposed)
@@ -347,7 +347,7 @@ class DepthSepW(WeightProgram):
         y = K.as_view(K.empty_ndhwc(mid.B, co, mid.D, mid.H, mid.W, mid.t.device))
         stats, rows = None, 0
         if want_stats:
-            rows = K.conv_stats_rows(gp, False)
+            rows = K.conv_stats_rows(gp, False, 0, mid, y)
             if rows > 0:
                 stats = torch.empty((mid.B, rows, co, 2), dtype=torch.float64, device=mid.t.device)
         return (gp, mid, self.pm.weight, self.pm.bias, y, 0, None, stats, False), (y, stats, rows)
@@ -367,7 +367,7 @@ class DepthSepW(WeightProgram):
         pw, pb = self.pm.weight, self.pm.bias
         g_pw = K.grad_target(pw)
         g_pb = None if skip_bias else K.grad_target(pb)
-        dmid = K.as_view(K.empty_ndhwc(mid.B, mid.C, mid.D, mid.H, mid.W, mid.t.device))
+        dmid = K.like(mid)
         if g_pw is not None:
             return "both", (gp, mid, draw, pw, dmid, g_pw, g_pb, 0, None, None, 0, None, False), dmid, [g_pw, g_pb]
         if g_pb is None:
@@ -386,7 +386,7 @@ class DepthSepW(WeightProgram):
         g_pb = None if skip_bias else K.grad_target(pb)
         if g_pw is not None or g_pb is not None:
             K.conv_bwd_weight(gp, mid, draw, g_pw, g_pb, 0, None, False)
-        dmid = K.as_view(K.empty_ndhwc(mid.B, mid.C, mid.D, mid.H, mid.W, mid.t.device))
+        dmid = K.like(mid)
         K.conv_bwd_data(gp, draw, pw, dmid, 0, None, None, False)
         return dmid, [g_pw, g_pb]
 
@@ -397,7 +397,7 @@ class DepthSepW(WeightProgram):
             return None
         x = saved.x
         if dx_out is None:
-            dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+            dx_out = K.like(x)
             dx_acc = False
         return (saved.gd, not self.transposed, dmid, self.dm.weight, None, dx_out, ACCUMULATE if dx_acc else 0), dx_out
 
@@ -412,13 +412,13 @@ class DepthSepW(WeightProgram):
         dx = None
         if need_dx and data:
             if saved.pre is not None:
-                du = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+                du = K.like(x)
                 K.conv_bwd_data(gd, dmid, dwt, du, 0, None, None, self.transposed)
                 x0, r0, g0 = saved.pre
                 dx = _pre_backward(x0, r0, g0, du, dx_out, dx_acc).t
             else:
                 if dx_out is None:
-                    dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+                    dx_out = K.like(x)
                     dx_acc = False
                 K.conv_bwd_data(gd, dmid, dwt, dx_out, ACCUMULATE if dx_acc else 0, None, None, self.transposed)
                 dx = dx_out.t
@@ -467,7 +467,7 @@ class SEConvW(WeightProgram):
         """everything of fwd() but the gate and the conv launch: gate3 = (mean, hidden, gate) of SEGate.fwd(x) (or of a batched
         K.se_gate_fwdN).  Returns (call tuple for K.conv_fwd / conv_fwdN, [y, stats, rows, saved])"""
         mean, hidden, g = gate3
-        u = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+        u = K.like(x)
         K.affine_act(x, g, None, None, u, 0)
         call, (y, stats, rows, cs) = self.conv.fwd_prepare(u, False, None, want_stats)
         s = Saved()
@@ -496,7 +496,7 @@ class SEConvW(WeightProgram):
         dx = None
         if need_dx:
             if dx_out is None:
-                dx_out = K.as_view(K.empty_ndhwc(x.B, x.C, x.D, x.H, x.W, x.t.device))
+                dx_out = K.like(x)
                 dx_acc = False
             K.affine_act_bwd_apply(du, x, None, None, A, Bc, None, dx_out, ACCUMULATE if dx_acc else 0)
             dx = dx_out.t
@@ -560,7 +560,7 @@ def _seg_epilogue_forward(seg, raw, stats, rows, ws, out, accumulate, alpha_row,
         if rows <= K.fused_max_rows():
             # small tensor: coefficients are computed in the epilogue kernel's prologue (one launch less)
             if out is None:
-                out = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
+                out = K.like(raw)
                 accumulate = False
             fl = (RELU if seg.relu_out else 0) | (ACCUMULATE if accumulate else 0)
             s.a, s.b, s.mr, s.sumraw = K.affine_act_gn(raw, stats, rows, seg.norm.weight, seg.norm.bias, G, seg.norm.eps, wp, out, fl)
@@ -573,7 +573,7 @@ def _seg_epilogue_forward(seg, raw, stats, rows, ws, out, accumulate, alpha_row,
     if not need_pass:
         return raw, s
     if out is None:
-        out = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
+        out = K.like(raw)
         accumulate = False
     fl = (RELU if seg.relu_out else 0) | (ACCUMULATE if accumulate else 0)
     K.affine_act(raw, s.a, s.b, wp, out, fl)
@@ -673,7 +673,7 @@ def _gn_bwd_term(seg, s, alpha):
     return dict(raw=raw, a=s.a, b=s.b, mr=s.mr, sumraw=s.sumraw, gamma=seg.norm.weight, beta=seg.norm.bias,
                 wptr=_wptr(alpha[0], alpha[1]), dalpha_ptr=(C.c_void_p(alpha[2].data_ptr() + 4 * alpha[1]) if alpha[2] is not None else None),
                 relu=seg.relu_out, conv_bias=cbias,
-                draw=K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device)))
+                draw=K.like(raw))
 
 
 def _weight_backward(order):
@@ -949,11 +949,11 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
         if ident:
             # the raw tensor is the input itself: the apply pass writes dx directly
             if dx_out is None:
-                dx_out = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
+                dx_out = K.like(raw)
                 dx_acc = False
             target, tfl = dx_out, fl | (ACCUMULATE if dx_acc else 0)
         else:
-            target, tfl = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device)), fl
+            target, tfl = K.like(raw), fl
         if rows <= K.fused_max_rows() and raw.B <= 4:
             dgamma, dbeta, dcb = K.affine_act_bwd_apply_gn(dout, raw, s.a, s.b, sums, rows, seg.norm.weight, seg.norm.bias, s.mr, wp,
                                                            s.sumraw, cbias, target, s.G, tfl, dap)
@@ -984,7 +984,7 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
         dx = None
         if need_dx:
             if dx_out is None:
-                dx_out = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
+                dx_out = K.like(raw)
                 dx_acc = False
             K.affine_act_bwd_apply(dout, raw, None, None, A, Bc, None, dx_out, ACCUMULATE if dx_acc else 0)
             dx = dx_out.t
@@ -1002,7 +1002,7 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
             if dap is not None:
                 sums, rows = pre_sums if pre_sums is not None else K.affine_act_bwd_reduce(dout, raw, None, None, fl)
             A = K.plain_bwd_coeffs(sums, rows, wp, raw.B, raw.C, raw.t.device, dap, want_A=True)
-            draw = K.as_view(K.empty_ndhwc(raw.B, raw.C, raw.D, raw.H, raw.W, raw.t.device))
+            draw = K.like(raw)
             K.affine_act_bwd_apply(dout, raw, None, None, A, None, None, draw, fl)
         else:
             draw = dout

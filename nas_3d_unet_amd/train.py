@@ -212,8 +212,11 @@ class Trainer:
     n_buckets >= 2 (data parallel only): bucketed gradient exchange overlapped with backward, see the module docstring."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph=True, process_group=None,
-                 n_buckets=None, params=None, comm=None):
+                 n_buckets=None, params=None, comm=None, storage=None):
         self.model = model
+        if storage is not None:
+            from . import unet as _unet
+            _unet.set_storage(model, storage)   # "bf16": bf16 activation storage on the HBM-bound levels (BASELINE configs[4])
         self.loss_fn = WeightedDiceLoss()
         self.lr, self.betas, self.eps = lr, betas, eps
         self.device = next(model.parameters()).device

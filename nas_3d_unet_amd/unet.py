@@ -44,6 +44,17 @@ def build_stems_and_head(net, in_channels, init_n_kernels, out_channels, n_nodes
     return nn.Sequential(ConvOps(head_in, out_channels, kernel_size=1, dropout_rate=head_dropout, ops_order="weight"), nn.Sigmoid())
 
 
+def set_storage(net, storage):
+    """"fp32" (the reference's arithmetic, default) or "bf16": bf16 STORAGE of the activations and activation gradients of
+    the stems and of the cells with node width <= fused.BF16_MAX_NODE_WIDTH (the HBM-bound levels; BASELINE configs[4]: 4x128^3
+    patches), fp32 arithmetic everywhere, fp32 weights / statistics / deep levels.  Searched nets only (the supernet's N-term
+    kernels are fp32)."""
+    if storage not in ("fp32", "bf16"):
+        raise ValueError("storage must be 'fp32' or 'bf16'")
+    net._n3d_storage = storage
+    net._net_plan = None
+
+
 def body(net, x, alphas=None):
     """Everything ahead of the head.  alphas: None (searched net) or (alpha1_down, alpha1_up, alpha2_down, alpha2_up), already
     softmaxed.  Stems and cells run as one autograd node (fused.NetFn) unless fused.WHOLE_NET is off."""

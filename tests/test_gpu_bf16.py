@@ -1,0 +1,208 @@
+"""GPU: the bf16-storage configuration (BASELINE configs[4]: 4x128^3 patches; reference config.yml:58 patch_shape 128,
+train.py:117-128).  Storage of the HBM-bound levels' activations / activation gradients is bfloat16, arithmetic is fp32.
+
+Stated tolerances (bf16 has 8 significand bits: one rounding = 2^-9 relative; a value passes through ~25 stored tensors between
+input and logits, a gradient through ~50):
+  * kernel level: a bf16-storage kernel equals the fp32 kernel run on the SAME bf16-rounded inputs up to the rounding of its
+    own output: |err| <= 2^-8 * max|ref| (outputs stored in bf16), 1e-5 relative where the output is fp32;
+  * whole net vs the fp32 reference (golden vectors / CPU oracle): loss 2e-3 abs, logits 3e-2 * range, probabilities 3e-2
+    abs, parameter-gradient vector 6e-2 relative in L2, every tensor within 1.5e-2 * ||g_total||;
+  * run to run: bit-identical."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_common as gc
+from _util import assert_close, dev
+from oracle import ref_path as orc
+from test_gpu_nets import build_net, keep_logits
+
+pytestmark = pytest.mark.gpu
+
+TOL_LOSS, TOL_LOGITS, TOL_PROBS, TOL_GVEC, TOL_GTENSOR = 2e-3, 3e-2, 3e-2, 6e-2, 1.5e-2
+ULP = 2.0 ** -8
+
+
+def _bf(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).bfloat16()
+
+
+def _view(t16):
+    from nas_3d_unet_amd import kernels as K
+    B, C, D, H, W = t16.shape
+    v = K.empty_ndhwc(B, C, D, H, W, torch.device("cuda"), torch.bfloat16)
+    v.copy_(t16.cuda())
+    return K.as_view(v)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,dil,transposed,shape", [
+    (4, 12, 1, 1, 1, False, (32, 32, 32)),     # stem0 (streaming 1x1x1 kernel)
+    (12, 4, 1, 1, 1, False, (32, 32, 32)),     # preprocess of the top cell
+    (12, 8, 1, 2, 1, False, (16, 16, 16)),     # stride-2 preprocess (gather)
+    (4, 12, 3, 2, 1, False, (16, 16, 16)),     # stem1
+    (4, 4, 3, 1, 1, False, (8, 16, 16)),       # conv
+    (8, 8, 3, 1, 2, False, (8, 16, 16)),       # dil_conv
+    (8, 8, 3, 2, 1, False, (8, 16, 16)),       # down_conv
+    (4, 4, 3, 2, 1, True, (4, 8, 8)),          # up_conv
+    (8, 8, 3, 2, 2, True, (4, 8, 8)),          # up_dil_conv
+    (24, 16, 1, 1, 1, False, (8, 8, 8)),       # boundary conv: bf16 in, fp32 out (checked in both mixes below)
+])
+@pytest.mark.parametrize("mix", ["bf16->bf16", "bf16->f32", "f32->bf16"])
+def test_conv_family_bf16_storage(cin, cout, k, stride, dil, transposed, shape, mix):
+    """forward, data gradient and weight gradient of every conv shape of the bf16 cells through the C ABI (N3D_SRC_BF16 /
+    N3D_DST_BF16) against torch fp32 on the bf16-rounded operands"""
+    from nas_3d_unet_amd import kernels as K
+    from nas_3d_unet_amd.prim_ops import _padding
+    rng = np.random.default_rng(cin * 1000 + cout * 10 + k + stride)
+    B = 2
+    pad = _padding(k, stride, dil)
+    opad = 0 if stride == 1 else 1
+    x16 = _bf(rng.standard_normal((B, cin) + shape).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((cin, cout, k, k, k) if transposed else (cout, cin, k, k, k)) * 0.2).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1)
+    xin = x16.float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    if transposed:
+        yr = F.conv_transpose3d(xin, wr, b, stride=stride, padding=pad, output_padding=opad, dilation=dil)
+    else:
+        yr = F.conv3d(xin, wr, b, stride=stride, padding=pad, dilation=dil)
+    dy16 = _bf(rng.standard_normal(tuple(yr.shape)).astype(np.float32))
+    yr.backward(dy16.float())
+    in16, out16 = mix.startswith("bf16"), mix.endswith("bf16")
+    dev_ = torch.device("cuda")
+    xv = _view(x16) if in16 else K.as_view(dev(x16.float().numpy()))
+    if transposed:
+        g = K.conv_geom(B, yr.shape[2], yr.shape[3], yr.shape[4], cout, cin, k, stride, dil, pad)
+    else:
+        g = K.conv_geom(B, *shape, cin, cout, k, stride, dil, pad)
+    with K.storage(torch.bfloat16 if out16 else torch.float32):
+        y = K.as_view(K.empty_ndhwc(*yr.shape, dev_))
+    wd, bd = w.cuda(), b.cuda()
+    K.conv_fwd(g, xv, wd, bd, y, 0, None, None, transposed)
+    assert_close(y.t.float(), yr.detach(), ULP if out16 else 1e-5, "y")
+    # data gradient: dy has the output's storage type, dx the input's
+    dyv = _view(dy16) if out16 else K.as_view(dev(dy16.float().numpy()))
+    dx = K.like(xv)
+    K.conv_bwd_data(g, dyv, wd, dx, 0, None, None, transposed)
+    assert_close(dx.t.float(), xin.grad, ULP if in16 else 1e-5, "dx")
+    dw, db = torch.empty_like(wd), torch.empty_like(bd)
+    K.conv_bwd_weight(g, xv, dyv, dw, None if transposed else db, 0, None, transposed)
+    assert_close(dw, wr.grad, 2e-5, "dw")
+
+
+@pytest.mark.parametrize("C,shape,B", [(4, (16, 16, 16), 2), (8, (32, 16, 16), 2), (12, (8, 8, 16), 3), (8, (4, 4, 4), 2), (4, (48, 32, 32), 1)])
+def test_node_epilogues_bf16_storage(C, shape, B):
+    """GroupNorm -> ReLU -> node sum of two conv outputs (searched.py:45-50) and its backward with every tensor in bf16:
+    against the same kernels in fp32 storage on the bf16-rounded operands (forward: the stored node rounds once more)"""
+    from nas_3d_unet_amd import kernels as K
+    from nas_3d_unet_amd.programs import group_count
+    rng = np.random.default_rng(C * 10 + B)
+    G = group_count(C)
+    raws16 = [_bf(rng.standard_normal((B, C) + shape).astype(np.float32) * 1.5 + 0.3) for _ in range(2)]
+    dout16 = _bf(rng.standard_normal((B, C) + shape).astype(np.float32))
+    gam = [torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)).cuda().requires_grad_(True) for _ in range(2)]
+    bet = [torch.from_numpy(rng.standard_normal(C).astype(np.float32)).cuda().requires_grad_(True) for _ in range(2)]
+    res = {}
+    for tag in ("f32", "bf16"):
+        if tag == "bf16":
+            raws = [_view(r) for r in raws16]
+            dout = _view(dout16)
+        else:
+            raws = [K.as_view(dev(r.float().numpy())) for r in raws16]
+            dout = K.as_view(dev(dout16.float().numpy()))
+        sts = [K.channel_stats(r) for r in raws]
+        out = K.like(raws[0])
+        terms = [(raws[i], sts[i][0], sts[i][1], gam[i], bet[i], None, True) for i in range(2)]
+        sv = K.affine_act_gn2(terms, G, 1e-5, out, 0)
+        tds = [dict(raw=raws[i], a=sv[i][0], b=sv[i][1], mr=sv[i][2], sumraw=sv[i][3], gamma=gam[i], beta=bet[i], wptr=None, relu=True,
+                    conv_bias=None, draw=K.like(raws[i]), dalpha_ptr=None) for i in range(2)]
+        gouts = K.affine_act_bwd_gn2(dout, tds, G)
+        res[tag] = (out.t.float().clone(), [t["draw"].t.float().clone() for t in tds], [(a.clone(), b.clone()) for a, b, _ in gouts])
+    assert_close(res["bf16"][0], res["f32"][0].cpu().numpy(), ULP, "node")
+    for i in range(2):
+        assert_close(res["bf16"][1][i], res["f32"][1][i].cpu().numpy(), ULP, "draw%d" % i)
+        assert_close(res["bf16"][2][i][0], res["f32"][2][i][0].cpu().numpy(), 1e-5, "dgamma%d" % i)
+        assert_close(res["bf16"][2][i][1], res["f32"][2][i][1].cpu().numpy(), 1e-5, "dbeta%d" % i)
+
+
+def _run_bf16(net, x, t):
+    with keep_logits() as k:
+        l, p = net.forward_loss(x, t)
+        logits = k.logits
+    l.backward()
+    return float(l), logits, p.detach()
+
+
+def _check_against_fp32(l, logits, p, grads, lr, zr, pr, gr):
+    assert abs(l - lr) <= TOL_LOSS, (l, lr)
+    assert float((logits.cpu() - zr).abs().max()) <= TOL_LOGITS * float(zr.abs().max())
+    assert float((p.cpu() - pr).abs().max()) <= TOL_PROBS
+    tot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in gr.values())))
+    err2 = 0.0
+    for n, g in grads.items():
+        d = float((g.cpu().double() - gr[n].double()).norm())
+        assert d <= TOL_GTENSOR * tot, (n, d / tot)
+        err2 += d * d
+    assert err2 ** 0.5 <= TOL_GVEC * tot, err2 ** 0.5 / tot
+
+
+def test_searched_net_bf16_vs_golden_d4s64(golden):
+    """net/searched/G_CONV/d4s64 (the golden 64^3 patch of the reference) through the bf16-storage path: loss, logits, probabilities"""
+    from nas_3d_unet_amd import unet
+    g = golden("nets")
+    key, kind, gname, depth, size, batch, adam = [c for c in gc.net_cases() if c[0] == "net/searched/G_CONV/d4s64"][0]
+    net, _ = build_net(kind, gname, depth)
+    unet.set_storage(net, "bf16")
+    xn, tn = gc.net_batch(key, batch, size)
+    l, logits, p = _run_bf16(net, dev(xn), dev(tn))
+    c = size // 2
+    s = slice(c - 3, c + 3)
+    assert abs(l - float(g[key + "/loss"])) <= TOL_LOSS
+    assert np.abs(logits[:, :, s, s, s].cpu().numpy() - g[key + "/logits_crop"]).max() <= TOL_LOGITS * float(g[key + "/logits_absmax"])
+    assert np.abs(p[:, :, s, s, s].cpu().numpy() - g[key + "/probs_crop"]).max() <= TOL_PROBS
+    total = float(g[key + "/gnorm_total"])
+    for n, q in net.named_parameters():
+        ref = float(g[key + "/gnorm/" + n])
+        assert abs(float(q.grad.double().norm()) - ref) <= TOL_GTENSOR * total + 0.05 * ref, n
+    # the storage policy really is in force: stems and the node-width <= 8 cells hold bf16, the deep cells fp32
+    dts = [pl.dt for pl in net._net_plan.cells]
+    assert net._net_plan.stem_dt == torch.bfloat16 and dts[0] == torch.bfloat16 and dts[-1] == torch.bfloat16 and dts[3] == torch.float32
+
+
+@pytest.mark.parametrize("size,batch", [(64, 2), (128, 1)])
+def test_searched_net_bf16_vs_cpu_oracle(size, batch):
+    """seeded 64^3 (batch 2) and 128^3 (the configuration's patch size) cases against the fp32 CPU oracle: loss, logits,
+    probabilities, every parameter gradient; and a second run of the same step is bit-identical"""
+    from nas_3d_unet_amd import unet
+    rng = np.random.default_rng(size)
+    xn = rng.standard_normal((batch, 4, size, size, size)).astype(np.float32)
+    tn = (rng.uniform(0, 1, (batch, 3, size, size, size)) < 0.3).astype(np.float32)
+    P = orc.make_params(orc.searched_param_specs(orc.DEFAULT_CFG, orc.G_CONV), requires_grad=True)
+    pr, zr = orc.searched_forward(P, torch.from_numpy(xn), orc.G_CONV, return_logits=True)
+    lr = orc.dice_loss(pr, torch.from_numpy(tn))
+    lr.backward()
+    runs = []
+    for _ in range(2):
+        net, _ = build_net("searched", "G_CONV", 4)
+        unet.set_storage(net, "bf16")
+        l, logits, p = _run_bf16(net, dev(xn), dev(tn))
+        runs.append((l, logits, p, {n: q.grad.clone() for n, q in net.named_parameters()}))
+    l, logits, p, grads = runs[0]
+    _check_against_fp32(l, logits, p, grads, float(lr), zr.detach(), pr.detach(), {n: q.grad for n, q in P.items()})
+    assert runs[1][0] == l and torch.equal(runs[1][1], logits) and all(torch.equal(runs[1][3][n], grads[n]) for n in grads)
+
+
+def test_trainer_bf16_storage_graph_replay():
+    """Trainer(storage='bf16') under HIP-graph replay: losses of three Adam steps follow the fp32 trainer's within the bf16 tolerance"""
+    from nas_3d_unet_amd.train import Trainer
+    rng = np.random.default_rng(3)
+    x = dev(rng.standard_normal((2, 4, 32, 32, 32)).astype(np.float32))
+    t = dev((rng.uniform(0, 1, (2, 3, 32, 32, 32)) < 0.3).astype(np.float32))
+    out = {}
+    for st in ("fp32", "bf16"):
+        net, _ = build_net("searched", "G_CONV", 4)
+        tr = Trainer(net, graph=True, storage=st)
+        out[st] = [float(tr.step(x, t)) for _ in range(3)]
+    np.testing.assert_allclose(out["bf16"], out["fp32"], rtol=0, atol=TOL_LOSS)
+    assert out["bf16"][2] < out["bf16"][0]
