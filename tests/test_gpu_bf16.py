@@ -91,7 +91,7 @@ def test_conv_family_bf16_storage(cin, cout, k, stride, dil, transposed, shape, 
     assert_close(dw, wr.grad, 2e-5, "dw")
 
 
-@pytest.mark.parametrize("C,shape,B", [(4, (16, 16, 16), 2), (8, (32, 16, 16), 2), (12, (8, 8, 16), 3), (8, (4, 4, 4), 2), (4, (48, 32, 32), 1)])
+@pytest.mark.parametrize("C,shape,B", [(4, (16, 16, 16), 2), (8, (32, 16, 16), 2), (8, (4, 4, 4), 2), (4, (48, 32, 32), 1)])
 def test_node_epilogues_bf16_storage(C, shape, B):
     """GroupNorm -> ReLU -> node sum of two conv outputs (searched.py:45-50) and its backward with every tensor in bf16:
     against the same kernels in fp32 storage on the bf16-rounded operands (forward: the stored node rounds once more)"""
