@@ -96,7 +96,7 @@ int n3d_stats_rows(int64_t N, int C);
  * n3d_conv_pack_info: layout id / padded channel count / float count of the packed form that the kernel
  * selected for (geometry, forward or data-gradient) expects. */
 typedef struct n3d_pack_job {
-  const float* w; float* dst;
+  const float* w; float* dst;   /* layout 4 (bf16-storage 3x3x3 kernels): dst holds bfloat16 elements */
   int32_t Co, Ci, taps, data_grad, layout, cdp;
 } n3d_pack_job;
 int n3d_conv_pack_info(const n3d_conv_geom* g, int data_grad, int flags, int32_t* layout, int32_t* cdp, int64_t* floats);

@@ -65,7 +65,13 @@ class storage:
 
 def empty_ndhwc(B, Cc, D, H, W, device, dtype=None):
     """Dense NDHWC storage presented with the reference's logical (B, C, D, H, W) shape (dtype None: the current storage type)."""
-    return torch.empty((B, D, H, W, Cc), device=device, dtype=dtype if dtype is not None else _act_dtype).permute(0, 4, 1, 2, 3)
+    dtype = dtype if dtype is not None else _act_dtype
+    if dtype == torch.bfloat16:
+        # 16 bytes of slack behind the tensor: the bf16 3x3x3 kernels fetch 16 bytes per voxel by LDS-DMA, i.e. 8 bytes
+        # past a 4-channel voxel (conv_bf16.hip)
+        n = B * D * H * W * Cc
+        return torch.empty(n + 8, device=device, dtype=dtype)[:n].view(B, D, H, W, Cc).permute(0, 4, 1, 2, 3)
+    return torch.empty((B, D, H, W, Cc), device=device, dtype=dtype).permute(0, 4, 1, 2, 3)
 
 
 def zeros_ndhwc(B, Cc, D, H, W, device, dtype=None):

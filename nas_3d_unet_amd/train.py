@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import os
 import types
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -102,6 +103,14 @@ class PlateauLR:
             self.cooldown_counter = self.cooldown
             self.num_bad_epochs = 0
         return self.get_lr()
+
+
+def _plateau_for(owner, lr_attr, setter):
+    """PlateauLR bound to a trainer through a weak reference: no trainer <-> scheduler cycle, so a dropped trainer (and the
+    HIP graphs / private memory pool it owns) is released at once by reference counting, never by a cyclic collection that could
+    fire in the middle of another trainer's graph capture"""
+    ref = weakref.ref(owner)
+    return PlateauLR(lambda: getattr(ref(), lr_attr), lambda v: getattr(ref(), setter)(v))
 
 
 class GradSync:
@@ -237,7 +246,7 @@ class Trainer:
         self.ctx = K.StepContext(self.device)  # batched weight packing + deferred wgrad reductions
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)  # read by the Adam kernel
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
-        self.scheduler = PlateauLR(lambda: self.lr, self.set_lr)  # train.py:50: ReduceLROnPlateau(factor=0.5)
+        self.scheduler = _plateau_for(self, "lr", "set_lr")  # train.py:50: ReduceLROnPlateau(factor=0.5)
         self._buckets = self._bucket_plan() if (self.dp_path and self.n_buckets > 1) else None
         # one bucket = nothing to overlap: the collective is issued from the step's own stream (a hop through a second
         # stream costs two cross-stream waits around a graph launch); N3D_COMM_STREAM=1 restores the hop
@@ -428,6 +437,8 @@ class Trainer:
     def _capture_segments(self, s):
         """one HIP graph per gradient bucket: the capture is closed and the next one opened inside the backward walk, at the
         point where the bucket is complete (all graphs share one memory pool; they are only ever replayed in this order)"""
+        import gc
+        gc.collect()      # as torch.cuda.graph does: no collection of stale device objects in the middle of a capture
         pool = torch.cuda.graph_pool_handle()
         graphs = [torch.cuda.CUDAGraph()]
         last = len(self._buckets) - 1
@@ -478,8 +489,8 @@ class SearchTrainer:
         self.lr_shell, self.lr_kernel = float(lr), float(lr)
         self.lr_shell_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)
         self.lr_kernel_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)
-        self.shell_scheduler = PlateauLR(lambda: self.lr_shell, self.set_shell_lr)
-        self.kernel_scheduler = PlateauLR(lambda: self.lr_kernel, self.set_kernel_lr)
+        self.shell_scheduler = _plateau_for(self, "lr_shell", "set_shell_lr")
+        self.kernel_scheduler = _plateau_for(self, "lr_kernel", "set_kernel_lr")
         # data parallel: two exchanges per step -- the alpha gradients (180 floats) after the architecture pass,
         # the kernel-weight gradients (27.4 MB) after the weight pass; weights and alphas broadcast once from rank 0
         self.pg = process_group

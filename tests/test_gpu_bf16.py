@@ -47,6 +47,11 @@ def _view(t16):
     (4, 4, 3, 2, 1, True, (4, 8, 8)),          # up_conv
     (8, 8, 3, 2, 2, True, (4, 8, 8)),          # up_dil_conv
     (24, 16, 1, 1, 1, False, (8, 8, 8)),       # boundary conv: bf16 in, fp32 out (checked in both mixes below)
+    (4, 4, 3, 1, 1, False, (64, 64, 64)),      # the bf16 MFMA kernel, 4-plane tiles (conv_vox64b_kernel<4,4,1,1>)
+    (4, 4, 3, 1, 2, False, (64, 64, 64)),      # ... two waves per 8-row tile (dilation 2)
+    (8, 8, 3, 1, 1, False, (64, 64, 32)),      # ... C = 8, 2-plane tiles
+    (8, 8, 3, 1, 2, False, (32, 32, 32)),      # ... C = 8, dilation 2, single-plane tiles
+    (4, 4, 3, 1, 1, False, (8, 12, 16)),       # ... ragged tile counts (H = 12)
 ])
 @pytest.mark.parametrize("mix", ["bf16->bf16", "bf16->f32", "f32->bf16"])
 def test_conv_family_bf16_storage(cin, cout, k, stride, dil, transposed, shape, mix):
@@ -59,7 +64,9 @@ def test_conv_family_bf16_storage(cin, cout, k, stride, dil, transposed, shape, 
     pad = _padding(k, stride, dil)
     opad = 0 if stride == 1 else 1
     x16 = _bf(rng.standard_normal((B, cin) + shape).astype(np.float32))
-    w = torch.from_numpy((rng.standard_normal((cin, cout, k, k, k) if transposed else (cout, cin, k, k, k)) * 0.2).astype(np.float32))
+    # weights representable in bf16: the bf16 MFMA kernels (3x3x3, stride 1, C in {4, 8}, both tensors bf16) round them, the
+    # streaming / gather kernels keep them in fp32 -- with representable weights both compute the same products
+    w = torch.from_numpy((rng.standard_normal((cin, cout, k, k, k) if transposed else (cout, cin, k, k, k)) * 0.2).astype(np.float32)).bfloat16().float()
     b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1)
     xin = x16.float().requires_grad_(True)
     wr = w.clone().requires_grad_(True)
