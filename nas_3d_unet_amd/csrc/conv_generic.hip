@@ -1462,12 +1462,12 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   // dense: the kernel computes G[co'][ci'][tap] = sum dyK[o][co'] * xK[i(o,tap)][ci'] with xK on the i side.
   // forward conv: xK = x (Ci), dyK = dy (Co), dw native (Co,Ci,k^3) = G.
   // transposed conv (weight (CinT=Co_geom, CoutT=Ci_geom)): xK = dy_T (i side, Ci), dyK = x_T (o side, Co): same G layout.
-  if ((!dbias || transposed) && !(flags & N3D_ANY_BF16)) {
+  if ((!dbias || transposed) && (!(flags & N3D_ANY_BF16) || (sb16 && db16))) {
     // vox64 weight gradient (3x3x3 stride 1, C = 4 / 8); it does not produce the bias gradient, which the callers on the
     // hot path obtain analytically from the GroupNorm backward sums (n3d_gn_bwd_coeffs)
     int nch = 0;
-    int hv = vox_wgrad_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, s);
-    if (hv == 0) hv = vox_wgrad_s2_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, s);
+    int hv = vox_wgrad_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, s);   // fp32, or both tensors in bf16 storage
+    if (hv == 0 && !(flags & N3D_ANY_BF16)) hv = vox_wgrad_s2_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, s);
     if (hv < 0) return hv;
     if (hv == 1) {
       const int C = g->Ci, nout = C * C * taps;

@@ -1326,16 +1326,19 @@ static int launch_vox_c(VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
 // fewer instructions per voxel, which is what matters at these sizes (a lone wave issues ~1 instruction / 4 cycles).
 // ------------------------------------------------------------------------------------------------
 struct VwArgs {
-  const float* x; int64_t xld;
-  const float* dy; int64_t dyld;
+  const void* x; int64_t xld;       // T elements (fp32, or bf16 storage: one 16-byte LDS slot per voxel, operands widened on read)
+  const void* dy; int64_t dyld;
   float* partial;       // [workgroup][27][C*C]
   int D, H, W, dchunk;  // dchunk: planes per workgroup (multiple of 4)
   const void* zero_page;
 };
 
-template <int C, int DIL>
+template <int C, int DIL, typename T = float>
 __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
-  constexpr int Q = C / 4, TD = 4, GH = 4, GW = 16;
+  constexpr bool B16 = sizeof(T) == 2;
+  constexpr int QC = C / 4;                 // channel quads = accumulator tiles per side
+  constexpr int Q = B16 ? 1 : QC;           // 16-byte LDS slots per voxel (a bf16 voxel of 4 or 8 channels takes one)
+  constexpr int TD = 4, GH = 4, GW = 16;
   constexpr int LD = TD + 2 * DIL, LH = GH + 2 * DIL, LW = GW + 2 * DIL;
   constexpr int PLANE = LH * LW, NVOX = LD * PLANE;
   // One staged tile = the X halo tile ([Q][NVOX] float4) followed by the dY tile ([TD*GH rows][16 voxels][Q] float4), filled
@@ -1362,25 +1365,26 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
   const int h0 = (bx % th_n) * GH;
   const int dbeg = (bx / th_n) * a.dchunk;
   const int64_t N = (int64_t)a.D * a.H * a.W;
-  const float* xb = a.x + (int64_t)b * N * a.xld;
-  const float* dyb = a.dy + (int64_t)b * N * a.dyld;
+  const T* xb = reinterpret_cast<const T*>(a.x) + (int64_t)b * N * a.xld;
+  const T* dyb = reinterpret_cast<const T*>(a.dy) + (int64_t)b * N * a.dyld;
   const float4* zp = reinterpret_cast<const float4*>(a.zero_page);
   const int blk = lane >> 2, i4 = lane & 3;
   const int tap0 = wave * 7;
+  constexpr int EPS = B16 ? 8 : 4;          // LDS elements per slot
   int toff[7];
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     const int tap = (tap0 + t < 27) ? tap0 + t : 26;
     const int kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
-    toff[t] = ((kd * DIL) * PLANE + (kh * DIL) * LW + kw * DIL + blk) * 4 + i4;
+    toff[t] = ((kd * DIL) * PLANE + (kh * DIL) * LW + kw * DIL + blk) * EPS + i4;
   }
-  f32x4 acc[7][Q][Q];
+  f32x4 acc[7][QC][QC];
 #pragma unroll
   for (int t = 0; t < 7; ++t)
 #pragma unroll
-    for (int qa = 0; qa < Q; ++qa)
+    for (int qa = 0; qa < QC; ++qa)
 #pragma unroll
-      for (int qb = 0; qb < Q; ++qb) acc[t][qa][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int qb = 0; qb < QC; ++qb) acc[t][qa][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -1397,7 +1401,7 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
         const int wx = idx % LW, hy = (idx / LW) % LH, dz = idx / PLANE;
         const int gd = d0 - DIL + dz, gh = h0 - DIL + hy, gw = w0 - DIL + wx;
         const bool inb = slot < Q * NVOX && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-        if (inb) srcp = reinterpret_cast<const float4*>(xb + (((int64_t)gd * a.H + gh) * a.W + gw) * a.xld + q * 4);
+        if (inb) srcp = reinterpret_cast<const float4*>(xb + (((int64_t)gd * a.H + gh) * a.W + gw) * a.xld + q * 4);   // bf16: 16 bytes from the voxel
       } else {
         // dY tile: slot' = (row * 16 + voxel) * Q + q, row = g * GH + hh
         const int sl = slot - NXC * 64;
@@ -1418,24 +1422,36 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
     if (k + 1 < ntile) stage(dbeg + (k + 1) * TD, wtile + ((k + 1) & 1) * BUF);
     const float* tf = reinterpret_cast<const float*>(wtile + (k & 1) * BUF);
     const float* yf = tf + NXC * 64 * 4;
+    const bf16_t* th = reinterpret_cast<const bf16_t*>(wtile + (k & 1) * BUF);
+    const bf16_t* yh = th + NXC * 64 * 8;
     // ---- 16 rows of 16 voxels: row r = (g, hh) -> output plane d0+g, row h0+hh
 #pragma unroll
     for (int r = 0; r < TD * GH; ++r) {
       const int g = r >> 2, hh = r & 3;
-      const int rbase = (g * PLANE + hh * LW) * 4;
-      float avs[7][Q], bvs[Q];
+      const int rbase = (g * PLANE + hh * LW) * EPS;
+      float avs[7][QC], bvs[QC];
+      if constexpr (B16) {
+        // one slot per voxel, channel c at element c of the slot; widened to fp32 (a shift) on the way to the MFMA
 #pragma unroll
-      for (int qb = 0; qb < Q; ++qb) bvs[qb] = yf[((r * GW + blk) * Q + qb) * 4 + i4];
+        for (int qb = 0; qb < QC; ++qb) bvs[qb] = ld1(yh + (r * GW + blk) * 8 + qb * 4 + i4);
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+          for (int qa = 0; qa < QC; ++qa) avs[t][qa] = ld1(th + rbase + toff[t] + qa * 4);
+      } else {
+#pragma unroll
+        for (int qb = 0; qb < QC; ++qb) bvs[qb] = yf[((r * GW + blk) * Q + qb) * 4 + i4];
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+          for (int qa = 0; qa < QC; ++qa) avs[t][qa] = tf[qa * NVOX * 4 + rbase + toff[t]];
+      }
 #pragma unroll
       for (int t = 0; t < 7; ++t)
 #pragma unroll
-        for (int qa = 0; qa < Q; ++qa) avs[t][qa] = tf[qa * NVOX * 4 + rbase + toff[t]];
+        for (int qa = 0; qa < QC; ++qa)
 #pragma unroll
-      for (int t = 0; t < 7; ++t)
-#pragma unroll
-        for (int qa = 0; qa < Q; ++qa)
-#pragma unroll
-          for (int qb = 0; qb < Q; ++qb) acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(avs[t][qa], bvs[qb], acc[t][qa][qb], 0, 0, 0);
+          for (int qb = 0; qb < QC; ++qb) acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(avs[t][qa], bvs[qb], acc[t][qa][qb], 0, 0, 0);
     }
   }
   // ---- add the 16 block tiles (lanes with equal lane&3) and write this workgroup's slab
@@ -1444,9 +1460,9 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
   for (int t = 0; t < 7; ++t) {
     if (tap0 + t < 27) {
 #pragma unroll
-      for (int qa = 0; qa < Q; ++qa)
+      for (int qa = 0; qa < QC; ++qa)
 #pragma unroll
-        for (int qb = 0; qb < Q; ++qb)
+        for (int qb = 0; qb < QC; ++qb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sum = wave_classsum_f(acc[t][qa][qb][r], 4);
@@ -1629,6 +1645,13 @@ int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
 
 struct VwPlan { bool ok; int C, dil, dchunk, tiles; size_t lds; };
 
+// dynamic LDS of vox_wgrad_kernel with `slots` 16-byte LDS slots per voxel (fp32: C / 4; bf16 storage: 1)
+static size_t vw_plan_lds(int slots, int dil) {
+  const size_t Qn = slots, nvox = (size_t)(4 + 2 * dil) * (4 + 2 * dil) * (16 + 2 * dil);
+  const size_t nxc = (Qn * nvox + 63) / 64, nyc = (4 * 4 * 16 * Qn + 63) / 64, nch = (nxc + nyc + 3) / 4 * 4;
+  return 2 * nch * 64 * 16;   // two staged tiles (X halo tile + dY tile each)
+}
+
 static VwPlan vw_plan(const n3d_conv_geom* g) {
   VwPlan p; p.ok = false;
   if (g->depthwise || g->k != 3 || g->stride != 1 || g->Ci != g->Co || (g->Ci != 4 && g->Ci != 8)) return p;
@@ -1640,11 +1663,7 @@ static VwPlan vw_plan(const n3d_conv_geom* g) {
   while (columns * dsplit < 384 && dsplit * 2 <= nd && nd % (dsplit * 2) == 0) dsplit *= 2;
   p.ok = true; p.C = g->Ci; p.dil = g->dil; p.dchunk = D / dsplit;
   p.tiles = (W / 16) * (H / 4) * dsplit;
-  {
-    const size_t Qn = g->Ci / 4, nvox = (size_t)(4 + 2 * g->dil) * (4 + 2 * g->dil) * (16 + 2 * g->dil);
-    const size_t nxc = (Qn * nvox + 63) / 64, nyc = (4 * 4 * 16 * Qn + 63) / 64, nch = (nxc + nyc + 3) / 4 * 4;
-    p.lds = 2 * nch * 64 * 16;   // two staged tiles (X halo tile + dY tile each)
-  }
+  p.lds = vw_plan_lds(g->Ci / 4, g->dil);
   return p;
 }
 
@@ -1652,8 +1671,11 @@ static VwPlan vw_plan(const n3d_conv_geom* g) {
 int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                   float* partial, size_t avail_floats, int* nchunks_out, hipStream_t s) {
   if ((flags & (N3D_RELU_IN | N3D_NO_MFMA)) || in_gate) return 0;
+  const bool b16 = (flags & N3D_SRC_BF16) && (flags & N3D_DST_BF16);
+  if (!b16 && (flags & (N3D_SRC_BF16 | N3D_DST_BF16))) return 0;   // mixed storage: the generic kernel
   VwPlan p = vw_plan(g);
-  if (!p.ok || xld % 4 != 0 || !aligned16(x)) return 0;
+  if (!p.ok || xld % 4 != 0 || dyld % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & (b16 ? 7 : 15)) != 0) return 0;
+  if (b16 && ((reinterpret_cast<uintptr_t>(dy) & 7) != 0 || (p.C == 8 && (xld % 8 != 0 || dyld % 8 != 0 || !aligned16(x) || !aligned16(dy))))) return 0;
   const int nwg = p.tiles * g->B;
   if ((size_t)nwg * 27 * p.C * p.C > avail_floats) return 0;
   VwArgs a;
@@ -1661,7 +1683,17 @@ int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const flo
   a.zero_page = zero_page_ptr();
   if (!a.zero_page) return 0;
   dim3 grid(p.tiles, g->B);
-  if (p.C == 4) {
+  if (b16) {
+    // bf16 storage: the LDS image is the fp32 C = 4 one (one slot per voxel) for both channel counts
+    const size_t lds16 = vw_plan_lds(1, p.dil);
+    if (p.C == 4) {
+      if (p.dil == 1) hipLaunchKernelGGL((vox_wgrad_kernel<4, 1, bf16_t>), grid, dim3(256), lds16, s, a);
+      else hipLaunchKernelGGL((vox_wgrad_kernel<4, 2, bf16_t>), grid, dim3(256), lds16, s, a);
+    } else {
+      if (p.dil == 1) hipLaunchKernelGGL((vox_wgrad_kernel<8, 1, bf16_t>), grid, dim3(256), lds16, s, a);
+      else hipLaunchKernelGGL((vox_wgrad_kernel<8, 2, bf16_t>), grid, dim3(256), lds16, s, a);
+    }
+  } else if (p.C == 4) {
     if (p.dil == 1) hipLaunchKernelGGL((vox_wgrad_kernel<4, 1>), grid, dim3(256), p.lds, s, a);
     else hipLaunchKernelGGL((vox_wgrad_kernel<4, 2>), grid, dim3(256), p.lds, s, a);
   } else {
