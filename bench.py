@@ -185,13 +185,19 @@ def search_step_bench(args, device):
         la, lw = tr.step(x, t, vx, vt)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    extra = {}
+    if not args.no_kernel_table:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import kernel_table
+        rows, ncalls = kernel_table.table(lambda: tr._both(x, t, vx, vt), device)
+        extra = {"roofline_by_time": rows, "launches_per_step": ncalls}
     print(json.dumps({
         "metric": "supernet search steps/sec (arch pass + weight pass, each fwd + Dice + bwd + Adam)", "value": round(args.steps / dt, 3),
         "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "patches_per_s": round(2 * args.batch * args.steps / dt, 2),
         "config": {"workload": "nas.py ShellNet search step, train batch=%d + val batch=%d 4x%d^3 fp32" % (args.batch, args.batch, args.size),
-                   "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "loss_arch": round(float(la), 5), "loss_weight": round(float(lw), 5)}}), flush=True)
+                   "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "loss_arch": round(float(la), 5), "loss_weight": round(float(lw), 5)}, **extra}), flush=True)
 
 
 def main():
@@ -207,6 +213,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-kernel-table", action="store_true", help="skip roofline_by_time (the per-entry-point time table of one step)")
     ap.add_argument("--buckets", type=int, default=None, help="gradient buckets of the data-parallel exchange (default: N3D_DP_BUCKETS or 1); "
                     ">= 2: all-reduce of a bucket on a side stream under the backward of the next one")
     ap.add_argument("--comm", choices=["torch", "rccl"], default=None, help="all-reduce through torch.distributed (default) or the C ABI's n3d_comm_*")
@@ -276,6 +283,13 @@ def main():
         }
         if not args.no_roofline:
             out["roofline"] = conv_kernel_roofline(device, args.batch, args.size)
+        if world == 1 and not args.no_kernel_table:
+            # what actually dominates the step: top entry points by measured microseconds per step, each against its roofline
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import kernel_table
+            rows, ncalls = kernel_table.table(lambda: trainer._eager(x, t), device)
+            out["roofline_by_time"] = rows
+            out["launches_per_step"] = ncalls
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.size)
         print(json.dumps(out), flush=True)
