@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/n3d.h"
 
@@ -82,7 +83,8 @@ static inline EwMap ew_map(int64_t N, int C) {
   if (m.vpb < 1) m.vpb = 1;
   int64_t nit = cdiv(N, m.vpb);          // block-iterations per sample
   int64_t it = cdiv(nit, 1024);          // cap rows per sample at 1024
-  if (it < 4) it = nit < 4 ? (nit < 1 ? 1 : nit) : 4;
+  static const int min_it = getenv("N3D_EW_IT") ? atoi(getenv("N3D_EW_IT")) : 4;   // (tuning knob)
+  if (it < min_it) it = nit < min_it ? (nit < 1 ? 1 : nit) : min_it;
   m.iters = (int)it;
   m.vpc = (int64_t)m.vpb * m.iters;
   m.rows = (int)cdiv(N, m.vpc);
