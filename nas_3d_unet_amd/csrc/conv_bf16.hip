@@ -33,12 +33,13 @@ static const void* zero_page16_ptr() {
   return p;
 }
 
-// Wq[tap][cd][cs] in bf16; forward: cd = co, cs = ci; data gradient: cd = ci, cs = co, taps flipped (26 - tap)
+// Wq[tap][cd][cs] in bf16; forward: cd = co, cs = ci; data_grad 1 (stride-1 data gradient): cd = ci, cs = co, taps flipped
+// (26 - tap); data_grad 2 (gather form of the stride-2 data gradient / transposed forward): channels transposed, taps as they are
 __global__ void pack_vox16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wq, int C, int data_grad) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 27 * C * C) return;
   const int cs = i % C, cd = (i / C) % C, tap = i / (C * C);
-  const int co = data_grad ? cs : cd, ci = data_grad ? cd : cs, t2 = data_grad ? 26 - tap : tap;
+  const int co = data_grad ? cs : cd, ci = data_grad ? cd : cs, t2 = data_grad == 1 ? 26 - tap : tap;
   st1(wq + i, w[((int64_t)co * C + ci) * 27 + t2]);
 }
 
@@ -254,6 +255,363 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
   }
 }
 
+
+// ---- operand helpers shared by the stride-2 / transposed forms ----------------------------------------------------
+// weights of one tap for this lane's output-channel row(s): [hf = output quad][kh = K half] 8-byte A operands
+template <int C>
+struct W16 { uint2 k[C / 4][C / 4]; };
+template <int C>
+__device__ __forceinline__ W16<C> ldw16(const uint4* wl, int tap, int j) {
+  W16<C> w;
+  if constexpr (C == 4) {
+    w.k[0][0] = reinterpret_cast<const uint2*>(wl)[tap * 4 + j];
+  } else {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const uint4 q = wl[tap * 8 + hf * 4 + j];
+      w.k[hf][0] = make_uint2(q.x, q.y); w.k[hf][1] = make_uint2(q.z, q.w);
+    }
+  }
+  return w;
+}
+// one voxel's channels from its LDS slot: 8 bytes (C = 4, low half of the slot) or 16 bytes
+template <int C>
+__device__ __forceinline__ uint4 rd_slot(const uint4* tile, int idx) {
+  if constexpr (C == 4) {
+    const uint2 v = reinterpret_cast<const uint2*>(tile)[2 * idx];
+    return make_uint4(v.x, v.y, 0u, 0u);
+  } else {
+    return tile[idx];
+  }
+}
+template <int C>
+__device__ __forceinline__ void mac16(f32x4 (&acc)[C / 4], const W16<C>& w, const uint4 x) {
+#pragma unroll
+  for (int hf = 0; hf < C / 4; ++hf) {
+    acc[hf] = mfma_bf16_4x4x4(w.k[hf][0], make_uint2(x.x, x.y), acc[hf]);
+    if constexpr (C == 8) acc[hf] = mfma_bf16_4x4x4(w.k[hf][1], make_uint2(x.z, x.w), acc[hf]);
+  }
+}
+// GroupNorm partial row of a tile from the per-lane sums (as conv_vox64_kernel)
+template <int C>
+__device__ __forceinline__ void tile_stats_row(const float (&cs)[C / 4][4], const float (&cq)[C / 4][4], const int lane, double* row /* [C][2] */) {
+  const bool odd = lane & 1, hi = lane & 2;
+#pragma unroll
+  for (int hf = 0; hf < C / 4; ++hf) {
+    float u[2], uq[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float keep = odd ? cs[hf][2 + k] : cs[hf][k], send = odd ? cs[hf][k] : cs[hf][2 + k];
+      u[k] = keep + dpp_f<0xB1>(send);
+      const float keepq = odd ? cq[hf][2 + k] : cq[hf][k], sendq = odd ? cq[hf][k] : cq[hf][2 + k];
+      uq[k] = keepq + dpp_f<0xB1>(sendq);
+    }
+    float v1 = (hi ? u[1] : u[0]) + dpp_f<0x4E>(hi ? u[0] : u[1]);
+    float v2 = (hi ? uq[1] : uq[0]) + dpp_f<0x4E>(hi ? uq[0] : uq[1]);
+    v1 = wave_classsum_f(v1, 4); v2 = wave_classsum_f(v2, 4);
+    if (lane < 4) {
+      const int ch = (lane & 1) * 2 + (lane >> 1);
+      reinterpret_cast<double2*>(row + (hf * 4 + ch) * 2)[0] = make_double2((double)v1, (double)v2);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// vox_s2 on bf16 tensors (conv_vox_s2_kernel, conv_mfma.hip): stride-2 3x3x3 conv forward / data gradient of the stride-2
+// transposed conv, C = 4 / 8.  Same tile (rows de-interleaved by W parity), one 16-byte slot per voxel, bf16 MFMA.
+// ------------------------------------------------------------------------------------------------
+struct Vs2bArgs {
+  const bf16_t* src; int64_t sld; int D, H, W;
+  bf16_t* dst; int64_t dld; int oD, oH, oW;
+  const bf16_t* wq; const float* bias; int flags;
+  double* stats; int rows_per_sample; int tiles; const void* zero_page;
+};
+
+template <int C, int TD, int DIL>
+__global__ __launch_bounds__(64, 2) void conv_vox_s2b_kernel(Vs2bArgs a) {
+  constexpr int HF = C / 4;
+  constexpr int LD = 2 * (TD - 1) + 2 * DIL + 1, LH = 7 + 2 * DIL, LW = 31 + 2 * DIL;
+  constexpr int HW = (LW + 1) / 2, RW = 2 * HW;
+  constexpr int PLANE = LH * RW, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64;
+  constexpr int NW4 = (27 * C * C * 2 + 15) / 16, NWI = (NW4 + 63) / 64;
+  constexpr int ROT = ((2 * RW * 4) % 64) / 4;
+  extern __shared__ __attribute__((aligned(16))) uint4 vlds16[];
+  uint4* tile = vlds16;
+  uint4* wl = vlds16 + LD * PSTRIDE;
+  const int lane = threadIdx.x;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int b = wg / a.tiles;
+  const int tile_id = wg - b * a.tiles;
+  const int tw_n = a.oW / 16, th_n = a.oH / 4;
+  int bx = tile_id;
+  const int w0 = (bx % tw_n) * 16; bx /= tw_n;
+  const int h0 = (bx % th_n) * 4;
+  const int d0 = (bx / th_n) * TD;
+  const int64_t Ns = (int64_t)a.D * a.H * a.W, Nd = (int64_t)a.oD * a.oH * a.oW;
+  const bf16_t* srcb = a.src + (int64_t)b * Ns * a.sld;
+  bf16_t* dstb = a.dst + (int64_t)b * Nd * a.dld;
+  const int j = lane & 3;
+  const int hh = lane >> 4, ww = ((lane & 15) - (hh & 1) * ROT) & 15;
+  const bool accum = a.flags & N3D_ACCUMULATE;
+  const int64_t vox_off = ((int64_t)(h0 + hh) * a.oW + w0 + ww);
+  float4 biasv[HF], prevv[TD][HF];
+#pragma unroll
+  for (int hf = 0; hf < HF; ++hf) {
+    biasv[hf] = a.bias ? *reinterpret_cast<const float4*>(a.bias + hf * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < TD; ++g)
+      prevv[g][hf] = accum ? ld4(dstb + (((int64_t)(d0 + g) * a.oH * a.oW) + vox_off) * a.dld + hf * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const uint4* __restrict__ wq4 = reinterpret_cast<const uint4*>(a.wq);
+    const uint4* zp = reinterpret_cast<const uint4*>(a.zero_page);
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      const int idx = lane + i * 64;
+      __builtin_amdgcn_global_load_lds((gptr_t)(idx < NW4 ? wq4 + idx : zp), (lptr_t)(wl + i * 64), 16, 0, 0);
+    }
+    const int64_t pstride = (int64_t)a.H * a.W * a.sld;
+    const int id0 = 2 * d0 - DIL, ih0 = 2 * h0 - DIL, iw0 = 2 * w0 - DIL;
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+      const int pos = lane + i * 64;
+      const int row = pos / RW, rem = pos - row * RW;
+      const int par = rem / HW, half = rem - par * HW;
+      const int wx = 2 * half + par;
+      const int gh = ih0 + row, gw = iw0 + wx;
+      const bool okp = pos < PLANE && wx < LW && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      const bf16_t* prow = srcb + ((int64_t)gh * a.W + gw) * a.sld;
+#pragma unroll
+      for (int dz = 0; dz < LD; ++dz) {
+        const int gd = id0 + dz;
+        const bool inb = okp && gd >= 0 && gd < a.D;
+        const bf16_t* p = prow + gd * pstride;
+        __builtin_amdgcn_global_load_lds((gptr_t)(inb ? reinterpret_cast<const void*>(p) : reinterpret_cast<const void*>(zp)),
+                                         (lptr_t)(tile + dz * PSTRIDE + i * 64), 16, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  f32x4 acc[TD][HF];
+#pragma unroll
+  for (int hf = 0; hf < HF; ++hf) {
+    const f32x4 bv = {biasv[hf].x, biasv[hf].y, biasv[hf].z, biasv[hf].w};
+#pragma unroll
+    for (int g = 0; g < TD; ++g) acc[g][hf] = bv;
+  }
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9) {
+    const int kh = t9 / 3, kw = t9 % 3;
+    W16<C> wr[3];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) wr[kd] = ldw16<C>(wl, kd * 9 + t9, j);
+    const int base = (2 * hh + kh * DIL) * RW + ((kw * DIL) & 1) * HW + ww + ((kw * DIL) >> 1);
+    uint4 av[LD];
+#pragma unroll
+    for (int dz = 0; dz < LD; ++dz) av[dz] = rd_slot<C>(tile, dz * PSTRIDE + base);
+#pragma unroll
+    for (int dz = 0; dz < LD; ++dz) {
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) {
+        const int g2 = dz - kd * DIL;                 // = 2 * output plane
+        if (g2 >= 0 && (g2 & 1) == 0 && (g2 >> 1) < TD) mac16<C>(acc[g2 >> 1], wr[kd], av[dz]);
+      }
+    }
+  }
+  float cs[HF][4], cq[HF][4];
+#pragma unroll
+  for (int hf = 0; hf < HF; ++hf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[hf][r] = cq[hf][r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < TD; ++g) {
+    bf16_t* o = dstb + (((int64_t)(d0 + g) * a.oH * a.oW) + vox_off) * a.dld;
+#pragma unroll
+    for (int hf = 0; hf < HF; ++hf) {
+      const f32x4 v = acc[g][hf];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { cs[hf][r] += v[r]; cq[hf][r] = fmaf(v[r], v[r], cq[hf][r]); }
+      const float4 pv = prevv[g][hf];
+      st4(o + hf * 4, make_float4(v[0] + pv.x, v[1] + pv.y, v[2] + pv.z, v[3] + pv.w));
+    }
+  }
+  if (a.stats) tile_stats_row<C>(cs, cq, lane, a.stats + ((int64_t)b * a.rows_per_sample + tile_id) * C * 2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// vox_up on bf16 tensors (conv_vox_up_kernel, conv_mfma.hip): stride-2 transposed 3x3x3 conv forward / data gradient of the
+// stride-2 convs, C = 4 / 8: one wave = 4 x 16 source voxels -> all 8 output parity classes.
+// ------------------------------------------------------------------------------------------------
+struct VupbArgs {
+  const bf16_t* src; int64_t sld; int D, H, W;
+  bf16_t* dst; int64_t dld;
+  const bf16_t* wq; const float* bias; int flags;
+  double* stats; int rows_per_sample; int tiles; const void* zero_page;
+};
+__host__ __device__ constexpr int vupb_count(int dil, int s) { return dil == 2 ? 1 : (s == 0 ? 2 : (s == 1 ? 1 : 0)); }
+__host__ __device__ constexpr int vupb_p(int dil, int s, int i) { return dil == 2 ? 0 : (s == 0 ? i : 1); }
+__host__ __device__ constexpr int vupb_k(int dil, int s, int i) { return dil == 2 ? 1 - s : (s == 0 ? 1 + i : 0); }
+
+template <int C, int DIL>
+__global__ __launch_bounds__(64, 2) void conv_vox_upb_kernel(VupbArgs a) {
+  constexpr int HF = C / 4;
+  constexpr int LD = 3, LH = 6, LW = 18;
+  constexpr int PLANE = LH * LW, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64;
+  constexpr int NW4 = (27 * C * C * 2 + 15) / 16, NWI = (NW4 + 63) / 64;
+  extern __shared__ __attribute__((aligned(16))) uint4 vlds16[];
+  uint4* tile = vlds16;
+  uint4* wl = vlds16 + LD * PSTRIDE;
+  const int lane = threadIdx.x;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int b = wg / a.tiles;
+  const int tile_id = wg - b * a.tiles;
+  const int tw_n = a.W / 16, th_n = a.H / 4;
+  int bx = tile_id;
+  const int w0 = (bx % tw_n) * 16; bx /= tw_n;
+  const int h0 = (bx % th_n) * 4;
+  const int d0 = bx / th_n;
+  const int64_t Ns = (int64_t)a.D * a.H * a.W;
+  const int oH = 2 * a.H, oW = 2 * a.W;
+  const bf16_t* srcb = a.src + (int64_t)b * Ns * a.sld;
+  bf16_t* dstb = a.dst + (int64_t)b * 8 * Ns * a.dld;
+  const int j = lane & 3;
+  const int hh = lane >> 4, ww = ((lane & 15) - (hh & 1) * (LW % 16)) & 15;
+  const bool accum = a.flags & N3D_ACCUMULATE;
+  const int64_t obase = (((int64_t)(2 * d0) * oH + 2 * (h0 + hh)) * oW + 2 * (w0 + ww)) * a.dld;
+  auto ooff = [&](int cls) { return (((int64_t)(cls >> 2) * oH + ((cls >> 1) & 1)) * oW + (cls & 1)) * a.dld; };
+  float4 biasv[HF], prevv[8][HF];
+#pragma unroll
+  for (int hf = 0; hf < HF; ++hf) {
+    biasv[hf] = a.bias ? *reinterpret_cast<const float4*>(a.bias + hf * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int cls = 0; cls < 8; ++cls)
+      prevv[cls][hf] = accum ? ld4(dstb + obase + ooff(cls) + hf * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const uint4* __restrict__ wq4 = reinterpret_cast<const uint4*>(a.wq);
+    const uint4* zp = reinterpret_cast<const uint4*>(a.zero_page);
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      const int idx = lane + i * 64;
+      __builtin_amdgcn_global_load_lds((gptr_t)(idx < NW4 ? wq4 + idx : zp), (lptr_t)(wl + i * 64), 16, 0, 0);
+    }
+    const int64_t pstride = (int64_t)a.H * a.W * a.sld;
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+      const int pos = lane + i * 64;
+      const int wx = pos % LW, hy = pos / LW;
+      const int gh = h0 - 1 + hy, gw = w0 - 1 + wx;
+      const bool okp = pos < PLANE && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+      const bf16_t* prow = srcb + ((int64_t)gh * a.W + gw) * a.sld;
+#pragma unroll
+      for (int dz = 0; dz < LD; ++dz) {
+        const int gd = d0 - 1 + dz;
+        const bool inb = okp && gd >= 0 && gd < a.D;
+        const bf16_t* p = prow + gd * pstride;
+        __builtin_amdgcn_global_load_lds((gptr_t)(inb ? reinterpret_cast<const void*>(p) : reinterpret_cast<const void*>(zp)),
+                                         (lptr_t)(tile + dz * PSTRIDE + i * 64), 16, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  f32x4 acc[8][HF];
+#pragma unroll
+  for (int hf = 0; hf < HF; ++hf) {
+    const f32x4 bv = {biasv[hf].x, biasv[hf].y, biasv[hf].z, biasv[hf].w};
+#pragma unroll
+    for (int cls = 0; cls < 8; ++cls) acc[cls][hf] = bv;
+  }
+#pragma unroll
+  for (int sd = -1; sd <= 1; ++sd) {
+    if (vupb_count(DIL, sd) == 0) continue;
+    uint4 av[3][3];
+#pragma unroll
+    for (int sh = -1; sh <= 1; ++sh)
+#pragma unroll
+      for (int sw = -1; sw <= 1; ++sw)
+        if (vupb_count(DIL, sh) > 0 && vupb_count(DIL, sw) > 0)
+          av[sh + 1][sw + 1] = rd_slot<C>(tile, (1 + sd) * PSTRIDE + (hh + 1 + sh) * LW + (ww + 1 + sw));
+#pragma unroll
+    for (int sh = -1; sh <= 1; ++sh)
+#pragma unroll
+      for (int sw = -1; sw <= 1; ++sw) {
+        if (vupb_count(DIL, sh) == 0 || vupb_count(DIL, sw) == 0) continue;
+#pragma unroll
+        for (int id = 0; id < vupb_count(DIL, sd); ++id)
+#pragma unroll
+          for (int ih = 0; ih < vupb_count(DIL, sh); ++ih)
+#pragma unroll
+            for (int iw = 0; iw < vupb_count(DIL, sw); ++iw) {
+              const int cls = vupb_p(DIL, sd, id) * 4 + vupb_p(DIL, sh, ih) * 2 + vupb_p(DIL, sw, iw);
+              const int tap = vupb_k(DIL, sd, id) * 9 + vupb_k(DIL, sh, ih) * 3 + vupb_k(DIL, sw, iw);
+              const W16<C> wr = ldw16<C>(wl, tap, j);
+              mac16<C>(acc[cls], wr, av[sh + 1][sw + 1]);
+            }
+      }
+  }
+  float cs[HF][4], cq[HF][4];
+#pragma unroll
+  for (int hf = 0; hf < HF; ++hf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[hf][r] = cq[hf][r] = 0.f;
+#pragma unroll
+  for (int cls = 0; cls < 8; ++cls) {
+    bf16_t* o = dstb + obase + ooff(cls);
+#pragma unroll
+    for (int hf = 0; hf < HF; ++hf) {
+      const f32x4 v = acc[cls][hf];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { cs[hf][r] += v[r]; cq[hf][r] = fmaf(v[r], v[r], cq[hf][r]); }
+      const float4 pv = prevv[cls][hf];
+      st4(o + hf * 4, make_float4(v[0] + pv.x, v[1] + pv.y, v[2] + pv.z, v[3] + pv.w));
+    }
+  }
+  if (a.stats) tile_stats_row<C>(cs, cq, lane, a.stats + ((int64_t)b * a.rows_per_sample + tile_id) * C * 2);
+}
+
+struct Vs2bPlan { bool ok; int C, td, dil, tiles; size_t lds; };
+static Vs2bPlan vs2b_plan(const n3d_conv_geom* g, bool data_grad) {
+  Vs2bPlan p; p.ok = false;
+  if (data_grad || g->depthwise || g->k != 3 || g->stride != 2 || g->Ci != g->Co || (g->Ci != 4 && g->Ci != 8)) return p;
+  if (!(g->dil == 1 || g->dil == 2) || g->pad != g->dil) return p;
+  if (g->Wo % 16 != 0 || g->Ho % 4 != 0) return p;
+  p.C = g->Ci; p.dil = g->dil;
+  p.td = (g->Ci == 4 && g->Do % 2 == 0) ? 2 : 1;
+  p.tiles = (g->Wo / 16) * (g->Ho / 4) * (g->Do / p.td);
+  const int LD = 2 * (p.td - 1) + 2 * g->dil + 1, LH = 7 + 2 * g->dil, LW = 31 + 2 * g->dil;
+  const size_t pstride = ((size_t)LH * 2 * ((LW + 1) / 2) + 63) / 64 * 64;
+  const size_t wslots = (((size_t)27 * g->Ci * g->Ci * 2 + 15) / 16 + 63) / 64 * 64;
+  p.lds = ((size_t)LD * pstride + wslots) * 16;
+  p.ok = p.lds <= 64 * 1024;
+  return p;
+}
+struct VupbPlan { bool ok; int C, dil, tiles; size_t lds; };
+static VupbPlan vupb_plan(const n3d_conv_geom* g, bool data_grad) {
+  VupbPlan p; p.ok = false;
+  if (!data_grad || g->depthwise || g->k != 3 || g->stride != 2 || g->Ci != g->Co || (g->Ci != 4 && g->Ci != 8)) return p;
+  if (!(g->dil == 1 || g->dil == 2) || g->pad != g->dil) return p;
+  if (g->Di != 2 * g->Do || g->Hi != 2 * g->Ho || g->Wi != 2 * g->Wo) return p;
+  if (g->Wo % 16 != 0 || g->Ho % 4 != 0) return p;
+  p.C = g->Ci; p.dil = g->dil;
+  p.tiles = (g->Wo / 16) * (g->Ho / 4) * g->Do;
+  const size_t wslots = (((size_t)27 * g->Ci * g->Ci * 2 + 15) / 16 + 63) / 64 * 64;
+  p.lds = ((size_t)3 * 128 + wslots) * 16;
+  p.ok = true;
+  return p;
+}
+
 struct Vx16Plan { bool ok; int C, td, dil, tiles, nw; size_t lds; };
 
 static Vx16Plan vx16_plan(const n3d_conv_geom* g) {
@@ -296,45 +654,81 @@ static void launch_vox16_c(const Vx16Args& a, const Vx16Plan& p, int B, hipStrea
 }
 
 // ---- interface to conv_generic.hip -------------------------------------------------------------------------------
-// weights of this conv are packed as layout 4 (bf16 [27][cd][cs]) when both tensors are bf16 and the shape is served here
-bool vox16_serves(const n3d_conv_geom* g, int flags) {
-  return (flags & N3D_SRC_BF16) && (flags & N3D_DST_BF16) && !(flags & N3D_NO_MFMA) && vx16_plan(g).ok;
+// Which bf16 kernel serves (geometry, gather direction)?  0 none, 1 vox64b, 2 vox_s2b, 3 vox_upb.  Only with both tensors in bf16.
+static int vox16_kind(const n3d_conv_geom* g, bool data_grad, int flags) {
+  if (!((flags & N3D_SRC_BF16) && (flags & N3D_DST_BF16)) || (flags & N3D_NO_MFMA)) return 0;
+  if (vs2b_plan(g, data_grad).ok) return 2;
+  if (vupb_plan(g, data_grad).ok) return 3;
+  if (vx16_plan(g).ok) return 1;
+  return 0;
+}
+// packed-weight layout of n3d_pack_batch: 4 = bf16 [27][cd][cs], data gradient transposed + taps flipped (vox64b, vox_s2b);
+// 5 = bf16, data gradient transposed only (vox_upb); 0 = not served here
+int vox16_layout(const n3d_conv_geom* g, bool data_grad, int flags) {
+  const int k = vox16_kind(g, data_grad, flags);
+  return k == 0 ? 0 : (k == 3 ? 5 : 4);
 }
 
-int vox16_stats_rows(const n3d_conv_geom* g, int flags) {
-  if (!vox16_serves(g, flags)) return 0;
-  const Vx16Plan v = vx16_plan(g);
-  return v.tiles * v.nw;
-}
-
-void vox16_pack(const float* w, void* wq, int C, int data_grad, hipStream_t s) {
-  hipLaunchKernelGGL(pack_vox16_kernel, dim3((unsigned)cdiv(27 * C * C, 256)), dim3(256), 0, s, w, (bf16_t*)wq, C, data_grad);
+int vox16_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags) {
+  switch (vox16_kind(g, data_grad, flags)) {
+    case 1: { const Vx16Plan v = vx16_plan(g); return v.tiles * v.nw; }
+    case 2: return vs2b_plan(g, data_grad).tiles;
+    case 3: return vupb_plan(g, data_grad).tiles;
+    default: return 0;
+  }
 }
 
 // 1 = launched, 0 = not applicable, < 0 error
 int vox16_conv_try(const n3d_conv_geom* g, bool data_grad, const void* src, int64_t sld, const float* w, const float* bias, void* dst,
                    int64_t dld, int flags, const float* in_gate, const void* relu_src, const float* out_gate, double* stats, void* ws,
                    size_t ws_bytes, hipStream_t s) {
-  if (!vox16_serves(g, flags)) return 0;
-  const Vx16Plan v = vx16_plan(g);
+  const int kind = vox16_kind(g, data_grad, flags);
+  if (!kind) return 0;
+  const int C = g->Ci;
   const bool extras = in_gate || relu_src || out_gate || (flags & N3D_RELU_IN);
   const bool aligned = sld % 4 == 0 && dld % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 7) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0 &&
-                       (v.C == 4 || (sld % 8 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0));
+                       (C == 4 || (sld % 8 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0));
   if (extras || !aligned) {
-    if (stats || (flags & N3D_PREPACKED)) { set_error("conv(vox64b): gate / relu extras or an unaligned tensor on a shape whose statistics rows / packed weights assume this kernel"); return N3D_ERR_UNSUPPORTED; }
+    if (stats || (flags & N3D_PREPACKED)) { set_error("conv(bf16 mfma): gate / relu extras or an unaligned tensor on a shape whose statistics rows / packed weights assume this kernel"); return N3D_ERR_UNSUPPORTED; }
     return 0;
   }
-  const size_t need = (size_t)27 * v.C * v.C * 2;
-  if (!ws || ws_bytes < need) { set_error("conv(vox64b): workspace too small"); return N3D_ERR_WORKSPACE; }
-  if (!(flags & N3D_PREPACKED)) vox16_pack(w, ws, v.C, data_grad ? 1 : 0, s);
-  Vx16Args a;
-  a.src = (const bf16_t*)src; a.sld = sld; a.dst = (bf16_t*)dst; a.dld = dld; a.wq = (const bf16_t*)ws; a.bias = bias;
-  a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.flags = flags; a.stats = stats; a.rows_per_sample = v.tiles * v.nw; a.tiles = v.tiles;
-  a.zero_page = zero_page16_ptr();
-  if (!a.zero_page) { set_error("conv(vox64b): zero page symbol unavailable"); return N3D_ERR_HIP; }
-  if (v.C == 4) launch_vox16_c<4>(a, v, g->B, s); else launch_vox16_c<8>(a, v, g->B, s);
+  const size_t need = (size_t)27 * C * C * 2;
+  if (!ws || ws_bytes < need) { set_error("conv(bf16 mfma): workspace too small"); return N3D_ERR_WORKSPACE; }
+  // pack modes: vox64b 0 / 1 (data gradient: transposed + flipped), vox_s2b 0 (forward-type gathers only), vox_upb 2 (transposed)
+  if (!(flags & N3D_PREPACKED))
+    hipLaunchKernelGGL(pack_vox16_kernel, dim3((unsigned)cdiv(27 * C * C, 256)), dim3(256), 0, s, w, (bf16_t*)ws, C,
+                       kind == 3 ? 2 : (kind == 1 && data_grad ? 1 : 0));
+  const void* zp = zero_page16_ptr();
+  if (!zp) { set_error("conv(bf16 mfma): zero page symbol unavailable"); return N3D_ERR_HIP; }
+  if (kind == 1) {
+    const Vx16Plan v = vx16_plan(g);
+    Vx16Args a;
+    a.src = (const bf16_t*)src; a.sld = sld; a.dst = (bf16_t*)dst; a.dld = dld; a.wq = (const bf16_t*)ws; a.bias = bias;
+    a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.flags = flags; a.stats = stats; a.rows_per_sample = v.tiles * v.nw; a.tiles = v.tiles; a.zero_page = zp;
+    if (v.C == 4) launch_vox16_c<4>(a, v, g->B, s); else launch_vox16_c<8>(a, v, g->B, s);
+  } else if (kind == 2) {
+    const Vs2bPlan v = vs2b_plan(g, data_grad);
+    Vs2bArgs a;
+    a.src = (const bf16_t*)src; a.sld = sld; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.dst = (bf16_t*)dst; a.dld = dld; a.oD = g->Do; a.oH = g->Ho; a.oW = g->Wo;
+    a.wq = (const bf16_t*)ws; a.bias = bias; a.flags = flags; a.stats = stats; a.rows_per_sample = v.tiles; a.tiles = v.tiles; a.zero_page = zp;
+    const dim3 grid(v.tiles * g->B), blk(64);
+    if (v.C == 4) {
+      if (v.td == 2) { if (v.dil == 1) hipLaunchKernelGGL((conv_vox_s2b_kernel<4, 2, 1>), grid, blk, v.lds, s, a); else hipLaunchKernelGGL((conv_vox_s2b_kernel<4, 2, 2>), grid, blk, v.lds, s, a); }
+      else { if (v.dil == 1) hipLaunchKernelGGL((conv_vox_s2b_kernel<4, 1, 1>), grid, blk, v.lds, s, a); else hipLaunchKernelGGL((conv_vox_s2b_kernel<4, 1, 2>), grid, blk, v.lds, s, a); }
+    } else {
+      if (v.dil == 1) hipLaunchKernelGGL((conv_vox_s2b_kernel<8, 1, 1>), grid, blk, v.lds, s, a); else hipLaunchKernelGGL((conv_vox_s2b_kernel<8, 1, 2>), grid, blk, v.lds, s, a);
+    }
+  } else {
+    const VupbPlan v = vupb_plan(g, data_grad);
+    VupbArgs a;
+    a.src = (const bf16_t*)src; a.sld = sld; a.D = g->Do; a.H = g->Ho; a.W = g->Wo; a.dst = (bf16_t*)dst; a.dld = dld;
+    a.wq = (const bf16_t*)ws; a.bias = bias; a.flags = flags; a.stats = stats; a.rows_per_sample = v.tiles; a.tiles = v.tiles; a.zero_page = zp;
+    const dim3 grid(v.tiles * g->B), blk(64);
+    if (v.C == 4) { if (v.dil == 1) hipLaunchKernelGGL((conv_vox_upb_kernel<4, 1>), grid, blk, v.lds, s, a); else hipLaunchKernelGGL((conv_vox_upb_kernel<4, 2>), grid, blk, v.lds, s, a); }
+    else { if (v.dil == 1) hipLaunchKernelGGL((conv_vox_upb_kernel<8, 1>), grid, blk, v.lds, s, a); else hipLaunchKernelGGL((conv_vox_upb_kernel<8, 2>), grid, blk, v.lds, s, a); }
+  }
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { set_error("conv(vox64b) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+  if (e != hipSuccess) { set_error("conv(bf16 mfma) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
   return 1;
 }
 

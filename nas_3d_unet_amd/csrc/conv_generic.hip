@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
     // layout 2: vox64 / vox_s2 (data gradient: channels transposed + taps flipped); layout 3: vox_up (channels transposed only)
     const int co = jb.data_grad ? cs : cd, ci = jb.data_grad ? cd : cs, t2 = (jb.data_grad && (jb.layout == 2 || jb.layout == 4)) ? 26 - tap : tap;
     const float v = jb.w[((int64_t)co * C + ci) * 27 + t2];
-    if (jb.layout == 4) st1(reinterpret_cast<bf16_t*>(jb.dst) + i, v);   // bf16 [27][cd][cs]: the bf16-storage vox64 kernels (conv_bf16.hip)
+    if (jb.layout >= 4) st1(reinterpret_cast<bf16_t*>(jb.dst) + i, v);   // bf16 [27][cd][cs]: the bf16-storage vox64 kernels (conv_bf16.hip)
     else jb.dst[i] = v;
   }
 }
@@ -1199,8 +1199,8 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
                   void* ws, size_t ws_bytes, hipStream_t s);
 int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags);
 // bf16-storage vox64 family (conv_bf16.hip)
-bool vox16_serves(const n3d_conv_geom* g, int flags);
-int vox16_stats_rows(const n3d_conv_geom* g, int flags);
+int vox16_layout(const n3d_conv_geom* g, bool data_grad, int flags);
+int vox16_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags);
 int vox16_conv_try(const n3d_conv_geom* g, bool data_grad, const void* src, int64_t sld, const float* w, const float* bias, void* dst,
                    int64_t dld, int flags, const float* in_gate, const void* relu_src, const float* out_gate, double* stats, void* ws,
                    size_t ws_bytes, hipStream_t s);
@@ -1274,7 +1274,7 @@ size_t n3d_conv_workspace_bytes(const n3d_conv_geom* g) {
 // (transposed=1) kernel writes into `stats` ([B][rows][Cout][2] doubles)
 int n3d_conv_stats_rows(const n3d_conv_geom* g, int transposed, int flags) {
   if (!g) return 0;
-  if (vox16_serves(g, flags)) return vox16_stats_rows(g, flags);
+  if (int r16 = vox16_stats_rows(g, transposed != 0, flags)) return r16;
   int r = mfma_conv_stats_rows(g, transposed != 0, flags);
   if (r > 0) return r;
   if (r < 0) return 0;  // the kernel for this shape cannot emit statistics: use n3d_channel_stats
@@ -1790,7 +1790,7 @@ int n3d_conv_pack_info(const n3d_conv_geom* g, int data_grad, int flags, int32_t
   const int taps = g->k * g->k * g->k;
   const int Cs = data_grad ? g->Co : g->Ci, Cd = data_grad ? g->Ci : g->Co;
   if (g->depthwise) { *layout = -1; *cdp = 0; *floats = 0; return N3D_OK; }  // depthwise kernels read native weights
-  if (vox16_serves(g, flags)) { *layout = 4; *cdp = Cd; *floats = ((int64_t)27 * Cd * Cs + 1) / 2; return N3D_OK; }   // bf16 [27][cd][cs]
+  if (const int l16 = vox16_layout(g, data_grad != 0, flags)) { *layout = l16; *cdp = Cd; *floats = ((int64_t)27 * Cd * Cs + 1) / 2; return N3D_OK; }   // bf16 [27][cd][cs]
   const int ml = mfma_pack_layout(g, data_grad != 0, flags);
   if (ml == 2 || ml == 3) { *layout = ml; *cdp = Cd; *floats = (int64_t)27 * Cd * Cs; return N3D_OK; }
   if (ml == 1) { *layout = 1; *cdp = Cd; *floats = (int64_t)taps * Cs * Cd; return N3D_OK; }

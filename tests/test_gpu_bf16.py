@@ -52,6 +52,13 @@ def _view(t16):
     (8, 8, 3, 1, 1, False, (64, 64, 32)),      # ... C = 8, 2-plane tiles
     (8, 8, 3, 1, 2, False, (32, 32, 32)),      # ... C = 8, dilation 2, single-plane tiles
     (4, 4, 3, 1, 1, False, (8, 12, 16)),       # ... ragged tile counts (H = 12)
+    (4, 4, 3, 2, 1, False, (32, 32, 64)),      # stride 2 on the bf16 MFMA kernels: forward = conv_vox_s2b<4,2,1>, data gradient = conv_vox_upb<4,1>
+    (4, 4, 3, 2, 2, False, (32, 32, 64)),      # ... dilation 2
+    (8, 8, 3, 2, 1, False, (16, 16, 64)),      # ... C = 8
+    (8, 8, 3, 2, 2, False, (8, 16, 32)),
+    (4, 4, 3, 2, 1, True, (8, 8, 16)),         # transposed: forward = conv_vox_upb, data gradient = conv_vox_s2b
+    (8, 8, 3, 2, 2, True, (4, 8, 16)),
+    (4, 4, 3, 2, 2, True, (16, 16, 32)),
 ])
 @pytest.mark.parametrize("mix", ["bf16->bf16", "bf16->f32", "f32->bf16"])
 def test_conv_family_bf16_storage(cin, cout, k, stride, dil, transposed, shape, mix):
