@@ -225,3 +225,23 @@ def test_trainer_bf16_storage_graph_replay():
         out[st] = [float(tr.step(x, t)) for _ in range(3)]
     np.testing.assert_allclose(out["bf16"], out["fp32"], rtol=0, atol=TOL_LOSS)
     assert out["bf16"][2] < out["bf16"][0]
+
+
+def test_searched_net_bf16_with_non_conv_primitives_vs_oracle():
+    """G_ALL (depthwise-separable, SE, pooling, identity primitives): the cells that contain primitives without bf16 kernels stay
+    fp32 as a whole, the stems (and any all-conv cell) store bf16 -- mixed storage with conversions in the cells' preprocess convs.
+    Against the fp32 CPU oracle at the bf16 tolerance."""
+    from nas_3d_unet_amd import unet
+    rng = np.random.default_rng(5)
+    xn = rng.standard_normal((2, 4, 32, 32, 32)).astype(np.float32)
+    tn = (rng.uniform(0, 1, (2, 3, 32, 32, 32)) < 0.3).astype(np.float32)
+    P = orc.make_params(orc.searched_param_specs(orc.DEFAULT_CFG, orc.G_ALL), requires_grad=True)
+    pr, zr = orc.searched_forward(P, torch.from_numpy(xn), orc.G_ALL, return_logits=True)
+    lr = orc.dice_loss(pr, torch.from_numpy(tn))
+    lr.backward()
+    net, _ = build_net("searched", "G_ALL", 4)
+    unet.set_storage(net, "bf16")
+    l, logits, p = _run_bf16(net, dev(xn), dev(tn))
+    assert net._net_plan.stem_dt == torch.bfloat16 and all(pl.dt == torch.float32 for pl in net._net_plan.cells)
+    _check_against_fp32(l, logits, p, {n: q.grad for n, q in net.named_parameters()}, float(lr), zr.detach(), pr.detach(),
+                        {n: q.grad for n, q in P.items()})
