@@ -1467,7 +1467,7 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     // hot path obtain analytically from the GroupNorm backward sums (n3d_gn_bwd_coeffs)
     int nch = 0;
     int hv = vox_wgrad_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, s);   // fp32, or both tensors in bf16 storage
-    if (hv == 0 && !(flags & N3D_ANY_BF16)) hv = vox_wgrad_s2_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, s);
+    if (hv == 0) hv = vox_wgrad_s2_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, s);
     if (hv < 0) return hv;
     if (hv == 1) {
       const int C = g->Ci, nout = C * C * taps;

@@ -1482,14 +1482,16 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
 // The generic kernel gave every tap its own workgroups, i.e. re-read dY 27 times.
 // ------------------------------------------------------------------------------------------------
 struct Vw2Args {
-  const float* x; int64_t xld; int D, H, W;        // big grid (conv input / transposed-conv output gradient)
-  const float* dy; int64_t dyld; int oD, oH, oW;   // small grid
+  const void* x; int64_t xld; int D, H, W;         // big grid (conv input / transposed-conv output gradient); T elements
+  const void* dy; int64_t dyld; int oD, oH, oW;    // small grid
   float* partial; int dchunk; const void* zero_page;
 };
 
-template <int C, int DIL>
+template <int C, int DIL, typename T = float>
 __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
-  constexpr int Q = C / 4, TD = 2, GH = 4, GW = 16;
+  constexpr bool B16 = sizeof(T) == 2;
+  constexpr int QC = C / 4, Q = B16 ? 1 : QC, EPS = B16 ? 8 : 4;   // accumulator quads; LDS slots per voxel; elements per slot
+  constexpr int TD = 2, GH = 4, GW = 16;
   constexpr int LD = 2 * (TD - 1) + 2 * DIL + 1, LH = 7 + 2 * DIL, LW = 31 + 2 * DIL;
   constexpr int HW = (LW + 1) / 2, RW = 2 * HW, PLANE = LH * RW, NVOX = LD * PLANE;
   constexpr int NXC = (Q * NVOX + 63) / 64, NYC = (TD * GH * GW * Q + 63) / 64, NCH = (NXC + NYC + 3) / 4 * 4, BUF = NCH * 64;
@@ -1508,8 +1510,8 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
   const int h0 = (bx % th_n) * GH;
   const int dbeg = (bx / th_n) * a.dchunk;
   const int64_t Nx = (int64_t)a.D * a.H * a.W, Ny = (int64_t)a.oD * a.oH * a.oW;
-  const float* xb = a.x + (int64_t)b * Nx * a.xld;
-  const float* dyb = a.dy + (int64_t)b * Ny * a.dyld;
+  const T* xb = reinterpret_cast<const T*>(a.x) + (int64_t)b * Nx * a.xld;
+  const T* dyb = reinterpret_cast<const T*>(a.dy) + (int64_t)b * Ny * a.dyld;
   const float4* zp = reinterpret_cast<const float4*>(a.zero_page);
   const int blk = lane >> 2, i4 = lane & 3;
   const int tap0 = wave * 7;
@@ -1519,15 +1521,15 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
     const int tap = (tap0 + t < 27) ? tap0 + t : 26;
     const int kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
     // X voxel (2g + kd*DIL, 2hh + kh*DIL, 2blk + kw*DIL): W parity and half index
-    toff[t] = ((kd * DIL) * PLANE + (kh * DIL) * RW + ((kw * DIL) & 1) * HW + ((kw * DIL) >> 1) + blk) * 4 + i4;
+    toff[t] = ((kd * DIL) * PLANE + (kh * DIL) * RW + ((kw * DIL) & 1) * HW + ((kw * DIL) >> 1) + blk) * EPS + i4;
   }
-  f32x4 acc[7][Q][Q];
+  f32x4 acc[7][QC][QC];
 #pragma unroll
   for (int t = 0; t < 7; ++t)
 #pragma unroll
-    for (int qa = 0; qa < Q; ++qa)
+    for (int qa = 0; qa < QC; ++qa)
 #pragma unroll
-      for (int qb = 0; qb < Q; ++qb) acc[t][qa][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int qb = 0; qb < QC; ++qb) acc[t][qa][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   auto stage = [&](int d0, float4* buf) {
@@ -1566,23 +1568,34 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
     if (k + 1 < ntile) stage(dbeg + (k + 1) * TD, wtile + ((k + 1) & 1) * BUF);
     const float* tf = reinterpret_cast<const float*>(wtile + (k & 1) * BUF);
     const float* yf = tf + NXC * 64 * 4;
+    const bf16_t* th = reinterpret_cast<const bf16_t*>(wtile + (k & 1) * BUF);
+    const bf16_t* yh = th + NXC * 64 * 8;
 #pragma unroll
     for (int r = 0; r < TD * GH; ++r) {
       const int g = r >> 2, hh = r & 3;
-      const int rbase = ((2 * g) * PLANE + (2 * hh) * RW) * 4;
-      float avs[7][Q], bvs[Q];
+      const int rbase = ((2 * g) * PLANE + (2 * hh) * RW) * EPS;
+      float avs[7][QC], bvs[QC];
+      if constexpr (B16) {
 #pragma unroll
-      for (int qb = 0; qb < Q; ++qb) bvs[qb] = yf[((r * GW + blk) * Q + qb) * 4 + i4];
+        for (int qb = 0; qb < QC; ++qb) bvs[qb] = ld1(yh + (r * GW + blk) * 8 + qb * 4 + i4);
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+          for (int qa = 0; qa < QC; ++qa) avs[t][qa] = ld1(th + rbase + toff[t] + qa * 4);
+      } else {
+#pragma unroll
+        for (int qb = 0; qb < QC; ++qb) bvs[qb] = yf[((r * GW + blk) * Q + qb) * 4 + i4];
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+          for (int qa = 0; qa < QC; ++qa) avs[t][qa] = tf[qa * NVOX * 4 + rbase + toff[t]];
+      }
 #pragma unroll
       for (int t = 0; t < 7; ++t)
 #pragma unroll
-        for (int qa = 0; qa < Q; ++qa) avs[t][qa] = tf[qa * NVOX * 4 + rbase + toff[t]];
+        for (int qa = 0; qa < QC; ++qa)
 #pragma unroll
-      for (int t = 0; t < 7; ++t)
-#pragma unroll
-        for (int qa = 0; qa < Q; ++qa)
-#pragma unroll
-          for (int qb = 0; qb < Q; ++qb) acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(avs[t][qa], bvs[qb], acc[t][qa][qb], 0, 0, 0);
+          for (int qb = 0; qb < QC; ++qb) acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(avs[t][qa], bvs[qb], acc[t][qa][qb], 0, 0, 0);
     }
   }
   float* out = a.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 27) * (C * C);
@@ -1590,9 +1603,9 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
   for (int t = 0; t < 7; ++t) {
     if (tap0 + t < 27) {
 #pragma unroll
-      for (int qa = 0; qa < Q; ++qa)
+      for (int qa = 0; qa < QC; ++qa)
 #pragma unroll
-        for (int qb = 0; qb < Q; ++qb)
+        for (int qb = 0; qb < QC; ++qb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sum = wave_classsum_f(acc[t][qa][qb][r], 4);
@@ -1612,14 +1625,19 @@ int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   // small problems (16^3 outputs) leave this tile scheme with a few dozen long-running workgroups: the per-tap generic
   // kernel is faster there (measured 8.7 vs 12.7 us at (2,8,16^3)); from 32^3 outputs on it is 2x faster and reads dY once
   if ((int64_t)g->B * g->Do * g->Ho * g->Wo < 32768) return 0;
-  if (xld % 4 != 0 || dyld % 4 != 0 || !aligned16(x) || !aligned16(dy)) return 0;
+  const bool b16 = (flags & N3D_SRC_BF16) && (flags & N3D_DST_BF16);
+  if (!b16 && (flags & (N3D_SRC_BF16 | N3D_DST_BF16))) return 0;   // mixed storage: the generic kernel
+  if (xld % 4 != 0 || dyld % 4 != 0) return 0;
+  if (!b16 && (!aligned16(x) || !aligned16(dy))) return 0;
+  if (b16 && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 7) != 0 ||
+              (g->Ci == 8 && (xld % 8 != 0 || dyld % 8 != 0 || !aligned16(x) || !aligned16(dy))))) return 0;
   const int columns = g->B * (g->Ho / 4) * (g->Wo / 16);
   int nd = g->Do / 2, dsplit = 1;
   while (columns * dsplit < 384 && dsplit * 2 <= nd && nd % (dsplit * 2) == 0) dsplit *= 2;
   const int tiles = (g->Wo / 16) * (g->Ho / 4) * dsplit;
   const int nwg = tiles * g->B;
   if ((size_t)nwg * 27 * g->Ci * g->Ci > avail_floats) return 0;
-  const size_t Qn = g->Ci / 4;
+  const size_t Qn = b16 ? 1 : g->Ci / 4;   // LDS slots per voxel
   const size_t LDn = 2 + 2 * g->dil + 1, LHn = 7 + 2 * g->dil, LWn = 31 + 2 * g->dil;
   const size_t nvox = LDn * LHn * 2 * ((LWn + 1) / 2);
   const size_t nxc = (Qn * nvox + 63) / 64, nyc = (2 * 4 * 16 * Qn + 63) / 64, nch = (nxc + nyc + 3) / 4 * 4;
@@ -1630,7 +1648,15 @@ int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   a.partial = partial; a.dchunk = g->Do / dsplit; a.zero_page = zero_page_ptr();
   if (!a.zero_page) return 0;
   dim3 grid(tiles, g->B);
-  if (g->Ci == 4) {
+  if (b16) {
+    if (g->Ci == 4) {
+      if (g->dil == 1) hipLaunchKernelGGL((vox_wgrad_s2_kernel<4, 1, bf16_t>), grid, dim3(256), lds, s, a);
+      else hipLaunchKernelGGL((vox_wgrad_s2_kernel<4, 2, bf16_t>), grid, dim3(256), lds, s, a);
+    } else {
+      if (g->dil == 1) hipLaunchKernelGGL((vox_wgrad_s2_kernel<8, 1, bf16_t>), grid, dim3(256), lds, s, a);
+      else hipLaunchKernelGGL((vox_wgrad_s2_kernel<8, 2, bf16_t>), grid, dim3(256), lds, s, a);
+    }
+  } else if (g->Ci == 4) {
     if (g->dil == 1) hipLaunchKernelGGL((vox_wgrad_s2_kernel<4, 1>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((vox_wgrad_s2_kernel<4, 2>), grid, dim3(256), lds, s, a);
   } else {

@@ -59,6 +59,9 @@ def _view(t16):
     (4, 4, 3, 2, 1, True, (8, 8, 16)),         # transposed: forward = conv_vox_upb, data gradient = conv_vox_s2b
     (8, 8, 3, 2, 2, True, (4, 8, 16)),
     (4, 4, 3, 2, 2, True, (16, 16, 32)),
+    (4, 4, 3, 2, 1, False, (64, 64, 64)),      # large enough for the MFMA stride-2 weight gradient (vox_wgrad_s2_kernel<.., bf16>)
+    (8, 8, 3, 2, 2, False, (32, 64, 64)),
+    (4, 4, 3, 2, 1, True, (32, 32, 32)),       # ... with the roles swapped (transposed conv)
 ])
 @pytest.mark.parametrize("mix", ["bf16->bf16", "bf16->f32", "f32->bf16"])
 def test_conv_family_bf16_storage(cin, cout, k, stride, dil, transposed, shape, mix):
