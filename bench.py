@@ -94,7 +94,7 @@ def conv_kernel_roofline(device, batch, size, iters=40):
     bytes_ = 2.0 * batch * size ** 3 * c * 4
     ach = flops / sec / 1e12
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_vox64.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_conv_vox64_f32_2x4x%d.json" % size)
     if os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
