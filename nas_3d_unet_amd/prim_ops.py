@@ -68,6 +68,13 @@ class BaseOp(nn.Module):
         self.dropout = nn.Dropout3d(dropout_rate) if dropout_rate > 0 else None
         self._segments = None
 
+    def __setattr__(self, name, value):
+        # the launch programs are built once from (ops_list, norm, dropout, weight modules): re-assigning one of them
+        # (e.g. `op.dropout = None`, as the reference's users do to switch the head's Dropout3d off) must rebuild them
+        if name in ("norm", "dropout", "activation", "conv", "depth_conv", "point_conv", "fc", "ops_list") and "_segments" in self.__dict__:
+            self.__dict__["_segments"] = None
+        super().__setattr__(name, value)
+
     # subclasses describe their weight op ------------------------------------------------------
     def _weight_program(self):
         raise NotImplementedError

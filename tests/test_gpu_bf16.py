@@ -192,14 +192,15 @@ def test_searched_net_bf16_vs_golden_d4s64(golden):
     assert net._net_plan.stem_dt == torch.bfloat16 and dts[0] == torch.bfloat16 and dts[-1] == torch.bfloat16 and dts[3] == torch.float32
 
 
-@pytest.mark.parametrize("size,batch", [(64, 2), (128, 1)])
+@pytest.mark.parametrize("size,batch", [(64, 2), (128, 1), ((32, 64, 96), 3)])
 def test_searched_net_bf16_vs_cpu_oracle(size, batch):
     """seeded 64^3 (batch 2) and 128^3 (the configuration's patch size) cases against the fp32 CPU oracle: loss, logits,
     probabilities, every parameter gradient; and a second run of the same step is bit-identical"""
     from nas_3d_unet_amd import unet
-    rng = np.random.default_rng(size)
-    xn = rng.standard_normal((batch, 4, size, size, size)).astype(np.float32)
-    tn = (rng.uniform(0, 1, (batch, 3, size, size, size)) < 0.3).astype(np.float32)
+    shape = (size, size, size) if isinstance(size, int) else size     # also a non-cubic patch with a batch of 3
+    rng = np.random.default_rng(shape[0] + shape[2])
+    xn = rng.standard_normal((batch, 4) + shape).astype(np.float32)
+    tn = (rng.uniform(0, 1, (batch, 3) + shape) < 0.3).astype(np.float32)
     P = orc.make_params(orc.searched_param_specs(orc.DEFAULT_CFG, orc.G_CONV), requires_grad=True)
     pr, zr = orc.searched_forward(P, torch.from_numpy(xn), orc.G_CONV, return_logits=True)
     lr = orc.dice_loss(pr, torch.from_numpy(tn))
