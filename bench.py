@@ -277,9 +277,12 @@ def main():
             "config": {"workload": "searched.py SearchedNet/G_conv train step, batch=%d 4x%d^3 %s per GPU" % (args.batch, args.size, "fp32" if args.dtype == "f32" else "bf16-storage"),
                        "global_batch": world * args.batch, "patch": [4, args.size, args.size, args.size],
                        "parallelism": "dp%d" % world, "dp_buckets": len(trainer.sync.ranges) if trainer.dp_path else None, "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "final_loss": round(final_loss, 5)},
-            "whole_net": {"tflops_fwd_bwd": round(value * FLOP_FWD_BWD_PER_PATCH / 1e12, 3),
-                          "algorithmic_gbs": round(value * 3 * BYTES_FWD_PER_PATCH / 1e9, 1),
-                          "hbm_frac_of_8TBs": round(value * 3 * BYTES_FWD_PER_PATCH / 1e9 / world / PEAK_HBM_GBS, 4)},
+            # algorithmic work per patch scales with the voxel count (figures quoted at 64^3); bf16 storage halves the
+            # bytes of the levels it covers (~94 % of the activation bytes)
+            "whole_net": (lambda vox, byt: {"tflops_fwd_bwd": round(value * FLOP_FWD_BWD_PER_PATCH * vox / 1e12, 3),
+                                            "algorithmic_gbs": round(value * 3 * BYTES_FWD_PER_PATCH * vox * byt / 1e9, 1),
+                                            "hbm_frac_of_8TBs": round(value * 3 * BYTES_FWD_PER_PATCH * vox * byt / 1e9 / world / PEAK_HBM_GBS, 4)})(
+                (args.size / 64.0) ** 3, 1.0 if args.dtype == "f32" else 1.0 - 0.94 / 2),
         }
         if not args.no_roofline:
             out["roofline"] = conv_kernel_roofline(device, args.batch, args.size)
