@@ -109,6 +109,11 @@ typedef struct n3d_final_job {
   int32_t nchunks, ntiles, tci, tco, ci_t, co_t, Co, Ci, taps, pad_;
 } n3d_final_job;
 int n3d_wgrad_finalize_batch(const n3d_final_job* jobs /* host array */, int njobs, void* stream);
+/* Both batch calls compact their job table into the kernel arguments (pointers as 3-bit segment + 29-bit float offset against
+ * up to eight 2 GB address segments per launch); jobs whose addresses do not fit one table go to further launches.
+ * n3d_selftest_job_tables: host-only check of that encoding on scattered fake addresses (no device needed);
+ * returns the number of launches its 300 jobs take, < 0 on a mismatch. */
+int n3d_selftest_job_tables(void);
 
 /* y[o side] = conv(x[i side]) + bias */
 int n3d_conv_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias,

@@ -128,6 +128,7 @@ PROTOTYPES = {
     "n3d_conv_pack_info": (_i, [_gp, _i, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "n3d_pack_batch": (_i, [C.POINTER(PackJob), _i, _p]),
     "n3d_wgrad_finalize_batch": (_i, [C.POINTER(FinalJob), _i, _p]),
+    "n3d_selftest_job_tables": (_i, []),
     "n3d_convT_fwd": (_i, [_gp, _p, _i64, _p, _p, _p, _i64, _i, _p, _p, _p, _sz, _p]),
     "n3d_convT_bwd_data": (_i, [_gp, _p, _i64, _p, _p, _i64, _i, _p, _sz, _p]),
     "n3d_convT_bwd_weight": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _i, _p, _sz, C.POINTER(FinalJob), _p]),

@@ -6,6 +6,8 @@
 // These kernels cover every shape of the path; the MFMA kernels in conv_mfma.hip take over the
 // FLOP-heavy 3x3x3 shapes.
 #include "n3d_common.h"
+#include <algorithm>
+#include <vector>
 
 namespace n3d {
 
@@ -987,80 +989,134 @@ __global__ void channel_sum_final_kernel(const float* __restrict__ partial, int 
 
 
 // ------------------------------------------------------------------------------------------------
-// batched weight packing / batched weight-gradient reduction: jobs travel BY VALUE in the kernel
-// arguments (graph-capturable, no device-side table to maintain); blockIdx.y selects the job.
-// layouts: 0 generic [tap][cs][cdp]; 1 gemm16 [tap][cs/16][kk][cd][j]; 2 vox64 [tap][cd][cs] (flipped for data grad)
+// batched weight packing / batched weight-gradient reduction: the job table travels BY VALUE in the kernel
+// arguments (graph-capturable, no device-side table to maintain), compacted to 16 / 36 bytes per job so that a whole
+// train step fits one 4 KB argument block: a pointer becomes (segment : 3 bits, float offset : 29 bits) against up to
+// eight 2 GB address segments of the batch (parameters, gradients, packed slots and workspaces live in a few allocations).
+// layouts: 0 generic [tap][cs][cdp]; 1 gemm16 [tap][cs/16][kk][cd][j]; 2 vox64 [tap][cd][cs] (flipped for data grad);
+//          3 vox_up (as 2, never flipped); 4 / 5 = 2 / 3 in bfloat16
 // ------------------------------------------------------------------------------------------------
-#define N3D_PACK_JOBS 64
-#define N3D_FINAL_JOBS 40
-struct PackJobs { n3d_pack_job j[N3D_PACK_JOBS]; int start[N3D_PACK_JOBS + 1]; int n; };
-// start[k] = first workgroup of job k in the flattened grid (only the workgroups a job needs are launched: a
-// (max elements, jobs) grid spends its time dispatching empty workgroups)
-struct FinalJobs { n3d_final_job j[N3D_FINAL_JOBS]; int start[N3D_FINAL_JOBS + 1]; int n; };
+#define N3D_PACK_JOBS 192
+#define N3D_FINAL_JOBS 96
+#define N3D_NO_OFF 0xffffffffu
+struct PackJobD { uint32_t w, dst; uint16_t Co, Ci, cdp; uint8_t taps, mode; };   // mode = layout | data_grad << 4
+struct SegBases { uintptr_t b[8]; };
+__device__ __forceinline__ float* seg_ptr(const SegBases& sb, uint32_t off) { return reinterpret_cast<float*>(sb.b[off >> 29]) + (off & 0x1fffffffu); }
+struct PackJobs { SegBases seg; PackJobD j[N3D_PACK_JOBS]; int start[N3D_PACK_JOBS + 1]; int n; };
+struct FinalJobD { uint32_t partial, pbias, dw, dbias; int32_t nchunks; uint16_t ntiles, Co, Ci, ci_t, co_t; uint8_t tci, tco, taps, pad_; };
+struct FinalJobs { SegBases seg; FinalJobD j[N3D_FINAL_JOBS]; int start[N3D_FINAL_JOBS + 1]; int n; };
+static_assert(sizeof(PackJobs) <= 4000 && sizeof(FinalJobs) <= 4000, "job tables must fit the kernel argument block");
+
+// elements of one tap of the packed form (the tap is the slowest index of every layout)
+__host__ __device__ inline int pack_tap_elems(int layout, int Cs, int Cd, int cdp, int Co) {
+  return layout == 0 ? Cs * cdp : (layout == 1 ? Cs * Cd : Co * Co);
+}
+
+template <int TAPS>
+__device__ __forceinline__ void pack_taps(const float* __restrict__ src, float* __restrict__ dst, const int taps, const int E, const int r,
+                                          const bool flip, const bool bf16, const bool live) {
+  // the taps of one (source channel, destination channel) pair are `taps` consecutive floats of the native weight:
+  // a lane reads its whole run (two cache lines, fully used) and writes one element per tap, consecutive lanes to
+  // consecutive addresses.  (Walking the packed form element by element reads 4 bytes per cache line and tap.)
+  float v[TAPS > 0 ? TAPS : 1];
+  if (TAPS > 0) {
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) v[t] = live ? src[flip ? TAPS - 1 - t : t] : 0.f;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      if (bf16) st1(reinterpret_cast<bf16_t*>(dst) + (int64_t)t * E + r, v[t]);
+      else dst[(int64_t)t * E + r] = v[t];
+    }
+  } else {
+    for (int t = 0; t < taps; ++t) {
+      const float x = live ? src[flip ? taps - 1 - t : t] : 0.f;
+      if (bf16) st1(reinterpret_cast<bf16_t*>(dst) + (int64_t)t * E + r, x);
+      else dst[(int64_t)t * E + r] = x;
+    }
+  }
+}
 
 __global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
-  // flattened grid: start[k] = first workgroup of job k; binary search (each probe is a dependent scalar load)
+  // flattened grid: start[k] = first workgroup of job k (only the workgroups a job needs are launched);
+  // binary search over the offsets (each probe is a dependent scalar load)
   int jx = 0;
-  for (int step = 32; step >= 1; step >>= 1)
+  for (int step = 128; step >= 1; step >>= 1)
     if (jx + step < jobs.n && (int)blockIdx.x >= jobs.start[jx + step]) jx += step;
-  const n3d_pack_job jb = jobs.j[jx];
-  const int Co = jb.Co, Ci = jb.Ci, taps = jb.taps;
-  const int Cs = jb.data_grad ? Co : Ci, Cd = jb.data_grad ? Ci : Co;
-  const int i = (blockIdx.x - jobs.start[jx]) * 256 + threadIdx.x;
-  if (jb.layout == 0) {
-    const int Cdp = jb.cdp;
-    if (i >= taps * Cs * Cdp) return;
-    const int cd = i % Cdp, cs = (i / Cdp) % Cs, tap = i / (Cdp * Cs);
-    float v = 0.f;
-    if (cd < Cd) {
-      const int co = jb.data_grad ? cs : cd, ci = jb.data_grad ? cd : cs;
-      v = jb.w[((int64_t)co * Ci + ci) * taps + tap];
-    }
-    jb.dst[i] = v;
-  } else if (jb.layout == 1) {
-    if (i >= taps * Cs * Cd) return;
-    const int j = i & 3, cd = (i >> 2) % Cd, rest = (i >> 2) / Cd;
-    const int kk = rest & 3, c16 = (rest >> 2) % (Cs / 16), tap = (rest >> 2) / (Cs / 16);
-    const int cs = c16 * 16 + kk * 4 + j;
-    const int co = jb.data_grad ? cs : cd, ci = jb.data_grad ? cd : cs;
-    jb.dst[i] = jb.w[((int64_t)co * Ci + ci) * taps + tap];
+  const PackJobD jb = jobs.j[jx];
+  const int Co = jb.Co, Ci = jb.Ci, taps = jb.taps, layout = jb.mode & 15;
+  const bool data_grad = (jb.mode >> 4) != 0;
+  const int Cs = data_grad ? Co : Ci, Cd = data_grad ? Ci : Co;
+  const int E = pack_tap_elems(layout, Cs, Cd, jb.cdp, Co);
+  const int r = (blockIdx.x - jobs.start[jx]) * 256 + threadIdx.x;
+  if (r >= E) return;
+  int cs, cd;
+  if (layout == 0) {
+    cd = r % jb.cdp; cs = r / jb.cdp;
+  } else if (layout == 1) {
+    const int j = r & 3, rest = (r >> 2) / Cd;
+    cd = (r >> 2) % Cd;
+    cs = (rest >> 2) * 16 + (rest & 3) * 4 + j;
   } else {
-    const int C = Co;
-    if (i >= 27 * C * C) return;
-    const int cs = i % C, cd = (i / C) % C, tap = i / (C * C);
-    // layout 2: vox64 / vox_s2 (data gradient: channels transposed + taps flipped); layout 3: vox_up (channels transposed only)
-    const int co = jb.data_grad ? cs : cd, ci = jb.data_grad ? cd : cs, t2 = (jb.data_grad && (jb.layout == 2 || jb.layout == 4)) ? 26 - tap : tap;
-    const float v = jb.w[((int64_t)co * C + ci) * 27 + t2];
-    if (jb.layout >= 4) st1(reinterpret_cast<bf16_t*>(jb.dst) + i, v);   // bf16 [27][cd][cs]: the bf16-storage vox64 kernels (conv_bf16.hip)
-    else jb.dst[i] = v;
+    cs = r % Co; cd = r / Co;
   }
+  const bool live = cd < Cd;
+  const int co = data_grad ? cs : cd, ci = data_grad ? cd : cs;
+  const float* src = seg_ptr(jobs.seg, jb.w) + ((int64_t)co * Ci + ci) * taps;
+  float* dst = seg_ptr(jobs.seg, jb.dst);
+  // layouts 2 / 4: the data gradient is the same kernel run with the taps mirrored
+  const bool flip = data_grad && (layout == 2 || layout == 4);
+  if (taps == 27) pack_taps<27>(src, dst, taps, E, r, flip, layout >= 4, live);
+  else if (taps == 1) pack_taps<1>(src, dst, taps, E, r, false, layout >= 4, live);
+  else pack_taps<0>(src, dst, taps, E, r, flip, layout >= 4, live);
 }
 
 #define N3D_FINAL_DIRECT_MAX 16  // jobs with at most this many chunks: one thread sums all chunks of its slab position
 
-__device__ __forceinline__ void final_store(const n3d_final_job& jb, const int p, const int nslab, const int nb, const int T, const float tot) {
+// many-chunk jobs: a workgroup covers 2^k slab positions x 256 / 2^k chunk segments; the more chunks, the more segments,
+// so that no thread walks more than ~32 rows (a head gradient at 128^3 has 2048 rows of 36 floats: with a fixed
+// 32 x 8 split two workgroups walked 256 rows each, one memory round trip per eight rows)
+__host__ __device__ inline int final_pos_log2(int nchunks) { return nchunks <= 128 ? 5 : (nchunks <= 512 ? 3 : 2); }
+__host__ __device__ inline int final_job_blocks(int el, int nchunks) {
+  return nchunks <= N3D_FINAL_DIRECT_MAX ? (el + 255) / 256 : (el + (1 << final_pos_log2(nchunks)) - 1) >> final_pos_log2(nchunks);
+}
+
+__device__ __forceinline__ void final_store(const FinalJobD& jb, const SegBases& sb, const int p, const int nslab, const int nb, const int T, const float tot) {
   if (p < nslab) {
-    if (jb.dw) {
+    if (jb.dw != N3D_NO_OFF) {
       const int tile = p / T, q = p - tile * T;
       const int cot = tile % jb.tco, cit = (tile / jb.tco) % jb.tci, tap = tile / (jb.tco * jb.tci);
       const int ci = cit * jb.ci_t + q / jb.co_t, co = cot * jb.co_t + q % jb.co_t;
-      if (ci < jb.Ci && co < jb.Co) jb.dw[((int64_t)co * jb.Ci + ci) * jb.taps + tap] = tot;
+      if (ci < jb.Ci && co < jb.Co) seg_ptr(sb, jb.dw)[((int64_t)co * jb.Ci + ci) * jb.taps + tap] = tot;
     }
-  } else if (p < nslab + nb && jb.dbias) {
+  } else if (p < nslab + nb && jb.dbias != N3D_NO_OFF) {
     const int co = p - nslab;
-    if (co < jb.Co) jb.dbias[co] = tot;
+    if (co < jb.Co) seg_ptr(sb, jb.dbias)[co] = tot;
   }
+}
+
+template <int NL>
+__device__ __forceinline__ float final_direct(const float* __restrict__ partial, const int nchunks, const int64_t cs, const int p) {
+  float v[NL];
+#pragma unroll
+  for (int c = 0; c < NL; ++c) v[c] = partial[(c < nchunks ? c : 0) * cs + p];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NL; ++c) s += (c < nchunks) ? v[c] : 0.f;
+  return s;
 }
 
 __global__ __launch_bounds__(256) void wgrad_final_batch_kernel(FinalJobs jobs) {
   // Slab positions are walked in the order the partial slabs are stored in (tile-major), so every slab row is read
   // as contiguous pieces (reading in weight-tensor order walks the slabs with a multi-KB stride per lane); sums are
   // formed in a fixed order (deterministic) and scattered to the native (Co, Ci, taps) weight layout.
-  __shared__ float seg[8][32];
+  __shared__ float seg[256];
   int jx = 0;  // binary search over the job start offsets (each probe is a dependent scalar load)
-  for (int step = 32; step >= 1; step >>= 1)
+  for (int step = 64; step >= 1; step >>= 1)
     if (jx + step < jobs.n && (int)blockIdx.x >= jobs.start[jx + step]) jx += step;
-  const n3d_final_job jb = jobs.j[jx];
+  const FinalJobD jb = jobs.j[jx];
+  const float* partial = seg_ptr(jobs.seg, jb.partial);
+  const float* pbias = jb.pbias != N3D_NO_OFF ? seg_ptr(jobs.seg, jb.pbias) : nullptr;
+  const bool has_dw = jb.dw != N3D_NO_OFF, has_db = jb.dbias != N3D_NO_OFF;
   const int lb = blockIdx.x - jobs.start[jx];
   const int T = jb.ci_t * jb.co_t;
   const int nslab = jb.ntiles * T;
@@ -1069,47 +1125,81 @@ __global__ __launch_bounds__(256) void wgrad_final_batch_kernel(FinalJobs jobs) 
   if (jb.nchunks <= N3D_FINAL_DIRECT_MAX) {
     // few chunks: 256 positions per workgroup, all rows of a position requested up front
     const int p = lb * 256 + threadIdx.x;
-    float v[N3D_FINAL_DIRECT_MAX];
     float s = 0.f;
     if (p < nslab) {
-      if (!jb.dw) return;
-#pragma unroll
-      for (int c = 0; c < N3D_FINAL_DIRECT_MAX; ++c) v[c] = jb.partial[(c < jb.nchunks ? c : 0) * cs + p];
-#pragma unroll
-      for (int c = 0; c < N3D_FINAL_DIRECT_MAX; ++c) s += (c < jb.nchunks) ? v[c] : 0.f;
-    } else if (p < nslab + nb && jb.dbias) {
-      for (int c = 0; c < jb.nchunks; ++c) s += jb.pbias[(int64_t)c * nb + (p - nslab)];
+      if (!has_dw) return;
+      s = jb.nchunks <= 4 ? final_direct<4>(partial, jb.nchunks, cs, p) : final_direct<N3D_FINAL_DIRECT_MAX>(partial, jb.nchunks, cs, p);
+    } else if (p < nslab + nb && has_db) {
+      for (int c = 0; c < jb.nchunks; ++c) s += pbias[(int64_t)c * nb + (p - nslab)];
     }
-    final_store(jb, p, nslab, nb, T, s);
+    final_store(jb, jobs.seg, p, nslab, nb, T, s);
     return;
   }
-  // many chunks: 32 positions x 8 chunk segments per workgroup, segments combined in LDS
-  const int oi = threadIdx.x & 31, sg = threadIdx.x >> 5;
-  const int p = lb * 32 + oi;
+  // many chunks: P positions x S chunk segments per workgroup, segments combined in LDS
+  const int pl = final_pos_log2(jb.nchunks), P = 1 << pl, S = 256 >> pl;
+  const int oi = threadIdx.x & (P - 1), sg = threadIdx.x >> pl;
+  const int p = lb * P + oi;
   float s = 0.f;
   if (p < nslab) {
-    if (jb.dw) {
+    if (has_dw) {
       // eight slab rows in flight per step (a rolled load -> add loop pays one memory latency per row)
       int c = sg;
-      for (; c + 56 < jb.nchunks; c += 64) {
+      for (; c + 7 * S < jb.nchunks; c += 8 * S) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = jb.partial[(c + 8 * u) * cs + p];
+        for (int u = 0; u < 8; ++u) v[u] = partial[(c + S * u) * cs + p];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += v[u];
       }
-      for (; c < jb.nchunks; c += 8) s += jb.partial[c * cs + p];
+      for (; c < jb.nchunks; c += S) s += partial[c * cs + p];
     }
-  } else if (p < nslab + nb && jb.dbias) {
-    for (int c = sg; c < jb.nchunks; c += 8) s += jb.pbias[(int64_t)c * nb + (p - nslab)];
+  } else if (p < nslab + nb && has_db) {
+    for (int c = sg; c < jb.nchunks; c += S) s += pbias[(int64_t)c * nb + (p - nslab)];
   }
-  seg[sg][oi] = s;
+  seg[sg * P + oi] = s;
   __syncthreads();
   if (sg == 0) {
     float tot = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) tot += seg[k][oi];
-    final_store(jb, p, nslab, nb, T, tot);
+    for (int k = 0; k < S; ++k) tot += seg[k * P + oi];
+    final_store(jb, jobs.seg, p, nslab, nb, T, tot);
+  }
+}
+
+// job grouping: the pointers of a group are sorted and cut into <= 8 segments of < 2 GB; a launch takes as many consecutive
+// jobs as the table holds and the segments cover (one job alone always fits: it has at most four pointers)
+struct SegTable {
+  SegBases sb; int n = 0;
+  static constexpr uintptr_t SPAN = ((uintptr_t)1 << 29) * sizeof(float);
+  bool build(uintptr_t* ptrs, int np) {
+    std::sort(ptrs, ptrs + np);
+    n = 0;
+    for (int i = 0; i < np; ++i) {
+      if (!ptrs[i]) continue;
+      if (n == 0 || ptrs[i] - sb.b[n - 1] >= SPAN - sizeof(float)) {
+        if (n == 8) return false;
+        sb.b[n++] = ptrs[i];
+      }
+    }
+    for (int i = n; i < 8; ++i) sb.b[i] = n ? sb.b[0] : 0;
+    return true;
+  }
+  uint32_t enc(const void* p) const {
+    if (!p) return N3D_NO_OFF;
+    const uintptr_t a = (uintptr_t)p;
+    int k = 0;
+    while (k + 1 < n && sb.b[k + 1] <= a) ++k;
+    return ((uint32_t)k << 29) | (uint32_t)((a - sb.b[k]) / sizeof(float));
+  }
+};
+
+template <int NP, typename Job, typename GetPtrs>
+static int seg_group(const Job* jobs, int remaining, int cap, SegTable& st, GetPtrs get) {
+  int n = remaining < cap ? remaining : cap;
+  std::vector<uintptr_t> ptrs;
+  for (;; n = (n + 1) / 2) {
+    ptrs.clear();
+    for (int i = 0; i < n; ++i) { const void* q[NP]; get(jobs[i], q); for (int k = 0; k < NP; ++k) ptrs.push_back((uintptr_t)q[k]); }
+    if (st.build(ptrs.data(), (int)ptrs.size()) || n == 1) return n;
   }
 }
 
@@ -1801,22 +1891,33 @@ int n3d_conv_pack_info(const n3d_conv_geom* g, int data_grad, int flags, int32_t
 
 int n3d_pack_batch(const n3d_pack_job* jobs, int njobs, void* stream) {
   N3D_CHECK_ARG(jobs && njobs >= 0, "pack_batch: bad args");
-  for (int base = 0; base < njobs; base += N3D_PACK_JOBS) {
-    const int n = njobs - base < N3D_PACK_JOBS ? njobs - base : N3D_PACK_JOBS;
+  for (int i = 0; i < njobs; ++i) {
+    const n3d_pack_job& q = jobs[i];
+    N3D_CHECK_ARG(q.w && q.dst && q.Co > 0 && q.Ci > 0 && q.Co < 65536 && q.Ci < 65536 && q.cdp >= 0 && q.cdp < 65536 && q.taps > 0 && q.taps < 256 &&
+                  q.layout >= 0 && q.layout <= 5 && ((uintptr_t)q.w & 3) == 0 && ((uintptr_t)q.dst & 3) == 0, "pack_batch: bad job");
+  }
+  int base = 0;
+  while (base < njobs) {
+    SegTable sp;
+    const int n = seg_group<2>(jobs + base, njobs - base, N3D_PACK_JOBS, sp, [](const n3d_pack_job& q, const void** o) { o[0] = q.w; o[1] = q.dst; });
     PackJobs pj;
+    pj.seg = sp.sb;
     int nblk = 0;
     for (int i = 0; i < n; ++i) {
-      pj.j[i] = jobs[base + i];
-      const n3d_pack_job& q = pj.j[i];
+      const n3d_pack_job& q = jobs[base + i];
+      PackJobD& d = pj.j[i];
+      d.w = sp.enc(q.w); d.dst = sp.enc(q.dst);
+      d.Co = (uint16_t)q.Co; d.Ci = (uint16_t)q.Ci; d.cdp = (uint16_t)q.cdp; d.taps = (uint8_t)q.taps;
+      d.mode = (uint8_t)(q.layout | (q.data_grad ? 16 : 0));
       const int Cs = q.data_grad ? q.Co : q.Ci, Cd = q.data_grad ? q.Ci : q.Co;
-      const int el = q.layout == 0 ? q.taps * Cs * q.cdp : (q.layout == 1 ? q.taps * Cs * Cd : 27 * q.Co * q.Co);
       pj.start[i] = nblk;
-      nblk += (int)cdiv(el, 256);
+      nblk += (int)cdiv(pack_tap_elems(q.layout, Cs, Cd, q.cdp, q.Co), 256);
     }
     for (int i = n; i < N3D_PACK_JOBS; ++i) { pj.j[i] = pj.j[0]; pj.start[i] = nblk; }
     pj.start[N3D_PACK_JOBS] = nblk;
     pj.n = n;
     if (nblk > 0) hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, pj);
+    base += n;
   }
   N3D_LAUNCH_CHECK();
   return N3D_OK;
@@ -1824,25 +1925,78 @@ int n3d_pack_batch(const n3d_pack_job* jobs, int njobs, void* stream) {
 
 int n3d_wgrad_finalize_batch(const n3d_final_job* jobs, int njobs, void* stream) {
   N3D_CHECK_ARG(jobs && njobs >= 0, "wgrad_finalize_batch: bad args");
-  for (int base = 0; base < njobs; base += N3D_FINAL_JOBS) {
-    const int n = njobs - base < N3D_FINAL_JOBS ? njobs - base : N3D_FINAL_JOBS;
+  for (int i = 0; i < njobs; ++i) {
+    const n3d_final_job& q = jobs[i];
+    if (q.nchunks == 0) continue;   // nothing deferred
+    N3D_CHECK_ARG(q.nchunks > 0 && q.ntiles > 0 && q.ntiles < 65536 && q.Co > 0 && q.Ci > 0 && q.Co < 65536 && q.Ci < 65536 && q.tci > 0 &&
+                  q.tci < 256 && q.tco > 0 && q.tco < 256 && q.ci_t > 0 && q.ci_t < 65536 && q.co_t > 0 && q.co_t < 65536 && q.taps > 0 &&
+                  q.taps < 256 && q.partial, "wgrad_finalize_batch: bad job");
+  }
+  int base = 0;
+  while (base < njobs) {
+    SegTable sp;
+    const int n = seg_group<4>(jobs + base, njobs - base, N3D_FINAL_JOBS, sp, [](const n3d_final_job& q, const void** o) {
+      o[0] = q.partial; o[1] = q.pbias; o[2] = q.dw; o[3] = q.dbias; });
     FinalJobs fj;
+    fj.seg = sp.sb;
     int nblk = 0;
     for (int i = 0; i < n; ++i) {
-      fj.j[i] = jobs[base + i];
-      const int el = fj.j[i].ntiles * fj.j[i].ci_t * fj.j[i].co_t + fj.j[i].tco * fj.j[i].co_t;
+      const n3d_final_job& q = jobs[base + i];
+      FinalJobD& d = fj.j[i];
+      d.partial = sp.enc(q.partial); d.pbias = sp.enc(q.pbias); d.dw = sp.enc(q.dw); d.dbias = sp.enc(q.dbias);
+      d.nchunks = q.nchunks; d.ntiles = (uint16_t)q.ntiles; d.Co = (uint16_t)q.Co; d.Ci = (uint16_t)q.Ci;
+      d.tci = (uint8_t)q.tci; d.tco = (uint8_t)q.tco; d.ci_t = (uint16_t)q.ci_t; d.co_t = (uint16_t)q.co_t; d.taps = (uint8_t)q.taps; d.pad_ = 0;
       fj.start[i] = nblk;
-      nblk += (int)cdiv(el, fj.j[i].nchunks <= N3D_FINAL_DIRECT_MAX ? 256 : 32);
+      nblk += q.nchunks > 0 ? final_job_blocks(q.ntiles * q.ci_t * q.co_t + q.tco * q.co_t, q.nchunks) : 0;
     }
     for (int i = n; i < N3D_FINAL_JOBS; ++i) { fj.j[i] = fj.j[0]; fj.start[i] = nblk; }
     fj.start[N3D_FINAL_JOBS] = nblk;
     fj.n = n;
     if (nblk > 0) hipLaunchKernelGGL(wgrad_final_batch_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, fj);
+    base += n;
   }
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
 
+
+// host-only self-test of the job-table pointer encoding (tests/test_host_cpu.py): scattered fake addresses are grouped and
+// every encoded pointer must decode to itself; returns the number of launches the 300 jobs would take, < 0 on a mismatch
+int n3d_selftest_job_tables(void) {
+  std::vector<n3d_final_job> jobs(300);
+  uint64_t r = 0x9e3779b97f4a7c15ull;
+  auto next = [&]() { r ^= r << 13; r ^= r >> 7; r ^= r << 17; return r; };
+  for (size_t i = 0; i < jobs.size(); ++i) {
+    n3d_final_job& q = jobs[i];
+    const uintptr_t region[4] = {0x700000000000ull, 0x700000000000ull, 0x7f0000000000ull, 0x7f0000000000ull};
+    uintptr_t a[4];
+    // the first 100 jobs live in two compact allocations, the next 100 are spread over 64 GB, the last 100 over 4 TB
+    for (int k = 0; k < 4; ++k) a[k] = region[k] + (next() % (i < 100 ? (1ull << 28) : (i < 200 ? (1ull << 36) : (1ull << 42)))) / 4 * 4;
+    q.partial = (const float*)a[0]; q.pbias = (i & 1) ? (const float*)a[1] : nullptr; q.dw = (float*)a[2]; q.dbias = (i & 2) ? (float*)a[3] : nullptr;
+  }
+  int launches = 0;
+  size_t base = 0;
+  while (base < jobs.size()) {
+    SegTable st;
+    const int n = seg_group<4>(jobs.data() + base, (int)(jobs.size() - base), N3D_FINAL_JOBS, st, [](const n3d_final_job& q, const void** o) {
+      o[0] = q.partial; o[1] = q.pbias; o[2] = q.dw; o[3] = q.dbias; });
+    if (n < 1) return -1;
+    for (int i = 0; i < n; ++i) {
+      const n3d_final_job& q = jobs[base + i];
+      const void* ptrs[4] = {q.partial, q.pbias, q.dw, q.dbias};
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t e = st.enc(ptrs[k]);
+        if (!ptrs[k]) { if (e != N3D_NO_OFF) return -2; continue; }
+        if (e == N3D_NO_OFF) return -3;
+        if (st.sb.b[e >> 29] + (uintptr_t)(e & 0x1fffffffu) * sizeof(float) != (uintptr_t)ptrs[k]) return -4;
+      }
+    }
+    base += n;
+    ++launches;
+  }
+  if (base != jobs.size()) return -5;
+  return launches;
+}
 
 int n3d_convT_bwd_weight(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, float* dw, float* dbias, int flags,
                          void* ws, size_t ws_bytes, n3d_final_job* deferred, void* stream) {

@@ -287,3 +287,11 @@ def test_dropout_gate_host_generator_is_uniform():
     assert u0.min() >= 0.0 and u0.max() < 1.0 and abs(u0.mean() - 0.5) < 0.02 and abs((u0 < 0.1).mean() - 0.1) < 0.02
     assert not np.array_equal(u0, u1)
     assert lib.n3d_dropout3d_uniform(C.c_uint64(77), 0, 5) == u0[5]
+
+
+def test_batch_job_tables_encode_scattered_addresses():
+    """n3d_pack_batch / n3d_wgrad_finalize_batch compact their job tables into the kernel arguments (segment + offset);
+    the host-side grouping must make progress and decode exactly for addresses scattered over terabytes."""
+    from nas_3d_unet_amd import _lib
+    launches = _lib.load().n3d_selftest_job_tables()
+    assert 4 <= launches <= 300, launches
