@@ -996,58 +996,126 @@ __global__ void channel_sum_final_kernel(const float* __restrict__ partial, int 
 // layouts: 0 generic [tap][cs][cdp]; 1 gemm16 [tap][cs/16][kk][cd][j]; 2 vox64 [tap][cd][cs] (flipped for data grad);
 //          3 vox_up (as 2, never flipped); 4 / 5 = 2 / 3 in bfloat16
 // ------------------------------------------------------------------------------------------------
-#define N3D_PACK_JOBS 192
-#define N3D_FINAL_JOBS 96
+#define N3D_PACK_JOBS 160
+#define N3D_FINAL_JOBS 80
+#define N3D_JOB_UNITS 512      // entries of the workgroup -> job map
+#define N3D_PACK_GSHIFT 2      // a map entry covers 4 workgroups of the pack kernel ...
+#define N3D_FINAL_GSHIFT 4     // ... and 16 of the reduction kernel (a job's workgroup count is rounded up to whole entries)
 #define N3D_NO_OFF 0xffffffffu
-struct PackJobD { uint32_t w, dst; uint16_t Co, Ci, cdp; uint8_t taps, mode; };   // mode = layout | data_grad << 4
+struct PackJobD { uint32_t w, dst, start; uint16_t Co, Ci, cdp; uint8_t taps, mode; };   // mode = layout | data_grad << 4
+struct FinalJobD { uint32_t partial, pbias, dw, dbias, start; int32_t nchunks; uint16_t ntiles, Co, Ci, ci_t, co_t; uint8_t tci, tco, taps, pad_; };
 struct SegBases { uintptr_t b[8]; };
-__device__ __forceinline__ float* seg_ptr(const SegBases& sb, uint32_t off) { return reinterpret_cast<float*>(sb.b[off >> 29]) + (off & 0x1fffffffu); }
-struct PackJobs { SegBases seg; PackJobD j[N3D_PACK_JOBS]; int start[N3D_PACK_JOBS + 1]; int n; };
-struct FinalJobD { uint32_t partial, pbias, dw, dbias; int32_t nchunks; uint16_t ntiles, Co, Ci, ci_t, co_t; uint8_t tci, tco, taps, pad_; };
-struct FinalJobs { SegBases seg; FinalJobD j[N3D_FINAL_JOBS]; int start[N3D_FINAL_JOBS + 1]; int n; };
+// The kernel-argument block is slow memory for anything but the one scalar fetch every kernel starts with: each DEPENDENT
+// read is a ~1-2 us round trip (a binary search over start offsets cost 8 of them: 20 us for a 4 us kernel) and vector
+// reads of it are slower still (every wave crossing to host-visible memory: 43 us).  So a workgroup makes exactly two scalar
+// trips: (1) the eight bases and its entry of the workgroup -> job byte map, (2) its job record.  The empty asm statements
+// pin the loads where they are written (the compiler otherwise sinks them behind branches and turns the register selects
+// back into indexed loads = more trips).
+// the bases stay eight scalar VALUES (macro-declared locals passed by value): kept in a private struct or array, the
+// compiler turns the select chain into an indexed load and moves the array to LDS
+__device__ __forceinline__ float* seg_sel(uint32_t off, uint64_t b0, uint64_t b1, uint64_t b2, uint64_t b3, uint64_t b4, uint64_t b5, uint64_t b6,
+                                          uint64_t b7) {
+  const uint32_t k = off >> 29;
+  uint64_t b = b0;
+  b = k == 1 ? b1 : b; b = k == 2 ? b2 : b; b = k == 3 ? b3 : b; b = k == 4 ? b4 : b;
+  b = k == 5 ? b5 : b; b = k == 6 ? b6 : b; b = k == 7 ? b7 : b;
+  return reinterpret_cast<float*>(b) + (off & 0x1fffffffu);
+}
+// trip 1: the eight bases (sb0..sb7) and the map entry of this workgroup (-> jx), one wait for all of them
+#define N3D_FETCH_HEAD(jobs, GSHIFT)                                                                                              \
+  int u_ = (int)blockIdx.x >> (GSHIFT);                                                                                           \
+  u_ = u_ < N3D_JOB_UNITS ? u_ : N3D_JOB_UNITS - 1; /* (a single job larger than the map: every entry names it) */                \
+  uint32_t w_ = (jobs).unit[u_ >> 2];                                                                                             \
+  uint64_t sb0 = (jobs).seg.b[0], sb1 = (jobs).seg.b[1], sb2 = (jobs).seg.b[2], sb3 = (jobs).seg.b[3], sb4 = (jobs).seg.b[4],     \
+           sb5 = (jobs).seg.b[5], sb6 = (jobs).seg.b[6], sb7 = (jobs).seg.b[7];                                                   \
+  asm volatile("" : "+s"(w_), "+s"(sb0), "+s"(sb1), "+s"(sb2), "+s"(sb3), "+s"(sb4), "+s"(sb5), "+s"(sb6), "+s"(sb7));            \
+  const int jx = (w_ >> ((u_ & 3) * 8)) & 255
+#define N3D_SEG(off) seg_sel(off, sb0, sb1, sb2, sb3, sb4, sb5, sb6, sb7)
+template <typename J>
+__device__ __forceinline__ J fetch_job(const J& src) {
+  struct Words { uint32_t w[sizeof(J) / 4]; };
+  static_assert(sizeof(J) % 4 == 0, "job records are whole dwords");
+  Words t = *reinterpret_cast<const Words*>(&src);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(J) / 4; ++i) asm volatile("" : "+s"(t.w[i]));
+  return __builtin_bit_cast(J, t);
+}
+struct PackJobs { SegBases seg; uint32_t unit[N3D_JOB_UNITS / 4]; PackJobD j[N3D_PACK_JOBS]; };
+struct FinalJobs { SegBases seg; uint32_t unit[N3D_JOB_UNITS / 4]; FinalJobD j[N3D_FINAL_JOBS]; };
 static_assert(sizeof(PackJobs) <= 4000 && sizeof(FinalJobs) <= 4000, "job tables must fit the kernel argument block");
+static_assert(N3D_PACK_JOBS <= 256 && N3D_FINAL_JOBS <= 256, "job ids are bytes");
 
 // elements of one tap of the packed form (the tap is the slowest index of every layout)
 __host__ __device__ inline int pack_tap_elems(int layout, int Cs, int Cd, int cdp, int Co) {
   return layout == 0 ? Cs * cdp : (layout == 1 ? Cs * Cd : Co * Co);
 }
 
-template <int TAPS>
-__device__ __forceinline__ void pack_taps(const float* __restrict__ src, float* __restrict__ dst, const int taps, const int E, const int r,
-                                          const bool flip, const bool bf16, const bool live) {
-  // the taps of one (source channel, destination channel) pair are `taps` consecutive floats of the native weight:
-  // a lane reads its whole run (two cache lines, fully used) and writes one element per tap, consecutive lanes to
-  // consecutive addresses.  (Walking the packed form element by element reads 4 bytes per cache line and tap.)
-  float v[TAPS > 0 ? TAPS : 1];
-  if (TAPS > 0) {
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) v[t] = live ? src[flip ? TAPS - 1 - t : t] : 0.f;
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      if (bf16) st1(reinterpret_cast<bf16_t*>(dst) + (int64_t)t * E + r, v[t]);
-      else dst[(int64_t)t * E + r] = v[t];
-    }
-  } else {
-    for (int t = 0; t < taps; ++t) {
-      const float x = live ? src[flip ? taps - 1 - t : t] : 0.f;
-      if (bf16) st1(reinterpret_cast<bf16_t*>(dst) + (int64_t)t * E + r, x);
-      else dst[(int64_t)t * E + r] = x;
-    }
-  }
+// destination channels of the packed form (layout 0 pads them to cdp)
+__host__ __device__ inline int pack_dst_channels(int layout, int Cd, int cdp) { return layout == 0 ? cdp : Cd; }
+// workgroups of one pack job: 3x3x3 weights go by 16 x 16 (source, destination) channel tiles, others by 256 elements of a tap
+__host__ __device__ inline int pack_job_blocks(int layout, int Cs, int Cd, int cdp, int Co, int taps) {
+  if (taps == 27) return ((Cs + 15) / 16) * ((pack_dst_channels(layout, Cd, cdp) + 15) / 16);
+  return (pack_tap_elems(layout, Cs, Cd, cdp, Co) + 255) / 256;
 }
+#define N3D_PACK_PITCH 433   // 16 input channels x 27 taps + 1: odd, so that lanes walking output channels spread over the LDS banks
 
 __global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
-  // flattened grid: start[k] = first workgroup of job k (only the workgroups a job needs are launched);
-  // binary search over the offsets (each probe is a dependent scalar load)
-  int jx = 0;
-  for (int step = 128; step >= 1; step >>= 1)
-    if (jx + step < jobs.n && (int)blockIdx.x >= jobs.start[jx + step]) jx += step;
-  const PackJobD jb = jobs.j[jx];
+  // flattened grid: the byte map names the job of a workgroup, the job record its first workgroup
+  __shared__ float tile[16 * N3D_PACK_PITCH];
+  N3D_FETCH_HEAD(jobs, N3D_PACK_GSHIFT);
+  const PackJobD jb = fetch_job(jobs.j[jx]);
+  const int lb = (int)blockIdx.x - (int)jb.start;
   const int Co = jb.Co, Ci = jb.Ci, taps = jb.taps, layout = jb.mode & 15;
   const bool data_grad = (jb.mode >> 4) != 0;
   const int Cs = data_grad ? Co : Ci, Cd = data_grad ? Ci : Co;
   const int E = pack_tap_elems(layout, Cs, Cd, jb.cdp, Co);
-  const int r = (blockIdx.x - jobs.start[jx]) * 256 + threadIdx.x;
+  const float* __restrict__ w = N3D_SEG(jb.w);
+  float* __restrict__ dst = N3D_SEG(jb.dst);
+  const bool bf16 = layout >= 4;
+  const int t = threadIdx.x;
+  if (taps == 27) {
+    // The native weight is (Co, Ci, 27): for one output channel, 16 input channels are 432 consecutive floats.  A workgroup
+    // takes a 16 x 16 channel tile: the 16 runs are read as they lie (coalesced) into LDS, then every thread writes the 27
+    // taps of one (source, destination) pair, consecutive lanes to consecutive packed addresses.  A train step packs 3.5 M
+    // weights twice (forward and data-gradient form): 28 MB moved in 14 us inside the step's graph, of which 2 us are the
+    // two argument-block trips (measured with the loads / the stores compiled out: 9 / 8 us).
+    const int CdP = pack_dst_channels(layout, Cd, jb.cdp);
+    const int tiles_d = (CdP + 15) / 16;
+    if (lb >= ((Cs + 15) / 16) * tiles_d) return;
+    const int cs0 = (lb / tiles_d) * 16, cd0 = (lb % tiles_d) * 16;
+    const int co0 = data_grad ? cs0 : cd0, ci0 = data_grad ? cd0 : cs0;
+#pragma unroll
+    for (int i = 0; i < 27; ++i) {
+      const int e = i * 256 + t;
+      const int co_l = e / 432, wq = e - co_l * 432, ci_l = wq / 27;
+      const bool ok = co0 + co_l < Co && ci0 + ci_l < Ci;
+      tile[co_l * N3D_PACK_PITCH + wq] = ok ? w[((int64_t)(co0 + co_l) * Ci + ci0) * 27 + wq] : 0.f;
+    }
+    __syncthreads();
+    int cs_l, cd_l;
+    if (layout == 0) { cd_l = t & 15; cs_l = t >> 4; }
+    else if (layout == 1) { cd_l = (t >> 2) & 15; cs_l = (t >> 6) * 4 + (t & 3); }
+    else { cs_l = t & 15; cd_l = t >> 4; }
+    const int cs = cs0 + cs_l, cd = cd0 + cd_l;
+    if (cs >= Cs || cd >= CdP) return;
+    int r;
+    if (layout == 0) r = cs * jb.cdp + cd;
+    else if (layout == 1) r = (((cs >> 4) * 4 + ((cs >> 2) & 3)) * Cd + cd) * 4 + (cs & 3);
+    else r = cd * Co + cs;
+    const bool live = cd < Cd;
+    const float* src = tile + (data_grad ? cs_l : cd_l) * N3D_PACK_PITCH + (data_grad ? cd_l : cs_l) * 27;
+    // layouts 2 / 4: the data gradient is the same kernel run with the taps mirrored
+    const bool flip = data_grad && (layout == 2 || layout == 4);
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const float v = live ? src[flip ? 26 - k : k] : 0.f;
+      if (bf16) st1(reinterpret_cast<bf16_t*>(dst) + (int64_t)k * E + r, v);
+      else dst[(int64_t)k * E + r] = v;
+    }
+    return;
+  }
+  // other kernel sizes (1x1x1 above all): one thread per element of a tap
+  const int r = lb * 256 + t;
   if (r >= E) return;
   int cs, cd;
   if (layout == 0) {
@@ -1061,36 +1129,44 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
   }
   const bool live = cd < Cd;
   const int co = data_grad ? cs : cd, ci = data_grad ? cd : cs;
-  const float* src = seg_ptr(jobs.seg, jb.w) + ((int64_t)co * Ci + ci) * taps;
-  float* dst = seg_ptr(jobs.seg, jb.dst);
-  // layouts 2 / 4: the data gradient is the same kernel run with the taps mirrored
+  const float* src = w + ((int64_t)co * Ci + ci) * taps;
   const bool flip = data_grad && (layout == 2 || layout == 4);
-  if (taps == 27) pack_taps<27>(src, dst, taps, E, r, flip, layout >= 4, live);
-  else if (taps == 1) pack_taps<1>(src, dst, taps, E, r, false, layout >= 4, live);
-  else pack_taps<0>(src, dst, taps, E, r, flip, layout >= 4, live);
+  for (int k = 0; k < taps; ++k) {
+    const float v = live ? src[flip ? taps - 1 - k : k] : 0.f;
+    if (bf16) st1(reinterpret_cast<bf16_t*>(dst) + (int64_t)k * E + r, v);
+    else dst[(int64_t)k * E + r] = v;
+  }
 }
 
 #define N3D_FINAL_DIRECT_MAX 16  // jobs with at most this many chunks: one thread sums all chunks of its slab position
 
 // many-chunk jobs: a workgroup covers 2^k slab positions x 256 / 2^k chunk segments; the more chunks, the more segments,
 // so that no thread walks more than ~32 rows (a head gradient at 128^3 has 2048 rows of 36 floats: with a fixed
-// 32 x 8 split two workgroups walked 256 rows each, one memory round trip per eight rows)
-__host__ __device__ inline int final_pos_log2(int nchunks) { return nchunks <= 128 ? 5 : (nchunks <= 512 ? 3 : 2); }
-__host__ __device__ inline int final_job_blocks(int el, int nchunks) {
+// 32 x 8 split two workgroups walked 256 rows each, one memory round trip per eight rows).  Measured on the 75 jobs of
+// a 64^3 train step (32 MB of partial slabs): 29 us in two launches before, 21 us in one now.
+__host__ __device__ inline int final_pos_log2(int nchunks) { return nchunks <= 64 ? 6 : (nchunks <= 256 ? 4 : (nchunks <= 1024 ? 3 : 2)); }
+// few-chunk jobs whose tile fits a workgroup go by (ci tile, co tile): all taps of the tile, transposed through LDS
+#define N3D_FINAL_TILE_FLOATS 7168   // >= co_t * (ci_t * taps + 1) for ci_t * co_t <= 256, taps <= 27
+__host__ __device__ inline bool final_tile_path(int nchunks, int ci_t, int co_t, int taps) {
+  return nchunks <= 4 && ci_t * co_t <= 256 && taps <= 27;
+}
+__host__ __device__ inline int final_job_blocks(int nchunks, int ntiles, int tci, int tco, int ci_t, int co_t, int taps) {
+  if (final_tile_path(nchunks, ci_t, co_t, taps)) return tci * tco;
+  const int el = ntiles * ci_t * co_t + tco * co_t;
   return nchunks <= N3D_FINAL_DIRECT_MAX ? (el + 255) / 256 : (el + (1 << final_pos_log2(nchunks)) - 1) >> final_pos_log2(nchunks);
 }
 
-__device__ __forceinline__ void final_store(const FinalJobD& jb, const SegBases& sb, const int p, const int nslab, const int nb, const int T, const float tot) {
+__device__ __forceinline__ void final_store(const FinalJobD& jb, float* dwp, float* dbp, const int p, const int nslab, const int nb, const int T, const float tot) {
   if (p < nslab) {
     if (jb.dw != N3D_NO_OFF) {
       const int tile = p / T, q = p - tile * T;
       const int cot = tile % jb.tco, cit = (tile / jb.tco) % jb.tci, tap = tile / (jb.tco * jb.tci);
       const int ci = cit * jb.ci_t + q / jb.co_t, co = cot * jb.co_t + q % jb.co_t;
-      if (ci < jb.Ci && co < jb.Co) seg_ptr(sb, jb.dw)[((int64_t)co * jb.Ci + ci) * jb.taps + tap] = tot;
+      if (ci < jb.Ci && co < jb.Co) dwp[((int64_t)co * jb.Ci + ci) * jb.taps + tap] = tot;
     }
   } else if (p < nslab + nb && jb.dbias != N3D_NO_OFF) {
     const int co = p - nslab;
-    if (co < jb.Co) seg_ptr(sb, jb.dbias)[co] = tot;
+    if (co < jb.Co) dbp[co] = tot;
   }
 }
 
@@ -1109,21 +1185,72 @@ __global__ __launch_bounds__(256) void wgrad_final_batch_kernel(FinalJobs jobs) 
   // Slab positions are walked in the order the partial slabs are stored in (tile-major), so every slab row is read
   // as contiguous pieces (reading in weight-tensor order walks the slabs with a multi-KB stride per lane); sums are
   // formed in a fixed order (deterministic) and scattered to the native (Co, Ci, taps) weight layout.
-  __shared__ float seg[256];
-  int jx = 0;  // binary search over the job start offsets (each probe is a dependent scalar load)
-  for (int step = 64; step >= 1; step >>= 1)
-    if (jx + step < jobs.n && (int)blockIdx.x >= jobs.start[jx + step]) jx += step;
-  const FinalJobD jb = jobs.j[jx];
-  const float* partial = seg_ptr(jobs.seg, jb.partial);
-  const float* pbias = jb.pbias != N3D_NO_OFF ? seg_ptr(jobs.seg, jb.pbias) : nullptr;
+  __shared__ float tile[N3D_FINAL_TILE_FLOATS];
+  float* seg = tile;
+  N3D_FETCH_HEAD(jobs, N3D_FINAL_GSHIFT);
+  const FinalJobD jb = fetch_job(jobs.j[jx]);
+  const int first = (int)jb.start;
+  const float* partial = N3D_SEG(jb.partial);
+  const float* pbias = jb.pbias != N3D_NO_OFF ? N3D_SEG(jb.pbias) : nullptr;
+  float* dwp = N3D_SEG(jb.dw);
+  float* dbp = N3D_SEG(jb.dbias);
   const bool has_dw = jb.dw != N3D_NO_OFF, has_db = jb.dbias != N3D_NO_OFF;
-  const int lb = blockIdx.x - jobs.start[jx];
+  const int lb = blockIdx.x - first;
   const int T = jb.ci_t * jb.co_t;
   const int nslab = jb.ntiles * T;
   const int nb = jb.tco * jb.co_t;
   const int64_t cs = nslab;
+  if (final_tile_path(jb.nchunks, jb.ci_t, jb.co_t, jb.taps)) {
+    // At most four chunks, tile <= 256 positions: the workgroup owns one (ci tile, co tile) with ALL its taps.  Thread q sums its slab
+    // position of every tap (each tap's tile is a contiguous piece of every slab row) into LDS laid out as the native weight
+    // wants it, [co][ci][tap]; the tile then leaves as co_t runs of ci_t * taps consecutive floats.  (Scattering every sum
+    // straight to (co, ci, tap) writes 4 bytes per cache line and the 27 taps of a line come from 27 different workgroups.)
+    if (lb >= jb.tci * jb.tco) return;
+    const int cit = lb / jb.tco, cot = lb - cit * jb.tco;
+    const int q = threadIdx.x, taps = jb.taps, run = jb.ci_t * taps, pitch = run | 1;   // odd pitch: co_l-consecutive lanes spread over the banks
+    if (has_dw) {
+      if (q < T) {
+        const int ci_l = q / jb.co_t, co_l = q - ci_l * jb.co_t;
+        float* trow = tile + co_l * pitch + ci_l * taps;
+        const float* pq = partial + (int64_t)(cit * jb.tco + cot) * T + q;
+        const int64_t tap_stride = (int64_t)jb.tci * jb.tco * T;
+        if (taps == 27) {
+          // every row of every tap requested before the first sum: one memory round trip per thread
+          float v[27][4];
+#pragma unroll
+          for (int k = 0; k < 27; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[k][c] = pq[k * tap_stride + (c < jb.nchunks ? c : 0) * cs];
+#pragma unroll
+          for (int k = 0; k < 27; ++k) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a += (c < jb.nchunks) ? v[k][c] : 0.f;
+            trow[k] = a;
+          }
+        } else {
+#pragma unroll 3
+          for (int k = 0; k < taps; ++k) trow[k] = final_direct<4>(pq + k * tap_stride, jb.nchunks, cs, 0);
+        }
+      }
+      __syncthreads();
+      const int total = jb.co_t * run;
+      for (int e = q; e < total; e += 256) {
+        const int co_l = e / run, wq = e - co_l * run, ci_l = wq / taps;
+        const int co = cot * jb.co_t + co_l, ci = cit * jb.ci_t + ci_l;
+        if (co < jb.Co && ci < jb.Ci) dwp[((int64_t)co * jb.Ci + cit * jb.ci_t) * taps + wq] = tile[co_l * pitch + wq];
+      }
+    }
+    if (has_db && cit == 0 && q < jb.co_t) {
+      const int co = cot * jb.co_t + q;
+      float sb_ = 0.f;
+      for (int c = 0; c < jb.nchunks; ++c) sb_ += pbias[(int64_t)c * nb + co];
+      if (co < jb.Co) dbp[co] = sb_;
+    }
+    return;
+  }
   if (jb.nchunks <= N3D_FINAL_DIRECT_MAX) {
-    // few chunks: 256 positions per workgroup, all rows of a position requested up front
+    // few chunks, large tiles (1x1x1 convs: the tile is the whole matrix): 256 positions per workgroup, all rows of a position requested up front
     const int p = lb * 256 + threadIdx.x;
     float s = 0.f;
     if (p < nslab) {
@@ -1132,7 +1259,7 @@ __global__ __launch_bounds__(256) void wgrad_final_batch_kernel(FinalJobs jobs) 
     } else if (p < nslab + nb && has_db) {
       for (int c = 0; c < jb.nchunks; ++c) s += pbias[(int64_t)c * nb + (p - nslab)];
     }
-    final_store(jb, jobs.seg, p, nslab, nb, T, s);
+    final_store(jb, dwp, dbp, p, nslab, nb, T, s);
     return;
   }
   // many chunks: P positions x S chunk segments per workgroup, segments combined in LDS
@@ -1161,7 +1288,7 @@ __global__ __launch_bounds__(256) void wgrad_final_batch_kernel(FinalJobs jobs) 
   if (sg == 0) {
     float tot = 0.f;
     for (int k = 0; k < S; ++k) tot += seg[k * P + oi];
-    final_store(jb, jobs.seg, p, nslab, nb, T, tot);
+    final_store(jb, dwp, dbp, p, nslab, nb, T, tot);
   }
 }
 
@@ -1201,6 +1328,25 @@ static int seg_group(const Job* jobs, int remaining, int cap, SegTable& st, GetP
     for (int i = 0; i < n; ++i) { const void* q[NP]; get(jobs[i], q); for (int k = 0; k < NP; ++k) ptrs.push_back((uintptr_t)q[k]); }
     if (st.build(ptrs.data(), (int)ptrs.size()) || n == 1) return n;
   }
+}
+
+// workgroup -> job byte map: job i takes blocks[i] workgroups rounded up to whole map entries; returns how many of the n
+// jobs fit the map (>= 1: a single job larger than the map is named by every entry), fills start[] and *nblk
+static int unit_map(const int* blocks, int n, int gshift, uint32_t* unit, uint32_t* start, int* nblk) {
+  const int G = 1 << gshift;
+  uint8_t* u8 = reinterpret_cast<uint8_t*>(unit);
+  memset(u8, 0, N3D_JOB_UNITS);
+  int units = 0, m = 0;
+  for (; m < n; ++m) {
+    const int uj = (blocks[m] + G - 1) >> gshift;
+    if (units + uj > N3D_JOB_UNITS) break;
+    start[m] = (uint32_t)units << gshift;
+    for (int k = 0; k < uj; ++k) u8[units + k] = (uint8_t)m;
+    units += uj;
+  }
+  if (m == 0) { start[0] = 0; *nblk = blocks[0]; return 1; }
+  *nblk = units << gshift;
+  return m;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1899,23 +2045,25 @@ int n3d_pack_batch(const n3d_pack_job* jobs, int njobs, void* stream) {
   int base = 0;
   while (base < njobs) {
     SegTable sp;
-    const int n = seg_group<2>(jobs + base, njobs - base, N3D_PACK_JOBS, sp, [](const n3d_pack_job& q, const void** o) { o[0] = q.w; o[1] = q.dst; });
+    int n = seg_group<2>(jobs + base, njobs - base, N3D_PACK_JOBS, sp, [](const n3d_pack_job& q, const void** o) { o[0] = q.w; o[1] = q.dst; });
     PackJobs pj;
     pj.seg = sp.sb;
-    int nblk = 0;
+    int blocks[N3D_PACK_JOBS], nblk = 0;
+    uint32_t start[N3D_PACK_JOBS];
+    for (int i = 0; i < n; ++i) {
+      const n3d_pack_job& q = jobs[base + i];
+      const int Cs = q.data_grad ? q.Co : q.Ci, Cd = q.data_grad ? q.Ci : q.Co;
+      blocks[i] = pack_job_blocks(q.layout, Cs, Cd, q.cdp, q.Co, q.taps);
+    }
+    n = unit_map(blocks, n, N3D_PACK_GSHIFT, pj.unit, start, &nblk);
     for (int i = 0; i < n; ++i) {
       const n3d_pack_job& q = jobs[base + i];
       PackJobD& d = pj.j[i];
-      d.w = sp.enc(q.w); d.dst = sp.enc(q.dst);
+      d.w = sp.enc(q.w); d.dst = sp.enc(q.dst); d.start = start[i];
       d.Co = (uint16_t)q.Co; d.Ci = (uint16_t)q.Ci; d.cdp = (uint16_t)q.cdp; d.taps = (uint8_t)q.taps;
       d.mode = (uint8_t)(q.layout | (q.data_grad ? 16 : 0));
-      const int Cs = q.data_grad ? q.Co : q.Ci, Cd = q.data_grad ? q.Ci : q.Co;
-      pj.start[i] = nblk;
-      nblk += (int)cdiv(pack_tap_elems(q.layout, Cs, Cd, q.cdp, q.Co), 256);
     }
-    for (int i = n; i < N3D_PACK_JOBS; ++i) { pj.j[i] = pj.j[0]; pj.start[i] = nblk; }
-    pj.start[N3D_PACK_JOBS] = nblk;
-    pj.n = n;
+    for (int i = n; i < N3D_PACK_JOBS; ++i) pj.j[i] = pj.j[0];
     if (nblk > 0) hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, pj);
     base += n;
   }
@@ -1930,35 +2078,36 @@ int n3d_wgrad_finalize_batch(const n3d_final_job* jobs, int njobs, void* stream)
     if (q.nchunks == 0) continue;   // nothing deferred
     N3D_CHECK_ARG(q.nchunks > 0 && q.ntiles > 0 && q.ntiles < 65536 && q.Co > 0 && q.Ci > 0 && q.Co < 65536 && q.Ci < 65536 && q.tci > 0 &&
                   q.tci < 256 && q.tco > 0 && q.tco < 256 && q.ci_t > 0 && q.ci_t < 65536 && q.co_t > 0 && q.co_t < 65536 && q.taps > 0 &&
-                  q.taps < 256 && q.partial, "wgrad_finalize_batch: bad job");
+                  q.taps < 256 && q.ntiles == q.taps * q.tci * q.tco && q.partial, "wgrad_finalize_batch: bad job");
   }
   int base = 0;
   while (base < njobs) {
     SegTable sp;
-    const int n = seg_group<4>(jobs + base, njobs - base, N3D_FINAL_JOBS, sp, [](const n3d_final_job& q, const void** o) {
+    int n = seg_group<4>(jobs + base, njobs - base, N3D_FINAL_JOBS, sp, [](const n3d_final_job& q, const void** o) {
       o[0] = q.partial; o[1] = q.pbias; o[2] = q.dw; o[3] = q.dbias; });
     FinalJobs fj;
     fj.seg = sp.sb;
-    int nblk = 0;
+    int blocks[N3D_FINAL_JOBS], nblk = 0;
+    uint32_t start[N3D_FINAL_JOBS];
+    for (int i = 0; i < n; ++i) {
+      const n3d_final_job& q = jobs[base + i];
+      blocks[i] = q.nchunks > 0 ? final_job_blocks(q.nchunks, q.ntiles, q.tci, q.tco, q.ci_t, q.co_t, q.taps) : 0;
+    }
+    n = unit_map(blocks, n, N3D_FINAL_GSHIFT, fj.unit, start, &nblk);
     for (int i = 0; i < n; ++i) {
       const n3d_final_job& q = jobs[base + i];
       FinalJobD& d = fj.j[i];
-      d.partial = sp.enc(q.partial); d.pbias = sp.enc(q.pbias); d.dw = sp.enc(q.dw); d.dbias = sp.enc(q.dbias);
+      d.partial = sp.enc(q.partial); d.pbias = sp.enc(q.pbias); d.dw = sp.enc(q.dw); d.dbias = sp.enc(q.dbias); d.start = start[i];
       d.nchunks = q.nchunks; d.ntiles = (uint16_t)q.ntiles; d.Co = (uint16_t)q.Co; d.Ci = (uint16_t)q.Ci;
       d.tci = (uint8_t)q.tci; d.tco = (uint8_t)q.tco; d.ci_t = (uint16_t)q.ci_t; d.co_t = (uint16_t)q.co_t; d.taps = (uint8_t)q.taps; d.pad_ = 0;
-      fj.start[i] = nblk;
-      nblk += q.nchunks > 0 ? final_job_blocks(q.ntiles * q.ci_t * q.co_t + q.tco * q.co_t, q.nchunks) : 0;
     }
-    for (int i = n; i < N3D_FINAL_JOBS; ++i) { fj.j[i] = fj.j[0]; fj.start[i] = nblk; }
-    fj.start[N3D_FINAL_JOBS] = nblk;
-    fj.n = n;
+    for (int i = n; i < N3D_FINAL_JOBS; ++i) fj.j[i] = fj.j[0];
     if (nblk > 0) hipLaunchKernelGGL(wgrad_final_batch_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, fj);
     base += n;
   }
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
-
 
 // host-only self-test of the job-table pointer encoding (tests/test_host_cpu.py): scattered fake addresses are grouped and
 // every encoded pointer must decode to itself; returns the number of launches the 300 jobs would take, < 0 on a mismatch

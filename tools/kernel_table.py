@@ -170,6 +170,20 @@ def describe(name, args):
             return (name, h.B, h.N, h.Ci, h.Co, h.x_dtype), 6 * h.B * h.N * h.Ci * h.Co, 2 * xb + pb
         if name == "n3d_adam_step":
             return (name, v[4]), 0, 7 * 4 * v[4]
+        if name == "n3d_pack_batch":      # reads every weight once per job, writes its packed form (layout 0 pads the channels)
+            jobs, n, byts = args[0], v[1], 0
+            for i in range(n):
+                j = jobs[i]
+                cs, cd = (j.Co, j.Ci) if j.data_grad else (j.Ci, j.Co)
+                el = j.taps * (cs * j.cdp if j.layout == 0 else (cs * cd if j.layout == 1 else j.Co * j.Co))
+                byts += 4 * j.Co * j.Ci * j.taps + (2 if j.layout >= 4 else 4) * el
+            return (name, n), 0, byts
+        if name == "n3d_wgrad_finalize_batch":   # reads every partial slab, writes each gradient once
+            jobs, n, byts = args[0], v[1], 0
+            for i in range(n):
+                j = jobs[i]
+                byts += 4 * (j.nchunks * (j.ntiles * j.ci_t * j.co_t + j.tco * j.co_t) + j.Co * j.Ci * j.taps + j.Co)
+            return (name, n), 0, byts
     except Exception:
         pass
     scal = tuple(x for x in v if isinstance(x, (int, float)) and not (isinstance(x, int) and x > (1 << 32)))
@@ -238,7 +252,7 @@ def table(run_step, device, top=5, candidates=14):
     ranked = sorted(groups.items(), key=lambda kv: -kv[1]["coarse_us"])[:candidates]
     rows = []
     for sig, gr in ranked:
-        if gr["name"] in ("n3d_pack_batch", "n3d_wgrad_finalize_batch") or gr["name"].startswith("n3d_comm"):
+        if gr["name"].startswith("n3d_comm"):
             us = gr["coarse_us"] / gr["calls"]
         else:
             try:
