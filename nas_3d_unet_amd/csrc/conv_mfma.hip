@@ -1733,6 +1733,167 @@ int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const flo
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// tile16: the gemm16 problem with MANY voxels -- 3x3x3 stride-1 conv (dilation 1 / 2) with 16 -> 16 channels on >= 16k
+// voxels (the C = 16 level of 128^3 patches: 2 x 32^3).  gemm16 gathers its A operand from global memory once per tap
+// (27 x 64 bytes per voxel through L1/L2: 21 % of the fp32 MFMA peak at M = 65536); here a workgroup stages the halo tile
+// of its 2 x 4 x 16 output voxels in LDS once (LDS-DMA, 64-byte voxel records) and every tap is one ds_read_b128 per
+// 16-voxel row: lane (m = lane&15, kk = lane>>4) reads channels 4kk..4kk+3 of voxel m = the A operand of four
+// v_mfma_f32_16x16x4_f32 steps, 1 KiB contiguous per wave-instruction (conflict-free).  The B operand (27 float4 per
+// lane, the gemm16 packed layout Wp[tap][kk][cd][j]) lives in registers for the whole tile; an input gate scales it
+// once per workgroup instead of the A values.  Same arguments, same epilogue (bias, ReLU mask, output gate,
+// accumulate), same statistics rows (one per 128 voxels) as the gemm16 plan it replaces.
+//   DG: data gradient = the same conv with mirrored taps (weights packed transposed by the pack kernel).
+// ------------------------------------------------------------------------------------------------
+template <int DIL, bool DG>
+__global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const void* zero_page, int tiles) {
+  constexpr int TD = 2, TH = 4, TW = 16;
+  constexpr int LD = TD + 2 * DIL, LH = TH + 2 * DIL, LW = TW + 2 * DIL, NV = LD * LH * LW;
+  constexpr int NP = NV * 4, NIT = (NP + 255) / 256;   // float4 pieces of the halo tile, DMA instructions per thread
+  extern __shared__ __attribute__((aligned(16))) float4 t16[];   // [NIT * 256] float4: voxel-major, 4 pieces per voxel
+  __shared__ double red[4 * 16 * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, kk = lane >> 4;
+  int wg = blockIdx.x;
+  {  // XCD-aware placement (see conv_vox64_kernel): every XCD takes one contiguous run of tiles
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int b = wg / tiles, tid = wg - b * tiles;
+  const int D = a.Dd, H = a.Hd, W = a.Wd;
+  const int tw_n = W / TW, th_n = H / TH;
+  const int w0 = (tid % tw_n) * TW, h0 = ((tid / tw_n) % th_n) * TH, d0 = (tid / (tw_n * th_n)) * TD;
+  const int lz = wave >> 1, ly0 = (wave & 1) * 2;   // this wave: plane lz, rows ly0 and ly0 + 1 of the tile
+  const int64_t N = (int64_t)D * H * W;
+  const bool accum = a.flags & N3D_ACCUMULATE;
+
+  // epilogue operands first (ordinary loads, in flight behind the fill)
+  const float e_bias = a.bias ? a.bias[m] : 0.f;
+  const float e_gate = a.out_gate ? a.out_gate[(int64_t)b * 16 + m] : 1.f;
+  float e_relu[2][4], e_prev[2][4];
+  int64_t orow[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    orow[t] = (int64_t)b * N + ((int64_t)(d0 + lz) * H + h0 + ly0 + t) * W + w0 + kk * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      e_relu[t][r] = a.relu_src ? a.relu_src[(orow[t] + r) * a.rld + m] : 1.f;
+      e_prev[t][r] = accum ? a.dst[(orow[t] + r) * a.dld + m] : 0.f;
+    }
+  }
+  // weights: Wp[tap][kk][cd = m][j], one float4 per lane and tap
+  float4 bv[27];
+  {
+    const float4* __restrict__ wp4 = reinterpret_cast<const float4*>(a.wp);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) bv[tap] = wp4[(tap * 4 + kk) * 16 + m];
+  }
+  float4 gq = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (a.in_gate) gq = *reinterpret_cast<const float4*>(a.in_gate + (int64_t)b * 16 + kk * 4);
+
+  // ---- halo tile by LDS-DMA: instruction i of wave w fills pieces [(4i + w) * 64, +64) = 16 voxel records
+  {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const float4* zp = reinterpret_cast<const float4*>(zero_page);
+    const float* srcb = a.src + (int64_t)b * N * a.sld;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int pc = (i * 4 + wave) * 64 + lane;
+      const int v = pc >> 2, q = pc & 3;
+      const int x = v % LW, y = (v / LW) % LH, z = v / (LW * LH);
+      const int gd = d0 - DIL + z, gh = h0 - DIL + y, gw = w0 - DIL + x;
+      const bool ok = v < NV && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+      const float* sp = srcb + (((int64_t)gd * H + gh) * W + gw) * a.sld + q * 4;
+      __builtin_amdgcn_global_load_lds((gptr_t)(ok ? reinterpret_cast<const float4*>(sp) : zp), (lptr_t)(t16 + (i * 4 + wave) * 64), 16, 0, 0);
+    }
+  }
+  if (a.in_gate) {
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) { bv[tap].x *= gq.x; bv[tap].y *= gq.y; bv[tap].z *= gq.z; bv[tap].w *= gq.w; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 acc[2], acc2[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const float relu_floor = (a.flags & N3D_RELU_IN) ? 0.f : -INFINITY;
+  const float4* arow = t16 + ((lz * LH + ly0) * LW + m) * 4 + kk;
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        constexpr int dummy = 0; (void)dummy;
+        const int oz = (DG ? 2 - kd : kd) * DIL, oy = (DG ? 2 - kh : kh) * DIL, ox = (DG ? 2 - kw : kw) * DIL;
+        const float4 w4 = bv[(kd * 3 + kh) * 3 + kw];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          float4 av = arow[((oz * LH + oy + t) * LW + ox) * 4];
+          av.x = fmaxf(av.x, relu_floor); av.y = fmaxf(av.y, relu_floor); av.z = fmaxf(av.z, relu_floor); av.w = fmaxf(av.w, relu_floor);
+          // two accumulator chains per row (x,z / y,w): a dependent 16x16x4 MFMA has 40 cycles latency vs 32 issue
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, w4.x, acc[t], 0, 0, 0);
+          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, w4.y, acc2[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, w4.z, acc[t], 0, 0, 0);
+          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, w4.w, acc2[t], 0, 0, 0);
+        }
+      }
+
+  // ---- epilogue: lane holds channel m of voxels 4kk .. 4kk+3 of each row
+  float csum = 0.f, csq = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = acc[t][r] + acc2[t][r] + e_bias;
+      if (!(e_relu[t][r] > 0.f)) v = 0.f;
+      v = v * e_gate + e_prev[t][r];
+      a.dst[(orow[t] + r) * a.dld + m] = v;
+      csum += v; csq = fmaf(v, v, csq);
+    }
+  if (a.stats) {
+    const double s = xsum32_d(xsum16_d((double)csum)), q = xsum32_d(xsum16_d((double)csq));
+    if (kk == 0) { red[(wave * 16 + m) * 2] = s; red[(wave * 16 + m) * 2 + 1] = q; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int q2 = threadIdx.x & 1, col = threadIdx.x >> 1;
+      double tot = 0;
+      for (int w = 0; w < 4; ++w) tot += red[(w * 16 + col) * 2 + q2];
+      a.stats[(((int64_t)b * a.rows_per_sample + tid) * 16 + col) * 2 + q2] = tot;
+    }
+  }
+}
+
+static bool tile16_applies(const MfArgs& a, int ksplit) {
+  static const bool off = getenv("N3D_NO_TILE16") != nullptr;   // (A/B knob)
+  if (off || ksplit != 1 || a.k != 3 || a.sn != 1 || a.den != 1 || a.Cs != 16 || a.Cd != 16) return false;
+  const int d = a.dt < 0 ? -a.dt : a.dt;
+  if ((d != 1 && d != 2) || a.off != -a.dt) return false;
+  if (a.Ds != a.Dd || a.Hs != a.Hd || a.Ws != a.Wd || a.Wd % 16 != 0 || a.Hd % 4 != 0 || a.Dd % 2 != 0) return false;
+  if (a.stats && a.rows_per_sample != (a.Wd / 16) * (a.Hd / 4) * (a.Dd / 2)) return false;
+  return a.sld % 4 == 0 && aligned16(a.src) && aligned16(a.wp);
+}
+
+static bool launch_tile16(const MfArgs& a, hipStream_t s) {
+  const void* zp = zero_page_ptr();
+  if (!zp) return false;
+  const int d = a.dt < 0 ? -a.dt : a.dt;
+  const int tiles = (a.Wd / 16) * (a.Hd / 4) * (a.Dd / 2);
+  const int nv = (2 + 2 * d) * (4 + 2 * d) * (16 + 2 * d);
+  const size_t shm = (size_t)((nv * 4 + 255) / 256) * 256 * 16;
+  const dim3 grid((unsigned)(tiles * a.B));
+  if (d == 1) {
+    if (a.dt > 0) hipLaunchKernelGGL((conv_tile16_kernel<1, false>), grid, dim3(256), shm, s, a, zp, tiles);
+    else hipLaunchKernelGGL((conv_tile16_kernel<1, true>), grid, dim3(256), shm, s, a, zp, tiles);
+  } else {
+    if (a.dt > 0) hipLaunchKernelGGL((conv_tile16_kernel<2, false>), grid, dim3(256), shm, s, a, zp, tiles);
+    else hipLaunchKernelGGL((conv_tile16_kernel<2, true>), grid, dim3(256), shm, s, a, zp, tiles);
+  }
+  return true;
+}
+
 struct G16Plan { int mt, nt, ksplit, rows_per_block; bool ok; };
 
 static G16Plan g16_plan(const n3d_conv_geom* g, bool data_grad) {
@@ -1867,6 +2028,11 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
     if (r <= 0) return r;
   }
   const int64_t M = (int64_t)g->B * a.Dd * a.Hd * a.Wd;
+  if (tile16_applies(a, p.ksplit) && launch_tile16(a, s)) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("conv(tile16) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+    return 1;
+  }
   if (p.ksplit == 16) launch_g16<1, 1, 16>(a, M, s);
   else if (p.ksplit == 4) launch_g16<1, 1, 4>(a, M, s);
   else if (p.nt == 2) launch_g16<2, 2, 1>(a, M, s);
