@@ -22,6 +22,10 @@ CASES = [
     (8, 8, 3, 2, 2, True, 2, (4, 4, 6)),
     (16, 16, 3, 1, 1, False, 2, (8, 8, 8)),      # gemm16, KSPLIT=4
     (16, 16, 3, 1, 2, False, 2, (24, 24, 24)),   # gemm16, KSPLIT=1 (tiles > 1024)
+    # tile16 (LDS halo tile + 16x16x4 MFMA): the gemm16 problem with many voxels (> 16k), W % 16 == 0, H % 4 == 0, D % 2 == 0
+    (16, 16, 3, 1, 1, False, 2, (16, 20, 32)),
+    (16, 16, 3, 1, 2, False, 1, (18, 24, 48)),
+    (16, 16, 3, 1, 1, False, 2, (32, 32, 32)),   # the C = 16 level of a 128^3 patch
     (16, 16, 3, 2, 1, False, 2, (8, 8, 8)),
     (16, 16, 3, 2, 1, True, 2, (4, 4, 4)),
     (32, 32, 3, 1, 1, False, 2, (4, 4, 4)),
