@@ -720,36 +720,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void conv_wgrad_final_kernel(const float* __restrict__ partial, const float* __restrict__ pbias, int nchunks,
-                                                               int ntiles, int tci, int tco, int CI_T, int CO_T, int Co, int Ci, int taps,
-                                                               float* __restrict__ dw, float* __restrict__ dbias) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int nw = Co * Ci * taps;
-  if (i < nw) {
-    if (dw) {
-      const int tap = i % taps, ci = (i / taps) % Ci, co = i / (taps * Ci);
-      const int cit = ci / CI_T, cot = co / CO_T;
-      const int tile = (tap * tci + cit) * tco + cot;
-      const int q = (ci % CI_T) * CO_T + (co % CO_T);
-      float s = 0.f;
-      int c = 0;
-      for (; c + 7 < nchunks; c += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = partial[((int64_t)(c + u) * ntiles + tile) * (CI_T * CO_T) + q];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-      }
-      for (; c < nchunks; ++c) s += partial[((int64_t)c * ntiles + tile) * (CI_T * CO_T) + q];
-      dw[i] = s;
-    }
-  } else if (i < nw + Co && dbias) {
-    const int co = i - nw;
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += pbias[((int64_t)c * tco + co / CO_T) * CO_T + co % CO_T];
-    dbias[co] = s;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // depthwise family (groups == C): per-lane weights, float4 over 4 channels
@@ -1706,13 +1676,10 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     if (hv == 0) hv = vox_wgrad_s2_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, s);
     if (hv < 0) return hv;
     if (hv == 1) {
-      const int C = g->Ci, nout = C * C * taps;
-      if (deferred) {
-        fill_job(deferred, wsf, nullptr, dw, nullptr, nch, taps, 1, 1, C, C, C, C, taps);
-      } else {
-        hipLaunchKernelGGL(conv_wgrad_final_kernel, dim3((unsigned)cdiv(nout, 256)), dim3(256), 0, s, wsf, (const float*)nullptr, nch, taps, 1, 1,
-                           C, C, C, C, taps, dw, (float*)nullptr);
-      }
+      const int C = g->Ci;
+      n3d_final_job job;
+      fill_job(deferred ? deferred : &job, wsf, nullptr, dw, nullptr, nch, taps, 1, 1, C, C, C, C, taps);
+      if (!deferred) if (int e = n3d_wgrad_finalize_batch(&job, 1, stream)) return e;
       N3D_LAUNCH_CHECK();
       return N3D_OK;
     }
@@ -1737,13 +1704,9 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
       if (!handled) handled = mfma_wgrad_try(g, x, xld, dy, dyld, flags, in_gate, wsf, pb, (1024 + nt16) * 256, &nch, &ntl, s);
     }
     if (handled == 1) {
-      const int nout = g->Co * g->Ci * taps + g->Co;
-      if (deferred) {
-        fill_job(deferred, wsf, pb, dw, transposed ? nullptr : dbias, nch, ntl, g->Ci / 16, g->Co / 16, 16, 16, g->Co, g->Ci, taps);
-      } else {
-        hipLaunchKernelGGL(conv_wgrad_final_kernel, dim3((unsigned)cdiv(nout, 256)), dim3(256), 0, s, wsf, pb, nch, ntl, g->Ci / 16,
-                           g->Co / 16, 16, 16, g->Co, g->Ci, taps, dw, transposed ? nullptr : dbias);
-      }
+      n3d_final_job job;
+      fill_job(deferred ? deferred : &job, wsf, pb, dw, transposed ? nullptr : dbias, nch, ntl, g->Ci / 16, g->Co / 16, 16, 16, g->Co, g->Ci, taps);
+      if (!deferred) if (int e = n3d_wgrad_finalize_batch(&job, 1, stream)) return e;
       N3D_LAUNCH_CHECK();
       return N3D_OK;
     }
@@ -1772,13 +1735,9 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
         default: launch_k1_wgrad_c<6>(q, g->Co, nchunks, s); break;
       }
       // one "tile" holding the whole [Ci][Co] slab: ci_t = Ci, co_t = Co
-      if (deferred) {
-        fill_job(deferred, q.partial, q.pbias, dw, dbias, nchunks, 1, 1, 1, g->Ci, g->Co, g->Co, g->Ci, 1);
-      } else {
-        const int nout = g->Co * g->Ci + g->Co;
-        hipLaunchKernelGGL(conv_wgrad_final_kernel, dim3((unsigned)cdiv(nout, 256)), dim3(256), 0, s, q.partial, q.pbias, nchunks, 1, 1, 1, g->Ci,
-                           g->Co, g->Co, g->Ci, 1, dw, dbias);
-      }
+      n3d_final_job job;
+      fill_job(deferred ? deferred : &job, q.partial, q.pbias, dw, dbias, nchunks, 1, 1, 1, g->Ci, g->Co, g->Co, g->Ci, 1);
+      if (!deferred) if (int e = n3d_wgrad_finalize_batch(&job, 1, stream)) return e;
       N3D_LAUNCH_CHECK();
       return N3D_OK;
     }
@@ -1799,13 +1758,9 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   else if (p.ci_t == 4 && p.co_t == 16) launch_wgrad_t<4, 16>(a, p, s);
   else if (p.ci_t == 4 && p.co_t == 8) launch_wgrad_t<4, 8>(a, p, s);
   else launch_wgrad_t<4, 4>(a, p, s);
-  const int nout = g->Co * g->Ci * taps + g->Co;
-  if (deferred) {
-    fill_job(deferred, a.partial, a.pbias, dw, transposed ? nullptr : dbias, p.nchunks, p.ntiles, p.tci, p.tco, p.ci_t, p.co_t, g->Co, g->Ci, taps);
-  } else {
-    hipLaunchKernelGGL(conv_wgrad_final_kernel, dim3((unsigned)cdiv(nout, 256)), dim3(256), 0, s, a.partial, a.pbias, p.nchunks, p.ntiles,
-                       p.tci, p.tco, p.ci_t, p.co_t, g->Co, g->Ci, taps, dw, transposed ? nullptr : dbias);
-  }
+  n3d_final_job job;
+  fill_job(deferred ? deferred : &job, a.partial, a.pbias, dw, transposed ? nullptr : dbias, p.nchunks, p.ntiles, p.tci, p.tco, p.ci_t, p.co_t, g->Co, g->Ci, taps);
+  if (!deferred) if (int e = n3d_wgrad_finalize_batch(&job, 1, stream)) return e;
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

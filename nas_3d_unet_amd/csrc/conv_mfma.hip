@@ -303,7 +303,7 @@ __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) vo
 // ------------------------------------------------------------------------------------------------
 // weight gradient for 16-multiple channel counts:  G[ci][co] (per tap) = sum_v X[map(v,tap)][ci] * dY[v][co]
 //   MFMA A[m = ci][k = voxel], B[k = voxel][n = co]; the voxel range is split over workgroups (grid.y) and
-//   over the 4 waves of a workgroup; partial slabs are summed by conv_wgrad_final_kernel in fixed order.
+//   over the 4 waves of a workgroup; partial slabs are summed by wgrad_final_batch_kernel in fixed order.
 // ------------------------------------------------------------------------------------------------
 struct Wg16Args {
   const float* x; int64_t xld; int Di, Hi, Wi, Ci;
