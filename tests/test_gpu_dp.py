@@ -100,3 +100,66 @@ def test_comm_wrapper_allreduce_one_rank():
     torch.cuda.synchronize()
     assert torch.equal(g.cpu(), torch.arange(1000, dtype=torch.float32))
     _lib.check(lib.n3d_comm_destroy(comm), "destroy")
+
+
+def _two_rank_worker(rank, world, port, out, graph, buckets):
+    """one of two processes sharing cuda:0; gloo carries the CUDA gradient buffer (RCCL refuses two ranks on one device)"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.pop("N3D_FORCE_DP", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nas_3d_unet_amd.train import Trainer
+    from test_gpu_nets import build_net as bn
+    rng = np.random.default_rng(77)
+    xs = rng.standard_normal((2 * world, 4, 16, 16, 16)).astype(np.float32)
+    ts = (rng.uniform(0, 1, (2 * world, 3, 16, 16, 16)) < 0.3).astype(np.float32)
+    net, _ = bn("searched", "G_CONV", 2)
+    if rank == 1:   # rank 0's weights must win
+        with torch.no_grad():
+            for q in net.parameters():
+                q.add_(0.25)
+    tr = Trainer(net, graph=graph, n_buckets=buckets)
+    assert tr.dp_path and tr.sync.world == world and len(tr.sync.ranges) == buckets
+    x, t = dev(xs[2 * rank:2 * rank + 2]), dev(ts[2 * rank:2 * rank + 2])
+    losses = [float(tr.step(x, t)) for _ in range(3)]
+    torch.save({"losses": losses, "flat": tr.fp.flat.detach().cpu()}, out + ".r%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph,buckets", [(False, 2), (True, 1), (True, 2)])
+def test_two_processes_on_one_gpu_equal_the_global_batch(tmp_path, graph, buckets):
+    """world_size 2 for real (two processes, each running the HIP trainer on its shard, gradients exchanged through GradSync):
+    single bucket after the step, or buckets exchanged while the backward walk continues (eager, and as HIP-graph segments);
+    three Adam steps give both ranks identical weights, equal to one process training on the concatenated batch (GroupNorm is
+    per sample and the Dice loss a mean over (b, c) rows, so the mean of the shard gradients is the global-batch gradient)."""
+    import torch.multiprocessing as mp
+    from nas_3d_unet_amd.train import Trainer
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "dp2")
+    mp.spawn(_two_rank_worker, args=(2, port, out, graph, buckets), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".r0"), torch.load(out + ".r1")
+    assert torch.equal(r0["flat"], r1["flat"])
+    # one process, global batch of 4
+    forced = os.environ.pop("N3D_FORCE_DP", None)
+    try:
+        rng = np.random.default_rng(77)
+        xs = rng.standard_normal((4, 4, 16, 16, 16)).astype(np.float32)
+        ts = (rng.uniform(0, 1, (4, 3, 16, 16, 16)) < 0.3).astype(np.float32)
+        net, _ = build_net("searched", "G_CONV", 2)
+        ref = Trainer(net, graph=graph)
+        lr_ = [float(ref.step(dev(xs), dev(ts))) for _ in range(3)]
+        wr = ref.fp.flat.detach().cpu()
+    finally:
+        if forced is not None:
+            os.environ["N3D_FORCE_DP"] = forced
+    # the global loss is the mean of the two shard losses
+    np.testing.assert_allclose([(a + b) / 2 for a, b in zip(r0["losses"], r1["losses"])], lr_, rtol=0, atol=5e-6)
+    scale = float(wr.abs().max())
+    assert float((r0["flat"] - wr).abs().max()) <= 2e-5 * scale, float((r0["flat"] - wr).abs().max())
