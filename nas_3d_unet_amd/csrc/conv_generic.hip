@@ -1718,7 +1718,9 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     // 2048 voxels per workgroup, more when the slab workspace (sized for the tiled kernel) or 1024 workgroups would be exceeded
     int64_t maxc = (int64_t)(avail / (nslab + g->Co));
     if (maxc > 1024) maxc = 1024;
+    // (down to 512 on the small levels: 65 536 voxels in 2048-voxel chunks are 32 workgroups walking four trips each)
     int64_t chunk = K1W_CHUNK;
+    while (chunk > 512 && cdiv(total, chunk) < 256) chunk >>= 1;
     if (maxc >= 1 && cdiv(total, chunk) > maxc) chunk = (cdiv(total, maxc) + 255) / 256 * 256;
     const int nchunks = (int)cdiv(total, chunk);
     if (maxc >= 64 && (size_t)nchunks * (nslab + g->Co) <= avail) {

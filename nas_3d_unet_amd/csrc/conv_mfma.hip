@@ -261,11 +261,19 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
       uint32_t ub2, ur2;
       a.fNd.divmod(first, ub2, ur2);
       const int row = (int)(ur2 / ROWS_PER_BLOCK);
+      // 8 voxels per sample (the 2^3 level): rows 0-7 (lanes kk 0/1) are one sample, rows 8-15 (kk 2/3) the next
+      const bool two = Nd * 2 == ROWS_PER_BLOCK;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const double s = xsum32_d(xsum16_d((double)csum[n])), q = xsum32_d(xsum16_d((double)csq[n]));
-        if (kk == 0)
-          *reinterpret_cast<double2*>(a.stats + (((int64_t)ub2 * a.rows_per_sample + row) * a.Cd + n0 + n * 16 + m) * 2) = make_double2(s, q);
+        double s = xsum16_d((double)csum[n]), q = xsum16_d((double)csq[n]);
+        if (two) {
+          const int64_t smp = (int64_t)ub2 + (kk >> 1);
+          if (!(kk & 1) && smp < a.B) *reinterpret_cast<double2*>(a.stats + (smp * a.Cd + n0 + n * 16 + m) * 2) = make_double2(s, q);
+        } else {
+          s = xsum32_d(s); q = xsum32_d(q);
+          if (kk == 0)
+            *reinterpret_cast<double2*>(a.stats + (((int64_t)ub2 * a.rows_per_sample + row) * a.Cd + n0 + n * 16 + m) * 2) = make_double2(s, q);
+        }
       }
     }
   } else if (a.stats) {
@@ -1932,6 +1940,7 @@ int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags) {
   G16Plan p = g16_plan(g, data_grad);
   if (!p.ok) return 0;
   const int64_t Nd = data_grad ? (int64_t)g->Di * g->Hi * g->Wi : (int64_t)g->Do * g->Ho * g->Wo;
+  if (Nd * 2 == p.rows_per_block && p.ksplit > 1) return 1;   // the 2^3 level: a 16-row tile holds two samples, one row each
   if (Nd % p.rows_per_block != 0) return -1;  // statistics not produced by this kernel: caller must use n3d_channel_stats
   return (int)(Nd / p.rows_per_block);
 }
@@ -2066,8 +2075,11 @@ int g16_prepare(const n3d_conv_geom* g, bool data_grad, const float* src, int64_
   if ((int64_t)g->B * Nd >= (1ll << 31)) return 0;  // 32-bit voxel indexing
   a.fNd = FastDiv((uint32_t)Nd); a.fWd = FastDiv((uint32_t)a.Wd); a.fHd = FastDiv((uint32_t)a.Hd); a.fC16 = FastDiv((uint32_t)(a.Cs / 16));
   if (stats) {
-    if (Nd % p.rows_per_block != 0) { set_error("conv(mfma): statistics requested for a shape whose n3d_conv_stats_rows() is -1"); return N3D_ERR_INVALID; }
-    a.rows_per_sample = (int)(Nd / p.rows_per_block);
+    if (Nd * 2 == p.rows_per_block && p.ksplit > 1) a.rows_per_sample = 1;
+    else {
+      if (Nd % p.rows_per_block != 0) { set_error("conv(mfma): statistics requested for a shape whose n3d_conv_stats_rows() is -1"); return N3D_ERR_INVALID; }
+      a.rows_per_sample = (int)(Nd / p.rows_per_block);
+    }
   } else a.rows_per_sample = 0;
   const size_t need = (size_t)taps * a.Cs * a.Cd * 4;
   if (!ws || ws_bytes < need) { set_error("conv(mfma): workspace too small (%zu < %zu)", ws_bytes, need); return N3D_ERR_WORKSPACE; }

@@ -30,7 +30,9 @@ CASES = [
     (16, 16, 3, 2, 1, True, 2, (4, 4, 4)),
     (32, 32, 3, 1, 1, False, 2, (4, 4, 4)),
     (32, 32, 3, 2, 2, True, 3, (4, 2, 2)),
-    (64, 64, 3, 1, 1, False, 2, (2, 2, 2)),      # 8 voxels per sample: no fused statistics
+    (64, 64, 3, 1, 1, False, 2, (2, 2, 2)),      # 8 voxels per sample: a 16-row MFMA tile holds two samples, one statistics row each
+    (64, 64, 3, 1, 1, False, 3, (2, 2, 2)),      # ... odd batch: the last tile holds one sample
+    (32, 32, 3, 1, 2, False, 1, (2, 2, 2)),
     (64, 64, 3, 2, 1, False, 2, (4, 4, 4)),
     (64, 64, 3, 2, 1, True, 2, (2, 2, 2)),
     (12, 8, 1, 2, 1, False, 2, (8, 8, 8)),
