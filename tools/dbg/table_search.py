@@ -28,7 +28,7 @@ def describe(name, args):
         return tuple(sig), f, b
     return orig(name, args)
 kernel_table.describe = describe
-rows, n = kernel_table.table(lambda: tr._both(x, t, vx, vt), dev, top=60, candidates=60)
+rows, n = kernel_table.table(lambda: tr._both(x, t, vx, vt), dev, top=500, candidates=500)
 print("launches", n)
 for r in rows:
     print("%7.1f us/step %3d x %6.2f  %-30s %s  frac=%s" % (r["us_per_step"], r["calls_per_step"], r["us_per_call"], r["entry"], r["shape"][:150], r.get("frac")))
