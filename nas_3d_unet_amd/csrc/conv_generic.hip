@@ -1416,6 +1416,8 @@ int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const flo
 int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                      float* partial, size_t avail_floats, int* nchunks_out, hipStream_t s);
 struct Wg16Args;
+int wgrad_tile16_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
+                     float* partial, size_t avail_floats, int* nchunks_out, float** pbias_out, hipStream_t s);
 int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                    float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s,
                    Wg16Args* prepared = nullptr);
@@ -1469,6 +1471,10 @@ size_t n3d_conv_workspace_bytes(const n3d_conv_geom* g) {
       const size_t nt = (size_t)taps * (g->Ci / 16) * (g->Co / 16);
       const size_t c = (1024 + nt) * (256 + 16) * 4;
       if (c > a) a = c;
+      if (g->k == 3 && g->Ci == 16 && g->Co == 16 && (int64_t)g->B * No >= 32768) {   // wgrad_tile16: <= 256 workgroup slabs
+        const size_t c2 = (size_t)256 * (27 * 256 + 16) * 4;
+        if (c2 > a) a = c2;
+      }
     }
     bytes += align_up(a > b ? a : b, 256) + 256;
   }
@@ -1679,6 +1685,19 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
       const int C = g->Ci;
       n3d_final_job job;
       fill_job(deferred ? deferred : &job, wsf, nullptr, dw, nullptr, nch, taps, 1, 1, C, C, C, C, taps);
+      if (!deferred) if (int e = n3d_wgrad_finalize_batch(&job, 1, stream)) return e;
+      N3D_LAUNCH_CHECK();
+      return N3D_OK;
+    }
+  }
+  if (!(flags & (N3D_NO_MFMA | N3D_ANY_BF16)) && xld % 4 == 0 && dyld % 4 == 0 && !transposed) {
+    // many-voxel 16 -> 16 channel 3x3x3 stride-1 convs: LDS-tile MFMA weight gradient (conv_mfma.hip, wgrad_tile16)
+    int nch = 0;
+    float* pb = nullptr;
+    const int h = wgrad_tile16_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, &pb, s);
+    if (h == 1) {
+      n3d_final_job job;
+      fill_job(deferred ? deferred : &job, wsf, pb, dw, dbias, nch, 27, 1, 1, 16, 16, 16, 16, 27);
       if (!deferred) if (int e = n3d_wgrad_finalize_batch(&job, 1, stream)) return e;
       N3D_LAUNCH_CHECK();
       return N3D_OK;

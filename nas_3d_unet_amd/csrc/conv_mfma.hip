@@ -2196,6 +2196,145 @@ int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const fl
   return 1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad_tile16: weight gradient of the tile16 shapes (3x3x3 stride-1 conv, 16 -> 16 channels, many voxels).
+//   G[tap][ci][co] = sum_v X[v + tap][ci] * dY[v][co]   as v_mfma_f32_16x16x4_f32 with K = four W-consecutive voxels:
+//   A[i = ci][k] = X[v_k + tap][ci]: ONE ds_read_b32 per lane from the LDS halo tile (lane (m, kk) -> channel m of voxel kk of the
+//   group: 256 contiguous bytes per wave, conflict-free); B[k][j = co] = dY[v_k][co]: tap-independent, loaded once per tile
+//   into 32 registers (one per voxel group).  The 27 taps are split over the four waves (7/7/7/6): no cross-wave reduction, a
+//   wave keeps 7 x 2 accumulator tiles (two chains per tap); a workgroup walks tiles_per_wg tiles and leaves one partial slab
+//   [27][16][16] + [16] for the common fixed-order finalize.  conv_wgrad16_kernel gathers both operands from global memory
+//   4 bytes per lane and voxel, one tap per workgroup: 80 us at (2,16,32^3); this form: see DESIGN.md.
+// ------------------------------------------------------------------------------------------------
+struct WgT16Args {
+  const float* x; int64_t xld; const float* dy; int64_t dyld;
+  int D, H, W, B, flags;
+  const float* in_gate;
+  float* partial;   // [nwg][27][256]
+  float* pbias;     // [nwg][16]
+  int tiles_per_sample, tiles_total, tiles_per_wg;
+  const void* zero_page;
+};
+
+template <int DIL>
+__global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
+  constexpr int TD = 2, TH = 4, TW = 16;
+  constexpr int LD = TD + 2 * DIL, LH = TH + 2 * DIL, LW = TW + 2 * DIL, NV = LD * LH * LW;
+  constexpr int NP = NV * 4, NIT = (NP + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float4 wt16[];   // X halo tile: [NIT * 256] float4, voxel-major 64-byte records
+  const float* xl = reinterpret_cast<const float*>(wt16);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, kk = lane >> 4;
+  const int tap0 = wave * 7, ntap = wave < 3 ? 7 : 6;
+  const int D = a.D, H = a.H, W = a.W;
+  const int tw_n = W / TW, th_n = H / TH;
+  const int64_t N = (int64_t)D * H * W;
+  const float floor_ = (a.flags & N3D_RELU_IN) ? 0.f : -INFINITY;
+  f32x4 acc[7][2];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  float bsum = 0.f;
+  // LDS float index of this lane's A element for group 0, tap offset 0
+  const int abase = (kk * 16) + m;
+  for (int it = 0; it < a.tiles_per_wg; ++it) {
+    const int tg = (int)blockIdx.x * a.tiles_per_wg + it;
+    if (tg >= a.tiles_total) break;
+    const int b = tg / a.tiles_per_sample, tid = tg - b * a.tiles_per_sample;
+    const int w0 = (tid % tw_n) * TW, h0 = ((tid / tw_n) % th_n) * TH, d0 = (tid / (tw_n * th_n)) * TD;
+    // B operand: channel m of voxel 4*xq + kk of every row of the tile (32 groups), straight from global memory
+    float bv[32];
+    {
+      const float* dyb = a.dy + ((int64_t)b * N + ((int64_t)d0 * H + h0) * W + w0 + kk) * a.dyld + m;
+#pragma unroll
+      for (int gi = 0; gi < 32; ++gi) {
+        const int row = gi >> 2, xq = gi & 3, z = row >> 2, y = row & 3;
+        bv[gi] = dyb[(((int64_t)z * H + y) * W + xq * 4) * a.dyld];
+      }
+    }
+    const float gq = a.in_gate ? a.in_gate[(int64_t)b * 16 + m] : 1.f;
+    {  // X halo tile by LDS-DMA (as conv_tile16_kernel)
+      typedef const __attribute__((address_space(1))) void* gptr_t;
+      typedef __attribute__((address_space(3))) void* lptr_t;
+      const float4* zp = reinterpret_cast<const float4*>(a.zero_page);
+      const float* srcb = a.x + (int64_t)b * N * a.xld;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        const int pc = (i * 4 + wave) * 64 + lane;
+        const int v = pc >> 2, q = pc & 3;
+        const int x = v % LW, y = (v / LW) % LH, z = v / (LW * LH);
+        const int gd = d0 - DIL + z, gh = h0 - DIL + y, gw = w0 - DIL + x;
+        const bool ok = v < NV && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        const float* sp = srcb + (((int64_t)gd * H + gh) * W + gw) * a.xld + q * 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)(ok ? reinterpret_cast<const float4*>(sp) : zp), (lptr_t)(wt16 + (i * 4 + wave) * 64), 16, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int gi = 0; gi < 32; ++gi) bsum += bv[gi];
+    }
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      if (t < ntap) {
+        const int tap = tap0 + t;
+        const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
+        const float* ap = xl + abase + (((kd * DIL) * LH + kh * DIL) * LW + kw * DIL) * 16;
+#pragma unroll
+        for (int gi = 0; gi < 32; ++gi) {
+          const int row = gi >> 2, xq = gi & 3, z = row >> 2, y = row & 3;
+          float av = ap[((z * LH + y) * LW + xq * 4) * 16];
+          av = fmaxf(av, floor_) * gq;
+          acc[t][gi & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[gi], acc[t][gi & 1], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();   // the next tile's fill overwrites the LDS image
+  }
+  // D: rows (ci) 4*kk + r, column (co) m  ->  slab position ci*16 + co
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    if (t < ntap) {
+      float* p = a.partial + ((int64_t)blockIdx.x * 27 + tap0 + t) * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[(kk * 4 + r) * 16 + m] = acc[t][0][r] + acc[t][1][r];
+    }
+  }
+  if (wave == 0) {
+    bsum = xsum32_f(xsum16_f(bsum));
+    if (kk == 0) a.pbias[(int64_t)blockIdx.x * 16 + m] = bsum;
+  }
+}
+
+#define N3D_WGT16_MAX_WG 256
+// 1 = launched (partial slabs [nwg][27][256] at `partial`, bias rows [nwg][16] behind them), 0 = shape not served
+int wgrad_tile16_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
+                     float* partial, size_t avail_floats, int* nchunks_out, float** pbias_out, hipStream_t s) {
+  static const bool off = getenv("N3D_NO_TILE16") != nullptr;   // (A/B knob)
+  if (off || g->depthwise || g->k != 3 || g->stride != 1 || g->Ci != 16 || g->Co != 16 || (g->dil != 1 && g->dil != 2) || g->pad != g->dil) return 0;
+  if (g->Wi % 16 != 0 || g->Hi % 4 != 0 || g->Di % 2 != 0 || xld % 4 != 0 || !aligned16(x)) return 0;
+  if (flags & (N3D_SRC_BF16 | N3D_DST_BF16 | N3D_NO_MFMA)) return 0;
+  const int tiles_per_sample = (g->Wi / 16) * (g->Hi / 4) * (g->Di / 2);
+  const int64_t tiles_total = (int64_t)tiles_per_sample * g->B;
+  if (tiles_total < 256 || tiles_total >= (1 << 30)) return 0;     // >= 32768 voxels: below, the K-split kernels are faster
+  const int nwg = tiles_total < N3D_WGT16_MAX_WG ? (int)tiles_total : N3D_WGT16_MAX_WG;
+  if ((size_t)nwg * (27 * 256 + 16) > avail_floats) return 0;
+  WgT16Args a;
+  a.x = x; a.xld = xld; a.dy = dy; a.dyld = dyld; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.B = g->B; a.flags = flags; a.in_gate = in_gate;
+  a.partial = partial; a.pbias = partial + (size_t)nwg * 27 * 256;
+  a.tiles_per_sample = tiles_per_sample; a.tiles_total = (int)tiles_total; a.tiles_per_wg = (int)cdiv(tiles_total, nwg);
+  a.zero_page = zero_page_ptr();
+  if (!a.zero_page) return 0;
+  const int d = g->dil;
+  const int nv = (2 + 2 * d) * (4 + 2 * d) * (16 + 2 * d);
+  const size_t shm = (size_t)((nv * 4 + 255) / 256) * 256 * 16;
+  const int grid = (int)cdiv(tiles_total, a.tiles_per_wg);
+  if (d == 1) hipLaunchKernelGGL(wgrad_tile16_kernel<1>, dim3(grid), dim3(256), shm, s, a);
+  else hipLaunchKernelGGL(wgrad_tile16_kernel<2>, dim3(grid), dim3(256), shm, s, a);
+  *nchunks_out = grid; *pbias_out = a.pbias;
+  return 1;
+}
+
 // Data gradient + weight gradient of a non-transposed conv whose channel counts are multiples of 16 and whose data
 // gradient is a tiny GEMM (K-split plan), in one launch.  Returns 1 if launched, 0 if the shape does not qualify.
 int mfma_bwd_dual_try(const n3d_conv_geom* g, bool transposed, const float* dy, int64_t dyld, const float* wp_packed, float* dx,

@@ -25,7 +25,9 @@ CASES = [
     # tile16 (LDS halo tile + 16x16x4 MFMA): the gemm16 problem with many voxels (> 16k), W % 16 == 0, H % 4 == 0, D % 2 == 0
     (16, 16, 3, 1, 1, False, 2, (16, 20, 32)),
     (16, 16, 3, 1, 2, False, 1, (18, 24, 48)),
-    (16, 16, 3, 1, 1, False, 2, (32, 32, 32)),   # the C = 16 level of a 128^3 patch
+    (16, 16, 3, 1, 1, False, 2, (32, 32, 32)),   # the C = 16 level of a 128^3 patch (>= 256 tiles: LDS-tile weight gradient too)
+    (16, 16, 3, 1, 2, False, 2, (16, 32, 32)),
+    (16, 16, 3, 1, 1, False, 3, (12, 32, 32)),   # 576 tiles over 256 workgroups: ragged tiles-per-workgroup, workgroups span samples
     (16, 16, 3, 2, 1, False, 2, (8, 8, 8)),
     (16, 16, 3, 2, 1, True, 2, (4, 4, 4)),
     (32, 32, 3, 1, 1, False, 2, (4, 4, 4)),
