@@ -1874,6 +1874,137 @@ __global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const voi
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// tile16_up: the den = 2 gather of the 16-channel level -- forward of a stride-2 transposed 3x3x3 conv and data gradient of a
+// stride-2 conv (destination grid = 2 x source grid exactly):   dst[o] = sum_k W[k] . src[(o + pad - k*dil) / 2]   (if divisible).
+// Through the gemm16 gather map every output voxel visits all 27 taps and masks the 23.6 that do not divide (27 us at 2 x 32^3
+// outputs).  Here a workgroup owns 1 x 4 x 16 SOURCE voxels and produces all 8 output parity classes from one LDS halo tile:
+// per dimension, o = 2s + p takes  dil 1: p = 0 -> (k 1, s), p = 1 -> (k 0, s + 1), (k 2, s);  dil 2: p = 0 -> (k 0, s + 1), (k 1, s),
+// (k 2, s - 1), p = 1 -> nothing -- so the 27 taps are used exactly once over the 8 classes, each as ONE ds_read_b128 per 16-voxel
+// source row feeding four v_mfma_f32_16x16x4_f32 (the A-operand scheme of conv_tile16).  Same arguments and epilogue as gemm16;
+// one statistics row per workgroup (512 outputs).
+// ------------------------------------------------------------------------------------------------
+template <int DIL>
+__global__ __launch_bounds__(256, 2) void conv_tile16_up_kernel(MfArgs a, const void* zero_page, int tiles) {
+  constexpr int TH = 4, TW = 16;
+  constexpr int LO = DIL == 2 ? 1 : 0;                   // source halo below (above: always 1)
+  constexpr int LD = 1 + LO + 1, LH = TH + LO + 1, LW = TW + LO + 1, NV = LD * LH * LW;
+  constexpr int NP = NV * 4, NIT = (NP + 255) / 256;
+  constexpr int NCLS = DIL == 1 ? 8 : 1;                 // output parity classes that receive taps
+  extern __shared__ __attribute__((aligned(16))) float4 t16[];
+  __shared__ double red[4 * 16 * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, kk = lane >> 4;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int b = wg / tiles, tid = wg - b * tiles;
+  const int Ds = a.Ds, Hs = a.Hs, Ws = a.Ws, Dd = a.Dd, Hd = a.Hd, Wd = a.Wd;
+  const int tw_n = Ws / TW, th_n = Hs / TH;
+  const int w0 = (tid % tw_n) * TW, h0 = ((tid / tw_n) % th_n) * TH, d0 = tid / (tw_n * th_n);
+  const int ly = wave;                                    // this wave: source row ly of the tile
+  const bool accum = a.flags & N3D_ACCUMULATE;
+  const float e_bias = a.bias ? a.bias[m] : 0.f;
+  const float e_gate = a.out_gate ? a.out_gate[(int64_t)b * 16 + m] : 1.f;
+  float4 bv[27];
+  {
+    const float4* __restrict__ wp4 = reinterpret_cast<const float4*>(a.wp);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) bv[tap] = wp4[(tap * 4 + kk) * 16 + m];
+  }
+  float4 gq = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (a.in_gate) gq = *reinterpret_cast<const float4*>(a.in_gate + (int64_t)b * 16 + kk * 4);
+  {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const float4* zp = reinterpret_cast<const float4*>(zero_page);
+    const float* srcb = a.src + (int64_t)b * Ds * Hs * Ws * a.sld;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int pc = (i * 4 + wave) * 64 + lane;
+      const int v = pc >> 2, q = pc & 3;
+      const int x = v % LW, y = (v / LW) % LH, z = v / (LW * LH);
+      const int gd = d0 - LO + z, gh = h0 - LO + y, gw = w0 - LO + x;
+      const bool ok = v < NV && (unsigned)gd < (unsigned)Ds && (unsigned)gh < (unsigned)Hs && (unsigned)gw < (unsigned)Ws;
+      const float* sp = srcb + (((int64_t)gd * Hs + gh) * Ws + gw) * a.sld + q * 4;
+      __builtin_amdgcn_global_load_lds((gptr_t)(ok ? reinterpret_cast<const float4*>(sp) : zp), (lptr_t)(t16 + (i * 4 + wave) * 64), 16, 0, 0);
+    }
+  }
+  if (a.in_gate) {
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) { bv[tap].x *= gq.x; bv[tap].y *= gq.y; bv[tap].z *= gq.z; bv[tap].w *= gq.w; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 acc[NCLS], acc2[NCLS];
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) { acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const float relu_floor = (a.flags & N3D_RELU_IN) ? 0.f : -INFINITY;
+  const float4* arow = t16 + ((LO * LH + ly + LO) * LW + LO + m) * 4 + kk;   // source voxel (d0, h0 + ly, w0 + m)
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        // per dimension: output parity and source shift of tap k
+        const int pd = DIL == 1 ? (kd != 1) : 0, ph = DIL == 1 ? (kh != 1) : 0, pw = DIL == 1 ? (kw != 1) : 0;
+        const int sd = DIL == 1 ? (kd == 0) : 1 - kd, sh = DIL == 1 ? (kh == 0) : 1 - kh, sw = DIL == 1 ? (kw == 0) : 1 - kw;
+        const int cls = DIL == 1 ? pd * 4 + ph * 2 + pw : 0;
+        const float4 w4 = bv[(kd * 3 + kh) * 3 + kw];
+        float4 av = arow[((sd * LH + sh) * LW + sw) * 4];
+        av.x = fmaxf(av.x, relu_floor); av.y = fmaxf(av.y, relu_floor); av.z = fmaxf(av.z, relu_floor); av.w = fmaxf(av.w, relu_floor);
+        acc[cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, w4.x, acc[cls], 0, 0, 0);
+        acc2[cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, w4.y, acc2[cls], 0, 0, 0);
+        acc[cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, w4.z, acc[cls], 0, 0, 0);
+        acc2[cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, w4.w, acc2[cls], 0, 0, 0);
+      }
+
+  // ---- epilogue: lane holds channel m of source voxels 4kk .. 4kk+3 of its row, for every output parity class
+  float csum = 0.f, csq = 0.f;
+  const int64_t Nd = (int64_t)Dd * Hd * Wd;
+#pragma unroll
+  for (int cls = 0; cls < 8; ++cls) {
+    const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
+    const int64_t orow = (int64_t)b * Nd + ((int64_t)(2 * d0 + pd) * Hd + 2 * (h0 + ly) + ph) * Wd + 2 * (w0 + kk * 4) + pw;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t o = orow + 2 * r;
+      float v = e_bias;
+      if (cls < NCLS) v += acc[cls < NCLS ? cls : 0][r] + acc2[cls < NCLS ? cls : 0][r];
+      if (a.relu_src && !(a.relu_src[o * a.rld + m] > 0.f)) v = 0.f;
+      v *= e_gate;
+      if (accum) v += a.dst[o * a.dld + m];
+      a.dst[o * a.dld + m] = v;
+      csum += v; csq = fmaf(v, v, csq);
+    }
+  }
+  if (a.stats) {
+    const double s = xsum32_d(xsum16_d((double)csum)), q = xsum32_d(xsum16_d((double)csq));
+    if (kk == 0) { red[(wave * 16 + m) * 2] = s; red[(wave * 16 + m) * 2 + 1] = q; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int q2 = threadIdx.x & 1, col = threadIdx.x >> 1;
+      double tot = 0;
+      for (int w = 0; w < 4; ++w) tot += red[(w * 16 + col) * 2 + q2];
+      a.stats[(((int64_t)b * tiles + tid) * 16 + col) * 2 + q2] = tot;
+    }
+  }
+}
+
+// geometry-only decision (n3d_conv_stats_rows must agree with the launch): tiles per sample, 0 = not this kernel
+static int tile16_up_tiles(const n3d_conv_geom* g, bool data_grad) {
+  static const bool off = getenv("N3D_NO_TILE16") != nullptr;
+  if (off || !data_grad || g->depthwise || g->k != 3 || g->stride != 2 || g->Ci != 16 || g->Co != 16) return 0;
+  if ((g->dil != 1 && g->dil != 2) || g->pad != g->dil) return 0;
+  if (g->Di != 2 * g->Do || g->Hi != 2 * g->Ho || g->Wi != 2 * g->Wo || g->Wo % 16 != 0 || g->Ho % 4 != 0) return 0;
+  if ((int64_t)g->B * g->Di * g->Hi * g->Wi < 16384 * 2) return 0;    // the K-split plans serve the small levels
+  return (g->Wo / 16) * (g->Ho / 4) * g->Do;
+}
+
 static bool tile16_applies(const MfArgs& a, int ksplit) {
   static const bool off = getenv("N3D_NO_TILE16") != nullptr;   // (A/B knob)
   if (off || ksplit != 1 || a.k != 3 || a.sn != 1 || a.den != 1 || a.Cs != 16 || a.Cd != 16) return false;
@@ -1939,6 +2070,7 @@ int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags) {
   }
   G16Plan p = g16_plan(g, data_grad);
   if (!p.ok) return 0;
+  if (p.ksplit == 1) { const int t = tile16_up_tiles(g, data_grad); if (t) return t; }
   const int64_t Nd = data_grad ? (int64_t)g->Di * g->Hi * g->Wi : (int64_t)g->Do * g->Ho * g->Wo;
   if (Nd * 2 == p.rows_per_block && p.ksplit > 1) return 1;   // the 2^3 level: a 16-row tile holds two samples, one row each
   if (Nd % p.rows_per_block != 0) return -1;  // statistics not produced by this kernel: caller must use n3d_channel_stats
@@ -2037,6 +2169,26 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
     if (r <= 0) return r;
   }
   const int64_t M = (int64_t)g->B * a.Dd * a.Hd * a.Wd;
+  if (p.ksplit == 1) {
+    const int tiles = tile16_up_tiles(g, data_grad);
+    if (tiles) {
+      const void* zp = zero_page_ptr();
+      if (a.sld % 4 != 0 || !aligned16(a.src) || !aligned16(a.wp) || !zp) {
+        if (stats) { set_error("conv(tile16_up): misaligned source with statistics requested"); return N3D_ERR_UNSUPPORTED; }
+      } else {
+        a.rows_per_sample = tiles;
+        const int d = g->dil, lo = d == 2 ? 1 : 0;
+        const int nv = (2 + lo) * (4 + lo + 1) * (16 + lo + 1);
+        const size_t shm = (size_t)((nv * 4 + 255) / 256) * 256 * 16;
+        const dim3 grid((unsigned)(tiles * g->B));
+        if (d == 1) hipLaunchKernelGGL(conv_tile16_up_kernel<1>, grid, dim3(256), shm, s, a, zp, tiles);
+        else hipLaunchKernelGGL(conv_tile16_up_kernel<2>, grid, dim3(256), shm, s, a, zp, tiles);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error("conv(tile16_up) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+        return 1;
+      }
+    }
+  }
   if (tile16_applies(a, p.ksplit) && launch_tile16(a, s)) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("conv(tile16) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }

@@ -28,6 +28,12 @@ CASES = [
     (16, 16, 3, 1, 1, False, 2, (32, 32, 32)),   # the C = 16 level of a 128^3 patch (>= 256 tiles: LDS-tile weight gradient too)
     (16, 16, 3, 1, 2, False, 2, (16, 32, 32)),
     (16, 16, 3, 1, 1, False, 3, (12, 32, 32)),   # 576 tiles over 256 workgroups: ragged tiles-per-workgroup, workgroups span samples
+    # tile16_up: transposed forward / stride-2 data gradient of the 16-channel level with >= 32k destination voxels
+    (16, 16, 3, 2, 1, True, 2, (8, 16, 32)),
+    (16, 16, 3, 2, 2, True, 2, (8, 16, 32)),
+    (16, 16, 3, 2, 1, False, 2, (16, 32, 64)),
+    (16, 16, 3, 2, 2, False, 1, (32, 32, 32)),
+    (16, 16, 3, 2, 1, True, 3, (6, 8, 48)),
     (16, 16, 3, 2, 1, False, 2, (8, 8, 8)),
     (16, 16, 3, 2, 1, True, 2, (4, 4, 4)),
     (32, 32, 3, 1, 1, False, 2, (4, 4, 4)),

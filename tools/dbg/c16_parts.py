@@ -45,3 +45,35 @@ for (stride, dil, transposed) in [(1, 1, False), (1, 2, False), (2, 1, False), (
             ctx.final.clear()
         tw = timeit(wg)
     print("C16 %s s%d d%d in %d^3 out %d^3: fwd %.1f us  dgrad %.1f us  wgrad %.1f us" % ("convT" if transposed else "conv ", stride, dil, si, so, tf, td, tw))
+
+# the forward pair of a node as the net issues it: stride-1 + stride-2 conv from the same input level, with statistics
+S2 = S
+x = K.as_view(K.empty_ndhwc(B, C, S2, S2, S2, dev).normal_())
+w1 = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05; w2 = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
+g1 = K.conv_geom(B, S2, S2, S2, C, C, 3, 1, 1, 1); g2 = K.conv_geom(B, S2, S2, S2, C, C, 3, 2, 1, 1)
+y1 = K.as_view(K.empty_ndhwc(B, C, S2, S2, S2, dev)); y2 = K.as_view(K.empty_ndhwc(B, C, S2 // 2, S2 // 2, S2 // 2, dev))
+r1, r2 = K.conv_stats_rows(g1, False), K.conv_stats_rows(g2, False)
+st1 = torch.zeros((B, r1, C, 2), dtype=torch.float64, device=dev); st2 = torch.zeros((B, r2, C, 2), dtype=torch.float64, device=dev)
+ctx = K.StepContext(dev)
+with K.step_context(ctx):
+    b1 = torch.randn(C, device=dev); b2 = torch.randn(C, device=dev)
+    calls = [(g1, x, w1, b1, y1, 0, None, st1, False), (g2, x, w2, b2, y2, 0, None, st2, False)]
+    K.conv_fwd2(calls)
+    ctx.freeze(); ctx.pack_all()
+    print("rows", r1, r2)
+    print("fwd2 (s1 + s2, stats): %.1f us" % timeit(lambda: K.conv_fwd2(calls)))
+    print("fwd s1 stats alone: %.1f us" % timeit(lambda: K.conv_fwd(g1, x, w1, None, y1, 0, None, st1, False)))
+    print("fwd s2 stats alone: %.1f us" % timeit(lambda: K.conv_fwd(g2, x, w2, None, y2, 0, None, st2, False)))
+
+# the same stride-1 conv on channel slices of 48-channel concat buffers (voxel pitch 192 bytes), as inside a cell
+big_x = K.empty_ndhwc(B, 48, S2, S2, S2, dev).normal_(); big_y = K.empty_ndhwc(B, 48, S2, S2, S2, dev)
+for name, xs, ys in (("dense -> dense", x, y1), ("slice -> dense", K.as_view(big_x[:, 16:32]), y1), ("dense -> slice", x, K.as_view(big_y[:, 16:32])),
+                     ("slice -> slice", K.as_view(big_x[:, 16:32]), K.as_view(big_y[:, 16:32]))):
+    with K.step_context(ctx):
+        print("fwd s1 stats %s (ld %d -> %d): %.1f us" % (name, xs.ld, ys.ld, timeit(lambda: K.conv_fwd(g1, xs, w1, None, ys, 0, None, st1, False))))
+        print("fwd s1 stats + accumulate %s: %.1f us" % (name, timeit(lambda: K.conv_fwd(g1, xs, w1, None, ys, K.ACCUMULATE, None, st1, False))))
+
+with K.step_context(ctx):
+    for name, fill in (("relu(randn)", lambda t: t.normal_().clamp_(min=0)), ("denormals 1e-40", lambda t: t.fill_(1e-40)), ("zeros", lambda t: t.zero_()), ("randn*1e-20", lambda t: t.normal_().mul_(1e-20))):
+        fill(x.t)
+        print("fwd s1 stats, x = %s: %.1f us" % (name, timeit(lambda: K.conv_fwd(g1, x, w1, b1, y1, 0, None, st1, False))))
