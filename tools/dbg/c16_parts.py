@@ -23,7 +23,7 @@ def timeit(fn, reps=10, rounds=3):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) * 1e3 / (reps * rounds)
 
-C, S, B = 16, int(sys.argv[1]) if len(sys.argv) > 1 else 32, 2
+C, S, B = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), (int(sys.argv[1]) if len(sys.argv) > 1 else 32), 2
 for (stride, dil, transposed) in [(1, 1, False), (1, 2, False), (2, 1, False), (2, 2, False), (2, 1, True)]:
     pad = _padding(3, stride, dil)
     si = S // 2 if transposed else S          # conv-input side of the call
@@ -44,7 +44,7 @@ for (stride, dil, transposed) in [(1, 1, False), (1, 2, False), (2, 1, False), (
             K.conv_bwd_weight(g, x, y, dw, None, 0, None, transposed)
             ctx.final.clear()
         tw = timeit(wg)
-    print("C16 %s s%d d%d in %d^3 out %d^3: fwd %.1f us  dgrad %.1f us  wgrad %.1f us" % ("convT" if transposed else "conv ", stride, dil, si, so, tf, td, tw))
+    print("C%d %s s%d d%d in %d^3 out %d^3: fwd %.1f us  dgrad %.1f us  wgrad %.1f us" % (C, "convT" if transposed else "conv ", stride, dil, si, so, tf, td, tw))
 
 # the forward pair of a node as the net issues it: stride-1 + stride-2 conv from the same input level, with statistics
 S2 = S
