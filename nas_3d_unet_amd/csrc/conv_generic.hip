@@ -6,6 +6,7 @@
 // These kernels cover every shape of the path; the MFMA kernels in conv_mfma.hip take over the
 // FLOP-heavy 3x3x3 shapes.
 #include "n3d_common.h"
+#define N3D_WG16_SLABS 1024   // 256-float partial slabs reserved for the gemm16 weight-gradient kernels (+ one per tile)
 #include <algorithm>
 #include <vector>
 
@@ -1418,6 +1419,7 @@ int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
 struct Wg16Args;
 int wgrad_tile16_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                      float* partial, size_t avail_floats, int* nchunks_out, float** pbias_out, hipStream_t s);
+bool wgrad_tile16_plan(const n3d_conv_geom* g, int* chunks, int* tiles_per_wg);
 int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                    float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s,
                    Wg16Args* prepared = nullptr);
@@ -1469,10 +1471,11 @@ size_t n3d_conv_workspace_bytes(const n3d_conv_geom* g) {
     }
     if (g->Ci % 16 == 0 && g->Co % 16 == 0) {  // MFMA weight-gradient slabs (conv_mfma.hip)
       const size_t nt = (size_t)taps * (g->Ci / 16) * (g->Co / 16);
-      const size_t c = (1024 + nt) * (256 + 16) * 4;
+      const size_t c = (N3D_WG16_SLABS + nt) * (256 + 16) * 4;
       if (c > a) a = c;
-      if (g->k == 3 && g->Ci == 16 && g->Co == 16 && (int64_t)g->B * No >= 32768) {   // wgrad_tile16: <= 256 workgroup slabs
-        const size_t c2 = (size_t)256 * (27 * 256 + 16) * 4;
+      int chunks = 0, tpw = 0;
+      if (wgrad_tile16_plan(g, &chunks, &tpw)) {   // LDS-tile weight gradient: one slab set per chunk of tiles
+        const size_t c2 = ((size_t)chunks * nt * 256 + (size_t)chunks * (g->Co / 16) * 16) * 4;
         if (c2 > a) a = c2;
       }
     }
@@ -1697,7 +1700,7 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     const int h = wgrad_tile16_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, &pb, s);
     if (h == 1) {
       n3d_final_job job;
-      fill_job(deferred ? deferred : &job, wsf, pb, dw, dbias, nch, 27, 1, 1, 16, 16, 16, 16, 27);
+      fill_job(deferred ? deferred : &job, wsf, pb, dw, dbias, nch, 27 * (g->Ci / 16) * (g->Co / 16), g->Ci / 16, g->Co / 16, 16, 16, g->Co, g->Ci, 27);
       if (!deferred) if (int e = n3d_wgrad_finalize_batch(&job, 1, stream)) return e;
       N3D_LAUNCH_CHECK();
       return N3D_OK;
@@ -1706,9 +1709,9 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   if (!(flags & (N3D_NO_MFMA | N3D_ANY_BF16)) && xld % 4 == 0 && dyld % 4 == 0) {
     int nch = 0, ntl = 0;
     const size_t nt16 = (size_t)taps * (g->Ci / 16) * (g->Co / 16);
-    float* pb = wsf + (1024 + nt16) * 256;
+    float* pb = wsf + (N3D_WG16_SLABS + nt16) * 256;
     int handled = 0;
-    if (g->Ci % 16 == 0 && g->Co % 16 == 0 && (1024 + nt16) * (256 + 16) <= avail) {
+    if (g->Ci % 16 == 0 && g->Co % 16 == 0 && (N3D_WG16_SLABS + nt16) * (256 + 16) <= avail) {
       if (dual && dual->ws && dual->ws_bytes >= (size_t)taps * g->Ci * g->Co * 4) {
         if (!(dual->flags & N3D_PREPACKED)) mfma_pack16(dual->w, (float*)dual->ws, g->Co, g->Ci, taps, transposed ? 0 : 1, s);
         // run_wgrad's (x, dy) are kernel roles (i side, o side); a transposed conv's output gradient sits on the i side
@@ -1716,11 +1719,11 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
         const float* true_x = transposed ? dy : x; const int64_t true_xld = transposed ? dyld : xld;
         handled = mfma_bwd_dual_try(g, transposed, true_dy, true_dyld, (const float*)dual->ws, dual->dx, dual->dxld, dual->flags,
                                     dual->relu_src, dual->rld, dual->out_gate, true_x, true_xld, flags, in_gate, wsf, pb,
-                                    (1024 + nt16) * 256, &nch, &ntl, s);
+                                    (N3D_WG16_SLABS + nt16) * 256, &nch, &ntl, s);
         if (handled < 0) return handled;
         if (handled == 1) dual->done = true;
       }
-      if (!handled) handled = mfma_wgrad_try(g, x, xld, dy, dyld, flags, in_gate, wsf, pb, (1024 + nt16) * 256, &nch, &ntl, s);
+      if (!handled) handled = mfma_wgrad_try(g, x, xld, dy, dyld, flags, in_gate, wsf, pb, (N3D_WG16_SLABS + nt16) * 256, &nch, &ntl, s);
     }
     if (handled == 1) {
       n3d_final_job job;
@@ -1955,10 +1958,10 @@ int n3d_conv_bwd_both2(const n3d_conv_bwd_call* c0, const n3d_conv_bwd_call* c1,
       float* wsf = (float*)((char*)c->ws_weight + skip);
       const size_t avail = (c->ws_weight_bytes - skip) / 4;
       const size_t nt16 = (size_t)taps * (g->Ci / 16) * (g->Co / 16);
-      if ((1024 + nt16) * (256 + 16) > avail) { quad = false; break; }
+      if ((N3D_WG16_SLABS + nt16) * (256 + 16) > avail) { quad = false; break; }
       b[i] = BwdOne{g, c->transposed != 0, c->dy, c->dyld, (const float*)c->ws_data, c->dx, c->dxld, c->flags_data & ~N3D_RELU_IN,
                     c->relu_src, c->rld, c->out_gate, c->x, c->xld, c->transposed ? (c->flags_weight & ~N3D_RELU_IN) : c->flags_weight,
-                    c->in_gate, wsf, wsf + (1024 + nt16) * 256, (1024 + nt16) * 256, 0, 0};
+                    c->in_gate, wsf, wsf + (N3D_WG16_SLABS + nt16) * 256, (N3D_WG16_SLABS + nt16) * 256, 0, 0};
     }
   }
   if (quad) {

@@ -2330,7 +2330,8 @@ int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const fl
   a.tci = g->Ci / 16; a.tco = g->Co / 16;
   const int ntiles = taps * a.tci * a.tco;
   // aim for ~1024 workgroups; each needs at least 64 voxels to amortise the LDS reduction
-  int64_t nch = cdiv(1024, ntiles);
+  static const int wg_target = getenv("N3D_WG16_TARGET") ? atoi(getenv("N3D_WG16_TARGET")) : 1024;   // (tuning knob)
+  int64_t nch = cdiv(wg_target, ntiles);
   if (nch < 1) nch = 1;
   int64_t maxch = cdiv(total, 64);
   if (nch > maxch) nch = maxch;
@@ -2362,9 +2363,10 @@ struct WgT16Args {
   const float* x; int64_t xld; const float* dy; int64_t dyld;
   int D, H, W, B, flags;
   const float* in_gate;
-  float* partial;   // [nwg][27][256]
-  float* pbias;     // [nwg][16]
+  float* partial;   // [chunks][27 * tci * tco][256]   (tile index (tap * tci + cit) * tco + cot, as conv_wgrad16_kernel)
+  float* pbias;     // [chunks][tco][16]
   int tiles_per_sample, tiles_total, tiles_per_wg;
+  int Ci, Co;       // multiples of 16: blockIdx.y = cit * tco + cot selects the 16 x 16 channel tile of this workgroup
   const void* zero_page;
 };
 
@@ -2378,6 +2380,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, kk = lane >> 4;
   const int tap0 = wave * 7, ntap = wave < 3 ? 7 : 6;
+  const int tci = a.Ci >> 4, tco = a.Co >> 4;
+  const int cit = (int)blockIdx.y / tco, cot = (int)blockIdx.y - cit * tco;
   const int D = a.D, H = a.H, W = a.W;
   const int tw_n = W / TW, th_n = H / TH;
   const int64_t N = (int64_t)D * H * W;
@@ -2396,15 +2400,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
     // B operand: channel m of voxel 4*xq + kk of every row of the tile (32 groups), straight from global memory
     float bv[32];
     {
-      const float* dyb = a.dy + ((int64_t)b * N + ((int64_t)d0 * H + h0) * W + w0 + kk) * a.dyld + m;
+      const float* dyb = a.dy + ((int64_t)b * N + ((int64_t)d0 * H + h0) * W + w0 + kk) * a.dyld + cot * 16 + m;
 #pragma unroll
       for (int gi = 0; gi < 32; ++gi) {
         const int row = gi >> 2, xq = gi & 3, z = row >> 2, y = row & 3;
         bv[gi] = dyb[(((int64_t)z * H + y) * W + xq * 4) * a.dyld];
       }
     }
-    const float gq = a.in_gate ? a.in_gate[(int64_t)b * 16 + m] : 1.f;
-    {  // X halo tile by LDS-DMA (as conv_tile16_kernel)
+    const float gq = a.in_gate ? a.in_gate[(int64_t)b * a.Ci + cit * 16 + m] : 1.f;
+    {  // X halo tile (the 16 input channels of this workgroup's tile) by LDS-DMA, as conv_tile16_kernel
       typedef const __attribute__((address_space(1))) void* gptr_t;
       typedef __attribute__((address_space(3))) void* lptr_t;
       const float4* zp = reinterpret_cast<const float4*>(a.zero_page);
@@ -2416,7 +2420,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
         const int x = v % LW, y = (v / LW) % LH, z = v / (LW * LH);
         const int gd = d0 - DIL + z, gh = h0 - DIL + y, gw = w0 - DIL + x;
         const bool ok = v < NV && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-        const float* sp = srcb + (((int64_t)gd * H + gh) * W + gw) * a.xld + q * 4;
+        const float* sp = srcb + (((int64_t)gd * H + gh) * W + gw) * a.xld + cit * 16 + q * 4;
         __builtin_amdgcn_global_load_lds((gptr_t)(ok ? reinterpret_cast<const float4*>(sp) : zp), (lptr_t)(wt16 + (i * 4 + wave) * 64), 16, 0, 0);
       }
     }
@@ -2447,43 +2451,62 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     if (t < ntap) {
-      float* p = a.partial + ((int64_t)blockIdx.x * 27 + tap0 + t) * 256;
+      float* p = a.partial + (((int64_t)blockIdx.x * 27 + tap0 + t) * tci * tco + (int64_t)cit * tco + cot) * 256;
 #pragma unroll
       for (int r = 0; r < 4; ++r) p[(kk * 4 + r) * 16 + m] = acc[t][0][r] + acc[t][1][r];
     }
   }
-  if (wave == 0) {
+  if (wave == 0 && cit == 0) {
     bsum = xsum32_f(xsum16_f(bsum));
-    if (kk == 0) a.pbias[(int64_t)blockIdx.x * 16 + m] = bsum;
+    if (kk == 0) a.pbias[((int64_t)blockIdx.x * tco + cot) * 16 + m] = bsum;
   }
 }
 
 #define N3D_WGT16_MAX_WG 256
-// 1 = launched (partial slabs [nwg][27][256] at `partial`, bias rows [nwg][16] behind them), 0 = shape not served
+// plan of the LDS-tile weight gradient: chunks (grid.x) and tiles per workgroup; false = shape not served.
+// Served: 3x3x3 stride-1 convs (dilation 1 / 2) with channel counts multiples of 16 (<= 64) on tileable volumes with enough tiles x
+// channel tiles to fill a good part of the chip -- below that the K-split kernels (one launch for data + weight gradient) win.
+bool wgrad_tile16_plan(const n3d_conv_geom* g, int* chunks, int* tiles_per_wg) {
+  static const bool off = getenv("N3D_NO_TILE16") != nullptr;   // (A/B knob)
+  static const int min_units = getenv("N3D_WGT16_MIN") ? atoi(getenv("N3D_WGT16_MIN")) : 256;   // (tuning knob)
+  if (off || g->depthwise || g->k != 3 || g->stride != 1 || g->Ci % 16 != 0 || g->Co % 16 != 0 || g->Ci > 64 || g->Co > 64) return false;
+  if ((g->dil != 1 && g->dil != 2) || g->pad != g->dil) return false;
+  if (g->Wi % 16 != 0 || g->Hi % 4 != 0 || g->Di % 2 != 0) return false;
+  const int64_t tiles_total = (int64_t)(g->Wi / 16) * (g->Hi / 4) * (g->Di / 2) * g->B;
+  const int combos = (g->Ci / 16) * (g->Co / 16);
+  if (tiles_total * combos < min_units || tiles_total >= (1 << 30)) return false;
+  int64_t nx = N3D_WGT16_MAX_WG / combos;
+  if (nx < 1) nx = 1;
+  if (nx > tiles_total) nx = tiles_total;
+  const int64_t tpw = cdiv(tiles_total, nx);
+  *tiles_per_wg = (int)tpw;
+  *chunks = (int)cdiv(tiles_total, tpw);
+  return true;
+}
+
+// 1 = launched (partial slabs [chunks][27 * tci * tco][256] at `partial`, bias rows [chunks][tco][16] behind them), 0 = shape not served
 int wgrad_tile16_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                      float* partial, size_t avail_floats, int* nchunks_out, float** pbias_out, hipStream_t s) {
-  static const bool off = getenv("N3D_NO_TILE16") != nullptr;   // (A/B knob)
-  if (off || g->depthwise || g->k != 3 || g->stride != 1 || g->Ci != 16 || g->Co != 16 || (g->dil != 1 && g->dil != 2) || g->pad != g->dil) return 0;
-  if (g->Wi % 16 != 0 || g->Hi % 4 != 0 || g->Di % 2 != 0 || xld % 4 != 0 || !aligned16(x)) return 0;
-  if (flags & (N3D_SRC_BF16 | N3D_DST_BF16 | N3D_NO_MFMA)) return 0;
-  const int tiles_per_sample = (g->Wi / 16) * (g->Hi / 4) * (g->Di / 2);
-  const int64_t tiles_total = (int64_t)tiles_per_sample * g->B;
-  if (tiles_total < 256 || tiles_total >= (1 << 30)) return 0;     // >= 32768 voxels: below, the K-split kernels are faster
-  const int nwg = tiles_total < N3D_WGT16_MAX_WG ? (int)tiles_total : N3D_WGT16_MAX_WG;
-  if ((size_t)nwg * (27 * 256 + 16) > avail_floats) return 0;
+  int chunks = 0, tpw = 0;
+  if (!wgrad_tile16_plan(g, &chunks, &tpw)) return 0;
+  if (xld % 4 != 0 || !aligned16(x) || (flags & (N3D_SRC_BF16 | N3D_DST_BF16 | N3D_NO_MFMA))) return 0;
+  const int tci = g->Ci / 16, tco = g->Co / 16;
+  const size_t slabs = (size_t)chunks * 27 * tci * tco;
+  if (slabs * 256 + (size_t)chunks * tco * 16 > avail_floats) return 0;
   WgT16Args a;
   a.x = x; a.xld = xld; a.dy = dy; a.dyld = dyld; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.B = g->B; a.flags = flags; a.in_gate = in_gate;
-  a.partial = partial; a.pbias = partial + (size_t)nwg * 27 * 256;
-  a.tiles_per_sample = tiles_per_sample; a.tiles_total = (int)tiles_total; a.tiles_per_wg = (int)cdiv(tiles_total, nwg);
+  a.partial = partial; a.pbias = partial + slabs * 256;
+  a.tiles_per_sample = (g->Wi / 16) * (g->Hi / 4) * (g->Di / 2); a.tiles_total = a.tiles_per_sample * g->B; a.tiles_per_wg = tpw;
+  a.Ci = g->Ci; a.Co = g->Co;
   a.zero_page = zero_page_ptr();
   if (!a.zero_page) return 0;
   const int d = g->dil;
   const int nv = (2 + 2 * d) * (4 + 2 * d) * (16 + 2 * d);
   const size_t shm = (size_t)((nv * 4 + 255) / 256) * 256 * 16;
-  const int grid = (int)cdiv(tiles_total, a.tiles_per_wg);
-  if (d == 1) hipLaunchKernelGGL(wgrad_tile16_kernel<1>, dim3(grid), dim3(256), shm, s, a);
-  else hipLaunchKernelGGL(wgrad_tile16_kernel<2>, dim3(grid), dim3(256), shm, s, a);
-  *nchunks_out = grid; *pbias_out = a.pbias;
+  const dim3 grid((unsigned)chunks, (unsigned)(tci * tco));
+  if (d == 1) hipLaunchKernelGGL(wgrad_tile16_kernel<1>, grid, dim3(256), shm, s, a);
+  else hipLaunchKernelGGL(wgrad_tile16_kernel<2>, grid, dim3(256), shm, s, a);
+  *nchunks_out = chunks; *pbias_out = a.pbias;
   return 1;
 }
 

@@ -28,6 +28,10 @@ CASES = [
     (16, 16, 3, 1, 1, False, 2, (32, 32, 32)),   # the C = 16 level of a 128^3 patch (>= 256 tiles: LDS-tile weight gradient too)
     (16, 16, 3, 1, 2, False, 2, (16, 32, 32)),
     (16, 16, 3, 1, 1, False, 3, (12, 32, 32)),   # 576 tiles over 256 workgroups: ragged tiles-per-workgroup, workgroups span samples
+    (32, 32, 3, 1, 1, False, 2, (16, 16, 16)),   # 64 tiles x 4 channel tiles: the LDS-tile weight gradient on 32 channels
+    (32, 32, 3, 1, 2, False, 2, (16, 16, 16)),
+    (32, 16, 3, 1, 1, False, 2, (16, 16, 32)),   # Ci != Co
+    (16, 48, 3, 1, 1, False, 1, (16, 32, 32)),
     # tile16_up: transposed forward / stride-2 data gradient of the 16-channel level with >= 32k destination voxels
     (16, 16, 3, 2, 1, True, 2, (8, 16, 32)),
     (16, 16, 3, 2, 2, True, 2, (8, 16, 32)),
