@@ -361,6 +361,10 @@ struct K1Args {
   // up: the data gradient of a stride-2 1x1x1 conv -- destination voxel (d,h,w) takes source voxel (d/2,h/2,w/2) when all three
   // are even and nothing otherwise; Ns = source voxels per sample
   int up, Wd, Hd; int64_t Ns; FastDiv fWd, fHd;
+  // flat: the destination is dense (dld == Cd) with >= 2 quads per voxel and 16-byte aligned 64-voxel runs: a wave transposes its
+  // 64 voxel records through LDS and writes them as consecutive 16-byte pieces (per-voxel stores of a 12-channel tensor put 16 bytes
+  // on every 48-byte pitch: three partial-line instructions per line)
+  int flat;
 };
 constexpr int K1_VPB = 1024;   // voxels per workgroup
 
@@ -370,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
   constexpr int VPT = EXTRA ? 2 : K1_VPB / 256;   // data-gradient form: no statistics rows to agree on, fewer registers per voxel
   __shared__ __attribute__((aligned(16))) float4 wl[CSQ * 4 * CDQ];
   __shared__ double red[4][CDQ * 8];
+  __shared__ __attribute__((aligned(16))) TD stage[CDQ >= 2 ? 4 * 64 * CDQ * 4 : 4];   // [wave][voxel][Cd]
   const int t = threadIdx.x, b = blockIdx.y;
   for (int i = t; i < CSQ * 4 * CDQ; i += 256) {
     const int cs = i / CDQ, q = i - cs * CDQ;
@@ -454,10 +459,42 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
         r.x += prev[i][q].x; r.y += prev[i][q].y; r.z += prev[i][q].z; r.w += prev[i][q].w;
       }
       if (ok[i]) {
-        st4(db + (base + i * 256) * a.dld + q * 4, r);
+        if (CDQ >= 2 && a.flat) st4(stage + ((t >> 6) * 64 + (t & 63)) * (CDQ * 4) + q * 4, r);
+        else st4(db + (base + i * 256) * a.dld + q * 4, r);
         s1[q * 4] += r.x; s1[q * 4 + 1] += r.y; s1[q * 4 + 2] += r.z; s1[q * 4 + 3] += r.w;
         s2[q * 4] = fmaf(r.x, r.x, s2[q * 4]); s2[q * 4 + 1] = fmaf(r.y, r.y, s2[q * 4 + 1]);
         s2[q * 4 + 2] = fmaf(r.z, r.z, s2[q * 4 + 2]); s2[q * 4 + 3] = fmaf(r.w, r.w, s2[q * 4 + 3]);
+      }
+    }
+    if constexpr (CDQ >= 2) {
+      if (a.flat) {
+        // the wave's 64 voxels (base + i*256 + lane) are one contiguous run of the dense destination
+        const int wave = t >> 6, lane = t & 63;
+        const int64_t v0 = (int64_t)blockIdx.x * (VPT * 256) + i * 256 + wave * 64;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (v0 < a.N) {
+          const int64_t nvox = a.N - v0 < 64 ? a.N - v0 : 64;
+          const int npieces = (int)(nvox * (CDQ * 4) * (int)sizeof(TD) / 16);        // whole 16-byte pieces of the valid run
+          const uint4* sp = reinterpret_cast<const uint4*>(stage + wave * 64 * (CDQ * 4));
+          uint4* dp = reinterpret_cast<uint4*>(db + v0 * (CDQ * 4));
+          constexpr int NPC = 64 * CDQ * 4 * (int)sizeof(TD) / 16;
+#pragma unroll
+          for (int pc = 0; pc < (NPC + 63) / 64; ++pc) {
+            const int k = pc * 64 + lane;
+            if (k < npieces) dp[k] = sp[k];
+          }
+          // a run that ends in the middle of a piece (bf16, odd number of quads, ragged tail): the last voxels one by one
+          const int64_t done = (int64_t)npieces * 16 / ((CDQ * 4) * (int)sizeof(TD));
+          if (lane >= done && lane < nvox) {
+#pragma unroll
+            for (int q = 0; q < CDQ; ++q) st4(db + (v0 + lane) * (CDQ * 4) + q * 4, ld4(stage + (wave * 64 + lane) * (CDQ * 4) + q * 4));
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
   }
@@ -1567,6 +1604,13 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
       q.src = src; q.sld = sld; q.dst = dst; q.dld = dld; q.wp = a.wp; q.Cdp = a.Cdp; q.bias = bias; q.flags = flags; q.relu_src = relu_src;
       q.rld = rld; q.stats = stats; q.N = (int64_t)a.Dd * a.Hd * a.Wd;
       q.up = a.den == 2 ? 1 : 0; q.Wd = a.Wd; q.Hd = a.Hd; q.Ns = (int64_t)a.Ds * a.Hs * a.Ws; q.fWd = a.fWd; q.fHd = a.fHd;
+      {
+        static const bool noflat = getenv("N3D_K1_NOFLAT") != nullptr;   // (A/B knob)
+        const size_t esz = db16 ? 2 : 4;
+        // fp32 destinations only: measured at 2 x 128^3, 12-channel writes 54.5 -> 42.5 us (fp32) but 31.1 -> 35.2 us (bf16: the 8-byte LDS
+        // stores on a 24-byte pitch cost more than the partial-line stores they replace)
+        q.flat = (!noflat && !db16 && a.Cd >= 8 && dld == a.Cd && aligned16(dst) && ((size_t)q.N * a.Cd * esz) % 16 == 0) ? 1 : 0;
+      }
       const bool extra = (flags & N3D_ACCUMULATE) || relu_src || q.up;
       N3D_CHECK_ARG(!(extra && stats), "conv(1x1x1): statistics together with accumulate / relu mask are not supported");
       const dim3 grid((unsigned)cdiv(q.N, extra ? 512 : K1_VPB), (unsigned)g->B);
