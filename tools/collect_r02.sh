@@ -6,10 +6,10 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r02; mkdir -p $O
 python3 bench.py > $O/bench_line.log 2>&1
-tools/profile_r02.sh bench --steps 10 --warmup 3 --no-kernel-table
-tools/profile_r02.sh search --workload search --steps 5 --warmup 2 --no-kernel-table
-tools/profile_r02.sh p128_f32 --size 128 --steps 6 --warmup 2 --no-kernel-table
-tools/profile_r02.sh p128_bf16 --size 128 --dtype bf16 --steps 6 --warmup 2 --no-kernel-table
+tools/profile_r02.sh bench          # the default command itself: the roofline loop of the conv kernel is part of the profile
+tools/profile_r02.sh search --workload search --steps 5 --warmup 2 --no-kernel-table --no-cpu-baseline
+tools/profile_r02.sh p128_f32 --size 128 --steps 6 --warmup 2 --no-kernel-table --no-cpu-baseline
+tools/profile_r02.sh p128_bf16 --size 128 --dtype bf16 --steps 6 --warmup 2 --no-kernel-table --no-cpu-baseline
 python3 bench.py --workload search --steps 10 --warmup 3 > $O/search_stdout.log 2>&1
 python3 bench.py --size 128 --steps 20 --warmup 3 --no-cpu-baseline > $O/p128_f32_bench.log 2>&1
 python3 bench.py --size 128 --dtype bf16 --steps 20 --warmup 3 --no-cpu-baseline > $O/p128_bf16_bench.log 2>&1
