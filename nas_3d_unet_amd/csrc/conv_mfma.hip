@@ -574,8 +574,11 @@ extern "C" int n3d_debug_vox_stamps2(unsigned long long* host, int n) {
 // from ONE shared halo tile (6 x 10 x 18 positions instead of 2 x 6 x 6 x 18), which cuts the LDS-DMA instructions
 // per output voxel by 29 % -- the fill is bound by the texture-address path (16 cycles per 1 KiB instruction per CU).
 // The two waves split the fill chunk-wise and meet at ONE workgroup barrier before the MFMA phase.
+#ifndef VOX_LB
+#define VOX_LB 2
+#endif
 template <int C, int TD, int DIL, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void conv_vox64_kernel(VxArgs a) {
+__global__ __launch_bounds__(64 * NW, VOX_LB) void conv_vox64_kernel(VxArgs a) {
   constexpr int Q = C / 4, GH = 4 * NW, GW = 16;
   constexpr int LD = TD + 2 * DIL, LH = GH + 2 * DIL, LW = GW + 2 * DIL;
   constexpr int PLANE = LH * LW, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64, QSTRIDE = LD * PSTRIDE;
