@@ -200,6 +200,58 @@ def search_step_bench(args, device):
                    "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "loss_arch": round(float(la), 5), "loss_weight": round(float(lw), 5)}, **extra}), flush=True)
 
 
+def other_configs(device, batch, no_graph):
+    """The other single-GPU BASELINE configs, timed in the same process after the headline measurement (10 steps each after 3 warm-up
+    steps, HIP-graph replay) so that the driver's own run of the default command carries them: configs[2] (supernet search step at
+    4x64^3), the 4x128^3 train step in fp32 and configs[4] (4x128^3 with bf16 storage).  Each entry is a measurement or an error string."""
+    from nas_3d_unet_amd import nas, searched
+    from nas_3d_unet_amd.train import SearchTrainer, Trainer
+    out = {}
+
+    def timed(step, steps=10, warmup=3):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def search():
+        torch.manual_seed(1234)
+        net = nas.ShellNet(CFG["in_channels"], CFG["init_n_kernels"], CFG["out_channels"], CFG["depth"], CFG["n_nodes"], False, CFG["channel_change"]).to(device)
+        net.train()
+        tr = SearchTrainer(net, graph=not no_graph)
+        xn, tn = synthetic_batch(batch, 64, 1234)
+        vxn, vtn = synthetic_batch(batch, 64, 4321)
+        x, t, vx, vt = (torch.from_numpy(a).to(device) for a in (xn, tn, vxn, vtn))
+        x, vx = to_patch_layout(x), to_patch_layout(vx)
+        sec = timed(lambda: tr.step(x, t, vx, vt))
+        return {"ms_per_step": round(sec * 1e3, 3), "steps_per_s": round(1.0 / sec, 3), "patches_per_s": round(2 * batch / sec, 2)}
+
+    def train128(storage):
+        torch.manual_seed(1234)
+        net = searched.SearchedNet(CFG["in_channels"], CFG["init_n_kernels"], CFG["out_channels"], CFG["depth"], CFG["n_nodes"], CFG["channel_change"],
+                                   searched.Genotype(**G_CONV)).to(device)
+        net.train()
+        tr = Trainer(net, graph=not no_graph, storage=storage)
+        xn, tn = synthetic_batch(batch, 128, 1234)
+        x, t = to_patch_layout(torch.from_numpy(xn).to(device)), torch.from_numpy(tn).to(device)
+        sec = timed(lambda: tr.step(x, t))
+        return {"ms_per_step": round(sec * 1e3, 3), "patches_per_s": round(batch / sec, 2)}
+
+    for name, fn in (("configs[2]: nas.py supernet search step, batch 2 + 2, 4x64^3 fp32", search),
+                     ("searched.py train step, batch 2, 4x128^3 fp32", lambda: train128(None)),
+                     ("configs[4]: searched.py train step, batch 2, 4x128^3 bf16 storage", lambda: train128("bf16"))):
+        try:
+            out[name] = fn()
+        except Exception as e:   # the headline line must not depend on these
+            out[name] = "failed: %s" % (str(e)[:200],)
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +266,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip roofline_by_time (the per-entry-point time table of one step)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip other_configs (search step and the 128^3 train steps, timed after the headline run)")
     ap.add_argument("--buckets", type=int, default=None, help="gradient buckets of the data-parallel exchange (default: N3D_DP_BUCKETS or 1); "
                     ">= 2: all-reduce of a bucket on a side stream under the backward of the next one")
     ap.add_argument("--comm", choices=["torch", "rccl"], default=None, help="all-reduce through torch.distributed (default) or the C ABI's n3d_comm_*")
@@ -295,6 +348,10 @@ def main():
             out["launches_per_step"] = ncalls
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.size)
+        if world == 1 and not args.no_other_configs and args.size == 64 and args.dtype == "f32":
+            del trainer
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(device, args.batch, args.no_graph)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

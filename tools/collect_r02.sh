@@ -14,7 +14,7 @@ python3 bench.py --workload search --steps 10 --warmup 3 > $O/search_stdout.log 
 python3 bench.py --size 128 --steps 20 --warmup 3 --no-cpu-baseline > $O/p128_f32_bench.log 2>&1
 python3 bench.py --size 128 --dtype bf16 --steps 20 --warmup 3 --no-cpu-baseline > $O/p128_bf16_bench.log 2>&1
 for v in "N3D_X=1" "N3D_FORCE_DP=1" "N3D_FORCE_DP=1 N3D_DP_BUCKETS=2" "N3D_FORCE_DP=1 N3D_COMM=rccl" "N3D_FORCE_DP=1 N3D_DP_BUCKETS=2 N3D_COMM=rccl"; do
-  echo "== $v"; env $v python3 bench.py --steps 100 --warmup 10 --no-roofline --no-cpu-baseline --no-kernel-table 2>&1 | grep metric | cut -c1-330
+  echo "== $v"; env $v python3 bench.py --steps 100 --warmup 10 --no-roofline --no-cpu-baseline --no-kernel-table --no-other-configs 2>&1 | grep metric | cut -c1-330
 done > $O/dp_variants.log 2>&1
 grep -h metric $O/bench_line.log | cut -c1-200
 ls $O
