@@ -511,7 +511,9 @@ class SearchTrainer:
         self.lr_kernel = float(lr)
         self.lr_kernel_dev.fill_(self.lr_kernel)
 
-    def _pass(self, x, t, arch, update=True):
+    def _pass(self, x, t, arch, update=True, pack=True):
+        """pack=False: the conv weights were packed by the pass before and have not changed since (the weight pass of a step
+        follows the architecture pass, which only moves the alphas)"""
         for p in self.kparams:
             p.requires_grad_(not arch)
         for p in self.aparams:
@@ -519,7 +521,8 @@ class SearchTrainer:
         if arch:
             self.agrad.zero_()  # alpha gradients arrive through autograd accumulation (softmax backward)
         with K.step_context(self.ctx):
-            self.ctx.pack_all()
+            if pack:
+                self.ctx.pack_all()
             loss = _loss_of(self.model, self.loss_fn, x, t)
             prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True
             try:
@@ -547,7 +550,7 @@ class SearchTrainer:
 
     def _both(self, x, t, vx, vt, update=True):
         la = self._pass(vx, vt, True, update)
-        lw = self._pass(x, t, False, update)
+        lw = self._pass(x, t, False, update, pack=False)   # same weights as the architecture pass just packed
         return la, lw
 
     def step(self, x, t, val_x, val_t):
@@ -572,7 +575,7 @@ class SearchTrainer:
                 with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
                     la = self._pass(self._svx, self._svt, True, update=False)
                 with torch.cuda.graph(gw, pool=pool, capture_error_mode="thread_local"):
-                    lw = self._pass(self._sx, self._st, False, update=False)
+                    lw = self._pass(self._sx, self._st, False, update=False, pack=False)
                 self._losses, self._graphs = (la, lw), (ga, gw)
             else:
                 g = torch.cuda.CUDAGraph()
