@@ -997,6 +997,99 @@ __global__ void channel_sum_final_kernel(const float* __restrict__ partial, int 
 
 
 // ------------------------------------------------------------------------------------------------
+// depthwise 3x3x3 stride-1 weight gradient on tileable volumes: dW[c][tap] = sum_v x[v + tap][c] * dy[v][c].
+// dw_wgrad_kernel reads its 27 neighbours per voxel from global memory (432 bytes per voxel and channel quad through L1 / L2)
+// and pays a 112-value wave reduction per 512 voxels.  Here a workgroup stages the halo tile of one channel quad for 4 x 4 x 16
+// output voxels in LDS (LDS-DMA), a thread owns one voxel (27 ds_read_b128 + 108 FMAs), walks several tiles and reduces once.
+// One workgroup column per channel quad (blockIdx.y).  Same partial-slab layout as dw_wgrad_kernel.
+// ------------------------------------------------------------------------------------------------
+__device__ float4 n3d_dw_zero_page[1];   // zero-initialised source of the padding for the LDS-DMA fill
+static const void* dw_zero_page() {
+  static thread_local const void* p = nullptr;
+  static thread_local int dev = -1;
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) return nullptr;
+  if (!p || d != dev) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(n3d_dw_zero_page)) != hipSuccess) return nullptr;
+    p = q; dev = d;
+  }
+  return p;
+}
+struct DwTileArgs {
+  const float* x; int64_t xld; const float* dy; int64_t dyld;
+  int D, H, W, B, C;
+  float* partial;  // [chunks][27][C]
+  float* pbias;    // [chunks][C]
+  int tiles_per_sample, tiles_total, tiles_per_wg;
+  const void* zero_page;
+};
+
+__global__ __launch_bounds__(256) void dw_wgrad_tile_kernel(DwTileArgs a) {
+  constexpr int TD = 4, TH = 4, TW = 16, LD = TD + 2, LH = TH + 2, LW = TW + 2, NV = LD * LH * LW, NIT = (NV + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float4 tl[NIT * 256];
+  __shared__ float red[4][28 * 4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int quad = blockIdx.y;
+  const int tx = t & 15, ty = (t >> 4) & 3, tz = t >> 6;   // this thread's voxel of the tile (a wave = one z plane)
+  const int D = a.D, H = a.H, W = a.W;
+  const int tw_n = W / TW, th_n = H / TH;
+  const int64_t N = (int64_t)D * H * W;
+  float4 acc[27], bs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const float4* zp = reinterpret_cast<const float4*>(a.zero_page);
+  for (int it = 0; it < a.tiles_per_wg; ++it) {
+    const int tg = (int)blockIdx.x * a.tiles_per_wg + it;
+    if (tg >= a.tiles_total) break;
+    const int b = tg / a.tiles_per_sample, tid = tg - b * a.tiles_per_sample;
+    const int w0 = (tid % tw_n) * TW, h0 = ((tid / tw_n) % th_n) * TH, d0 = (tid / (tw_n * th_n)) * TD;
+    const float4 g = *reinterpret_cast<const float4*>(a.dy + ((int64_t)b * N + ((int64_t)(d0 + tz) * H + h0 + ty) * W + w0 + tx) * a.dyld + quad * 4);
+    const float* xb = a.x + (int64_t)b * N * a.xld + quad * 4;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int v = (i * 4 + wave) * 64 + lane;
+      const int x = v % LW, y = (v / LW) % LH, z = v / (LW * LH);
+      const int gd = d0 - 1 + z, gh = h0 - 1 + y, gw = w0 - 1 + x;
+      const bool ok = v < NV && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+      const float* sp = xb + (((int64_t)gd * H + gh) * W + gw) * a.xld;
+      __builtin_amdgcn_global_load_lds((gptr_t)(ok ? reinterpret_cast<const float4*>(sp) : zp), (lptr_t)(tl + (i * 4 + wave) * 64), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const float4* c0 = tl + (tz * LH + ty) * LW + tx;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float4 q = c0[(kd * LH + kh) * LW + kw];
+          float4& r = acc[(kd * 3 + kh) * 3 + kw];
+          r.x = fmaf(q.x, g.x, r.x); r.y = fmaf(q.y, g.y, r.y); r.z = fmaf(q.z, g.z, r.z); r.w = fmaf(q.w, g.w, r.w);
+        }
+    bs.x += g.x; bs.y += g.y; bs.z += g.z; bs.w += g.w;
+    __syncthreads();   // the next tile's fill overwrites the image
+  }
+  // wave sums, then the four waves through LDS
+#pragma unroll
+  for (int k = 0; k < 28; ++k) {
+    const float4 v = k < 27 ? acc[k < 27 ? k : 0] : bs;
+    const float s0 = wave_sum_f(v.x), s1 = wave_sum_f(v.y), s2 = wave_sum_f(v.z), s3 = wave_sum_f(v.w);
+    if (lane == 0) { red[wave][k * 4] = s0; red[wave][k * 4 + 1] = s1; red[wave][k * 4 + 2] = s2; red[wave][k * 4 + 3] = s3; }
+  }
+  __syncthreads();
+  if (t < 28 * 4) {
+    const int k = t >> 2, j = t & 3;
+    const float s = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    if (k < 27) a.partial[((int64_t)blockIdx.x * 27 + k) * a.C + quad * 4 + j] = s;
+    else a.pbias[(int64_t)blockIdx.x * a.C + quad * 4 + j] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // batched weight packing / batched weight-gradient reduction: the job table travels BY VALUE in the kernel
 // arguments (graph-capturable, no device-side table to maintain), compacted to 16 / 36 bytes per job so that a whole
 // train step fits one 4 KB argument block: a pointer becomes (segment : 3 bits, float offset : 29 bits) against up to
@@ -1691,6 +1784,37 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     a.B = g->B; a.C = g->Ci; a.k = 3; a.stride = g->stride; a.pad = g->pad; a.partial = wsf;
     a.fNo = FastDiv((uint32_t)No); a.fWo = FastDiv((uint32_t)g->Wo); a.fHo = FastDiv((uint32_t)g->Ho);
     const int64_t total = (int64_t)g->B * No;
+    {
+      // tileable stride-1 shapes with enough (tile, channel quad) units: the LDS-tile kernel
+      static const bool notile = getenv("N3D_DW_NOTILE") != nullptr;   // (A/B knob)
+      const int quads = g->Ci / 4;
+      if (!notile && g->k == 3 && g->stride == 1 && g->dil == 1 && g->pad == 1 && g->Wi % 16 == 0 && g->Hi % 4 == 0 && g->Di % 4 == 0 && g->Ci % 4 == 0 &&
+          xld % 4 == 0 && dyld % 4 == 0 && aligned16(x) && aligned16(dy)) {
+        const int tiles_per_sample = (g->Wi / 16) * (g->Hi / 4) * (g->Di / 4);
+        const int64_t tiles_total = (int64_t)tiles_per_sample * g->B;
+        const void* zp = dw_zero_page();
+        if (tiles_total * quads >= 64 && tiles_total < (1 << 30) && zp) {
+          int64_t nx = 256 / quads;
+          if (nx < 1) nx = 1;
+          if (nx > tiles_total) nx = tiles_total;
+          const int tpw = (int)cdiv(tiles_total, nx);
+          const int chunks = (int)cdiv(tiles_total, tpw);
+          if ((size_t)chunks * 28 * g->Ci <= avail) {
+            DwTileArgs q;
+            q.x = x; q.xld = xld; q.dy = dy; q.dyld = dyld; q.D = g->Di; q.H = g->Hi; q.W = g->Wi; q.B = g->B; q.C = g->Ci;
+            q.partial = wsf; q.pbias = wsf + (size_t)chunks * 27 * g->Ci;
+            q.tiles_per_sample = tiles_per_sample; q.tiles_total = (int)tiles_total; q.tiles_per_wg = tpw; q.zero_page = zp;
+            hipLaunchKernelGGL(dw_wgrad_tile_kernel, dim3((unsigned)chunks, (unsigned)quads), dim3(256), 0, s, q);
+            n3d_final_job job;
+            fill_job(&job, q.partial, q.pbias, dw, dbias, chunks, 27, 1, 1, 1, g->Ci, g->Ci, 1, 27);
+            if (deferred) *deferred = job;
+            else if (int e = n3d_wgrad_finalize_batch(&job, 1, stream)) return e;
+            N3D_LAUNCH_CHECK();
+            return N3D_OK;
+          }
+        }
+      }
+    }
     // short chunks (the voxel loop is a dependent load -> FMA chain): about two trips per thread -- a workgroup covers
     // 256 / (C/4) voxels per trip, so wide channel counts need far smaller chunks than 512 voxels; bounded by the slab workspace
     const int64_t vpb = 256 / (a.C / 4) > 0 ? 256 / (a.C / 4) : 1;

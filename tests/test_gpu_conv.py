@@ -190,7 +190,10 @@ def test_conv_family(cin, cout, k, stride, dil, transposed, B, shape):
 
 
 @pytest.mark.parametrize("c,stride,transposed,shape", [(4, 1, False, (6, 8, 10)), (8, 2, False, (8, 8, 8)), (16, 2, True, (4, 4, 6)),
-                                                         (64, 1, False, (2, 2, 2)), (32, 2, True, (2, 2, 2))])
+                                                         (64, 1, False, (2, 2, 2)), (32, 2, True, (2, 2, 2)),
+                                                         # LDS-tile weight gradient: W % 16 == 0, H % 4 == 0, D % 4 == 0, >= 64 (tile, quad) units
+                                                         (4, 1, False, (16, 16, 32)), (8, 1, False, (8, 12, 32)), (16, 1, False, (16, 16, 16)),
+                                                         (12, 1, False, (12, 8, 48))])
 def test_depthwise_family(c, stride, transposed, shape):
     from nas_3d_unet_amd import kernels as K
     B = 2
