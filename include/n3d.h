@@ -434,6 +434,21 @@ int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t* step_ptr,
                   int inc_step, void* stream);
 
+/* ---- stream hand-off (no reference counterpart: the reference runs one CUDA stream, train.py:117-128) ----------------
+ * Device-side ordering between two HIP streams whose work was launched as SEPARATE graphs: the weight-gradient kernels of
+ * a train step run on a side stream next to the backward chain (train.Trainer).  On this stack an event between two graph
+ * launches costs ~190 us per hand-off and an intra-graph fork ~19 us per edge without overlap; a flag in device memory costs
+ * a ~2 us kernel on each side (tools/handoff_cost.cpp).
+ * Protocol: each stream owns a device uint32 STEP counter (starts at 1, bumped once per step by that stream's last sync
+ * call, bump != 0).  n3d_sync_signal stores *step to *flag (release, agent scope) behind everything enqueued so far on
+ * `stream`; n3d_sync_wait holds `stream` until *flag >= *step (its own stream's counter; wrap-safe compare), polling with
+ * one lane.  The poll is bounded: after max_polls tries (~0.3 us each) the wait gives up, adds 1 to *timeouts and lets the
+ * stream continue -- results are then wrong, the GPU is never hung; callers read *timeouts (train.Trainer.check_sync).
+ * The two streams must map to different hardware queues (a wait at the head of the queue that also carries the signal
+ * would time out); train.Trainer probes this once. */
+int n3d_sync_signal(void* flag, void* step, int bump, void* stream);
+int n3d_sync_wait(const void* flag, void* step, void* timeouts, int bump, int64_t max_polls, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

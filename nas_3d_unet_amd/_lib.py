@@ -191,6 +191,8 @@ PROTOTYPES = {
     "n3d_comm_allreduce_sum": (_i, [_p, _p, _i64, _p]),
     "n3d_comm_destroy": (_i, [_p]),
     "n3d_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _f, _p, _i, _p]),
+    "n3d_sync_signal": (_i, [_p, _p, _i, _p]),
+    "n3d_sync_wait": (_i, [_p, _p, _p, _i, _i64, _p]),
 }
 
 # flags (include/n3d.h)

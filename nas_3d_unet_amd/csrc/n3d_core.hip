@@ -13,7 +13,47 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace n3d
 
+// ---- device-side stream hand-off (include/n3d.h, "stream hand-off") --------------------------------------------------------
+// One lane publishes / polls a 32-bit step number in device memory.  The producing kernels of the hand-off are ordinary
+// predecessors of the signal kernel on its stream (a kernel boundary releases their stores at agent scope); the consumer
+// kernels are ordinary successors of the wait kernel on the other stream (a kernel boundary acquires).  The poll is a
+// relaxed agent-scope load with s_sleep between tries and is BOUNDED: a wait that gives up adds 1 to *timeouts and lets the
+// stream go on (wrong results, never a hung GPU); callers check the counter.
+namespace {
+__global__ void sync_signal_kernel(unsigned* flag, unsigned* step, int bump) {
+  unsigned s = *step;
+  __hip_atomic_store(flag, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (bump) *step = s + 1;
+}
+__global__ void sync_wait_kernel(const unsigned* flag, unsigned* step, unsigned* timeouts, int bump, long max_polls) {
+  unsigned want = *step;
+  bool ok = false;
+  for (long it = 0; it < max_polls; ++it) {
+    // steps are compared modulo 2^32 (the counters wrap after 4e9 steps)
+    if ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) { ok = true; break; }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (!ok) atomicAdd(timeouts, 1u);
+  if (bump) *step = want + 1;
+}
+}  // namespace
+
 extern "C" {
+int n3d_sync_signal(void* flag, void* step, int bump, void* stream) {
+  N3D_CHECK_ARG(flag && step, "n3d_sync_signal: null pointer");
+  hipLaunchKernelGGL(sync_signal_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned*)flag, (unsigned*)step, bump);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+int n3d_sync_wait(const void* flag, void* step, void* timeouts, int bump, int64_t max_polls, void* stream) {
+  N3D_CHECK_ARG(flag && step && timeouts, "n3d_sync_wait: null pointer");
+  N3D_CHECK_ARG(max_polls > 0, "n3d_sync_wait: max_polls must be positive (the poll is bounded by construction)");
+  hipLaunchKernelGGL(sync_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned*)flag, (unsigned*)step,
+                     (unsigned*)timeouts, bump, (long)max_polls);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
 const char* n3d_last_error(void) { return n3d::g_err; }
 int n3d_version(void) { return 1; }
 int n3d_device_ok(void) {

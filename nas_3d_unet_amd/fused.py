@@ -269,6 +269,8 @@ def _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_da
             (_, g0), (_, g1) = P.pair_backward(seg0, s0, seg1, s1, dnodes[node], (True, t0, a0), (True, t1, a1))
             put(seg1, g1)
             put(seg0, g0)
+            if NODE_DONE_HOOK is not None:
+                NODE_DONE_HOOK()
         flat = []
     else:
         flat = None
@@ -392,6 +394,8 @@ def _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_da
                                            pre.get(unit[0]) if len(unit) == 1 else None, pre_se.get(unit[0]) if len(unit) == 1 else None,
                                            len(unit) == 1 and unit[0] in pre_da)
                     put(seg, gl)
+            if NODE_DONE_HOOK is not None:
+                NODE_DONE_HOOK()
     for i in range(2):
         if not pre_started[i]:
             dpre[i].t.zero_()
@@ -487,6 +491,7 @@ WHOLE_NET = True  # nets run stems + cells as ONE autograd node (NetFn); False: 
 # into down_cells + up_cells; -1 = the stems, i.e. the end) has been launched -- the point where a gradient bucket can be handed
 # to the all-reduce while the backward of the remaining cells goes on (train.Trainer)
 CELL_DONE_HOOK = None
+NODE_DONE_HOOK = None   # called inside a searched cell's backward after every node (the side-stream schedule's finer cut points)
 
 
 class _NetPlan:

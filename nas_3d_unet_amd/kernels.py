@@ -198,6 +198,12 @@ class StepContext:
         self.jobs = None
         self.final = []
         self.keep = []
+        # deferred weight-gradient LAUNCHES (train.Trainer's side-stream schedule): with defer_wgrad the weight-gradient kernels
+        # nothing on the backward chain waits for are queued here (operands kept alive) and launched by flush_wgrads() on
+        # whatever stream is current then
+        self.defer_wgrad = False
+        self.wq = []
+        self.hold = []         # operands of launched-but-possibly-still-running side work, released by the trainer after the join
 
     # ---- weight packing
     def slot(self, w, g, data_grad, flags):
@@ -236,15 +242,51 @@ class StepContext:
             torch.cuda.current_stream().wait_stream(self.side)
             self.side_dirty = False
 
+    def mark(self, tag):
+        """a cut point in the queue: flush_wgrads calls on_mark(tag) when it gets there (the trainer puts a device-side wait)"""
+        self.wq.append(("mark", tag))
+
+    def queued(self):
+        """launches queued since the last mark"""
+        n = 0
+        for item in reversed(self.wq):
+            if item[0] == "mark":
+                break
+            n += 1
+        return n
+
+    def flush_wgrads(self, on_mark=None):
+        """launch every queued weight-gradient kernel on the CURRENT stream, in queue order (the caller orders the stream behind
+        the producers: on_mark(tag) at every mark)"""
+        q, self.wq = self.wq, []
+        n = 0
+        for item in q:
+            if item[0] == "mark":
+                if on_mark is not None:
+                    on_mark(item[1])
+                continue
+            launch, job, ws, keep = item
+            if _DROP_SIDE:      # timing probe only (tools/dbg/side_sweep.py): the main chain without its weight gradients
+                continue
+            launch(stream_ptr())
+            if job.nchunks > 0:
+                self.final.append(job)
+            self.hold.append((ws, keep))
+            n += 1
+        return n
+
     def flush_final(self):
+        if self.wq:
+            self.flush_wgrads()
         self.join()
         if self.final:
             arr = (FinalJob * len(self.final))(*self.final)
             check(_lib.load().n3d_wgrad_finalize_batch(arr, len(self.final), stream_ptr()), "n3d_wgrad_finalize_batch")
-        self.final, self.keep = [], []
+        self.final, self.keep, self.hold = [], [], []
 
 
 _ctx = None
+_DROP_SIDE = False
 
 
 class step_context:
@@ -261,6 +303,27 @@ class step_context:
     def __exit__(self, *exc):
         global _ctx
         _ctx = self.prev
+        return False
+
+
+def deferring():
+    """is the side-stream schedule queueing weight-gradient launches right now?"""
+    return _ctx is not None and _ctx.defer_wgrad
+
+
+class no_defer:
+    """with no_defer(): weight gradients launch in place (their dy operand is a buffer the backward chain goes on writing)"""
+
+    def __enter__(self):
+        self.ctx = _ctx
+        self.prev = _ctx.defer_wgrad if _ctx is not None else False
+        if _ctx is not None:
+            _ctx.defer_wgrad = False
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.defer_wgrad = self.prev
         return False
 
 
@@ -319,10 +382,22 @@ def conv_bwd_weight(g, x: View, dy: View, dw, dbias, flags=0, in_gate=None, tran
     lib = _lib.load()
     job = FinalJob() if (_ctx is not None and defer) else None
     jp = C.byref(job) if job is not None else None
+    if transposed and in_gate is not None:
+        raise N3DError("convT_bwd_weight: gate not supported")
+    if job is not None and _ctx.defer_wgrad:
+        # queued: launched by StepContext.flush_wgrads() (side stream); x / dy / ws stay alive until the trainer's join
+        if transposed:
+            def launch(sp, g=g, x=x, dy=dy, dw=dw, dbias=dbias, flags=flags, ws=ws, n=n, jp=jp):
+                check(lib.n3d_convT_bwd_weight(C.byref(g), x.p, x.ld, dy.p, dy.ld, ptr(dw), ptr(dbias), flags, ptr(ws), n, jp, sp),
+                      "n3d_convT_bwd_weight")
+        else:
+            def launch(sp, g=g, x=x, dy=dy, dw=dw, dbias=dbias, flags=flags, in_gate=in_gate, ws=ws, n=n, jp=jp):
+                check(lib.n3d_conv_bwd_weight(C.byref(g), x.p, x.ld, dy.p, dy.ld, ptr(dw), ptr(dbias), flags, ptr(in_gate), ptr(ws), n, jp, sp),
+                      "n3d_conv_bwd_weight")
+        _ctx.wq.append((launch, job, ws, (x.t, dy.t, in_gate, dw, dbias)))
+        return
     sp = _side_launch_ptr([x.t, dy.t, ws, in_gate]) if job is not None else stream_ptr()
     if transposed:
-        if in_gate is not None:
-            raise N3DError("convT_bwd_weight: gate not supported")
         check(lib.n3d_convT_bwd_weight(C.byref(g), x.p, x.ld, dy.p, dy.ld, ptr(dw), ptr(dbias), flags, ptr(ws), n, jp,
                                        sp), "n3d_convT_bwd_weight")
     else:
@@ -362,6 +437,14 @@ def conv_fwdN(calls):
 def conv_bwd_both2(calls):
     """Backward (data + weight gradient) of two convs, one launch where libn3d can fold them.
     calls = [(g, x, dy, w, dx, dw, dbias, flags_data, relu_src, out_gate, flags_weight, in_gate, transposed)] * 2"""
+    if deferring():
+        # side-stream schedule: only the data gradients stay on the backward chain (one launch where libn3d can fold them);
+        # the two weight gradients are queued
+        for (g, x, dy, w, dx, dw, dbias, flags_data, relu_src, out_gate, flags_weight, in_gate, transposed) in calls:
+            conv_bwd_weight(g, x, dy, dw, dbias, flags_weight, in_gate, transposed)
+        conv_bwd_data2([(g, dy, w, dx, flags_data, relu_src, out_gate, transposed)
+                        for (g, x, dy, w, dx, dw, dbias, flags_data, relu_src, out_gate, flags_weight, in_gate, transposed) in calls])
+        return
     cs, keep, jobs = [], [], []
     for (g, x, dy, w, dx, dw, dbias, flags_data, relu_src, out_gate, flags_weight, in_gate, transposed) in calls:
         _need_f32("conv_bwd_both2", x, dy, dx)
@@ -411,6 +494,10 @@ def conv_bwd_both(g, x: View, dy: View, w, dx: View, dw, dbias, flags_data=0, re
                   flags_weight=0, in_gate=None, transposed=False):
     """conv_bwd_data + conv_bwd_weight of one conv; one launch where libn3d can fold them."""
     _need_f32("conv_bwd_both", x, dy, dx)
+    if deferring() and not g.depthwise:
+        conv_bwd_weight(g, x, dy, dw, dbias, flags_weight, in_gate, transposed)      # queued for the side stream
+        conv_bwd_data(g, dy, w, dx, flags_data, relu_src, out_gate, transposed)
+        return
     wsd, wspd, nd, flags_data = _packed(w, g, not transposed, flags_data, dy.t.device)
     ws, n = _ws(g, x.t.device)
     job = FinalJob() if (_ctx is not None and not g.depthwise) else None
@@ -955,6 +1042,18 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_t, lr=1e-3, beta1=0.9, beta
     check(_lib.load().n3d_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, ptr(lr_dev),
                                     beta1, beta2, eps, weight_decay, grad_scale, ptr(step_t), 1 if inc_step else 0, stream_ptr()),
           "n3d_adam_step")
+
+
+# ------------------------------------------------------------------------------------------ stream hand-off
+def sync_signal(flag_ptr, step_ptr, bump=False):
+    """publish *step to *flag behind everything on the current stream (include/n3d.h, "stream hand-off"); pointers are ints"""
+    check(_lib.load().n3d_sync_signal(C.c_void_p(flag_ptr), C.c_void_p(step_ptr), 1 if bump else 0, stream_ptr()), "n3d_sync_signal")
+
+
+def sync_wait(flag_ptr, step_ptr, timeouts_ptr, bump=False, max_polls=5000000):
+    """hold the current stream until *flag >= *step (bounded poll: ~0.3 us per try)"""
+    check(_lib.load().n3d_sync_wait(C.c_void_p(flag_ptr), C.c_void_p(step_ptr), C.c_void_p(timeouts_ptr), 1 if bump else 0, int(max_polls),
+                                    stream_ptr()), "n3d_sync_wait")
 
 
 # ------------------------------------------------------------------------------------------ fused head

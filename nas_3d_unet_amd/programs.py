@@ -1005,7 +1005,10 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
             draw = K.like(raw)
             K.affine_act_bwd_apply(dout, raw, None, None, A, None, None, draw, fl)
         else:
-            draw = dout
+            # d(raw) IS the incoming gradient buffer, which the backward chain may go on accumulating into: no queued launch on it
+            with K.no_defer():
+                dx, wg = seg.weight.bwd(s.ws, dout, need_dx, dx_out, dx_acc)
+            return dx, list(wg) + extra
     dx, wg = seg.weight.bwd(s.ws, draw, need_dx, dx_out, dx_acc)
     return dx, list(wg) + extra
 

@@ -184,6 +184,164 @@ class GradSync:
                 self.reduce_range(i)
 
 
+_side_prio = [None]
+_side_streams = {}   # device index -> [side streams made so far]: trainers share them (every new HIP stream may become another
+                     # hardware queue, and with more queues than the scheduler keeps resident a spinning wait kernel is only
+                     # relieved at the end of a ~1 ms time slice)
+
+
+def _low_priority_stream(device):
+    """a stream of the LOWEST priority the runtime offers (the side work must not take compute units from the backward chain);
+    torch only exposes normal / high, so the stream is made through HIP and wrapped"""
+    if os.environ.get("N3D_SIDE_PRIORITY", "low") != "low":
+        return torch.cuda.Stream(device=device)
+    try:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        if _side_prio[0] is None:
+            lo, hi = C.c_int(0), C.c_int(0)
+            if hip.hipDeviceGetStreamPriorityRange(C.byref(lo), C.byref(hi)) != 0:
+                raise OSError("hipDeviceGetStreamPriorityRange")
+            _side_prio[0] = lo.value
+        with torch.cuda.device(device):
+            h = C.c_void_p()
+            if hip.hipStreamCreateWithPriority(C.byref(h), 1, _side_prio[0]) != 0 or not h.value:   # 1 = hipStreamNonBlocking
+                raise OSError("hipStreamCreateWithPriority")
+        return torch.cuda.ExternalStream(h.value, device=device)
+    except Exception:
+        return torch.cuda.Stream(device=device)
+
+
+class SideSchedule:
+    """Weight-gradient kernels on a SIDE HIP stream, tied to the backward chain by flags in device memory (include/n3d.h,
+    "stream hand-off"; round 3).
+
+    Nothing on the backward chain waits for a weight gradient until the slab reduction in front of Adam, and the chain is
+    latency-bound (a few workgroups per launch), so the chip has room for them next to it.  With `deferring()` active the
+    weight-gradient launches are queued (kernels.StepContext.wq); at a cut point -- the end of a node / cell of the backward
+    walk with at least `min_queue` launches queued, and the end of the walk -- the main stream stores the step number to a
+    flag and the queue gets a mark.  `launch_side()` (on the side stream) then issues, per mark, a one-lane wait kernel on
+    that flag followed by the queued kernels, and publishes a 'done' flag; `finish()` (main stream) waits for it and runs the
+    slab reduction.  Main chain, side work and tail are replayed as three separately launched HIP graphs: an event between
+    graph launches costs ~190 us per hand-off on this stack and an intra-graph fork ~19 us per edge without overlapping, a
+    flag costs a ~2 us kernel on each side (tools/handoff_cost.cpp).
+    Device words of `sync` (int32): [0] main-stream step, [1] time-outs, [2] side-stream step, [8 + i] flag of cut i,
+    [8 + JOIN] side work of this step done."""
+    JOIN = 100
+
+    def __init__(self, device, ctx, min_queue=None):
+        self.device, self.ctx = device, ctx
+        self.min_queue = int(os.environ.get("N3D_SIDE_MIN_QUEUE", "3")) if min_queue is None else int(min_queue)
+        self.sync = torch.zeros(128, dtype=torch.int32, device=device)
+        self.sync[0] = 1
+        self.sync[2] = 1
+        self.seen = 0
+        self.replays = 0
+        self.watch = None
+        self.stream = self._probe()
+
+    def ptr(self, i):
+        return self.sync.data_ptr() + 4 * i
+
+    def _probe(self):
+        """a side stream that really runs next to the current one: a few device-side ping-pongs must complete without a time-out
+        and fast (a wait kernel at the head of the hardware queue that also carries its signal only ends by its time-out; streams
+        that share a time-sliced queue hand over in ~1 ms instead of ~5 us).  Tries a few streams; None = schedule off."""
+        import time
+        main = torch.cuda.current_stream(self.device)
+        rounds = 8
+        pool = _side_streams.setdefault(self.device.index or 0, [])
+        for attempt in range(4):
+            if attempt < len(pool):
+                side = pool[attempt]         # a stream an earlier trainer of this process made: reuse before making another
+            else:
+                side = _low_priority_stream(self.device) if attempt < 2 else torch.cuda.Stream(device=self.device)
+                pool.append(side)
+            ok = True
+            for timed in (False, True):      # the first pass also loads the two kernels
+                probe = torch.zeros(4 + 2 * rounds, dtype=torch.int32, device=self.device)   # [0] step = 1, [1] time-outs, [4 + i] flags
+                probe[0] = 1
+                base = probe.data_ptr()
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                with torch.cuda.stream(side):
+                    for i in range(rounds):     # side waits for main's flag i, then publishes its own
+                        K.sync_wait(base + 4 * (4 + 2 * i), base, base + 4, False, 20000)   # <= ~10 ms each
+                        K.sync_signal(base + 4 * (5 + 2 * i), base, False)
+                with torch.cuda.stream(main):
+                    for i in range(rounds):
+                        K.sync_signal(base + 4 * (4 + 2 * i), base, False)
+                        K.sync_wait(base + 4 * (5 + 2 * i), base, base + 4, False, 20000)
+                torch.cuda.synchronize(self.device)
+                dt = time.perf_counter() - t0
+                ok = ok and int(probe[1].item()) == 0 and (not timed or dt < 5e-3)
+            if ok:
+                return side
+        return None
+
+    def check(self):
+        """raises if a device-side wait ever timed out (the results of that step would be wrong)"""
+        n = int(self.sync[1].item())
+        if n != self.seen:
+            self.seen = n
+            raise K.N3DError("side-stream schedule: %d device-side wait(s) timed out -- the two streams did not run concurrently; "
+                             "gradients of those steps are unreliable (N3D_SIDE_WGRAD=0 turns the schedule off)" % n)
+
+    class _Deferring:
+        def __init__(self, owner):
+            self.o = owner
+
+        def __enter__(self):
+            o = self.o
+            o._cuts = 0
+            o.ctx.defer_wgrad = True
+            self.prev = (_fused.CELL_DONE_HOOK, _fused.NODE_DONE_HOOK)
+            outer = self.prev[0]
+
+            def cell(k):
+                o.cut(final=k < 0)
+                if outer is not None:
+                    outer(k)
+            _fused.CELL_DONE_HOOK, _fused.NODE_DONE_HOOK = cell, o.cut
+            return o
+
+        def __exit__(self, *exc):
+            if exc[0] is None:
+                self.o.cut(final=True)     # whatever was queued after the last cut of the walk (still on the main stream)
+            self.o.ctx.defer_wgrad = False
+            _fused.CELL_DONE_HOOK, _fused.NODE_DONE_HOOK = self.prev
+            return False
+
+    def deferring(self):
+        """with side.deferring(): run forward + backward; weight-gradient launches are queued, flags stored at the cut points"""
+        return SideSchedule._Deferring(self)
+
+    def cut(self, final=False):
+        ctx = self.ctx
+        n = ctx.queued()
+        if n > 0 and (final or (n >= self.min_queue and self._cuts < self.JOIN - 1)):
+            K.sync_signal(self.ptr(8 + self._cuts), self.ptr(0), False)
+            ctx.wq.insert(len(ctx.wq) - n, ("mark", self._cuts))    # the wait goes IN FRONT of the launches it guards
+            ctx.wq.append(("mark", -1))                              # closes the group (no wait)
+            self._cuts += 1
+
+    def launch_side(self):
+        """on the side stream (the caller selects it): per group a device-side wait for the main stream's flag, then the queued
+        launches; at the end the 'done' flag of this step"""
+        def on_mark(tag):
+            if tag >= 0:
+                K.sync_wait(self.ptr(8 + tag), self.ptr(2), self.ptr(1), False)
+        with K.step_context(self.ctx):
+            self.ctx.flush_wgrads(on_mark)
+        K.sync_signal(self.ptr(8 + self.JOIN), self.ptr(2), True)
+
+    def finish(self):
+        """on the main stream: wait for the side stream's 'done' flag, then reduce the weight-gradient slabs (one launch)"""
+        K.sync_wait(self.ptr(8 + self.JOIN), self.ptr(0), self.ptr(1), True)
+        with K.step_context(self.ctx):
+            self.ctx.flush_final()
+
+
 class _Ctx:
     """stand-in for an autograd context when a Function's forward / backward are called directly (Trainer's pipeline)"""
 
@@ -213,6 +371,36 @@ def flatten_params(params, device=None):
     return flat, grad, offs
 
 
+def _dropout_states(model):
+    return [m._n3d_state for m in model.modules() if getattr(m, "_n3d_state", None) is not None]
+
+
+class _Snapshot:
+    """optimizer-visible state of a trainer (weights, Adam moments, step counters, dropout generators): taken before the
+    schedules are timed against each other on the real step, put back afterwards"""
+
+    def __init__(self, tensors):
+        self.tensors = [t for t in tensors if t is not None]
+        self.saved = [t.clone() for t in self.tensors]
+
+    def restore(self):
+        with torch.no_grad():
+            for t, v in zip(self.tensors, self.saved):
+                t.copy_(v)
+
+
+def _time_schedule(run, device, warm=2, reps=6):
+    import time
+    for _ in range(warm):
+        run()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize(device)
+    return (time.perf_counter() - t0) / reps
+
+
 class Trainer:
     """One searched-net (or any model built from nas_3d_unet_amd ops) training step.
 
@@ -221,8 +409,21 @@ class Trainer:
     n_buckets >= 2 (data parallel only): bucketed gradient exchange overlapped with backward, see the module docstring."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph=True, process_group=None,
-                 n_buckets=None, params=None, comm=None, storage=None):
+                 n_buckets=None, params=None, comm=None, storage=None, side_wgrad=None):
         self.model = model
+        # side_wgrad (default: N3D_SIDE_WGRAD, on): the weight-gradient kernels of the C in {4, 8} levels -- nothing on the
+        # backward chain waits for them -- are queued during the backward walk and launched on a SIDE HIP stream at a few cut
+        # points (cell boundaries), as separately launched graphs tied to the main chain by events; the streams join once,
+        # in front of the slab reduction + Adam.  (Round 3: two per-SAMPLE chains measured no gain -- batching already is that
+        # overlap -- while the step's DAG has this slack: tools/two_chain_probe.py, tools/seg_overlap.cpp.)
+        env = os.environ.get("N3D_SIDE_WGRAD", "1")
+        self.side_wgrad = (env != "0") if side_wgrad is None else bool(side_wgrad)
+        # graph mode captures BOTH schedules, times them on the real step and replays the faster one ("force": no comparison);
+        # a replayed step is re-timed every 256 steps and the trainer falls back to the plain graph if the side schedule degrades
+        # (e.g. another library created hardware queues and the two streams are time-sliced)
+        self._side_force = side_wgrad == "force" or (side_wgrad is None and env == "force")
+        self._use_side = False
+        self.schedule_times = None   # (plain seconds per step, side seconds per step) measured at capture
         if storage is not None:
             from . import unet as _unet
             _unet.set_storage(model, storage)   # "bf16": bf16 activation storage on the HBM-bound levels (BASELINE configs[4])
@@ -242,6 +443,7 @@ class Trainer:
         self.n_buckets = max(1, n_buckets)
         self._graph = None
         self._segments = None
+        self._side_graphs = None
         self._static_x = self._static_t = self._static_loss = None
         self.ctx = K.StepContext(self.device)  # batched weight packing + deferred wgrad reductions
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)  # read by the Adam kernel
@@ -252,6 +454,9 @@ class Trainer:
         # stream costs two cross-stream waits around a graph launch); N3D_COMM_STREAM=1 restores the hop
         want_cs = self.dp_path and (self._buckets is not None or os.environ.get("N3D_COMM_STREAM") == "1")
         self._comm_stream = torch.cuda.Stream(device=self.device) if (want_cs and self.device.type == "cuda") else None
+        self.side = SideSchedule(self.device, self.ctx) if (self.side_wgrad and self.device.type == "cuda") else None
+        if self.side is not None and self.side.stream is None:
+            self.side = None
         ranges = [r for _, r in self._buckets] if self._buckets is not None else None
         self.sync = GradSync(self.fp.grad, self.pg, 1, self._comm_stream, ranges, comm)
         if self.world > 1:
@@ -313,23 +518,27 @@ class Trainer:
             self.ctx.freeze()              # first pass only recorded which weights / layouts are needed
         return loss.detach()
 
-    def _pipeline(self, x, t, on_bucket):
+    def _pipeline(self, x, t, on_bucket=None, cell_hook=None):
         """forward + Dice + backward WITHOUT autograd: fused.NetFn and head.HeadDiceFn are called directly, so the backward walk
-        is one Python function on this thread and can hand over gradient buckets on the way: on_bucket(j) is called as soon as
-        every gradient of self._buckets[j] has been launched (its deferred weight-gradient reductions included)."""
+        is one Python function on this thread and can hand over work on the way.  Bucketed exchange: on_bucket(j) is called as
+        soon as every gradient of self._buckets[j] has been launched (its deferred weight-gradient reductions included).
+        Side-stream schedule: cell_hook(k) is called when the backward of cell k (-1: the stems, i.e. the end) has been launched."""
         from . import head as _head, programs as _P
         m = self.model
         plan = getattr(m, "_net_plan", None)
         if plan is None:
             plan = m._net_plan = _fused.net_plan(m, supernet=False)
         op = m.last_conv[0]
-        closes = {k: j for j, (k, _) in enumerate(self._buckets)}
+        if cell_hook is not None:
+            hook = cell_hook
+        else:
+            closes = {k: j for j, (k, _) in enumerate(self._buckets)}
 
-        def hook(k):
-            j = closes.get(k)
-            if j is not None:
-                self.ctx.flush_final()
-                on_bucket(j)
+            def hook(k):
+                j = closes.get(k)
+                if j is not None:
+                    self.ctx.flush_final()
+                    on_bucket(j)
 
         with torch.no_grad(), K.step_context(self.ctx):
             self.ctx.pack_all()
@@ -349,11 +558,36 @@ class Trainer:
             self.ctx.freeze()
         return loss
 
-    def _pipeline_ok(self, x):
+    def _direct_ok(self):
+        """can the step run as the autograd-free pipeline (a stems / cells / fusable-head net with the Dice loss)?"""
         from . import head as _head
         m = self.model
-        return (self._buckets is not None and _fused.WHOLE_NET and isinstance(self.loss_fn, WeightedDiceLoss)
-                and not hasattr(m, "kernel") and _head.fusable(m.last_conv, torch.empty((1, m.last_conv[0].conv.weight.shape[1], 1, 1, 1), device="meta")))
+        return (_fused.WHOLE_NET and isinstance(self.loss_fn, WeightedDiceLoss) and not hasattr(m, "kernel")
+                and all(hasattr(m, a) for a in ("stem0", "stem1", "down_cells", "up_cells", "last_conv"))
+                and _head.fusable(m.last_conv, torch.empty((1, m.last_conv[0].conv.weight.shape[1], 1, 1, 1), device="meta")))
+
+    def _pipeline_ok(self, x):
+        return self._buckets is not None and self._direct_ok()
+
+    def _side_ok(self):
+        return self.side is not None and self._buckets is None and self._direct_ok()
+
+    def check_sync(self):
+        """raises if a device-side wait of the side-stream schedule ever timed out"""
+        if self.side is not None:
+            self.side.check()
+
+    def _side_pass(self, x, t):
+        """the autograd-free pipeline with every deferrable weight-gradient launch queued (SideSchedule); returns the loss"""
+        with self.side.deferring():
+            return self._pipeline(x, t, cell_hook=_fused.CELL_DONE_HOOK)
+
+    def _side_step_eager(self, x, t):
+        loss = self._side_pass(x, t)
+        with torch.cuda.stream(self.side.stream):
+            self.side.launch_side()
+        self.side.finish()
+        return loss
 
     def _reduce_on_side(self, j):
         """bucket j is complete on the current stream: all-reduce it on the comm stream"""
@@ -377,6 +611,10 @@ class Trainer:
         if self.dp_path and self._pipeline_ok(x):
             loss = self._pipeline(x, t, self._reduce_on_side)
             torch.cuda.current_stream().wait_stream(self._comm_stream)
+        elif self._side_ok():
+            loss = self._side_step_eager(x, t)
+            if self.dp_path:
+                self._allreduce()
         else:
             loss = self._fwd_bwd(x, t)
             if self.dp_path:
@@ -388,7 +626,7 @@ class Trainer:
     def step(self, x, t):
         if not self.use_graph:
             return self._eager(x, t)
-        if self._graph is None and self._segments is None:
+        if self._graph is None and self._segments is None and self._side_graphs is None:
             self._capture(x, t)
         if x.shape != self._static_x.shape or t.shape != self._static_t.shape:
             # a batch of another shape (the reference's generator yields a smaller last batch of an epoch): the captured
@@ -396,6 +634,9 @@ class Trainer:
             return self._eager(x, t)
         self._static_x.copy_(x)
         self._static_t.copy_(t)
+        if self._use_side:
+            self._watched_side_replay()
+            return self._side_loss
         if self._segments is not None:
             # bucketed exchange: segment j's graph completes bucket j; its all-reduce runs on the comm stream under segment j+1
             for j, g in enumerate(self._segments):
@@ -410,10 +651,67 @@ class Trainer:
             self._update()
         return self._static_loss
 
+    def _replay_side(self):
+        # three graphs, no host-side cross-stream dependency: the streams meet through device flags (SideSchedule)
+        g_main, g_side, g_tail = self._side_graphs
+        g_main.replay()
+        with torch.cuda.stream(self.side.stream):
+            g_side.replay()
+        g_tail.replay()
+        if self.dp_path:
+            self._allreduce()
+            self._update()
+
+    def _replay_plain(self):
+        self._graph.replay()
+        if self.dp_path:
+            self._allreduce()
+            self._update()
+
+    def _watched_side_replay(self):
+        """one replayed step of the side schedule.  Every 256th one is bracketed with events; one step later (no host wait on the
+        fast path) the trainer checks the time-outs of the device-side waits (raises) and that step's GPU time against the plain
+        schedule's measured time -- a side schedule that has become slower than the plain graph is dropped."""
+        sd = self.side
+        sd.replays += 1
+        if sd.replays % 256 == 0:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._replay_side()
+            e1.record()
+            sd.watch = (e0, e1)
+            return
+        self._replay_side()
+        if sd.watch is not None:
+            e0, e1 = sd.watch
+            sd.watch = None
+            e1.synchronize()
+            sd.check()
+            if self.schedule_times is not None and e0.elapsed_time(e1) * 1e-3 > 1.5 * self.schedule_times[0] + 2e-4:
+                import warnings
+                warnings.warn("nas_3d_unet_amd: the side-stream schedule degraded (%.2f ms per step against %.2f ms for the plain graph); "
+                              "falling back to the plain graph" % (e0.elapsed_time(e1), self.schedule_times[0] * 1e3))
+                self._use_side = False
+
+    def _choose_schedule(self):
+        """time the two captured schedules on the real step (state saved and restored around it) and keep the faster one"""
+        if self._side_force:
+            self._use_side = True
+            return
+        snap = _Snapshot([self.fp.flat, self.fp.exp_avg, self.fp.exp_avg_sq, self.fp.step, self.fp.grad] + _dropout_states(self.model))
+        tp = _time_schedule(self._replay_plain, self.device)
+        ts = _time_schedule(self._replay_side, self.device)
+        self.side.check()
+        snap.restore()
+        torch.cuda.synchronize(self.device)
+        self.schedule_times = (tp, ts)
+        self._use_side = ts < tp
+
     def _capture(self, x, t):
         self._static_x = x.clone()
         self._static_t = t.clone()
         segmented = self.dp_path and self._pipeline_ok(x)
+        sided = not segmented and self._side_ok()
         # warm-up on a side stream (allocator + lazy module state); no optimizer launch, the weights stay as they are
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
@@ -422,17 +720,56 @@ class Trainer:
                 if segmented:
                     self._pipeline(self._static_x, self._static_t, lambda j: None)
                 else:
-                    self._fwd_bwd(self._static_x, self._static_t)
+                    if sided:
+                        self._side_step_eager(self._static_x, self._static_t)
+                    if not (sided and self._side_force):
+                        self._fwd_bwd(self._static_x, self._static_t)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         if segmented:
             return self._capture_segments(s)
+        if sided:
+            self._capture_side(s)
+            if self._side_force:
+                self._use_side = True
+                return
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):  # RCCL's watchdog thread may touch the runtime meanwhile
             self._static_loss = self._fwd_bwd(self._static_x, self._static_t)
             if not self.dp_path:
                 self._update()
         self._graph = g
+        if sided:
+            self._choose_schedule()
+
+    def _capture_side(self, s):
+        """The side-stream schedule as three HIP graphs: the main chain (forward, Dice, backward with a flag store at every cut),
+        the weight-gradient launches behind their device-side waits (replayed on the side stream), and the tail (wait for the
+        side stream's flag, slab reduction, Adam).  The tail is a graph of its own only because the slab-reduction job table is
+        complete once the weight-gradient launches have been issued."""
+        import gc
+        gc.collect()
+        pool = torch.cuda.graph_pool_handle()
+        side = self.side.stream
+        g_main, g_side, g_tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            g_main.capture_begin(pool=pool, capture_error_mode="thread_local")
+            self._side_loss = self._side_pass(self._static_x, self._static_t)
+            g_main.capture_end()
+        with torch.cuda.stream(side):
+            g_side.capture_begin(capture_error_mode="thread_local")   # kernels only: workspaces were allocated when queued
+            self.side.launch_side()
+            g_side.capture_end()
+        with torch.cuda.stream(s):
+            g_tail.capture_begin(pool=pool, capture_error_mode="thread_local")
+            self.side.finish()
+            if not self.dp_path:
+                self._update()
+            g_tail.capture_end()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._side_graphs = (g_main, g_side, g_tail)
 
     def _capture_segments(self, s):
         """one HIP graph per gradient bucket: the capture is closed and the next one opened inside the backward walk, at the
@@ -467,8 +804,15 @@ class SearchTrainer:
     (the reference computes and discards them, search.py:231) and the weight pass does not compute alpha
     gradients -- requires_grad is switched per pass, so the corresponding kernels are simply not launched."""
 
-    def __init__(self, shell, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph=True, process_group=None, comm=None):
+    def __init__(self, shell, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph=True, process_group=None, comm=None, side_wgrad=None):
         self.model = shell
+        # the weight pass queues its weight-gradient kernels for the side stream (SideSchedule); the architecture pass has none
+        env = os.environ.get("N3D_SIDE_WGRAD", "1")
+        self.side_wgrad = (env != "0") if side_wgrad is None else bool(side_wgrad)
+        self._side_force = side_wgrad == "force" or (side_wgrad is None and env == "force")   # as in Trainer: no comparison
+        self._side_active = True     # _pass: queue the weight pass' weight gradients for the side stream (when there is one)
+        self._use_side = False
+        self.schedule_times = None
         self.loss_fn = WeightedDiceLoss()
         self.lr, self.betas, self.eps = lr, betas, eps
         self.device = next(shell.parameters()).device
@@ -483,8 +827,12 @@ class SearchTrainer:
         self.afp = types.SimpleNamespace(params=self.aparams, offsets=aoffs, exp_avg=self.a_m, exp_avg_sq=self.a_v, step=self.a_step)
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
         self.ctx = K.StepContext(self.device)
+        self.side = SideSchedule(self.device, self.ctx) if (self.side_wgrad and self.device.type == "cuda") else None
+        if self.side is not None and self.side.stream is None:
+            self.side = None
         self.use_graph = graph
         self._graph = None
+        self._side_graphs = None
         # two learning rates (search.py:103-106): alphas ("shell") and kernel weights, each on its own plateau schedule
         self.lr_shell, self.lr_kernel = float(lr), float(lr)
         self.lr_shell_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)
@@ -511,30 +859,48 @@ class SearchTrainer:
         self.lr_kernel = float(lr)
         self.lr_kernel_dev.fill_(self.lr_kernel)
 
-    def _pass(self, x, t, arch, update=True, pack=True):
+    def _pass(self, x, t, arch, update=True, pack=True, side="inline"):
         """pack=False: the conv weights were packed by the pass before and have not changed since (the weight pass of a step
-        follows the architecture pass, which only moves the alphas)"""
+        follows the architecture pass, which only moves the alphas).
+        side (weight pass with a SideSchedule): "inline" = queue the weight-gradient launches, then issue them on the side stream
+        and join (eager use); "main" = only the main-stream part (the graph capture issues launch_side / finish itself)."""
         for p in self.kparams:
             p.requires_grad_(not arch)
         for p in self.aparams:
             p.requires_grad_(arch)
         if arch:
             self.agrad.zero_()  # alpha gradients arrive through autograd accumulation (softmax backward)
+        sided = self.side is not None and self._side_active and not arch
         with K.step_context(self.ctx):
             if pack:
                 self.ctx.pack_all()
             loss = _loss_of(self.model, self.loss_fn, x, t)
             prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True
             try:
-                loss.backward(self._one)  # seed gradient kept resident: no fill launch per step
+                if sided:
+                    with self.side.deferring():
+                        loss.backward(self._one)
+                else:
+                    loss.backward(self._one)  # seed gradient kept resident: no fill launch per step
             finally:
                 _fused.REUSE_GRAD_OUTPUT = prev
-            self.ctx.flush_final()
+            if not sided:
+                self.ctx.flush_final()
+        if sided and side == "main":
+            return loss.detach()
+        if sided:
+            with torch.cuda.stream(self.side.stream):
+                self.side.launch_side()
+            self.side.finish()
         if not self.ctx.frozen and not arch:
             self.ctx.freeze()
         if update:
             self._update(arch)
         return loss.detach()
+
+    def check_sync(self):
+        if self.side is not None:
+            self.side.check()
 
     def _update(self, arch):
         """exchange (data parallel) + Adam of the pass that just ran"""
@@ -553,11 +919,40 @@ class SearchTrainer:
         lw = self._pass(x, t, False, update, pack=False)   # same weights as the architecture pass just packed
         return la, lw
 
+    def _capture_side(self, s):
+        """four graphs: the architecture pass (+ its Adam unless an exchange sits in between), the weight pass' main chain, its
+        weight-gradient kernels (replayed on the side stream), and the tail (join, slab reduction, Adam)"""
+        import gc
+        gc.collect()
+        pool = torch.cuda.graph_pool_handle()
+        g_arch, g_main, g_side, g_tail = (torch.cuda.CUDAGraph() for _ in range(4))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            g_arch.capture_begin(pool=pool, capture_error_mode="thread_local")
+            la = self._pass(self._svx, self._svt, True, update=not self.dp_path)
+            g_arch.capture_end()
+            g_main.capture_begin(pool=pool, capture_error_mode="thread_local")
+            lw = self._pass(self._sx, self._st, False, update=False, pack=False, side="main")
+            g_main.capture_end()
+        with torch.cuda.stream(self.side.stream):
+            g_side.capture_begin(capture_error_mode="thread_local")
+            self.side.launch_side()
+            g_side.capture_end()
+        with torch.cuda.stream(s):
+            g_tail.capture_begin(pool=pool, capture_error_mode="thread_local")
+            self.side.finish()
+            if not self.dp_path:
+                self._update(False)
+            g_tail.capture_end()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._side_losses, self._side_graphs = (la, lw), (g_arch, g_main, g_side, g_tail)
+
     def step(self, x, t, val_x, val_t):
         """returns (architecture-pass loss, weight-pass loss) as device scalars"""
         if not self.use_graph:
             return self._both(x, t, val_x, val_t)
-        if self._graph is None and self._graphs is None:
+        if self._graph is None and self._graphs is None and self._side_graphs is None:
             self._sx, self._st, self._svx, self._svt = x.clone(), t.clone(), val_x.clone(), val_t.clone()
             # warm-up on a side stream (allocator + lazy module state) WITHOUT the optimizer launches: weights, alphas,
             # Adam moments and step counters -- possibly just loaded from a checkpoint (search.py:108-127) -- stay untouched
@@ -568,28 +963,72 @@ class SearchTrainer:
                     self._both(self._sx, self._st, self._svx, self._svt, update=False)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
-            if self.dp_path:
-                # one graph per pass (forward + backward only); the exchange and Adam of each pass run eagerly behind it
-                pool = torch.cuda.graph_pool_handle()
-                ga, gw = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
-                    la = self._pass(self._svx, self._svt, True, update=False)
-                with torch.cuda.graph(gw, pool=pool, capture_error_mode="thread_local"):
-                    lw = self._pass(self._sx, self._st, False, update=False, pack=False)
-                self._losses, self._graphs = (la, lw), (ga, gw)
+            if self.side is not None:
+                self._capture_side(s)
+            if self.side is not None and self._side_force:
+                self._use_side = True
             else:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # RCCL's watchdog thread may touch the runtime meanwhile
-                    self._losses = self._both(self._sx, self._st, self._svx, self._svt)
-                self._graph = g
+                self._side_active = False
+                if self.dp_path:
+                    # one graph per pass (forward + backward only); the exchange and Adam of each pass run eagerly behind it
+                    pool = torch.cuda.graph_pool_handle()
+                    ga, gw = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
+                        la = self._pass(self._svx, self._svt, True, update=False)
+                    with torch.cuda.graph(gw, pool=pool, capture_error_mode="thread_local"):
+                        lw = self._pass(self._sx, self._st, False, update=False, pack=False)
+                    self._losses, self._graphs = (la, lw), (ga, gw)
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):  # RCCL's watchdog thread may touch the runtime meanwhile
+                        self._losses = self._both(self._sx, self._st, self._svx, self._svt)
+                    self._graph = g
+                self._side_active = True
+                if self.side is not None:
+                    self._choose_schedule()
         if any(a.shape != b.shape for a, b in ((x, self._sx), (t, self._st), (val_x, self._svx), (val_t, self._svt))):
             return self._both(x, t, val_x, val_t)   # remainder batch of an epoch: eager step (the graph is for one shape)
         self._sx.copy_(x); self._st.copy_(t); self._svx.copy_(val_x); self._svt.copy_(val_t)
+        if self._use_side:
+            self._replay_side()
+            sd = self.side
+            sd.replays += 1
+            if sd.replays % 256 == 0:
+                sd.check()
+            return self._side_losses
+        self._replay_plain()
+        return self._losses
+
+    def _replay_side(self):
+        g_arch, g_main, g_side, g_tail = self._side_graphs
+        g_arch.replay()
+        if self.dp_path:
+            self._update(True)
+        g_main.replay()
+        with torch.cuda.stream(self.side.stream):
+            g_side.replay()
+        g_tail.replay()
+        if self.dp_path:
+            self._update(False)
+
+    def _replay_plain(self):
         if self._graphs is not None:
             self._graphs[0].replay()
             self._update(True)
             self._graphs[1].replay()
             self._update(False)
-            return self._losses
+            return
         self._graph.replay()
-        return self._losses
+
+    def _choose_schedule(self):
+        """time the two captured schedules on the real step (state saved and restored around it) and keep the faster one"""
+        snap = _Snapshot([self.fp.flat, self.fp.exp_avg, self.fp.exp_avg_sq, self.fp.step, self.fp.grad, self.aflat, self.agrad, self.a_m, self.a_v,
+                          self.a_step] + _dropout_states(self.model))
+        tp = _time_schedule(self._replay_plain, self.device, warm=1, reps=3)
+        ts = _time_schedule(self._replay_side, self.device, warm=1, reps=3)
+        self.side.check()
+        snap.restore()
+        torch.cuda.synchronize(self.device)
+        self.schedule_times = (tp, ts)
+        self._use_side = ts < tp
+
