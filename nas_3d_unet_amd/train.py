@@ -375,6 +375,15 @@ def _dropout_states(model):
     return [m._n3d_state for m in model.modules() if getattr(m, "_n3d_state", None) is not None]
 
 
+def _dropout_snapshot(model, device):
+    """snapshot of every Dropout3d generator of the model (created now if a module has not drawn yet)"""
+    from . import programs as _P
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout3d):
+            _P.dropout_state(m, device)
+    return _Snapshot(_dropout_states(model))
+
+
 class _Snapshot:
     """optimizer-visible state of a trainer (weights, Adam moments, step counters, dropout generators): taken before the
     schedules are timed against each other on the real step, put back afterwards"""
@@ -708,6 +717,15 @@ class Trainer:
         self._use_side = ts < tp
 
     def _capture(self, x, t):
+        """capture (and, with a side stream, choose the schedule); the Dropout3d generators come out as they went in, so the
+        masks of the training run do not depend on how many warm-up / timing passes the capture needed"""
+        snap = _dropout_snapshot(self.model, self.device)
+        try:
+            self._capture_impl(x, t)
+        finally:
+            snap.restore()
+
+    def _capture_impl(self, x, t):
         self._static_x = x.clone()
         self._static_t = t.clone()
         segmented = self.dp_path and self._pipeline_ok(x)
@@ -953,6 +971,7 @@ class SearchTrainer:
         if not self.use_graph:
             return self._both(x, t, val_x, val_t)
         if self._graph is None and self._graphs is None and self._side_graphs is None:
+            drop_snap = _dropout_snapshot(self.model, self.device)   # restored below: masks independent of the warm-up passes
             self._sx, self._st, self._svx, self._svt = x.clone(), t.clone(), val_x.clone(), val_t.clone()
             # warm-up on a side stream (allocator + lazy module state) WITHOUT the optimizer launches: weights, alphas,
             # Adam moments and step counters -- possibly just loaded from a checkpoint (search.py:108-127) -- stay untouched
@@ -986,6 +1005,7 @@ class SearchTrainer:
                 self._side_active = True
                 if self.side is not None:
                     self._choose_schedule()
+            drop_snap.restore()
         if any(a.shape != b.shape for a, b in ((x, self._sx), (t, self._st), (val_x, self._svx), (val_t, self._svt))):
             return self._both(x, t, val_x, val_t)   # remainder batch of an epoch: eager step (the graph is for one shape)
         self._sx.copy_(x); self._st.copy_(t); self._svx.copy_(val_x); self._svt.copy_(val_t)

@@ -1,0 +1,169 @@
+"""GPU: the side-stream schedule of the weight-gradient kernels (train.SideSchedule, n3d_sync_signal / n3d_sync_wait).
+
+The hand-off primitives must order two streams and must never hang; the schedule must not change a gradient (the reference
+runs one stream, train.py:117-128): every parameter gradient against the plain one-stream trainer, eagerly and replayed from
+the three captured graphs, for the searched net and for the supernet's weight pass (search.py:233-238)."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_nets import build_net
+from _util import dev, fill_module
+from oracle import ref_path as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _words(n=16):
+    w = torch.zeros(n, dtype=torch.int32, device="cuda")   # [0] step of stream A, [1] time-outs, [2] step of stream B, [4..] flags
+    w[0] = 1
+    w[2] = 1
+    return w
+
+
+def test_sync_handoff_orders_two_streams():
+    from nas_3d_unet_amd import kernels as K
+    w = _words()
+    p = lambda i: w.data_ptr() + 4 * i
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    src = torch.zeros(1 << 22, device="cuda")
+    dst = torch.zeros(4, 1 << 22, device="cuda")
+    torch.cuda.synchronize()
+    for r in range(4):
+        # the consumer is enqueued FIRST: without the device-side wait it would copy the previous round's values
+        with torch.cuda.stream(b):
+            K.sync_wait(p(4), p(2), p(1), True)
+            dst[r].copy_(src)
+        with torch.cuda.stream(a):
+            for _ in range(8):
+                src.add_(1.0)          # several dependent kernels ahead of the signal
+            K.sync_signal(p(4), p(0), True)
+            # ... and the producer must not run ahead into the next round before the consumer has read: the reverse hand-off
+            K.sync_wait(p(5), p(0), p(1), False)
+        with torch.cuda.stream(b):
+            K.sync_signal(p(5), p(2), False)
+    torch.cuda.synchronize()
+    assert int(w[1]) == 0, "a device-side wait timed out"
+    for r in range(4):
+        assert float(dst[r].min()) == float(dst[r].max()) == 8.0 * (r + 1), r
+    assert int(w[0]) == 5 and int(w[2]) == 5
+
+
+def test_sync_wait_is_bounded():
+    """a wait whose flag never arrives gives up after max_polls tries, counts a time-out and lets its stream go on"""
+    from nas_3d_unet_amd import kernels as K
+    w = _words()
+    p = lambda i: w.data_ptr() + 4 * i
+    out = torch.zeros(8, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        K.sync_wait(p(4), p(0), p(1), False, max_polls=2000)
+        out.fill_(3.0)
+    torch.cuda.synchronize()
+    assert int(w[1]) == 1 and float(out.sum()) == 24.0
+    with pytest.raises(Exception):
+        K.sync_wait(p(4), p(0), p(1), False, max_polls=0)
+
+
+def _batch(seed, size=32, batch=2):
+    rng = np.random.default_rng(seed)
+    x = dev(rng.standard_normal((batch, 4, size, size, size)).astype(np.float32))
+    t = dev((rng.uniform(0, 1, (batch, 3, size, size, size)) < 0.3).astype(np.float32))
+    return x, t
+
+
+@pytest.mark.parametrize("gname", ["G_CONV", "G_ALL"])
+def test_side_schedule_gradients_equal_plain(gname):
+    from nas_3d_unet_amd.train import Trainer
+    x, t = _batch(41)
+    net, _ = build_net("searched", gname, 4)
+    plain = Trainer(net, graph=False, side_wgrad=False)
+    plain._fwd_bwd(x, t)
+    ref = plain.fp.grad.clone()
+    tot = float(ref.double().norm())
+    net2, _ = build_net("searched", gname, 4)
+    tr = Trainer(net2, graph=False, side_wgrad=True)
+    assert tr.side is not None and tr._side_ok(), "the side stream was not accepted on this box"
+    for _ in range(3):        # first pass records the pack jobs; later ones run pre-packed
+        tr.fp.grad.zero_()
+        tr._side_step_eager(x, t)
+        torch.cuda.synchronize()
+        tr.check_sync()
+        assert int((tr.side.sync[8:108] > 0).sum()) >= 6, "no cut points were placed"
+        assert float((tr.fp.grad - ref).double().norm()) <= 1e-5 * tot
+    # the C in {4, 8} levels run the SAME weight-gradient kernels on the same operands: bit-identical there
+    names = [n for n, _ in net2.named_parameters()]
+    for n, q, off in zip(names, tr.fp.params, tr.fp.offsets):
+        if n.startswith("up_cells.4._ops") and n.endswith("conv.weight"):
+            assert torch.equal(tr.fp.grad[off:off + q.numel()], ref[off:off + q.numel()]), n
+
+
+def test_side_schedule_graph_replay_matches_plain_trainer():
+    from nas_3d_unet_amd.train import Trainer
+    x, t = _batch(43)
+    out = []
+    for side in (False, "force"):
+        net, _ = build_net("searched", "G_CONV", 4)
+        tr = Trainer(net, graph=True, side_wgrad=side)
+        losses = [float(tr.step(x, t)) for _ in range(4)]
+        torch.cuda.synchronize()
+        tr.check_sync()
+        if side:
+            assert tr._use_side and tr._side_graphs is not None
+        out.append((losses, tr.fp.flat.clone()))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=2e-5)
+    # Adam moves an element whose gradient is fp32 noise by ~lr per step either way: compare where it matters
+    d = (out[0][1] - out[1][1]).abs()
+    assert float(d.double().norm()) <= 2e-4 * float(out[0][1].double().norm())
+
+
+def test_schedule_choice_leaves_the_state_alone():
+    """the default trainer times both captured schedules on the real step at capture time: weights, Adam moments, step counters
+    and the Dropout3d generator must come out of that exactly as they went in"""
+    from nas_3d_unet_amd import programs as P
+    from nas_3d_unet_amd.train import Trainer
+    x, t = _batch(47)
+    res = []
+    for side in (False, None):
+        torch.manual_seed(5)
+        net, head = build_net("searched", "G_CONV", 4, keep_dropout=True)
+        net.train()
+        P.dropout_state(head[0].dropout, torch.device("cuda", torch.cuda.current_device()), seed=1234)   # both nets: the same masks
+        tr = Trainer(net, graph=True, side_wgrad=side)
+        losses = [float(tr.step(x, t)) for _ in range(3)]
+        res.append((losses, tr.fp.flat.clone(), int(tr.fp.step), tr))
+    tr = res[1][3]
+    assert tr.schedule_times is not None and min(tr.schedule_times) > 0
+    assert res[0][2] == res[1][2] == 3
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=2e-5)   # same dropout masks, same trajectory
+    d = (res[0][1] - res[1][1]).abs()
+    assert float(d.double().norm()) <= 2e-4 * float(res[0][1].double().norm())
+
+
+def test_search_weight_pass_on_the_side_stream():
+    from nas_3d_unet_amd import nas
+    from nas_3d_unet_amd.train import SearchTrainer
+    cfg = orc.DEFAULT_CFG._replace(depth=2)
+    rng = np.random.default_rng(53)
+    mk = lambda: (dev(rng.standard_normal((2, 4, 16, 16, 16)).astype(np.float32)),
+                  dev((rng.uniform(0, 1, (2, 3, 16, 16, 16)) < 0.3).astype(np.float32)))
+    (x, t), (vx, vt) = mk(), mk()
+    res = []
+    for side, graph in ((False, False), (True, False), ("force", True)):
+        net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)
+        fill_module(net)
+        net.kernel.last_conv[0].dropout = None
+        net = net.cuda()
+        tr = SearchTrainer(net, graph=graph, side_wgrad=side)
+        if side:
+            assert tr.side is not None
+        got = [tuple(float(v) for v in tr.step(x, t, vx, vt)) for _ in range(2)]
+        torch.cuda.synchronize()
+        tr.check_sync()
+        res.append((got, tr.fp.grad.clone(), tr.agrad.clone()))
+    tot, atot = float(res[0][1].double().norm()), float(res[0][2].double().norm())
+    for got, g, ag in res[1:]:
+        np.testing.assert_allclose(np.array(got), np.array(res[0][0]), rtol=0, atol=2e-5)
+        # gradients of the second step (the buffers hold the last pass): the first steps' Adam updates may differ by noise-level signs
+        assert float((g - res[0][1]).double().norm()) <= 2e-3 * tot
+        assert float((ag - res[0][2]).double().norm()) <= 2e-3 * atot
