@@ -52,16 +52,19 @@ def to_patch_layout(x):
     return x.contiguous(memory_format=torch.channels_last_3d)
 
 
-def conv_kernel_roofline(device, batch, size, iters=40):
+def conv_kernel_roofline(device, batch, size, iters=40, bf16=False):
     """Time the dominant FLOP kernel -- the 3x3x3 stride-1 conv at C=4 on (batch, 4, size^3), the shape of up-cell 4
     (43 % of the net's FLOPs; the same kernel serves its data gradient) -- with HIP events on the launch stream.
     The launches are replayed from a HIP graph with pre-packed weights, so the figure is kernel time plus the
     ~1.7 us dependent-launch boundary, not host launch cost.  Algorithmic FLOPs = 2*B*S^3*C*C*27 per launch,
-    algorithmic bytes = input + output tensor."""
+    algorithmic bytes = input + output tensor.
+    bf16 (BASELINE configs[4]): the same conv on bf16-stored tensors (conv_vox64b_kernel, v_mfma_f32_4x4x4_16b_bf16), priced
+    against HBM: bytes / time / 8 TB/s."""
     from nas_3d_unet_amd import kernels as K
     c = 4
-    x = K.as_view(K.empty_ndhwc(batch, c, size, size, size, device).normal_())
-    y = K.as_view(K.empty_ndhwc(batch, c, size, size, size, device))
+    dt = torch.bfloat16 if bf16 else torch.float32
+    x = K.as_view(K.empty_ndhwc(batch, c, size, size, size, device, dt).normal_())
+    y = K.as_view(K.empty_ndhwc(batch, c, size, size, size, device, dt))
     w = torch.randn(c, c, 3, 3, 3, device=device) * 0.1
     b = torch.randn(c, device=device) * 0.1
     g = K.conv_geom(batch, size, size, size, c, c, 3, 1, 1, 1)
@@ -91,19 +94,29 @@ def conv_kernel_roofline(device, batch, size, iters=40):
     e1.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3 / (iters * reps)
     flops = 2.0 * batch * size ** 3 * c * c * 27
-    bytes_ = 2.0 * batch * size ** 3 * c * 4
+    bytes_ = 2.0 * batch * size ** 3 * c * (2 if bf16 else 4)
     ach = flops / sec / 1e12
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_conv_vox64_f32_2x4x%d.json" % size)
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # HBM traffic per launch: PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) need their own rocprofv3 --pmc passes, so the
+    # figure is read from the tracked summary of that pass (tools/collect_pmc_r03.sh), not measured inside this run
+    traffic, src = None, None
+    for rnd in ("r03", "r02"):
+        pmc = os.path.join(ROOT, "profiles", "%s_pmc_conv_vox64%s_%s_2x4x%d.json" % (rnd, "b" if bf16 else "", "bf16" if bf16 else "f32", size))
+        if os.path.exists(pmc):
+            try:
+                traffic, src = json.load(open(pmc)).get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(pmc)
+            except Exception:
+                traffic = None
+            break
+    common = {"us_per_launch": round(sec * 1e6, 2), "algorithmic_flop_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
+              "traffic": traffic, "traffic_source": (src + " (separate rocprofv3 --pmc passes of the same launch, not this run)") if src else None}
+    if bf16:
+        gbs = bytes_ / sec / 1e9
+        return {"bound": "hbm", "kernel": "conv_vox64b_kernel<4,4,1>: 3x3x3 s1 d1 conv, C=4, bf16 storage, (%d,4,%d^3), GN-stats epilogue" % (batch, size),
+                "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                "achieved_tflops": round(ach, 3), **common}
     return {"bound": "mfma", "kernel": "conv_vox64_kernel<4,4,1>: 3x3x3 s1 d1 conv, C=4, (%d,4,%d^3), GN-stats epilogue" % (batch, size),
             "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
-            "us_per_launch": round(sec * 1e6, 2), "algorithmic_flop_per_launch": flops, "algorithmic_bytes_per_launch": bytes_,
-            "algorithmic_gbs": round(bytes_ / sec / 1e9, 1), "traffic": traffic}
+            "algorithmic_gbs": round(bytes_ / sec / 1e9, 1), **common}
 
 
 def usable_cores():
@@ -154,13 +167,21 @@ def cpu_baseline(batch, size, budget_s=22.0):
             times.append(time.perf_counter() - t0)
         return float(np.median(times)), len(times)
 
-    med, n = timed(cores, 7, budget_s * 0.5)
-    med1, n1 = timed(1, 2, budget_s * 0.5)
+    # best of a small thread sweep (round-2 review: "all cores" was slower than one thread on a contended box)
+    sweep = sorted({1, min(4, cores), min(8, cores), cores})
+    share = budget_s / len(sweep)
+    runs = {}
+    for th in sweep:
+        runs[th] = timed(th, 7 if th > 1 else 3, share)
     torch.set_num_threads(cores)
-    return {"value": round(batch / med, 3), "unit": "patches/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "one_thread": {"value": round(batch / med1, 3), "unit": "patches/s", "cores": 1,
-                           "sample": "%d timed fwd+bwd iterations, median %.2f s" % (n1, med1)},
-            "sample": "%d timed fwd+bwd iterations of the same net at batch %d, 4x%d^3 fp32 (median %.3f s)" % (n, batch, size, med)}
+    best = min(runs, key=lambda th: runs[th][0])
+    med, n = runs[best]
+    return {"value": round(batch / med, 3), "unit": "patches/s", "cores": best, "kind": "port", "cpu_model": cpu_model(), "usable_cores": cores,
+            "thread_sweep": {str(th): {"value": round(batch / m, 3), "iterations": k, "median_s": round(m, 3)} for th, (m, k) in runs.items()},
+            "one_thread": {"value": round(batch / runs[1][0], 3), "unit": "patches/s", "cores": 1,
+                           "sample": "%d timed fwd+bwd iterations, median %.2f s" % (runs[1][1], runs[1][0])},
+            "sample": "best of threads in %s: %d timed fwd+bwd iterations of the same net at batch %d, 4x%d^3 fp32 with %d threads (median %.3f s)"
+                      % (sweep, n, batch, size, best, med)}
 
 
 def search_step_bench(args, device):
@@ -179,6 +200,11 @@ def search_step_bench(args, device):
     x, vx = to_patch_layout(x), to_patch_layout(vx)
     for _ in range(args.warmup):
         tr.step(x, t, vx, vt)
+    if not args.no_graph and args.warmup > 0:
+        own = tr.input_buffers()              # as in main(): the batches sit in the trainer's input buffers
+        for dst, src in zip(own, (x, t, vx, vt)):
+            dst.copy_(src)
+        x, t, vx, vt = own
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -188,9 +214,16 @@ def search_step_bench(args, device):
     extra = {}
     if not args.no_kernel_table:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import kernel_table
-        rows, ncalls = kernel_table.table(lambda: tr._both(x, t, vx, vt), device)
-        extra = {"roofline_by_time": rows, "launches_per_step": ncalls}
+        try:
+            import kernel_table
+            side, tr.side = tr.side, None      # the single-stream schedule: one entry point = one launch of the dependent chain
+            try:
+                rows, ncalls = kernel_table.table(lambda: tr._both(x, t, vx, vt), device)
+            finally:
+                tr.side = side
+            extra = {"roofline_by_time": rows, "launches_per_step": ncalls}
+        except Exception as e:
+            extra = {"roofline_by_time": "failed: %s" % (str(e)[:200],)}
     print(json.dumps({
         "metric": "supernet search steps/sec (arch pass + weight pass, each fwd + Dice + bwd + Adam)", "value": round(args.steps / dt, 3),
         "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -208,9 +241,15 @@ def other_configs(device, batch, no_graph):
     from nas_3d_unet_amd.train import SearchTrainer, Trainer
     out = {}
 
-    def timed(step, steps=10, warmup=3):
+    def timed(tr, bufs, steps=10, warmup=3):
         for _ in range(warmup):
-            step()
+            tr.step(*bufs)
+        if not no_graph:
+            own = tr.input_buffers()          # as in main(): the batch sits in the trainer's input buffers
+            for dst, src in zip(own, bufs):
+                dst.copy_(src)
+            bufs = own
+        step = lambda: tr.step(*bufs)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -227,7 +266,7 @@ def other_configs(device, batch, no_graph):
         vxn, vtn = synthetic_batch(batch, 64, 4321)
         x, t, vx, vt = (torch.from_numpy(a).to(device) for a in (xn, tn, vxn, vtn))
         x, vx = to_patch_layout(x), to_patch_layout(vx)
-        sec = timed(lambda: tr.step(x, t, vx, vt))
+        sec = timed(tr, (x, t, vx, vt))
         return {"ms_per_step": round(sec * 1e3, 3), "steps_per_s": round(1.0 / sec, 3), "patches_per_s": round(2 * batch / sec, 2)}
 
     def train128(storage):
@@ -238,7 +277,7 @@ def other_configs(device, batch, no_graph):
         tr = Trainer(net, graph=not no_graph, storage=storage)
         xn, tn = synthetic_batch(batch, 128, 1234)
         x, t = to_patch_layout(torch.from_numpy(xn).to(device)), torch.from_numpy(tn).to(device)
-        sec = timed(lambda: tr.step(x, t))
+        sec = timed(tr, (x, t))
         return {"ms_per_step": round(sec * 1e3, 3), "patches_per_s": round(batch / sec, 2)}
 
     for name, fn in (("configs[2]: nas.py supernet search step, batch 2 + 2, 4x64^3 fp32", search),
@@ -275,6 +314,23 @@ def main():
                          "search: supernet search step, arch pass + weight pass (configs[2]; informational, N=1 only)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: start the N ranks as fresh child processes (one per GPU) BEFORE anything here touches the GPU,
+        # and leave with their exit code; the JSON line is rank 0's
+        import subprocess
+        n_dev = torch.cuda.device_count()      # counting devices does not initialise the GPU
+        if n_dev < args.gpus:
+            sys.exit("bench.py: --gpus %d requested, but this node shows %d GPU(s)" % (args.gpus, n_dev))
+        port = os.environ.get("MASTER_PORT", "29511")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit("bench.py: --gpus %d does not match WORLD_SIZE=%s of the launcher" % (args.gpus, os.environ["WORLD_SIZE"]))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -303,6 +359,12 @@ def main():
 
     for _ in range(args.warmup):
         loss = trainer.step(x, t)
+    if not args.no_graph and args.warmup > 0:
+        # the synthetic batch lives in the trainer's own input buffers, where the on-device data step (n3d_patch_batch) would
+        # put it: resident in HBM when the timed region starts, no per-step staging copy
+        bx, bt = trainer.input_buffers()
+        bx.copy_(x); bt.copy_(t)
+        x, t = bx, bt
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -329,7 +391,9 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.dtype == "f32" else "bf16 storage (levels with <= 8 channels per node, stems, head input) / f32 arithmetic", "data": "synthetic",
             "config": {"workload": "searched.py SearchedNet/G_conv train step, batch=%d 4x%d^3 %s per GPU" % (args.batch, args.size, "fp32" if args.dtype == "f32" else "bf16-storage"),
                        "global_batch": world * args.batch, "patch": [4, args.size, args.size, args.size],
-                       "parallelism": "dp%d" % world, "dp_buckets": len(trainer.sync.ranges) if trainer.dp_path else None, "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "final_loss": round(final_loss, 5)},
+                       "parallelism": "dp%d" % world, "dp_buckets": len(trainer.sync.ranges) if trainer.dp_path else None, "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "final_loss": round(final_loss, 5),
+                       "schedule": ("side-stream weight gradients" if getattr(trainer, "_use_side", False) else "single stream"),
+                       "schedule_ms": [round(v * 1e3, 3) for v in trainer.schedule_times] if getattr(trainer, "schedule_times", None) else None},
             # algorithmic work per patch scales with the voxel count (figures quoted at 64^3); bf16 storage halves the
             # bytes of the levels it covers (~94 % of the activation bytes)
             "whole_net": (lambda vox, byt: {"tflops_fwd_bwd": round(value * FLOP_FWD_BWD_PER_PATCH * vox / 1e12, 3),
@@ -338,14 +402,23 @@ def main():
                 (args.size / 64.0) ** 3, 1.0 if args.dtype == "f32" else 1.0 - 0.94 / 2),
         }
         if not args.no_roofline:
-            out["roofline"] = conv_kernel_roofline(device, args.batch, args.size)
+            out["roofline"] = conv_kernel_roofline(device, args.batch, args.size, bf16=args.dtype == "bf16")
         if world == 1 and not args.no_kernel_table:
             # what actually dominates the step: top entry points by measured microseconds per step, each against its roofline
+            # (recorded on the single-stream schedule: one entry point = one launch of the dependent chain; the replay reuses the
+            # recorded pointers, so a failure here must not cost the headline line)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import kernel_table
-            rows, ncalls = kernel_table.table(lambda: trainer._eager(x, t), device)
-            out["roofline_by_time"] = rows
-            out["launches_per_step"] = ncalls
+            try:
+                import kernel_table
+                side, trainer.side = getattr(trainer, "side", None), None
+                try:
+                    rows, ncalls = kernel_table.table(lambda: trainer._eager(x, t), device)
+                finally:
+                    trainer.side = side
+                out["roofline_by_time"] = rows
+                out["launches_per_step"] = ncalls
+            except Exception as e:
+                out["roofline_by_time"] = "failed: %s" % (str(e)[:200],)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.size)
         if world == 1 and not args.no_other_configs and args.size == 64 and args.dtype == "f32":

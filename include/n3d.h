@@ -426,8 +426,10 @@ int n3d_comm_allreduce_sum(void* comm, float* buf, int64_t n, void* stream);
 int n3d_comm_destroy(void* comm);
 
 /* ---- flat Adam (train.py:49,128; search.py:103-104,228,238): torch.optim.Adam defaults ------------
- * step_ptr: device int32 holding the number of steps already taken; if inc_step != 0 a second tiny
- * launch increments it after the update (graph-replay safe).  grad_scale multiplies g (DP mean). */
+ * step_ptr: device int32 holding the number of steps already taken; inc_step == 1: a second tiny launch
+ * increments it after the update (graph-replay safe); inc_step == 2: step_ptr points to int32[2] =
+ * {steps, ticket counter (zero between launches)} and the last workgroup of the update launch itself counts
+ * the step (no second launch).  grad_scale multiplies g (DP mean). */
 int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   const float* lr_ptr /* if not NULL the learning rate is read from this device float instead of
                   `lr`: a captured graph then follows the ReduceLROnPlateau schedule (train.py:50,77) */,

@@ -1900,7 +1900,7 @@ __global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float lr_imm, const float* __restrict__ lr_ptr, float b1, float b2, float eps,
-                                                   float wd, float gscale, const int32_t* __restrict__ step_ptr) {
+                                                   float wd, float gscale, int32_t* __restrict__ step_ptr, int ticketed) {
   const int step = *step_ptr + 1;
   const float lr = lr_ptr ? *lr_ptr : lr_imm;
   const double bc1 = 1.0 - pow((double)b1, (double)step);
@@ -1916,6 +1916,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
     p[i] = pi - step_size * (mi / denom);
+  }
+  if (ticketed) {
+    // inc_step == 2: step_ptr[1] is a ticket counter.  Every workgroup has read the step before it draws its ticket, so the
+    // workgroup that draws the last one may count the step and clear the counter (no second launch)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned tk = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(step_ptr + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tk == gridDim.x - 1) {
+        __hip_atomic_store(reinterpret_cast<unsigned*>(step_ptr + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(step_ptr, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 __global__ void step_inc_kernel(int32_t* step_ptr) { *step_ptr += 1; }
@@ -2542,8 +2554,8 @@ int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, lr_ptr,
-                     beta1, beta2, eps, weight_decay, grad_scale, step_ptr);
-  if (inc_step) hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_ptr);
+                     beta1, beta2, eps, weight_decay, grad_scale, step_ptr, inc_step == 2 ? 1 : 0);
+  if (inc_step == 1) hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_ptr);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

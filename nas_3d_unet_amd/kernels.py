@@ -1038,10 +1038,21 @@ def dice_bwd(p, t, smooth, sums, dloss, dp):
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
               grad_scale=1.0, inc_step=True, lr_dev=None):
-    """lr_dev: optional 1-element device tensor holding the learning rate (read by the kernel; survives graph replay)"""
+    """lr_dev: optional 1-element device tensor holding the learning rate (read by the kernel; survives graph replay).
+    step_t: int32 step counter; a view made by `step_counter()` carries a ticket word behind it, and the update launch then
+    counts the step itself (no second launch)"""
+    inc = 0 if not inc_step else (2 if getattr(step_t, "_n3d_ticketed", False) else 1)
     check(_lib.load().n3d_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, ptr(lr_dev),
-                                    beta1, beta2, eps, weight_decay, grad_scale, ptr(step_t), 1 if inc_step else 0, stream_ptr()),
+                                    beta1, beta2, eps, weight_decay, grad_scale, ptr(step_t), inc, stream_ptr()),
           "n3d_adam_step")
+
+
+def step_counter(device):
+    """1-element int32 step counter (a view of two words: the second is the Adam kernel's ticket counter)"""
+    two = torch.zeros(2, dtype=torch.int32, device=device)
+    st = two[:1]
+    st._n3d_ticketed = True
+    return st
 
 
 # ------------------------------------------------------------------------------------------ stream hand-off

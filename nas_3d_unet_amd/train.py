@@ -51,7 +51,7 @@ class FlatParams:
         self.grad = torch.zeros(n, dtype=torch.float32, device=device)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=device)
-        self.step = torch.zeros(1, dtype=torch.int32, device=device)
+        self.step = K.step_counter(device) if torch.device(device).type == "cuda" else torch.zeros(1, dtype=torch.int32, device=device)
         self.offsets = offs
         with torch.no_grad():
             for p, o in zip(self.params, offs):
@@ -641,8 +641,12 @@ class Trainer:
             # a batch of another shape (the reference's generator yields a smaller last batch of an epoch): the captured
             # graph is for one shape only, so this step runs eagerly (same kernels, same update)
             return self._eager(x, t)
-        self._static_x.copy_(x)
-        self._static_t.copy_(t)
+        # a caller that fills the trainer's own input buffers (input_buffers(): the data step writes the batch straight into them)
+        # has no copy to pay; any other tensor is copied in
+        if x is not self._static_x:
+            self._static_x.copy_(x)
+        if t is not self._static_t:
+            self._static_t.copy_(t)
         if self._use_side:
             self._watched_side_replay()
             return self._side_loss
@@ -659,6 +663,11 @@ class Trainer:
             self._allreduce()
             self._update()
         return self._static_loss
+
+    def input_buffers(self):
+        """(x, t) device buffers the captured graphs read (None before the first graph step).  A data step that writes a batch
+        straight into them (datastep.patch_batch(out=...)) and passes THESE tensors to step() skips the per-step input copy."""
+        return self._static_x, self._static_t
 
     def _replay_side(self):
         # three graphs, no host-side cross-stream dependency: the streams meet through device flags (SideSchedule)
@@ -840,7 +849,7 @@ class SearchTrainer:
         self.aflat, self.agrad, aoffs = flatten_params(self.aparams, self.device)
         self.a_m = torch.zeros_like(self.aflat)
         self.a_v = torch.zeros_like(self.aflat)
-        self.a_step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.a_step = K.step_counter(self.device) if self.device.type == "cuda" else torch.zeros(1, dtype=torch.int32, device=self.device)
         # the alphas' Adam state in the shape checkpoint.adam_state_dict reads (optim_shell, search.py:103)
         self.afp = types.SimpleNamespace(params=self.aparams, offsets=aoffs, exp_avg=self.a_m, exp_avg_sq=self.a_v, step=self.a_step)
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
@@ -1008,7 +1017,9 @@ class SearchTrainer:
             drop_snap.restore()
         if any(a.shape != b.shape for a, b in ((x, self._sx), (t, self._st), (val_x, self._svx), (val_t, self._svt))):
             return self._both(x, t, val_x, val_t)   # remainder batch of an epoch: eager step (the graph is for one shape)
-        self._sx.copy_(x); self._st.copy_(t); self._svx.copy_(val_x); self._svt.copy_(val_t)
+        for dst, src in ((self._sx, x), (self._st, t), (self._svx, val_x), (self._svt, val_t)):
+            if src is not dst:      # input_buffers(): a caller that fills the trainer's own buffers has no copy to pay
+                dst.copy_(src)
         if self._use_side:
             self._replay_side()
             sd = self.side
@@ -1018,6 +1029,10 @@ class SearchTrainer:
             return self._side_losses
         self._replay_plain()
         return self._losses
+
+    def input_buffers(self):
+        """(x, t, val_x, val_t) device buffers the captured graphs read (see Trainer.input_buffers)"""
+        return self._sx, self._st, self._svx, self._svt
 
     def _replay_side(self):
         g_arch, g_main, g_side, g_tail = self._side_graphs

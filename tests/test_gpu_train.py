@@ -117,3 +117,61 @@ def test_trainer_gradients_equal_autograd_gradients(gname):
         tr._fwd_bwd(x, t)
         for n, p in net2.named_parameters():
             assert float((p.grad - ref[n]).double().norm()) <= 1e-5 * tot, n
+
+
+@pytest.mark.parametrize("schedule", ["single-stream", "side-stream"])
+def test_benchmarked_configuration_vs_oracle(schedule):
+    """BASELINE configs[1] in one piece, as bench.py times it: SearchedNet / G_conv, batch 2, 4x64^3 fp32, TRAIN mode (head
+    Dropout3d(0.5) active, searched.py:91-93; the mask made explicit so that the oracle can use the same one), `Trainer(graph=True)`
+    on either schedule.  Step 1: loss, probabilities and every parameter's gradient against the CPU oracle
+    (oracle.searched_forward(drop_mask=) + Dice, train.py:121-125); steps 2-3 (graph replay): losses and weights against
+    torch.optim.Adam on the oracle (train.py:49,128)."""
+    from nas_3d_unet_amd.programs import forced_dropout_gate
+    from nas_3d_unet_amd.train import Trainer
+    from oracle import ref_path as orc
+    key = "bench/searched/G_CONV/d4s64/b2/drop"
+    xn, tn = gc.net_batch(key, 2, 64)
+    gate_n = gc.case_drop_gate(key, 2, 12, 0.5)
+    assert 0 < (gate_n == 0).sum() < gate_n.size          # a real mask: some channels dropped, some kept
+    # ---- oracle trajectory
+    P = orc.make_params(orc.searched_param_specs(orc.DEFAULT_CFG, orc.G_CONV), requires_grad=True)
+    opt = torch.optim.Adam(list(P.values()))
+    xo, to, go = torch.from_numpy(xn), torch.from_numpy(tn), torch.from_numpy(gate_n)
+    ref_losses, ref_p, ref_g = [], None, None
+    for it in range(3):
+        opt.zero_grad()
+        po = orc.searched_forward(P, xo, orc.G_CONV, drop_mask=go)
+        lo = orc.dice_loss(po, to)
+        lo.backward()
+        if it == 0:
+            ref_p = po.detach().clone()
+            ref_g = {n: q.grad.detach().clone() for n, q in P.items()}
+        ref_losses.append(float(lo.detach()))
+        opt.step()
+    # ---- HIP
+    net, head = build_net("searched", "G_CONV", 4, keep_dropout=True)
+    net.train()
+    x, t, gate = dev(xn), dev(tn), dev(gate_n)
+    with forced_dropout_gate(gate):
+        with torch.no_grad():
+            l0, p0 = net.forward_loss(x, t)
+        assert abs(float(l0) - ref_losses[0]) < 5e-6
+        assert float((p0.cpu() - ref_p).abs().max()) < 2e-5
+        tr = Trainer(net, graph=True, side_wgrad="force" if schedule == "side-stream" else False)
+        losses = [float(tr.step(x, t))]
+        if schedule == "side-stream":
+            assert tr._use_side, "the side stream was not accepted on this box"
+        total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in ref_g.values())))
+        for n, q in net.named_parameters():
+            d = float((q.grad.cpu() - ref_g[n]).abs().max())
+            # (conv biases ahead of a GroupNorm have a mathematically zero gradient: at 2 x 64^3 the reference's own value is
+            # ~1e-3 of fp32 cancellation noise, hence the absolute term)
+            assert d <= 2e-4 * float(ref_g[n].abs().max()) + 3e-5 * total, (n, d)
+        losses += [float(tr.step(x, t)) for _ in range(2)]
+        torch.cuda.synchronize()
+        tr.check_sync()
+    np.testing.assert_allclose(losses, ref_losses, rtol=0, atol=2e-4)
+    for n, q in net.named_parameters():
+        ref = float(P[n].detach().double().norm())
+        # (Adam moves an element whose gradient is fp32 noise by ~lr per step whatever its sign: see test_trainer_matches_reference_adam)
+        assert abs(float(q.detach().double().norm()) - ref) <= 5e-4 * ref + 3e-3, n

@@ -29,6 +29,11 @@ HOST_ONLY = {"n3d_conv_workspace_bytes", "n3d_conv_stats_rows", "n3d_conv_pack_i
              "n3d_dropout3d_uniform", "n3d_comm_unique_id", "n3d_comm_init", "n3d_comm_destroy"}
 
 
+# entry points that are never replayed for timing: they change state the step depends on (weights and moments, the dropout
+# generator) or hold a stream until another stream acts (the device-side hand-off); their coarse per-call event time is reported
+NO_REPLAY = {"n3d_adam_step", "n3d_dropout3d_gate", "n3d_sync_wait", "n3d_sync_signal"}
+
+
 class Recorder:
     """with Recorder() as r: ...   r.calls = [(name, args)] of every libn3d call made inside"""
 
@@ -252,7 +257,7 @@ def table(run_step, device, top=5, candidates=14):
     ranked = sorted(groups.items(), key=lambda kv: -kv[1]["coarse_us"])[:candidates]
     rows = []
     for sig, gr in ranked:
-        if gr["name"].startswith("n3d_comm"):
+        if gr["name"].startswith("n3d_comm") or gr["name"] in NO_REPLAY:
             us = gr["coarse_us"] / gr["calls"]
         else:
             try:
