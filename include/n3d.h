@@ -49,7 +49,11 @@ extern "C" {
  * and the kernel converts on load / store, computing in fp32.  Conv family: SRC = the first activation tensor of the call (x; dy of a
  * data gradient; x of a weight gradient), DST = the second (y; dx and relu_src of a data gradient; dy of a weight gradient).
  * Epilogue family (n3d_channel_stats / n3d_affine_act*): every activation tensor of one call shares ONE type, N3D_ACT_BF16 (or the
- * `dtype` field of the term structures). */
+ * `dtype` field of the term structures).
+ * READABLE SLACK: the 3x3x3 kernels of the bf16 path fill their LDS tiles 16 bytes per voxel (LDS-DMA), so a bf16 tensor with
+ * 4 channels (an 8-byte voxel) is read up to 8 bytes past its last element.  Every bf16 activation tensor handed to the conv
+ * family must therefore be followed by at least 16 readable bytes in the same allocation (their content is ignored); the
+ * Python host allocates bf16 tensors with that slack and repacks foreign ones (kernels.as_view). */
 #define N3D_SRC_BF16 64
 #define N3D_DST_BF16 128
 #define N3D_ACT_BF16 64

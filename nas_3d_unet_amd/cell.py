@@ -54,6 +54,6 @@ class Cell(nn.Module):
 
     def forward(self, x0, x1, alpha1, alpha2):
         # one launch program per cell (fused.py); the result is the channel concatenation of the node outputs
-        if self._plan is None:
+        if not fused.current(self._plan):
             self._plan = fused.supernet_plan(self)
         return fused.CellFn.apply(self._plan, x0, x1, alpha1, alpha2, *self._plan.params)

@@ -20,11 +20,9 @@ struct Rccl {
   const char* (*GetErrorString)(int) = nullptr;
 };
 
-static Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+static Rccl load_rccl() {
+  Rccl r;
+  {
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);   // torch's copy, if torch.distributed brought it in
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
@@ -38,6 +36,11 @@ static Rccl* rccl() {
       if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) r.h = nullptr;
     }
   }
+  return r;
+}
+
+static Rccl* rccl() {
+  static Rccl r = load_rccl();   // function-local static: initialised once, also when two threads make the first call
   return r.h ? &r : nullptr;
 }
 
@@ -58,7 +61,10 @@ int n3d_comm_available(void) { return rccl() ? 1 : 0; }
 int n3d_comm_unique_id(void* id_out) {
   N3D_CHECK_ARG(id_out, "comm_unique_id: null output");
   Rccl* r = rccl();
-  if (!r) N3D_UNSUPPORTED("comm_unique_id: librccl.so.1 could not be loaded (%s)", dlerror() ? dlerror() : "?");
+  if (!r) {
+    const char* why = dlerror();    // one call: dlerror() clears the message it returns
+    N3D_UNSUPPORTED("comm_unique_id: librccl.so.1 could not be loaded (%s)", why ? why : "?");
+  }
   if (int e = r->GetUniqueId(id_out)) return rccl_fail("ncclGetUniqueId", e);
   return N3D_OK;
 }

@@ -55,6 +55,7 @@ class _Plan:
         self.pre0, self.pre1, self.n_nodes, self.c_node, self.edges, self.params = pre0, pre1, n_nodes, c_node, edges, params
         self.index = {id(p): i for i, p in enumerate(params)}
         self.pairs = pairs  # searched cell: node k = exactly two single-primitive edges (2k, 2k+1)
+        self.version = P.PLAN_VERSION[0]   # of the ops' launch programs this plan was built from
         self.dt = torch.float32  # storage type of the cell's activations (bf16 configuration: set by _NetPlan)
 
 
@@ -502,8 +503,9 @@ class _NetPlan:
         self.stem0, self.stem1 = _single_segment(net.stem0), _single_segment(net.stem1)
         make = supernet_plan if supernet else searched_plan
         cells = list(net.down_cells) + list(net.up_cells)
+        self.version = P.PLAN_VERSION[0]
         for c in cells:
-            if c._plan is None:
+            if c._plan is None or c._plan.version != P.PLAN_VERSION[0]:
                 c._plan = make(c)
         self.cells = [c._plan for c in cells]
         # storage policy (BASELINE configs[4]): with net._n3d_storage == "bf16" the stems and the cells of the HBM-bound levels
@@ -537,6 +539,11 @@ class _NetPlan:
 
 def net_plan(net, supernet):
     return _NetPlan(net, supernet)
+
+
+def current(plan):
+    """is a cached cell / net plan still built from the ops' current launch programs?"""
+    return plan is not None and plan.version == P.PLAN_VERSION[0]
 
 
 class NetFn(torch.autograd.Function):

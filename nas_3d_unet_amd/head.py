@@ -87,10 +87,12 @@ def run(head, x):
 
 
 def run_loss(head, x, t, smooth=1e-6):
-    """(Dice loss, probabilities) of the head on features x against the target t"""
+    """(Dice loss, probabilities) of the head on features x against the target t.  The probabilities are returned for
+    inspection only and carry NO gradient on either path (the fused kernels form the Dice gradient inside the head's backward
+    pass): a caller who wants another loss on them uses run() and differentiates through that."""
     if not fusable(head, x) or t.dtype != torch.float32:
         from .loss import WeightedDiceLoss
         p = head(x)
-        return WeightedDiceLoss(smooth=smooth)(p, t), p
+        return WeightedDiceLoss(smooth=smooth)(p, t), p.detach()
     op = head[0]
     return HeadDiceFn.apply(_gate(op, x), float(smooth), x, t, op.conv.weight, op.conv.bias)

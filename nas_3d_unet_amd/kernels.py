@@ -75,7 +75,21 @@ def empty_ndhwc(B, Cc, D, H, W, device, dtype=None):
 
 
 def zeros_ndhwc(B, Cc, D, H, W, device, dtype=None):
-    return torch.zeros((B, D, H, W, Cc), device=device, dtype=dtype if dtype is not None else _act_dtype).permute(0, 4, 1, 2, 3)
+    dtype = dtype if dtype is not None else _act_dtype
+    if dtype == torch.bfloat16:      # same 16 bytes of slack as empty_ndhwc
+        n = B * D * H * W * Cc
+        return torch.zeros(n + 8, device=device, dtype=dtype)[:n].view(B, D, H, W, Cc).permute(0, 4, 1, 2, 3)
+    return torch.zeros((B, D, H, W, Cc), device=device, dtype=dtype).permute(0, 4, 1, 2, 3)
+
+
+def _bf16_slack_ok(t, ld):
+    """bf16 tensors whose voxel is 8 bytes (4 channels) are read 16 bytes at a time by the LDS-DMA tile fills (conv_bf16.hip), i.e.
+    up to 8 bytes past the last element: the storage behind the tensor must hold them (include/n3d.h, N3D_SRC_BF16)"""
+    if t.dtype != torch.bfloat16 or t.shape[1] != 4:
+        return True
+    B, Cc, D, H, W = t.shape
+    last = t.storage_offset() + (B * D * H * W - 1) * ld + Cc        # one past the last element, in elements
+    return t.untyped_storage().nbytes() >= (last + 4) * 2
 
 
 def like(v):
@@ -158,7 +172,7 @@ def as_view(t, what="tensor", bf16_ok=True):
     if t.dtype != torch.float32 and not (bf16_ok and t.dtype == torch.bfloat16):
         raise N3DError("%s: fp32 expected, got %s" % (what, t.dtype))
     ld = _pitch_of(t)
-    if ld is None or (t.data_ptr() % (4 * t.element_size()) != 0) or (ld % 4 != 0 and t.shape[1] % 4 == 0):
+    if ld is None or (t.data_ptr() % (4 * t.element_size()) != 0) or (ld % 4 != 0 and t.shape[1] % 4 == 0) or not _bf16_slack_ok(t, ld):
         B, Cc, D, H, W = t.shape
         n = empty_ndhwc(B, Cc, D, H, W, t.device, t.dtype)
         n.copy_(t)  # layout plumbing (strided copy); arithmetic stays in libn3d

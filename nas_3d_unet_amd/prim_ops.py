@@ -73,6 +73,7 @@ class BaseOp(nn.Module):
         # (e.g. `op.dropout = None`, as the reference's users do to switch the head's Dropout3d off) must rebuild them
         if name in ("norm", "dropout", "activation", "conv", "depth_conv", "point_conv", "fc", "ops_list") and "_segments" in self.__dict__:
             self.__dict__["_segments"] = None
+            P.PLAN_VERSION[0] += 1    # cached cell / net plans (fused.searched_plan / supernet_plan / net_plan) hold the old segments
         super().__setattr__(name, value)
 
     # subclasses describe their weight op ------------------------------------------------------

@@ -18,6 +18,10 @@ from . import kernels as K
 from ._lib import ACCUMULATE, RELU, RELU_IN, N3DError
 
 
+# bumped whenever an op's launch program is invalidated (prim_ops.BaseOp.__setattr__): cached cell / net plans compare it
+PLAN_VERSION = [0]
+
+
 def group_count(c):
     """GroupNorm group rule of the reference (prim_ops.py:57)."""
     return 1 if c % 16 != 0 else c // 16

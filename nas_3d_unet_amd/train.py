@@ -147,11 +147,30 @@ class GradSync:
         if rank == 0:
             _lib.check(lib.n3d_comm_unique_id(buf), "n3d_comm_unique_id")
         box = [bytes(buf.raw)]
-        dist.broadcast_object_list(box, src=0, group=self.pg)   # the 128-byte id travels out of band
+        # the 128-byte id travels out of band, from the group's rank 0 (`src` is a GLOBAL rank, also for a sub-group)
+        src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
+        dist.broadcast_object_list(box, src=src, group=self.pg)
         comm = C.c_void_p()
         idb = (C.c_char * 128).from_buffer_copy(box[0])
-        _lib.check(lib.n3d_comm_init(idb, self.world, rank, C.byref(comm)), "n3d_comm_init")
+        with torch.cuda.device(self.g.device):     # the communicator binds to the current HIP device
+            _lib.check(lib.n3d_comm_init(idb, self.world, rank, C.byref(comm)), "n3d_comm_init")
         self._comm = comm
+
+    def close(self):
+        """destroy the communicator this object created (N3D_COMM=rccl); safe to call twice"""
+        comm, self._comm = self._comm, None
+        if comm is not None:
+            from . import _lib
+            try:
+                _lib.load().n3d_comm_destroy(comm)
+            except Exception:
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def reduce_range(self, i):
         """SUM all-reduce of bucket i on the CURRENT stream"""
@@ -535,7 +554,7 @@ class Trainer:
         from . import head as _head, programs as _P
         m = self.model
         plan = getattr(m, "_net_plan", None)
-        if plan is None:
+        if not _fused.current(plan):
             plan = m._net_plan = _fused.net_plan(m, supernet=False)
         op = m.last_conv[0]
         if cell_hook is not None:

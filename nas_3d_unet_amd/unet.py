@@ -65,7 +65,7 @@ def body(net, x, alphas=None):
         a1d, a1u, a2d, a2u = alphas
         return route(net, x, lambda cell, skip, cur: cell(skip, cur, a1d, a2d), lambda cell, skip, cur: cell(skip, cur, a1u, a2u), head=False)
     plan = getattr(net, "_net_plan", None)
-    if plan is None:
+    if not fused.current(plan):      # first call, or an op's norm / dropout / conv was re-assigned since
         plan = net._net_plan = fused.net_plan(net, supernet=alphas is not None)
     return fused.NetFn.apply(plan, x, *(alphas if alphas is not None else (None,) * 4), *plan.params)
 

@@ -249,3 +249,22 @@ def test_searched_net_bf16_with_non_conv_primitives_vs_oracle():
     assert net._net_plan.stem_dt == torch.bfloat16 and all(pl.dt == torch.float32 for pl in net._net_plan.cells)
     _check_against_fp32(l, logits, p, {n: q.grad for n, q in net.named_parameters()}, float(lr), zr.detach(), pr.detach(),
                         {n: q.grad for n, q in P.items()})
+
+
+def test_foreign_bf16_tensor_without_slack_is_repacked():
+    """the bf16 3x3x3 kernels read 16 bytes per 8-byte voxel, i.e. up to 8 bytes past a dense 4-channel tensor.
+    Tensors the package allocates carry that slack; a caller-owned one that does not must be repacked by as_view, not
+    handed to the kernels as it is (include/n3d.h, "READABLE SLACK")."""
+    from nas_3d_unet_amd import kernels as K
+    own = K.empty_ndhwc(2, 4, 8, 8, 8, torch.device("cuda"), torch.bfloat16)
+    assert K.as_view(own).t.data_ptr() == own.data_ptr()                      # slack present: used in place
+    z = K.zeros_ndhwc(2, 4, 8, 8, 8, torch.device("cuda"), torch.bfloat16)
+    assert K.as_view(z).t.data_ptr() == z.data_ptr() and float(z.float().abs().sum()) == 0.0
+    foreign = torch.randn(2, 8, 8, 8, 4, device="cuda").to(torch.bfloat16).permute(0, 4, 1, 2, 3)   # dense NDHWC, exact-size storage
+    v = K.as_view(foreign)
+    assert v.t.data_ptr() != foreign.data_ptr() and torch.equal(v.t, foreign)
+    assert v.t.untyped_storage().nbytes() >= foreign.numel() * 2 + 16
+    wide = torch.randn(2, 8, 8, 8, 8, device="cuda").to(torch.bfloat16).permute(0, 4, 1, 2, 3)      # 16-byte voxels: nothing is over-read
+    assert K.as_view(wide).t.data_ptr() == wide.data_ptr()
+    inner = K.empty_ndhwc(2, 12, 8, 8, 8, torch.device("cuda"), torch.bfloat16)[:, 4:8]               # a channel slice of a wider buffer
+    assert K.as_view(inner).t.data_ptr() == inner.data_ptr()
