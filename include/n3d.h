@@ -453,6 +453,9 @@ int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * The two streams must map to different hardware queues (a wait at the head of the queue that also carries the signal
  * would time out); train.Trainer probes this once. */
 int n3d_sync_signal(void* flag, void* step, int bump, void* stream);
+/* diagnostic: stores the 100 MHz wall clock (s_memrealtime) to *out (device uint64) when the stream gets there -- rocprofv3's
+ * kernel trace serialises the two streams, so the timeline of the side-stream schedule is taken with these (tools/side_timeline.py) */
+int n3d_stamp(void* out, void* stream);
 int n3d_sync_wait(const void* flag, void* step, void* timeouts, int bump, int64_t max_polls, void* stream);
 
 #ifdef __cplusplus

@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libn3d.so")
+LIB_PATH = os.environ.get("N3D_LIB") or os.path.join(_HERE, "libn3d.so")   # N3D_LIB: another build of the same ABI (A/B timing of a kernel change)
 
 
 class N3DError(RuntimeError):
@@ -193,6 +193,7 @@ PROTOTYPES = {
     "n3d_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _f, _p, _i, _p]),
     "n3d_sync_signal": (_i, [_p, _p, _i, _p]),
     "n3d_sync_wait": (_i, [_p, _p, _p, _i, _i64, _p]),
+    "n3d_stamp": (_i, [_p, _p]),
 }
 
 # flags (include/n3d.h)

@@ -37,9 +37,16 @@ __global__ void sync_wait_kernel(const unsigned* flag, unsigned* step, unsigned*
   if (!ok) atomicAdd(timeouts, 1u);
   if (bump) *step = want + 1;
 }
+__global__ void stamp_kernel(unsigned long long* out) { *out = __builtin_amdgcn_s_memrealtime(); }
 }  // namespace
 
 extern "C" {
+int n3d_stamp(void* out, void* stream) {
+  N3D_CHECK_ARG(out && (reinterpret_cast<uintptr_t>(out) & 7) == 0, "n3d_stamp: needs an 8-byte aligned device word");
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)out);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
 int n3d_sync_signal(void* flag, void* step, int bump, void* stream) {
   N3D_CHECK_ARG(flag && step, "n3d_sync_signal: null pointer");
   hipLaunchKernelGGL(sync_signal_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned*)flag, (unsigned*)step, bump);

@@ -1081,6 +1081,11 @@ def sync_wait(flag_ptr, step_ptr, timeouts_ptr, bump=False, max_polls=5000000):
                                     stream_ptr()), "n3d_sync_wait")
 
 
+def stamp(ptr_):
+    """diagnostic: the current stream stores the 100 MHz wall clock to the device uint64 at `ptr_` when it gets there"""
+    check(_lib.load().n3d_stamp(C.c_void_p(ptr_), stream_ptr()), "n3d_stamp")
+
+
 # ------------------------------------------------------------------------------------------ fused head
 def dropout3d_gate(state, p, B, Cc):
     """(B, C) Dropout3d gate drawn on the device from `state` (uint32[3]: seed_lo, seed_hi, counter; the counter advances)"""

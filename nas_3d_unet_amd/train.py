@@ -257,6 +257,10 @@ class SideSchedule:
         self.seen = 0
         self.replays = 0
         self.watch = None
+        # N3D_SIDE_TRACE=1 (tools/side_timeline.py): wall-clock stamps next to every hand-off.  int64 words: [0] main: first cut,
+        # [2 i + 2] main stored flag i, [2 i + 3] side passed wait i, [300] side done, [301] main passed the join, [302] slab
+        # reduction launched behind it
+        self.trace = torch.zeros(304, dtype=torch.int64, device=device) if os.environ.get("N3D_SIDE_TRACE") == "1" else None
         self.stream = self._probe()
 
     def ptr(self, i):
@@ -340,6 +344,8 @@ class SideSchedule:
         n = ctx.queued()
         if n > 0 and (final or (n >= self.min_queue and self._cuts < self.JOIN - 1)):
             K.sync_signal(self.ptr(8 + self._cuts), self.ptr(0), False)
+            if self.trace is not None:
+                K.stamp(self.trace.data_ptr() + 8 * (2 * self._cuts + 2))
             ctx.wq.insert(len(ctx.wq) - n, ("mark", self._cuts))    # the wait goes IN FRONT of the launches it guards
             ctx.wq.append(("mark", -1))                              # closes the group (no wait)
             self._cuts += 1
@@ -350,15 +356,23 @@ class SideSchedule:
         def on_mark(tag):
             if tag >= 0:
                 K.sync_wait(self.ptr(8 + tag), self.ptr(2), self.ptr(1), False)
+                if self.trace is not None:
+                    K.stamp(self.trace.data_ptr() + 8 * (2 * tag + 3))
         with K.step_context(self.ctx):
             self.ctx.flush_wgrads(on_mark)
         K.sync_signal(self.ptr(8 + self.JOIN), self.ptr(2), True)
+        if self.trace is not None:
+            K.stamp(self.trace.data_ptr() + 8 * 300)
 
     def finish(self):
         """on the main stream: wait for the side stream's 'done' flag, then reduce the weight-gradient slabs (one launch)"""
         K.sync_wait(self.ptr(8 + self.JOIN), self.ptr(0), self.ptr(1), True)
+        if self.trace is not None:
+            K.stamp(self.trace.data_ptr() + 8 * 301)
         with K.step_context(self.ctx):
             self.ctx.flush_final()
+        if self.trace is not None:
+            K.stamp(self.trace.data_ptr() + 8 * 302)
 
 
 class _Ctx:
@@ -690,10 +704,12 @@ class Trainer:
 
     def _replay_side(self):
         # three graphs, no host-side cross-stream dependency: the streams meet through device flags (SideSchedule)
+        # (the side graph goes first: its device-side waits are then in place when the main chain reaches its cuts, also when the
+        # host is slower at launching than the GPU at running, e.g. under a profiler)
         g_main, g_side, g_tail = self._side_graphs
-        g_main.replay()
         with torch.cuda.stream(self.side.stream):
             g_side.replay()
+        g_main.replay()
         g_tail.replay()
         if self.dp_path:
             self._allreduce()
@@ -1058,9 +1074,9 @@ class SearchTrainer:
         g_arch.replay()
         if self.dp_path:
             self._update(True)
-        g_main.replay()
         with torch.cuda.stream(self.side.stream):
-            g_side.replay()
+            g_side.replay()      # first: see Trainer._replay_side
+        g_main.replay()
         g_tail.replay()
         if self.dp_path:
             self._update(False)

@@ -8,7 +8,7 @@ from nas_3d_unet_amd.train import SearchTrainer
 dev = torch.device("cuda")
 torch.manual_seed(1)
 net = nas.ShellNet(4, 4, 3, 4, 3, False, True).to(dev); net.train()
-tr = SearchTrainer(net, graph=False)
+tr = SearchTrainer(net, graph=False, side_wgrad=False)
 xn, tn = bench.synthetic_batch(2, 64, 1); vxn, vtn = bench.synthetic_batch(2, 64, 2)
 x, t, vx, vt = (torch.from_numpy(a).to(dev) for a in (xn, tn, vxn, vtn))
 x, vx = bench.to_patch_layout(x), bench.to_patch_layout(vx)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Timeline of the side-stream schedule of one replayed train step, from wall-clock stamps the two streams store next to every
+hand-off (N3D_SIDE_TRACE=1; rocprofv3's kernel trace serialises the streams and cannot show this).
+    python tools/side_timeline.py [--size 64] [--dtype f32|bf16] > profiles/r03_side_timeline.txt
+Columns: when the MAIN stream published cut i (microseconds from the step's first cut), when the SIDE stream got past its wait on
+it (= its weight-gradient group i starts), the lag between the two, and an upper bound of how long the group ran (until the side
+stream got past its NEXT wait, which includes any time it spent waiting there)."""
+import argparse, os, sys, time
+os.environ["N3D_SIDE_TRACE"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from nas_3d_unet_amd import searched
+from nas_3d_unet_amd.train import Trainer
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=64)
+ap.add_argument("--dtype", default="f32")
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+torch.manual_seed(1234)
+net = searched.SearchedNet(4, 4, 3, 4, 3, True, searched.Genotype(**bench.G_CONV)).to(dev)
+net.train()
+tr = Trainer(net, graph=True, side_wgrad="force", storage="bf16" if args.dtype == "bf16" else None)
+xn, tn = bench.synthetic_batch(2, args.size, 1234)
+x, t = bench.to_patch_layout(torch.from_numpy(xn).to(dev)), torch.from_numpy(tn).to(dev)
+for _ in range(10):
+    tr.step(x, t)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(30):
+    tr.step(x, t)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / 30 * 1e3
+tr.check_sync()
+st = tr.side.trace.cpu().numpy().astype("int64")
+n = int((tr.side.sync[8:108] > 0).sum())
+us = lambda v: (int(v) - int(st[2])) / 100.0      # 100 MHz clock
+print("searched-net train step, batch 2, 4x%d^3 %s, side-stream schedule (with the stamps' own launches): %.3f ms per step, %d cuts" % (args.size, args.dtype, ms, n))
+print("%4s %12s %14s %10s %12s" % ("cut", "main signal", "side past wait", "side lag", "group ran"))
+for i in range(n):
+    m, w = us(st[2 * i + 2]), us(st[2 * i + 3])
+    nxt = us(st[2 * (i + 1) + 3]) if i + 1 < n else us(st[300])
+    print("%4d %12.1f %14.1f %10.1f %12s" % (i, m, w, w - m, "<= %.1f" % (nxt - w)))
+print("side stream done at %.1f us; main stream past the join at %.1f us (main's last cut at %.1f us); slab reduction launched by %.1f us"
+      % (us(st[300]), us(st[301]), us(st[2 * (n - 1) + 2]), us(st[302])))

@@ -51,7 +51,7 @@ def main():
     torch.manual_seed(1234)
     net = searched.SearchedNet(4, 4, 3, 4, 3, True, searched.Genotype(**bench.G_CONV)).to(dev)
     net.train()
-    tr = Trainer(net, graph=True)
+    tr = Trainer(net, graph=True, side_wgrad=False)   # the plain single-stream trainer: this probe makes its own streams
     xn, tn = bench.synthetic_batch(2, args.size, 1234)
     x, t = bench.to_patch_layout(torch.from_numpy(xn).to(dev)), torch.from_numpy(tn).to(dev)
 
