@@ -231,6 +231,28 @@ def test_trainer_bf16_storage_graph_replay():
     assert out["bf16"][2] < out["bf16"][0]
 
 
+def test_bf16_storage_trains_with_fp32_at_128():
+    """BASELINE configs[4] at its own size (config.yml:58; train.py:117-128): 20 HIP-graph-replayed Adam steps on a batch of
+    4x128^3 patches, bf16 storage against the fp32 trainer from the same weights -- the loss curves must stay together
+    (<= 2e-3 at EVERY step) and must actually move."""
+    import bench
+    from nas_3d_unet_amd.train import Trainer
+    xn, tn = bench.synthetic_batch(2, 128, 77)
+    x, t = bench.to_patch_layout(dev(xn / 50.0)), dev(tn)
+    curves = []
+    for storage in (None, "bf16"):
+        net, _ = build_net("searched", "G_CONV", 4)       # closed-form weights, head Dropout3d off: the two runs see the same net
+        tr = Trainer(net, graph=True, storage=storage)
+        curves.append([float(tr.step(x, t)) for _ in range(20)])
+        torch.cuda.synchronize()
+        tr.check_sync()
+        del tr, net
+        torch.cuda.empty_cache()
+    f32, b16 = np.array(curves[0]), np.array(curves[1])
+    assert np.abs(f32 - b16).max() <= 2e-3, (f32, b16)
+    assert f32[0] - f32[-1] > 5e-3, "the fp32 run did not train: the comparison would be vacuous"
+
+
 def test_searched_net_bf16_with_non_conv_primitives_vs_oracle():
     """G_ALL (depthwise-separable, SE, pooling, identity primitives): the cells that contain primitives without bf16 kernels stay
     fp32 as a whole, the stems (and any all-conv cell) store bf16 -- mixed storage with conversions in the cells' preprocess convs.
