@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 --pmc passes of tools/collect_profiles.sh for one kernel: median counter value per dispatch.
+"""Summarise the rocprofv3 --pmc passes of tools/collect_pmc_r02.sh for one kernel: median counter value per dispatch.
    usage: pmc_summary.py <dir with pmc_*/> <kernel substring> <out.json>"""
 import csv, glob, json, statistics, sys, collections
 root, kname, out = sys.argv[1], sys.argv[2], sys.argv[3]
