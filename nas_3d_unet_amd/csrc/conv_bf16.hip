@@ -12,6 +12,7 @@
 //   * Output rounded to bf16 on store (v_cvt_pk_bf16_f32, round-to-nearest-even).
 // The MFMA phase shrinks 4x against the fp32 kernel, the fill moves half the bytes: the kernel is bound by the LDS-DMA fill and
 // HBM, which is where this configuration lives.
+#include <stdlib.h>
 #include "n3d_common.h"
 
 namespace n3d {
@@ -58,11 +59,21 @@ __device__ __forceinline__ f32x4 mfma_bf16_4x4x4(const uint2 a, const uint2 b, c
   return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(bf16x4v, a), __builtin_bit_cast(bf16x4v, b), c, 0, 0, 0);
 }
 
-template <int C, int TD, int DIL, int NW>
+// P2 (round 3; C = 4, DENSE source tensors only: voxel pitch 4 elements, 16-byte aligned): the LDS image is dense -- 8 bytes per
+// voxel, rows of 20 voxels starting at the even column w0 - 2 -- and one DMA lane fetches a PAIR of voxels (16 contiguous bytes).
+// The one-slot-per-voxel image moves 16 bytes per 8-byte voxel (half of every fetch is the neighbour) and reads the low half of
+// every slot (2-way bank conflict on each read); the dense image halves the fill (60 DMA lanes per plane instead of 108: one
+// instruction instead of two) and reads consecutive 8-byte voxels.  Slices of a wider buffer (the node slices of a cell output,
+// voxel pitch 24 bytes) cannot be fetched in pairs and keep the slot image.
+template <int C, int TD, int DIL, int NW, bool P2 = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
+  static_assert(!P2 || C == 4, "the dense two-voxels-per-slot image is the C = 4 form");
   constexpr int HF = C / 4, GH = 4 * NW, GW = 16;
   constexpr int LD = TD + 2 * DIL, LH = GH + 2 * DIL, LW = GW + 2 * DIL;
-  constexpr int PLANE = LH * LW, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64;
+  constexpr int LWS = P2 ? 10 : LW;                // 16-byte slots per tile row
+  constexpr int LW8 = P2 ? 20 : 2 * LW;            // row pitch in 8-byte units
+  constexpr int WOFF = P2 ? (2 - DIL) : 0;         // column of the halo's first voxel inside a row of the dense image
+  constexpr int PLANE = LH * LWS, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64;
   constexpr int NW4 = (27 * C * C * 2 + 15) / 16, NWI = (NW4 + 63) / 64;   // 16-byte pieces of the packed weights
   extern __shared__ __attribute__((aligned(16))) uint4 vlds16[];  // tile [LD][PSTRIDE] slots, then the weights
   uint4* tile = vlds16;
@@ -112,8 +123,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
 #pragma unroll
     for (int i = 0; i < NPOS; ++i) {
       const int pos = lane + i * 64;
-      const int wx = pos % LW, hy = pos / LW;
-      const int gh = h0 - DIL + hy, gw = w0 - DIL + wx;
+      const int wx = pos % LWS, hy = pos / LWS;
+      const int gh = h0 - DIL + hy, gw = P2 ? w0 - 2 + 2 * wx : w0 - DIL + wx;   // P2: an even column, the pair never straddles the volume's edge
       const bool okp = pos < PLANE && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
       const bf16_t* prow = srcb + ((int64_t)gh * a.W + gw) * a.sld;
       static_assert(LD % NW == 0, "tile depth must split evenly over the waves");
@@ -139,11 +150,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
 #pragma unroll
     for (int g = 0; g < TD; ++g) acc[g][hf] = bv;
   }
-  float cs[HF][4], cq[HF][4];
+  // statistics rows: one per 4 output planes, so that a TD = 8 tile writes exactly the two rows (in the same summation order) that
+  // the two TD = 4 tiles it replaces would write -- n3d_conv_stats_rows does not depend on which form runs
+  constexpr int SR = TD == 8 ? 2 : 1;
+  float cs[SR][HF][4], cq[SR][HF][4];
 #pragma unroll
-  for (int hf = 0; hf < HF; ++hf)
+  for (int sr = 0; sr < SR; ++sr)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) cs[hf][r] = cq[hf][r] = 0.f;
+    for (int hf = 0; hf < HF; ++hf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs[sr][hf][r] = cq[sr][hf][r] = 0.f;
   bf16_t* const o_plane0 = dstb + ((int64_t)d0 * a.H * a.W + vox_off) * a.dld;
   const int64_t o_pstride = (int64_t)a.H * a.W * a.dld;
   auto emit_plane = [&](int g) {
@@ -152,7 +168,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
     for (int hf = 0; hf < HF; ++hf) {
       const f32x4 v = acc[g][hf];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { cs[hf][r] += v[r]; cq[hf][r] = fmaf(v[r], v[r], cq[hf][r]); }
+      for (int r = 0; r < 4; ++r) { cs[SR == 2 ? g / 4 : 0][hf][r] += v[r]; cq[SR == 2 ? g / 4 : 0][hf][r] = fmaf(v[r], v[r], cq[SR == 2 ? g / 4 : 0][hf][r]); }
       float4 w4 = make_float4(v[0], v[1], v[2], v[3]);
       { const float4 pv = prevv[g][hf]; w4.x += pv.x; w4.y += pv.y; w4.z += pv.z; w4.w += pv.w; }
       st4(o + hf * 4, w4);
@@ -170,14 +186,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
 #pragma unroll
     for (int g = 0; g < TD; ++g) acc2[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     uint2 avb[2][9];
+    // 8-byte index of voxel (row, col) of plane dz: slot image = low half of slot row * LW + col; dense image = row * 20 + col + WOFF
+    auto vidx = [&](int dz, int row, int col) { return 2 * dz * PSTRIDE + row * LW8 + (P2 ? col + WOFF : 2 * col); };
 #pragma unroll
-    for (int t9 = 0; t9 < 9; ++t9) avb[0][t9] = tile2[2 * ((hrow + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL))];
+    for (int t9 = 0; t9 < 9; ++t9) avb[0][t9] = tile2[vidx(0, hrow + (t9 / 3) * DIL, ww + (t9 % 3) * DIL)];
 #pragma unroll
     for (int dz = 0; dz < LD; ++dz) {
       if (dz + 1 < LD) {
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9)
-          avb[(dz + 1) & 1][t9] = tile2[2 * ((dz + 1) * PSTRIDE + (hrow + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL))];
+          avb[(dz + 1) & 1][t9] = tile2[vidx(dz + 1, hrow + (t9 / 3) * DIL, ww + (t9 % 3) * DIL)];
       }
       const uint2* av = avb[dz & 1];
 #pragma unroll
@@ -234,13 +252,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
   if (a.stats) {
     const bool odd = lane & 1, hi = lane & 2;
 #pragma unroll
+    for (int sr = 0; sr < SR; ++sr)
+#pragma unroll
     for (int hf = 0; hf < HF; ++hf) {
       float u[2], uq[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const float keep = odd ? cs[hf][2 + k] : cs[hf][k], send = odd ? cs[hf][k] : cs[hf][2 + k];
+        const float keep = odd ? cs[sr][hf][2 + k] : cs[sr][hf][k], send = odd ? cs[sr][hf][k] : cs[sr][hf][2 + k];
         u[k] = keep + dpp_f<0xB1>(send);
-        const float keepq = odd ? cq[hf][2 + k] : cq[hf][k], sendq = odd ? cq[hf][k] : cq[hf][2 + k];
+        const float keepq = odd ? cq[sr][hf][2 + k] : cq[sr][hf][k], sendq = odd ? cq[sr][hf][k] : cq[sr][hf][2 + k];
         uq[k] = keepq + dpp_f<0xB1>(sendq);
       }
       float v1 = (hi ? u[1] : u[0]) + dpp_f<0x4E>(hi ? u[0] : u[1]);
@@ -248,7 +268,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
       v1 = wave_classsum_f(v1, 4); v2 = wave_classsum_f(v2, 4);
       if (lane < 4) {
         const int ch = (lane & 1) * 2 + (lane >> 1);
-        double* o = a.stats + (((int64_t)b * a.rows_per_sample + tile_id * NW + wave) * C + hf * 4 + ch) * 2;
+        // row of the TD = 4 tile this half stands for: its D block is 2 * (d0 / 8) + sr, i.e. tile id + sr * (tiles per D block) + ...
+        int row = tile_id * NW + wave;
+        if (SR == 2) row = (((d0 / 4) + sr) * th_n + h0 / GH) * tw_n + w0 / GW;
+        double* o = a.stats + (((int64_t)b * a.rows_per_sample + row) * C + hf * 4 + ch) * 2;
         reinterpret_cast<double2*>(o)[0] = make_double2((double)v1, (double)v2);
       }
     }
@@ -612,7 +635,7 @@ static VupbPlan vupb_plan(const n3d_conv_geom* g, bool data_grad) {
   return p;
 }
 
-struct Vx16Plan { bool ok; int C, td, dil, tiles, nw; size_t lds; };
+struct Vx16Plan { bool ok; int C, td, dil, tiles, nw; size_t lds, lds_p2; };
 
 static Vx16Plan vx16_plan(const n3d_conv_geom* g) {
   Vx16Plan p; p.ok = false;
@@ -630,11 +653,23 @@ static Vx16Plan vx16_plan(const n3d_conv_geom* g) {
   const size_t pstride = ((size_t)(4 * p.nw + 2 * g->dil) * (16 + 2 * g->dil) + 63) / 64 * 64;
   const size_t wslots = (((size_t)27 * g->Ci * g->Ci * 2 + 15) / 16 + 63) / 64 * 64;
   p.lds = ((size_t)(td + 2 * g->dil) * pstride + wslots) * 16;
+  const size_t pstride2 = ((size_t)(4 * p.nw + 2 * g->dil) * 10 + 63) / 64 * 64;     // dense image: 10 slots (20 voxels) per row
+  p.lds_p2 = ((size_t)(td + 2 * g->dil) * pstride2 + wslots) * 16;
   return p;
 }
 
+// p2: the source is a DENSE 4-channel tensor (pitch 4, 16-byte aligned): the two-voxels-per-slot image
 template <int C, int TD, int DIL>
-static void launch_vox16_t(const Vx16Args& a, const Vx16Plan& p, int B, hipStream_t s) {
+static void launch_vox16_t(const Vx16Args& a, const Vx16Plan& p, int B, hipStream_t s, bool p2) {
+  if constexpr (C == 4) {
+    if (p2) {
+      if constexpr (TD == 4) {
+        if (p.nw == 2) { hipLaunchKernelGGL((conv_vox64b_kernel<C, TD, DIL, 2, true>), dim3(p.tiles * B), dim3(128), p.lds_p2, s, a); return; }
+      }
+      hipLaunchKernelGGL((conv_vox64b_kernel<C, TD, DIL, 1, true>), dim3(p.tiles * B), dim3(64), p.lds_p2, s, a);
+      return;
+    }
+  }
   if constexpr (C == 4 && TD == 4) {
     if (p.nw == 2) { hipLaunchKernelGGL((conv_vox64b_kernel<C, TD, DIL, 2>), dim3(p.tiles * B), dim3(128), p.lds, s, a); return; }
   }
@@ -642,15 +677,15 @@ static void launch_vox16_t(const Vx16Args& a, const Vx16Plan& p, int B, hipStrea
 }
 
 template <int C>
-static void launch_vox16_c(const Vx16Args& a, const Vx16Plan& p, int B, hipStream_t s) {
+static void launch_vox16_c(const Vx16Args& a, const Vx16Plan& p, int B, hipStream_t s, bool p2) {
   if (p.dil == 1) {
-    if (p.td == 4) return launch_vox16_t<C, 4, 1>(a, p, B, s);
-    if (p.td == 2) return launch_vox16_t<C, 2, 1>(a, p, B, s);
-    return launch_vox16_t<C, 1, 1>(a, p, B, s);
+    if (p.td == 4) return launch_vox16_t<C, 4, 1>(a, p, B, s, p2);
+    if (p.td == 2) return launch_vox16_t<C, 2, 1>(a, p, B, s, p2);
+    return launch_vox16_t<C, 1, 1>(a, p, B, s, p2);
   }
-  if (p.td == 4) return launch_vox16_t<C, 4, 2>(a, p, B, s);
-  if (p.td == 2) return launch_vox16_t<C, 2, 2>(a, p, B, s);
-  return launch_vox16_t<C, 1, 2>(a, p, B, s);
+  if (p.td == 4) return launch_vox16_t<C, 4, 2>(a, p, B, s, p2);
+  if (p.td == 2) return launch_vox16_t<C, 2, 2>(a, p, B, s, p2);
+  return launch_vox16_t<C, 1, 2>(a, p, B, s, p2);
 }
 
 // ---- interface to conv_generic.hip -------------------------------------------------------------------------------
@@ -705,7 +740,21 @@ int vox16_conv_try(const n3d_conv_geom* g, bool data_grad, const void* src, int6
     Vx16Args a;
     a.src = (const bf16_t*)src; a.sld = sld; a.dst = (bf16_t*)dst; a.dld = dld; a.wq = (const bf16_t*)ws; a.bias = bias;
     a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.flags = flags; a.stats = stats; a.rows_per_sample = v.tiles * v.nw; a.tiles = v.tiles; a.zero_page = zp;
-    if (v.C == 4) launch_vox16_c<4>(a, v, g->B, s); else launch_vox16_c<8>(a, v, g->B, s);
+    static const bool nop2 = getenv("N3D_VOX16_NOP2") != nullptr;   // (A/B knob)
+    const bool p2 = !nop2 && v.C == 4 && sld == 4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    if (p2 && v.nw == 1 && v.td == 4 && g->Di % 8 == 0 && (int64_t)v.tiles * g->B / 2 >= 2048) {
+      // dense image, many tiles: 8 output planes per tile (the D halo is re-fetched every 8 planes instead of every 4: 24.4 -> 22.1 us at
+      // (2,4,128^3)); the kernel still writes one statistics row per 4 planes, in the rows and the order of the 4-plane plan
+      a.tiles = v.tiles / 2;
+      const size_t pstride2 = ((size_t)(4 + 2 * g->dil) * 10 + 63) / 64 * 64, wslots = (((size_t)27 * 16 * 2 + 15) / 16 + 63) / 64 * 64;
+      const size_t lds8 = ((size_t)(8 + 2 * g->dil) * pstride2 + wslots) * 16;
+      if (g->dil == 1) hipLaunchKernelGGL((conv_vox64b_kernel<4, 8, 1, 1, true>), dim3(a.tiles * g->B), dim3(64), lds8, s, a);
+      else hipLaunchKernelGGL((conv_vox64b_kernel<4, 8, 2, 1, true>), dim3(a.tiles * g->B), dim3(64), lds8, s, a);
+      hipError_t e__ = hipGetLastError();
+      if (e__ != hipSuccess) { set_error("conv(bf16 mfma): launch error: %s", hipGetErrorString(e__)); return N3D_ERR_HIP; }
+      return 1;
+    }
+    if (v.C == 4) launch_vox16_c<4>(a, v, g->B, s, p2); else launch_vox16_c<8>(a, v, g->B, s, false);
   } else if (kind == 2) {
     const Vs2bPlan v = vs2b_plan(g, data_grad);
     Vs2bArgs a;

@@ -113,6 +113,43 @@ def test_conv_family_bf16_storage(cin, cout, k, stride, dil, transposed, shape, 
         assert_close(dw2, wr.grad, 2e-5, "dw (no bias gradient)")
 
 
+@pytest.mark.parametrize("dil", [1, 2])
+def test_dense_bf16_conv_8_plane_tiles_and_their_statistics_rows(dil):
+    """round 3: a DENSE 4-channel bf16 source takes the two-voxels-per-slot LDS image and, with >= 4096 tiles, 8 output planes per
+    tile -- which must still write the statistics rows of the 4-plane plan (n3d_conv_stats_rows does not know which form runs): the
+    output against torch fp32 on the bf16-rounded operands, every statistics row against the sums of its own 4 x 4 x 16 voxel block"""
+    from nas_3d_unet_amd import kernels as K
+    rng = np.random.default_rng(90 + dil)
+    B, C, shape = 2, 4, (64, 128, 128)
+    x16 = _bf(rng.standard_normal((B, C) + shape).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((C, C, 3, 3, 3)) * 0.2).astype(np.float32)).bfloat16().float()
+    b = torch.from_numpy(rng.standard_normal(C).astype(np.float32) * 0.1)
+    yr = F.conv3d(x16.float(), w, b, padding=dil, dilation=dil)
+    xv = _view(x16)
+    assert xv.ld == 4                                             # dense: the pair-fetching image
+    g = K.conv_geom(B, *shape, C, C, 3, 1, dil, dil)
+    with K.storage(torch.bfloat16):
+        y = K.as_view(K.empty_ndhwc(*yr.shape, torch.device("cuda")))
+    rows = K.conv_stats_rows(g, False, 0, xv, y)
+    assert rows == (shape[0] // 4) * (shape[1] // 4) * (shape[2] // 16)
+    stats = torch.full((B, rows, C, 2), float("nan"), dtype=torch.float64, device="cuda")
+    K.conv_fwd(g, xv, w.cuda(), b.cuda(), y, 0, None, stats, False)
+    assert_close(y.t.float(), yr, ULP, "y")
+    st = stats.cpu()
+    assert not torch.isnan(st).any(), "a statistics row of the 4-plane plan was not written"
+    # row (d4, h4, w16) = sums over that block of the fp32 result (before the bf16 rounding of the store)
+    blk = yr.double().reshape(B, C, shape[0] // 4, 4, shape[1] // 4, 4, shape[2] // 16, 16)
+    s1 = blk.sum(dim=(3, 5, 7)).permute(0, 2, 3, 4, 1).reshape(B, rows, C)
+    s2 = (blk * blk).sum(dim=(3, 5, 7)).permute(0, 2, 3, 4, 1).reshape(B, rows, C)
+    if dil == 1:
+        assert float((st[..., 0] - s1).abs().max()) <= 1e-4 * float(s1.abs().max())
+        assert float((st[..., 1] - s2).abs().max()) <= 1e-4 * float(s2.abs().max())
+    else:
+        # dilation 2 runs two-wave 8-row tiles, whose rows come in (tile, wave) order: the per-sample totals are what GroupNorm uses
+        assert float((st[..., 0].sum(1) - s1.sum(1)).abs().max()) <= 1e-5 * float(s2.sum(1).max())
+        assert float((st[..., 1].sum(1) - s2.sum(1)).abs().max()) <= 1e-5 * float(s2.sum(1).max())
+
+
 @pytest.mark.parametrize("C,shape,B", [(4, (16, 16, 16), 2), (8, (32, 16, 16), 2), (8, (4, 4, 4), 2), (4, (48, 32, 32), 1)])
 def test_node_epilogues_bf16_storage(C, shape, B):
     """GroupNorm -> ReLU -> node sum of two conv outputs (searched.py:45-50) and its backward with every tensor in bf16:
