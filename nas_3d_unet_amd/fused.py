@@ -492,7 +492,8 @@ WHOLE_NET = True  # nets run stems + cells as ONE autograd node (NetFn); False: 
 # into down_cells + up_cells; -1 = the stems, i.e. the end) has been launched -- the point where a gradient bucket can be handed
 # to the all-reduce while the backward of the remaining cells goes on (train.Trainer)
 CELL_DONE_HOOK = None
-NODE_DONE_HOOK = None   # called inside a searched cell's backward after every node (the side-stream schedule's finer cut points)
+NODE_DONE_HOOK = None   # called (force=False) inside a cell's backward after every node and (force=True) after each stem: the
+                        # side-stream schedule's finer cut points
 
 
 class _NetPlan:
@@ -605,6 +606,8 @@ class NetFn(torch.autograd.Function):
                     grads[off + j] = gg
             if need_x:
                 dx = d if dx is None else dx + d
+            if NODE_DONE_HOOK is not None:
+                NODE_DONE_HOOK(True)     # side-stream schedule: stem1's weight gradient starts under stem0's epilogue backward
         ctx.st0 = ctx.st1 = ctx.states = None
         if CELL_DONE_HOOK is not None:
             CELL_DONE_HOOK(-1)

@@ -218,6 +218,8 @@ class StepContext:
         self.defer_wgrad = False
         self.wq = []
         self.hold = []         # operands of launched-but-possibly-still-running side work, released by the trainer after the join
+        self.keep_jobs = []
+        self.final_side = []   # slab-reduction jobs of the launches flush_wgrads issued (the side stream's own)
 
     # ---- weight packing
     def slot(self, w, g, data_grad, flags):
@@ -284,19 +286,32 @@ class StepContext:
                 continue
             launch(stream_ptr())
             if job.nchunks > 0:
-                self.final.append(job)
+                self.final_side.append(job)
             self.hold.append((ws, keep))
             n += 1
         return n
+
+    def finalize_now(self, n_main):
+        """side stream: reduce the slabs of every weight gradient this stream has launched so far (in order behind them) and of the
+        first n_main jobs of the main chain (the caller knows they are complete: the side stream has passed a wait on a flag the
+        main stream stored behind them); the operands stay held until flush_final"""
+        jobs = self.final_side + self.final[:n_main]
+        if jobs:
+            arr = (FinalJob * len(jobs))(*jobs)
+            check(_lib.load().n3d_wgrad_finalize_batch(arr, len(jobs), stream_ptr()), "n3d_wgrad_finalize_batch")
+            self.keep_jobs.append(arr)
+            self.final_side = []
+            self.final = self.final[n_main:]
 
     def flush_final(self):
         if self.wq:
             self.flush_wgrads()
         self.join()
-        if self.final:
-            arr = (FinalJob * len(self.final))(*self.final)
-            check(_lib.load().n3d_wgrad_finalize_batch(arr, len(self.final), stream_ptr()), "n3d_wgrad_finalize_batch")
-        self.final, self.keep, self.hold = [], [], []
+        jobs = self.final + self.final_side
+        if jobs:
+            arr = (FinalJob * len(jobs))(*jobs)
+            check(_lib.load().n3d_wgrad_finalize_batch(arr, len(jobs), stream_ptr()), "n3d_wgrad_finalize_batch")
+        self.final, self.final_side, self.keep, self.hold, self.keep_jobs = [], [], [], [], []
 
 
 _ctx = None
