@@ -224,6 +224,8 @@ def _low_priority_stream(device):
             _side_prio[0] = lo.value
         with torch.cuda.device(device):
             h = C.c_void_p()
+            # (a CU mask on the side stream -- hipExtStreamCreateWithCUMask, half / a quarter / an eighth of the CUs -- changed neither
+            # the chain's time under the side work nor the tail: what the side work costs the chain is not compute units)
             if hip.hipStreamCreateWithPriority(C.byref(h), 1, _side_prio[0]) != 0 or not h.value:   # 1 = hipStreamNonBlocking
                 raise OSError("hipStreamCreateWithPriority")
         return torch.cuda.ExternalStream(h.value, device=device)

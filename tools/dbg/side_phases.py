@@ -34,7 +34,5 @@ def run(drop, mq=3):
     mx = max(e[0].elapsed_time(e[2]) for e in evs[5:])
     print("drop_side=%s min_queue=%d prio=%s: main graph %.3f ms, tail %.3f ms, sum %.3f, worst step %.3f" % (drop, mq, os.environ.get("N3D_SIDE_PRIORITY", "low"), a, b, a + b, mx), flush=True)
     tr.check_sync()
-for ef in ("0", "5", "8"):
-    os.environ["N3D_SIDE_EARLY_FINALIZE"] = ef
-    print("early_finalize", ef)
-    run(False, 3)
+run(True)
+run(False)
