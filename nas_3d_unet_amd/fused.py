@@ -155,7 +155,88 @@ def _run_forward(plan, x0, x1, alpha1, alpha2):
         return _run_forward_impl(plan, x0, x1, alpha1, alpha2)
 
 
+# Side-stream forward of a supernet cell (train.SideSchedule sets SIDE_FWD; round 3).  A node sums the MixedOps of ALL earlier states
+# (cell.py:76-81), but only the edge from the node computed LAST is on the dependent chain: the weight ops of every other edge read
+# tensors that have been complete for a while.  With SIDE_FWD set, those run on the side stream -- the edges from the two preprocess
+# outputs into nodes 1.. and one of node 0's two edges right behind the preprocess ops, an edge from node k into a later node as
+# soon as node k is written -- and the main stream keeps one edge per node plus the epilogues, which wait (device flag) for the
+# side stream's part of their node.  SIDE_FWD: .fork() main stores a flag, returns its id; .side(wait_id) context manager: launches
+# go to the side stream behind a wait on that flag; .side_signal() side stores a flag, returns its id; .join(id) main waits for it.
+SIDE_FWD = None
+
+
+def _run_forward_side(plan, x0, x1, alpha1, alpha2, sf):
+    st = P.Saved()
+    x0v, x1v = K.as_view(x0, "x0"), K.as_view(x1, "x1")
+    shp = plan.pre1.weight.out_shape(x1v)
+    p0 = K.as_view(K.empty_ndhwc(*shp, x1v.t.device))
+    p1 = K.as_view(K.empty_ndhwc(*shp, x1v.t.device))
+    if tuple(plan.pre0.weight.out_shape(x0v)) == tuple(shp) and plan.pre0.dropout is None and plan.pre1.dropout is None:
+        st.s_pre0, st.s_pre1 = P.pair_forward(plan.pre0, x0v, plan.pre1, x1v, p0, p1)
+    else:
+        p0, st.s_pre0 = P.seg_forward(plan.pre0, x0v)
+        p1, st.s_pre1 = P.seg_forward(plan.pre1, x1v)
+    xs = [p0, p1]
+    cn, nn = plan.c_node, plan.n_nodes
+    flat = _flat_terms(plan)
+    units = _node_fwd_units(plan)
+    # the node buffer (its shape is that of any term's output)
+    seg0, in0 = flat[0][2], xs[flat[0][1]]
+    oshp = seg0.weight.out_shape(in0)
+    out = K.as_view(K.empty_ndhwc(oshp[0], nn * cn, oshp[2], oshp[3], oshp[4], in0.t.device))
+    nodes = [_slice_view(out, k, cn) for k in range(nn)]
+    xs.extend(nodes)
+
+    def args_of(fi):
+        _, idx, seg, col, amat, row = flat[fi]
+        arow = (alpha1 if amat == 1 else alpha2)[row] if amat else None
+        return (seg, xs[idx], arow, col)
+
+    def on_side(node, idx):
+        """does the weight phase of a term of `node` reading state `idx` run on the side stream?"""
+        return idx == 1 if node == 0 else idx <= node          # node n's newest input is state n + 1
+
+    order = {node: [fi for unit in units[node] for fi in unit] for node in range(nn)}     # the epilogue order of the node's terms
+    res = {}
+    side_done = {}
+    # side stream, behind the preprocess ops: every term that reads p0 / p1 and is not main's
+    f0 = sf.fork()
+    with sf.side(f0):
+        for node in range(nn):
+            mine = [fi for fi in order[node] if flat[fi][1] <= 1 and on_side(node, flat[fi][1])]
+            if mine:
+                for fi, r in zip(mine, P.group_weight_phase([args_of(fi) for fi in mine])):
+                    res[fi] = r
+                side_done.setdefault(node, []).append(sf.side_signal())
+    st.saved = [None] * len(flat)
+    for node in range(nn):
+        mine = [fi for fi in order[node] if not on_side(node, flat[fi][1])]
+        for fi, r in zip(mine, P.group_weight_phase([args_of(fi) for fi in mine])):
+            res[fi] = r
+        for tok in side_done.get(node, []):
+            sf.join(tok)
+        started = False
+        for unit in units[node]:
+            for fi, sv in zip(unit, P.group_epilogue_phase([args_of(fi) for fi in unit], [res[fi] for fi in unit], nodes[node], started)):
+                st.saved[fi] = sv
+            started = True
+        # node `node` is written: the side stream may take the edges from it into the nodes after the next one
+        later = [(n2, fi) for n2 in range(node + 2, nn) for fi in order[n2] if flat[fi][1] == node + 2]
+        if later:
+            f = sf.fork()
+            with sf.side(f):
+                for n2 in sorted({n2 for n2, _ in later}):
+                    mine = [fi for m, fi in later if m == n2]
+                    for fi, r in zip(mine, P.group_weight_phase([args_of(fi) for fi in mine])):
+                        res[fi] = r
+                    side_done.setdefault(n2, []).append(sf.side_signal())
+    st.xs, st.out = xs, out
+    return out.t, st
+
+
 def _run_forward_impl(plan, x0, x1, alpha1, alpha2):
+    if SIDE_FWD is not None and not plan.pairs and _grouping(plan.c_node):
+        return _run_forward_side(plan, x0, x1, alpha1, alpha2, SIDE_FWD)
     st = P.Saved()
     x0v, x1v = K.as_view(x0, "x0"), K.as_view(x1, "x1")
     # the two preprocess ops (cell.py:47-50) are independent and of one output shape: paired epilogue launch

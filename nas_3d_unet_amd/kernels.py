@@ -17,8 +17,31 @@ from ._lib import ConvBwdCall, ConvFwdCall, DwJob, GnFwdTerm, GnBwdTerm, PlainCo
 __all__ = ["View", "as_view", "empty_ndhwc", "stream_ptr", "conv_geom", "ptr"]
 
 
+# Launch redirection (train.SideSchedule, round 3): inside `with on_side(stream)` every libn3d launch goes to the given HIP stream
+# while torch's current stream -- and with it every allocation -- stays where it is.  The caller orders the two streams with
+# sync_signal / sync_wait and keeps every tensor of the redirected launches alive until the streams have joined.
+_redirect = None
+
+
 def stream_ptr():
+    if _redirect is not None:
+        return C.c_void_p(_redirect)
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class on_side:
+    def __init__(self, stream):
+        self.ptr = stream if isinstance(stream, int) else stream.cuda_stream
+
+    def __enter__(self):
+        global _redirect
+        self.prev, _redirect = _redirect, self.ptr
+        return self
+
+    def __exit__(self, *exc):
+        global _redirect
+        _redirect = self.prev
+        return False
 
 
 def _side_launch_ptr(tensors):
@@ -572,7 +595,7 @@ class stats_cache:
 
 def channel_stats(x: View):
     if _stats_cache is not None:
-        key = (x.p.value, x.ld, x.B, x.C, x.N)
+        key = (x.p.value, x.ld, x.B, x.C, x.N, _redirect)    # per launch stream: a result computed on one stream is not ordered for the other
         hit = _stats_cache.get(key)
         if hit is None:
             hit = _stats_cache[key] = (_channel_stats(x), x.t)   # the tensor reference keeps its address from being reused
@@ -586,7 +609,7 @@ def channel_statsN(xs):
     out = [None] * len(xs)
     todo = {}
     for i, x in enumerate(xs):
-        key = (x.p.value, x.ld, x.B, x.C, x.N)
+        key = (x.p.value, x.ld, x.B, x.C, x.N, _redirect)
         hit = _stats_cache.get(key) if _stats_cache is not None else None
         if hit is not None:
             out[i] = hit[0]

@@ -801,7 +801,15 @@ def group_forward(terms, out, accumulate):
     """Supernet node (cell.py:76-81): out (+)= sum_k alpha_k * op_k(x_k) for up to 8 primitives of any kind (GroupNorm-type
     convs, identity-with-norm, SE gates, pooling).  terms = [(segment, input View, alpha row | None, alpha column)].
     The weight ops run first (two neighbouring plain convs in one launch), then the coefficients -- all GroupNorm ones in one
-    launch, one per SE gate -- and ONE pass over `out` for everything.  Returns the saved states, in term order."""
+    launch, one per SE gate -- and ONE pass over `out` for everything.  Returns the saved states, in term order.
+    The two halves are callable on their own: the weight phase of a term only reads the term's input, so the trainers' side-stream
+    schedule runs it early on a second stream for the terms whose input is not the node computed last (fused._run_forward_side)."""
+    return group_epilogue_phase(terms, group_weight_phase(terms), out, accumulate)
+
+
+def group_weight_phase(terms):
+    """first half of group_forward: every weight op of `terms` (any number) and the channel statistics their epilogues need.
+    Returns [[raw View, stats | None, rows, weight-op state]] in term order."""
     res = []
     # the gates of the stride-2 SE convs of this chunk: their input statistics in one launch, the gates in one launch
     sec = [k for k, t in enumerate(terms) if isinstance(t[0].weight, SEConvW)]
@@ -881,6 +889,15 @@ def group_forward(terms, out, accumulate):
     need = [r[0] for r, (seg, _, _, _) in zip(res, terms) if (seg.norm is not None and r[1] is None) or (seg.norm is None and seg.se_gate is not None)]
     if len(need) >= 2:
         K.channel_statsN(need)   # fills the statistics cache; the per-term calls below hit it
+    for r, (seg, _, _, _) in zip(res, terms):
+        if (seg.norm is not None or seg.se_gate is not None) and r[1] is None:
+            r[1], r[2] = K.channel_stats(r[0])      # (a hit in the statistics cache after the batched launch above)
+    return [list(r) for r in res]
+
+
+def group_epilogue_phase(terms, res, out, accumulate):
+    """second half of group_forward: coefficients (all GroupNorm ones in one launch, SE gates) and ONE pass over `out` for up to 8
+    terms whose weight phase (`res`, in term order) is complete on the launching stream.  Returns the saved states."""
     saved, gn, se = [], [], []
     for r, (seg, _, _, _) in zip(res, terms):
         s = Saved()
@@ -894,15 +911,17 @@ def group_forward(terms, out, accumulate):
             gn.append((s, (r[0], r[1], r[2], seg.norm.weight, seg.norm.bias)))
         elif seg.se_gate is not None:
             s.kind = "se"
-            se.append((s, seg.se_gate.fc, r[0]))
+            se.append((s, seg.se_gate.fc, r[0], (r[1], r[2]) if r[1] is not None else None))
         saved.append(s)
     if len(se) == 1:
-        s, fc, raw = se[0]
-        s.mean, s.hidden, s.a = SEGate(fc).fwd(raw)
+        s, fc, raw, st = se[0]
+        if st is None:
+            st = K.channel_stats(raw)
+        s.mean, s.hidden, s.a = K.se_gate_fwd(st[0], st[1], raw.N, fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, raw.B, raw.C)
     elif se:
         raw0 = se[0][2]
-        sts = [K.channel_stats(raw) for _, _, raw in se]
-        for (s, _, _), (mean, hidden, gate) in zip(se, K.se_gate_fwdN([(st, rows, fc) for (st, rows), (_, fc, _) in zip(sts, se)], raw0.N, raw0.B, raw0.C)):
+        sts = [st if st is not None else K.channel_stats(raw) for _, _, raw, st in se]
+        for (s, _, _, _), (mean, hidden, gate) in zip(se, K.se_gate_fwdN([(st, rows, fc) for (st, rows), (_, fc, _, _) in zip(sts, se)], raw0.N, raw0.B, raw0.C)):
             s.mean, s.hidden, s.a = mean, hidden, gate
     if gn:
         eps = [seg.norm.eps for seg, _, _, _ in terms if seg.norm is not None]

@@ -248,7 +248,7 @@ class SideSchedule:
     flag costs a ~2 us kernel on each side (tools/handoff_cost.cpp).
     Device words of `sync` (int32): [0] main-stream step, [1] time-outs, [2] side-stream step, [8 + i] flag of cut i,
     [8 + JOIN] side work of this step done."""
-    JOIN = 100
+    JOIN = 400
 
     def __init__(self, device, ctx, min_queue=None):
         self.device, self.ctx = device, ctx
@@ -256,16 +256,21 @@ class SideSchedule:
         # cuts from the end at which the side stream reduces the slabs it has so far (0 = off, the default: measured at 64^3 the
         # tail shrinks 66 -> 49 us but the reduction takes 24 us out of the chain it runs beside)
         self.early_finalize = int(os.environ.get("N3D_SIDE_EARLY_FINALIZE", "0"))
-        self.sync = torch.zeros(128, dtype=torch.int32, device=device)
+        self.sync = torch.zeros(8 + self.JOIN + 8, dtype=torch.int32, device=device)
         self.sync[0] = 1
         self.sync[2] = 1
+        self._cuts = 0
+        self._main_jobs = {}
+        self._last_cut = -1
+        self._pass_active = False
+        self.arena = []        # every tensor made while forward_mode() is on: held until finish() (see forward_mode)
         self.seen = 0
         self.replays = 0
         self.watch = None
         # N3D_SIDE_TRACE=1 (tools/side_timeline.py): wall-clock stamps next to every hand-off.  int64 words: [0] main: first cut,
         # [2 i + 2] main stored flag i, [2 i + 3] side passed wait i, [300] side done, [301] main passed the join, [302] slab
         # reduction launched behind it
-        self.trace = torch.zeros(304, dtype=torch.int64, device=device) if os.environ.get("N3D_SIDE_TRACE") == "1" else None
+        self.trace = torch.zeros(2 * self.JOIN + 8, dtype=torch.int64, device=device) if os.environ.get("N3D_SIDE_TRACE") == "1" else None
         self.stream = self._probe()
 
     def ptr(self, i):
@@ -321,8 +326,8 @@ class SideSchedule:
 
         def __enter__(self):
             o = self.o
-            o._cuts = 0
-            o._main_jobs = []
+            if not o._pass_active:
+                o.begin_pass()
             o.ctx.defer_wgrad = True
             self.prev = (_fused.CELL_DONE_HOOK, _fused.NODE_DONE_HOOK)
             outer = self.prev[0]
@@ -341,6 +346,121 @@ class SideSchedule:
             _fused.CELL_DONE_HOOK, _fused.NODE_DONE_HOOK = self.prev
             return False
 
+    # -- one pass (forward + backward of one batch) = one step of the flag protocol ------------------------------------------
+    def begin_pass(self):
+        """flag ids are handed out from 0 within a pass (forward hand-offs and the cuts of the backward walk share them)"""
+        self._cuts = 0
+        self._main_jobs = {}
+        self._last_cut = -1
+        self._pass_active = True
+
+    def _flag(self):
+        i = self._cuts
+        if i >= self.JOIN:
+            raise K.N3DError("side-stream schedule: more than %d hand-offs in one pass" % self.JOIN)
+        self._cuts += 1
+        return i
+
+    # -- inline side work of the forward pass (fused._run_forward_side) -------------------------------------------------------
+    def fork(self):
+        """main stream: store a flag behind everything launched so far; returns its id"""
+        i = self._flag()
+        K.sync_signal(self.ptr(8 + i), self.ptr(0), False)
+        return i
+
+    class _Side:
+        def __init__(self, owner, wait_id):
+            self.o, self.wait_id = owner, wait_id
+
+        def __enter__(self):
+            self.redirect = K.on_side(self.o.stream)
+            self.redirect.__enter__()
+            K.sync_wait(self.o.ptr(8 + self.wait_id), self.o.ptr(2), self.o.ptr(1), False)
+            return self
+
+        def __exit__(self, *exc):
+            return self.redirect.__exit__(*exc)
+
+    def side(self, wait_id):
+        """with side(flag id): launches go to the side stream, behind a device-side wait on that flag of the main stream"""
+        return SideSchedule._Side(self, wait_id)
+
+    def side_signal(self):
+        """inside side(): store a flag behind the side stream's launches so far; returns its id"""
+        i = self._flag()
+        K.sync_signal(self.ptr(8 + i), self.ptr(2), False)
+        return i
+
+    def join(self, i):
+        """main stream: wait for a flag of the side stream"""
+        K.sync_wait(self.ptr(8 + i), self.ptr(0), self.ptr(1), False)
+
+    class _Forward:
+        """forward_mode(): supernet cells run their off-chain edges on the side stream (fused.SIDE_FWD), and every tensor created
+        meanwhile is held in `arena` until finish().  Allocations stay on torch's current stream; with two streams in flight the
+        allocator's stream-ordered reuse of a block freed by Python is not ordered against the OTHER stream's pending kernels, so
+        nothing made during the pass is released before the streams have joined (a TorchDispatchMode sees every new tensor)."""
+
+        def __init__(self, owner):
+            self.o = owner
+
+        def __enter__(self):
+            from torch.utils._python_dispatch import TorchDispatchMode
+            keep = self.o.arena
+
+            class Arena(TorchDispatchMode):
+                def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                    out = func(*args, **(kwargs or {}))
+                    if isinstance(out, torch.Tensor):
+                        keep.append(out)
+                    elif isinstance(out, (tuple, list)):
+                        keep.extend(t for t in out if isinstance(t, torch.Tensor))
+                    return out
+
+            if not self.o._pass_active:
+                self.o.begin_pass()
+            self.mode = Arena()
+            self.mode.__enter__()
+            self.prev, _fused.SIDE_FWD = _fused.SIDE_FWD, self.o
+            return self.o
+
+        def __exit__(self, *exc):
+            _fused.SIDE_FWD = self.prev
+            return self.mode.__exit__(*exc)
+
+    def forward_mode(self):
+        return SideSchedule._Forward(self)
+
+    # -- the side stream's work as a HIP graph captured next to torch's capture of the main stream --------------------------------
+    def _hip(self):
+        import ctypes as C
+        if getattr(self, "_hiplib", None) is None:
+            self._hiplib = C.CDLL("libamdhip64.so")
+        return self._hiplib
+
+    def raw_capture_begin(self):
+        """the side stream starts capturing (thread-local mode, like torch's capture of the main stream); launches redirected to it
+        while the main stream is being captured land in a graph of their own"""
+        import ctypes as C
+        if self._hip().hipStreamBeginCapture(C.c_void_p(self.stream.cuda_stream), 1) != 0:
+            raise K.N3DError("hipStreamBeginCapture on the side stream failed")
+
+    def raw_capture_end(self):
+        """-> executable graph handle (replayed with raw_replay)"""
+        import ctypes as C
+        hip, g, ex = self._hip(), C.c_void_p(), C.c_void_p()
+        if hip.hipStreamEndCapture(C.c_void_p(self.stream.cuda_stream), C.byref(g)) != 0 or not g.value:
+            raise K.N3DError("hipStreamEndCapture on the side stream failed")
+        if hip.hipGraphInstantiate(C.byref(ex), g, None, None, C.c_size_t(0)) != 0 or not ex.value:
+            raise K.N3DError("hipGraphInstantiate of the side graph failed")
+        self._raw_graphs = getattr(self, "_raw_graphs", []) + [(g, ex)]
+        return ex
+
+    def raw_replay(self, ex):
+        import ctypes as C
+        if self._hip().hipGraphLaunch(ex, C.c_void_p(self.stream.cuda_stream)) != 0:
+            raise K.N3DError("hipGraphLaunch of the side graph failed")
+
     def deferring(self):
         """with side.deferring(): run forward + backward; weight-gradient launches are queued, flags stored at the cut points"""
         return SideSchedule._Deferring(self)
@@ -350,26 +470,29 @@ class SideSchedule:
         ctx = self.ctx
         n = ctx.queued()
         if n > 0 and (final or (n >= self.min_queue and self._cuts < self.JOIN - 1)):
-            K.sync_signal(self.ptr(8 + self._cuts), self.ptr(0), False)
-            self._main_jobs.append(len(ctx.final))     # slab-reduction jobs the main chain has issued in front of this flag
+            i = self._flag()
+            K.sync_signal(self.ptr(8 + i), self.ptr(0), False)
+            self._main_jobs[i] = len(ctx.final)     # slab-reduction jobs the main chain has issued in front of this flag
             if self.trace is not None:
-                K.stamp(self.trace.data_ptr() + 8 * (2 * self._cuts + 2))
-            ctx.wq.insert(len(ctx.wq) - n, ("mark", self._cuts))    # the wait goes IN FRONT of the launches it guards
-            ctx.wq.append(("mark", -1))                              # closes the group (no wait)
-            self._cuts += 1
+                K.stamp(self.trace.data_ptr() + 8 * (2 * i + 2))
+            ctx.wq.insert(len(ctx.wq) - n, ("mark", i))    # the wait goes IN FRONT of the launches it guards
+            ctx.wq.append(("mark", -1))                    # closes the group (no wait)
+            self._last_cut = i
 
     def launch_side(self):
         """on the side stream (the caller selects it): per group a device-side wait for the main stream's flag, then the queued
         launches; at the end the 'done' flag of this step"""
-        early = self._cuts - self.early_finalize if self.early_finalize > 0 else -1
+        marks = [it[1] for it in self.ctx.wq if it[0] == "mark" and it[1] >= 0]
+        early = marks[-self.early_finalize] if 0 < self.early_finalize < len(marks) else -1
+        prev = {t: (marks[k - 1] if k > 0 else None) for k, t in enumerate(marks)}
 
         def on_mark(tag):
             if tag >= 0:
-                if tag == early and tag > 0:
+                if tag == early and prev[tag] is not None:
                     # the side stream idles between its groups: the slabs of everything it has launched so far (and of the main
                     # chain's own jobs in front of the flag it passed last) are reduced here, so that the reduction behind the join
                     # only has the last few groups left
-                    self.ctx.finalize_now(self._main_jobs[tag - 1])
+                    self.ctx.finalize_now(self._main_jobs[prev[tag]])
                 K.sync_wait(self.ptr(8 + tag), self.ptr(2), self.ptr(1), False)
                 if self.trace is not None:
                     K.stamp(self.trace.data_ptr() + 8 * (2 * tag + 3))
@@ -377,17 +500,19 @@ class SideSchedule:
             self.ctx.flush_wgrads(on_mark)
         K.sync_signal(self.ptr(8 + self.JOIN), self.ptr(2), True)
         if self.trace is not None:
-            K.stamp(self.trace.data_ptr() + 8 * 300)
+            K.stamp(self.trace.data_ptr() + 8 * (2 * self.JOIN + 4))
 
     def finish(self):
         """on the main stream: wait for the side stream's 'done' flag, then reduce the weight-gradient slabs (one launch)"""
         K.sync_wait(self.ptr(8 + self.JOIN), self.ptr(0), self.ptr(1), True)
+        self._pass_active = False
+        self.arena.clear()        # (rebinding would orphan the list the dispatch mode of forward_mode() appends to)
         if self.trace is not None:
-            K.stamp(self.trace.data_ptr() + 8 * 301)
+            K.stamp(self.trace.data_ptr() + 8 * (2 * self.JOIN + 5))
         with K.step_context(self.ctx):
             self.ctx.flush_final()
         if self.trace is not None:
-            K.stamp(self.trace.data_ptr() + 8 * 302)
+            K.stamp(self.trace.data_ptr() + 8 * (2 * self.JOIN + 6))
 
 
 class _Ctx:
@@ -887,7 +1012,8 @@ class SearchTrainer:
         env = os.environ.get("N3D_SIDE_WGRAD", "1")
         self.side_wgrad = (env != "0") if side_wgrad is None else bool(side_wgrad)
         self._side_force = side_wgrad == "force" or (side_wgrad is None and env == "force")   # as in Trainer: no comparison
-        self._side_active = True     # _pass: queue the weight pass' weight gradients for the side stream (when there is one)
+        self._side_active = True     # _pass: use the side stream (when there is one)
+        self.side_forward = os.environ.get("N3D_SIDE_FORWARD", "1") != "0"   # ... also for the off-chain edges of the forward passes
         self._use_side = False
         self.schedule_times = None
         self.loss_fn = WeightedDiceLoss()
@@ -947,14 +1073,20 @@ class SearchTrainer:
             p.requires_grad_(arch)
         if arch:
             self.agrad.zero_()  # alpha gradients arrive through autograd accumulation (softmax backward)
-        sided = self.side is not None and self._side_active and not arch
+        # with a side stream BOTH passes use it: the forward of either pass runs the off-chain edges of every supernet cell there
+        # (fused._run_forward_side), the weight pass also queues its weight-gradient launches for it
+        sided = self.side is not None and self._side_active
         with K.step_context(self.ctx):
             if pack:
                 self.ctx.pack_all()
-            loss = _loss_of(self.model, self.loss_fn, x, t)
+            if sided and self.side_forward:
+                with self.side.forward_mode():
+                    loss = _loss_of(self.model, self.loss_fn, x, t)
+            else:
+                loss = _loss_of(self.model, self.loss_fn, x, t)
             prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True
             try:
-                if sided:
+                if sided and not arch:
                     with self.side.deferring():
                         loss.backward(self._one)
                 else:
@@ -966,7 +1098,7 @@ class SearchTrainer:
         if sided and side == "main":
             return loss.detach()
         if sided:
-            with torch.cuda.stream(self.side.stream):
+            with K.on_side(self.side.stream):
                 self.side.launch_side()
             self.side.finish()
         if not self.ctx.frozen and not arch:
@@ -997,33 +1129,37 @@ class SearchTrainer:
         return la, lw
 
     def _capture_side(self, s):
-        """four graphs: the architecture pass (+ its Adam unless an exchange sits in between), the weight pass' main chain, its
-        weight-gradient kernels (replayed on the side stream), and the tail (join, slab reduction, Adam)"""
+        """Per pass three graphs: the main chain (torch capture), the side stream's work -- the forward's off-chain edges, then
+        (weight pass) the queued weight-gradient groups -- captured on the side stream AT THE SAME TIME as a raw HIP graph, and
+        the tail (join, slab reduction, Adam unless an exchange sits in between)."""
         import gc
         gc.collect()
         pool = torch.cuda.graph_pool_handle()
-        g_arch, g_main, g_side, g_tail = (torch.cuda.CUDAGraph() for _ in range(4))
+        sd = self.side
         torch.cuda.synchronize()
-        with torch.cuda.stream(s):
-            g_arch.capture_begin(pool=pool, capture_error_mode="thread_local")
-            la = self._pass(self._svx, self._svt, True, update=not self.dp_path)
-            g_arch.capture_end()
-            g_main.capture_begin(pool=pool, capture_error_mode="thread_local")
-            lw = self._pass(self._sx, self._st, False, update=False, pack=False, side="main")
-            g_main.capture_end()
-        with torch.cuda.stream(self.side.stream):
-            g_side.capture_begin(capture_error_mode="thread_local")
-            self.side.launch_side()
-            g_side.capture_end()
-        with torch.cuda.stream(s):
-            g_tail.capture_begin(pool=pool, capture_error_mode="thread_local")
-            self.side.finish()
-            if not self.dp_path:
-                self._update(False)
-            g_tail.capture_end()
+        graphs, losses = [], []
+        for arch, (bx, bt) in ((True, (self._svx, self._svt)), (False, (self._sx, self._st))):
+            g_main, g_tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            sd.raw_capture_begin()
+            try:
+                with torch.cuda.stream(s):
+                    g_main.capture_begin(pool=pool, capture_error_mode="thread_local")
+                    losses.append(self._pass(bx, bt, arch, update=False, pack=arch, side="main"))
+                    g_main.capture_end()
+                with K.on_side(sd.stream):
+                    sd.launch_side()
+            finally:
+                side_exec = sd.raw_capture_end()
+            with torch.cuda.stream(s):
+                g_tail.capture_begin(pool=pool, capture_error_mode="thread_local")
+                sd.finish()
+                if not self.dp_path:
+                    self._update(arch)
+                g_tail.capture_end()
+            graphs.append((g_main, side_exec, g_tail))
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self._side_losses, self._side_graphs = (la, lw), (g_arch, g_main, g_side, g_tail)
+        self._side_losses, self._side_graphs = tuple(losses), graphs
 
     def step(self, x, t, val_x, val_t):
         """returns (architecture-pass loss, weight-pass loss) as device scalars"""
@@ -1085,16 +1221,12 @@ class SearchTrainer:
         return self._sx, self._st, self._svx, self._svt
 
     def _replay_side(self):
-        g_arch, g_main, g_side, g_tail = self._side_graphs
-        g_arch.replay()
-        if self.dp_path:
-            self._update(True)
-        with torch.cuda.stream(self.side.stream):
-            g_side.replay()      # first: see Trainer._replay_side
-        g_main.replay()
-        g_tail.replay()
-        if self.dp_path:
-            self._update(False)
+        for arch, (g_main, side_exec, g_tail) in zip((True, False), self._side_graphs):
+            self.side.raw_replay(side_exec)      # first: see Trainer._replay_side
+            g_main.replay()
+            g_tail.replay()
+            if self.dp_path:
+                self._update(arch)
 
     def _replay_plain(self):
         if self._graphs is not None:

@@ -16,17 +16,18 @@ def run(drop):
     x, vx = bench.to_patch_layout(x), bench.to_patch_layout(vx)
     for _ in range(4): tr.step(x, t, vx, vt)
     K._DROP_SIDE = False
-    g_arch, g_main, g_side, g_tail = tr._side_graphs
+    (ga_main, ga_side, ga_tail), (gw_main, gw_side, gw_tail) = tr._side_graphs
     n = 12
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n)]
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n)]
     torch.cuda.synchronize()
     for i in range(n):
-        evs[i][0].record(); g_arch.replay(); evs[i][1].record()
-        with torch.cuda.stream(tr.side.stream): g_side.replay()
-        g_main.replay(); evs[i][2].record(); g_tail.replay(); evs[i][3].record()
+        evs[i][0].record(); tr.side.raw_replay(ga_side); ga_main.replay(); evs[i][1].record(); ga_tail.replay(); evs[i][2].record()
+        tr.side.raw_replay(gw_side); gw_main.replay(); evs[i][3].record(); gw_tail.replay(); evs[i][4].record()
     torch.cuda.synchronize()
     f = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in evs[2:]) / (n - 2)
-    print("drop_side=%s: arch pass %.3f ms, weight pass main %.3f ms, tail %.3f ms, sum %.3f; cuts %d" % (drop, f(0, 1), f(1, 2), f(2, 3), f(0, 3), int((tr.side.sync[8:108] > 0).sum())), flush=True)
+    print("drop_side=%s fwd_side=%s: arch pass main %.3f + tail %.3f ms, weight pass main %.3f + tail %.3f ms, sum %.3f; hand-offs %d" % (
+        drop, tr.side_forward, f(0, 1), f(1, 2), f(2, 3), f(3, 4), f(0, 4), int((tr.side.sync[8:8 + tr.side.JOIN] > 0).sum())), flush=True)
     tr.check_sync()
-run(True)
+run(False)
+os.environ['N3D_SIDE_FORWARD'] = '0'
 run(False)
