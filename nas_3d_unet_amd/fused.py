@@ -163,6 +163,7 @@ def _run_forward(plan, x0, x1, alpha1, alpha2):
 # side stream's part of their node.  SIDE_FWD: .fork() main stores a flag, returns its id; .side(wait_id) context manager: launches
 # go to the side stream behind a wait on that flag; .side_signal() side stores a flag, returns its id; .join(id) main waits for it.
 SIDE_FWD = None
+SIDE_NODE0_SPLIT = __import__("os").environ.get("N3D_SIDE_NODE0", "main") == "split"   # node 0: both edges on the main stream (one of them on the side stream measured 0.1 ms slower per search step)
 
 
 def _run_forward_side(plan, x0, x1, alpha1, alpha2, sf):
@@ -194,7 +195,9 @@ def _run_forward_side(plan, x0, x1, alpha1, alpha2, sf):
 
     def on_side(node, idx):
         """does the weight phase of a term of `node` reading state `idx` run on the side stream?"""
-        return idx == 1 if node == 0 else idx <= node          # node n's newest input is state n + 1
+        if node == 0:
+            return idx == 1 and SIDE_NODE0_SPLIT
+        return idx <= node          # node n's newest input is state n + 1
 
     order = {node: [fi for unit in units[node] for fi in unit] for node in range(nn)}     # the epilogue order of the node's terms
     res = {}

@@ -167,3 +167,50 @@ def test_search_weight_pass_on_the_side_stream():
         # gradients of the second step (the buffers hold the last pass): the first steps' Adam updates may differ by noise-level signs
         assert float((g - res[0][1]).double().norm()) <= 2e-3 * tot
         assert float((ag - res[0][2]).double().norm()) <= 2e-3 * atot
+
+
+def test_supernet_forward_on_two_streams_is_bit_identical():
+    """fused._run_forward_side: the off-chain edges of every supernet cell run their weight ops on the side stream, the epilogues stay
+    on the main stream in the usual order -- same kernels on the same operands, so probabilities, loss and every gradient must equal
+    the single-stream forward bit for bit (cell.py:76-82 semantics are untouched)."""
+    from nas_3d_unet_amd import kernels as K, loss, nas
+    from nas_3d_unet_amd.train import SideSchedule
+    cfg = orc.DEFAULT_CFG._replace(depth=3)
+    rng = np.random.default_rng(61)
+    x = dev(rng.standard_normal((2, 4, 32, 32, 32)).astype(np.float32))
+    t = dev((rng.uniform(0, 1, (2, 3, 32, 32, 32)) < 0.3).astype(np.float32))
+    net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)
+    fill_module(net)
+    net.kernel.last_conv[0].dropout = None
+    net = net.cuda()
+    with torch.no_grad():                      # alphas away from the uniform point: every MixedOp weight differs
+        for a in net.alphas():
+            a.copy_(torch.from_numpy(rng.standard_normal(tuple(a.shape)).astype(np.float32)).cuda())
+    out = []
+    for two_streams in (False, True, True):
+        for p in net.parameters():
+            p.grad = None
+        if two_streams:
+            sd = SideSchedule(torch.device("cuda", torch.cuda.current_device()), K.StepContext(torch.device("cuda")))
+            assert sd.stream is not None, "the side stream was not accepted on this box"
+            with sd.forward_mode():
+                p_ = net(x)
+            l = loss.WeightedDiceLoss()(p_, t)
+            l.backward()
+            with K.on_side(sd.stream):
+                sd.launch_side()
+            sd.finish()
+            torch.cuda.synchronize()
+            sd.check()
+            assert int((sd.sync[8:8 + sd.JOIN] > 0).sum()) >= 20, "no hand-offs were placed"
+        else:
+            p_ = net(x)
+            l = loss.WeightedDiceLoss()(p_, t)
+            l.backward()
+        out.append((p_.detach().clone(), float(l.detach()), {n: q.grad.clone() for n, q in net.named_parameters() if q.grad is not None}))
+    for got in out[1:]:
+        assert torch.equal(got[0], out[0][0])
+        assert got[1] == out[0][1]
+        assert got[2].keys() == out[0][2].keys()
+        for n in got[2]:
+            assert torch.equal(got[2][n], out[0][2][n]), n

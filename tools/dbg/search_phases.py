@@ -29,5 +29,3 @@ def run(drop):
         drop, tr.side_forward, f(0, 1), f(1, 2), f(2, 3), f(3, 4), f(0, 4), int((tr.side.sync[8:8 + tr.side.JOIN] > 0).sum())), flush=True)
     tr.check_sync()
 run(False)
-os.environ['N3D_SIDE_FORWARD'] = '0'
-run(False)
