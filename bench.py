@@ -77,7 +77,8 @@ def conv_kernel_roofline(device, batch, size, iters=40, bf16=False):
         ctx.pack_all()
         K.conv_fwd(g, x, w, b, y, 0, None, stats, False)   # pre-packed path
         torch.cuda.synchronize()
-        side = torch.cuda.Stream(device=device)
+        from nas_3d_unet_amd.train import capture_stream
+        side = capture_stream(device)     # the process-wide capture stream: every extra stream is another hardware queue
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
@@ -267,7 +268,8 @@ def other_configs(device, batch, no_graph):
         x, t, vx, vt = (torch.from_numpy(a).to(device) for a in (xn, tn, vxn, vtn))
         x, vx = to_patch_layout(x), to_patch_layout(vx)
         sec = timed(tr, (x, t, vx, vt))
-        return {"ms_per_step": round(sec * 1e3, 3), "steps_per_s": round(1.0 / sec, 3), "patches_per_s": round(2 * batch / sec, 2)}
+        return {"ms_per_step": round(sec * 1e3, 3), "steps_per_s": round(1.0 / sec, 3), "patches_per_s": round(2 * batch / sec, 2),
+                "schedule_ms": [round(v * 1e3, 3) for v in tr.schedule_times] if getattr(tr, "schedule_times", None) else None}
 
     def train128(storage):
         torch.manual_seed(1234)
@@ -278,7 +280,8 @@ def other_configs(device, batch, no_graph):
         xn, tn = synthetic_batch(batch, 128, 1234)
         x, t = to_patch_layout(torch.from_numpy(xn).to(device)), torch.from_numpy(tn).to(device)
         sec = timed(tr, (x, t))
-        return {"ms_per_step": round(sec * 1e3, 3), "patches_per_s": round(batch / sec, 2)}
+        return {"ms_per_step": round(sec * 1e3, 3), "patches_per_s": round(batch / sec, 2),
+                "schedule_ms": [round(v * 1e3, 3) for v in tr.schedule_times] if getattr(tr, "schedule_times", None) else None}
 
     for name, fn in (("configs[2]: nas.py supernet search step, batch 2 + 2, 4x64^3 fp32", search),
                      ("searched.py train step, batch 2, 4x128^3 fp32", lambda: train128(None)),
@@ -343,8 +346,9 @@ def main():
     device = torch.device("cuda", local)
 
     from nas_3d_unet_amd import _lib, searched
-    from nas_3d_unet_amd.train import Trainer
+    from nas_3d_unet_amd.train import Trainer, reserve_side_streams
     _lib.require_device()
+    reserve_side_streams(device)     # before anything else runs on the GPU: the side streams of every trainer this process builds
     if args.workload == "search":
         return search_step_bench(args, device)
 

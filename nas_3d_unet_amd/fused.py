@@ -100,9 +100,33 @@ def _node_units(plan):
     if getattr(plan, "_units", None) is not None:
         return plan._units
     flat = _flat_terms(plan)
-    units = []
+    units = [_units_of(plan, flat, [fi for fi, t in enumerate(flat) if t[0] == node]) for node in range(plan.n_nodes)]
+    plan._units = units
+    return units
+
+
+def _node_units_split(plan, side_inputs=(0, 1)):
+    """the units of each node for the two-stream BACKWARD (SIDE_BWD): (units of the main stream's terms, units of the side stream's).
+    The side stream takes the terms whose input is one of the preprocess outputs in `side_inputs` (both, or only the second one
+    when it has other work); the main stream keeps the terms that read a NODE -- their input gradients are what the next node's
+    backward waits for -- and the rest.  The two sets accumulate their input gradients into disjoint tensors (a preprocess
+    gradient belongs to ONE stream), so they can run on two streams without ordering between them."""
+    cache = plan.__dict__.setdefault("_units_split", {})
+    key = tuple(side_inputs)
+    if key in cache:
+        return cache[key]
+    flat = _flat_terms(plan)
+    out = []
     for node in range(plan.n_nodes):
         mine = [fi for fi, t in enumerate(flat) if t[0] == node]
+        out.append((_units_of(plan, flat, [fi for fi in mine if flat[fi][1] not in key]), _units_of(plan, flat, [fi for fi in mine if flat[fi][1] in key])))
+    cache[key] = out
+    return out
+
+
+def _units_of(plan, flat, mine):
+    """launch units of the terms `mine` (indices into flat) of one node: see _node_units"""
+    if True:
         pairable = [fi for fi in mine if PAIR_SUPERNET_TERMS and P.gn_pairable(flat[fi][2])]
         dense = [fi for fi in pairable if isinstance(flat[fi][2].weight, P.DenseConvW)]
         # position of the term among its edge's dense terms first, edge second: neighbours come from different edges
@@ -127,9 +151,7 @@ def _node_units(plan):
                 if len(group) % 2:
                     u.append((group[-1],))
         u.extend((fi,) for fi in mine if fi not in pairable)
-        units.append(u)
-    plan._units = units
-    return units
+        return u
 
 
 def _node_fwd_units(plan):
@@ -163,6 +185,7 @@ def _run_forward(plan, x0, x1, alpha1, alpha2):
 # side stream's part of their node.  SIDE_FWD: .fork() main stores a flag, returns its id; .side(wait_id) context manager: launches
 # go to the side stream behind a wait on that flag; .side_signal() side stores a flag, returns its id; .join(id) main waits for it.
 SIDE_FWD = None
+SIDE_BWD = None      # the same object while the backward pass of a supernet may use the side stream (see _run_backward_impl)
 SIDE_NODE0_SPLIT = __import__("os").environ.get("N3D_SIDE_NODE0", "main") == "split"   # node 0: both edges on the main stream (one of them on the side stream measured 0.1 ms slower per search step)
 
 
@@ -306,6 +329,9 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
     """dx_targets = ((View | None, accumulate), (View | None, accumulate)): where the gradients of the two cell inputs go
     (NetFn passes the producers' gradient buffers); own_dout: `dout` is a private buffer the cell may accumulate into."""
     with K.storage(plan.dt):
+        if SIDE_BWD is not None and not plan.pairs:
+            with SIDE_BWD.arena_mode():      # (this runs on autograd's thread: the mode of the forward pass is not active here)
+                return _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, own_dout)
         return _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, own_dout)
 
 
@@ -372,13 +398,15 @@ def _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_da
 
         all_units = _node_units(plan)
         batch_reduce = _grouping(cn)
-        for node in reversed(range(nn)):
+
+        def run_node(node, node_units):
+            """backward of the terms in `node_units` (units of ONE node, all of them or the subset one stream handles)"""
             # the primitives that stay single (identity, SE gates, pooling) all start with a reduction pass over the same node
             # gradient: those passes run up to eight per launch
             pre, pre_se, pre_da = {}, {}, set()
             if batch_reduce:
                 want = []
-                for unit in all_units[node]:
+                for unit in node_units:
                     if len(unit) == 1:
                         fi, = unit
                         _, _, seg, _, amat, row = flat[fi]
@@ -419,7 +447,7 @@ def _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_da
                         raw = st.saved[chunk[0]].raw
                         for fi, r in zip(chunk, K.se_gate_bwdN(tds, raw.N, raw.B, raw.C)):
                             pre_se[fi] = r
-            rev = list(reversed(all_units[node]))
+            rev = list(reversed(node_units))
             skip = set()
             for ui, unit in enumerate(rev):
                 if ui in skip:
@@ -479,8 +507,35 @@ def _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_da
                                            pre.get(unit[0]) if len(unit) == 1 else None, pre_se.get(unit[0]) if len(unit) == 1 else None,
                                            len(unit) == 1 and unit[0] in pre_da)
                     put(seg, gl)
-            if NODE_DONE_HOOK is not None:
-                NODE_DONE_HOOK()
+
+        sb = SIDE_BWD if (SIDE_BWD is not None and batch_reduce) else None
+        if sb is None:
+            for node in reversed(range(nn)):
+                run_node(node, all_units[node])
+                if NODE_DONE_HOOK is not None:
+                    NODE_DONE_HOOK()
+        else:
+            # two streams (train.SideSchedule): the terms that read a NODE stay on the main stream -- their input gradients are what the
+            # next node's backward waits for -- and the terms that read a preprocess output go to the side stream, behind a flag
+            # that says "the gradient of this node is complete".  The two sets accumulate into disjoint tensors (node gradients /
+            # preprocess gradients, which only the side stream touches until the join below).
+            split = _node_units_split(plan, sb.bwd_side_inputs)
+            ready = sb.fork()
+            side_tok = None
+            for node in reversed(range(nn)):
+                on_main, on_side = split[node]
+                if on_side:
+                    with sb.side(ready):
+                        run_node(node, on_side)
+                        side_tok = sb.side_signal()
+                if on_main:
+                    run_node(node, on_main)
+                if NODE_DONE_HOOK is not None:
+                    NODE_DONE_HOOK()
+                if node > 0:
+                    ready = sb.fork()     # every node-to-node edge out of node - 1 has run: its gradient is complete
+            if side_tok is not None:
+                sb.join(side_tok)
     for i in range(2):
         if not pre_started[i]:
             dpre[i].t.zero_()

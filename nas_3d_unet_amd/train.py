@@ -203,6 +203,20 @@ class GradSync:
                 self.reduce_range(i)
 
 
+_capture_streams = {}
+
+
+def capture_stream(device):
+    """the ONE stream every trainer of this process warms up and captures on.  Streams are hardware queues: with more of them than
+    the scheduler keeps resident side by side (four, counting the default stream, on this stack) a device-side wait of the side
+    schedule is only relieved at the end of a time slice -- so nothing here makes a stream it does not need"""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _capture_streams.get(key)
+    if st is None:
+        st = _capture_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 _side_prio = [None]
 _side_streams = {}   # device index -> [side streams made so far]: trainers share them (every new HIP stream may become another
                      # hardware queue, and with more queues than the scheduler keeps resident a spinning wait kernel is only
@@ -233,6 +247,31 @@ def _low_priority_stream(device):
         return torch.cuda.Stream(device=device)
 
 
+def reserve_side_streams(device, n=2):
+    """Make the process's side streams NOW and put a launch on each.  Which hardware queue / pipe a HIP stream gets is settled when
+    it is first used, in creation order; streams made early sit next to the default stream's queue and run side by side with it,
+    while streams made after a lot of other activity were seen to share a time slice with it (a search step of 58 instead of
+    14.5 ms: tools/dbg/slowmode.py).  Every trainer calls this first; a program that does other GPU work before it builds a
+    trainer can call it right after selecting the device.  (A late reservation is not an error: the trainers time both schedules
+    and keep the single-stream one if the side streams do not pay.)"""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return []
+    pool = _side_streams.setdefault(device.index or 0, [])
+    made = False
+    while len(pool) < n:
+        pool.append(_low_priority_stream(device))
+        made = True
+    if made:
+        scratch = torch.zeros(8, dtype=torch.int32, device=device)
+        scratch[0] = 1
+        for st in pool:
+            with K.on_side(st):
+                K.sync_signal(scratch.data_ptr() + 16, scratch.data_ptr(), False)
+        torch.cuda.synchronize(device)
+    return pool
+
+
 class SideSchedule:
     """Weight-gradient kernels on a SIDE HIP stream, tied to the backward chain by flags in device memory (include/n3d.h,
     "stream hand-off"; round 3).
@@ -250,7 +289,10 @@ class SideSchedule:
     [8 + JOIN] side work of this step done."""
     JOIN = 400
 
-    def __init__(self, device, ctx, min_queue=None):
+    def __init__(self, device, ctx, min_queue=None, wgrad_stream=False):
+        """wgrad_stream: a SECOND side stream for the weight-gradient launches (the supernet's weight pass keeps the first one busy
+        with the preprocess-fed edges of its forward and backward); without it, or when no second stream passes the probe, the
+        weight gradients share the one side stream"""
         self.device, self.ctx = device, ctx
         self.min_queue = int(os.environ.get("N3D_SIDE_MIN_QUEUE", "3")) if min_queue is None else int(min_queue)
         # cuts from the end at which the side stream reduces the slabs it has so far (0 = off, the default: measured at 64^3 the
@@ -263,7 +305,9 @@ class SideSchedule:
         self._main_jobs = {}
         self._last_cut = -1
         self._pass_active = False
-        self.arena = []        # every tensor made while forward_mode() is on: held until finish() (see forward_mode)
+        self.live = False      # backward_mode(): cuts hand their group to the side stream at once
+        self.bwd_side_inputs = (0, 1)   # backward_mode(): the side stream takes the edges fed by these preprocess outputs
+        self.arena = []        # every tensor made while forward_mode() / arena_mode() is on: held until finish()
         self.seen = 0
         self.replays = 0
         self.watch = None
@@ -272,11 +316,26 @@ class SideSchedule:
         # reduction launched behind it
         self.trace = torch.zeros(2 * self.JOIN + 8, dtype=torch.int64, device=device) if os.environ.get("N3D_SIDE_TRACE") == "1" else None
         self.stream = self._probe()
+        self.wstream = self.stream
+        if wgrad_stream and self.stream is not None and os.environ.get("N3D_SIDE_WSTREAM", "1") != "0":
+            w = self._probe(exclude=(self.stream,))
+            if w is not None:
+                self.wstream = w
+        self.sync[3] = 1          # the weight-gradient stream's own step counter (used when it is a stream of its own)
+        self._side_tok = None     # the side stream's latest flag of this pass (live cuts make the weight-gradient stream wait for it)
+
+    @property
+    def split(self):
+        return self.wstream is not self.stream
+
+    def wptr(self):
+        """step word of the stream that runs the weight gradients"""
+        return self.ptr(3) if self.split else self.ptr(2)
 
     def ptr(self, i):
         return self.sync.data_ptr() + 4 * i
 
-    def _probe(self):
+    def _probe(self, exclude=()):
         """a side stream that really runs next to the current one: a few device-side ping-pongs must complete without a time-out
         and fast (a wait kernel at the head of the hardware queue that also carries its signal only ends by its time-out; streams
         that share a time-sliced queue hand over in ~1 ms instead of ~5 us).  Tries a few streams; None = schedule off."""
@@ -284,12 +343,14 @@ class SideSchedule:
         main = torch.cuda.current_stream(self.device)
         rounds = 8
         pool = _side_streams.setdefault(self.device.index or 0, [])
-        for attempt in range(4):
+        for attempt in range(5):
             if attempt < len(pool):
                 side = pool[attempt]         # a stream an earlier trainer of this process made: reuse before making another
             else:
-                side = _low_priority_stream(self.device) if attempt < 2 else torch.cuda.Stream(device=self.device)
+                side = _low_priority_stream(self.device) if attempt < 3 else torch.cuda.Stream(device=self.device)
                 pool.append(side)
+            if any(side is e for e in exclude):
+                continue
             ok = True
             for timed in (False, True):      # the first pass also loads the two kernels
                 probe = torch.zeros(4 + 2 * rounds, dtype=torch.int32, device=self.device)   # [0] step = 1, [1] time-outs, [4 + i] flags
@@ -352,6 +413,7 @@ class SideSchedule:
         self._cuts = 0
         self._main_jobs = {}
         self._last_cut = -1
+        self._side_tok = None
         self._pass_active = True
 
     def _flag(self):
@@ -389,11 +451,66 @@ class SideSchedule:
         """inside side(): store a flag behind the side stream's launches so far; returns its id"""
         i = self._flag()
         K.sync_signal(self.ptr(8 + i), self.ptr(2), False)
+        self._side_tok = i
         return i
 
     def join(self, i):
         """main stream: wait for a flag of the side stream"""
         K.sync_wait(self.ptr(8 + i), self.ptr(0), self.ptr(1), False)
+
+    class _ArenaMode:
+        """every tensor created inside (on the calling thread) is held in owner.arena until finish()"""
+
+        def __init__(self, owner):
+            self.o = owner
+
+        def __enter__(self):
+            from torch.utils._python_dispatch import TorchDispatchMode
+            keep = self.o.arena
+
+            class Arena(TorchDispatchMode):
+                def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                    out = func(*args, **(kwargs or {}))
+                    if isinstance(out, torch.Tensor):
+                        keep.append(out)
+                    elif isinstance(out, (tuple, list)):
+                        keep.extend(t for t in out if isinstance(t, torch.Tensor))
+                    return out
+
+            self.mode = Arena()
+            self.mode.__enter__()
+            return self
+
+        def __exit__(self, *exc):
+            return self.mode.__exit__(*exc)
+
+    def arena_mode(self):
+        return SideSchedule._ArenaMode(self)
+
+    class _Backward:
+        """backward_mode(): supernet cells run the backward of their preprocess-fed edges on the side stream (fused.SIDE_BWD), and
+        the schedule is LIVE: a cut of the backward walk hands the weight-gradient launches queued so far to the side stream at
+        once (behind a wait on the cut's flag) instead of at the end of the pass -- the side stream is busy during the walk now,
+        what is appended at the end would run after all of it"""
+
+        def __init__(self, owner):
+            self.o = owner
+
+        def __enter__(self):
+            if not self.o._pass_active:
+                self.o.begin_pass()
+            self.prev, _fused.SIDE_BWD = _fused.SIDE_BWD, self.o
+            self.o.live = True
+            return self.o
+
+        def __exit__(self, *exc):
+            _fused.SIDE_BWD = self.prev
+            self.o.live = False
+            return False
+
+    def backward_mode(self, side_inputs=(0, 1)):
+        self.bwd_side_inputs = tuple(side_inputs)
+        return SideSchedule._Backward(self)
 
     class _Forward:
         """forward_mode(): supernet cells run their off-chain edges on the side stream (fused.SIDE_FWD), and every tensor created
@@ -442,24 +559,29 @@ class SideSchedule:
         """the side stream starts capturing (thread-local mode, like torch's capture of the main stream); launches redirected to it
         while the main stream is being captured land in a graph of their own"""
         import ctypes as C
-        if self._hip().hipStreamBeginCapture(C.c_void_p(self.stream.cuda_stream), 1) != 0:
-            raise K.N3DError("hipStreamBeginCapture on the side stream failed")
+        for st in ([self.stream, self.wstream] if self.split else [self.stream]):
+            if self._hip().hipStreamBeginCapture(C.c_void_p(st.cuda_stream), 1) != 0:
+                raise K.N3DError("hipStreamBeginCapture on a side stream failed")
 
     def raw_capture_end(self):
         """-> executable graph handle (replayed with raw_replay)"""
         import ctypes as C
-        hip, g, ex = self._hip(), C.c_void_p(), C.c_void_p()
-        if hip.hipStreamEndCapture(C.c_void_p(self.stream.cuda_stream), C.byref(g)) != 0 or not g.value:
-            raise K.N3DError("hipStreamEndCapture on the side stream failed")
-        if hip.hipGraphInstantiate(C.byref(ex), g, None, None, C.c_size_t(0)) != 0 or not ex.value:
-            raise K.N3DError("hipGraphInstantiate of the side graph failed")
-        self._raw_graphs = getattr(self, "_raw_graphs", []) + [(g, ex)]
-        return ex
+        hip, out = self._hip(), []
+        for st in ([self.stream, self.wstream] if self.split else [self.stream]):
+            g, ex = C.c_void_p(), C.c_void_p()
+            if hip.hipStreamEndCapture(C.c_void_p(st.cuda_stream), C.byref(g)) != 0 or not g.value:
+                raise K.N3DError("hipStreamEndCapture on a side stream failed")
+            if hip.hipGraphInstantiate(C.byref(ex), g, None, None, C.c_size_t(0)) != 0 or not ex.value:
+                raise K.N3DError("hipGraphInstantiate of a side graph failed")
+            self._raw_graphs = getattr(self, "_raw_graphs", []) + [(g, ex)]
+            out.append((ex, st))
+        return out
 
-    def raw_replay(self, ex):
+    def raw_replay(self, execs):
         import ctypes as C
-        if self._hip().hipGraphLaunch(ex, C.c_void_p(self.stream.cuda_stream)) != 0:
-            raise K.N3DError("hipGraphLaunch of the side graph failed")
+        for ex, st in execs:
+            if self._hip().hipGraphLaunch(ex, C.c_void_p(st.cuda_stream)) != 0:
+                raise K.N3DError("hipGraphLaunch of a side graph failed")
 
     def deferring(self):
         """with side.deferring(): run forward + backward; weight-gradient launches are queued, flags stored at the cut points"""
@@ -475,13 +597,25 @@ class SideSchedule:
             self._main_jobs[i] = len(ctx.final)     # slab-reduction jobs the main chain has issued in front of this flag
             if self.trace is not None:
                 K.stamp(self.trace.data_ptr() + 8 * (2 * i + 2))
+            if self.live:
+                # the side stream takes the group now: wait for the flag, then the launches (their slab-reduction jobs are recorded)
+                with K.on_side(self.wstream):
+                    K.sync_wait(self.ptr(8 + i), self.wptr(), self.ptr(1), False)
+                    if self.split and self._side_tok is not None:
+                        # operands the SIDE stream produced (the d(raw) of its edges): behind its latest flag
+                        K.sync_wait(self.ptr(8 + self._side_tok), self.wptr(), self.ptr(1), False)
+                    if self.trace is not None:
+                        K.stamp(self.trace.data_ptr() + 8 * (2 * i + 3))
+                    ctx.flush_wgrads()
+                return
             ctx.wq.insert(len(ctx.wq) - n, ("mark", i))    # the wait goes IN FRONT of the launches it guards
             ctx.wq.append(("mark", -1))                    # closes the group (no wait)
             self._last_cut = i
 
-    def launch_side(self):
-        """on the side stream (the caller selects it): per group a device-side wait for the main stream's flag, then the queued
-        launches; at the end the 'done' flag of this step"""
+    def launch_side(self, redirect=False):
+        """the weight-gradient stream: per group a device-side wait for the main stream's flag, then the queued launches; then the
+        'done' flags of this pass (one per side stream).  redirect=False: the caller has made the (single) side stream current;
+        True: the launches are redirected here (K.on_side), as the search trainer's simultaneous captures need"""
         marks = [it[1] for it in self.ctx.wq if it[0] == "mark" and it[1] >= 0]
         early = marks[-self.early_finalize] if 0 < self.early_finalize < len(marks) else -1
         prev = {t: (marks[k - 1] if k > 0 else None) for k, t in enumerate(marks)}
@@ -493,17 +627,25 @@ class SideSchedule:
                     # chain's own jobs in front of the flag it passed last) are reduced here, so that the reduction behind the join
                     # only has the last few groups left
                     self.ctx.finalize_now(self._main_jobs[prev[tag]])
-                K.sync_wait(self.ptr(8 + tag), self.ptr(2), self.ptr(1), False)
+                K.sync_wait(self.ptr(8 + tag), self.wptr(), self.ptr(1), False)
                 if self.trace is not None:
                     K.stamp(self.trace.data_ptr() + 8 * (2 * tag + 3))
-        with K.step_context(self.ctx):
-            self.ctx.flush_wgrads(on_mark)
-        K.sync_signal(self.ptr(8 + self.JOIN), self.ptr(2), True)
-        if self.trace is not None:
-            K.stamp(self.trace.data_ptr() + 8 * (2 * self.JOIN + 4))
+
+        import contextlib
+        with (K.on_side(self.wstream) if redirect else contextlib.nullcontext()):
+            with K.step_context(self.ctx):
+                self.ctx.flush_wgrads(on_mark)
+            if self.split:
+                K.sync_signal(self.ptr(8 + self.JOIN + 1), self.ptr(3), True)
+        with (K.on_side(self.stream) if redirect else contextlib.nullcontext()):
+            K.sync_signal(self.ptr(8 + self.JOIN), self.ptr(2), True)
+            if self.trace is not None:
+                K.stamp(self.trace.data_ptr() + 8 * (2 * self.JOIN + 4))
 
     def finish(self):
         """on the main stream: wait for the side stream's 'done' flag, then reduce the weight-gradient slabs (one launch)"""
+        if self.split:
+            K.sync_wait(self.ptr(8 + self.JOIN + 1), self.ptr(0), self.ptr(1), False)
         K.sync_wait(self.ptr(8 + self.JOIN), self.ptr(0), self.ptr(1), True)
         self._pass_active = False
         self.arena.clear()        # (rebinding would orphan the list the dispatch mode of forward_mode() appends to)
@@ -612,6 +754,7 @@ class Trainer:
         self.loss_fn = WeightedDiceLoss()
         self.lr, self.betas, self.eps = lr, betas, eps
         self.device = next(model.parameters()).device
+        reserve_side_streams(self.device)     # first thing on the GPU (see there), also when THIS trainer will not use them
         plist = list(params) if params is not None else list(model.parameters())
         self.fp = FlatParams(plist, self.device)
         self.use_graph = graph
@@ -915,7 +1058,7 @@ class Trainer:
         segmented = self.dp_path and self._pipeline_ok(x)
         sided = not segmented and self._side_ok()
         # warm-up on a side stream (allocator + lazy module state); no optimizer launch, the weights stay as they are
-        s = torch.cuda.Stream(device=self.device)
+        s = capture_stream(self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
@@ -1014,11 +1157,14 @@ class SearchTrainer:
         self._side_force = side_wgrad == "force" or (side_wgrad is None and env == "force")   # as in Trainer: no comparison
         self._side_active = True     # _pass: use the side stream (when there is one)
         self.side_forward = os.environ.get("N3D_SIDE_FORWARD", "1") != "0"   # ... also for the off-chain edges of the forward passes
+        self.side_backward = os.environ.get("N3D_SIDE_BACKWARD", "1") != "0"  # ... and for the preprocess-fed edges of the backward passes
+        self.side_backward_weight = tuple(int(c) for c in os.environ.get("N3D_SIDE_BACKWARD_W", "") if c.isdigit())   # (weight pass: which ones; default none)
         self._use_side = False
         self.schedule_times = None
         self.loss_fn = WeightedDiceLoss()
         self.lr, self.betas, self.eps = lr, betas, eps
         self.device = next(shell.parameters()).device
+        reserve_side_streams(self.device)
         self.kparams = list(shell.kernel.parameters())
         self.aparams = list(shell.alphas())
         self.fp = FlatParams(self.kparams, self.device)
@@ -1030,9 +1176,11 @@ class SearchTrainer:
         self.afp = types.SimpleNamespace(params=self.aparams, offsets=aoffs, exp_avg=self.a_m, exp_avg_sq=self.a_v, step=self.a_step)
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
         self.ctx = K.StepContext(self.device)
-        self.side = SideSchedule(self.device, self.ctx) if (self.side_wgrad and self.device.type == "cuda") else None
+        self.side = SideSchedule(self.device, self.ctx, wgrad_stream=True) if (self.side_wgrad and self.device.type == "cuda") else None
         if self.side is not None and self.side.stream is None:
             self.side = None
+        if self.side is not None and "N3D_SIDE_EARLY_FINALIZE" not in os.environ:
+            self.side.early_finalize = 6      # 384 slab jobs per weight pass: reducing most of them early shrinks the tail 0.23 -> 0.15 ms
         self.use_graph = graph
         self._graph = None
         self._side_graphs = None
@@ -1086,11 +1234,18 @@ class SearchTrainer:
                 loss = _loss_of(self.model, self.loss_fn, x, t)
             prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True
             try:
-                if sided and not arch:
-                    with self.side.deferring():
-                        loss.backward(self._one)
-                else:
-                    loss.backward(self._one)  # seed gradient kept resident: no fill launch per step
+                import contextlib
+                # architecture pass: the side stream takes both preprocess-fed edges of every node (6 of a cell's 9: 7.8 -> 6.9 ms);
+                # weight pass: it already carries every weight gradient -- with both edge sets on top the pass takes 9.6 instead of
+                # 8.1 ms, with one 9.1 -- so its backward stays on one stream
+                # -- unless they run on a stream of their own (SideSchedule.split): then the weight pass does the same, 8.1 -> 7.1 ms
+                bwd_inputs = (0, 1) if (arch or (sided and self.side.split)) else self.side_backward_weight
+                with (self.side.backward_mode(bwd_inputs) if (sided and self.side_backward and bwd_inputs) else contextlib.nullcontext()):
+                    if sided and not arch:
+                        with self.side.deferring():
+                            loss.backward(self._one)
+                    else:
+                        loss.backward(self._one)  # seed gradient kept resident: no fill launch per step
             finally:
                 _fused.REUSE_GRAD_OUTPUT = prev
             if not sided:
@@ -1098,8 +1253,7 @@ class SearchTrainer:
         if sided and side == "main":
             return loss.detach()
         if sided:
-            with K.on_side(self.side.stream):
-                self.side.launch_side()
+            self.side.launch_side(redirect=True)
             self.side.finish()
         if not self.ctx.frozen and not arch:
             self.ctx.freeze()
@@ -1146,8 +1300,7 @@ class SearchTrainer:
                     g_main.capture_begin(pool=pool, capture_error_mode="thread_local")
                     losses.append(self._pass(bx, bt, arch, update=False, pack=arch, side="main"))
                     g_main.capture_end()
-                with K.on_side(sd.stream):
-                    sd.launch_side()
+                sd.launch_side(redirect=True)
             finally:
                 side_exec = sd.raw_capture_end()
             with torch.cuda.stream(s):
@@ -1170,7 +1323,7 @@ class SearchTrainer:
             self._sx, self._st, self._svx, self._svt = x.clone(), t.clone(), val_x.clone(), val_t.clone()
             # warm-up on a side stream (allocator + lazy module state) WITHOUT the optimizer launches: weights, alphas,
             # Adam moments and step counters -- possibly just loaded from a checkpoint (search.py:108-127) -- stay untouched
-            s = torch.cuda.Stream(device=self.device)
+            s = capture_stream(self.device)
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 for _ in range(2):

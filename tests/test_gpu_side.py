@@ -197,8 +197,7 @@ def test_supernet_forward_on_two_streams_is_bit_identical():
                 p_ = net(x)
             l = loss.WeightedDiceLoss()(p_, t)
             l.backward()
-            with K.on_side(sd.stream):
-                sd.launch_side()
+            sd.launch_side(redirect=True)
             sd.finish()
             torch.cuda.synchronize()
             sd.check()

@@ -26,6 +26,6 @@ def run(drop):
     torch.cuda.synchronize()
     f = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in evs[2:]) / (n - 2)
     print("drop_side=%s fwd_side=%s: arch pass main %.3f + tail %.3f ms, weight pass main %.3f + tail %.3f ms, sum %.3f; hand-offs %d" % (
-        drop, tr.side_forward, f(0, 1), f(1, 2), f(2, 3), f(3, 4), f(0, 4), int((tr.side.sync[8:8 + tr.side.JOIN] > 0).sum())), flush=True)
+        drop, (tr.side_forward, tr.side.split), f(0, 1), f(1, 2), f(2, 3), f(3, 4), f(0, 4), int((tr.side.sync[8:8 + tr.side.JOIN] > 0).sum())), flush=True)
     tr.check_sync()
 run(False)

@@ -198,7 +198,8 @@ def describe(name, args):
 def _time_call(name, args, device, reps=20, rounds=3):
     lib = _lib.load()
     fn = getattr(lib, name)
-    side = torch.cuda.Stream(device=device)
+    from nas_3d_unet_amd.train import capture_stream
+    side = capture_stream(device)      # the process-wide capture stream (every extra stream is another hardware queue)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.stream(side):
         sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
