@@ -25,3 +25,17 @@ def golden():
         return cache[name]
 
     return load
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _reserve_side_streams():
+    """on a GPU box: the side streams of the trainers' two- / three-stream schedules are made before any other test touches the
+    GPU (hardware-queue placement follows creation order: nas_3d_unet_amd.train.reserve_side_streams)"""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            from nas_3d_unet_amd.train import reserve_side_streams
+            reserve_side_streams(torch.device("cuda", torch.cuda.current_device()))
+    except Exception:
+        pass
+    yield

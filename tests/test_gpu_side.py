@@ -23,9 +23,12 @@ def _words(n=16):
 
 def test_sync_handoff_orders_two_streams():
     from nas_3d_unet_amd import kernels as K
+    from nas_3d_unet_amd.train import reserve_side_streams
     w = _words()
     p = lambda i: w.data_ptr() + 4 * i
-    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    # the process's reserved side streams: two arbitrary torch-pool streams may share a hardware queue (late in a long test session
+    # they did, and every wait below ran into its time-out) -- which is why the trainers never use those for a hand-off
+    a, b = reserve_side_streams(torch.device("cuda", torch.cuda.current_device()))[:2]
     src = torch.zeros(1 << 22, device="cuda")
     dst = torch.zeros(4, 1 << 22, device="cuda")
     torch.cuda.synchronize()
