@@ -903,14 +903,17 @@ class Trainer:
             self.side.check()
 
     def _side_pass(self, x, t):
-        """the autograd-free pipeline with every deferrable weight-gradient launch queued (SideSchedule); returns the loss"""
-        with self.side.deferring():
+        """the autograd-free pipeline on two streams (SideSchedule): every deferrable weight-gradient launch is queued and handed to
+        the side stream at the cuts of the backward walk (live), and the off-chain pieces of the net itself run there inline
+        (fused.SIDE_FWD / SIDE_BWD).  Forward and backward run on this thread, so one arena covers both.  Returns the loss."""
+        sd = self.side
+        sd.begin_pass()
+        with sd.forward_mode(), sd.backward_mode(), sd.deferring():
             return self._pipeline(x, t, cell_hook=_fused.CELL_DONE_HOOK)
 
     def _side_step_eager(self, x, t):
         loss = self._side_pass(x, t)
-        with torch.cuda.stream(self.side.stream):
-            self.side.launch_side()
+        self.side.launch_side(redirect=True)
         self.side.finish()
         return loss
 
@@ -989,9 +992,8 @@ class Trainer:
         # three graphs, no host-side cross-stream dependency: the streams meet through device flags (SideSchedule)
         # (the side graph goes first: its device-side waits are then in place when the main chain reaches its cuts, also when the
         # host is slower at launching than the GPU at running, e.g. under a profiler)
-        g_main, g_side, g_tail = self._side_graphs
-        with torch.cuda.stream(self.side.stream):
-            g_side.replay()
+        g_main, side_exec, g_tail = self._side_graphs
+        self.side.raw_replay(side_exec)
         g_main.replay()
         g_tail.replay()
         if self.dp_path:
@@ -1088,33 +1090,35 @@ class Trainer:
             self._choose_schedule()
 
     def _capture_side(self, s):
-        """The side-stream schedule as three HIP graphs: the main chain (forward, Dice, backward with a flag store at every cut),
-        the weight-gradient launches behind their device-side waits (replayed on the side stream), and the tail (wait for the
-        side stream's flag, slab reduction, Adam).  The tail is a graph of its own only because the slab-reduction job table is
-        complete once the weight-gradient launches have been issued."""
+        """The side-stream schedule as three HIP graphs: the main chain (torch capture: forward, Dice, backward with a flag store at
+        every hand-off), the side stream's work behind its device-side waits -- captured AT THE SAME TIME as a raw HIP graph, since
+        its launches are issued in the middle of the main chain's -- and the tail (wait for the side stream's 'done' flag, slab
+        reduction, Adam).  The tail is a graph of its own because the slab-reduction job table is complete only once every
+        weight-gradient launch has been issued."""
         import gc
         gc.collect()
         pool = torch.cuda.graph_pool_handle()
-        side = self.side.stream
-        g_main, g_side, g_tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        sd = self.side
+        g_main, g_tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
-        with torch.cuda.stream(s):
-            g_main.capture_begin(pool=pool, capture_error_mode="thread_local")
-            self._side_loss = self._side_pass(self._static_x, self._static_t)
-            g_main.capture_end()
-        with torch.cuda.stream(side):
-            g_side.capture_begin(capture_error_mode="thread_local")   # kernels only: workspaces were allocated when queued
-            self.side.launch_side()
-            g_side.capture_end()
+        sd.raw_capture_begin()
+        try:
+            with torch.cuda.stream(s):
+                g_main.capture_begin(pool=pool, capture_error_mode="thread_local")
+                self._side_loss = self._side_pass(self._static_x, self._static_t)
+                g_main.capture_end()
+            sd.launch_side(redirect=True)
+        finally:
+            side_exec = sd.raw_capture_end()
         with torch.cuda.stream(s):
             g_tail.capture_begin(pool=pool, capture_error_mode="thread_local")
-            self.side.finish()
+            sd.finish()
             if not self.dp_path:
                 self._update()
             g_tail.capture_end()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self._side_graphs = (g_main, g_side, g_tail)
+        self._side_graphs = (g_main, side_exec, g_tail)
 
     def _capture_segments(self, s):
         """one HIP graph per gradient bucket: the capture is closed and the next one opened inside the backward walk, at the
@@ -1158,6 +1162,7 @@ class SearchTrainer:
         self._side_active = True     # _pass: use the side stream (when there is one)
         self.side_forward = os.environ.get("N3D_SIDE_FORWARD", "1") != "0"   # ... also for the off-chain edges of the forward passes
         self.side_backward = os.environ.get("N3D_SIDE_BACKWARD", "1") != "0"  # ... and for the preprocess-fed edges of the backward passes
+        self.side_backward_inputs = tuple(int(c) for c in os.environ.get("N3D_SIDE_BACKWARD_IN", "01") if c.isdigit())   # (probe knob)
         self.side_backward_weight = tuple(int(c) for c in os.environ.get("N3D_SIDE_BACKWARD_W", "") if c.isdigit())   # (weight pass: which ones; default none)
         self._use_side = False
         self.schedule_times = None
@@ -1239,7 +1244,7 @@ class SearchTrainer:
                 # weight pass: it already carries every weight gradient -- with both edge sets on top the pass takes 9.6 instead of
                 # 8.1 ms, with one 9.1 -- so its backward stays on one stream
                 # -- unless they run on a stream of their own (SideSchedule.split): then the weight pass does the same, 8.1 -> 7.1 ms
-                bwd_inputs = (0, 1) if (arch or (sided and self.side.split)) else self.side_backward_weight
+                bwd_inputs = self.side_backward_inputs if (arch or (sided and self.side.split)) else self.side_backward_weight
                 with (self.side.backward_mode(bwd_inputs) if (sided and self.side_backward and bwd_inputs) else contextlib.nullcontext()):
                     if sided and not arch:
                         with self.side.deferring():

@@ -22,10 +22,9 @@ def run(drop, mq=3):
     torch.cuda.synchronize()
     for i in range(n):
         evs[i][0].record()
+        tr.side.raw_replay(g_side)
         g_main.replay()
         evs[i][1].record()
-        with torch.cuda.stream(tr.side.stream):
-            g_side.replay()
         g_tail.replay()
         evs[i][2].record()
     torch.cuda.synchronize()
