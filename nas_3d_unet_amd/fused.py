@@ -171,10 +171,11 @@ def _node_fwd_units(plan):
     return units
 
 
-def _run_forward(plan, x0, x1, alpha1, alpha2):
-    """Returns (cell output tensor, saved state)."""
+def _run_forward(plan, x0, x1, alpha1, alpha2, pre0_early=None):
+    """Returns (cell output tensor, saved state).  pre0_early = (View, saved state, flag id): the cell's first preprocess op has
+    already been launched on the side stream (NetFn.forward, SIDE_FWD); the cell joins it instead of running it."""
     with K.stats_cache(), K.storage(plan.dt):
-        return _run_forward_impl(plan, x0, x1, alpha1, alpha2)
+        return _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early)
 
 
 # Side-stream forward of a supernet cell (train.SideSchedule sets SIDE_FWD; round 3).  A node sums the MixedOps of ALL earlier states
@@ -260,16 +261,22 @@ def _run_forward_side(plan, x0, x1, alpha1, alpha2, sf):
     return out.t, st
 
 
-def _run_forward_impl(plan, x0, x1, alpha1, alpha2):
+def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None):
     if SIDE_FWD is not None and not plan.pairs and _grouping(plan.c_node):
         return _run_forward_side(plan, x0, x1, alpha1, alpha2, SIDE_FWD)
     st = P.Saved()
     x0v, x1v = K.as_view(x0, "x0"), K.as_view(x1, "x1")
     # the two preprocess ops (cell.py:47-50) are independent and of one output shape: paired epilogue launch
     shp = plan.pre1.weight.out_shape(x1v)
-    p0 = K.as_view(K.empty_ndhwc(*shp, x1v.t.device))
-    p1 = K.as_view(K.empty_ndhwc(*shp, x1v.t.device))
-    if tuple(plan.pre0.weight.out_shape(x0v)) == tuple(shp) and plan.pre0.dropout is None and plan.pre1.dropout is None:
+    if pre0_early is not None:
+        # the skip-side preprocess op ran on the side stream as soon as its input existed: only the other one is on the chain
+        p0, st.s_pre0, tok = pre0_early
+        p1, st.s_pre1 = P.seg_forward(plan.pre1, x1v)
+        SIDE_FWD.join(tok)
+        st.pre0_side = True
+    elif tuple(plan.pre0.weight.out_shape(x0v)) == tuple(shp) and plan.pre0.dropout is None and plan.pre1.dropout is None:
+        p0 = K.as_view(K.empty_ndhwc(*shp, x1v.t.device))
+        p1 = K.as_view(K.empty_ndhwc(*shp, x1v.t.device))
         st.s_pre0, st.s_pre1 = P.pair_forward(plan.pre0, x0v, plan.pre1, x1v, p0, p1)
     else:
         p0, st.s_pre0 = P.seg_forward(plan.pre0, x0v)
@@ -540,8 +547,19 @@ def _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_da
         if not pre_started[i]:
             dpre[i].t.zero_()
     (t0, acc0), (t1, acc1) = dx_targets if dx_targets is not None else ((None, False), (None, False))
-    (d0, g0), (d1, g1) = P.pair_backward(plan.pre0, st.s_pre0, plan.pre1, st.s_pre1, dpre[0], (need_x0, t0, acc0), (need_x1, t1, acc1),
-                                         dpre[1])
+    if SIDE_BWD is not None and plan.pairs and getattr(st, "pre0_side", False) and need_x0 and t0 is None:
+        # an up cell of the searched net: the gradient of its SKIP input is not needed before the backward walk reaches the lower
+        # part of the U, so the backward of the skip-side preprocess op goes to the side stream; NetFn.backward joins its flag
+        # (st.side_tok) before anything else touches that gradient buffer
+        sb = SIDE_BWD
+        f = sb.fork()
+        with sb.side(f):
+            d0, g0 = P.seg_backward(plan.pre0, st.s_pre0, dpre[0], True, None, False)
+            st.side_tok = sb.side_signal()
+        d1, g1 = P.seg_backward(plan.pre1, st.s_pre1, dpre[1], need_x1, t1, acc1)
+    else:
+        (d0, g0), (d1, g1) = P.pair_backward(plan.pre0, st.s_pre0, plan.pre1, st.s_pre1, dpre[0], (need_x0, t0, acc0), (need_x1, t1, acc1),
+                                             dpre[1])
     put(plan.pre0, g0)
     put(plan.pre1, g1)
     return d0, d1, da1, da2, grads
@@ -697,15 +715,45 @@ class NetFn(torch.autograd.Function):
     def forward(ctx, nplan, x, a1d, a1u, a2d, a2u, *params):
         xv = K.as_view(x, "input")
         al = [a.detach().contiguous() if a is not None else None for a in (a1d, a1u, a2d, a2u)]
-        with K.storage(nplan.stem_dt):
-            s0, st0 = P.seg_forward(nplan.stem0, xv)
-            s1, st1 = P.seg_forward(nplan.stem1, xv)
+        sf = SIDE_FWD
+        early = {}       # up cell k -> (View, saved state, flag id) of its skip-side preprocess op, launched on the side stream
+
+        def spawn_pre0(act_index):
+            """searched net, SIDE_FWD: the activation `act_index` exists now -- the up cell that takes it as its skip input does
+            not need it before the whole lower part of the U has run, so its 1x1x1 preprocess op starts on the side stream here"""
+            if sf is None or nplan.supernet:
+                return
+            for k in range(nplan.n_down, len(nplan.wiring)):
+                pl = nplan.cells[k]
+                if nplan.wiring[k][0] == act_index and pl.pairs and pl.pre0.dropout is None:
+                    f = sf.fork()
+                    with sf.side(f), K.storage(pl.dt):
+                        p0, s_pre0 = P.seg_forward(pl.pre0, K.as_view(acts[act_index], "x0"))
+                        early[k] = (p0, s_pre0, sf.side_signal())
+
+        if sf is not None:
+            # the two stems are independent chains (conv, coefficients, epilogue): one of them on the side stream
+            f = sf.fork()
+            with sf.side(f), K.storage(nplan.stem_dt):
+                s1, st1 = P.seg_forward(nplan.stem1, xv)
+                tok1 = sf.side_signal()
+            with K.storage(nplan.stem_dt):
+                s0, st0 = P.seg_forward(nplan.stem0, xv)
+            sf.join(tok1)
+        else:
+            with K.storage(nplan.stem_dt):
+                s0, st0 = P.seg_forward(nplan.stem0, xv)
+                s1, st1 = P.seg_forward(nplan.stem1, xv)
         acts, states = [s0.t, s1.t], []
+        spawn_pre0(0)
+        spawn_pre0(1)
         for k, (i0, i1, _) in enumerate(nplan.wiring):
             a1, a2 = (al[0], al[2]) if k < nplan.n_down else (al[1], al[3])
-            out, st = _run_forward(nplan.cells[k], acts[i0], acts[i1], a1, a2)
+            out, st = _run_forward(nplan.cells[k], acts[i0], acts[i1], a1, a2, early.pop(k, None))
             acts.append(out)
             states.append(st)
+            if k < nplan.n_down:
+                spawn_pre0(2 + k)
         ctx.nplan, ctx.al, ctx.st0, ctx.st1, ctx.states = nplan, al, st0, st1, states
         return acts[-1]
 
@@ -718,13 +766,24 @@ class NetFn(torch.autograd.Function):
         gbuf[-1] = dout
         grads = [None] * len(nplan.params)
         das = [None] * 4
+        pending = {}     # activation index -> flag id: its gradient buffer is being written by the side stream (SIDE_BWD)
+
+        def settle(*idx):
+            for i in idx:
+                if i in pending:
+                    SIDE_BWD.join(pending.pop(i))
+
         for k in reversed(range(len(nplan.cells))):
             i0, i1, io = nplan.wiring[k]
             down = k < nplan.n_down
             a1, a2 = (al[0], al[2]) if down else (al[1], al[3])
+            settle(i0, i1, io)
             targets = tuple((K.as_view(gbuf[i], "grad") if gbuf[i] is not None else None, gbuf[i] is not None) for i in (i0, i1))
             d0, d1, da1, da2, gl = _run_backward(nplan.cells[k], ctx.states[k], gbuf[io], a1, a2, True, True, want_da, targets,
                                                  own_dout=gbuf[io] is not dout)
+            tok = getattr(ctx.states[k], "side_tok", None)
+            if tok is not None:
+                pending[i0] = tok
             ctx.states[k] = None
             gbuf[io] = None
             gbuf[i0], gbuf[i1] = d0, d1
@@ -735,6 +794,7 @@ class NetFn(torch.autograd.Function):
                     das[slot] = d if das[slot] is None else das[slot].add_(d)
             if CELL_DONE_HOOK is not None:
                 CELL_DONE_HOOK(k)
+        settle(0, 1)
         need_x = ctx.needs_input_grad[1]
         dx = None
         n0 = len(nplan.stem0.params())
