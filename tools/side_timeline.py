@@ -36,13 +36,16 @@ ms = (time.perf_counter() - t0) / 30 * 1e3
 tr.check_sync()
 st = tr.side.trace.cpu().numpy().astype("int64")
 J = tr.side.JOIN
-n = int((tr.side.sync[8:8 + J] > 0).sum())
-us = lambda v: (int(v) - int(st[2])) / 100.0      # 100 MHz clock
-print("searched-net train step, batch 2, 4x%d^3 %s, side-stream schedule (with the stamps' own launches): %.3f ms per step, %d cuts" % (args.size, args.dtype, ms, n))
-print("%4s %12s %14s %10s %12s" % ("cut", "main signal", "side past wait", "side lag", "group ran"))
-for i in range(n):
+used = int((tr.side.sync[8:8 + J] > 0).sum())
+cuts = [i for i in range(J) if st[2 * i + 2] != 0 and st[2 * i + 3] != 0]     # the stamped hand-offs: the cuts of the backward walk
+t0 = int(st[2 * cuts[0] + 2])
+us = lambda v: (int(v) - t0) / 100.0      # 100 MHz clock
+print("searched-net train step, batch 2, 4x%d^3 %s, side-stream schedule (with the stamps' own launches): %.3f ms per step; %d hand-offs per step, "
+      "%d of them cuts of the backward walk (weight-gradient groups), the rest forks / joins of the net's off-chain pieces" % (args.size, args.dtype, ms, used, len(cuts)))
+print("%4s %12s %14s %10s %12s" % ("flag", "main signal", "side past wait", "side lag", "group ran"))
+for k, i in enumerate(cuts):
     m, w = us(st[2 * i + 2]), us(st[2 * i + 3])
-    nxt = us(st[2 * (i + 1) + 3]) if i + 1 < n else us(st[2 * J + 4])
+    nxt = us(st[2 * cuts[k + 1] + 3]) if k + 1 < len(cuts) else us(st[2 * J + 4])
     print("%4d %12.1f %14.1f %10.1f %12s" % (i, m, w, w - m, "<= %.1f" % (nxt - w)))
 print("side stream done at %.1f us; main stream past the join at %.1f us (main's last cut at %.1f us); slab reduction launched by %.1f us"
-      % (us(st[2 * J + 4]), us(st[2 * J + 5]), us(st[2 * (n - 1) + 2]), us(st[2 * J + 6])))
+      % (us(st[2 * J + 4]), us(st[2 * J + 5]), us(st[2 * cuts[-1] + 2]), us(st[2 * J + 6])))
