@@ -279,6 +279,17 @@ int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const float* do
 int n3d_bwd_small2_ok(int B, int64_t N, int C, int G);
 int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const float* dout1 /* as in ..._reduce2 */, int64_t dld1, const n3d_gn_bwd_term* t0,
                               const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* stream);
+/* The general form (round 3).  n3d_bwd_small_mode: 0 = shape not taken, 1 = one workgroup per group as above, 2 = one workgroup per
+ * (group, sample) for B = 2..4 samples of up to 2048 channel quads per group EACH (the 8^3 level at 16 channels per group): d(raw)
+ * is per sample; each workgroup stores its parameter-gradient contribution to `scratch` (n3d_bwd_small_scratch_bytes) and the one
+ * that draws the last of the group's tickets adds them in sample order.  `tickets`: G zero-initialised words that no other
+ * launch in flight uses; they are zero again when the launch is over (atomicInc wrapping at B - 1), so a replayed graph needs
+ * no reset.  scratch / tickets may be NULL for mode 1.  t1 == NULL: a single epilogue (dout1 must be NULL then). */
+int n3d_bwd_small_mode(int B, int64_t N, int C, int G);
+size_t n3d_bwd_small_scratch_bytes(int B, int G);
+int n3d_affine_act_bwd_small(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
+                             const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* scratch, size_t scratch_bytes,
+                             uint32_t* tickets, void* stream);
 /* the same pairing for tensors with more partial rows than the fused prologues accept (the 32^3 / 64^3 levels):
  * n3d_gn_coeffs2 = two n3d_gn_coeffs in one launch (fills a_out, b_out, mean_rstd_out, sumraw of both terms);
  * n3d_affine_act2 = two n3d_affine_act into one output (reads a_out / b_out as the coefficients; stats unused);

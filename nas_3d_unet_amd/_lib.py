@@ -144,6 +144,9 @@ PROTOTYPES = {
     "n3d_affine_act2": (_i, [C.POINTER(GnFwdTerm), C.POINTER(GnFwdTerm), _p, _i64, _p, _i64, _i, _i64, _i, _i, _p]),
     "n3d_bwd_small2_ok": (_i, [_i, _i64, _i, _i]),
     "n3d_affine_act_bwd_small2": (_i, [_p, _i64, _p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _i, _p]),
+    "n3d_bwd_small_mode": (_i, [_i, _i64, _i, _i]),
+    "n3d_bwd_small_scratch_bytes": (C.c_size_t, [_i, _i]),
+    "n3d_affine_act_bwd_small": (_i, [_p, _i64, _p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _i, _p, C.c_size_t, _p, _p]),
     "n3d_gn_bwd_coeffs2": (_i, [C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i, _i, _i64, _p]),
     "n3d_affine_act_bwd_apply2": (_i, [_p, _i64, _p, _i64, C.POINTER(GnBwdTerm), C.POINTER(GnBwdTerm), _i, _i64, _i, _p]),
     "n3d_plain_bwd_coeffsN": (_i, [C.POINTER(PlainCoefTerm), _i, _i, _i, _p]),

@@ -13,6 +13,11 @@
 //   src coordinate = (dst*sn + off + tap*dt) / den   (valid iff divisible and in range).
 #include <stdlib.h>
 #include "n3d_common.h"
+// cache policy of the weight-gradient kernels' LDS-DMA loads (cpol bits: 1 = sc0, 2 = nt, 16 = sc1).  These kernels run on the side
+// stream next to the backward chain and stream 8-25 MB tensors through the L2s that hold the chain's working set.
+#ifndef N3D_WGRAD_AUX
+#define N3D_WGRAD_AUX 0
+#endif
 
 namespace n3d {
 
@@ -1422,7 +1427,7 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
           srcp = reinterpret_cast<const float4*>(dyb + (((int64_t)(d0 + g) * a.H + h0 + hh) * a.W + w0 + vx) * a.dyld + q * 4);
         }
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)srcp, (lptr_t)(buf + c * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)srcp, (lptr_t)(buf + c * 64), 16, 0, N3D_WGRAD_AUX);
     }
   };
   const int ntile = a.dchunk / TD;
@@ -1568,7 +1573,7 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
           srcp = reinterpret_cast<const float4*>(dyb + (((int64_t)(d0 + g) * a.oH + h0 + hh) * a.oW + w0 + vx) * a.dyld + q * 4);
         }
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)srcp, (lptr_t)(buf + c * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)srcp, (lptr_t)(buf + c * 64), 16, 0, N3D_WGRAD_AUX);
     }
   };
   const int ntile = a.dchunk / TD;
@@ -2424,7 +2429,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
         const int gd = d0 - DIL + z, gh = h0 - DIL + y, gw = w0 - DIL + x;
         const bool ok = v < NV && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
         const float* sp = srcb + (((int64_t)gd * H + gh) * W + gw) * a.xld + cit * 16 + q * 4;
-        __builtin_amdgcn_global_load_lds((gptr_t)(ok ? reinterpret_cast<const float4*>(sp) : zp), (lptr_t)(wt16 + (i * 4 + wave) * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(ok ? reinterpret_cast<const float4*>(sp) : zp), (lptr_t)(wt16 + (i * 4 + wave) * 64), 16, 0, N3D_WGRAD_AUX);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1238,27 +1238,36 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __re
 // fp64 across waves in a fixed order, coefficients in fp64 as the two-launch path does.
 // ------------------------------------------------------------------------------------------------
 // TWO: term 1 has its own output gradient dout1 (the two preprocess ops of a cell, independent outputs of one shape)
-template <int QPT, bool TWO, typename T = float>
+// SPLIT: one workgroup per (group, SAMPLE) -- blockIdx.y = sample -- for tensors whose B samples do not fit one workgroup (the 8^3
+//   level at 16 channels per group: 2048 quads per sample).  Everything up to d(raw) is per sample; the parameter gradients sum
+//   over the samples, so each workgroup stores its contribution to `scratch` and the one that draws the last ticket of the group
+//   (atomicInc wrapping at B - 1: the counter is back at 0 for the next launch / graph replay) adds them in sample order.
+// NT: 2 = a node's two terms; 1 = a single epilogue (a preprocess op whose partner has another shape)
+template <int QPT, bool TWO, bool SPLIT, int NT, typename T = float>
 __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ dout1,
-                                                            int64_t dld1, GnBwdTerm t0, GnBwdTerm t1, int B, int N, int C, int G, double count) {
+                                                            int64_t dld1, GnBwdTerm t0, GnBwdTerm t1, int B, int N, int C, int G, double count,
+                                                            double* __restrict__ scratch, unsigned* __restrict__ tickets) {
+  constexpr int MB = SPLIT ? 1 : 4;
   __shared__ float red[QPT * 16][2][32];   // [slot = i*16 + wave][term][(S1 | S2) x 16 channels]
-  __shared__ double tot[4][2][32];         // [b][term][(S1 | S2) x 16 channels]
-  __shared__ float fco[4][2][2][16];       // forward a | b of (sample, term, channel): staged once, read twice per element
-  __shared__ float coef[4][2][3][16];      // [b][term][A | B | C][channel]
-  __shared__ double contrib[4][2][3][16];  // [b][term][dgamma | dbeta | dbias][channel]
+  __shared__ double tot[MB][2][32];        // [b][term][(S1 | S2) x 16 channels]
+  __shared__ float fco[MB][2][2][16];      // forward a | b of (sample, term, channel): staged once, read twice per element
+  __shared__ float coef[MB][2][3][16];     // [b][term][A | B | C][channel]
+  __shared__ double contrib[MB][2][3][16]; // [b][term][dgamma | dbeta | dbias][channel]
+  __shared__ unsigned last_one;
   const int g = blockIdx.x, cg = C / G, cpg4 = cg >> 2;
+  const int b0 = SPLIT ? (int)blockIdx.y : 0, Bl = SPLIT ? 1 : B;   // first sample / number of samples of this workgroup
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   // a sample's quads occupy a whole number of waves (padded with idle lanes when N * cg/4 is not a multiple of 64: the 2^3 level)
-  const int real_b = N * cpg4, per_b = (real_b + 63) & ~63, total = B * per_b;
+  const int real_b = N * cpg4, per_b = (real_b + 63) & ~63, total = Bl * per_b;
   const int q = t % cpg4;                  // the channel quad of every element of this thread
   const int c0 = g * cg + q * 4;
   const float thr0 = t0.relu ? 0.f : -INFINITY, thr1 = t1.relu ? 0.f : -INFINITY;
-  if (t < B * 2 * 2 * 16) {
+  if (t < Bl * 2 * 2 * 16) {
     const int b = t >> 6, k = (t >> 5) & 1, ab = (t >> 4) & 1, c = t & 15;
     const GnBwdTerm& tm = k ? t1 : t0;
-    fco[b][k][ab][c] = c < cg ? (ab ? tm.b : tm.a)[b * C + g * cg + c] : 0.f;
+    fco[b][k][ab][c] = (c < cg && k < NT) ? (ab ? tm.b : tm.a)[(b0 + b) * C + g * cg + c] : 0.f;
   }
-  float4 d4[QPT], e4[TWO ? QPT : 1], r0[QPT], r1[QPT];
+  float4 d4[QPT], e4[TWO ? QPT : 1], r0[QPT], r1[NT == 2 ? QPT : 1];
   bool ok[QPT];
   int bi[QPT];
   int64_t vox[QPT];
@@ -1268,21 +1277,22 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const T* __restrict
     const int eb = e / per_b, er = e - eb * per_b;
     ok[i] = e < total && er < real_b;
     bi[i] = ok[i] ? eb : 0;
-    vox[i] = (int64_t)bi[i] * N + (ok[i] ? er : 0) / cpg4;
+    vox[i] = (int64_t)(b0 + bi[i]) * N + (ok[i] ? er : 0) / cpg4;
     d4[i] = ld4(dout + vox[i] * dld + c0);
     if (TWO) e4[TWO ? i : 0] = ld4(dout1 + vox[i] * dld1 + c0);
     r0[i] = ld4(reinterpret_cast<const T*>(t0.raw) + vox[i] * t0.rld + c0);
-    r1[i] = ld4(reinterpret_cast<const T*>(t1.raw) + vox[i] * t1.rld + c0);
+    if (NT == 2) r1[NT == 2 ? i : 0] = ld4(reinterpret_cast<const T*>(t1.raw) + vox[i] * t1.rld + c0);
   }
   __syncthreads();
   // ---- pass 1: S1 = sum g, S2 = sum g * raw per (sample, channel), g = dout behind the term's ReLU mask
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     const float4 e4i = TWO ? e4[TWO ? i : 0] : d4[i];
+    const float4 r1i = NT == 2 ? r1[NT == 2 ? i : 0] : r0[i];
     const float dd[2][4] = {{d4[i].x, d4[i].y, d4[i].z, d4[i].w}, {e4i.x, e4i.y, e4i.z, e4i.w}};
-    const float ra[2][4] = {{r0[i].x, r0[i].y, r0[i].z, r0[i].w}, {r1[i].x, r1[i].y, r1[i].z, r1[i].w}};
+    const float ra[2][4] = {{r0[i].x, r0[i].y, r0[i].z, r0[i].w}, {r1i.x, r1i.y, r1i.z, r1i.w}};
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NT; ++k) {
       const float thr = k ? thr1 : thr0;
       const float4 fa = ld4(&fco[bi[i]][k][0][q * 4]), fb = ld4(&fco[bi[i]][k][1][q * 4]);
       const float aa[4] = {fa.x, fa.y, fa.z, fa.w}, bb[4] = {fb.x, fb.y, fb.z, fb.w};
@@ -1297,10 +1307,10 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const T* __restrict
   }
   __syncthreads();
   // fixed-order sum of the wave slots of each sample: slot s covers the quads [64 s, 64 s + 64), a sample per_b / 64 of them
-  if (t < B * 2 * 32) {
+  if (t < Bl * 2 * 32) {
     const int b = t >> 6, k = (t >> 5) & 1, idx = t & 31;
     double s = 0;
-    if ((idx & 15) < cg) {
+    if ((idx & 15) < cg && k < NT) {
       const int spb = per_b >> 6, s0 = b * spb;
       for (int sl = s0; sl < s0 + spb; ++sl) s += (double)red[sl][k][idx];
     }
@@ -1308,12 +1318,13 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const T* __restrict
   }
   __syncthreads();
   // ---- coefficients of d(raw) = A * g + B + C * raw and the per-sample parameter-gradient contributions
-  if (t < B * 2 * 16) {
+  if (t < Bl * 2 * 16) {
     const int b = t >> 5, k = (t >> 4) & 1, c = t & 15;
-    if (c < cg) {
+    if (c < cg && k < NT) {
       const GnBwdTerm& tm = k ? t1 : t0;
+      const int gb = b0 + b;
       const double w = tm.wptr ? (double)*tm.wptr : 1.0;
-      const double mn = tm.mean_rstd[(b * G + g) * 2], rsd = tm.mean_rstd[(b * G + g) * 2 + 1];
+      const double mn = tm.mean_rstd[(gb * G + g) * 2], rsd = tm.mean_rstd[(gb * G + g) * 2 + 1];
       double c1 = 0, c2 = 0;
       for (int cc = 0; cc < cg; ++cc) {
         const double gm = (double)tm.gamma[g * cg + cc];
@@ -1327,21 +1338,33 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const T* __restrict
       const double S1 = tot[b][k][c], S2 = tot[b][k][16 + c];
       const double Av = rsd * gam * w, Bv = -rsd * c1 + rsd * rsd * c2 * mn, Cv = -rsd * rsd * c2;
       coef[b][k][0][c] = (float)Av; coef[b][k][1][c] = (float)Bv; coef[b][k][2][c] = (float)Cv;
-      contrib[b][k][0][c] = w * rsd * (S2 - mn * S1);
-      contrib[b][k][1][c] = w * S1;
-      contrib[b][k][2][c] = tm.dbias_conv ? Av * S1 + count * Bv + Cv * tm.sumraw[b * C + g * cg + c] : 0.0;
+      const double cdg = w * rsd * (S2 - mn * S1), cdb = w * S1;
+      const double cdc = tm.dbias_conv ? Av * S1 + count * Bv + Cv * tm.sumraw[gb * C + g * cg + c] : 0.0;
+      contrib[b][k][0][c] = cdg; contrib[b][k][1][c] = cdb; contrib[b][k][2][c] = cdc;
+      if (SPLIT) {
+        double* sc = scratch + ((((int64_t)g * B + gb) * 2 + k) * 3) * 16 + c;
+        __hip_atomic_store(sc, cdg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sc + 16, cdb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sc + 32, cdc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+      }
     }
   }
   __syncthreads();
+  if (SPLIT && t == 0) {
+    // the ticket goes out before the d(raw) pass: by the time that pass is through, the last sample's workgroup has its answer
+    last_one = atomicInc(&tickets[g], (unsigned)(B - 1)) == (unsigned)(B - 1);
+  }
   // ---- pass 2: d(raw) of both terms from the registers
 #pragma unroll
   for (int i = 0; i < QPT; ++i) {
     if (!ok[i]) continue;
     const float4 e4i = TWO ? e4[TWO ? i : 0] : d4[i];
+    const float4 r1i = NT == 2 ? r1[NT == 2 ? i : 0] : r0[i];
     const float dd[2][4] = {{d4[i].x, d4[i].y, d4[i].z, d4[i].w}, {e4i.x, e4i.y, e4i.z, e4i.w}};
-    const float ra[2][4] = {{r0[i].x, r0[i].y, r0[i].z, r0[i].w}, {r1[i].x, r1[i].y, r1[i].z, r1[i].w}};
+    const float ra[2][4] = {{r0[i].x, r0[i].y, r0[i].z, r0[i].w}, {r1i.x, r1i.y, r1i.z, r1i.w}};
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NT; ++k) {
       const float thr = k ? thr1 : thr0;
       const float4 fa = ld4(&fco[bi[i]][k][0][q * 4]), fb = ld4(&fco[bi[i]][k][1][q * 4]);
       const float4 qA = ld4(&coef[bi[i]][k][0][q * 4]), qB = ld4(&coef[bi[i]][k][1][q * 4]),
@@ -1360,12 +1383,26 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const T* __restrict
     }
   }
   // ---- parameter gradients: sums over the samples in sample order
+  if (SPLIT) {
+    __syncthreads();
+    if (!last_one) return;
+    __threadfence();
+  }
   if (t < 2 * 16) {
     const int k = t >> 4, c = t & 15;
-    if (c < cg) {
+    if (c < cg && k < NT) {
       const GnBwdTerm& tm = k ? t1 : t0;
       double dg = 0, db = 0, dbc = 0;
-      for (int b = 0; b < B; ++b) { dg += contrib[b][k][0][c]; db += contrib[b][k][1][c]; dbc += contrib[b][k][2][c]; }
+      for (int b = 0; b < B; ++b) {
+        if (SPLIT) {
+          const double* sc = scratch + ((((int64_t)g * B + b) * 2 + k) * 3) * 16 + c;
+          dg += __hip_atomic_load(sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          db += __hip_atomic_load(sc + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dbc += __hip_atomic_load(sc + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          dg += contrib[b][k][0][c]; db += contrib[b][k][1][c]; dbc += contrib[b][k][2][c];
+        }
+      }
       if (tm.dgamma) tm.dgamma[g * cg + c] = (float)dg;
       if (tm.dbeta) tm.dbeta[g * cg + c] = (float)db;
       if (tm.dbias_conv) tm.dbias_conv[g * cg + c] = (float)dbc;
@@ -2145,40 +2182,72 @@ int n3d_bwd_small2_ok(int B, int64_t N, int C, int G) {
   return ((int64_t)B * per_b <= 2048) ? 1 : 0;
 }
 
-int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
-                              const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* stream) {
-  N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0 && t0->dtype == t1->dtype, "affine_act_bwd_small2: bad args");
+// 0 = not taken; 1 = one workgroup per group (all samples: n3d_bwd_small2_ok); 2 = one workgroup per (group, sample)
+int n3d_bwd_small_mode(int B, int64_t N, int C, int G) {
+  if (n3d_bwd_small2_ok(B, N, C, G)) return 1;
+  if (!pair_shape_ok(C, G) || B < 2 || B > 4 || N < 1 || N > 4096) return 0;
+  const int cpg4 = (C / G) / 4;
+  if (cpg4 < 1) return 0;
+  return ((N * cpg4 + 63) / 64 * 64 <= 2048) ? 2 : 0;
+}
+
+size_t n3d_bwd_small_scratch_bytes(int B, int G) { return (size_t)G * B * 2 * 3 * 16 * sizeof(double); }
+
+static int bwd_small_launch(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
+                            const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* scratch, size_t scratch_bytes, uint32_t* tickets,
+                            void* stream, const char* what) {
+  N3D_CHECK_ARG(dout && t0 && B > 0 && N > 0 && (!t1 || t0->dtype == t1->dtype), "affine_act_bwd_small: bad args");
+  N3D_CHECK_ARG(t1 || !dout1, "affine_act_bwd_small: dout1 needs a second term");
   const bool bf = t0->dtype == N3D_BF16;
-  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_small2(dout1)", bf)) return e; }
-  if (!n3d_bwd_small2_ok(B, N, C, G)) N3D_UNSUPPORTED("affine_act_bwd_small2: shape not supported (B=%d N=%lld C=%d G=%d)", B, (long long)N, C, G);
-  if (int e = check_vec(dout, dld, C, "bwd_small2(dout)", bf)) return e;
+  if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_small(dout1)", bf)) return e; }
+  const int mode = n3d_bwd_small_mode(B, N, C, G);
+  if (!mode || (mode == 2 && !(scratch && tickets)))
+    N3D_UNSUPPORTED("%s: shape not supported (B=%d N=%lld C=%d G=%d%s)", what, B, (long long)N, C, G, mode == 2 ? "; needs scratch and tickets" : "");
+  if (mode == 2) N3D_CHECK_ARG(scratch_bytes >= n3d_bwd_small_scratch_bytes(B, G), "affine_act_bwd_small: scratch too small");
+  if (int e = check_vec(dout, dld, C, "bwd_small(dout)", bf)) return e;
   GnBwdTerm k[2];
-  const n3d_gn_bwd_term* ts[2] = {t0, t1};
+  const n3d_gn_bwd_term* ts[2] = {t0, t1 ? t1 : t0};
   for (int i = 0; i < 2; ++i) {
     const n3d_gn_bwd_term* t = ts[i];
-    N3D_CHECK_ARG(t->raw && t->a && t->b && t->gamma && t->mean_rstd && t->draw, "affine_act_bwd_small2: null term pointer");
-    N3D_CHECK_ARG(!t->dalpha, "affine_act_bwd_small2: MixedOp weight gradients are not produced here (use the reduce2 / apply_gn2 pair)");
-    N3D_CHECK_ARG(!t->dbias_conv || t->sumraw, "affine_act_bwd_small2: dbias_conv needs the forward per-channel sums");
-    if (int e = check_vec(t->raw, t->rld, C, "bwd_small2(raw)", bf)) return e;
-    if (int e = check_vec(t->draw, t->drld, C, "bwd_small2(draw)", bf)) return e;
+    N3D_CHECK_ARG(t->raw && t->a && t->b && t->gamma && t->mean_rstd && t->draw, "affine_act_bwd_small: null term pointer");
+    N3D_CHECK_ARG(!t->dalpha, "affine_act_bwd_small: MixedOp weight gradients are not produced here (use the reduce2 / apply_gn2 pair)");
+    N3D_CHECK_ARG(!t->dbias_conv || t->sumraw, "affine_act_bwd_small: dbias_conv needs the forward per-channel sums");
+    if (int e = check_vec(t->raw, t->rld, C, "bwd_small(raw)", bf)) return e;
+    if (int e = check_vec(t->draw, t->drld, C, "bwd_small(draw)", bf)) return e;
     k[i] = GnBwdTerm{t->raw, t->rld, t->a, t->b, nullptr, 0, t->gamma, t->mean_rstd, t->wptr, t->sumraw, t->draw, t->drld,
                      t->dgamma, t->dbeta, nullptr, t->dbias_conv, t->relu, nullptr, nullptr, nullptr};
   }
-  const int64_t quads = (int64_t)B * ((N * ((C / G) / 4) + 63) / 64 * 64);
+  const int64_t per_b = (N * ((C / G) / 4) + 63) / 64 * 64;
+  const int64_t quads = mode == 2 ? per_b : (int64_t)B * per_b;
   hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(G, mode == 2 ? B : 1);
+  double* sc = (double*)scratch;
   with_act_type(bf, [&](auto* tag) {
     using T = N3D_T(tag);
     const T* d0 = (const T*)dout; const T* d1 = (const T*)dout1;
-    if (quads <= 1024) {
-      if (dout1) hipLaunchKernelGGL((gn_bwd_small2_kernel<1, true, T>), dim3(G), dim3(1024), 0, s, d0, dld, d1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
-      else hipLaunchKernelGGL((gn_bwd_small2_kernel<1, false, T>), dim3(G), dim3(1024), 0, s, d0, dld, d1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
-    } else {
-      if (dout1) hipLaunchKernelGGL((gn_bwd_small2_kernel<2, true, T>), dim3(G), dim3(1024), 0, s, d0, dld, d1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
-      else hipLaunchKernelGGL((gn_bwd_small2_kernel<2, false, T>), dim3(G), dim3(1024), 0, s, d0, dld, d1, dld1, k[0], k[1], B, (int)N, C, G, (double)N);
-    }
+#define N3D_BS(Q, TW, SP, NT_) hipLaunchKernelGGL((gn_bwd_small2_kernel<Q, TW, SP, NT_, T>), grid, dim3(1024), 0, s, d0, dld, d1, dld1, k[0], k[1], B, (int)N, C, G, (double)N, sc, tickets)
+#define N3D_BS_Q(TW, SP, NT_) do { if (quads <= 1024) N3D_BS(1, TW, SP, NT_); else N3D_BS(2, TW, SP, NT_); } while (0)
+    if (!t1) { if (mode == 2) N3D_BS_Q(false, true, 1); else N3D_BS_Q(false, false, 1); }
+    else if (dout1) { if (mode == 2) N3D_BS_Q(true, true, 2); else N3D_BS_Q(true, false, 2); }
+    else { if (mode == 2) N3D_BS_Q(false, true, 2); else N3D_BS_Q(false, false, 2); }
+#undef N3D_BS_Q
+#undef N3D_BS
   });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
+}
+
+int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
+                              const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* stream) {
+  N3D_CHECK_ARG(t1, "affine_act_bwd_small2: two terms");
+  if (!n3d_bwd_small2_ok(B, N, C, G)) N3D_UNSUPPORTED("affine_act_bwd_small2: shape not supported (B=%d N=%lld C=%d G=%d)", B, (long long)N, C, G);
+  return bwd_small_launch(dout, dld, dout1, dld1, t0, t1, B, N, C, G, nullptr, 0, nullptr, stream, "affine_act_bwd_small2");
+}
+
+int n3d_affine_act_bwd_small(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
+                             const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* scratch, size_t scratch_bytes,
+                             uint32_t* tickets, void* stream) {
+  return bwd_small_launch(dout, dld, dout1, dld1, t0, t1, B, N, C, G, scratch, scratch_bytes, tickets, stream, "affine_act_bwd_small");
 }
 
 int n3d_gn_coeffs2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int B, int C, int G, int64_t N, float eps, void* stream) {
@@ -2561,12 +2630,15 @@ int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 }
 
 // fused variants: statistics rows -> coefficients in the kernel prologue (rows <= N3D_FUSED_MAX_ROWS)
-int n3d_fused_max_rows(void) { return 64; }
+int n3d_fused_max_rows(void) {
+  static const int v = [] { const char* e = getenv("N3D_FUSED_MAX_ROWS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 64; }();
+  return v;
+}
 
 int n3d_affine_act_gn(const float* raw, int64_t rld, const double* stats, int rows, const float* gamma, const float* beta, int G, float eps,
                       const float* wptr, float* out, int64_t old_, int B, int64_t N, int C, int flags, float* a_out, float* b_out,
                       float* mean_rstd_out, double* sumraw, void* stream) {
-  N3D_CHECK_ARG(raw && out && stats && gamma && beta && a_out && b_out && mean_rstd_out && C <= 64 && C % G == 0 && rows >= 1 && rows <= 64,
+  N3D_CHECK_ARG(raw && out && stats && gamma && beta && a_out && b_out && mean_rstd_out && C <= 64 && C % G == 0 && rows >= 1 && rows <= n3d_fused_max_rows(),
                 "affine_act_gn: bad args");
   const bool bf = flags & N3D_ACT_BF16;
   if (int e = check_vec(raw, rld, C, "affine_act_gn(raw)", bf)) return e;
@@ -2589,7 +2661,7 @@ int n3d_affine_act_bwd_apply_gn(const float* dout, int64_t dld, const float* raw
                                 const double* sums, int rows, const float* gamma, const float* mean_rstd, const float* wptr,
                                 const double* sumraw, float* draw, int64_t drld, int B, int64_t N, int C, int G, int flags,
                                 float* dgamma, float* dbeta, float* dalpha, float* dbias_conv, void* stream) {
-  N3D_CHECK_ARG(dout && raw && draw && sums && gamma && mean_rstd && C <= 64 && C % G == 0 && rows >= 1 && rows <= 64 && B <= GNF_MAXB,
+  N3D_CHECK_ARG(dout && raw && draw && sums && gamma && mean_rstd && C <= 64 && C % G == 0 && rows >= 1 && rows <= n3d_fused_max_rows() && B <= GNF_MAXB,
                 "affine_act_bwd_apply_gn: bad args (needs rows <= 64, B <= 4)");
   N3D_CHECK_ARG(!dbias_conv || sumraw, "affine_act_bwd_apply_gn: dbias_conv needs the forward per-channel sums");
   const bool bf = flags & N3D_ACT_BF16;

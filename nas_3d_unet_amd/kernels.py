@@ -8,6 +8,7 @@ arithmetic kernel on the path is a libn3d kernel.  Logical tensor shape is the r
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -757,6 +758,7 @@ def affine_act_gn2(terms, G, eps, out: View, flags=0, out1: View | None = None):
 
 
 SMALL_NODE_BACKWARD = True   # the one-launch epilogue backward of a node on the small levels (n3d_affine_act_bwd_small2)
+SINGLE_SMALL_BACKWARD = os.environ.get("N3D_SINGLE_SMALL_BACKWARD", "0") != "0"   # ... and of a single epilogue (programs.seg_backward): measured no faster either
 
 
 def affine_act_bwd_gn2(dout: View, terms, G, dout1: View | None = None):
@@ -767,22 +769,9 @@ def affine_act_bwd_gn2(dout: View, terms, G, dout1: View | None = None):
     dev = raw0.t.device
     B, Cc, N = raw0.B, raw0.C, raw0.N
     lib = _lib.load()
-    if (SMALL_NODE_BACKWARD and all(t.get("dalpha_ptr") is None for t in terms) and lib.n3d_bwd_small2_ok(B, N, Cc, G)):
+    if SMALL_NODE_BACKWARD and all(t.get("dalpha_ptr") is None for t in terms) and small_backward_mode(B, N, Cc, G):
         # small levels: reduction, coefficients, parameter gradients and both d(raw) in ONE launch
-        ts, outs = [], []
-        for t in terms:
-            dgamma, dbeta = grad_target(t["gamma"]), grad_target(t["beta"])
-            cb = t.get("conv_bias")
-            dcb = grad_target(cb) if (cb is not None and t["sumraw"] is not None) else None
-            raw, draw = t["raw"], t["draw"]
-            ts.append(GnBwdTerm(raw.p.value, raw.ld, t["a"].data_ptr(), t["b"].data_ptr(), None, 0, 1 if t["relu"] else 0,
-                                t["gamma"].data_ptr(), t["mr"].data_ptr(), _vp(t.get("wptr")), _vp(t["sumraw"]), draw.p.value, draw.ld,
-                                _vp(dgamma), _vp(dbeta), None, _vp(dcb), None, None, None, raw.dt, 0))
-            outs.append((dgamma, dbeta, dcb))
-        d1p, d1ld = (dout1.p, dout1.ld) if dout1 is not None else (None, 0)
-        check(lib.n3d_affine_act_bwd_small2(dout.p, dout.ld, d1p, d1ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, G, stream_ptr()),
-              "n3d_affine_act_bwd_small2")
-        return outs
+        return affine_act_bwd_small(dout, terms, G, dout1)
     rows = stats_rows(N, Cc)
     sums = torch.empty((2, B, rows, Cc, 3), dtype=torch.float64, device=dev)
     ts, outs = [], []
@@ -809,6 +798,70 @@ def affine_act_bwd_gn2(dout: View, terms, G, dout1: View | None = None):
         check(lib.n3d_gn_bwd_coeffs2(C.byref(ts[0]), C.byref(ts[1]), B, Cc, G, N, stream_ptr()), "n3d_gn_bwd_coeffs2")
         check(lib.n3d_affine_act_bwd_apply2(dout.p, dout.ld, d1p, d1ld, C.byref(ts[0]), C.byref(ts[1]), B, N, Cc, stream_ptr()),
               "n3d_affine_act_bwd_apply2")
+    return outs
+
+
+_ticket_pools = {}   # device index -> [zeroed int32 words, next word]
+
+
+def _tickets(device, n):
+    """`n` zeroed words for a kernel that draws self-resetting tickets (atomicInc wrapping at the last one: zero again when the
+    launch is over, so a replayed graph and the next call site that comes round to the same words find them ready).  Two launches
+    may not use the same words AT THE SAME TIME; the pool hands out 4096 words round-robin, a step uses a few dozen."""
+    key = device.index or 0
+    pool = _ticket_pools.get(key)
+    if pool is None:
+        pool = _ticket_pools[key] = [torch.zeros(4096, dtype=torch.int32, device=device), 0]
+    if pool[1] + n > 4096:
+        pool[1] = 0
+    ptr = pool[0].data_ptr() + 4 * pool[1]
+    pool[1] += n
+    return ptr
+
+
+_small_modes = {}
+# mode 2 of small_backward_mode (the 8^3 level at batch 2) is OFF by default: measured on the benchmarked step it is no faster than the
+# reduce2 + apply_gn2 pair it replaces (main chain 1.928 vs 1.920 ms, profiles/r03_contention_probes.log) -- a dependent launch
+# boundary costs ~1.65 us on this machine, less than the serial latency the 1024-thread form adds
+MID_NODE_BACKWARD = os.environ.get("N3D_MID_BACKWARD", "0") != "0"
+
+
+def small_backward_mode(B, N, Cc, G):
+    """0 = the one-launch epilogue backward does not take this shape; 1 = one workgroup per GroupNorm group; 2 = one per (group,
+    sample) (include/n3d.h, n3d_affine_act_bwd_small)"""
+    key = (B, N, Cc, G)
+    m = _small_modes.get(key)
+    if m is None:
+        m = _small_modes[key] = int(_lib.load().n3d_bwd_small_mode(B, N, Cc, G)) if MID_NODE_BACKWARD else int(_lib.load().n3d_bwd_small2_ok(B, N, Cc, G))
+    return m
+
+
+def affine_act_bwd_small(dout: View, terms, G, dout1: View | None = None):
+    """The whole GroupNorm-epilogue backward of one or two terms (dicts as affine_act_bwd_gn2) in ONE launch; the caller has checked
+    small_backward_mode().  Returns [(dgamma, dbeta, dconv_bias | None)] per term."""
+    raw0 = terms[0]["raw"]
+    dev = raw0.t.device
+    B, Cc, N = raw0.B, raw0.C, raw0.N
+    lib = _lib.load()
+    ts, outs = [], []
+    for t in terms:
+        dgamma, dbeta = grad_target(t["gamma"]), grad_target(t["beta"])
+        cb = t.get("conv_bias")
+        dcb = grad_target(cb) if (cb is not None and t["sumraw"] is not None) else None
+        raw, draw = t["raw"], t["draw"]
+        ts.append(GnBwdTerm(raw.p.value, raw.ld, t["a"].data_ptr(), t["b"].data_ptr(), None, 0, 1 if t["relu"] else 0,
+                            t["gamma"].data_ptr(), t["mr"].data_ptr(), _vp(t.get("wptr")), _vp(t["sumraw"]), draw.p.value, draw.ld,
+                            _vp(dgamma), _vp(dbeta), None, _vp(dcb), None, None, None, raw.dt, 0))
+        outs.append((dgamma, dbeta, dcb))
+    d1p, d1ld = (dout1.p, dout1.ld) if dout1 is not None else (None, 0)
+    scratch, sbytes, tick = None, 0, None
+    if small_backward_mode(B, N, Cc, G) == 2:
+        sbytes = int(lib.n3d_bwd_small_scratch_bytes(B, G))
+        scratch = torch.empty(sbytes // 8, dtype=torch.float64, device=dev)
+        tick = _tickets(dev, G)
+    check(lib.n3d_affine_act_bwd_small(dout.p, dout.ld, d1p, d1ld, C.byref(ts[0]), C.byref(ts[1]) if len(ts) > 1 else None, B, N, Cc, G,
+                                       scratch.data_ptr() if scratch is not None else None, sbytes, tick, stream_ptr()),
+          "n3d_affine_act_bwd_small")
     return outs
 
 

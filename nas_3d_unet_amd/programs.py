@@ -614,12 +614,25 @@ def pair_forward(segA, xA, segB, xB, out, outB=None, accumulate=False, alphaA=No
                 r[1], r[2] = K.channel_stats(r[0])
         res = [tuple(r) for r in res]
     else:
-        for seg, x in ((segA, xA), (segB, xB)):
-            want_stats = seg.norm is not None and seg.weight.produces_stats
-            raw, stats, rows, ws = seg.weight.fwd(x, seg.relu_in, None, want_stats)
-            if seg.norm is not None and stats is None:
-                stats, rows = K.channel_stats(raw)
-            res.append((raw, stats, rows, ws))
+        res = [pair_weight_phase(seg, x) for seg, x in ((segA, xA), (segB, xB))]
+    return pair_epilogue_phase(segA, res[0], segB, res[1], out, outB, accumulate, alphaA, alphaB)
+
+
+def pair_weight_phase(seg, x):
+    """the weight op of ONE op of a pair and the channel statistics its epilogue needs: (raw, stats, rows, weight-op state).  The
+    side-stream schedule launches the op of a searched-cell node whose input is not the node computed last early, on the side
+    stream (fused._run_forward_impl), and hands the result to pair_epilogue_phase."""
+    want_stats = seg.norm is not None and seg.weight.produces_stats
+    raw, stats, rows, ws = seg.weight.fwd(x, seg.relu_in, None, want_stats)
+    if seg.norm is not None and stats is None:
+        stats, rows = K.channel_stats(raw)
+    return (raw, stats, rows, ws)
+
+
+def pair_epilogue_phase(segA, resA, segB, resB, out, outB=None, accumulate=False, alphaA=None, alphaB=None):
+    """second half of pair_forward: the two epilogues (one launch where they pair) of weight ops that are complete on the
+    launching stream"""
+    res = [resA, resB]
     (rawA, stA, rowsA, wsA), (rawB, stB, rowsB, wsB) = res
     G = group_count(rawA.C)
     if (_pairable_fwd(segA) and _pairable_fwd(segB) and rawA.C == rawB.C and rawA.N == rawB.N
@@ -948,6 +961,19 @@ def needs_reduce(seg, s, dalpha):
     return s.kind in ("gn", "se") or dalpha is not None
 
 
+def _finish_gn_backward(seg, s, draw, need_dx, dx_out, dx_acc, cbias, dcb, dgamma, dbeta):
+    """weight-op backward behind a GroupNorm epilogue backward that has produced d(raw) and the norm's parameter gradients"""
+    dx, wg = seg.weight.bwd(s.ws, draw, need_dx, dx_out, dx_acc, dcb is not None)
+    wg = list(wg)
+    if dcb is not None:
+        # the conv bias gradient came out of the GroupNorm backward sums: put it in the bias slot
+        plist = seg.weight.params()
+        for i, p in enumerate(plist):
+            if p is cbias:
+                wg[i] = dcb
+    return dx, wg + [dgamma, dbeta]
+
+
 def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_row=None, alpha_k=0, dalpha=None, pre_sums=None, pre_se=None,
                  pre_dalpha=False):
     """Backward of one segment.  dout: View of d(out).  Returns (dx tensor | None, [param grads])
@@ -962,13 +988,22 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
     fl = RELU if seg.relu_out else 0
     extra = []
     if s.kind == "gn":
-        sums, rows = pre_sums if pre_sums is not None else K.affine_act_bwd_reduce(dout, raw, s.a, s.b, fl)
         cbias = seg.weight.norm_fed_bias()
         if cbias is not None and not cbias.requires_grad:
             cbias = None
         ident = isinstance(seg.weight, IdentityW)
         if ident and not need_dx:
             ident = False
+        if (pre_sums is None and dap is None and not ident and K.SMALL_NODE_BACKWARD and K.SINGLE_SMALL_BACKWARD
+                and K.small_backward_mode(raw.B, raw.N, raw.C, s.G)):
+            # small levels: reduction, coefficients, parameter gradients and d(raw) in ONE launch (the two-term form of a node's
+            # epilogue backward, K.affine_act_bwd_gn2, run for this one term)
+            draw = K.like(raw)
+            (dgamma, dbeta, dcb), = K.affine_act_bwd_small(dout, [dict(raw=raw, a=s.a, b=s.b, mr=s.mr, sumraw=s.sumraw, gamma=seg.norm.weight,
+                                                                      beta=seg.norm.bias, wptr=wp, relu=seg.relu_out, conv_bias=cbias,
+                                                                      draw=draw)], s.G)
+            return _finish_gn_backward(seg, s, draw, need_dx, dx_out, dx_acc, cbias, dcb, dgamma, dbeta)
+        sums, rows = pre_sums if pre_sums is not None else K.affine_act_bwd_reduce(dout, raw, s.a, s.b, fl)
         if ident:
             # the raw tensor is the input itself: the apply pass writes dx directly
             if dx_out is None:
@@ -986,16 +1021,7 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
             K.affine_act_bwd_apply(dout, raw, s.a, s.b, A, Bc, Cc, target, tfl)
         if ident:
             return dx_out.t, [dgamma, dbeta]
-        draw = target
-        dx, wg = seg.weight.bwd(s.ws, draw, need_dx, dx_out, dx_acc, dcb is not None)
-        wg = list(wg)
-        if dcb is not None:
-            # the conv bias gradient came out of the GroupNorm backward sums: put it in the bias slot
-            plist = seg.weight.params()
-            for i, p in enumerate(plist):
-                if p is cbias:
-                    wg[i] = dcb
-        return dx, wg + [dgamma, dbeta]
+        return _finish_gn_backward(seg, s, target, need_dx, dx_out, dx_acc, cbias, dcb, dgamma, dbeta)
     elif s.kind == "se":
         sums, rows = pre_sums if pre_sums is not None else K.affine_act_bwd_reduce(dout, raw, s.a, None, 0)
         fc = seg.se_gate.fc

@@ -238,8 +238,11 @@ def _low_priority_stream(device):
             _side_prio[0] = lo.value
         with torch.cuda.device(device):
             h = C.c_void_p()
-            # (a CU mask on the side stream -- hipExtStreamCreateWithCUMask, half / a quarter / an eighth of the CUs -- changed neither
-            # the chain's time under the side work nor the tail: what the side work costs the chain is not compute units)
+            # (A CU mask on the side stream does not help: hipExtStreamCreateWithCUMask makes a BLOCKING stream -- next to torch's
+            # legacy default stream every hand-off then takes a time slice, a 9.6 ms step -- and with the whole step moved to a
+            # non-blocking stream, a side stream held to 28 or 24 compute units of every XCD [mask bit i = CU i // 8 of XCD i % 8,
+            # tools/cumask_map.cpp; a mask that empties an XCD is ignored] leaves the chain's time under the side work where it
+            # was, 2.01 ms: what the side work costs the chain is not compute units.  profiles/r03_contention_probes.log)
             if hip.hipStreamCreateWithPriority(C.byref(h), 1, _side_prio[0]) != 0 or not h.value:   # 1 = hipStreamNonBlocking
                 raise OSError("hipStreamCreateWithPriority")
         return torch.cuda.ExternalStream(h.value, device=device)

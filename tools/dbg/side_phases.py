@@ -33,5 +33,12 @@ def run(drop, mq=3):
     mx = max(e[0].elapsed_time(e[2]) for e in evs[5:])
     print("drop_side=%s min_queue=%d prio=%s: main graph %.3f ms, tail %.3f ms, sum %.3f, worst step %.3f" % (drop, mq, os.environ.get("N3D_SIDE_PRIORITY", "low"), a, b, a + b, mx), flush=True)
     tr.check_sync()
-run(True)
-run(False)
+if os.environ.get("N3D_MAIN_NB"):
+    # everything on a non-blocking stream instead of the legacy default stream (a CU-masked side stream is a BLOCKING stream)
+    nb = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(nb):
+        run(True)
+        run(False)
+else:
+    run(True)
+    run(False)

@@ -17,6 +17,7 @@ from nas_3d_unet_amd.train import Trainer
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=64)
 ap.add_argument("--dtype", default="f32")
+ap.add_argument("--drop", action="store_true", help="capture the schedule WITHOUT the weight-gradient launches (hand-offs only): main stream free of contention")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.manual_seed(1234)
@@ -25,6 +26,9 @@ net.train()
 tr = Trainer(net, graph=True, side_wgrad="force", storage="bf16" if args.dtype == "bf16" else None)
 xn, tn = bench.synthetic_batch(2, args.size, 1234)
 x, t = bench.to_patch_layout(torch.from_numpy(xn).to(dev)), torch.from_numpy(tn).to(dev)
+if args.drop:
+    from nas_3d_unet_amd import kernels as K
+    K._DROP_SIDE = True
 for _ in range(10):
     tr.step(x, t)
 torch.cuda.synchronize()
@@ -42,10 +46,12 @@ t0 = int(st[2 * cuts[0] + 2])
 us = lambda v: (int(v) - t0) / 100.0      # 100 MHz clock
 print("searched-net train step, batch 2, 4x%d^3 %s, side-stream schedule (with the stamps' own launches): %.3f ms per step; %d hand-offs per step, "
       "%d of them cuts of the backward walk (weight-gradient groups), the rest forks / joins of the net's off-chain pieces" % (args.size, args.dtype, ms, used, len(cuts)))
-print("%4s %12s %14s %10s %12s" % ("flag", "main signal", "side past wait", "side lag", "group ran"))
+print("%4s %12s %14s %10s %12s %10s" % ("flag", "main signal", "side past wait", "side lag", "group ran", "main seg"))
+prev = 0.0
 for k, i in enumerate(cuts):
     m, w = us(st[2 * i + 2]), us(st[2 * i + 3])
     nxt = us(st[2 * cuts[k + 1] + 3]) if k + 1 < len(cuts) else us(st[2 * J + 4])
-    print("%4d %12.1f %14.1f %10.1f %12s" % (i, m, w, w - m, "<= %.1f" % (nxt - w)))
+    print("%4d %12.1f %14.1f %10.1f %12s %10.1f" % (i, m, w, w - m, "<= %.1f" % (nxt - w), m - prev))
+    prev = m
 print("side stream done at %.1f us; main stream past the join at %.1f us (main's last cut at %.1f us); slab reduction launched by %.1f us"
       % (us(st[2 * J + 4]), us(st[2 * J + 5]), us(st[2 * cuts[-1] + 2]), us(st[2 * J + 6])))
