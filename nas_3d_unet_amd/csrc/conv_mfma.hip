@@ -1349,7 +1349,66 @@ struct VwArgs {
   const void* zero_page;
 };
 
-template <int C, int DIL, typename T = float>
+// Epilogue of the vox weight-gradient kernels: every wave holds 7 * QC * QC accumulator tiles acc[t][qa][qb] of the 4x4x1 MFMA --
+// register r of lane (block b = lane >> 2, j = lane & 3) is the partial sum of dW[tap0 + t][ci = 4 qa + r][co = 4 qb + j] over the
+// voxels block b saw -- and the slab wants the sum over the 16 blocks.  The four registers of a tile are reduced TOGETHER: a
+// v_permlane32_swap of (r0, r1) puts the two wave halves of r0 side by side in the low half of the pair and those of r1 in the
+// high half, so ONE add folds lane ^ 32 for both; the same with (r2, r3), then a v_permlane16_swap of the two results folds lane ^ 16
+// for all four and leaves row 0 / 1 / 2 / 3 of the wave with r0 / r2 / r1 / r3; two DPP row rotations finish inside the rows.
+// 3 swaps + 5 adds + 1 store of 16 lanes per tile instead of 4 x (2 swaps + 2 DPP + 4 adds + a 4-lane store): the epilogue was
+// 3 (C = 4) / 7 us (C = 8) of these 12 us kernels (tools/dbg/wgrad_ns.py with -DVW_NO_EPI).
+template <int C, int QC>
+__device__ __forceinline__ void vw_store_tiles(const f32x4 (&acc)[7][QC][QC], float* __restrict__ out, const int tap0, const int lane) {
+  const int rsel = ((lane >> 4) & 1) * 2 + (lane >> 5);     // the accumulator register this lane's row ends up with
+  const bool writer = (lane & 15) < 4;
+  float* o = out + rsel * C + (lane & 3);
+#ifdef VW_NO_EPI
+  if (tap0 < 0)
+#endif
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    if (tap0 + t < 27) {
+#pragma unroll
+      for (int qa = 0; qa < QC; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < QC; ++qb) {
+          // (scalars first: __builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)
+          const float v0 = acc[t][qa][qb][0], v1 = acc[t][qa][qb][1], v2 = acc[t][qa][qb][2], v3 = acc[t][qa][qb][3];
+          const auto s01 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, v0), __builtin_bit_cast(int, v1), false, false);
+          const auto s23 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, v2), __builtin_bit_cast(int, v3), false, false);
+          const float ab = __builtin_bit_cast(float, (int)s01[0]) + __builtin_bit_cast(float, (int)s01[1]);
+          const float cd = __builtin_bit_cast(float, (int)s23[0]) + __builtin_bit_cast(float, (int)s23[1]);
+          const auto sx = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(int, ab), __builtin_bit_cast(int, cd), false, false);
+          float x = __builtin_bit_cast(float, (int)sx[0]) + __builtin_bit_cast(float, (int)sx[1]);
+          x += dpp_f<0x124>(x);   // row_ror:4
+          x += dpp_f<0x128>(x);   // row_ror:8
+          if (writer) o[(tap0 + t) * (C * C) + (qa * 4) * C + qb * 4] = x;
+        }
+    }
+  }
+}
+
+// wait until at most `n` of this wave's vector-memory operations are outstanding (they retire in order)
+__device__ __forceinline__ void wait_vmcnt(const int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// NS: 0 = the workgroup walks a.dchunk / 4 tiles through two buffers (tile k+1 is requested when tile k has landed); NS = 1 / 2 / 4 =
+// NS buffers, the tiles go in groups of NS that are requested together.  At 64^3 / 32^3 every workgroup of these launches is resident
+// at once (a few hundred of them), so the kernel lasts as long as ONE workgroup's chain of memory round trips, and a tile's MFMAs
+// (0.4 us) are far shorter than a round trip: with NS buffers the chain is a.dchunk / (4 NS) round trips instead of a.dchunk / 4.
+template <int C, int DIL, typename T = float, int NS = 0>
 __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
   constexpr bool B16 = sizeof(T) == 2;
   constexpr int QC = C / 4;                 // channel quads = accumulator tiles per side
@@ -1404,41 +1463,57 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  // stage tile `d0` into buffer `buf`: this wave's chunks are wave, wave+4, ...
-  auto stage = [&](int d0, float4* buf) {
-#pragma unroll 1
-    for (int m = 0; m < NCH / 4; ++m) {   // rolled: the address arithmetic of 4-12 chunks unrolled spills at C = 8
-      const int c = m * 4 + wave;                       // uniform
-      const int slot = c * 64 + lane;
-      const float4* srcp = zp;
-      if (c < NXC) {
-        // X tile: slot = q * NVOX + idx, idx = (dz * LH + hy) * LW + wx
-        const int q = slot / NVOX, idx = slot - q * NVOX;
-        const int wx = idx % LW, hy = (idx / LW) % LH, dz = idx / PLANE;
-        const int gd = d0 - DIL + dz, gh = h0 - DIL + hy, gw = w0 - DIL + wx;
-        const bool inb = slot < Q * NVOX && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-        if (inb) srcp = reinterpret_cast<const float4*>(xb + (((int64_t)gd * a.H + gh) * a.W + gw) * a.xld + q * 4);   // bf16: 16 bytes from the voxel
-      } else {
-        // dY tile: slot' = (row * 16 + voxel) * Q + q, row = g * GH + hh
-        const int sl = slot - NXC * 64;
-        const int q = sl % Q, vx = (sl / Q) % GW, row = sl / (Q * GW);
-        if (row < TD * GH) {
-          const int g = row / GH, hh = row - g * GH;
-          srcp = reinterpret_cast<const float4*>(dyb + (((int64_t)(d0 + g) * a.H + h0 + hh) * a.W + w0 + vx) * a.dyld + q * 4);
-        }
+  // stage tile `d0` into buffer `buf`: this wave's chunks are wave, wave+4, ...  Where a lane's slot of chunk m lies relative to
+  // plane d0 does not depend on the tile, so the slot -> voxel arithmetic (divisions by the tile extents) is done ONCE per workgroup:
+  // soff[m] = element offset from plane d0 of the chunk's tensor, sdz[m] = the slot's plane relative to d0 (a value that fails the
+  // plane test for slots outside the volume in H / W and for padding slots).  Per tile and chunk that leaves a compare, a select and
+  // a 64-bit add in front of the DMA -- the arithmetic was 3.9 of this kernel's 13.5 us at (2,4,64^3) and 26 of 83 us at (2,4,128^3)
+  // (tools/dbg/wgrad_ns.py, -DVW_NO_STAGE2).
+  constexpr int M = NCH / 4;
+  int soff[M], sdz[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int c = m * 4 + wave;                       // uniform
+    const int slot = c * 64 + lane;
+    soff[m] = 0; sdz[m] = -(1 << 20);
+    if (c < NXC) {
+      // X tile: slot = q * NVOX + idx, idx = (dz * LH + hy) * LW + wx
+      const int q = slot / NVOX, idx = slot - q * NVOX;
+      const int wx = idx % LW, hy = (idx / LW) % LH, dz = idx / PLANE;
+      const int gh = h0 - DIL + hy, gw = w0 - DIL + wx;
+      if (slot < Q * NVOX && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) {
+        soff[m] = (((dz - DIL) * a.H + gh) * a.W + gw) * (int)a.xld + q * 4;   // bf16: 16 bytes from the voxel
+        sdz[m] = dz - DIL;
       }
+    } else {
+      // dY tile: slot' = (row * 16 + voxel) * Q + q, row = g * GH + hh
+      const int sl = slot - NXC * 64;
+      const int q = sl % Q, vx = (sl / Q) % GW, row = sl / (Q * GW);
+      if (row < TD * GH) {
+        const int g = row / GH, hh = row - g * GH;
+        soff[m] = ((g * a.H + h0 + hh) * a.W + w0 + vx) * (int)a.dyld + q * 4;
+        sdz[m] = g;
+      }
+    }
+  }
+  const int64_t xplane = (int64_t)a.H * a.W * a.xld, yplane = (int64_t)a.H * a.W * a.dyld;
+  auto stage = [&](int d0, float4* buf) {
+#ifdef VW_NO_STAGE2
+    if (a.D > 0) return;
+#endif
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int c = m * 4 + wave;                       // uniform
+      const bool isx = c < NXC;
+      const T* base = (isx ? xb + (int64_t)d0 * xplane : dyb + (int64_t)d0 * yplane) + soff[m];
+      const float4* srcp = (unsigned)(d0 + sdz[m]) < (unsigned)a.D ? reinterpret_cast<const float4*>(base) : zp;
       __builtin_amdgcn_global_load_lds((gptr_t)srcp, (lptr_t)(buf + c * 64), 16, 0, N3D_WGRAD_AUX);
     }
   };
-  const int ntile = a.dchunk / TD;
-  stage(dbeg, wtile);
-  for (int k = 0; k < ntile; ++k) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile k landed for every wave; everyone is done with the buffer tile k+1 is about to overwrite
-    if (k + 1 < ntile) stage(dbeg + (k + 1) * TD, wtile + ((k + 1) & 1) * BUF);
-    const float* tf = reinterpret_cast<const float*>(wtile + (k & 1) * BUF);
+  auto compute = [&](const float4* buf) {
+    const float* tf = reinterpret_cast<const float*>(buf);
     const float* yf = tf + NXC * 64 * 4;
-    const bf16_t* th = reinterpret_cast<const bf16_t*>(wtile + (k & 1) * BUF);
+    const bf16_t* th = reinterpret_cast<const bf16_t*>(buf);
     const bf16_t* yh = th + NXC * 64 * 8;
     // ---- 16 rows of 16 voxels: row r = (g, hh) -> output plane d0+g, row h0+hh
 #pragma unroll
@@ -1455,38 +1530,61 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
 #pragma unroll
           for (int qa = 0; qa < QC; ++qa) avs[t][qa] = ld1(th + rbase + toff[t] + qa * 4);
       } else {
+#ifdef VW_NO_LDS
+#pragma unroll
+        for (int qb = 0; qb < QC; ++qb) bvs[qb] = (float)(r + qb + lane);
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+          for (int qa = 0; qa < QC; ++qa) avs[t][qa] = (float)(toff[t] + r + qa);
+#else
 #pragma unroll
         for (int qb = 0; qb < QC; ++qb) bvs[qb] = yf[((r * GW + blk) * Q + qb) * 4 + i4];
 #pragma unroll
         for (int t = 0; t < 7; ++t)
 #pragma unroll
           for (int qa = 0; qa < QC; ++qa) avs[t][qa] = tf[qa * NVOX * 4 + rbase + toff[t]];
+#endif
       }
 #pragma unroll
       for (int t = 0; t < 7; ++t)
 #pragma unroll
         for (int qa = 0; qa < QC; ++qa)
 #pragma unroll
+#ifdef VW_NO_MFMA
+          for (int qb = 0; qb < QC; ++qb) acc[t][qa][qb][0] += avs[t][qa] * bvs[qb];
+#else
           for (int qb = 0; qb < QC; ++qb) acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(avs[t][qa], bvs[qb], acc[t][qa][qb], 0, 0, 0);
+#endif
+    }
+  };
+  if constexpr (NS > 0) {
+    // NS tiles in flight at once; tile k is complete when all but the (NS - 1 - k) * NCH / 4 youngest requests of every wave are
+    const int ntile = a.dchunk / TD;           // a multiple of NS (host)
+    for (int t0 = 0; t0 < ntile; t0 += NS) {
+      if (t0) __syncthreads();                 // everyone is done with the buffers of the previous group
+#pragma unroll
+      for (int k = 0; k < NS; ++k) stage(dbeg + (t0 + k) * TD, wtile + k * BUF);
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        wait_vmcnt((NS - 1 - k) * (NCH / 4));
+        __syncthreads();
+        compute(wtile + k * BUF);
+      }
+    }
+  } else {
+    const int ntile = a.dchunk / TD;
+    stage(dbeg, wtile);
+    for (int k = 0; k < ntile; ++k) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // tile k landed for every wave; everyone is done with the buffer tile k+1 is about to overwrite
+      if (k + 1 < ntile) stage(dbeg + (k + 1) * TD, wtile + ((k + 1) & 1) * BUF);
+      compute(wtile + (k & 1) * BUF);
     }
   }
   // ---- add the 16 block tiles (lanes with equal lane&3) and write this workgroup's slab
   float* out = a.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 27) * (C * C);
-#pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    if (tap0 + t < 27) {
-#pragma unroll
-      for (int qa = 0; qa < QC; ++qa)
-#pragma unroll
-        for (int qb = 0; qb < QC; ++qb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float sum = wave_classsum_f(acc[t][qa][qb][r], 4);
-            // D[blk][row r = ci][col lane&3 = co]
-            if (lane < 4) out[(tap0 + t) * (C * C) + (qa * 4 + r) * C + qb * 4 + lane] = sum;
-          }
-    }
-  }
+  vw_store_tiles<C, QC>(acc, out, tap0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1548,13 +1646,18 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
       for (int qb = 0; qb < QC; ++qb) acc[t][qa][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  auto stage = [&](int d0, float4* buf) {
-    const int id0 = 2 * d0 - DIL, ih0 = 2 * h0 - DIL, iw0 = 2 * w0 - DIL;
-#pragma unroll 1
-    for (int m = 0; m < NCH / 4; ++m) {
+  // slot -> voxel arithmetic once per workgroup (see vox_wgrad_kernel): soff = element offset from plane 2 d0 of X / plane d0 of dY,
+  // sdz = the slot's plane relative to that (a value that fails the plane test for slots outside the volume in H / W and padding)
+  constexpr int M = NCH / 4;
+  constexpr bool PRE = M <= 16;       // (C = 8, dilation 2, fp32: 23 chunks per wave -- the two tables would spill; arithmetic per tile there)
+  int soff[PRE ? M : 1], sdz[PRE ? M : 1];
+  if constexpr (PRE) {
+    const int ih0 = 2 * h0 - DIL, iw0 = 2 * w0 - DIL;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
       const int c = m * 4 + wave;
       const int slot = c * 64 + lane;
-      const float4* srcp = zp;
+      soff[m] = 0; sdz[m] = -(1 << 20);
       if (c < NXC) {
         // X tile: slot = q * NVOX + (dz * LH + row) * RW + par * HW + half
         const int q = slot / NVOX, idx = slot - q * NVOX;
@@ -1562,18 +1665,60 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
         const int row = rem / RW, r2 = rem - row * RW;
         const int par = r2 / HW, half = r2 - par * HW;
         const int wx = 2 * half + par;
-        const int gd = id0 + dz, gh = ih0 + row, gw = iw0 + wx;
-        const bool inb = slot < Q * NVOX && wx < LW && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-        if (inb) srcp = reinterpret_cast<const float4*>(xb + (((int64_t)gd * a.H + gh) * a.W + gw) * a.xld + q * 4);
+        const int gh = ih0 + row, gw = iw0 + wx;
+        if (slot < Q * NVOX && wx < LW && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W) {
+          soff[m] = (((dz - DIL) * a.H + gh) * a.W + gw) * (int)a.xld + q * 4;
+          sdz[m] = dz - DIL;
+        }
       } else {
         const int sl = slot - NXC * 64;
         const int q = sl % Q, vx = (sl / Q) % GW, row = sl / (Q * GW);
         if (row < TD * GH) {
           const int g = row / GH, hh = row - g * GH;
-          srcp = reinterpret_cast<const float4*>(dyb + (((int64_t)(d0 + g) * a.oH + h0 + hh) * a.oW + w0 + vx) * a.dyld + q * 4);
+          soff[m] = ((g * a.oH + h0 + hh) * a.oW + w0 + vx) * (int)a.dyld + q * 4;
+          sdz[m] = g;
         }
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)srcp, (lptr_t)(buf + c * 64), 16, 0, N3D_WGRAD_AUX);
+    }
+  }
+  const int64_t xplane = (int64_t)a.H * a.W * a.xld, yplane = (int64_t)a.oH * a.oW * a.dyld;
+  auto stage = [&](int d0, float4* buf) {
+    if constexpr (PRE) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const int c = m * 4 + wave;
+        const bool isx = c < NXC;
+        const T* base = (isx ? xb + (int64_t)(2 * d0) * xplane : dyb + (int64_t)d0 * yplane) + soff[PRE ? m : 0];
+        const bool inb = isx ? (unsigned)(2 * d0 + sdz[PRE ? m : 0]) < (unsigned)a.D : sdz[PRE ? m : 0] >= 0;
+        const float4* srcp = inb ? reinterpret_cast<const float4*>(base) : zp;
+        __builtin_amdgcn_global_load_lds((gptr_t)srcp, (lptr_t)(buf + c * 64), 16, 0, N3D_WGRAD_AUX);
+      }
+    } else {
+      const int id0 = 2 * d0 - DIL, ih0 = 2 * h0 - DIL, iw0 = 2 * w0 - DIL;
+#pragma unroll 1
+      for (int m = 0; m < M; ++m) {
+        const int c = m * 4 + wave;
+        const int slot = c * 64 + lane;
+        const float4* srcp = zp;
+        if (c < NXC) {
+          const int q = slot / NVOX, idx = slot - q * NVOX;
+          const int dz = idx / PLANE, rem = idx - dz * PLANE;
+          const int row = rem / RW, r2 = rem - row * RW;
+          const int par = r2 / HW, half = r2 - par * HW;
+          const int wx = 2 * half + par;
+          const int gd = id0 + dz, gh = ih0 + row, gw = iw0 + wx;
+          const bool inb = slot < Q * NVOX && wx < LW && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+          if (inb) srcp = reinterpret_cast<const float4*>(xb + (((int64_t)gd * a.H + gh) * a.W + gw) * a.xld + q * 4);
+        } else {
+          const int sl = slot - NXC * 64;
+          const int q = sl % Q, vx = (sl / Q) % GW, row = sl / (Q * GW);
+          if (row < TD * GH) {
+            const int g = row / GH, hh = row - g * GH;
+            srcp = reinterpret_cast<const float4*>(dyb + (((int64_t)(d0 + g) * a.oH + h0 + hh) * a.oW + w0 + vx) * a.dyld + q * 4);
+          }
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)srcp, (lptr_t)(buf + c * 64), 16, 0, N3D_WGRAD_AUX);
+      }
     }
   };
   const int ntile = a.dchunk / TD;
@@ -1615,20 +1760,7 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
     }
   }
   float* out = a.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 27) * (C * C);
-#pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    if (tap0 + t < 27) {
-#pragma unroll
-      for (int qa = 0; qa < QC; ++qa)
-#pragma unroll
-        for (int qb = 0; qb < QC; ++qb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float sum = wave_classsum_f(acc[t][qa][qb][r], 4);
-            if (lane < 4) out[(tap0 + t) * (C * C) + (qa * 4 + r) * C + qb * 4 + lane] = sum;
-          }
-    }
-  }
+  vw_store_tiles<C, QC>(acc, out, tap0, lane);
 }
 
 // returns 1 if handled (slab layout as vox_wgrad_try: ci_t = co_t = C, tci = tco = 1, ntiles = 27)
@@ -1685,14 +1817,27 @@ int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   return 1;
 }
 
-struct VwPlan { bool ok; int C, dil, dchunk, tiles; size_t lds; };
+struct VwPlan { bool ok; int C, dil, dchunk, tiles, ns; size_t lds; };
 
 // dynamic LDS of vox_wgrad_kernel with `slots` 16-byte LDS slots per voxel (fp32: C / 4; bf16 storage: 1)
-static size_t vw_plan_lds(int slots, int dil) {
+static size_t vw_stage_lds(int slots, int dil) {
   const size_t Qn = slots, nvox = (size_t)(4 + 2 * dil) * (4 + 2 * dil) * (16 + 2 * dil);
   const size_t nxc = (Qn * nvox + 63) / 64, nyc = (4 * 4 * 16 * Qn + 63) / 64, nch = (nxc + nyc + 3) / 4 * 4;
-  return 2 * nch * 64 * 16;   // two staged tiles (X halo tile + dY tile each)
+  return nch * 64 * 16;       // one staged tile (X halo tile + dY tile)
 }
+// tiles requested together (NS of vox_wgrad_kernel) for a workgroup of `ntile` tiles: as many as 64 KiB of LDS hold (two workgroups
+// per compute unit), 0 = the two-buffer walk
+static int vw_stages(int ntile, size_t stage_bytes) {
+  static const int forced = [] { const char* e = getenv("N3D_VW_NS"); return e ? atoi(e) : -1; }();
+  if (forced == 0) return 0;
+  // (a workgroup with ONE tile runs the two-buffer form: measured 8.8 vs 10.6 us at (2,8,32^3) for the same work)
+  for (int ns : {4, 2}) {
+    if (forced > 0 && ns != forced) continue;
+    if (ntile % ns == 0 && (size_t)ns * stage_bytes <= 64 * 1024) return ns;
+  }
+  return (forced == 1 && (size_t)stage_bytes <= 64 * 1024) ? 1 : 0;
+}
+static size_t vw_plan_lds(int slots, int dil, int ns) { return (size_t)(ns ? ns : 2) * vw_stage_lds(slots, dil); }
 
 static VwPlan vw_plan(const n3d_conv_geom* g) {
   VwPlan p; p.ok = false;
@@ -1702,10 +1847,11 @@ static VwPlan vw_plan(const n3d_conv_geom* g) {
   if (W % 16 != 0 || H % 4 != 0 || D % 4 != 0) return p;
   const int columns = g->B * (H / 4) * (W / 16);
   int nd = D / 4, dsplit = 1;
-  while (columns * dsplit < 384 && dsplit * 2 <= nd && nd % (dsplit * 2) == 0) dsplit *= 2;
+  static const int want_wgs = [] { const char* e = getenv("N3D_VW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 384; }();
+  while (columns * dsplit < want_wgs && dsplit * 2 <= nd && nd % (dsplit * 2) == 0) dsplit *= 2;
   p.ok = true; p.C = g->Ci; p.dil = g->dil; p.dchunk = D / dsplit;
   p.tiles = (W / 16) * (H / 4) * dsplit;
-  p.lds = vw_plan_lds(g->Ci / 4, g->dil);
+  p.ns = 0; p.lds = 0;        // settled by the caller (the LDS image depends on the storage type)
   return p;
 }
 
@@ -1725,23 +1871,21 @@ int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const flo
   a.zero_page = zero_page_ptr();
   if (!a.zero_page) return 0;
   dim3 grid(p.tiles, g->B);
-  if (b16) {
-    // bf16 storage: the LDS image is the fp32 C = 4 one (one slot per voxel) for both channel counts
-    const size_t lds16 = vw_plan_lds(1, p.dil);
-    if (p.C == 4) {
-      if (p.dil == 1) hipLaunchKernelGGL((vox_wgrad_kernel<4, 1, bf16_t>), grid, dim3(256), lds16, s, a);
-      else hipLaunchKernelGGL((vox_wgrad_kernel<4, 2, bf16_t>), grid, dim3(256), lds16, s, a);
-    } else {
-      if (p.dil == 1) hipLaunchKernelGGL((vox_wgrad_kernel<8, 1, bf16_t>), grid, dim3(256), lds16, s, a);
-      else hipLaunchKernelGGL((vox_wgrad_kernel<8, 2, bf16_t>), grid, dim3(256), lds16, s, a);
-    }
-  } else if (p.C == 4) {
-    if (p.dil == 1) hipLaunchKernelGGL((vox_wgrad_kernel<4, 1>), grid, dim3(256), p.lds, s, a);
-    else hipLaunchKernelGGL((vox_wgrad_kernel<4, 2>), grid, dim3(256), p.lds, s, a);
-  } else {
-    if (p.dil == 1) hipLaunchKernelGGL((vox_wgrad_kernel<8, 1>), grid, dim3(256), p.lds, s, a);
-    else hipLaunchKernelGGL((vox_wgrad_kernel<8, 2>), grid, dim3(256), p.lds, s, a);
-  }
+  // bf16 storage: the LDS image is the fp32 C = 4 one (one slot per voxel) for both channel counts
+  const int slots = b16 ? 1 : p.C / 4;
+  const int ns = vw_stages(p.dchunk / 4, vw_stage_lds(slots, p.dil));
+  const size_t lds = vw_plan_lds(slots, p.dil, ns);
+#define N3D_VW_T(C_, D_, T_) do { \
+    if (ns == 4) hipLaunchKernelGGL((vox_wgrad_kernel<C_, D_, T_, 4>), grid, dim3(256), lds, s, a); \
+    else if (ns == 2) hipLaunchKernelGGL((vox_wgrad_kernel<C_, D_, T_, 2>), grid, dim3(256), lds, s, a); \
+    else if (ns == 1) hipLaunchKernelGGL((vox_wgrad_kernel<C_, D_, T_, 1>), grid, dim3(256), lds, s, a); \
+    else hipLaunchKernelGGL((vox_wgrad_kernel<C_, D_, T_, 0>), grid, dim3(256), lds, s, a); } while (0)
+#define N3D_VW(T_) do { \
+    if (p.C == 4) { if (p.dil == 1) N3D_VW_T(4, 1, T_); else N3D_VW_T(4, 2, T_); } \
+    else { if (p.dil == 1) N3D_VW_T(8, 1, T_); else N3D_VW_T(8, 2, T_); } } while (0)
+  if (b16) N3D_VW(bf16_t); else N3D_VW(float);
+#undef N3D_VW
+#undef N3D_VW_T
   *nchunks_out = nwg;
   return 1;
 }
