@@ -54,7 +54,8 @@ __global__ void pack16_kernel(const float* __restrict__ w, float* __restrict__ w
 
 template <int MT, int NT, int KSPLIT>
 __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const int by, float* lds) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index as a SCALAR: the K-slice a wave owns (tap, channel block, their offsets) is then computed on the scalar unit
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 15, kk = lane >> 4;
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
   const int64_t Mtot = (int64_t)a.B * Nd;
