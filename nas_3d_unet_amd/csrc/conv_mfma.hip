@@ -13,6 +13,7 @@
 //   src coordinate = (dst*sn + off + tap*dt) / den   (valid iff divisible and in range).
 #include <stdlib.h>
 #include "n3d_common.h"
+#include <type_traits>
 // cache policy of the weight-gradient kernels' LDS-DMA loads (cpol bits: 1 = sc0, 2 = nt, 16 = sc1).  These kernels run on the side
 // stream next to the backward chain and stream 8-25 MB tensors through the L2s that hold the chain's working set.
 #ifndef N3D_WGRAD_AUX
@@ -52,11 +53,24 @@ __global__ void pack16_kernel(const float* __restrict__ w, float* __restrict__ w
   wp[i] = w[((int64_t)co * Ci + ci) * taps + tap];
 }
 
+#ifdef G16_STAMP
+// debug build only (tools/dbg/g16_stamps.py): phase stamps of wave 0 / wave 15 of every gemm16 workgroup
+__device__ unsigned long long g16_stamp_buf[4096 * 16];
+#define GSTAMP(k) do { if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == 15)) { const int wgl_ = blockIdx.x + gridDim.x * blockIdx.y; \
+    if (wgl_ < 4096) g16_stamp_buf[wgl_ * 16 + (wave ? 8 : 0) + (k)] = clock64(); } } while (0)
+extern "C" int n3d_debug_g16_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g16_stamp_buf), (size_t)n * 8);
+}
+#else
+#define GSTAMP(k)
+#endif
+
 template <int MT, int NT, int KSPLIT>
 __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const int by, float* lds) {
   // the wave index as a SCALAR: the K-slice a wave owns (tap, channel block, their offsets) is then computed on the scalar unit
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 15, kk = lane >> 4;
+  GSTAMP(0);
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
   const int64_t Mtot = (int64_t)a.B * Nd;
   constexpr int ROWS_PER_WAVE = 16 * MT;
@@ -126,44 +140,96 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
 
   // K loop, software-pipelined by hand: the operands of group g+step are requested before the MFMAs of group g
   // issue, so each wave keeps one group of global loads in flight behind its matrix work.
-  // per-lane 32-bit voxel index math (tensors on this path are < 2^31 voxels); one 64-bit multiply-add per load
+  //
+  // Operand addressing (round 3).  Sixteen waves share four SIMDs here, so what a wave spends before its loads are out is VALU
+  // issue slots: the per-group, per-lane address arithmetic (tap offsets, 64-bit pointer, range tests, zero select) was ~40 VALU
+  // instructions and the load phase 5 of this kernel's 8 us (tools/dbg/g16_stamps.py).  The voxel index is linear in (lane part) +
+  // (tap part) -- also for the stride-2 data gradient, where the source voxel is (row + tap) / 2 and exists only when row and tap
+  // agree in parity: then (row + tap) / 2 = (row >> 1) + ((tap + (tap & 1)) >> 1) -- so the lane part is a byte offset computed ONCE
+  // (voffA), the tap part moves the base of a BUFFER resource on the scalar unit, and a lane whose tap falls outside the volume
+  // (or whose row does not exist) presents an offset beyond the resource's range: the buffer load returns zeros for it, no select.
+  // Per group and lane that leaves three adds, three compares and one select.
+  const bool den2 = a.den == 2;
   const float relu_floor = relu_in ? 0.f : -INFINITY;
-  int rbase[MT];
+  int pd[MT], ph[MT], pw[MT], lpar[MT];
+  uint32_t voffA[MT];
+  constexpr uint32_t OOB = 0x80000000u;           // >= num_records of the resources below, with or without the scalar offset
+  constexpr int RSRC_FLAGS = 0x00020000;          // gfx9 raw buffer: 32-bit data format, no swizzle
 #pragma unroll
-  for (int t = 0; t < MT; ++t) rbase[t] = rb[t] * a.Ds;
-  auto load_group = [&](int g, float4 (&av)[MT], float4 (&bv)[NT]) {
+  for (int t = 0; t < MT; ++t) {
+    pd[t] = den2 ? rd[t] >> 1 : rd[t] * a.sn;
+    ph[t] = den2 ? rh[t] >> 1 : rh[t] * a.sn;
+    pw[t] = den2 ? rw[t] >> 1 : rw[t] * a.sn;
+    lpar[t] = den2 ? ((rd[t] & 1) | ((rh[t] & 1) << 1) | ((rw[t] & 1) << 2)) : 0;
+    const int vox = ((rb[t] * a.Ds + pd[t]) * a.Hs + ph[t]) * a.Ws + pw[t];
+    voffA[t] = rvalid[t] ? (uint32_t)((vox * (int)a.sld + kk * 4) * 4) : OOB;
+  }
+  const uint32_t voffB = (uint32_t)((kk * a.Cd + n0 + m) * 16);
+  // The tap part, ONE table per workgroup: thread g works out group g (tap = g / (Cs/16), its three offsets, the stride-2 halves and
+  // parities, the element offset of the tap in the source, the byte offset of the group in the packed weights) -- ~100 instructions
+  // once instead of on the scalar unit of every wave for every group, where 16 waves x 8 groups x ~100 scalar instructions on the
+  // compute unit's ONE scalar ALU were the longest part of the kernel.  Entry: { source byte offset + BIAS, weight byte offset,
+  // sd | sh << 8 | sw << 16 | parity << 24 }.  The source resource starts BIAS bytes in front of the tensor so that the scalar offset
+  // of a tap that reaches backwards stays non-negative; only lanes whose voxel exists add it.
+  __shared__ int gtab[256 * 4];
+  const int bias_el = ((4 * a.Hs + 4) * a.Ws + 4) * (int)a.sld;      // |tap offset| <= 4 voxels per axis (pad, dilation <= 2)
+  for (int g = threadIdx.x; g < ngroups; g += blockDim.x) {
     const int tap = (int)a.fC16.div((uint32_t)g), c16 = g - tap * c16n;
     // k is 1 or 3: constant divisors
     const int kd = (k == 3) ? tap / 9 : 0, kh = (k == 3) ? (tap % 9) / 3 : 0, kw = (k == 3) ? tap % 3 : 0;
     const int od = a.off + kd * a.dt, oh = a.off + kh * a.dt, ow = a.off + kw * a.dt;
+    // tap part of the voxel coordinate: the offset itself, or its upper half for the stride-2 data gradient
+    const int sd = den2 ? (od + (od & 1)) >> 1 : od, sh = den2 ? (oh + (oh & 1)) >> 1 : oh, sw = den2 ? (ow + (ow & 1)) >> 1 : ow;
+    const int spar = den2 ? ((od & 1) | ((oh & 1) << 1) | ((ow & 1) << 2)) : 0;
+    const int soff = ((sd * a.Hs + sh) * a.Ws + sw) * (int)a.sld + c16 * 16;
+    int4 e;
+    e.x = (soff + bias_el) * 4;
+    e.y = g * 4 * a.Cd * 16;
+    e.z = (sd & 0xff) | ((sh & 0xff) << 8) | ((sw & 0xff) << 16) | (spar << 24);
+    e.w = 0;
+    *reinterpret_cast<int4*>(&gtab[g * 4]) = e;
+  }
+  __syncthreads();
+#ifndef VOX_NO_LOAD
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src) - bias_el, 0, 0x7fffffff, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, 0x7fffffff, RSRC_FLAGS);
+#endif
+  typedef int v4i_t __attribute__((ext_vector_type(4)));
+  // GATE (a std::bool_constant): the per-(sample, channel) input gate of the SE primitives; the run-time test is made once, around
+  // the load phase (a branch per group would make every group its own basic block)
+  auto load_group = [&](auto gate_c, int g, float4 (&av)[MT], float4 (&bv)[NT]) {
+    constexpr bool GATE = decltype(gate_c)::value;
+    const int4 e = *reinterpret_cast<const int4*>(&gtab[g * 4]);      // one address for the whole wave
+    const int soffA = __builtin_amdgcn_readfirstlane(e.x), soffB = __builtin_amdgcn_readfirstlane(e.y);
+    const int pk = e.z;
+    const int sd = (int)(signed char)(pk & 0xff), sh = (int)(signed char)((pk >> 8) & 0xff), sw = (int)(signed char)((pk >> 16) & 0xff);
+    const int spar = pk >> 24;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      int nd = rd[t] * a.sn + od, nh = rh[t] * a.sn + oh, nw = rw[t] * a.sn + ow;
-      bool ok = rvalid[t];
-      if (a.den == 2) { ok = ok && !((nd | nh | nw) & 1); nd >>= 1; nh >>= 1; nw >>= 1; }
-      // unsigned compares fold the two-sided range tests
-      ok = ok && (unsigned)nd < (unsigned)a.Ds && (unsigned)nh < (unsigned)a.Hs && (unsigned)nw < (unsigned)a.Ws;
-      const int idx = ok ? ((rbase[t] + nd) * a.Hs + nh) * a.Ws + nw : 0;   // voxel 0 is always a legal address
-      const float* sp = a.src + (int64_t)idx * a.sld + kk * 4 + c16 * 16;
+      const int nd = pd[t] + sd, nh = ph[t] + sh, nw = pw[t] + sw;
+      // unsigned compares fold the two-sided range tests (bitwise &: a short-circuit && becomes control flow)
+      const bool ok = ((unsigned)nd < (unsigned)a.Ds) & ((unsigned)nh < (unsigned)a.Hs) & ((unsigned)nw < (unsigned)a.Ws) & (lpar[t] == spar);
 #ifdef VOX_NO_LOAD
-      float4 v = make_float4((float)idx, 1.f, 2.f, 3.f);
-      (void)sp;
+      float4 v = make_float4((float)nd, 1.f, 2.f, ok ? 3.f : 0.f);
 #else
-      float4 v = *reinterpret_cast<const float4*>(sp);
+      const v4i_t raw = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(ok ? voffA[t] : OOB), soffA, 0);
+      float4 v = __builtin_bit_cast(float4, raw);
 #endif
+      // (unconditional: a branch per group on the ReLU flag keeps the compiler from batching the loads of the eight groups)
       v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
-      if (a.in_gate) {
+      if constexpr (GATE) {
+        const int c16 = g % c16n;
         const float4 gq = *reinterpret_cast<const float4*>(a.in_gate + (int64_t)rb[t] * a.Cs + c16 * 16 + kk * 4);
         v.x *= gq.x; v.y *= gq.y; v.z *= gq.z; v.w *= gq.w;
       }
-      av[t] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      av[t] = v;
     }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
 #ifdef VOX_NO_LOAD
       bv[n] = make_float4((float)g, 1.f, (float)m, 3.f);
 #else
-      bv[n] = wp4[((int64_t)g * 4 + kk) * a.Cd + n0 + n * 16 + m];
+      bv[n] = __builtin_bit_cast(float4, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(rwt, (int)(voffB + n * 256), soffB, 0));
 #endif
     }
   };
@@ -188,35 +254,53 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
         acc2[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].w, bv[n].w, acc2[t][n], 0, 0, 0);
       }
   };
+  GSTAMP(1);
   if (KSPLIT == 16 && ngroups <= 16 * 8) {
     // tiny GEMM: every operand this wave will ever need is requested up front (<= 8 groups, 16 float4 per lane),
     // so the whole K loop costs one memory round trip
     float4 avs[8][MT], bvs[8][NT];
+    if (a.in_gate) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int g = wave + i * 16;
-      load_group(g < ngroups ? g : ngroups - 1, avs[i], bvs[i]);
+      for (int i = 0; i < 8; ++i) {
+        const int g = wave + i * 16;
+        load_group(std::true_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int g = wave + i * 16;
+        load_group(std::false_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i]);
+      }
     }
+    GSTAMP(2);
+#ifdef G16_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GSTAMP(3);
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       if (wave + i * 16 < ngroups) mfma_group(avs[i], bvs[i]);
   } else {
     const int g0 = (KSPLIT > 1 ? wave : 0), step = (KSPLIT > 1 ? KSPLIT : 1);
     float4 avA[MT], bvA[NT], avB[MT], bvB[NT];
-    if (g0 < ngroups) load_group(g0, avA, bvA);
-    for (int g = g0; g < ngroups; g += 2 * step) {
-      const bool hasB = g + step < ngroups;
-      if (hasB) load_group(g + step, avB, bvB);
-      mfma_group(avA, bvA);
-      if (g + 2 * step < ngroups) load_group(g + 2 * step, avA, bvA);
-      if (hasB) mfma_group(avB, bvB);
-    }
+    auto walk = [&](auto gate_c) {
+      if (g0 < ngroups) load_group(gate_c, g0, avA, bvA);
+      for (int g = g0; g < ngroups; g += 2 * step) {
+        const bool hasB = g + step < ngroups;
+        if (hasB) load_group(gate_c, g + step, avB, bvB);
+        mfma_group(avA, bvA);
+        if (g + 2 * step < ngroups) load_group(gate_c, g + 2 * step, avA, bvA);
+        if (hasB) mfma_group(avB, bvB);
+      }
+    };
+    if (a.in_gate) walk(std::true_type{}); else walk(std::false_type{});
   }
 #pragma unroll
   for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[t][n] += acc2[t][n];
 
+  GSTAMP(4);
   if (KSPLIT > 1) {
     // reduce the K-slices through LDS into wave 0
     f32x4* l4 = reinterpret_cast<f32x4*>(lds);
@@ -237,6 +321,7 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
     }
   }
 
+  GSTAMP(5);
   // ---- epilogue: D layout -> lane holds column n = lane&15, rows 4*(lane>>4) + r
   float csum[NT], csq[NT];
 #pragma unroll
@@ -260,6 +345,7 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
       }
     }
   }
+  GSTAMP(6);
   if (a.stats && KSPLIT > 1) {
     // only wave 0 holds data: its lanes kk == 0 write the block's partial row directly (no LDS, no barrier)
     if (wave == 0) {
@@ -306,6 +392,10 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
       a.stats[(((int64_t)b * a.rows_per_sample + row) * a.Cd + n0 + n * 16 + col) * 2 + q2] = s;
     }
   }
+#ifdef G16_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GSTAMP(7);
+#endif
 }
 
 template <int MT, int NT, int KSPLIT>
@@ -2193,6 +2283,12 @@ static G16Plan g16_plan(const n3d_conv_geom* g, bool data_grad) {
   if (g->depthwise) return p;
   const int Cs = data_grad ? g->Co : g->Ci, Cd = data_grad ? g->Ci : g->Co;
   if (Cs % 16 != 0 || Cd % 16 != 0) return p;
+  // the kernel's per-workgroup tap table holds 256 K-groups (taps x Cs / 16), its packed tap offsets 8 bits, its byte offsets 31
+  if ((int64_t)g->k * g->k * g->k * (Cs / 16) > 256 || g->pad > 4 || g->dil > 2) return p;
+  {
+    const int64_t Ns = data_grad ? (int64_t)g->Do * g->Ho * g->Wo : (int64_t)g->Di * g->Hi * g->Wi;
+    if ((int64_t)g->B * Ns * Cs * 4 >= (1ll << 30) || (int64_t)g->k * g->k * g->k * Cs * Cd * 4 >= (1ll << 30)) return p;
+  }
   const int64_t Nd = data_grad ? (int64_t)g->Di * g->Hi * g->Wi : (int64_t)g->Do * g->Ho * g->Wo;
   const int64_t M = (int64_t)g->B * Nd;
   const int64_t tiles = cdiv(M, 16) * (Cd / 16);
@@ -2378,6 +2474,11 @@ int g16_prepare(const n3d_conv_geom* g, bool data_grad, const float* src, int64_
     a.sn = 1; a.off = g->pad; a.dt = -g->dil; a.den = g->stride; }
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
   if ((int64_t)g->B * Nd >= (1ll << 31)) return 0;  // 32-bit voxel indexing
+  {
+    // 31-bit byte offsets into the source (its voxel pitch may be that of a wider buffer)
+    const int64_t Ns = data_grad ? (int64_t)g->Do * g->Ho * g->Wo : (int64_t)g->Di * g->Hi * g->Wi;
+    if (((int64_t)g->B * Ns + 8 * ((int64_t)(data_grad ? g->Ho : g->Hi) + 1) * ((data_grad ? g->Wo : g->Wi) + 1)) * sld * 4 >= (1ll << 30)) return 0;
+  }
   a.fNd = FastDiv((uint32_t)Nd); a.fWd = FastDiv((uint32_t)a.Wd); a.fHd = FastDiv((uint32_t)a.Hd); a.fC16 = FastDiv((uint32_t)(a.Cs / 16));
   if (stats) {
     if (Nd * 2 == p.rows_per_block && p.ksplit > 1) a.rows_per_sample = 1;
