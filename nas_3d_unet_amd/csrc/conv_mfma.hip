@@ -255,20 +255,21 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
       }
   };
   GSTAMP(1);
-  if (KSPLIT == 16 && ngroups <= 16 * 8) {
+  if ((KSPLIT == 16 || (KSPLIT == 4 && MT == 1 && NT == 1)) && ngroups <= KSPLIT * 8) {
     // tiny GEMM: every operand this wave will ever need is requested up front (<= 8 groups, 16 float4 per lane),
-    // so the whole K loop costs one memory round trip
+    // so the whole K loop costs one memory round trip.  (KSPLIT == 4: the 16-channel convs of the 16^3 level, 27 groups over four
+    // waves -- the two-buffer walk below took seven round trips there)
     float4 avs[8][MT], bvs[8][NT];
     if (a.in_gate) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int g = wave + i * 16;
+        const int g = wave + i * KSPLIT;
         load_group(std::true_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i]);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int g = wave + i * 16;
+        const int g = wave + i * KSPLIT;
         load_group(std::false_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i]);
       }
     }
@@ -279,7 +280,7 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
 #endif
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (wave + i * 16 < ngroups) mfma_group(avs[i], bvs[i]);
+      if (wave + i * KSPLIT < ngroups) mfma_group(avs[i], bvs[i]);
   } else {
     const int g0 = (KSPLIT > 1 ? wave : 0), step = (KSPLIT > 1 ? KSPLIT : 1);
     float4 avA[MT], bvA[NT], avB[MT], bvB[NT];
