@@ -617,6 +617,118 @@ __global__ __launch_bounds__(256) void affine_act_gn_kernel(const T* __restrict_
 // All global loads of the prologue (parameter vectors and every partial row this workgroup needs) are issued
 // before the first use, so the prologue costs ONE memory round trip; everything after it is LDS work.
 #define GNF_MAXB 4
+struct GnBwdTerm {
+  const float* raw; int64_t rld; const float* a; const float* b; const double* sums; int rows; const float* gamma; const float* mean_rstd;
+  const float* wptr; const double* sumraw; float* draw; int64_t drld; float* dgamma; float* dbeta; float* dalpha; float* dbias_conv; int relu;
+  const float* cA; const float* cB; const float* cC;   // PRE variant: coefficients from n3d_gn_bwd_coeffs2
+};
+
+// GroupNorm-backward coefficients of BOTH terms of a pair, wave level (see affine_bwd_apply_gn_kernel); strip[k][0..2][c] = A, B, C.
+// Everything a wave needs from memory -- the partial rows of the two terms (same row count: they come out of one reduce2 launch),
+// statistics, parameters -- is requested before any of the arithmetic.  That matters most for the LEADER wave (workgroup (0,0),
+// wave 0), which also forms the parameter gradients and therefore needs the rows of ALL samples: these tensors were written by the
+// previous launch on other XCDs, a round trip is ~2 us, the leader used to make one per sample, and the launch is over when its
+// slowest workgroup is.  NB = samples this wave handles (1, or GNF_MAXB for the leader with the unused ones predicated off), DEPTH =
+// rows per lane requested together.
+template <int NT, int NB, int DEPTH>
+__device__ __forceinline__ void gn_bwd_prologue_impl(const GnBwdTerm& t0, const GnBwdTerm& t1, const int B, const int C, const int G,
+                                                     const double count, float (*strip)[3][64]) {
+  constexpr bool LEAD = NB > 1;
+  const int lane = threadIdx.x & 63;
+  const int cg = C / G;
+  const int c = lane & (C - 1), rs = lane / C, nslots = 64 / C;
+  const int gq = c / cg;
+  const GnBwdTerm* ts[2] = {&t0, &t1};
+  const int nbw = LEAD ? B : 1;
+  const int rows = t0.rows;           // == t1.rows (NT == 1: t1 is t0)
+  double w[NT], gam[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) { w[k] = ts[k]->wptr ? (double)*ts[k]->wptr : 1.0; gam[k] = (double)ts[k]->gamma[c]; }
+  int bs[NB];
+  double mn[NB][NT], rsd[NB][NT], pf[NB][NT], acc[NB][NT][3];
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    bs[kb] = LEAD ? ((int)blockIdx.y + 1 + (kb < nbw ? kb : 0)) % B : (int)blockIdx.y;   // own sample last (kb == nbw - 1)
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      mn[kb][k] = ts[k]->mean_rstd[(bs[kb] * G + gq) * 2]; rsd[kb][k] = ts[k]->mean_rstd[(bs[kb] * G + gq) * 2 + 1];
+      pf[kb][k] = (LEAD && ts[k]->dbias_conv) ? ts[k]->sumraw[bs[kb] * C + c] : 0.0;
+      acc[kb][k][0] = acc[kb][k][1] = acc[kb][k][2] = 0.0;
+    }
+  }
+  for (int r = rs; r < rows; r += DEPTH * nslots) {
+    double v[NB][NT][DEPTH][3];
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+          const int rr = r + u * nslots;
+          const double* p = ts[k]->sums + (((int64_t)bs[kb] * rows + (rr < rows ? rr : rs)) * C + c) * 3;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) v[kb][k][u][q] = p[q];
+        }
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u)
+          if (r + u * nslots < rows) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[kb][k][q] += v[kb][k][u][q];
+          }
+  }
+  double dg[NT], db[NT], dz[NT], dbc[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) dg[k] = db[k] = dz[k] = dbc[k] = 0.0;
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    if (kb < nbw) {
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        const GnBwdTerm& t = *ts[k];
+        double S1 = acc[kb][k][0], S2 = acc[kb][k][1], Sz = acc[kb][k][2];
+        S1 = wave_classsum_d(S1, C); S2 = wave_classsum_d(S2, C);
+        if (t.dalpha) Sz = wave_classsum_d(Sz, C);
+        const double n = count * cg;
+        const double c1 = wave_groupsum_d(gam[k] * w[k] * S1, cg) / n;
+        const double c2 = wave_groupsum_d(gam[k] * w[k] * rsd[kb][k] * (S2 - mn[kb][k] * S1), cg) / n;
+        const double A1 = rsd[kb][k] * gam[k] * w[k], B1 = -rsd[kb][k] * c1 + rsd[kb][k] * rsd[kb][k] * c2 * mn[kb][k],
+                     C1 = -rsd[kb][k] * rsd[kb][k] * c2;
+        if (kb == nbw - 1 && lane < C) { strip[k][0][lane] = (float)A1; strip[k][1][lane] = (float)B1; strip[k][2][lane] = (float)C1; }
+        if (LEAD) {
+          dg[k] += w[k] * rsd[kb][k] * (S2 - mn[kb][k] * S1);
+          db[k] += w[k] * S1;
+          dz[k] += Sz;
+          if (t.dbias_conv) dbc[k] += A1 * S1 + count * B1 + C1 * pf[kb][k];
+        }
+      }
+    }
+  }
+  if (LEAD) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      const GnBwdTerm& t = *ts[k];
+      if (lane < C) {
+        if (t.dgamma) t.dgamma[c] = (float)dg[k];
+        if (t.dbeta) t.dbeta[c] = (float)db[k];
+        if (t.dbias_conv) t.dbias_conv[c] = (float)dbc[k];
+      }
+      if (t.dalpha) {
+        const double sdz = wave_sum_d(lane < C ? dz[k] : 0.0);
+        if (lane == 0) *t.dalpha = (float)sdz;
+      }
+    }
+  }
+}
+__device__ __forceinline__ void gn_bwd_prologue_wave2(const GnBwdTerm& t0, const GnBwdTerm& t1, const int B, const int C, const int G,
+                                                      const double count, const bool lead_w, float (*strip)[3][64]) {
+  if (lead_w) gn_bwd_prologue_impl<2, GNF_MAXB, 2>(t0, t1, B, C, G, count, strip);
+  else gn_bwd_prologue_impl<2, 1, 4>(t0, t1, B, C, G, count, strip);
+}
+
 template <bool RELU, bool ACC, typename T = float>
 __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ raw,
                                                                   int64_t rld, const float* __restrict__ a, const float* __restrict__ bb,
@@ -659,58 +771,13 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const T* __res
     // wave-level prologue (no workgroup barrier): lane = row slot x channel; partial rows -> class sums over the
     // row slots -> DPP group sums -> GroupNorm-backward coefficients, redundantly in every wave.  Wave 0 of the
     // leader workgroup walks all B samples to emit dgamma / dbeta / dalpha / conv-bias gradient.
-    const int lane = t & 63, wave = t >> 6;
-    const int c = lane & (C - 1), rs = lane / C, nslots = 64 / C;
-    const int gq = c / cg;
-    const double w = wptr ? (double)*wptr : 1.0;
-    const double gam = (double)gamma[c];
+    const int wave = t >> 6;
     const bool lead_w = leader && wave == 0;
-    const int nbw = lead_w ? B : 1;
-    double dg = 0, db = 0, dz = 0, dbc = 0;
-    for (int k = 0; k < nbw; ++k) {
-      const int b = lead_w ? ((int)blockIdx.y + 1 + k) % B : (int)blockIdx.y;  // own sample last
-      const double mn = mean_rstd[(b * G + gq) * 2], rsd = mean_rstd[(b * G + gq) * 2 + 1];
-      const double pf = (lead_w && dbias_conv) ? sumraw[b * C + c] : 0.0;
-      const double* sb = sums + (int64_t)b * rows * C * 3 + c * 3;
-      double S1 = 0, S2 = 0, Sz = 0;
-      {
-        int r = rs;
-        for (; r + 3 * nslots < rows; r += 4 * nslots) {
-          double v[4][3];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) v[u][q] = sb[(int64_t)(r + u * nslots) * C * 3 + q];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { S1 += v[u][0]; S2 += v[u][1]; Sz += v[u][2]; }
-        }
-        for (; r < rows; r += nslots) { S1 += sb[(int64_t)r * C * 3]; S2 += sb[(int64_t)r * C * 3 + 1]; Sz += sb[(int64_t)r * C * 3 + 2]; }
-      }
-      S1 = wave_classsum_d(S1, C); S2 = wave_classsum_d(S2, C);
-      if (dalpha) Sz = wave_classsum_d(Sz, C);
-      const double n = count * cg;
-      const double c1 = wave_groupsum_d(gam * w * S1, cg) / n;
-      const double c2 = wave_groupsum_d(gam * w * rsd * (S2 - mn * S1), cg) / n;
-      const double A1 = rsd * gam * w, B1 = -rsd * c1 + rsd * rsd * c2 * mn, C1 = -rsd * rsd * c2;
-      if (k == nbw - 1 && lane < C) { coefw[wave][0][lane] = (float)A1; coefw[wave][1][lane] = (float)B1; coefw[wave][2][lane] = (float)C1; }
-      if (lead_w) {
-        dg += w * rsd * (S2 - mn * S1);
-        db += w * S1;
-        dz += Sz;
-        if (dbias_conv) dbc += A1 * S1 + count * B1 + C1 * pf;
-      }
-    }
-    if (lead_w) {
-      if (lane < C) {
-        if (dgamma) dgamma[c] = (float)dg;
-        if (dbeta) dbeta[c] = (float)db;
-        if (dbias_conv) dbias_conv[c] = (float)dbc;
-      }
-      if (dalpha) {
-        const double sdz = wave_sum_d(lane < C ? dz : 0.0);
-        if (lane == 0) *dalpha = (float)sdz;
-      }
-    }
+    // (the pair kernels' prologue with one term: all operands of the wave -- for the leader the rows of every sample -- in one go)
+    const GnBwdTerm tm = {nullptr, 0, a, bb, sums, rows, gamma, mean_rstd, wptr, sumraw, nullptr, 0, dgamma, dbeta, dalpha, dbias_conv,
+                          RELU ? 1 : 0, nullptr, nullptr, nullptr};
+    if (lead_w) gn_bwd_prologue_impl<1, GNF_MAXB, 2>(tm, tm, B, C, G, count, &coefw[wave]);
+    else gn_bwd_prologue_impl<1, 1, 4>(tm, tm, B, C, G, count, &coefw[wave]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1072,66 +1139,15 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const T* __rest
   }
 }
 
-struct GnBwdTerm {
-  const float* raw; int64_t rld; const float* a; const float* b; const double* sums; int rows; const float* gamma; const float* mean_rstd;
-  const float* wptr; const double* sumraw; float* draw; int64_t drld; float* dgamma; float* dbeta; float* dalpha; float* dbias_conv; int relu;
-  const float* cA; const float* cB; const float* cC;   // PRE variant: coefficients from n3d_gn_bwd_coeffs2
-};
 
-// GroupNorm-backward coefficients of one term, wave level (see affine_bwd_apply_gn_kernel); strip[0..2][c] = A, B, C
-__device__ __forceinline__ void gn_bwd_prologue_wave(const GnBwdTerm& t, const int B, const int C, const int G, const double count, const bool lead_w,
-                                                     float (*strip)[64]) {
-  const int lane = threadIdx.x & 63;
-  const int cg = C / G;
-  const int c = lane & (C - 1), rs = lane / C, nslots = 64 / C;
-  const int gq = c / cg;
-  const double w = t.wptr ? (double)*t.wptr : 1.0;
-  const double gam = (double)t.gamma[c];
-  const int nbw = lead_w ? B : 1;
-  double dg = 0, db = 0, dz = 0, dbc = 0;
-  for (int k = 0; k < nbw; ++k) {
-    const int b = lead_w ? ((int)blockIdx.y + 1 + k) % B : (int)blockIdx.y;  // own sample last
-    const double mn = t.mean_rstd[(b * G + gq) * 2], rsd = t.mean_rstd[(b * G + gq) * 2 + 1];
-    const double pf = (lead_w && t.dbias_conv) ? t.sumraw[b * C + c] : 0.0;
-    const double* sb = t.sums + (int64_t)b * t.rows * C * 3 + c * 3;
-    double S1 = 0, S2 = 0, Sz = 0;
-    int r = rs;
-    for (; r + 3 * nslots < t.rows; r += 4 * nslots) {
-      double v[4][3];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) v[u][q] = sb[(int64_t)(r + u * nslots) * C * 3 + q];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { S1 += v[u][0]; S2 += v[u][1]; Sz += v[u][2]; }
-    }
-    for (; r < t.rows; r += nslots) { S1 += sb[(int64_t)r * C * 3]; S2 += sb[(int64_t)r * C * 3 + 1]; Sz += sb[(int64_t)r * C * 3 + 2]; }
-    S1 = wave_classsum_d(S1, C); S2 = wave_classsum_d(S2, C);
-    if (t.dalpha) Sz = wave_classsum_d(Sz, C);
-    const double n = count * cg;
-    const double c1 = wave_groupsum_d(gam * w * S1, cg) / n;
-    const double c2 = wave_groupsum_d(gam * w * rsd * (S2 - mn * S1), cg) / n;
-    const double A1 = rsd * gam * w, B1 = -rsd * c1 + rsd * rsd * c2 * mn, C1 = -rsd * rsd * c2;
-    if (k == nbw - 1 && lane < C) { strip[0][lane] = (float)A1; strip[1][lane] = (float)B1; strip[2][lane] = (float)C1; }
-    if (lead_w) {
-      dg += w * rsd * (S2 - mn * S1);
-      db += w * S1;
-      dz += Sz;
-      if (t.dbias_conv) dbc += A1 * S1 + count * B1 + C1 * pf;
-    }
-  }
-  if (lead_w) {
-    if (lane < C) {
-      if (t.dgamma) t.dgamma[c] = (float)dg;
-      if (t.dbeta) t.dbeta[c] = (float)db;
-      if (t.dbias_conv) t.dbias_conv[c] = (float)dbc;
-    }
-    if (t.dalpha) {
-      const double sdz = wave_sum_d(lane < C ? dz : 0.0);
-      if (lane == 0) *t.dalpha = (float)sdz;
-    }
-  }
-}
+#ifdef EW_STAMP
+// debug build only (tools/dbg/ew_stamps.py): phase stamps of wave 0 of every workgroup of the apply_gn2 / reduce2 kernels
+__device__ unsigned long long ew_stamp_buf[4096 * 8];
+#define ESTAMP(k) do { if (threadIdx.x == 0) { const int wgl_ = blockIdx.x + gridDim.x * blockIdx.y; if (wgl_ < 4096) ew_stamp_buf[wgl_ * 8 + (k)] = clock64(); } } while (0)
+extern "C" int n3d_debug_ew_stamps(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ew_stamp_buf), (size_t)n * 8); }
+#else
+#define ESTAMP(k)
+#endif
 
 template <bool PRE, bool TWO, typename T = float>
 __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ dout1,
@@ -1139,6 +1155,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __re
                                                                    int C, EwMap m) {
   __shared__ __attribute__((aligned(16))) float cw[4][2][3][64];  // [wave][term][A|B|C][channel]
   const int t = threadIdx.x, wave = t >> 6;
+  ESTAMP(0);
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   const int by = blockIdx.y;
   const T* dbp = dout + (int64_t)by * N * dld + c4 * 4;
@@ -1170,8 +1187,9 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __re
     cA[1] = ld4(t1.cA + co); cB[1] = ld4(t1.cB + co); cC[1] = ld4(t1.cC + co);
   } else {
     const bool lead_w = blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
-    gn_bwd_prologue_wave(t0, B, C, G, count, lead_w, cw[wave][0]);
-    gn_bwd_prologue_wave(t1, B, C, G, count, lead_w, cw[wave][1]);
+    ESTAMP(1);
+    gn_bwd_prologue_wave2(t0, t1, B, C, G, count, lead_w, cw[wave]);
+    ESTAMP(3);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1206,11 +1224,21 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __re
     }
     st4(op, make_float4(o[0], o[1], o[2], o[3]));
   };
+  ESTAMP(4);
+#ifdef EW_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ESTAMP(5);
+#endif
 #pragma unroll
   for (int i = 0; i < PF; ++i) {
     const int64_t v = v0 + (int64_t)i * m.vpb;
     if (i < m.iters && v < N) { one(0, dq[i], r0[i], o0 + v * t0.drld); one(1, TWO ? dq1[TWO ? i : 0] : dq[i], r1[i], o1 + v * t1.drld); }
   }
+#ifdef EW_STAMP
+  ESTAMP(6);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ESTAMP(7);
+#endif
   for (int it = PF; it < m.iters; it += PF) {   // four iterations at a time, loads first
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
