@@ -12,6 +12,8 @@ _node_units (terms grouped so that launches can be shared), i.e. the same sum wi
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import kernels as K
@@ -261,6 +263,36 @@ def _run_forward_side(plan, x0, x1, alpha1, alpha2, sf):
     return out.t, st
 
 
+SIDE_PAIRS = os.environ.get("N3D_SIDE_PAIRS", "1") != "0"   # searched cells with C <= 8: one conv of a node early on the side stream
+# (the FORWARD of the down cells' first preprocess op early on the side stream as well: measured slower, 1.992 vs 1.982 ms -- the two
+# preprocess ops of a down cell share their conv and epilogue launches on the chain, and splitting that pair costs more than the join)
+SIDE_PRE0_FWD_ALL = os.environ.get("N3D_SIDE_PRE0_FWD_ALL", "0") != "0"
+SIDE_PRE0_BWD = os.environ.get("N3D_SIDE_PRE0_BWD", "1") != "0"     # searched cells: the backward of EVERY cell's first preprocess op on the side stream
+SIDE_PAIRS_BWD = os.environ.get("N3D_SIDE_PAIRS_BWD", "1") != "0"   # ... and the data gradients into one preprocess gradient (needs a third stream)
+
+
+def _early_pair_ops(plan):
+    """{node: edge index} -- for every node of a searched cell at most ONE op that reads a preprocess output (state 0 / 1) and is a plain
+    conv: the op the side stream runs ahead of the node chain.  Of two such ops the transposed / strided one goes (the cheaper launch)."""
+    got = getattr(plan, "_early_pairs", None)
+    if got is not None:
+        return got
+    got = {}
+    for node in range(plan.n_nodes):
+        cands = []
+        for e in (2 * node, 2 * node + 1):
+            _, idx, segs, _, _ = plan.edges[e]
+            seg = segs[0][0]
+            if idx <= 1 and isinstance(seg.weight, P.DenseConvW) and P.gn_pairable(seg):
+                cands.append((0 if (seg.weight.transposed or seg.weight.stride > 1) else 1, e))
+        # the other op of the node must be a pair-epilogue op too (pair_epilogue_phase)
+        other_ok = all(P.gn_pairable(plan.edges[e][2][0][0]) for e in (2 * node, 2 * node + 1))
+        if cands and other_ok:
+            got[node] = sorted(cands)[0][1]
+    plan._early_pairs = got
+    return got
+
+
 def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None):
     if SIDE_FWD is not None and not plan.pairs and _grouping(plan.c_node):
         return _run_forward_side(plan, x0, x1, alpha1, alpha2, SIDE_FWD)
@@ -288,6 +320,18 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None):
     st.saved = []
     if plan.pairs:
         # searched cell: each node is one pair (both weight ops, then ONE epilogue launch writing the node slice)
+        early = _early_pair_ops(plan) if (SIDE_FWD is not None and SIDE_PAIRS and cn <= 8) else {}
+        side_res = {}
+        if early:
+            # C <= 8: the two convs of a node are two launches (no common MFMA problem).  The ones that read a preprocess output do
+            # not depend on the node chain: the side stream takes them all now, in node order, a flag behind each
+            sf = SIDE_FWD
+            f0 = sf.fork()
+            with sf.side(f0):
+                for node in sorted(early):
+                    e = early[node]
+                    _, idx, segs, _, _ = plan.edges[e]
+                    side_res[node] = (e, P.pair_weight_phase(segs[0][0], xs[idx]), sf.side_signal())
         for node in range(nn):
             (_, i0, segs0, _, _), (_, i1, segs1, _, _) = plan.edges[2 * node], plan.edges[2 * node + 1]
             seg0, seg1 = segs0[0][0], segs1[0][0]
@@ -296,7 +340,16 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None):
                 out = K.as_view(K.empty_ndhwc(shp[0], nn * cn, shp[2], shp[3], shp[4], xs[i0].t.device))
                 nodes = [_slice_view(out, k, cn) for k in range(nn)]
                 xs.extend(nodes)
-            s0, s1 = P.pair_forward(seg0, xs[i0], seg1, xs[i1], nodes[node])
+            if node in side_res:
+                e, res_side, tok = side_res[node]
+                if e == 2 * node:
+                    res0, res1 = res_side, P.pair_weight_phase(seg1, xs[i1])
+                else:
+                    res0, res1 = P.pair_weight_phase(seg0, xs[i0]), res_side
+                SIDE_FWD.join(tok)
+                s0, s1 = P.pair_epilogue_phase(seg0, res0, seg1, res1, nodes[node])
+            else:
+                s0, s1 = P.pair_forward(seg0, xs[i0], seg1, xs[i1], nodes[node])
             st.saved.extend([s0, s1])
         st.xs, st.out = xs, out
         return out.t, st
@@ -332,17 +385,19 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None):
     return out.t, st
 
 
-def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets=None, own_dout=False):
+def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets=None, own_dout=False, late_joins=()):
     """dx_targets = ((View | None, accumulate), (View | None, accumulate)): where the gradients of the two cell inputs go
-    (NetFn passes the producers' gradient buffers); own_dout: `dout` is a private buffer the cell may accumulate into."""
+    (NetFn passes the producers' gradient buffers); own_dout: `dout` is a private buffer the cell may accumulate into;
+    late_joins: flags of side-stream work that is still writing one of the two target buffers -- joined in front of the preprocess
+    backward, the first thing of this cell that touches them."""
     with K.storage(plan.dt):
         if SIDE_BWD is not None and not plan.pairs:
             with SIDE_BWD.arena_mode():      # (this runs on autograd's thread: the mode of the forward pass is not active here)
-                return _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, own_dout)
-        return _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, own_dout)
+                return _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, own_dout, late_joins)
+        return _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, own_dout, late_joins)
 
 
-def _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, own_dout):
+def _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, own_dout, late_joins=()):
     cn, nn = plan.c_node, plan.n_nodes
     dv = K.as_view(dout, "grad_output")
     out = st.out
@@ -378,17 +433,48 @@ def _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_da
 
     if plan.pairs:
         # searched cell: nodes in reverse; each node's two epilogue backwards share their launches (P.pair_backward)
+        # C <= 8 (two data-gradient launches per node) with a weight-gradient stream of its own: every data gradient into ONE of
+        # the two preprocess gradients -- the one with more writers -- runs on the side stream, behind a flag per node; the chain
+        # keeps the gradients into the nodes (and into the other preprocess output) and joins once, in front of the preprocess
+        # backward.  All writers of a buffer stay on one stream, in program order: same accumulation order, same bits.
+        sb = SIDE_BWD
+        side_idx, side_tok = None, None
+        if sb is not None and SIDE_PAIRS_BWD and cn <= 8 and getattr(sb, "split", False):
+            writers = [sum(1 for e in plan.edges if e[1] == k) for k in (0, 1)]
+            side_idx = 0 if writers[0] > writers[1] else 1
         for node in reversed(range(nn)):
             (_, i0, segs0, _, _), (_, i1, segs1, _, _) = plan.edges[2 * node], plan.edges[2 * node + 1]
             seg0, seg1 = segs0[0][0], segs1[0][0]
             s0, s1 = st.saved[2 * node], st.saved[2 * node + 1]
             t1, a1 = tgt(i1)   # second edge first: same accumulation order as the unpaired reverse walk
             t0, a0 = tgt(i0)
-            (_, g0), (_, g1) = P.pair_backward(seg0, s0, seg1, s1, dnodes[node], (True, t0, a0), (True, t1, a1))
+            items = None
+            if side_idx is not None and side_idx in (i0, i1):
+                items = P.pair_backward_epilogue(seg0, s0, seg1, s1, dnodes[node], (True, t0, a0), (True, t1, a1))
+            if items is None:
+                (_, g0), (_, g1) = P.pair_backward(seg0, s0, seg1, s1, dnodes[node], (True, t0, a0), (True, t1, a1))
+            else:
+                it0, it1 = items
+                res = {}
+                on_side = [(1, it1)] if i1 == side_idx else []
+                if i0 == side_idx:
+                    on_side.append((0, it0))
+                on_main = [(k, it) for k, it, idx in ((1, it1, i1), (0, it0, i0)) if idx != side_idx]
+                ready = sb.fork()
+                with sb.side(ready):
+                    for (k, _), r in zip(on_side, P._weight_backward(tuple(it for _, it in on_side))):
+                        res[k] = r
+                    side_tok = sb.side_signal()
+                if on_main:
+                    for (k, _), r in zip(on_main, P._weight_backward(tuple(it for _, it in on_main))):
+                        res[k] = r
+                g0, g1 = res[0][1], res[1][1]
             put(seg1, g1)
             put(seg0, g0)
             if NODE_DONE_HOOK is not None:
                 NODE_DONE_HOOK()
+        if side_tok is not None:
+            sb.join(side_tok)
         flat = []
     else:
         flat = None
@@ -547,14 +633,18 @@ def _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_da
         if not pre_started[i]:
             dpre[i].t.zero_()
     (t0, acc0), (t1, acc1) = dx_targets if dx_targets is not None else ((None, False), (None, False))
-    if SIDE_BWD is not None and plan.pairs and getattr(st, "pre0_side", False) and need_x0 and t0 is None:
-        # an up cell of the searched net: the gradient of its SKIP input is not needed before the backward walk reaches the lower
-        # part of the U, so the backward of the skip-side preprocess op goes to the side stream; NetFn.backward joins its flag
-        # (st.side_tok) before anything else touches that gradient buffer
+    for tok in late_joins:
+        SIDE_BWD.join(tok)
+    if (SIDE_BWD is not None and plan.pairs and need_x0 and dx_targets is not None
+            and (getattr(st, "pre0_side", False) or SIDE_PRE0_BWD)):
+        # searched net: the gradient of a cell's FIRST input -- the skip of an up cell, the output of the cell before the previous
+        # one for a down cell -- is not needed by the next cell of the backward walk (that one reads the gradient of the SECOND
+        # input), so the backward of that preprocess op goes to the side stream; NetFn.backward joins its flag (st.side_tok) in
+        # front of whatever touches that gradient buffer next
         sb = SIDE_BWD
         f = sb.fork()
         with sb.side(f):
-            d0, g0 = P.seg_backward(plan.pre0, st.s_pre0, dpre[0], True, None, False)
+            d0, g0 = P.seg_backward(plan.pre0, st.s_pre0, dpre[0], True, t0, acc0)
             st.side_tok = sb.side_signal()
         d1, g1 = P.seg_backward(plan.pre1, st.s_pre1, dpre[1], need_x1, t1, acc1)
     else:
@@ -723,7 +813,7 @@ class NetFn(torch.autograd.Function):
             not need it before the whole lower part of the U has run, so its 1x1x1 preprocess op starts on the side stream here"""
             if sf is None or nplan.supernet:
                 return
-            for k in range(nplan.n_down, len(nplan.wiring)):
+            for k in range(0 if SIDE_PRE0_FWD_ALL else nplan.n_down, len(nplan.wiring)):
                 pl = nplan.cells[k]
                 if nplan.wiring[k][0] == act_index and pl.pairs and pl.pre0.dropout is None:
                     f = sf.fork()
@@ -777,10 +867,11 @@ class NetFn(torch.autograd.Function):
             i0, i1, io = nplan.wiring[k]
             down = k < nplan.n_down
             a1, a2 = (al[0], al[2]) if down else (al[1], al[3])
-            settle(i0, i1, io)
+            settle(io)                                                      # read from the first launch on
+            late = [pending.pop(i) for i in (i0, i1) if i in pending]       # only written, by the preprocess backward at the end
             targets = tuple((K.as_view(gbuf[i], "grad") if gbuf[i] is not None else None, gbuf[i] is not None) for i in (i0, i1))
             d0, d1, da1, da2, gl = _run_backward(nplan.cells[k], ctx.states[k], gbuf[io], a1, a2, True, True, want_da, targets,
-                                                 own_dout=gbuf[io] is not dout)
+                                                 own_dout=gbuf[io] is not dout, late_joins=late)
             tok = getattr(ctx.states[k], "side_tok", None)
             if tok is not None:
                 pending[i0] = tok

@@ -681,6 +681,20 @@ def pair_backward(segA, sA, segB, sB, dout, argsA, argsB, doutB=None, alphaA=Non
     return results[1], results[0]
 
 
+def pair_backward_epilogue(segA, sA, segB, sB, dout, argsA, argsB):
+    """First half of pair_backward for a searched-cell node whose two terms pair: the epilogue backward (both d(raw) and the norms'
+    parameter gradients).  Returns the two `_weight_backward` items (A, B), or None when the pair form does not apply.  The caller
+    runs the weight-op backwards itself -- fused._run_backward_impl puts the one whose input gradient goes to a preprocess output
+    on the side stream."""
+    if not (sA.kind == "gn" and sB.kind == "gn" and not isinstance(segA.weight, IdentityW) and not isinstance(segB.weight, IdentityW)
+            and sA.raw.C == sB.raw.C and sA.raw.N == sB.raw.N and K.pair_shape_ok(sA.raw.C)):
+        return None
+    none = (None, 0, None)
+    terms = [_gn_bwd_term(segA, sA, none), _gn_bwd_term(segB, sB, none)]
+    outs = K.affine_act_bwd_gn2(dout, terms, sA.G, None)
+    return (segA, sA, terms[0], outs[0], argsA), (segB, sB, terms[1], outs[1], argsB)
+
+
 def _gn_bwd_term(seg, s, alpha):
     """descriptor of one GroupNorm-type term for K.affine_act_bwd_gn2 / affine_act_bwd_gnN; alpha = (row, column, dalpha row | None)"""
     cbias = seg.weight.norm_fed_bias()

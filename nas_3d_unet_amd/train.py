@@ -782,7 +782,8 @@ class Trainer:
         # stream costs two cross-stream waits around a graph launch); N3D_COMM_STREAM=1 restores the hop
         want_cs = self.dp_path and (self._buckets is not None or os.environ.get("N3D_COMM_STREAM") == "1")
         self._comm_stream = torch.cuda.Stream(device=self.device) if (want_cs and self.device.type == "cuda") else None
-        self.side = SideSchedule(self.device, self.ctx) if (self.side_wgrad and self.device.type == "cuda") else None
+        # (a weight-gradient stream of its own lets the side stream run data gradients of the C <= 8 cells inline: fused.SIDE_PAIRS_BWD)
+        self.side = SideSchedule(self.device, self.ctx, wgrad_stream=_fused.SIDE_PAIRS_BWD) if (self.side_wgrad and self.device.type == "cuda") else None
         if self.side is not None and self.side.stream is None:
             self.side = None
         ranges = [r for _, r in self._buckets] if self._buckets is not None else None
