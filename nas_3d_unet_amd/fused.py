@@ -267,6 +267,7 @@ SIDE_PAIRS = os.environ.get("N3D_SIDE_PAIRS", "1") != "0"   # searched cells wit
 # (the FORWARD of the down cells' first preprocess op early on the side stream as well: measured slower, 1.992 vs 1.982 ms -- the two
 # preprocess ops of a down cell share their conv and epilogue launches on the chain, and splitting that pair costs more than the join)
 SIDE_PRE0_FWD_ALL = os.environ.get("N3D_SIDE_PRE0_FWD_ALL", "0") != "0"
+SIDE_STEM1_BWD = os.environ.get("N3D_SIDE_STEM1_BWD", "1") != "0"   # stem1's backward (parameter gradients only) beside stem0's
 SIDE_PRE0_BWD = os.environ.get("N3D_SIDE_PRE0_BWD", "1") != "0"     # searched cells: the backward of EVERY cell's first preprocess op on the side stream
 SIDE_PAIRS_BWD = os.environ.get("N3D_SIDE_PAIRS_BWD", "1") != "0"   # ... and the data gradients into one preprocess gradient (needs a third stream)
 
@@ -890,7 +891,15 @@ class NetFn(torch.autograd.Function):
         dx = None
         n0 = len(nplan.stem0.params())
         for seg, st, g, off in ((nplan.stem1, ctx.st1, gbuf[1], n0), (nplan.stem0, ctx.st0, gbuf[0], 0)):
-            d, gl = P.seg_backward(seg, st, K.as_view(g, "grad"), need_x)
+            if seg is nplan.stem1 and SIDE_BWD is not None and SIDE_STEM1_BWD and not need_x and not nplan.supernet:
+                # the two stems' backwards are independent and produce parameter gradients only: one of them on the side stream,
+                # whose 'done' flag the tail waits for anyway (no join of its own)
+                f = SIDE_BWD.fork()
+                with SIDE_BWD.side(f):
+                    d, gl = P.seg_backward(seg, st, K.as_view(g, "grad"), need_x)
+                    SIDE_BWD.side_signal()
+            else:
+                d, gl = P.seg_backward(seg, st, K.as_view(g, "grad"), need_x)
             for j, (p, gg) in enumerate(zip(seg.params(), gl)):
                 if gg is not None and getattr(p, "_n3d_grad", None) is None:
                     grads[off + j] = gg
