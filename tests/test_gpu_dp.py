@@ -56,8 +56,10 @@ def test_trainer_dp_schedules_match_single_gpu(one_rank_group, graph, buckets, c
     l, w = _losses_and_weights(tr, x, t)
     if graph and buckets > 1:
         assert tr._segments is not None and len(tr._segments) == buckets
-    np.testing.assert_allclose(l, lr_, rtol=0, atol=2e-6)
-    assert float((w - wr).abs().max()) <= 2e-6
+    # (the bucketed exchange replays the single-stream schedule, the reference trainer the side-stream one: the same arithmetic with
+    # the two preprocess epilogue backwards of a cell in one launch there and in two here -- a different fp32 rounding of the same sums)
+    np.testing.assert_allclose(l, lr_, rtol=0, atol=5e-6)
+    assert float((w - wr).abs().max()) <= 5e-6
 
 
 def test_search_trainer_dp_matches_single_gpu(one_rank_group):

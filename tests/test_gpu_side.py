@@ -120,6 +120,26 @@ def test_side_schedule_graph_replay_matches_plain_trainer():
     assert float(d.double().norm()) <= 2e-4 * float(out[0][1].double().norm())
 
 
+@pytest.mark.parametrize("size", [32, 64])
+def test_side_schedule_is_reproducible_run_to_run(size):
+    """three streams, ~60 device-side hand-offs per step, gradient buffers that the side stream accumulates into behind deferred
+    joins: two trainers built alike must end up with bit-identical weights (a missing join would show as run-to-run noise)"""
+    from nas_3d_unet_amd.train import Trainer
+    x, t = _batch(47, size=size)
+    flats = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        net, _ = build_net("searched", "G_CONV", 4)
+        tr = Trainer(net, graph=True, side_wgrad="force")
+        for _ in range(5):
+            tr.step(x, t)
+        torch.cuda.synchronize()
+        tr.check_sync()
+        assert tr._use_side
+        flats.append(tr.fp.flat.clone())
+    assert torch.equal(flats[0], flats[1])
+
+
 def test_schedule_choice_leaves_the_state_alone():
     """the default trainer times both captured schedules on the real step at capture time: weights, Adam moments, step counters
     and the Dropout3d generator must come out of that exactly as they went in"""
