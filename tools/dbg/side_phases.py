@@ -8,7 +8,7 @@ from nas_3d_unet_amd.train import Trainer
 dev = torch.device("cuda")
 xn, tn = bench.synthetic_batch(2, 64, 1234)
 x, t = bench.to_patch_layout(torch.from_numpy(xn).to(dev)), torch.from_numpy(tn).to(dev)
-def run(drop, mq=3):
+def run(drop, mq=int(os.environ.get("MQ", "3"))):
     K._DROP_SIDE = drop
     torch.manual_seed(1234)
     net = searched.SearchedNet(4, 4, 3, 4, 3, True, searched.Genotype(**bench.G_CONV)).to(dev); net.train()
