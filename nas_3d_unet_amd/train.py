@@ -762,6 +762,7 @@ class Trainer:
         # a replayed step is re-timed every 256 steps and the trainer falls back to the plain graph if the side schedule degrades
         # (e.g. another library created hardware queues and the two streams are time-sliced)
         self._side_force = side_wgrad == "force" or (side_wgrad is None and env == "force")
+        self._side_explicit = side_wgrad is not None     # an eager trainer (graph=False) takes the side schedule only when asked to
         self._use_side = False
         self.schedule_times = None   # (plain seconds per step, side seconds per step) measured at capture
         if storage is not None:
@@ -952,11 +953,15 @@ class Trainer:
         self.lr = float(lr)
         self.lr_dev.fill_(self.lr)
 
-    def _eager(self, x, t):
+    def _eager(self, x, t, allow_side=True):
+        """allow_side=False: single stream whatever the trainer was built with.  The side-stream schedule ties its streams together
+        with device-side waits, and anything that makes the HOST wait for the device in the middle of a pass (the caching allocator
+        returning memory to the driver when a new shape does not fit its cache, for one) leaves those waits spinning until their
+        time-out; a replayed graph allocates nothing, an eager pass on a shape seen for the first time may."""
         if self.dp_path and self._pipeline_ok(x):
             loss = self._pipeline(x, t, self._reduce_on_side)
             torch.cuda.current_stream().wait_stream(self._comm_stream)
-        elif self._side_ok():
+        elif allow_side and self._side_ok() and (self._side_explicit or self.use_graph):
             loss = self._side_step_eager(x, t)
             if self.dp_path:
                 self._allreduce()
@@ -975,8 +980,8 @@ class Trainer:
             self._capture(x, t)
         if x.shape != self._static_x.shape or t.shape != self._static_t.shape:
             # a batch of another shape (the reference's generator yields a smaller last batch of an epoch): the captured
-            # graph is for one shape only, so this step runs eagerly (same kernels, same update)
-            return self._eager(x, t)
+            # graph is for one shape only, so this step runs eagerly (same kernels, same update) -- on ONE stream (see _eager)
+            return self._eager(x, t, allow_side=False)
         # a caller that fills the trainer's own input buffers (input_buffers(): the data step writes the batch straight into them)
         # has no copy to pay; any other tensor is copied in
         if x is not self._static_x:
@@ -1377,7 +1382,12 @@ class SearchTrainer:
                     self._choose_schedule()
             drop_snap.restore()
         if any(a.shape != b.shape for a, b in ((x, self._sx), (t, self._st), (val_x, self._svx), (val_t, self._svt))):
-            return self._both(x, t, val_x, val_t)   # remainder batch of an epoch: eager step (the graph is for one shape)
+            # remainder batch of an epoch: eager step (the graph is for one shape), on ONE stream (Trainer._eager says why)
+            was, self._side_active = self._side_active, False
+            try:
+                return self._both(x, t, val_x, val_t)
+            finally:
+                self._side_active = was
         for dst, src in ((self._sx, x), (self._st, t), (self._svx, val_x), (self._svt, val_t)):
             if src is not dst:      # input_buffers(): a caller that fills the trainer's own buffers has no copy to pay
                 dst.copy_(src)
