@@ -35,7 +35,7 @@ def run(drop, mq=int(os.environ.get("MQ", "3"))):
     tr.check_sync()
 if os.environ.get("N3D_MAIN_NB"):
     # everything on a non-blocking stream instead of the legacy default stream (a CU-masked side stream is a BLOCKING stream)
-    nb = torch.cuda.Stream(device=dev)
+    nb = torch.cuda.Stream(device=dev, priority=-1 if os.environ.get("N3D_MAIN_NB") == "high" else 0)
     with torch.cuda.stream(nb):
         run(True)
         run(False)
