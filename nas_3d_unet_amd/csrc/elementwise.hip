@@ -39,6 +39,30 @@ __device__ __forceinline__ void block_reduce_to_row(double (&vals)[NV * 4], int 
   }
 }
 
+// The same for cpb a power of two <= 16 with the wave stage packed four values to a register (wave_classsum4_f): NT terms of
+// three kinds (s1, s2, sz) x 4 channels each, X[3 t + kind]; ONE LDS round and one barrier for all terms.  The wave stage is
+// fp32, the cross-wave sum fp64 as in block_reduce_to_row.  rows[t][(c4 * 4 + j) * 3 + kind].
+template <int NT, int cpb>
+__device__ __forceinline__ void block_reduce_packed_rows(const float (&X)[NT * 3], double* const (&rows)[NT],
+                                                         float* ldsf /* [4 waves][16][NT*3][4] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15;
+  if (l16 < cpb) {
+    float* o = ldsf + ((wave * 16 + l16) * (NT * 3)) * 4 + classsum4_sel(lane);
+#pragma unroll
+    for (int q = 0; q < NT * 3; ++q) o[q * 4] = X[q];
+  }
+  __syncthreads();
+  const int nq = cpb * NT * 12;
+  for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+    const int c4 = i / (NT * 12), q = i % (NT * 12);     // q = (t * 3 + kind) * 4 + j
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += (double)ldsf[(w * 16 + c4) * (NT * 12) + q];
+    const int t = q / 12, kind = (q % 12) / 4, j = q % 4;
+    rows[t][(c4 * 4 + j) * 3 + kind] = s;
+  }
+}
+
 // NOTE on wave classes: when 64 % cpb != 0 the lanes < cpb of different waves hold different
 // classes; the LDS slot is indexed by the class, and every class is present in every wave
 // (cpb <= 64), so each (wave, class) slot is written exactly once.
@@ -255,6 +279,17 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(const T* __restr
     }
   }
   // the wave-level stage runs in fp32 (<= 64 lanes x <= 4 partials each), the cross-wave / cross-row stages in fp64
+  double* row = sums + ((int64_t)b * gridDim.x + blockIdx.x) * C * 3;
+  if (is_pow2(m.cpb) && m.cpb <= 16) {
+    class_dispatch16(m.cpb, [&](auto cc) {
+      constexpr int CPB = decltype(cc)::value;
+      const float X[3] = {wave_classsum4_f<CPB>(s1[0], s1[1], s1[2], s1[3]), wave_classsum4_f<CPB>(s2[0], s2[1], s2[2], s2[3]),
+                          wave_classsum4_f<CPB>(sz[0], sz[1], sz[2], sz[3])};
+      double* const rows[1] = {row};
+      block_reduce_packed_rows<1, CPB>(X, rows, reinterpret_cast<float*>(lds));
+    });
+    return;
+  }
   double vals[12];
   if (is_pow2(m.cpb)) {
 #pragma unroll
@@ -265,7 +300,6 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(const T* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) { vals[j] = s1[j]; vals[4 + j] = s2[j]; vals[8 + j] = sz[j]; }
   }
-  double* row = sums + ((int64_t)b * gridDim.x + blockIdx.x) * C * 3;
   block_reduce_to_row<3>(vals, m.cpb, row, lds, is_pow2(m.cpb));
 }
 
@@ -518,8 +552,11 @@ __global__ __launch_bounds__(256) void affine_act_gn_kernel(const T* __restrict_
       }
       for (; r < rows; r += nslots) { const double2 v = st2[(int64_t)r * C + c]; s += v.x; ss += v.y; }
     }
-    s = wave_classsum_d(s, C); ss = wave_classsum_d(ss, C);
-    const double gs = wave_groupsum_d(s, cg), gss = wave_groupsum_d(ss, cg);
+    double gv[2] = {s, ss};
+    wave_classsum_dn<2>(gv, C);
+    s = gv[0];
+    wave_groupsum_dn<2>(gv, cg);
+    const double gs = gv[0], gss = gv[1];
     const double n = count * cg;
     const double mean = gs / n;
     double var = gss / n - mean * mean;
@@ -686,15 +723,25 @@ __device__ __forceinline__ void gn_bwd_prologue_impl(const GnBwdTerm& t0, const 
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) {
     if (kb < nbw) {
+      double cs[NT * 2], gsum[NT * 2];
+#pragma unroll
+      for (int k = 0; k < NT; ++k) { cs[2 * k] = acc[kb][k][0]; cs[2 * k + 1] = acc[kb][k][1]; }
+      wave_classsum_dn<NT * 2>(cs, C);
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        gsum[2 * k] = gam[k] * w[k] * cs[2 * k];
+        gsum[2 * k + 1] = gam[k] * w[k] * rsd[kb][k] * (cs[2 * k + 1] - mn[kb][k] * cs[2 * k]);
+      }
+      wave_groupsum_dn<NT * 2>(gsum, cg);
 #pragma unroll
       for (int k = 0; k < NT; ++k) {
         const GnBwdTerm& t = *ts[k];
-        double S1 = acc[kb][k][0], S2 = acc[kb][k][1], Sz = acc[kb][k][2];
-        S1 = wave_classsum_d(S1, C); S2 = wave_classsum_d(S2, C);
-        if (t.dalpha) Sz = wave_classsum_d(Sz, C);
+        const double S1 = cs[2 * k], S2 = cs[2 * k + 1];
+        double Sz = acc[kb][k][2];
+        if (LEAD && t.dalpha) Sz = wave_classsum_d(Sz, C);
         const double n = count * cg;
-        const double c1 = wave_groupsum_d(gam[k] * w[k] * S1, cg) / n;
-        const double c2 = wave_groupsum_d(gam[k] * w[k] * rsd[kb][k] * (S2 - mn[kb][k] * S1), cg) / n;
+        const double c1 = gsum[2 * k] / n;
+        const double c2 = gsum[2 * k + 1] / n;
         const double A1 = rsd[kb][k] * gam[k] * w[k], B1 = -rsd[kb][k] * c1 + rsd[kb][k] * rsd[kb][k] * c2 * mn[kb][k],
                      C1 = -rsd[kb][k] * rsd[kb][k] * c2;
         if (kb == nbw - 1 && lane < C) { strip[k][0][lane] = (float)A1; strip[k][1][lane] = (float)B1; strip[k][2][lane] = (float)C1; }
@@ -725,8 +772,10 @@ __device__ __forceinline__ void gn_bwd_prologue_impl(const GnBwdTerm& t0, const 
 }
 __device__ __forceinline__ void gn_bwd_prologue_wave2(const GnBwdTerm& t0, const GnBwdTerm& t1, const int B, const int C, const int G,
                                                       const double count, const bool lead_w, float (*strip)[3][64]) {
-  if (lead_w) gn_bwd_prologue_impl<2, GNF_MAXB, 2>(t0, t1, B, C, G, count, strip);
-  else gn_bwd_prologue_impl<2, 1, 4>(t0, t1, B, C, G, count, strip);
+  if (lead_w) {
+    if (B <= 2) gn_bwd_prologue_impl<2, 2, 4>(t0, t1, B, C, G, count, strip);   // (no slots predicated off: half the requests)
+    else gn_bwd_prologue_impl<2, GNF_MAXB, 2>(t0, t1, B, C, G, count, strip);
+  } else gn_bwd_prologue_impl<2, 1, 4>(t0, t1, B, C, G, count, strip);
 }
 
 template <bool RELU, bool ACC, typename T = float>
@@ -776,8 +825,10 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const T* __res
     // (the pair kernels' prologue with one term: all operands of the wave -- for the leader the rows of every sample -- in one go)
     const GnBwdTerm tm = {nullptr, 0, a, bb, sums, rows, gamma, mean_rstd, wptr, sumraw, nullptr, 0, dgamma, dbeta, dalpha, dbias_conv,
                           RELU ? 1 : 0, nullptr, nullptr, nullptr};
-    if (lead_w) gn_bwd_prologue_impl<1, GNF_MAXB, 2>(tm, tm, B, C, G, count, &coefw[wave]);
-    else gn_bwd_prologue_impl<1, 1, 4>(tm, tm, B, C, G, count, &coefw[wave]);
+    if (lead_w) {
+      if (B <= 2) gn_bwd_prologue_impl<1, 2, 4>(tm, tm, B, C, G, count, &coefw[wave]);
+      else gn_bwd_prologue_impl<1, GNF_MAXB, 2>(tm, tm, B, C, G, count, &coefw[wave]);
+    } else gn_bwd_prologue_impl<1, 1, 4>(tm, tm, B, C, G, count, &coefw[wave]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -958,8 +1009,11 @@ __device__ __forceinline__ void gn_fwd_prologue_wave(const GnFwdTerm& t, const i
     for (int u = 0; u < 4; ++u) { s += v[u].x; ss += v[u].y; }
   }
   for (; r < t.rows; r += nslots) { const double2 v = st2[(int64_t)r * C + c]; s += v.x; ss += v.y; }
-  s = wave_classsum_d(s, C); ss = wave_classsum_d(ss, C);
-  const double gs = wave_groupsum_d(s, cg), gss = wave_groupsum_d(ss, cg);
+  double gv[2] = {s, ss};
+  wave_classsum_dn<2>(gv, C);
+  s = gv[0];
+  wave_groupsum_dn<2>(gv, cg);
+  const double gs = gv[0], gss = gv[1];
   const double n = count * cg;
   const double mean = gs / n;
   double var = gss / n - mean * mean;
@@ -1064,6 +1118,21 @@ __global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwd
   }
 }
 
+#ifdef EW_STAMP
+#define EW_STAMP_ON 1
+// debug build only (tools/dbg/ew_stamps.py): phase stamps of wave 0 of every workgroup of the apply_gn2 / reduce2 kernels
+__device__ unsigned long long ew_stamp_buf[4096 * 8];
+#define ESTAMP(k) do { if (threadIdx.x == 0 && EW_STAMP_ON) { const int wgl_ = blockIdx.x + gridDim.x * blockIdx.y; if (wgl_ < 4096) ew_stamp_buf[wgl_ * 8 + (k)] = clock64(); } } while (0)
+extern "C" int n3d_debug_ew_stamps(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ew_stamp_buf), (size_t)n * 8); }
+#else
+#define ESTAMP(k)
+#endif
+#ifdef EW_STAMP_R2
+#define AESTAMP(k)
+#else
+#define AESTAMP(k) ESTAMP(k)
+#endif
+
 // backward pass 1 for two ops that share the node gradient dout: sums0 / sums1 rows as affine_bwd_reduce_kernel
 struct BwdRedTerm { const float* raw; int64_t rld; const float* a; const float* b; double* sums; int relu; };
 
@@ -1074,6 +1143,9 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const T* __rest
   __shared__ double lds[4 * 64 * 12];
   const int b = blockIdx.y;
   const int t = threadIdx.x;
+#ifdef EW_STAMP_R2
+  ESTAMP(0);
+#endif
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   const bool active = vl < m.vpb;
   float s1[2][4], s2[2][4], sz[2][4];
@@ -1126,6 +1198,32 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const T* __rest
       }
     }
   }
+#ifdef EW_STAMP_R2
+  ESTAMP(1);
+#endif
+  if (m.cpb <= 16) {
+    const int64_t ro = ((int64_t)b * gridDim.x + blockIdx.x) * C * 3;
+    double* const rows[2] = {t0.sums + ro, t1.sums + ro};
+    class_dispatch16(m.cpb, [&](auto cc) {
+      constexpr int CPB = decltype(cc)::value;
+      float X[6];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        X[3 * k + 0] = wave_classsum4_f<CPB>(s1[k][0], s1[k][1], s1[k][2], s1[k][3]);
+        X[3 * k + 1] = wave_classsum4_f<CPB>(s2[k][0], s2[k][1], s2[k][2], s2[k][3]);
+        X[3 * k + 2] = wave_classsum4_f<CPB>(sz[k][0], sz[k][1], sz[k][2], sz[k][3]);
+      }
+#ifdef EW_STAMP_R2
+      ESTAMP(2);
+#endif
+      block_reduce_packed_rows<2, CPB>(X, rows, reinterpret_cast<float*>(lds));
+    });
+#ifdef EW_STAMP_R2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ESTAMP(6);
+#endif
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     double vals[12];
@@ -1135,19 +1233,21 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const T* __rest
     }
     double* row = (k == 0 ? t0.sums : t1.sums) + ((int64_t)b * gridDim.x + blockIdx.x) * C * 3;
     if (k == 1) __syncthreads();
+#ifdef EW_STAMP_R2
+    ESTAMP(2 + 2 * k);
+#endif
     block_reduce_to_row<3>(vals, m.cpb, row, lds, true);
+#ifdef EW_STAMP_R2
+    ESTAMP(3 + 2 * k);
+#endif
   }
+#ifdef EW_STAMP_R2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ESTAMP(6);
+#endif
 }
 
 
-#ifdef EW_STAMP
-// debug build only (tools/dbg/ew_stamps.py): phase stamps of wave 0 of every workgroup of the apply_gn2 / reduce2 kernels
-__device__ unsigned long long ew_stamp_buf[4096 * 8];
-#define ESTAMP(k) do { if (threadIdx.x == 0) { const int wgl_ = blockIdx.x + gridDim.x * blockIdx.y; if (wgl_ < 4096) ew_stamp_buf[wgl_ * 8 + (k)] = clock64(); } } while (0)
-extern "C" int n3d_debug_ew_stamps(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ew_stamp_buf), (size_t)n * 8); }
-#else
-#define ESTAMP(k)
-#endif
 
 template <bool PRE, bool TWO, typename T = float>
 __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ dout1,
@@ -1155,7 +1255,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __re
                                                                    int C, EwMap m) {
   __shared__ __attribute__((aligned(16))) float cw[4][2][3][64];  // [wave][term][A|B|C][channel]
   const int t = threadIdx.x, wave = t >> 6;
-  ESTAMP(0);
+  AESTAMP(0);
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   const int by = blockIdx.y;
   const T* dbp = dout + (int64_t)by * N * dld + c4 * 4;
@@ -1187,9 +1287,9 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __re
     cA[1] = ld4(t1.cA + co); cB[1] = ld4(t1.cB + co); cC[1] = ld4(t1.cC + co);
   } else {
     const bool lead_w = blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
-    ESTAMP(1);
+    AESTAMP(1);
     gn_bwd_prologue_wave2(t0, t1, B, C, G, count, lead_w, cw[wave]);
-    ESTAMP(3);
+    AESTAMP(3);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1224,10 +1324,10 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __re
     }
     st4(op, make_float4(o[0], o[1], o[2], o[3]));
   };
-  ESTAMP(4);
+  AESTAMP(4);
 #ifdef EW_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  ESTAMP(5);
+  AESTAMP(5);
 #endif
 #pragma unroll
   for (int i = 0; i < PF; ++i) {
@@ -1235,9 +1335,9 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __re
     if (i < m.iters && v < N) { one(0, dq[i], r0[i], o0 + v * t0.drld); one(1, TWO ? dq1[TWO ? i : 0] : dq[i], r1[i], o1 + v * t1.drld); }
   }
 #ifdef EW_STAMP
-  ESTAMP(6);
+  AESTAMP(6);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  ESTAMP(7);
+  AESTAMP(7);
 #endif
   for (int it = PF; it < m.iters; it += PF) {   // four iterations at a time, loads first
 #pragma unroll

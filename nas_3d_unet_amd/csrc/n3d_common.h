@@ -1,5 +1,6 @@
 // Shared host/device helpers for libn3d (gfx950 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -172,6 +173,40 @@ __device__ __forceinline__ float wave_classsum_f(float v, int cpb) {
   if (cpb <= 32) v = xsum32_f(v);
   return v;
 }
+// class sums of FOUR values at once, cpb a power of two <= 16.  v_permlane32_swap of (v0, v1) lays the two wave halves of v0 side by
+// side in the low half of the register pair and those of v1 in the high half, so one add folds lane ^ 32 of both; the same for
+// (v2, v3); a v_permlane16_swap of the two results folds lane ^ 16 of all four and leaves row r of the wave (lanes 16 r ..) with
+// v[{0, 2, 1, 3}[r]]; DPP rotations finish inside the rows.  3 swaps + 3 adds + <= 4 DPP adds instead of 4 x (2 swaps + ...):
+// the swaps are what these reductions wait for.  Lane l of row r returns the sum of v[{0,2,1,3}[r]] over the lanes of class l % cpb.
+// (cpb is a template argument here and in class_dispatch16 below: with a run-time cpb every `if (cpb <= ..)` step of every value
+// became a scalar branch -- 24 values x 6 branches in the epilogue-backward reduction, most of that kernel after its loads)
+template <int CPB>
+__device__ __forceinline__ float wave_classsum4_f(float v0, float v1, float v2, float v3) {
+  const auto s01 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, v0), __builtin_bit_cast(int, v1), false, false);
+  const auto s23 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, v2), __builtin_bit_cast(int, v3), false, false);
+  const float ab = __builtin_bit_cast(float, (int)s01[0]) + __builtin_bit_cast(float, (int)s01[1]);
+  const float cd = __builtin_bit_cast(float, (int)s23[0]) + __builtin_bit_cast(float, (int)s23[1]);
+  const auto sx = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(int, ab), __builtin_bit_cast(int, cd), false, false);
+  float x = __builtin_bit_cast(float, (int)sx[0]) + __builtin_bit_cast(float, (int)sx[1]);
+  if (CPB <= 8) x += dpp_f<0x128>(x);   // row_ror:8
+  if (CPB <= 4) x += dpp_f<0x124>(x);   // row_ror:4
+  if (CPB <= 2) x += dpp_f<0x4E>(x);    // quad_perm [2,3,0,1]
+  if (CPB <= 1) x += dpp_f<0xB1>(x);    // quad_perm [1,0,3,2]
+  return x;
+}
+// f(std::integral_constant<int, cpb>) for cpb in {1, 2, 4, 8, 16}: one uniform branch, straight-line code behind it
+template <typename F>
+__device__ __forceinline__ void class_dispatch16(int cpb, F&& f) {
+  switch (cpb) {
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    case 8: f(std::integral_constant<int, 8>{}); break;
+    default: f(std::integral_constant<int, 16>{}); break;
+  }
+}
+// the value index (0..3) that wave_classsum4_f leaves in this lane's row
+__device__ __forceinline__ int classsum4_sel(int lane) { return ((lane >> 4) & 1) * 2 + (lane >> 5); }
 __device__ __forceinline__ double wave_classsum_d(double v, int cpb) {
   if (cpb <= 1) v += dpp_d<0xB1>(v);
   if (cpb <= 2) v += dpp_d<0x4E>(v);
@@ -181,6 +216,30 @@ __device__ __forceinline__ double wave_classsum_d(double v, int cpb) {
   if (cpb <= 32) v = xsum32_d(v);
   return v;
 }
+template <int CPB>
+__device__ __forceinline__ double wave_classsum_d_t(double v) {
+  if (CPB <= 1) v += dpp_d<0xB1>(v);
+  if (CPB <= 2) v += dpp_d<0x4E>(v);
+  if (CPB <= 4) v += dpp_d<0x124>(v);
+  if (CPB <= 8) v += dpp_d<0x128>(v);
+  if (CPB <= 16) v = xsum16_d(v);
+  if (CPB <= 32) v = xsum32_d(v);
+  return v;
+}
+// NV values at once behind ONE uniform switch on the width: with a run-time width every step of every value is a scalar branch
+// (six per value), and the values' chains cannot interleave across the branches
+template <int NV>
+__device__ __forceinline__ void wave_classsum_dn(double (&v)[NV], int cpb) {
+#define N3D_CS_CASE(W) case W: _Pragma("unroll") for (int q = 0; q < NV; ++q) v[q] = wave_classsum_d_t<W>(v[q]); break;
+  switch (cpb) {
+    N3D_CS_CASE(4) N3D_CS_CASE(8) N3D_CS_CASE(16) N3D_CS_CASE(32)
+    case 64: break;
+    default:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = wave_classsum_d(v[q], cpb);
+  }
+#undef N3D_CS_CASE
+}
 __device__ __forceinline__ bool is_pow2(int x) { return (x & (x - 1)) == 0; }
 // every lane ends up with the sum over its aligned group of cg consecutive lanes (cg = 1, 2, 4, 8 or 16): DPP only
 __device__ __forceinline__ double wave_groupsum_d(double v, int cg) {
@@ -189,6 +248,26 @@ __device__ __forceinline__ double wave_groupsum_d(double v, int cg) {
   if (cg >= 8) v += dpp_d<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of each 8
   if (cg >= 16) v += dpp_d<0x140>(v);  // row_mirror: lane i <-> 15 - i of each 16
   return v;
+}
+
+template <int CG>
+__device__ __forceinline__ double wave_groupsum_d_t(double v) {
+  if (CG >= 2) v += dpp_d<0xB1>(v);
+  if (CG >= 4) v += dpp_d<0x4E>(v);
+  if (CG >= 8) v += dpp_d<0x141>(v);
+  if (CG >= 16) v += dpp_d<0x140>(v);
+  return v;
+}
+template <int NV>
+__device__ __forceinline__ void wave_groupsum_dn(double (&v)[NV], int cg) {
+#define N3D_GS_CASE(W) case W: _Pragma("unroll") for (int q = 0; q < NV; ++q) v[q] = wave_groupsum_d_t<W>(v[q]); break;
+  switch (cg) {
+    N3D_GS_CASE(4) N3D_GS_CASE(8) N3D_GS_CASE(16)
+    default:
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = wave_groupsum_d(v[q], cg);
+  }
+#undef N3D_GS_CASE
 }
 
 // sum over the lanes of a wave that share (lane % cpb); result valid in lanes < cpb (any cpb <= 64)

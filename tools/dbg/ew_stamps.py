@@ -7,6 +7,8 @@ from nas_3d_unet_amd import kernels as K, _lib
 dev = torch.device("cuda")
 lib = _lib.load()
 names = ["start", "first loads out", "prologue 0", "prologue 1", "rest of loads out", "loads landed", "math + stores out", "stores done"]
+if os.environ.get("EW_R2"):   # a -DEW_STAMP -DEW_STAMP_R2 build: the stamps are those of reduce2
+    names = ["start", "loads + sums done", "class sums (both terms)", "-", "-", "-", "rows written", "-"]
 K.SMALL_NODE_BACKWARD = False
 for (c, shape) in [(32, (8, 8, 8)), (16, (16, 16, 16)), (64, (4, 4, 4)), (8, (32, 32, 32))]:
     B = 2
