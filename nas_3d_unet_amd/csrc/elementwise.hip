@@ -1424,13 +1424,20 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const T* __restrict
       const float thr = k ? thr1 : thr0;
       const float4 fa = ld4(&fco[bi[i]][k][0][q * 4]), fb = ld4(&fco[bi[i]][k][1][q * 4]);
       const float aa[4] = {fa.x, fa.y, fa.z, fa.w}, bb[4] = {fb.x, fb.y, fb.z, fb.w};
+      float gmv[4], grv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float z = fmaf(aa[j], ra[k][j], bb[j]);
-        const float gm = (ok[i] && z > thr) ? dd[k][j] : 0.f;
-        const float s1 = wave_classsum_f(gm, cpg4), s2 = wave_classsum_f(gm * ra[k][j], cpg4);
-        if (lane < cpg4) { red[i * 16 + wave][k][q * 4 + j] = s1; red[i * 16 + wave][k][16 + q * 4 + j] = s2; }
+        gmv[j] = (ok[i] && z > thr) ? dd[k][j] : 0.f;
+        grv[j] = gmv[j] * ra[k][j];
       }
+      // the four channels of the quad reduced together (wave_classsum4_f): row r of the wave ends up with channel {0,2,1,3}[r]
+      class_dispatch16(cpg4, [&](auto cc) {
+        constexpr int CPB = decltype(cc)::value;
+        const float s1 = wave_classsum4_f<CPB>(gmv[0], gmv[1], gmv[2], gmv[3]), s2 = wave_classsum4_f<CPB>(grv[0], grv[1], grv[2], grv[3]);
+        const int l16 = lane & 15, j = classsum4_sel(lane);
+        if (l16 < CPB) { red[i * 16 + wave][k][l16 * 4 + j] = s1; red[i * 16 + wave][k][16 + l16 * 4 + j] = s2; }
+      });
     }
   }
   __syncthreads();

@@ -45,7 +45,11 @@ def test_trainer_dp_schedules_match_single_gpu(one_rank_group, graph, buckets, c
     os.environ.pop("N3D_FORCE_DP")
     try:
         net, _ = build_net("searched", "G_CONV", 4)
-        ref = Trainer(net, graph=graph)
+        # the bucketed exchange replays the single-stream schedule (graph segments), everything else the side-stream one: the
+        # reference trainer is given the same schedule, so the comparison is bit for bit (the two schedules differ by an fp32
+        # rounding of the preprocess epilogue backward, and Adam turns 1e-6 on a weight into 1e-3 within three steps:
+        # tools/dbg/chaos_probe.py; tests/test_gpu_side.py compares the schedules themselves)
+        ref = Trainer(net, graph=graph, side_wgrad=False if (graph and buckets > 1) else None)
         assert not ref.dp_path
         lr_, wr = _losses_and_weights(ref, x, t)
     finally:
@@ -56,10 +60,7 @@ def test_trainer_dp_schedules_match_single_gpu(one_rank_group, graph, buckets, c
     l, w = _losses_and_weights(tr, x, t)
     if graph and buckets > 1:
         assert tr._segments is not None and len(tr._segments) == buckets
-    # (the bucketed exchange replays the single-stream schedule, the reference trainer the side-stream one: the same arithmetic with
-    # the two preprocess epilogue backwards of a cell in one launch there and in two here -- a different fp32 rounding of the same sums)
-    np.testing.assert_allclose(l, lr_, rtol=0, atol=5e-6)
-    assert float((w - wr).abs().max()) <= 5e-6
+    assert l == lr_ and torch.equal(w, wr)
 
 
 def test_search_trainer_dp_matches_single_gpu(one_rank_group):
@@ -155,7 +156,11 @@ def test_two_processes_on_one_gpu_equal_the_global_batch(tmp_path, graph, bucket
         xs = rng.standard_normal((4, 4, 16, 16, 16)).astype(np.float32)
         ts = (rng.uniform(0, 1, (4, 3, 16, 16, 16)) < 0.3).astype(np.float32)
         net, _ = build_net("searched", "G_CONV", 2)
-        ref = Trainer(net, graph=graph)
+        # the bucketed exchange replays the single-stream schedule (graph segments), everything else the side-stream one: the
+        # reference trainer is given the same schedule, so the comparison is bit for bit (the two schedules differ by an fp32
+        # rounding of the preprocess epilogue backward, and Adam turns 1e-6 on a weight into 1e-3 within three steps:
+        # tools/dbg/chaos_probe.py; tests/test_gpu_side.py compares the schedules themselves)
+        ref = Trainer(net, graph=graph, side_wgrad=False if (graph and buckets > 1) else None)
         lr_ = [float(ref.step(dev(xs), dev(ts))) for _ in range(3)]
         wr = ref.fp.flat.detach().cpu()
     finally:
