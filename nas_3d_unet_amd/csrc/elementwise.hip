@@ -40,26 +40,26 @@ __device__ __forceinline__ void block_reduce_to_row(double (&vals)[NV * 4], int 
 }
 
 // The same for cpb a power of two <= 16 with the wave stage packed four values to a register (wave_classsum4_f): NT terms of
-// three kinds (s1, s2, sz) x 4 channels each, X[3 t + kind]; ONE LDS round and one barrier for all terms.  The wave stage is
-// fp32, the cross-wave sum fp64 as in block_reduce_to_row.  rows[t][(c4 * 4 + j) * 3 + kind].
-template <int NT, int cpb>
-__device__ __forceinline__ void block_reduce_packed_rows(const float (&X)[NT * 3], double* const (&rows)[NT],
-                                                         float* ldsf /* [4 waves][16][NT*3][4] */) {
+// NK kinds (s1, s2, sz / sum, sum of squares) x 4 channels each, X[NK t + kind]; ONE LDS round and one barrier for all terms.  The
+// wave stage is fp32, the cross-wave sum fp64 as in block_reduce_to_row.  rows[t][(c4 * 4 + j) * NK + kind].
+template <int NT, int NK, int cpb>
+__device__ __forceinline__ void block_reduce_packed_rows(const float (&X)[NT * NK], double* const (&rows)[NT],
+                                                         float* ldsf /* [4 waves][16][NT*NK][4] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15;
   if (l16 < cpb) {
-    float* o = ldsf + ((wave * 16 + l16) * (NT * 3)) * 4 + classsum4_sel(lane);
+    float* o = ldsf + ((wave * 16 + l16) * (NT * NK)) * 4 + classsum4_sel(lane);
 #pragma unroll
-    for (int q = 0; q < NT * 3; ++q) o[q * 4] = X[q];
+    for (int q = 0; q < NT * NK; ++q) o[q * 4] = X[q];
   }
   __syncthreads();
-  const int nq = cpb * NT * 12;
+  const int nq = cpb * NT * NK * 4;
   for (int i = threadIdx.x; i < nq; i += blockDim.x) {
-    const int c4 = i / (NT * 12), q = i % (NT * 12);     // q = (t * 3 + kind) * 4 + j
+    const int c4 = i / (NT * NK * 4), q = i % (NT * NK * 4);     // q = (t * NK + kind) * 4 + j
     double s = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s += (double)ldsf[(w * 16 + c4) * (NT * 12) + q];
-    const int t = q / 12, kind = (q % 12) / 4, j = q % 4;
-    rows[t][(c4 * 4 + j) * 3 + kind] = s;
+    for (int w = 0; w < 4; ++w) s += (double)ldsf[(w * 16 + c4) * (NT * NK * 4) + q];
+    const int t = q / (NK * 4), kind = (q % (NK * 4)) / 4, j = q % 4;
+    rows[t][(c4 * 4 + j) * NK + kind] = s;
   }
 }
 
@@ -91,10 +91,19 @@ __device__ __forceinline__ void channel_stats_body(const T* __restrict__ x, int6
       }
     }
   }
+  double* row = stats + ((int64_t)b * gridDim.x + blockIdx.x) * C * 2;
+  if (is_pow2(m.cpb) && m.cpb <= 16) {
+    class_dispatch16(m.cpb, [&](auto cc) {
+      constexpr int CPB = decltype(cc)::value;
+      const float X[2] = {wave_classsum4_f<CPB>(s[0], s[1], s[2], s[3]), wave_classsum4_f<CPB>(ss[0], ss[1], ss[2], ss[3])};
+      double* const rows[1] = {row};
+      block_reduce_packed_rows<1, 2, CPB>(X, rows, reinterpret_cast<float*>(lds));
+    });
+    return;
+  }
   double vals[8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) { vals[j] = s[j]; vals[4 + j] = ss[j]; }
-  double* row = stats + ((int64_t)b * gridDim.x + blockIdx.x) * C * 2;
   block_reduce_to_row<2>(vals, m.cpb, row, lds);
 }
 template <typename T>
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(const T* __restr
       const float X[3] = {wave_classsum4_f<CPB>(s1[0], s1[1], s1[2], s1[3]), wave_classsum4_f<CPB>(s2[0], s2[1], s2[2], s2[3]),
                           wave_classsum4_f<CPB>(sz[0], sz[1], sz[2], sz[3])};
       double* const rows[1] = {row};
-      block_reduce_packed_rows<1, CPB>(X, rows, reinterpret_cast<float*>(lds));
+      block_reduce_packed_rows<1, 3, CPB>(X, rows, reinterpret_cast<float*>(lds));
     });
     return;
   }
@@ -1216,7 +1225,7 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const T* __rest
 #ifdef EW_STAMP_R2
       ESTAMP(2);
 #endif
-      block_reduce_packed_rows<2, CPB>(X, rows, reinterpret_cast<float*>(lds));
+      block_reduce_packed_rows<2, 3, CPB>(X, rows, reinterpret_cast<float*>(lds));
     });
 #ifdef EW_STAMP_R2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1642,12 +1651,22 @@ __global__ __launch_bounds__(256) void affine_bwd_reduceN_kernel(const float* __
       }
     }
   }
+  double* row = tm.sums + ((int64_t)b * gridDim.x + blockIdx.x) * C * 3;
+  if (m.cpb <= 16) {
+    class_dispatch16(m.cpb, [&](auto cc) {
+      constexpr int CPB = decltype(cc)::value;
+      const float X[3] = {wave_classsum4_f<CPB>(s1[0], s1[1], s1[2], s1[3]), wave_classsum4_f<CPB>(s2[0], s2[1], s2[2], s2[3]),
+                          wave_classsum4_f<CPB>(sz[0], sz[1], sz[2], sz[3])};
+      double* const rows[1] = {row};
+      block_reduce_packed_rows<1, 3, CPB>(X, rows, reinterpret_cast<float*>(lds));
+    });
+    return;
+  }
   double vals[12];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     vals[j] = wave_classsum_f(s1[j], m.cpb); vals[4 + j] = wave_classsum_f(s2[j], m.cpb); vals[8 + j] = wave_classsum_f(sz[j], m.cpb);
   }
-  double* row = tm.sums + ((int64_t)b * gridDim.x + blockIdx.x) * C * 3;
   block_reduce_to_row<3>(vals, m.cpb, row, lds, true);
 }
 
