@@ -304,6 +304,7 @@ class SideSchedule:
         # live cuts: the slabs launched so far are reduced on the weight-gradient stream behind the n-th group (0 = never, -1 = at 55 %
         # of the groups the fullest pass so far had).  64^3 train step: tail 0.078 -> 0.064 ms, chain +0.001 (n = 11 of 20)
         self.early_at = int(os.environ.get("N3D_SIDE_EARLY_AT", "-1"))
+        self.tail_inline = tuple(int(c) for c in os.environ.get("N3D_SIDE_TAIL_INLINE", "2").split(",") if c.strip().isdigit())
         self._live_cuts = 0
         self._live_cuts_max = 0
         self.sync = torch.zeros(8 + self.JOIN + 8, dtype=torch.int32, device=device)
@@ -608,11 +609,16 @@ class SideSchedule:
                 K.stamp(self.trace.data_ptr() + 8 * (2 * i + 2))
             if self.live:
                 # the side stream takes the group now: wait for the flag, then the launches (their slab-reduction jobs are recorded)
-                with K.on_side(self.wstream):
-                    K.sync_wait(self.ptr(8 + i), self.wptr(), self.ptr(1), False)
-                    if self.split and self._side_tok is not None:
+                # the weight-gradient stream is backlogged at the end of the walk (the 64^3-level kernels: the join waited ~45 us
+                # behind the chain's last cut, tools/side_timeline.py) while the inline side stream is mostly idle there: the group
+                # tail_inline positions from the end (default: the second to last) goes to that stream instead; 1.865 -> 1.85 ms
+                inline = self.split and self._live_cuts_max >= 8 and (self._live_cuts_max - self._live_cuts) in self.tail_inline
+                with K.on_side(self.stream if inline else self.wstream):
+                    word = self.ptr(2) if inline else self.wptr()
+                    K.sync_wait(self.ptr(8 + i), word, self.ptr(1), False)
+                    if self.split and self._side_tok is not None and not inline:
                         # operands the SIDE stream produced (the d(raw) of its edges): behind its latest flag
-                        K.sync_wait(self.ptr(8 + self._side_tok), self.wptr(), self.ptr(1), False)
+                        K.sync_wait(self.ptr(8 + self._side_tok), word, self.ptr(1), False)
                     if self.trace is not None:
                         K.stamp(self.trace.data_ptr() + 8 * (2 * i + 3))
                     ctx.flush_wgrads()
