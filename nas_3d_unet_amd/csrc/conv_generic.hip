@@ -611,17 +611,20 @@ __global__ __launch_bounds__(256) void conv_k1_wgrad_kernel(K1WgArgs a) {
     }
   }
   const int wave = t >> 6, lane = t & 63;
+  static_assert(CO % 4 == 0, "k1 weight gradient: CO must be a multiple of 4");
+  const int sel = classsum4_sel(lane);       // (four accumulators per wave sum: see conv_wgrad_kernel)
+  const bool wr = (lane & 15) == 0;
 #pragma unroll
   for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
-    for (int c = 0; c < CO; ++c) {
-      const float sv = wave_sum_f(acc[ci][c]);
-      if (lane == 0) red[wave][ci * CO + c] = sv;
+    for (int c = 0; c < CO; c += 4) {
+      const float sv = wave_classsum4_f<1>(acc[ci][c], acc[ci][c + 1], acc[ci][c + 2], acc[ci][c + 3]);
+      if (wr) red[wave][ci * CO + c + sel] = sv;
     }
 #pragma unroll
-  for (int c = 0; c < CO; ++c) {
-    const float sv = wave_sum_f(accb[c]);
-    if (lane == 0) red[wave][CI * CO + c] = sv;
+  for (int c = 0; c < CO; c += 4) {
+    const float sv = wave_classsum4_f<1>(accb[c], accb[c + 1], accb[c + 2], accb[c + 3]);
+    if (wr) red[wave][CI * CO + c + sel] = sv;
   }
   __syncthreads();
   for (int j = t; j < NV; j += 256) {
@@ -736,17 +739,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       for (int j = 0; j < CO_T; ++j) acc[c][j] = fmaf(xv[c], dyv[j], acc[c][j]);
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // wave sums four accumulators at a time (wave_classsum4_f: 3 permlane swaps per four values instead of 8): row r of the wave ends up
+  // with the total of value {0, 2, 1, 3}[r], its first lane writes it
+  static_assert(CO_T % 4 == 0, "conv_wgrad_kernel: CO_T must be a multiple of 4");
+  const int sel = classsum4_sel(lane);
+  const bool wr = (lane & 15) == 0;
 #pragma unroll
   for (int c = 0; c < CI_T; ++c)
 #pragma unroll
-    for (int j = 0; j < CO_T; ++j) {
-      const float s = wave_sum_f(acc[c][j]);
-      if (lane == 0) red[wave][c * CO_T + j] = s;
+    for (int j = 0; j < CO_T; j += 4) {
+      const float s = wave_classsum4_f<1>(acc[c][j], acc[c][j + 1], acc[c][j + 2], acc[c][j + 3]);
+      if (wr) red[wave][c * CO_T + j + sel] = s;
     }
 #pragma unroll
-  for (int j = 0; j < CO_T; ++j) {
-    const float s = wave_sum_f(bacc[j]);
-    if (lane == 0) red[wave][CI_T * CO_T + j] = s;
+  for (int j = 0; j < CO_T; j += 4) {
+    const float s = wave_classsum4_f<1>(bacc[j], bacc[j + 1], bacc[j + 2], bacc[j + 3]);
+    if (wr) red[wave][CI_T * CO_T + j + sel] = s;
   }
   __syncthreads();
   const int ntiles = gridDim.y;
@@ -1470,9 +1478,11 @@ static WgradPlan wgrad_plan(int B, int64_t No, int Ci, int Co, int taps) {
   const int64_t total = (int64_t)B * No;
   // short chunks: the voxel loop of the kernel is a dependent load -> FMA chain (one memory latency per
   // iteration), so per-thread trip count, not block count, sets the kernel time on these small problems
-  int64_t nch = cdiv(total, 512);
+  static const int chunk0 = getenv("N3D_WGRAD_CHUNK") ? atoi(getenv("N3D_WGRAD_CHUNK")) : 512;     // (tuning knobs)
+  static const int max_wgs = getenv("N3D_WGRAD_MAX_WGS") ? atoi(getenv("N3D_WGRAD_MAX_WGS")) : 8192;
+  int64_t nch = cdiv(total, chunk0);
   // keep the grid around a few thousand blocks
-  while (nch * p.ntiles > 8192 && nch > 1) nch = (nch + 1) / 2;
+  while (nch * p.ntiles > max_wgs && nch > 1) nch = (nch + 1) / 2;
   if (nch > 512) nch = 512;
   p.chunk = cdiv(total, nch);
   p.chunk = cdiv(p.chunk, 256) * 256;
