@@ -95,10 +95,13 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
   }
   if (!a.partial) return;
   const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-  for (int co = 0; co < HEAD_COMAX; ++co) {
-    const double d0 = wave_sum_d(spt[co]), d1 = wave_sum_d(sp[co]), d2 = wave_sum_d(st[co]);
-    if (lane == 0) { red[co * 3][wave] = d0; red[co * 3 + 1][wave] = d1; red[co * 3 + 2][wave] = d2; }
+  {
+    // the four channels of each of the three sums together (wave_sum4_d): row r of the wave ends up with channel {0, 2, 1, 3}[r]
+    static_assert(HEAD_COMAX == 4, "head_fwd: packed wave sums");
+    const double d0 = wave_sum4_d(spt[0], spt[1], spt[2], spt[3]), d1 = wave_sum4_d(sp[0], sp[1], sp[2], sp[3]),
+                 d2 = wave_sum4_d(st[0], st[1], st[2], st[3]);
+    const int co = classsum4_sel(lane);
+    if ((lane & 15) == 0) { red[co * 3][wave] = d0; red[co * 3 + 1][wave] = d1; red[co * 3 + 2][wave] = d2; }
   }
   __syncthreads();
   if (tid < a.Co * 3) {
@@ -233,15 +236,21 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   if (!a.partial) return;
   // block sums -> one partial slab [ci][co] (+ bias row) per workgroup; the common fixed-order finalize adds the slabs
   const int wave = tid >> 6, lane = tid & 63;
+  // (four accumulators per wave sum, wave_classsum4_f: row r of the wave ends up with the total of value {0, 2, 1, 3}[r])
+  static_assert(CI % 4 == 0 && HEAD_COMAX == 4, "head_bwd: packed wave sums");
+  const int sel = classsum4_sel(lane);
+  const bool wr = (lane & 15) == 0;
 #pragma unroll
   for (int co = 0; co < HEAD_COMAX; ++co) {
 #pragma unroll
-    for (int ci = 0; ci < CI; ++ci) {
-      const float s = wave_sum_f(acc[co][ci]);
-      if (lane == 0) red[wave][ci * HEAD_COMAX + co] = s;
+    for (int ci = 0; ci < CI; ci += 4) {
+      const float s = wave_classsum4_f<1>(acc[co][ci], acc[co][ci + 1], acc[co][ci + 2], acc[co][ci + 3]);
+      if (wr) red[wave][(ci + sel) * HEAD_COMAX + co] = s;
     }
-    const float sb = wave_sum_f(accb[co]);
-    if (lane == 0) red[wave][HEAD_COMAX * CI + co] = sb;
+  }
+  {
+    const float sb = wave_classsum4_f<1>(accb[0], accb[1], accb[2], accb[3]);
+    if (wr) red[wave][HEAD_COMAX * CI + sel] = sb;
   }
   __syncthreads();
   const int chunk = b * a.chunks_per_sample + blockIdx.x;

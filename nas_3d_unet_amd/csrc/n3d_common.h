@@ -209,6 +209,23 @@ __device__ __forceinline__ void class_dispatch16(int cpb, F&& f) {
     default: f(std::integral_constant<int, 16>{}); break;
   }
 }
+// the same for four doubles, whole-wave sums: row r of the wave returns the total of v[{0, 2, 1, 3}[r]] (6 swaps instead of 16)
+__device__ __forceinline__ double wave_sum4_d(double v0, double v1, double v2, double v3) {
+  auto lo = [](double v) { return (int)(__builtin_bit_cast(long long, v) & 0xffffffffll); };
+  auto hi = [](double v) { return (int)(__builtin_bit_cast(long long, v) >> 32); };
+  auto mk = [](int l, int h) { return __builtin_bit_cast(double, ((long long)h << 32) | (unsigned int)l); };
+  const auto l01 = __builtin_amdgcn_permlane32_swap(lo(v0), lo(v1), false, false), h01 = __builtin_amdgcn_permlane32_swap(hi(v0), hi(v1), false, false);
+  const auto l23 = __builtin_amdgcn_permlane32_swap(lo(v2), lo(v3), false, false), h23 = __builtin_amdgcn_permlane32_swap(hi(v2), hi(v3), false, false);
+  const double ab = mk((int)l01[0], (int)h01[0]) + mk((int)l01[1], (int)h01[1]);
+  const double cd = mk((int)l23[0], (int)h23[0]) + mk((int)l23[1], (int)h23[1]);
+  const auto lx = __builtin_amdgcn_permlane16_swap(lo(ab), lo(cd), false, false), hx = __builtin_amdgcn_permlane16_swap(hi(ab), hi(cd), false, false);
+  double x = mk((int)lx[0], (int)hx[0]) + mk((int)lx[1], (int)hx[1]);
+  x += dpp_d<0x128>(x);   // row_ror:8
+  x += dpp_d<0x124>(x);   // row_ror:4
+  x += dpp_d<0x4E>(x);    // quad_perm [2,3,0,1]
+  x += dpp_d<0xB1>(x);    // quad_perm [1,0,3,2]
+  return x;
+}
 // the value index (0..3) that wave_classsum4_f leaves in this lane's row
 __device__ __forceinline__ int classsum4_sel(int lane) { return ((lane >> 4) & 1) * 2 + (lane >> 5); }
 __device__ __forceinline__ double wave_classsum_d(double v, int cpb) {
