@@ -67,6 +67,7 @@ __device__ __forceinline__ f32x4 mfma_bf16_4x4x4(const uint2 a, const uint2 b, c
 // voxel pitch 24 bytes) cannot be fetched in pairs and keep the slot image.
 template <int C, int TD, int DIL, int NW, bool P2 = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
+  N3D_CHAIN_PRIO();
   static_assert(!P2 || C == 4, "the dense two-voxels-per-slot image is the C = 4 form");
   constexpr int HF = C / 4, GH = 4 * NW, GW = 16;
   constexpr int LD = TD + 2 * DIL, LH = GH + 2 * DIL, LW = GW + 2 * DIL;
@@ -352,6 +353,7 @@ struct Vs2bArgs {
 
 template <int C, int TD, int DIL>
 __global__ __launch_bounds__(64, 2) void conv_vox_s2b_kernel(Vs2bArgs a) {
+  N3D_CHAIN_PRIO();
   constexpr int HF = C / 4;
   constexpr int LD = 2 * (TD - 1) + 2 * DIL + 1, LH = 7 + 2 * DIL, LW = 31 + 2 * DIL;
   constexpr int HW = (LW + 1) / 2, RW = 2 * HW;
@@ -483,6 +485,7 @@ __host__ __device__ constexpr int vupb_k(int dil, int s, int i) { return dil == 
 
 template <int C, int DIL>
 __global__ __launch_bounds__(64, 2) void conv_vox_upb_kernel(VupbArgs a) {
+  N3D_CHAIN_PRIO();
   constexpr int HF = C / 4;
   constexpr int LD = 3, LH = 6, LW = 18;
   constexpr int PLANE = LH * LW, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64;

@@ -46,6 +46,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 
 template <int CO_T, int SV, int CSQ, typename TS = float, typename TD = float>
 __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
+  N3D_CHAIN_PRIO();
   __shared__ double red[4][CO_T * 2];
   const int b = blockIdx.z, cot = blockIdx.y;
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd, Ns = (int64_t)a.Ds * a.Hs * a.Ws;
@@ -371,6 +372,7 @@ constexpr int K1_VPB = 1024;   // voxels per workgroup
 // EXTRA: the data-gradient extras (accumulate into dst, ReLU mask source) are in use -- they cost 8 * CDQ registers per voxel
 template <int CSQ, int CDQ, bool EXTRA, typename TS = float, typename TD = float>   // Cs = 4 * CSQ, Cd = 4 * CDQ
 __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
+  N3D_CHAIN_PRIO();
   constexpr int VPT = EXTRA ? 2 : K1_VPB / 256;   // data-gradient form: no statistics rows to agree on, fewer registers per voxel
   __shared__ __attribute__((aligned(16))) float4 wl[CSQ * 4 * CDQ];
   __shared__ double red[4][CDQ * 8];
@@ -851,11 +853,11 @@ __device__ __forceinline__ void dw_gather_body(const DwArgs& a) {
   }
   *op = make_float4(acc.x + prev.x, acc.y + prev.y, acc.z + prev.z, acc.w + prev.w);
 }
-__global__ __launch_bounds__(256) void dw_gather_kernel(DwArgs a) { dw_gather_body(a); }
+__global__ __launch_bounds__(256) void dw_gather_kernel(DwArgs a) { N3D_CHAIN_PRIO(); dw_gather_body(a); }
 // the depthwise convs of up to 8 primitives of a supernet node (one per edge, cell.py:76-81) in one launch: grid.z = job; all
 // jobs share the output shape and channel count (blockIdx.x covers the output voxels), their sources may differ in shape
 struct DwArgsN { DwArgs j[8]; };
-__global__ __launch_bounds__(256) void dw_gatherN_kernel(DwArgsN js) {
+__global__ __launch_bounds__(256) void dw_gatherN_kernel(DwArgsN js) { N3D_CHAIN_PRIO();
   DwArgs a;
   switch (blockIdx.z) { case 0: a = js.j[0]; break; case 1: a = js.j[1]; break; case 2: a = js.j[2]; break; case 3: a = js.j[3]; break;
                         case 4: a = js.j[4]; break; case 5: a = js.j[5]; break; case 6: a = js.j[6]; break; default: a = js.j[7]; break; }

@@ -67,6 +67,7 @@ extern "C" int n3d_debug_g16_stamps(unsigned long long* host, int n) {
 
 template <int MT, int NT, int KSPLIT>
 __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const int by, float* lds) {
+  N3D_CHAIN_PRIO();
   // the wave index as a SCALAR: the K-slice a wave owns (tap, channel block, their offsets) is then computed on the scalar unit
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 15, kk = lane >> 4;
@@ -676,6 +677,7 @@ extern "C" int n3d_debug_vox_stamps2(unsigned long long* host, int n) {
 #endif
 template <int C, int TD, int DIL, int NW>
 __global__ __launch_bounds__(64 * NW, VOX_LB) void conv_vox64_kernel(VxArgs a) {
+  N3D_CHAIN_PRIO();
   constexpr int Q = C / 4, GH = 4 * NW, GW = 16;
   constexpr int LD = TD + 2 * DIL, LH = GH + 2 * DIL, LW = GW + 2 * DIL;
   constexpr int PLANE = LH * LW, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64, QSTRIDE = LD * PSTRIDE;
@@ -967,6 +969,7 @@ struct Vs2Args {
 
 template <int C, int TD, int DIL>
 __global__ __launch_bounds__(64, 2) void conv_vox_s2_kernel(Vs2Args a) {
+  N3D_CHAIN_PRIO();
   constexpr int Q = C / 4;
   constexpr int LD = 2 * (TD - 1) + 2 * DIL + 1, LH = 7 + 2 * DIL, LW = 31 + 2 * DIL;
   constexpr int HW = (LW + 1) / 2, RW = 2 * HW;              // half-row (one W parity) and row pitch in float4
@@ -1185,6 +1188,7 @@ __host__ __device__ constexpr int vup_k(int dil, int s, int i) { return dil == 2
 
 template <int C, int DIL>
 __global__ __launch_bounds__(64, 2) void conv_vox_up_kernel(VupArgs a) {
+  N3D_CHAIN_PRIO();
   constexpr int Q = C / 4;
   constexpr int LD = 3, LH = 6, LW = 18;
   constexpr int PLANE = LH * LW, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64, QSTRIDE = LD * PSTRIDE;
@@ -1999,6 +2003,7 @@ int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const flo
 // ------------------------------------------------------------------------------------------------
 template <int DIL, bool DG>
 __global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const void* zero_page, int tiles) {
+  N3D_CHAIN_PRIO();
   constexpr int TD = 2, TH = 4, TW = 16;
   constexpr int LD = TD + 2 * DIL, LH = TH + 2 * DIL, LW = TW + 2 * DIL, NV = LD * LH * LW;
   constexpr int NP = NV * 4, NIT = (NP + 255) / 256;   // float4 pieces of the halo tile, DMA instructions per thread
@@ -2130,6 +2135,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const voi
 // ------------------------------------------------------------------------------------------------
 template <int DIL>
 __global__ __launch_bounds__(256, 2) void conv_tile16_up_kernel(MfArgs a, const void* zero_page, int tiles) {
+  N3D_CHAIN_PRIO();
   constexpr int TH = 4, TW = 16;
   constexpr int LO = DIL == 2 ? 1 : 0;                   // source halo below (above: always 1)
   constexpr int LD = 1 + LO + 1, LH = TH + LO + 1, LW = TW + LO + 1, NV = LD * LH * LW;

@@ -108,12 +108,12 @@ __device__ __forceinline__ void channel_stats_body(const T* __restrict__ x, int6
 }
 template <typename T>
 __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, int64_t ld, int64_t N, int C,
-                                                            EwMap m, double* __restrict__ stats) {
+                                                            EwMap m, double* __restrict__ stats) { N3D_CHAIN_PRIO();
   channel_stats_body(x, ld, N, C, m, stats);
 }
 // up to 8 tensors of one shape in one launch (grid.z = tensor): the inputs of a supernet node's primitives
 struct StatsJobN { const float* x[8]; int64_t ld[8]; double* stats[8]; };
-__global__ __launch_bounds__(256) void channel_statsN_kernel(StatsJobN js, int64_t N, int C, EwMap m) {
+__global__ __launch_bounds__(256) void channel_statsN_kernel(StatsJobN js, int64_t N, int C, EwMap m) { N3D_CHAIN_PRIO();
   const float* x; int64_t ld; double* st;
   switch (blockIdx.z) {
     case 0: x = js.x[0]; ld = js.ld[0]; st = js.stats[0]; break; case 1: x = js.x[1]; ld = js.ld[1]; st = js.stats[1]; break;
@@ -188,6 +188,7 @@ __device__ __forceinline__ void gn_coeffs_body(const GnCoefArgs q, int C, int G,
 }
 // grid (B, terms): blockIdx.y selects the op (two ops of a searched-cell node share one launch)
 __global__ __launch_bounds__(256) void gn_coeffs_kernel(GnCoefArgs q0, GnCoefArgs q1, int C, int G, double count, float eps) {
+  N3D_CHAIN_PRIO();
   gn_coeffs_body(blockIdx.y ? q1 : q0, C, G, count, eps);
 }
 // up to N3D_MAX_GROUP_TERMS ops of a supernet node in one launch: grid (B, terms).  The descriptors live in the kernel
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(GnCoefArgs q0, GnCoefArg
   switch (i) { case 0: dst = arr[0]; break; case 1: dst = arr[1]; break; case 2: dst = arr[2]; break; case 3: dst = arr[3]; break; \
                case 4: dst = arr[4]; break; case 5: dst = arr[5]; break; case 6: dst = arr[6]; break; default: dst = arr[7]; break; }
 struct GnCoefArgsN { GnCoefArgs q[8]; };
-__global__ __launch_bounds__(256) void gn_coeffsN_kernel(GnCoefArgsN qs, int C, int G, double count, float eps) {
+__global__ __launch_bounds__(256) void gn_coeffsN_kernel(GnCoefArgsN qs, int C, int G, double count, float eps) { N3D_CHAIN_PRIO();
   GnCoefArgs q;
   N3D_PICK8(qs.q, blockIdx.y, q);
   gn_coeffs_body(q, C, G, count, eps);
@@ -209,6 +210,7 @@ template <bool RELU, bool ACC, typename T = float>
 __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ raw, int64_t rld, const float* __restrict__ a,
                                                          const float* __restrict__ bb, const float* __restrict__ wptr,
                                                          T* __restrict__ out, int64_t old_, int64_t N, int C, EwMap m) {
+  N3D_CHAIN_PRIO();
   const int b = blockIdx.y;
   const int t = threadIdx.x;
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
@@ -245,6 +247,7 @@ template <bool RELU, typename T = float>
 __global__ __launch_bounds__(256) void affine_bwd_reduce_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ raw,
                                                                 int64_t rld, const float* __restrict__ a, const float* __restrict__ bb,
                                                                 int64_t N, int C, EwMap m, double* __restrict__ sums) {
+  N3D_CHAIN_PRIO();
   __shared__ double lds[4 * 64 * 12];
   const int b = blockIdx.y;
   const int t = threadIdx.x;
@@ -416,10 +419,11 @@ __device__ __forceinline__ void gn_bwd_coeffs_body(const GnBwdCoefArgs q, int B,
 }
 // grid (terms): blockIdx.x selects the op
 __global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffs_kernel(GnBwdCoefArgs q0, GnBwdCoefArgs q1, int B, int C, int G, double count) {
+  N3D_CHAIN_PRIO();
   gn_bwd_coeffs_body(blockIdx.x ? q1 : q0, B, C, G, count);
 }
 struct GnBwdCoefArgsN { GnBwdCoefArgs q[8]; };
-__global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffsN_kernel(GnBwdCoefArgsN qs, int B, int C, int G, double count) {
+__global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffsN_kernel(GnBwdCoefArgsN qs, int B, int C, int G, double count) { N3D_CHAIN_PRIO();
   GnBwdCoefArgs q;
   N3D_PICK8(qs.q, blockIdx.x, q);
   gn_bwd_coeffs_body(q, B, C, G, count);
@@ -470,6 +474,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_kernel(const T* __restri
                                                                const float* __restrict__ A, const float* __restrict__ Bc,
                                                                const float* __restrict__ Cc, T* __restrict__ draw, int64_t drld,
                                                                int64_t N, int C, EwMap m) {
+  N3D_CHAIN_PRIO();
   const int b = blockIdx.y;
   const int t = threadIdx.x;
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
@@ -519,6 +524,7 @@ __global__ __launch_bounds__(256) void affine_act_gn_kernel(const T* __restrict_
                                                             float eps, const float* __restrict__ wptr, T* __restrict__ out, int64_t old_,
                                                             int64_t N, int C, EwMap m, float* __restrict__ a_out, float* __restrict__ b_out,
                                                             float* __restrict__ mr_out, double* __restrict__ sumraw) {
+  N3D_CHAIN_PRIO();
   __shared__ double part[256];
   __shared__ double tot[128];
   __shared__ float ab[2][64];
@@ -796,6 +802,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const T* __res
                                                                   T* __restrict__ draw, int64_t drld, int64_t N, int C, EwMap m,
                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dalpha,
                                                                   float* __restrict__ dbias_conv) {
+  N3D_CHAIN_PRIO();
   __shared__ double part[256];
   __shared__ double tot[192];
   __shared__ double gc[64 * 2];
@@ -1042,6 +1049,7 @@ __device__ __forceinline__ void gn_fwd_prologue_wave(const GnFwdTerm& t, const i
 template <bool ACC, bool PRE, typename T = float>
 __global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwdTerm t1, int G, double count, float eps, T* __restrict__ out,
                                                              int64_t old_, T* __restrict__ out1, int64_t old1, int64_t N, int C, EwMap m) {
+  N3D_CHAIN_PRIO();
   __shared__ __attribute__((aligned(16))) float abw[4][2][2][64];  // [wave][term][a|b][channel]
   const int b = blockIdx.y, t = threadIdx.x, wave = t >> 6;
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
@@ -1149,6 +1157,7 @@ struct BwdRedTerm { const float* raw; int64_t rld; const float* a; const float* 
 template <bool TWO, typename T = float>
 __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ dout1,
                                                                  int64_t dld1, BwdRedTerm t0, BwdRedTerm t1, int64_t N, int C, EwMap m) {
+  N3D_CHAIN_PRIO();
   __shared__ double lds[4 * 64 * 12];
   const int b = blockIdx.y;
   const int t = threadIdx.x;
@@ -1262,6 +1271,7 @@ template <bool PRE, bool TWO, typename T = float>
 __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ dout1,
                                                                    int64_t dld1, GnBwdTerm t0, GnBwdTerm t1, int B, int G, double count, int64_t N,
                                                                    int C, EwMap m) {
+  N3D_CHAIN_PRIO();
   __shared__ __attribute__((aligned(16))) float cw[4][2][3][64];  // [wave][term][A|B|C][channel]
   const int t = threadIdx.x, wave = t >> 6;
   AESTAMP(0);
@@ -1384,6 +1394,7 @@ template <int QPT, bool TWO, bool SPLIT, int NT, typename T = float>
 __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const T* __restrict__ dout, int64_t dld, const T* __restrict__ dout1,
                                                             int64_t dld1, GnBwdTerm t0, GnBwdTerm t1, int B, int N, int C, int G, double count,
                                                             double* __restrict__ scratch, unsigned* __restrict__ tickets) {
+  N3D_CHAIN_PRIO();
   constexpr int MB = SPLIT ? 1 : 4;
   __shared__ float red[QPT * 16][2][32];   // [slot = i*16 + wave][term][(S1 | S2) x 16 channels]
   __shared__ double tot[MB][2][32];        // [b][term][(S1 | S2) x 16 channels]
@@ -1563,7 +1574,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_small2_kernel(const T* __restrict
 struct FwdTermN { const float* raw[8]; int64_t rld[8]; const float* a[8]; const float* b[8]; const float* wptr[8]; int relu[8]; int n; };
 
 template <bool ACC>
-__global__ __launch_bounds__(256) void affine_actN_kernel(FwdTermN ts, float* __restrict__ out, int64_t old_, int64_t N, int C, EwMap m) {
+__global__ __launch_bounds__(256) void affine_actN_kernel(FwdTermN ts, float* __restrict__ out, int64_t old_, int64_t N, int C, EwMap m) { N3D_CHAIN_PRIO();
   const int b = blockIdx.y, t = threadIdx.x;
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   if (vl >= m.vpb) return;
@@ -1607,7 +1618,7 @@ __global__ __launch_bounds__(256) void affine_actN_kernel(FwdTermN ts, float* __
 struct BwdRedTermN { BwdRedTerm t[8]; };
 // grid (rows, B, terms): the reduction pass of affine_bwd_reduce2_kernel for term blockIdx.z
 __global__ __launch_bounds__(256) void affine_bwd_reduceN_kernel(const float* __restrict__ dout, int64_t dld, BwdRedTermN ts, int64_t N, int C,
-                                                                 EwMap m) {
+                                                                 EwMap m) { N3D_CHAIN_PRIO();
   __shared__ double lds[4 * 64 * 12];
   BwdRedTerm tm;
   N3D_PICK8(ts.t, blockIdx.z, tm);
@@ -1675,7 +1686,7 @@ struct BwdApplyTerm { const float* raw; int64_t rld; const float* a; const float
 struct BwdApplyTermN { BwdApplyTerm t[8]; };
 // grid (rows, B, terms): draw = cA * g + cB + cC * raw of term blockIdx.z (g = dout behind the term's ReLU mask)
 __global__ __launch_bounds__(256) void affine_bwd_applyN_kernel(const float* __restrict__ dout, int64_t dld, BwdApplyTermN ts, int64_t N, int C,
-                                                                EwMap m) {
+                                                                EwMap m) { N3D_CHAIN_PRIO();
   BwdApplyTerm tm;
   N3D_PICK8(ts.t, blockIdx.z, tm);
   const int b = blockIdx.y, t = threadIdx.x;
@@ -1743,7 +1754,7 @@ __device__ __forceinline__ void se_gate_fwd_body(const double* __restrict__ stat
 }
 __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const double* __restrict__ stats, int rows, double count, const float* __restrict__ w1,
                                                           const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
-                                                          int C, float* __restrict__ mean, float* __restrict__ hidden, float* __restrict__ gate) {
+                                                          int C, float* __restrict__ mean, float* __restrict__ hidden, float* __restrict__ gate) { N3D_CHAIN_PRIO();
   se_gate_fwd_body(stats, rows, count, w1, b1, w2, b2, C, mean, hidden, gate);
 }
 // the SE gates of up to 8 primitives of a supernet node: grid (B, gates) forward, grid (gates) backward
@@ -1752,7 +1763,7 @@ struct SeTerm {
   const float* wptr; float* dw1; float* db1; float* dw2; float* db2; float* dalpha; float* A; float* Bc;
 };
 struct SeTermN { SeTerm t[8]; };
-__global__ __launch_bounds__(256) void se_gate_fwdN_kernel(SeTermN ts, double count, int C) {
+__global__ __launch_bounds__(256) void se_gate_fwdN_kernel(SeTermN ts, double count, int C) { N3D_CHAIN_PRIO();
   SeTerm q;
   N3D_PICK8(ts.t, blockIdx.y, q);
   se_gate_fwd_body(q.sums, q.rows, count, q.w1, q.b1, q.w2, q.b2, C, q.mean, q.hidden, q.gate);
@@ -1816,10 +1827,10 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const double* __restri
                                                           const float* __restrict__ gate, const float* __restrict__ w1,
                                                           const float* __restrict__ w2, int B, int C, double count, float* __restrict__ dw1,
                                                           float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
-                                                          float* __restrict__ dalpha, float* __restrict__ A, float* __restrict__ Bc) {
+                                                          float* __restrict__ dalpha, float* __restrict__ A, float* __restrict__ Bc) { N3D_CHAIN_PRIO();
   se_gate_bwd_body(sums, rows, wptr, mean, hidden, gate, w1, w2, B, C, count, dw1, db1, dw2, db2, dalpha, A, Bc);
 }
-__global__ __launch_bounds__(256) void se_gate_bwdN_kernel(SeTermN ts, int B, int C, double count) {
+__global__ __launch_bounds__(256) void se_gate_bwdN_kernel(SeTermN ts, int B, int C, double count) { N3D_CHAIN_PRIO();
   SeTerm q;
   N3D_PICK8(ts.t, blockIdx.x, q);
   se_gate_bwd_body(q.sums, q.rows, q.wptr, q.mean, q.hidden, q.gate, q.w1, q.w2, B, C, count, q.dw1, q.db1, q.dw2, q.db2, q.dalpha, q.A, q.Bc);
@@ -1830,7 +1841,7 @@ __global__ __launch_bounds__(256) void se_gate_bwdN_kernel(SeTermN ts, int B, in
 // ------------------------------------------------------------------------------------------------
 template <bool MAX>
 __global__ __launch_bounds__(256) void pool2_fwd_kernel(const float* __restrict__ x, int64_t xld, float* __restrict__ y, int64_t yld, int Di,
-                                                        int Hi, int Wi, int C) {
+                                                        int Hi, int Wi, int C) { N3D_CHAIN_PRIO();
   const int Do = Di / 2, Ho = Hi / 2, Wo = Wi / 2;
   const int cpb = C / 4;
   const int64_t total = (int64_t)Do * Ho * Wo * cpb;
@@ -1862,7 +1873,7 @@ __global__ __launch_bounds__(256) void pool2_fwd_kernel(const float* __restrict_
 
 // average AND max pooling of one tensor in one pass (a stride-2 edge of a down cell carries both primitives, prim_ops.py:29-30)
 __global__ __launch_bounds__(256) void pool2_fwd_both_kernel(const float* __restrict__ x, int64_t xld, float* __restrict__ ya, int64_t yald,
-                                                             float* __restrict__ ym, int64_t ymld, int Di, int Hi, int Wi, int C) {
+                                                             float* __restrict__ ym, int64_t ymld, int Di, int Hi, int Wi, int C) { N3D_CHAIN_PRIO();
   const int Do = Di / 2, Ho = Hi / 2, Wo = Wi / 2;
   const int cpb = C / 4;
   const int64_t total = (int64_t)Do * Ho * Wo * cpb;
@@ -1897,7 +1908,7 @@ __global__ __launch_bounds__(256) void pool2_fwd_both_kernel(const float* __rest
 template <bool ACC>
 __global__ __launch_bounds__(256) void pool2_bwd_both_kernel(const float* __restrict__ dy, int64_t dyld, const float* __restrict__ x, int64_t xld,
                                                              float* __restrict__ dx, int64_t dxld, int Di, int Hi, int Wi, int C,
-                                                             const float* __restrict__ wa, const float* __restrict__ wm) {
+                                                             const float* __restrict__ wa, const float* __restrict__ wm) { N3D_CHAIN_PRIO();
   const int Do = Di / 2, Ho = Hi / 2, Wo = Wi / 2;
   const int cpb = C / 4;
   const int64_t total = (int64_t)Do * Ho * Wo * cpb;
@@ -1944,7 +1955,7 @@ __global__ __launch_bounds__(256) void pool2_bwd_both_kernel(const float* __rest
 template <bool MAX, bool ACC>
 __global__ __launch_bounds__(256) void pool2_bwd_kernel(const float* __restrict__ dy, int64_t dyld, const float* __restrict__ x, int64_t xld,
                                                         float* __restrict__ dx, int64_t dxld, int Di, int Hi, int Wi, int C,
-                                                        const float* __restrict__ wptr) {
+                                                        const float* __restrict__ wptr) { N3D_CHAIN_PRIO();
   const int Do = Di / 2, Ho = Hi / 2, Wo = Wi / 2;
   const int cpb = C / 4;
   const int64_t total = (int64_t)Do * Ho * Wo * cpb;

@@ -45,6 +45,7 @@ struct HeadFwdArgs {
 // thread = voxel; lanes walk consecutive voxels (x: Ci * sizeof(TX) contiguous bytes per voxel, p / t: strided per channel)
 template <typename TX, int CIQ>
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
+  N3D_CHAIN_PRIO();
   constexpr int CI = CIQ * 4;
   __shared__ float wsm[HEAD_COMAX][CI];
   __shared__ double red[HEAD_COMAX * 3][4];
@@ -151,6 +152,7 @@ struct HeadBwdArgs {
 // dx[ci] = gate[ci] * sum_co W[co][ci] * dlogit[co];  dW[co][ci] = gate[ci] * sum_v dlogit[co] * x[ci];  dbias[co] = sum_v dlogit[co]
 template <typename TX, typename TD, int CIQ>
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
+  N3D_CHAIN_PRIO();
   constexpr int CI = CIQ * 4, NV = HEAD_COMAX * CI + HEAD_COMAX;
   __shared__ float wsm[HEAD_COMAX][CI];
   __shared__ float gsm[CI];
