@@ -297,7 +297,7 @@ class SideSchedule:
         with the preprocess-fed edges of its forward and backward); without it, or when no second stream passes the probe, the
         weight gradients share the one side stream"""
         self.device, self.ctx = device, ctx
-        self.min_queue = int(os.environ.get("N3D_SIDE_MIN_QUEUE", "3")) if min_queue is None else int(min_queue)
+        self.min_queue = int(os.environ.get("N3D_SIDE_MIN_QUEUE", "5")) if min_queue is None else int(min_queue)
         # cuts from the end at which the side stream reduces the slabs it has so far (0 = off, the default: measured at 64^3 the
         # tail shrinks 66 -> 49 us but the reduction takes 24 us out of the chain it runs beside)
         self.early_finalize = int(os.environ.get("N3D_SIDE_EARLY_FINALIZE", "0"))
