@@ -260,28 +260,37 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
     // tiny GEMM: every operand this wave will ever need is requested up front (<= 8 groups, 16 float4 per lane),
     // so the whole K loop costs one memory round trip.  (KSPLIT == 4: the 16-channel convs of the 16^3 level, 27 groups over four
     // waves -- the two-buffer walk below took seven round trips there)
-    float4 avs[8][MT], bvs[8][NT];
-    if (a.in_gate) {
+    // The number of groups per wave is dispatched to a compile-time count (2 / 4 / 8): the loop used to run eight times with the
+    // groups beyond the wave's share clamped to the last one -- loads and address arithmetic issued for nothing, 1.7 useful
+    // iterations of 8 for a 16-channel conv, 3.4 for 32 channels -- and issue slots are what this kernel is short of.
+    auto tiny = [&](auto ni_c) {
+      constexpr int NI = decltype(ni_c)::value;
+      float4 avs[NI][MT], bvs[NI][NT];
+      if (a.in_gate) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int g = wave + i * KSPLIT;
-        load_group(std::true_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i]);
-      }
-    } else {
+        for (int i = 0; i < NI; ++i) {
+          const int g = wave + i * KSPLIT;
+          load_group(std::true_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i]);
+        }
+      } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int g = wave + i * KSPLIT;
-        load_group(std::false_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i]);
+        for (int i = 0; i < NI; ++i) {
+          const int g = wave + i * KSPLIT;
+          load_group(std::false_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i]);
+        }
       }
-    }
-    GSTAMP(2);
+      GSTAMP(2);
 #ifdef G16_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GSTAMP(3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      GSTAMP(3);
 #endif
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (wave + i * KSPLIT < ngroups) mfma_group(avs[i], bvs[i]);
+      for (int i = 0; i < NI; ++i)
+        if (wave + i * KSPLIT < ngroups) mfma_group(avs[i], bvs[i]);
+    };
+    if (ngroups <= KSPLIT * 2) tiny(std::integral_constant<int, 2>{});
+    else if (ngroups <= KSPLIT * 4) tiny(std::integral_constant<int, 4>{});
+    else tiny(std::integral_constant<int, 8>{});
   } else {
     const int g0 = (KSPLIT > 1 ? wave : 0), step = (KSPLIT > 1 ? KSPLIT : 1);
     float4 avA[MT], bvA[NT], avB[MT], bvB[NT];
