@@ -198,7 +198,7 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
   typedef int v4i_t __attribute__((ext_vector_type(4)));
   // GATE (a std::bool_constant): the per-(sample, channel) input gate of the SE primitives; the run-time test is made once, around
   // the load phase (a branch per group would make every group its own basic block)
-  auto load_group = [&](auto gate_c, int g, float4 (&av)[MT], float4 (&bv)[NT]) {
+  auto load_group = [&](auto gate_c, int g, float4 (&av)[MT], float4 (&bv)[NT], float4 (&gv)[MT]) {
     constexpr bool GATE = decltype(gate_c)::value;
     const int4 e = *reinterpret_cast<const int4*>(&gtab[g * 4]);      // one address for the whole wave
     const int soffA = __builtin_amdgcn_readfirstlane(e.x), soffB = __builtin_amdgcn_readfirstlane(e.y);
@@ -216,14 +216,14 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
       const v4i_t raw = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(ok ? voffA[t] : OOB), soffA, 0);
       float4 v = __builtin_bit_cast(float4, raw);
 #endif
-      // (unconditional: a branch per group on the ReLU flag keeps the compiler from batching the loads of the eight groups)
-      v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+      // (the input ReLU and the gate are applied in mfma_group: anything that touches the loaded value HERE makes the compiler
+      // wait for it between the groups' requests -- s_waitcnt vmcnt(2) in the middle of the load phase -- and the round trips of
+      // a wave's groups then follow each other instead of overlapping)
+      av[t] = v;
       if constexpr (GATE) {
         const int c16 = g % c16n;
-        const float4 gq = *reinterpret_cast<const float4*>(a.in_gate + (int64_t)rb[t] * a.Cs + c16 * 16 + kk * 4);
-        v.x *= gq.x; v.y *= gq.y; v.z *= gq.z; v.w *= gq.w;
+        gv[t] = *reinterpret_cast<const float4*>(a.in_gate + (int64_t)rb[t] * a.Cs + c16 * 16 + kk * 4);
       }
-      av[t] = v;
     }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -234,7 +234,17 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
 #endif
     }
   };
-  auto mfma_group = [&](const float4 (&av)[MT], const float4 (&bv)[NT]) {
+  auto mfma_group = [&](auto gate_c, const float4 (&av0)[MT], const float4 (&bv)[NT], const float4 (&gv)[MT]) {
+    constexpr bool GATE = decltype(gate_c)::value;
+    float4 av[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      // (unconditional fmax: a branch on the ReLU flag per group would make every group its own basic block)
+      float4 v = av0[t];
+      v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+      if constexpr (GATE) { v.x *= gv[t].x; v.y *= gv[t].y; v.z *= gv[t].z; v.w *= gv[t].w; }
+      av[t] = v;
+    }
 #ifdef VOX_NO_MFMA
     acc[0][0][0] += av[0].x * bv[0].x + av[0].y * bv[0].y + av[0].z * bv[0].z + av[0].w * bv[0].w;
     return;
@@ -267,41 +277,47 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
       constexpr int NI = decltype(ni_c)::value;
       float4 avs[NI][MT], bvs[NI][NT];
       if (a.in_gate) {
+        float4 gvs[NI][MT];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           const int g = wave + i * KSPLIT;
-          load_group(std::true_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i]);
+          load_group(std::true_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i], gvs[i]);
         }
+        GSTAMP(2);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          if (wave + i * KSPLIT < ngroups) mfma_group(std::true_type{}, avs[i], bvs[i], gvs[i]);
       } else {
+        float4 gnone[MT];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           const int g = wave + i * KSPLIT;
-          load_group(std::false_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i]);
+          load_group(std::false_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i], gnone);
         }
-      }
-      GSTAMP(2);
+        GSTAMP(2);
 #ifdef G16_STAMP
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      GSTAMP(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GSTAMP(3);
 #endif
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
-        if (wave + i * KSPLIT < ngroups) mfma_group(avs[i], bvs[i]);
+        for (int i = 0; i < NI; ++i)
+          if (wave + i * KSPLIT < ngroups) mfma_group(std::false_type{}, avs[i], bvs[i], gnone);
+      }
     };
     if (ngroups <= KSPLIT * 2) tiny(std::integral_constant<int, 2>{});
     else if (ngroups <= KSPLIT * 4) tiny(std::integral_constant<int, 4>{});
     else tiny(std::integral_constant<int, 8>{});
   } else {
     const int g0 = (KSPLIT > 1 ? wave : 0), step = (KSPLIT > 1 ? KSPLIT : 1);
-    float4 avA[MT], bvA[NT], avB[MT], bvB[NT];
+    float4 avA[MT], bvA[NT], avB[MT], bvB[NT], gvA[MT], gvB[MT];
     auto walk = [&](auto gate_c) {
-      if (g0 < ngroups) load_group(gate_c, g0, avA, bvA);
+      if (g0 < ngroups) load_group(gate_c, g0, avA, bvA, gvA);
       for (int g = g0; g < ngroups; g += 2 * step) {
         const bool hasB = g + step < ngroups;
-        if (hasB) load_group(gate_c, g + step, avB, bvB);
-        mfma_group(avA, bvA);
-        if (g + 2 * step < ngroups) load_group(gate_c, g + 2 * step, avA, bvA);
-        if (hasB) mfma_group(avB, bvB);
+        if (hasB) load_group(gate_c, g + step, avB, bvB, gvB);
+        mfma_group(gate_c, avA, bvA, gvA);
+        if (g + 2 * step < ngroups) load_group(gate_c, g + 2 * step, avA, bvA, gvA);
+        if (hasB) mfma_group(gate_c, avB, bvB, gvB);
       }
     };
     if (a.in_gate) walk(std::true_type{}); else walk(std::false_type{});
