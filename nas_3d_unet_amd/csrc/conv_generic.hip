@@ -286,12 +286,18 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(GatherArgs a) {
   }
   if (a.stats) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // fp32 tree over the 64 lanes of a wave (as the MFMA kernels do), four channels at a time (wave_classsum4_f: row r of the wave
+    // ends up with channel {0, 2, 1, 3}[r] of the quad); waves and rows are added in fp64
+    static_assert(CO_T % 4 == 0, "conv_gather_kernel: CO_T must be a multiple of 4");
+    const int sel = classsum4_sel(lane);
 #pragma unroll
-    for (int j = 0; j < CO_T; ++j) {
-      // fp32 DPP tree over the 64 lanes of a wave (as the MFMA kernels do); waves and rows are added in fp64
-      const float val = valid ? acc[j] : 0.f;
-      const float s = wave_sum_f(val), ss = wave_sum_f(val * val);
-      if (lane == 0) { red[wave][j * 2] = (double)s; red[wave][j * 2 + 1] = (double)ss; }
+    for (int j = 0; j < CO_T; j += 4) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = valid ? acc[j + e] : 0.f;
+      const float s = wave_classsum4_f<1>(v[0], v[1], v[2], v[3]);
+      const float ss = wave_classsum4_f<1>(v[0] * v[0], v[1] * v[1], v[2] * v[2], v[3] * v[3]);
+      if ((lane & 15) == 0) { red[wave][(j + sel) * 2] = (double)s; red[wave][(j + sel) * 2 + 1] = (double)ss; }
     }
     __syncthreads();
     if (threadIdx.x < CO_T * 2) {
@@ -502,10 +508,13 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
   }
   if (a.stats) {
     const int wave = t >> 6, lane = t & 63;
+    // (four channels per wave sum, wave_classsum4_f: row r of the wave ends up with channel {0, 2, 1, 3}[r] of the quad)
+    const int sel = classsum4_sel(lane);
 #pragma unroll
-    for (int j = 0; j < CDQ * 4; ++j) {
-      const float s = wave_sum_f(s1[j]), ss = wave_sum_f(s2[j]);
-      if (lane == 0) { red[wave][j * 2] = (double)s; red[wave][j * 2 + 1] = (double)ss; }
+    for (int q = 0; q < CDQ; ++q) {
+      const float s = wave_classsum4_f<1>(s1[q * 4], s1[q * 4 + 1], s1[q * 4 + 2], s1[q * 4 + 3]);
+      const float ss = wave_classsum4_f<1>(s2[q * 4], s2[q * 4 + 1], s2[q * 4 + 2], s2[q * 4 + 3]);
+      if ((lane & 15) == 0) { red[wave][(q * 4 + sel) * 2] = (double)s; red[wave][(q * 4 + sel) * 2 + 1] = (double)ss; }
     }
     __syncthreads();
     if (t < CDQ * 8)
