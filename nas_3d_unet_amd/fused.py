@@ -269,6 +269,7 @@ SIDE_PAIRS = os.environ.get("N3D_SIDE_PAIRS", "1") != "0"   # searched cells wit
 SIDE_PRE0_FWD_ALL = os.environ.get("N3D_SIDE_PRE0_FWD_ALL", "0") != "0"
 SIDE_STEM1_BWD = os.environ.get("N3D_SIDE_STEM1_BWD", "1") != "0"   # stem1's backward (parameter gradients only) beside stem0's
 SIDE_PRE0_BWD = os.environ.get("N3D_SIDE_PRE0_BWD", "1") != "0"     # searched cells: the backward of EVERY cell's first preprocess op on the side stream
+SIDE_PAIRS_BOTH = os.environ.get("N3D_SIDE_PAIRS_BOTH", "1") != "0"   # ... and of nodes whose two convs both read node outputs, one conv beside the other (1.756 -> 1.748 ms)
 SIDE_PAIRS_BWD = os.environ.get("N3D_SIDE_PAIRS_BWD", "1") != "0"   # ... and the data gradients into one preprocess gradient (needs a third stream)
 
 
@@ -348,6 +349,19 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None):
                 else:
                     res0, res1 = P.pair_weight_phase(seg0, xs[i0]), res_side
                 SIDE_FWD.join(tok)
+                s0, s1 = P.pair_epilogue_phase(seg0, res0, seg1, res1, nodes[node])
+            elif (SIDE_PAIRS_BOTH and SIDE_FWD is not None and cn <= 8 and isinstance(seg0.weight, P.DenseConvW)
+                  and isinstance(seg1.weight, P.DenseConvW) and P.gn_pairable(seg0) and P.gn_pairable(seg1)):
+                # both convs read node outputs: still two launches (no common MFMA problem) -- the cheaper one beside the other
+                sf = SIDE_FWD
+                cheap1 = seg1.weight.transposed or seg1.weight.stride > 1
+                sa, ia, sb_, ib = (seg1, i1, seg0, i0) if cheap1 else (seg0, i0, seg1, i1)
+                with sf.side(sf.fork()):
+                    res_a = P.pair_weight_phase(sa, xs[ia])
+                    tok = sf.side_signal()
+                res_b = P.pair_weight_phase(sb_, xs[ib])
+                sf.join(tok)
+                res0, res1 = (res_b, res_a) if cheap1 else (res_a, res_b)
                 s0, s1 = P.pair_epilogue_phase(seg0, res0, seg1, res1, nodes[node])
             else:
                 s0, s1 = P.pair_forward(seg0, xs[i0], seg1, xs[i1], nodes[node])
