@@ -1275,6 +1275,13 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __re
   __shared__ __attribute__((aligned(16))) float cw[4][2][3][64];  // [wave][term][A|B|C][channel]
   const int t = threadIdx.x, wave = t >> 6;
   AESTAMP(0);
+  if (!PRE && blockIdx.x == gridDim.x - 1) {
+    // the extra workgroup of the launch (grid.x = rows + 1): the parameter gradients, which need the partial rows of EVERY sample.
+    // They used to be the job of wave 0 of workgroup (0, 0) in front of its share of the apply work, and a launch lasts as long
+    // as its slowest workgroup; here they run beside the apply workgroups, whose waves all handle one sample
+    if (blockIdx.y == 0 && wave == 0) gn_bwd_prologue_wave2(t0, t1, B, C, G, count, true, cw[0]);
+    return;
+  }
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   const int by = blockIdx.y;
   const T* dbp = dout + (int64_t)by * N * dld + c4 * 4;
@@ -1305,9 +1312,8 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __re
     cA[0] = ld4(t0.cA + co); cB[0] = ld4(t0.cB + co); cC[0] = ld4(t0.cC + co);
     cA[1] = ld4(t1.cA + co); cB[1] = ld4(t1.cB + co); cC[1] = ld4(t1.cC + co);
   } else {
-    const bool lead_w = blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
     AESTAMP(1);
-    gn_bwd_prologue_wave2(t0, t1, B, C, G, count, lead_w, cw[wave]);
+    gn_bwd_prologue_wave2(t0, t1, B, C, G, count, false, cw[wave]);
     AESTAMP(3);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -2359,8 +2365,9 @@ int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const float* do
   if (dout1) { if (int e = check_vec(dout1, dld1, C, "bwd_apply_gn2(dout1)", bf)) return e; }
   with_act_type(bf, [&](auto* tag) {
     using T = N3D_T(tag);
-    if (dout1) hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, true, T>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
-    else hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, false, T>), dim3(m.rows, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
+    // (grid.x = rows + 1: the last workgroup column forms the parameter gradients)
+    if (dout1) hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, true, T>), dim3(m.rows + 1, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
+    else hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, false, T>), dim3(m.rows + 1, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
   });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
