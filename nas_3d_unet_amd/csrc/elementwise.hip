@@ -812,7 +812,18 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const T* __res
   __shared__ __attribute__((aligned(16))) float coefw[4][3][64];
   const int t = threadIdx.x;
   const int cg = C / G;
-  const bool leader = (blockIdx.x == 0 && blockIdx.y == 0);
+  const bool wave_path = is_pow2(C) && cg <= 16;
+  if (wave_path && blockIdx.x == gridDim.x - 1) {
+    // the extra workgroup column (grid.x = rows + 1, see affine_bwd_apply_gn2_kernel): the parameter gradients
+    if (blockIdx.y == 0 && t < 64) {
+      const GnBwdTerm tm = {nullptr, 0, a, bb, sums, rows, gamma, mean_rstd, wptr, sumraw, nullptr, 0, dgamma, dbeta, dalpha, dbias_conv,
+                            RELU ? 1 : 0, nullptr, nullptr, nullptr};
+      if (B <= 2) gn_bwd_prologue_impl<1, 2, 4>(tm, tm, B, C, G, count, &coefw[0]);
+      else gn_bwd_prologue_impl<1, GNF_MAXB, 2>(tm, tm, B, C, G, count, &coefw[0]);
+    }
+    return;
+  }
+  const bool leader = !wave_path && (blockIdx.x == 0 && blockIdx.y == 0);
   const int nb = leader ? B : 1;
   // ---- load phase (no dependent loads): the first iteration's tensor operands and forward coefficients, then
   // parameters, group statistics and this thread's share of the partial rows
@@ -837,14 +848,10 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn_kernel(const T* __res
     // row slots -> DPP group sums -> GroupNorm-backward coefficients, redundantly in every wave.  Wave 0 of the
     // leader workgroup walks all B samples to emit dgamma / dbeta / dalpha / conv-bias gradient.
     const int wave = t >> 6;
-    const bool lead_w = leader && wave == 0;
-    // (the pair kernels' prologue with one term: all operands of the wave -- for the leader the rows of every sample -- in one go)
+    // (the pair kernels' prologue with one term: all operands of the wave in one go)
     const GnBwdTerm tm = {nullptr, 0, a, bb, sums, rows, gamma, mean_rstd, wptr, sumraw, nullptr, 0, dgamma, dbeta, dalpha, dbias_conv,
                           RELU ? 1 : 0, nullptr, nullptr, nullptr};
-    if (lead_w) {
-      if (B <= 2) gn_bwd_prologue_impl<1, 2, 4>(tm, tm, B, C, G, count, &coefw[wave]);
-      else gn_bwd_prologue_impl<1, GNF_MAXB, 2>(tm, tm, B, C, G, count, &coefw[wave]);
-    } else gn_bwd_prologue_impl<1, 1, 4>(tm, tm, B, C, G, count, &coefw[wave]);
+    gn_bwd_prologue_impl<1, 1, 4>(tm, tm, B, C, G, count, &coefw[wave]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2874,7 +2881,9 @@ int n3d_affine_act_bwd_apply_gn(const float* dout, int64_t dld, const float* raw
   if (int e = check_vec(raw, rld, C, "bwd_apply_gn(raw)", bf)) return e;
   if (int e = check_vec(draw, drld, C, "bwd_apply_gn(draw)", bf)) return e;
   EwMap m = ew_map(N, C);
-  dim3 grid(m.rows, B), blk(256);
+  // wave-level prologue (C a power of two, group width <= 16): one extra workgroup column forms the parameter gradients
+  const bool wave_path = (C & (C - 1)) == 0 && C / G <= 16;
+  dim3 grid(m.rows + (wave_path ? 1 : 0), B), blk(256);
   hipStream_t s = (hipStream_t)stream;
   const bool relu = flags & N3D_RELU, acc = flags & N3D_ACCUMULATE;
   with_act_type(bf, [&](auto* tag) {
