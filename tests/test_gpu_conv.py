@@ -27,6 +27,8 @@ CASES = [
     (16, 16, 3, 1, 2, False, 1, (18, 24, 48)),
     (16, 16, 3, 1, 1, False, 2, (32, 32, 32)),   # the C = 16 level of a 128^3 patch (>= 256 tiles: LDS-tile weight gradient too)
     (16, 16, 3, 1, 2, False, 2, (16, 32, 32)),
+    (16, 16, 3, 1, 1, False, 2, (16, 16, 16)),   # the C = 16 level of the benchmarked 64^3 patch: 64 tiles, the lower bound of the LDS-tile
+    (16, 16, 3, 1, 2, False, 2, (16, 16, 16)),   # weight gradient (N3D_WGT16_MIN); data gradient / forward on the K-split plan (KSPLIT=4)
     (16, 16, 3, 1, 1, False, 3, (12, 32, 32)),   # 576 tiles over 256 workgroups: ragged tiles-per-workgroup, workgroups span samples
     (32, 32, 3, 1, 1, False, 2, (16, 16, 16)),   # 64 tiles x 4 channel tiles: the LDS-tile weight gradient on 32 channels
     (32, 32, 3, 1, 2, False, 2, (16, 16, 16)),
