@@ -382,16 +382,22 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
       const int row = (int)(ur2 / ROWS_PER_BLOCK);
       // 8 voxels per sample (the 2^3 level): rows 0-7 (lanes kk 0/1) are one sample, rows 8-15 (kk 2/3) the next
       const bool two = Nd * 2 == ROWS_PER_BLOCK;
+      // the sum and the sum of squares of a column are folded over the four row groups TOGETHER (fp32, as the other conv kernels'
+      // statistics epilogues): one v_permlane swap pair instead of eight
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        double s = xsum16_d((double)csum[n]), q = xsum16_d((double)csq[n]);
         if (two) {
+          // fold lane ^ 16 only: rows 0 / 1 = sum / sum of squares of the first sample, rows 2 / 3 of the second
+          const auto sx = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(int, csum[n]), __builtin_bit_cast(int, csq[n]), false, false);
+          const float x = __builtin_bit_cast(float, (int)sx[0]) + __builtin_bit_cast(float, (int)sx[1]);
           const int64_t smp = (int64_t)ub2 + (kk >> 1);
-          if (!(kk & 1) && smp < a.B) *reinterpret_cast<double2*>(a.stats + (smp * a.Cd + n0 + n * 16 + m) * 2) = make_double2(s, q);
+          if (smp < a.B) a.stats[(smp * a.Cd + n0 + n * 16 + m) * 2 + (kk & 1)] = (double)x;
         } else {
-          s = xsum32_d(s); q = xsum32_d(q);
-          if (kk == 0)
-            *reinterpret_cast<double2*>(a.stats + (((int64_t)ub2 * a.rows_per_sample + row) * a.Cd + n0 + n * 16 + m) * 2) = make_double2(s, q);
+          const auto s32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, csum[n]), __builtin_bit_cast(int, csq[n]), false, false);
+          const float ab = __builtin_bit_cast(float, (int)s32[0]) + __builtin_bit_cast(float, (int)s32[1]);   // rows 0,1: sum; rows 2,3: squares
+          const float x = xsum16_f(ab);
+          if (!(kk & 1))
+            a.stats[(((int64_t)ub2 * a.rows_per_sample + row) * a.Cd + n0 + n * 16 + m) * 2 + (kk >> 1)] = (double)x;
         }
       }
     }
