@@ -115,9 +115,11 @@ def test_side_schedule_graph_replay_matches_plain_trainer():
             assert tr._use_side and tr._side_graphs is not None
         out.append((losses, tr.fp.flat.clone()))
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=2e-5)
-    # Adam moves an element whose gradient is fp32 noise by ~lr per step either way: compare where it matters
+    # Adam moves an element whose gradient is fp32 noise by ~lr per step either way, and the two schedules differ by an fp32 rounding
+    # of the preprocess epilogue backward: on this net a 1e-6 nudge of 1 % of the weights after step 1 grows to 8e-4 of the norm by
+    # step 4 (tools/dbg/chaos_probe.py).  A weight gradient that went missing moves a whole layer by 4 lr: ~1e-2 of the norm.
     d = (out[0][1] - out[1][1]).abs()
-    assert float(d.double().norm()) <= 2e-4 * float(out[0][1].double().norm())
+    assert float(d.double().norm()) <= 2e-3 * float(out[0][1].double().norm())
 
 
 @pytest.mark.parametrize("size", [32, 64])
@@ -160,7 +162,7 @@ def test_schedule_choice_leaves_the_state_alone():
     assert res[0][2] == res[1][2] == 3
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=2e-5)   # same dropout masks, same trajectory
     d = (res[0][1] - res[1][1]).abs()
-    assert float(d.double().norm()) <= 2e-4 * float(res[0][1].double().norm())
+    assert float(d.double().norm()) <= 2e-3 * float(res[0][1].double().norm())     # (see the replay test above for the bound)
 
 
 def test_search_weight_pass_on_the_side_stream():
