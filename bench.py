@@ -212,7 +212,8 @@ def search_step_bench(args, device):
         la, lw = tr.step(x, t, vx, vt)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    extra = {}
+    tr.check_sync()
+    extra = {"sync_timeouts": tr.sync_timeouts(), "schedule": "three streams" if tr._use_side else "single stream"}
     if not args.no_kernel_table:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         try:
@@ -222,9 +223,9 @@ def search_step_bench(args, device):
                 rows, ncalls = kernel_table.table(lambda: tr._both(x, t, vx, vt), device)
             finally:
                 tr.side = side
-            extra = {"roofline_by_time": rows, "launches_per_step": ncalls}
+            extra.update({"roofline_by_time": rows, "launches_per_step": ncalls})
         except Exception as e:
-            extra = {"roofline_by_time": "failed: %s" % (str(e)[:200],)}
+            extra["roofline_by_time"] = "failed: %s" % (str(e)[:200],)
     print(json.dumps({
         "metric": "supernet search steps/sec (arch pass + weight pass, each fwd + Dice + bwd + Adam)", "value": round(args.steps / dt, 3),
         "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -256,7 +257,9 @@ def other_configs(device, batch, no_graph):
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps
+        sec = (time.perf_counter() - t0) / steps
+        tr.check_sync()        # a timed-out hand-off (update withheld on the device) must not be reported as a measurement
+        return sec
 
     def search():
         torch.manual_seed(1234)
@@ -384,6 +387,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     final_loss = float(loss)
+    # the side-stream schedule orders its streams with BOUNDED device-side waits; a wait that gave up withholds the update on the
+    # device (n3d_adam_step_guarded) -- the line certifies that none did during the steps it reports (summed over the ranks)
+    sync_timeouts = trainer.sync_timeouts()
+    if world > 1:
+        st = torch.tensor([float(sync_timeouts)], device=device, dtype=torch.float64)
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        sync_timeouts = int(st.item())
+    trainer.check_sync()     # raises (no line) if a hand-off timed out
 
     if rank == 0:
         patches = world * args.batch * args.steps
@@ -391,7 +402,7 @@ def main():
         out = {
             "metric": "4x%d^3 patches/sec (train step: fwd + Dice + bwd + Adam%s)" % (args.size, " + RCCL all-reduce" if world > 1 else ""),
             "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "sync_timeouts": sync_timeouts,
             "vs_baseline": None, "dtype": "f32" if args.dtype == "f32" else "bf16 storage (levels with <= 8 channels per node, stems, head input) / f32 arithmetic", "data": "synthetic",
             "config": {"workload": "searched.py SearchedNet/G_conv train step, batch=%d 4x%d^3 %s per GPU" % (args.batch, args.size, "fp32" if args.dtype == "f32" else "bf16-storage"),
                        "global_batch": world * args.batch, "patch": [4, args.size, args.size, args.size],
@@ -421,6 +432,7 @@ def main():
                     trainer.side = side
                 out["roofline_by_time"] = rows
                 out["launches_per_step"] = ncalls
+                out["roofline_by_time_schedule"] = "single stream, eager (one entry point = one launch of the dependent chain); the headline ran: " + out["config"]["schedule"]
             except Exception as e:
                 out["roofline_by_time"] = "failed: %s" % (str(e)[:200],)
         if world == 1 and not args.no_cpu_baseline:

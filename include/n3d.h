@@ -451,6 +451,24 @@ int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t* step_ptr,
                   int inc_step, void* stream);
 
+/* Guarded update (round 4): the stream hand-offs below are BOUNDED waits -- one that gives up lets its stream go on with operands
+ * that are not there yet.  Such a step must never reach the weights (train.py:121-128: a step is forward, backward, update --
+ * there is no "update from garbage" in the reference).  n3d_adam_step_guarded is n3d_adam_step with a test in front, uniform
+ * over the grid: if *timeouts != *acked (uint32: time-outs counted by n3d_sync_wait vs. time-outs the host has acknowledged;
+ * both NULL = no test) or *peer_flag != 0 (data parallel: the flags of all ranks, SUM-all-reduced together with the
+ * gradients; NULL = no test) the launch updates NOTHING -- parameters, moments and the step counter stay as they are -- writes
+ * NaN to *loss (if not NULL) and 1 to *host_word (if not NULL; a word from n3d_host_word_alloc, which the host polls without a
+ * HIP call).  inc_step must be 0 or 2 when a test is requested.  n3d_guard_flag writes the local test (1.0 / 0.0) to *flag for
+ * the all-reduce. */
+int n3d_adam_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                          const float* lr_ptr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                          int32_t* step_ptr, int inc_step, const void* timeouts, const void* acked, const float* peer_flag,
+                          float* loss, void* host_word, void* stream);
+int n3d_guard_flag(const void* timeouts, const void* acked, float* flag, void* stream);
+/* 64 bytes of pinned, device-mapped, coherent host memory (zeroed); the pointer is valid on the host and in kernels */
+int n3d_host_word_alloc(void** host_ptr);
+int n3d_host_word_free(void* host_ptr);
+
 /* ---- stream hand-off (no reference counterpart: the reference runs one CUDA stream, train.py:117-128) ----------------
  * Device-side ordering between two HIP streams whose work was launched as SEPARATE graphs: the weight-gradient kernels of
  * a train step run on a side stream next to the backward chain (train.Trainer).  On this stack an event between two graph
@@ -468,6 +486,14 @@ int n3d_sync_signal(void* flag, void* step, int bump, void* stream);
  * kernel trace serialises the two streams, so the timeline of the side-stream schedule is taken with these (tools/side_timeline.py) */
 int n3d_stamp(void* out, void* stream);
 int n3d_sync_wait(const void* flag, void* step, void* timeouts, int bump, int64_t max_polls, void* stream);
+/* The side streams and their graphs, made through the HIP runtime libn3d is linked against (the one that launches the kernels):
+ * a non-blocking stream of the lowest priority the device offers; thread-local capture of a stream into an instantiated
+ * executable graph (the side streams are captured NEXT TO torch's capture of the main stream); launch / destroy. */
+int n3d_stream_create_low_priority(void** stream_out);
+int n3d_stream_capture_begin(void* stream);
+int n3d_stream_capture_end(void* stream, void** graph_exec_out);
+int n3d_graph_launch(void* graph_exec, void* stream);
+int n3d_graph_destroy(void* graph_exec);
 
 #ifdef __cplusplus
 }

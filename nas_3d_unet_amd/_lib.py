@@ -194,6 +194,15 @@ PROTOTYPES = {
     "n3d_comm_allreduce_sum": (_i, [_p, _p, _i64, _p]),
     "n3d_comm_destroy": (_i, [_p]),
     "n3d_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _f, _p, _i, _p]),
+    "n3d_adam_step_guarded": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _f, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "n3d_guard_flag": (_i, [_p, _p, _p, _p]),
+    "n3d_host_word_alloc": (_i, [C.POINTER(C.c_void_p)]),
+    "n3d_host_word_free": (_i, [_p]),
+    "n3d_stream_create_low_priority": (_i, [C.POINTER(C.c_void_p)]),
+    "n3d_stream_capture_begin": (_i, [_p]),
+    "n3d_stream_capture_end": (_i, [_p, C.POINTER(C.c_void_p)]),
+    "n3d_graph_launch": (_i, [_p, _p]),
+    "n3d_graph_destroy": (_i, [_p]),
     "n3d_sync_signal": (_i, [_p, _p, _i, _p]),
     "n3d_sync_wait": (_i, [_p, _p, _p, _i, _i64, _p]),
     "n3d_stamp": (_i, [_p, _p]),

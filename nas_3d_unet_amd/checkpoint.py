@@ -74,7 +74,16 @@ def load_scheduler_state_dict(s, d):
 
 
 # ------------------------------------------------------------------------------------------------ train.py:85-93 / 52-67
+def _checked(trainer):
+    """a checkpoint is a host-visible point: a timed-out stream hand-off (whose update was withheld on the device) raises here
+    instead of being written out as if the steps since had trained (train.Trainer.check_sync)"""
+    chk = getattr(trainer, "check_sync", None)
+    if chk is not None:
+        chk()
+
+
 def train_state_dicts(trainer, epoch, history, best_loss):
+    _checked(trainer)
     return {"epoch": epoch, "history": history, "model_param": trainer.model.state_dict(),
             "optim": adam_state_dict(trainer.fp, trainer.lr, trainer.betas, trainer.eps),
             "scheduler": scheduler_state_dict(trainer.scheduler), "best_loss": best_loss}
@@ -93,6 +102,7 @@ def load_train_state_dicts(trainer, sd, new_lr=False):
 def search_state_dicts(trainer, epoch, geno_count, history, best_loss):
     """the reference's search checkpoint: two optimizers, two schedulers (the reference stores the KERNEL scheduler under
     both scheduler keys, search.py:174; here each key holds its own scheduler)"""
+    _checked(trainer)
     return {"epoch": epoch, "geno_count": geno_count, "history": history, "model_param": trainer.model.state_dict(),
             "optim_shell": adam_state_dict(trainer.afp, trainer.lr_shell, trainer.betas, trainer.eps),
             "optim_kernel": adam_state_dict(trainer.fp, trainer.lr_kernel, trainer.betas, trainer.eps),

@@ -2113,9 +2113,29 @@ __global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam, amsgrad=False, maximize=False)
 // ------------------------------------------------------------------------------------------------
+struct AdamGuard { const unsigned* timeouts; const unsigned* acked; const float* peer_flag; float* loss; unsigned* host_word; };
+__global__ void guard_flag_kernel(const unsigned* timeouts, const unsigned* acked, float* flag) {
+  *flag = (__hip_atomic_load(timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != *acked) ? 1.f : 0.f;
+}
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float lr_imm, const float* __restrict__ lr_ptr, float b1, float b2, float eps,
-                                                   float wd, float gscale, int32_t* __restrict__ step_ptr, int ticketed) {
+                                                   float wd, float gscale, int32_t* __restrict__ step_ptr, int ticketed, AdamGuard gd) {
+  // guard (include/n3d.h, n3d_adam_step_guarded): a device-side wait of this step's stream hand-offs gave up (time-outs counted
+  // != time-outs the host has acknowledged) or a peer rank reported one (all-reduced flag != 0) -> the gradients are not to be
+  // trusted: NO update, moments and step counter untouched (the ticket counter stays 0), the loss scalar becomes NaN and the
+  // host-visible word is set.  Uniform over the grid, two scalar loads on the good path.
+  {
+    bool skip = false;
+    if (gd.timeouts) skip = __hip_atomic_load(gd.timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != *gd.acked;
+    if (gd.peer_flag) skip = skip || (*gd.peer_flag != 0.f);
+    if (skip) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (gd.loss) *gd.loss = __builtin_nanf("");
+        if (gd.host_word) __hip_atomic_store(gd.host_word, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+  }
   const int step = *step_ptr + 1;
   const float lr = lr_ptr ? *lr_ptr : lr_imm;
   const double bc1 = 1.0 - pow((double)b1, (double)step);
@@ -2827,7 +2847,22 @@ int n3d_ndhwc_to_ncdhw(const float* src, int64_t sld, float* dst, int B, int C, 
 
 int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, const float* lr_ptr, float beta1,
                   float beta2, float eps, float weight_decay, float grad_scale, int32_t* step_ptr, int inc_step, void* stream) {
+  return n3d_adam_step_guarded(param, grad, exp_avg, exp_avg_sq, n, lr, lr_ptr, beta1, beta2, eps, weight_decay, grad_scale, step_ptr, inc_step,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+int n3d_guard_flag(const void* timeouts, const void* acked, float* flag, void* stream) {
+  N3D_CHECK_ARG(timeouts && acked && flag, "guard_flag: null pointer");
+  hipLaunchKernelGGL(guard_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned*)timeouts, (const unsigned*)acked, flag);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+int n3d_adam_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, const float* lr_ptr, float beta1,
+                          float beta2, float eps, float weight_decay, float grad_scale, int32_t* step_ptr, int inc_step,
+                          const void* timeouts, const void* acked, const float* peer_flag, float* loss, void* host_word, void* stream) {
   N3D_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_ptr && n > 0, "adam_step: bad args");
+  N3D_CHECK_ARG((timeouts == nullptr) == (acked == nullptr), "adam_step_guarded: timeouts and acked come together");
+  N3D_CHECK_ARG(inc_step != 1 || (!timeouts && !peer_flag), "adam_step_guarded: a guarded update counts its own step (inc_step 0 or 2)");
+  const AdamGuard gd{(const unsigned*)timeouts, (const unsigned*)acked, peer_flag, loss, (unsigned*)host_word};
   // elements per workgroup: 8192 = four rounds of two float4 per lane.  Few fat workgroups beat many thin ones here: 1.8 M
   // parameters take 25.9 us at 1024 per workgroup (1771 workgroups), 16.5 at 2048, 12.4 at 4096, 11.1 at 8192 (4.6 TB/s), 13.4 at 16384
   static const int adam_epb = [] { const char* e = getenv("N3D_ADAM_EPB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8192; }();
@@ -2835,7 +2870,7 @@ int n3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, lr_ptr,
-                     beta1, beta2, eps, weight_decay, grad_scale, step_ptr, inc_step == 2 ? 1 : 0);
+                     beta1, beta2, eps, weight_decay, grad_scale, step_ptr, inc_step == 2 ? 1 : 0, gd);
   if (inc_step == 1) hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_ptr);
   N3D_LAUNCH_CHECK();
   return N3D_OK;

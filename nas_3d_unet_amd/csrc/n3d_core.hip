@@ -61,6 +61,78 @@ int n3d_sync_wait(const void* flag, void* step, void* timeouts, int bump, int64_
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
+// ---- host-visible word, side streams and raw stream capture (include/n3d.h, "stream hand-off") --------------------------------
+// These go through the HIP runtime libn3d itself is linked against -- the one that launches the kernels -- instead of a second
+// copy a Python-side dlopen("libamdhip64.so") might resolve to.
+int n3d_host_word_alloc(void** host_ptr) {
+  N3D_CHECK_ARG(host_ptr, "n3d_host_word_alloc: null pointer");
+  void* p = nullptr;
+  // pinned, mapped, coherent: the device stores to it (system scope), the host reads it without any HIP call
+  if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || !p) {
+    n3d::set_error("n3d_host_word_alloc: hipHostMalloc failed");
+    (void)hipGetLastError();
+    return N3D_ERR_HIP;
+  }
+  memset(p, 0, 64);
+  *host_ptr = p;
+  return N3D_OK;
+}
+int n3d_host_word_free(void* host_ptr) {
+  if (host_ptr && hipHostFree(host_ptr) != hipSuccess) { (void)hipGetLastError(); return N3D_ERR_HIP; }
+  return N3D_OK;
+}
+int n3d_stream_create_low_priority(void** stream_out) {
+  N3D_CHECK_ARG(stream_out, "n3d_stream_create_low_priority: null pointer");
+  int lo = 0, hi = 0;
+  hipStream_t s = nullptr;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, lo) != hipSuccess || !s) {
+    n3d::set_error("n3d_stream_create_low_priority: HIP stream creation failed");
+    (void)hipGetLastError();
+    return N3D_ERR_HIP;
+  }
+  *stream_out = (void*)s;
+  return N3D_OK;
+}
+int n3d_stream_capture_begin(void* stream) {
+  if (hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    n3d::set_error("n3d_stream_capture_begin: hipStreamBeginCapture failed");
+    (void)hipGetLastError();
+    return N3D_ERR_HIP;
+  }
+  return N3D_OK;
+}
+int n3d_stream_capture_end(void* stream, void** graph_exec_out) {
+  N3D_CHECK_ARG(graph_exec_out, "n3d_stream_capture_end: null pointer");
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ex = nullptr;
+  if (hipStreamEndCapture((hipStream_t)stream, &g) != hipSuccess || !g) {
+    n3d::set_error("n3d_stream_capture_end: hipStreamEndCapture failed");
+    (void)hipGetLastError();
+    return N3D_ERR_HIP;
+  }
+  const hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);      // the executable graph is self-contained
+  if (e != hipSuccess || !ex) {
+    n3d::set_error("n3d_stream_capture_end: hipGraphInstantiate failed");
+    (void)hipGetLastError();
+    return N3D_ERR_HIP;
+  }
+  *graph_exec_out = (void*)ex;
+  return N3D_OK;
+}
+int n3d_graph_launch(void* graph_exec, void* stream) {
+  N3D_CHECK_ARG(graph_exec, "n3d_graph_launch: null graph");
+  if (hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream) != hipSuccess) {
+    n3d::set_error("n3d_graph_launch: hipGraphLaunch failed");
+    (void)hipGetLastError();
+    return N3D_ERR_HIP;
+  }
+  return N3D_OK;
+}
+int n3d_graph_destroy(void* graph_exec) {
+  if (graph_exec && hipGraphExecDestroy((hipGraphExec_t)graph_exec) != hipSuccess) { (void)hipGetLastError(); return N3D_ERR_HIP; }
+  return N3D_OK;
+}
 const char* n3d_last_error(void) { return n3d::g_err; }
 int n3d_version(void) { return 1; }
 int n3d_device_ok(void) {

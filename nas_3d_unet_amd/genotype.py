@@ -18,7 +18,6 @@ class GenoParser:
         stride-2 scores rescaled by len(primitive list)/len(NormOps) (genotype.py:28-45)."""
         alpha1, alpha2 = np.asarray(alpha1), np.asarray(alpha2)
         strided_names = DownOps if downward else UpOps
-        scale = len(strided_names) / len(NormOps)
         picked = []
         e = 0
         for n_in in range(2, 2 + self.n_nodes):
@@ -27,7 +26,9 @@ class GenoParser:
                 is_strided = (edge < 2) if downward else (edge == 1)
                 if is_strided:
                     j = int(np.argmax(alpha2[e]))
-                    scored.append((alpha2[e][j] * scale, strided_names[j], edge))
+                    # the reference's order of operations, in the matrix's own dtype: (a * n_strided) / n_normal -- on float32
+                    # scores a precomputed ratio differs by 1 ulp for half of all values, which decides a near-tie (genotype.py:35,38)
+                    scored.append((alpha2[e][j] * len(strided_names) / len(NormOps), strided_names[j], edge))
                 else:
                     j = int(np.argmax(alpha1[e]))
                     scored.append((alpha1[e][j], NormOps[j], edge))

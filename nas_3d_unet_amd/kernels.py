@@ -1141,15 +1141,95 @@ def dice_bwd(p, t, smooth, sums, dloss, dp):
                                    ptr(dloss), ptr(dp), ds[0], ds[1], ds[2], stream_ptr()), "n3d_dice_bwd")
 
 
+class UpdateGuard:
+    """what n3d_adam_step_guarded tests in front of an update (include/n3d.h, "Guarded update"): pointers (ints) to the device
+    words {time-outs counted, time-outs acknowledged}, optionally the all-reduced peer flag (float), the loss scalar that
+    becomes NaN when the update is withheld, and the host-visible word"""
+    __slots__ = ("timeouts", "acked", "peer_flag", "loss", "host_word")
+
+    def __init__(self, timeouts, acked, peer_flag=None, loss=None, host_word=None):
+        self.timeouts, self.acked, self.peer_flag, self.loss, self.host_word = timeouts, acked, peer_flag, loss, host_word
+
+    def with_loss(self, loss):
+        """the same guard reporting into another loss scalar (tensor or None)"""
+        return UpdateGuard(self.timeouts, self.acked, self.peer_flag, loss.data_ptr() if loss is not None else None, self.host_word)
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
-              grad_scale=1.0, inc_step=True, lr_dev=None):
+              grad_scale=1.0, inc_step=True, lr_dev=None, guard=None):
     """lr_dev: optional 1-element device tensor holding the learning rate (read by the kernel; survives graph replay).
     step_t: int32 step counter; a view made by `step_counter()` carries a ticket word behind it, and the update launch then
-    counts the step itself (no second launch)"""
+    counts the step itself (no second launch).  guard: UpdateGuard -- the update is withheld on the device when a stream
+    hand-off of this step timed out (here or, data parallel, on a peer rank)"""
     inc = 0 if not inc_step else (2 if getattr(step_t, "_n3d_ticketed", False) else 1)
-    check(_lib.load().n3d_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, ptr(lr_dev),
-                                    beta1, beta2, eps, weight_decay, grad_scale, ptr(step_t), inc, stream_ptr()),
-          "n3d_adam_step")
+    if guard is None:
+        check(_lib.load().n3d_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, ptr(lr_dev),
+                                        beta1, beta2, eps, weight_decay, grad_scale, ptr(step_t), inc, stream_ptr()),
+              "n3d_adam_step")
+        return
+    vp = lambda v: C.c_void_p(v) if v else None
+    check(_lib.load().n3d_adam_step_guarded(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), lr, ptr(lr_dev),
+                                            beta1, beta2, eps, weight_decay, grad_scale, ptr(step_t), inc, vp(guard.timeouts), vp(guard.acked),
+                                            vp(guard.peer_flag), vp(guard.loss), vp(guard.host_word), stream_ptr()),
+          "n3d_adam_step_guarded")
+
+
+def guard_flag(timeouts_ptr, acked_ptr, flag_ptr):
+    """*flag = 1.0 if a hand-off of this rank timed out and is not acknowledged, else 0.0 (all-reduced with the gradients)"""
+    check(_lib.load().n3d_guard_flag(C.c_void_p(timeouts_ptr), C.c_void_p(acked_ptr), C.c_void_p(flag_ptr), stream_ptr()), "n3d_guard_flag")
+
+
+class HostWord:
+    """one 32-bit word of pinned, device-mapped host memory (n3d_host_word_alloc): kernels store to it, `value` reads it without
+    touching the HIP runtime"""
+
+    def __init__(self):
+        p = C.c_void_p()
+        check(_lib.load().n3d_host_word_alloc(C.byref(p)), "n3d_host_word_alloc")
+        self.ptr = p.value
+        self._w = C.cast(p, C.POINTER(C.c_uint32))
+
+    @property
+    def value(self):
+        return int(self._w[0])
+
+    def clear(self):
+        self._w[0] = 0
+
+    def __del__(self):
+        p, self.ptr = getattr(self, "ptr", None), None
+        if p:
+            try:
+                _lib.load().n3d_host_word_free(C.c_void_p(p))
+            except Exception:
+                pass
+
+
+# the side streams and their graphs, through libn3d's own HIP runtime (include/n3d.h, "stream hand-off")
+def stream_create_low_priority():
+    """-> HIP stream handle (int): non-blocking, lowest priority of the current device"""
+    h = C.c_void_p()
+    check(_lib.load().n3d_stream_create_low_priority(C.byref(h)), "n3d_stream_create_low_priority")
+    return h.value
+
+
+def stream_capture_begin(stream):
+    check(_lib.load().n3d_stream_capture_begin(C.c_void_p(stream)), "n3d_stream_capture_begin")
+
+
+def stream_capture_end(stream):
+    """-> executable graph handle (int)"""
+    ex = C.c_void_p()
+    check(_lib.load().n3d_stream_capture_end(C.c_void_p(stream), C.byref(ex)), "n3d_stream_capture_end")
+    return ex.value
+
+
+def graph_launch(graph_exec, stream):
+    check(_lib.load().n3d_graph_launch(C.c_void_p(graph_exec), C.c_void_p(stream)), "n3d_graph_launch")
+
+
+def graph_destroy(graph_exec):
+    _lib.load().n3d_graph_destroy(C.c_void_p(graph_exec))
 
 
 def step_counter(device):
@@ -1166,8 +1246,13 @@ def sync_signal(flag_ptr, step_ptr, bump=False):
     check(_lib.load().n3d_sync_signal(C.c_void_p(flag_ptr), C.c_void_p(step_ptr), 1 if bump else 0, stream_ptr()), "n3d_sync_signal")
 
 
+SYNC_MAX_POLLS = [None]   # tests: force every wait of the side schedule to give up after this many polls
+
+
 def sync_wait(flag_ptr, step_ptr, timeouts_ptr, bump=False, max_polls=5000000):
     """hold the current stream until *flag >= *step (bounded poll: ~0.3 us per try)"""
+    if SYNC_MAX_POLLS[0] is not None:
+        max_polls = SYNC_MAX_POLLS[0]
     check(_lib.load().n3d_sync_wait(C.c_void_p(flag_ptr), C.c_void_p(step_ptr), C.c_void_p(timeouts_ptr), 1 if bump else 0, int(max_polls),
                                     stream_ptr()), "n3d_sync_wait")
 

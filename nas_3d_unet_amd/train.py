@@ -37,6 +37,9 @@ def _loss_of(model, loss_fn, x, t):
     return loss_fn(model(x), t)
 
 
+GRAD_HEADER = 4   # floats in front of a flat gradient buffer (FlatParams.grad_full)
+
+
 class FlatParams:
     """Re-homes a list of parameters into one flat buffer (+ a flat gradient buffer)."""
 
@@ -48,7 +51,10 @@ class FlatParams:
             n += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned
         self.numel = n
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=device)
+        # 16 bytes in front of the gradients: word 0 is the "a stream hand-off of this rank timed out" flag that data-parallel
+        # ranks SUM-all-reduce together with the gradients (GradSync), so that every rank withholds the same update
+        self.grad_full = torch.zeros(n + GRAD_HEADER, dtype=torch.float32, device=device)
+        self.grad = self.grad_full[GRAD_HEADER:]
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=device)
         self.step = K.step_counter(device) if torch.device(device).type == "cuda" else torch.zeros(1, dtype=torch.int32, device=device)
@@ -62,9 +68,9 @@ class FlatParams:
                 p._n3d_grad = g  # backward kernels write here (programs.py / kernels.grad_target)
                 p.grad = g
 
-    def adam(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, lr_dev=None):
+    def adam(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, lr_dev=None, guard=None):
         K.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step, lr, betas[0], betas[1], eps,
-                    weight_decay, grad_scale, True, lr_dev)
+                    weight_decay, grad_scale, True, lr_dev, guard)
 
 
 class PlateauLR:
@@ -122,7 +128,10 @@ class GradSync:
     element ranges in ISSUE order (default: n_buckets equal slices).  backend "torch" = torch.distributed.all_reduce;
     "rccl" = the C ABI's n3d_comm_allreduce_sum on a communicator of its own (unique id exchanged through the process group)."""
 
-    def __init__(self, flat_grad, process_group=None, n_buckets=2, comm_stream=None, ranges=None, backend=None):
+    def __init__(self, flat_grad, process_group=None, n_buckets=2, comm_stream=None, ranges=None, backend=None, header=None):
+        """header: the full buffer `flat_grad` is a view of (FlatParams.grad_full: GRAD_HEADER floats in front of it) -- those
+        words are exchanged together with the bucket that is issued LAST (the one that starts at 0)"""
+        self.header = header
         self.g = flat_grad
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -179,13 +188,16 @@ class GradSync:
         a, b = self.ranges[i]
         if b <= a:
             return
+        buf = self.g
+        if self.header is not None and a == 0 and i == len(self.ranges) - 1:
+            buf, b = self.header, b + GRAD_HEADER      # the hand-off flag rides in front of the last bucket
         if self._comm is not None:
             from . import _lib
             import ctypes as C
-            _lib.check(_lib.load().n3d_comm_allreduce_sum(self._comm, C.c_void_p(self.g.data_ptr() + 4 * a), b - a,
+            _lib.check(_lib.load().n3d_comm_allreduce_sum(self._comm, C.c_void_p(buf.data_ptr() + 4 * a), b - a,
                                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), "n3d_comm_allreduce_sum")
         else:
-            dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.pg)
+            dist.all_reduce(buf[a:b], op=dist.ReduceOp.SUM, group=self.pg)
 
     def all_reduce(self):
         """sum-reduce every bucket, in issue order"""
@@ -206,18 +218,23 @@ class GradSync:
 _capture_streams = {}
 
 
+def _dev_key(device):
+    """index of a torch device; an index-less 'cuda' means the current device"""
+    device = torch.device(device)
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
 def capture_stream(device):
     """the ONE stream every trainer of this process warms up and captures on.  Streams are hardware queues: with more of them than
     the scheduler keeps resident side by side (four, counting the default stream, on this stack) a device-side wait of the side
     schedule is only relieved at the end of a time slice -- so nothing here makes a stream it does not need"""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = _dev_key(device)
     st = _capture_streams.get(key)
     if st is None:
         st = _capture_streams[key] = torch.cuda.Stream(device=device)
     return st
 
 
-_side_prio = [None]
 _side_streams = {}   # device index -> [side streams made so far]: trainers share them (every new HIP stream may become another
                      # hardware queue, and with more queues than the scheduler keeps resident a spinning wait kernel is only
                      # relieved at the end of a ~1 ms time slice)
@@ -229,24 +246,15 @@ def _low_priority_stream(device):
     if os.environ.get("N3D_SIDE_PRIORITY", "low") != "low":
         return torch.cuda.Stream(device=device)
     try:
-        import ctypes as C
-        hip = C.CDLL("libamdhip64.so")
-        if _side_prio[0] is None:
-            lo, hi = C.c_int(0), C.c_int(0)
-            if hip.hipDeviceGetStreamPriorityRange(C.byref(lo), C.byref(hi)) != 0:
-                raise OSError("hipDeviceGetStreamPriorityRange")
-            _side_prio[0] = lo.value
         with torch.cuda.device(device):
-            h = C.c_void_p()
             # (A CU mask on the side stream does not help: hipExtStreamCreateWithCUMask makes a BLOCKING stream -- next to torch's
             # legacy default stream every hand-off then takes a time slice, a 9.6 ms step -- and with the whole step moved to a
             # non-blocking stream, a side stream held to 28 or 24 compute units of every XCD [mask bit i = CU i // 8 of XCD i % 8,
             # tools/cumask_map.cpp; a mask that empties an XCD is ignored] leaves the chain's time under the side work where it
             # was, 2.01 ms: what the side work costs the chain is not compute units.  profiles/r03_contention_probes.log)
-            if hip.hipStreamCreateWithPriority(C.byref(h), 1, _side_prio[0]) != 0 or not h.value:   # 1 = hipStreamNonBlocking
-                raise OSError("hipStreamCreateWithPriority")
-        return torch.cuda.ExternalStream(h.value, device=device)
-    except Exception:
+            h = K.stream_create_low_priority()     # through libn3d: the HIP runtime that launches the kernels makes the stream
+        return torch.cuda.ExternalStream(h, device=device)
+    except K.N3DError:
         return torch.cuda.Stream(device=device)
 
 
@@ -260,7 +268,7 @@ def reserve_side_streams(device, n=2):
     device = torch.device(device)
     if device.type != "cuda":
         return []
-    pool = _side_streams.setdefault(device.index or 0, [])
+    pool = _side_streams.setdefault(_dev_key(device), [])
     made = False
     while len(pool) < n:
         pool.append(_low_priority_stream(device))
@@ -288,8 +296,14 @@ class SideSchedule:
     slab reduction.  Main chain, side work and tail are replayed as three separately launched HIP graphs: an event between
     graph launches costs ~190 us per hand-off on this stack and an intra-graph fork ~19 us per edge without overlapping, a
     flag costs a ~2 us kernel on each side (tools/handoff_cost.cpp).
-    Device words of `sync` (int32): [0] main-stream step, [1] time-outs, [2] side-stream step, [8 + i] flag of cut i,
-    [8 + JOIN] side work of this step done."""
+    Device words of `sync` (int32): [0] main-stream step, [1] time-outs, [2] side-stream step, [3] weight-gradient stream step,
+    [4] time-outs the host has acknowledged, [8 + i] flag of cut i, [8 + JOIN] side work of this step done.
+
+    A wait that gives up lets its stream go on (never a hung GPU), so the step's gradients may be wrong.  That must not reach the
+    weights: every optimizer launch of a trainer with a SideSchedule is GUARDED (`guard()`, n3d_adam_step_guarded) -- while
+    sync[1] != sync[4] it updates nothing, writes NaN to the loss and sets a host-visible word.  The trainers poll that word at
+    every step() (no HIP call) and at every host-visible point (check()); a time-out is FATAL for the schedule: the trainer
+    raises until `acknowledge()` (Trainer.recover) has been called, which also retires the side schedule."""
     JOIN = 400
 
     def __init__(self, device, ctx, min_queue=None, wgrad_stream=False):
@@ -310,6 +324,8 @@ class SideSchedule:
         self.sync = torch.zeros(8 + self.JOIN + 8, dtype=torch.int32, device=device)
         self.sync[0] = 1
         self.sync[2] = 1
+        self.host_word = K.HostWord()     # set by a guarded update that was withheld
+        self.failed = 0                   # time-outs seen and not yet acknowledged (the trainers refuse to step while > 0)
         self._cuts = 0
         self._main_jobs = {}
         self._last_cut = -1
@@ -351,7 +367,7 @@ class SideSchedule:
         import time
         main = torch.cuda.current_stream(self.device)
         rounds = 8
-        pool = _side_streams.setdefault(self.device.index or 0, [])
+        pool = _side_streams.setdefault(_dev_key(self.device), [])
         for attempt in range(5):
             if attempt < len(pool):
                 side = pool[attempt]         # a stream an earlier trainer of this process made: reuse before making another
@@ -382,13 +398,44 @@ class SideSchedule:
                 return side
         return None
 
+    def guard(self, loss=None, peer_flag=None):
+        """UpdateGuard for an optimizer launch behind this schedule's hand-offs (loss: the scalar that turns NaN)"""
+        return K.UpdateGuard(self.ptr(1), self.ptr(4), peer_flag, loss.data_ptr() if loss is not None else None, self.host_word.ptr)
+
+    def _fail(self, n):
+        raise K.N3DError("side-stream schedule: %d device-side wait(s) timed out -- the streams did not run concurrently.  The updates of "
+                         "the affected steps were WITHHELD on the device (weights, Adam moments and step counters are those of the last "
+                         "good step; the loss of a withheld step reads NaN).  The trainer refuses to step until recover() is called, "
+                         "which acknowledges the time-outs and continues on one stream (N3D_SIDE_WGRAD=0 turns the schedule off)" % n)
+
+    def poll(self):
+        """host-only test (no HIP call, no synchronisation): raises if a guarded update has been withheld, or if an earlier
+        check() found time-outs that nobody has acknowledged"""
+        if self.failed or self.host_word.value:
+            if not self.failed:
+                self.failed = max(1, int(self.sync[1].item()) - self.seen)
+            self._fail(self.failed)
+
     def check(self):
-        """raises if a device-side wait ever timed out (the results of that step would be wrong)"""
+        """synchronising test: raises if a device-side wait has timed out since the last acknowledge()"""
         n = int(self.sync[1].item())
         if n != self.seen:
-            self.seen = n
-            raise K.N3DError("side-stream schedule: %d device-side wait(s) timed out -- the two streams did not run concurrently; "
-                             "gradients of those steps are unreliable (N3D_SIDE_WGRAD=0 turns the schedule off)" % n)
+            self.failed = n - self.seen
+        if self.failed or self.host_word.value:
+            self._fail(max(self.failed, 1))
+
+    def sync_timeouts_now(self):
+        """the device's time-out counter (synchronises)"""
+        return int(self.sync[1].item())
+
+    def acknowledge(self):
+        """the caller has dealt with the time-outs (Trainer.recover): updates are allowed again"""
+        torch.cuda.synchronize(self.device)
+        self.sync[4] = self.sync[1]
+        self.seen = int(self.sync[1].item())
+        self.failed = 0
+        self.host_word.clear()
+        torch.cuda.synchronize(self.device)
 
     class _Deferring:
         def __init__(self, owner):
@@ -559,39 +606,34 @@ class SideSchedule:
         return SideSchedule._Forward(self)
 
     # -- the side stream's work as a HIP graph captured next to torch's capture of the main stream --------------------------------
-    def _hip(self):
-        import ctypes as C
-        if getattr(self, "_hiplib", None) is None:
-            self._hiplib = C.CDLL("libamdhip64.so")
-        return self._hiplib
-
     def raw_capture_begin(self):
         """the side stream starts capturing (thread-local mode, like torch's capture of the main stream); launches redirected to it
-        while the main stream is being captured land in a graph of their own"""
-        import ctypes as C
+        while the main stream is being captured land in a graph of their own.  Capture, instantiation and launch go through
+        libn3d (n3d_stream_capture_* / n3d_graph_*): the HIP runtime that launches the kernels owns the graphs."""
         for st in ([self.stream, self.wstream] if self.split else [self.stream]):
-            if self._hip().hipStreamBeginCapture(C.c_void_p(st.cuda_stream), 1) != 0:
-                raise K.N3DError("hipStreamBeginCapture on a side stream failed")
+            K.stream_capture_begin(st.cuda_stream)
 
     def raw_capture_end(self):
-        """-> executable graph handle (replayed with raw_replay)"""
-        import ctypes as C
-        hip, out = self._hip(), []
+        """-> [(executable graph handle, stream)] (replayed with raw_replay, released with raw_destroy)"""
+        out, err = [], None
         for st in ([self.stream, self.wstream] if self.split else [self.stream]):
-            g, ex = C.c_void_p(), C.c_void_p()
-            if hip.hipStreamEndCapture(C.c_void_p(st.cuda_stream), C.byref(g)) != 0 or not g.value:
-                raise K.N3DError("hipStreamEndCapture on a side stream failed")
-            if hip.hipGraphInstantiate(C.byref(ex), g, None, None, C.c_size_t(0)) != 0 or not ex.value:
-                raise K.N3DError("hipGraphInstantiate of a side graph failed")
-            self._raw_graphs = getattr(self, "_raw_graphs", []) + [(g, ex)]
-            out.append((ex, st))
+            try:
+                out.append((K.stream_capture_end(st.cuda_stream), st))
+            except K.N3DError as e:      # end the other stream's capture too before raising
+                err = e
+        if err is not None:
+            self.raw_destroy(out)
+            raise err
         return out
 
     def raw_replay(self, execs):
-        import ctypes as C
         for ex, st in execs:
-            if self._hip().hipGraphLaunch(ex, C.c_void_p(st.cuda_stream)) != 0:
-                raise K.N3DError("hipGraphLaunch of a side graph failed")
+            K.graph_launch(ex, st.cuda_stream)
+
+    @staticmethod
+    def raw_destroy(execs):
+        for ex, _ in execs or ():
+            K.graph_destroy(ex)
 
     def deferring(self):
         """with side.deferring(): run forward + backward; weight-gradient launches are queued, flags stored at the cut points"""
@@ -625,7 +667,8 @@ class SideSchedule:
                     self._live_cuts += 1
                     self._live_cuts_max = max(self._live_cuts_max, self._live_cuts)
                     at = self.early_at if self.early_at >= 0 else (int(round(0.55 * self._live_cuts_max)) if self._live_cuts_max >= 8 else 0)
-                    if at and self._live_cuts == at:
+                    if at and self._live_cuts == at and not inline:   # (an inline group runs on the OTHER side stream: the slabs of
+                        # the weight-gradient stream's launches are not ordered in front of a reduction issued there)
                         # the slabs of everything launched so far (and of the chain's own jobs in front of this flag) are reduced on
                         # the weight-gradient stream here: the reduction behind the join only has the last groups left
                         ctx.finalize_now(self._main_jobs[i])
@@ -698,7 +741,9 @@ def flatten_params(params, device=None):
         offs.append(n)
         n += (p.numel() + 3) // 4 * 4
     flat = torch.zeros(n, dtype=torch.float32, device=device)
-    grad = torch.zeros(n, dtype=torch.float32, device=device)
+    full = torch.zeros(n + GRAD_HEADER, dtype=torch.float32, device=device)   # header: see FlatParams.grad_full
+    grad = full[GRAD_HEADER:]
+    grad._n3d_full = full
     with torch.no_grad():
         for p, o in zip(params, offs):
             v = flat[o:o + p.numel()].view(p.shape)
@@ -706,6 +751,27 @@ def flatten_params(params, device=None):
             p.data = v
             p.grad = grad[o:o + p.numel()].view(p.shape)
     return flat, grad, offs
+
+
+def _agree_on_side(side, device, world, pg):
+    """data parallel: the side-stream probe is rank-local and timing-based, but every rank must take the same schedule decisions
+    (they decide which graphs exist and, for the trainers' own timing runs, nothing else may differ between ranks): the side
+    schedule is on only if EVERY rank has one"""
+    if world > 1 and torch.device(device).type == "cuda":
+        ok = torch.tensor([1.0 if side is not None else 0.0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=pg)
+        if float(ok.item()) == 0.0:
+            return None
+    return side
+
+
+def _agree_bool(flag, device, world, pg):
+    """True only if `flag` is true on every rank (one MIN all-reduce; single process: flag itself)"""
+    if world > 1 and torch.device(device).type == "cuda":
+        ok = torch.tensor([1.0 if flag else 0.0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=pg)
+        return float(ok.item()) != 0.0
+    return bool(flag)
 
 
 def _dropout_states(model):
@@ -770,6 +836,7 @@ class Trainer:
         self._side_force = side_wgrad == "force" or (side_wgrad is None and env == "force")
         self._side_explicit = side_wgrad is not None     # an eager trainer (graph=False) takes the side schedule only when asked to
         self._use_side = False
+        self._side_retired = False   # recover() after a timed-out hand-off: the rest of the run stays on one stream
         self.schedule_times = None   # (plain seconds per step, side seconds per step) measured at capture
         if storage is not None:
             from . import unet as _unet
@@ -806,8 +873,9 @@ class Trainer:
         self.side = SideSchedule(self.device, self.ctx, wgrad_stream=_fused.SIDE_PAIRS_BWD) if (self.side_wgrad and self.device.type == "cuda") else None
         if self.side is not None and self.side.stream is None:
             self.side = None
+        self.side = _agree_on_side(self.side, self.device, self.world, self.pg)
         ranges = [r for _, r in self._buckets] if self._buckets is not None else None
-        self.sync = GradSync(self.fp.grad, self.pg, 1, self._comm_stream, ranges, comm)
+        self.sync = GradSync(self.fp.grad, self.pg, 1, self._comm_stream, ranges, comm, header=self.fp.grad_full)
         if self.world > 1:
             dist.broadcast(self.fp.flat, src=0, group=self.pg)
 
@@ -919,12 +987,45 @@ class Trainer:
         return self._buckets is not None and self._direct_ok()
 
     def _side_ok(self):
-        return self.side is not None and self._buckets is None and self._direct_ok()
+        return self.side is not None and not getattr(self, "_side_retired", False) and self._buckets is None and self._direct_ok()
 
     def check_sync(self):
-        """raises if a device-side wait of the side-stream schedule ever timed out"""
+        """synchronising check (call it at every host-visible point: before a checkpoint is written, at the end of an epoch, before
+        a loss is reported): raises if a device-side wait of the side-stream schedule has timed out.  The updates of such steps
+        were withheld on the device, so the weights are those of the last good step; `recover()` continues on one stream."""
         if self.side is not None:
             self.side.check()
+
+    def sync_timeouts(self):
+        """device-side waits that have timed out since the trainer was built (synchronises; 0 without a side schedule)"""
+        return int(self.side.sync[1].item()) if self.side is not None else 0
+
+    def _poll(self):
+        if self.side is not None:
+            self.side.poll()
+
+    def recover(self):
+        """after a time-out (check_sync / step raised): acknowledge it and go on WITHOUT the side-stream schedule.  Nothing has to
+        be restored -- the guarded updates of the affected steps never ran -- but those batches are lost to training."""
+        if self.side is None:
+            return
+        self.side.acknowledge()
+        self._use_side = False
+        self._retire_side_graphs()
+        self._side_retired = True
+        if self._graph is None and self._segments is None:
+            self._static_x = self._static_t = None      # "force" had no plain graph: the next step captures one
+
+    def _retire_side_graphs(self):
+        g, self._side_graphs = self._side_graphs, None
+        if g is not None:
+            SideSchedule.raw_destroy(g[1])
+
+    def _guard(self, loss=None):
+        """UpdateGuard of this trainer's optimizer launches (None without a side schedule: nothing can time out)"""
+        if self.side is None:
+            return None
+        return self.side.guard(loss, self.fp.grad_full.data_ptr() if self.dp_path else None)
 
     def _side_pass(self, x, t):
         """the autograd-free pipeline on two streams (SideSchedule): every deferrable weight-gradient launch is queued and handed to
@@ -949,10 +1050,17 @@ class Trainer:
             self.sync.reduce_range(j)
 
     def _allreduce(self):
+        # word 0 of the gradient header: "a hand-off of THIS rank timed out" -- summed over the ranks with the gradients, so that
+        # every rank withholds the same update (a rank without a side schedule contributes 0)
+        if self.sync.active:
+            if self.side is not None:
+                K.guard_flag(self.side.ptr(1), self.side.ptr(4), self.fp.grad_full.data_ptr())
+            else:
+                self.fp.grad_full[:1].zero_()
         self.sync.all_reduce()
 
-    def _update(self):
-        self.fp.adam(self.lr, self.betas, self.eps, 0.0, 1.0 / self.world, self.lr_dev)
+    def _update(self, loss=None):
+        self.fp.adam(self.lr, self.betas, self.eps, 0.0, 1.0 / self.world, self.lr_dev, self._guard(loss))
 
     def set_lr(self, lr):
         """new learning rate for the following steps (also inside an already captured graph)"""
@@ -975,14 +1083,15 @@ class Trainer:
             loss = self._fwd_bwd(x, t)
             if self.dp_path:
                 self._allreduce()
-        self._update()
+        self._update(loss)
         return loss
 
     # -- public ---------------------------------------------------------------------------------
     def step(self, x, t):
+        self._poll()     # host-only: a withheld update (timed-out hand-off) is fatal until recover()
         if not self.use_graph:
             return self._eager(x, t)
-        if self._graph is None and self._segments is None and self._side_graphs is None:
+        if self._static_x is None or (self._graph is None and self._segments is None and self._side_graphs is None):
             self._capture(x, t)
         if x.shape != self._static_x.shape or t.shape != self._static_t.shape:
             # a batch of another shape (the reference's generator yields a smaller last batch of an epoch): the captured
@@ -1003,12 +1112,12 @@ class Trainer:
                 g.replay()
                 self._reduce_on_side(j)
             torch.cuda.current_stream().wait_stream(self._comm_stream)
-            self._update()
+            self._update(self._static_loss)
             return self._static_loss
         self._graph.replay()
         if self.dp_path:
             self._allreduce()
-            self._update()
+            self._update(self._static_loss)
         return self._static_loss
 
     def input_buffers(self):
@@ -1016,7 +1125,7 @@ class Trainer:
         straight into them (datastep.patch_batch(out=...)) and passes THESE tensors to step() skips the per-step input copy."""
         return self._static_x, self._static_t
 
-    def _replay_side(self):
+    def _replay_side(self, exchange=True):
         # three graphs, no host-side cross-stream dependency: the streams meet through device flags (SideSchedule)
         # (the side graph goes first: its device-side waits are then in place when the main chain reaches its cuts, also when the
         # host is slower at launching than the GPU at running, e.g. under a profiler)
@@ -1024,15 +1133,15 @@ class Trainer:
         self.side.raw_replay(side_exec)
         g_main.replay()
         g_tail.replay()
-        if self.dp_path:
+        if self.dp_path and exchange:
             self._allreduce()
-            self._update()
+            self._update(self._side_loss)
 
-    def _replay_plain(self):
+    def _replay_plain(self, exchange=True):
         self._graph.replay()
-        if self.dp_path:
+        if self.dp_path and exchange:
             self._allreduce()
-            self._update()
+            self._update(self._static_loss)
 
     def _watched_side_replay(self):
         """one replayed step of the side schedule.  Every 256th one is bracketed with events; one step later (no host wait on the
@@ -1052,7 +1161,8 @@ class Trainer:
             e0, e1 = sd.watch
             sd.watch = None
             e1.synchronize()
-            sd.check()
+            sd.check()      # (the per-step poll() has seen a withheld update long before; this also catches a time-out whose step
+                            # was not followed by an update yet)
             if self.schedule_times is not None and e0.elapsed_time(e1) * 1e-3 > 1.5 * self.schedule_times[0] + 2e-4:
                 import warnings
                 warnings.warn("nas_3d_unet_amd: the side-stream schedule degraded (%.2f ms per step against %.2f ms for the plain graph); "
@@ -1064,14 +1174,21 @@ class Trainer:
         if self._side_force:
             self._use_side = True
             return
-        snap = _Snapshot([self.fp.flat, self.fp.exp_avg, self.fp.exp_avg_sq, self.fp.step, self.fp.grad] + _dropout_states(self.model))
-        tp = _time_schedule(self._replay_plain, self.device)
-        ts = _time_schedule(self._replay_side, self.device)
-        self.side.check()
+        snap = _Snapshot([self.fp.flat, self.fp.exp_avg, self.fp.exp_avg_sq, self.fp.step, self.fp.grad_full] + _dropout_states(self.model))
+        # data parallel: the timing runs replay the graphs only -- no collective, no update -- so a rank whose timing differs (or
+        # whose side streams misbehave) cannot mispair all-reduces with its peers; the DECISION is then agreed on (MIN over ranks)
+        tp = _time_schedule(lambda: self._replay_plain(exchange=False), self.device)
+        ts = _time_schedule(lambda: self._replay_side(exchange=False), self.device)
+        bad = self.side.sync_timeouts_now() != self.side.seen
         snap.restore()
+        if bad:
+            # hand-offs timed out while the side schedule was being timed: the state is restored, the schedule is not used
+            self.side.acknowledge()
         torch.cuda.synchronize(self.device)
         self.schedule_times = (tp, ts)
-        self._use_side = ts < tp
+        self._use_side = _agree_bool(ts < tp and not bad, self.device, self.world, self.pg)
+        if not self._use_side:
+            self._retire_side_graphs()     # the plain graph won: the side graphs (and their raw HIP executables) are released
 
     def _capture(self, x, t):
         """capture (and, with a side stream, choose the schedule); the Dropout3d generators come out as they went in, so the
@@ -1112,7 +1229,7 @@ class Trainer:
         with torch.cuda.graph(g, capture_error_mode="thread_local"):  # RCCL's watchdog thread may touch the runtime meanwhile
             self._static_loss = self._fwd_bwd(self._static_x, self._static_t)
             if not self.dp_path:
-                self._update()
+                self._update(self._static_loss)
         self._graph = g
         if sided:
             self._choose_schedule()
@@ -1142,7 +1259,7 @@ class Trainer:
             g_tail.capture_begin(pool=pool, capture_error_mode="thread_local")
             sd.finish()
             if not self.dp_path:
-                self._update()
+                self._update(self._side_loss)
             g_tail.capture_end()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -1212,6 +1329,8 @@ class SearchTrainer:
         self.side = SideSchedule(self.device, self.ctx, wgrad_stream=True) if (self.side_wgrad and self.device.type == "cuda") else None
         if self.side is not None and self.side.stream is None:
             self.side = None
+        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        self.side = _agree_on_side(self.side, self.device, self.world, process_group)
         if self.side is not None and "N3D_SIDE_EARLY_FINALIZE" not in os.environ:
             self.side.early_finalize = 6      # 384 slab jobs per weight pass: reducing most of them early shrinks the tail 0.23 -> 0.15 ms
         self.use_graph = graph
@@ -1228,8 +1347,8 @@ class SearchTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
         self.dp_path = self.world > 1 or (dist.is_initialized() and os.environ.get("N3D_FORCE_DP") == "1")
-        self.sync_alpha = GradSync(self.agrad, self.pg, 1, None, None, "torch")      # tiny: always through torch.distributed
-        self.sync_kernel = GradSync(self.fp.grad, self.pg, 1, None, None, comm)
+        self.sync_alpha = GradSync(self.agrad, self.pg, 1, None, None, "torch", header=self.agrad._n3d_full)   # tiny: always through torch.distributed
+        self.sync_kernel = GradSync(self.fp.grad, self.pg, 1, None, None, comm, header=self.fp.grad_full)
         self._graphs = None
         if self.world > 1:
             dist.broadcast(self.fp.flat, src=0, group=self.pg)
@@ -1291,24 +1410,52 @@ class SearchTrainer:
         if not self.ctx.frozen and not arch:
             self.ctx.freeze()
         if update:
-            self._update(arch)
+            self._update(arch, loss.detach())
         return loss.detach()
 
     def check_sync(self):
+        """synchronising check for timed-out hand-offs (see Trainer.check_sync)"""
         if self.side is not None:
             self.side.check()
 
-    def _update(self, arch):
-        """exchange (data parallel) + Adam of the pass that just ran"""
+    def sync_timeouts(self):
+        return int(self.side.sync[1].item()) if self.side is not None else 0
+
+    def recover(self):
+        """after a time-out: acknowledge it and go on without the side-stream schedule (see Trainer.recover)"""
+        if self.side is None:
+            return
+        self.side.acknowledge()
+        self._use_side = False
+        self._retire_side_graphs()
+        self._side_active = False
+        self._side_retired = True
+        if self._graph is None and self._graphs is None:
+            self._sx = None      # "force" had no plain graphs: the next step captures them
+
+    def _retire_side_graphs(self):
+        gs, self._side_graphs = self._side_graphs, None
+        for g in gs or ():
+            SideSchedule.raw_destroy(g[1])
+
+    def _update(self, arch, loss=None):
+        """exchange (data parallel) + Adam of the pass that just ran; guarded: a timed-out hand-off (on any rank) withholds it"""
+        sd = self.side
+        gbuf = self.agrad._n3d_full if arch else self.fp.grad_full
+        sync = self.sync_alpha if arch else self.sync_kernel
+        if self.dp_path:
+            if sync.active:
+                if sd is not None:
+                    K.guard_flag(sd.ptr(1), sd.ptr(4), gbuf.data_ptr())
+                else:
+                    gbuf[:1].zero_()
+            sync.all_reduce()
+        guard = sd.guard(loss, gbuf.data_ptr() if self.dp_path else None) if sd is not None else None
         if arch:
-            if self.dp_path:
-                self.sync_alpha.all_reduce()
             K.adam_step(self.aflat, self.agrad, self.a_m, self.a_v, self.a_step, self.lr_shell, self.betas[0], self.betas[1], self.eps,
-                        grad_scale=1.0 / self.world, lr_dev=self.lr_shell_dev)
+                        grad_scale=1.0 / self.world, lr_dev=self.lr_shell_dev, guard=guard)
         else:
-            if self.dp_path:
-                self.sync_kernel.all_reduce()
-            self.fp.adam(self.lr_kernel, self.betas, self.eps, 0.0, 1.0 / self.world, self.lr_kernel_dev)
+            self.fp.adam(self.lr_kernel, self.betas, self.eps, 0.0, 1.0 / self.world, self.lr_kernel_dev, guard)
 
     def _both(self, x, t, vx, vt, update=True):
         la = self._pass(vx, vt, True, update)
@@ -1340,7 +1487,7 @@ class SearchTrainer:
                 g_tail.capture_begin(pool=pool, capture_error_mode="thread_local")
                 sd.finish()
                 if not self.dp_path:
-                    self._update(arch)
+                    self._update(arch, losses[-1])
                 g_tail.capture_end()
             graphs.append((g_main, side_exec, g_tail))
         torch.cuda.current_stream().wait_stream(s)
@@ -1349,9 +1496,11 @@ class SearchTrainer:
 
     def step(self, x, t, val_x, val_t):
         """returns (architecture-pass loss, weight-pass loss) as device scalars"""
+        if self.side is not None:
+            self.side.poll()     # host-only: a withheld update (timed-out hand-off) is fatal until recover()
         if not self.use_graph:
             return self._both(x, t, val_x, val_t)
-        if self._graph is None and self._graphs is None and self._side_graphs is None:
+        if getattr(self, "_sx", None) is None or (self._graph is None and self._graphs is None and self._side_graphs is None):
             drop_snap = _dropout_snapshot(self.model, self.device)   # restored below: masks independent of the warm-up passes
             self._sx, self._st, self._svx, self._svt = x.clone(), t.clone(), val_x.clone(), val_t.clone()
             # warm-up on a side stream (allocator + lazy module state) WITHOUT the optimizer launches: weights, alphas,
@@ -1363,9 +1512,10 @@ class SearchTrainer:
                     self._both(self._sx, self._st, self._svx, self._svt, update=False)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
-            if self.side is not None:
+            sided = self.side is not None and not getattr(self, "_side_retired", False)
+            if sided:
                 self._capture_side(s)
-            if self.side is not None and self._side_force:
+            if sided and self._side_force:
                 self._use_side = True
             else:
                 self._side_active = False
@@ -1383,8 +1533,8 @@ class SearchTrainer:
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):  # RCCL's watchdog thread may touch the runtime meanwhile
                         self._losses = self._both(self._sx, self._st, self._svx, self._svt)
                     self._graph = g
-                self._side_active = True
-                if self.side is not None:
+                self._side_active = sided
+                if sided:
                     self._choose_schedule()
             drop_snap.restore()
         if any(a.shape != b.shape for a, b in ((x, self._sx), (t, self._st), (val_x, self._svx), (val_t, self._svt))):
@@ -1411,32 +1561,40 @@ class SearchTrainer:
         """(x, t, val_x, val_t) device buffers the captured graphs read (see Trainer.input_buffers)"""
         return self._sx, self._st, self._svx, self._svt
 
-    def _replay_side(self):
-        for arch, (g_main, side_exec, g_tail) in zip((True, False), self._side_graphs):
+    def _replay_side(self, exchange=True):
+        for k, (arch, (g_main, side_exec, g_tail)) in enumerate(zip((True, False), self._side_graphs)):
             self.side.raw_replay(side_exec)      # first: see Trainer._replay_side
             g_main.replay()
             g_tail.replay()
-            if self.dp_path:
-                self._update(arch)
+            if self.dp_path and exchange:
+                self._update(arch, self._side_losses[k])
 
-    def _replay_plain(self):
+    def _replay_plain(self, exchange=True):
         if self._graphs is not None:
             self._graphs[0].replay()
-            self._update(True)
+            if exchange:
+                self._update(True, self._losses[0])
             self._graphs[1].replay()
-            self._update(False)
+            if exchange:
+                self._update(False, self._losses[1])
             return
         self._graph.replay()
 
     def _choose_schedule(self):
         """time the two captured schedules on the real step (state saved and restored around it) and keep the faster one"""
-        snap = _Snapshot([self.fp.flat, self.fp.exp_avg, self.fp.exp_avg_sq, self.fp.step, self.fp.grad, self.aflat, self.agrad, self.a_m, self.a_v,
-                          self.a_step] + _dropout_states(self.model))
-        tp = _time_schedule(self._replay_plain, self.device, warm=1, reps=3)
-        ts = _time_schedule(self._replay_side, self.device, warm=1, reps=3)
-        self.side.check()
+        snap = _Snapshot([self.fp.flat, self.fp.exp_avg, self.fp.exp_avg_sq, self.fp.step, self.fp.grad_full, self.aflat, self.agrad._n3d_full,
+                          self.a_m, self.a_v, self.a_step] + _dropout_states(self.model))
+        # data parallel: graphs only, no collective and no update while timing; the decision is agreed on (Trainer._choose_schedule)
+        ex = not self.dp_path
+        tp = _time_schedule(lambda: self._replay_plain(exchange=ex), self.device, warm=1, reps=3)
+        ts = _time_schedule(lambda: self._replay_side(exchange=ex), self.device, warm=1, reps=3)
+        bad = self.side.sync_timeouts_now() != self.side.seen
         snap.restore()
+        if bad:
+            self.side.acknowledge()
         torch.cuda.synchronize(self.device)
         self.schedule_times = (tp, ts)
-        self._use_side = ts < tp
+        self._use_side = _agree_bool(ts < tp and not bad, self.device, self.world, self.pg)
+        if not self._use_side:
+            self._retire_side_graphs()
 

@@ -268,14 +268,16 @@ def test_trainer_bf16_storage_graph_replay():
     assert out["bf16"][2] < out["bf16"][0]
 
 
-def test_bf16_storage_trains_with_fp32_at_128():
+@pytest.mark.parametrize("scale", [1.0 / 50.0, 1.0], ids=["scaled", "bench-range"])
+def test_bf16_storage_trains_with_fp32_at_128(scale):
     """BASELINE configs[4] at its own size (config.yml:58; train.py:117-128): 20 HIP-graph-replayed Adam steps on a batch of
     4x128^3 patches, bf16 storage against the fp32 trainer from the same weights -- the loss curves must stay together
-    (<= 2e-3 at EVERY step) and must actually move."""
+    (<= 2e-3 at EVERY step) and must actually move.  "bench-range": the synthetic batch exactly as bench.py feeds it (values in
+    [10, 110] inside the ball, 0 outside: preprocess.py:87-93), not rescaled."""
     import bench
     from nas_3d_unet_amd.train import Trainer
     xn, tn = bench.synthetic_batch(2, 128, 77)
-    x, t = bench.to_patch_layout(dev(xn / 50.0)), dev(tn)
+    x, t = bench.to_patch_layout(dev((xn * scale).astype(np.float32))), dev(tn)
     curves = []
     for storage in (None, "bf16"):
         net, _ = build_net("searched", "G_CONV", 4)       # closed-form weights, head Dropout3d off: the two runs see the same net

@@ -48,19 +48,52 @@ def test_trainer_dp_schedules_match_single_gpu(one_rank_group, graph, buckets, c
         # the bucketed exchange replays the single-stream schedule (graph segments), everything else the side-stream one: the
         # reference trainer is given the same schedule, so the comparison is bit for bit (the two schedules differ by an fp32
         # rounding of the preprocess epilogue backward, and Adam turns 1e-6 on a weight into 1e-3 within three steps:
-        # tools/dbg/chaos_probe.py; tests/test_gpu_side.py compares the schedules themselves)
-        ref = Trainer(net, graph=graph, side_wgrad=False if (graph and buckets > 1) else None)
+        # tools/chaos_probe.py, profiles/r04_chaos_probe.log; tests/test_gpu_side.py compares the schedules themselves)
+        # (graph, one bucket: both trainers are PINNED to the side schedule -- left to themselves each would pick by its own
+        # wall-clock timing, and the comparison below is bit for bit)
+        sched = False if (graph and buckets > 1) else ("force" if graph else None)
+        ref = Trainer(net, graph=graph, side_wgrad=sched)
         assert not ref.dp_path
         lr_, wr = _losses_and_weights(ref, x, t)
     finally:
         os.environ["N3D_FORCE_DP"] = "1"
     net, _ = build_net("searched", "G_CONV", 4)
-    tr = Trainer(net, graph=graph, n_buckets=buckets, comm=comm)
+    tr = Trainer(net, graph=graph, n_buckets=buckets, comm=comm, side_wgrad=sched)
     assert tr.dp_path and len(tr.sync.ranges) == buckets and (comm != "rccl" or tr.sync._comm is not None)
+    assert ref._use_side == tr._use_side or buckets > 1
     l, w = _losses_and_weights(tr, x, t)
     if graph and buckets > 1:
         assert tr._segments is not None and len(tr._segments) == buckets
     assert l == lr_ and torch.equal(w, wr)
+
+
+def test_dp_peer_flag_withholds_the_update_on_every_rank(one_rank_group):
+    """data parallel: the "a hand-off of this rank timed out" word rides in front of the gradients through the SUM all-reduce, and
+    the guarded Adam of EVERY rank tests the sum -- here a 1-rank RCCL group: the flag written before the exchange must still
+    withhold the update after it (weights bit-unchanged, loss NaN, next step raises, recover() continues)"""
+    from nas_3d_unet_amd import kernels as K
+    from nas_3d_unet_amd.train import Trainer
+    rng = np.random.default_rng(45)
+    x = dev(rng.standard_normal((2, 4, 32, 32, 32)).astype(np.float32))
+    t = dev((rng.uniform(0, 1, (2, 3, 32, 32, 32)) < 0.3).astype(np.float32))
+    net, _ = build_net("searched", "G_CONV", 4)
+    tr = Trainer(net, graph=True, side_wgrad="force")
+    assert tr.dp_path and tr.side is not None
+    tr.step(x, t)
+    torch.cuda.synchronize()
+    assert float(tr.fp.grad_full[0]) == 0.0 and int(tr.fp.step) == 1
+    w = tr.fp.flat.clone()
+    tr.side.sync[1] += 1
+    l = tr.step(x, t)
+    torch.cuda.synchronize()
+    assert float(tr.fp.grad_full[0]) == 1.0, "the flag did not travel with the gradients"
+    assert torch.isnan(l) and torch.equal(tr.fp.flat, w) and int(tr.fp.step) == 1
+    with pytest.raises(K.N3DError, match="timed out"):
+        tr.step(x, t)
+    tr.recover()
+    l = tr.step(x, t)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(l)) and int(tr.fp.step) == 2 and float(tr.fp.grad_full[0]) == 0.0
 
 
 def test_search_trainer_dp_matches_single_gpu(one_rank_group):
@@ -159,8 +192,11 @@ def test_two_processes_on_one_gpu_equal_the_global_batch(tmp_path, graph, bucket
         # the bucketed exchange replays the single-stream schedule (graph segments), everything else the side-stream one: the
         # reference trainer is given the same schedule, so the comparison is bit for bit (the two schedules differ by an fp32
         # rounding of the preprocess epilogue backward, and Adam turns 1e-6 on a weight into 1e-3 within three steps:
-        # tools/dbg/chaos_probe.py; tests/test_gpu_side.py compares the schedules themselves)
-        ref = Trainer(net, graph=graph, side_wgrad=False if (graph and buckets > 1) else None)
+        # tools/chaos_probe.py, profiles/r04_chaos_probe.log; tests/test_gpu_side.py compares the schedules themselves)
+        # (graph, one bucket: both trainers are PINNED to the side schedule -- left to themselves each would pick by its own
+        # wall-clock timing, and the comparison below is bit for bit)
+        sched = False if (graph and buckets > 1) else ("force" if graph else None)
+        ref = Trainer(net, graph=graph, side_wgrad=sched)
         lr_ = [float(ref.step(dev(xs), dev(ts))) for _ in range(3)]
         wr = ref.fp.flat.detach().cpu()
     finally:

@@ -117,7 +117,7 @@ def test_side_schedule_graph_replay_matches_plain_trainer():
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=2e-5)
     # Adam moves an element whose gradient is fp32 noise by ~lr per step either way, and the two schedules differ by an fp32 rounding
     # of the preprocess epilogue backward: on this net a 1e-6 nudge of 1 % of the weights after step 1 grows to 8e-4 of the norm by
-    # step 4 (tools/dbg/chaos_probe.py).  A weight gradient that went missing moves a whole layer by 4 lr: ~1e-2 of the norm.
+    # step 4 (tools/chaos_probe.py, profiles/r04_chaos_probe.log).  A weight gradient that went missing moves a whole layer by 4 lr: ~1e-2 of the norm.
     d = (out[0][1] - out[1][1]).abs()
     assert float(d.double().norm()) <= 2e-3 * float(out[0][1].double().norm())
 
@@ -238,3 +238,128 @@ def test_supernet_forward_on_two_streams_is_bit_identical():
         assert got[2].keys() == out[0][2].keys()
         for n in got[2]:
             assert torch.equal(got[2][n], out[0][2][n]), n
+
+
+# ---- a timed-out hand-off must never reach the weights (n3d_adam_step_guarded; train.py:121-128: a step is forward, backward,
+# update -- there is no "update from garbage") ---------------------------------------------------------------------------------
+def test_guarded_adam_withholds_the_update():
+    """the kernel-level contract: time-outs != acknowledged (or a peer's flag) -> parameters, moments and the step counter are
+    bit-unchanged, the loss reads NaN, the host word is set; equal counters -> the ordinary update, bit-identical to n3d_adam_step"""
+    from nas_3d_unet_amd import kernels as K
+    n = 10000
+    g = torch.randn(n, device="cuda")
+    mk = lambda: (torch.ones(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), K.step_counter("cuda"))
+    words = torch.zeros(4, dtype=torch.int32, device="cuda")     # [0] time-outs, [1] acknowledged
+    flag = torch.zeros(1, device="cuda")
+    hw = K.HostWord()
+    p0, m0, v0, st0 = mk()
+    K.adam_step(p0, g, m0, v0, st0)                               # reference: the unguarded update
+    for bad_words, bad_flag in ((False, False), (True, False), (False, True)):
+        p, m, v, st = mk()
+        loss = torch.full((), 0.5, device="cuda")
+        words[0], words[1] = (3 if bad_words else 2), 2
+        flag[0] = 1.0 if bad_flag else 0.0
+        hw.clear()
+        guard = K.UpdateGuard(words.data_ptr(), words.data_ptr() + 4, flag.data_ptr(), loss.data_ptr(), hw.ptr)
+        K.adam_step(p, g, m, v, st, guard=guard)
+        torch.cuda.synchronize()
+        if bad_words or bad_flag:
+            assert torch.equal(p, torch.ones_like(p)) and float(m.abs().max()) == 0.0 and float(v.abs().max()) == 0.0
+            assert int(st) == 0 and int(st._base[1] if st._base is not None else 0) == 0
+            assert torch.isnan(loss) and hw.value == 1
+        else:
+            assert torch.equal(p, p0) and torch.equal(m, m0) and torch.equal(v, v0) and int(st) == 1
+            assert float(loss) == 0.5 and hw.value == 0
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_timed_out_handoff_never_reaches_the_weights(graph):
+    """two good steps, then a time-out is counted on the device (what n3d_sync_wait does when it gives up) in the middle of the
+    run: the step's update is withheld (weights, moments, step counter bit-unchanged), its loss is NaN, the NEXT step() raises --
+    and keeps raising -- until recover(), after which training goes on (on one stream)."""
+    from nas_3d_unet_amd import kernels as K
+    from nas_3d_unet_amd.train import Trainer
+    x, t = _batch(59)
+    net, _ = build_net("searched", "G_CONV", 4)
+    tr = Trainer(net, graph=graph, side_wgrad="force" if graph else True)
+    assert tr.side is not None
+    for _ in range(2):
+        l = tr.step(x, t)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(l)) and int(tr.fp.step) == 2 and tr.sync_timeouts() == 0
+    w, m, v = tr.fp.flat.clone(), tr.fp.exp_avg.clone(), tr.fp.exp_avg_sq.clone()
+    tr.side.sync[1] += 1                       # a wait gave up
+    l = tr.step(x, t)
+    torch.cuda.synchronize()
+    assert torch.isnan(l), "the loss of a withheld step must read NaN"
+    assert torch.equal(tr.fp.flat, w) and torch.equal(tr.fp.exp_avg, m) and torch.equal(tr.fp.exp_avg_sq, v) and int(tr.fp.step) == 2
+    for _ in range(2):
+        with pytest.raises(K.N3DError, match="timed out"):
+            tr.step(x, t)
+    with pytest.raises(K.N3DError, match="timed out"):
+        tr.check_sync()
+    assert torch.equal(tr.fp.flat, w) and int(tr.fp.step) == 2
+    tr.recover()
+    l = tr.step(x, t)
+    torch.cuda.synchronize()
+    tr.check_sync()
+    assert np.isfinite(float(l)) and int(tr.fp.step) == 3 and not torch.equal(tr.fp.flat, w)
+    assert not tr._use_side
+
+
+def test_a_real_timed_out_wait_is_caught():
+    """the side graph is launched first and every wait of this capture gives up after ONE poll (a side wait far ahead of its
+    signal): real time-outs, counted by n3d_sync_wait itself.  No update may happen, from the first replay on."""
+    from nas_3d_unet_amd import kernels as K
+    from nas_3d_unet_amd.train import Trainer
+    x, t = _batch(61)
+    net, _ = build_net("searched", "G_CONV", 4)
+    tr = Trainer(net, graph=True, side_wgrad="force")
+    assert tr.side is not None
+    w = tr.fp.flat.clone()
+    K.SYNC_MAX_POLLS[0] = 1
+    try:
+        l = tr.step(x, t)                      # warm-up passes + capture + first replay
+        torch.cuda.synchronize()
+    finally:
+        K.SYNC_MAX_POLLS[0] = None
+    assert tr.sync_timeouts() > 0, "no wait timed out: the injection did not work"
+    assert torch.isnan(l) and torch.equal(tr.fp.flat, w) and int(tr.fp.step) == 0
+    with pytest.raises(K.N3DError, match="timed out"):
+        tr.step(x, t)
+    tr.recover()
+    for _ in range(2):
+        l = tr.step(x, t)
+    torch.cuda.synchronize()
+    tr.check_sync()
+    assert np.isfinite(float(l)) and int(tr.fp.step) == 2 and not torch.equal(tr.fp.flat, w)
+
+
+def test_search_trainer_withholds_both_updates():
+    from nas_3d_unet_amd import kernels as K, nas
+    from nas_3d_unet_amd.train import SearchTrainer
+    cfg = orc.DEFAULT_CFG._replace(depth=2)
+    rng = np.random.default_rng(67)
+    mk = lambda: (dev(rng.standard_normal((2, 4, 16, 16, 16)).astype(np.float32)),
+                  dev((rng.uniform(0, 1, (2, 3, 16, 16, 16)) < 0.3).astype(np.float32)))
+    (x, t), (vx, vt) = mk(), mk()
+    net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)
+    fill_module(net)
+    net.kernel.last_conv[0].dropout = None
+    tr = SearchTrainer(net.cuda(), graph=True, side_wgrad="force")
+    assert tr.side is not None
+    tr.step(x, t, vx, vt)
+    torch.cuda.synchronize()
+    w, a = tr.fp.flat.clone(), tr.aflat.clone()
+    tr.side.sync[1] += 1
+    la, lw = tr.step(x, t, vx, vt)
+    torch.cuda.synchronize()
+    assert torch.isnan(la) and torch.isnan(lw)
+    assert torch.equal(tr.fp.flat, w) and torch.equal(tr.aflat, a) and int(tr.fp.step) == 1 and int(tr.a_step) == 1
+    with pytest.raises(K.N3DError, match="timed out"):
+        tr.step(x, t, vx, vt)
+    tr.recover()
+    la, lw = tr.step(x, t, vx, vt)
+    torch.cuda.synchronize()
+    tr.check_sync()
+    assert np.isfinite(float(la)) and np.isfinite(float(lw)) and int(tr.fp.step) == 2 and not torch.equal(tr.aflat, a)

@@ -42,7 +42,7 @@ def test_lr_schedule_follows_through_graph_replay():
     for graph in (False, True):
         net, _ = build_net(kind, gname, depth)
         # (the same single-stream schedule on both sides: the side-stream schedule differs from it by an fp32 rounding of the
-        # preprocess epilogue backward, which Adam turns into 1e-3 on some weights within three steps -- tools/dbg/chaos_probe.py)
+        # preprocess epilogue backward, which Adam turns into 1e-3 on some weights within three steps -- tools/chaos_probe.py, profiles/r04_chaos_probe.log)
         tr = Trainer(net, graph=graph, side_wgrad=False)
         tr.step(x, t)
         tr.step(x, t)
@@ -150,6 +150,8 @@ def test_benchmarked_configuration_vs_oracle(schedule):
             ref_g = {n: q.grad.detach().clone() for n, q in P.items()}
         ref_losses.append(float(lo.detach()))
         opt.step()
+        if it == 0:
+            ref_w1 = {n: q.detach().clone() for n, q in P.items()}      # the weights after the FIRST update
     # ---- HIP
     net, head = build_net("searched", "G_CONV", 4, keep_dropout=True)
     net.train()
@@ -169,6 +171,20 @@ def test_benchmarked_configuration_vs_oracle(schedule):
             # (conv biases ahead of a GroupNorm have a mathematically zero gradient: at 2 x 64^3 the reference's own value is
             # ~1e-3 of fp32 cancellation noise, hence the absolute term)
             assert d <= 2e-4 * float(ref_g[n].abs().max()) + 3e-5 * total, (n, d)
+        # the first update, element by element (round-3 review: a norm cannot see a sign error in one layer).  At step 1 Adam moves
+        # an element by lr * g / (|g| + eps), i.e. by lr towards -sign(g) wherever |g| >> eps, so every element whose gradient
+        # stands clear of the gradient tolerance above (|g| > 1e-3 max|g| + 1e-4 |g_total|: its sign is certain) must match the
+        # oracle's torch.optim.Adam to rounding; a wrong sign would be 2 lr = 2e-3 off
+        w1 = {n: q.detach().cpu().clone() for n, q in net.named_parameters()}
+        checked = 0
+        for n, q in w1.items():
+            g = ref_g[n]
+            sel = g.abs() > 1e-3 * float(g.abs().max()) + 1e-4 * total
+            checked += int(sel.sum())
+            if bool(sel.any()):
+                d = float((q - ref_w1[n])[sel].abs().max())
+                assert d <= 2e-5, (n, d, int(sel.sum()))
+        assert checked > 1000, checked
         losses += [float(tr.step(x, t)) for _ in range(2)]
         torch.cuda.synchronize()
         tr.check_sync()

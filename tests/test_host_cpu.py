@@ -90,6 +90,17 @@ def test_genotype_parser(golden, key):
     assert [n for n, _ in gu] == list(g[key + "/up_names"]) and [i for _, i in gu] == list(g[key + "/up_idx"])
 
 
+@pytest.mark.parametrize("key", ["tie/%s/%d" % (d, i) for d in ("down", "up") for i in range(4)])
+def test_genotype_parser_on_near_tied_scores(golden, key):
+    """index work is bit-exact: a stride-2 edge whose rescaled score ties (or is one float32 step off) a stride-1 edge's -- the
+    decoded genotype then hangs on the reference's order of operations, (a * n) / 5 in float32 (genotype.py:35,38); every case was
+    kept because a precomputed-ratio decoder decodes it differently (make_golden.gen_geno_ties)"""
+    from nas_3d_unet_amd.genotype import GenoParser
+    g = golden("geno_ties")
+    got = GenoParser(3).parse(g[key + "/a1"], g[key + "/a2"], "/down/" in key)
+    assert [n for n, _ in got] == list(g[key + "/names"]) and [i for _, i in got] == list(g[key + "/idx"])
+
+
 def test_fresh_shellnet_genotype_is_the_degenerate_one():
     from nas_3d_unet_amd import nas
     gene = nas.ShellNet(4, 4, 3, 2, 3, False, True).get_gene()   # zero alphas (SURVEY appendix D)

@@ -207,6 +207,13 @@ def test_genotype(golden, key):
     assert [n for n, _ in gu] == list(g[key + "/up_names"]) and [i for _, i in gu] == list(g[key + "/up_idx"])
 
 
+@pytest.mark.parametrize("key", ["tie/%s/%d" % (d, i) for d in ("down", "up") for i in range(4)])
+def test_oracle_genotype_on_near_tied_scores(golden, key):
+    g = golden("geno_ties")
+    got = orc.parse_genotype(g[key + "/a1"], g[key + "/a2"], 3, "/down/" in key)
+    assert [n for n, _ in got] == list(g[key + "/names"]) and [i for _, i in got] == list(g[key + "/idx"])
+
+
 def _net2_forward(kind, gname, depth, opt, P, x, key, batch):
     cfg = orc.DEFAULT_CFG._replace(depth=depth)
     gate = T(gc.case_drop_gate(key, batch, cfg.n_nodes * cfg.init_n_kernels, opt["drop"])) if opt.get("drop") else None

@@ -1,7 +1,7 @@
 """How fast does a rounding-sized perturbation of the weights grow over Adam steps?  Two identical single-stream trainers; after the
 first step a few weights of one are nudged by PERT (default 1e-7); the weight difference after each further step is printed."""
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests")); sys.path.insert(0, os.path.join(R, "tests", "golden"))
 import numpy as np, torch
 from test_gpu_nets import build_net
