@@ -387,9 +387,16 @@ int n3d_dice_bwd(const float* p, int64_t psb, int64_t psc, int64_t psv, const fl
  * n3d_head_bwd: one pass writes dx (+)= and the weight / bias gradient slabs.  Either dp (gradient w.r.t. p) is given, or
  *   (t, sums [, dloss]) and the Dice gradient is formed on the fly.  p is recomputed from x, nothing saved is read.
  *   ws: n3d_head_workspace_bytes(); deferred as in n3d_conv_bwd_weight. */
+/* NODE-PLANAR input (round 4): the head's input is the concatenation of a cell's node outputs (cell.py:82, searched.py:51).
+ * Written into one (B, Ci) buffer every node epilogue stores 16 bytes on a 48-byte voxel pitch (0.28 of the HBM roofline at
+ * 128^3); with node_c > 0 the nodes stay DENSE tensors of their own -- channel c of voxel (b, v) is element
+ * x[(c / node_c) * x_node_stride + (b * N + v) * xld + c % node_c], xld >= node_c -- and the head (its only consumer) gathers
+ * the Ci / node_c pointers itself; dx of n3d_head_bwd is laid out the same way with dx_node_stride.  node_c == 0: the ordinary
+ * pitched layout (the two strides are ignored). */
 typedef struct n3d_head {
   const void* x; int64_t xld; int32_t x_dtype; int32_t B; int32_t Ci; int32_t Co; int64_t N;
   const float* w; const float* bias; const float* gate;
+  int64_t x_node_stride; int64_t dx_node_stride; int32_t node_c; int32_t pad_;
 } n3d_head;
 float n3d_dropout3d_uniform(uint64_t seed, uint32_t counter, uint32_t index);
 int n3d_dropout3d_gate(uint32_t* state, float p, int B, int C, float* gate, void* stream);

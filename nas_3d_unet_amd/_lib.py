@@ -91,7 +91,8 @@ class ConvBwdCall(C.Structure):
 class Head(C.Structure):
     """n3d_head (include/n3d.h)"""
     _fields_ = [("x", C.c_void_p), ("xld", C.c_int64), ("x_dtype", C.c_int32), ("B", C.c_int32), ("Ci", C.c_int32), ("Co", C.c_int32),
-                ("N", C.c_int64), ("w", C.c_void_p), ("bias", C.c_void_p), ("gate", C.c_void_p)]
+                ("N", C.c_int64), ("w", C.c_void_p), ("bias", C.c_void_p), ("gate", C.c_void_p),
+                ("x_node_stride", C.c_int64), ("dx_node_stride", C.c_int64), ("node_c", C.c_int32), ("pad_", C.c_int32)]
 
 
 class PatchDesc(C.Structure):

@@ -34,8 +34,14 @@ __global__ void dropout3d_gate_kernel(uint32_t* __restrict__ state, float p, int
   if (threadIdx.x == 0) state[2] = st[2] + 1;
 }
 
+// element offset of channel quad q of a voxel record: q * 4 in the ordinary pitched layout; node-planar (include/n3d.h, n3d_head):
+// node q / QN starts node_stride elements further, the quad sits at (q % QN) * 4 inside the node's record
+__device__ __forceinline__ int64_t head_quad_off(int q, int qn, int64_t node_stride) {
+  return qn ? (int64_t)(q / qn) * node_stride + (q % qn) * 4 : (int64_t)q * 4;
+}
+
 struct HeadFwdArgs {
-  const void* x; int64_t xld; int64_t N;
+  const void* x; int64_t xld; int64_t N; int64_t xns; int qn;   // xns / qn: node stride and quads per node (qn == 0: pitched layout)
   const float* w; const float* bias; const float* gate;
   float* p; int64_t psb, psc, psv; float* logits;
   const float* t; int64_t tsb, tsc, tsv;
@@ -59,6 +65,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
 #pragma unroll
   for (int co = 0; co < HEAD_COMAX; ++co) bias[co] = co < a.Co ? a.bias[co] : 0.f;
   const TX* xb = reinterpret_cast<const TX*>(a.x) + (int64_t)b * a.N * a.xld;
+  int64_t qoff[CIQ];
+#pragma unroll
+  for (int q = 0; q < CIQ; ++q) qoff[q] = head_quad_off(q, a.qn, a.xns);
   float spt[HEAD_COMAX], sp[HEAD_COMAX], st[HEAD_COMAX];
 #pragma unroll
   for (int co = 0; co < HEAD_COMAX; ++co) spt[co] = sp[co] = st[co] = 0.f;
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
     const int64_t v = v0 + tid + k * 256;
     const int64_t vc = v < a.N ? v : v0;
 #pragma unroll
-    for (int q = 0; q < CIQ; ++q) xqs[k][q] = ld4(xb + vc * a.xld + q * 4);
+    for (int q = 0; q < CIQ; ++q) xqs[k][q] = ld4(xb + vc * a.xld + qoff[q]);
 #pragma unroll
     for (int co = 0; co < HEAD_COMAX; ++co) tvs[k][co] = (a.t && co < a.Co) ? a.t[b * a.tsb + co * a.tsc + vc * a.tsv] : 0.f;
   }
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(256) void head_dice_finalize_kernel(const double* _
 }
 
 struct HeadBwdArgs {
-  const void* x; int64_t xld; int64_t N;
+  const void* x; int64_t xld; int64_t N; int64_t xns, dxns; int qn;
   const float* w; const float* bias; const float* gate;
   const float* dp; int64_t dsb, dsc, dsv;
   const float* t; int64_t tsb, tsc, tsv;
@@ -190,6 +199,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   }
   const TX* xb = reinterpret_cast<const TX*>(a.x) + (int64_t)b * a.N * a.xld;
   TD* dxb = reinterpret_cast<TD*>(a.dx) + (int64_t)b * a.N * a.dxld;
+  int64_t qoff[CIQ], dqoff[CIQ];
+#pragma unroll
+  for (int q = 0; q < CIQ; ++q) { qoff[q] = head_quad_off(q, a.qn, a.xns); dqoff[q] = head_quad_off(q, a.qn, a.dxns); }
   float acc[HEAD_COMAX][CI], accb[HEAD_COMAX];
 #pragma unroll
   for (int co = 0; co < HEAD_COMAX; ++co) {
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     const int64_t v = v0 + tid + k * 256;
     const int64_t vc = v < a.N ? v : v0;
 #pragma unroll
-    for (int q = 0; q < CIQ; ++q) xqs[k][q] = ld4(xb + vc * a.xld + q * 4);
+    for (int q = 0; q < CIQ; ++q) xqs[k][q] = ld4(xb + vc * a.xld + qoff[q]);
 #pragma unroll
     for (int co = 0; co < HEAD_COMAX; ++co) {
       gin[k][co] = 0.f;
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     float4 prevq[CIQ];
     if (a.accumulate) {
 #pragma unroll
-      for (int q = 0; q < CIQ; ++q) prevq[q] = ld4(dxb + v * a.dxld + q * 4);
+      for (int q = 0; q < CIQ; ++q) prevq[q] = ld4(dxb + v * a.dxld + dqoff[q]);
     }
     float dl[HEAD_COMAX];
 #pragma unroll
@@ -257,7 +269,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
       }
       float4 ov = make_float4(o[0], o[1], o[2], o[3]);
       if (a.accumulate) { ov.x += prevq[q].x; ov.y += prevq[q].y; ov.z += prevq[q].z; ov.w += prevq[q].w; }
-      st4(dxb + v * a.dxld + q * 4, ov);
+      st4(dxb + v * a.dxld + dqoff[q], ov);
     }
   }
   if (!a.partial) return;
@@ -330,6 +342,12 @@ static int check_head(const n3d_head* h, const char* what) {
     N3D_UNSUPPORTED("%s: Ci in {4,8,12,16,24,32} and Co <= %d are built (Ci=%d Co=%d)", what, HEAD_COMAX, h->Ci, h->Co);
   N3D_CHECK_ARG(h->x_dtype == N3D_F32 || h->x_dtype == N3D_BF16, "%s: unknown dtype %d", what, h->x_dtype);
   const int esz = h->x_dtype == N3D_BF16 ? 2 : 4;
+  if (h->node_c) {
+    N3D_CHECK_ARG(h->node_c > 0 && h->node_c % 4 == 0 && h->Ci % h->node_c == 0 && h->xld >= h->node_c && h->xld % 4 == 0 &&
+                  h->x_node_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(h->x) % (4 * esz)) == 0,
+                  "%s: node-planar x needs node_c %% 4 == 0, Ci %% node_c == 0, ld >= node_c, quad-aligned node stride", what);
+    return 0;
+  }
   N3D_CHECK_ARG(h->xld >= h->Ci && h->xld % 4 == 0 && (reinterpret_cast<uintptr_t>(h->x) % (4 * esz)) == 0, "%s: x needs ld %% 4 == 0 and quad alignment", what);
   return 0;
 }
@@ -363,6 +381,7 @@ int n3d_head_fwd(const n3d_head* h, float* p, int64_t psb, int64_t psc, int64_t 
   N3D_CHECK_ARG(!t || (partial && sums && loss), "head_fwd: the Dice mode needs partial / sums / loss");
   HeadFwdArgs a;
   a.x = h->x; a.xld = h->xld; a.N = h->N; a.w = h->w; a.bias = h->bias; a.gate = h->gate;
+  a.qn = h->node_c / 4; a.xns = h->x_node_stride;
   a.p = p; a.psb = psb; a.psc = psc; a.psv = psv; a.logits = logits;
   a.t = t; a.tsb = tsb; a.tsc = tsc; a.tsv = tsv; a.partial = t ? partial : nullptr; a.rows = (int)cdiv(h->N, HEAD_CHUNK);
   a.Ci = h->Ci; a.Co = h->Co;
@@ -379,7 +398,7 @@ int n3d_head_bwd(const n3d_head* h, const float* dp, int64_t dsb, int64_t dsc, i
                  float* dw, float* dbias, void* ws, size_t ws_bytes, n3d_final_job* deferred, void* stream) {
   if (deferred) deferred->nchunks = 0;
   if (int e = check_head(h, "head_bwd")) return e;
-  N3D_CHECK_ARG(dx && dxld >= h->Ci && dxld % 4 == 0, "head_bwd: bad dx");
+  N3D_CHECK_ARG(dx && dxld >= (h->node_c ? h->node_c : h->Ci) && dxld % 4 == 0 && (!h->node_c || h->dx_node_stride % 4 == 0), "head_bwd: bad dx");
   N3D_CHECK_ARG((dp != nullptr) != (t != nullptr && sums != nullptr), "head_bwd: give either dp or (t, sums)");
   N3D_CHECK_ARG(dx_dtype == N3D_F32 || dx_dtype == N3D_BF16, "head_bwd: unknown dx dtype");
   const bool want_w = dw || dbias;
@@ -388,6 +407,7 @@ int n3d_head_bwd(const n3d_head* h, const float* dp, int64_t dsb, int64_t dsc, i
   if (want_w && (!ws || ws_bytes < need)) { set_error("head_bwd: workspace too small (%zu < %zu)", ws_bytes, need); return N3D_ERR_WORKSPACE; }
   HeadBwdArgs a;
   a.x = h->x; a.xld = h->xld; a.N = h->N; a.w = h->w; a.bias = h->bias; a.gate = h->gate;
+  a.qn = h->node_c / 4; a.xns = h->x_node_stride; a.dxns = h->dx_node_stride;
   a.dp = dp; a.dsb = dsb; a.dsc = dsc; a.dsv = dsv; a.t = t; a.tsb = tsb; a.tsc = tsc; a.tsv = tsv;
   a.sums = dp ? nullptr : sums; a.dloss = dloss; a.smooth = (double)smooth; a.BC = h->B * h->Co;
   a.dx = dx; a.dxld = dxld; a.accumulate = (flags & N3D_ACCUMULATE) ? 1 : 0;

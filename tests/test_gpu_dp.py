@@ -60,8 +60,8 @@ def test_trainer_dp_schedules_match_single_gpu(one_rank_group, graph, buckets, c
     net, _ = build_net("searched", "G_CONV", 4)
     tr = Trainer(net, graph=graph, n_buckets=buckets, comm=comm, side_wgrad=sched)
     assert tr.dp_path and len(tr.sync.ranges) == buckets and (comm != "rccl" or tr.sync._comm is not None)
-    assert ref._use_side == tr._use_side or buckets > 1
     l, w = _losses_and_weights(tr, x, t)
+    assert ref._use_side == tr._use_side or buckets > 1
     if graph and buckets > 1:
         assert tr._segments is not None and len(tr._segments) == buckets
     assert l == lr_ and torch.equal(w, wr)
