@@ -173,11 +173,21 @@ def _node_fwd_units(plan):
     return units
 
 
-def _run_forward(plan, x0, x1, alpha1, alpha2, pre0_early=None):
+def _run_forward(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=False):
     """Returns (cell output tensor, saved state).  pre0_early = (View, saved state, flag id): the cell's first preprocess op has
-    already been launched on the side stream (NetFn.forward, SIDE_FWD); the cell joins it instead of running it."""
+    already been launched on the side stream (NetFn.forward, SIDE_FWD); the cell joins it instead of running it.
+    planar (searched cells): the node outputs stay dense tensors (kernels.Planar, a 6-D output) instead of channel slices of one
+    concatenation buffer -- for the net's LAST cell, whose only reader is the fused head."""
     with K.stats_cache(), K.storage(plan.dt):
-        return _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early)
+        return _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early, planar and plan.pairs)
+
+
+# The last cell's output feeds the head only (nas.py:77-78, searched.py:110-111).  As channel slices of one (B, 3 c) buffer every
+# node epilogue writes 16 bytes on a 48-byte pitch and every epilogue backward reads its gradient the same way: 0.28-0.47 of the HBM
+# roofline at 4x128^3 (round-3 review).  With PLANAR_LAST the callers that own both sides (unet.body -> head.run / run_loss, the
+# trainers' pipeline) set PLANAR_OUT around NetFn.forward and the last cell keeps its nodes dense; the head gathers three pointers.
+PLANAR_LAST = os.environ.get("N3D_PLANAR_LAST", "1") != "0"
+PLANAR_OUT = False
 
 
 # Side-stream forward of a supernet cell (train.SideSchedule sets SIDE_FWD; round 3).  A node sums the MixedOps of ALL earlier states
@@ -295,7 +305,7 @@ def _early_pair_ops(plan):
     return got
 
 
-def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None):
+def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=False):
     if SIDE_FWD is not None and not plan.pairs and _grouping(plan.c_node):
         return _run_forward_side(plan, x0, x1, alpha1, alpha2, SIDE_FWD)
     st = P.Saved()
@@ -339,8 +349,12 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None):
             seg0, seg1 = segs0[0][0], segs1[0][0]
             if out is None:
                 shp = seg0.weight.out_shape(xs[i0])
-                out = K.as_view(K.empty_ndhwc(shp[0], nn * cn, shp[2], shp[3], shp[4], xs[i0].t.device))
-                nodes = [_slice_view(out, k, cn) for k in range(nn)]
+                if planar:
+                    out = K.empty_planar(nn, shp[0], cn, shp[2], shp[3], shp[4], xs[i0].t.device)
+                    nodes = out.nodes
+                else:
+                    out = K.as_view(K.empty_ndhwc(shp[0], nn * cn, shp[2], shp[3], shp[4], xs[i0].t.device))
+                    nodes = [_slice_view(out, k, cn) for k in range(nn)]
                 xs.extend(nodes)
             if node in side_res:
                 e, res_side, tok = side_res[node]
@@ -414,9 +428,17 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
 
 def _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, own_dout, late_joins=()):
     cn, nn = plan.c_node, plan.n_nodes
-    dv = K.as_view(dout, "grad_output")
     out = st.out
     dev = out.t.device
+    if isinstance(out, K.Planar):
+        # node-planar output (the net's last cell): the gradient arrives as dense per-node tensors too
+        dv = K.as_planar(dout, "grad_output")
+        if not ((REUSE_GRAD_OUTPUT or own_dout) and dv.t is dout):
+            dcat = K.empty_planar(out.nn, out.B, out.cn, out.D, out.H, out.W, dev, out.t.dtype)
+            dcat.t.copy_(dv.t)
+            dv = dcat
+        return _run_backward_nodes(plan, st, dv.nodes, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, late_joins)
+    dv = K.as_view(dout, "grad_output")
     # node slices of the incoming gradient receive further contributions.  A trainer that owns the whole backward
     # (train.Trainer / SearchTrainer set REUSE_GRAD_OUTPUT) lets the cell accumulate straight into autograd's buffer: it is
     # either this cell's consumer's freshly returned dx or autograd's own accumulation buffer, and nobody reads it again.
@@ -427,6 +449,13 @@ def _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_da
         dcat = K.like(out)
         _copy_into(dv, dcat)
     dnodes = [_slice_view(dcat, k, cn) for k in range(nn)]
+    return _run_backward_nodes(plan, st, dnodes, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, late_joins)
+
+
+def _run_backward_nodes(plan, st, dnodes, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, late_joins=()):
+    """the backward walk of a cell given the gradient Views of its nodes (channel slices of one buffer, or dense tensors)"""
+    cn, nn = plan.c_node, plan.n_nodes
+    dev = st.out.t.device
     p0, p1 = st.xs[0], st.xs[1]
     dpre = [K.like(p0), K.like(p1)]
     pre_started = [False, False]
@@ -854,7 +883,8 @@ class NetFn(torch.autograd.Function):
         spawn_pre0(1)
         for k, (i0, i1, _) in enumerate(nplan.wiring):
             a1, a2 = (al[0], al[2]) if k < nplan.n_down else (al[1], al[3])
-            out, st = _run_forward(nplan.cells[k], acts[i0], acts[i1], a1, a2, early.pop(k, None))
+            out, st = _run_forward(nplan.cells[k], acts[i0], acts[i1], a1, a2, early.pop(k, None),
+                                   planar=PLANAR_OUT and k == len(nplan.wiring) - 1)
             acts.append(out)
             states.append(st)
             if k < nplan.n_down:

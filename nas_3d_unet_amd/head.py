@@ -18,22 +18,39 @@ KEEP_LOGITS = False   # tests: keep the pre-sigmoid activations of the last run(
 last_logits = None
 
 
+def feat_shape(x):
+    """(B, C) of a feature map: a 5-D (B, C, D, H, W) tensor, or a node-planar 6-D (nn, B, cn, D, H, W) one (kernels.Planar)"""
+    return (x.shape[1], x.shape[0] * x.shape[2]) if x.dim() == 6 else (x.shape[0], x.shape[1])
+
+
 def fusable(head, x):
     op = head[0]
     return (len(head) == 2 and isinstance(head[1], torch.nn.Sigmoid) and getattr(op, "ops_list", None) == ["weight"]
             and not getattr(op, "depthwised", True) and op._k == 1 and op._stride == 1 and not op._transposed
-            and x.shape[1] in (4, 8, 12, 16, 24, 32) and op.conv.weight.shape[0] <= 4)
+            and feat_shape(x)[1] in (4, 8, 12, 16, 24, 32) and op.conv.weight.shape[0] <= 4)
 
 
 def _gate(op, x):
-    return P.draw_gate(op.dropout, op.training, x.shape[0], x.shape[1], x.device)
+    B, Cc = feat_shape(x)
+    return P.draw_gate(op.dropout, op.training, B, Cc, x.device)
+
+
+def _feat_view(x):
+    return K.as_planar(x, "head input") if x.dim() == 6 else K.as_view(x, "head input", bf16_ok=True)
+
+
+def _feat_like(xv):
+    """gradient buffer of the head input's layout"""
+    if isinstance(xv, K.Planar):
+        return K.empty_planar(xv.nn, xv.B, xv.cn, xv.D, xv.H, xv.W, xv.t.device, xv.t.dtype)
+    return K.as_view(K.empty_ndhwc(xv.B, xv.C, xv.D, xv.H, xv.W, xv.t.device, xv.t.dtype), bf16_ok=True)
 
 
 class HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gate, x, w, b):
         global last_logits
-        xv = K.as_view(x, "head input", bf16_ok=True)
+        xv = _feat_view(x)
         p, logits, _, _ = K.head_fwd(xv, w, b, gate, want_logits=KEEP_LOGITS)
         if KEEP_LOGITS:
             last_logits = logits
@@ -45,7 +62,7 @@ class HeadFn(torch.autograd.Function):
         xv, w, b = ctx.xv, ctx.w, ctx.b
         if K._bcv_strides(dp) is None:
             dp = dp.contiguous()
-        dx = K.as_view(K.empty_ndhwc(xv.B, xv.C, xv.D, xv.H, xv.W, xv.t.device, xv.t.dtype), bf16_ok=True)
+        dx = _feat_like(xv)
         dw, db = K.grad_target(w), K.grad_target(b)
         K.head_bwd(xv, w, b, ctx.gate, dx, dw, db, dp=dp)
         inplace = getattr(w, "_n3d_grad", None) is not None
@@ -57,7 +74,7 @@ class HeadDiceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gate, smooth, x, t, w, b):
         global last_logits
-        xv = K.as_view(x, "head input", bf16_ok=True)
+        xv = _feat_view(x)
         if K._bcv_strides(t) is None:
             t = t.contiguous()
         p, logits, sums, loss = K.head_fwd(xv, w, b, gate, t, smooth, want_logits=KEEP_LOGITS)
@@ -70,7 +87,7 @@ class HeadDiceFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss, _dp):
         xv, w, b = ctx.xv, ctx.w, ctx.b
-        dx = K.as_view(K.empty_ndhwc(xv.B, xv.C, xv.D, xv.H, xv.W, xv.t.device, xv.t.dtype), bf16_ok=True)
+        dx = _feat_like(xv)
         dw, db = K.grad_target(w), K.grad_target(b)
         K.head_bwd(xv, w, b, ctx.gate, dx, dw, db, t=ctx.t, sums=ctx.sums, dloss=dloss.contiguous(), smooth=ctx.smooth)
         inplace = getattr(w, "_n3d_grad", None) is not None

@@ -156,6 +156,42 @@ class View:
         self.N = self.D * self.H * self.W
 
 
+class Planar:
+    """Node-planar feature map (include/n3d.h, n3d_head): the concatenation of a cell's `nn` node outputs kept as `nn` DENSE
+    (B, cn, D, H, W) NDHWC tensors in one allocation -- storage (nn, B, D, H, W, cn), presented to torch as the 6-D tensor
+    `t` of shape (nn, B, cn, D, H, W).  Only the fused head reads it (three pointers instead of one 48-byte voxel record);
+    `nodes[k]` is the ordinary dense View of node k."""
+    __slots__ = ("t", "nodes", "nn", "cn", "B", "C", "D", "H", "W", "N", "dt", "node_stride")
+
+    def __init__(self, t):
+        self.t = t
+        self.nn, self.B, self.cn, self.D, self.H, self.W = (int(v) for v in t.shape)
+        self.C, self.N = self.nn * self.cn, self.D * self.H * self.W
+        self.dt = _lib.BF16 if t.dtype == torch.bfloat16 else _lib.F32
+        self.node_stride = self.B * self.N * self.cn
+        self.nodes = [View(t[k], self.cn) for k in range(self.nn)]
+
+
+def empty_planar(nn, B, cn, D, H, W, device, dtype=None):
+    dtype = dtype if dtype is not None else _act_dtype
+    n = nn * B * D * H * W * cn
+    slack = 8 if dtype == torch.bfloat16 else 0      # bf16: the 16-byte-per-voxel LDS-DMA reads run 8 bytes past a 4-channel voxel
+    return Planar(torch.empty(n + slack, device=device, dtype=dtype)[:n].view(nn, B, D, H, W, cn).permute(0, 1, 5, 2, 3, 4))
+
+
+def as_planar(t, what="tensor"):
+    """a 6-D (nn, B, cn, D, H, W) tensor with dense (nn, B, D, H, W, cn) storage -> Planar (repacked with a copy otherwise)"""
+    if not isinstance(t, torch.Tensor) or t.dim() != 6 or not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16):
+        raise N3DError("%s: expected a node-planar (nn, B, cn, D, H, W) device tensor" % what)
+    nn, B, cn, D, H, W = t.shape
+    want = (B * D * H * W * cn, D * H * W * cn, 1, H * W * cn, W * cn, cn)
+    if tuple(t.stride()) != want or t.data_ptr() % (4 * t.element_size()) != 0:
+        n = empty_planar(nn, B, cn, D, H, W, t.device, t.dtype)
+        n.t.copy_(t)
+        return n
+    return Planar(t)
+
+
 def _pitch_of(t):
     """Return the voxel pitch if `t` is a pitched NDHWC view, else None."""
     B, Cc, D, H, W = t.shape
@@ -1270,11 +1306,17 @@ def dropout3d_gate(state, p, B, Cc):
     return gate
 
 
-def _head_desc(x: View, w, bias, gate):
-    return _lib.Head(x.p.value, x.ld, x.dt, x.B, x.C, int(w.shape[0]), x.N, w.data_ptr(), bias.data_ptr(), _vp(gate))
+def _head_desc(x, w, bias, gate, dx=None):
+    """x (and dx): View, or Planar -- the node-planar layout of include/n3d.h"""
+    if isinstance(x, Planar):
+        if dx is not None and not (isinstance(dx, Planar) and dx.cn == x.cn and dx.nn == x.nn):
+            raise N3DError("head: a node-planar input needs a node-planar gradient of the same node layout")
+        return _lib.Head(x.nodes[0].p.value, x.cn, x.dt, x.B, x.C, int(w.shape[0]), x.N, w.data_ptr(), bias.data_ptr(), _vp(gate),
+                         x.node_stride, dx.node_stride if dx is not None else 0, x.cn, 0)
+    return _lib.Head(x.p.value, x.ld, x.dt, x.B, x.C, int(w.shape[0]), x.N, w.data_ptr(), bias.data_ptr(), _vp(gate), 0, 0, 0, 0)
 
 
-def head_fwd(x: View, w, bias, gate, t=None, smooth=1e-6, want_logits=False):
+def head_fwd(x, w, bias, gate, t=None, smooth=1e-6, want_logits=False):
     """p = sigmoid(conv1x1x1(x * gate) + bias) as a contiguous (B, Co, D, H, W) tensor; with a target t also the Dice sums
     and loss from the same pass.  Returns (p, logits | None, sums | None, loss | None)."""
     lib = _lib.load()
@@ -1296,11 +1338,11 @@ def head_fwd(x: View, w, bias, gate, t=None, smooth=1e-6, want_logits=False):
     return p, logits, sums, loss
 
 
-def head_bwd(x: View, w, bias, gate, dx: View, dw, dbias, dp=None, t=None, sums=None, dloss=None, smooth=1e-6, accumulate=False):
+def head_bwd(x, w, bias, gate, dx, dw, dbias, dp=None, t=None, sums=None, dloss=None, smooth=1e-6, accumulate=False):
     """backward of head_fwd in one pass: dx (+)=, dw, dbias.  Either dp (gradient w.r.t. p, any uniform strides) or
-    (t, sums[, dloss]) for the fused Dice gradient."""
+    (t, sums[, dloss]) for the fused Dice gradient.  x / dx: Views, or both Planar."""
     lib = _lib.load()
-    h = _head_desc(x, w, bias, gate)
+    h = _head_desc(x, w, bias, gate, dx if isinstance(x, Planar) else None)
     ws = None
     n = 0
     job = None
@@ -1311,7 +1353,8 @@ def head_bwd(x: View, w, bias, gate, dx: View, dw, dbias, dp=None, t=None, sums=
     ds = _bcv_strides(dp) if dp is not None else (0, 0, 0)
     ts = _bcv_strides(t) if t is not None else (0, 0, 0)
     check(lib.n3d_head_bwd(C.byref(h), ptr(dp), ds[0], ds[1], ds[2], ptr(t), ts[0], ts[1], ts[2], float(smooth), ptr(sums), ptr(dloss),
-                           dx.p, dx.ld, dx.dt, ACCUMULATE if accumulate else 0, ptr(dw), ptr(dbias), ptr(ws), n,
+                           dx.nodes[0].p if isinstance(dx, Planar) else dx.p, dx.cn if isinstance(dx, Planar) else dx.ld, dx.dt,
+                           ACCUMULATE if accumulate else 0, ptr(dw), ptr(dbias), ptr(ws), n,
                            C.byref(job) if job is not None else None, stream_ptr()), "n3d_head_bwd")
     if job is not None and job.nchunks > 0:
         _ctx.final.append(job)

@@ -960,8 +960,12 @@ class Trainer:
         with torch.no_grad(), K.step_context(self.ctx):
             self.ctx.pack_all()
             nctx = _Ctx((False, False) + (False,) * 4 + (True,) * len(plan.params))
-            body = _fused.NetFn.forward(nctx, plan, x, None, None, None, None, *plan.params)
-            gate = _P.draw_gate(op.dropout, op.training, body.shape[0], body.shape[1], body.device)
+            prev_pl, _fused.PLANAR_OUT = _fused.PLANAR_OUT, _fused.PLANAR_LAST     # (_direct_ok: the head is the fused one)
+            try:
+                body = _fused.NetFn.forward(nctx, plan, x, None, None, None, None, *plan.params)
+            finally:
+                _fused.PLANAR_OUT = prev_pl
+            gate = _P.draw_gate(op.dropout, op.training, *_head.feat_shape(body), body.device)
             hctx = _Ctx((False, False, True, False, True, True))
             loss, _ = _head.HeadDiceFn.forward(hctx, gate, float(self.loss_fn.smooth), body, t, op.conv.weight, op.conv.bias)
             dbody = _head.HeadDiceFn.backward(hctx, self._one, None)[2]

@@ -55,9 +55,11 @@ def set_storage(net, storage):
     net._net_plan = None
 
 
-def body(net, x, alphas=None):
+def body(net, x, alphas=None, planar=False):
     """Everything ahead of the head.  alphas: None (searched net) or (alpha1_down, alpha1_up, alpha2_down, alpha2_up), already
-    softmaxed.  Stems and cells run as one autograd node (fused.NetFn) unless fused.WHOLE_NET is off."""
+    softmaxed.  Stems and cells run as one autograd node (fused.NetFn) unless fused.WHOLE_NET is off.
+    planar: the caller hands the result to the fused head and nothing else -- the last cell may then keep its node outputs as
+    dense tensors (a 6-D node-planar result, fused.PLANAR_LAST) instead of one concatenation buffer."""
     if not fused.WHOLE_NET:
         if alphas is None:
             plain = lambda cell, skip, cur: cell(skip, cur)
@@ -67,17 +69,32 @@ def body(net, x, alphas=None):
     plan = getattr(net, "_net_plan", None)
     if not fused.current(plan):      # first call, or an op's norm / dropout / conv was re-assigned since
         plan = net._net_plan = fused.net_plan(net, supernet=alphas is not None)
-    return fused.NetFn.apply(plan, x, *(alphas if alphas is not None else (None,) * 4), *plan.params)
+    prev, fused.PLANAR_OUT = fused.PLANAR_OUT, bool(planar and fused.PLANAR_LAST and alphas is None)
+    try:
+        return fused.NetFn.apply(plan, x, *(alphas if alphas is not None else (None,) * 4), *plan.params)
+    finally:
+        fused.PLANAR_OUT = prev
 
 
 def run(net, x, alphas=None):
     """Forward of either net: probabilities (B, n_out, D, H, W).  The head (Dropout3d -> 1x1x1 conv -> sigmoid) is one launch."""
-    return _head.run(net.last_conv, body(net, x, alphas))
+    return _head.run(net.last_conv, body(net, x, alphas, planar=_head_takes_planar(net)))
 
 
 def run_loss(net, x, t, alphas=None, smooth=1e-6):
     """(Dice loss, probabilities): forward with the loss of loss.py:12-14 formed inside the head's passes (the trainers' path)"""
-    return _head.run_loss(net.last_conv, body(net, x, alphas), t, smooth)
+    import torch
+    return _head.run_loss(net.last_conv, body(net, x, alphas, planar=_head_takes_planar(net) and t.dtype == torch.float32), t, smooth)
+
+
+def _head_takes_planar(net):
+    """is the head the fused kernel pair (which reads a node-planar input), not the op-by-op fallback?"""
+    import torch
+    ok = getattr(net, "_n3d_head_planar", None)
+    if ok is None:
+        ci = net.last_conv[0].conv.weight.shape[1] if hasattr(net.last_conv[0], "conv") else 0
+        ok = net._n3d_head_planar = bool(ci) and _head.fusable(net.last_conv, torch.empty((1, ci, 1, 1, 1), device="meta"))
+    return ok
 
 
 def route(net, x, call_down, call_up, head=True):

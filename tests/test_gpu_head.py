@@ -142,3 +142,75 @@ def test_train_mode_head_draws_fresh_masks_under_graph_replay():
     losses = [float(tr.step(x, t)) for _ in range(6)]
     assert all(np.isfinite(losses))
     assert len({round(l, 7) for l in losses}) >= 3, losses
+
+
+# ---- node-planar head input (include/n3d.h, n3d_head.node_c; fused.PLANAR_LAST) ----------------------------------------------
+@pytest.mark.parametrize("cn,nn,co,shape,batch", [(4, 3, 3, (8, 12, 16), 2), (8, 3, 2, (6, 6, 6), 1), (4, 1, 1, (4, 6, 10), 3), (8, 4, 4, (4, 8, 8), 2)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_head_on_node_planar_input_equals_the_concatenated_one(cn, nn, co, shape, batch, dtype):
+    """the same head launches on `nn` dense node tensors (three pointers) and on their concatenation (one pitched record per
+    voxel): probabilities, loss, dx, dw, db must be bit-identical -- only addresses differ (cell.py:82, searched.py:51)"""
+    from nas_3d_unet_amd import kernels as K
+    rng = np.random.default_rng(cn * 10 + nn)
+    ci = cn * nn
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    xn = rng.standard_normal((batch, ci) + shape).astype(np.float32)
+    w = dev((rng.standard_normal((co, ci, 1, 1, 1)) * 0.4).astype(np.float32))
+    b = dev(rng.standard_normal(co).astype(np.float32) * 0.2)
+    t = dev((rng.uniform(0, 1, (batch, co) + shape) < 0.3).astype(np.float32))
+    gate = dev(((rng.uniform(0, 1, (batch, ci)) >= 0.5) / 0.5).astype(np.float32))
+    cat = K.empty_ndhwc(batch, ci, *shape, torch.device("cuda"), td)
+    cat.copy_(dev(xn))
+    xv = K.as_view(cat)
+    pl = K.empty_planar(nn, batch, cn, *shape, torch.device("cuda"), td)
+    for k in range(nn):
+        pl.nodes[k].t.copy_(cat[:, k * cn:(k + 1) * cn])
+    assert K.as_planar(pl.t).t.data_ptr() == pl.t.data_ptr()
+    out = []
+    for x in (xv, pl):
+        p, logits, sums, loss = K.head_fwd(x, w, b, gate, t, want_logits=True)
+        dx = K.as_view(K.empty_ndhwc(batch, ci, *shape, torch.device("cuda"), td)) if x is xv else K.empty_planar(nn, batch, cn, *shape, torch.device("cuda"), td)
+        dw, db = torch.empty_like(w), torch.empty_like(b)
+        K.head_bwd(x, w, b, gate, dx, dw, db, t=t, sums=sums)
+        torch.cuda.synchronize()
+        dxc = dx.t if x is xv else torch.cat([n.t for n in dx.nodes], dim=1)
+        out.append((p, logits, float(loss), dxc.float(), dw, db))
+    for a_, b_ in zip(out[0], out[1]):
+        assert (a_ == b_) if isinstance(a_, float) else torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+@pytest.mark.parametrize("path", ["autograd", "pipeline"])
+def test_last_cell_node_planar_equals_concatenated(storage, path):
+    """SearchedNet with the last cell's nodes kept dense (fused.PLANAR_LAST) against the concatenation buffer: same kernels on
+    the same values -- loss and every parameter gradient bit-identical, through autograd (forward_loss) and through the trainers'
+    autograd-free pipeline"""
+    from nas_3d_unet_amd import fused, unet
+    from nas_3d_unet_amd.train import Trainer
+    from test_gpu_nets import build_net
+    rng = np.random.default_rng(71)
+    x = dev(rng.standard_normal((2, 4, 32, 32, 32)).astype(np.float32))
+    t = dev((rng.uniform(0, 1, (2, 3, 32, 32, 32)) < 0.3).astype(np.float32))
+    res = []
+    for planar in (False, True):
+        prev, fused.PLANAR_LAST = fused.PLANAR_LAST, planar
+        try:
+            net, _ = build_net("searched", "G_CONV", 4)
+            unet.set_storage(net, storage)
+            if path == "autograd":
+                l, p = net.forward_loss(x, t)
+                l.backward()
+                grads = {n: q.grad.clone() for n, q in net.named_parameters()}
+            else:
+                tr = Trainer(net, graph=False, side_wgrad=False)
+                assert tr._direct_ok()
+                l = tr._pipeline(x, t, cell_hook=lambda k: None)
+                tr.ctx.flush_final()
+                grads = {"flat": tr.fp.grad.clone()}
+            torch.cuda.synchronize()
+            res.append((float(l), grads))
+        finally:
+            fused.PLANAR_LAST = prev
+    assert res[0][0] == res[1][0]
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
