@@ -368,6 +368,10 @@ struct K1Args {
   // up: the data gradient of a stride-2 1x1x1 conv -- destination voxel (d,h,w) takes source voxel (d/2,h/2,w/2) when all three
   // are even and nothing otherwise; Ns = source voxels per sample
   int up, Wd, Hd; int64_t Ns; FastDiv fWd, fHd;
+  // sparse (up + accumulate): only the destination voxels with three even coordinates receive anything, the rest keep their value --
+  // the launch walks the Ns SOURCE voxels and read-modify-writes their destinations instead of rewriting the whole tensor
+  // (12 -> 8 at 2 x 128^3 -> 64^3: 400 MB of traffic for 50 MB of work)
+  int sparse; FastDiv fWs, fHs;
   // flat: the destination is dense (dld == Cd) with >= 2 quads per voxel and 16-byte aligned 64-voxel runs: a wave transposes its
   // 64 voxel records through LDS and writes them as consecutive 16-byte pieces (per-voxel stores of a 12-channel tensor put 16 bytes
   // on every 48-byte pitch: three partial-line instructions per line)
@@ -382,7 +386,8 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
   constexpr int VPT = EXTRA ? 2 : K1_VPB / 256;   // data-gradient form: no statistics rows to agree on, fewer registers per voxel
   __shared__ __attribute__((aligned(16))) float4 wl[CSQ * 4 * CDQ];
   __shared__ double red[4][CDQ * 8];
-  __shared__ __attribute__((aligned(16))) TD stage[CDQ >= 2 ? 4 * 64 * CDQ * 4 : 4];   // [wave][voxel][Cd]
+  constexpr bool FLAT_OK = CDQ >= 2 && CDQ <= 3;
+  __shared__ __attribute__((aligned(16))) TD stage[FLAT_OK ? 4 * 64 * CDQ * 4 : 4];   // [wave][voxel][Cd]
   const int t = threadIdx.x, b = blockIdx.y;
   for (int i = t; i < CSQ * 4 * CDQ; i += 256) {
     const int cs = i / CDQ, q = i - cs * CDQ;
@@ -395,16 +400,24 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
   const float floor_ = (a.flags & N3D_RELU_IN) ? 0.f : -INFINITY;
   float4 x[VPT][CSQ], prev[EXTRA ? VPT : 1][CDQ], msk[EXTRA ? VPT : 1][CDQ];
   bool ok[VPT];
+  int64_t vdst[VPT];      // destination voxel of slot i
+  const bool sparse = EXTRA && a.sparse;
+  const int64_t nwalk = sparse ? a.Ns : a.N;
   // every global operand is requested before the first use
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int64_t v = base + i * 256;
-    ok[i] = v < a.N;
-    const int64_t vc = ok[i] ? v : a.N - 1;
+    ok[i] = v < nwalk;
+    int64_t vc = ok[i] ? v : nwalk - 1;
     int64_t vs = vc;
     bool hit = true;
     if constexpr (EXTRA) {
-      if (a.up) {
+      if (sparse) {
+        uint32_t q1, uw, ud, uh;
+        a.fWs.divmod((uint32_t)vc, q1, uw);
+        a.fHs.divmod(q1, ud, uh);
+        vc = ((int64_t)(2 * ud) * a.Hd + 2 * uh) * a.Wd + 2 * uw;
+      } else if (a.up) {
         uint32_t q1, uw, ud, uh;
         a.fWd.divmod((uint32_t)vc, q1, uw);
         a.fHd.divmod(q1, ud, uh);
@@ -413,6 +426,7 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
         if (!hit) vs = 0;
       }
     }
+    vdst[i] = vc;
 #pragma unroll
     for (int q = 0; q < CSQ; ++q) {
       x[i][q] = ld4(sb + vs * a.sld + q * 4);
@@ -467,14 +481,14 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
         r.x += prev[i][q].x; r.y += prev[i][q].y; r.z += prev[i][q].z; r.w += prev[i][q].w;
       }
       if (ok[i]) {
-        if (CDQ >= 2 && a.flat) st4(stage + ((t >> 6) * 64 + (t & 63)) * (CDQ * 4) + q * 4, r);
-        else st4(db + (base + i * 256) * a.dld + q * 4, r);
+        if (FLAT_OK && a.flat) st4(stage + ((t >> 6) * 64 + (t & 63)) * (CDQ * 4) + q * 4, r);
+        else st4(db + vdst[i] * a.dld + q * 4, r);
         s1[q * 4] += r.x; s1[q * 4 + 1] += r.y; s1[q * 4 + 2] += r.z; s1[q * 4 + 3] += r.w;
         s2[q * 4] = fmaf(r.x, r.x, s2[q * 4]); s2[q * 4 + 1] = fmaf(r.y, r.y, s2[q * 4 + 1]);
         s2[q * 4 + 2] = fmaf(r.z, r.z, s2[q * 4 + 2]); s2[q * 4 + 3] = fmaf(r.w, r.w, s2[q * 4 + 3]);
       }
     }
-    if constexpr (CDQ >= 2) {
+    if constexpr (FLAT_OK) {
       if (a.flat) {
         // the wave's 64 voxels (base + i*256 + lane) are one contiguous run of the dense destination
         const int wave = t >> 6, lane = t & 63;
@@ -529,7 +543,9 @@ static bool k1_shape_ok(const n3d_conv_geom* g, bool data_grad) {
   if (g->stride != 1 && !(g->stride == 2 && data_grad && g->pad == 0 && g->Di % 2 == 0 && g->Hi % 2 == 0 && g->Wi % 2 == 0)) return false;
   const int Cs = data_grad ? g->Co : g->Ci, Cd = data_grad ? g->Ci : g->Co;
   const int64_t N = (int64_t)g->Di * g->Hi * g->Wi;
-  // register budget: (Cs/4) * (Cd/4) <= 6 covers the nets' shapes (4->12, 12->4, 12->8, 24->4 and their data gradients)
+  // register budget: (Cs/4) * (Cd/4) <= 6 covers the nets' shapes (4->12, 12->4, 12->8, 24->4 and their data gradients).  (A 24-channel
+  // destination -- the data gradient of the last up cell's 24 -> 4 preprocess conv -- was tried in round 4: with two voxels per thread the
+  // kernel spills, +0.47 ms per 128^3 step; with one it is 0.02-0.04 ms slower than the gather kernel it replaces: profiles/r04_128_ab.log)
   return Cs % 4 == 0 && Cs >= 4 && Cs <= 24 && Cd % 4 == 0 && Cd >= 4 && Cd <= 12 && (Cs / 4) * (Cd / 4) <= 6 && N >= 32768;
 }
 
@@ -1620,6 +1636,10 @@ size_t n3d_conv_workspace_bytes(const n3d_conv_geom* g) {
       const size_t c = (size_t)1024 * 27 * g->Ci * g->Ci * 4;
       if (c > a) a = c;
     }
+    if (g->k == 3 && g->stride == 2 && g->Ci == 4 && g->Co % 4 == 0 && g->Co > 4 && g->Co <= 16) {  // the stems' 4 -> 12 conv, co-tiled (vox_wgrad_s2_try)
+      const size_t c = (size_t)1024 * 27 * g->Ci * g->Co * 4;
+      if (c > a) a = c;
+    }
     if (g->Ci % 16 == 0 && g->Co % 16 == 0) {  // MFMA weight-gradient slabs (conv_mfma.hip)
       const size_t nt = (size_t)taps * (g->Ci / 16) * (g->Co / 16);
       const size_t c = (N3D_WG16_SLABS + nt) * (256 + 16) * 4;
@@ -1725,9 +1745,15 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
         // stores on a 24-byte pitch cost more than the partial-line stores they replace)
         q.flat = (!noflat && !db16 && a.Cd >= 8 && dld == a.Cd && aligned16(dst) && ((size_t)q.N * a.Cd * esz) % 16 == 0) ? 1 : 0;
       }
+      {
+        static const bool nosparse = getenv("N3D_K1_NOSPARSE") != nullptr;   // (A/B knob)
+        q.sparse = (q.up && (flags & N3D_ACCUMULATE) && !nosparse) ? 1 : 0;
+        q.fWs = FastDiv((uint32_t)(a.Wd >> 1)); q.fHs = FastDiv((uint32_t)(a.Hd >> 1));
+        if (q.sparse) q.flat = 0;
+      }
       const bool extra = (flags & N3D_ACCUMULATE) || relu_src || q.up;
       N3D_CHECK_ARG(!(extra && stats), "conv(1x1x1): statistics together with accumulate / relu mask are not supported");
-      const dim3 grid((unsigned)cdiv(q.N, extra ? 512 : K1_VPB), (unsigned)g->B);
+      const dim3 grid((unsigned)cdiv(q.sparse ? q.Ns : q.N, extra ? 512 : K1_VPB), (unsigned)g->B);
       switch (a.Cs / 4) {
         case 1: launch_k1_c<1>(q, a.Cd, grid, s); break;
         case 2: launch_k1_c<2>(q, a.Cd, grid, s); break;
@@ -1874,9 +1900,9 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     if (hv == 0) hv = vox_wgrad_s2_try(g, x, xld, dy, dyld, flags, in_gate, wsf, avail, &nch, s);
     if (hv < 0) return hv;
     if (hv == 1) {
-      const int C = g->Ci;
+      const int C = g->Ci, tco = g->Co / C;     // tco > 1: the stem's 4 -> 12 stride-2 conv as Co / 4 column tiles (vox_wgrad_s2_try)
       n3d_final_job job;
-      fill_job(deferred ? deferred : &job, wsf, nullptr, dw, nullptr, nch, taps, 1, 1, C, C, C, C, taps);
+      fill_job(deferred ? deferred : &job, wsf, nullptr, dw, nullptr, nch, taps * tco, 1, tco, C, C, g->Co, C, taps);
       if (!deferred) if (int e = n3d_wgrad_finalize_batch(&job, 1, stream)) return e;
       N3D_LAUNCH_CHECK();
       return N3D_OK;

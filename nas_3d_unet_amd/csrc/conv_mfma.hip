@@ -54,7 +54,7 @@ __global__ void pack16_kernel(const float* __restrict__ w, float* __restrict__ w
 }
 
 #ifdef G16_STAMP
-// debug build only (tools/dbg/g16_stamps.py): phase stamps of wave 0 / wave 15 of every gemm16 workgroup
+// debug build only (tools/g16_stamps.py): phase stamps of wave 0 / wave 15 of every gemm16 workgroup
 __device__ unsigned long long g16_stamp_buf[4096 * 16];
 #define GSTAMP(k) do { if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == 15)) { const int wgl_ = blockIdx.x + gridDim.x * blockIdx.y; \
     if (wgl_ < 4096) g16_stamp_buf[wgl_ * 16 + (wave ? 8 : 0) + (k)] = clock64(); } } while (0)
@@ -144,7 +144,7 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
   //
   // Operand addressing (round 3).  Sixteen waves share four SIMDs here, so what a wave spends before its loads are out is VALU
   // issue slots: the per-group, per-lane address arithmetic (tap offsets, 64-bit pointer, range tests, zero select) was ~40 VALU
-  // instructions and the load phase 5 of this kernel's 8 us (tools/dbg/g16_stamps.py).  The voxel index is linear in (lane part) +
+  // instructions and the load phase 5 of this kernel's 8 us (tools/g16_stamps.py).  The voxel index is linear in (lane part) +
   // (tap part) -- also for the stride-2 data gradient, where the source voxel is (row + tap) / 2 and exists only when row and tap
   // agree in parity: then (row + tap) / 2 = (row >> 1) + ((tap + (tap & 1)) >> 1) -- so the lane part is a byte offset computed ONCE
   // (voffA), the tap part moves the base of a BUFFER resource on the scalar unit, and a lane whose tap falls outside the volume
@@ -1483,9 +1483,10 @@ struct VwArgs {
 // high half, so ONE add folds lane ^ 32 for both; the same with (r2, r3), then a v_permlane16_swap of the two results folds lane ^ 16
 // for all four and leaves row 0 / 1 / 2 / 3 of the wave with r0 / r2 / r1 / r3; two DPP row rotations finish inside the rows.
 // 3 swaps + 5 adds + 1 store of 16 lanes per tile instead of 4 x (2 swaps + 2 DPP + 4 adds + a 4-lane store): the epilogue was
-// 3 (C = 4) / 7 us (C = 8) of these 12 us kernels (tools/dbg/wgrad_ns.py with -DVW_NO_EPI).
+// 3 (C = 4) / 7 us (C = 8) of these 12 us kernels (tools/wgrad_ns.py with -DVW_NO_EPI).
 template <int C, int QC>
-__device__ __forceinline__ void vw_store_tiles(const f32x4 (&acc)[7][QC][QC], float* __restrict__ out, const int tap0, const int lane) {
+__device__ __forceinline__ void vw_store_tiles(const f32x4 (&acc)[7][QC][QC], float* __restrict__ out, const int tap0, const int lane,
+                                               const int tap_stride = C * C) {
   const int rsel = ((lane >> 4) & 1) * 2 + (lane >> 5);     // the accumulator register this lane's row ends up with
   const bool writer = (lane & 15) < 4;
   float* o = out + rsel * C + (lane & 3);
@@ -1509,7 +1510,7 @@ __device__ __forceinline__ void vw_store_tiles(const f32x4 (&acc)[7][QC][QC], fl
           float x = __builtin_bit_cast(float, (int)sx[0]) + __builtin_bit_cast(float, (int)sx[1]);
           x += dpp_f<0x124>(x);   // row_ror:4
           x += dpp_f<0x128>(x);   // row_ror:8
-          if (writer) o[(tap0 + t) * (C * C) + (qa * 4) * C + qb * 4] = x;
+          if (writer) o[(tap0 + t) * tap_stride + (qa * 4) * C + qb * 4] = x;
         }
     }
   }
@@ -1595,7 +1596,7 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
   // soff[m] = element offset from plane d0 of the chunk's tensor, sdz[m] = the slot's plane relative to d0 (a value that fails the
   // plane test for slots outside the volume in H / W and for padding slots).  Per tile and chunk that leaves a compare, a select and
   // a 64-bit add in front of the DMA -- the arithmetic was 3.9 of this kernel's 13.5 us at (2,4,64^3) and 26 of 83 us at (2,4,128^3)
-  // (tools/dbg/wgrad_ns.py, -DVW_NO_STAGE2).
+  // (tools/wgrad_ns.py, -DVW_NO_STAGE2).
   constexpr int M = NCH / 4;
   int soff[M], sdz[M];
 #pragma unroll
@@ -1726,6 +1727,8 @@ struct Vw2Args {
   const void* x; int64_t xld; int D, H, W;         // big grid (conv input / transposed-conv output gradient); T elements
   const void* dy; int64_t dyld; int oD, oH, oW;    // small grid
   float* partial; int dchunk; const void* zero_page;
+  int tco;   // output-channel tiles of C channels (grid.z): dY has tco * C channels, workgroup z takes channels [z C, z C + C) -- the
+             // stem's 4 -> 12 conv as three 4 -> 4 problems in one launch; slabs [workgroup][tap][z][C][C] (final job: tco tiles per tap)
 };
 
 template <int C, int DIL, typename T = float>
@@ -1752,7 +1755,7 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
   const int dbeg = (bx / th_n) * a.dchunk;
   const int64_t Nx = (int64_t)a.D * a.H * a.W, Ny = (int64_t)a.oD * a.oH * a.oW;
   const T* xb = reinterpret_cast<const T*>(a.x) + (int64_t)b * Nx * a.xld;
-  const T* dyb = reinterpret_cast<const T*>(a.dy) + (int64_t)b * Ny * a.dyld;
+  const T* dyb = reinterpret_cast<const T*>(a.dy) + (int64_t)b * Ny * a.dyld + (int)blockIdx.z * C;
   const float4* zp = reinterpret_cast<const float4*>(a.zero_page);
   const int blk = lane >> 2, i4 = lane & 3;
   const int tap0 = wave * 7;
@@ -1886,15 +1889,20 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
           for (int qb = 0; qb < QC; ++qb) acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(avs[t][qa], bvs[qb], acc[t][qa][qb], 0, 0, 0);
     }
   }
-  float* out = a.partial + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 27) * (C * C);
-  vw_store_tiles<C, QC>(acc, out, tap0, lane);
+  float* out = a.partial + (((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 27) * a.tco + blockIdx.z) * (C * C);
+  vw_store_tiles<C, QC>(acc, out, tap0, lane, a.tco * C * C);
 }
 
-// returns 1 if handled (slab layout as vox_wgrad_try: ci_t = co_t = C, tci = tco = 1, ntiles = 27)
+// returns 1 if handled (slab layout as vox_wgrad_try: ci_t = co_t = C, tci = 1, ntiles = 27 * tco; tco = Co / Ci = 1 except for the
+// stem's 4 -> 12 conv)
 int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                      float* partial, size_t avail_floats, int* nchunks_out, hipStream_t s) {
   if ((flags & (N3D_RELU_IN | N3D_NO_MFMA)) || in_gate) return 0;
-  if (g->depthwise || g->k != 3 || g->stride != 2 || g->Ci != g->Co || (g->Ci != 4 && g->Ci != 8)) return 0;
+  if (g->depthwise || g->k != 3 || g->stride != 2 || (g->Ci != 4 && g->Ci != 8)) return 0;
+  // square, or (fp32) 4 -> 8 / 12 / 16 channels as Co / 4 problems of 4 -> 4 in one launch (stem1, nas.py:29 / searched.py:70)
+  const int tco = g->Co / g->Ci;
+  static const bool no_cotile = getenv("N3D_VW_NO_COTILE") != nullptr;   // (A/B knob)
+  if (g->Co != g->Ci && (no_cotile || !(g->Ci == 4 && g->Co % 4 == 0 && tco >= 2 && tco <= 4 && !(flags & (N3D_SRC_BF16 | N3D_DST_BF16))))) return 0;
   if (!(g->dil == 1 || g->dil == 2) || g->pad != g->dil) return 0;
   if (g->Wo % 16 != 0 || g->Ho % 4 != 0 || g->Do % 2 != 0) return 0;
   // small problems (16^3 outputs) leave this tile scheme with a few dozen long-running workgroups: the per-tap generic
@@ -1911,7 +1919,7 @@ int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   while (columns * dsplit < 384 && dsplit * 2 <= nd && nd % (dsplit * 2) == 0) dsplit *= 2;
   const int tiles = (g->Wo / 16) * (g->Ho / 4) * dsplit;
   const int nwg = tiles * g->B;
-  if ((size_t)nwg * 27 * g->Ci * g->Ci > avail_floats) return 0;
+  if ((size_t)nwg * 27 * g->Ci * g->Co > avail_floats) return 0;
   const size_t Qn = b16 ? 1 : g->Ci / 4;   // LDS slots per voxel
   const size_t LDn = 2 + 2 * g->dil + 1, LHn = 7 + 2 * g->dil, LWn = 31 + 2 * g->dil;
   const size_t nvox = LDn * LHn * 2 * ((LWn + 1) / 2);
@@ -1920,9 +1928,9 @@ int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   if (lds > 160 * 1024) return 0;
   Vw2Args a;
   a.x = x; a.xld = xld; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.dy = dy; a.dyld = dyld; a.oD = g->Do; a.oH = g->Ho; a.oW = g->Wo;
-  a.partial = partial; a.dchunk = g->Do / dsplit; a.zero_page = zero_page_ptr();
+  a.partial = partial; a.dchunk = g->Do / dsplit; a.zero_page = zero_page_ptr(); a.tco = tco;
   if (!a.zero_page) return 0;
-  dim3 grid(tiles, g->B);
+  dim3 grid(tiles, g->B, tco);
   if (b16) {
     if (g->Ci == 4) {
       if (g->dil == 1) hipLaunchKernelGGL((vox_wgrad_s2_kernel<4, 1, bf16_t>), grid, dim3(256), lds, s, a);

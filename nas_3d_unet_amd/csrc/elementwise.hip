@@ -1144,7 +1144,7 @@ __global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwd
 
 #ifdef EW_STAMP
 #define EW_STAMP_ON 1
-// debug build only (tools/dbg/ew_stamps.py): phase stamps of wave 0 of every workgroup of the apply_gn2 / reduce2 kernels
+// debug build only (tools/ew_stamps.py): phase stamps of wave 0 of every workgroup of the apply_gn2 / reduce2 kernels
 __device__ unsigned long long ew_stamp_buf[4096 * 8];
 #define ESTAMP(k) do { if (threadIdx.x == 0 && EW_STAMP_ON) { const int wgl_ = blockIdx.x + gridDim.x * blockIdx.y; if (wgl_ < 4096) ew_stamp_buf[wgl_ * 8 + (k)] = clock64(); } } while (0)
 extern "C" int n3d_debug_ew_stamps(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ew_stamp_buf), (size_t)n * 8); }

@@ -342,7 +342,7 @@ class StepContext:
                     on_mark(item[1])
                 continue
             launch, job, ws, keep = item
-            if _DROP_SIDE:      # timing probe only (tools/dbg/side_sweep.py): the main chain without its weight gradients
+            if _DROP_SIDE:      # timing probe only (tools/side_timeline.py --drop): the main chain without its weight gradients
                 continue
             launch(stream_ptr())
             if job.nchunks > 0:

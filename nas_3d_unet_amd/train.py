@@ -262,7 +262,7 @@ def reserve_side_streams(device, n=2):
     """Make the process's side streams NOW and put a launch on each.  Which hardware queue / pipe a HIP stream gets is settled when
     it is first used, in creation order; streams made early sit next to the default stream's queue and run side by side with it,
     while streams made after a lot of other activity were seen to share a time slice with it (a search step of 58 instead of
-    14.5 ms: tools/dbg/slowmode.py).  Every trainer calls this first; a program that does other GPU work before it builds a
+    14.5 ms; docs/history/DESIGN_r01-r03.md).  Every trainer calls this first; a program that does other GPU work before it builds a
     trainer can call it right after selecting the device.  (A late reservation is not an error: the trainers time both schedules
     and keep the single-stream one if the side streams do not pay.)"""
     device = torch.device(device)

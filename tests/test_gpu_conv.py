@@ -81,8 +81,13 @@ CASES = [
     (4, 12, 1, 1, 1, False, 2, (32, 32, 32)),
     (12, 4, 1, 1, 1, False, 2, (32, 33, 32)),    # ragged: the last workgroup is partial
     (12, 8, 1, 1, 1, False, 1, (32, 32, 40)),
-    (24, 4, 1, 1, 1, False, 2, (32, 32, 32)),
+    (24, 4, 1, 1, 1, False, 2, (32, 32, 32)),    # (its data gradient, 4 -> 24, is the widest destination of the streaming kernel)
+    (4, 24, 1, 1, 1, False, 1, (32, 32, 40)),
     (12, 8, 1, 2, 1, False, 2, (32, 32, 64)),    # stride 2: its data gradient is the zero-upsampling form of the same kernel
+    # the stems' 4 -> 12 stride-2 conv (nas.py:29, searched.py:70): weight gradient as Co / 4 column tiles of the 4 -> 4 stride-2 MFMA kernel
+    (4, 12, 3, 2, 1, False, 2, (64, 64, 64)),
+    (4, 8, 3, 2, 1, False, 2, (32, 64, 64)),
+    (4, 16, 3, 2, 2, False, 2, (64, 32, 64)),
 ]
 
 

@@ -5,7 +5,7 @@
 #                                  roofline loop of the conv kernel), stdout of that run in bench_stdout_under_rocprof.log
 #   {search,p128_f32,p128_bf16}_kernel_stats.csv + *_bench.log   the other three workloads, one summary each
 #   side_timeline*.txt             timeline of the side-stream schedule from device clock stamps (tools/side_timeline.py)
-#   side_phases.log, search_phases.log   main graph / tail times with the side work dropped and running (tools/dbg/*_phases.py)
+#   side_phases.log, search_phases.log   main graph / tail times with the side work dropped and running (tools/*_phases.py)
 #   two_chain_probe.log, handoff_cost.log, seg_overlap.log   the scheduling probes of DESIGN.md section 5
 #   schedules.log                  train step with the side schedule off / on / forced, and the 1-rank RCCL variants
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -39,7 +39,7 @@ for t in handoff_cost seg_overlap; do
 done
 python3 tools/side_timeline.py > $O/side_timeline.txt 2>&1
 python3 tools/side_timeline.py --size 128 --dtype bf16 > $O/side_timeline_p128_bf16.txt 2>&1
-python3 tools/dbg/side_phases.py > $O/side_phases.log 2>&1
-python3 tools/dbg/search_phases.py > $O/search_phases.log 2>&1
+python3 tools/side_phases.py > $O/side_phases.log 2>&1
+python3 tools/search_phases.py > $O/search_phases.log 2>&1
 grep -h metric $O/bench_line.log | cut -c1-200
 ls $O

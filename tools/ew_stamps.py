@@ -1,6 +1,6 @@
 """Phase stamps of n3d_affine_act_bwd_apply_gn2 (debug build -DEW_STAMP, N3D_LIB=.../libn3d_ew.so) in a reduce2 -> apply_gn2 chain."""
 import sys, os, ctypes as C
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 import numpy as np, torch
 from nas_3d_unet_amd import kernels as K, _lib

@@ -1,7 +1,7 @@
 """Phase stamps of the gemm16 kernels (debug build -DG16_STAMP, N3D_LIB=.../libn3d_g16.so): where the time of a deep-level conv goes.
 Runs a chain of dependent convs (as the step does) and prints, per phase, the median over workgroups of (stamp - kernel's first stamp)."""
 import sys, os, ctypes as C
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 import numpy as np, torch
 from nas_3d_unet_amd import kernels as K, _lib

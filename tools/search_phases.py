@@ -1,6 +1,6 @@
 """search step with the side schedule: GPU time of the architecture-pass graph, the weight pass' main graph and its tail"""
 import sys, os, time
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 import torch, bench
 from nas_3d_unet_amd import nas, kernels as K

@@ -1,6 +1,6 @@
 """side-stream schedule: time of the main graph (under contention from the side stream) and of the tail (join wait + slab reduction + Adam)"""
 import sys, os, time
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 import torch, bench
 from nas_3d_unet_amd import searched, kernels as K

@@ -1,6 +1,6 @@
 """Per-launch table of one train step IN EXECUTION ORDER (replay-timed per (entry, shape) group).  usage: table_seq.py [size] [batch] [storage]"""
 import sys, os, json, collections
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tools"))
 import numpy as np, torch
 import bench, kernel_table

@@ -1,6 +1,6 @@
 """vox_wgrad: stages in flight (N3D_VW_NS) x workgroup target (N3D_VW_WGS); one process per setting (the knobs are read once)"""
 import sys, os, subprocess
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, R)
     import torch
