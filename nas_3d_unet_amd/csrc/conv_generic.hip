@@ -1892,7 +1892,8 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   // dense: the kernel computes G[co'][ci'][tap] = sum dyK[o][co'] * xK[i(o,tap)][ci'] with xK on the i side.
   // forward conv: xK = x (Ci), dyK = dy (Co), dw native (Co,Ci,k^3) = G.
   // transposed conv (weight (CinT=Co_geom, CoutT=Ci_geom)): xK = dy_T (i side, Ci), dyK = x_T (o side, Co): same G layout.
-  if ((!dbias || transposed) && (!(flags & N3D_ANY_BF16) || (sb16 && db16))) {
+  // (fp32 X with bf16 dY: the stem's stride-2 conv in the bf16 configuration, taken by vox_wgrad_s2_try alone)
+  if ((!dbias || transposed) && (!(flags & N3D_ANY_BF16) || (sb16 && db16) || (!sb16 && db16 && !transposed && g->stride == 2 && g->Ci == 4))) {
     // vox64 weight gradient (3x3x3 stride 1, C = 4 / 8); it does not produce the bias gradient, which the callers on the
     // hot path obtain analytically from the GroupNorm backward sums (n3d_gn_bwd_coeffs)
     int nch = 0;

@@ -1731,14 +1731,16 @@ struct Vw2Args {
              // stem's 4 -> 12 conv as three 4 -> 4 problems in one launch; slabs [workgroup][tap][z][C][C] (final job: tco tiles per tap)
 };
 
-template <int C, int DIL, typename T = float>
+// T / TY: storage types of X and dY (TY = T except for the stem in the bf16 configuration: fp32 net input, bf16 gradient)
+template <int C, int DIL, typename T = float, typename TY = T>
 __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
-  constexpr bool B16 = sizeof(T) == 2;
-  constexpr int QC = C / 4, Q = B16 ? 1 : QC, EPS = B16 ? 8 : 4;   // accumulator quads; LDS slots per voxel; elements per slot
+  constexpr bool B16 = sizeof(T) == 2, BY16 = sizeof(TY) == 2;
+  constexpr int QC = C / 4, Q = B16 ? 1 : QC, EPS = B16 ? 8 : 4;   // accumulator quads; LDS slots per voxel; elements per slot (X image)
+  constexpr int QY = BY16 ? 1 : QC;                                 // LDS slots per voxel of the dY image
   constexpr int TD = 2, GH = 4, GW = 16;
   constexpr int LD = 2 * (TD - 1) + 2 * DIL + 1, LH = 7 + 2 * DIL, LW = 31 + 2 * DIL;
   constexpr int HW = (LW + 1) / 2, RW = 2 * HW, PLANE = LH * RW, NVOX = LD * PLANE;
-  constexpr int NXC = (Q * NVOX + 63) / 64, NYC = (TD * GH * GW * Q + 63) / 64, NCH = (NXC + NYC + 3) / 4 * 4, BUF = NCH * 64;
+  constexpr int NXC = (Q * NVOX + 63) / 64, NYC = (TD * GH * GW * QY + 63) / 64, NCH = (NXC + NYC + 3) / 4 * 4, BUF = NCH * 64;
   extern __shared__ __attribute__((aligned(16))) float4 wtile[];  // [2][BUF]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1755,7 +1757,7 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
   const int dbeg = (bx / th_n) * a.dchunk;
   const int64_t Nx = (int64_t)a.D * a.H * a.W, Ny = (int64_t)a.oD * a.oH * a.oW;
   const T* xb = reinterpret_cast<const T*>(a.x) + (int64_t)b * Nx * a.xld;
-  const T* dyb = reinterpret_cast<const T*>(a.dy) + (int64_t)b * Ny * a.dyld + (int)blockIdx.z * C;
+  const TY* dyb = reinterpret_cast<const TY*>(a.dy) + (int64_t)b * Ny * a.dyld + (int)blockIdx.z * C;
   const float4* zp = reinterpret_cast<const float4*>(a.zero_page);
   const int blk = lane >> 2, i4 = lane & 3;
   const int tap0 = wave * 7;
@@ -1802,7 +1804,7 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
         }
       } else {
         const int sl = slot - NXC * 64;
-        const int q = sl % Q, vx = (sl / Q) % GW, row = sl / (Q * GW);
+        const int q = sl % QY, vx = (sl / QY) % GW, row = sl / (QY * GW);
         if (row < TD * GH) {
           const int g = row / GH, hh = row - g * GH;
           soff[m] = ((g * a.oH + h0 + hh) * a.oW + w0 + vx) * (int)a.dyld + q * 4;
@@ -1818,7 +1820,8 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
       for (int m = 0; m < M; ++m) {
         const int c = m * 4 + wave;
         const bool isx = c < NXC;
-        const T* base = (isx ? xb + (int64_t)(2 * d0) * xplane : dyb + (int64_t)d0 * yplane) + soff[PRE ? m : 0];
+        const void* base = isx ? static_cast<const void*>(xb + (int64_t)(2 * d0) * xplane + soff[PRE ? m : 0])
+                               : static_cast<const void*>(dyb + (int64_t)d0 * yplane + soff[PRE ? m : 0]);
         const bool inb = isx ? (unsigned)(2 * d0 + sdz[PRE ? m : 0]) < (unsigned)a.D : sdz[PRE ? m : 0] >= 0;
         const float4* srcp = inb ? reinterpret_cast<const float4*>(base) : zp;
         __builtin_amdgcn_global_load_lds((gptr_t)srcp, (lptr_t)(buf + c * 64), 16, 0, N3D_WGRAD_AUX);
@@ -1841,7 +1844,7 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
           if (inb) srcp = reinterpret_cast<const float4*>(xb + (((int64_t)gd * a.H + gh) * a.W + gw) * a.xld + q * 4);
         } else {
           const int sl = slot - NXC * 64;
-          const int q = sl % Q, vx = (sl / Q) % GW, row = sl / (Q * GW);
+          const int q = sl % QY, vx = (sl / QY) % GW, row = sl / (QY * GW);
           if (row < TD * GH) {
             const int g = row / GH, hh = row - g * GH;
             srcp = reinterpret_cast<const float4*>(dyb + (((int64_t)(d0 + g) * a.oH + h0 + hh) * a.oW + w0 + vx) * a.dyld + q * 4);
@@ -1866,16 +1869,19 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
       const int g = r >> 2, hh = r & 3;
       const int rbase = ((2 * g) * PLANE + (2 * hh) * RW) * EPS;
       float avs[7][QC], bvs[QC];
-      if constexpr (B16) {
+      if constexpr (BY16) {
 #pragma unroll
         for (int qb = 0; qb < QC; ++qb) bvs[qb] = ld1(yh + (r * GW + blk) * 8 + qb * 4 + i4);
+      } else {
+#pragma unroll
+        for (int qb = 0; qb < QC; ++qb) bvs[qb] = yf[((r * GW + blk) * QY + qb) * 4 + i4];
+      }
+      if constexpr (B16) {
 #pragma unroll
         for (int t = 0; t < 7; ++t)
 #pragma unroll
           for (int qa = 0; qa < QC; ++qa) avs[t][qa] = ld1(th + rbase + toff[t] + qa * 4);
       } else {
-#pragma unroll
-        for (int qb = 0; qb < QC; ++qb) bvs[qb] = yf[((r * GW + blk) * Q + qb) * 4 + i4];
 #pragma unroll
         for (int t = 0; t < 7; ++t)
 #pragma unroll
@@ -1902,16 +1908,19 @@ int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   // square, or (fp32) 4 -> 8 / 12 / 16 channels as Co / 4 problems of 4 -> 4 in one launch (stem1, nas.py:29 / searched.py:70)
   const int tco = g->Co / g->Ci;
   static const bool no_cotile = getenv("N3D_VW_NO_COTILE") != nullptr;   // (A/B knob)
-  if (g->Co != g->Ci && (no_cotile || !(g->Ci == 4 && g->Co % 4 == 0 && tco >= 2 && tco <= 4 && !(flags & (N3D_SRC_BF16 | N3D_DST_BF16))))) return 0;
+  // (the stem reads the fp32 net input also in the bf16 configuration: X fp32, dY fp32 or bf16)
+  if (g->Co != g->Ci && (no_cotile || !(g->Ci == 4 && g->Co % 4 == 0 && tco >= 2 && tco <= 4 && !(flags & N3D_SRC_BF16)))) return 0;
   if (!(g->dil == 1 || g->dil == 2) || g->pad != g->dil) return 0;
   if (g->Wo % 16 != 0 || g->Ho % 4 != 0 || g->Do % 2 != 0) return 0;
   // small problems (16^3 outputs) leave this tile scheme with a few dozen long-running workgroups: the per-tap generic
   // kernel is faster there (measured 8.7 vs 12.7 us at (2,8,16^3)); from 32^3 outputs on it is 2x faster and reads dY once
   if ((int64_t)g->B * g->Do * g->Ho * g->Wo < 32768) return 0;
   const bool b16 = (flags & N3D_SRC_BF16) && (flags & N3D_DST_BF16);
-  if (!b16 && (flags & (N3D_SRC_BF16 | N3D_DST_BF16))) return 0;   // mixed storage: the generic kernel
+  const bool mixed = !(flags & N3D_SRC_BF16) && (flags & N3D_DST_BF16) && g->Ci == 4;   // fp32 X, bf16 dY (C = 4 only: the stem)
+  if (!b16 && !mixed && (flags & (N3D_SRC_BF16 | N3D_DST_BF16))) return 0;   // other mixed storage: the generic kernel
   if (xld % 4 != 0 || dyld % 4 != 0) return 0;
-  if (!b16 && (!aligned16(x) || !aligned16(dy))) return 0;
+  if (mixed && (!aligned16(x) || (reinterpret_cast<uintptr_t>(dy) & 7) != 0)) return 0;
+  if (!b16 && !mixed && (!aligned16(x) || !aligned16(dy))) return 0;
   if (b16 && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 7) != 0 ||
               (g->Ci == 8 && (xld % 8 != 0 || dyld % 8 != 0 || !aligned16(x) || !aligned16(dy))))) return 0;
   const int columns = g->B * (g->Ho / 4) * (g->Wo / 16);
@@ -1920,10 +1929,11 @@ int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   const int tiles = (g->Wo / 16) * (g->Ho / 4) * dsplit;
   const int nwg = tiles * g->B;
   if ((size_t)nwg * 27 * g->Ci * g->Co > avail_floats) return 0;
-  const size_t Qn = b16 ? 1 : g->Ci / 4;   // LDS slots per voxel
+  const size_t Qn = b16 ? 1 : g->Ci / 4;   // LDS slots per voxel (X image; dY: one slot per voxel in bf16)
+  const size_t Qy = (b16 || mixed) ? 1 : g->Ci / 4;
   const size_t LDn = 2 + 2 * g->dil + 1, LHn = 7 + 2 * g->dil, LWn = 31 + 2 * g->dil;
   const size_t nvox = LDn * LHn * 2 * ((LWn + 1) / 2);
-  const size_t nxc = (Qn * nvox + 63) / 64, nyc = (2 * 4 * 16 * Qn + 63) / 64, nch = (nxc + nyc + 3) / 4 * 4;
+  const size_t nxc = (Qn * nvox + 63) / 64, nyc = (2 * 4 * 16 * Qy + 63) / 64, nch = (nxc + nyc + 3) / 4 * 4;
   const size_t lds = 2 * nch * 64 * 16;
   if (lds > 160 * 1024) return 0;
   Vw2Args a;
@@ -1931,7 +1941,10 @@ int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   a.partial = partial; a.dchunk = g->Do / dsplit; a.zero_page = zero_page_ptr(); a.tco = tco;
   if (!a.zero_page) return 0;
   dim3 grid(tiles, g->B, tco);
-  if (b16) {
+  if (mixed) {
+    if (g->dil == 1) hipLaunchKernelGGL((vox_wgrad_s2_kernel<4, 1, float, bf16_t>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((vox_wgrad_s2_kernel<4, 2, float, bf16_t>), grid, dim3(256), lds, s, a);
+  } else if (b16) {
     if (g->Ci == 4) {
       if (g->dil == 1) hipLaunchKernelGGL((vox_wgrad_s2_kernel<4, 1, bf16_t>), grid, dim3(256), lds, s, a);
       else hipLaunchKernelGGL((vox_wgrad_s2_kernel<4, 2, bf16_t>), grid, dim3(256), lds, s, a);

@@ -62,6 +62,7 @@ def _view(t16):
     (4, 4, 3, 2, 1, False, (64, 64, 64)),      # large enough for the MFMA stride-2 weight gradient (vox_wgrad_s2_kernel<.., bf16>)
     (8, 8, 3, 2, 2, False, (32, 64, 64)),
     (4, 4, 3, 2, 1, True, (32, 32, 32)),       # ... with the roles swapped (transposed conv)
+    (4, 12, 3, 2, 1, False, (64, 64, 64)),     # stem1 at full size: co-tiled stride-2 MFMA weight gradient, fp32 input with a bf16 gradient ("f32->bf16")
 ])
 @pytest.mark.parametrize("mix", ["bf16->bf16", "bf16->f32", "f32->bf16"])
 def test_conv_family_bf16_storage(cin, cout, k, stride, dil, transposed, shape, mix):
