@@ -119,6 +119,32 @@ int n3d_wgrad_finalize_batch(const n3d_final_job* jobs /* host array */, int njo
  * returns the number of launches its 300 jobs take, < 0 on a mismatch. */
 int n3d_selftest_job_tables(void);
 
+/* ---- "weight_norm" 1x1x1 conv WITHOUT its raw output (round 4; stem0: ConvOps(in, 3 c, kernel_size=1, ops_order='weight_norm'),
+ * nas.py:28 / searched.py:69, prim_ops.py:68-83).  With 4 (8) input channels, raw = W x + bias costs 4 (8) FMAs per channel to
+ * recompute, while storing it and reading it back in the GroupNorm epilogue and in both passes of its backward -- and writing d(raw)
+ * for the weight gradient -- moves the 12-channel tensor five more times (0.2 ms of a 4x128^3 step).  The op then runs as
+ *   forward : n3d_conv_k1_norm_fwd(y = NULL, stats)   statistics of raw only, nothing stored
+ *             n3d_gn_coeffs                           (a, b) per (sample, channel)
+ *             n3d_conv_k1_norm_fwd(y, oscale = a, oshift = b)   y = a * (W x + bias) + b in one pass over x
+ *   backward: n3d_conv_k1_norm_bwd_reduce             rows [B][n3d_conv_k1_norm_rows][Co][3] as n3d_affine_act_bwd_reduce writes them
+ *             n3d_gn_bwd_coeffs                       (A, Bc, Cc), d gamma, d beta, d bias
+ *             n3d_conv_k1_norm_bwd_apply_wgrad        d(raw) = A g + (Cc raw + Bc) in registers -> dW slabs (deferred as
+ *                                                     n3d_conv_bwd_weight); d(raw) is never written, so the op has NO input gradient
+ * (Ci, Co) in {(4,4), (4,8), (4,12), (8,4)}, stride 1, >= 32768 voxels per sample (n3d_conv_k1_norm_ok); x fp32 or bf16
+ * (N3D_SRC_BF16), y / dout fp32 or bf16 (N3D_DST_BF16); flags & N3D_RELU: the op has a ReLU behind its norm.  w: the native
+ * (Co, Ci) weight for the backward calls; ws of the forward call as n3d_conv_fwd (packed weights, N3D_PREPACKED honoured). */
+int n3d_conv_k1_norm_ok(const n3d_conv_geom* g);
+int n3d_conv_k1_norm_rows(const n3d_conv_geom* g);
+int n3d_conv_k1_norm_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias, float* y, int64_t yld,
+                         int flags, const float* oscale, const float* oshift, double* stats, void* ws, size_t ws_bytes, void* stream);
+int n3d_conv_k1_norm_bwd_reduce(const n3d_conv_geom* g, const void* x, int64_t xld, const float* w, const float* bias, const void* dout,
+                                int64_t dld, const float* a, const float* b, int flags, double* sums, void* stream);
+int n3d_conv_k1_norm_bwd_apply_wgrad(const n3d_conv_geom* g, const void* x, int64_t xld, const float* w, const float* bias,
+                                     const void* dout, int64_t dld, const float* a, const float* b, const float* A, const float* Bc,
+                                     const float* Cc, int flags, float* dw, void* ws, size_t ws_bytes, n3d_final_job* deferred,
+                                     void* stream);
+
+
 /* y[o side] = conv(x[i side]) + bias */
 int n3d_conv_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias,
                  float* y, int64_t yld, int flags, const float* in_gate, double* stats,

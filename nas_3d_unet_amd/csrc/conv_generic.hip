@@ -372,6 +372,9 @@ struct K1Args {
   // the launch walks the Ns SOURCE voxels and read-modify-writes their destinations instead of rewriting the whole tensor
   // (12 -> 8 at 2 x 128^3 -> 64^3: 400 MB of traffic for 50 MB of work)
   int sparse; FastDiv fWs, fHs;
+  // "weight_norm" recompute form (n3d_conv_k1_norm_fwd): nostore = statistics only, nothing is written; oscale / oshift [B][Cd] = the
+  // GroupNorm coefficients applied to the conv result before it is stored (out = oscale * (W x + bias) + oshift)
+  int nostore; const float* oscale; const float* oshift;
   // flat: the destination is dense (dld == Cd) with >= 2 quads per voxel and 16-byte aligned 64-voxel runs: a wave transposes its
   // 64 voxel records through LDS and writes them as consecutive 16-byte pieces (per-voxel stores of a 12-channel tensor put 16 bytes
   // on every 48-byte pitch: three partial-line instructions per line)
@@ -440,12 +443,14 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
       }
     }
   }
-  float4 acc[VPT][CDQ];
+  float4 acc[VPT][CDQ], osc[CDQ], osh[CDQ];
 #pragma unroll
   for (int q = 0; q < CDQ; ++q) {
     const float4 bq = a.bias ? *reinterpret_cast<const float4*>(a.bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < VPT; ++i) acc[i][q] = bq;
+    osc[q] = a.oscale ? *reinterpret_cast<const float4*>(a.oscale + (int64_t)b * (CDQ * 4) + q * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    osh[q] = a.oshift ? *reinterpret_cast<const float4*>(a.oshift + (int64_t)b * (CDQ * 4) + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
 #pragma unroll
@@ -481,7 +486,11 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
         r.x += prev[i][q].x; r.y += prev[i][q].y; r.z += prev[i][q].z; r.w += prev[i][q].w;
       }
       if (ok[i]) {
-        if (FLAT_OK && a.flat) st4(stage + ((t >> 6) * 64 + (t & 63)) * (CDQ * 4) + q * 4, r);
+        if (a.oscale) {      // (the statistics of this pass, if any, are those of the stored values)
+          r.x = fmaf(osc[q].x, r.x, osh[q].x); r.y = fmaf(osc[q].y, r.y, osh[q].y); r.z = fmaf(osc[q].z, r.z, osh[q].z); r.w = fmaf(osc[q].w, r.w, osh[q].w);
+        }
+        if (a.nostore) {}
+        else if (FLAT_OK && a.flat) st4(stage + ((t >> 6) * 64 + (t & 63)) * (CDQ * 4) + q * 4, r);
         else st4(db + vdst[i] * a.dld + q * 4, r);
         s1[q * 4] += r.x; s1[q * 4 + 1] += r.y; s1[q * 4 + 2] += r.z; s1[q * 4 + 3] += r.w;
         s2[q * 4] = fmaf(r.x, r.x, s2[q * 4]); s2[q * 4 + 1] = fmaf(r.y, r.y, s2[q * 4 + 1]);
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
       }
     }
     if constexpr (FLAT_OK) {
-      if (a.flat) {
+      if (a.flat && !a.nostore) {
         // the wave's 64 voxels (base + i*256 + lane) are one contiguous run of the dense destination
         const int wave = t >> 6, lane = t & 63;
         const int64_t v0 = (int64_t)blockIdx.x * (VPT * 256) + i * 256 + wave * 64;
@@ -683,6 +692,136 @@ static void launch_k1_wgrad_c(const K1WgArgs& a, int Co, int nchunks, hipStream_
   else if (sb) launch_k1_wgrad_d<CIQ, bf16_t, float>(a, Co, nchunks, s);
   else if (db) launch_k1_wgrad_d<CIQ, float, bf16_t>(a, Co, nchunks, s);
   else launch_k1_wgrad_d<CIQ, float, float>(a, Co, nchunks, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// "weight_norm" 1x1x1 conv with few channels on a large volume (stem0: 4 -> 12 at 64^3 / 128^3; nas.py:28, searched.py:69;
+// prim_ops.py:68-83), backward WITHOUT the raw conv output: raw = W x + bias costs Ci FMAs per channel to recompute from the
+// Ci-channel input, while storing it and reading it back (forward epilogue, both backward passes) and writing d(raw) for the
+// weight gradient move 12-channel tensors five more times.  Thread = voxel, all Co channels:
+//   k1n_bwd_reduce:      rows (sum g, sum g raw, sum dout z) per channel, as affine_bwd_reduce_kernel writes them (gn_bwd_coeffs reads them)
+//   k1n_bwd_apply_wgrad: d(raw) = A g + (Cc raw + Bc) in registers, dW[co][ci] += d(raw)[co] x[ci] -> one slab per workgroup for the
+//                        common fixed-order finalize; d(raw) is never written (nothing else reads it: the op has no input gradient)
+// raw is formed in the forward kernel's order (bias, then ci ascending, fmaf): bit-identical to what conv_k1_kernel computed.
+// ------------------------------------------------------------------------------------------------
+struct K1nArgs {
+  const void* x; int64_t xld; const void* dout; int64_t dld;      // TS / TD elements
+  const float* w; const float* bias;                               // native (Co, Ci) weight, (Co) bias or NULL
+  const float* a; const float* b;                                  // forward GroupNorm coefficients [B][Co]
+  const float* A; const float* Bc; const float* Cc;                // backward coefficients [B][Co] (apply)
+  double* sums; float* partial;                                    // reduce: [B][rows][Co][3]; apply: [B * rows][Ci][Co]
+  int64_t N; int chunk; int relu;
+};
+
+template <int CIQ, int COQ, bool APPLY, typename TS, typename TD>
+__global__ __launch_bounds__(256) void k1n_bwd_kernel(K1nArgs q) {
+  constexpr int CI = CIQ * 4, CO = COQ * 4, NV = APPLY ? CI * CO : CO * 3;
+  __shared__ float wsm[CO][CI + 1];
+  __shared__ float red[4][NV];
+  const int t = threadIdx.x, b = blockIdx.y;
+  for (int i = t; i < CO * CI; i += 256) wsm[i / CI][i % CI] = q.w[i];
+  float bias[CO], av[CO], bv[CO], Av[APPLY ? CO : 1], Bv[APPLY ? CO : 1], Cv[APPLY ? CO : 1];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    bias[c] = q.bias ? q.bias[c] : 0.f;
+    av[c] = q.a[b * CO + c]; bv[c] = q.b[b * CO + c];
+    if constexpr (APPLY) { Av[c] = q.A[b * CO + c]; Bv[c] = q.Bc[b * CO + c]; Cv[c] = q.Cc[b * CO + c]; }
+  }
+  float acc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) acc[j] = 0.f;
+  const TS* xb = reinterpret_cast<const TS*>(q.x) + (int64_t)b * q.N * q.xld;
+  const TD* db = reinterpret_cast<const TD*>(q.dout) + (int64_t)b * q.N * q.dld;
+  const int64_t i0 = (int64_t)blockIdx.x * q.chunk;
+  int64_t i1 = i0 + q.chunk;
+  if (i1 > q.N) i1 = q.N;
+  __syncthreads();
+  for (int64_t i = i0 + t; i < i1; i += 512) {
+    float4 xq[2][CIQ], gq[2][COQ];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {      // two voxels in flight per trip
+      const int64_t v = i + u * 256;
+      ok[u] = v < i1;
+      const int64_t vc = ok[u] ? v : i;
+#pragma unroll
+      for (int k = 0; k < CIQ; ++k) xq[u][k] = ld4(xb + vc * q.xld + k * 4);
+#pragma unroll
+      for (int k = 0; k < COQ; ++k) gq[u][k] = ld4(db + vc * q.dld + k * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!ok[u]) continue;
+      float xv[CI], d[CO];
+#pragma unroll
+      for (int k = 0; k < CIQ; ++k) { xv[k * 4] = xq[u][k].x; xv[k * 4 + 1] = xq[u][k].y; xv[k * 4 + 2] = xq[u][k].z; xv[k * 4 + 3] = xq[u][k].w; }
+#pragma unroll
+      for (int k = 0; k < COQ; ++k) { d[k * 4] = gq[u][k].x; d[k * 4 + 1] = gq[u][k].y; d[k * 4 + 2] = gq[u][k].z; d[k * 4 + 3] = gq[u][k].w; }
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        float raw = bias[c];
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) raw = fmaf(xv[ci], wsm[c][ci], raw);
+        float z = fmaf(av[c], raw, bv[c]);
+        float g = d[c];
+        if (q.relu) { g = z > 0.f ? g : 0.f; z = fmaxf(z, 0.f); }
+        if constexpr (APPLY) {
+          const float dr = fmaf(Av[c], g, fmaf(Cv[c], raw, Bv[c]));
+#pragma unroll
+          for (int ci = 0; ci < CI; ++ci) acc[ci * CO + c] = fmaf(xv[ci], dr, acc[ci * CO + c]);
+        } else {
+          acc[c * 3] += g;
+          acc[c * 3 + 1] = fmaf(g, raw, acc[c * 3 + 1]);
+          acc[c * 3 + 2] = fmaf(d[c], z, acc[c * 3 + 2]);
+        }
+      }
+    }
+  }
+  // block sums: four accumulators per packed wave sum (see conv_k1_wgrad_kernel), the four waves added in a fixed order
+  const int wave = t >> 6, lane = t & 63;
+  static_assert(NV % 4 == 0, "k1n: NV must be a multiple of 4");
+  const int sel = classsum4_sel(lane);
+  const bool wr = (lane & 15) == 0;
+#pragma unroll
+  for (int j = 0; j < NV; j += 4) {
+    const float sv = wave_classsum4_f<1>(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+    if (wr) red[wave][j + sel] = sv;
+  }
+  __syncthreads();
+  const int64_t row = (int64_t)b * gridDim.x + blockIdx.x;
+  for (int j = t; j < NV; j += 256) {
+    if constexpr (APPLY) q.partial[row * NV + j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    else q.sums[row * NV + j] = (double)red[0][j] + (double)red[1][j] + (double)red[2][j] + (double)red[3][j];
+  }
+}
+
+static bool k1n_shape_ok(const n3d_conv_geom* g) {
+  const int64_t N = (int64_t)g->Do * g->Ho * g->Wo;
+  return g->k == 1 && g->stride == 1 && g->pad == 0 && !g->depthwise && (g->Ci == 4 || g->Ci == 8) && (g->Co == 4 || g->Co == 8 || g->Co == 12) &&
+         (g->Ci / 4) * (g->Co / 4) <= 3 && N >= 32768 && N < (1ll << 31);
+}
+static int k1n_chunk(int64_t N) {      // voxels per workgroup: 2048, fewer on the small levels (>= 256 workgroups per sample where possible)
+  int64_t chunk = 2048;
+  while (chunk > 512 && cdiv(N, chunk) < 256) chunk >>= 1;
+  return (int)chunk;
+}
+
+template <bool APPLY, typename TS, typename TD>
+static bool launch_k1n_t(const K1nArgs& q, int Ci, int Co, dim3 grid, hipStream_t s) {
+  if (Ci == 4 && Co == 4) hipLaunchKernelGGL((k1n_bwd_kernel<1, 1, APPLY, TS, TD>), grid, dim3(256), 0, s, q);
+  else if (Ci == 4 && Co == 8) hipLaunchKernelGGL((k1n_bwd_kernel<1, 2, APPLY, TS, TD>), grid, dim3(256), 0, s, q);
+  else if (Ci == 4 && Co == 12) hipLaunchKernelGGL((k1n_bwd_kernel<1, 3, APPLY, TS, TD>), grid, dim3(256), 0, s, q);
+  else if (Ci == 8 && Co == 4) hipLaunchKernelGGL((k1n_bwd_kernel<2, 1, APPLY, TS, TD>), grid, dim3(256), 0, s, q);
+  else return false;
+  return true;
+}
+template <bool APPLY>
+static bool launch_k1n(const K1nArgs& q, int Ci, int Co, int flags, dim3 grid, hipStream_t s) {
+  const bool sb = flags & N3D_SRC_BF16, db = flags & N3D_DST_BF16;
+  if (sb && db) return launch_k1n_t<APPLY, bf16_t, bf16_t>(q, Ci, Co, grid, s);
+  if (sb) return launch_k1n_t<APPLY, bf16_t, float>(q, Ci, Co, grid, s);
+  if (db) return launch_k1n_t<APPLY, float, bf16_t>(q, Ci, Co, grid, s);
+  return launch_k1n_t<APPLY, float, float>(q, Ci, Co, grid, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1684,6 +1823,10 @@ static DwArgs dw_args(const n3d_conv_geom* g, bool data_grad, const float* src, 
   return a;
 }
 
+// extras of n3d_conv_k1_norm_fwd for the 1x1x1 streaming kernel (set around its run_gather call on the calling thread)
+struct K1Norm { const float* oscale; const float* oshift; bool nostore; bool used; };
+static thread_local K1Norm* g_k1_norm = nullptr;
+
 static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
                       int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate,
                       double* stats, void* ws, size_t ws_bytes, void* stream) {
@@ -1730,7 +1873,8 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
     return N3D_ERR_UNSUPPORTED;
   }
   if (k1_shape_ok(g, data_grad)) {
-    const bool fits = !in_gate && !out_gate && sld % 4 == 0 && dld % 4 == 0 && aligned_quad(src, sb16) && aligned_quad(dst, db16) && aligned16(a.wp) &&
+    const bool nostore = g_k1_norm && g_k1_norm->nostore;
+    const bool fits = !in_gate && !out_gate && sld % 4 == 0 && (nostore || (dld % 4 == 0 && aligned_quad(dst, db16))) && aligned_quad(src, sb16) && aligned16(a.wp) &&
                       (!bias || aligned16(bias)) && (!relu_src || (rld % 4 == 0 && aligned_quad(relu_src, db16))) && a.Cdp % 4 == 0 &&
                       !(a.den == 2 && (bias || stats));   // the zero-upsampling form carries neither
     if (fits) {
@@ -1747,6 +1891,8 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
       }
       {
         static const bool nosparse = getenv("N3D_K1_NOSPARSE") != nullptr;   // (A/B knob)
+        q.nostore = 0; q.oscale = q.oshift = nullptr;
+        if (g_k1_norm) { q.nostore = g_k1_norm->nostore ? 1 : 0; q.oscale = g_k1_norm->oscale; q.oshift = g_k1_norm->oshift; g_k1_norm->used = true; if (q.nostore) q.flat = 0; }
         q.sparse = (q.up && (flags & N3D_ACCUMULATE) && !nosparse) ? 1 : 0;
         q.fWs = FastDiv((uint32_t)(a.Wd >> 1)); q.fHs = FastDiv((uint32_t)(a.Hd >> 1));
         if (q.sparse) q.flat = 0;
@@ -1780,6 +1926,64 @@ int n3d_conv_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const floa
   if (int e = check_geom(g, "conv_fwd")) return e;
   N3D_CHECK_ARG(x && w && y && xld >= g->Ci && yld >= g->Co, "conv_fwd: bad pointers/pitches");
   return run_gather(g, false, x, xld, w, bias, y, yld, flags, in_gate, nullptr, 0, nullptr, stats, ws, ws_bytes, stream);
+}
+
+static void fill_job(n3d_final_job* j, const float* partial, const float* pbias, float* dw, float* dbias, int nch, int ntl, int tci, int tco,
+                     int ci_t, int co_t, int Co, int Ci, int taps);
+
+int n3d_conv_k1_norm_ok(const n3d_conv_geom* g) { return g && check_geom(g, "conv_k1_norm_ok") == 0 && k1n_shape_ok(g) && k1_shape_ok(g, false) ? 1 : 0; }
+int n3d_conv_k1_norm_rows(const n3d_conv_geom* g) { return g ? (int)cdiv((int64_t)g->Do * g->Ho * g->Wo, k1n_chunk((int64_t)g->Do * g->Ho * g->Wo)) : 0; }
+
+int n3d_conv_k1_norm_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias, float* y, int64_t yld,
+                         int flags, const float* oscale, const float* oshift, double* stats, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_geom(g, "conv_k1_norm_fwd")) return e;
+  N3D_CHECK_ARG(x && w && xld >= g->Ci && (y ? yld >= g->Co : stats != nullptr), "conv_k1_norm_fwd: bad pointers / pitches (y == NULL needs stats)");
+  N3D_CHECK_ARG((oscale == nullptr) == (oshift == nullptr) && !(stats && oscale), "conv_k1_norm_fwd: oscale and oshift come together, without statistics");
+  if (!n3d_conv_k1_norm_ok(g)) N3D_UNSUPPORTED("conv_k1_norm_fwd: 1x1x1 stride-1 convs with (Ci, Co) in {(4,4), (4,8), (4,12), (8,4)} on >= 32768 voxels");
+  K1Norm nx = {oscale, oshift, y == nullptr, false};
+  g_k1_norm = &nx;
+  const int r = run_gather(g, false, x, xld, w, bias, y, yld, flags | N3D_NO_MFMA, nullptr, nullptr, 0, nullptr, stats, ws, ws_bytes, stream);
+  g_k1_norm = nullptr;
+  if (r) return r;
+  if (!nx.used) N3D_UNSUPPORTED("conv_k1_norm_fwd: the operands do not fit the 1x1x1 streaming kernel (alignment / pitches)");
+  return N3D_OK;
+}
+
+int n3d_conv_k1_norm_bwd_reduce(const n3d_conv_geom* g, const void* x, int64_t xld, const float* w, const float* bias, const void* dout,
+                                int64_t dld, const float* a, const float* b, int flags, double* sums, void* stream) {
+  if (int e = check_geom(g, "conv_k1_norm_bwd_reduce")) return e;
+  N3D_CHECK_ARG(x && w && dout && a && b && sums && xld >= g->Ci && dld >= g->Co && xld % 4 == 0 && dld % 4 == 0, "conv_k1_norm_bwd_reduce: bad args");
+  if (!k1n_shape_ok(g)) N3D_UNSUPPORTED("conv_k1_norm_bwd_reduce: shape");
+  K1nArgs q = {};
+  q.x = x; q.xld = xld; q.dout = dout; q.dld = dld; q.w = w; q.bias = bias; q.a = a; q.b = b; q.sums = sums;
+  q.N = (int64_t)g->Do * g->Ho * g->Wo; q.chunk = k1n_chunk(q.N); q.relu = (flags & N3D_RELU) ? 1 : 0;
+  if (!launch_k1n<false>(q, g->Ci, g->Co, flags, dim3((unsigned)cdiv(q.N, q.chunk), (unsigned)g->B), (hipStream_t)stream)) N3D_UNSUPPORTED("conv_k1_norm_bwd_reduce: channels");
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_conv_k1_norm_bwd_apply_wgrad(const n3d_conv_geom* g, const void* x, int64_t xld, const float* w, const float* bias, const void* dout,
+                                     int64_t dld, const float* a, const float* b, const float* A, const float* Bc, const float* Cc, int flags,
+                                     float* dw, void* ws, size_t ws_bytes, n3d_final_job* deferred, void* stream) {
+  if (deferred) deferred->nchunks = 0;
+  if (int e = check_geom(g, "conv_k1_norm_bwd_apply_wgrad")) return e;
+  N3D_CHECK_ARG(x && w && dout && a && b && A && Bc && Cc && dw && ws && xld >= g->Ci && dld >= g->Co && xld % 4 == 0 && dld % 4 == 0,
+                "conv_k1_norm_bwd_apply_wgrad: bad args");
+  if (!k1n_shape_ok(g)) N3D_UNSUPPORTED("conv_k1_norm_bwd_apply_wgrad: shape");
+  K1nArgs q = {};
+  q.x = x; q.xld = xld; q.dout = dout; q.dld = dld; q.w = w; q.bias = bias; q.a = a; q.b = b; q.A = A; q.Bc = Bc; q.Cc = Cc;
+  q.N = (int64_t)g->Do * g->Ho * g->Wo; q.chunk = k1n_chunk(q.N); q.relu = (flags & N3D_RELU) ? 1 : 0;
+  const int rows = (int)cdiv(q.N, q.chunk), nchunks = rows * g->B;
+  const size_t need = (size_t)nchunks * g->Ci * g->Co * sizeof(float);
+  if (ws_bytes < need) { set_error("conv_k1_norm_bwd_apply_wgrad: workspace too small (%zu < %zu)", ws_bytes, need); return N3D_ERR_WORKSPACE; }
+  q.partial = (float*)ws;
+  if (!launch_k1n<true>(q, g->Ci, g->Co, flags, dim3((unsigned)rows, (unsigned)g->B), (hipStream_t)stream)) N3D_UNSUPPORTED("conv_k1_norm_bwd_apply_wgrad: channels");
+  N3D_LAUNCH_CHECK();
+  // one "tile" holding the whole [Ci][Co] slab per workgroup: ci_t = Ci, co_t = Co (as the 1x1x1 weight-gradient kernel)
+  n3d_final_job job;
+  fill_job(deferred ? deferred : &job, q.partial, nullptr, dw, nullptr, nchunks, 1, 1, 1, g->Ci, g->Co, g->Co, g->Ci, 1);
+  if (!deferred) if (int e = n3d_wgrad_finalize_batch(&job, 1, stream)) return e;
+  return N3D_OK;
 }
 
 int n3d_conv_bwd_data(const n3d_conv_geom* g, const float* dy, int64_t dyld, const float* w, float* dx, int64_t dxld, int flags,

@@ -865,19 +865,21 @@ class NetFn(torch.autograd.Function):
                         p0, s_pre0 = P.seg_forward(pl.pre0, K.as_view(acts[act_index], "x0"))
                         early[k] = (p0, s_pre0, sf.side_signal())
 
+        # the net input needs no gradient (the usual case): a stem may run without storing its raw conv output (P.recompute_ok)
+        rc = not ctx.needs_input_grad[1]
         if sf is not None:
             # the two stems are independent chains (conv, coefficients, epilogue): one of them on the side stream
             f = sf.fork()
             with sf.side(f), K.storage(nplan.stem_dt):
-                s1, st1 = P.seg_forward(nplan.stem1, xv)
+                s1, st1 = P.seg_forward(nplan.stem1, xv, recompute=rc)
                 tok1 = sf.side_signal()
             with K.storage(nplan.stem_dt):
-                s0, st0 = P.seg_forward(nplan.stem0, xv)
+                s0, st0 = P.seg_forward(nplan.stem0, xv, recompute=rc)
             sf.join(tok1)
         else:
             with K.storage(nplan.stem_dt):
-                s0, st0 = P.seg_forward(nplan.stem0, xv)
-                s1, st1 = P.seg_forward(nplan.stem1, xv)
+                s0, st0 = P.seg_forward(nplan.stem0, xv, recompute=rc)
+                s1, st1 = P.seg_forward(nplan.stem1, xv, recompute=rc)
         acts, states = [s0.t, s1.t], []
         spawn_pre0(0)
         spawn_pre0(1)

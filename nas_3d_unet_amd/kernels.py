@@ -497,6 +497,53 @@ def conv_bwd_weight(g, x: View, dy: View, dw, dbias, flags=0, in_gate=None, tran
         _ctx.keep.append(ws)  # the partial slabs live in ws until StepContext.flush_final()
 
 
+# ---- "weight_norm" 1x1x1 conv without its raw output (include/n3d.h: n3d_conv_k1_norm_*; programs._seg_forward_recompute) ----------
+def conv_k1_norm_ok(g):
+    return bool(_lib.load().n3d_conv_k1_norm_ok(C.byref(g)))
+
+
+def conv_k1_norm_fwd(g, x: View, w, bias, y, oscale=None, oshift=None, stats=None):
+    """y None: statistics of raw = W x + bias only (nothing stored); else y = oscale * raw + oshift in one pass over x"""
+    flags = (_lib.SRC_BF16 if x.dt == _lib.BF16 else 0) | (_lib.DST_BF16 if (y is not None and y.dt == _lib.BF16) else 0)
+    ws, wsp, n, flags = _packed(w, g, False, flags, x.t.device)
+    check(_lib.load().n3d_conv_k1_norm_fwd(C.byref(g), x.p, x.ld, ptr(w), ptr(bias), y.p if y is not None else None, y.ld if y is not None else 0,
+                                           flags, ptr(oscale), ptr(oshift), ptr(stats), wsp, n, stream_ptr()), "n3d_conv_k1_norm_fwd")
+
+
+def conv_k1_norm_bwd_reduce(g, x: View, w, bias, dout: View, a, b, relu=False):
+    """-> (sums, rows): the rows n3d_gn_bwd_coeffs reads, with raw recomputed from x"""
+    lib = _lib.load()
+    rows = int(lib.n3d_conv_k1_norm_rows(C.byref(g)))
+    sums = torch.empty((x.B, rows, g.Co, 3), dtype=torch.float64, device=x.t.device)
+    flags = _cflags(RELU if relu else 0, x, dout)
+    check(lib.n3d_conv_k1_norm_bwd_reduce(C.byref(g), x.p, x.ld, ptr(w), ptr(bias), dout.p, dout.ld, ptr(a), ptr(b), flags, ptr(sums), stream_ptr()),
+          "n3d_conv_k1_norm_bwd_reduce")
+    return sums, rows
+
+
+def conv_k1_norm_bwd_apply_wgrad(g, x: View, w, bias, dout: View, a, b, A, Bc, Cc_, dw, relu=False):
+    """d(raw) in registers -> weight-gradient slabs (a weight-gradient launch like conv_bwd_weight: deferred reduction, queued for the
+    side stream while the side-stream schedule is collecting)"""
+    lib = _lib.load()
+    flags = _cflags(RELU if relu else 0, x, dout)
+    n = int(lib.n3d_conv_k1_norm_rows(C.byref(g))) * x.B * g.Ci * g.Co * 4     # one [Ci][Co] slab per workgroup
+    ws = torch.empty(max(n, 256), dtype=torch.uint8, device=x.t.device)
+    job = FinalJob() if _ctx is not None else None
+    jp = C.byref(job) if job is not None else None
+
+    def launch(sp):
+        check(lib.n3d_conv_k1_norm_bwd_apply_wgrad(C.byref(g), x.p, x.ld, ptr(w), ptr(bias), dout.p, dout.ld, ptr(a), ptr(b), ptr(A), ptr(Bc), ptr(Cc_),
+                                                   flags, ptr(dw), ptr(ws), n, jp, sp), "n3d_conv_k1_norm_bwd_apply_wgrad")
+
+    if job is not None and _ctx.defer_wgrad:
+        _ctx.wq.append((launch, job, ws, (x.t, dout.t, a, b, A, Bc, Cc_, dw, w, bias)))
+        return
+    launch(stream_ptr())
+    if job is not None and job.nchunks > 0:
+        _ctx.final.append(job)
+        _ctx.keep.append(ws)
+
+
 def conv_fwd2(calls):
     """Two forward convs, one launch where libn3d can fold them.  calls = [(g, x, w, bias, y, flags, in_gate, stats, transposed)] * 2"""
     cs, keep = [], []

@@ -541,8 +541,63 @@ def _wptr(alpha_row, k):
     return C.c_void_p(alpha_row.data_ptr() + 4 * k)
 
 
-def seg_forward(seg, x, drop_gate=None, out=None, accumulate=False, alpha_row=None, alpha_k=0):
-    """Run one segment.  x/out: kernels.View.  Returns (out_view, saved)."""
+RECOMPUTE_K1 = __import__("os").environ.get("N3D_K1_RECOMPUTE", "1") != "0"
+
+
+def recompute_ok(seg, x):
+    """can this segment run WITHOUT storing its raw conv output (include/n3d.h, n3d_conv_k1_norm_*)?  A 'weight_norm' 1x1x1 conv with
+    4 (8) input channels on a large volume: stem0.  The caller must not need the op's input gradient."""
+    w = seg.weight
+    if not (RECOMPUTE_K1 and isinstance(w, DenseConvW) and w.k == 1 and w.stride == 1 and not w.transposed and seg.norm is not None
+            and not seg.relu_in and not seg.relu_out and seg.se_gate is None and seg.dropout is None and x.C % 4 == 0):
+        return False
+    return K.conv_k1_norm_ok(w.geom(x))
+
+
+def _seg_forward_recompute(seg, x, out=None):
+    """the segment as statistics pass -> coefficients -> conv + normalise pass: the raw tensor is never written"""
+    w = seg.weight
+    g = w.geom(x)
+    Co = g.Co
+    rows = K.conv_stats_rows(g, False, _lib_flags_src(x))
+    stats = torch.empty((x.B, rows, Co, 2), dtype=torch.float64, device=x.t.device)
+    K.conv_k1_norm_fwd(g, x, w.m.weight, w.m.bias, None, None, None, stats)
+    G = group_count(Co)
+    s = Saved()
+    s.kind, s.G, s.raw, s.ws = "gn_rc", G, None, None
+    s.x, s.g = x, g
+    s.a, s.b, s.mr, s.sumraw = K.gn_coeffs(stats, rows, seg.norm.weight, seg.norm.bias, x.B, Co, G, g.Do * g.Ho * g.Wo, seg.norm.eps)
+    if out is None:
+        out = K.as_view(K.empty_ndhwc(g.B, Co, g.Do, g.Ho, g.Wo, x.t.device))
+    K.conv_k1_norm_fwd(g, x, w.m.weight, w.m.bias, out, s.a, s.b, None)
+    return out, s
+
+
+def _lib_flags_src(x):
+    from ._lib import SRC_BF16, BF16
+    return SRC_BF16 if x.dt == BF16 else 0
+
+
+def _seg_backward_recompute(seg, s, dout, need_dx):
+    if need_dx:
+        raise N3DError("a segment run in recompute form has no input gradient (programs.recompute_ok: the caller decides at forward time)")
+    w = seg.weight
+    x, g = s.x, s.g
+    cbias = w.m.bias if w.m.bias.requires_grad else None
+    sums, rows = K.conv_k1_norm_bwd_reduce(g, x, w.m.weight, w.m.bias, dout, s.a, s.b)
+    dgamma, dbeta, A, Bc, Cc, dcb = K.gn_bwd_coeffs(sums, rows, seg.norm.weight, s.mr, None, x.B, g.Co, s.G, g.Do * g.Ho * g.Wo, None,
+                                                    seg.norm.bias, s.sumraw, cbias)
+    dw = K.grad_target(w.m.weight)
+    if dw is not None:
+        K.conv_k1_norm_bwd_apply_wgrad(g, x, w.m.weight, w.m.bias, dout, s.a, s.b, A, Bc, Cc, dw)
+    return None, [dw, dcb, dgamma, dbeta]
+
+
+def seg_forward(seg, x, drop_gate=None, out=None, accumulate=False, alpha_row=None, alpha_k=0, recompute=False):
+    """Run one segment.  x/out: kernels.View.  Returns (out_view, saved).  recompute: the caller does not need the op's input gradient
+    and the raw conv output may stay unwritten where the op qualifies (recompute_ok)."""
+    if recompute and drop_gate is None and not accumulate and alpha_row is None and recompute_ok(seg, x):
+        return _seg_forward_recompute(seg, x, out)
     want_stats = seg.norm is not None and seg.weight.produces_stats
     raw, stats, rows, ws = seg.weight.fwd(x, seg.relu_in, drop_gate, want_stats)
     return _seg_epilogue_forward(seg, raw, stats, rows, ws, out, accumulate, alpha_row, alpha_k)
@@ -996,6 +1051,8 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
     pre_sums = (sums, rows): the reduction pass was already done (K.affine_act_bwd_reduceN over several terms of a node);
     pre_se = (dw1, db1, dw2, db2, A, Bc): so was the SE gate backward (K.se_gate_bwdN); pre_dalpha: so was dalpha of an
     un-normalised primitive (K.plain_dalphaN)."""
+    if s.kind == "gn_rc":
+        return _seg_backward_recompute(seg, s, dout, need_dx)
     wp = _wptr(alpha_row, alpha_k)
     dap = C.c_void_p(dalpha.data_ptr() + 4 * alpha_k) if dalpha is not None else None
     raw = s.raw

@@ -193,3 +193,36 @@ def test_benchmarked_configuration_vs_oracle(schedule):
         ref = float(P[n].detach().double().norm())
         # (Adam moves an element whose gradient is fp32 noise by ~lr per step whatever its sign: see test_trainer_matches_reference_adam)
         assert abs(float(q.detach().double().norm()) - ref) <= 5e-4 * ref + 3e-3, n
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_stem_without_its_raw_output_matches_the_stored_form(storage):
+    """stem0 ('weight_norm' 1x1x1 conv, nas.py:28 / searched.py:69) in recompute form (n3d_conv_k1_norm_*: statistics pass, then conv +
+    normalise in one pass; backward recomputes raw from the 4-channel input and never writes d(raw)) against the ordinary form
+    (raw stored, epilogue passes): same loss, same probabilities (the forward arithmetic is identical), every gradient within the
+    fp32 reduction-order noise (1e-5 of the gradient norm; the stem's own parameters included)"""
+    from nas_3d_unet_amd import programs as P, unet
+    rng = np.random.default_rng(73)
+    x = dev(rng.standard_normal((2, 4, 32, 32, 32)).astype(np.float32))
+    t = dev((rng.uniform(0, 1, (2, 3, 32, 32, 32)) < 0.3).astype(np.float32))
+    res = []
+    for rc in (False, True):
+        prev, P.RECOMPUTE_K1 = P.RECOMPUTE_K1, rc
+        try:
+            net, _ = build_net("searched", "G_CONV", 4)
+            unet.set_storage(net, storage)
+            l, p = net.forward_loss(x, t)
+            l.backward()
+            torch.cuda.synchronize()
+            res.append((float(l), p.clone(), {n: q.grad.clone() for n, q in net.named_parameters()}))
+        finally:
+            P.RECOMPUTE_K1 = prev
+    if storage == "fp32":
+        assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    else:   # bf16: the stored form rounds raw to bf16 before it normalises, the recompute form normalises the fp32 value
+        assert abs(res[0][0] - res[1][0]) < 2e-4
+    tot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in res[0][2].values())))
+    tol = 1e-5 if storage == "fp32" else 2e-2
+    for n, g in res[0][2].items():
+        assert float((g - res[1][2][n]).double().norm()) <= tol * tot, n
+    assert any(n.startswith("stem0") for n in res[0][2])
