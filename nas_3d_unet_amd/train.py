@@ -606,21 +606,54 @@ class SideSchedule:
         return SideSchedule._Forward(self)
 
     # -- the side stream's work as a HIP graph captured next to torch's capture of the main stream --------------------------------
+    def close_bucket(self, on_closed):
+        """data parallel, bucketed exchange on device flags: every gradient of a bucket has been LAUNCHED (the backward walk is past
+        the cell that completes it).  The weight-gradient stream takes whatever is still queued, waits for the main stream's flag
+        behind everything launched so far (and the side stream's latest flag), reduces every slab launched so far -- and
+        `on_closed()` then puts the bucket's all-reduce on that stream (eagerly, or as the boundary between two captured segments
+        of the stream).  The chain does not wait for anything here."""
+        self.cut(final=True)
+        i = self.fork()
+        with K.on_side(self.wstream):
+            word = self.wptr()
+            K.sync_wait(self.ptr(8 + i), word, self.ptr(1), False)
+            if self.split and self._side_tok is not None:
+                K.sync_wait(self.ptr(8 + self._side_tok), word, self.ptr(1), False)
+            with K.step_context(self.ctx):
+                self.ctx.finalize_now(len(self.ctx.final))
+        on_closed()
+
+    def split_wstream_capture(self):
+        """end the capture segment of the weight-gradient stream and open the next one (the all-reduce of a closed bucket is
+        launched between the two at replay)"""
+        st = self.wstream
+        self._wsegs.append(K.stream_capture_end(st.cuda_stream))
+        K.stream_capture_begin(st.cuda_stream)
+
     def raw_capture_begin(self):
         """the side stream starts capturing (thread-local mode, like torch's capture of the main stream); launches redirected to it
         while the main stream is being captured land in a graph of their own.  Capture, instantiation and launch go through
         libn3d (n3d_stream_capture_* / n3d_graph_*): the HIP runtime that launches the kernels owns the graphs."""
+        self._wsegs = []
         for st in ([self.stream, self.wstream] if self.split else [self.stream]):
             K.stream_capture_begin(st.cuda_stream)
 
     def raw_capture_end(self):
-        """-> [(executable graph handle, stream)] (replayed with raw_replay, released with raw_destroy)"""
+        """-> [(executable graph handle, stream)] (replayed with raw_replay, released with raw_destroy).  The weight-gradient stream
+        may have been captured in several segments (split_wstream_capture): its entries then come in segment order, and
+        `self.wseg_count` says how many of the returned entries (the last ones) they are."""
         out, err = [], None
+        segs, self._wsegs = self._wsegs, []
         for st in ([self.stream, self.wstream] if self.split else [self.stream]):
             try:
-                out.append((K.stream_capture_end(st.cuda_stream), st))
+                ex = K.stream_capture_end(st.cuda_stream)
+                if st is self.wstream:
+                    out.extend((e, st) for e in segs + [ex])
+                else:
+                    out.append((ex, st))
             except K.N3DError as e:      # end the other stream's capture too before raising
                 err = e
+        self.wseg_count = len(segs) + 1
         if err is not None:
             self.raw_destroy(out)
             raise err
@@ -836,6 +869,8 @@ class Trainer:
         self._side_force = side_wgrad == "force" or (side_wgrad is None and env == "force")
         self._side_explicit = side_wgrad is not None     # an eager trainer (graph=False) takes the side schedule only when asked to
         self._use_side = False
+        self._capturing_side = False
+        self._side_wsegs = 1
         self._side_retired = False   # recover() after a timed-out hand-off: the rest of the run stays on one stream
         self.schedule_times = None   # (plain seconds per step, side seconds per step) measured at capture
         if storage is not None:
@@ -867,13 +902,17 @@ class Trainer:
         self._buckets = self._bucket_plan() if (self.dp_path and self.n_buckets > 1) else None
         # one bucket = nothing to overlap: the collective is issued from the step's own stream (a hop through a second
         # stream costs two cross-stream waits around a graph launch); N3D_COMM_STREAM=1 restores the hop
-        want_cs = self.dp_path and (self._buckets is not None or os.environ.get("N3D_COMM_STREAM") == "1")
+        # (the bucketed exchange on device flags puts its all-reduces on the weight-gradient stream; the event-tied graph segments --
+        # buckets without a side schedule -- make their comm stream when they first need it: every stream is a hardware queue)
+        want_cs = self.dp_path and os.environ.get("N3D_COMM_STREAM") == "1"
         self._comm_stream = torch.cuda.Stream(device=self.device) if (want_cs and self.device.type == "cuda") else None
         # (a weight-gradient stream of its own lets the side stream run data gradients of the C <= 8 cells inline: fused.SIDE_PAIRS_BWD)
         self.side = SideSchedule(self.device, self.ctx, wgrad_stream=_fused.SIDE_PAIRS_BWD) if (self.side_wgrad and self.device.type == "cuda") else None
         if self.side is not None and self.side.stream is None:
             self.side = None
         self.side = _agree_on_side(self.side, self.device, self.world, self.pg)
+        if self.side is not None and self._buckets is not None:
+            self.side.tail_inline = ()      # every weight-gradient group on ONE stream: a closed bucket's slabs are reduced there
         ranges = [r for _, r in self._buckets] if self._buckets is not None else None
         self.sync = GradSync(self.fp.grad, self.pg, 1, self._comm_stream, ranges, comm, header=self.fp.grad_full)
         if self.world > 1:
@@ -991,7 +1030,7 @@ class Trainer:
         return self._buckets is not None and self._direct_ok()
 
     def _side_ok(self):
-        return self.side is not None and not getattr(self, "_side_retired", False) and self._buckets is None and self._direct_ok()
+        return self.side is not None and not getattr(self, "_side_retired", False) and self._direct_ok()
 
     def check_sync(self):
         """synchronising check (call it at every host-visible point: before a checkpoint is written, at the end of an epoch, before
@@ -1038,7 +1077,30 @@ class Trainer:
         sd = self.side
         sd.begin_pass()
         with sd.forward_mode(), sd.backward_mode(), sd.deferring():
-            return self._pipeline(x, t, cell_hook=_fused.CELL_DONE_HOOK)
+            cut_hook = _fused.CELL_DONE_HOOK          # (the deferring's: a cut of the weight-gradient queue at every cell boundary)
+            if self._buckets is None:
+                return self._pipeline(x, t, cell_hook=cut_hook)
+            # bucketed exchange (data parallel) on device flags: a bucket that the backward walk has completed is closed on the
+            # weight-gradient stream (SideSchedule.close_bucket) and all-reduced THERE, under the rest of the backward; the last
+            # bucket (the head of the flat buffer, with the hand-off flag in front) goes out behind the tail, on the step's stream
+            closes = {k: j for j, (k, _) in enumerate(self._buckets[:-1])}
+
+            def hook(k):
+                cut_hook(k)
+                j = closes.get(k)
+                if j is not None:
+                    sd.close_bucket(lambda: self._bucket_closed(j))
+            return self._pipeline(x, t, cell_hook=hook)
+
+    def _bucket_closed(self, j):
+        """bucket j is complete on the weight-gradient stream: while the streams are being captured the stream's graph is cut here
+        (the all-reduce is launched between the segments at replay), eagerly the all-reduce goes out now"""
+        sd = self.side
+        if self._capturing_side:
+            sd.split_wstream_capture()
+        else:
+            with torch.cuda.stream(sd.wstream):
+                self.sync.reduce_range(j)
 
     def _side_step_eager(self, x, t):
         loss = self._side_pass(x, t)
@@ -1046,8 +1108,17 @@ class Trainer:
         self.side.finish()
         return loss
 
+    def _allreduce_last(self):
+        """bucketed exchange on flags: the buckets closed during the backward walk are on their way (weight-gradient stream, joined
+        by the tail); the last one -- with the hand-off flag in front of it -- goes out here, on the step's stream"""
+        if self.sync.active:
+            K.guard_flag(self.side.ptr(1), self.side.ptr(4), self.fp.grad_full.data_ptr())
+            self.sync.reduce_range(len(self.sync.ranges) - 1)
+
     def _reduce_on_side(self, j):
         """bucket j is complete on the current stream: all-reduce it on the comm stream"""
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.device)
         cs = self._comm_stream
         cs.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cs):
@@ -1076,13 +1147,16 @@ class Trainer:
         with device-side waits, and anything that makes the HOST wait for the device in the middle of a pass (the caching allocator
         returning memory to the driver when a new shape does not fit its cache, for one) leaves those waits spinning until their
         time-out; a replayed graph allocates nothing, an eager pass on a shape seen for the first time may."""
-        if self.dp_path and self._pipeline_ok(x):
+        if self.dp_path and self._pipeline_ok(x) and not (allow_side and self._side_ok() and (self._side_explicit or self.use_graph)):
             loss = self._pipeline(x, t, self._reduce_on_side)
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         elif allow_side and self._side_ok() and (self._side_explicit or self.use_graph):
             loss = self._side_step_eager(x, t)
             if self.dp_path:
-                self._allreduce()
+                if self._buckets is not None:
+                    self._allreduce_last()
+                else:
+                    self._allreduce()
         else:
             loss = self._fwd_bwd(x, t)
             if self.dp_path:
@@ -1134,11 +1208,28 @@ class Trainer:
         # (the side graph goes first: its device-side waits are then in place when the main chain reaches its cuts, also when the
         # host is slower at launching than the GPU at running, e.g. under a profiler)
         g_main, side_exec, g_tail = self._side_graphs
-        self.side.raw_replay(side_exec)
+        nseg = self._side_wsegs
+        if nseg <= 1:
+            self.side.raw_replay(side_exec)
+            g_main.replay()
+            g_tail.replay()
+            if self.dp_path and exchange:
+                self._allreduce()
+                self._update(self._side_loss)
+            return
+        # bucketed exchange on flags: the weight-gradient stream's graph comes in segments, bucket j's all-reduce between segment j
+        # and j + 1 on that stream (no host-side dependency: the segments wait for the chain's flags on the device)
+        head, wsegs = side_exec[:-nseg], side_exec[-nseg:]
+        self.side.raw_replay(head + wsegs[:1])
         g_main.replay()
+        for j in range(1, nseg):
+            if exchange:
+                with torch.cuda.stream(self.side.wstream):
+                    self.sync.reduce_range(j - 1)
+            self.side.raw_replay(wsegs[j:j + 1])
         g_tail.replay()
-        if self.dp_path and exchange:
-            self._allreduce()
+        if exchange:
+            self._allreduce_last()
             self._update(self._side_loss)
 
     def _replay_plain(self, exchange=True):
@@ -1206,8 +1297,8 @@ class Trainer:
     def _capture_impl(self, x, t):
         self._static_x = x.clone()
         self._static_t = t.clone()
-        segmented = self.dp_path and self._pipeline_ok(x)
-        sided = not segmented and self._side_ok()
+        sided = self._side_ok()
+        segmented = self.dp_path and self._pipeline_ok(x) and not sided      # (buckets without a side stream: event-tied graph segments)
         # warm-up on a side stream (allocator + lazy module state); no optimizer launch, the weights stay as they are
         s = capture_stream(self.device)
         s.wait_stream(torch.cuda.current_stream())
@@ -1251,6 +1342,7 @@ class Trainer:
         g_main, g_tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         sd.raw_capture_begin()
+        self._capturing_side = True
         try:
             with torch.cuda.stream(s):
                 g_main.capture_begin(pool=pool, capture_error_mode="thread_local")
@@ -1258,6 +1350,7 @@ class Trainer:
                 g_main.capture_end()
             sd.launch_side(redirect=True)
         finally:
+            self._capturing_side = False
             side_exec = sd.raw_capture_end()
         with torch.cuda.stream(s):
             g_tail.capture_begin(pool=pool, capture_error_mode="thread_local")
@@ -1268,6 +1361,7 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._side_graphs = (g_main, side_exec, g_tail)
+        self._side_wsegs = sd.wseg_count
 
     def _capture_segments(self, s):
         """one HIP graph per gradient bucket: the capture is closed and the next one opened inside the backward walk, at the

@@ -51,7 +51,7 @@ def test_trainer_dp_schedules_match_single_gpu(one_rank_group, graph, buckets, c
         # tools/chaos_probe.py, profiles/r04_chaos_probe.log; tests/test_gpu_side.py compares the schedules themselves)
         # (graph, one bucket: both trainers are PINNED to the side schedule -- left to themselves each would pick by its own
         # wall-clock timing, and the comparison below is bit for bit)
-        sched = False if (graph and buckets > 1) else ("force" if graph else None)
+        sched = "force" if graph else (True if buckets > 1 else None)
         ref = Trainer(net, graph=graph, side_wgrad=sched)
         assert not ref.dp_path
         lr_, wr = _losses_and_weights(ref, x, t)
@@ -62,8 +62,34 @@ def test_trainer_dp_schedules_match_single_gpu(one_rank_group, graph, buckets, c
     assert tr.dp_path and len(tr.sync.ranges) == buckets and (comm != "rccl" or tr.sync._comm is not None)
     l, w = _losses_and_weights(tr, x, t)
     assert ref._use_side == tr._use_side or buckets > 1
-    if graph and buckets > 1:
-        assert tr._segments is not None and len(tr._segments) == buckets
+    if buckets > 1:
+        # the bucketed exchange rides on the side-stream schedule: bucket j's all-reduce on the weight-gradient stream, tied to the chain
+        # by device flags (graph: the stream's graph comes in `buckets` segments with the all-reduces launched between them)
+        assert tr.side is not None and tr._segments is None
+        if graph:
+            assert tr._use_side and tr._side_wsegs == buckets
+    assert l == lr_ and torch.equal(w, wr)
+
+
+@pytest.mark.parametrize("buckets", [2, 3])
+def test_bucketed_exchange_without_a_side_stream_uses_graph_segments(one_rank_group, buckets):
+    """side_wgrad=False: no device-flag schedule -- the bucketed exchange falls back to one HIP graph per bucket, tied to the comm
+    stream by events (the round-2 form); same weights as the plain single-stream trainer, bit for bit"""
+    from nas_3d_unet_amd.train import Trainer
+    rng = np.random.default_rng(41)
+    x = dev(rng.standard_normal((2, 4, 32, 32, 32)).astype(np.float32))
+    t = dev((rng.uniform(0, 1, (2, 3, 32, 32, 32)) < 0.3).astype(np.float32))
+    os.environ.pop("N3D_FORCE_DP")
+    try:
+        net, _ = build_net("searched", "G_CONV", 4)
+        ref = Trainer(net, graph=True, side_wgrad=False)
+        lr_, wr = _losses_and_weights(ref, x, t)
+    finally:
+        os.environ["N3D_FORCE_DP"] = "1"
+    net, _ = build_net("searched", "G_CONV", 4)
+    tr = Trainer(net, graph=True, n_buckets=buckets, side_wgrad=False)
+    l, w = _losses_and_weights(tr, x, t)
+    assert tr._segments is not None and len(tr._segments) == buckets
     assert l == lr_ and torch.equal(w, wr)
 
 
@@ -195,7 +221,7 @@ def test_two_processes_on_one_gpu_equal_the_global_batch(tmp_path, graph, bucket
         # tools/chaos_probe.py, profiles/r04_chaos_probe.log; tests/test_gpu_side.py compares the schedules themselves)
         # (graph, one bucket: both trainers are PINNED to the side schedule -- left to themselves each would pick by its own
         # wall-clock timing, and the comparison below is bit for bit)
-        sched = False if (graph and buckets > 1) else ("force" if graph else None)
+        sched = "force" if graph else (True if buckets > 1 else None)
         ref = Trainer(net, graph=graph, side_wgrad=sched)
         lr_ = [float(ref.step(dev(xs), dev(ts))) for _ in range(3)]
         wr = ref.fp.flat.detach().cpu()
@@ -206,3 +232,25 @@ def test_two_processes_on_one_gpu_equal_the_global_batch(tmp_path, graph, bucket
     np.testing.assert_allclose([(a + b) / 2 for a, b in zip(r0["losses"], r1["losses"])], lr_, rtol=0, atol=5e-6)
     scale = float(wr.abs().max())
     assert float((r0["flat"] - wr).abs().max()) <= 2e-5 * scale, float((r0["flat"] - wr).abs().max())
+
+
+def test_bench_on_two_gpus_when_the_node_has_them():
+    """`python bench.py --gpus 2` starts its own ranks (one process per GPU, RCCL over xGMI) and prints ONE JSON line on rank 0.  Skipped
+    on a single-GPU box (this pool); the day a multi-GPU node runs the suite it exercises the real N > 1 path, bucketed exchange
+    included."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29533")
+    env.pop("N3D_FORCE_DP", None)
+    for extra in ([], ["--buckets", "2"]):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
+                              "--no-other-configs", "--no-kernel-table", "--no-roofline"] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["sync_timeouts"] == 0 and d["value"] > 0
+        assert d["config"]["dp_buckets"] == (2 if extra else 1)
