@@ -179,7 +179,7 @@ def _run_forward(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=False):
     planar (searched cells): the node outputs stay dense tensors (kernels.Planar, a 6-D output) instead of channel slices of one
     concatenation buffer -- for the net's LAST cell, whose only reader is the fused head."""
     with K.stats_cache(), K.storage(plan.dt):
-        return _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early, planar and plan.pairs)
+        return _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early, planar)
 
 
 # The last cell's output feeds the head only (nas.py:77-78, searched.py:110-111).  As channel slices of one (B, 3 c) buffer every
@@ -202,7 +202,18 @@ SIDE_BWD = None      # the same object while the backward pass of a supernet may
 SIDE_NODE0_SPLIT = __import__("os").environ.get("N3D_SIDE_NODE0", "main") == "split"   # node 0: both edges on the main stream (one of them on the side stream measured 0.1 ms slower per search step)
 
 
-def _run_forward_side(plan, x0, x1, alpha1, alpha2, sf):
+def _node_buffer(plan, shape, device, planar):
+    """(output object, node Views): one (B, n c) concatenation buffer with the nodes as channel slices, or -- planar, the net's last
+    cell -- the nodes as dense tensors of their own (kernels.Planar)"""
+    cn, nn = plan.c_node, plan.n_nodes
+    if planar:
+        out = K.empty_planar(nn, shape[0], cn, shape[2], shape[3], shape[4], device)
+        return out, out.nodes
+    out = K.as_view(K.empty_ndhwc(shape[0], nn * cn, shape[2], shape[3], shape[4], device))
+    return out, [_slice_view(out, k, cn) for k in range(nn)]
+
+
+def _run_forward_side(plan, x0, x1, alpha1, alpha2, sf, planar=False):
     st = P.Saved()
     x0v, x1v = K.as_view(x0, "x0"), K.as_view(x1, "x1")
     shp = plan.pre1.weight.out_shape(x1v)
@@ -220,8 +231,7 @@ def _run_forward_side(plan, x0, x1, alpha1, alpha2, sf):
     # the node buffer (its shape is that of any term's output)
     seg0, in0 = flat[0][2], xs[flat[0][1]]
     oshp = seg0.weight.out_shape(in0)
-    out = K.as_view(K.empty_ndhwc(oshp[0], nn * cn, oshp[2], oshp[3], oshp[4], in0.t.device))
-    nodes = [_slice_view(out, k, cn) for k in range(nn)]
+    out, nodes = _node_buffer(plan, oshp, in0.t.device, planar)
     xs.extend(nodes)
 
     def args_of(fi):
@@ -307,7 +317,7 @@ def _early_pair_ops(plan):
 
 def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=False):
     if SIDE_FWD is not None and not plan.pairs and _grouping(plan.c_node):
-        return _run_forward_side(plan, x0, x1, alpha1, alpha2, SIDE_FWD)
+        return _run_forward_side(plan, x0, x1, alpha1, alpha2, SIDE_FWD, planar)
     st = P.Saved()
     x0v, x1v = K.as_view(x0, "x0"), K.as_view(x1, "x1")
     # the two preprocess ops (cell.py:47-50) are independent and of one output shape: paired epilogue launch
@@ -348,13 +358,7 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=Fals
             (_, i0, segs0, _, _), (_, i1, segs1, _, _) = plan.edges[2 * node], plan.edges[2 * node + 1]
             seg0, seg1 = segs0[0][0], segs1[0][0]
             if out is None:
-                shp = seg0.weight.out_shape(xs[i0])
-                if planar:
-                    out = K.empty_planar(nn, shp[0], cn, shp[2], shp[3], shp[4], xs[i0].t.device)
-                    nodes = out.nodes
-                else:
-                    out = K.as_view(K.empty_ndhwc(shp[0], nn * cn, shp[2], shp[3], shp[4], xs[i0].t.device))
-                    nodes = [_slice_view(out, k, cn) for k in range(nn)]
+                out, nodes = _node_buffer(plan, seg0.weight.out_shape(xs[i0]), xs[i0].t.device, planar)
                 xs.extend(nodes)
             if node in side_res:
                 e, res_side, tok = side_res[node]
@@ -394,9 +398,7 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=Fals
                 _, idx, seg, col, amat, row = flat[fi]
                 xin = xs[idx]
                 if out is None:
-                    shp = seg.weight.out_shape(xin)
-                    out = K.as_view(K.empty_ndhwc(shp[0], nn * cn, shp[2], shp[3], shp[4], xin.t.device))
-                    nodes = [_slice_view(out, k, cn) for k in range(nn)]
+                    out, nodes = _node_buffer(plan, seg.weight.out_shape(xin), xin.t.device, planar)
                     xs.extend(nodes)
                 arow = (alpha1 if amat == 1 else alpha2)[row] if amat else None
                 args.append((seg, xin, arow, col))

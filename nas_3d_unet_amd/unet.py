@@ -69,7 +69,7 @@ def body(net, x, alphas=None, planar=False):
     plan = getattr(net, "_net_plan", None)
     if not fused.current(plan):      # first call, or an op's norm / dropout / conv was re-assigned since
         plan = net._net_plan = fused.net_plan(net, supernet=alphas is not None)
-    prev, fused.PLANAR_OUT = fused.PLANAR_OUT, bool(planar and fused.PLANAR_LAST and alphas is None)
+    prev, fused.PLANAR_OUT = fused.PLANAR_OUT, bool(planar and fused.PLANAR_LAST)
     try:
         return fused.NetFn.apply(plan, x, *(alphas if alphas is not None else (None,) * 4), *plan.params)
     finally:

@@ -214,3 +214,34 @@ def test_last_cell_node_planar_equals_concatenated(storage, path):
     assert res[0][0] == res[1][0]
     for n in res[0][1]:
         assert torch.equal(res[0][1][n], res[1][1][n]), n
+
+
+def test_supernet_last_cell_node_planar_equals_concatenated():
+    """the supernet's last cell with dense node tensors (a node sums 10-22 weighted primitives into its buffer, cell.py:76-82): loss,
+    alpha gradients and every parameter gradient bit-identical to the concatenation buffer"""
+    from nas_3d_unet_amd import fused, nas
+    from _util import fill_module
+    cfg = orc.DEFAULT_CFG._replace(depth=2)
+    rng = np.random.default_rng(79)
+    x = dev(rng.standard_normal((2, 4, 16, 16, 16)).astype(np.float32))
+    t = dev((rng.uniform(0, 1, (2, 3, 16, 16, 16)) < 0.3).astype(np.float32))
+    res = []
+    for planar in (False, True):
+        prev, fused.PLANAR_LAST = fused.PLANAR_LAST, planar
+        try:
+            net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)
+            fill_module(net)
+            net.kernel.last_conv[0].dropout = None
+            net = net.cuda()
+            with torch.no_grad():
+                for a in net.alphas():
+                    a.copy_(torch.from_numpy(np.random.default_rng(3).standard_normal(tuple(a.shape)).astype(np.float32)).cuda())
+            l, _ = net.forward_loss(x, t)
+            l.backward()
+            torch.cuda.synchronize()
+            res.append((float(l), {n: q.grad.clone() for n, q in net.named_parameters() if q.grad is not None}))
+        finally:
+            fused.PLANAR_LAST = prev
+    assert res[0][0] == res[1][0] and res[0][1].keys() == res[1][1].keys()
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
