@@ -497,6 +497,14 @@ def conv_bwd_weight(g, x: View, dy: View, dw, dbias, flags=0, in_gate=None, tran
         _ctx.keep.append(ws)  # the partial slabs live in ws until StepContext.flush_final()
 
 
+def conv_fwd_nol(g, x0: View, x1: View, coef, relu_mask, w, bias, y: View, stats=None):
+    """normalise-on-load probe (include/n3d.h, n3d_conv_fwd_nol): the conv of the node relu?(a0 x0 + b0) + relu?(a1 x1 + b1)"""
+    _need_f32("conv_fwd_nol", x0, x1, y)
+    ws, wsp, n, flags = _packed(w, g, False, 0, x0.t.device)
+    check(_lib.load().n3d_conv_fwd_nol(C.byref(g), x0.p, x0.ld, x1.p, x1.ld, ptr(coef), int(relu_mask), ptr(w), ptr(bias), y.p, y.ld, flags,
+                                       ptr(stats), wsp, n, stream_ptr()), "n3d_conv_fwd_nol")
+
+
 # ---- "weight_norm" 1x1x1 conv without its raw output (include/n3d.h: n3d_conv_k1_norm_*; programs._seg_forward_recompute) ----------
 def conv_k1_norm_ok(g):
     return bool(_lib.load().n3d_conv_k1_norm_ok(C.byref(g)))
