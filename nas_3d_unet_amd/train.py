@@ -337,9 +337,10 @@ class SideSchedule:
         self.replays = 0
         self.watch = None
         # N3D_SIDE_TRACE=1 (tools/side_timeline.py): wall-clock stamps next to every hand-off.  int64 words: [0] main: first cut,
-        # [2 i + 2] main stored flag i, [2 i + 3] side passed wait i, [300] side done, [301] main passed the join, [302] slab
-        # reduction launched behind it
-        self.trace = torch.zeros(2 * self.JOIN + 8, dtype=torch.int64, device=device) if os.environ.get("N3D_SIDE_TRACE") == "1" else None
+        # [2 i + 2] main stored flag i, [2 i + 3] side passed wait i, [2 JOIN + 4] side done, [2 JOIN + 5] main passed the join,
+        # [2 JOIN + 6] slab reduction launched behind it, [2 JOIN + 8 + i] the weight-gradient group behind cut i has been launched through
+        # (its last kernel is done when the stamp executes: group busy time = this minus [2 i + 3])
+        self.trace = torch.zeros(3 * self.JOIN + 16, dtype=torch.int64, device=device) if os.environ.get("N3D_SIDE_TRACE") == "1" else None
         self.stream = self._probe()
         self.wstream = self.stream
         if wgrad_stream and self.stream is not None and os.environ.get("N3D_SIDE_WSTREAM", "1") != "0":
@@ -697,6 +698,8 @@ class SideSchedule:
                     if self.trace is not None:
                         K.stamp(self.trace.data_ptr() + 8 * (2 * i + 3))
                     ctx.flush_wgrads()
+                    if self.trace is not None:
+                        K.stamp(self.trace.data_ptr() + 8 * (2 * self.JOIN + 8 + i))
                     self._live_cuts += 1
                     self._live_cuts_max = max(self._live_cuts_max, self._live_cuts)
                     at = self.early_at if self.early_at >= 0 else (int(round(0.55 * self._live_cuts_max)) if self._live_cuts_max >= 8 else 0)

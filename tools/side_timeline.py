@@ -17,6 +17,7 @@ from nas_3d_unet_amd.train import Trainer
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=64)
 ap.add_argument("--dtype", default="f32")
+ap.add_argument("--raw", default=None, help="also write every non-zero stamp (index, 100 MHz ticks) of the step to this file")
 ap.add_argument("--drop", action="store_true", help="capture the schedule WITHOUT the weight-gradient launches (hand-offs only): main stream free of contention")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -48,10 +49,30 @@ print("searched-net train step, batch 2, 4x%d^3 %s, side-stream schedule (with t
       "%d of them cuts of the backward walk (weight-gradient groups), the rest forks / joins of the net's off-chain pieces" % (args.size, args.dtype, ms, used, len(cuts)))
 print("%4s %12s %14s %10s %12s %10s" % ("flag", "main signal", "side past wait", "side lag", "group ran", "main seg"))
 prev = 0.0
+busy = 0.0
 for k, i in enumerate(cuts):
     m, w = us(st[2 * i + 2]), us(st[2 * i + 3])
-    nxt = us(st[2 * cuts[k + 1] + 3]) if k + 1 < len(cuts) else us(st[2 * J + 4])
-    print("%4d %12.1f %14.1f %10.1f %12s %10.1f" % (i, m, w, w - m, "<= %.1f" % (nxt - w), m - prev))
+    end = st[2 * J + 8 + i]
+    if end:
+        ran = us(end) - w
+        busy += ran
+        txt = "%.1f" % ran
+    else:
+        nxt = us(st[2 * cuts[k + 1] + 3]) if k + 1 < len(cuts) else us(st[2 * J + 4])
+        txt = "<= %.1f" % (nxt - w)
+    print("%4d %12.1f %14.1f %10.1f %12s %10.1f" % (i, m, w, w - m, txt, m - prev))
     prev = m
+span = us(st[2 * J + 6]) if st[2 * J + 6] else us(st[2 * J + 5])
+print("busy fractions over the %.1f us from the first cut to the slab reduction: main stream 1.00 by construction (the dependent chain), "
+      "weight-gradient stream %.2f (%.1f us of kernels in %d groups); over the whole %.0f us step: %.2f"
+      % (span, busy / span if span > 0 else 0.0, busy, len(cuts), ms * 1e3, busy / (ms * 1e3)))
+if args.raw:
+    with open(args.raw, "w") as f:
+        f.write("# raw n3d_stamp dump of one replayed step (100 MHz device clock ticks); index map in train.SideSchedule.__init__: [2i+2] main stored flag i, "
+                "[2i+3] weight-gradient / side stream past its wait on flag i, [%d+i] group behind cut i finished, [%d] side done, [%d] main past the join, [%d] slab reduction launched\n"
+                % (2 * J + 8, 2 * J + 4, 2 * J + 5, 2 * J + 6))
+        for i, v in enumerate(st):
+            if v:
+                f.write("%d %d\n" % (i, int(v)))
 print("side stream done at %.1f us; main stream past the join at %.1f us (main's last cut at %.1f us); slab reduction launched by %.1f us"
       % (us(st[2 * J + 4]), us(st[2 * J + 5]), us(st[2 * cuts[-1] + 2]), us(st[2 * J + 6])))
