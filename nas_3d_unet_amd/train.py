@@ -1067,6 +1067,16 @@ class Trainer:
         if g is not None:
             SideSchedule.raw_destroy(g[1])
 
+    def close(self):
+        """release the raw HIP graphs of the side streams (torch's own graphs and pools go with the object)"""
+        try:
+            self._retire_side_graphs()
+        except Exception:
+            pass
+
+    def __del__(self):
+        self.close()
+
     def _guard(self, loss=None):
         """UpdateGuard of this trainer's optimizer launches (None without a side schedule: nothing can time out)"""
         if self.side is None:
@@ -1538,6 +1548,16 @@ class SearchTrainer:
         gs, self._side_graphs = self._side_graphs, None
         for g in gs or ():
             SideSchedule.raw_destroy(g[1])
+
+    def close(self):
+        """release the raw HIP graphs of the side streams"""
+        try:
+            self._retire_side_graphs()
+        except Exception:
+            pass
+
+    def __del__(self):
+        self.close()
 
     def _update(self, arch, loss=None):
         """exchange (data parallel) + Adam of the pass that just ran; guarded: a timed-out hand-off (on any rank) withholds it"""
