@@ -99,11 +99,13 @@ int n3d_stats_rows(int64_t N, int C);
  * the next conv reads it.  n3d_conv_fwd_nol is n3d_conv_fwd of the 3x3x3 stride-1 C = 4 conv (dilation 1 / 2, the 64^3-level
  * shapes of the vox64 kernel) whose input is that node, NOT materialised: x0 arrives in the LDS halo tile by LDS-DMA as always, x1
  * through registers, the lanes normalise their own slots in place (padding slots stay 0: the zero padding applies to the node).
- * coef: float[B][4][4] = a0, b0, a1, b1 per sample; relu_mask bit 0 / 1 = ReLU on term 0 / 1.  Result bit-identical to
- * n3d_conv_fwd on the materialised node.  Measured, not adopted: profiles/r04_nol_probe.log, DESIGN.md. */
-int n3d_conv_fwd_nol(const n3d_conv_geom* g, const float* x0, int64_t x0ld, const float* x1, int64_t x1ld, const float* coef,
-                     int relu_mask, const float* w, const float* bias, float* y, int64_t yld, int flags, double* stats, void* ws,
-                     size_t ws_bytes, void* stream);
+ * a0, b0, a1, b1: float[B][4] each (the GroupNorm coefficients n3d_gn_coeffs2 writes); relu_mask bit 0 / 1 = ReLU on term 0 / 1.
+ * Result bit-identical to n3d_conv_fwd on the materialised node.  n3d_conv_fwd_nol_ok: does the geometry run on the kernel that has
+ * this form (C = 4, 4-plane tiles)?  profiles/r04_nol_probe.log, DESIGN.md section 5. */
+int n3d_conv_fwd_nol_ok(const n3d_conv_geom* g);
+int n3d_conv_fwd_nol(const n3d_conv_geom* g, const float* x0, int64_t x0ld, const float* x1, int64_t x1ld, const float* a0,
+                     const float* b0, const float* a1, const float* b1, int relu_mask, const float* w, const float* bias, float* y,
+                     int64_t yld, int flags, double* stats, void* ws, size_t ws_bytes, void* stream);
 
 /* Batched weight packing: the conv kernels read weights from a kernel-friendly packed copy.  By default each
  * conv call packs into its workspace (one tiny extra launch); a trainer instead packs ALL weights of the net
@@ -418,7 +420,8 @@ int n3d_dice_bwd(const float* p, int64_t psb, int64_t psc, int64_t psv, const fl
  * n3d_dropout3d_gate: draws the gate on the device: gate[i] = u(seed, counter, i) >= p ? 1/(1-p) : 0 with u =
  *   n3d_dropout3d_uniform (splitmix64, host-callable); state = device uint32[3] {seed_lo, seed_hi, counter}; the launch
  *   increments the counter, so a captured HIP graph draws a new mask on every replay.
- * n3d_head_fwd: p = sigmoid(conv(x * gate) + bias) (logits optionally stored too); with t != NULL also
+ * n3d_head_fwd: p = sigmoid(conv(x * gate) + bias) (logits optionally stored too; p may be NULL when t is given: a training step
+ *   needs the loss and the sums only, and the backward pass recomputes p); with t != NULL also
  *   sums[b][c] = (sum p*t, sum p, sum t) and *loss = 1 - mean_bc (2*sum pt + smooth) / (sum p + sum t + smooth);
  *   partial: double[B][Co][n3d_head_rows(N)][3] scratch.
  * n3d_head_bwd: one pass writes dx (+)= and the weight / bias gradient slabs.  Either dp (gradient w.r.t. p) is given, or

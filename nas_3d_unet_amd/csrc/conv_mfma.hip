@@ -658,8 +658,8 @@ struct VxArgs {
   const void* zero_page; // 16 zero bytes in device memory
   // normalise-on-load (NOL, round-4 probe; n3d_conv_fwd_nol): the conv input is a searched-cell NODE that was never materialised --
   // node = relu?(a0 * src + b0) + relu?(a1 * src2 + b1) per voxel and channel (searched.py:45-50 behind prim_ops.py:68-83), formed in
-  // the LDS tile: src arrives by LDS-DMA as always, src2 through registers; padding slots stay 0.  coef: [B][4][C] = a0, b0, a1, b1
-  const float* src2; int64_t sld2; const float* coef; int nol_relu;   // nol_relu: bit 0 / 1 = ReLU on term 0 / 1
+  // the LDS tile: src arrives by LDS-DMA as always, src2 through registers; padding slots stay 0.  nol_c[4]: a0, b0, a1, b1, each [B][C]
+  const float* src2; int64_t sld2; const float* nol_c[4]; int nol_relu;   // nol_relu: bit 0 / 1 = ReLU on term 0 / 1
 };
 
 // Wq[tap][cd][cs]; forward: cd=co, cs=ci, tap'=tap; data gradient: cd=ci, cs=co, tap'=26-tap
@@ -835,8 +835,8 @@ __global__ __launch_bounds__(64 * NW, VOX_LB) void conv_vox64_kernel(VxArgs a) {
     if constexpr (NOL) {
       // the lane normalises the slots it filled itself, in place (same wave wrote them: vmcnt(0), no barrier); slots outside the
       // volume hold the zero page's 0 and stay untouched -- the conv's zero padding applies to the NODE, not to its raw terms
-      const float4* cf = reinterpret_cast<const float4*>(a.coef) + (int64_t)b * 4;
-      const float4 ca0 = cf[0], cb0 = cf[1], ca1 = cf[2], cb1 = cf[3];
+      const float4 ca0 = reinterpret_cast<const float4*>(a.nol_c[0])[b], cb0 = reinterpret_cast<const float4*>(a.nol_c[1])[b],
+                   ca1 = reinterpret_cast<const float4*>(a.nol_c[2])[b], cb1 = reinterpret_cast<const float4*>(a.nol_c[3])[b];
       const float f0 = (a.nol_relu & 1) ? 0.f : -INFINITY, f1 = (a.nol_relu & 2) ? 0.f : -INFINITY;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -2463,7 +2463,7 @@ int g16_prepare(const n3d_conv_geom* g, bool data_grad, const float* src, int64_
                 void* ws, size_t ws_bytes, hipStream_t s, MfArgs* out, G16Plan* plan);
 
 // extras of n3d_conv_fwd_nol for the vox64 kernel (set around its mfma_conv_try call on the calling thread)
-struct VoxNol { const float* src2; int64_t sld2; const float* coef; int relu; bool used; };
+struct VoxNol { const float* src2; int64_t sld2; const float* c[4]; int relu; bool used; };
 static thread_local VoxNol* g_vox_nol = nullptr;
 
 int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
@@ -2528,10 +2528,12 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
       VxArgs a;
       a.src = src; a.sld = sld; a.dst = dst; a.dld = dld; a.wq = wq; a.bias = bias; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.flags = flags;
       a.stats = stats; a.rows_per_sample = v.tiles * v.nw;
-      a.src2 = nullptr; a.sld2 = 0; a.coef = nullptr; a.nol_relu = 0;
+      a.src2 = nullptr; a.sld2 = 0; a.nol_relu = 0;
+      for (int k = 0; k < 4; ++k) a.nol_c[k] = nullptr;
       if (g_vox_nol) {
-        if (v.C != 4 || v.td != 4 || data_grad || g_vox_nol->sld2 % 4 != 0 || !aligned16(g_vox_nol->src2) || !aligned16(g_vox_nol->coef)) return 0;
-        a.src2 = g_vox_nol->src2; a.sld2 = g_vox_nol->sld2; a.coef = g_vox_nol->coef; a.nol_relu = g_vox_nol->relu; g_vox_nol->used = true;
+        if (v.C != 4 || v.td != 4 || data_grad || g_vox_nol->sld2 % 4 != 0 || !aligned16(g_vox_nol->src2)) return 0;
+        for (int k = 0; k < 4; ++k) { if (!aligned16(g_vox_nol->c[k])) return 0; a.nol_c[k] = g_vox_nol->c[k]; }
+        a.src2 = g_vox_nol->src2; a.sld2 = g_vox_nol->sld2; a.nol_relu = g_vox_nol->relu; g_vox_nol->used = true;
       }
       const int launched = v.C == 4 ? launch_vox_c<4>(a, v, g->B, s) : launch_vox_c<8>(a, v, g->B, s);
       if (!launched) { set_error("conv(vox64): zero page symbol unavailable"); return N3D_ERR_HIP; }
@@ -2990,14 +2992,18 @@ int mfma_bwd_quad_try(BwdOne* c0, BwdOne* c1, hipStream_t s) {
 
 // ---- normalise-on-load probe (include/n3d.h, n3d_conv_fwd_nol) ---------------------------------------------------------------
 using namespace n3d;
-extern "C" int n3d_conv_fwd_nol(const n3d_conv_geom* g, const float* x0, int64_t x0ld, const float* x1, int64_t x1ld, const float* coef,
-                                int relu_mask, const float* w, const float* bias, float* y, int64_t yld, int flags, double* stats, void* ws,
-                                size_t ws_bytes, void* stream) {
-  N3D_CHECK_ARG(g && x0 && x1 && coef && w && y && ws && x0ld >= g->Ci && x1ld >= g->Ci && yld >= g->Co, "conv_fwd_nol: bad args");
+extern "C" int n3d_conv_fwd_nol_ok(const n3d_conv_geom* g) {
+  if (!g) return 0;
   VxPlan v = vx_plan(g);
-  if (!v.ok || v.C != 4 || v.td != 4 || (flags & (N3D_SRC_BF16 | N3D_DST_BF16 | N3D_RELU_IN)))
+  return v.ok && v.C == 4 && v.td == 4 ? 1 : 0;
+}
+extern "C" int n3d_conv_fwd_nol(const n3d_conv_geom* g, const float* x0, int64_t x0ld, const float* x1, int64_t x1ld, const float* a0,
+                                const float* b0, const float* a1, const float* b1, int relu_mask, const float* w, const float* bias, float* y,
+                                int64_t yld, int flags, double* stats, void* ws, size_t ws_bytes, void* stream) {
+  N3D_CHECK_ARG(g && x0 && x1 && a0 && b0 && a1 && b1 && w && y && ws && x0ld >= g->Ci && x1ld >= g->Ci && yld >= g->Co, "conv_fwd_nol: bad args");
+  if (!n3d_conv_fwd_nol_ok(g) || (flags & (N3D_SRC_BF16 | N3D_DST_BF16 | N3D_RELU_IN)))
     N3D_UNSUPPORTED("conv_fwd_nol: the 3x3x3 stride-1 C = 4 conv on 4-plane tiles only (fp32)");
-  VoxNol nx = {x1, x1ld, coef, relu_mask, false};
+  VoxNol nx = {x1, x1ld, {a0, b0, a1, b1}, relu_mask, false};
   g_vox_nol = &nx;
   const int r = mfma_conv_try(g, false, x0, x0ld, w, bias, y, yld, flags, nullptr, nullptr, 0, nullptr, stats, ws, ws_bytes, (hipStream_t)stream);
   g_vox_nol = nullptr;

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
     for (int co = 0; co < HEAD_COMAX; ++co) {
       if (co < a.Co) {
         const float pr = 1.0f / (1.0f + expf(-z[co]));
-        a.p[b * a.psb + co * a.psc + v * a.psv] = pr;
+        if (a.p) a.p[b * a.psb + co * a.psc + v * a.psv] = pr;
         if (a.logits) a.logits[b * a.psb + co * a.psc + v * a.psv] = z[co];
         spt[co] = fmaf(pr, tv[co], spt[co]); sp[co] += pr; st[co] += tv[co];
       }
@@ -377,7 +377,7 @@ size_t n3d_head_workspace_bytes(const n3d_head* h) {
 int n3d_head_fwd(const n3d_head* h, float* p, int64_t psb, int64_t psc, int64_t psv, float* logits, const float* t, int64_t tsb,
                  int64_t tsc, int64_t tsv, float smooth, double* partial, double* sums, float* loss, void* stream) {
   if (int e = check_head(h, "head_fwd")) return e;
-  N3D_CHECK_ARG(p, "head_fwd: no output");
+  N3D_CHECK_ARG(p || t, "head_fwd: no output (p may be NULL only in the Dice mode: the trainers' step needs the loss alone)");
   N3D_CHECK_ARG(!t || (partial && sums && loss), "head_fwd: the Dice mode needs partial / sums / loss");
   HeadFwdArgs a;
   a.x = h->x; a.xld = h->xld; a.N = h->N; a.w = h->w; a.bias = h->bias; a.gate = h->gate;

@@ -293,6 +293,32 @@ SIDE_PAIRS_BOTH = os.environ.get("N3D_SIDE_PAIRS_BOTH", "1") != "0"   # ... and 
 SIDE_PAIRS_BWD = os.environ.get("N3D_SIDE_PAIRS_BWD", "1") != "0"   # ... and the data gradients into one preprocess gradient (needs a third stream)
 
 
+# Normalise-on-load (round 4, SURVEY 7 hard part 3): in a searched cell whose node readers are all 3x3x3 stride-1 C = 4 convs on 4-plane
+# tiles (the last up cell at 2 x 64^3 / 128^3), the epilogue launch of every node but the last leaves the chain -- the coefficient launch
+# stays, the epilogue runs on the side stream (the node is still needed by the head / the backward pass) and the readers form the node
+# in their LDS tile from its two raw terms (n3d_conv_fwd_nol).  The kernel-level probe promised 5-6 us per hand-off
+# (profiles/r04_nol_probe.log); IN the step the form is slower (+0.009 ms at 64^3, +0.04 ms at 128^3, profiles/r04_nol_in_situ_ab.log: the
+# extra issue work of the convs and the flag hand-offs stay on the chain, the epilogue still runs beside it) -- OFF by default, kept behind
+# N3D_NOL=1 with its parity test.
+NOL = os.environ.get("N3D_NOL", "0") != "0"
+
+
+def _nol_nodes(plan, xs):
+    """nodes (indices) of a searched cell whose epilogue may run off the chain: every op that reads them can normalise on load"""
+    if not (NOL and plan.pairs and plan.c_node == 4 and plan.dt == torch.float32):
+        return set()
+    ok = set(range(plan.n_nodes - 1))
+    for node, idx, segs, _, _ in plan.edges:
+        if idx >= 2:
+            seg = segs[0][0]
+            j = idx - 2
+            if not (isinstance(seg.weight, P.DenseConvW) and P.gn_pairable(seg) and not seg.relu_in and seg.weight.nol_ok(xs[idx])):
+                ok.discard(j)
+    # a node nobody reads gains nothing
+    read = {idx - 2 for _, idx, _, _, _ in plan.edges if idx >= 2}
+    return ok & read
+
+
 def _early_pair_ops(plan):
     """{node: edge index} -- for every node of a searched cell at most ONE op that reads a preprocess output (state 0 / 1) and is a plain
     conv: the op the side stream runs ahead of the node chain.  Of two such ops the transposed / strided one goes (the cheaper launch)."""
@@ -360,6 +386,8 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=Fals
             if out is None:
                 out, nodes = _node_buffer(plan, seg0.weight.out_shape(xs[i0]), xs[i0].t.device, planar)
                 xs.extend(nodes)
+                nol_nodes = _nol_nodes(plan, xs) if SIDE_FWD is not None else set()
+            ns = SIDE_FWD if node in nol_nodes else None
             if node in side_res:
                 e, res_side, tok = side_res[node]
                 if e == 2 * node:
@@ -367,7 +395,7 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=Fals
                 else:
                     res0, res1 = P.pair_weight_phase(seg0, xs[i0]), res_side
                 SIDE_FWD.join(tok)
-                s0, s1 = P.pair_epilogue_phase(seg0, res0, seg1, res1, nodes[node])
+                s0, s1 = P.pair_epilogue_phase(seg0, res0, seg1, res1, nodes[node], nol_side=ns)
             elif (SIDE_PAIRS_BOTH and SIDE_FWD is not None and cn <= 8 and isinstance(seg0.weight, P.DenseConvW)
                   and isinstance(seg1.weight, P.DenseConvW) and P.gn_pairable(seg0) and P.gn_pairable(seg1)):
                 # both convs read node outputs: still two launches (no common MFMA problem) -- the cheaper one beside the other
@@ -380,10 +408,18 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=Fals
                 res_b = P.pair_weight_phase(sb_, xs[ib])
                 sf.join(tok)
                 res0, res1 = (res_b, res_a) if cheap1 else (res_a, res_b)
-                s0, s1 = P.pair_epilogue_phase(seg0, res0, seg1, res1, nodes[node])
+                s0, s1 = P.pair_epilogue_phase(seg0, res0, seg1, res1, nodes[node], nol_side=ns)
             else:
-                s0, s1 = P.pair_forward(seg0, xs[i0], seg1, xs[i1], nodes[node])
+                s0, s1 = P.pair_forward(seg0, xs[i0], seg1, xs[i1], nodes[node], nol_side=ns)
             st.saved.extend([s0, s1])
+        # the nodes whose epilogue ran on the side stream are complete behind these joins (the head / the next cell / the backward pass
+        # read the materialised node); from here on nobody normalises on load
+        for s0 in st.saved[::2]:
+            tok = getattr(s0, "nol_tok", None)
+            if tok is not None:
+                SIDE_FWD.join(tok)
+        for nv in nodes:
+            nv.nol = None
         st.xs, st.out = xs, out
         return out.t, st
     # supernet cell (cell.py:76-81): node = sum over its edges of sum_k alpha[e][k] * op_k(x_e), accumulated unit by unit

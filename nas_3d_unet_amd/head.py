@@ -77,11 +77,14 @@ class HeadDiceFn(torch.autograd.Function):
         xv = _feat_view(x)
         if K._bcv_strides(t) is None:
             t = t.contiguous()
-        p, logits, sums, loss = K.head_fwd(xv, w, b, gate, t, smooth, want_logits=KEEP_LOGITS)
+        # (the trainers' autograd-free pipeline sets `skip_p`: a step needs the loss, and the backward pass recomputes p from x)
+        want_p = KEEP_LOGITS or not getattr(ctx, "skip_p", False)
+        p, logits, sums, loss = K.head_fwd(xv, w, b, gate, t, smooth, want_logits=KEEP_LOGITS, want_p=want_p)
         if KEEP_LOGITS:
             last_logits = logits
         ctx.xv, ctx.gate, ctx.w, ctx.b, ctx.t, ctx.sums, ctx.smooth = xv, gate, w, b, t, sums, smooth
-        ctx.mark_non_differentiable(p)
+        if p is not None:
+            ctx.mark_non_differentiable(p)
         return loss, p
 
     @staticmethod

@@ -145,9 +145,11 @@ def _same_dt(what, *views):
 class View:
     """Pitched NDHWC view of a logical (B, C, D, H, W) device tensor (fp32, or bf16 storage: dt = N3D_F32 / N3D_BF16;
     the pitch counts elements)."""
-    __slots__ = ("t", "p", "ld", "B", "C", "D", "H", "W", "N", "dt")
+    __slots__ = ("t", "p", "ld", "B", "C", "D", "H", "W", "N", "dt", "nol")
 
     def __init__(self, t, ld):
+        self.nol = None      # (raw0 View, raw1 View, (a0, b0, a1, b1), relu mask): a searched-cell node whose epilogue runs off the chain -- a
+                             # consumer conv that can normalise on load reads the raw terms instead (programs.DenseConvW.fwd, fused.NOL)
         self.t = t
         self.p = C.c_void_p(t.data_ptr())
         self.ld = int(ld)
@@ -280,6 +282,8 @@ class StepContext:
         self.hold = []         # operands of launched-but-possibly-still-running side work, released by the trainer after the join
         self.keep_jobs = []
         self.final_side = []   # slab-reduction jobs of the launches flush_wgrads issued (the side stream's own)
+        self.final_inline = [] # ... of the groups that went to the OTHER side stream (reduced by the tail only: an early reduction on the
+                               # weight-gradient stream is not ordered behind them)
 
     # ---- weight packing
     def slot(self, w, g, data_grad, flags):
@@ -331,9 +335,9 @@ class StepContext:
             n += 1
         return n
 
-    def flush_wgrads(self, on_mark=None):
+    def flush_wgrads(self, on_mark=None, inline=False):
         """launch every queued weight-gradient kernel on the CURRENT stream, in queue order (the caller orders the stream behind
-        the producers: on_mark(tag) at every mark)"""
+        the producers: on_mark(tag) at every mark).  inline: the stream is not the weight-gradient stream (see final_inline)"""
         q, self.wq = self.wq, []
         n = 0
         for item in q:
@@ -346,7 +350,7 @@ class StepContext:
                 continue
             launch(stream_ptr())
             if job.nchunks > 0:
-                self.final_side.append(job)
+                (self.final_inline if inline else self.final_side).append(job)
             self.hold.append((ws, keep))
             n += 1
         return n
@@ -367,11 +371,11 @@ class StepContext:
         if self.wq:
             self.flush_wgrads()
         self.join()
-        jobs = self.final + self.final_side
+        jobs = self.final + self.final_side + self.final_inline
         if jobs:
             arr = (FinalJob * len(jobs))(*jobs)
             check(_lib.load().n3d_wgrad_finalize_batch(arr, len(jobs), stream_ptr()), "n3d_wgrad_finalize_batch")
-        self.final, self.final_side, self.keep, self.hold, self.keep_jobs = [], [], [], [], []
+        self.final, self.final_side, self.final_inline, self.keep, self.hold, self.keep_jobs = [], [], [], [], [], []
 
 
 _ctx = None
@@ -497,12 +501,18 @@ def conv_bwd_weight(g, x: View, dy: View, dw, dbias, flags=0, in_gate=None, tran
         _ctx.keep.append(ws)  # the partial slabs live in ws until StepContext.flush_final()
 
 
-def conv_fwd_nol(g, x0: View, x1: View, coef, relu_mask, w, bias, y: View, stats=None):
-    """normalise-on-load probe (include/n3d.h, n3d_conv_fwd_nol): the conv of the node relu?(a0 x0 + b0) + relu?(a1 x1 + b1)"""
+def conv_fwd_nol_ok(g):
+    return bool(_lib.load().n3d_conv_fwd_nol_ok(C.byref(g)))
+
+
+def conv_fwd_nol(g, x0: View, x1: View, coefs, relu_mask, w, bias, y: View, stats=None):
+    """normalise-on-load (include/n3d.h, n3d_conv_fwd_nol): the conv of the node relu?(a0 x0 + b0) + relu?(a1 x1 + b1) that was not
+    materialised; coefs = (a0, b0, a1, b1), each (B, C)"""
     _need_f32("conv_fwd_nol", x0, x1, y)
     ws, wsp, n, flags = _packed(w, g, False, 0, x0.t.device)
-    check(_lib.load().n3d_conv_fwd_nol(C.byref(g), x0.p, x0.ld, x1.p, x1.ld, ptr(coef), int(relu_mask), ptr(w), ptr(bias), y.p, y.ld, flags,
-                                       ptr(stats), wsp, n, stream_ptr()), "n3d_conv_fwd_nol")
+    a0, b0, a1, b1 = coefs
+    check(_lib.load().n3d_conv_fwd_nol(C.byref(g), x0.p, x0.ld, x1.p, x1.ld, ptr(a0), ptr(b0), ptr(a1), ptr(b1), int(relu_mask), ptr(w), ptr(bias),
+                                       y.p, y.ld, flags, ptr(stats), wsp, n, stream_ptr()), "n3d_conv_fwd_nol")
 
 
 # ---- "weight_norm" 1x1x1 conv without its raw output (include/n3d.h: n3d_conv_k1_norm_*; programs._seg_forward_recompute) ----------
@@ -815,9 +825,12 @@ def pair_shape_ok(Cc):
     return 4 <= Cc <= 64 and (Cc & (Cc - 1)) == 0
 
 
-def affine_act_gn2(terms, G, eps, out: View, flags=0, out1: View | None = None):
+def affine_act_gn2(terms, G, eps, out: View, flags=0, out1: View | None = None, split=False):
     """Two GroupNorm -> [ReLU] -> weighted-sum epilogues into one output: terms = [(raw, stats, rows, gamma, beta, wptr, relu)] * 2.
-    Returns [(a, b, mean_rstd, sumraw)] * 2 (saved for backward)."""
+    Returns [(a, b, mean_rstd, sumraw)] * 2 (saved for backward).
+    split (large tensors only: coefficient launch + epilogue launch): only the coefficients are launched here; returns (saved, launch)
+    with launch() = the epilogue launch, for the caller to put on another stream (normalise-on-load, fused.NOL) -- or (saved, None) when
+    this shape takes the one-launch form."""
     raw0 = terms[0][0]
     _same_dt("affine_act_gn2", raw0, terms[1][0], out, out1)
     flags |= _aflag(raw0)
@@ -840,11 +853,15 @@ def affine_act_gn2(terms, G, eps, out: View, flags=0, out1: View | None = None):
     if pair_ok(Cc, G, terms[0][2], terms[1][2], B):
         check(lib.n3d_affine_act_gn2(C.byref(ts[0]), C.byref(ts[1]), G, eps, out.p, out.ld, o1p, o1ld, B, raw0.N, Cc, flags,
                                      stream_ptr()), "n3d_affine_act_gn2")
-    else:
-        # large tensors: coefficients of both ops in one launch, then the two-term epilogue
-        check(lib.n3d_gn_coeffs2(C.byref(ts[0]), C.byref(ts[1]), B, Cc, G, raw0.N, eps, stream_ptr()), "n3d_gn_coeffs2")
-        check(lib.n3d_affine_act2(C.byref(ts[0]), C.byref(ts[1]), out.p, out.ld, o1p, o1ld, B, raw0.N, Cc, flags, stream_ptr()),
-              "n3d_affine_act2")
+        return (saved, None) if split else saved
+    # large tensors: coefficients of both ops in one launch, then the two-term epilogue
+    check(lib.n3d_gn_coeffs2(C.byref(ts[0]), C.byref(ts[1]), B, Cc, G, raw0.N, eps, stream_ptr()), "n3d_gn_coeffs2")
+
+    def launch(ts=ts, N=raw0.N):
+        check(lib.n3d_affine_act2(C.byref(ts[0]), C.byref(ts[1]), out.p, out.ld, o1p, o1ld, B, N, Cc, flags, stream_ptr()), "n3d_affine_act2")
+    if split:
+        return saved, launch
+    launch()
     return saved
 
 
@@ -1371,14 +1388,16 @@ def _head_desc(x, w, bias, gate, dx=None):
     return _lib.Head(x.p.value, x.ld, x.dt, x.B, x.C, int(w.shape[0]), x.N, w.data_ptr(), bias.data_ptr(), _vp(gate), 0, 0, 0, 0)
 
 
-def head_fwd(x, w, bias, gate, t=None, smooth=1e-6, want_logits=False):
+def head_fwd(x, w, bias, gate, t=None, smooth=1e-6, want_logits=False, want_p=True):
     """p = sigmoid(conv1x1x1(x * gate) + bias) as a contiguous (B, Co, D, H, W) tensor; with a target t also the Dice sums
     and loss from the same pass.  Returns (p, logits | None, sums | None, loss | None)."""
     lib = _lib.load()
     h = _head_desc(x, w, bias, gate)
     dev = x.t.device
     Co = int(w.shape[0])
-    p = torch.empty((x.B, Co, x.D, x.H, x.W), dtype=torch.float32, device=dev)
+    if not want_p and (t is None or want_logits):
+        raise N3DError("head_fwd: the probabilities can only be skipped in the Dice mode without logits")
+    p = torch.empty((x.B, Co, x.D, x.H, x.W), dtype=torch.float32, device=dev) if want_p else None
     logits = torch.empty_like(p) if want_logits else None
     sums = loss = partial = None
     ts = (0, 0, 0)

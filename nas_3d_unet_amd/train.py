@@ -319,6 +319,10 @@ class SideSchedule:
         # of the groups the fullest pass so far had).  64^3 train step: tail 0.078 -> 0.064 ms, chain +0.001 (n = 11 of 20)
         self.early_at = int(os.environ.get("N3D_SIDE_EARLY_AT", "-1"))
         self.tail_inline = tuple(int(c) for c in os.environ.get("N3D_SIDE_TAIL_INLINE", "2").split(",") if c.strip().isdigit())
+        # every k-th weight-gradient group on the inline side stream (0 = none).  At 4x128^3 the weight-gradient stream is the LONGER one:
+        # 94 % busy during the backward walk, 130-260 us behind every cut, and the join waits 180 us behind the chain's last cut
+        # (profiles/r04_side_timeline_p128_bf16.txt) while the inline side stream idles
+        self.alternate = int(os.environ.get("N3D_SIDE_ALTERNATE", "0"))
         self._live_cuts = 0
         self._live_cuts_max = 0
         self.sync = torch.zeros(8 + self.JOIN + 8, dtype=torch.int32, device=device)
@@ -688,7 +692,8 @@ class SideSchedule:
                 # the weight-gradient stream is backlogged at the end of the walk (the 64^3-level kernels: the join waited ~45 us
                 # behind the chain's last cut, tools/side_timeline.py) while the inline side stream is mostly idle there: the group
                 # tail_inline positions from the end (default: the second to last) goes to that stream instead; 1.865 -> 1.85 ms
-                inline = self.split and self._live_cuts_max >= 8 and (self._live_cuts_max - self._live_cuts) in self.tail_inline
+                inline = self.split and ((self._live_cuts_max >= 8 and (self._live_cuts_max - self._live_cuts) in self.tail_inline)
+                                         or (self.alternate > 0 and self._live_cuts % self.alternate == self.alternate - 1))
                 with K.on_side(self.stream if inline else self.wstream):
                     word = self.ptr(2) if inline else self.wptr()
                     K.sync_wait(self.ptr(8 + i), word, self.ptr(1), False)
@@ -697,7 +702,7 @@ class SideSchedule:
                         K.sync_wait(self.ptr(8 + self._side_tok), word, self.ptr(1), False)
                     if self.trace is not None:
                         K.stamp(self.trace.data_ptr() + 8 * (2 * i + 3))
-                    ctx.flush_wgrads()
+                    ctx.flush_wgrads(inline=inline)
                     if self.trace is not None:
                         K.stamp(self.trace.data_ptr() + 8 * (2 * self.JOIN + 8 + i))
                     self._live_cuts += 1
@@ -915,7 +920,7 @@ class Trainer:
             self.side = None
         self.side = _agree_on_side(self.side, self.device, self.world, self.pg)
         if self.side is not None and self._buckets is not None:
-            self.side.tail_inline = ()      # every weight-gradient group on ONE stream: a closed bucket's slabs are reduced there
+            self.side.tail_inline, self.side.alternate = (), 0      # every weight-gradient group on ONE stream: a closed bucket's slabs are reduced there
         ranges = [r for _, r in self._buckets] if self._buckets is not None else None
         self.sync = GradSync(self.fp.grad, self.pg, 1, self._comm_stream, ranges, comm, header=self.fp.grad_full)
         if self.world > 1:
@@ -1009,6 +1014,7 @@ class Trainer:
                 _fused.PLANAR_OUT = prev_pl
             gate = _P.draw_gate(op.dropout, op.training, *_head.feat_shape(body), body.device)
             hctx = _Ctx((False, False, True, False, True, True))
+            hctx.skip_p = True        # the step returns the loss only: the head does not write the probabilities
             loss, _ = _head.HeadDiceFn.forward(hctx, gate, float(self.loss_fn.smooth), body, t, op.conv.weight, op.conv.bias)
             dbody = _head.HeadDiceFn.backward(hctx, self._one, None)[2]
             prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True

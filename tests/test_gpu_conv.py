@@ -348,7 +348,8 @@ def test_conv_normalising_on_load_equals_conv_of_the_materialised_node(dil, shap
     if K.conv_stats_rows(g, False) <= 0 or shape[0] % 4:
         pytest.skip("not a 4-plane vox64 shape")
     r0, r1 = K.as_view(torch.from_numpy(r0n).to(dev)), K.as_view(torch.from_numpy(r1n).to(dev))
-    w, b, coef = torch.from_numpy(wn).to(dev), torch.from_numpy(bn).to(dev), torch.from_numpy(coefn).to(dev)
+    w, b = torch.from_numpy(wn).to(dev), torch.from_numpy(bn).to(dev)
+    coef = tuple(torch.from_numpy(np.ascontiguousarray(coefn[:, k])).to(dev) for k in range(4))      # a0, b0, a1, b1, each (B, C)
     y = K.as_view(K.empty_ndhwc(B, c, *shape, dev))
     rows = K.conv_stats_rows(g, False)
     stats = torch.zeros((B, rows, c, 2), dtype=torch.float64, device=dev)
@@ -363,7 +364,7 @@ def test_conv_normalising_on_load_equals_conv_of_the_materialised_node(dil, shap
     assert_close(st[..., 0], yr.double().sum(dim=(2, 3, 4)).numpy(), 1e-5, "stats sum")
     # ... and bit for bit against the conv of the node the epilogue arithmetic produces (fmaf, max, add in the kernels' order)
     nd = K.as_view(K.empty_ndhwc(B, c, *shape, dev))
-    a0, b0, a1, b1 = (coef[:, k].contiguous() for k in range(4))
+    a0, b0, a1, b1 = coef
     K.affine_act(r0, a0, b0, None, nd, K.RELU)
     K.affine_act(r1, a1, b1, None, nd, K.RELU | K.ACCUMULATE)
     y2 = K.as_view(K.empty_ndhwc(B, c, *shape, dev))

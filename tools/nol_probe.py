@@ -47,7 +47,7 @@ def case(size, dil, batch=2, planar=True):
     rows = K.conv_stats_rows(g, False)
     stats = torch.empty((batch, rows, c, 2), dtype=torch.float64, device=dev)
     a0, b0, a1, b1 = (torch.randn(batch, c, device=dev) for _ in range(4))
-    coef = torch.stack([a0, b0, a1, b1], dim=1).contiguous()       # [B][4][C]
+    coef = (a0, b0, a1, b1)
     terms = [(raw0, None, 0, None, None, None, True), (raw1, None, 0, None, None, None, True)]
 
     def act2():
