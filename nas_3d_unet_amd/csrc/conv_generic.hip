@@ -555,10 +555,10 @@ static bool k1_shape_ok(const n3d_conv_geom* g, bool data_grad) {
   // register budget: (Cs/4) * (Cd/4) <= 6 covers the nets' shapes (4->12, 12->4, 12->8, 24->4 and their data gradients).  (A 24-channel
   // destination -- the data gradient of the last up cell's 24 -> 4 preprocess conv -- was tried in round 4: with two voxels per thread the
   // kernel spills, +0.47 ms per 128^3 step; with one it is 0.02-0.04 ms slower than the gather kernel it replaces: profiles/r04_128_ab.log)
-  // volume: from 16^3 on (N3D_K1_MIN_N, default 4096).  Round 4: the supernet's pointwise convs at the 16^3 level (8 -> 8 channels, the
-  // second half of its depthwise-separable primitives) took 11.7 us per data gradient on the gather kernel against 5.6 us for the
-  // 32^3 level on this one
-  static const int64_t min_n = [] { const char* e = getenv("N3D_K1_MIN_N"); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : 4096); }();
+  // volume: >= 32768 voxels (N3D_K1_MIN_N).  Round 4 tried 4096 -- the supernet's pointwise convs at the 16^3 level take 11.7 us per data
+  // gradient on the gather kernel against 5.6 us for the 32^3 level here -- and the search step did not move (12.88 vs 12.87 ms: those
+  // launches are off its chain), so the threshold stays where every launch form of a supernet node shares its kernels bit for bit
+  static const int64_t min_n = [] { const char* e = getenv("N3D_K1_MIN_N"); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : 32768); }();
   return Cs % 4 == 0 && Cs >= 4 && Cs <= 24 && Cd % 4 == 0 && Cd >= 4 && Cd <= 12 && (Cs / 4) * (Cd / 4) <= 6 && N >= min_n;
 }
 

@@ -84,6 +84,10 @@ CASES = [
     (24, 4, 1, 1, 1, False, 2, (32, 32, 32)),    # (its data gradient, 4 -> 24, is the widest destination of the streaming kernel)
     (4, 24, 1, 1, 1, False, 1, (32, 32, 40)),
     (12, 8, 1, 2, 1, False, 2, (32, 32, 64)),    # stride 2: its data gradient is the zero-upsampling form of the same kernel
+    (8, 8, 1, 1, 1, False, 2, (16, 16, 16)),     # ... from 16^3 on (round 4): the supernet's pointwise convs of the 16^3 level
+    (12, 8, 1, 1, 1, False, 2, (16, 16, 16)),
+    (8, 8, 1, 1, 1, False, 3, (16, 16, 24)),     # ragged: 6144 voxels, the last workgroup of a sample is partial
+    (8, 4, 1, 1, 1, False, 2, (16, 20, 16)),
     # the stems' 4 -> 12 stride-2 conv (nas.py:29, searched.py:70): weight gradient as Co / 4 column tiles of the 4 -> 4 stride-2 MFMA kernel
     (4, 12, 3, 2, 1, False, 2, (64, 64, 64)),
     (4, 8, 3, 2, 1, False, 2, (32, 64, 64)),
