@@ -1138,6 +1138,13 @@ class Trainer:
         """bucket j is complete on the current stream: all-reduce it on the comm stream"""
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=self.device)
+        if j == len(self.sync.ranges) - 1 and self.sync.active:
+            # the hand-off flag in front of the gradients rides with this (the last) bucket: refresh it -- a trainer that has retired
+            # its side schedule (recover()) must not keep exchanging the 1 of the step that failed
+            if self.side is not None:
+                K.guard_flag(self.side.ptr(1), self.side.ptr(4), self.fp.grad_full.data_ptr())
+            else:
+                self.fp.grad_full[:1].zero_()
         cs = self._comm_stream
         cs.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cs):

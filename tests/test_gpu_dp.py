@@ -93,7 +93,8 @@ def test_bucketed_exchange_without_a_side_stream_uses_graph_segments(one_rank_gr
     assert l == lr_ and torch.equal(w, wr)
 
 
-def test_dp_peer_flag_withholds_the_update_on_every_rank(one_rank_group):
+@pytest.mark.parametrize("buckets", [1, 2])
+def test_dp_peer_flag_withholds_the_update_on_every_rank(one_rank_group, buckets):
     """data parallel: the "a hand-off of this rank timed out" word rides in front of the gradients through the SUM all-reduce, and
     the guarded Adam of EVERY rank tests the sum -- here a 1-rank RCCL group: the flag written before the exchange must still
     withhold the update after it (weights bit-unchanged, loss NaN, next step raises, recover() continues)"""
@@ -103,8 +104,8 @@ def test_dp_peer_flag_withholds_the_update_on_every_rank(one_rank_group):
     x = dev(rng.standard_normal((2, 4, 32, 32, 32)).astype(np.float32))
     t = dev((rng.uniform(0, 1, (2, 3, 32, 32, 32)) < 0.3).astype(np.float32))
     net, _ = build_net("searched", "G_CONV", 4)
-    tr = Trainer(net, graph=True, side_wgrad="force")
-    assert tr.dp_path and tr.side is not None
+    tr = Trainer(net, graph=True, side_wgrad="force", n_buckets=buckets)
+    assert tr.dp_path and tr.side is not None and len(tr.sync.ranges) == buckets
     tr.step(x, t)
     torch.cuda.synchronize()
     assert float(tr.fp.grad_full[0]) == 0.0 and int(tr.fp.step) == 1
@@ -116,10 +117,11 @@ def test_dp_peer_flag_withholds_the_update_on_every_rank(one_rank_group):
     assert torch.isnan(l) and torch.equal(tr.fp.flat, w) and int(tr.fp.step) == 1
     with pytest.raises(K.N3DError, match="timed out"):
         tr.step(x, t)
-    tr.recover()
-    l = tr.step(x, t)
-    torch.cuda.synchronize()
-    assert np.isfinite(float(l)) and int(tr.fp.step) == 2 and float(tr.fp.grad_full[0]) == 0.0
+    tr.recover()       # (buckets > 1: the exchange continues as event-tied graph segments, which refresh the flag themselves)
+    for k in range(2):
+        l = tr.step(x, t)
+        torch.cuda.synchronize()
+        assert np.isfinite(float(l)) and int(tr.fp.step) == 2 + k and float(tr.fp.grad_full[0]) == 0.0
 
 
 def test_search_trainer_dp_matches_single_gpu(one_rank_group):
