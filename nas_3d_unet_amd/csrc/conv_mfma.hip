@@ -1597,6 +1597,7 @@ __device__ __forceinline__ void wait_vmcnt(const int n) {
 // NS buffers, the tiles go in groups of NS that are requested together.  At 64^3 / 32^3 every workgroup of these launches is resident
 // at once (a few hundred of them), so the kernel lasts as long as ONE workgroup's chain of memory round trips, and a tile's MFMAs
 // (0.4 us) are far shorter than a round trip: with NS buffers the chain is a.dchunk / (4 NS) round trips instead of a.dchunk / 4.
+typedef short vw_bf16x4 __attribute__((ext_vector_type(4)));
 template <int C, int DIL, typename T = float, int NS = 0>
 __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
   constexpr bool B16 = sizeof(T) == 2;
@@ -1704,6 +1705,38 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
     const float* yf = tf + NXC * 64 * 4;
     const bf16_t* th = reinterpret_cast<const bf16_t*>(buf);
     const bf16_t* yh = th + NXC * 64 * 8;
+#if !defined(VW_BF16_K1)
+    if constexpr (B16) {
+      // bf16 storage (round 4): v_mfma_f32_4x4x4_16b_bf16 with K = the FOUR ROWS of an output plane.  Block b is still W voxel b; lane
+      // (b, i) holds channel i of that voxel column in rows hh = 0..3 -- four 2-byte LDS reads packed into two registers, no widening
+      // shift -- so one instruction does the work of four 4x4x1 issues.  The fp32-widening form was MFMA-issue bound like the fp32
+      // kernel (SQ_VALU_MFMA_BUSY_CYCLES / SQ_WAVE_CYCLES = 0.89 at (2,4,128^3), 0.96 for fp32) with twice its LDS instructions and 50 %
+      // more VALU: 63 us (d = 1) / 83 us (d = 2) against 59 / 59 for fp32 (profiles/r04_pmc_wgrad.json).
+      auto pack4 = [](const bf16_t* p0, const int stride) {
+        const uint32_t v0 = p0[0], v1 = p0[stride], v2 = p0[2 * stride], v3 = p0[3 * stride];
+        return make_uint2(v0 | (v1 << 16), v2 | (v3 << 16));
+      };
+#pragma unroll
+      for (int g = 0; g < TD; ++g) {
+        uint2 bq[QC], aq[7][QC];
+#pragma unroll
+        for (int qb = 0; qb < QC; ++qb) bq[qb] = pack4(yh + ((g * GH) * GW + blk) * 8 + qb * 4 + i4, GW * 8);
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+          for (int qa = 0; qa < QC; ++qa) aq[t][qa] = pack4(th + (g * PLANE) * EPS + toff[t] + qa * 4, LW * EPS);
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+          for (int qa = 0; qa < QC; ++qa)
+#pragma unroll
+            for (int qb = 0; qb < QC; ++qb)
+              acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(vw_bf16x4, aq[t][qa]), __builtin_bit_cast(vw_bf16x4, bq[qb]),
+                                                                      acc[t][qa][qb], 0, 0, 0);
+      }
+      return;
+    }
+#endif
     // ---- 16 rows of 16 voxels: row r = (g, hh) -> output plane d0+g, row h0+hh
 #pragma unroll
     for (int r = 0; r < TD * GH; ++r) {
