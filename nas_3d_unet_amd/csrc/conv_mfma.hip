@@ -1718,6 +1718,7 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
       };
 #pragma unroll
       for (int g = 0; g < TD; ++g) {
+        // (requesting plane g + 1's operands ahead of plane g's MFMAs measured no better: 52.5 vs 50.1 us at (2,4,128^3))
         uint2 bq[QC], aq[7][QC];
 #pragma unroll
         for (int qb = 0; qb < QC; ++qb) bq[qb] = pack4(yh + ((g * GH) * GW + blk) * 8 + qb * 4 + i4, GW * 8);
@@ -1733,6 +1734,40 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
             for (int qb = 0; qb < QC; ++qb)
               acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(vw_bf16x4, aq[t][qa]), __builtin_bit_cast(vw_bf16x4, bq[qb]),
                                                                       acc[t][qa][qb], 0, 0, 0);
+      }
+      return;
+    }
+#endif
+#if !defined(VW_NO_PREFETCH) && !defined(VW_NO_LDS) && !defined(VW_NO_MFMA)
+    if constexpr (!B16) {
+      // fp32: the operands of row r + PF are requested before the MFMAs of row r are issued (three register sets, rotation resolved
+      // by the full unroll).  hipcc's own schedule asked for a row's operands 3 - 7 MFMAs ahead of their use and then sat on
+      // s_waitcnt lgkmcnt(0) (78 VGPRs of the 256 two workgroups per compute unit leave a wave); with two waves per SIMD the LDS
+      // latency was not covered.
+      constexpr int PF = 2, NR = TD * GH;
+      float avs[PF + 1][7][QC], bvs[PF + 1][QC];
+      auto load_row = [&](const int r, float (&av)[7][QC], float (&bv)[QC]) {
+        const int rbase = ((r >> 2) * PLANE + (r & 3) * LW) * EPS;
+#pragma unroll
+        for (int qb = 0; qb < QC; ++qb) bv[qb] = yf[((r * GW + blk) * Q + qb) * 4 + i4];
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+          for (int qa = 0; qa < QC; ++qa) av[t][qa] = tf[qa * NVOX * 4 + rbase + toff[t]];
+      };
+#pragma unroll
+      for (int r = 0; r < PF; ++r) load_row(r, avs[r], bvs[r]);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (r + PF < NR) load_row(r + PF, avs[(r + PF) % (PF + 1)], bvs[(r + PF) % (PF + 1)]);
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+          for (int qa = 0; qa < QC; ++qa)
+#pragma unroll
+            for (int qb = 0; qb < QC; ++qb)
+              acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(avs[r % (PF + 1)][t][qa], bvs[r % (PF + 1)][qb], acc[t][qa][qb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       return;
     }
@@ -1958,6 +1993,63 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
     const float* yf = tf + NXC * 64 * 4;
     const bf16_t* th = reinterpret_cast<const bf16_t*>(wtile + (k & 1) * BUF);
     const bf16_t* yh = th + NXC * 64 * 8;
+    if constexpr (B16 && BY16) {
+      // both images bf16: the four rows of an output plane are K of v_mfma_f32_4x4x4_16b_bf16 (see vox_wgrad_kernel)
+      auto pack4 = [](const bf16_t* p0, const int stride) {
+        const uint32_t v0 = p0[0], v1 = p0[stride], v2 = p0[2 * stride], v3 = p0[3 * stride];
+        return make_uint2(v0 | (v1 << 16), v2 | (v3 << 16));
+      };
+#pragma unroll
+      for (int g = 0; g < TD; ++g) {
+        uint2 bq[QC], aq[7][QC];
+#pragma unroll
+        for (int qb = 0; qb < QC; ++qb) bq[qb] = pack4(yh + ((g * GH) * GW + blk) * 8 + qb * 4 + i4, GW * 8);
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+          for (int qa = 0; qa < QC; ++qa) aq[t][qa] = pack4(th + ((2 * g) * PLANE) * EPS + toff[t] + qa * 4, 2 * RW * EPS);
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+          for (int qa = 0; qa < QC; ++qa)
+#pragma unroll
+            for (int qb = 0; qb < QC; ++qb)
+              acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(vw_bf16x4, aq[t][qa]), __builtin_bit_cast(vw_bf16x4, bq[qb]),
+                                                                      acc[t][qa][qb], 0, 0, 0);
+      }
+      continue;
+    }
+#if !defined(VW_NO_PREFETCH)
+    if constexpr (!B16 && !BY16) {
+      // fp32: operands of row r + 2 requested before the MFMAs of row r (see vox_wgrad_kernel)
+      constexpr int PF = 2, NR = TD * GH;
+      float avs[PF + 1][7][QC], bvs[PF + 1][QC];
+      auto load_row = [&](const int r, float (&av)[7][QC], float (&bv)[QC]) {
+        const int rbase = ((2 * (r >> 2)) * PLANE + (2 * (r & 3)) * RW) * EPS;
+#pragma unroll
+        for (int qb = 0; qb < QC; ++qb) bv[qb] = yf[((r * GW + blk) * QY + qb) * 4 + i4];
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+          for (int qa = 0; qa < QC; ++qa) av[t][qa] = tf[qa * NVOX * 4 + rbase + toff[t]];
+      };
+#pragma unroll
+      for (int r = 0; r < PF; ++r) load_row(r, avs[r], bvs[r]);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (r + PF < NR) load_row(r + PF, avs[(r + PF) % (PF + 1)], bvs[(r + PF) % (PF + 1)]);
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+          for (int qa = 0; qa < QC; ++qa)
+#pragma unroll
+            for (int qb = 0; qb < QC; ++qb)
+              acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(avs[r % (PF + 1)][t][qa], bvs[r % (PF + 1)][qb], acc[t][qa][qb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      continue;
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < TD * GH; ++r) {
       const int g = r >> 2, hh = r & 3;
