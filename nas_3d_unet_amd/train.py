@@ -513,12 +513,18 @@ class SideSchedule:
         """inside side(): store a flag behind the side stream's launches so far; returns its id"""
         i = self._flag()
         K.sync_signal(self.ptr(8 + i), self.ptr(2), False)
+        if self.trace is not None:
+            K.stamp(self.trace.data_ptr() + 8 * (2 * i + 2))      # (a join flag: the side stream stored it ...)
         self._side_tok = i
         return i
 
     def join(self, i):
         """main stream: wait for a flag of the side stream"""
+        if self.trace is not None:
+            K.stamp(self.trace.data_ptr() + 8 * (2 * self.JOIN + 8 + i))   # (... the main stream arrived at its wait ...)
         K.sync_wait(self.ptr(8 + i), self.ptr(0), self.ptr(1), False)
+        if self.trace is not None:
+            K.stamp(self.trace.data_ptr() + 8 * (2 * i + 3))      # (... and got past it)
 
     class _ArenaMode:
         """every tensor created inside (on the calling thread) is held in owner.arena until finish()"""

@@ -33,6 +33,21 @@ for name, (g_main, g_side, g_tail) in zip(("architecture pass", "weight pass"), 
     t0 = min(int(st[2 * i + 2]) for i in flags)
     us = lambda v: (int(v) - t0) / 100.0
     print("== %s: main graph %.3f ms + tail %.3f ms; %d stamped hand-offs" % (name, e0.elapsed_time(e1), e1.elapsed_time(e2), len(flags)))
+    # joins of the inline side stream (forward / backward off-chain edges): [2i+2] side stored the flag, [2J+8+i] main arrived, [2i+3] main past
+    joins = [i for i in flags if st[2 * J + 8 + i] != 0 and st[2 * J + 8 + i] <= st[2 * i + 3] and st[2 * i + 2] <= st[2 * i + 3] and (st[2 * i + 3] - st[2 * J + 8 + i]) < 10**6]
+    joins = [i for i in joins if abs(int(st[2 * i + 3]) - int(st[2 * J + 8 + i])) >= 0 and i not in getattr(sd, "_cut_ids", ())]
+    waited = 0.0
+    rows = []
+    for i in sorted(joins, key=lambda i: st[2 * J + 8 + i]):
+        arr, sig, past = us(st[2 * J + 8 + i]), us(st[2 * i + 2]), us(st[2 * i + 3])
+        if sig > past: continue     # a cut (main signals, the other stream waits): listed below
+        rows.append((i, arr, sig, past)); waited += past - arr
+    if rows:
+        print("joins (main waits for the inline side stream): %d, main spent %.1f us at them in total (a pass-through wait costs ~2 us)" % (len(rows), waited))
+        print("%4s %12s %12s %12s %10s %12s" % ("flag", "main arrived", "side stored", "main past", "main wait", "side late by"))
+        for i, arr, sig, past in rows:
+            print("%4d %12.1f %12.1f %12.1f %10.1f %12.1f" % (i, arr, sig, past, past - arr, max(0.0, sig - arr)))
+    flags = [i for i in flags if i not in {r[0] for r in rows}]
     print("%4s %12s %14s %10s %12s" % ("flag", "main signal", "other past wait", "lag", "group ran"))
     busy = 0.0
     for i in sorted(flags, key=lambda i: st[2 * i + 2]):
