@@ -6,6 +6,8 @@
 #   side_timeline*.txt + side_stamps*.txt   timeline of the three-stream schedule from device clock stamps, the raw stamp dump, busy fractions
 #   schedules.log                  side schedule off / auto / forced, 1-rank RCCL group with 1 / 2 / 3 buckets (tools/collect_schedules.sh)
 #   nol_probe.log, conv_ab.log     the normalise-on-load probe; forward / data-gradient timing of the C in {4, 8} convs on dense tensors
+#   search_timeline.txt, search_table.log, search_phases.log   the search step: joins / cuts of both passes from device stamps, launch table, phases
+#   pmc_wgrad_*.json + pmc_wgrad.log   PMC of the stride-1 weight-gradient kernel, fp32 and bf16 storage, (2,4,128^3) d = 1 / 2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r04; mkdir -p $O
 python3 bench.py > $O/bench_line.log 2>&1
@@ -27,6 +29,11 @@ python3 bench.py --workload search --steps 10 --warmup 3 > $O/search_bench.log 2
 bash tools/collect_schedules.sh $O > /dev/null 2>&1
 python3 tools/side_timeline.py --raw $O/side_stamps.txt > $O/side_timeline.txt 2>&1
 python3 tools/side_timeline.py --size 128 --dtype bf16 --raw $O/side_stamps_p128_bf16.txt > $O/side_timeline_p128_bf16.txt 2>&1
+python3 tools/side_timeline.py --size 128 > $O/side_timeline_p128_f32.txt 2>&1
+python3 tools/search_timeline.py > $O/search_timeline.txt 2>&1
+python3 tools/search_table.py 70 > $O/search_table.log 2>&1
+python3 tools/search_phases.py > $O/search_phases.log 2>&1
+bash tools/collect_pmc_wgrad.sh > $O/pmc_wgrad.log 2>&1; cp gpurun_out/r04w/pmc_wgrad_*.json $O/ 2>/dev/null
 python3 tools/nol_probe.py > $O/nol_probe.log 2>&1
 python3 tools/conv_ab.py > $O/conv_ab.log 2>&1
 for a in "64" "128" "128 2 bf16"; do python3 tools/table_seq.py $a > "$O/launch_table_seq_$(echo $a | tr ' ' _ | sed 's/_2_/_/').txt" 2>&1; done

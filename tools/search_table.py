@@ -1,5 +1,5 @@
 """Launch table of one supernet search step (eager, one stream): every libn3d call recorded, replay-timed per (entry, shape) group,
-summed by entry and by (entry, shape).  usage: search_table.py [top]"""
+summed by entry and by (entry, shape).  usage: search_table.py [top] [file for the launch-order listing]"""
 import sys, os, collections
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tools"))
@@ -32,6 +32,11 @@ for name, args in rec.calls:
     if us == us:
         by_name[name][0] += 1; by_name[name][1] += us
         by_sig[(name, kernel_table._shape_text(sig)[:120])][0] += 1; by_sig[(name, kernel_table._shape_text(sig)[:120])][1] += us
+if len(sys.argv) > 2:     # the whole step in launch order
+    with open(sys.argv[2], "w") as f:
+        for i, (name, args) in enumerate(rec.calls):
+            sig, _, _ = kernel_table.describe(name, args)
+            f.write("%4d %7.2f  %-30s %s\n" % (i, times[sig], name, kernel_table._shape_text(sig)[:120]))
 tot = sum(v[1] for v in by_name.values())
 print("search step, eager single stream: %d libn3d launches, replay-timed sum %.2f ms" % (len(rec.calls), tot / 1e3))
 print("== by entry point")

@@ -34,8 +34,7 @@ for name, (g_main, g_side, g_tail) in zip(("architecture pass", "weight pass"), 
     us = lambda v: (int(v) - t0) / 100.0
     print("== %s: main graph %.3f ms + tail %.3f ms; %d stamped hand-offs" % (name, e0.elapsed_time(e1), e1.elapsed_time(e2), len(flags)))
     # joins of the inline side stream (forward / backward off-chain edges): [2i+2] side stored the flag, [2J+8+i] main arrived, [2i+3] main past
-    joins = [i for i in flags if st[2 * J + 8 + i] != 0 and st[2 * J + 8 + i] <= st[2 * i + 3] and st[2 * i + 2] <= st[2 * i + 3] and (st[2 * i + 3] - st[2 * J + 8 + i]) < 10**6]
-    joins = [i for i in joins if abs(int(st[2 * i + 3]) - int(st[2 * J + 8 + i])) >= 0 and i not in getattr(sd, "_cut_ids", ())]
+    joins = [i for i in flags if st[2 * J + 8 + i] != 0 and st[2 * J + 8 + i] < st[2 * i + 3]]
     waited = 0.0
     rows = []
     for i in sorted(joins, key=lambda i: st[2 * J + 8 + i]):

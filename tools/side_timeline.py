@@ -42,7 +42,10 @@ tr.check_sync()
 st = tr.side.trace.cpu().numpy().astype("int64")
 J = tr.side.JOIN
 used = int((tr.side.sync[8:8 + J] > 0).sum())
-cuts = [i for i in range(J) if st[2 * i + 2] != 0 and st[2 * i + 3] != 0]     # the stamped hand-offs: the cuts of the backward walk
+# the stamped hand-offs.  A cut of the backward walk: [2i+2] main stored the flag <= [2i+3] the weight-gradient stream got past its wait <= [2J+8+i]
+# its group ended.  A join of the inline side stream: [2i+2] the side stream stored the flag, [2J+8+i] main arrived at its wait < [2i+3] main got past
+is_join = lambda i: st[2 * J + 8 + i] != 0 and st[2 * J + 8 + i] < st[2 * i + 3]
+cuts = [i for i in range(J) if st[2 * i + 2] != 0 and st[2 * i + 3] != 0 and not is_join(i)]
 t0 = int(st[2 * cuts[0] + 2])
 us = lambda v: (int(v) - t0) / 100.0      # 100 MHz clock
 print("searched-net train step, batch 2, 4x%d^3 %s, side-stream schedule (with the stamps' own launches): %.3f ms per step; %d hand-offs per step, "
@@ -62,6 +65,20 @@ for k, i in enumerate(cuts):
         txt = "<= %.1f" % (nxt - w)
     print("%4d %12.1f %14.1f %10.1f %12s %10.1f" % (i, m, w, w - m, txt, m - prev))
     prev = m
+# joins of the inline side stream (off-chain pieces of the net): [2i+2] the side stream stored flag i, [2J+8+i] main arrived at its wait, [2i+3] main past
+rows = []
+for i in range(J):
+    if not (st[2 * i + 2] and st[2 * i + 3] and is_join(i)):
+        continue
+    arr, sig, past = us(st[2 * J + 8 + i]), us(st[2 * i + 2]), us(st[2 * i + 3])
+    if arr <= past and sig <= past:
+        rows.append((arr, i, sig, past))
+if rows:
+    rows.sort()
+    print("joins (main waits for the inline side stream): %d; main spent %.1f us at them in total (a pass-through wait costs ~3 us)" % (len(rows), sum(r[3] - r[0] for r in rows)))
+    print("%4s %12s %12s %12s %10s" % ("flag", "main arrived", "side stored", "main past", "main wait"))
+    for arr, i, sig, past in rows:
+        print("%4d %12.1f %12.1f %12.1f %10.1f" % (i, arr, sig, past, past - arr))
 span = us(st[2 * J + 6]) if st[2 * J + 6] else us(st[2 * J + 5])
 print("busy fractions over the %.1f us from the first cut to the slab reduction: main stream 1.00 by construction (the dependent chain), "
       "weight-gradient stream %.2f (%.1f us of kernels in %d groups); over the whole %.0f us step: %.2f"
