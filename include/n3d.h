@@ -533,6 +533,8 @@ int n3d_sync_signal(void* flag, void* step, int bump, void* stream);
  * kernel trace serialises the two streams, so the timeline of the side-stream schedule is taken with these (tools/side_timeline.py) */
 int n3d_stamp(void* out, void* stream);
 int n3d_sync_wait(const void* flag, void* step, void* timeouts, int bump, int64_t max_polls, void* stream);
+/* the same for TWO flags in one launch (both must have reached *step; one time-out is counted if either has not) */
+int n3d_sync_wait2(const void* flag0, const void* flag1, void* step, void* timeouts, int bump, int64_t max_polls, void* stream);
 /* The side streams and their graphs, made through the HIP runtime libn3d is linked against (the one that launches the kernels):
  * a non-blocking stream of the lowest priority the device offers; thread-local capture of a stream into an instantiated
  * executable graph (the side streams are captured NEXT TO torch's capture of the main stream); launch / destroy. */

@@ -213,6 +213,7 @@ PROTOTYPES = {
     "n3d_graph_destroy": (_i, [_p]),
     "n3d_sync_signal": (_i, [_p, _p, _i, _p]),
     "n3d_sync_wait": (_i, [_p, _p, _p, _i, _i64, _p]),
+    "n3d_sync_wait2": (_i, [_p, _p, _p, _p, _i, _i64, _p]),
     "n3d_stamp": (_i, [_p, _p]),
 }
 

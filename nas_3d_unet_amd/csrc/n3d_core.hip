@@ -37,6 +37,21 @@ __global__ void sync_wait_kernel(const unsigned* flag, unsigned* step, unsigned*
   if (!ok) atomicAdd(timeouts, 1u);
   if (bump) *step = want + 1;
 }
+// two flags, one launch: where a stream has two joins in a row (a cell's own side work and the late writer of one of its gradient
+// buffers) the second wait kernel and its boundary (~3.3 us on the chain) go
+__global__ void sync_wait2_kernel(const unsigned* flag0, const unsigned* flag1, unsigned* step, unsigned* timeouts, int bump, long max_polls) {
+  unsigned want = *step;
+  bool ok0 = false, ok1 = false;
+  for (long it = 0; it < max_polls; ++it) {
+    if (!ok0 && (int)(__hip_atomic_load(flag0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) ok0 = true;
+    if (!ok1 && (int)(__hip_atomic_load(flag1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) ok1 = true;
+    if (ok0 && ok1) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (!(ok0 && ok1)) atomicAdd(timeouts, 1u);
+  if (bump) *step = want + 1;
+}
 __global__ void stamp_kernel(unsigned long long* out) { *out = __builtin_amdgcn_s_memrealtime(); }
 }  // namespace
 
@@ -57,6 +72,14 @@ int n3d_sync_wait(const void* flag, void* step, void* timeouts, int bump, int64_
   N3D_CHECK_ARG(flag && step && timeouts, "n3d_sync_wait: null pointer");
   N3D_CHECK_ARG(max_polls > 0, "n3d_sync_wait: max_polls must be positive (the poll is bounded by construction)");
   hipLaunchKernelGGL(sync_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned*)flag, (unsigned*)step,
+                     (unsigned*)timeouts, bump, (long)max_polls);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+int n3d_sync_wait2(const void* flag0, const void* flag1, void* step, void* timeouts, int bump, int64_t max_polls, void* stream) {
+  N3D_CHECK_ARG(flag0 && flag1 && step && timeouts, "n3d_sync_wait2: null pointer");
+  N3D_CHECK_ARG(max_polls > 0, "n3d_sync_wait2: max_polls must be positive (the poll is bounded by construction)");
+  hipLaunchKernelGGL(sync_wait2_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned*)flag0, (const unsigned*)flag1, (unsigned*)step,
                      (unsigned*)timeouts, bump, (long)max_polls);
   N3D_LAUNCH_CHECK();
   return N3D_OK;

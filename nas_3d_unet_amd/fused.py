@@ -556,7 +556,7 @@ def _run_backward_nodes(plan, st, dnodes, alpha1, alpha2, need_x0, need_x1, want
             if NODE_DONE_HOOK is not None:
                 NODE_DONE_HOOK()
         if side_tok is not None:
-            sb.join(side_tok)
+            late_joins = [side_tok] + list(late_joins)     # joined with the late writers below: two flags per wait launch
         flat = []
     else:
         flat = None
@@ -715,8 +715,8 @@ def _run_backward_nodes(plan, st, dnodes, alpha1, alpha2, need_x0, need_x1, want
         if not pre_started[i]:
             dpre[i].t.zero_()
     (t0, acc0), (t1, acc1) = dx_targets if dx_targets is not None else ((None, False), (None, False))
-    for tok in late_joins:
-        SIDE_BWD.join(tok)
+    if late_joins:
+        SIDE_BWD.join_many(late_joins)
     if (SIDE_BWD is not None and plan.pairs and need_x0 and dx_targets is not None
             and (getattr(st, "pre0_side", False) or SIDE_PRE0_BWD)):
         # searched net: the gradient of a cell's FIRST input -- the skip of an up cell, the output of the cell before the previous

@@ -1365,6 +1365,14 @@ def sync_wait(flag_ptr, step_ptr, timeouts_ptr, bump=False, max_polls=5000000):
                                     stream_ptr()), "n3d_sync_wait")
 
 
+def sync_wait2(flag0_ptr, flag1_ptr, step_ptr, timeouts_ptr, bump=False, max_polls=5000000):
+    """sync_wait on two flags with one launch"""
+    if SYNC_MAX_POLLS[0] is not None:
+        max_polls = SYNC_MAX_POLLS[0]
+    check(_lib.load().n3d_sync_wait2(C.c_void_p(flag0_ptr), C.c_void_p(flag1_ptr), C.c_void_p(step_ptr), C.c_void_p(timeouts_ptr),
+                                     1 if bump else 0, int(max_polls), stream_ptr()), "n3d_sync_wait2")
+
+
 def stamp(ptr_):
     """diagnostic: the current stream stores the 100 MHz wall clock to the device uint64 at `ptr_` when it gets there"""
     check(_lib.load().n3d_stamp(C.c_void_p(ptr_), stream_ptr()), "n3d_stamp")

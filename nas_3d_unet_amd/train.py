@@ -526,6 +526,23 @@ class SideSchedule:
         if self.trace is not None:
             K.stamp(self.trace.data_ptr() + 8 * (2 * i + 3))      # (... and got past it)
 
+    def join_many(self, ids):
+        """main stream: wait for several flags of the side stream -- two per launch (n3d_sync_wait2)"""
+        ids = list(ids)
+        k = 0
+        while k + 1 < len(ids):
+            a, b = ids[k], ids[k + 1]
+            if self.trace is not None:
+                for i in (a, b):
+                    K.stamp(self.trace.data_ptr() + 8 * (2 * self.JOIN + 8 + i))
+            K.sync_wait2(self.ptr(8 + a), self.ptr(8 + b), self.ptr(0), self.ptr(1), False)
+            if self.trace is not None:
+                for i in (a, b):
+                    K.stamp(self.trace.data_ptr() + 8 * (2 * i + 3))
+            k += 2
+        if k < len(ids):
+            self.join(ids[k])
+
     class _ArenaMode:
         """every tensor created inside (on the calling thread) is held in owner.arena until finish()"""
 

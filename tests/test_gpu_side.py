@@ -68,6 +68,44 @@ def test_sync_wait_is_bounded():
         K.sync_wait(p(4), p(0), p(1), False, max_polls=0)
 
 
+def test_sync_wait2_waits_for_both_flags():
+    """n3d_sync_wait2: the stream goes on only when BOTH flags have reached its step; bounded like the single wait"""
+    from nas_3d_unet_amd import kernels as K
+    from nas_3d_unet_amd.train import reserve_side_streams
+    w = _words()
+    p = lambda i: w.data_ptr() + 4 * i
+    a, b, c = reserve_side_streams(torch.device("cuda", torch.cuda.current_device()), 3)[:3]
+    w[3] = 1     # the third stream's step word
+    src0, src1 = torch.zeros(1 << 22, device="cuda"), torch.zeros(1 << 22, device="cuda")
+    dst = torch.zeros(2, 1 << 22, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(c):            # the consumer first: it must hold until both producers have signalled
+        K.sync_wait2(p(4), p(5), p(2), p(1), True)
+        dst[0].copy_(src0)
+        dst[1].copy_(src1)
+    with torch.cuda.stream(a):
+        for _ in range(6):
+            src0.add_(1.0)
+        K.sync_signal(p(4), p(0), True)
+    with torch.cuda.stream(b):
+        for _ in range(9):
+            src1.add_(1.0)
+        K.sync_signal(p(5), p(3), True)
+    torch.cuda.synchronize()
+    assert int(w[1]) == 0, "the two-flag wait timed out"
+    assert float(dst[0].min()) == float(dst[0].max()) == 6.0 and float(dst[1].min()) == float(dst[1].max()) == 9.0
+    # one flag missing: a time-out is counted, the stream goes on
+    w2 = _words()
+    q = lambda i: w2.data_ptr() + 4 * i
+    out = torch.zeros(8, device="cuda")
+    with torch.cuda.stream(c):
+        K.sync_signal(q(4), q(0), False)
+        K.sync_wait2(q(4), q(5), q(0), q(1), False, max_polls=2000)
+        out.fill_(2.0)
+    torch.cuda.synchronize()
+    assert int(w2[1]) == 1 and float(out.sum()) == 16.0
+
+
 def _batch(seed, size=32, batch=2):
     rng = np.random.default_rng(seed)
     x = dev(rng.standard_normal((batch, 4, size, size, size)).astype(np.float32))

@@ -31,7 +31,7 @@ HOST_ONLY = {"n3d_conv_workspace_bytes", "n3d_conv_stats_rows", "n3d_conv_pack_i
 
 # entry points that are never replayed for timing: they change state the step depends on (weights and moments, the dropout
 # generator) or hold a stream until another stream acts (the device-side hand-off); their coarse per-call event time is reported
-NO_REPLAY = {"n3d_adam_step", "n3d_dropout3d_gate", "n3d_sync_wait", "n3d_sync_signal"}
+NO_REPLAY = {"n3d_adam_step", "n3d_dropout3d_gate", "n3d_sync_wait", "n3d_sync_wait2", "n3d_sync_signal"}
 
 
 class Recorder:
