@@ -350,23 +350,26 @@ struct GnBwdCoefArgs {
   float* A; float* Bc; float* Cc; const double* sumraw; float* dbias_conv;
 };
 
+// BP: samples side by side = 256-thread slices of the workgroup (2 for the batch-2 steps of the benchmark configurations: half the
+// waves to launch and to meet at the barriers; 4 for larger batches)
+template <int BP>
 __device__ __forceinline__ void gn_bwd_coeffs_body(const GnBwdCoefArgs q, int B, int C, int G, double count) {
   const double* __restrict__ sums = q.sums; const int rows = q.rows; const float* __restrict__ gamma = q.gamma;
   const float* __restrict__ mean_rstd = q.mean_rstd; const float* __restrict__ wptr = q.wptr;
   float* __restrict__ dgamma = q.dgamma; float* __restrict__ dbeta = q.dbeta; float* __restrict__ dalpha = q.dalpha;
   float* __restrict__ A = q.A; float* __restrict__ Bc = q.Bc; float* __restrict__ Cc = q.Cc;
   const double* __restrict__ sumraw = q.sumraw; float* __restrict__ dbias_conv = q.dbias_conv;
-  __shared__ double part[GNB_BP][256];
-  __shared__ double tot[GNB_BP][192];
-  __shared__ double gc[GNB_BP][64 * 2];
-  __shared__ double acc4[GNB_BP][4][64];  // per-sample dgamma, dbeta, dz, dbias contributions
+  __shared__ double part[BP][256];
+  __shared__ double tot[BP][192];
+  __shared__ double gc[BP][64 * 2];
+  __shared__ double acc4[BP][4][64];  // per-sample dgamma, dbeta, dz, dbias contributions
   const int bl = threadIdx.x >> 8, t = threadIdx.x & 255;
   const int cg = C / G;
   const double w = wptr ? (double)*wptr : 1.0;
   // independent loads first: they overlap the row reductions
   const double gam = (t < C) ? (double)gamma[t] : 0.0;
   double dg = 0, db = 0, dz = 0, dbc = 0;
-  for (int b0 = 0; b0 < B; b0 += GNB_BP) {
+  for (int b0 = 0; b0 < B; b0 += BP) {
     const int b = b0 + bl;
     const bool act = b < B;
     const int bb = act ? b : B - 1;
@@ -405,28 +408,32 @@ __device__ __forceinline__ void gn_bwd_coeffs_body(const GnBwdCoefArgs q, int B,
   __syncthreads();
   if (bl == 0 && t < C) {
     double a0 = 0, a1 = 0, a3 = 0;
-    for (int k = 0; k < GNB_BP; ++k) { a0 += acc4[k][0][t]; a1 += acc4[k][1][t]; a3 += acc4[k][3][t]; }
+    for (int k = 0; k < BP; ++k) { a0 += acc4[k][0][t]; a1 += acc4[k][1][t]; a3 += acc4[k][3][t]; }
     if (dgamma) dgamma[t] = (float)a0;
     if (dbeta) dbeta[t] = (float)a1;
     if (dbias_conv) dbias_conv[t] = (float)a3;
   }
-  if (dalpha && threadIdx.x == 0) {
+  if (dalpha && threadIdx.x < 64) {
+    // (one wave: per-channel totals over the samples, then a butterfly over the 64 lanes -- a fixed tree instead of 64 BP serial adds)
     double sdz = 0;
-    for (int k = 0; k < GNB_BP; ++k)
-      for (int i = 0; i < 64; ++i) sdz += acc4[k][2][i];
-    *dalpha = (float)sdz;
+    for (int k = 0; k < BP; ++k) sdz += acc4[k][2][threadIdx.x];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sdz += __shfl_xor(sdz, o, 64);
+    if (threadIdx.x == 0) *dalpha = (float)sdz;
   }
 }
 // grid (terms): blockIdx.x selects the op
-__global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffs_kernel(GnBwdCoefArgs q0, GnBwdCoefArgs q1, int B, int C, int G, double count) {
+template <int BP>
+__global__ __launch_bounds__(256 * BP) void gn_bwd_coeffs_kernel(GnBwdCoefArgs q0, GnBwdCoefArgs q1, int B, int C, int G, double count) {
   N3D_CHAIN_PRIO();
-  gn_bwd_coeffs_body(blockIdx.x ? q1 : q0, B, C, G, count);
+  gn_bwd_coeffs_body<BP>(blockIdx.x ? q1 : q0, B, C, G, count);
 }
 struct GnBwdCoefArgsN { GnBwdCoefArgs q[8]; };
-__global__ __launch_bounds__(256 * GNB_BP) void gn_bwd_coeffsN_kernel(GnBwdCoefArgsN qs, int B, int C, int G, double count) { N3D_CHAIN_PRIO();
+template <int BP>
+__global__ __launch_bounds__(256 * BP) void gn_bwd_coeffsN_kernel(GnBwdCoefArgsN qs, int B, int C, int G, double count) { N3D_CHAIN_PRIO();
   GnBwdCoefArgs q;
   N3D_PICK8(qs.q, blockIdx.x, q);
-  gn_bwd_coeffs_body(q, B, C, G, count);
+  gn_bwd_coeffs_body<BP>(q, B, C, G, count);
 }
 
 __device__ __forceinline__ void plain_bwd_coeffs_body(const double* __restrict__ sums, int rows, const float* __restrict__ wptr,
@@ -448,10 +455,11 @@ __device__ __forceinline__ void plain_bwd_coeffs_body(const double* __restrict__
   if (dalpha) {
     if (t < 64) zred[t] = (t < C) ? dz : 0.0;
     __syncthreads();
-    if (t == 0) {
-      double s = 0;
-      for (int i = 0; i < 64; ++i) s += zred[i];
-      *dalpha = (float)s;
+    if (t < 64) {
+      double s = zred[t];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (t == 0) *dalpha = (float)s;
     }
   }
 }
@@ -1835,6 +1843,62 @@ __device__ __forceinline__ void se_gate_bwd_body(const double* __restrict__ sums
     }
   }
 }
+// B == 2: the two samples side by side in one 512-thread workgroup (slice bl = tid / 256 takes sample bl): ONE dependent chain rows ->
+// gate gradient -> hidden gradient -> coefficients instead of two in a row; the per-channel sums meet in LDS and are added in
+// sample order, i.e. the same additions in the same order as the loop above (0 + s0 + s1)
+__device__ __forceinline__ void se_gate_bwd_body2(const double* __restrict__ sums, int rows, const float* __restrict__ wptr,
+                                                  const float* __restrict__ mean, const float* __restrict__ hidden,
+                                                  const float* __restrict__ gate, const float* __restrict__ w1,
+                                                  const float* __restrict__ w2, int C, double count, float* __restrict__ dw1,
+                                                  float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2,
+                                                  float* __restrict__ dalpha, float* __restrict__ A, float* __restrict__ Bc) {
+  __shared__ double part[2][256];
+  __shared__ double tot[2][192];
+  __shared__ double red[2][64];
+  __shared__ double dpre1_sh[2];
+  __shared__ double acc[2][4][64];   // dw1, dw2, db2, dz of each sample
+  const int b = threadIdx.x >> 8, t = threadIdx.x & 255;
+  const double w = wptr ? (double)*wptr : 1.0;
+  reduce_rows_b(sums + (int64_t)b * rows * C * 3, rows, C * 3, part[b], tot[b], t, true);
+  double dpre2 = 0, s_dz = 0, s_dw2 = 0;
+  if (t < C) {
+    const double g = gate[b * C + t];
+    const double dgate = w * tot[b][t * 3 + 1];
+    dpre2 = dgate * g * (1.0 - g);
+    s_dz = tot[b][t * 3 + 2];
+    s_dw2 = dpre2 * (double)hidden[b];
+  }
+  if (t < 64) red[b][t] = (t < C) ? dpre2 * (double)w2[t] : 0.0;
+  __syncthreads();
+  if (t == 0) {
+    double dh = 0;
+    for (int i = 0; i < 64; ++i) dh += red[b][i];
+    dpre1_sh[b] = hidden[b] > 0.f ? dh : 0.0;
+  }
+  __syncthreads();
+  const double dpre1 = dpre1_sh[b];
+  if (t < 64) {
+    const bool in = t < C;
+    acc[b][0][t] = in ? dpre1 * (double)mean[b * C + t] : 0.0;
+    acc[b][1][t] = in ? s_dw2 : 0.0;
+    acc[b][2][t] = in ? dpre2 : 0.0;
+    acc[b][3][t] = in ? s_dz : 0.0;
+    if (in) {
+      A[b * C + t] = (float)(w * (double)gate[b * C + t]);
+      Bc[b * C + t] = (float)(dpre1 * (double)w1[t] / count);
+    }
+  }
+  __syncthreads();
+  if (b == 0 && t < C) {
+    dw1[t] = (float)(acc[0][0][t] + acc[1][0][t]); dw2[t] = (float)(acc[0][1][t] + acc[1][1][t]); db2[t] = (float)(acc[0][2][t] + acc[1][2][t]);
+  }
+  if (threadIdx.x == 0) db1[0] = (float)(dpre1_sh[0] + dpre1_sh[1]);
+  if (dalpha && threadIdx.x == 0) {
+    double s = 0;
+    for (int i = 0; i < 64; ++i) s += acc[0][3][i] + acc[1][3][i];
+    *dalpha = (float)s;
+  }
+}
 __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const double* __restrict__ sums, int rows, const float* __restrict__ wptr,
                                                           const float* __restrict__ mean, const float* __restrict__ hidden,
                                                           const float* __restrict__ gate, const float* __restrict__ w1,
@@ -1847,6 +1911,14 @@ __global__ __launch_bounds__(256) void se_gate_bwdN_kernel(SeTermN ts, int B, in
   SeTerm q;
   N3D_PICK8(ts.t, blockIdx.x, q);
   se_gate_bwd_body(q.sums, q.rows, q.wptr, q.mean, q.hidden, q.gate, q.w1, q.w2, B, C, count, q.dw1, q.db1, q.dw2, q.db2, q.dalpha, q.A, q.Bc);
+}
+__global__ __launch_bounds__(512) void se_gate_bwdN2_kernel(SeTermN ts, int C, double count) { N3D_CHAIN_PRIO();
+  SeTerm q;
+  N3D_PICK8(ts.t, blockIdx.x, q);
+  se_gate_bwd_body2(q.sums, q.rows, q.wptr, q.mean, q.hidden, q.gate, q.w1, q.w2, C, count, q.dw1, q.db1, q.dw2, q.db2, q.dalpha, q.A, q.Bc);
+}
+__global__ __launch_bounds__(512) void se_gate_bwd2_kernel(SeTerm q, int C, double count) { N3D_CHAIN_PRIO();
+  se_gate_bwd_body2(q.sums, q.rows, q.wptr, q.mean, q.hidden, q.gate, q.w1, q.w2, C, count, q.dw1, q.db1, q.dw2, q.db2, q.dalpha, q.A, q.Bc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2309,7 +2381,8 @@ int n3d_gn_bwd_coeffs(const double* sums, int rows, const float* gamma, const fl
   N3D_CHECK_ARG(sums && gamma && mean_rstd && A && Bc && Cc && C <= 64 && C % G == 0, "gn_bwd_coeffs: bad args");
   N3D_CHECK_ARG(!dbias_conv || sumraw, "gn_bwd_coeffs: dbias_conv needs the forward per-channel sums");
   const GnBwdCoefArgs q{sums, rows, gamma, mean_rstd, wptr, dgamma, dbeta, dalpha, A, Bc, Cc, sumraw, dbias_conv};
-  hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(1), dim3(256 * GNB_BP), 0, (hipStream_t)stream, q, q, B, C, G, (double)N);
+  if (B <= 2) hipLaunchKernelGGL(gn_bwd_coeffs_kernel<2>, dim3(1), dim3(512), 0, (hipStream_t)stream, q, q, B, C, G, (double)N);
+  else hipLaunchKernelGGL(gn_bwd_coeffs_kernel<GNB_BP>, dim3(1), dim3(256 * GNB_BP), 0, (hipStream_t)stream, q, q, B, C, G, (double)N);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2530,7 +2603,8 @@ int n3d_gn_bwd_coeffs2(const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int
     q[i] = GnBwdCoefArgs{t->sums, t->rows, t->gamma, t->mean_rstd, t->wptr, t->dgamma, t->dbeta, t->dalpha, t->cA, t->cB, t->cC, t->sumraw,
                          t->dbias_conv};
   }
-  hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(2), dim3(256 * GNB_BP), 0, (hipStream_t)stream, q[0], q[1], B, C, G, (double)N);
+  if (B <= 2) hipLaunchKernelGGL(gn_bwd_coeffs_kernel<2>, dim3(2), dim3(512), 0, (hipStream_t)stream, q[0], q[1], B, C, G, (double)N);
+  else hipLaunchKernelGGL(gn_bwd_coeffs_kernel<GNB_BP>, dim3(2), dim3(256 * GNB_BP), 0, (hipStream_t)stream, q[0], q[1], B, C, G, (double)N);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2630,7 +2704,8 @@ int n3d_gn_bwd_coeffsN(const n3d_gn_bwd_term* terms, int n, int B, int C, int G,
     qs.q[i] = GnBwdCoefArgs{t->sums, t->rows, t->gamma, t->mean_rstd, t->wptr, t->dgamma, t->dbeta, t->dalpha, t->cA, t->cB, t->cC, t->sumraw,
                             t->dbias_conv};
   }
-  hipLaunchKernelGGL(gn_bwd_coeffsN_kernel, dim3(n), dim3(256 * GNB_BP), 0, (hipStream_t)stream, qs, B, C, G, (double)N);
+  if (B <= 2) hipLaunchKernelGGL(gn_bwd_coeffsN_kernel<2>, dim3(n), dim3(512), 0, (hipStream_t)stream, qs, B, C, G, (double)N);
+  else hipLaunchKernelGGL(gn_bwd_coeffsN_kernel<GNB_BP>, dim3(n), dim3(256 * GNB_BP), 0, (hipStream_t)stream, qs, B, C, G, (double)N);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2710,8 +2785,14 @@ int n3d_se_gate_bwd(const double* sums, int rows, const float* wptr, const float
                     const float* w1, const float* w2, int B, int C, int64_t N, float* dw1, float* db1, float* dw2, float* db2,
                     float* dalpha, float* A, float* Bc, void* stream) {
   N3D_CHECK_ARG(sums && mean && hidden && gate && w1 && w2 && dw1 && db1 && dw2 && db2 && A && Bc && C <= 64, "se_gate_bwd: bad args");
-  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, rows, wptr, mean, hidden, gate, w1, w2, B, C,
-                     (double)N, dw1, db1, dw2, db2, dalpha, A, Bc);
+  if (B == 2) {
+    const SeTerm q{sums, rows, w1, nullptr, w2, nullptr, const_cast<float*>(mean), const_cast<float*>(hidden), const_cast<float*>(gate), wptr, dw1, db1, dw2,
+                   db2, dalpha, A, Bc};
+    hipLaunchKernelGGL(se_gate_bwd2_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, q, C, (double)N);
+  } else {
+    hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, rows, wptr, mean, hidden, gate, w1, w2, B, C,
+                       (double)N, dw1, db1, dw2, db2, dalpha, A, Bc);
+  }
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2744,7 +2825,8 @@ int n3d_se_gate_bwdN(const n3d_se_term* terms, int n, int64_t N, int B, int C, v
   N3D_CHECK_ARG(terms && B > 0 && N > 0 && C >= 1 && C <= 64, "se_gate_bwdN: bad args");
   SeTermN ts;
   if (int e = se_terms(terms, n, true, &ts, "se_gate_bwdN")) return e;
-  hipLaunchKernelGGL(se_gate_bwdN_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, ts, B, C, (double)N);
+  if (B == 2) hipLaunchKernelGGL(se_gate_bwdN2_kernel, dim3(n), dim3(512), 0, (hipStream_t)stream, ts, C, (double)N);
+  else hipLaunchKernelGGL(se_gate_bwdN_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, ts, B, C, (double)N);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
