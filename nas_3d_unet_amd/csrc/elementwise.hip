@@ -1757,19 +1757,27 @@ __device__ __forceinline__ void se_gate_fwd_body(const double* __restrict__ stat
   __shared__ float hsh;
   const int b = blockIdx.x;
   const int t = threadIdx.x;
+  __shared__ float msh[64], w1sh[64];
+  const float w1_t = (t < C) ? w1[t] : 0.f, w2_t = (t < C) ? w2[t] : 0.f, b2_t = (t < C) ? b2[t] : 0.f;   // issued before the row loads
+  const float b1_0 = b1[0];
   reduce_rows(stats + (int64_t)b * rows * C * 2, rows, C * 2, part, tot);
-  if (t < C) mean[b * C + t] = (float)(tot[t * 2] / count);
+  if (t < C) {
+    // the channel means (a double division each) in parallel; the hidden unit below adds them in channel order as before
+    const float m = (float)(tot[t * 2] / count);
+    mean[b * C + t] = m;
+    msh[t] = m; w1sh[t] = w1_t;
+  }
   __syncthreads();
   if (t == 0) {
-    float h = b1[0];
-    for (int c = 0; c < C; ++c) h = fmaf(w1[c], (float)(tot[c * 2] / count), h);
+    float h = b1_0;
+    for (int c = 0; c < C; ++c) h = fmaf(w1sh[c], msh[c], h);
     h = fmaxf(h, 0.f);
     hidden[b] = h;
     hsh = h;
   }
   __syncthreads();
   if (t < C) {
-    const float pre = fmaf(w2[t], hsh, b2[t]);
+    const float pre = fmaf(w2_t, hsh, b2_t);
     gate[b * C + t] = 1.0f / (1.0f + __expf(-pre));
   }
 }
