@@ -2073,7 +2073,8 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     // short chunks (the voxel loop is a dependent load -> FMA chain): about two trips per thread -- a workgroup covers
     // 256 / (C/4) voxels per trip, so wide channel counts need far smaller chunks than 512 voxels; bounded by the slab workspace
     const int64_t vpb = 256 / (a.C / 4) > 0 ? 256 / (a.C / 4) : 1;
-    int64_t nch = cdiv(total, 2 * vpb < 512 ? 2 * vpb : 512);
+    static const int trips = [] { const char* e = getenv("N3D_DW_TRIPS"); const int v = e ? atoi(e) : 2; return v >= 1 ? v : 2; }();   // (A/B knob)
+    int64_t nch = cdiv(total, trips * vpb < 512 ? trips * vpb : 512);
     if (nch > 1024) nch = 1024;
     a.chunk = cdiv(total, nch);
     const int nchunks = (int)cdiv(total, a.chunk);
