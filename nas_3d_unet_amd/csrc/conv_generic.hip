@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
       acc[27][0] += g.x; acc[27][1] += g.y; acc[27][2] += g.z; acc[27][3] += g.w;
       const float* xb = a.x + (int64_t)b * Ni * a.xld + c4 * 4;
       // one kd plane at a time: its nine loads are issued from clamped addresses before the first use (a branch per
-      // tap serialises on one memory latency per tap: 27 per voxel)
+      // tap serialises on one memory latency per tap: 27 per voxel; all 27 at once measured no better and takes 256 VGPRs)
 #pragma unroll
       for (int kd = 0; kd < 3; ++kd) {
         const int id = od * a.stride - a.pad + kd;
@@ -2073,7 +2073,7 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     // short chunks (the voxel loop is a dependent load -> FMA chain): about two trips per thread -- a workgroup covers
     // 256 / (C/4) voxels per trip, so wide channel counts need far smaller chunks than 512 voxels; bounded by the slab workspace
     const int64_t vpb = 256 / (a.C / 4) > 0 ? 256 / (a.C / 4) : 1;
-    static const int trips = [] { const char* e = getenv("N3D_DW_TRIPS"); const int v = e ? atoi(e) : 2; return v >= 1 ? v : 2; }();   // (A/B knob)
+    static const int trips = [] { const char* e = getenv("N3D_DW_TRIPS"); const int v = e ? atoi(e) : 1; return v >= 1 ? v : 1; }();   // (A/B knob; 2 until round 4: search step tail 0.45 -> 0.365 ms with 1)
     int64_t nch = cdiv(total, trips * vpb < 512 ? trips * vpb : 512);
     if (nch > 1024) nch = 1024;
     a.chunk = cdiv(total, nch);
