@@ -18,6 +18,7 @@ MI355X-first mechanics (none of which the reference has):
 from __future__ import annotations
 
 import os
+import time
 import types
 import weakref
 
@@ -281,6 +282,16 @@ def reserve_side_streams(device, n=2):
                 K.sync_signal(scratch.data_ptr() + 16, scratch.data_ptr(), False)
         torch.cuda.synchronize(device)
     return pool
+
+
+def _let_comm_watchdog_retire(dp):
+    """Data parallel, before a stream capture: the warm-up steps' collectives are complete (the caller has synchronised), but
+    torch.distributed's watchdog thread retires their work objects -- event queries, event destruction, tensors handed back to the
+    caching allocator -- on its own 100 ms poll, i.e. possibly in the middle of the capture.  One poll interval of patience keeps the
+    runtime's other thread idle while three streams are being captured.  (Round 4: a run of the GPU suite in eight aborted from a
+    runtime thread -- no Python frame, no message -- exactly inside the first bucketed data-parallel capture.)"""
+    if dp:
+        time.sleep(0.25)
 
 
 class SideSchedule:
@@ -1370,6 +1381,7 @@ class Trainer:
                 self._use_side = True
                 return
         g = torch.cuda.CUDAGraph()
+        _let_comm_watchdog_retire(self.dp_path)
         with torch.cuda.graph(g, capture_error_mode="thread_local"):  # RCCL's watchdog thread may touch the runtime meanwhile
             self._static_loss = self._fwd_bwd(self._static_x, self._static_t)
             if not self.dp_path:
@@ -1390,6 +1402,7 @@ class Trainer:
         sd = self.side
         g_main, g_tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
+        _let_comm_watchdog_retire(self.dp_path)
         sd.raw_capture_begin()
         self._capturing_side = True
         try:
@@ -1428,6 +1441,7 @@ class Trainer:
                 graphs[-1].capture_begin(pool=pool, capture_error_mode="thread_local")
 
         torch.cuda.synchronize()
+        _let_comm_watchdog_retire(self.dp_path)
         with torch.cuda.stream(s):
             graphs[0].capture_begin(pool=pool, capture_error_mode="thread_local")
             self._static_loss = self._pipeline(self._static_x, self._static_t, on_bucket)
@@ -1628,6 +1642,7 @@ class SearchTrainer:
         pool = torch.cuda.graph_pool_handle()
         sd = self.side
         torch.cuda.synchronize()
+        _let_comm_watchdog_retire(self.dp_path)
         graphs, losses = [], []
         for arch, (bx, bt) in ((True, (self._svx, self._svt)), (False, (self._sx, self._st))):
             g_main, g_tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()

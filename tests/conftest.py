@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the HIP runtime's queue-error handler aborts the process from a runtime thread and says why only at log level >= 1 (errors only):
+# a GPU-side fault in a test run must not be a silent "Fatal Python error: Aborted" (set before anything initialises the runtime)
+os.environ.setdefault("AMD_LOG_LEVEL", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
     if p not in sys.path:
