@@ -66,6 +66,7 @@ extern "C" {
  * o = floor((i + 2*pad - dil*(k-1) - 1)/stride) + 1.  "i side" is what the window slides over.
  * For a transposed convolution the i side is its OUTPUT and the o side its INPUT. */
 #define N3D_MAX_GROUP_TERMS 8   /* terms / jobs per batched launch (the N-term entry points below) */
+#define N3D_MAX_REDUCE_TERMS 16 /* n3d_affine_act_bwd_reduceN / n3d_node_bwd_coeffs: every term of a supernet node level in one launch */
 
 typedef struct n3d_conv_geom {
   int32_t B;
@@ -345,7 +346,7 @@ int n3d_affine_act_bwd_apply2(const float* dout, int64_t dld, const float* dout1
  * n3d_gn_coeffsN: n x n3d_gn_coeffs in one launch.  n3d_affine_actN: out (+)= sum_k w_k * act_k(a_k * raw_k + b_k) in term
  * order, one pass over the node buffer; a_k = a_out, b_k = b_out of the term, NULL meaning 1 / 0, so the node's other
  * primitives (SE gate: a = gate; pooling, identity-with-norm) ride in the same pass.  Backward: n3d_affine_act_bwd_reduceN (fills sums of every term; all terms read the
- * same node gradient; a / b NULL = 1 / 0 as in n3d_affine_act_bwd_reduce, so the other primitives' reductions ride along), n3d_gn_bwd_coeffsN (cA / cB / cC and the parameter gradients), n3d_affine_act_bwd_applyN (every draw). */
+ * same node gradient; a / b NULL = 1 / 0 as in n3d_affine_act_bwd_reduce, so the other primitives' reductions ride along; this entry takes up to N3D_MAX_REDUCE_TERMS terms), n3d_gn_bwd_coeffsN (cA / cB / cC and the parameter gradients), n3d_affine_act_bwd_applyN (every draw). */
 int n3d_gn_coeffsN(const n3d_gn_fwd_term* terms, int n, int B, int C, int G, int64_t N, float eps, void* stream);
 int n3d_affine_actN(const n3d_gn_fwd_term* terms, int n, float* out, int64_t old_, int B, int64_t N, int C, int flags, void* stream);
 int n3d_affine_act_bwd_reduceN(const float* dout, int64_t dld, const n3d_gn_bwd_term* terms, int n, int B, int64_t N, int C, void* stream);
@@ -384,6 +385,11 @@ typedef struct n3d_se_term {
 } n3d_se_term;
 int n3d_se_gate_fwdN(const n3d_se_term* terms, int n, int64_t N, int B, int C, void* stream);
 int n3d_se_gate_bwdN(const n3d_se_term* terms, int n, int64_t N, int B, int C, void* stream);
+/* All coefficient computations of one node level of the supernet backward (cell.py:76-81: a node's MixedOps all consume the node's
+ * gradient) -- n3d_gn_bwd_coeffsN of up to N3D_MAX_REDUCE_TERMS GroupNorm-type terms and n3d_se_gate_bwdN of up to
+ * N3D_MAX_GROUP_TERMS SE gates -- in ONE launch at B = 2 with both kinds present (the same per-term work, same results), else as
+ * those launches. */
+int n3d_node_bwd_coeffs(const n3d_gn_bwd_term* gn, int n_gn, const n3d_se_term* se, int n_se, int B, int C, int G, int64_t N, void* stream);
 
 
 /* ---- 2x2x2 pooling, stride 2 (prim_ops.py:160-163) ------------------------------------------------ */

@@ -196,6 +196,11 @@ __global__ __launch_bounds__(256) void gn_coeffs_kernel(GnCoefArgs q0, GnCoefArg
 #define N3D_PICK8(arr, i, dst)                                                                                     \
   switch (i) { case 0: dst = arr[0]; break; case 1: dst = arr[1]; break; case 2: dst = arr[2]; break; case 3: dst = arr[3]; break; \
                case 4: dst = arr[4]; break; case 5: dst = arr[5]; break; case 6: dst = arr[6]; break; default: dst = arr[7]; break; }
+#define N3D_PICK16(arr, i, dst)                                                                                    \
+  switch (i) { case 0: dst = arr[0]; break; case 1: dst = arr[1]; break; case 2: dst = arr[2]; break; case 3: dst = arr[3]; break; \
+               case 4: dst = arr[4]; break; case 5: dst = arr[5]; break; case 6: dst = arr[6]; break; case 7: dst = arr[7]; break; \
+               case 8: dst = arr[8]; break; case 9: dst = arr[9]; break; case 10: dst = arr[10]; break; case 11: dst = arr[11]; break; \
+               case 12: dst = arr[12]; break; case 13: dst = arr[13]; break; case 14: dst = arr[14]; break; default: dst = arr[15]; break; }
 struct GnCoefArgsN { GnCoefArgs q[8]; };
 __global__ __launch_bounds__(256) void gn_coeffsN_kernel(GnCoefArgsN qs, int C, int G, double count, float eps) { N3D_CHAIN_PRIO();
   GnCoefArgs q;
@@ -1636,13 +1641,13 @@ __global__ __launch_bounds__(256) void affine_actN_kernel(FwdTermN ts, float* __
   }
 }
 
-struct BwdRedTermN { BwdRedTerm t[8]; };
+struct BwdRedTermN { BwdRedTerm t[N3D_MAX_REDUCE_TERMS]; };   // 16: every term of a node level in ONE reduction launch
 // grid (rows, B, terms): the reduction pass of affine_bwd_reduce2_kernel for term blockIdx.z
 __global__ __launch_bounds__(256) void affine_bwd_reduceN_kernel(const float* __restrict__ dout, int64_t dld, BwdRedTermN ts, int64_t N, int C,
                                                                  EwMap m) { N3D_CHAIN_PRIO();
   __shared__ double lds[4 * 64 * 12];
   BwdRedTerm tm;
-  N3D_PICK8(ts.t, blockIdx.z, tm);
+  N3D_PICK16(ts.t, blockIdx.z, tm);
   const int b = blockIdx.y;
   const int t = threadIdx.x;
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
@@ -1927,6 +1932,21 @@ __global__ __launch_bounds__(512) void se_gate_bwdN2_kernel(SeTermN ts, int C, d
 }
 __global__ __launch_bounds__(512) void se_gate_bwd2_kernel(SeTerm q, int C, double count) { N3D_CHAIN_PRIO();
   se_gate_bwd_body2(q.sums, q.rows, q.wptr, q.mean, q.hidden, q.gate, q.w1, q.w2, C, count, q.dw1, q.db1, q.dw2, q.db2, q.dalpha, q.A, q.Bc);
+}
+// Every coefficient computation of a node level of the supernet backward in ONE launch (B = 2): workgroups [0, n_gn) are GroupNorm terms
+// (gn_bwd_coeffs_body), [n_gn, n_gn + n_se) SE gates (se_gate_bwd_body2) -- the same bodies, i.e. the same bits, as the two launches
+struct NodeCoefArgs { GnBwdCoefArgs g[N3D_MAX_REDUCE_TERMS]; SeTerm s[8]; int n_gn; };
+__global__ __launch_bounds__(512) void node_bwd_coeffs_kernel(NodeCoefArgs qs, int C, int G, double count) { N3D_CHAIN_PRIO();
+  const int i = blockIdx.x;
+  if (i < qs.n_gn) {
+    GnBwdCoefArgs q;
+    N3D_PICK16(qs.g, i, q);
+    gn_bwd_coeffs_body<2>(q, 2, C, G, count);
+  } else {
+    SeTerm q;
+    N3D_PICK8(qs.s, i - qs.n_gn, q);
+    se_gate_bwd_body2(q.sums, q.rows, q.wptr, q.mean, q.hidden, q.gate, q.w1, q.w2, C, count, q.dw1, q.db1, q.dw2, q.db2, q.dalpha, q.A, q.Bc);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2686,10 +2706,11 @@ int n3d_affine_actN(const n3d_gn_fwd_term* terms, int n, float* out, int64_t old
 
 int n3d_affine_act_bwd_reduceN(const float* dout, int64_t dld, const n3d_gn_bwd_term* terms, int n, int B, int64_t N, int C, void* stream) {
   N3D_CHECK_ARG(dout && terms && B > 0 && N > 0, "affine_act_bwd_reduceN: bad args");
-  if (int e = check_group(n, C, "affine_act_bwd_reduceN")) return e;
+  N3D_CHECK_ARG(n >= 1 && n <= N3D_MAX_REDUCE_TERMS, "affine_act_bwd_reduceN: 1..16 terms");
+  if (int e = check_group(1, C, "affine_act_bwd_reduceN")) return e;
   if (int e = check_vec(dout, dld, C, "bwd_reduceN(dout)")) return e;
   BwdRedTermN ts;
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < N3D_MAX_REDUCE_TERMS; ++i) {
     const n3d_gn_bwd_term* t = &terms[i < n ? i : 0];
     N3D_CHECK_ARG(t->raw && t->sums, "affine_act_bwd_reduceN: null term pointer");  // a / b may be NULL: scale 1 / shift 0
     if (int e = check_vec(t->raw, t->rld, C, "bwd_reduceN(raw)")) return e;
@@ -2836,6 +2857,36 @@ int n3d_se_gate_bwdN(const n3d_se_term* terms, int n, int64_t N, int B, int C, v
   if (B == 2) hipLaunchKernelGGL(se_gate_bwdN2_kernel, dim3(n), dim3(512), 0, (hipStream_t)stream, ts, C, (double)N);
   else hipLaunchKernelGGL(se_gate_bwdN_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, ts, B, C, (double)N);
   N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_node_bwd_coeffs(const n3d_gn_bwd_term* gn, int n_gn, const n3d_se_term* se, int n_se, int B, int C, int G, int64_t N, void* stream) {
+  N3D_CHECK_ARG(n_gn >= 0 && n_gn <= N3D_MAX_REDUCE_TERMS && n_se >= 0 && n_se <= N3D_MAX_GROUP_TERMS && n_gn + n_se >= 1 && (n_gn == 0 || gn) &&
+                (n_se == 0 || se), "node_bwd_coeffs: 0..16 GroupNorm terms, 0..8 SE gates");
+  if (B == 2 && n_gn >= 1 && n_se >= 1) {
+    N3D_CHECK_ARG(B > 0 && N > 0 && G >= 1 && C % G == 0 && C >= 1 && C <= 64, "node_bwd_coeffs: bad args");
+    if (int e = check_group(1, C, "node_bwd_coeffs")) return e;
+    NodeCoefArgs qs;
+    qs.n_gn = n_gn;
+    for (int i = 0; i < N3D_MAX_REDUCE_TERMS; ++i) {
+      const n3d_gn_bwd_term* t = &gn[i < n_gn ? i : 0];
+      N3D_CHECK_ARG(t->sums && t->gamma && t->mean_rstd && t->cA && t->cB && t->cC && t->rows >= 1, "node_bwd_coeffs: null GroupNorm term pointer");
+      N3D_CHECK_ARG(!t->dbias_conv || t->sumraw, "node_bwd_coeffs: dbias_conv needs the forward per-channel sums");
+      qs.g[i] = GnBwdCoefArgs{t->sums, t->rows, t->gamma, t->mean_rstd, t->wptr, t->dgamma, t->dbeta, t->dalpha, t->cA, t->cB, t->cC, t->sumraw,
+                              t->dbias_conv};
+    }
+    SeTermN ts;
+    if (int e = se_terms(se, n_se, true, &ts, "node_bwd_coeffs")) return e;
+    for (int i = 0; i < 8; ++i) qs.s[i] = ts.t[i];
+    hipLaunchKernelGGL(node_bwd_coeffs_kernel, dim3(n_gn + n_se), dim3(512), 0, (hipStream_t)stream, qs, C, G, (double)N);
+    N3D_LAUNCH_CHECK();
+    return N3D_OK;
+  }
+  // other batch sizes / one kind only: the separate launches
+  for (int i = 0; i < n_gn; i += N3D_MAX_GROUP_TERMS)
+    if (int e = n3d_gn_bwd_coeffsN(gn + i, n_gn - i < N3D_MAX_GROUP_TERMS ? n_gn - i : N3D_MAX_GROUP_TERMS, B, C, G, N, stream)) return e;
+  if (n_se >= 1)
+    if (int e = n3d_se_gate_bwdN(se, n_se, N, B, C, stream)) return e;
   return N3D_OK;
 }
 

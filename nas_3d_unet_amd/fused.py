@@ -198,6 +198,7 @@ PLANAR_OUT = False
 # side stream's part of their node.  SIDE_FWD: .fork() main stores a flag, returns its id; .side(wait_id) context manager: launches
 # go to the side stream behind a wait on that flag; .side_signal() side stores a flag, returns its id; .join(id) main waits for it.
 SIDE_FWD = None
+NODE_PHASES = os.environ.get("N3D_NODE_PHASES", "1") != "0"   # one reduction + one coefficient launch per node level of the supernet backward (A/B knob)
 SIDE_BWD = None      # the same object while the backward pass of a supernet may use the side stream (see _run_backward_impl)
 SIDE_NODE0_SPLIT = __import__("os").environ.get("N3D_SIDE_NODE0", "main") == "split"   # node 0: both edges on the main stream (one of them on the side stream measured 0.1 ms slower per search step)
 
@@ -578,7 +579,7 @@ def _run_backward_nodes(plan, st, dnodes, alpha1, alpha2, need_x0, need_x1, want
             """backward of the terms in `node_units` (units of ONE node, all of them or the subset one stream handles)"""
             # the primitives that stay single (identity, SE gates, pooling) all start with a reduction pass over the same node
             # gradient: those passes run up to eight per launch
-            pre, pre_se, pre_da = {}, {}, set()
+            pre, pre_se, pre_da, prep = {}, {}, set(), {}
             if batch_reduce:
                 want = []
                 for unit in node_units:
@@ -589,11 +590,37 @@ def _run_backward_nodes(plan, st, dnodes, alpha1, alpha2, need_x0, need_x1, want
                         if P.needs_reduce(seg, s, alpha_of(amat, row)[1]):
                             want.append((fi, (s.raw, s.a if s.kind != "plain" else None, s.b if s.kind == "gn" else None,
                                               seg.relu_out and s.kind != "se")))
-                for i in range(0, len(want), K.MAX_GROUP_TERMS):
-                    chunk = want[i:i + K.MAX_GROUP_TERMS]
-                    if len(chunk) >= 2:
-                        for (fi, _), r in zip(chunk, K.affine_act_bwd_reduceN(dnodes[node], [c[1] for c in chunk])):
-                            pre[fi] = r
+                # NODE_PHASES (round 4): with N-term GroupNorm groups among the units, the node level's reductions are ONE launch (the
+                # groups' terms and the single primitives', up to 16) and its coefficient computations another (GroupNorm terms and SE
+                # gates behind a per-workgroup switch) -- P.group_backward then only runs the apply pass and the weight ops
+                group_units = [u for u in node_units if len(u) >= 3] if NODE_PHASES else []
+                if group_units:
+                    for u in group_units:
+                        tl = []
+                        for fi in u:
+                            _, _, seg, col, amat, row = flat[fi]
+                            arow, dal = alpha_of(amat, row)
+                            tl.append((seg, st.saved[fi], (arow, col, dal)))
+                        prep[u] = P.group_prepare(tl, dnodes[node])
+                    gate_specs = []
+                    for k, (fi, _) in enumerate(want):
+                        if st.saved[fi].kind == "se":
+                            _, _, seg, col, amat, row = flat[fi]
+                            arow, dal = alpha_of(amat, row)
+                            s = st.saved[fi]
+                            gate_specs.append((k, dict(wptr=P._wptr(arow, col), mean=s.mean, hidden=s.hidden, gate=s.a, fc=seg.se_gate.fc,
+                                                       dalpha_ptr=(dal.data_ptr() + 4 * col) if dal is not None else None)))
+                    rs, ses = K.node_bwd_prologue(dnodes[node], [prep[u] for u in group_units], [c[1] for c in want], gate_specs)
+                    for (fi, _), r in zip(want, rs):
+                        pre[fi] = r
+                    for (k, _), r in zip(gate_specs, ses):
+                        pre_se[want[k][0]] = r
+                else:
+                    for i in range(0, len(want), K.MAX_GROUP_TERMS):
+                        chunk = want[i:i + K.MAX_GROUP_TERMS]
+                        if len(chunk) >= 2:
+                            for (fi, _), r in zip(chunk, K.affine_act_bwd_reduceN(dnodes[node], [c[1] for c in chunk])):
+                                pre[fi] = r
                 # ... the pooling primitives' dalpha = <d node, pooled> come out of one launch
                 pools = [fi for fi, _ in want if fi in pre and isinstance(flat[fi][2].weight, P.PoolW) and not flat[fi][2].relu_out]
                 for i in range(0, len(pools), K.MAX_GROUP_TERMS):
@@ -608,7 +635,7 @@ def _run_backward_nodes(plan, st, dnodes, alpha1, alpha2, need_x0, need_x1, want
                         K.plain_dalphaN(tds, raw.B, raw.C)
                         pre_da.update(chunk)
                 # ... and the SE gates among them share one gate-backward launch
-                gates = [fi for fi, _ in want if fi in pre and st.saved[fi].kind == "se"]
+                gates = [fi for fi, _ in want if fi in pre and fi not in pre_se and st.saved[fi].kind == "se"]
                 for i in range(0, len(gates), K.MAX_GROUP_TERMS):
                     chunk = gates[i:i + K.MAX_GROUP_TERMS]
                     if len(chunk) >= 2:
@@ -653,7 +680,7 @@ def _run_backward_nodes(plan, st, dnodes, alpha1, alpha2, need_x0, need_x1, want
                         target, acc = tgt(idx)
                         terms.append((seg, st.saved[fi], (True, target, acc), (arow, col, dal)))
                     terms.reverse()
-                    for (seg, _, _, _), (_, gl) in zip(terms, P.group_backward(terms, dnodes[node])):
+                    for (seg, _, _, _), (_, gl) in zip(terms, P.group_backward(terms, dnodes[node], prep.get(unit))):
                         put(seg, gl)
                     continue
                 if len(unit) == 2:

@@ -1016,34 +1016,126 @@ def affine_actN(terms, out: View, flags=0):
     check(_lib.load().n3d_affine_actN(arr, n, out.p, out.ld, raw0.B, raw0.N, raw0.C, flags, stream_ptr()), "n3d_affine_actN")
 
 
+class GnGroupBwd:
+    """Backward of one N-term GroupNorm group (affine_act_gnN), phase by phase: reductions, coefficients + parameter gradients, d(raw).
+    terms = [dict(raw, a, b, mr, sumraw, gamma, beta, wptr, relu, conv_bias, draw, dalpha_ptr)]; .outs = [(dgamma, dbeta, dconv_bias |
+    None)].  The phases of several groups (and of a node's other primitives) can share launches: node_bwd_prologue."""
+
+    def __init__(self, dout: View, terms, G):
+        n = len(terms)
+        raw0 = terms[0]["raw"]
+        _need_f32("affine_act_bwd_gnN", dout, *[t["raw"] for t in terms])
+        dev = raw0.t.device
+        self.dout, self.terms, self.G, self.n = dout, terms, G, n
+        self.B, self.C, self.N = raw0.B, raw0.C, raw0.N
+        rows = stats_rows(self.N, self.C)
+        self.sums = torch.empty((n, self.B, rows, self.C, 3), dtype=torch.float64, device=dev)
+        self.coef = torch.empty((n, 3, self.B, self.C), dtype=torch.float32, device=dev)
+        self.arr = (GnBwdTerm * n)()
+        self.outs = []
+        for i, t in enumerate(terms):
+            dgamma, dbeta = grad_target(t["gamma"]), grad_target(t["beta"])
+            cb = t.get("conv_bias")
+            dcb = grad_target(cb) if (cb is not None and t["sumraw"] is not None) else None
+            raw, draw = t["raw"], t["draw"]
+            self.arr[i] = GnBwdTerm(raw.p.value, raw.ld, t["a"].data_ptr(), t["b"].data_ptr(), self.sums[i].data_ptr(), rows, 1 if t["relu"] else 0,
+                                    t["gamma"].data_ptr(), t["mr"].data_ptr(), _vp(t.get("wptr")), _vp(t["sumraw"]), draw.p.value, draw.ld,
+                                    _vp(dgamma), _vp(dbeta), _vp(t.get("dalpha_ptr")), _vp(dcb), *[self.coef[i, j].data_ptr() for j in range(3)])
+            self.outs.append((dgamma, dbeta, dcb))
+
+    def reduce(self):
+        check(_lib.load().n3d_affine_act_bwd_reduceN(self.dout.p, self.dout.ld, self.arr, self.n, self.B, self.N, self.C, stream_ptr()),
+              "n3d_affine_act_bwd_reduceN")
+
+    def coeffs(self):
+        check(_lib.load().n3d_gn_bwd_coeffsN(self.arr, self.n, self.B, self.C, self.G, self.N, stream_ptr()), "n3d_gn_bwd_coeffsN")
+
+    def apply(self):
+        check(_lib.load().n3d_affine_act_bwd_applyN(self.dout.p, self.dout.ld, self.arr, self.n, self.B, self.N, self.C, stream_ptr()),
+              "n3d_affine_act_bwd_applyN")
+
+
 def affine_act_bwd_gnN(dout: View, terms, G):
-    """Backward of affine_act_gnN, three launches for all terms (reductions, coefficients + parameter gradients, d(raw)):
-    terms = [dict(raw, a, b, mr, sumraw, gamma, beta, wptr, relu, conv_bias, draw, dalpha_ptr)].
+    """Backward of affine_act_gnN, three launches for all terms (reductions, coefficients + parameter gradients, d(raw)).
     Returns [(dgamma, dbeta, dconv_bias | None)]."""
-    n = len(terms)
-    raw0 = terms[0]["raw"]
-    _need_f32("affine_act_bwd_gnN", dout, *[t["raw"] for t in terms])
-    dev = raw0.t.device
-    B, Cc, N = raw0.B, raw0.C, raw0.N
-    rows = stats_rows(N, Cc)
-    sums = torch.empty((n, B, rows, Cc, 3), dtype=torch.float64, device=dev)
-    coef = torch.empty((n, 3, B, Cc), dtype=torch.float32, device=dev)
-    arr = (GnBwdTerm * n)()
-    outs = []
-    for i, t in enumerate(terms):
-        dgamma, dbeta = grad_target(t["gamma"]), grad_target(t["beta"])
-        cb = t.get("conv_bias")
-        dcb = grad_target(cb) if (cb is not None and t["sumraw"] is not None) else None
-        raw, draw = t["raw"], t["draw"]
-        arr[i] = GnBwdTerm(raw.p.value, raw.ld, t["a"].data_ptr(), t["b"].data_ptr(), sums[i].data_ptr(), rows, 1 if t["relu"] else 0,
-                           t["gamma"].data_ptr(), t["mr"].data_ptr(), _vp(t.get("wptr")), _vp(t["sumraw"]), draw.p.value, draw.ld,
-                           _vp(dgamma), _vp(dbeta), _vp(t.get("dalpha_ptr")), _vp(dcb), *[coef[i, j].data_ptr() for j in range(3)])
-        outs.append((dgamma, dbeta, dcb))
+    g = GnGroupBwd(dout, terms, G)
+    g.reduce()
+    g.coeffs()
+    g.apply()
+    return g.outs
+
+
+MAX_REDUCE_TERMS = 16      # N3D_MAX_REDUCE_TERMS
+
+
+def node_bwd_prologue(dout: View, groups, singles, gates):
+    """The reduction and coefficient phases of ONE node level of the supernet backward, two launches for everything that consumes the
+    node gradient `dout`: groups = [GnGroupBwd] (their apply() is left to the caller), singles = [(raw, a | None, b | None, relu)] =
+    the reductions of the node's other primitives (affine_act_bwd_reduceN), gates = [(index into singles, dict(wptr, mean, hidden,
+    gate, fc, dalpha_ptr))] = the SE gates among them (se_gate_bwdN).  Returns ([(sums, rows)] per single, [(dw1, db1, dw2, db2, A,
+    Bc)] per gate).  More than 16 reductions / 16 GroupNorm terms / 8 gates: the phases fall back to one launch per group."""
     lib = _lib.load()
-    check(lib.n3d_affine_act_bwd_reduceN(dout.p, dout.ld, arr, n, B, N, Cc, stream_ptr()), "n3d_affine_act_bwd_reduceN")
-    check(lib.n3d_gn_bwd_coeffsN(arr, n, B, Cc, G, N, stream_ptr()), "n3d_gn_bwd_coeffsN")
-    check(lib.n3d_affine_act_bwd_applyN(dout.p, dout.ld, arr, n, B, N, Cc, stream_ptr()), "n3d_affine_act_bwd_applyN")
-    return outs
+    g0 = groups[0]
+    B, Cc, N, dev = g0.B, g0.C, g0.N, dout.t.device
+    rows = stats_rows(N, Cc)
+    ns = len(singles)
+    _need_f32("node_bwd_prologue", dout, *[t[0] for t in singles])
+    ssum = torch.empty((max(ns, 1), B, rows, Cc, 3), dtype=torch.float64, device=dev)
+    ngn = sum(g.n for g in groups)
+    # ---- reductions
+    if ngn + ns <= MAX_REDUCE_TERMS:
+        arr = (GnBwdTerm * (ngn + ns))()
+        k = 0
+        for g in groups:
+            for i in range(g.n):
+                arr[k] = g.arr[i]
+                k += 1
+        for i, (raw, a, b, relu) in enumerate(singles):
+            arr[k + i] = GnBwdTerm(raw.p.value, raw.ld, _vp(a), _vp(b), ssum[i].data_ptr(), rows, 1 if relu else 0, *([None] * 4), None, 0, *([None] * 7))
+        check(lib.n3d_affine_act_bwd_reduceN(dout.p, dout.ld, arr, ngn + ns, B, N, Cc, stream_ptr()), "n3d_affine_act_bwd_reduceN")
+    else:
+        for g in groups:
+            g.reduce()
+        for i0 in range(0, ns, MAX_REDUCE_TERMS):
+            chunk = singles[i0:i0 + MAX_REDUCE_TERMS]
+            arr = (GnBwdTerm * len(chunk))()
+            for i, (raw, a, b, relu) in enumerate(chunk):
+                arr[i] = GnBwdTerm(raw.p.value, raw.ld, _vp(a), _vp(b), ssum[i0 + i].data_ptr(), rows, 1 if relu else 0, *([None] * 4), None, 0, *([None] * 7))
+            check(lib.n3d_affine_act_bwd_reduceN(dout.p, dout.ld, arr, len(chunk), B, N, Cc, stream_ptr()), "n3d_affine_act_bwd_reduceN")
+    pre = [(ssum[i], rows) for i in range(ns)]
+    # ---- coefficients
+    se_arr, se_out = None, []
+    if gates:
+        coef = torch.empty((len(gates), 2, B, Cc), dtype=torch.float32, device=dev)
+        se_arr = (SeTerm * len(gates))()
+        for i, (si, t) in enumerate(gates):
+            fc = t["fc"]
+            dw1, db1, dw2, db2 = (grad_target(fc[0].weight), grad_target(fc[0].bias), grad_target(fc[2].weight), grad_target(fc[2].bias))
+            dw1 = dw1 if dw1 is not None else torch.empty((1, Cc), dtype=torch.float32, device=dev)
+            db1 = db1 if db1 is not None else torch.empty((1,), dtype=torch.float32, device=dev)
+            dw2 = dw2 if dw2 is not None else torch.empty((Cc, 1), dtype=torch.float32, device=dev)
+            db2 = db2 if db2 is not None else torch.empty((Cc,), dtype=torch.float32, device=dev)
+            se_arr[i] = SeTerm(ssum[si].data_ptr(), rows, 0, fc[0].weight.data_ptr(), None, fc[2].weight.data_ptr(), None,
+                               t["mean"].data_ptr(), t["hidden"].data_ptr(), t["gate"].data_ptr(), _vp(t.get("wptr")), dw1.data_ptr(),
+                               db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), _vp(t.get("dalpha_ptr")), coef[i, 0].data_ptr(), coef[i, 1].data_ptr())
+            se_out.append((dw1, db1, dw2, db2, coef[i, 0], coef[i, 1]))
+    same_g = len({g.G for g in groups}) == 1
+    if same_g and ngn <= MAX_REDUCE_TERMS and len(gates) <= MAX_GROUP_TERMS:
+        garr = (GnBwdTerm * ngn)()
+        k = 0
+        for g in groups:
+            for i in range(g.n):
+                garr[k] = g.arr[i]
+                k += 1
+        check(lib.n3d_node_bwd_coeffs(garr, ngn, se_arr, len(gates), B, Cc, g0.G, N, stream_ptr()), "n3d_node_bwd_coeffs")
+    else:
+        for g in groups:
+            g.coeffs()
+        for i0 in range(0, len(gates), MAX_GROUP_TERMS):
+            n = min(MAX_GROUP_TERMS, len(gates) - i0)
+            sub = (SeTerm * n)(*[se_arr[i0 + i] for i in range(n)])
+            check(lib.n3d_se_gate_bwdN(sub, n, N, B, Cc, stream_ptr()), "n3d_se_gate_bwdN")
+    return pre, se_out
 
 
 def affine_act_bwd_reduceN(dout: View, terms):

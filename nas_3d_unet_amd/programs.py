@@ -1045,11 +1045,24 @@ def group_epilogue_phase(terms, res, out, accumulate):
     return saved
 
 
-def group_backward(terms, dout):
+def group_prepare(terms, dout):
+    """the descriptors of an N-term group's backward, ahead of its phases: terms = [(segment, saved, (alpha row, column, dalpha row |
+    None))] in forward order.  Returns a K.GnGroupBwd whose reduce / coeffs phases the caller runs (K.node_bwd_prologue: shared with
+    the node's other primitives) before it hands it to group_backward."""
+    tds = [_gn_bwd_term(seg, s, al if al is not None else (None, 0, None)) for seg, s, al in terms]
+    return K.GnGroupBwd(dout, tds, terms[0][1].G)
+
+
+def group_backward(terms, dout, prepared=None):
     """Backward of group_forward.  terms = [(segment, saved, (need_dx, dx_out, dx_acc), (alpha row, column, dalpha row | None))] in
-    forward order; dout: View of the node gradient all of them consume.  Returns [(dx, grads)] in forward order."""
-    tds = [_gn_bwd_term(seg, s, al if al is not None else (None, 0, None)) for seg, s, _, al in terms]
-    outs = K.affine_act_bwd_gnN(dout, tds, terms[0][1].G)
+    forward order; dout: View of the node gradient all of them consume.  prepared: group_prepare's object for the same terms, its
+    reductions and coefficients done.  Returns [(dx, grads)] in forward order."""
+    if prepared is not None:
+        prepared.apply()
+        tds, outs = prepared.terms, prepared.outs
+    else:
+        tds = [_gn_bwd_term(seg, s, al if al is not None else (None, 0, None)) for seg, s, _, al in terms]
+        outs = K.affine_act_bwd_gnN(dout, tds, terms[0][1].G)
     order = [(seg, s, td, o, args) for (seg, s, args, _), td, o in zip(terms, tds, outs)][::-1]
     return _weight_backward(order)[::-1]
 
