@@ -1488,6 +1488,11 @@ class SearchTrainer:
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
         self.ctx = K.StepContext(self.device)
         self.side = SideSchedule(self.device, self.ctx, wgrad_stream=True) if (self.side_wgrad and self.device.type == "cuda") else None
+        if self.side is not None and "N3D_SIDE_TAIL_INLINE" not in os.environ:
+            # the weight pass' weight-gradient stream (219 launches) ends ~0.5 ms behind the chain: the last, third-last and fifth-last
+            # groups of the walk go to the inline side stream instead (weight pass 5.83 + 0.49 -> 5.97 + 0.17 ms; more groups there
+            # slow the chain by more than they take off the tail: tools/search_phases.py sweep)
+            self.side.tail_inline = (1, 3, 5)
         if self.side is not None and self.side.stream is None:
             self.side = None
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
