@@ -389,6 +389,8 @@ int n3d_se_gate_bwdN(const n3d_se_term* terms, int n, int64_t N, int B, int C, v
  * gradient) -- n3d_gn_bwd_coeffsN of up to N3D_MAX_REDUCE_TERMS GroupNorm-type terms and n3d_se_gate_bwdN of up to
  * N3D_MAX_GROUP_TERMS SE gates -- in ONE launch at B = 2 with both kinds present (the same per-term work, same results), else as
  * those launches. */
+/* forward counterpart: n3d_gn_coeffsN of 1..8 GroupNorm-type terms and n3d_se_gate_fwdN of 1..8 SE gates of one group in one launch */
+int n3d_node_fwd_coeffs(const n3d_gn_fwd_term* gn, int n_gn, const n3d_se_term* se, int n_se, int B, int C, int G, int64_t N, float eps, void* stream);
 int n3d_node_bwd_coeffs(const n3d_gn_bwd_term* gn, int n_gn, const n3d_se_term* se, int n_se, int B, int C, int G, int64_t N, void* stream);
 
 

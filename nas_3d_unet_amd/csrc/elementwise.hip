@@ -1802,6 +1802,20 @@ __global__ __launch_bounds__(256) void se_gate_fwdN_kernel(SeTermN ts, double co
   N3D_PICK8(ts.t, blockIdx.y, q);
   se_gate_fwd_body(q.sums, q.rows, count, q.w1, q.b1, q.w2, q.b2, C, q.mean, q.hidden, q.gate);
 }
+// the GroupNorm coefficients AND the SE gates of a supernet node's group in one launch: grid (B, n_gn + n_se), the same bodies
+struct NodeFwdCoefArgs { GnCoefArgs g[8]; SeTerm s[8]; int n_gn; };
+__global__ __launch_bounds__(256) void node_fwd_coeffs_kernel(NodeFwdCoefArgs qs, int C, int G, double count, float eps) { N3D_CHAIN_PRIO();
+  const int i = blockIdx.y;
+  if (i < qs.n_gn) {
+    GnCoefArgs q;
+    N3D_PICK8(qs.g, i, q);
+    gn_coeffs_body(q, C, G, count, eps);
+  } else {
+    SeTerm q;
+    N3D_PICK8(qs.s, i - qs.n_gn, q);
+    se_gate_fwd_body(q.sums, q.rows, count, q.w1, q.b1, q.w2, q.b2, C, q.mean, q.hidden, q.gate);
+  }
+}
 
 __device__ __forceinline__ void se_gate_bwd_body(const double* __restrict__ sums, int rows, const float* __restrict__ wptr,
                                                  const float* __restrict__ mean, const float* __restrict__ hidden,
@@ -2856,6 +2870,25 @@ int n3d_se_gate_bwdN(const n3d_se_term* terms, int n, int64_t N, int B, int C, v
   if (int e = se_terms(terms, n, true, &ts, "se_gate_bwdN")) return e;
   if (B == 2) hipLaunchKernelGGL(se_gate_bwdN2_kernel, dim3(n), dim3(512), 0, (hipStream_t)stream, ts, C, (double)N);
   else hipLaunchKernelGGL(se_gate_bwdN_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, ts, B, C, (double)N);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_node_fwd_coeffs(const n3d_gn_fwd_term* gn, int n_gn, const n3d_se_term* se, int n_se, int B, int C, int G, int64_t N, float eps, void* stream) {
+  N3D_CHECK_ARG(gn && se && n_gn >= 1 && n_gn <= N3D_MAX_GROUP_TERMS && n_se >= 1 && n_se <= N3D_MAX_GROUP_TERMS && B > 0 && N > 0 && G >= 1 &&
+                C % G == 0 && C <= 64, "node_fwd_coeffs: 1..8 GroupNorm terms and 1..8 SE gates");
+  if (int e = check_group(n_gn, C, "node_fwd_coeffs")) return e;
+  NodeFwdCoefArgs qs;
+  qs.n_gn = n_gn;
+  for (int i = 0; i < 8; ++i) {
+    const n3d_gn_fwd_term* t = &gn[i < n_gn ? i : 0];
+    N3D_CHECK_ARG(t->stats && t->gamma && t->beta && t->a_out && t->b_out && t->rows >= 1, "node_fwd_coeffs: null GroupNorm term pointer");
+    qs.g[i] = GnCoefArgs{t->stats, t->rows, t->gamma, t->beta, t->a_out, t->b_out, t->mean_rstd_out, t->sumraw};
+  }
+  SeTermN ts;
+  if (int e = se_terms(se, n_se, false, &ts, "node_fwd_coeffs")) return e;
+  for (int i = 0; i < 8; ++i) qs.s[i] = ts.t[i];
+  hipLaunchKernelGGL(node_fwd_coeffs_kernel, dim3(B, n_gn + n_se), dim3(256), 0, (hipStream_t)stream, qs, C, G, (double)N, eps);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

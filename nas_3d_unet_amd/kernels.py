@@ -1005,6 +1005,39 @@ def gn_coeffsN(terms, G, eps):
     return saved
 
 
+def node_fwd_coeffs(gn_terms, G, eps, se_terms):
+    """gn_coeffsN(gn_terms, G, eps) and se_gate_fwdN(se_terms) -- the coefficient computations of one supernet node group -- in ONE
+    launch: gn_terms = [(raw, stats, rows, gamma, beta)], se_terms = [(stats, rows, fc)] on tensors of the same (B, C, N).
+    Returns ([(a, b, mean_rstd, sumraw)], [(mean, hidden, gate)])."""
+    n, m = len(gn_terms), len(se_terms)
+    raw0 = gn_terms[0][0]
+    _need_f32("node_fwd_coeffs", *[t[0] for t in gn_terms])
+    dev = raw0.t.device
+    B, Cc = raw0.B, raw0.C
+    fbuf = torch.empty((n, 2 * B * Cc + 2 * B * G), dtype=torch.float32, device=dev)
+    dbuf = torch.empty((n, B * Cc), dtype=torch.float64, device=dev)
+    arr = (GnFwdTerm * n)()
+    saved = []
+    for i, (raw, stats, rows, gamma, beta) in enumerate(gn_terms):
+        a = fbuf[i, :B * Cc].view(B, Cc)
+        b = fbuf[i, B * Cc:2 * B * Cc].view(B, Cc)
+        mr = fbuf[i, 2 * B * Cc:].view(B, G, 2)
+        sr = dbuf[i].view(B, Cc)
+        arr[i] = GnFwdTerm(raw.p.value, raw.ld, stats.data_ptr(), rows, 0, gamma.data_ptr(), beta.data_ptr(), None, a.data_ptr(),
+                           b.data_ptr(), mr.data_ptr(), sr.data_ptr())
+        saved.append((a, b, mr, sr))
+    buf = torch.empty((m, 2 * B * Cc + B), dtype=torch.float32, device=dev)
+    sarr = (SeTerm * m)()
+    out = []
+    for i, (stats, rows, fc) in enumerate(se_terms):
+        mean, gate, hidden = buf[i, :B * Cc].view(B, Cc), buf[i, B * Cc:2 * B * Cc].view(B, Cc), buf[i, 2 * B * Cc:]
+        sarr[i] = SeTerm(stats.data_ptr(), rows, 0, fc[0].weight.data_ptr(), fc[0].bias.data_ptr(), fc[2].weight.data_ptr(),
+                         fc[2].bias.data_ptr(), mean.data_ptr(), hidden.data_ptr(), gate.data_ptr(), *([None] * 8))
+        out.append((mean, hidden, gate))
+    check(_lib.load().n3d_node_fwd_coeffs(arr, n, sarr, m, B, Cc, G, raw0.N, eps, stream_ptr()), "n3d_node_fwd_coeffs")
+    return saved, out
+
+
 def affine_actN(terms, out: View, flags=0):
     """out (+)= sum_k w_k * act_k(a_k * raw_k + b_k) for up to 8 terms in one pass: terms = [(raw, a | None, b | None, wptr, relu)]."""
     n = len(terms)

@@ -11,6 +11,7 @@ autograd Functions can share them.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -908,6 +909,9 @@ def group_ok(segs):
             and all(g.norm.eps == segs[0].norm.eps for g in segs))
 
 
+NODE_FWD_COEFFS = os.environ.get("N3D_NODE_FWD_COEFFS", "1") != "0"   # (A/B knob) GroupNorm coefficients + SE gates of a group in one launch
+
+
 def group_forward(terms, out, accumulate):
     """Supernet node (cell.py:76-81): out (+)= sum_k alpha_k * op_k(x_k) for up to 8 primitives of any kind (GroupNorm-type
     convs, identity-with-norm, SE gates, pooling).  terms = [(segment, input View, alpha row | None, alpha column)].
@@ -1024,7 +1028,22 @@ def group_epilogue_phase(terms, res, out, accumulate):
             s.kind = "se"
             se.append((s, seg.se_gate.fc, r[0], (r[1], r[2]) if r[1] is not None else None))
         saved.append(s)
-    if len(se) == 1:
+    merged = False
+    if NODE_FWD_COEFFS and gn and se and len({(raw.B, raw.C, raw.N) for _, _, raw, _ in se} | {(g[1][0].B, g[1][0].C, g[1][0].N) for g in gn}) == 1:
+        # GroupNorm coefficients and SE gates of the group in ONE launch (the same bodies as gn_coeffsN / se_gate_fwdN)
+        eps = [seg.norm.eps for seg, _, _, _ in terms if seg.norm is not None]
+        if any(e != eps[0] for e in eps):
+            raise N3DError("group_forward: GroupNorm terms of one node with different eps")
+        sts = [st if st is not None else K.channel_stats(raw) for _, _, raw, st in se]
+        gout, sout = K.node_fwd_coeffs([g[1] for g in gn], gn[0][0].G, eps[0], [(st, rows, fc) for (st, rows), (_, fc, _, _) in zip(sts, se)])
+        for (s, _), (a, b, mr, sr) in zip(gn, gout):
+            s.a, s.b, s.mr, s.sumraw = a, b, mr, sr
+        for (s, _, _, _), (mean, hidden, gate) in zip(se, sout):
+            s.mean, s.hidden, s.a = mean, hidden, gate
+        merged = True
+    if merged:
+        pass
+    elif len(se) == 1:
         s, fc, raw, st = se[0]
         if st is None:
             st = K.channel_stats(raw)
@@ -1034,7 +1053,7 @@ def group_epilogue_phase(terms, res, out, accumulate):
         sts = [st if st is not None else K.channel_stats(raw) for _, _, raw, st in se]
         for (s, _, _, _), (mean, hidden, gate) in zip(se, K.se_gate_fwdN([(st, rows, fc) for (st, rows), (_, fc, _, _) in zip(sts, se)], raw0.N, raw0.B, raw0.C)):
             s.mean, s.hidden, s.a = mean, hidden, gate
-    if gn:
+    if gn and not merged:
         eps = [seg.norm.eps for seg, _, _, _ in terms if seg.norm is not None]
         if any(e != eps[0] for e in eps):
             raise N3DError("group_forward: GroupNorm terms of one node with different eps")
