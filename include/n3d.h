@@ -352,6 +352,12 @@ int n3d_affine_actN(const n3d_gn_fwd_term* terms, int n, float* out, int64_t old
 int n3d_affine_act_bwd_reduceN(const float* dout, int64_t dld, const n3d_gn_bwd_term* terms, int n, int B, int64_t N, int C, void* stream);
 int n3d_gn_bwd_coeffsN(const n3d_gn_bwd_term* terms, int n, int B, int C, int G, int64_t N, void* stream);
 int n3d_affine_act_bwd_applyN(const float* dout, int64_t dld, const n3d_gn_bwd_term* terms, int n, int B, int64_t N, int C, void* stream);
+/* The apply passes of a node level's single primitives (SE gates, identity-with-norm: cell.py:29-32) in ONE launch: every term is
+ * draw' = cA * g + cB + cC * raw (g = dout behind the term's ReLU mask a * raw + b > 0 when relu and a are set; NULL a / b / cA / cB / cC
+ * = 1 / 0 / 1 / 0 / 0); CONSECUTIVE terms with the same `draw` (at most 4) are summed into it in term order, on top of its previous
+ * content if bit 0 of the first term's `pad_` is set -- what n3d_affine_act_bwd_apply launches in that order would leave there.
+ * n <= N3D_MAX_REDUCE_TERMS terms, at most 8 distinct targets. */
+int n3d_affine_act_bwd_apply_sum(const float* dout, int64_t dld, const n3d_gn_bwd_term* terms, int n, int B, int64_t N, int C, void* stream);
 /* plain (no norm) epilogue backward coefficients: A = w, Bc = Cc = 0, dalpha = sum Sz */
 int n3d_plain_bwd_coeffs(const double* sums, int rows, const float* wptr, int B, int C, float* dalpha,
                          float* A, void* stream);

@@ -165,6 +165,7 @@ PROTOTYPES = {
     "n3d_se_gate_fwdN": (_i, [C.POINTER(SeTerm), _i, _i64, _i, _i, _p]),
     "n3d_se_gate_bwdN": (_i, [C.POINTER(SeTerm), _i, _i64, _i, _i, _p]),
     "n3d_node_bwd_coeffs": (_i, [_p, _i, _p, _i, _i, _i, _i, _i64, _p]),
+    "n3d_affine_act_bwd_apply_sum": (_i, [_p, _i64, _p, _i, _i, _i64, _i, _p]),
     "n3d_node_fwd_coeffs": (_i, [_p, _i, _p, _i, _i, _i, _i, _i64, _f, _p]),
     "n3d_channel_statsN": (_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), _i, _i, _i64, _i, _p]),
     "n3d_gn_coeffsN": (_i, [C.POINTER(GnFwdTerm), _i, _i, _i, _i, _i64, C.c_float, _p]),

@@ -1751,6 +1751,72 @@ __global__ __launch_bounds__(256) void affine_bwd_applyN_kernel(const float* __r
   }
 }
 
+// The apply passes of a node level's SINGLE primitives (SE gates, identity-with-norm) in one launch: grid (rows, B, targets); a target is an
+// input-gradient tensor and takes the sum of 1..4 terms -- x = t_0 (+ previous content); x = t_k + x -- i.e. exactly what the separate
+// launches of affine_bwd_apply_kernel leave behind, in the same order (terms of different targets never meet).
+struct ApplySumArgs { BwdApplyTerm t[N3D_MAX_REDUCE_TERMS]; int start[8], count[8], acc[8]; };
+__global__ __launch_bounds__(256) void affine_bwd_apply_sum_kernel(const float* __restrict__ dout, int64_t dld, ApplySumArgs ts, int64_t N, int C,
+                                                                   EwMap m) { N3D_CHAIN_PRIO();
+  int start, count, acc;
+  N3D_PICK8(ts.start, blockIdx.z, start);
+  N3D_PICK8(ts.count, blockIdx.z, count);
+  N3D_PICK8(ts.acc, blockIdx.z, acc);
+  const int b = blockIdx.y, t = threadIdx.x;
+  const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
+  if (vl >= m.vpb) return;
+  const int64_t v0 = (int64_t)blockIdx.x * m.vpc + vl;
+  if (v0 >= N) return;
+  const int co = b * C + c4 * 4;
+  const float* db = dout + (int64_t)b * N * dld + c4 * 4;
+  BwdApplyTerm tm[4];
+  float4 fa[4], fb[4], qA[4], qB[4], qC[4];
+  float thr[4];
+  bool mask[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    N3D_PICK16(ts.t, start + (k < count ? k : 0), tm[k]);
+    mask[k] = tm[k].relu && tm[k].a;
+    fa[k] = tm[k].a ? ld4(tm[k].a + co) : make_float4(1.f, 1.f, 1.f, 1.f);
+    fb[k] = tm[k].b ? ld4(tm[k].b + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    qA[k] = tm[k].cA ? ld4(tm[k].cA + co) : make_float4(1.f, 1.f, 1.f, 1.f);
+    qB[k] = tm[k].cB ? ld4(tm[k].cB + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    qC[k] = tm[k].cC ? ld4(tm[k].cC + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    thr[k] = 0.f;
+  }
+  float* ob = tm[0].draw + (int64_t)b * N * tm[0].drld + c4 * 4;
+  for (int it = 0; it < m.iters; ++it) {
+    const int64_t v = v0 + (int64_t)it * m.vpb;
+    if (v >= N) break;
+    const float4 dq = ld4(db + v * dld);
+    float4 rq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < count) rq[k] = ld4(tm[k].raw + (int64_t)b * N * tm[k].rld + c4 * 4 + v * tm[k].rld);
+    float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (acc) pq = ld4(ob + v * tm[0].drld);
+    const float d[4] = {dq.x, dq.y, dq.z, dq.w};
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < count) {
+        const float r[4] = {rq[k].x, rq[k].y, rq[k].z, rq[k].w};
+        const float a4[4] = {fa[k].x, fa[k].y, fa[k].z, fa[k].w}, b4[4] = {fb[k].x, fb[k].y, fb[k].z, fb[k].w};
+        const float A4[4] = {qA[k].x, qA[k].y, qA[k].z, qA[k].w}, B4[4] = {qB[k].x, qB[k].y, qB[k].z, qB[k].w}, C4[4] = {qC[k].x, qC[k].y, qC[k].z, qC[k].w};
+        const float p4[4] = {pq.x, pq.y, pq.z, pq.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float g = d[j];
+          if (mask[k]) { const float z = fmaf(a4[j], r[j], b4[j]); g = z > thr[k] ? g : 0.f; }
+          float o = fmaf(A4[j], g, fmaf(C4[j], r[j], B4[j]));
+          if (k == 0) { if (acc) o += p4[j]; x[j] = o; }
+          else x[j] = o + x[j];
+        }
+      }
+    }
+    st4(ob + v * tm[0].drld, make_float4(x[0], x[1], x[2], x[3]));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // SE gate
 // ------------------------------------------------------------------------------------------------
@@ -2767,6 +2833,39 @@ int n3d_affine_act_bwd_applyN(const float* dout, int64_t dld, const n3d_gn_bwd_t
   }
   EwMap m = ew_map(N, C);
   hipLaunchKernelGGL(affine_bwd_applyN_kernel, dim3(m.rows, B, n), dim3(256), 0, (hipStream_t)stream, dout, dld, ts, N, C, m);
+  N3D_LAUNCH_CHECK();
+  return N3D_OK;
+}
+
+int n3d_affine_act_bwd_apply_sum(const float* dout, int64_t dld, const n3d_gn_bwd_term* terms, int n, int B, int64_t N, int C, void* stream) {
+  N3D_CHECK_ARG(dout && terms && n >= 1 && n <= N3D_MAX_REDUCE_TERMS && B > 0 && N > 0, "affine_act_bwd_apply_sum: 1..16 terms");
+  if (int e = check_group(1, C, "affine_act_bwd_apply_sum")) return e;
+  if (int e = check_vec(dout, dld, C, "bwd_apply_sum(dout)")) return e;
+  ApplySumArgs ts;
+  int nt = 0;
+  for (int i = 0; i < 8; ++i) ts.start[i] = ts.count[i] = ts.acc[i] = 0;
+  for (int i = 0; i < N3D_MAX_REDUCE_TERMS; ++i) {
+    const n3d_gn_bwd_term* t = &terms[i < n ? i : 0];
+    N3D_CHECK_ARG(t->raw && t->draw, "affine_act_bwd_apply_sum: null term pointer");   // a / b / cA / cB / cC may be NULL: 1 / 0 / 1 / 0 / 0
+    if (int e = check_vec(t->raw, t->rld, C, "bwd_apply_sum(raw)")) return e;
+    if (int e = check_vec(t->draw, t->drld, C, "bwd_apply_sum(target)")) return e;
+    ts.t[i] = BwdApplyTerm{t->raw, t->rld, t->a, t->b, t->cA, t->cB, t->cC, t->draw, t->drld, t->relu};
+    if (i < n) {
+      if (i > 0 && terms[i - 1].draw == t->draw) {
+        N3D_CHECK_ARG(ts.count[nt - 1] < 4 && terms[i - 1].drld == t->drld, "affine_act_bwd_apply_sum: at most 4 terms per target, one pitch");
+        ++ts.count[nt - 1];
+      } else {
+        N3D_CHECK_ARG(nt < 8, "affine_act_bwd_apply_sum: at most 8 targets");
+        ts.start[nt] = i; ts.count[nt] = 1; ts.acc[nt] = t->pad_ & 1;
+        ++nt;
+      }
+    }
+  }
+  for (int i = 0; i < nt; ++i)
+    for (int j = 0; j < i; ++j)
+      N3D_CHECK_ARG(terms[ts.start[i]].draw != terms[ts.start[j]].draw, "affine_act_bwd_apply_sum: the terms of a target must be consecutive");
+  EwMap m = ew_map(N, C);
+  hipLaunchKernelGGL(affine_bwd_apply_sum_kernel, dim3(m.rows, B, nt), dim3(256), 0, (hipStream_t)stream, dout, dld, ts, N, C, m);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

@@ -198,6 +198,7 @@ PLANAR_OUT = False
 # side stream's part of their node.  SIDE_FWD: .fork() main stores a flag, returns its id; .side(wait_id) context manager: launches
 # go to the side stream behind a wait on that flag; .side_signal() side stores a flag, returns its id; .join(id) main waits for it.
 SIDE_FWD = None
+NODE_APPLY = os.environ.get("N3D_NODE_APPLY", "1") != "0"     # ... and one apply launch for the level's SE gates and identity primitives (A/B knob)
 NODE_PHASES = os.environ.get("N3D_NODE_PHASES", "1") != "0"   # one reduction + one coefficient launch per node level of the supernet backward (A/B knob)
 SIDE_BWD = None      # the same object while the backward pass of a supernet may use the side stream (see _run_backward_impl)
 SIDE_NODE0_SPLIT = __import__("os").environ.get("N3D_SIDE_NODE0", "main") == "split"   # node 0: both edges on the main stream (one of them on the side stream measured 0.1 ms slower per search step)
@@ -579,7 +580,7 @@ def _run_backward_nodes(plan, st, dnodes, alpha1, alpha2, need_x0, need_x1, want
             """backward of the terms in `node_units` (units of ONE node, all of them or the subset one stream handles)"""
             # the primitives that stay single (identity, SE gates, pooling) all start with a reduction pass over the same node
             # gradient: those passes run up to eight per launch
-            pre, pre_se, pre_da, prep = {}, {}, set(), {}
+            pre, pre_se, pre_da, prep, done = {}, {}, set(), {}, {}
             if batch_reduce:
                 want = []
                 for unit in node_units:
@@ -610,11 +611,59 @@ def _run_backward_nodes(plan, st, dnodes, alpha1, alpha2, need_x0, need_x1, want
                             s = st.saved[fi]
                             gate_specs.append((k, dict(wptr=P._wptr(arow, col), mean=s.mean, hidden=s.hidden, gate=s.a, fc=seg.se_gate.fc,
                                                        dalpha_ptr=(dal.data_ptr() + 4 * col) if dal is not None else None)))
-                    rs, ses = K.node_bwd_prologue(dnodes[node], [prep[u] for u in group_units], [c[1] for c in want], gate_specs)
+                    ident_specs = []
+                    if NODE_APPLY:
+                        for k, (fi, _) in enumerate(want):
+                            _, _, seg, col, amat, row = flat[fi]
+                            s = st.saved[fi]
+                            if s.kind == "gn" and isinstance(seg.weight, P.IdentityW) and s.G == prep[group_units[0]].G:
+                                arow, dal = alpha_of(amat, row)
+                                ident_specs.append((k, dict(gamma=seg.norm.weight, beta=seg.norm.bias, mr=s.mr, wptr=P._wptr(arow, col),
+                                                            dalpha_ptr=(dal.data_ptr() + 4 * col) if dal is not None else None)))
+                    rs, ses, ids = K.node_bwd_prologue(dnodes[node], [prep[u] for u in group_units], [c[1] for c in want], gate_specs, ident_specs)
                     for (fi, _), r in zip(want, rs):
                         pre[fi] = r
                     for (k, _), r in zip(gate_specs, ses):
                         pre_se[want[k][0]] = r
+                    if NODE_APPLY:
+                        # the apply passes of the SE gates and identity primitives: ONE launch, in the reverse walk's order per target
+                        pre_id = {want[k][0]: r for (k, _), r in zip(ident_specs, ids) if r is not None}
+                        items, outs = [], []
+                        snap = list(pre_started)
+                        for unit in reversed(node_units):
+                            if len(unit) != 1 or (unit[0] not in pre_se and unit[0] not in pre_id):
+                                continue
+                            fi = unit[0]
+                            _, idx, seg, col, amat, row = flat[fi]
+                            s = st.saved[fi]
+                            target, acc = tgt(idx)
+                            if fi in pre_se:
+                                dw1, db1, dw2, db2, A, Bc = pre_se[fi]
+                                items.append((s.raw, None, None, False, A, Bc, None, target, acc))
+                                outs.append((fi, seg, target, [dw1, db1, dw2, db2]))
+                            else:
+                                dgamma, dbeta, cA, cB, cC = pre_id[fi]
+                                items.append((s.raw, s.a, s.b, seg.relu_out, cA, cB, cC, target, acc))
+                                outs.append((fi, seg, target, [dgamma, dbeta]))
+                        # (a target's terms must be consecutive for the launch: they are -- a target is one edge's input gradient and an
+                        # edge's single primitives are neighbours in the walk; anything else falls back to the per-primitive path)
+                        ok = len(items) >= 2 and len(items) <= K.MAX_REDUCE_TERMS
+                        if ok:
+                            seen, last = set(), None
+                            per = {}
+                            for it in items:
+                                key = it[7].p.value
+                                if key != last and key in seen:
+                                    ok = False
+                                seen.add(key); last = key
+                                per[key] = per.get(key, 0) + 1
+                            ok = ok and len(per) <= 8 and max(per.values()) <= 4
+                        if ok:
+                            K.node_bwd_apply_sum(dnodes[node], items)
+                            for fi, seg, target, gl in outs:
+                                done[fi] = (seg, gl)
+                        else:
+                            pre_started[:] = snap      # nothing was written: the per-primitive path claims the targets itself
                 else:
                     for i in range(0, len(want), K.MAX_GROUP_TERMS):
                         chunk = want[i:i + K.MAX_GROUP_TERMS]
@@ -653,6 +702,9 @@ def _run_backward_nodes(plan, st, dnodes, alpha1, alpha2, need_x0, need_x1, want
             skip = set()
             for ui, unit in enumerate(rev):
                 if ui in skip:
+                    continue
+                if len(unit) == 1 and unit[0] in done:      # its apply pass ran in the node level's merged launch (NODE_APPLY)
+                    put(*done[unit[0]])
                     continue
                 # the average and the max pooling of one edge (two single units next to each other): one pass over the input gradient
                 if len(unit) == 1 and ui + 1 < len(rev) and len(rev[ui + 1]) == 1:

@@ -1101,12 +1101,15 @@ def affine_act_bwd_gnN(dout: View, terms, G):
 MAX_REDUCE_TERMS = 16      # N3D_MAX_REDUCE_TERMS
 
 
-def node_bwd_prologue(dout: View, groups, singles, gates):
+def node_bwd_prologue(dout: View, groups, singles, gates, idents=()):
     """The reduction and coefficient phases of ONE node level of the supernet backward, two launches for everything that consumes the
     node gradient `dout`: groups = [GnGroupBwd] (their apply() is left to the caller), singles = [(raw, a | None, b | None, relu)] =
     the reductions of the node's other primitives (affine_act_bwd_reduceN), gates = [(index into singles, dict(wptr, mean, hidden,
-    gate, fc, dalpha_ptr))] = the SE gates among them (se_gate_bwdN).  Returns ([(sums, rows)] per single, [(dw1, db1, dw2, db2, A,
-    Bc)] per gate).  More than 16 reductions / 16 GroupNorm terms / 8 gates: the phases fall back to one launch per group."""
+    gate, fc, dalpha_ptr))] = the SE gates among them (se_gate_bwdN), idents = [(index into singles, dict(gamma, beta, mr, wptr,
+    dalpha_ptr))] = identity-with-norm primitives whose GroupNorm coefficients join the groups' launch (they are dropped, i.e. left
+    to their own fused kernel, when the launch has no room).  Returns ([(sums, rows)] per single, [(dw1, db1, dw2, db2, A, Bc)] per
+    gate, [(dgamma, dbeta, cA, cB, cC) | None] per ident).  More than 16 reductions / 16 GroupNorm terms / 8 gates: the phases fall
+    back to one launch per group."""
     lib = _lib.load()
     g0 = groups[0]
     B, Cc, N, dev = g0.B, g0.C, g0.N, dout.t.device
@@ -1153,14 +1156,26 @@ def node_bwd_prologue(dout: View, groups, singles, gates):
                                db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), _vp(t.get("dalpha_ptr")), coef[i, 0].data_ptr(), coef[i, 1].data_ptr())
             se_out.append((dw1, db1, dw2, db2, coef[i, 0], coef[i, 1]))
     same_g = len({g.G for g in groups}) == 1
+    id_out = [None] * len(idents)
     if same_g and ngn <= MAX_REDUCE_TERMS and len(gates) <= MAX_GROUP_TERMS:
-        garr = (GnBwdTerm * ngn)()
+        nid = min(len(idents), MAX_REDUCE_TERMS - ngn)
+        garr = (GnBwdTerm * (ngn + nid))()
         k = 0
         for g in groups:
             for i in range(g.n):
                 garr[k] = g.arr[i]
                 k += 1
-        check(lib.n3d_node_bwd_coeffs(garr, ngn, se_arr, len(gates), B, Cc, g0.G, N, stream_ptr()), "n3d_node_bwd_coeffs")
+        if nid:
+            icoef = torch.empty((nid, 3, B, Cc), dtype=torch.float32, device=dev)
+            for i, (si, t) in enumerate(idents[:nid]):
+                dgamma, dbeta = grad_target(t["gamma"]), grad_target(t["beta"])
+                dgamma = dgamma if dgamma is not None else torch.empty((Cc,), dtype=torch.float32, device=dev)
+                dbeta = dbeta if dbeta is not None else torch.empty((Cc,), dtype=torch.float32, device=dev)
+                garr[k + i] = GnBwdTerm(None, 0, None, None, ssum[si].data_ptr(), rows, 0, t["gamma"].data_ptr(), t["mr"].data_ptr(), _vp(t.get("wptr")),
+                                        None, None, 0, dgamma.data_ptr(), dbeta.data_ptr(), _vp(t.get("dalpha_ptr")), None,
+                                        *[icoef[i, j].data_ptr() for j in range(3)])
+                id_out[i] = (dgamma, dbeta, icoef[i, 0], icoef[i, 1], icoef[i, 2])
+        check(lib.n3d_node_bwd_coeffs(garr, ngn + nid, se_arr, len(gates), B, Cc, g0.G, N, stream_ptr()), "n3d_node_bwd_coeffs")
     else:
         for g in groups:
             g.coeffs()
@@ -1168,7 +1183,21 @@ def node_bwd_prologue(dout: View, groups, singles, gates):
             n = min(MAX_GROUP_TERMS, len(gates) - i0)
             sub = (SeTerm * n)(*[se_arr[i0 + i] for i in range(n)])
             check(lib.n3d_se_gate_bwdN(sub, n, N, B, Cc, stream_ptr()), "n3d_se_gate_bwdN")
-    return pre, se_out
+    return pre, se_out, id_out
+
+
+def node_bwd_apply_sum(dout: View, items):
+    """The apply passes of a node level's single primitives in ONE launch: items = [(raw, a | None, b | None, relu, cA, cB, cC | None,
+    target View, accumulate)] in issue order; consecutive items with the same target are summed into it in that order (the first one's
+    `accumulate` decides whether on top of its previous content) -- what K.affine_act_bwd_apply calls in that order would leave there."""
+    n = len(items)
+    raw0 = items[0][0]
+    _need_f32("node_bwd_apply_sum", dout, *[it[0] for it in items], *[it[7] for it in items])
+    arr = (GnBwdTerm * n)()
+    for i, (raw, a, b, relu, cA, cB, cC, target, acc) in enumerate(items):
+        arr[i] = GnBwdTerm(raw.p.value, raw.ld, _vp(a), _vp(b), None, 0, 1 if relu else 0, None, None, None, None, target.p.value, target.ld,
+                           None, None, None, None, _vp(cA), _vp(cB), _vp(cC), 0, 1 if acc else 0)
+    check(_lib.load().n3d_affine_act_bwd_apply_sum(dout.p, dout.ld, arr, n, raw0.B, raw0.N, raw0.C, stream_ptr()), "n3d_affine_act_bwd_apply_sum")
 
 
 def affine_act_bwd_reduceN(dout: View, terms):
