@@ -1468,7 +1468,11 @@ class SearchTrainer:
         self._side_active = True     # _pass: use the side stream (when there is one)
         self.side_forward = os.environ.get("N3D_SIDE_FORWARD", "1") != "0"   # ... also for the off-chain edges of the forward passes
         self.side_backward = os.environ.get("N3D_SIDE_BACKWARD", "1") != "0"  # ... and for the preprocess-fed edges of the backward passes
-        self.side_backward_inputs = tuple(int(c) for c in os.environ.get("N3D_SIDE_BACKWARD_IN", "01") if c.isdigit())   # (probe knob)
+        # which preprocess-fed edges the side stream takes in the backward: the second input's only (round 4; "01" = both until then --
+        # since the node levels' phases are single launches the chain absorbs the first input's terms in its own, wider, launches
+        # and the side stream's last node level -- which the chain waits for at the end of every cell -- is half as long:
+        # architecture pass 5.45 -> 5.25 ms, tools/search_phases.py)
+        self.side_backward_inputs = tuple(int(c) for c in os.environ.get("N3D_SIDE_BACKWARD_IN", "1") if c.isdigit())
         self.side_backward_weight = tuple(int(c) for c in os.environ.get("N3D_SIDE_BACKWARD_W", "") if c.isdigit())   # (weight pass: which ones; default none)
         self._use_side = False
         self.schedule_times = None
@@ -1489,10 +1493,11 @@ class SearchTrainer:
         self.ctx = K.StepContext(self.device)
         self.side = SideSchedule(self.device, self.ctx, wgrad_stream=True) if (self.side_wgrad and self.device.type == "cuda") else None
         if self.side is not None and "N3D_SIDE_TAIL_INLINE" not in os.environ:
-            # the weight pass' weight-gradient stream (219 launches) ends ~0.5 ms behind the chain: the last, third-last and fifth-last
-            # groups of the walk go to the inline side stream instead (weight pass 5.83 + 0.49 -> 5.97 + 0.17 ms; more groups there
-            # slow the chain by more than they take off the tail: tools/search_phases.py sweep)
-            self.side.tail_inline = (1, 3, 5)
+            # the weight pass' weight-gradient stream (219 launches) ends ~0.5 ms behind the chain: every other group of the walk's last
+            # eleven goes to the inline side stream instead, which has little else to do in the backward (weight pass 5.57 + 0.51 ->
+            # 5.78 + 0.09 ms; more groups there slow the chain by more than they take off the tail: tools/search_phases.py sweeps,
+            # DESIGN.md section 5)
+            self.side.tail_inline = (1, 3, 5, 7, 9, 11)
         if self.side is not None and self.side.stream is None:
             self.side = None
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
