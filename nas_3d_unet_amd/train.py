@@ -1563,6 +1563,8 @@ class SearchTrainer:
                 # 8.1 ms, with one 9.1 -- so its backward stays on one stream
                 # -- unless they run on a stream of their own (SideSchedule.split): then the weight pass does the same, 8.1 -> 7.1 ms
                 bwd_inputs = self.side_backward_inputs if (arch or (sided and self.side.split)) else self.side_backward_weight
+                if not arch and sided and self.side.split and os.environ.get("N3D_SIDE_BACKWARD_IN_W") is not None:   # (probe knob: the weight pass' own choice)
+                    bwd_inputs = tuple(int(c) for c in os.environ["N3D_SIDE_BACKWARD_IN_W"] if c.isdigit())
                 with (self.side.backward_mode(bwd_inputs) if (sided and self.side_backward and bwd_inputs) else contextlib.nullcontext()):
                     if sided and not arch:
                         with self.side.deferring():
