@@ -595,6 +595,11 @@ def _run_backward_nodes(plan, st, dnodes, alpha1, alpha2, need_x0, need_x1, want
                 # groups' terms and the single primitives', up to 16) and its coefficient computations another (GroupNorm terms and SE
                 # gates behind a per-workgroup switch) -- P.group_backward then only runs the apply pass and the weight ops
                 group_units = [u for u in node_units if len(u) >= 3] if NODE_PHASES else []
+                if group_units and NODE_APPLY:
+                    # a leftover PAIR of GroupNorm terms (the ninth and tenth of a node) rides in the same phases instead of its own
+                    # reduce2 + apply_gn2 launches
+                    group_units += [u for u in node_units if len(u) == 2 and all(st.saved[fi].kind == "gn" and P.gn_pairable(flat[fi][2]) for fi in u)
+                                    and st.saved[u[0]].G == st.saved[group_units[0][0]].G]
                 if group_units:
                     for u in group_units:
                         tl = []
@@ -723,7 +728,7 @@ def _run_backward_nodes(plan, st, dnodes, alpha1, alpha2, need_x0, need_x1, want
                         K.pool2_bwd_both(dnodes[node], st.saved[fa].ws.x, target, acc, wps[False], wps[True])
                         skip.add(ui + 1)
                         continue
-                if len(unit) >= 3:
+                if len(unit) >= 3 or unit in prep:
                     # targets are claimed in reverse term order, like the unpaired reverse walk
                     terms = []
                     for fi in reversed(unit):
