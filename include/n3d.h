@@ -346,7 +346,7 @@ int n3d_affine_act_bwd_apply2(const float* dout, int64_t dld, const float* dout1
  * n3d_gn_coeffsN: n x n3d_gn_coeffs in one launch.  n3d_affine_actN: out (+)= sum_k w_k * act_k(a_k * raw_k + b_k) in term
  * order, one pass over the node buffer; a_k = a_out, b_k = b_out of the term, NULL meaning 1 / 0, so the node's other
  * primitives (SE gate: a = gate; pooling, identity-with-norm) ride in the same pass.  Backward: n3d_affine_act_bwd_reduceN (fills sums of every term; all terms read the
- * same node gradient; a / b NULL = 1 / 0 as in n3d_affine_act_bwd_reduce, so the other primitives' reductions ride along; this entry takes up to N3D_MAX_REDUCE_TERMS terms), n3d_gn_bwd_coeffsN (cA / cB / cC and the parameter gradients), n3d_affine_act_bwd_applyN (every draw). */
+ * same node gradient; a / b NULL = 1 / 0 as in n3d_affine_act_bwd_reduce, so the other primitives' reductions ride along; this entry and n3d_affine_act_bwd_applyN take up to N3D_MAX_REDUCE_TERMS terms), n3d_gn_bwd_coeffsN (cA / cB / cC and the parameter gradients), n3d_affine_act_bwd_applyN (every draw). */
 int n3d_gn_coeffsN(const n3d_gn_fwd_term* terms, int n, int B, int C, int G, int64_t N, float eps, void* stream);
 int n3d_affine_actN(const n3d_gn_fwd_term* terms, int n, float* out, int64_t old_, int B, int64_t N, int C, int flags, void* stream);
 int n3d_affine_act_bwd_reduceN(const float* dout, int64_t dld, const n3d_gn_bwd_term* terms, int n, int B, int64_t N, int C, void* stream);

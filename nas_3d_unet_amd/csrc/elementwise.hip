@@ -1709,12 +1709,12 @@ __global__ __launch_bounds__(256) void affine_bwd_reduceN_kernel(const float* __
 
 struct BwdApplyTerm { const float* raw; int64_t rld; const float* a; const float* b; const float* cA; const float* cB; const float* cC;
                       float* draw; int64_t drld; int relu; };
-struct BwdApplyTermN { BwdApplyTerm t[8]; };
+struct BwdApplyTermN { BwdApplyTerm t[N3D_MAX_REDUCE_TERMS]; };
 // grid (rows, B, terms): draw = cA * g + cB + cC * raw of term blockIdx.z (g = dout behind the term's ReLU mask)
 __global__ __launch_bounds__(256) void affine_bwd_applyN_kernel(const float* __restrict__ dout, int64_t dld, BwdApplyTermN ts, int64_t N, int C,
                                                                 EwMap m) { N3D_CHAIN_PRIO();
   BwdApplyTerm tm;
-  N3D_PICK8(ts.t, blockIdx.z, tm);
+  N3D_PICK16(ts.t, blockIdx.z, tm);
   const int b = blockIdx.y, t = threadIdx.x;
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   if (vl >= m.vpb) return;
@@ -2820,11 +2820,11 @@ int n3d_gn_bwd_coeffsN(const n3d_gn_bwd_term* terms, int n, int B, int C, int G,
 }
 
 int n3d_affine_act_bwd_applyN(const float* dout, int64_t dld, const n3d_gn_bwd_term* terms, int n, int B, int64_t N, int C, void* stream) {
-  N3D_CHECK_ARG(dout && terms && B > 0 && N > 0, "affine_act_bwd_applyN: bad args");
-  if (int e = check_group(n, C, "affine_act_bwd_applyN")) return e;
+  N3D_CHECK_ARG(dout && terms && B > 0 && N > 0 && n >= 1 && n <= N3D_MAX_REDUCE_TERMS, "affine_act_bwd_applyN: bad args (1..16 terms)");
+  if (int e = check_group(1, C, "affine_act_bwd_applyN")) return e;
   if (int e = check_vec(dout, dld, C, "bwd_applyN(dout)")) return e;
   BwdApplyTermN ts;
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < N3D_MAX_REDUCE_TERMS; ++i) {
     const n3d_gn_bwd_term* t = &terms[i < n ? i : 0];
     N3D_CHECK_ARG(t->raw && t->a && t->b && t->cA && t->cB && t->cC && t->draw, "affine_act_bwd_applyN: null term pointer");
     if (int e = check_vec(t->raw, t->rld, C, "bwd_applyN(raw)")) return e;

@@ -1084,6 +1084,8 @@ class GnGroupBwd:
         check(_lib.load().n3d_gn_bwd_coeffsN(self.arr, self.n, self.B, self.C, self.G, self.N, stream_ptr()), "n3d_gn_bwd_coeffsN")
 
     def apply(self):
+        if getattr(self, "applied", False):      # (ran in node_bwd_prologue's launch for all groups of the level)
+            return
         check(_lib.load().n3d_affine_act_bwd_applyN(self.dout.p, self.dout.ld, self.arr, self.n, self.B, self.N, self.C, stream_ptr()),
               "n3d_affine_act_bwd_applyN")
 
@@ -1118,26 +1120,14 @@ def node_bwd_prologue(dout: View, groups, singles, gates, idents=()):
     _need_f32("node_bwd_prologue", dout, *[t[0] for t in singles])
     ssum = torch.empty((max(ns, 1), B, rows, Cc, 3), dtype=torch.float64, device=dev)
     ngn = sum(g.n for g in groups)
-    # ---- reductions
-    if ngn + ns <= MAX_REDUCE_TERMS:
-        arr = (GnBwdTerm * (ngn + ns))()
-        k = 0
-        for g in groups:
-            for i in range(g.n):
-                arr[k] = g.arr[i]
-                k += 1
-        for i, (raw, a, b, relu) in enumerate(singles):
-            arr[k + i] = GnBwdTerm(raw.p.value, raw.ld, _vp(a), _vp(b), ssum[i].data_ptr(), rows, 1 if relu else 0, *([None] * 4), None, 0, *([None] * 7))
-        check(lib.n3d_affine_act_bwd_reduceN(dout.p, dout.ld, arr, ngn + ns, B, N, Cc, stream_ptr()), "n3d_affine_act_bwd_reduceN")
-    else:
-        for g in groups:
-            g.reduce()
-        for i0 in range(0, ns, MAX_REDUCE_TERMS):
-            chunk = singles[i0:i0 + MAX_REDUCE_TERMS]
-            arr = (GnBwdTerm * len(chunk))()
-            for i, (raw, a, b, relu) in enumerate(chunk):
-                arr[i] = GnBwdTerm(raw.p.value, raw.ld, _vp(a), _vp(b), ssum[i0 + i].data_ptr(), rows, 1 if relu else 0, *([None] * 4), None, 0, *([None] * 7))
-            check(lib.n3d_affine_act_bwd_reduceN(dout.p, dout.ld, arr, len(chunk), B, N, Cc, stream_ptr()), "n3d_affine_act_bwd_reduceN")
+    # ---- reductions: every term of the level, 16 per launch
+    allt = [g.arr[i] for g in groups for i in range(g.n)]
+    for i, (raw, a, b, relu) in enumerate(singles):
+        allt.append(GnBwdTerm(raw.p.value, raw.ld, _vp(a), _vp(b), ssum[i].data_ptr(), rows, 1 if relu else 0, *([None] * 4), None, 0, *([None] * 7)))
+    for i0 in range(0, len(allt), MAX_REDUCE_TERMS):
+        chunk = allt[i0:i0 + MAX_REDUCE_TERMS]
+        arr = (GnBwdTerm * len(chunk))(*chunk)
+        check(lib.n3d_affine_act_bwd_reduceN(dout.p, dout.ld, arr, len(chunk), B, N, Cc, stream_ptr()), "n3d_affine_act_bwd_reduceN")
     pre = [(ssum[i], rows) for i in range(ns)]
     # ---- coefficients
     se_arr, se_out = None, []
@@ -1183,6 +1173,12 @@ def node_bwd_prologue(dout: View, groups, singles, gates, idents=()):
             n = min(MAX_GROUP_TERMS, len(gates) - i0)
             sub = (SeTerm * n)(*[se_arr[i0 + i] for i in range(n)])
             check(lib.n3d_se_gate_bwdN(sub, n, N, B, Cc, stream_ptr()), "n3d_se_gate_bwdN")
+    # ---- the groups' apply passes in ONE launch where they fit (their d(raw) buffers are what the weight ops read later)
+    if len(groups) >= 2 and ngn <= MAX_REDUCE_TERMS:
+        garr = (GnBwdTerm * ngn)(*[g.arr[i] for g in groups for i in range(g.n)])
+        check(lib.n3d_affine_act_bwd_applyN(dout.p, dout.ld, garr, ngn, B, N, Cc, stream_ptr()), "n3d_affine_act_bwd_applyN")
+        for g in groups:
+            g.applied = True
     return pre, se_out, id_out
 
 
