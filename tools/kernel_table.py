@@ -137,6 +137,15 @@ def describe(name, args):
                     ff, bb = _conv_cost(g, "bwd_data", 0)
                 sig.append(_gtuple(g)); f += ff; b += bb
             return tuple(sig), f, b
+        if name == "n3d_conv_fwdN":
+            calls, n = args[0], v[1]
+            sig, f, b = [name], 0, 0
+            for i in range(n):
+                c = calls[i]
+                g = c.g.contents
+                ff, bb = _conv_cost(g, "fwdT" if c.transposed else "fwd", c.flags)
+                sig.append(_gtuple(g)); f += ff; b += bb
+            return tuple(sig), f, b
         if name == "n3d_affine_act_gn2":
             B, N, Cc, fl = v[8], v[9], v[10], v[11]
             return (name, B, N, Cc, fl & 0x44, bool(v[6])), *ew(B, N, Cc, 4 if v[6] else 3, fl & _lib.ACT_BF16)
