@@ -180,6 +180,41 @@ def test_side_schedule_is_reproducible_run_to_run(size):
     assert torch.equal(flats[0], flats[1])
 
 
+def test_one_slow_sample_does_not_retire_the_side_schedule():
+    """the replay monitor (every 256th step bracketed with events): a single slow sample -- the bracket also holds whatever the host did
+    between the graph launches -- is measured again; only three slow samples in a row drop the side schedule for the plain graph"""
+    import warnings
+    from nas_3d_unet_amd.train import Trainer
+    x, t = _batch(53)
+    net, _ = build_net("searched", "G_CONV", 4)
+    tr = Trainer(net, graph=True, side_wgrad="force")
+    for _ in range(3):
+        tr.step(x, t)
+    assert tr._use_side
+    real = tr.schedule_times
+    tr.schedule_times = (1e-9, 1e-9)      # every sample now counts as slow against this "plain graph time"
+    tr.side.replays = 255                  # the next replay is a sampled one
+    tr.step(x, t)                          # sampled (slow sample 1) ...
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        tr.step(x, t)                      # ... evaluated here: slow -> measured again, nothing dropped
+        assert tr._use_side and tr.side.recheck == 1
+        tr.schedule_times = real
+        tr.step(x, t)                      # the re-measurement (an honest sample) ...
+        tr.step(x, t)                      # ... evaluated: fine again
+    assert tr._use_side and tr.side.recheck == 0 and tr.side.slow_run == 0
+    # three slow samples in a row do retire it
+    tr.schedule_times = (1e-9, 1e-9)
+    tr.side.replays = 255
+    with pytest.warns(UserWarning, match="degraded"):
+        for _ in range(7):
+            tr.step(x, t)
+    assert not tr._use_side
+    l = float(tr.step(x, t))               # the plain graph takes over
+    assert np.isfinite(l)
+    tr.check_sync()
+
+
 def test_schedule_choice_leaves_the_state_alone():
     """the default trainer times both captured schedules on the real step at capture time: weights, Adam moments, step counters
     and the Dropout3d generator must come out of that exactly as they went in"""
