@@ -1227,11 +1227,12 @@ class SegmentFn(torch.autograd.Function):
 # to the nn.Dropout3d module, so a captured HIP graph draws a fresh mask on every replay and no torch RNG kernel runs.
 _forced_gate = None
 _drop_serial = [0]
+PASS_TAG = None      # "arch" / "weight" while a SearchTrainer pass runs (a forced gate may differ between the two)
 
 
 class forced_dropout_gate:
     """with forced_dropout_gate(g): every Dropout3d inside uses the given (B, C) gate tensor (parity tests feed the mask
-    the CPU oracle used).  g = None: dropout off."""
+    the CPU oracle used).  g = None: dropout off.  g = {"arch": ga, "weight": gw}: the search step's two passes use one each."""
 
     def __init__(self, gate):
         self.gate = gate
@@ -1266,7 +1267,8 @@ def dropout_state(drop, device, seed=None):
 def draw_gate(drop, training, B, Cc, device):
     """the Dropout3d gate of this call: None (inactive), the forced one, or a fresh draw"""
     if _forced_gate is not None:
-        return _forced_gate[0]
+        g = _forced_gate[0]
+        return g[PASS_TAG] if isinstance(g, dict) else g
     if drop is None or not training or drop.p <= 0:
         return None
     return K.dropout3d_gate(dropout_state(drop, device), drop.p, B, Cc)

@@ -290,7 +290,7 @@ def _let_comm_watchdog_retire(dp):
     caching allocator -- on its own 100 ms poll, i.e. possibly in the middle of the capture.  One poll interval of patience keeps the
     runtime's other thread idle while three streams are being captured.  (Round 4: a run of the GPU suite in eight aborted from a
     runtime thread -- no Python frame, no message -- exactly inside the first bucketed data-parallel capture.)"""
-    if dp:
+    if dp and os.environ.get("N3D_DP_CAPTURE_SLEEP", "1") != "0":
         time.sleep(0.25)
 
 
@@ -1560,6 +1560,8 @@ class SearchTrainer:
         # with a side stream BOTH passes use it: the forward of either pass runs the off-chain edges of every supernet cell there
         # (fused._run_forward_side), the weight pass also queues its weight-gradient launches for it
         sided = self.side is not None and self._side_active
+        from . import programs as _P
+        _P.PASS_TAG = "arch" if arch else "weight"
         with K.step_context(self.ctx):
             if pack:
                 self.ctx.pack_all()

@@ -147,6 +147,31 @@ def search_batches(key, batch, size):
     return x, t, vx, vt
 
 
+def search_bench_case():
+    """BASELINE configs[2] as bench.py times it (search.py:211-238; nas.py:50-52 head Dropout3d(0.1) in train mode):
+    (key, depth, patch size, batch per pass, steps, dropout rate) -- fixture search64.npz"""
+    return ("search/d4s64/b2/drop", 4, 64, 2, 2, 0.1)
+
+
+def search_drop_gates(key, steps, batch, channels, p):
+    """the head's Dropout3d masks of a search run made explicit: gates[step][0 = architecture pass, 1 = weight pass], each a
+    (batch, channels) case_drop_gate with one to four dropped channels (the first salt that has them: at p = 0.1 a fresh draw
+    of 24 drops nothing 8 % of the time, and a mask that drops nothing tests nothing)"""
+    out = []
+    for s in range(steps):
+        row = []
+        for name in ("arch", "weight"):
+            for salt in range(64):
+                g = case_drop_gate("%s/step%d/%s/%d" % (key, s, name, salt), batch, channels, p)
+                if 1 <= int((g == 0).sum()) <= 4:
+                    break
+            else:
+                raise AssertionError("no usable gate")
+            row.append(g)
+        out.append(tuple(row))
+    return out
+
+
 def dice_cases():
     return [("dice/a", (2, 3, 4, 6, 8)), ("dice/b", (1, 3, 16, 16, 16)), ("dice/c", (3, 3, 2, 2, 2))]
 

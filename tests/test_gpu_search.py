@@ -96,6 +96,76 @@ def test_search_trajectory_depth4_matches_reference(golden, graph):
             assert abs(mine - ref) <= 1e-2 * ref + 2e-3 * total, (n, step, mine, ref)
 
 
+@pytest.mark.parametrize("schedule", ["single-stream", "side-stream"])
+def test_search_benchmarked_configuration_vs_reference(golden, schedule):
+    """BASELINE configs[2] in ONE piece at the benchmarked size, as bench.py times it: depth-4 supernet, 2 + 2 patches of 4x64^3
+    fp32, TRAIN mode (head Dropout3d(0.1), nas.py:50-52; the masks made explicit, one per pass), SearchTrainer(graph=True) pinned
+    to either schedule, against the trajectory the REFERENCE modules + two torch.optim.Adam produced (tests/golden/make_golden.py
+    gen_search64, search.py:211-238): alpha gradients element by element, both losses, small kernel-weight gradients of the first
+    weight pass element by element, every kernel-weight gradient norm, alphas after each step.  Tolerances: those of
+    test_search_trajectory_depth4_matches_reference."""
+    import golden_common as gc
+    from nas_3d_unet_amd import nas
+    from nas_3d_unet_amd.programs import forced_dropout_gate
+    from nas_3d_unet_amd.train import SearchTrainer
+    g = golden("search64")
+    key, depth, size, batch, steps, p = gc.search_bench_case()
+    cfg = orc.DEFAULT_CFG._replace(depth=depth)
+    net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)
+    fill_module(net)
+    assert abs(net.kernel.last_conv[0].dropout.p - p) < 1e-12
+    net = net.cuda()
+    net.train()
+    gates = gc.search_drop_gates(key, steps, batch, cfg.n_nodes * cfg.init_n_kernels, p)
+    assert all(0 < (ga == 0).sum() and 0 < (gw == 0).sum() for ga, gw in gates)     # real masks
+    ga, gw = torch.from_numpy(gates[0][0]).cuda(), torch.from_numpy(gates[0][1]).cuda()
+    tr = SearchTrainer(net, graph=True, side_wgrad="force" if schedule == "side-stream" else False)
+    x, t, vx, vt = (torch.from_numpy(a).cuda() for a in gc.search_batches(key, batch, size))
+    anames = ("alpha2_down", "alpha2_up", "alpha1_down", "alpha1_up")
+    with forced_dropout_gate({"arch": ga, "weight": gw}):
+        for step in range(steps):
+            ga.copy_(torch.from_numpy(gates[step][0]))      # the captured graphs read these two tensors
+            gw.copy_(torch.from_numpy(gates[step][1]))
+            la, lw = tr.step(x, t, vx, vt)
+            if schedule == "side-stream":
+                assert tr._use_side, "the side streams were not accepted on this box"
+            else:
+                assert not tr._use_side and tr.side is None
+            np.testing.assert_allclose([float(la), float(lw)], g["%s/step%d/losses" % (key, step)], rtol=0, atol=2e-5)
+            scale = max(np.abs(g["%s/step%d/dalpha/%s" % (key, step, n)]).max() for n in anames)
+            for n in anames:
+                ref = g["%s/step%d/dalpha/%s" % (key, step, n)]
+                mine = getattr(net, n).grad.detach().cpu().numpy()
+                tol = (5e-4 * np.abs(ref).max()) if step == 0 else 5e-3 * scale
+                assert np.abs(mine - ref).max() <= tol, (n, step, np.abs(mine - ref).max(), np.abs(ref).max())
+                unused = np.abs(ref).max(axis=1) == 0
+                assert np.array_equal(mine[unused], np.zeros_like(mine[unused]))
+                # the alphas after the step's Adam update: lr-sized moves, so a sign flip of a noise-level gradient is 2e-3
+                a_ref = g["%s/step%d/alpha/%s" % (key, step, n)]
+                assert np.abs(getattr(net, n).detach().cpu().numpy() - a_ref).max() <= 2.5e-3 * (step + 1), (n, step)
+            total = float(g["%s/step%d/gnorm_total" % (key, step)])
+            mine_total = float(torch.sqrt(sum((q.grad.double() ** 2).sum() for q in net.kernel.parameters())))
+            assert abs(mine_total - total) <= 5e-3 * total, (step, mine_total, total)
+            checked = 0
+            for n, q in net.kernel.named_parameters():
+                ref = float(g["%s/step%d/gnorm/kernel.%s" % (key, step, n)])
+                mine = float(q.grad.double().norm())
+                assert abs(mine - ref) <= 1e-2 * ref + 2e-3 * total, (n, step, mine, ref)
+                gk = "%s/step0/grad/kernel.%s" % (key, n)
+                if step == 0 and gk in g.files:
+                    # element by element (a norm cannot see a sign error): stems, preprocess convs and the head
+                    d = np.abs(q.grad.cpu().numpy() - g[gk]).max()
+                    assert d <= 1e-2 * np.abs(g[gk]).max() + 2e-4 * total, (n, d, np.abs(g[gk]).max())
+                    checked += 1
+            assert step > 0 or checked >= 8, checked
+        torch.cuda.synchronize()
+        tr.check_sync()
+    assert tr.sync_timeouts() == 0
+    for n, q in net.kernel.named_parameters():
+        ref = float(g["%s/final/pnorm/kernel.%s" % (key, n)])
+        assert abs(float(q.detach().double().norm()) - ref) <= 5e-4 * ref + 3e-3, n
+
+
 def test_search_step_with_shared_normal_alphas_matches_oracle():
     """normal_w_share=True (nas.py:109-113): alpha1_up IS alpha1_down, so its gradient collects the stride-1 edges of both the
     down and the up cells.  One search step through SearchTrainer against the oracle + torch.optim.Adam."""

@@ -271,3 +271,41 @@ def test_search_trajectory(golden):
         lw.backward()
         ok.step()
         np.testing.assert_allclose([float(la), float(lw)], g["%s/step%d/losses" % (key, step)], rtol=0, atol=2e-5)
+
+
+def test_search_benchmarked_size_first_step(golden):
+    """BASELINE configs[2] at the benchmarked size (2 + 2 patches of 4x64^3, depth 4, head Dropout3d(0.1) with explicit masks;
+    fixture search64.npz from the reference): the oracle's FIRST search step -- alpha gradients, both losses, the stored
+    kernel-weight gradients and every gradient norm of the weight pass.  (One step only: ~40 s of CPU.)"""
+    g = golden("search64")
+    key, depth, size, batch, steps, p = gc.search_bench_case()
+    cfg = orc.DEFAULT_CFG._replace(depth=depth)
+    P = orc.make_params(orc.supernet_param_specs(cfg), requires_grad=True)
+    x, t, vx, vt = (T(a) for a in gc.search_batches(key, batch, size))
+    ga, gw = (T(a) for a in gc.search_drop_gates(key, steps, batch, cfg.n_nodes * cfg.init_n_kernels, p)[0])
+    anames = ("alpha2_down", "alpha2_up", "alpha1_down", "alpha1_up")
+    oa = torch.optim.Adam([P[n] for n in anames])
+    la = orc.dice_loss(orc.supernet_forward(P, vx, cfg, drop_mask=ga), vt)
+    la.backward()
+    for n in anames:
+        close(P[n].grad, g["%s/step0/dalpha/%s" % (key, n)], rtol=2e-4)
+    oa.step()
+    for n in anames:
+        close(P[n].detach(), g["%s/step0/alpha/%s" % (key, n)], rtol=1e-5)
+    for q in P.values():
+        q.grad = None
+    lw = orc.dice_loss(orc.supernet_forward(P, x, cfg, drop_mask=gw), t)
+    lw.backward()
+    np.testing.assert_allclose([float(la), float(lw)], g["%s/step0/losses" % key], rtol=0, atol=2e-5)
+    total = float(g["%s/step0/gnorm_total" % key])
+    n_full = 0
+    for n, q in P.items():
+        if not n.startswith("kernel."):
+            continue
+        ref = float(g["%s/step0/gnorm/%s" % (key, n)])
+        assert abs(float(q.grad.double().norm()) - ref) <= 1e-3 * ref + 1e-4 * total, n
+        gk = "%s/step0/grad/%s" % (key, n)
+        if gk in g.files:
+            n_full += 1
+            assert np.abs(q.grad.numpy() - g[gk]).max() <= 1e-3 * np.abs(g[gk]).max() + 1e-5 * total, n
+    assert n_full >= 8
