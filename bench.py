@@ -314,7 +314,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip other_configs (search step and the 128^3 train steps, timed after the headline run)")
     ap.add_argument("--buckets", type=int, default=None, help="gradient buckets of the data-parallel exchange (default: N3D_DP_BUCKETS or 1); "
                     ">= 2: all-reduce of a bucket on a side stream under the backward of the next one")
-    ap.add_argument("--comm", choices=["torch", "rccl"], default=None, help="all-reduce through torch.distributed (default) or the C ABI's n3d_comm_*")
+    ap.add_argument("--comm", choices=["torch", "rccl"], default=None, help="gradient all-reduce through the C ABI's n3d_comm_* (default) or torch.distributed")
     ap.add_argument("--workload", choices=["train", "search"], default="train",
                     help="train: searched-net train step (BASELINE configs[1], the contract default); "
                          "search: supernet search step, arch pass + weight pass (configs[2]; informational, N=1 only)")
@@ -372,28 +372,28 @@ def main():
         bx, bt = trainer.input_buffers()
         bx.copy_(x); bt.copy_(t)
         x, t = bx, bt
-    if world > 1:
-        dist.barrier()
+    # the ranks meet through the trainers' own RCCL communicator (nas_3d_unet_amd.comm: ONE per process; torch.distributed only
+    # carries the rendezvous -- its NCCL backend never builds a communicator, i.e. no second set of RCCL queues next to the step's)
+    from nas_3d_unet_amd import comm as n3d_comm
+    cm = n3d_comm.for_group(None, device) if world > 1 else None
+    if cm is not None:
+        cm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(x, t)
-    if world > 1:
-        dist.barrier()
+    if cm is not None:
+        cm.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    if cm is not None:
+        dt = max(cm.gather_floats(dt))       # MAX over ranks
     final_loss = float(loss)
     # the side-stream schedule orders its streams with BOUNDED device-side waits; a wait that gave up withholds the update on the
     # device (n3d_adam_step_guarded) -- the line certifies that none did during the steps it reports (summed over the ranks)
     sync_timeouts = trainer.sync_timeouts()
-    if world > 1:
-        st = torch.tensor([float(sync_timeouts)], device=device, dtype=torch.float64)
-        dist.all_reduce(st, op=dist.ReduceOp.SUM)
-        sync_timeouts = int(st.item())
+    if cm is not None:
+        sync_timeouts = int(sum(cm.gather_floats(sync_timeouts)))
     trainer.check_sync()     # raises (no line) if a hand-off timed out
 
     if rank == 0:
@@ -443,7 +443,9 @@ def main():
             out["other_configs"] = other_configs(device, args.batch, args.no_graph)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
-        dist.barrier()
+        if cm is not None:
+            cm.barrier()
+        n3d_comm.close_all()
         dist.destroy_process_group()
 
 

@@ -499,6 +499,8 @@ int n3d_comm_available(void);
 int n3d_comm_unique_id(void* id_out /* N3D_COMM_ID_BYTES */);
 int n3d_comm_init(const void* id, int world, int rank, void** comm_out);
 int n3d_comm_allreduce_sum(void* comm, float* buf, int64_t n, void* stream);
+/* in-place broadcast of n floats from rank `root` (the one-off weight broadcast when a trainer is built), stream-ordered */
+int n3d_comm_broadcast(void* comm, float* buf, int64_t n, int root, void* stream);
 int n3d_comm_destroy(void* comm);
 
 /* ---- flat Adam (train.py:49,128; search.py:103-104,228,238): torch.optim.Adam defaults ------------

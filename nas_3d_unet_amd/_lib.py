@@ -203,6 +203,7 @@ PROTOTYPES = {
     "n3d_comm_unique_id": (_i, [_p]),
     "n3d_comm_init": (_i, [_p, _i, _i, C.POINTER(C.c_void_p)]),
     "n3d_comm_allreduce_sum": (_i, [_p, _p, _i64, _p]),
+    "n3d_comm_broadcast": (_i, [_p, _p, _i64, _i, _p]),
     "n3d_comm_destroy": (_i, [_p]),
     "n3d_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _f, _p, _i, _p]),
     "n3d_adam_step_guarded": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _f, _p, _i, _p, _p, _p, _p, _p, _p]),

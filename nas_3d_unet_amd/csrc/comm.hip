@@ -9,13 +9,14 @@
 
 namespace n3d {
 
-// the five entry points used, with RCCL's (= NCCL's) C signatures; enums passed as ints (ncclFloat32 = 7, ncclSum = 0)
+// the six entry points used, with RCCL's (= NCCL's) C signatures; enums passed as ints (ncclFloat32 = 7, ncclSum = 0)
 struct Id128 { char b[128]; };   // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value
 struct Rccl {
   void* h = nullptr;
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, Id128, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
@@ -31,9 +32,10 @@ static Rccl load_rccl() {
       r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
       r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
       r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+      r.Broadcast = (decltype(r.Broadcast))dlsym(h, "ncclBroadcast");
       r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
       r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
-      if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) r.h = nullptr;
+      if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.Broadcast || !r.CommDestroy) r.h = nullptr;
     }
   }
   return r;
@@ -86,6 +88,14 @@ int n3d_comm_allreduce_sum(void* comm, float* buf, int64_t n, void* stream) {
   Rccl* r = rccl();
   if (!r) N3D_UNSUPPORTED("comm_allreduce_sum: RCCL not loaded");
   if (int e = r->AllReduce(buf, buf, (size_t)n, /* ncclFloat32 */ 7, /* ncclSum */ 0, comm, (hipStream_t)stream)) return rccl_fail("ncclAllReduce", e);
+  return N3D_OK;
+}
+
+int n3d_comm_broadcast(void* comm, float* buf, int64_t n, int root, void* stream) {
+  N3D_CHECK_ARG(comm && buf && n > 0 && root >= 0, "comm_broadcast: bad args");
+  Rccl* r = rccl();
+  if (!r) N3D_UNSUPPORTED("comm_broadcast: RCCL not loaded");
+  if (int e = r->Broadcast(buf, buf, (size_t)n, /* ncclFloat32 */ 7, root, comm, (hipStream_t)stream)) return rccl_fail("ncclBroadcast", e);
   return N3D_OK;
 }
 

@@ -8,23 +8,23 @@ MI355X-first mechanics (none of which the reference has):
     launch updates everything (n3d_adam_step);
   * forward + backward (+ Adam) of a fixed-shape step is captured once into a HIP graph and
     replayed, which removes the per-kernel host launch cost (~300 launches per step);
-  * data parallel: one process per GPU, parameters broadcast once, per step a SUM all-reduce of the flat gradient
-    buffer over RCCL (torch.distributed backend "nccl", or the C ABI's n3d_comm_* with N3D_COMM=rccl), the mean folded
-    into the Adam kernel.  Default: ONE bucket issued from the step's own stream after the captured forward + backward
-    graph (7.3 MB is latency-bound on xGMI and a stream hop costs more than it hides on one GPU).  n_buckets >= 2:
-    the step runs without autograd as graph segments split at cell boundaries of the backward pass; the bucket a segment
-    completes is all-reduced on a side HIP stream while the next segment's backward kernels run.
+  * data parallel: one process per GPU, parameters broadcast once, per step a SUM all-reduce of the flat gradient buffer over
+    RCCL through the C ABI's n3d_comm_* on ONE communicator per process (comm.py: no torch.distributed collective inside the step,
+    so nothing of ProcessGroupNCCL's watchdog can meet a stream capture), the mean folded into the Adam kernel.  Default: ONE
+    bucket issued from the step's own stream behind the step's graphs.  n_buckets >= 2: on the side-stream schedule a bucket that
+    the backward walk has completed is reduced and all-reduced ON THE WEIGHT-GRADIENT STREAM under the rest of the backward
+    (device flags, no host wait); without a side schedule the exchange stays a single bucket.
 """
 from __future__ import annotations
 
 import os
-import time
 import types
 import weakref
 
 import torch
 import torch.distributed as dist
 
+from . import comm as _comm
 from . import fused as _fused
 from . import kernels as K
 from .loss import WeightedDiceLoss
@@ -121,15 +121,21 @@ def _plateau_for(owner, lr_attr, setter):
 
 
 class GradSync:
-    """Bucketed SUM all-reduce of one flat gradient buffer (RCCL on GPUs, gloo on CPU tensors); callers divide by the world
-    size (folded into the Adam kernel).
+    """Bucketed SUM all-reduce of one flat gradient buffer; callers divide by the world size (folded into the Adam kernel).
 
     xGMI is point-to-point (7 links per GPU) and the whole payload is 2-7 MB (searched net) / 27 MB (supernet), so the
     collective is latency-bound: a few large buckets, never one call per tensor.  `ranges`: the buckets as (begin, end)
-    element ranges in ISSUE order (default: n_buckets equal slices).  backend "torch" = torch.distributed.all_reduce;
-    "rccl" = the C ABI's n3d_comm_allreduce_sum on a communicator of its own (unique id exchanged through the process group)."""
+    element ranges in ISSUE order (default: n_buckets equal slices).
+    backend (default: "rccl" for CUDA tensors on an NCCL group, else "torch"):
+      "rccl"  = n3d_comm_allreduce_sum on the process's shared communicator (comm.for_group): stream-ordered on the CURRENT stream,
+                no Work object, no event, no thread that polls it later -- nothing that can collide with a stream capture
+                (comm.py says what did in round 4);
+      "torch" = torch.distributed.all_reduce (gloo on CPU tensors; two gloo processes sharing one GPU).  On an NCCL group the call is
+                issued on a comm stream of this object's own that is NEVER captured, tied to the current stream by two event waits:
+                ProcessGroupNCCL's watchdog polls the Work's end event until it has retired it, and HIP refuses that poll while the
+                stream the event was last recorded on is capturing."""
 
-    def __init__(self, flat_grad, process_group=None, n_buckets=2, comm_stream=None, ranges=None, backend=None, header=None):
+    def __init__(self, flat_grad, process_group=None, n_buckets=2, ranges=None, backend=None, header=None):
         """header: the full buffer `flat_grad` is a view of (FlatParams.grad_full: GRAD_HEADER floats in front of it) -- those
         words are exchanged together with the bucket that is issued LAST (the one that starts at 0)"""
         self.header = header
@@ -140,50 +146,25 @@ class GradSync:
         nb = max(1, min(n_buckets, n // 4 if n >= 4 else 1))
         self.edges = [n * i // nb // 4 * 4 for i in range(nb)] + [n]
         self.ranges = list(ranges) if ranges is not None else list(zip(self.edges[:-1], self.edges[1:]))
-        self.comm_stream = comm_stream
         self.force = dist.is_initialized() and os.environ.get("N3D_FORCE_DP") == "1"  # see Trainer.dp_path
         self.active = self.world > 1 or self.force
-        self.backend = backend or os.environ.get("N3D_COMM", "torch")
         self._comm = None
-        if self.backend == "rccl" and self.active and flat_grad.is_cuda:
-            self._init_rccl()
-
-    def _init_rccl(self):
-        import ctypes as C
-        from . import _lib
-        lib = _lib.load()
-        rank = dist.get_rank(self.pg)
-        buf = (C.c_char * 128)()
-        if rank == 0:
-            _lib.check(lib.n3d_comm_unique_id(buf), "n3d_comm_unique_id")
-        box = [bytes(buf.raw)]
-        # the 128-byte id travels out of band, from the group's rank 0 (`src` is a GLOBAL rank, also for a sub-group)
-        src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
-        dist.broadcast_object_list(box, src=src, group=self.pg)
-        comm = C.c_void_p()
-        idb = (C.c_char * 128).from_buffer_copy(box[0])
-        with torch.cuda.device(self.g.device):     # the communicator binds to the current HIP device
-            _lib.check(lib.n3d_comm_init(idb, self.world, rank, C.byref(comm)), "n3d_comm_init")
-        self._comm = comm
+        self._torch_stream = None
+        want = backend or os.environ.get("N3D_COMM") or "rccl"
+        if want not in ("rccl", "torch"):
+            raise ValueError("GradSync: backend must be 'rccl' or 'torch', not %r" % (want,))
+        if self.active and want == "rccl":
+            self._comm = _comm.for_group(self.pg, flat_grad.device)     # None: CPU tensors / not an NCCL group -> torch.distributed
+        self.backend = "rccl" if self._comm is not None else "torch"
+        if self.active and self.backend == "torch" and flat_grad.is_cuda and _comm._is_nccl(self.pg):
+            self._torch_stream = torch.cuda.Stream(device=flat_grad.device)
 
     def close(self):
-        """destroy the communicator this object created (N3D_COMM=rccl); safe to call twice"""
-        comm, self._comm = self._comm, None
-        if comm is not None:
-            from . import _lib
-            try:
-                _lib.load().n3d_comm_destroy(comm)
-            except Exception:
-                pass
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        """(the communicator is the process's shared one: comm.close_all() destroys it)"""
+        self._comm = None
 
     def reduce_range(self, i):
-        """SUM all-reduce of bucket i on the CURRENT stream"""
+        """SUM all-reduce of bucket i, ordered on the CURRENT stream"""
         if not self.active:
             return
         a, b = self.ranges[i]
@@ -193,10 +174,13 @@ class GradSync:
         if self.header is not None and a == 0 and i == len(self.ranges) - 1:
             buf, b = self.header, b + GRAD_HEADER      # the hand-off flag rides in front of the last bucket
         if self._comm is not None:
-            from . import _lib
-            import ctypes as C
-            _lib.check(_lib.load().n3d_comm_allreduce_sum(self._comm, C.c_void_p(buf.data_ptr() + 4 * a), b - a,
-                                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "n3d_comm_allreduce_sum")
+            self._comm.allreduce_sum_ptr(buf.data_ptr() + 4 * a, b - a)
+        elif self._torch_stream is not None:
+            cur, cs = torch.cuda.current_stream(), self._torch_stream
+            cs.wait_stream(cur)
+            with torch.cuda.stream(cs):
+                dist.all_reduce(buf[a:b], op=dist.ReduceOp.SUM, group=self.pg)
+            cur.wait_stream(cs)
         else:
             dist.all_reduce(buf[a:b], op=dist.ReduceOp.SUM, group=self.pg)
 
@@ -204,16 +188,28 @@ class GradSync:
         """sum-reduce every bucket, in issue order"""
         if not self.active:
             return
-        if self.comm_stream is not None:
-            cs = self.comm_stream
-            cs.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cs):
-                for i in range(len(self.ranges)):
-                    self.reduce_range(i)
-            torch.cuda.current_stream().wait_stream(cs)
+        for i in range(len(self.ranges)):
+            self.reduce_range(i)
+
+    def broadcast(self, t, src=0):
+        """rank `src`'s copy of t to every rank (once, when a trainer is built)"""
+        if self.world <= 1:
+            return
+        if self._comm is not None:
+            self._comm.broadcast(t, src)
         else:
-            for i in range(len(self.ranges)):
-                self.reduce_range(i)
+            dist.broadcast(t, src=dist.get_global_rank(self.pg, src) if self.pg is not None else src, group=self.pg)
+
+    def all_true(self, flag):
+        """True only if `flag` is true on every rank (data-parallel ranks must take the same schedule decisions: they decide which
+        graphs exist and in which order collectives are issued)"""
+        if self.world <= 1:
+            return bool(flag)
+        if self._comm is not None:
+            return self._comm.all_true(flag)
+        ok = torch.tensor([1.0 if flag else 0.0], device=self.g.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.pg)
+        return float(ok.item()) != 0.0
 
 
 _capture_streams = {}
@@ -282,16 +278,6 @@ def reserve_side_streams(device, n=2):
                 K.sync_signal(scratch.data_ptr() + 16, scratch.data_ptr(), False)
         torch.cuda.synchronize(device)
     return pool
-
-
-def _let_comm_watchdog_retire(dp):
-    """Data parallel, before a stream capture: the warm-up steps' collectives are complete (the caller has synchronised), but
-    torch.distributed's watchdog thread retires their work objects -- event queries, event destruction, tensors handed back to the
-    caching allocator -- on its own 100 ms poll, i.e. possibly in the middle of the capture.  One poll interval of patience keeps the
-    runtime's other thread idle while three streams are being captured.  (Round 4: a run of the GPU suite in eight aborted from a
-    runtime thread -- no Python frame, no message -- exactly inside the first bucketed data-parallel capture.)"""
-    if dp and os.environ.get("N3D_DP_CAPTURE_SLEEP", "1") != "0":
-        time.sleep(0.25)
 
 
 class SideSchedule:
@@ -828,27 +814,6 @@ def flatten_params(params, device=None):
     return flat, grad, offs
 
 
-def _agree_on_side(side, device, world, pg):
-    """data parallel: the side-stream probe is rank-local and timing-based, but every rank must take the same schedule decisions
-    (they decide which graphs exist and, for the trainers' own timing runs, nothing else may differ between ranks): the side
-    schedule is on only if EVERY rank has one"""
-    if world > 1 and torch.device(device).type == "cuda":
-        ok = torch.tensor([1.0 if side is not None else 0.0], device=device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=pg)
-        if float(ok.item()) == 0.0:
-            return None
-    return side
-
-
-def _agree_bool(flag, device, world, pg):
-    """True only if `flag` is true on every rank (one MIN all-reduce; single process: flag itself)"""
-    if world > 1 and torch.device(device).type == "cuda":
-        ok = torch.tensor([1.0 if flag else 0.0], device=device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=pg)
-        return float(ok.item()) != 0.0
-    return bool(flag)
-
-
 def _dropout_states(model):
     return [m._n3d_state for m in model.modules() if getattr(m, "_n3d_state", None) is not None]
 
@@ -934,31 +899,28 @@ class Trainer:
             n_buckets = int(os.environ.get("N3D_DP_BUCKETS", "1"))
         self.n_buckets = max(1, n_buckets)
         self._graph = None
-        self._segments = None
         self._side_graphs = None
         self._static_x = self._static_t = self._static_loss = None
         self.ctx = K.StepContext(self.device)  # batched weight packing + deferred wgrad reductions
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)  # read by the Adam kernel
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
         self.scheduler = _plateau_for(self, "lr", "set_lr")  # train.py:50: ReduceLROnPlateau(factor=0.5)
-        self._buckets = self._bucket_plan() if (self.dp_path and self.n_buckets > 1) else None
-        # one bucket = nothing to overlap: the collective is issued from the step's own stream (a hop through a second
-        # stream costs two cross-stream waits around a graph launch); N3D_COMM_STREAM=1 restores the hop
-        # (the bucketed exchange on device flags puts its all-reduces on the weight-gradient stream; the event-tied graph segments --
-        # buckets without a side schedule -- make their comm stream when they first need it: every stream is a hardware queue)
-        want_cs = self.dp_path and os.environ.get("N3D_COMM_STREAM") == "1"
-        self._comm_stream = torch.cuda.Stream(device=self.device) if (want_cs and self.device.type == "cuda") else None
         # (a weight-gradient stream of its own lets the side stream run data gradients of the C <= 8 cells inline: fused.SIDE_PAIRS_BWD)
         self.side = SideSchedule(self.device, self.ctx, wgrad_stream=_fused.SIDE_PAIRS_BWD) if (self.side_wgrad and self.device.type == "cuda") else None
         if self.side is not None and self.side.stream is None:
             self.side = None
-        self.side = _agree_on_side(self.side, self.device, self.world, self.pg)
-        if self.side is not None and self._buckets is not None:
+        self.sync = GradSync(self.fp.grad, self.pg, 1, None, comm, header=self.fp.grad_full)
+        # data parallel: the side-stream probe is rank-local and timing-based, but every rank must take the same schedule decisions
+        # (they decide which graphs exist and in which order the collectives go out): the side schedule is on only if EVERY rank has one
+        if not self.sync.all_true(self.side is not None):
+            self.side = None
+        # the bucketed, overlapped exchange rides on the side-stream schedule (a closed bucket is reduced and sent from the
+        # weight-gradient stream); without one the exchange is a single bucket behind the step
+        self._buckets = self._bucket_plan() if (self.dp_path and self.n_buckets > 1 and self.side is not None) else None
+        if self._buckets is not None:
             self.side.tail_inline, self.side.alternate = (), 0      # every weight-gradient group on ONE stream: a closed bucket's slabs are reduced there
-        ranges = [r for _, r in self._buckets] if self._buckets is not None else None
-        self.sync = GradSync(self.fp.grad, self.pg, 1, self._comm_stream, ranges, comm, header=self.fp.grad_full)
-        if self.world > 1:
-            dist.broadcast(self.fp.flat, src=0, group=self.pg)
+            self.sync.ranges = [r for _, r in self._buckets]
+        self.sync.broadcast(self.fp.flat)
 
     # -- bucket plan ------------------------------------------------------------------------------
     def _bucket_plan(self):
@@ -1016,28 +978,17 @@ class Trainer:
             self.ctx.freeze()              # first pass only recorded which weights / layouts are needed
         return loss.detach()
 
-    def _pipeline(self, x, t, on_bucket=None, cell_hook=None):
+    def _pipeline(self, x, t, cell_hook):
         """forward + Dice + backward WITHOUT autograd: fused.NetFn and head.HeadDiceFn are called directly, so the backward walk
-        is one Python function on this thread and can hand over work on the way.  Bucketed exchange: on_bucket(j) is called as
-        soon as every gradient of self._buckets[j] has been launched (its deferred weight-gradient reductions included).
-        Side-stream schedule: cell_hook(k) is called when the backward of cell k (-1: the stems, i.e. the end) has been launched."""
+        is one Python function on this thread and can hand over work on the way: cell_hook(k) is called when the backward of cell k
+        (-1: the stems, i.e. the end) has been launched."""
         from . import head as _head, programs as _P
         m = self.model
         plan = getattr(m, "_net_plan", None)
         if not _fused.current(plan):
             plan = m._net_plan = _fused.net_plan(m, supernet=False)
         op = m.last_conv[0]
-        if cell_hook is not None:
-            hook = cell_hook
-        else:
-            closes = {k: j for j, (k, _) in enumerate(self._buckets)}
-
-            def hook(k):
-                j = closes.get(k)
-                if j is not None:
-                    self.ctx.flush_final()
-                    on_bucket(j)
-
+        hook = cell_hook
         with torch.no_grad(), K.step_context(self.ctx):
             self.ctx.pack_all()
             nctx = _Ctx((False, False) + (False,) * 4 + (True,) * len(plan.params))
@@ -1069,9 +1020,6 @@ class Trainer:
                 and all(hasattr(m, a) for a in ("stem0", "stem1", "down_cells", "up_cells", "last_conv"))
                 and _head.fusable(m.last_conv, torch.empty((1, m.last_conv[0].conv.weight.shape[1], 1, 1, 1), device="meta")))
 
-    def _pipeline_ok(self, x):
-        return self._buckets is not None and self._direct_ok()
-
     def _side_ok(self):
         return self.side is not None and not getattr(self, "_side_retired", False) and self._direct_ok()
 
@@ -1099,7 +1047,7 @@ class Trainer:
         self._use_side = False
         self._retire_side_graphs()
         self._side_retired = True
-        if self._graph is None and self._segments is None:
+        if self._graph is None:
             self._static_x = self._static_t = None      # "force" had no plain graph: the next step captures one
 
     def _retire_side_graphs(self):
@@ -1168,22 +1116,6 @@ class Trainer:
             K.guard_flag(self.side.ptr(1), self.side.ptr(4), self.fp.grad_full.data_ptr())
             self.sync.reduce_range(len(self.sync.ranges) - 1)
 
-    def _reduce_on_side(self, j):
-        """bucket j is complete on the current stream: all-reduce it on the comm stream"""
-        if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=self.device)
-        if j == len(self.sync.ranges) - 1 and self.sync.active:
-            # the hand-off flag in front of the gradients rides with this (the last) bucket: refresh it -- a trainer that has retired
-            # its side schedule (recover()) must not keep exchanging the 1 of the step that failed
-            if self.side is not None:
-                K.guard_flag(self.side.ptr(1), self.side.ptr(4), self.fp.grad_full.data_ptr())
-            else:
-                self.fp.grad_full[:1].zero_()
-        cs = self._comm_stream
-        cs.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(cs):
-            self.sync.reduce_range(j)
-
     def _allreduce(self):
         # word 0 of the gradient header: "a hand-off of THIS rank timed out" -- summed over the ranks with the gradients, so that
         # every rank withholds the same update (a rank without a side schedule contributes 0)
@@ -1207,10 +1139,7 @@ class Trainer:
         with device-side waits, and anything that makes the HOST wait for the device in the middle of a pass (the caching allocator
         returning memory to the driver when a new shape does not fit its cache, for one) leaves those waits spinning until their
         time-out; a replayed graph allocates nothing, an eager pass on a shape seen for the first time may."""
-        if self.dp_path and self._pipeline_ok(x) and not (allow_side and self._side_ok() and (self._side_explicit or self.use_graph)):
-            loss = self._pipeline(x, t, self._reduce_on_side)
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
-        elif allow_side and self._side_ok() and (self._side_explicit or self.use_graph):
+        if allow_side and self._side_ok() and (self._side_explicit or self.use_graph):
             loss = self._side_step_eager(x, t)
             if self.dp_path:
                 if self._buckets is not None:
@@ -1229,7 +1158,7 @@ class Trainer:
         self._poll()     # host-only: a withheld update (timed-out hand-off) is fatal until recover()
         if not self.use_graph:
             return self._eager(x, t)
-        if self._static_x is None or (self._graph is None and self._segments is None and self._side_graphs is None):
+        if self._static_x is None or (self._graph is None and self._side_graphs is None):
             self._capture(x, t)
         if x.shape != self._static_x.shape or t.shape != self._static_t.shape:
             # a batch of another shape (the reference's generator yields a smaller last batch of an epoch): the captured
@@ -1244,14 +1173,6 @@ class Trainer:
         if self._use_side:
             self._watched_side_replay()
             return self._side_loss
-        if self._segments is not None:
-            # bucketed exchange: segment j's graph completes bucket j; its all-reduce runs on the comm stream under segment j+1
-            for j, g in enumerate(self._segments):
-                g.replay()
-                self._reduce_on_side(j)
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
-            self._update(self._static_loss)
-            return self._static_loss
         self._graph.replay()
         if self.dp_path:
             self._allreduce()
@@ -1299,9 +1220,12 @@ class Trainer:
             self._update(self._static_loss)
 
     def _watched_side_replay(self):
-        """one replayed step of the side schedule.  Every 256th one is bracketed with events; one step later (no host wait on the
-        fast path) the trainer checks the time-outs of the device-side waits (raises) and that step's GPU time against the plain
-        schedule's measured time -- a side schedule that has become slower than the plain graph is dropped."""
+        """one replayed step of the side schedule.  Every 256th one is bracketed with events; one step later the trainer checks the
+        time-outs of the device-side waits (raises) and that step's GPU time against the plain schedule's measured time -- a side
+        schedule that has become slower than the plain graph is dropped.  Data parallel: the verdict is COLLECTIVE (every rank counts
+        the same replays, so every rank is at this check in the same step; one tiny all-reduce of "my sample was fast") -- a rank
+        that retired its side schedule on its own would go on with another fp32 summation order than its peers and the replicas
+        would drift apart bit by bit."""
         sd = self.side
         sd.replays += 1
         recheck = getattr(sd, "recheck", 0)
@@ -1320,7 +1244,9 @@ class Trainer:
             e1.synchronize()
             sd.check()      # (the per-step poll() has seen a withheld update long before; this also catches a time-out whose step
                             # was not followed by an update yet)
-            slow = self.schedule_times is not None and e0.elapsed_time(e1) * 1e-3 > 1.5 * self.schedule_times[0] + 2e-4
+            ms = e0.elapsed_time(e1)
+            fast = self.schedule_times is None or ms * 1e-3 <= 1.5 * self.schedule_times[0] + 2e-4
+            slow = not (self.sync.all_true(fast) if self.dp_path else fast)
             # ONE slow sample proves nothing -- the bracket also holds whatever the host did between the three graph launches (a
             # 100 000-step soak dropped a healthy schedule on a single 3.5 ms sample): a slow sample is measured again, three in a row
             # retire the schedule
@@ -1328,10 +1254,11 @@ class Trainer:
             sd.recheck = 1 if (slow and sd.slow_run < 3) else 0
             if sd.slow_run >= 3:
                 import warnings
-                warnings.warn("nas_3d_unet_amd: the side-stream schedule degraded (%.2f ms per step against %.2f ms for the plain graph, three "
-                              "samples in a row); falling back to the plain graph" % (e0.elapsed_time(e1), self.schedule_times[0] * 1e3))
+                warnings.warn("nas_3d_unet_amd: the side-stream schedule degraded (%.2f ms per step on this rank against %.2f ms for the plain "
+                              "graph, three samples in a row%s); falling back to the plain graph"
+                              % (ms, self.schedule_times[0] * 1e3, " on at least one rank" if self.dp_path else ""))
                 self._use_side = False
-                if self._graph is None and self._segments is None:      # ("force": no plain graph was captured -- the next step captures one)
+                if self._graph is None:      # ("force": no plain graph was captured -- the next step captures one)
                     torch.cuda.synchronize(self.device)
                     self._retire_side_graphs()
                     self._side_retired = True
@@ -1354,7 +1281,7 @@ class Trainer:
             self.side.acknowledge()
         torch.cuda.synchronize(self.device)
         self.schedule_times = (tp, ts)
-        self._use_side = _agree_bool(ts < tp and not bad, self.device, self.world, self.pg)
+        self._use_side = self.sync.all_true(ts < tp and not bad)
         if not self._use_side:
             self._retire_side_graphs()     # the plain graph won: the side graphs (and their raw HIP executables) are released
 
@@ -1371,30 +1298,23 @@ class Trainer:
         self._static_x = x.clone()
         self._static_t = t.clone()
         sided = self._side_ok()
-        segmented = self.dp_path and self._pipeline_ok(x) and not sided      # (buckets without a side stream: event-tied graph segments)
         # warm-up on a side stream (allocator + lazy module state); no optimizer launch, the weights stay as they are
         s = capture_stream(self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
-                if segmented:
-                    self._pipeline(self._static_x, self._static_t, lambda j: None)
-                else:
-                    if sided:
-                        self._side_step_eager(self._static_x, self._static_t)
-                    if not (sided and self._side_force):
-                        self._fwd_bwd(self._static_x, self._static_t)
+                if sided:
+                    self._side_step_eager(self._static_x, self._static_t)
+                if not (sided and self._side_force):
+                    self._fwd_bwd(self._static_x, self._static_t)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        if segmented:
-            return self._capture_segments(s)
         if sided:
             self._capture_side(s)
             if self._side_force:
                 self._use_side = True
                 return
         g = torch.cuda.CUDAGraph()
-        _let_comm_watchdog_retire(self.dp_path)
         with torch.cuda.graph(g, capture_error_mode="thread_local"):  # RCCL's watchdog thread may touch the runtime meanwhile
             self._static_loss = self._fwd_bwd(self._static_x, self._static_t)
             if not self.dp_path:
@@ -1415,7 +1335,6 @@ class Trainer:
         sd = self.side
         g_main, g_tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
-        _let_comm_watchdog_retire(self.dp_path)
         sd.raw_capture_begin()
         self._capturing_side = True
         try:
@@ -1437,31 +1356,6 @@ class Trainer:
         torch.cuda.synchronize()
         self._side_graphs = (g_main, side_exec, g_tail)
         self._side_wsegs = sd.wseg_count
-
-    def _capture_segments(self, s):
-        """one HIP graph per gradient bucket: the capture is closed and the next one opened inside the backward walk, at the
-        point where the bucket is complete (all graphs share one memory pool; they are only ever replayed in this order)"""
-        import gc
-        gc.collect()      # as torch.cuda.graph does: no collection of stale device objects in the middle of a capture
-        pool = torch.cuda.graph_pool_handle()
-        graphs = [torch.cuda.CUDAGraph()]
-        last = len(self._buckets) - 1
-
-        def on_bucket(j):
-            graphs[-1].capture_end()
-            if j < last:
-                graphs.append(torch.cuda.CUDAGraph())
-                graphs[-1].capture_begin(pool=pool, capture_error_mode="thread_local")
-
-        torch.cuda.synchronize()
-        _let_comm_watchdog_retire(self.dp_path)
-        with torch.cuda.stream(s):
-            graphs[0].capture_begin(pool=pool, capture_error_mode="thread_local")
-            self._static_loss = self._pipeline(self._static_x, self._static_t, on_bucket)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        self._segments = graphs
-
 
 class SearchTrainer:
     """Supernet search step, first-order DARTS as in the reference (search.py:211-238):
@@ -1513,8 +1407,6 @@ class SearchTrainer:
             self.side.tail_inline = (1, 3, 5, 7, 9, 11)
         if self.side is not None and self.side.stream is None:
             self.side = None
-        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
-        self.side = _agree_on_side(self.side, self.device, self.world, process_group)
         if self.side is not None and "N3D_SIDE_EARLY_FINALIZE" not in os.environ:
             self.side.early_finalize = 6      # 384 slab jobs per weight pass: reducing most of them early shrinks the tail 0.23 -> 0.15 ms
         self.use_graph = graph
@@ -1531,12 +1423,13 @@ class SearchTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
         self.dp_path = self.world > 1 or (dist.is_initialized() and os.environ.get("N3D_FORCE_DP") == "1")
-        self.sync_alpha = GradSync(self.agrad, self.pg, 1, None, None, "torch", header=self.agrad._n3d_full)   # tiny: always through torch.distributed
-        self.sync_kernel = GradSync(self.fp.grad, self.pg, 1, None, None, comm, header=self.fp.grad_full)
+        self.sync_alpha = GradSync(self.agrad, self.pg, 1, None, comm, header=self.agrad._n3d_full)
+        self.sync_kernel = GradSync(self.fp.grad, self.pg, 1, None, comm, header=self.fp.grad_full)
         self._graphs = None
-        if self.world > 1:
-            dist.broadcast(self.fp.flat, src=0, group=self.pg)
-            dist.broadcast(self.aflat, src=0, group=self.pg)
+        if not self.sync_kernel.all_true(self.side is not None):     # every rank the same schedule (see Trainer)
+            self.side = None
+        self.sync_kernel.broadcast(self.fp.flat)
+        self.sync_kernel.broadcast(self.aflat)
 
     def set_shell_lr(self, lr):
         self.lr_shell = float(lr)
@@ -1669,7 +1562,6 @@ class SearchTrainer:
         pool = torch.cuda.graph_pool_handle()
         sd = self.side
         torch.cuda.synchronize()
-        _let_comm_watchdog_retire(self.dp_path)
         graphs, losses = [], []
         for arch, (bx, bt) in ((True, (self._svx, self._svt)), (False, (self._sx, self._st))):
             g_main, g_tail = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -1793,7 +1685,7 @@ class SearchTrainer:
             self.side.acknowledge()
         torch.cuda.synchronize(self.device)
         self.schedule_times = (tp, ts)
-        self._use_side = _agree_bool(ts < tp and not bad, self.device, self.world, self.pg)
+        self._use_side = self.sync_kernel.all_true(ts < tp and not bad)
         if not self._use_side:
             self._retire_side_graphs()
 

@@ -59,7 +59,9 @@ def test_trainer_dp_schedules_match_single_gpu(one_rank_group, graph, buckets, c
         os.environ["N3D_FORCE_DP"] = "1"
     net, _ = build_net("searched", "G_CONV", 4)
     tr = Trainer(net, graph=graph, n_buckets=buckets, comm=comm, side_wgrad=sched)
-    assert tr.dp_path and len(tr.sync.ranges) == buckets and (comm != "rccl" or tr.sync._comm is not None)
+    assert tr.dp_path and len(tr.sync.ranges) == buckets and tr.sync.backend == comm
+    # "rccl": the process's shared n3d_comm communicator; "torch": torch.distributed on a comm stream that is never captured
+    assert (tr.sync._comm is not None) if comm == "rccl" else (tr.sync._torch_stream is not None)
     l, w = _losses_and_weights(tr, x, t)
     assert ref._use_side == tr._use_side or buckets > 1
     if buckets > 1:
@@ -71,10 +73,35 @@ def test_trainer_dp_schedules_match_single_gpu(one_rank_group, graph, buckets, c
     assert l == lr_ and torch.equal(w, wr)
 
 
+def test_default_exchange_is_the_shared_rccl_communicator(one_rank_group):
+    """data-parallel trainers exchange through n3d_comm_* on ONE communicator per process group (comm.for_group), also the search
+    trainer's two exchanges -- no torch.distributed collective in the step, so ProcessGroupNCCL's watchdog has nothing to poll
+    while a stream is being captured (comm.py; profiles/r05_dp_capture_loop.log)"""
+    from nas_3d_unet_amd import comm as C, nas
+    from nas_3d_unet_amd.train import SearchTrainer, Trainer
+    net, _ = build_net("searched", "G_CONV", 2)
+    a = Trainer(net, graph=False)
+    net2, _ = build_net("searched", "G_CONV", 2)
+    b = Trainer(net2, graph=False, n_buckets=2)
+    cfg = orc.DEFAULT_CFG._replace(depth=2)
+    shell = fill_module(nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)).cuda()
+    c = SearchTrainer(shell, graph=False)
+    comms = [a.sync._comm, b.sync._comm, c.sync_alpha._comm, c.sync_kernel._comm]
+    assert all(x is not None and x is comms[0] for x in comms) and comms[0] is C.for_group(None, torch.device("cuda", 0))
+    assert all(s.backend == "rccl" and s._torch_stream is None for s in (a.sync, b.sync, c.sync_alpha, c.sync_kernel))
+    # broadcast / all_true on a 1-rank group: identities
+    w = torch.arange(8, dtype=torch.float32, device="cuda")
+    comms[0].broadcast(w)
+    torch.cuda.synchronize()
+    assert torch.equal(w.cpu(), torch.arange(8, dtype=torch.float32))
+    assert comms[0].all_true(True) and not comms[0].all_true(False)
+
+
 @pytest.mark.parametrize("buckets", [2, 3])
-def test_bucketed_exchange_without_a_side_stream_uses_graph_segments(one_rank_group, buckets):
-    """side_wgrad=False: no device-flag schedule -- the bucketed exchange falls back to one HIP graph per bucket, tied to the comm
-    stream by events (the round-2 form); same weights as the plain single-stream trainer, bit for bit"""
+def test_bucketed_exchange_without_a_side_stream_is_one_bucket(one_rank_group, buckets):
+    """side_wgrad=False: no device-flag schedule, nothing for a bucket to overlap with -- the exchange stays ONE bucket behind the
+    step's graph (round 5: the event-tied one-graph-per-bucket fallback of round 2 is gone); same weights as the plain
+    single-stream trainer, bit for bit"""
     from nas_3d_unet_amd.train import Trainer
     rng = np.random.default_rng(41)
     x = dev(rng.standard_normal((2, 4, 32, 32, 32)).astype(np.float32))
@@ -89,8 +116,36 @@ def test_bucketed_exchange_without_a_side_stream_uses_graph_segments(one_rank_gr
     net, _ = build_net("searched", "G_CONV", 4)
     tr = Trainer(net, graph=True, n_buckets=buckets, side_wgrad=False)
     l, w = _losses_and_weights(tr, x, t)
-    assert tr._segments is not None and len(tr._segments) == buckets
+    assert tr.dp_path and tr._buckets is None and len(tr.sync.ranges) == 1 and tr._graph is not None
     assert l == lr_ and torch.equal(w, wr)
+
+
+def test_replay_monitor_retires_the_side_schedule_collectively(one_rank_group):
+    """the 256-step re-timing of a replayed side schedule decides by an all-reduce ("my sample was fast" on every
+    rank), three slow samples in a row retire it -- on every rank in the same step.  Here: a 1-rank group whose plain-schedule time
+    is set absurdly low, so that every sample counts as slow."""
+    import warnings
+    from nas_3d_unet_amd.train import Trainer
+    rng = np.random.default_rng(47)
+    x = dev(rng.standard_normal((2, 4, 32, 32, 32)).astype(np.float32))
+    t = dev((rng.uniform(0, 1, (2, 3, 32, 32, 32)) < 0.3).astype(np.float32))
+    net, _ = build_net("searched", "G_CONV", 4)
+    tr = Trainer(net, graph=True, side_wgrad="force")
+    tr.step(x, t)
+    assert tr.dp_path and tr._use_side
+    calls = []
+    real = tr.sync.all_true
+    tr.sync.all_true = lambda flag: (calls.append(bool(flag)), real(flag))[1]
+    tr.schedule_times = (1e-7, 1e-7)
+    tr.side.replays = 254
+    with warnings.catch_warnings(record=True) as wn:
+        warnings.simplefilter("always")
+        for _ in range(10):
+            tr.step(x, t)
+    assert calls[:3] == [False, False, False] and not tr._use_side and any("degraded" in str(w.message) for w in wn)
+    tr.step(x, t)        # "force" had no plain graph: this step captured one and trains on
+    torch.cuda.synchronize()
+    assert tr._graph is not None and tr.sync_timeouts() == 0
 
 
 @pytest.mark.parametrize("buckets", [1, 2])

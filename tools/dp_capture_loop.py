@@ -52,14 +52,14 @@ def child(mode):
                 os.environ["N3D_FORCE_DP"] = "1"
         net, _ = build_net("searched", "G_CONV", 4)
         tr = Trainer(net, graph=graph, n_buckets=buckets, comm=comm, side_wgrad=sched)
-        assert tr.dp_path
+        assert tr.dp_path and (comm is None or tr.sync.backend == comm)
         l = [float(tr.step(x, t)) for _ in range(3)]
         tr.check_sync()
         if with_ref:
             assert l == lr_, (l, lr_)
         return tr
 
-    comm = os.environ.get("DP_LOOP_COMM", "torch")
+    comm = os.environ.get("DP_LOOP_COMM") or None      # None: the trainers' default (n3d_comm_* on the shared communicator)
     if mode == "suite":
         one(True, 1, comm, True)
         one(False, 1, comm, True)
