@@ -95,19 +95,6 @@ int n3d_conv_stats_rows(const n3d_conv_geom* g, int transposed, int flags);
 /* rows per sample written by n3d_channel_stats / n3d_affine_act_bwd_reduce for N voxels, C channels */
 int n3d_stats_rows(int64_t N, int C);
 
-/* ---- normalise-on-load PROBE (round 4; SURVEY 7, hard part 3 "consumer pass normalises on load").  A node of a searched cell is
- * relu?(a0 raw0 + b0) + relu?(a1 raw1 + b1) (searched.py:45-50 over prim_ops.py:68-83); today a node-epilogue launch writes it and
- * the next conv reads it.  n3d_conv_fwd_nol is n3d_conv_fwd of the 3x3x3 stride-1 C = 4 conv (dilation 1 / 2, the 64^3-level
- * shapes of the vox64 kernel) whose input is that node, NOT materialised: x0 arrives in the LDS halo tile by LDS-DMA as always, x1
- * through registers, the lanes normalise their own slots in place (padding slots stay 0: the zero padding applies to the node).
- * a0, b0, a1, b1: float[B][4] each (the GroupNorm coefficients n3d_gn_coeffs2 writes); relu_mask bit 0 / 1 = ReLU on term 0 / 1.
- * Result bit-identical to n3d_conv_fwd on the materialised node.  n3d_conv_fwd_nol_ok: does the geometry run on the kernel that has
- * this form (C = 4, 4-plane tiles)?  profiles/r04_nol_probe.log, DESIGN.md section 5. */
-int n3d_conv_fwd_nol_ok(const n3d_conv_geom* g);
-int n3d_conv_fwd_nol(const n3d_conv_geom* g, const float* x0, int64_t x0ld, const float* x1, int64_t x1ld, const float* a0,
-                     const float* b0, const float* a1, const float* b1, int relu_mask, const float* w, const float* bias, float* y,
-                     int64_t yld, int flags, double* stats, void* ws, size_t ws_bytes, void* stream);
-
 /* Batched weight packing: the conv kernels read weights from a kernel-friendly packed copy.  By default each
  * conv call packs into its workspace (one tiny extra launch); a trainer instead packs ALL weights of the net
  * with one launch per step (n3d_pack_batch) and passes N3D_PREPACKED + the packed slot as `ws`.

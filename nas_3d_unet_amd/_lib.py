@@ -117,8 +117,6 @@ PROTOTYPES = {
     "n3d_conv_stats_rows": (_i, [_gp, _i, _i]),
     "n3d_stats_rows": (_i, [_i64, _i]),
     "n3d_conv_fwd": (_i, [_gp, _p, _i64, _p, _p, _p, _i64, _i, _p, _p, _p, _sz, _p]),
-    "n3d_conv_fwd_nol_ok": (_i, [_gp]),
-    "n3d_conv_fwd_nol": (_i, [_gp, _p, _i64, _p, _i64, _p, _p, _p, _p, _i, _p, _p, _p, _i64, _i, _p, _p, _sz, _p]),
     "n3d_conv_k1_norm_ok": (_i, [_gp]),
     "n3d_conv_k1_norm_rows": (_i, [_gp]),
     "n3d_conv_k1_norm_fwd": (_i, [_gp, _p, _i64, _p, _p, _p, _i64, _i, _p, _p, _p, _p, _sz, _p]),

@@ -656,10 +656,6 @@ struct VxArgs {
   double* stats; int rows_per_sample;
   int tiles;            // tiles per sample
   const void* zero_page; // 16 zero bytes in device memory
-  // normalise-on-load (NOL, round-4 probe; n3d_conv_fwd_nol): the conv input is a searched-cell NODE that was never materialised --
-  // node = relu?(a0 * src + b0) + relu?(a1 * src2 + b1) per voxel and channel (searched.py:45-50 behind prim_ops.py:68-83), formed in
-  // the LDS tile: src arrives by LDS-DMA as always, src2 through registers; padding slots stay 0.  nol_c[4]: a0, b0, a1, b1, each [B][C]
-  const float* src2; int64_t sld2; const float* nol_c[4]; int nol_relu;   // nol_relu: bit 0 / 1 = ReLU on term 0 / 1
 };
 
 // Wq[tap][cd][cs]; forward: cd=co, cs=ci, tap'=tap; data gradient: cd=ci, cs=co, tap'=26-tap
@@ -710,9 +706,8 @@ extern "C" int n3d_debug_vox_stamps2(unsigned long long* host, int n) {
 #ifndef VOX_LB
 #define VOX_LB 2
 #endif
-template <int C, int TD, int DIL, int NW, bool NOL = false>
+template <int C, int TD, int DIL, int NW>
 __global__ __launch_bounds__(64 * NW, VOX_LB) void conv_vox64_kernel(VxArgs a) {
-  static_assert(!NOL || C == 4, "normalise-on-load: C = 4 only (probe)");
   N3D_CHAIN_PRIO();
   constexpr int Q = C / 4, GH = 4 * NW, GW = 16;
   constexpr int LD = TD + 2 * DIL, LH = GH + 2 * DIL, LW = GW + 2 * DIL;
@@ -782,30 +777,6 @@ __global__ __launch_bounds__(64 * NW, VOX_LB) void conv_vox64_kernel(VxArgs a) {
 #endif
     }
     const int64_t pstride = (int64_t)a.H * a.W * a.sld;
-    // NOL: the second raw term of the lane's own slots, requested through registers ahead of the DMA (one memory round trip for both)
-    float4 r1v[NOL ? NPOS : 1][NOL ? LD / NW : 1];
-    unsigned inbm[NOL ? NPOS : 1];
-    if constexpr (NOL) {
-      const float* s2b = a.src2 + (int64_t)b * N * a.sld2;
-      const int64_t p2stride = (int64_t)a.H * a.W * a.sld2;
-#pragma unroll
-      for (int i = 0; i < NPOS; ++i) {
-        const int pos = lane + i * 64;
-        const int wx = pos % LW, hy = pos / LW;
-        const int gh = h0 - DIL + hy, gw = w0 - DIL + wx;
-        const bool okp = pos < PLANE && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-        const float* prow2 = s2b + ((int64_t)gh * a.W + gw) * a.sld2;
-        inbm[i] = 0;
-#pragma unroll
-        for (int m = 0; m < LD / NW; ++m) {
-          const int dz = m * NW + (NW > 1 ? wave : 0);
-          const int gd = d0 - DIL + dz;
-          const bool inb = okp && gd >= 0 && gd < a.D;
-          r1v[i][m] = inb ? *reinterpret_cast<const float4*>(prow2 + gd * p2stride) : make_float4(0.f, 0.f, 0.f, 0.f);
-          inbm[i] |= inb ? (1u << m) : 0u;
-        }
-      }
-    }
 #pragma unroll
     for (int i = 0; i < NPOS; ++i) {
       const int pos = lane + i * 64;
@@ -832,32 +803,6 @@ __global__ __launch_bounds__(64 * NW, VOX_LB) void conv_vox64_kernel(VxArgs a) {
       }
     }
     VSTAMP(1);
-    if constexpr (NOL) {
-      // the lane normalises the slots it filled itself, in place (same wave wrote them: vmcnt(0), no barrier); slots outside the
-      // volume hold the zero page's 0 and stay untouched -- the conv's zero padding applies to the NODE, not to its raw terms
-      const float4 ca0 = reinterpret_cast<const float4*>(a.nol_c[0])[b], cb0 = reinterpret_cast<const float4*>(a.nol_c[1])[b],
-                   ca1 = reinterpret_cast<const float4*>(a.nol_c[2])[b], cb1 = reinterpret_cast<const float4*>(a.nol_c[3])[b];
-      const float f0 = (a.nol_relu & 1) ? 0.f : -INFINITY, f1 = (a.nol_relu & 2) ? 0.f : -INFINITY;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < NPOS; ++i) {
-#pragma unroll
-        for (int m = 0; m < LD / NW; ++m) {
-          if (inbm[i] & (1u << m)) {
-            const int dz = m * NW + (NW > 1 ? wave : 0);
-            float4* sl = tile + dz * PSTRIDE + i * 64 + lane;
-            const float4 v = *sl, r = r1v[i][m];
-            float4 z;
-            z.x = fmaxf(fmaf(ca0.x, v.x, cb0.x), f0) + fmaxf(fmaf(ca1.x, r.x, cb1.x), f1);
-            z.y = fmaxf(fmaf(ca0.y, v.y, cb0.y), f0) + fmaxf(fmaf(ca1.y, r.y, cb1.y), f1);
-            z.z = fmaxf(fmaf(ca0.z, v.z, cb0.z), f0) + fmaxf(fmaf(ca1.z, r.z, cb1.z), f1);
-            z.w = fmaxf(fmaf(ca0.w, v.w, cb0.w), f0) + fmaxf(fmaf(ca1.w, r.w, cb1.w), f1);
-            *sl = z;
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (NW > 1) __syncthreads();  // each wave reads rows the other wave's DMA filled
@@ -1492,14 +1437,8 @@ static int launch_vox_t(VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
   a.zero_page = zero_page_ptr();
   if (!a.zero_page) return 0;
   if constexpr (C == 4 && TD == 4) {
-    if (a.src2) {      // normalise-on-load form (n3d_conv_fwd_nol)
-      if (p.nw == 2) hipLaunchKernelGGL((conv_vox64_kernel<C, TD, DIL, 2, true>), dim3(p.tiles * B), dim3(128), p.lds, s, a);
-      else hipLaunchKernelGGL((conv_vox64_kernel<C, TD, DIL, 1, true>), dim3(p.tiles * B), dim3(64), p.lds, s, a);
-      return 1;
-    }
     if (p.nw == 2) { hipLaunchKernelGGL((conv_vox64_kernel<C, TD, DIL, 2>), dim3(p.tiles * B), dim3(128), p.lds, s, a); return 1; }
   }
-  if (a.src2) return 0;
   hipLaunchKernelGGL((conv_vox64_kernel<C, TD, DIL, 1>), dim3(p.tiles * B), dim3(64), p.lds, s, a);
   return 1;
 }
@@ -2587,10 +2526,6 @@ int g16_prepare(const n3d_conv_geom* g, bool data_grad, const float* src, int64_
                 int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate, double* stats,
                 void* ws, size_t ws_bytes, hipStream_t s, MfArgs* out, G16Plan* plan);
 
-// extras of n3d_conv_fwd_nol for the vox64 kernel (set around its mfma_conv_try call on the calling thread)
-struct VoxNol { const float* src2; int64_t sld2; const float* c[4]; int relu; bool used; };
-static thread_local VoxNol* g_vox_nol = nullptr;
-
 int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int64_t sld, const float* w, const float* bias, float* dst,
                   int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate, double* stats,
                   void* ws, size_t ws_bytes, hipStream_t s) {
@@ -2653,13 +2588,6 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
       VxArgs a;
       a.src = src; a.sld = sld; a.dst = dst; a.dld = dld; a.wq = wq; a.bias = bias; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.flags = flags;
       a.stats = stats; a.rows_per_sample = v.tiles * v.nw;
-      a.src2 = nullptr; a.sld2 = 0; a.nol_relu = 0;
-      for (int k = 0; k < 4; ++k) a.nol_c[k] = nullptr;
-      if (g_vox_nol) {
-        if (v.C != 4 || v.td != 4 || data_grad || g_vox_nol->sld2 % 4 != 0 || !aligned16(g_vox_nol->src2)) return 0;
-        for (int k = 0; k < 4; ++k) { if (!aligned16(g_vox_nol->c[k])) return 0; a.nol_c[k] = g_vox_nol->c[k]; }
-        a.src2 = g_vox_nol->src2; a.sld2 = g_vox_nol->sld2; a.nol_relu = g_vox_nol->relu; g_vox_nol->used = true;
-      }
       const int launched = v.C == 4 ? launch_vox_c<4>(a, v, g->B, s) : launch_vox_c<8>(a, v, g->B, s);
       if (!launched) { set_error("conv(vox64): zero page symbol unavailable"); return N3D_ERR_HIP; }
       hipError_t e = hipGetLastError();
@@ -3113,26 +3041,3 @@ int mfma_bwd_quad_try(BwdOne* c0, BwdOne* c1, hipStream_t s) {
 
 
 }  // namespace n3d
-
-
-// ---- normalise-on-load probe (include/n3d.h, n3d_conv_fwd_nol) ---------------------------------------------------------------
-using namespace n3d;
-extern "C" int n3d_conv_fwd_nol_ok(const n3d_conv_geom* g) {
-  if (!g) return 0;
-  VxPlan v = vx_plan(g);
-  return v.ok && v.C == 4 && v.td == 4 ? 1 : 0;
-}
-extern "C" int n3d_conv_fwd_nol(const n3d_conv_geom* g, const float* x0, int64_t x0ld, const float* x1, int64_t x1ld, const float* a0,
-                                const float* b0, const float* a1, const float* b1, int relu_mask, const float* w, const float* bias, float* y,
-                                int64_t yld, int flags, double* stats, void* ws, size_t ws_bytes, void* stream) {
-  N3D_CHECK_ARG(g && x0 && x1 && a0 && b0 && a1 && b1 && w && y && ws && x0ld >= g->Ci && x1ld >= g->Ci && yld >= g->Co, "conv_fwd_nol: bad args");
-  if (!n3d_conv_fwd_nol_ok(g) || (flags & (N3D_SRC_BF16 | N3D_DST_BF16 | N3D_RELU_IN)))
-    N3D_UNSUPPORTED("conv_fwd_nol: the 3x3x3 stride-1 C = 4 conv on 4-plane tiles only (fp32)");
-  VoxNol nx = {x1, x1ld, {a0, b0, a1, b1}, relu_mask, false};
-  g_vox_nol = &nx;
-  const int r = mfma_conv_try(g, false, x0, x0ld, w, bias, y, yld, flags, nullptr, nullptr, 0, nullptr, stats, ws, ws_bytes, (hipStream_t)stream);
-  g_vox_nol = nullptr;
-  if (r < 0) return r;
-  if (r != 1 || !nx.used) N3D_UNSUPPORTED("conv_fwd_nol: operands do not fit the vox64 kernel (alignment / pitches)");
-  return N3D_OK;
-}

@@ -12,7 +12,6 @@ _node_units (terms grouped so that launches can be shared), i.e. the same sum wi
 """
 from __future__ import annotations
 
-import os
 
 import torch
 
@@ -186,7 +185,7 @@ def _run_forward(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=False):
 # node epilogue writes 16 bytes on a 48-byte pitch and every epilogue backward reads its gradient the same way: 0.28-0.47 of the HBM
 # roofline at 4x128^3 (round-3 review).  With PLANAR_LAST the callers that own both sides (unet.body -> head.run / run_loss, the
 # trainers' pipeline) set PLANAR_OUT around NetFn.forward and the last cell keeps its nodes dense; the head gathers three pointers.
-PLANAR_LAST = os.environ.get("N3D_PLANAR_LAST", "1") != "0"
+PLANAR_LAST = True     # (tests switch it off to compare with the concatenated layout)
 PLANAR_OUT = False
 
 
@@ -198,10 +197,9 @@ PLANAR_OUT = False
 # side stream's part of their node.  SIDE_FWD: .fork() main stores a flag, returns its id; .side(wait_id) context manager: launches
 # go to the side stream behind a wait on that flag; .side_signal() side stores a flag, returns its id; .join(id) main waits for it.
 SIDE_FWD = None
-NODE_APPLY = os.environ.get("N3D_NODE_APPLY", "1") != "0"     # ... and one apply launch for the level's SE gates and identity primitives (A/B knob)
-NODE_PHASES = os.environ.get("N3D_NODE_PHASES", "1") != "0"   # one reduction + one coefficient launch per node level of the supernet backward (A/B knob)
+NODE_APPLY = True     # ... and one apply launch for the level's SE gates and identity primitives (tests compare with the per-term launches)
+NODE_PHASES = True    # one reduction + one coefficient launch per node level of the supernet backward (tests compare with the per-term launches)
 SIDE_BWD = None      # the same object while the backward pass of a supernet may use the side stream (see _run_backward_impl)
-SIDE_NODE0_SPLIT = __import__("os").environ.get("N3D_SIDE_NODE0", "main") == "split"   # node 0: both edges on the main stream (one of them on the side stream measured 0.1 ms slower per search step)
 
 
 def _node_buffer(plan, shape, device, planar):
@@ -244,7 +242,7 @@ def _run_forward_side(plan, x0, x1, alpha1, alpha2, sf, planar=False):
     def on_side(node, idx):
         """does the weight phase of a term of `node` reading state `idx` run on the side stream?"""
         if node == 0:
-            return idx == 1 and SIDE_NODE0_SPLIT
+            return False            # node 0: both edges on the main stream (one of them on the side stream measured 0.1 ms slower per search step)
         return idx <= node          # node n's newest input is state n + 1
 
     order = {node: [fi for unit in units[node] for fi in unit] for node in range(nn)}     # the epilogue order of the node's terms
@@ -285,40 +283,11 @@ def _run_forward_side(plan, x0, x1, alpha1, alpha2, sf, planar=False):
     return out.t, st
 
 
-SIDE_PAIRS = os.environ.get("N3D_SIDE_PAIRS", "1") != "0"   # searched cells with C <= 8: one conv of a node early on the side stream
-# (the FORWARD of the down cells' first preprocess op early on the side stream as well: measured slower, 1.992 vs 1.982 ms -- the two
-# preprocess ops of a down cell share their conv and epilogue launches on the chain, and splitting that pair costs more than the join)
-SIDE_PRE0_FWD_ALL = os.environ.get("N3D_SIDE_PRE0_FWD_ALL", "0") != "0"
-SIDE_STEM1_BWD = os.environ.get("N3D_SIDE_STEM1_BWD", "1") != "0"   # stem1's backward (parameter gradients only) beside stem0's
-SIDE_PRE0_BWD = os.environ.get("N3D_SIDE_PRE0_BWD", "1") != "0"     # searched cells: the backward of EVERY cell's first preprocess op on the side stream
-SIDE_PAIRS_BOTH = os.environ.get("N3D_SIDE_PAIRS_BOTH", "1") != "0"   # ... and of nodes whose two convs both read node outputs, one conv beside the other (1.756 -> 1.748 ms)
-SIDE_PAIRS_BWD = os.environ.get("N3D_SIDE_PAIRS_BWD", "1") != "0"   # ... and the data gradients into one preprocess gradient (needs a third stream)
-
-
-# Normalise-on-load (round 4, SURVEY 7 hard part 3): in a searched cell whose node readers are all 3x3x3 stride-1 C = 4 convs on 4-plane
-# tiles (the last up cell at 2 x 64^3 / 128^3), the epilogue launch of every node but the last leaves the chain -- the coefficient launch
-# stays, the epilogue runs on the side stream (the node is still needed by the head / the backward pass) and the readers form the node
-# in their LDS tile from its two raw terms (n3d_conv_fwd_nol).  The kernel-level probe promised 5-6 us per hand-off
-# (profiles/r04_nol_probe.log); IN the step the form is slower (+0.009 ms at 64^3, +0.04 ms at 128^3, profiles/r04_nol_in_situ_ab.log: the
-# extra issue work of the convs and the flag hand-offs stay on the chain, the epilogue still runs beside it) -- OFF by default, kept behind
-# N3D_NOL=1 with its parity test.
-NOL = os.environ.get("N3D_NOL", "0") != "0"
-
-
-def _nol_nodes(plan, xs):
-    """nodes (indices) of a searched cell whose epilogue may run off the chain: every op that reads them can normalise on load"""
-    if not (NOL and plan.pairs and plan.c_node == 4 and plan.dt == torch.float32):
-        return set()
-    ok = set(range(plan.n_nodes - 1))
-    for node, idx, segs, _, _ in plan.edges:
-        if idx >= 2:
-            seg = segs[0][0]
-            j = idx - 2
-            if not (isinstance(seg.weight, P.DenseConvW) and P.gn_pairable(seg) and not seg.relu_in and seg.weight.nol_ok(xs[idx])):
-                ok.discard(j)
-    # a node nobody reads gains nothing
-    read = {idx - 2 for _, idx, _, _, _ in plan.edges if idx >= 2}
-    return ok & read
+SIDE_PAIRS = True   # searched cells with C <= 8: one conv of a node early on the side stream
+SIDE_STEM1_BWD = True   # stem1's backward (parameter gradients only) beside stem0's
+SIDE_PRE0_BWD = True     # searched cells: the backward of EVERY cell's first preprocess op on the side stream
+SIDE_PAIRS_BOTH = True   # ... and of nodes whose two convs both read node outputs, one conv beside the other (1.756 -> 1.748 ms)
+SIDE_PAIRS_BWD = True   # ... and the data gradients into one preprocess gradient (needs a third stream)
 
 
 def _early_pair_ops(plan):
@@ -388,8 +357,6 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=Fals
             if out is None:
                 out, nodes = _node_buffer(plan, seg0.weight.out_shape(xs[i0]), xs[i0].t.device, planar)
                 xs.extend(nodes)
-                nol_nodes = _nol_nodes(plan, xs) if SIDE_FWD is not None else set()
-            ns = SIDE_FWD if node in nol_nodes else None
             if node in side_res:
                 e, res_side, tok = side_res[node]
                 if e == 2 * node:
@@ -397,7 +364,7 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=Fals
                 else:
                     res0, res1 = P.pair_weight_phase(seg0, xs[i0]), res_side
                 SIDE_FWD.join(tok)
-                s0, s1 = P.pair_epilogue_phase(seg0, res0, seg1, res1, nodes[node], nol_side=ns)
+                s0, s1 = P.pair_epilogue_phase(seg0, res0, seg1, res1, nodes[node])
             elif (SIDE_PAIRS_BOTH and SIDE_FWD is not None and cn <= 8 and isinstance(seg0.weight, P.DenseConvW)
                   and isinstance(seg1.weight, P.DenseConvW) and P.gn_pairable(seg0) and P.gn_pairable(seg1)):
                 # both convs read node outputs: still two launches (no common MFMA problem) -- the cheaper one beside the other
@@ -410,18 +377,10 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=Fals
                 res_b = P.pair_weight_phase(sb_, xs[ib])
                 sf.join(tok)
                 res0, res1 = (res_b, res_a) if cheap1 else (res_a, res_b)
-                s0, s1 = P.pair_epilogue_phase(seg0, res0, seg1, res1, nodes[node], nol_side=ns)
+                s0, s1 = P.pair_epilogue_phase(seg0, res0, seg1, res1, nodes[node])
             else:
-                s0, s1 = P.pair_forward(seg0, xs[i0], seg1, xs[i1], nodes[node], nol_side=ns)
+                s0, s1 = P.pair_forward(seg0, xs[i0], seg1, xs[i1], nodes[node])
             st.saved.extend([s0, s1])
-        # the nodes whose epilogue ran on the side stream are complete behind these joins (the head / the next cell / the backward pass
-        # read the materialised node); from here on nobody normalises on load
-        for s0 in st.saved[::2]:
-            tok = getattr(s0, "nol_tok", None)
-            if tok is not None:
-                SIDE_FWD.join(tok)
-        for nv in nodes:
-            nv.nol = None
         st.xs, st.out = xs, out
         return out.t, st
     # supernet cell (cell.py:76-81): node = sum over its edges of sum_k alpha[e][k] * op_k(x_e), accumulated unit by unit
@@ -979,7 +938,9 @@ class NetFn(torch.autograd.Function):
             not need it before the whole lower part of the U has run, so its 1x1x1 preprocess op starts on the side stream here"""
             if sf is None or nplan.supernet:
                 return
-            for k in range(0 if SIDE_PRE0_FWD_ALL else nplan.n_down, len(nplan.wiring)):
+            # (the down cells' first preprocess op stays on the chain: the two preprocess ops of a down cell share their conv and epilogue
+            # launches there, and splitting that pair measured slower than the join it saves)
+            for k in range(nplan.n_down, len(nplan.wiring)):
                 pl = nplan.cells[k]
                 if nplan.wiring[k][0] == act_index and pl.pairs and pl.pre0.dropout is None:
                     f = sf.fork()

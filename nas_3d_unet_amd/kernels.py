@@ -145,11 +145,9 @@ def _same_dt(what, *views):
 class View:
     """Pitched NDHWC view of a logical (B, C, D, H, W) device tensor (fp32, or bf16 storage: dt = N3D_F32 / N3D_BF16;
     the pitch counts elements)."""
-    __slots__ = ("t", "p", "ld", "B", "C", "D", "H", "W", "N", "dt", "nol")
+    __slots__ = ("t", "p", "ld", "B", "C", "D", "H", "W", "N", "dt")
 
     def __init__(self, t, ld):
-        self.nol = None      # (raw0 View, raw1 View, (a0, b0, a1, b1), relu mask): a searched-cell node whose epilogue runs off the chain -- a
-                             # consumer conv that can normalise on load reads the raw terms instead (programs.DenseConvW.fwd, fused.NOL)
         self.t = t
         self.p = C.c_void_p(t.data_ptr())
         self.ld = int(ld)
@@ -501,21 +499,6 @@ def conv_bwd_weight(g, x: View, dy: View, dw, dbias, flags=0, in_gate=None, tran
         _ctx.keep.append(ws)  # the partial slabs live in ws until StepContext.flush_final()
 
 
-def conv_fwd_nol_ok(g):
-    return bool(_lib.load().n3d_conv_fwd_nol_ok(C.byref(g)))
-
-
-def conv_fwd_nol(g, x0: View, x1: View, coefs, relu_mask, w, bias, y: View, stats=None):
-    """normalise-on-load (include/n3d.h, n3d_conv_fwd_nol): the conv of the node relu?(a0 x0 + b0) + relu?(a1 x1 + b1) that was not
-    materialised; coefs = (a0, b0, a1, b1), each (B, C)"""
-    _need_f32("conv_fwd_nol", x0, x1, y)
-    ws, wsp, n, flags = _packed(w, g, False, 0, x0.t.device)
-    a0, b0, a1, b1 = coefs
-    check(_lib.load().n3d_conv_fwd_nol(C.byref(g), x0.p, x0.ld, x1.p, x1.ld, ptr(a0), ptr(b0), ptr(a1), ptr(b1), int(relu_mask), ptr(w), ptr(bias),
-                                       y.p, y.ld, flags, ptr(stats), wsp, n, stream_ptr()), "n3d_conv_fwd_nol")
-
-
-# ---- "weight_norm" 1x1x1 conv without its raw output (include/n3d.h: n3d_conv_k1_norm_*; programs._seg_forward_recompute) ----------
 def conv_k1_norm_ok(g):
     return bool(_lib.load().n3d_conv_k1_norm_ok(C.byref(g)))
 
@@ -825,12 +808,9 @@ def pair_shape_ok(Cc):
     return 4 <= Cc <= 64 and (Cc & (Cc - 1)) == 0
 
 
-def affine_act_gn2(terms, G, eps, out: View, flags=0, out1: View | None = None, split=False):
+def affine_act_gn2(terms, G, eps, out: View, flags=0, out1: View | None = None):
     """Two GroupNorm -> [ReLU] -> weighted-sum epilogues into one output: terms = [(raw, stats, rows, gamma, beta, wptr, relu)] * 2.
-    Returns [(a, b, mean_rstd, sumraw)] * 2 (saved for backward).
-    split (large tensors only: coefficient launch + epilogue launch): only the coefficients are launched here; returns (saved, launch)
-    with launch() = the epilogue launch, for the caller to put on another stream (normalise-on-load, fused.NOL) -- or (saved, None) when
-    this shape takes the one-launch form."""
+    Returns [(a, b, mean_rstd, sumraw)] * 2 (saved for backward)."""
     raw0 = terms[0][0]
     _same_dt("affine_act_gn2", raw0, terms[1][0], out, out1)
     flags |= _aflag(raw0)
@@ -853,20 +833,14 @@ def affine_act_gn2(terms, G, eps, out: View, flags=0, out1: View | None = None, 
     if pair_ok(Cc, G, terms[0][2], terms[1][2], B):
         check(lib.n3d_affine_act_gn2(C.byref(ts[0]), C.byref(ts[1]), G, eps, out.p, out.ld, o1p, o1ld, B, raw0.N, Cc, flags,
                                      stream_ptr()), "n3d_affine_act_gn2")
-        return (saved, None) if split else saved
+        return saved
     # large tensors: coefficients of both ops in one launch, then the two-term epilogue
     check(lib.n3d_gn_coeffs2(C.byref(ts[0]), C.byref(ts[1]), B, Cc, G, raw0.N, eps, stream_ptr()), "n3d_gn_coeffs2")
-
-    def launch(ts=ts, N=raw0.N):
-        check(lib.n3d_affine_act2(C.byref(ts[0]), C.byref(ts[1]), out.p, out.ld, o1p, o1ld, B, N, Cc, flags, stream_ptr()), "n3d_affine_act2")
-    if split:
-        return saved, launch
-    launch()
+    check(lib.n3d_affine_act2(C.byref(ts[0]), C.byref(ts[1]), out.p, out.ld, o1p, o1ld, B, raw0.N, Cc, flags, stream_ptr()), "n3d_affine_act2")
     return saved
 
 
 SMALL_NODE_BACKWARD = True   # the one-launch epilogue backward of a node on the small levels (n3d_affine_act_bwd_small2)
-SINGLE_SMALL_BACKWARD = os.environ.get("N3D_SINGLE_SMALL_BACKWARD", "0") != "0"   # ... and of a single epilogue (programs.seg_backward): measured no faster either
 
 
 def affine_act_bwd_gn2(dout: View, terms, G, dout1: View | None = None):
@@ -928,19 +902,17 @@ def _tickets(device, n):
 
 
 _small_modes = {}
-# mode 2 of small_backward_mode (the 8^3 level at batch 2) is OFF by default: measured on the benchmarked step it is no faster than the
-# reduce2 + apply_gn2 pair it replaces (main chain 1.928 vs 1.920 ms, profiles/r03_contention_probes.log) -- a dependent launch
-# boundary costs ~1.65 us on this machine, less than the serial latency the 1024-thread form adds
-MID_NODE_BACKWARD = os.environ.get("N3D_MID_BACKWARD", "0") != "0"
+# (mode 2 of n3d_bwd_small_mode -- the 8^3 level at batch 2, one workgroup per (group, sample) -- is not used: on the benchmarked step it
+# measured no faster than the reduce2 + apply_gn2 pair it replaces, main chain 1.928 vs 1.920 ms, profiles/r03_contention_probes.log)
 
 
 def small_backward_mode(B, N, Cc, G):
-    """0 = the one-launch epilogue backward does not take this shape; 1 = one workgroup per GroupNorm group; 2 = one per (group,
-    sample) (include/n3d.h, n3d_affine_act_bwd_small)"""
+    """0 = the one-launch epilogue backward does not take this shape; 1 = one workgroup per GroupNorm group (include/n3d.h,
+    n3d_affine_act_bwd_small)"""
     key = (B, N, Cc, G)
     m = _small_modes.get(key)
     if m is None:
-        m = _small_modes[key] = int(_lib.load().n3d_bwd_small_mode(B, N, Cc, G)) if MID_NODE_BACKWARD else int(_lib.load().n3d_bwd_small2_ok(B, N, Cc, G))
+        m = _small_modes[key] = int(_lib.load().n3d_bwd_small2_ok(B, N, Cc, G))
     return m
 
 

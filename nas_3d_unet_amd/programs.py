@@ -196,23 +196,9 @@ class DenseConvW(WeightProgram):
         wp._n3d_nopack = True
         return xp, wp
 
-    def nol_ok(self, x):
-        """can this conv read the node `x` as its two raw terms + coefficients (n3d_conv_fwd_nol: 3x3x3 stride 1, C = 4, 4-plane tiles, fp32)?"""
-        return (self.k == 3 and self.stride == 1 and not self.transposed and x.C == 4 and x.dt == _F32
-                and self.m.weight.shape[0] == 4 and self.m.weight.shape[1] == 4 and K.conv_fwd_nol_ok(self.geom(x)))
-
     def fwd(self, x, relu_in, gate, want_stats):
         call, res = self.fwd_prepare(x, relu_in, gate, want_stats)
         g, xx, w, b, y, fl, gt, stats, tr = call
-        nol = getattr(xx, "nol", None)
-        if nol is not None and not relu_in and gt is None and not tr and self.nol_ok(xx):
-            # the node was not materialised on this stream (its epilogue runs on the side stream): normalise on load
-            raw0, raw1, coefs, mask = nol
-            K.conv_fwd_nol(g, raw0, raw1, coefs, mask, w, b, y, stats)
-            return res
-        if nol is not None:
-            raise N3DError("a node with a pending off-chain epilogue reached a conv that cannot normalise on load (fused.NOL plans only "
-                           "cells whose node readers all can)")
         K.conv_fwd(g, xx, w, b, y, fl, gt, stats, tr)
         return res
 
@@ -557,7 +543,7 @@ def _wptr(alpha_row, k):
     return C.c_void_p(alpha_row.data_ptr() + 4 * k)
 
 
-RECOMPUTE_K1 = __import__("os").environ.get("N3D_K1_RECOMPUTE", "1") != "0"
+RECOMPUTE_K1 = True     # (tests switch it off to compare with the stored form)
 
 
 def recompute_ok(seg, x):
@@ -664,7 +650,7 @@ def gn_pairable(seg):
     return _pairable_fwd(seg) and not isinstance(seg.weight, IdentityW) and seg.dropout is None
 
 
-def pair_forward(segA, xA, segB, xB, out, outB=None, accumulate=False, alphaA=None, alphaB=None, nol_side=None):
+def pair_forward(segA, xA, segB, xB, out, outB=None, accumulate=False, alphaA=None, alphaB=None):
     """Node of a searched cell: out = segA(xA) + segB(xB) (searched.py:45-50), `out` a View that is overwritten.
     With `outB` the two ops are independent (the two preprocess ops of a cell, cell.py:47-50): segA -> out, segB -> outB.
     Supernet nodes (cell.py:76-81) use it too: alphaX = (alpha row tensor, column) is the MixedOp weight of the term and
@@ -672,8 +658,7 @@ def pair_forward(segA, xA, segB, xB, out, outB=None, accumulate=False, alphaA=No
     Both weight ops run first; if both epilogues are small GroupNorm epilogues of one shape they share ONE launch
     (n3d_affine_act_gn2), otherwise the two ordinary epilogues run one after the other.  Returns (savedA, savedB)."""
     res = []
-    if (isinstance(segA.weight, DenseConvW) and isinstance(segB.weight, DenseConvW)
-            and getattr(xA, "nol", None) is None and getattr(xB, "nol", None) is None):
+    if isinstance(segA.weight, DenseConvW) and isinstance(segB.weight, DenseConvW):
         # both weight ops are plain convs: one launch where libn3d can fold them (n3d_conv_fwd2)
         calls = []
         for seg, x in ((segA, xA), (segB, xB)):
@@ -687,7 +672,7 @@ def pair_forward(segA, xA, segB, xB, out, outB=None, accumulate=False, alphaA=No
         res = [tuple(r) for r in res]
     else:
         res = [pair_weight_phase(seg, x) for seg, x in ((segA, xA), (segB, xB))]
-    return pair_epilogue_phase(segA, res[0], segB, res[1], out, outB, accumulate, alphaA, alphaB, nol_side)
+    return pair_epilogue_phase(segA, res[0], segB, res[1], out, outB, accumulate, alphaA, alphaB)
 
 
 def pair_weight_phase(seg, x):
@@ -701,12 +686,9 @@ def pair_weight_phase(seg, x):
     return (raw, stats, rows, ws)
 
 
-def pair_epilogue_phase(segA, resA, segB, resB, out, outB=None, accumulate=False, alphaA=None, alphaB=None, nol_side=None):
+def pair_epilogue_phase(segA, resA, segB, resB, out, outB=None, accumulate=False, alphaA=None, alphaB=None):
     """second half of pair_forward: the two epilogues (one launch where they pair) of weight ops that are complete on the
-    launching stream.
-    nol_side (a train.SideSchedule; fused.NOL): the node `out` is read only by convs that normalise on load -- on large tensors the
-    coefficient launch stays on this stream, the epilogue launch that materialises the node goes to the side stream (flag id in
-    out.nol_tok via the returned states' `.nol_tok`), and `out.nol` tells the readers where the raw terms are."""
+    launching stream."""
     res = [resA, resB]
     (rawA, stA, rowsA, wsA), (rawB, stB, rowsB, wsB) = res
     G = group_count(rawA.C)
@@ -716,22 +698,12 @@ def pair_epilogue_phase(segA, resA, segB, resB, out, outB=None, accumulate=False
         wpB = _wptr(*alphaB) if alphaB is not None else None
         terms = [(rawA, stA, rowsA, segA.norm.weight, segA.norm.bias, wpA, segA.relu_out),
                  (rawB, stB, rowsB, segB.norm.weight, segB.norm.bias, wpB, segB.relu_out)]
-        tok = None
-        if nol_side is not None and outB is None and not accumulate and wpA is None and wpB is None and rawA.dt == _F32:
-            sv, launch = K.affine_act_gn2(terms, G, segA.norm.eps, out, 0, None, split=True)
-            if launch is not None:
-                with nol_side.side(nol_side.fork()):
-                    launch()
-                    tok = nol_side.side_signal()
-                out.nol = (rawA, rawB, (sv[0][0], sv[0][1], sv[1][0], sv[1][1]), (1 if segA.relu_out else 0) | (2 if segB.relu_out else 0))
-        else:
-            sv = K.affine_act_gn2(terms, G, segA.norm.eps, out, ACCUMULATE if accumulate else 0, outB)
+        sv = K.affine_act_gn2(terms, G, segA.norm.eps, out, ACCUMULATE if accumulate else 0, outB)
         saved = []
         for (raw, _, _, ws), (a, b, mr, sr) in zip(res, sv):
             s = Saved()
             s.ws, s.raw, s.kind, s.G = ws, raw, "gn", G
             s.a, s.b, s.mr, s.sumraw = a, b, mr, sr
-            s.nol_tok = tok
             saved.append(s)
         return saved[0], saved[1]
     aA, kA = alphaA if alphaA is not None else (None, 0)
@@ -909,7 +881,7 @@ def group_ok(segs):
             and all(g.norm.eps == segs[0].norm.eps for g in segs))
 
 
-NODE_FWD_COEFFS = os.environ.get("N3D_NODE_FWD_COEFFS", "1") != "0"   # (A/B knob) GroupNorm coefficients + SE gates of a group in one launch
+NODE_FWD_COEFFS = True   # GroupNorm coefficients + SE gates of a group in one launch (tests compare with the per-term launches)
 
 
 def group_forward(terms, out, accumulate):
@@ -1126,15 +1098,6 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
         ident = isinstance(seg.weight, IdentityW)
         if ident and not need_dx:
             ident = False
-        if (pre_sums is None and dap is None and not ident and K.SMALL_NODE_BACKWARD and K.SINGLE_SMALL_BACKWARD
-                and K.small_backward_mode(raw.B, raw.N, raw.C, s.G)):
-            # small levels: reduction, coefficients, parameter gradients and d(raw) in ONE launch (the two-term form of a node's
-            # epilogue backward, K.affine_act_bwd_gn2, run for this one term)
-            draw = K.like(raw)
-            (dgamma, dbeta, dcb), = K.affine_act_bwd_small(dout, [dict(raw=raw, a=s.a, b=s.b, mr=s.mr, sumraw=s.sumraw, gamma=seg.norm.weight,
-                                                                      beta=seg.norm.bias, wptr=wp, relu=seg.relu_out, conv_bias=cbias,
-                                                                      draw=draw)], s.G)
-            return _finish_gn_backward(seg, s, draw, need_dx, dx_out, dx_acc, cbias, dcb, dgamma, dbeta)
         sums, rows = pre_sums if pre_sums is not None else K.affine_act_bwd_reduce(dout, raw, s.a, s.b, fl)
         if ident:
             # the raw tensor is the input itself: the apply pass writes dx directly

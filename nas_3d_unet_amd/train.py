@@ -240,8 +240,6 @@ _side_streams = {}   # device index -> [side streams made so far]: trainers shar
 def _low_priority_stream(device):
     """a stream of the LOWEST priority the runtime offers (the side work must not take compute units from the backward chain);
     torch only exposes normal / high, so the stream is made through HIP and wrapped"""
-    if os.environ.get("N3D_SIDE_PRIORITY", "low") != "low":
-        return torch.cuda.Stream(device=device)
     try:
         with torch.cuda.device(device):
             # (A CU mask on the side stream does not help: hipExtStreamCreateWithCUMask makes a BLOCKING stream -- next to torch's
@@ -308,18 +306,16 @@ class SideSchedule:
         with the preprocess-fed edges of its forward and backward); without it, or when no second stream passes the probe, the
         weight gradients share the one side stream"""
         self.device, self.ctx = device, ctx
-        self.min_queue = int(os.environ.get("N3D_SIDE_MIN_QUEUE", "5")) if min_queue is None else int(min_queue)
+        self.min_queue = 5 if min_queue is None else int(min_queue)
         # cuts from the end at which the side stream reduces the slabs it has so far (0 = off, the default: measured at 64^3 the
         # tail shrinks 66 -> 49 us but the reduction takes 24 us out of the chain it runs beside)
-        self.early_finalize = int(os.environ.get("N3D_SIDE_EARLY_FINALIZE", "0"))
+        self.early_finalize = 0
         # live cuts: the slabs launched so far are reduced on the weight-gradient stream behind the n-th group (0 = never, -1 = at 55 %
         # of the groups the fullest pass so far had).  64^3 train step: tail 0.078 -> 0.064 ms, chain +0.001 (n = 11 of 20)
-        self.early_at = int(os.environ.get("N3D_SIDE_EARLY_AT", "-1"))
-        self.tail_inline = tuple(int(c) for c in os.environ.get("N3D_SIDE_TAIL_INLINE", "2").split(",") if c.strip().isdigit())
-        # every k-th weight-gradient group on the inline side stream (0 = none).  At 4x128^3 the weight-gradient stream is the LONGER one:
-        # 94 % busy during the backward walk, 130-260 us behind every cut, and the join waits 180 us behind the chain's last cut
-        # (profiles/r04_side_timeline_p128_bf16.txt) while the inline side stream idles
-        self.alternate = int(os.environ.get("N3D_SIDE_ALTERNATE", "0"))
+        self.early_at = -1
+        # weight-gradient groups, counted from the end of the walk, that go to the INLINE side stream instead (see cut()).  (Every k-th
+        # group there, or a second weight-gradient stream, measured slower: profiles/r04_alternate_ab.log)
+        self.tail_inline = (2,)
         self._live_cuts = 0
         self._live_cuts_max = 0
         self.sync = torch.zeros(8 + self.JOIN + 8, dtype=torch.int32, device=device)
@@ -344,7 +340,7 @@ class SideSchedule:
         self.trace = torch.zeros(3 * self.JOIN + 16, dtype=torch.int64, device=device) if os.environ.get("N3D_SIDE_TRACE") == "1" else None
         self.stream = self._probe()
         self.wstream = self.stream
-        if wgrad_stream and self.stream is not None and os.environ.get("N3D_SIDE_WSTREAM", "1") != "0":
+        if wgrad_stream and self.stream is not None:
             w = self._probe(exclude=(self.stream,))
             if w is not None:
                 self.wstream = w
@@ -712,8 +708,7 @@ class SideSchedule:
                 # the weight-gradient stream is backlogged at the end of the walk (the 64^3-level kernels: the join waited ~45 us
                 # behind the chain's last cut, tools/side_timeline.py) while the inline side stream is mostly idle there: the group
                 # tail_inline positions from the end (default: the second to last) goes to that stream instead; 1.865 -> 1.85 ms
-                inline = self.split and ((self._live_cuts_max >= 8 and (self._live_cuts_max - self._live_cuts) in self.tail_inline)
-                                         or (self.alternate > 0 and self._live_cuts % self.alternate == self.alternate - 1))
+                inline = self.split and self._live_cuts_max >= 8 and (self._live_cuts_max - self._live_cuts) in self.tail_inline
                 with K.on_side(self.stream if inline else self.wstream):
                     word = self.ptr(2) if inline else self.wptr()
                     K.sync_wait(self.ptr(8 + i), word, self.ptr(1), False)
@@ -918,7 +913,7 @@ class Trainer:
         # weight-gradient stream); without one the exchange is a single bucket behind the step
         self._buckets = self._bucket_plan() if (self.dp_path and self.n_buckets > 1 and self.side is not None) else None
         if self._buckets is not None:
-            self.side.tail_inline, self.side.alternate = (), 0      # every weight-gradient group on ONE stream: a closed bucket's slabs are reduced there
+            self.side.tail_inline = ()      # every weight-gradient group on ONE stream: a closed bucket's slabs are reduced there
             self.sync.ranges = [r for _, r in self._buckets]
         self.sync.broadcast(self.fp.flat)
 
@@ -1373,14 +1368,14 @@ class SearchTrainer:
         self.side_wgrad = (env != "0") if side_wgrad is None else bool(side_wgrad)
         self._side_force = side_wgrad == "force" or (side_wgrad is None and env == "force")   # as in Trainer: no comparison
         self._side_active = True     # _pass: use the side stream (when there is one)
-        self.side_forward = os.environ.get("N3D_SIDE_FORWARD", "1") != "0"   # ... also for the off-chain edges of the forward passes
-        self.side_backward = os.environ.get("N3D_SIDE_BACKWARD", "1") != "0"  # ... and for the preprocess-fed edges of the backward passes
+        self.side_forward = True    # ... also for the off-chain edges of the forward passes
+        self.side_backward = True   # ... and for the preprocess-fed edges of the backward passes
         # which preprocess-fed edges the side stream takes in the backward: the second input's only (round 4; "01" = both until then --
         # since the node levels' phases are single launches the chain absorbs the first input's terms in its own, wider, launches
         # and the side stream's last node level -- which the chain waits for at the end of every cell -- is half as long:
         # architecture pass 5.45 -> 5.25 ms, tools/search_phases.py)
-        self.side_backward_inputs = tuple(int(c) for c in os.environ.get("N3D_SIDE_BACKWARD_IN", "1") if c.isdigit())
-        self.side_backward_weight = tuple(int(c) for c in os.environ.get("N3D_SIDE_BACKWARD_W", "") if c.isdigit())   # (weight pass: which ones; default none)
+        self.side_backward_inputs = (1,)
+        self.side_backward_weight = ()      # (weight pass without a weight-gradient stream of its own: none)
         self._use_side = False
         self.schedule_times = None
         self.loss_fn = WeightedDiceLoss()
@@ -1399,7 +1394,7 @@ class SearchTrainer:
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
         self.ctx = K.StepContext(self.device)
         self.side = SideSchedule(self.device, self.ctx, wgrad_stream=True) if (self.side_wgrad and self.device.type == "cuda") else None
-        if self.side is not None and "N3D_SIDE_TAIL_INLINE" not in os.environ:
+        if self.side is not None:
             # the weight pass' weight-gradient stream (219 launches) ends ~0.5 ms behind the chain: every other group of the walk's last
             # eleven goes to the inline side stream instead, which has little else to do in the backward (weight pass 5.57 + 0.51 ->
             # 5.78 + 0.09 ms; more groups there slow the chain by more than they take off the tail: tools/search_phases.py sweeps,
@@ -1407,7 +1402,7 @@ class SearchTrainer:
             self.side.tail_inline = (1, 3, 5, 7, 9, 11)
         if self.side is not None and self.side.stream is None:
             self.side = None
-        if self.side is not None and "N3D_SIDE_EARLY_FINALIZE" not in os.environ:
+        if self.side is not None:
             self.side.early_finalize = 6      # 384 slab jobs per weight pass: reducing most of them early shrinks the tail 0.23 -> 0.15 ms
         self.use_graph = graph
         self._graph = None
@@ -1471,8 +1466,6 @@ class SearchTrainer:
                 # 8.1 ms, with one 9.1 -- so its backward stays on one stream
                 # -- unless they run on a stream of their own (SideSchedule.split): then the weight pass does the same, 8.1 -> 7.1 ms
                 bwd_inputs = self.side_backward_inputs if (arch or (sided and self.side.split)) else self.side_backward_weight
-                if not arch and sided and self.side.split and os.environ.get("N3D_SIDE_BACKWARD_IN_W") is not None:   # (probe knob: the weight pass' own choice)
-                    bwd_inputs = tuple(int(c) for c in os.environ["N3D_SIDE_BACKWARD_IN_W"] if c.isdigit())
                 with (self.side.backward_mode(bwd_inputs) if (sided and self.side_backward and bwd_inputs) else contextlib.nullcontext()):
                     if sided and not arch:
                         with self.side.deferring():

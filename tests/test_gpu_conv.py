@@ -331,46 +331,3 @@ def test_conv_fwdN_matches_torch(specs):
         assert_close(y.t, yc, 2e-5, "y (fwdN)")
         if stats is not None:
             assert_close(stats.sum(dim=1).cpu().numpy()[..., 0], yc.double().sum(dim=(2, 3, 4)).numpy(), 1e-5, "stats (fwdN)")
-
-
-@pytest.mark.parametrize("dil,shape", [(1, (64, 64, 64)), (2, (64, 64, 64)), (1, (32, 64, 128))])     # 4-plane tiles: >= 8192 tile groups
-def test_conv_normalising_on_load_equals_conv_of_the_materialised_node(dil, shape):
-    """n3d_conv_fwd_nol (round-4 probe): the 3x3x3 C = 4 conv of a searched-cell node relu(a0 raw0 + b0) + relu(a1 raw1 + b1)
-    (searched.py:45-50) formed inside the conv's LDS tile, against the same conv on the node written by the epilogue kernel --
-    bit-identical, zero padding included (the padding applies to the node, not to its raw terms) -- and against torch"""
-    from nas_3d_unet_amd import kernels as K
-    rng = np.random.default_rng(dil * 7 + shape[2])
-    B, c = 2, 4
-    dev = torch.device("cuda")
-    r0n, r1n = _mk((B, c) + shape, 1), _mk((B, c) + shape, 2)
-    wn, bn = _mk((c, c, 3, 3, 3), 3, 0.1), _mk((c,), 4, 0.1)
-    coefn = (rng.standard_normal((B, 4, c)) * 0.7).astype(np.float32)
-    node = sum(torch.relu(torch.from_numpy(coefn[:, 2 * k])[:, :, None, None, None] * torch.from_numpy(r) + torch.from_numpy(coefn[:, 2 * k + 1])[:, :, None, None, None])
-               for k, r in enumerate((r0n, r1n)))
-    yr = F.conv3d(node, torch.from_numpy(wn), torch.from_numpy(bn), padding=dil, dilation=dil)
-    g = K.conv_geom(B, *shape, c, c, 3, 1, dil, dil)
-    if K.conv_stats_rows(g, False) <= 0 or shape[0] % 4:
-        pytest.skip("not a 4-plane vox64 shape")
-    r0, r1 = K.as_view(torch.from_numpy(r0n).to(dev)), K.as_view(torch.from_numpy(r1n).to(dev))
-    w, b = torch.from_numpy(wn).to(dev), torch.from_numpy(bn).to(dev)
-    coef = tuple(torch.from_numpy(np.ascontiguousarray(coefn[:, k])).to(dev) for k in range(4))      # a0, b0, a1, b1, each (B, C)
-    y = K.as_view(K.empty_ndhwc(B, c, *shape, dev))
-    rows = K.conv_stats_rows(g, False)
-    stats = torch.zeros((B, rows, c, 2), dtype=torch.float64, device=dev)
-    try:
-        K.conv_fwd_nol(g, r0, r1, coef, 3, w, b, y, stats)
-    except K.N3DError as e:
-        if "4-plane" in str(e):
-            pytest.skip("shape runs on shallower tiles")
-        raise
-    assert_close(y.t, yr, 2e-5, "y")
-    st = stats.sum(dim=1).cpu().numpy()
-    assert_close(st[..., 0], yr.double().sum(dim=(2, 3, 4)).numpy(), 1e-5, "stats sum")
-    # ... and bit for bit against the conv of the node the epilogue arithmetic produces (fmaf, max, add in the kernels' order)
-    nd = K.as_view(K.empty_ndhwc(B, c, *shape, dev))
-    a0, b0, a1, b1 = coef
-    K.affine_act(r0, a0, b0, None, nd, K.RELU)
-    K.affine_act(r1, a1, b1, None, nd, K.RELU | K.ACCUMULATE)
-    y2 = K.as_view(K.empty_ndhwc(B, c, *shape, dev))
-    K.conv_fwd(g, nd, w, b, y2, 0, None, None, False)
-    assert torch.equal(y.t, y2.t)

@@ -436,27 +436,3 @@ def test_search_trainer_withholds_both_updates():
     torch.cuda.synchronize()
     tr.check_sync()
     assert np.isfinite(float(la)) and np.isfinite(float(lw)) and int(tr.fp.step) == 2 and not torch.equal(tr.aflat, a)
-
-
-def test_normalise_on_load_in_the_last_cell_is_bit_identical():
-    """fused.NOL (off by default: measured slower in the step, profiles/r04_nol_in_situ_ab.log): the last up cell's node epilogues on the side
-    stream, their readers normalising on load -- the convs are bit-identical to the convs of the materialised nodes, so losses and weights of
-    a replayed run must equal the default schedule's bit for bit, and hand-offs must have been added"""
-    from nas_3d_unet_amd import fused
-    from nas_3d_unet_amd.train import Trainer
-    x, t = _batch(83, size=64)
-    out = []
-    for nol in (False, True):
-        prev, fused.NOL = fused.NOL, nol
-        try:
-            torch.manual_seed(5)
-            net, _ = build_net("searched", "G_CONV", 4)
-            tr = Trainer(net, graph=True, side_wgrad="force")
-            losses = [float(tr.step(x, t)) for _ in range(3)]
-            torch.cuda.synchronize()
-            tr.check_sync()
-            out.append((losses, tr.fp.flat.clone(), int((tr.side.sync[8:8 + tr.side.JOIN] > 0).sum())))
-        finally:
-            fused.NOL = prev
-    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
-    assert out[1][2] > out[0][2], "normalise-on-load placed no hand-offs: the path was not taken"
