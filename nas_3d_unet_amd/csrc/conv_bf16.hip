@@ -18,6 +18,7 @@
 namespace n3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short bf16x4v __attribute__((ext_vector_type(4)));
 
 __device__ float4 n3d_zero_page16[1];  // zero-initialised; source of the zero padding for LDS-DMA fills
@@ -65,7 +66,9 @@ __device__ __forceinline__ f32x4 mfma_bf16_4x4x4(const uint2 a, const uint2 b, c
 // every slot (2-way bank conflict on each read); the dense image halves the fill (60 DMA lanes per plane instead of 108: one
 // instruction instead of two) and reads consecutive 8-byte voxels.  Slices of a wider buffer (the node slices of a cell output,
 // voxel pitch 24 bytes) cannot be fetched in pairs and keep the slot image.
-template <int C, int TD, int DIL, int NW, bool P2 = false>
+// ACCM: -1 = N3D_ACCUMULATE is read from the flags; 0 / 1 = compiled in (the 8-plane form: the forward launch carries no operand
+// fetch of a previous value and none of its address arithmetic)
+template <int C, int TD, int DIL, int NW, bool P2 = false, int ACCM = -1>
 __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
   N3D_CHAIN_PRIO();
   static_assert(!P2 || C == 4, "the dense two-voxels-per-slot image is the C = 4 form");
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
   const int hh = lane >> 4, ww = ((lane & 15) - (hh & 1) * (LW % 16)) & 15;
   const int hrow = 4 * wave + hh;
   bf16_t* dstb = a.dst + (int64_t)b * N * a.dld;
-  const bool accum = a.flags & N3D_ACCUMULATE;
+  const bool accum = ACCM < 0 ? bool(a.flags & N3D_ACCUMULATE) : bool(ACCM);
   const int64_t vox_off = ((int64_t)(h0 + 4 * wave + hh) * a.W + w0 + ww);
   float4 biasv[HF], prevv[TD][HF];
 #pragma unroll
@@ -110,34 +113,39 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
       prevv[g][hf] = accum ? ld4(dstb + (((int64_t)(d0 + g) * a.H * a.W) + vox_off) * a.dld + hf * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   {
-    typedef const __attribute__((address_space(1))) void* gptr_t;
+    // Fill by LDS-DMA through BUFFER loads (round 5; it was global_load_lds with a per-lane 64-bit address and a zero page).  A raw
+    // buffer load returns 0 for an offset >= num_records, which is the conv's zero padding for free: the lane's byte offset inside
+    // its plane -- or OOB for a halo position outside H x W -- is computed ONCE per tile position, the plane's offset is a scalar
+    // (soffset), and a plane outside D takes a resource with num_records = 0 (a scalar select).  Per DMA instruction: no vector ALU
+    // work at all (the pointer form cost ~10 VALU instructions each: 64-bit multiply-add, two selects against the zero page, the
+    // bounds tests -- PMC before: 2.7 VALU per MFMA, profiles/r03_pmc_conv_vox64b_bf16_2x4x128.json).
     typedef __attribute__((address_space(3))) void* lptr_t;
-    const uint4* __restrict__ wq4 = reinterpret_cast<const uint4*>(a.wq);
-    const uint4* zp = reinterpret_cast<const uint4*>(a.zero_page);
+    constexpr uint32_t OOB = 0x80000000u;         // >= num_records below, with or without the scalar offset
+    constexpr int RSRC_FLAGS = 0x00020000;        // gfx9 raw buffer: 32-bit data format, no swizzle
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wq), 0, NW4 * 16, RSRC_FLAGS);
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
-      const int idx = lane + i * 64;
       if (NW == 1 || (i % NW) == wave)
-        __builtin_amdgcn_global_load_lds((gptr_t)(idx < NW4 ? wq4 + idx : zp), (lptr_t)(wl + i * 64), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(wl + i * 64), 16, (lane + i * 64) * 16, 0, 0, 0);
     }
-    const int64_t pstride = (int64_t)a.H * a.W * a.sld;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(srcb), 0, 0x7fffffff, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(srcb), 0, 0, RSRC_FLAGS);
+    const int pstride_b = a.H * a.W * (int)a.sld * 2;      // bytes per plane (a sample stays below 2 GB: checked by the launcher)
 #pragma unroll
     for (int i = 0; i < NPOS; ++i) {
       const int pos = lane + i * 64;
       const int wx = pos % LWS, hy = pos / LWS;
       const int gh = h0 - DIL + hy, gw = P2 ? w0 - 2 + 2 * wx : w0 - DIL + wx;   // P2: an even column, the pair never straddles the volume's edge
       const bool okp = pos < PLANE && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-      const bf16_t* prow = srcb + ((int64_t)gh * a.W + gw) * a.sld;
+      const uint32_t voff = okp ? (uint32_t)((gh * a.W + gw) * (int)a.sld * 2) : OOB;
       static_assert(LD % NW == 0, "tile depth must split evenly over the waves");
 #pragma unroll
       for (int m = 0; m < LD / NW; ++m) {
         const int dz = m * NW + (NW > 1 ? wave : 0);
         const int gd = d0 - DIL + dz;
-        const bool inb = okp && gd >= 0 && gd < a.D;
-        const bf16_t* p = prow + gd * pstride;
+        const bool ind = gd >= 0 && gd < a.D;          // wave-uniform
         // 16 bytes from the voxel's address: the whole voxel (C = 8) or the voxel and the 8 bytes behind it (C = 4)
-        __builtin_amdgcn_global_load_lds((gptr_t)(inb ? reinterpret_cast<const void*>(p) : reinterpret_cast<const void*>(zp)),
-                                         (lptr_t)(tile + dz * PSTRIDE + i * 64), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ind ? rs : rz, (lptr_t)(tile + dz * PSTRIDE + i * 64), 16, (int)voff, ind ? gd * pstride_b : 0, 0, 0);
       }
     }
   }
@@ -154,13 +162,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
   // statistics rows: one per 4 output planes, so that a TD = 8 tile writes exactly the two rows (in the same summation order) that
   // the two TD = 4 tiles it replaces would write -- n3d_conv_stats_rows does not depend on which form runs
   constexpr int SR = TD == 8 ? 2 : 1;
-  float cs[SR][HF][4], cq[SR][HF][4];
+  // (packed pairs: v_pk_add_f32 / v_pk_fma_f32 -- four instead of eight vector instructions per plane and channel quad)
+  f32x2 cs2[SR][HF][2], cq2[SR][HF][2];
 #pragma unroll
   for (int sr = 0; sr < SR; ++sr)
 #pragma unroll
     for (int hf = 0; hf < HF; ++hf)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cs[sr][hf][r] = cq[sr][hf][r] = 0.f;
+      for (int r = 0; r < 2; ++r) cs2[sr][hf][r] = cq2[sr][hf][r] = (f32x2){0.f, 0.f};
   bf16_t* const o_plane0 = dstb + ((int64_t)d0 * a.H * a.W + vox_off) * a.dld;
   const int64_t o_pstride = (int64_t)a.H * a.W * a.dld;
   auto emit_plane = [&](int g) {
@@ -169,9 +178,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
     for (int hf = 0; hf < HF; ++hf) {
       const f32x4 v = acc[g][hf];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { cs[SR == 2 ? g / 4 : 0][hf][r] += v[r]; cq[SR == 2 ? g / 4 : 0][hf][r] = fmaf(v[r], v[r], cq[SR == 2 ? g / 4 : 0][hf][r]); }
+      for (int r = 0; r < 2; ++r) {
+        const f32x2 v2 = {v[2 * r], v[2 * r + 1]};
+        cs2[SR == 2 ? g / 4 : 0][hf][r] += v2;
+        cq2[SR == 2 ? g / 4 : 0][hf][r] = __builtin_elementwise_fma(v2, v2, cq2[SR == 2 ? g / 4 : 0][hf][r]);
+      }
       float4 w4 = make_float4(v[0], v[1], v[2], v[3]);
-      { const float4 pv = prevv[g][hf]; w4.x += pv.x; w4.y += pv.y; w4.z += pv.z; w4.w += pv.w; }
+      if (accum) { const float4 pv = prevv[g][hf]; w4.x += pv.x; w4.y += pv.y; w4.z += pv.z; w4.w += pv.w; }   // (uniform branch)
       st4(o + hf * 4, w4);
     }
   };
@@ -206,13 +219,19 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
           const int g = dz - kd * DIL;
           if (g >= 0 && g < TD) {
             // two accumulator chains per output plane (even / odd tap)
+#ifdef VXB_ONE_CHAIN
+            acc[g][0] = mfma_bf16_4x4x4(wr[kd * 9 + t9], av[t9], acc[g][0]);
+#else
             if (t9 & 1) acc2[g] = mfma_bf16_4x4x4(wr[kd * 9 + t9], av[t9], acc2[g]);
             else acc[g][0] = mfma_bf16_4x4x4(wr[kd * 9 + t9], av[t9], acc[g][0]);
+#endif
           }
         }
       }
       if (dz - 2 * DIL >= 0) {
+#ifndef VXB_ONE_CHAIN
         acc[dz - 2 * DIL][0] += acc2[dz - 2 * DIL];
+#endif
         emit_plane(dz - 2 * DIL);
       }
     }
@@ -251,6 +270,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
   }
   // GroupNorm partial row of this tile (as conv_vox64_kernel)
   if (a.stats) {
+    float cs[SR][HF][4], cq[SR][HF][4];
+#pragma unroll
+    for (int sr = 0; sr < SR; ++sr)
+#pragma unroll
+      for (int hf = 0; hf < HF; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cs[sr][hf][r] = cs2[sr][hf][r >> 1][r & 1]; cq[sr][hf][r] = cq2[sr][hf][r >> 1][r & 1]; }
     const bool odd = lane & 1, hi = lane & 2;
 #pragma unroll
     for (int sr = 0; sr < SR; ++sr)
@@ -739,6 +765,8 @@ int vox16_conv_try(const n3d_conv_geom* g, bool data_grad, const void* src, int6
   const void* zp = zero_page16_ptr();
   if (!zp) { set_error("conv(bf16 mfma): zero page symbol unavailable"); return N3D_ERR_HIP; }
   if (kind == 1) {
+    // (the fill addresses a sample through a raw buffer resource: 32-bit byte offsets)
+    if ((int64_t)g->Di * g->Hi * g->Wi * sld * 2 >= 0x7fffffffLL) return 0;
     const Vx16Plan v = vx16_plan(g);
     Vx16Args a;
     a.src = (const bf16_t*)src; a.sld = sld; a.dst = (bf16_t*)dst; a.dld = dld; a.wq = (const bf16_t*)ws; a.bias = bias;
@@ -751,8 +779,14 @@ int vox16_conv_try(const n3d_conv_geom* g, bool data_grad, const void* src, int6
       a.tiles = v.tiles / 2;
       const size_t pstride2 = ((size_t)(4 + 2 * g->dil) * 10 + 63) / 64 * 64, wslots = (((size_t)27 * 16 * 2 + 15) / 16 + 63) / 64 * 64;
       const size_t lds8 = ((size_t)(8 + 2 * g->dil) * pstride2 + wslots) * 16;
-      if (g->dil == 1) hipLaunchKernelGGL((conv_vox64b_kernel<4, 8, 1, 1, true>), dim3(a.tiles * g->B), dim3(64), lds8, s, a);
-      else hipLaunchKernelGGL((conv_vox64b_kernel<4, 8, 2, 1, true>), dim3(a.tiles * g->B), dim3(64), lds8, s, a);
+      const bool acc = flags & N3D_ACCUMULATE;
+      if (g->dil == 1) {
+        if (acc) hipLaunchKernelGGL((conv_vox64b_kernel<4, 8, 1, 1, true, 1>), dim3(a.tiles * g->B), dim3(64), lds8, s, a);
+        else hipLaunchKernelGGL((conv_vox64b_kernel<4, 8, 1, 1, true, 0>), dim3(a.tiles * g->B), dim3(64), lds8, s, a);
+      } else {
+        if (acc) hipLaunchKernelGGL((conv_vox64b_kernel<4, 8, 2, 1, true, 1>), dim3(a.tiles * g->B), dim3(64), lds8, s, a);
+        else hipLaunchKernelGGL((conv_vox64b_kernel<4, 8, 2, 1, true, 0>), dim3(a.tiles * g->B), dim3(64), lds8, s, a);
+      }
       hipError_t e__ = hipGetLastError();
       if (e__ != hipSuccess) { set_error("conv(bf16 mfma): launch error: %s", hipGetErrorString(e__)); return N3D_ERR_HIP; }
       return 1;

@@ -67,7 +67,7 @@ def test_trainer_dp_schedules_match_single_gpu(one_rank_group, graph, buckets, c
     if buckets > 1:
         # the bucketed exchange rides on the side-stream schedule: bucket j's all-reduce on the weight-gradient stream, tied to the chain
         # by device flags (graph: the stream's graph comes in `buckets` segments with the all-reduces launched between them)
-        assert tr.side is not None and tr._segments is None
+        assert tr.side is not None and tr._buckets is not None
         if graph:
             assert tr._use_side and tr._side_wsegs == buckets
     assert l == lr_ and torch.equal(w, wr)

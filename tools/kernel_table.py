@@ -34,6 +34,12 @@ HOST_ONLY = {"n3d_conv_workspace_bytes", "n3d_conv_stats_rows", "n3d_conv_pack_i
 NO_REPLAY = {"n3d_adam_step", "n3d_dropout3d_gate", "n3d_sync_wait", "n3d_sync_wait2", "n3d_sync_signal"}
 
 
+# coefficient / gate kernels: a few workgroups over statistics rows (kilobytes) -- no roofline applies, their time is launch latency
+LATENCY_ONLY = {"n3d_gn_coeffs2", "n3d_gn_coeffsN", "n3d_gn_bwd_coeffs", "n3d_gn_bwd_coeffs2", "n3d_gn_bwd_coeffsN", "n3d_node_fwd_coeffs",
+                "n3d_node_bwd_coeffs", "n3d_se_gate_fwd", "n3d_se_gate_fwdN", "n3d_se_gate_bwd", "n3d_se_gate_bwdN", "n3d_plain_bwd_coeffs",
+                "n3d_guard_flag", "n3d_stamp"}
+
+
 class Recorder:
     """with Recorder() as r: ...   r.calls = [(name, args)] of every libn3d call made inside"""
 
@@ -146,6 +152,35 @@ def describe(name, args):
                 ff, bb = _conv_cost(g, "fwdT" if c.transposed else "fwd", c.flags)
                 sig.append(_gtuple(g)); f += ff; b += bb
             return tuple(sig), f, b
+        if name == "n3d_dwconv_batch":         # depthwise gather passes of up to 8 primitives, one launch
+            jobs, n = args[0], v[1]
+            sig, f, b = [name], 0, 0
+            for i in range(n):
+                j = jobs[i]
+                g = j.g.contents
+                ff, bb = _conv_cost(g, "bwd_data" if j.data_grad else "fwd", 0)
+                sig.append(_gtuple(g) + (int(j.data_grad),)); f += ff; b += bb + (bb // 2 if (j.flags & _lib.ACCUMULATE) else 0)
+            return tuple(sig), f, b
+        if name == "n3d_affine_actN":          # out (+)= sum of n normalised terms: n raw reads, one write (+ one read when accumulating)
+            n, B, N, Cc, fl = v[1], v[4], v[5], v[6], v[7]
+            return (name, n, B, N, Cc, fl & 0x44), *ew(B, N, Cc, n + (2 if fl & 4 else 1), False)
+        if name == "n3d_affine_act_bwd_reduceN":   # the node gradient once, every raw once (sums are rows of doubles: negligible)
+            n, B, N, Cc = v[3], v[4], v[5], v[6]
+            return (name, n, B, N, Cc), *ew(B, N, Cc, n + 1, False)
+        if name == "n3d_affine_act_bwd_applyN":    # ... and every d(raw) written
+            n, B, N, Cc = v[3], v[4], v[5], v[6]
+            return (name, n, B, N, Cc), *ew(B, N, Cc, 2 * n + 1, False)
+        if name == "n3d_affine_act_bwd_apply_sum":  # terms with the same target are summed in registers: one write (+ read) per TARGET
+            terms, n, B, N, Cc = args[2], v[3], v[4], v[5], v[6]
+            tg = {}
+            for i in range(n):
+                t = terms[i]
+                tg.setdefault(t.draw, bool(t.pad_))     # (pad_ carries "accumulate" of the first term of a target)
+            passes = n + 1 + sum(2 if acc else 1 for acc in tg.values())
+            return (name, n, len(tg), B, N, Cc), *ew(B, N, Cc, passes, False)
+        if name in LATENCY_ONLY:
+            scal = tuple(x for x in v if isinstance(x, (int, float)) and not (isinstance(x, int) and x > (1 << 32)))
+            return (name,) + scal[:6], 0, 0
         if name == "n3d_affine_act_gn2":
             B, N, Cc, fl = v[8], v[9], v[10], v[11]
             return (name, B, N, Cc, fl & 0x44, bool(v[6])), *ew(B, N, Cc, 4 if v[6] else 3, fl & _lib.ACT_BF16)
@@ -198,10 +233,13 @@ def describe(name, args):
                 j = jobs[i]
                 byts += 4 * (j.nchunks * (j.ntiles * j.ci_t * j.co_t + j.tco * j.co_t) + j.Co * j.Ci * j.taps + j.Co)
             return (name, n), 0, byts
-    except Exception:
-        pass
+    except Exception as e:      # a cost model that does not fit the recorded arguments must not cost the table -- but it must show
+        describe.errors[name] = "%s: %s" % (type(e).__name__, e)
     scal = tuple(x for x in v if isinstance(x, (int, float)) and not (isinstance(x, int) and x > (1 << 32)))
     return (name,) + scal[:6], None, None
+
+
+describe.errors = {}
 
 
 def _time_call(name, args, device, reps=20, rounds=3):
@@ -277,7 +315,11 @@ def table(run_step, device, top=5, candidates=14):
                 us = gr["coarse_us"] / gr["calls"]
         row = {"entry": gr["name"], "shape": _shape_text(sig), "calls_per_step": gr["calls"], "us_per_call": round(us, 2),
                "us_per_step": round(us * gr["calls"], 1)}
-        if gr["flop"] is not None:
+        if gr["name"] in LATENCY_ONLY:
+            row.update({"bound": "latency", "frac": None, "note": "coefficient kernel over statistics rows (kilobytes): launch latency, no roofline"})
+        elif gr["flop"] is None:
+            row.update({"bound": None, "frac": None, "note": "no cost model" + ((": " + describe.errors[gr["name"]]) if gr["name"] in describe.errors else "")})
+        else:
             bf16_mfma = gr["name"] in ("n3d_conv_fwd", "n3d_conv_bwd_data") and sig[-1] == 0xC0 and sig[1][9] == 3 and sig[1][10] == 1
             peak = PEAK_BF16_TFLOPS if bf16_mfma else PEAK_F32_TFLOPS   # the bf16-storage 3x3x3 kernels run v_mfma_f32_4x4x4_16b_bf16
             row["mfma_peak_tflops"] = peak
