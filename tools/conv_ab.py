@@ -10,6 +10,7 @@ from nas_3d_unet_amd._lib import ACCUMULATE
 from nas_3d_unet_amd.train import capture_stream
 
 dev = torch.device("cuda", 0)
+DT = torch.bfloat16 if os.environ.get("CONV_AB_DT") == "bf16" else torch.float32     # CONV_AB_DT=bf16: bf16-storage kernels (priced against HBM)
 
 
 def timed(fn, iters=40, reps=5):
@@ -32,12 +33,12 @@ def timed(fn, iters=40, reps=5):
 
 
 def case(c, size, dil, batch):
-    x = K.as_view(K.empty_ndhwc(batch, c, size, size, size, dev).normal_())
-    y = K.as_view(K.empty_ndhwc(batch, c, size, size, size, dev).normal_())
+    x = K.as_view(K.empty_ndhwc(batch, c, size, size, size, dev, DT).normal_())
+    y = K.as_view(K.empty_ndhwc(batch, c, size, size, size, dev, DT).normal_())
     w = torch.randn(c, c, 3, 3, 3, device=dev) * 0.1
     b = torch.randn(c, device=dev) * 0.1
     g = K.conv_geom(batch, size, size, size, c, c, 3, 1, dil, dil)
-    rows = K.conv_stats_rows(g, False)
+    rows = K.conv_stats_rows(g, False, 0, x, y)
     stats = torch.empty((batch, rows, c, 2), dtype=torch.float64, device=dev)
     ctx = K.StepContext(dev)
     with K.step_context(ctx):
@@ -49,6 +50,11 @@ def case(c, size, dil, batch):
         td = timed(lambda: K.conv_bwd_data(g, y, w, x, ACCUMULATE, None, None, False))
         tn = timed(lambda: K.conv_bwd_data(g, y, w, x, 0, None, None, False))
     fl = 2.0 * batch * size ** 3 * c * c * 27
+    if DT == torch.bfloat16:
+        by = 2.0 * batch * size ** 3 * c * 2      # input + output tensor, once each
+        print("bf16 C=%d %d^3 d=%d B=%d: fwd %.2f us (%.3f of 8 TB/s)  dgrad+acc %.2f us (%.3f, 3 passes)  dgrad %.2f us (%.3f)" %
+              (c, size, dil, batch, tf, by / tf / 1e3 / 8000, td, 1.5 * by / td / 1e3 / 8000, tn, by / tn / 1e3 / 8000), flush=True)
+        return
     print("C=%d %d^3 d=%d B=%d: fwd %.2f us (%.3f of 157.3 TF)  dgrad+acc %.2f us (%.3f)  dgrad %.2f us" %
           (c, size, dil, batch, tf, fl / tf / 1e6 / 157.3, td, fl / td / 1e6 / 157.3, tn), flush=True)
 
