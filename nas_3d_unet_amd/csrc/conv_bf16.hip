@@ -774,12 +774,12 @@ int vox16_conv_try(const n3d_conv_geom* g, bool data_grad, const void* src, int6
     static const bool nop2 = getenv("N3D_VOX16_NOP2") != nullptr;   // (A/B knob)
     const bool p2 = !nop2 && v.C == 4 && sld == 4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
     if (p2 && v.nw == 1 && v.td == 4 && g->Di % 8 == 0 && (int64_t)v.tiles * g->B / 2 >= 2048) {
+      const bool acc = flags & N3D_ACCUMULATE;
       // dense image, many tiles: 8 output planes per tile (the D halo is re-fetched every 8 planes instead of every 4: 24.4 -> 22.1 us at
       // (2,4,128^3)); the kernel still writes one statistics row per 4 planes, in the rows and the order of the 4-plane plan
       a.tiles = v.tiles / 2;
       const size_t pstride2 = ((size_t)(4 + 2 * g->dil) * 10 + 63) / 64 * 64, wslots = (((size_t)27 * 16 * 2 + 15) / 16 + 63) / 64 * 64;
       const size_t lds8 = ((size_t)(8 + 2 * g->dil) * pstride2 + wslots) * 16;
-      const bool acc = flags & N3D_ACCUMULATE;
       if (g->dil == 1) {
         if (acc) hipLaunchKernelGGL((conv_vox64b_kernel<4, 8, 1, 1, true, 1>), dim3(a.tiles * g->B), dim3(64), lds8, s, a);
         else hipLaunchKernelGGL((conv_vox64b_kernel<4, 8, 1, 1, true, 0>), dim3(a.tiles * g->B), dim3(64), lds8, s, a);

@@ -151,6 +151,45 @@ def test_dense_bf16_conv_8_plane_tiles_and_their_statistics_rows(dil):
         assert float((st[..., 1].sum(1) - s2.sum(1)).abs().max()) <= 1e-5 * float(s2.sum(1).max())
 
 
+@pytest.mark.parametrize("dil,shape", [(1, (128, 128, 128)), (1, (40, 128, 128)), (2, (64, 64, 128)), (1, (72, 64, 128))])
+def test_dense_bf16_conv_8_plane_tiles_forward_and_accumulating_data_gradient(dil, shape):
+    """round 5: the 8-plane tile form of the dense 4-channel bf16 3x3x3 conv fills its LDS tile through BUFFER loads (zero padding by the
+    resource's bounds check) and has its accumulate flag compiled in: forward with statistics rows and the data gradient ACCUMULATING
+    into its destination, full volumes and D not a multiple of 16, against torch fp32 on the bf16-rounded operands."""
+    from nas_3d_unet_amd import kernels as K
+    from nas_3d_unet_amd._lib import ACCUMULATE
+    rng = np.random.default_rng(190 + dil + shape[0])
+    B, C = 2, 4
+    x16 = _bf(rng.standard_normal((B, C) + shape).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((C, C, 3, 3, 3)) * 0.2).astype(np.float32)).bfloat16().float()
+    b = torch.from_numpy(rng.standard_normal(C).astype(np.float32) * 0.1)
+    yr = F.conv3d(x16.float(), w, b, padding=dil, dilation=dil)
+    xv = _view(x16)
+    assert xv.ld == 4
+    g = K.conv_geom(B, *shape, C, C, 3, 1, dil, dil)
+    with K.storage(torch.bfloat16):
+        y = K.as_view(K.empty_ndhwc(*yr.shape, torch.device("cuda")))
+    rows = K.conv_stats_rows(g, False, 0, xv, y)
+    stats = torch.full((B, rows, C, 2), float("nan"), dtype=torch.float64, device="cuda")
+    K.conv_fwd(g, xv, w.cuda(), b.cuda(), y, 0, None, stats, False)
+    assert_close(y.t.float(), yr, ULP, "y")
+    st = stats.cpu()
+    assert not torch.isnan(st).any(), "a statistics row was not written"
+    assert float((st[..., 0].sum(1) - yr.double().sum(dim=(2, 3, 4))).abs().max()) <= 1e-5 * float((yr.double() ** 2).sum(dim=(2, 3, 4)).max())
+    assert float((st[..., 1].sum(1) - (yr.double() ** 2).sum(dim=(2, 3, 4))).abs().max()) <= 1e-5 * float((yr.double() ** 2).sum(dim=(2, 3, 4)).max())
+    if rows == (shape[0] // 4) * (shape[1] // 4) * (shape[2] // 16):      # one-wave tiles: every row against its own 4 x 4 x 16 block
+        blk = yr.double().reshape(B, C, shape[0] // 4, 4, shape[1] // 4, 4, shape[2] // 16, 16)
+        s1 = blk.sum(dim=(3, 5, 7)).permute(0, 2, 3, 4, 1).reshape(B, rows, C)
+        assert float((st[..., 0] - s1).abs().max()) <= 1e-4 * float(s1.abs().max())
+    # data gradient, accumulating (the backward walk's form): dx_prev + conv^T(dy)
+    dy16 = _bf(rng.standard_normal((B, C) + shape).astype(np.float32))
+    dx0 = _bf(rng.standard_normal((B, C) + shape).astype(np.float32))
+    dxr = dx0.float() + F.conv_transpose3d(dy16.float(), w, None, padding=dil, dilation=dil)
+    dxv = _view(dx0.clone())
+    K.conv_bwd_data(g, _view(dy16), w.cuda(), dxv, ACCUMULATE, None, None, False)
+    assert_close(dxv.t.float(), dxr, ULP, "dx (accumulating)")
+
+
 @pytest.mark.parametrize("C,shape,B", [(4, (16, 16, 16), 2), (8, (32, 16, 16), 2), (8, (4, 4, 4), 2), (4, (48, 32, 32), 1)])
 def test_node_epilogues_bf16_storage(C, shape, B):
     """GroupNorm -> ReLU -> node sum of two conv outputs (searched.py:45-50) and its backward with every tensor in bf16:

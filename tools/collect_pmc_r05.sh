@@ -12,9 +12,9 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA
   timeout -k 5 150 rocprofv3 --pmc $grp --output-format csv -d $O/pmc_${tag}/pmc_$gt -- python3 tools/conv_pmc.py $case 20 > $O/pmc_${tag}_$gt.log 2>&1
   echo "$tag $gt rc=$?"
 done
-python3 tools/pmc_summary.py $O/pmc_${tag} conv_vox64b_kernel $O/pmc_${tag}.json > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/pmc_${tag} conv_vox64b_ $O/pmc_${tag}.json > /dev/null 2>&1
 rm -rf $O/pmc_${tag} $O/pmc_${tag}_*.log $O/kt_${tag}
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_${tag} -- python3 tools/conv_pmc.py $case 200 > /dev/null 2>&1
-grep -h conv_vox64b_kernel $O/kt_${tag}/*/*kernel_stats.csv | head -2 > $O/pmc_${tag}_kernel_time.csv
+grep -h "conv_vox64b_kernel\|conv_vox64b_march_kernel" $O/kt_${tag}/*/*kernel_stats.csv | head -2 > $O/pmc_${tag}_kernel_time.csv
 rm -rf $O/kt_${tag}
 cat $O/pmc_${tag}.json | grep -v dispatch | head -40; cat $O/pmc_${tag}_kernel_time.csv | cut -c1-200

@@ -47,6 +47,10 @@ def case(c, size, dil, batch):
         ctx.freeze()
         ctx.pack_all()
         tf = timed(lambda: K.conv_fwd(g, x, w, b, y, 0, None, stats, False))
+        if os.environ.get("CONV_AB_EXTRA"):
+            tns = timed(lambda: K.conv_fwd(g, x, w, b, y, 0, None, None, False))
+            tnb = timed(lambda: K.conv_fwd(g, x, w, None, y, 0, None, None, False))
+            print("   fwd %.2f us, without statistics %.2f us, without statistics and bias %.2f us" % (tf, tns, tnb), flush=True)
         td = timed(lambda: K.conv_bwd_data(g, y, w, x, ACCUMULATE, None, None, False))
         tn = timed(lambda: K.conv_bwd_data(g, y, w, x, 0, None, None, False))
     fl = 2.0 * batch * size ** 3 * c * c * 27
