@@ -177,7 +177,8 @@ def test_dense_bf16_conv_8_plane_tiles_forward_and_accumulating_data_gradient(di
     assert not torch.isnan(st).any(), "a statistics row was not written"
     assert float((st[..., 0].sum(1) - yr.double().sum(dim=(2, 3, 4))).abs().max()) <= 1e-5 * float((yr.double() ** 2).sum(dim=(2, 3, 4)).max())
     assert float((st[..., 1].sum(1) - (yr.double() ** 2).sum(dim=(2, 3, 4))).abs().max()) <= 1e-5 * float((yr.double() ** 2).sum(dim=(2, 3, 4)).max())
-    if rows == (shape[0] // 4) * (shape[1] // 4) * (shape[2] // 16):      # one-wave tiles: every row against its own 4 x 4 x 16 block
+    if dil == 1:      # one-wave tiles: every row against its own 4 x 4 x 16 block (dilation 2 runs two-wave tiles: rows in (tile, wave) order)
+        assert rows == (shape[0] // 4) * (shape[1] // 4) * (shape[2] // 16)
         blk = yr.double().reshape(B, C, shape[0] // 4, 4, shape[1] // 4, 4, shape[2] // 16, 16)
         s1 = blk.sum(dim=(3, 5, 7)).permute(0, 2, 3, 4, 1).reshape(B, rows, C)
         assert float((st[..., 0] - s1).abs().max()) <= 1e-4 * float(s1.abs().max())

@@ -20,7 +20,7 @@ torch.cuda.synchronize()
 with kernel_table.Recorder() as rec:
     tr.step(x, t, vx, vt)
     torch.cuda.synchronize()
-times, by_name, by_sig = {}, collections.defaultdict(lambda: [0, 0.0]), collections.defaultdict(lambda: [0, 0.0])
+times, by_name, by_sig, cost = {}, collections.defaultdict(lambda: [0, 0.0]), collections.defaultdict(lambda: [0, 0.0]), {}
 for name, args in rec.calls:
     sig, flop, byts = kernel_table.describe(name, args)
     if sig not in times:
@@ -32,6 +32,7 @@ for name, args in rec.calls:
     if us == us:
         by_name[name][0] += 1; by_name[name][1] += us
         by_sig[(name, kernel_table._shape_text(sig)[:120])][0] += 1; by_sig[(name, kernel_table._shape_text(sig)[:120])][1] += us
+        cost[(name, kernel_table._shape_text(sig)[:120])] = (flop, byts)
 if len(sys.argv) > 2:     # the whole step in launch order
     with open(sys.argv[2], "w") as f:
         for i, (name, args) in enumerate(rec.calls):
@@ -42,6 +43,16 @@ print("search step, eager single stream: %d libn3d launches, replay-timed sum %.
 print("== by entry point")
 for n, (k, us) in sorted(by_name.items(), key=lambda kv: -kv[1][1]):
     print("%5d %9.1f us %5.1f%%  avg %6.2f  %s" % (k, us, 100 * us / tot, us / k, n))
-print("== top (entry, shape) groups")
+print("== top (entry, shape) groups; roofline of one call: fraction of max(FLOP / 157.3 TF, bytes / 8 TB/s) -- 'lat' = coefficient kernel, no roofline")
 for (n, s), (k, us) in sorted(by_sig.items(), key=lambda kv: -kv[1][1])[:top]:
-    print("%5d %9.1f us %5.1f%%  avg %6.2f  %-28s %s" % (k, us, 100 * us / tot, us / k, n, s))
+    flop, byts = cost.get((n, s), (None, None))
+    if n in kernel_table.LATENCY_ONLY:
+        rf = "  lat"
+    elif flop is None:
+        rf = "    ?"
+    else:
+        t_m, t_h = flop / 157.3e12 * 1e6, byts / 8e12 * 1e6
+        rf = "%s %.2f" % ("M" if t_m > t_h else "H", max(t_m, t_h) / (us / k))
+    print("%5d %9.1f us %5.1f%%  avg %6.2f  %6s  %-28s %s" % (k, us, 100 * us / tot, us / k, rf, n, s))
+if kernel_table.describe.errors:
+    print("cost-model errors:", kernel_table.describe.errors)
