@@ -771,8 +771,7 @@ int vox16_conv_try(const n3d_conv_geom* g, bool data_grad, const void* src, int6
     Vx16Args a;
     a.src = (const bf16_t*)src; a.sld = sld; a.dst = (bf16_t*)dst; a.dld = dld; a.wq = (const bf16_t*)ws; a.bias = bias;
     a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.flags = flags; a.stats = stats; a.rows_per_sample = v.tiles * v.nw; a.tiles = v.tiles; a.zero_page = zp;
-    static const bool nop2 = getenv("N3D_VOX16_NOP2") != nullptr;   // (A/B knob)
-    const bool p2 = !nop2 && v.C == 4 && sld == 4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    const bool p2 = v.C == 4 && sld == 4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
     if (p2 && v.nw == 1 && v.td == 4 && g->Di % 8 == 0 && (int64_t)v.tiles * g->B / 2 >= 2048) {
       const bool acc = flags & N3D_ACCUMULATE;
       // dense image, many tiles: 8 output planes per tile (the D halo is re-fetched every 8 planes instead of every 4: 24.4 -> 22.1 us at

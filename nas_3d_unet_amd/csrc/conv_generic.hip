@@ -558,7 +558,7 @@ static bool k1_shape_ok(const n3d_conv_geom* g, bool data_grad) {
   // volume: >= 32768 voxels (N3D_K1_MIN_N).  Round 4 tried 4096 -- the supernet's pointwise convs at the 16^3 level take 11.7 us per data
   // gradient on the gather kernel against 5.6 us for the 32^3 level here -- and the search step did not move (12.88 vs 12.87 ms: those
   // launches are off its chain), so the threshold stays where every launch form of a supernet node shares its kernels bit for bit
-  static const int64_t min_n = [] { const char* e = getenv("N3D_K1_MIN_N"); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : 32768); }();
+  constexpr int64_t min_n = 32768;
   return Cs % 4 == 0 && Cs >= 4 && Cs <= 24 && Cd % 4 == 0 && Cd >= 4 && Cd <= 12 && (Cs / 4) * (Cd / 4) <= 6 && N >= min_n;
 }
 
@@ -1648,8 +1648,7 @@ static WgradPlan wgrad_plan(int B, int64_t No, int Ci, int Co, int taps) {
   const int64_t total = (int64_t)B * No;
   // short chunks: the voxel loop of the kernel is a dependent load -> FMA chain (one memory latency per
   // iteration), so per-thread trip count, not block count, sets the kernel time on these small problems
-  static const int chunk0 = getenv("N3D_WGRAD_CHUNK") ? atoi(getenv("N3D_WGRAD_CHUNK")) : 512;     // (tuning knobs)
-  static const int max_wgs = getenv("N3D_WGRAD_MAX_WGS") ? atoi(getenv("N3D_WGRAD_MAX_WGS")) : 8192;
+  constexpr int chunk0 = 512, max_wgs = 8192;
   int64_t nch = cdiv(total, chunk0);
   // keep the grid around a few thousand blocks
   while (nch * p.ntiles > max_wgs && nch > 1) nch = (nch + 1) / 2;
@@ -1887,14 +1886,14 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
       q.rld = rld; q.stats = stats; q.N = (int64_t)a.Dd * a.Hd * a.Wd;
       q.up = a.den == 2 ? 1 : 0; q.Wd = a.Wd; q.Hd = a.Hd; q.Ns = (int64_t)a.Ds * a.Hs * a.Ws; q.fWd = a.fWd; q.fHd = a.fHd;
       {
-        static const bool noflat = getenv("N3D_K1_NOFLAT") != nullptr;   // (A/B knob)
+        constexpr bool noflat = false;
         const size_t esz = db16 ? 2 : 4;
         // fp32 destinations only: measured at 2 x 128^3, 12-channel writes 54.5 -> 42.5 us (fp32) but 31.1 -> 35.2 us (bf16: the 8-byte LDS
         // stores on a 24-byte pitch cost more than the partial-line stores they replace)
         q.flat = (!noflat && !db16 && a.Cd >= 8 && dld == a.Cd && aligned16(dst) && ((size_t)q.N * a.Cd * esz) % 16 == 0) ? 1 : 0;
       }
       {
-        static const bool nosparse = getenv("N3D_K1_NOSPARSE") != nullptr;   // (A/B knob)
+        constexpr bool nosparse = false;
         q.nostore = 0; q.oscale = q.oshift = nullptr;
         if (g_k1_norm) { q.nostore = g_k1_norm->nostore ? 1 : 0; q.oscale = g_k1_norm->oscale; q.oshift = g_k1_norm->oshift; g_k1_norm->used = true; if (q.nostore) q.flat = 0; }
         q.sparse = (q.up && (flags & N3D_ACCUMULATE) && !nosparse) ? 1 : 0;
@@ -2041,7 +2040,7 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     const int64_t total = (int64_t)g->B * No;
     {
       // tileable stride-1 shapes with enough (tile, channel quad) units: the LDS-tile kernel
-      static const bool notile = getenv("N3D_DW_NOTILE") != nullptr;   // (A/B knob)
+      constexpr bool notile = false;
       const int quads = g->Ci / 4;
       if (!notile && g->k == 3 && g->stride == 1 && g->dil == 1 && g->pad == 1 && g->Wi % 16 == 0 && g->Hi % 4 == 0 && g->Di % 4 == 0 && g->Ci % 4 == 0 &&
           xld % 4 == 0 && dyld % 4 == 0 && aligned16(x) && aligned16(dy)) {
@@ -2073,7 +2072,7 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     // short chunks (the voxel loop is a dependent load -> FMA chain): about two trips per thread -- a workgroup covers
     // 256 / (C/4) voxels per trip, so wide channel counts need far smaller chunks than 512 voxels; bounded by the slab workspace
     const int64_t vpb = 256 / (a.C / 4) > 0 ? 256 / (a.C / 4) : 1;
-    static const int trips = [] { const char* e = getenv("N3D_DW_TRIPS"); const int v = e ? atoi(e) : 1; return v >= 1 ? v : 1; }();   // (A/B knob; 2 until round 4: search step tail 0.45 -> 0.365 ms with 1)
+    constexpr int trips = 1;   // (2 until round 4: search step tail 0.45 -> 0.365 ms with 1)
     int64_t nch = cdiv(total, trips * vpb < 512 ? trips * vpb : 512);
     if (nch > 1024) nch = 1024;
     a.chunk = cdiv(total, nch);

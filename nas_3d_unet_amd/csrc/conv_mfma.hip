@@ -1417,7 +1417,6 @@ static VxPlan vx_plan(const n3d_conv_geom* g) {
   if (D % 4 == 0 && groups / 4 >= 2048 && g->Ci == 4) td = 4;
   else if (D % 2 == 0 && groups / 2 >= 2048) td = 2;
 #if defined(VOX_STAMP) || defined(VOX_TUNE)
-  if (getenv("VOX_TD")) td = atoi(getenv("VOX_TD"));
 #endif
   p.ok = true; p.C = g->Ci; p.td = td; p.dil = g->dil;
   // two waves per workgroup on an 8-row tile (shared halo): pays for dilation 2, whose +-2 halo makes the single-wave
@@ -2032,7 +2031,7 @@ int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   if (g->depthwise || g->k != 3 || g->stride != 2 || (g->Ci != 4 && g->Ci != 8)) return 0;
   // square, or (fp32) 4 -> 8 / 12 / 16 channels as Co / 4 problems of 4 -> 4 in one launch (stem1, nas.py:29 / searched.py:70)
   const int tco = g->Co / g->Ci;
-  static const bool no_cotile = getenv("N3D_VW_NO_COTILE") != nullptr;   // (A/B knob)
+  constexpr bool no_cotile = false;
   // (the stem reads the fp32 net input also in the bf16 configuration: X fp32, dY fp32 or bf16)
   if (g->Co != g->Ci && (no_cotile || !(g->Ci == 4 && g->Co % 4 == 0 && tco >= 2 && tco <= 4 && !(flags & N3D_SRC_BF16)))) return 0;
   if (!(g->dil == 1 || g->dil == 2) || g->pad != g->dil) return 0;
@@ -2101,7 +2100,7 @@ static size_t vw_stage_lds(int slots, int dil) {
 // tiles requested together (NS of vox_wgrad_kernel) for a workgroup of `ntile` tiles: as many as 64 KiB of LDS hold (two workgroups
 // per compute unit), 0 = the two-buffer walk
 static int vw_stages(int ntile, size_t stage_bytes) {
-  static const int forced = [] { const char* e = getenv("N3D_VW_NS"); return e ? atoi(e) : -1; }();
+  constexpr int forced = -1;
   if (forced == 0) return 0;
   // (a workgroup with ONE tile runs the two-buffer form: measured 8.8 vs 10.6 us at (2,8,32^3) for the same work)
   for (int ns : {4, 2}) {
@@ -2120,7 +2119,7 @@ static VwPlan vw_plan(const n3d_conv_geom* g) {
   if (W % 16 != 0 || H % 4 != 0 || D % 4 != 0) return p;
   const int columns = g->B * (H / 4) * (W / 16);
   int nd = D / 4, dsplit = 1;
-  static const int want_wgs = [] { const char* e = getenv("N3D_VW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 384; }();
+  constexpr int want_wgs = 384;
   while (columns * dsplit < want_wgs && dsplit * 2 <= nd && nd % (dsplit * 2) == 0) dsplit *= 2;
   p.ok = true; p.C = g->Ci; p.dil = g->dil; p.dchunk = D / dsplit;
   p.tiles = (W / 16) * (H / 4) * dsplit;
@@ -2424,7 +2423,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile16_up_kernel(MfArgs a, const 
 
 // geometry-only decision (n3d_conv_stats_rows must agree with the launch): tiles per sample, 0 = not this kernel
 static int tile16_up_tiles(const n3d_conv_geom* g, bool data_grad) {
-  static const bool off = getenv("N3D_NO_TILE16") != nullptr;
+  constexpr bool off = false;
   if (off || !data_grad || g->depthwise || g->k != 3 || g->stride != 2 || g->Ci != 16 || g->Co != 16) return 0;
   if ((g->dil != 1 && g->dil != 2) || g->pad != g->dil) return 0;
   if (g->Di != 2 * g->Do || g->Hi != 2 * g->Ho || g->Wi != 2 * g->Wo || g->Wo % 16 != 0 || g->Ho % 4 != 0) return 0;
@@ -2433,7 +2432,7 @@ static int tile16_up_tiles(const n3d_conv_geom* g, bool data_grad) {
 }
 
 static bool tile16_applies(const MfArgs& a, int ksplit) {
-  static const bool off = getenv("N3D_NO_TILE16") != nullptr;   // (A/B knob)
+  constexpr bool off = false;
   if (off || ksplit != 1 || a.k != 3 || a.sn != 1 || a.den != 1 || a.Cs != 16 || a.Cd != 16) return false;
   const int d = a.dt < 0 ? -a.dt : a.dt;
   if ((d != 1 && d != 2) || a.off != -a.dt) return false;
@@ -2768,7 +2767,7 @@ int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const fl
   a.tci = g->Ci / 16; a.tco = g->Co / 16;
   const int ntiles = taps * a.tci * a.tco;
   // aim for ~1024 workgroups; each needs at least 64 voxels to amortise the LDS reduction
-  static const int wg_target = getenv("N3D_WG16_TARGET") ? atoi(getenv("N3D_WG16_TARGET")) : 1024;   // (tuning knob)
+  constexpr int wg_target = 1024;
   int64_t nch = cdiv(wg_target, ntiles);
   if (nch < 1) nch = 1;
   int64_t maxch = cdiv(total, 64);
@@ -2905,8 +2904,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
 // Served: 3x3x3 stride-1 convs (dilation 1 / 2) with channel counts multiples of 16 (<= 64) on tileable volumes with enough tiles x
 // channel tiles to fill a good part of the chip -- below that the K-split kernels (one launch for data + weight gradient) win.
 bool wgrad_tile16_plan(const n3d_conv_geom* g, int* chunks, int* tiles_per_wg) {
-  static const bool off = getenv("N3D_NO_TILE16") != nullptr;   // (A/B knob)
-  static const int min_units = getenv("N3D_WGT16_MIN") ? atoi(getenv("N3D_WGT16_MIN")) : 64;   // (tuning knob; 256 -> 64: step 1.89 -> 1.86 ms)
+  constexpr bool off = false;
+  constexpr int min_units = 64;   // (256 -> 64: step 1.89 -> 1.86 ms)
   if (off || g->depthwise || g->k != 3 || g->stride != 1 || g->Ci % 16 != 0 || g->Co % 16 != 0 || g->Ci > 64 || g->Co > 64) return false;
   if ((g->dil != 1 && g->dil != 2) || g->pad != g->dil) return false;
   if (g->Wi % 16 != 0 || g->Hi % 4 != 0 || g->Di % 2 != 0) return false;

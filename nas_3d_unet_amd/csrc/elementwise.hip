@@ -3138,7 +3138,7 @@ int n3d_adam_step_guarded(float* param, const float* grad, float* exp_avg, float
   const AdamGuard gd{(const unsigned*)timeouts, (const unsigned*)acked, peer_flag, loss, (unsigned*)host_word};
   // elements per workgroup: 8192 = four rounds of two float4 per lane.  Few fat workgroups beat many thin ones here: 1.8 M
   // parameters take 25.9 us at 1024 per workgroup (1771 workgroups), 16.5 at 2048, 12.4 at 4096, 11.1 at 8192 (4.6 TB/s), 13.4 at 16384
-  static const int adam_epb = [] { const char* e = getenv("N3D_ADAM_EPB"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8192; }();
+  constexpr int adam_epb = 8192;
   int64_t blocks = cdiv(n, adam_epb);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
@@ -3151,7 +3151,7 @@ int n3d_adam_step_guarded(float* param, const float* grad, float* exp_avg, float
 
 // fused variants: statistics rows -> coefficients in the kernel prologue (rows <= N3D_FUSED_MAX_ROWS)
 int n3d_fused_max_rows(void) {
-  static const int v = [] { const char* e = getenv("N3D_FUSED_MAX_ROWS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 64; }();
+  constexpr int v = 64;
   return v;
 }
 

@@ -84,21 +84,18 @@ static inline EwMap ew_map(int64_t N, int C) {
   if (m.vpb < 1) m.vpb = 1;
   int64_t nit = cdiv(N, m.vpb);          // block-iterations per sample
   int64_t it = cdiv(nit, 1024);          // cap rows per sample at 1024
-  static const int min_it = getenv("N3D_EW_IT") ? atoi(getenv("N3D_EW_IT")) : 4;   // (tuning knob)
+  constexpr int min_it = 4;
   // channel counts like the stems' 12: the class sums of a reduction go through ds_bpermute there, so fewer, longer rows pay
   // (epilogue backward of stem0 at 64^3: 43 -> 33 us over its three launches)
-  static const int min_it_np2 = getenv("N3D_EW_IT_NP2") ? atoi(getenv("N3D_EW_IT_NP2")) : 16;
+  constexpr int min_it_np2 = 16;
   int mi = (m.cpb & (m.cpb - 1)) ? min_it_np2 : min_it;
   // small tensors (the deep levels): a block's iterations are dependent memory round trips (load, use, store, next load), so a
   // launch lasts iterations x latency whatever the chip has idle -- one iteration for <= T1 block-iterations per sample, two up
   // to T2 (an N-term epilogue on 2 x 64 ch x 4^3: 7.9 -> ~4 us; search step 12.66 -> 12.45 ms with two everywhere below the
   // 64^3 level, while the 64^3 / 128^3 levels want the four: 4.53 -> 4.57 ms at 128^3 with two)
-  static const int t1 = getenv("N3D_EW_T1") ? atoi(getenv("N3D_EW_T1")) : 8;
-  static const int t2 = getenv("N3D_EW_T2") ? atoi(getenv("N3D_EW_T2")) : 256;
-  if (!getenv("N3D_EW_IT")) {
-    if (nit <= t1) mi = 1;
-    else if (nit <= t2 && mi > 2) mi = 2;
-  }
+  constexpr int t1 = 8, t2 = 256;
+  if (nit <= t1) mi = 1;
+  else if (nit <= t2 && mi > 2) mi = 2;
   if (it < mi) it = nit < mi ? (nit < 1 ? 1 : nit) : mi;
   m.iters = (int)it;
   m.vpc = (int64_t)m.vpb * m.iters;
