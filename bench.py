@@ -52,7 +52,7 @@ def to_patch_layout(x):
     return x.contiguous(memory_format=torch.channels_last_3d)
 
 
-def conv_kernel_roofline(device, batch, size, iters=40, bf16=False):
+def conv_kernel_roofline(device, batch, size, iters=40, bf16=False, c=4):
     """Time the dominant FLOP kernel -- the 3x3x3 stride-1 conv at C=4 on (batch, 4, size^3), the shape of up-cell 4
     (43 % of the net's FLOPs; the same kernel serves its data gradient) -- with HIP events on the launch stream.
     The launches are replayed from a HIP graph with pre-packed weights, so the figure is kernel time plus the
@@ -61,7 +61,6 @@ def conv_kernel_roofline(device, batch, size, iters=40, bf16=False):
     bf16 (BASELINE configs[4]): the same conv on bf16-stored tensors (conv_vox64b_kernel, v_mfma_f32_4x4x4_16b_bf16), priced
     against HBM: bytes / time / 8 TB/s."""
     from nas_3d_unet_amd import kernels as K
-    c = 4
     dt = torch.bfloat16 if bf16 else torch.float32
     x = K.as_view(K.empty_ndhwc(batch, c, size, size, size, device, dt).normal_())
     y = K.as_view(K.empty_ndhwc(batch, c, size, size, size, device, dt))
@@ -100,8 +99,8 @@ def conv_kernel_roofline(device, batch, size, iters=40, bf16=False):
     # HBM traffic per launch: PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) need their own rocprofv3 --pmc passes, so the
     # figure is read from the tracked summary of that pass (tools/collect_pmc_r04.sh), not measured inside this run
     traffic, src = None, None
-    for rnd in ("r04", "r03", "r02"):
-        pmc = os.path.join(ROOT, "profiles", "%s_pmc_conv_vox64%s_%s_2x4x%d.json" % (rnd, "b" if bf16 else "", "bf16" if bf16 else "f32", size))
+    for rnd in ("r05", "r04", "r03", "r02"):
+        pmc = os.path.join(ROOT, "profiles", "%s_pmc_conv_vox64%s_%s_2x%dx%d.json" % (rnd, "b" if bf16 else "", "bf16" if bf16 else "f32", c, size))
         if os.path.exists(pmc):
             try:
                 traffic, src = json.load(open(pmc)).get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(pmc)
@@ -112,10 +111,10 @@ def conv_kernel_roofline(device, batch, size, iters=40, bf16=False):
               "traffic": traffic, "traffic_source": (src + " (separate rocprofv3 --pmc passes of the same launch, not this run)") if src else None}
     if bf16:
         gbs = bytes_ / sec / 1e9
-        return {"bound": "hbm", "kernel": "conv_vox64b_kernel<4,4,1>: 3x3x3 s1 d1 conv, C=4, bf16 storage, (%d,4,%d^3), GN-stats epilogue" % (batch, size),
+        return {"bound": "hbm", "kernel": "conv_vox64b_kernel<%d,...>: 3x3x3 s1 d1 conv, C=%d, bf16 storage, (%d,%d,%d^3), GN-stats epilogue" % (c, c, batch, c, size),
                 "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                 "achieved_tflops": round(ach, 3), **common}
-    return {"bound": "mfma", "kernel": "conv_vox64_kernel<4,4,1>: 3x3x3 s1 d1 conv, C=4, (%d,4,%d^3), GN-stats epilogue" % (batch, size),
+    return {"bound": "mfma", "kernel": "conv_vox64_kernel<%d,...>: 3x3x3 s1 d1 conv, C=%d, (%d,%d,%d^3), GN-stats epilogue" % (c, c, batch, c, size),
             "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
             "algorithmic_gbs": round(bytes_ / sec / 1e9, 1), **common}
 
@@ -418,6 +417,9 @@ def main():
         }
         if not args.no_roofline:
             out["roofline"] = conv_kernel_roofline(device, args.batch, args.size, bf16=args.dtype == "bf16")
+            # the same kernel family one level down: C = 8 on the half-size volume (up-cell 3, 21 % of the net's FLOPs).  At 64^3 patches
+            # that is (2,8,32^3): 1024 one-wave tiles on 1024 SIMDs -- its no-fetch bound is 0.26 (profiles/r05_conv_ab.log)
+            out["roofline_c8"] = conv_kernel_roofline(device, args.batch, args.size // 2, bf16=args.dtype == "bf16", c=8)
         if world == 1 and not args.no_kernel_table:
             # what actually dominates the step: top entry points by measured microseconds per step, each against its roofline
             # (recorded on the single-stream schedule: one entry point = one launch of the dependent chain; the replay reuses the

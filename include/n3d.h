@@ -146,6 +146,16 @@ int n3d_conv_k1_norm_bwd_apply_wgrad(const n3d_conv_geom* g, const void* x, int6
                                      void* stream);
 
 
+/* ---- node-planar tensors (round 5).  A cell's output is torch.cat of its node outputs (cell.py:82, searched.py:51); as channel slices of
+ * one (B, n c) buffer every node epilogue writes 16 / 32 bytes on a 48 / 96-byte pitch (1.3-1.7x the algorithmic HBM traffic).  Where the
+ * only reader of the concatenation is a 1x1x1 preprocess conv, the nodes stay n DENSE (B, c, D, H, W) NDHWC tensors in one allocation --
+ * storage (n, B, D, H, W, c) -- and the conv entry points take the whole thing as ONE tensor whose PITCH IS SMALLER THAN ITS CHANNEL COUNT:
+ * (pointer to node 0, ld = c) with C = n c channels means node k at pointer + k * B * voxels * c elements.  Accepted by
+ *   n3d_conv_fwd        x     (xld < Ci)                      }  1x1x1, stride 1, no gates, >= 32768 voxels per sample, channels % 4 == 0,
+ *   n3d_conv_bwd_data   dx and relu_src (dxld = rld < Ci)     }  <= 24 channels on the planar side, <= 12 per node for the data gradient (one
+ *   n3d_conv_bwd_weight x     (xld < Ci)                      }  node per blockIdx.z); fp32 or bf16 storage -- N3D_ERR_UNSUPPORTED otherwise.
+ * The fused head reads the same layout through n3d_head.node_c. */
+
 /* y[o side] = conv(x[i side]) + bias */
 int n3d_conv_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias,
                  float* y, int64_t yld, int flags, const float* in_gate, double* stats,

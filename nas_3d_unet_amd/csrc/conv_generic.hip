@@ -379,6 +379,11 @@ struct K1Args {
   // 64 voxel records through LDS and writes them as consecutive 16-byte pieces (per-voxel stores of a 12-channel tensor put 16 bytes
   // on every 48-byte pitch: three partial-line instructions per line)
   int flat;
+  // node-planar operands (round 5; include/n3d.h, "node-planar tensors": a pitch SMALLER than the channel count = the channels come as
+  // C / pitch dense node tensors of `pitch` channels each, node k at base + k * node_stride elements).  Source (forward): sld < Cs, quad q
+  // is quad q % (sld/4) of node q / (sld/4).  Destination (data gradient; also its ReLU mask source and previous value): one node per
+  // blockIdx.z -- the kernel's Cd is the NODE's channel count, its weight columns start at blockIdx.z * Cd
+  int64_t src_node_stride, dst_node_stride, relu_node_stride;
 };
 constexpr int K1_VPB = 1024;   // voxels per workgroup
 
@@ -391,14 +396,25 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
   __shared__ double red[4][CDQ * 8];
   constexpr bool FLAT_OK = CDQ >= 2 && CDQ <= 3;
   __shared__ __attribute__((aligned(16))) TD stage[FLAT_OK ? 4 * 64 * CDQ * 4 : 4];   // [wave][voxel][Cd]
-  const int t = threadIdx.x, b = blockIdx.y;
+  const int t = threadIdx.x, b = blockIdx.y, z = blockIdx.z;     // z: destination node (node-planar data gradient), else 0
   for (int i = t; i < CSQ * 4 * CDQ; i += 256) {
     const int cs = i / CDQ, q = i - cs * CDQ;
-    wl[i] = *reinterpret_cast<const float4*>(a.wp + (int64_t)cs * a.Cdp + q * 4);
+    wl[i] = *reinterpret_cast<const float4*>(a.wp + (int64_t)cs * a.Cdp + (z * CDQ + q) * 4);
   }
   const int64_t base = (int64_t)blockIdx.x * (VPT * 256) + t;
   const TS* sb = reinterpret_cast<const TS*>(a.src) + (int64_t)b * (EXTRA && a.up ? a.Ns : a.N) * a.sld;
-  TD* db = reinterpret_cast<TD*>(a.dst) + (int64_t)b * a.N * a.dld;
+  // per-quad source bases (uniform): a node-planar source has sld < Cs
+  const TS* sq[CSQ];
+  {
+    const int nq = (int)(a.sld >> 2);           // quads per node (planar) -- or per voxel record
+#pragma unroll
+    for (int q = 0; q < CSQ; ++q) {
+      const int node = (nq > 0 && nq < CSQ) ? q / nq : 0;
+      sq[q] = sb + node * a.src_node_stride + (q - node * (nq < CSQ ? nq : 0)) * 4;
+    }
+  }
+  TD* db = reinterpret_cast<TD*>(a.dst) + z * a.dst_node_stride + (int64_t)b * a.N * a.dld;
+  const TD* rb = a.relu_src ? reinterpret_cast<const TD*>(a.relu_src) + z * a.relu_node_stride + (int64_t)b * a.N * a.rld : nullptr;
   const bool accum = EXTRA && (a.flags & N3D_ACCUMULATE);
   const float floor_ = (a.flags & N3D_RELU_IN) ? 0.f : -INFINITY;
   float4 x[VPT][CSQ], prev[EXTRA ? VPT : 1][CDQ], msk[EXTRA ? VPT : 1][CDQ];
@@ -432,14 +448,14 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
     vdst[i] = vc;
 #pragma unroll
     for (int q = 0; q < CSQ; ++q) {
-      x[i][q] = ld4(sb + vs * a.sld + q * 4);
+      x[i][q] = ld4(sq[q] + vs * a.sld);
       if (EXTRA && !hit) x[i][q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if constexpr (EXTRA) {
 #pragma unroll
       for (int q = 0; q < CDQ; ++q) {
         prev[i][q] = accum ? ld4(db + vc * a.dld + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        msk[i][q] = a.relu_src ? ld4(reinterpret_cast<const TD*>(a.relu_src) + ((int64_t)b * a.N + vc) * a.rld + q * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        msk[i][q] = rb ? ld4(rb + vc * a.rld + q * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
       }
     }
   }
@@ -546,11 +562,15 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
 }
 
 // shapes the 1x1x1 streaming kernel takes (the statistics row count depends on it: n3d_conv_stats_rows)
+static bool k1_dims_ok(const n3d_conv_geom* g, bool data_grad, int Cs, int Cd);
 static bool k1_shape_ok(const n3d_conv_geom* g, bool data_grad) {
+  return k1_dims_ok(g, data_grad, data_grad ? g->Co : g->Ci, data_grad ? g->Ci : g->Co);
+}
+// Cs / Cd: source / destination channels ONE launch handles (a node-planar destination is written node by node: Cd = the node's)
+static bool k1_dims_ok(const n3d_conv_geom* g, bool data_grad, int Cs, int Cd) {
   if (g->k != 1 || g->depthwise) return false;
   // stride 2: only the data gradient (zero-upsampling form), even input dims, no bias
   if (g->stride != 1 && !(g->stride == 2 && data_grad && g->pad == 0 && g->Di % 2 == 0 && g->Hi % 2 == 0 && g->Wi % 2 == 0)) return false;
-  const int Cs = data_grad ? g->Co : g->Ci, Cd = data_grad ? g->Ci : g->Co;
   const int64_t N = (int64_t)g->Di * g->Hi * g->Wi;
   // register budget: (Cs/4) * (Cd/4) <= 6 covers the nets' shapes (4->12, 12->4, 12->8, 24->4 and their data gradients).  (A 24-channel
   // destination -- the data gradient of the last up cell's 24 -> 4 preprocess conv -- was tried in round 4: with two voxels per thread the
@@ -591,6 +611,7 @@ static void launch_k1_c(const K1Args& a, int Cd, dim3 grid, hipStream_t s) {
 struct K1WgArgs {
   const void* x; int64_t xld; const void* dy; int64_t dyld; float* partial; float* pbias; int64_t total, chunk; int flags;   // x: TS elements, dy: TD elements
   int stride, Wo, Ho, Wi, Hi; int64_t No, Ni; FastDiv fNo, fWo, fHo;
+  int64_t x_node_stride;     // node-planar x (xld < Ci: see K1Args): elements between two nodes
 };
 constexpr int K1W_CHUNK = 2048;   // output voxels per workgroup
 
@@ -610,6 +631,16 @@ __global__ __launch_bounds__(256) void conv_k1_wgrad_kernel(K1WgArgs a) {
   for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[ci][c] = 0.f;
+  // per-quad bases of x (uniform): a node-planar x has xld < CI
+  const TS* xqb[CIQ];
+  {
+    const int nq = (int)(a.xld >> 2);
+#pragma unroll
+    for (int q = 0; q < CIQ; ++q) {
+      const int node = (nq > 0 && nq < CIQ) ? q / nq : 0;
+      xqb[q] = reinterpret_cast<const TS*>(a.x) + node * a.x_node_stride + (q - node * (nq < CIQ ? nq : 0)) * 4;
+    }
+  }
   for (int64_t i = i0 + t; i < i1; i += 512) {
     // two voxels in flight per trip
     float4 xq[2][CIQ], gq[2][COQ];
@@ -628,7 +659,7 @@ __global__ __launch_bounds__(256) void conv_k1_wgrad_kernel(K1WgArgs a) {
         xi = (int64_t)ub * a.Ni + ((int64_t)(2 * ud) * a.Hi + 2 * uh) * a.Wi + 2 * uw;
       }
 #pragma unroll
-      for (int q = 0; q < CIQ; ++q) xq[u][q] = ld4(reinterpret_cast<const TS*>(a.x) + xi * a.xld + q * 4);
+      for (int q = 0; q < CIQ; ++q) xq[u][q] = ld4(xqb[q] + xi * a.xld);
 #pragma unroll
       for (int q = 0; q < COQ; ++q) gq[u][q] = ld4(reinterpret_cast<const TD*>(a.dy) + vc * a.dyld + q * 4);
     }
@@ -1845,11 +1876,21 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
     N3D_LAUNCH_CHECK();
     return N3D_OK;
   }
-  if (!(flags & N3D_NO_MFMA)) {
+  // node-planar operands (a pitch smaller than the channel count; include/n3d.h): only the 1x1x1 streaming kernel reads / writes them
+  const int Cs_all = data_grad ? g->Co : g->Ci, Cd_all = data_grad ? g->Ci : g->Co;
+  const bool src_planar = sld < Cs_all, dst_planar = dld < Cd_all;
+  if (src_planar || dst_planar) {
+    const bool ok = g->k == 1 && g->stride == 1 && sld >= 4 && dld >= 4 && sld % 4 == 0 && dld % 4 == 0 && Cs_all % sld == 0 && Cd_all % dld == 0 &&
+                    !in_gate && !out_gate && (!dst_planar || (data_grad && !bias && !stats && (!relu_src || rld == dld))) &&
+                    k1_dims_ok(g, data_grad, Cs_all, dst_planar ? (int)dld : Cd_all);
+    if (!ok) N3D_UNSUPPORTED("conv: node-planar operands (pitch < channels) are taken by the 1x1x1 streaming kernel only (stride 1, no gates, "
+                             "<= 24 source / <= 12 destination channels per launch, >= 32768 voxels)");
+  }
+  if (!(flags & N3D_NO_MFMA) && !src_planar && !dst_planar) {
     int r = mfma_conv_try(g, data_grad, src, sld, w, bias, dst, dld, flags, in_gate, relu_src, rld, out_gate, stats, ws, ws_bytes, s);
     if (r != 0) return r < 0 ? r : N3D_OK;
   }
-  if (sb16 && db16) {
+  if (sb16 && db16 && !src_planar && !dst_planar) {
     int r = vox16_conv_try(g, data_grad, src, sld, w, bias, dst, dld, flags, in_gate, relu_src, out_gate, stats, ws, ws_bytes, s);
     if (r != 0) return r < 0 ? r : N3D_OK;
   }
@@ -1875,7 +1916,8 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
     set_error("conv: statistics on this shape need a 16-byte aligned source (n3d_conv_stats_rows assumed the parity-class kernel)");
     return N3D_ERR_UNSUPPORTED;
   }
-  if (k1_shape_ok(g, data_grad)) {
+  const int cd_eff = dst_planar ? (int)dld : a.Cd;       // destination channels of one launch slice (blockIdx.z = node)
+  if (k1_dims_ok(g, data_grad, a.Cs, cd_eff)) {
     const bool nostore = g_k1_norm && g_k1_norm->nostore;
     const bool fits = !in_gate && !out_gate && sld % 4 == 0 && (nostore || (dld % 4 == 0 && aligned_quad(dst, db16))) && aligned_quad(src, sb16) && aligned16(a.wp) &&
                       (!bias || aligned16(bias)) && (!relu_src || (rld % 4 == 0 && aligned_quad(relu_src, db16))) && a.Cdp % 4 == 0 &&
@@ -1890,7 +1932,7 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
         const size_t esz = db16 ? 2 : 4;
         // fp32 destinations only: measured at 2 x 128^3, 12-channel writes 54.5 -> 42.5 us (fp32) but 31.1 -> 35.2 us (bf16: the 8-byte LDS
         // stores on a 24-byte pitch cost more than the partial-line stores they replace)
-        q.flat = (!noflat && !db16 && a.Cd >= 8 && dld == a.Cd && aligned16(dst) && ((size_t)q.N * a.Cd * esz) % 16 == 0) ? 1 : 0;
+        q.flat = (!noflat && !db16 && cd_eff >= 8 && dld == cd_eff && aligned16(dst) && ((size_t)q.N * cd_eff * esz) % 16 == 0) ? 1 : 0;
       }
       {
         constexpr bool nosparse = false;
@@ -1902,14 +1944,18 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
       }
       const bool extra = (flags & N3D_ACCUMULATE) || relu_src || q.up;
       N3D_CHECK_ARG(!(extra && stats), "conv(1x1x1): statistics together with accumulate / relu mask are not supported");
-      const dim3 grid((unsigned)cdiv(q.sparse ? q.Ns : q.N, extra ? 512 : K1_VPB), (unsigned)g->B);
+      // node-planar operands: node k of a tensor starts k * (B * voxels * pitch) elements behind node 0
+      q.src_node_stride = src_planar ? (int64_t)g->B * q.N * sld : 0;
+      q.dst_node_stride = dst_planar ? (int64_t)g->B * q.N * dld : 0;
+      q.relu_node_stride = (dst_planar && relu_src) ? (int64_t)g->B * q.N * rld : 0;
+      const dim3 grid((unsigned)cdiv(q.sparse ? q.Ns : q.N, extra ? 512 : K1_VPB), (unsigned)g->B, (unsigned)(a.Cd / cd_eff));
       switch (a.Cs / 4) {
-        case 1: launch_k1_c<1>(q, a.Cd, grid, s); break;
-        case 2: launch_k1_c<2>(q, a.Cd, grid, s); break;
-        case 3: launch_k1_c<3>(q, a.Cd, grid, s); break;
-        case 4: launch_k1_c<4>(q, a.Cd, grid, s); break;
-        case 5: launch_k1_c<5>(q, a.Cd, grid, s); break;
-        default: launch_k1_c<6>(q, a.Cd, grid, s); break;
+        case 1: launch_k1_c<1>(q, cd_eff, grid, s); break;
+        case 2: launch_k1_c<2>(q, cd_eff, grid, s); break;
+        case 3: launch_k1_c<3>(q, cd_eff, grid, s); break;
+        case 4: launch_k1_c<4>(q, cd_eff, grid, s); break;
+        case 5: launch_k1_c<5>(q, cd_eff, grid, s); break;
+        default: launch_k1_c<6>(q, cd_eff, grid, s); break;
       }
       N3D_LAUNCH_CHECK();
       return N3D_OK;
@@ -1927,7 +1973,7 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
 int n3d_conv_fwd(const n3d_conv_geom* g, const float* x, int64_t xld, const float* w, const float* bias, float* y, int64_t yld, int flags,
                  const float* in_gate, double* stats, void* ws, size_t ws_bytes, void* stream) {
   if (int e = check_geom(g, "conv_fwd")) return e;
-  N3D_CHECK_ARG(x && w && y && xld >= g->Ci && yld >= g->Co, "conv_fwd: bad pointers/pitches");
+  N3D_CHECK_ARG(x && w && y && (xld >= g->Ci || (xld >= 4 && g->Ci % xld == 0)) && yld >= g->Co, "conv_fwd: bad pointers/pitches");
   return run_gather(g, false, x, xld, w, bias, y, yld, flags, in_gate, nullptr, 0, nullptr, stats, ws, ws_bytes, stream);
 }
 
@@ -1992,7 +2038,7 @@ int n3d_conv_k1_norm_bwd_apply_wgrad(const n3d_conv_geom* g, const void* x, int6
 int n3d_conv_bwd_data(const n3d_conv_geom* g, const float* dy, int64_t dyld, const float* w, float* dx, int64_t dxld, int flags,
                       const float* relu_src, int64_t rld, const float* out_gate, void* ws, size_t ws_bytes, void* stream) {
   if (int e = check_geom(g, "conv_bwd_data")) return e;
-  N3D_CHECK_ARG(dy && w && dx && dyld >= g->Co && dxld >= g->Ci, "conv_bwd_data: bad pointers/pitches");
+  N3D_CHECK_ARG(dy && w && dx && dyld >= g->Co && (dxld >= g->Ci || (dxld >= 4 && g->Ci % dxld == 0)), "conv_bwd_data: bad pointers/pitches");
   return run_gather(g, true, dy, dyld, w, nullptr, dx, dxld, flags & ~N3D_RELU_IN, nullptr, relu_src, rld, out_gate, nullptr, ws, ws_bytes,
                     stream);
 }
@@ -2157,6 +2203,9 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
       return N3D_OK;
     }
   }
+  const bool x_planar = !transposed && xld < g->Ci;      // node-planar x (include/n3d.h): the 1x1x1 streaming weight gradient only
+  if (x_planar && !(xld >= 4 && xld % 4 == 0 && g->Ci % xld == 0 && !in_gate && k1_wgrad_shape_ok(g) && dyld % 4 == 0 && aligned_quad(x, sb16) && aligned_quad(dy, db16)))
+    N3D_UNSUPPORTED("conv_bwd_weight: a node-planar x (pitch < channels) is taken by the 1x1x1 streaming weight gradient only");
   if (!transposed && !in_gate && k1_wgrad_shape_ok(g) && xld % 4 == 0 && dyld % 4 == 0 && aligned_quad(x, sb16) && aligned_quad(dy, db16)) {
     // 1x1x1 streaming weight gradient (large levels, few channels)
     const int64_t total = (int64_t)g->B * No;
@@ -2173,7 +2222,7 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
       K1WgArgs q;
       q.x = x; q.xld = xld; q.dy = dy; q.dyld = dyld; q.partial = wsf; q.pbias = wsf + (size_t)nchunks * nslab; q.total = total;
       q.chunk = chunk; q.flags = flags; q.stride = g->stride; q.Wo = g->Wo; q.Ho = g->Ho; q.Wi = g->Wi; q.Hi = g->Hi; q.No = No;
-      q.Ni = (int64_t)g->Di * g->Hi * g->Wi; q.fNo = FastDiv((uint32_t)No); q.fWo = FastDiv((uint32_t)g->Wo); q.fHo = FastDiv((uint32_t)g->Ho);
+      q.Ni = (int64_t)g->Di * g->Hi * g->Wi; q.x_node_stride = x_planar ? (int64_t)g->B * q.Ni * xld : 0; q.fNo = FastDiv((uint32_t)No); q.fWo = FastDiv((uint32_t)g->Wo); q.fHo = FastDiv((uint32_t)g->Ho);
       switch (g->Ci / 4) {
         case 1: launch_k1_wgrad_c<1>(q, g->Co, nchunks, s); break;
         case 2: launch_k1_wgrad_c<2>(q, g->Co, nchunks, s); break;

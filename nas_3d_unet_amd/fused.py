@@ -187,6 +187,11 @@ def _run_forward(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=False):
 # trainers' pipeline) set PLANAR_OUT around NetFn.forward and the last cell keeps its nodes dense; the head gathers three pointers.
 PLANAR_LAST = True     # (tests switch it off to compare with the concatenated layout)
 PLANAR_OUT = False
+# Round 5: the same for every cell whose concatenation is read by ONE 1x1x1 preprocess conv of the next cell and nothing else (searched
+# nets: the up cells -- an up cell's output is only the next up cell's x1) on >= 32768 voxels: the conv takes the node-planar tensor as it
+# is (include/n3d.h, "node-planar tensors": pitch < channels), its data gradient writes the per-node gradients, its weight gradient gathers
+# the nodes.  Here that is up-cell 3 (3 x 8 channels at 32^3 / 64^3 for 64^3 / 128^3 patches).
+PLANAR_INNER = True    # (tests switch it off to compare with the concatenated layout)
 
 
 # Side-stream forward of a supernet cell (train.SideSchedule sets SIDE_FWD; round 3).  A node sums the MixedOps of ALL earlier states
@@ -203,9 +208,15 @@ SIDE_BWD = None      # the same object while the backward pass of a supernet may
 
 
 def _node_buffer(plan, shape, device, planar):
-    """(output object, node Views): one (B, n c) concatenation buffer with the nodes as channel slices, or -- planar, the net's last
-    cell -- the nodes as dense tensors of their own (kernels.Planar)"""
+    """(output object, node Views): one (B, n c) concatenation buffer with the nodes as channel slices, or -- planar -- the nodes as
+    dense tensors of their own (kernels.Planar).  planar: True (the head reads it) or the output channel count of the ONE 1x1x1
+    preprocess conv that reads it (the node-planar form is taken where the streaming 1x1x1 kernels take it: channel counts, voxels)"""
     cn, nn = plan.c_node, plan.n_nodes
+    if planar is not True and planar:
+        co = int(planar)
+        vox = shape[2] * shape[3] * shape[4]
+        planar = (vox >= 32768 and cn % 4 == 0 and cn <= 12 and nn * cn <= 24 and co % 4 == 0 and co <= 12
+                  and (nn * cn // 4) * (co // 4) <= 6 and (co // 4) * (cn // 4) <= 6)
     if planar:
         out = K.empty_planar(nn, shape[0], cn, shape[2], shape[3], shape[4], device)
         return out, out.nodes
@@ -316,7 +327,7 @@ def _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=Fals
     if SIDE_FWD is not None and not plan.pairs and _grouping(plan.c_node):
         return _run_forward_side(plan, x0, x1, alpha1, alpha2, SIDE_FWD, planar)
     st = P.Saved()
-    x0v, x1v = K.as_view(x0, "x0"), K.as_view(x1, "x1")
+    x0v, x1v = K.as_view(x0, "x0"), K.as_act(x1, "x1")     # (x1 may be the previous up cell's node-planar output)
     # the two preprocess ops (cell.py:47-50) are independent and of one output shape: paired epilogue launch
     shp = plan.pre1.weight.out_shape(x1v)
     if pre0_early is not None:
@@ -903,6 +914,18 @@ class _NetPlan:
         for k in range(self.n_down, len(cells)):
             self.wiring.append((kept.pop(), newer, 2 + k))
             newer = 2 + k
+        # cells whose output may stay node-planar (PLANAR_INNER): read by exactly ONE op -- the x1 preprocess conv of a later cell, a plain
+        # 1x1x1 stride-1 conv -- and by nothing else; value = that conv's output channels (the shapes are checked when the cell runs)
+        self.planar_reader = {}
+        if not supernet:
+            for k in range(len(cells) - 1):
+                readers = [(j, side) for j, (i0, i1, _) in enumerate(self.wiring) for side, idx in ((0, i0), (1, i1)) if idx == 2 + k]
+                if len(readers) == 1 and readers[0][1] == 1 and self.cells[k].pairs:
+                    pre = self.cells[readers[0][0]].pre1
+                    w = pre.weight
+                    if (isinstance(w, P.DenseConvW) and w.k == 1 and w.stride == 1 and not w.transposed and pre.dropout is None
+                            and pre.se_gate is None and self.cells[readers[0][0]].pairs):
+                        self.planar_reader[k] = int(w.m.weight.shape[0])
         self.params = self.stem0.params() + self.stem1.params()
         self.offsets = []
         for pl in self.cells:
@@ -969,7 +992,7 @@ class NetFn(torch.autograd.Function):
         for k, (i0, i1, _) in enumerate(nplan.wiring):
             a1, a2 = (al[0], al[2]) if k < nplan.n_down else (al[1], al[3])
             out, st = _run_forward(nplan.cells[k], acts[i0], acts[i1], a1, a2, early.pop(k, None),
-                                   planar=PLANAR_OUT and k == len(nplan.wiring) - 1)
+                                   planar=(PLANAR_OUT and k == len(nplan.wiring) - 1) or (PLANAR_INNER and nplan.planar_reader.get(k, 0)))
             acts.append(out)
             states.append(st)
             if k < nplan.n_down:
@@ -999,7 +1022,7 @@ class NetFn(torch.autograd.Function):
             a1, a2 = (al[0], al[2]) if down else (al[1], al[3])
             settle(io)                                                      # read from the first launch on
             late = [pending.pop(i) for i in (i0, i1) if i in pending]       # only written, by the preprocess backward at the end
-            targets = tuple((K.as_view(gbuf[i], "grad") if gbuf[i] is not None else None, gbuf[i] is not None) for i in (i0, i1))
+            targets = tuple((K.as_act(gbuf[i], "grad") if gbuf[i] is not None else None, gbuf[i] is not None) for i in (i0, i1))
             d0, d1, da1, da2, gl = _run_backward(nplan.cells[k], ctx.states[k], gbuf[io], a1, a2, True, True, want_da, targets,
                                                  own_dout=gbuf[io] is not dout, late_joins=late)
             tok = getattr(ctx.states[k], "side_tok", None)

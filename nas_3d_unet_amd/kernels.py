@@ -117,7 +117,9 @@ def _bf16_slack_ok(t, ld):
 
 
 def like(v):
-    """fresh dense View of the shape and storage type of View v (gradient buffers, temporaries)"""
+    """fresh dense View of the shape and storage type of View v (gradient buffers, temporaries); a node-planar tensor gives a node-planar one"""
+    if isinstance(v, Planar):
+        return empty_planar(v.nn, v.B, v.cn, v.D, v.H, v.W, v.t.device, v.t.dtype)
     return View(empty_ndhwc(v.B, v.C, v.D, v.H, v.W, v.t.device, v.t.dtype), v.C)
 
 
@@ -159,9 +161,10 @@ class View:
 class Planar:
     """Node-planar feature map (include/n3d.h, n3d_head): the concatenation of a cell's `nn` node outputs kept as `nn` DENSE
     (B, cn, D, H, W) NDHWC tensors in one allocation -- storage (nn, B, D, H, W, cn), presented to torch as the 6-D tensor
-    `t` of shape (nn, B, cn, D, H, W).  Only the fused head reads it (three pointers instead of one 48-byte voxel record);
+    `t` of shape (nn, B, cn, D, H, W).  Readers: the fused head (n3d_head.node_c) and the 1x1x1 preprocess convs, which take it as ONE
+    tensor whose pitch `ld` = cn is smaller than its channel count C = nn cn (include/n3d.h, "node-planar tensors"): `p` points to node 0.
     `nodes[k]` is the ordinary dense View of node k."""
-    __slots__ = ("t", "nodes", "nn", "cn", "B", "C", "D", "H", "W", "N", "dt", "node_stride")
+    __slots__ = ("t", "nodes", "nn", "cn", "B", "C", "D", "H", "W", "N", "dt", "node_stride", "p", "ld")
 
     def __init__(self, t):
         self.t = t
@@ -170,6 +173,7 @@ class Planar:
         self.dt = _lib.BF16 if t.dtype == torch.bfloat16 else _lib.F32
         self.node_stride = self.B * self.N * self.cn
         self.nodes = [View(t[k], self.cn) for k in range(self.nn)]
+        self.p, self.ld = self.nodes[0].p, self.cn
 
 
 def empty_planar(nn, B, cn, D, H, W, device, dtype=None):
@@ -238,6 +242,13 @@ def as_view(t, what="tensor", bf16_ok=True):
         n.copy_(t)  # layout plumbing (strided copy); arithmetic stays in libn3d
         t, ld = n, Cc
     return View(t, ld)
+
+
+def as_act(t, what="tensor"):
+    """an activation (or its gradient) as the kernels take it: a 5-D tensor -> View, a 6-D node-planar one -> Planar"""
+    if isinstance(t, torch.Tensor) and t.dim() == 6:
+        return as_planar(t, what)
+    return as_view(t, what)
 
 
 def conv_geom(B, Di, Hi, Wi, Ci, Co, k, stride, dil, pad, depthwise=False):

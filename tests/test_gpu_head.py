@@ -245,3 +245,119 @@ def test_supernet_last_cell_node_planar_equals_concatenated():
     assert res[0][0] == res[1][0] and res[0][1].keys() == res[1][1].keys()
     for n in res[0][1]:
         assert torch.equal(res[0][1][n], res[1][1][n]), n
+
+
+# ---- node-planar tensors as operands of the 1x1x1 preprocess convs (include/n3d.h, "node-planar tensors"; fused.PLANAR_INNER) -----------
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+@pytest.mark.parametrize("cn,co,shape", [(8, 4, (32, 32, 32)), (4, 8, (32, 32, 64)), (8, 4, (33, 32, 32))])
+def test_k1_conv_on_node_planar_operands_equals_the_concatenated_form(storage, cn, co, shape):
+    """the 1x1x1 streaming kernels with a node-planar x side (pitch = cn < channels = 3 cn: three dense node tensors) against the same
+    calls on the concatenation buffer: forward (ReLU on load, statistics rows), data gradient (ReLU mask, accumulate) and weight
+    gradient -- the same arithmetic in the same order, bit for bit; a ragged voxel count included"""
+    from nas_3d_unet_amd import kernels as K
+    from nas_3d_unet_amd._lib import ACCUMULATE, RELU_IN
+    dt = torch.bfloat16 if storage == "bf16" else torch.float32
+    rng = np.random.default_rng(5 + cn + shape[0])
+    B, nn = 2, 3
+    d = torch.device("cuda")
+    xn = rng.standard_normal((B, nn * cn) + shape).astype(np.float32)
+    with K.storage(dt):
+        xc = K.as_view(K.empty_ndhwc(B, nn * cn, *shape, d))
+        xc.t.copy_(torch.from_numpy(xn).to(d))
+        xp = K.empty_planar(nn, B, cn, *shape, d)
+        for k in range(nn):
+            xp.nodes[k].t.copy_(xc.t[:, k * cn:(k + 1) * cn])
+        assert xp.ld == cn and xp.C == nn * cn
+        w = torch.from_numpy((rng.standard_normal((co, nn * cn, 1, 1, 1)) * 0.3).astype(np.float32)).to(d)
+        b = torch.from_numpy(rng.standard_normal(co).astype(np.float32) * 0.1).to(d)
+        g = K.conv_geom(B, *shape, nn * cn, co, 1, 1, 1, 0)
+        # forward
+        ys = []
+        for x in (xc, xp):
+            y = K.as_view(K.empty_ndhwc(B, co, *shape, d))
+            rows = K.conv_stats_rows(g, False, 0, x, y)
+            stats = torch.zeros((B, rows, co, 2), dtype=torch.float64, device=d)
+            K.conv_fwd(g, x, w, b, y, RELU_IN, None, stats, False)
+            ys.append((y.t.clone(), stats.clone()))
+        assert torch.equal(ys[0][0], ys[1][0]) and torch.equal(ys[0][1], ys[1][1])
+        ref = torch.nn.functional.conv3d(torch.relu(xc.t.float()), w, b)
+        assert float((ys[1][0].float() - ref).abs().max()) <= (2.0 ** -7 if storage == "bf16" else 1e-4) * float(ref.abs().max())
+        # data gradient: dx (+)= relu'(x) * W^T dy, into the concatenation buffer / into the three node tensors
+        dy = K.as_view(K.empty_ndhwc(B, co, *shape, d))
+        dy.t.copy_(torch.from_numpy(rng.standard_normal((B, co) + shape).astype(np.float32)).to(d))
+        d0 = torch.from_numpy(rng.standard_normal((B, nn * cn) + shape).astype(np.float32)).to(d)
+        for acc in (0, ACCUMULATE):
+            dxc = K.as_view(K.empty_ndhwc(B, nn * cn, *shape, d))
+            dxc.t.copy_(d0)
+            dxp = K.like(xp)
+            assert isinstance(dxp, K.Planar)
+            for k in range(nn):
+                dxp.nodes[k].t.copy_(dxc.t[:, k * cn:(k + 1) * cn])
+            K.conv_bwd_data(g, dy, w, dxc, acc, xc, None, False)
+            K.conv_bwd_data(g, dy, w, dxp, acc, xp, None, False)
+            for k in range(nn):
+                assert torch.equal(dxp.nodes[k].t, dxc.t[:, k * cn:(k + 1) * cn]), (acc, k)
+        # weight gradient
+        dws = []
+        for x in (xc, xp):
+            dw, db = torch.zeros_like(w), torch.zeros_like(b)
+            K.conv_bwd_weight(g, x, dy, dw, db, RELU_IN, None, False, defer=False)
+            dws.append((dw, db))
+        torch.cuda.synchronize()
+        assert torch.equal(dws[0][0], dws[1][0]) and torch.equal(dws[0][1], dws[1][1])
+
+
+def test_node_planar_operands_are_refused_where_no_kernel_takes_them():
+    """a pitch smaller than the channel count reaches only the 1x1x1 streaming kernels: anything else must fail loudly, not misread"""
+    from nas_3d_unet_amd import kernels as K
+    d = torch.device("cuda")
+    xp = K.empty_planar(3, 2, 8, 16, 16, 16, d)          # 4096 voxels: below the streaming kernels' volume
+    w = torch.zeros((4, 24, 1, 1, 1), device=d)
+    y = K.as_view(K.empty_ndhwc(2, 4, 16, 16, 16, d))
+    with pytest.raises(K.N3DError, match="node-planar"):
+        K.conv_fwd(K.conv_geom(2, 16, 16, 16, 24, 4, 1, 1, 1, 0), xp, w, None, y, 0, None, None, False)
+    xp = K.empty_planar(3, 2, 8, 32, 32, 32, d)
+    w3 = torch.zeros((4, 24, 3, 3, 3), device=d)
+    y = K.as_view(K.empty_ndhwc(2, 4, 32, 32, 32, d))
+    with pytest.raises(K.N3DError, match="node-planar|pitch"):
+        K.conv_fwd(K.conv_geom(2, 32, 32, 32, 24, 4, 3, 1, 1, 1), xp, w3, None, y, 0, None, None, False)
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+@pytest.mark.parametrize("path", ["autograd", "pipeline"])
+def test_inner_cell_node_planar_equals_concatenated(storage, path):
+    """SearchedNet at 4 x 64^3 with up-cell 3's nodes kept dense (fused.PLANAR_INNER: 3 x 8 channels on 32^3 voxels, read by the last cell's
+    x1 preprocess conv) against the concatenation buffer: loss and every parameter gradient bit-identical"""
+    from nas_3d_unet_amd import fused, kernels as K, unet
+    from nas_3d_unet_amd.train import Trainer
+    from test_gpu_nets import build_net
+    rng = np.random.default_rng(171)
+    x = dev(rng.standard_normal((2, 4, 64, 64, 64)).astype(np.float32))
+    t = dev((rng.uniform(0, 1, (2, 3, 64, 64, 64)) < 0.3).astype(np.float32))
+    res, made = [], []
+    orig = K.empty_planar
+    for planar in (False, True):
+        prev, fused.PLANAR_INNER = fused.PLANAR_INNER, planar
+        K.empty_planar = lambda *a, **k: (made.append((planar, a[2])), orig(*a, **k))[1]
+        try:
+            net, _ = build_net("searched", "G_CONV", 4)
+            unet.set_storage(net, storage)
+            if path == "autograd":
+                l, p = net.forward_loss(x, t)
+                l.backward()
+                grads = {n: q.grad.clone() for n, q in net.named_parameters()}
+            else:
+                tr = Trainer(net, graph=False, side_wgrad=False)
+                l = tr._pipeline(x, t, cell_hook=lambda k: None)
+                tr.ctx.flush_final()
+                grads = {"flat": tr.fp.grad.clone()}
+            torch.cuda.synchronize()
+            res.append((float(l), grads))
+        finally:
+            fused.PLANAR_INNER = prev
+            K.empty_planar = orig
+    assert any(pl and cn == 8 for pl, cn in made), "the inner cell never took the node-planar form"
+    assert not any((not pl) and cn == 8 for pl, cn in made)
+    assert res[0][0] == res[1][0]
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n

@@ -5,16 +5,17 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r05; mkdir -p $O
 TAG=${TAG:-after}
-case="bf16 4 128 2 1"; tag=conv_vox64b_bf16_2x4x128_$TAG
+#   CASE="f32 4 64 2 1" KNAME=conv_vox64_kernel NAME=conv_vox64_f32_2x4x64 selects another conv (tools/conv_pmc.py arguments, kernel substring, output name)
+case=${CASE:-"bf16 4 128 2 1"}; KNAME=${KNAME:-conv_vox64b_}; tag=${NAME:-conv_vox64b_bf16_2x4x128}_$TAG
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   gt=$(echo $grp | cut -d' ' -f1)
   rm -rf $O/pmc_${tag}/pmc_$gt
   timeout -k 5 150 rocprofv3 --pmc $grp --output-format csv -d $O/pmc_${tag}/pmc_$gt -- python3 tools/conv_pmc.py $case 20 > $O/pmc_${tag}_$gt.log 2>&1
   echo "$tag $gt rc=$?"
 done
-python3 tools/pmc_summary.py $O/pmc_${tag} conv_vox64b_ $O/pmc_${tag}.json > /dev/null 2>&1
+python3 tools/pmc_summary.py $O/pmc_${tag} $KNAME $O/pmc_${tag}.json > /dev/null 2>&1
 rm -rf $O/pmc_${tag} $O/pmc_${tag}_*.log $O/kt_${tag}
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_${tag} -- python3 tools/conv_pmc.py $case 200 > /dev/null 2>&1
-grep -h "conv_vox64b_kernel\|conv_vox64b_march_kernel" $O/kt_${tag}/*/*kernel_stats.csv | head -2 > $O/pmc_${tag}_kernel_time.csv
+grep -h "$KNAME" $O/kt_${tag}/*/*kernel_stats.csv | head -2 > $O/pmc_${tag}_kernel_time.csv
 rm -rf $O/kt_${tag}
 cat $O/pmc_${tag}.json | grep -v dispatch | head -40; cat $O/pmc_${tag}_kernel_time.csv | cut -c1-200
