@@ -1878,7 +1878,7 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
   }
   // node-planar operands (a pitch smaller than the channel count; include/n3d.h): only the 1x1x1 streaming kernel reads / writes them
   const int Cs_all = data_grad ? g->Co : g->Ci, Cd_all = data_grad ? g->Ci : g->Co;
-  const bool src_planar = sld < Cs_all, dst_planar = dld < Cd_all;
+  const bool src_planar = sld > 0 && sld < Cs_all, dst_planar = dst && dld > 0 && dld < Cd_all;     // (dst NULL: the statistics-only pass of n3d_conv_k1_norm_fwd)
   if (src_planar || dst_planar) {
     const bool ok = g->k == 1 && g->stride == 1 && sld >= 4 && dld >= 4 && sld % 4 == 0 && dld % 4 == 0 && Cs_all % sld == 0 && Cd_all % dld == 0 &&
                     !in_gate && !out_gate && (!dst_planar || (data_grad && !bias && !stats && (!relu_src || rld == dld))) &&
