@@ -122,7 +122,11 @@ def describe(name, args):
         if name in ("n3d_conv_bwd_data", "n3d_convT_bwd_data"):
             g = _geom(args[0]); fl = v[6]
             f, b = _conv_cost(g, "bwd_data" if name == "n3d_conv_bwd_data" else "bwd_dataT", fl)
-            return (name, _gtuple(g), fl & 0xC0), f, b
+            # what the op must also read, once each: the previous value of dx when it accumulates (the backward walk's second and third
+            # writers of an activation's gradient) and the ReLU mask source of a conv with ReLU on load (the input itself)
+            dx_bytes = g.B * (g.Di * g.Hi * g.Wi if name == "n3d_conv_bwd_data" else g.Do * g.Ho * g.Wo) * (g.Ci if name == "n3d_conv_bwd_data" else g.Co) * _esz(bool(fl & _lib.DST_BF16))
+            extra = (dx_bytes if fl & _lib.ACCUMULATE else 0) + (dx_bytes if (name == "n3d_conv_bwd_data" and v[7]) else 0)
+            return (name, _gtuple(g), fl & 0xC4, bool(name == "n3d_conv_bwd_data" and v[7])), f, b + extra
         if name in ("n3d_conv_bwd_weight", "n3d_convT_bwd_weight"):
             g = _geom(args[0]); fl = v[7]
             f, b = _conv_cost(g, "bwd_weight", fl)
@@ -320,7 +324,7 @@ def table(run_step, device, top=5, candidates=14):
         elif gr["flop"] is None:
             row.update({"bound": None, "frac": None, "note": "no cost model" + ((": " + describe.errors[gr["name"]]) if gr["name"] in describe.errors else "")})
         else:
-            bf16_mfma = gr["name"] in ("n3d_conv_fwd", "n3d_conv_bwd_data") and sig[-1] == 0xC0 and sig[1][9] == 3 and sig[1][10] == 1
+            bf16_mfma = gr["name"] in ("n3d_conv_fwd", "n3d_conv_bwd_data") and (sig[2] & 0xC0) == 0xC0 and sig[1][9] == 3 and sig[1][10] == 1
             peak = PEAK_BF16_TFLOPS if bf16_mfma else PEAK_F32_TFLOPS   # the bf16-storage 3x3x3 kernels run v_mfma_f32_4x4x4_16b_bf16
             row["mfma_peak_tflops"] = peak
             t_mfma = gr["flop"] / (peak * 1e12) * 1e6
