@@ -239,6 +239,14 @@ int n3d_channel_stats(const float* x, int64_t ld, int B, int64_t N, int C, doubl
 int n3d_channel_stats_t(const void* x, int64_t ld, int dtype, int B, int64_t N, int C, double* stats, void* stream);
 /* the same for up to N3D_MAX_GROUP_TERMS tensors of one (B, N, C) shape in one launch: xs / lds / stats are host arrays of n entries */
 int n3d_channel_statsN(const float* const* xs, const int64_t* lds, double* const* stats, int n, int B, int64_t N, int C, void* stream);
+/* ---- padded channels (round 5).  The reference takes feature maps of any channel count (nas.py:13-26, searched.py:55-66: init_n_kernels = 2,
+ * 6, ...); the kernels move channels four at a time.  Such a net runs with every feature map zero-padded to a multiple of 4 (zero conv
+ * weights / gamma / beta on the padded channels: they hold exactly 0 forward and receive exactly 0 backward).  Sums over a padded tensor
+ * are the real tensor's sums, so one thing changes: the ELEMENT COUNT of a GroupNorm group.  Every entry point below that takes a group
+ * count G accepts G < 0 = "ONE group whose real channel count is -G, stored in C >= -G channels": statistics are divided by N * (-G)
+ * instead of N * C.  (A real count that needs padding is never a multiple of 16, i.e. always one group: prim_ops.py:57.)  Not taken with
+ * G < 0: the one-launch small backward (n3d_bwd_small2_ok returns 0), n3d_node_fwd_coeffs / n3d_node_bwd_coeffs; conv-bias gradients out
+ * of the GroupNorm sums (dbias_conv) need the true count and must not be requested. */
 /* GroupNorm(G, C) statistics -> per-(b,c) affine y = a*x + b; mean_rstd[b][g] = (mean, rstd) (prim_ops.py:56-58) */
 int n3d_gn_coeffs(const double* stats, int rows, const float* gamma, const float* beta, int B, int C, int G,
                   int64_t N, float eps, float* a, float* b, float* mean_rstd, double* sumraw /* [B][C] or NULL */,

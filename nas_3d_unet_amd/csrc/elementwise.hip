@@ -2379,6 +2379,13 @@ __global__ void step_inc_kernel(int32_t* step_ptr) { *step_ptr += 1; }
 
 }  // namespace n3d
 
+// GroupNorm over zero-PADDED channels (round 5; include/n3d.h, "padded channels"): a group count G < 0 means ONE group whose REAL channel
+// count is -G, stored inside C >= -G channels of which the others are exactly zero (zero weights, gamma, beta).  Sums over the padded
+// tensor are the real tensor's sums, so only the element count of the group changes: the kernels take it as count * (C / G) with G = 1,
+// i.e. count = N * (-G) / C.
+static inline double gn_count(int64_t N, int C, int G) { return G < 0 ? (double)N * (double)(-G) / (double)C : (double)N; }
+static inline int gn_groups(int G) { return G < 0 ? 1 : G; }
+
 using namespace n3d;
 
 // ================================================================================================
@@ -2437,9 +2444,11 @@ int n3d_channel_statsN(const float* const* xs, const int64_t* lds, double* const
 
 int n3d_gn_coeffs(const double* stats, int rows, const float* gamma, const float* beta, int B, int C, int G, int64_t N, float eps,
                   float* a, float* b, float* mean_rstd, double* sumraw, void* stream) {
+  const double gn_cnt_ = gn_count(N, C, G);      // G < 0: ONE group of -G real channels inside C zero-padded ones (include/n3d.h)
+  G = gn_groups(G);
   N3D_CHECK_ARG(stats && gamma && beta && a && b && C <= 64 && G >= 1 && C % G == 0 && rows >= 1, "gn_coeffs: bad args");
   const GnCoefArgs q{stats, rows, gamma, beta, a, b, mean_rstd, sumraw};
-  hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B, 1), dim3(256), 0, (hipStream_t)stream, q, q, C, G, (double)N, eps);
+  hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B, 1), dim3(256), 0, (hipStream_t)stream, q, q, C, G, gn_cnt_, eps);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2486,11 +2495,13 @@ int n3d_affine_act_bwd_reduce(const float* dout, int64_t dld, const float* raw, 
 int n3d_gn_bwd_coeffs(const double* sums, int rows, const float* gamma, const float* mean_rstd, const float* wptr, int B, int C, int G,
                       int64_t N, float* dgamma, float* dbeta, float* dalpha, float* A, float* Bc, float* Cc, const double* sumraw,
                       float* dbias_conv, void* stream) {
+  const double gn_cnt_ = gn_count(N, C, G);      // G < 0: ONE group of -G real channels inside C zero-padded ones (include/n3d.h)
+  G = gn_groups(G);
   N3D_CHECK_ARG(sums && gamma && mean_rstd && A && Bc && Cc && C <= 64 && C % G == 0, "gn_bwd_coeffs: bad args");
   N3D_CHECK_ARG(!dbias_conv || sumraw, "gn_bwd_coeffs: dbias_conv needs the forward per-channel sums");
   const GnBwdCoefArgs q{sums, rows, gamma, mean_rstd, wptr, dgamma, dbeta, dalpha, A, Bc, Cc, sumraw, dbias_conv};
-  if (B <= 2) hipLaunchKernelGGL(gn_bwd_coeffs_kernel<2>, dim3(1), dim3(512), 0, (hipStream_t)stream, q, q, B, C, G, (double)N);
-  else hipLaunchKernelGGL(gn_bwd_coeffs_kernel<GNB_BP>, dim3(1), dim3(256 * GNB_BP), 0, (hipStream_t)stream, q, q, B, C, G, (double)N);
+  if (B <= 2) hipLaunchKernelGGL(gn_bwd_coeffs_kernel<2>, dim3(1), dim3(512), 0, (hipStream_t)stream, q, q, B, C, G, gn_cnt_);
+  else hipLaunchKernelGGL(gn_bwd_coeffs_kernel<GNB_BP>, dim3(1), dim3(256 * GNB_BP), 0, (hipStream_t)stream, q, q, B, C, G, gn_cnt_);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2499,6 +2510,8 @@ static bool pair_shape_ok(int C, int G) { return C >= 4 && C <= 64 && (C & (C - 
 
 int n3d_affine_act_gn2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int G, float eps, float* out, int64_t old_, float* out1,
                        int64_t old1, int B, int64_t N, int C, int flags, void* stream) {
+  const double gn_cnt_ = gn_count(N, C, G);      // G < 0: ONE group of -G real channels inside C zero-padded ones (include/n3d.h)
+  G = gn_groups(G);
   N3D_CHECK_ARG(t0 && t1 && out && B > 0 && N > 0, "affine_act_gn2: bad args");
   if (!pair_shape_ok(C, G) || t0->rows < 1 || t1->rows < 1 || t0->rows > n3d_fused_max_rows() || t1->rows > n3d_fused_max_rows())
     N3D_UNSUPPORTED("affine_act_gn2: shape not supported by the pair kernel (C=%d G=%d rows=%d/%d)", C, G, t0->rows, t1->rows);
@@ -2518,8 +2531,8 @@ int n3d_affine_act_gn2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int
   hipStream_t s = (hipStream_t)stream;
   with_act_type(bf, [&](auto* tag) {
     using T = N3D_T(tag);
-    if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true, false, T>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, (T*)out, old_, (T*)out1, old1, N, C, m);
-    else hipLaunchKernelGGL((affine_act_gn2_kernel<false, false, T>), grid, blk, 0, s, k[0], k[1], G, (double)N, eps, (T*)out, old_, (T*)out1, old1, N, C, m);
+    if (flags & N3D_ACCUMULATE) hipLaunchKernelGGL((affine_act_gn2_kernel<true, false, T>), grid, blk, 0, s, k[0], k[1], G, gn_cnt_, eps, (T*)out, old_, (T*)out1, old1, N, C, m);
+    else hipLaunchKernelGGL((affine_act_gn2_kernel<false, false, T>), grid, blk, 0, s, k[0], k[1], G, gn_cnt_, eps, (T*)out, old_, (T*)out1, old1, N, C, m);
   });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
@@ -2552,6 +2565,8 @@ int n3d_affine_act_bwd_reduce2(const float* dout, int64_t dld, const float* dout
 
 int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
                                  const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* stream) {
+  const double gn_cnt_ = gn_count(N, C, G);      // G < 0: ONE group of -G real channels inside C zero-padded ones (include/n3d.h)
+  G = gn_groups(G);
   N3D_CHECK_ARG(dout && t0 && t1 && B > 0 && N > 0, "affine_act_bwd_apply_gn2: bad args");
   if (!pair_shape_ok(C, G) || t0->rows < 1 || t1->rows < 1 || t0->rows > n3d_fused_max_rows() || t1->rows > n3d_fused_max_rows())
     N3D_UNSUPPORTED("affine_act_bwd_apply_gn2: shape not supported by the pair kernel (C=%d G=%d rows=%d/%d)", C, G, t0->rows, t1->rows);
@@ -2574,8 +2589,8 @@ int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const float* do
   with_act_type(bf, [&](auto* tag) {
     using T = N3D_T(tag);
     // (grid.x = rows + 1: the last workgroup column forms the parameter gradients)
-    if (dout1) hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, true, T>), dim3(m.rows + 1, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
-    else hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, false, T>), dim3(m.rows + 1, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], B, G, (double)N, N, C, m);
+    if (dout1) hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, true, T>), dim3(m.rows + 1, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], B, G, gn_cnt_, N, C, m);
+    else hipLaunchKernelGGL((affine_bwd_apply_gn2_kernel<false, false, T>), dim3(m.rows + 1, B), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dld, (const T*)dout1, dld1, k[0], k[1], B, G, gn_cnt_, N, C, m);
   });
   N3D_LAUNCH_CHECK();
   return N3D_OK;
@@ -2584,6 +2599,7 @@ int n3d_affine_act_bwd_apply_gn2(const float* dout, int64_t dld, const float* do
 // 1 if n3d_affine_act_bwd_small2 takes this shape: the group's quads fit one 1024-thread workgroup two deep, samples start on
 // wave boundaries
 int n3d_bwd_small2_ok(int B, int64_t N, int C, int G) {
+  if (G < 0) return 0;
   if (!pair_shape_ok(C, G) || B < 1 || B > 4 || N < 1 || N > 4096) return 0;
   const int cpg4 = (C / G) / 4;
   if (cpg4 < 1) return 0;
@@ -2594,6 +2610,7 @@ int n3d_bwd_small2_ok(int B, int64_t N, int C, int G) {
 
 // 0 = not taken; 1 = one workgroup per group (all samples: n3d_bwd_small2_ok); 2 = one workgroup per (group, sample)
 int n3d_bwd_small_mode(int B, int64_t N, int C, int G) {
+  if (G < 0) return 0;
   if (n3d_bwd_small2_ok(B, N, C, G)) return 1;
   if (!pair_shape_ok(C, G) || B < 2 || B > 4 || N < 1 || N > 4096) return 0;
   const int cpg4 = (C / G) / 4;
@@ -2649,6 +2666,7 @@ static int bwd_small_launch(const float* dout, int64_t dld, const float* dout1, 
 
 int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
                               const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* stream) {
+  if (G < 0) N3D_UNSUPPORTED("%s: padded-channel GroupNorm (G < 0) is not taken by the one-launch backward", "n3d_affine_act_bwd_small2");
   N3D_CHECK_ARG(t1, "affine_act_bwd_small2: two terms");
   if (!n3d_bwd_small2_ok(B, N, C, G)) N3D_UNSUPPORTED("affine_act_bwd_small2: shape not supported (B=%d N=%lld C=%d G=%d)", B, (long long)N, C, G);
   return bwd_small_launch(dout, dld, dout1, dld1, t0, t1, B, N, C, G, nullptr, 0, nullptr, stream, "affine_act_bwd_small2");
@@ -2657,10 +2675,13 @@ int n3d_affine_act_bwd_small2(const float* dout, int64_t dld, const float* dout1
 int n3d_affine_act_bwd_small(const float* dout, int64_t dld, const float* dout1, int64_t dld1, const n3d_gn_bwd_term* t0,
                              const n3d_gn_bwd_term* t1, int B, int64_t N, int C, int G, void* scratch, size_t scratch_bytes,
                              uint32_t* tickets, void* stream) {
+  if (G < 0) N3D_UNSUPPORTED("%s: padded-channel GroupNorm (G < 0) is not taken by the one-launch backward", "n3d_affine_act_bwd_small");
   return bwd_small_launch(dout, dld, dout1, dld1, t0, t1, B, N, C, G, scratch, scratch_bytes, tickets, stream, "affine_act_bwd_small");
 }
 
 int n3d_gn_coeffs2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int B, int C, int G, int64_t N, float eps, void* stream) {
+  const double gn_cnt_ = gn_count(N, C, G);      // G < 0: ONE group of -G real channels inside C zero-padded ones (include/n3d.h)
+  G = gn_groups(G);
   N3D_CHECK_ARG(t0 && t1 && C <= 64 && G >= 1 && C % G == 0, "gn_coeffs2: bad args");
   GnCoefArgs q[2];
   const n3d_gn_fwd_term* ts[2] = {t0, t1};
@@ -2669,7 +2690,7 @@ int n3d_gn_coeffs2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, int B, 
     N3D_CHECK_ARG(t->stats && t->gamma && t->beta && t->a_out && t->b_out && t->rows >= 1, "gn_coeffs2: null term pointer");
     q[i] = GnCoefArgs{t->stats, t->rows, t->gamma, t->beta, t->a_out, t->b_out, t->mean_rstd_out, t->sumraw};
   }
-  hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B, 2), dim3(256), 0, (hipStream_t)stream, q[0], q[1], C, G, (double)N, eps);
+  hipLaunchKernelGGL(gn_coeffs_kernel, dim3(B, 2), dim3(256), 0, (hipStream_t)stream, q[0], q[1], C, G, gn_cnt_, eps);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2701,6 +2722,8 @@ int n3d_affine_act2(const n3d_gn_fwd_term* t0, const n3d_gn_fwd_term* t1, float*
 }
 
 int n3d_gn_bwd_coeffs2(const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int B, int C, int G, int64_t N, void* stream) {
+  const double gn_cnt_ = gn_count(N, C, G);      // G < 0: ONE group of -G real channels inside C zero-padded ones (include/n3d.h)
+  G = gn_groups(G);
   N3D_CHECK_ARG(t0 && t1 && C <= 64 && G >= 1 && C % G == 0, "gn_bwd_coeffs2: bad args");
   GnBwdCoefArgs q[2];
   const n3d_gn_bwd_term* ts[2] = {t0, t1};
@@ -2711,8 +2734,8 @@ int n3d_gn_bwd_coeffs2(const n3d_gn_bwd_term* t0, const n3d_gn_bwd_term* t1, int
     q[i] = GnBwdCoefArgs{t->sums, t->rows, t->gamma, t->mean_rstd, t->wptr, t->dgamma, t->dbeta, t->dalpha, t->cA, t->cB, t->cC, t->sumraw,
                          t->dbias_conv};
   }
-  if (B <= 2) hipLaunchKernelGGL(gn_bwd_coeffs_kernel<2>, dim3(2), dim3(512), 0, (hipStream_t)stream, q[0], q[1], B, C, G, (double)N);
-  else hipLaunchKernelGGL(gn_bwd_coeffs_kernel<GNB_BP>, dim3(2), dim3(256 * GNB_BP), 0, (hipStream_t)stream, q[0], q[1], B, C, G, (double)N);
+  if (B <= 2) hipLaunchKernelGGL(gn_bwd_coeffs_kernel<2>, dim3(2), dim3(512), 0, (hipStream_t)stream, q[0], q[1], B, C, G, gn_cnt_);
+  else hipLaunchKernelGGL(gn_bwd_coeffs_kernel<GNB_BP>, dim3(2), dim3(256 * GNB_BP), 0, (hipStream_t)stream, q[0], q[1], B, C, G, gn_cnt_);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2751,6 +2774,8 @@ static int check_group(int n, int C, const char* who) {
 }
 
 int n3d_gn_coeffsN(const n3d_gn_fwd_term* terms, int n, int B, int C, int G, int64_t N, float eps, void* stream) {
+  const double gn_cnt_ = gn_count(N, C, G);      // G < 0: ONE group of -G real channels inside C zero-padded ones (include/n3d.h)
+  G = gn_groups(G);
   N3D_CHECK_ARG(terms && B > 0 && N > 0 && G >= 1 && C % G == 0, "gn_coeffsN: bad args");
   if (int e = check_group(n, C, "gn_coeffsN")) return e;
   GnCoefArgsN qs;
@@ -2759,7 +2784,7 @@ int n3d_gn_coeffsN(const n3d_gn_fwd_term* terms, int n, int B, int C, int G, int
     N3D_CHECK_ARG(t->stats && t->gamma && t->beta && t->a_out && t->b_out && t->rows >= 1, "gn_coeffsN: null term pointer");
     qs.q[i] = GnCoefArgs{t->stats, t->rows, t->gamma, t->beta, t->a_out, t->b_out, t->mean_rstd_out, t->sumraw};
   }
-  hipLaunchKernelGGL(gn_coeffsN_kernel, dim3(B, n), dim3(256), 0, (hipStream_t)stream, qs, C, G, (double)N, eps);
+  hipLaunchKernelGGL(gn_coeffsN_kernel, dim3(B, n), dim3(256), 0, (hipStream_t)stream, qs, C, G, gn_cnt_, eps);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2803,6 +2828,8 @@ int n3d_affine_act_bwd_reduceN(const float* dout, int64_t dld, const n3d_gn_bwd_
 }
 
 int n3d_gn_bwd_coeffsN(const n3d_gn_bwd_term* terms, int n, int B, int C, int G, int64_t N, void* stream) {
+  const double gn_cnt_ = gn_count(N, C, G);      // G < 0: ONE group of -G real channels inside C zero-padded ones (include/n3d.h)
+  G = gn_groups(G);
   N3D_CHECK_ARG(terms && B > 0 && N > 0 && G >= 1 && C % G == 0, "gn_bwd_coeffsN: bad args");
   if (int e = check_group(n, C, "gn_bwd_coeffsN")) return e;
   GnBwdCoefArgsN qs;
@@ -2813,8 +2840,8 @@ int n3d_gn_bwd_coeffsN(const n3d_gn_bwd_term* terms, int n, int B, int C, int G,
     qs.q[i] = GnBwdCoefArgs{t->sums, t->rows, t->gamma, t->mean_rstd, t->wptr, t->dgamma, t->dbeta, t->dalpha, t->cA, t->cB, t->cC, t->sumraw,
                             t->dbias_conv};
   }
-  if (B <= 2) hipLaunchKernelGGL(gn_bwd_coeffsN_kernel<2>, dim3(n), dim3(512), 0, (hipStream_t)stream, qs, B, C, G, (double)N);
-  else hipLaunchKernelGGL(gn_bwd_coeffsN_kernel<GNB_BP>, dim3(n), dim3(256 * GNB_BP), 0, (hipStream_t)stream, qs, B, C, G, (double)N);
+  if (B <= 2) hipLaunchKernelGGL(gn_bwd_coeffsN_kernel<2>, dim3(n), dim3(512), 0, (hipStream_t)stream, qs, B, C, G, gn_cnt_);
+  else hipLaunchKernelGGL(gn_bwd_coeffsN_kernel<GNB_BP>, dim3(n), dim3(256 * GNB_BP), 0, (hipStream_t)stream, qs, B, C, G, gn_cnt_);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
@@ -2974,6 +3001,7 @@ int n3d_se_gate_bwdN(const n3d_se_term* terms, int n, int64_t N, int B, int C, v
 }
 
 int n3d_node_fwd_coeffs(const n3d_gn_fwd_term* gn, int n_gn, const n3d_se_term* se, int n_se, int B, int C, int G, int64_t N, float eps, void* stream) {
+  if (G < 0) N3D_UNSUPPORTED("%s: padded-channel GroupNorm (G < 0) is not taken by the node-level launches (their SE gates share the count)", "n3d_node_fwd_coeffs");
   N3D_CHECK_ARG(gn && se && n_gn >= 1 && n_gn <= N3D_MAX_GROUP_TERMS && n_se >= 1 && n_se <= N3D_MAX_GROUP_TERMS && B > 0 && N > 0 && G >= 1 &&
                 C % G == 0 && C <= 64, "node_fwd_coeffs: 1..8 GroupNorm terms and 1..8 SE gates");
   if (int e = check_group(n_gn, C, "node_fwd_coeffs")) return e;
@@ -2993,6 +3021,7 @@ int n3d_node_fwd_coeffs(const n3d_gn_fwd_term* gn, int n_gn, const n3d_se_term* 
 }
 
 int n3d_node_bwd_coeffs(const n3d_gn_bwd_term* gn, int n_gn, const n3d_se_term* se, int n_se, int B, int C, int G, int64_t N, void* stream) {
+  if (G < 0) N3D_UNSUPPORTED("%s: padded-channel GroupNorm (G < 0) is not taken by the node-level launches (their SE gates share the count)", "n3d_node_bwd_coeffs");
   N3D_CHECK_ARG(n_gn >= 0 && n_gn <= N3D_MAX_REDUCE_TERMS && n_se >= 0 && n_se <= N3D_MAX_GROUP_TERMS && n_gn + n_se >= 1 && (n_gn == 0 || gn) &&
                 (n_se == 0 || se), "node_bwd_coeffs: 0..16 GroupNorm terms, 0..8 SE gates");
   if (B == 2 && n_gn >= 1 && n_se >= 1) {
@@ -3158,6 +3187,8 @@ int n3d_fused_max_rows(void) {
 int n3d_affine_act_gn(const float* raw, int64_t rld, const double* stats, int rows, const float* gamma, const float* beta, int G, float eps,
                       const float* wptr, float* out, int64_t old_, int B, int64_t N, int C, int flags, float* a_out, float* b_out,
                       float* mean_rstd_out, double* sumraw, void* stream) {
+  const double gn_cnt_ = gn_count(N, C, G);      // G < 0: ONE group of -G real channels inside C zero-padded ones (include/n3d.h)
+  G = gn_groups(G);
   N3D_CHECK_ARG(raw && out && stats && gamma && beta && a_out && b_out && mean_rstd_out && C <= 64 && C % G == 0 && rows >= 1 && rows <= n3d_fused_max_rows(),
                 "affine_act_gn: bad args");
   const bool bf = flags & N3D_ACT_BF16;
@@ -3169,7 +3200,7 @@ int n3d_affine_act_gn(const float* raw, int64_t rld, const double* stats, int ro
   const bool relu = flags & N3D_RELU, acc = flags & N3D_ACCUMULATE;
   with_act_type(bf, [&](auto* tag) {
     using T = N3D_T(tag);
-#define N3D_AAG(R, A_) hipLaunchKernelGGL((affine_act_gn_kernel<R, A_, T>), grid, blk, 0, s, (const T*)raw, rld, stats, rows, gamma, beta, G, (double)N, eps, wptr, (T*)out, old_, N, C, m, a_out, b_out, mean_rstd_out, sumraw)
+#define N3D_AAG(R, A_) hipLaunchKernelGGL((affine_act_gn_kernel<R, A_, T>), grid, blk, 0, s, (const T*)raw, rld, stats, rows, gamma, beta, G, gn_cnt_, eps, wptr, (T*)out, old_, N, C, m, a_out, b_out, mean_rstd_out, sumraw)
     if (relu && acc) N3D_AAG(true, true); else if (relu) N3D_AAG(true, false); else if (acc) N3D_AAG(false, true); else N3D_AAG(false, false);
 #undef N3D_AAG
   });
@@ -3181,6 +3212,8 @@ int n3d_affine_act_bwd_apply_gn(const float* dout, int64_t dld, const float* raw
                                 const double* sums, int rows, const float* gamma, const float* mean_rstd, const float* wptr,
                                 const double* sumraw, float* draw, int64_t drld, int B, int64_t N, int C, int G, int flags,
                                 float* dgamma, float* dbeta, float* dalpha, float* dbias_conv, void* stream) {
+  const double gn_cnt_ = gn_count(N, C, G);      // G < 0: ONE group of -G real channels inside C zero-padded ones (include/n3d.h)
+  G = gn_groups(G);
   N3D_CHECK_ARG(dout && raw && draw && sums && gamma && mean_rstd && C <= 64 && C % G == 0 && rows >= 1 && rows <= n3d_fused_max_rows() && B <= GNF_MAXB,
                 "affine_act_bwd_apply_gn: bad args (needs rows <= 64, B <= 4)");
   N3D_CHECK_ARG(!dbias_conv || sumraw, "affine_act_bwd_apply_gn: dbias_conv needs the forward per-channel sums");
@@ -3196,7 +3229,7 @@ int n3d_affine_act_bwd_apply_gn(const float* dout, int64_t dld, const float* raw
   const bool relu = flags & N3D_RELU, acc = flags & N3D_ACCUMULATE;
   with_act_type(bf, [&](auto* tag) {
     using T = N3D_T(tag);
-#define N3D_ABG(R, A_) hipLaunchKernelGGL((affine_bwd_apply_gn_kernel<R, A_, T>), grid, blk, 0, s, (const T*)dout, dld, (const T*)raw, rld, a, b, sums, rows, gamma, mean_rstd, wptr, sumraw, B, G, (double)N, (T*)draw, drld, N, C, m, dgamma, dbeta, dalpha, dbias_conv)
+#define N3D_ABG(R, A_) hipLaunchKernelGGL((affine_bwd_apply_gn_kernel<R, A_, T>), grid, blk, 0, s, (const T*)dout, dld, (const T*)raw, rld, a, b, sums, rows, gamma, mean_rstd, wptr, sumraw, B, G, gn_cnt_, (T*)draw, drld, N, C, m, dgamma, dbeta, dalpha, dbias_conv)
     if (relu && acc) N3D_ABG(true, true); else if (relu) N3D_ABG(true, false); else if (acc) N3D_ABG(false, true); else N3D_ABG(false, false);
 #undef N3D_ABG
   });

@@ -742,11 +742,17 @@ def _channel_stats(x: View):
     return st, rows
 
 
+def _ng(G):
+    """number of GroupNorm groups of a group-count argument: G < 0 is ONE group of -G real channels inside zero-padded ones (include/n3d.h,
+    "padded channels"; the C layer takes the negative value as it is)"""
+    return 1 if G < 0 else G
+
+
 def gn_coeffs(stats, rows, gamma, beta, B, Cc, G, N, eps=1e-5):
     dev = stats.device
     a = torch.empty((B, Cc), dtype=torch.float32, device=dev)
     b = torch.empty((B, Cc), dtype=torch.float32, device=dev)
-    mr = torch.empty((B, G, 2), dtype=torch.float32, device=dev)
+    mr = torch.empty((B, _ng(G), 2), dtype=torch.float32, device=dev)
     sr = torch.empty((B, Cc), dtype=torch.float64, device=dev)
     check(_lib.load().n3d_gn_coeffs(ptr(stats), rows, ptr(gamma), ptr(beta), B, Cc, G, N, eps, ptr(a), ptr(b), ptr(mr),
                                     ptr(sr), stream_ptr()), "n3d_gn_coeffs")
@@ -777,7 +783,7 @@ def affine_act_gn(raw: View, stats, rows, gamma, beta, G, eps, wptr, out: View, 
     dev = raw.t.device
     a = torch.empty((raw.B, raw.C), dtype=torch.float32, device=dev)
     b = torch.empty((raw.B, raw.C), dtype=torch.float32, device=dev)
-    mr = torch.empty((raw.B, G, 2), dtype=torch.float32, device=dev)
+    mr = torch.empty((raw.B, _ng(G), 2), dtype=torch.float32, device=dev)
     sr = torch.empty((raw.B, raw.C), dtype=torch.float64, device=dev)
     check(_lib.load().n3d_affine_act_gn(raw.p, raw.ld, ptr(stats), rows, ptr(gamma), ptr(beta), G, eps, wptr, out.p, out.ld,
                                         raw.B, raw.N, raw.C, flags, ptr(a), ptr(b), ptr(mr), ptr(sr), stream_ptr()),
@@ -810,6 +816,7 @@ def _vp(t):
 
 def pair_ok(Cc, G, rows0, rows1, B):
     """shapes the FUSED node-level pair kernels accept (include/n3d.h, n3d_affine_act_gn2)"""
+    G = _ng(G)
     return (4 <= Cc <= 64 and (Cc & (Cc - 1)) == 0 and Cc % G == 0 and Cc // G <= 16 and 1 <= rows0 <= fused_max_rows()
             and 1 <= rows1 <= fused_max_rows() and B <= 4)
 
@@ -828,13 +835,13 @@ def affine_act_gn2(terms, G, eps, out: View, flags=0, out1: View | None = None):
     dev = raw0.t.device
     B, Cc = raw0.B, raw0.C
     # one allocation for both terms' saved coefficients
-    fbuf = torch.empty((2, 2 * B * Cc + 2 * B * G), dtype=torch.float32, device=dev)
+    fbuf = torch.empty((2, 2 * B * Cc + 2 * B * _ng(G)), dtype=torch.float32, device=dev)
     dbuf = torch.empty((2, B * Cc), dtype=torch.float64, device=dev)
     ts, saved = [], []
     for i, (raw, stats, rows, gamma, beta, wptr, relu) in enumerate(terms):
         a = fbuf[i, :B * Cc].view(B, Cc)
         b = fbuf[i, B * Cc:2 * B * Cc].view(B, Cc)
-        mr = fbuf[i, 2 * B * Cc:].view(B, G, 2)
+        mr = fbuf[i, 2 * B * Cc:].view(B, _ng(G), 2)
         sr = dbuf[i].view(B, Cc)
         ts.append(GnFwdTerm(raw.p.value, raw.ld, stats.data_ptr(), rows, 1 if relu else 0, gamma.data_ptr(), beta.data_ptr(),
                             _vp(wptr), a.data_ptr(), b.data_ptr(), mr.data_ptr(), sr.data_ptr(), raw.dt, 0))
@@ -972,14 +979,14 @@ def gn_coeffsN(terms, G, eps):
     _need_f32("gn_coeffsN / affine_actN", *[t[0] for t in terms])
     dev = raw0.t.device
     B, Cc = raw0.B, raw0.C
-    fbuf = torch.empty((n, 2 * B * Cc + 2 * B * G), dtype=torch.float32, device=dev)
+    fbuf = torch.empty((n, 2 * B * Cc + 2 * B * _ng(G)), dtype=torch.float32, device=dev)
     dbuf = torch.empty((n, B * Cc), dtype=torch.float64, device=dev)
     arr = (GnFwdTerm * n)()
     saved = []
     for i, (raw, stats, rows, gamma, beta) in enumerate(terms):
         a = fbuf[i, :B * Cc].view(B, Cc)
         b = fbuf[i, B * Cc:2 * B * Cc].view(B, Cc)
-        mr = fbuf[i, 2 * B * Cc:].view(B, G, 2)
+        mr = fbuf[i, 2 * B * Cc:].view(B, _ng(G), 2)
         sr = dbuf[i].view(B, Cc)
         arr[i] = GnFwdTerm(raw.p.value, raw.ld, stats.data_ptr(), rows, 0, gamma.data_ptr(), beta.data_ptr(), None, a.data_ptr(),
                            b.data_ptr(), mr.data_ptr(), sr.data_ptr())
@@ -997,14 +1004,14 @@ def node_fwd_coeffs(gn_terms, G, eps, se_terms):
     _need_f32("node_fwd_coeffs", *[t[0] for t in gn_terms])
     dev = raw0.t.device
     B, Cc = raw0.B, raw0.C
-    fbuf = torch.empty((n, 2 * B * Cc + 2 * B * G), dtype=torch.float32, device=dev)
+    fbuf = torch.empty((n, 2 * B * Cc + 2 * B * _ng(G)), dtype=torch.float32, device=dev)
     dbuf = torch.empty((n, B * Cc), dtype=torch.float64, device=dev)
     arr = (GnFwdTerm * n)()
     saved = []
     for i, (raw, stats, rows, gamma, beta) in enumerate(gn_terms):
         a = fbuf[i, :B * Cc].view(B, Cc)
         b = fbuf[i, B * Cc:2 * B * Cc].view(B, Cc)
-        mr = fbuf[i, 2 * B * Cc:].view(B, G, 2)
+        mr = fbuf[i, 2 * B * Cc:].view(B, _ng(G), 2)
         sr = dbuf[i].view(B, Cc)
         arr[i] = GnFwdTerm(raw.p.value, raw.ld, stats.data_ptr(), rows, 0, gamma.data_ptr(), beta.data_ptr(), None, a.data_ptr(),
                            b.data_ptr(), mr.data_ptr(), sr.data_ptr())

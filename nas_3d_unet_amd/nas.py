@@ -22,12 +22,22 @@ class KernelNet(nn.Module):
         self.down_cells = nn.ModuleList(cells[:depth])
         self.up_cells = nn.ModuleList(cells[depth:])
         self.last_conv = head
+        # channel counts that are not multiples of 4 (the reference takes any init_n_kernels): the net runs as its zero-padded twin
+        self._n3d_padded = unet.needs_padding(init_n_kernels, depth, n_nodes, channel_change)
+        self._n3d_ctor = (in_channels, init_n_kernels, out_channels, depth, n_nodes, channel_change, None)
+
+    def _n3d_make_twin(self):
+        return unet.PaddedTwin(self, "supernet", *self._n3d_ctor, head_dropout=0.1)
 
     def forward(self, x, alpha1_down, alpha1_up, alpha2_down, alpha2_up):
         # the down cells share (alpha1_down, alpha2_down), the up cells (alpha1_up, alpha2_up)
+        if self._n3d_padded:
+            return unet.run_padded(self, x, (alpha1_down, alpha1_up, alpha2_down, alpha2_up))
         return unet.run(self, x, (alpha1_down, alpha1_up, alpha2_down, alpha2_up))
 
     def forward_loss(self, x, t, alpha1_down, alpha1_up, alpha2_down, alpha2_up, smooth=1e-6):
+        if self._n3d_padded:
+            return unet.run_padded(self, x, (alpha1_down, alpha1_up, alpha2_down, alpha2_up), t, smooth)
         return unet.run_loss(self, x, t, (alpha1_down, alpha1_up, alpha2_down, alpha2_up), smooth)
 
 

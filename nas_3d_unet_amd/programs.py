@@ -29,6 +29,21 @@ def group_count(c):
     return 1 if c % 16 != 0 else c // 16
 
 
+def gn_groups(norm, C):
+    """group-count argument of the GroupNorm kernels for a tensor of C channels behind `norm`.  A norm of a zero-padded twin net
+    (unet.PaddedTwin: channel counts that are not multiples of 4) carries the REAL channel count: -real = one group of `real` channels
+    inside the C stored ones (include/n3d.h, "padded channels"; real counts that need padding are never multiples of 16: one group)"""
+    real = getattr(norm, "_n3d_real_c", None)
+    if real is not None and real != C:
+        return -int(real)
+    return group_count(C)
+
+
+# conv-bias gradients of a conv that feeds a GroupNorm come analytically out of the GroupNorm backward sums (N * Bc + ...); the padded
+# twin switches that off (its GroupNorm kernels run with a scaled element count, the bias gradient needs the true one)
+ANALYTIC_CONV_BIAS = True
+
+
 class Saved:
     """bag of tensors / scalars kept between forward and backward of one segment"""
     pass
@@ -564,7 +579,7 @@ def _seg_forward_recompute(seg, x, out=None):
     rows = K.conv_stats_rows(g, False, _lib_flags_src(x))
     stats = torch.empty((x.B, rows, Co, 2), dtype=torch.float64, device=x.t.device)
     K.conv_k1_norm_fwd(g, x, w.m.weight, w.m.bias, None, None, None, stats)
-    G = group_count(Co)
+    G = gn_groups(seg.norm, Co)
     s = Saved()
     s.kind, s.G, s.raw, s.ws = "gn_rc", G, None, None
     s.x, s.g = x, g
@@ -616,7 +631,7 @@ def _seg_epilogue_forward(seg, raw, stats, rows, ws, out, accumulate, alpha_row,
         if stats is None:
             stats, rows = K.channel_stats(raw)
         cn = raw.C
-        G = group_count(cn)
+        G = gn_groups(seg.norm, cn)
         s.kind, s.G = "gn", G
         if rows <= K.fused_max_rows():
             # small tensor: coefficients are computed in the epilogue kernel's prologue (one launch less)
@@ -691,7 +706,7 @@ def pair_epilogue_phase(segA, resA, segB, resB, out, outB=None, accumulate=False
     launching stream."""
     res = [resA, resB]
     (rawA, stA, rowsA, wsA), (rawB, stB, rowsB, wsB) = res
-    G = group_count(rawA.C)
+    G = gn_groups(segA.norm, rawA.C)
     if (_pairable_fwd(segA) and _pairable_fwd(segB) and rawA.C == rawB.C and rawA.N == rawB.N
             and segA.norm.eps == segB.norm.eps and K.pair_shape_ok(rawA.C)):
         wpA = _wptr(*alphaA) if alphaA is not None else None
@@ -754,7 +769,7 @@ def pair_backward_epilogue(segA, sA, segB, sB, dout, argsA, argsB):
 
 def _gn_bwd_term(seg, s, alpha):
     """descriptor of one GroupNorm-type term for K.affine_act_bwd_gn2 / affine_act_bwd_gnN; alpha = (row, column, dalpha row | None)"""
-    cbias = seg.weight.norm_fed_bias()
+    cbias = seg.weight.norm_fed_bias() if ANALYTIC_CONV_BIAS else None
     if cbias is not None and not cbias.requires_grad:
         cbias = None
     raw = s.raw
@@ -994,7 +1009,7 @@ def group_epilogue_phase(terms, res, out, accumulate):
         if seg.norm is not None:
             if r[1] is None:
                 r[1], r[2] = K.channel_stats(r[0])
-            s.kind, s.G = "gn", group_count(r[0].C)
+            s.kind, s.G = "gn", gn_groups(seg.norm, r[0].C)
             gn.append((s, (r[0], r[1], r[2], seg.norm.weight, seg.norm.bias)))
         elif seg.se_gate is not None:
             s.kind = "se"
@@ -1092,7 +1107,7 @@ def seg_backward(seg, s, dout, need_dx=True, dx_out=None, dx_acc=False, alpha_ro
     fl = RELU if seg.relu_out else 0
     extra = []
     if s.kind == "gn":
-        cbias = seg.weight.norm_fed_bias()
+        cbias = seg.weight.norm_fed_bias() if ANALYTIC_CONV_BIAS else None
         if cbias is not None and not cbias.requires_grad:
             cbias = None
         ident = isinstance(seg.weight, IdentityW)

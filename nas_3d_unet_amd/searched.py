@@ -40,10 +40,20 @@ class SearchedNet(nn.Module):
         self.down_cells = nn.ModuleList(cells[:depth])
         self.up_cells = nn.ModuleList(cells[depth:])
         self.last_conv = head                                        # head dropout 0.5 here, 0.1 in the supernet
+        # channel counts that are not multiples of 4 (the reference takes any init_n_kernels): the net runs as its zero-padded twin
+        self._n3d_padded = unet.needs_padding(init_n_kernels, depth, n_nodes, channel_change)
+        self._n3d_ctor = (in_channels, init_n_kernels, out_channels, depth, n_nodes, channel_change, gene)
+
+    def _n3d_make_twin(self):
+        return unet.PaddedTwin(self, "searched", *self._n3d_ctor, head_dropout=0.5)
 
     def forward(self, x):
+        if self._n3d_padded:
+            return unet.run_padded(self, x)
         return unet.run(self, x)
 
     def forward_loss(self, x, t, smooth=1e-6):
         """(Dice loss of loss.py:12-14, probabilities) with the loss formed inside the head's launches (train.py:121-124)"""
+        if self._n3d_padded:
+            return unet.run_padded(self, x, None, t, smooth)
         return unet.run_loss(self, x, t, None, smooth)

@@ -848,6 +848,16 @@ def _time_schedule(run, device, warm=2, reps=6):
     return (time.perf_counter() - t0) / reps
 
 
+def _refuse_padded(model):
+    """a net whose channel counts are not multiples of 4 runs as a zero-padded twin behind the module API (unet.PaddedTwin); the
+    flat-buffer trainers own the parameters' storage and the backward walk of the net they are given, which such a net does not have"""
+    for m in (model, getattr(model, "kernel", None)):
+        if m is not None and getattr(m, "_n3d_padded", False):
+            raise K.N3DError("this net has feature-map channel counts that are not multiples of 4: it runs as a zero-padded twin behind the module "
+                             "API (forward / forward_loss under autograd, any torch optimizer); nas_3d_unet_amd.train.Trainer / SearchTrainer "
+                             "take nets whose channel counts are multiples of 4 (init_n_kernels = 4, 8, ...)")
+
+
 class Trainer:
     """One searched-net (or any model built from nas_3d_unet_amd ops) training step.
 
@@ -858,6 +868,7 @@ class Trainer:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph=True, process_group=None,
                  n_buckets=None, params=None, comm=None, storage=None, side_wgrad=None):
         self.model = model
+        _refuse_padded(model)
         # side_wgrad (default: N3D_SIDE_WGRAD, on): the weight-gradient kernels of the C in {4, 8} levels -- nothing on the
         # backward chain waits for them -- are queued during the backward walk and launched on a SIDE HIP stream at a few cut
         # points (cell boundaries), as separately launched graphs tied to the main chain by events; the streams join once,
@@ -1363,6 +1374,7 @@ class SearchTrainer:
 
     def __init__(self, shell, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph=True, process_group=None, comm=None, side_wgrad=None):
         self.model = shell
+        _refuse_padded(shell)
         # the weight pass queues its weight-gradient kernels for the side stream (SideSchedule); the architecture pass has none
         env = os.environ.get("N3D_SIDE_WGRAD", "1")
         self.side_wgrad = (env != "0") if side_wgrad is None else bool(side_wgrad)

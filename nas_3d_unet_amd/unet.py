@@ -27,13 +27,188 @@ def cell_specs(init_n_kernels, depth, n_nodes, channel_change):
         prev1 = n_nodes * node_c
         if channel_change:
             node_c //= 2
-    widths = sorted({wide} | {spec[2] for spec in specs})
-    if any(c % 4 for c in widths):
-        # the kernels move channels four at a time (16-byte NDHWC vectors); only a conv INPUT may have another count
-        raise NotImplementedError("nas_3d_unet_amd: every feature-map channel count must be a multiple of 4; init_n_kernels=%d, n_nodes=%d, "
-                                  "depth=%d give stems of %d and cell nodes of %s channels (config.yml's 4 / 3 / 4: 12 and 4..64)"
-                                  % (init_n_kernels, n_nodes, depth, wide, sorted({spec[2] for spec in specs})))
     return specs, prev1
+
+
+def needs_padding(init_n_kernels, depth, n_nodes, channel_change):
+    """does any feature map of this net have a channel count that is not a multiple of 4?  The kernels move channels four at a time
+    (16-byte NDHWC vectors); such a net runs as its zero-padded twin (PaddedTwin)."""
+    specs, _ = cell_specs(init_n_kernels, depth, n_nodes, channel_change)
+    return any(c % 4 for c in {n_nodes * init_n_kernels} | {spec[2] for spec in specs})
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+class PaddedTwin:
+    """A net whose feature-map channel counts are not multiples of 4 (the reference takes any init_n_kernels: nas.py:13-26,
+    searched.py:55-66) runs as a TWIN built by the same constructors with every feature map zero-padded to the next multiple of 4:
+    stems n c -> pad4(n c), node width c -> pad4(c), a cell output n c -> n pad4(c) (node by node).  The padded channels carry zero conv
+    weights, zero GroupNorm gamma / beta and zero SE weights, so they hold exactly 0 in every forward tensor and receive exactly 0 in every
+    gradient; the real channels see the reference's arithmetic -- with ONE correction: a GroupNorm group's element count is that of the
+    REAL channels (programs.gn_groups -> a negative group count at the C ABI, include/n3d.h "padded channels").  The user-visible module
+    keeps the reference's parameter shapes (state-dict parity); before every forward they are embedded into the twin's parameters and
+    after the backward the twin's gradients are cut back (index plumbing in torch, arithmetic in libn3d).  Module API only (forward /
+    forward_loss under autograd); the flat-buffer trainers refuse such a net."""
+
+    def __init__(self, real, kind, in_channels, init_n_kernels, out_channels, depth, n_nodes, channel_change, gene=None, head_dropout=0.0):
+        import torch
+        from .cell import Cell
+        from .searched import SearchedCell
+        self.n_nodes = n_nodes
+        specs, head_in = cell_specs(init_n_kernels, depth, n_nodes, channel_change)
+        wide = n_nodes * init_n_kernels
+        # which inputs are cell outputs (node-wise padding) and which are stem outputs (padded at the end): unet.route's wiring
+        kinds, older, newer, kept = [], "stem", "stem", ["stem", "stem"]
+        for _ in range(depth):
+            kinds.append((older, newer))
+            older, newer = newer, "cell"
+            kept.append("cell")
+        kept.pop()
+        for _ in range(depth + 1):
+            kinds.append((kept.pop(), newer))
+            newer = "cell"
+        self.kinds = kinds
+        padded_in = lambda c, kind_: _pad4(c) if kind_ == "stem" else n_nodes * _pad4(c // n_nodes)
+        twin = nn.Module()
+        twin.stem0 = ConvOps(in_channels, _pad4(wide), kernel_size=1, ops_order="weight_norm")
+        twin.stem1 = ConvOps(in_channels, _pad4(wide), kernel_size=3, stride=2, ops_order="weight_norm")
+        cells = []
+        for (c0, c1, width, down), (k0, k1) in zip(specs, kinds):
+            a, b, w = padded_in(c0, k0), padded_in(c1, k1), _pad4(width)
+            cells.append(SearchedCell(n_nodes, a, b, w, gene, downward=down) if kind == "searched" else Cell(n_nodes, a, b, w, downward=down))
+        twin.down_cells = nn.ModuleList(cells[:depth])
+        twin.up_cells = nn.ModuleList(cells[depth:])
+        twin.last_conv = nn.Sequential(ConvOps(n_nodes * _pad4(head_in // n_nodes), out_channels, kernel_size=1, dropout_rate=head_dropout,
+                                               ops_order="weight"), nn.Sigmoid())
+        dev = next(real.parameters()).device
+        self.twin = twin.to(dev)
+        for p in self.twin.parameters():
+            p.requires_grad_(True)
+        # GroupNorms remember the real channel count of their tensor
+        rmods = dict(real.named_modules())
+        for name, m in self.twin.named_modules():
+            if isinstance(m, nn.GroupNorm):
+                m._n3d_real_c = int(rmods[name].num_channels)
+        # per parameter and dimension: positions of the real entries inside the twin's (None = same size)
+        self.names = [n for n, _ in real.named_parameters() if not n.startswith("alpha")]
+        tp = dict(self.twin.named_parameters())
+        assert sorted(tp) == sorted(self.names), "padded twin: parameter names differ from the net's"
+        self.maps = {}
+        rp = dict(real.named_parameters())
+        for n in self.names:
+            r, t = rp[n], tp[n]
+            idx = []
+            for d, (rs, ts) in enumerate(zip(r.shape, t.shape)):
+                if rs == ts:
+                    idx.append(None)
+                    continue
+                block = False
+                if d == 1 and n.endswith("conv.weight"):
+                    # the input side of a conv that reads a CELL output: node-wise padding
+                    if n.startswith("last_conv."):
+                        block = True
+                    elif ".preprocess" in n:
+                        ci = int(n.split(".")[1]) + (0 if n.startswith("down_cells.") else depth)
+                        block = kinds[ci][0 if ".preprocess0." in n else 1] == "cell"
+                if block:
+                    c = rs // n_nodes
+                    assert rs == n_nodes * c and ts == n_nodes * _pad4(c), (n, rs, ts)
+                    pos = torch.cat([k * _pad4(c) + torch.arange(c) for k in range(n_nodes)])
+                else:
+                    assert ts == _pad4(rs), (n, d, rs, ts)
+                    pos = torch.arange(rs)
+                idx.append(pos.to(dev))
+            self.maps[n] = idx
+
+    def embed(self, real):
+        """real parameters -> the twin's (zeros elsewhere); module state that is not a parameter follows too"""
+        import torch
+        tp = dict(self.twin.named_parameters())
+        with torch.no_grad():
+            for n, r in real.named_parameters():
+                if n not in self.maps:
+                    continue
+                cur = r.detach()
+                for d, pos in enumerate(self.maps[n]):
+                    if pos is None:
+                        continue
+                    shape = list(cur.shape)
+                    shape[d] = tp[n].shape[d]
+                    new = torch.zeros(shape, dtype=cur.dtype, device=cur.device)
+                    new.index_copy_(d, pos, cur)
+                    cur = new
+                tp[n].copy_(cur)
+        self.twin.train(real.training)
+        rmods = dict(real.named_modules())
+        for name, m in self.twin.named_modules():
+            rm = rmods.get(name)
+            if rm is not None and hasattr(rm, "dropout") and hasattr(m, "dropout") and (rm.dropout is None) != (m.dropout is None):
+                m.dropout = None if rm.dropout is None else nn.Dropout3d(rm.dropout.p)
+
+    def extract(self, name, g):
+        """a gradient of the twin's parameter `name` -> the real parameter's shape"""
+        for d, pos in enumerate(self.maps[name]):
+            if pos is not None:
+                g = g.index_select(d, pos)
+        return g
+
+
+def run_padded(net, x, alphas=None, loss_target=None, smooth=1e-6):
+    """forward (probabilities, or (Dice loss, probabilities) with loss_target) of a net with odd channel counts through its padded twin"""
+    import torch
+    from . import programs as P
+    tw = net.__dict__.get("_n3d_twin")
+    if tw is None or next(net.parameters()).device != next(tw.twin.parameters()).device:
+        tw = net.__dict__["_n3d_twin"] = net._n3d_make_twin()      # (kept out of the module tree: the state dict stays the reference's)
+    names = tw.names
+    rp = dict(net.named_parameters())
+    reals = [rp[n] for n in names]
+    n_al = 0 if alphas is None else len(alphas)
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, xin, *rest):
+            al, _ = rest[:n_al], rest[n_al:]
+            tw.embed(net)
+            prev = (P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER)
+            P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER = False, False, False, False, False
+            try:
+                with torch.enable_grad():
+                    xi = xin.detach().requires_grad_(xin.requires_grad)
+                    ali = tuple(a.detach().requires_grad_(a.requires_grad) for a in al)
+                    if loss_target is None:
+                        out = (run(tw.twin, xi, ali if n_al else None),)
+                    else:
+                        out = run_loss(tw.twin, xi, loss_target, ali if n_al else None, smooth)
+            finally:
+                P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER = prev
+            ctx.saved = (xi, ali, out)
+            return tuple(o.detach() for o in out)
+
+        @staticmethod
+        def backward(ctx, *douts):
+            xi, ali, out = ctx.saved
+            tp = dict(tw.twin.named_parameters())
+            wanted = [xi] if xi.requires_grad else []
+            wanted += [a for a in ali if a.requires_grad]
+            wanted += [tp[n] for n in names]
+            outs = [o for o, d in zip(out, douts) if d is not None and o.requires_grad]
+            gouts = [d for o, d in zip(out, douts) if d is not None and o.requires_grad]
+            prev = (P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER)
+            P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER = False, False, False, False, False
+            try:
+                gs = list(torch.autograd.grad(outs, wanted, gouts, allow_unused=True))
+            finally:
+                P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER = prev
+            gx = gs.pop(0) if xi.requires_grad else None
+            gal = [gs.pop(0) if a.requires_grad else None for a in ali]
+            gpar = [tw.extract(n, g) if g is not None else None for n, g in zip(names, gs)]
+            return (gx, *gal, *gpar)
+
+    res = Fn.apply(x, *(alphas if alphas is not None else ()), *reals)
+    return res[0] if loss_target is None else res
 
 
 def build_stems_and_head(net, in_channels, init_n_kernels, out_channels, n_nodes, head_in, head_dropout):

@@ -227,9 +227,48 @@ def test_channel_plan_matches_oracle_and_rejects_unsupported_widths():
             assert tuple(names[pre + "preprocess0.conv.weight"])[:2] == (cn, c0), (k, specs[k])
             assert tuple(names[pre + "preprocess1.conv.weight"])[:2] == (cn, c1), (k, specs[k])
         assert tuple(names["kernel.last_conv.0.conv.weight"])[:2] == (cfg.out_channels, head_in)
-    for bad in ((2, 3, 3, True), (5, 3, 3, True), (6, 2, 3, False)):
-        with pytest.raises(NotImplementedError, match="multiple of 4"):
-            unet.cell_specs(*bad)
+
+
+def test_channel_counts_that_are_not_multiples_of_4_build_a_zero_padded_twin():
+    """round 5: the reference takes any init_n_kernels (nas.py:13-26, searched.py:55-66).  Such a net keeps the reference's parameter
+    names and shapes (checked against the oracle's inventory), and runs as a twin whose feature maps are zero-padded to multiples of 4:
+    embedding the parameters and cutting them back is the identity, everything outside the real positions is zero, cell-output inputs
+    are padded node by node and stem inputs at the end (host logic only: no kernel runs on the CPU)"""
+    import torch
+    from nas_3d_unet_amd import nas, searched, unet
+    from oracle import ref_path as orc
+    for init, nodes, depth, cc in ((2, 3, 3, True), (6, 3, 2, True), (5, 2, 2, False), (3, 3, 2, True)):
+        assert unet.needs_padding(init, depth, nodes, cc)
+        cfg = orc.NetCfg(4, init, 3, depth, nodes, cc)
+        gene = orc.Genotype([("down_conv", 0), ("down_dep_conv", 1), ("down_se_conv", 0), ("dep_conv", 2), ("max_pool", 1), ("identity", 2)][:2 * nodes],
+                            [("conv", 0), ("up_conv", 1), ("up_dep_conv", 1), ("se_conv", 2), ("identity", 0), ("up_se_conv", 1)][:2 * nodes])
+        nets = [(searched.SearchedNet(4, init, 3, depth, nodes, cc, searched.Genotype(list(gene.down), list(gene.up))), orc.searched_param_specs(cfg, gene), ""),
+                (nas.ShellNet(4, init, 3, depth, nodes, False, cc).kernel, orc.supernet_param_specs(cfg), "kernel.")]
+        for net, specs, prefix in nets:
+            want = {n[len(prefix):]: tuple(shape) for n, shape in specs if n.startswith(prefix) and "alpha" not in n}
+            assert {n: tuple(p.shape) for n, p in net.named_parameters()} == want
+            with torch.no_grad():
+                for q in net.parameters():
+                    q.copy_(torch.randn(q.shape))
+            tw = net._n3d_make_twin()
+            tw.embed(net)
+            tp = dict(tw.twin.named_parameters())
+            for n, r in net.named_parameters():
+                t = tp[n].detach()
+                assert torch.equal(tw.extract(n, t), r.detach()), n
+                assert abs(float(t.abs().sum()) - float(r.detach().abs().sum())) <= 1e-4 * (1.0 + float(r.detach().abs().sum())), n
+            # every feature-map width of the twin is a multiple of 4; the head still emits the real classes
+            for name, m in tw.twin.named_modules():
+                if isinstance(m, torch.nn.GroupNorm):
+                    assert m.num_channels % 4 == 0 and 0 < m._n3d_real_c <= m.num_channels
+            assert tp["last_conv.0.conv.weight"].shape[0] == 3
+            # a cell-output input is padded node by node: real channel j of node k sits at k * pad4(c) + j
+            w = tp["last_conv.0.conv.weight"].detach()
+            c = net.last_conv[0].conv.weight.shape[1] // nodes
+            cp = (c + 3) // 4 * 4
+            assert w.shape[1] == nodes * cp
+            assert torch.equal(w[:, [k * cp + j for k in range(nodes) for j in range(c)]], net.last_conv[0].conv.weight.detach())
+            assert float(w[:, [k * cp + j for k in range(nodes) for j in range(c, cp)]].abs().sum()) == 0.0
 
 
 def test_search_checkpoint_interop_with_torch_adam(tmp_path):
