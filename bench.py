@@ -443,12 +443,21 @@ def main():
             del trainer
             torch.cuda.empty_cache()
             out["other_configs"] = other_configs(device, args.batch, args.no_graph)
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
     if dist.is_initialized():
         if cm is not None:
             cm.barrier()
         n3d_comm.close_all()
         dist.destroy_process_group()
+    if out is not None:
+        # RCCL prints its version banner through C stdio, which a pipe only sees at exit: flush it now so that the JSON line is the LAST line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

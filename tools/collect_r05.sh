@@ -28,10 +28,10 @@ python3 bench.py --workload search --steps 10 --warmup 3 > $O/search_bench.log 2
 {
   echo "# data-parallel code path on a 1-rank RCCL group (N3D_FORCE_DP=1): ms per step, 30 steps after 5 warm-up, HIP-graph replay"
   for args in "" "--buckets 2" "--buckets 3" "--comm torch" "--comm torch --buckets 2"; do
-    N3D_FORCE_DP=1 MASTER_PORT=29577 python3 bench.py $args --no-other-configs --no-kernel-table --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | \
+    N3D_FORCE_DP=1 MASTER_PORT=29577 python3 bench.py $args --no-other-configs --no-kernel-table --no-cpu-baseline --no-roofline 2>/dev/null | grep '^{"metric"' | tail -1 | \
       python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('dp1 %-26s' % '$args', d['ms_per_step'], 'ms  buckets', d['config']['dp_buckets'], ' sync_timeouts', d['sync_timeouts'], ' schedule', d['config']['schedule'])"
   done
-  python3 bench.py --no-other-configs --no-kernel-table --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('single GPU, no process group   ', d['ms_per_step'], 'ms')"
+  python3 bench.py --no-other-configs --no-kernel-table --no-cpu-baseline --no-roofline 2>/dev/null | grep '^{"metric"' | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('single GPU, no process group   ', d['ms_per_step'], 'ms')"
 } > $O/schedules.log 2>&1
 python3 tools/side_timeline.py > $O/side_timeline.txt 2>&1
 python3 tools/side_timeline.py --size 128 > $O/side_timeline_p128_f32.txt 2>&1
