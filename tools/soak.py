@@ -9,6 +9,10 @@ import bench
 from nas_3d_unet_amd import searched, nas
 from nas_3d_unet_amd.train import Trainer, SearchTrainer
 dev = torch.device("cuda")
+if os.environ.get("N3D_FORCE_DP") == "1":      # the data-parallel code path on a 1-rank RCCL group (all-reduces through n3d_comm_*)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29591")
+    dist.init_process_group("nccl", rank=0, world_size=1)
 n_train = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 n_search = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 torch.manual_seed(1234)
@@ -56,3 +60,7 @@ print("search: %d replayed steps in %.2f s = %.2f ms per step incl. host; schedu
       % (n_search, dt, dt / max(1, n_search - 1) * 1e3, "side streams" if st._use_side else "single stream", st.sync_timeouts(), lw[0], lw[-1], la[0], la[-1]))
 assert lw[-1] < lw[0]
 print("soak OK")
+if os.environ.get("N3D_FORCE_DP") == "1":
+    from nas_3d_unet_amd import comm
+    comm.close_all()
+    dist.destroy_process_group()
