@@ -92,6 +92,7 @@ def train_state_dicts(trainer, epoch, history, best_loss):
 def load_train_state_dicts(trainer, sd, new_lr=False):
     """returns (next epoch, history, best_loss) like check_resume"""
     trainer.model.load_state_dict(sd["model_param"])   # parameters are views of the flat buffer: copied in place
+    getattr(trainer, "sync_from_module", lambda: None)()   # (a padded twin re-embeds the loaded parameters)
     if not new_lr:
         trainer.set_lr(load_adam_state_dict(trainer.fp, sd["optim"]))
         load_scheduler_state_dict(trainer.scheduler, sd["scheduler"])
@@ -113,6 +114,7 @@ def search_state_dicts(trainer, epoch, geno_count, history, best_loss):
 def load_search_state_dicts(trainer, sd, new_lr=False):
     """returns (next epoch, geno_count, history, best_loss) like search.py's check_resume"""
     trainer.model.load_state_dict(sd["model_param"])   # kernel weights and alphas are views of the flat buffers: copied in place
+    getattr(trainer, "sync_from_module", lambda: None)()   # (a padded twin re-embeds the loaded parameters)
     if not new_lr:
         trainer.set_shell_lr(load_adam_state_dict(trainer.afp, sd["optim_shell"]))
         trainer.set_kernel_lr(load_adam_state_dict(trainer.fp, sd["optim_kernel"]))

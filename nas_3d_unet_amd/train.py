@@ -849,13 +849,13 @@ def _time_schedule(run, device, warm=2, reps=6):
 
 
 def _refuse_padded(model):
-    """a net whose channel counts are not multiples of 4 runs as a zero-padded twin behind the module API (unet.PaddedTwin); the
-    flat-buffer trainers own the parameters' storage and the backward walk of the net they are given, which such a net does not have"""
+    """a supernet whose channel counts are not multiples of 4 runs as a zero-padded twin behind the module API (unet.PaddedTwin: forward /
+    forward_loss under autograd, any torch optimizer); Trainer trains a searched net's twin, SearchTrainer does not take one yet"""
     for m in (model, getattr(model, "kernel", None)):
         if m is not None and getattr(m, "_n3d_padded", False):
-            raise K.N3DError("this net has feature-map channel counts that are not multiples of 4: it runs as a zero-padded twin behind the module "
-                             "API (forward / forward_loss under autograd, any torch optimizer); nas_3d_unet_amd.train.Trainer / SearchTrainer "
-                             "take nets whose channel counts are multiples of 4 (init_n_kernels = 4, 8, ...)")
+            raise K.N3DError("this supernet has feature-map channel counts that are not multiples of 4: it runs as a zero-padded twin behind the "
+                             "module API (forward / forward_loss under autograd, any torch optimizer); nas_3d_unet_amd.train.SearchTrainer takes "
+                             "supernets whose channel counts are multiples of 4 (init_n_kernels = 4, 8, ...)")
 
 
 class Trainer:
@@ -868,7 +868,17 @@ class Trainer:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph=True, process_group=None,
                  n_buckets=None, params=None, comm=None, storage=None, side_wgrad=None):
         self.model = model
-        _refuse_padded(model)
+        # channel counts that are not multiples of 4: the trainer trains the net's zero-padded TWIN (unet.PaddedTwin; padded entries have
+        # exactly-zero gradients, so Adam never moves them) and cuts the parameters back into `model` at the host-visible points
+        # (check_sync() / sync_to_module()); sync_from_module() re-embeds after `model`'s parameters were written from outside
+        self._twin = None
+        if getattr(model, "_n3d_padded", False):
+            from . import unet as _unet
+            tw = self._twin = model._n3d_make_twin()
+            tw.embed(model)
+            tw.twin.forward_loss = lambda x, t, smooth=1e-6, _tw=tw.twin: _unet.run_loss(_tw, x, t, None, smooth)
+            model = tw.twin
+        self.net = model      # the module whose kernels run (the model itself, or its padded twin)
         # side_wgrad (default: N3D_SIDE_WGRAD, on): the weight-gradient kernels of the C in {4, 8} levels -- nothing on the
         # backward chain waits for them -- are queued during the backward walk and launched on a SIDE HIP stream at a few cut
         # points (cell boundaries), as separately launched graphs tied to the main chain by events; the streams join once,
@@ -936,7 +946,7 @@ class Trainer:
         stems, cells, head -- so what is complete after cell k is the TAIL of the flat buffer starting at cell k's first
         parameter.  Bucket j closes at the first point of the backward walk where at least thresholds[j] of the gradient
         bytes are complete; the last bucket closes at the end."""
-        m = self.model
+        m = self.net
         if not all(hasattr(m, a) for a in ("stem0", "stem1", "down_cells", "up_cells", "last_conv")):
             return None
         off = {id(p): (o, o + (p.numel() + 3) // 4 * 4) for p, o in zip(self.fp.params, self.fp.offsets)}
@@ -973,7 +983,7 @@ class Trainer:
     def _fwd_bwd(self, x, t):
         with K.step_context(self.ctx):
             self.ctx.pack_all()            # one launch packs every conv weight for this step
-            loss = _loss_of(self.model, self.loss_fn, x, t)
+            loss = _loss_of(self.net, self.loss_fn, x, t)
             prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True   # this backward is all ours (no hooks, no retain)
             try:
                 loss.backward(self._one)  # seed gradient kept resident: no fill launch per step
@@ -989,7 +999,7 @@ class Trainer:
         is one Python function on this thread and can hand over work on the way: cell_hook(k) is called when the backward of cell k
         (-1: the stems, i.e. the end) has been launched."""
         from . import head as _head, programs as _P
-        m = self.model
+        m = self.net
         plan = getattr(m, "_net_plan", None)
         if not _fused.current(plan):
             plan = m._net_plan = _fused.net_plan(m, supernet=False)
@@ -1021,7 +1031,7 @@ class Trainer:
     def _direct_ok(self):
         """can the step run as the autograd-free pipeline (a stems / cells / fusable-head net with the Dice loss)?"""
         from . import head as _head
-        m = self.model
+        m = self.net
         return (_fused.WHOLE_NET and isinstance(self.loss_fn, WeightedDiceLoss) and not hasattr(m, "kernel")
                 and all(hasattr(m, a) for a in ("stem0", "stem1", "down_cells", "up_cells", "last_conv"))
                 and _head.fusable(m.last_conv, torch.empty((1, m.last_conv[0].conv.weight.shape[1], 1, 1, 1), device="meta")))
@@ -1035,6 +1045,38 @@ class Trainer:
         were withheld on the device, so the weights are those of the last good step; `recover()` continues on one stream."""
         if self.side is not None:
             self.side.check()
+        self.sync_to_module()
+
+    def sync_to_module(self):
+        """padded twin: the trained parameters back into the user's module (reference shapes); nothing to do otherwise"""
+        if self._twin is not None:
+            tp = dict(self._twin.twin.named_parameters())
+            with torch.no_grad():
+                for n, r in self.model.named_parameters():
+                    r.copy_(self._twin.extract(n, tp[n].detach()))
+
+    def sync_from_module(self):
+        """padded twin: the user's module was written from outside (load_state_dict): embed its parameters again"""
+        if self._twin is not None:
+            self._twin.embed(self.model)
+
+    def _padctx(self):
+        """while kernels of a padded twin are being launched: conv-bias gradients by summation, per-term GroupNorm launches (the node-level
+        ones share their element count with SE gates), no node-planar inner cells (unet.run_padded does the same)"""
+        import contextlib
+        if self._twin is None:
+            return contextlib.nullcontext()
+        from . import programs as _P
+
+        @contextlib.contextmanager
+        def ctx():
+            prev = (_P.ANALYTIC_CONV_BIAS, _fused.NODE_PHASES, _fused.NODE_APPLY, _P.NODE_FWD_COEFFS, _fused.PLANAR_INNER)
+            _P.ANALYTIC_CONV_BIAS, _fused.NODE_PHASES, _fused.NODE_APPLY, _P.NODE_FWD_COEFFS, _fused.PLANAR_INNER = False, False, False, False, False
+            try:
+                yield
+            finally:
+                _P.ANALYTIC_CONV_BIAS, _fused.NODE_PHASES, _fused.NODE_APPLY, _P.NODE_FWD_COEFFS, _fused.PLANAR_INNER = prev
+        return ctx()
 
     def sync_timeouts(self):
         """device-side waits that have timed out since the trainer was built (synchronises; 0 without a side schedule)"""
@@ -1161,6 +1203,10 @@ class Trainer:
 
     # -- public ---------------------------------------------------------------------------------
     def step(self, x, t):
+        with self._padctx():
+            return self._step(x, t)
+
+    def _step(self, x, t):
         self._poll()     # host-only: a withheld update (timed-out hand-off) is fatal until recover()
         if not self.use_graph:
             return self._eager(x, t)
@@ -1275,7 +1321,7 @@ class Trainer:
         if self._side_force:
             self._use_side = True
             return
-        snap = _Snapshot([self.fp.flat, self.fp.exp_avg, self.fp.exp_avg_sq, self.fp.step, self.fp.grad_full] + _dropout_states(self.model))
+        snap = _Snapshot([self.fp.flat, self.fp.exp_avg, self.fp.exp_avg_sq, self.fp.step, self.fp.grad_full] + _dropout_states(self.net))
         # data parallel: the timing runs replay the graphs only -- no collective, no update -- so a rank whose timing differs (or
         # whose side streams misbehave) cannot mispair all-reduces with its peers; the DECISION is then agreed on (MIN over ranks)
         tp = _time_schedule(lambda: self._replay_plain(exchange=False), self.device)
@@ -1294,7 +1340,7 @@ class Trainer:
     def _capture(self, x, t):
         """capture (and, with a side stream, choose the schedule); the Dropout3d generators come out as they went in, so the
         masks of the training run do not depend on how many warm-up / timing passes the capture needed"""
-        snap = _dropout_snapshot(self.model, self.device)
+        snap = _dropout_snapshot(self.net, self.device)
         try:
             self._capture_impl(x, t)
         finally:

@@ -138,3 +138,37 @@ def test_gradsync_single_process_is_noop():
     g = torch.arange(10, dtype=torch.float32)
     GradSync(g, None, 4).all_reduce()
     assert torch.equal(g, torch.arange(10, dtype=torch.float32))
+
+
+def _id_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nas_3d_unet_amd import comm
+    got = []
+    for k in range(3):                       # three communicators in a row: the store keys must not collide
+        c = object.__new__(comm.Comm)        # (no RCCL on a CPU box: only the id exchange of Comm.__init__ is exercised)
+        c.rank, c.world = rank, world
+        mine = bytes([17 * (rank + 1) + k]) * 128
+        got.append(c._exchange_id(None, mine))
+    sub = dist.new_group([0, 1])
+    c = object.__new__(comm.Comm)
+    c.rank, c.world = dist.get_rank(sub), dist.get_world_size(sub)
+    got.append(c._exchange_id(sub, bytes([99 + rank]) * 128))
+    torch.save(got, out + ".id%d" % rank)
+    # for_group: CPU tensors / a gloo group keep torch.distributed (no communicator is made)
+    assert comm.for_group(None, torch.device("cpu")) is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_comm_unique_id_travels_through_the_rendezvous_store(tmp_path):
+    """nas_3d_unet_amd.comm: rank 0's 128-byte ncclUniqueId reaches every rank through torch.distributed's key-value store -- no
+    collective, so ProcessGroupNCCL has no Work object for its watchdog to poll -- once per communicator, keys
+    numbered per group in creation order"""
+    out = str(tmp_path / "ids")
+    mp.spawn(_id_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".id0"), torch.load(out + ".id1")
+    assert r0 == r1
+    assert r0[:3] == [bytes([17 + k]) * 128 for k in range(3)] and r0[3] == bytes([99]) * 128

@@ -9,6 +9,7 @@ import torch
 import golden_common as gc
 from test_gpu_nets import build_net
 from _util import dev
+from oracle import ref_path as orc
 
 pytestmark = pytest.mark.gpu
 
@@ -29,6 +30,47 @@ def test_trainer_matches_reference_adam(golden, graph, key, kind, gname, depth, 
         # Adam moves every element by ~lr per step whatever the gradient's size, so an element whose gradient is
         # fp32 noise (e.g. a conv bias ahead of a GroupNorm) may legitimately end up to adam*lr away
         assert abs(float(q.detach().double().norm()) - ref) <= 5e-4 * ref + adam * 1e-3, n
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_trainer_on_a_net_with_odd_channel_counts_matches_torch_adam(graph):
+    """round 5: init_n_kernels = 6 (stems 18, node widths 12 / 24 / 6: nas.py:13-26, searched.py:55-66 take any) -- Trainer trains the
+    net's zero-padded twin (unet.PaddedTwin): three Adam steps against the fp64 oracle + torch.optim.Adam (train.py:49,117-128); the
+    trained parameters reach the user's module at check_sync(); padded entries never move"""
+    from nas_3d_unet_amd import searched
+    from nas_3d_unet_amd.train import Trainer
+    from test_gpu_nets import _genotype_for
+    cfg = orc.NetCfg(4, 6, 3, 2, 3, True)
+    gene = _genotype_for(cfg.n_nodes)
+    net = searched.SearchedNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, cfg.channel_change,
+                               searched.Genotype(list(gene.down), list(gene.up)))
+    from _util import fill_module
+    fill_module(net)
+    net.last_conv[0].dropout = None
+    net = net.cuda()
+    rng = np.random.default_rng(23)
+    xn = rng.standard_normal((2, 4, 16, 16, 32)).astype(np.float32)
+    tn = (rng.uniform(0, 1, (2, 3, 16, 16, 32)) < 0.3).astype(np.float32)
+    P = orc.make_params(orc.searched_param_specs(cfg, gene), dtype=torch.float64, requires_grad=True)
+    opt = torch.optim.Adam(list(P.values()))
+    ref = []
+    for _ in range(3):
+        opt.zero_grad()
+        l = orc.dice_loss(orc.searched_forward(P, torch.from_numpy(xn).double(), gene, cfg), torch.from_numpy(tn).double())
+        l.backward(); opt.step()
+        ref.append(float(l))
+    tr = Trainer(net, graph=graph)
+    assert tr._twin is not None and tr.net is not net
+    losses = [float(tr.step(dev(xn), dev(tn))) for _ in range(3)]
+    np.testing.assert_allclose(losses, ref, rtol=0, atol=2e-4)
+    tr.check_sync()            # -> sync_to_module(): the user's module holds the trained parameters in the reference's shapes
+    for n, q in net.named_parameters():
+        r = float(P[n].detach().norm())
+        assert abs(float(q.detach().double().norm()) - r) <= 5e-4 * r + 3e-3, n
+    # padded entries are still exactly zero: total |twin| == total |module|
+    tot_t = sum(float(p.detach().abs().double().sum()) for p in tr.net.parameters())
+    tot_m = sum(float(p.detach().abs().double().sum()) for p in net.parameters())
+    assert abs(tot_t - tot_m) <= 1e-6 * tot_m
 
 
 def test_lr_schedule_follows_through_graph_replay():
