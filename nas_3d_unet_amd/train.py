@@ -905,6 +905,17 @@ class Trainer:
         reserve_side_streams(self.device)     # first thing on the GPU (see there), also when THIS trainer will not use them
         plist = list(params) if params is not None else list(model.parameters())
         self.fp = FlatParams(plist, self.device)
+        self._pad_mask = None
+        if self._twin is not None:
+            # gradients of the twin's PADDED parameter entries are not zero (GroupNorm couples a padded channel to its group) and Adam would
+            # move them by lr per step: they are masked in front of every update, so the padded entries stay exactly 0
+            names = {id(q): n for n, q in self._twin.twin.named_parameters()}
+            rshape = {n: q.shape for n, q in self.model.named_parameters()}
+            mask = torch.zeros_like(self.fp.grad)
+            for q, o in zip(self.fp.params, self.fp.offsets):
+                n = names[id(q)]
+                mask[o:o + q.numel()] = self._twin.embed_tensor(n, torch.ones(rshape[n], device=self.device), q.shape).reshape(-1)
+            self._pad_mask = mask
         self.use_graph = graph
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
@@ -1175,6 +1186,8 @@ class Trainer:
         self.sync.all_reduce()
 
     def _update(self, loss=None):
+        if self._pad_mask is not None:
+            self.fp.grad.mul_(self._pad_mask)
         self.fp.adam(self.lr, self.betas, self.eps, 0.0, 1.0 / self.world, self.lr_dev, self._guard(loss))
 
     def set_lr(self, lr):

@@ -45,8 +45,10 @@ class PaddedTwin:
     """A net whose feature-map channel counts are not multiples of 4 (the reference takes any init_n_kernels: nas.py:13-26,
     searched.py:55-66) runs as a TWIN built by the same constructors with every feature map zero-padded to the next multiple of 4:
     stems n c -> pad4(n c), node width c -> pad4(c), a cell output n c -> n pad4(c) (node by node).  The padded channels carry zero conv
-    weights, zero GroupNorm gamma / beta and zero SE weights, so they hold exactly 0 in every forward tensor and receive exactly 0 in every
-    gradient; the real channels see the reference's arithmetic -- with ONE correction: a GroupNorm group's element count is that of the
+    weights, zero GroupNorm gamma / beta and zero SE weights, so they hold exactly 0 in every forward tensor, and nothing of what flows back
+    through them reaches a real channel or a real parameter (a padded channel's activation gradient is NOT zero -- GroupNorm couples the
+    channels of a group -- but it only ever meets zero weights; the gradients of the padded PARAMETERS are discarded: extract() here, a mask
+    in front of Adam in train.Trainer); the real channels see the reference's arithmetic -- with ONE correction: a GroupNorm group's element count is that of the
     REAL channels (programs.gn_groups -> a negative group count at the C ABI, include/n3d.h "padded channels").  The user-visible module
     keeps the reference's parameter shapes (state-dict parity); before every forward they are embedded into the twin's parameters and
     after the backward the twin's gradients are cut back (index plumbing in torch, arithmetic in libn3d).  Module API only (forward /
@@ -128,24 +130,28 @@ class PaddedTwin:
         tp = dict(self.twin.named_parameters())
         with torch.no_grad():
             for n, r in real.named_parameters():
-                if n not in self.maps:
-                    continue
-                cur = r.detach()
-                for d, pos in enumerate(self.maps[n]):
-                    if pos is None:
-                        continue
-                    shape = list(cur.shape)
-                    shape[d] = tp[n].shape[d]
-                    new = torch.zeros(shape, dtype=cur.dtype, device=cur.device)
-                    new.index_copy_(d, pos, cur)
-                    cur = new
-                tp[n].copy_(cur)
+                if n in self.maps:
+                    tp[n].copy_(self.embed_tensor(n, r.detach(), tp[n].shape))
         self.twin.train(real.training)
         rmods = dict(real.named_modules())
         for name, m in self.twin.named_modules():
             rm = rmods.get(name)
             if rm is not None and hasattr(rm, "dropout") and hasattr(m, "dropout") and (rm.dropout is None) != (m.dropout is None):
                 m.dropout = None if rm.dropout is None else nn.Dropout3d(rm.dropout.p)
+
+    def embed_tensor(self, name, r, shape):
+        """a tensor of the real parameter `name`'s shape -> the twin parameter's `shape`, zeros at the padded positions"""
+        import torch
+        cur = r
+        for d, pos in enumerate(self.maps[name]):
+            if pos is None:
+                continue
+            sh = list(cur.shape)
+            sh[d] = shape[d]
+            new = torch.zeros(sh, dtype=cur.dtype, device=cur.device)
+            new.index_copy_(d, pos, cur)
+            cur = new
+        return cur
 
     def extract(self, name, g):
         """a gradient of the twin's parameter `name` -> the real parameter's shape"""
