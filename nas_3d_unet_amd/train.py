@@ -848,14 +848,47 @@ def _time_schedule(run, device, warm=2, reps=6):
     return (time.perf_counter() - t0) / reps
 
 
-def _refuse_padded(model):
-    """a supernet whose channel counts are not multiples of 4 runs as a zero-padded twin behind the module API (unet.PaddedTwin: forward /
-    forward_loss under autograd, any torch optimizer); Trainer trains a searched net's twin, SearchTrainer does not take one yet"""
-    for m in (model, getattr(model, "kernel", None)):
-        if m is not None and getattr(m, "_n3d_padded", False):
-            raise K.N3DError("this supernet has feature-map channel counts that are not multiples of 4: it runs as a zero-padded twin behind the "
-                             "module API (forward / forward_loss under autograd, any torch optimizer); nas_3d_unet_amd.train.SearchTrainer takes "
-                             "supernets whose channel counts are multiples of 4 (init_n_kernels = 4, 8, ...)")
+class _TwinShell:
+    """what SearchTrainer runs for a ShellNet whose kernel net has odd channel counts: the shell's own alphas around the kernel net's
+    zero-padded twin (unet.PaddedTwin)"""
+
+    def __init__(self, shell, twin):
+        self.shell, self.kernel = shell, twin
+
+    def forward_loss(self, x, t, smooth=1e-6):
+        from . import unet as _unet
+        return _unet.run_loss(self.kernel, x, t, tuple(self.shell._soft()), smooth)
+
+    def modules(self):
+        return self.kernel.modules()
+
+
+def _pad_mask_for(tw, real, fp, device):
+    """flat 0/1 mask over a FlatParams of a padded twin's parameters: 1 at the real entries"""
+    names = {id(q): n for n, q in tw.twin.named_parameters()}
+    rshape = {n: q.shape for n, q in real.named_parameters()}
+    mask = torch.zeros_like(fp.grad)
+    for q, o in zip(fp.params, fp.offsets):
+        n = names[id(q)]
+        mask[o:o + q.numel()] = tw.embed_tensor(n, torch.ones(rshape[n], device=device), q.shape).reshape(-1)
+    return mask
+
+
+def _padded_flags():
+    """context: while kernels of a padded twin are launched -- conv-bias gradients by summation, per-term GroupNorm launches (the node-level
+    ones share their element count with SE gates), no node-planar inner cells (unet.run_padded does the same)"""
+    import contextlib
+    from . import programs as _P
+
+    @contextlib.contextmanager
+    def ctx():
+        prev = (_P.ANALYTIC_CONV_BIAS, _fused.NODE_PHASES, _fused.NODE_APPLY, _P.NODE_FWD_COEFFS, _fused.PLANAR_INNER)
+        _P.ANALYTIC_CONV_BIAS, _fused.NODE_PHASES, _fused.NODE_APPLY, _P.NODE_FWD_COEFFS, _fused.PLANAR_INNER = False, False, False, False, False
+        try:
+            yield
+        finally:
+            _P.ANALYTIC_CONV_BIAS, _fused.NODE_PHASES, _fused.NODE_APPLY, _P.NODE_FWD_COEFFS, _fused.PLANAR_INNER = prev
+    return ctx()
 
 
 class Trainer:
@@ -909,13 +942,7 @@ class Trainer:
         if self._twin is not None:
             # gradients of the twin's PADDED parameter entries are not zero (GroupNorm couples a padded channel to its group) and Adam would
             # move them by lr per step: they are masked in front of every update, so the padded entries stay exactly 0
-            names = {id(q): n for n, q in self._twin.twin.named_parameters()}
-            rshape = {n: q.shape for n, q in self.model.named_parameters()}
-            mask = torch.zeros_like(self.fp.grad)
-            for q, o in zip(self.fp.params, self.fp.offsets):
-                n = names[id(q)]
-                mask[o:o + q.numel()] = self._twin.embed_tensor(n, torch.ones(rshape[n], device=self.device), q.shape).reshape(-1)
-            self._pad_mask = mask
+            self._pad_mask = _pad_mask_for(self._twin, self.model, self.fp, self.device)
         self.use_graph = graph
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
@@ -1075,19 +1102,7 @@ class Trainer:
         """while kernels of a padded twin are being launched: conv-bias gradients by summation, per-term GroupNorm launches (the node-level
         ones share their element count with SE gates), no node-planar inner cells (unet.run_padded does the same)"""
         import contextlib
-        if self._twin is None:
-            return contextlib.nullcontext()
-        from . import programs as _P
-
-        @contextlib.contextmanager
-        def ctx():
-            prev = (_P.ANALYTIC_CONV_BIAS, _fused.NODE_PHASES, _fused.NODE_APPLY, _P.NODE_FWD_COEFFS, _fused.PLANAR_INNER)
-            _P.ANALYTIC_CONV_BIAS, _fused.NODE_PHASES, _fused.NODE_APPLY, _P.NODE_FWD_COEFFS, _fused.PLANAR_INNER = False, False, False, False, False
-            try:
-                yield
-            finally:
-                _P.ANALYTIC_CONV_BIAS, _fused.NODE_PHASES, _fused.NODE_APPLY, _P.NODE_FWD_COEFFS, _fused.PLANAR_INNER = prev
-        return ctx()
+        return _padded_flags() if self._twin is not None else contextlib.nullcontext()
 
     def sync_timeouts(self):
         """device-side waits that have timed out since the trainer was built (synchronises; 0 without a side schedule)"""
@@ -1433,7 +1448,13 @@ class SearchTrainer:
 
     def __init__(self, shell, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graph=True, process_group=None, comm=None, side_wgrad=None):
         self.model = shell
-        _refuse_padded(shell)
+        # a kernel net with channel counts that are not multiples of 4: the trainer trains its zero-padded twin (see Trainer)
+        self._twin = None
+        self.net = shell
+        if getattr(getattr(shell, "kernel", None), "_n3d_padded", False):
+            tw = self._twin = shell.kernel._n3d_make_twin()
+            tw.embed(shell.kernel)
+            self.net = _TwinShell(shell, tw.twin)
         # the weight pass queues its weight-gradient kernels for the side stream (SideSchedule); the architecture pass has none
         env = os.environ.get("N3D_SIDE_WGRAD", "1")
         self.side_wgrad = (env != "0") if side_wgrad is None else bool(side_wgrad)
@@ -1453,9 +1474,10 @@ class SearchTrainer:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.device = next(shell.parameters()).device
         reserve_side_streams(self.device)
-        self.kparams = list(shell.kernel.parameters())
+        self.kparams = list(shell.kernel.parameters()) if self._twin is None else list(self._twin.twin.parameters())
         self.aparams = list(shell.alphas())
         self.fp = FlatParams(self.kparams, self.device)
+        self._pad_mask = _pad_mask_for(self._twin, shell.kernel, self.fp, self.device) if self._twin is not None else None
         self.aflat, self.agrad, aoffs = flatten_params(self.aparams, self.device)
         self.a_m = torch.zeros_like(self.aflat)
         self.a_v = torch.zeros_like(self.aflat)
@@ -1526,9 +1548,9 @@ class SearchTrainer:
                 self.ctx.pack_all()
             if sided and self.side_forward:
                 with self.side.forward_mode():
-                    loss = _loss_of(self.model, self.loss_fn, x, t)
+                    loss = _loss_of(self.net, self.loss_fn, x, t)
             else:
-                loss = _loss_of(self.model, self.loss_fn, x, t)
+                loss = _loss_of(self.net, self.loss_fn, x, t)
             prev, _fused.REUSE_GRAD_OUTPUT = _fused.REUSE_GRAD_OUTPUT, True
             try:
                 import contextlib
@@ -1562,6 +1584,7 @@ class SearchTrainer:
         """synchronising check for timed-out hand-offs (see Trainer.check_sync)"""
         if self.side is not None:
             self.side.check()
+        self.sync_to_module()
 
     def sync_timeouts(self):
         return int(self.side.sync[1].item()) if self.side is not None else 0
@@ -1610,6 +1633,8 @@ class SearchTrainer:
             K.adam_step(self.aflat, self.agrad, self.a_m, self.a_v, self.a_step, self.lr_shell, self.betas[0], self.betas[1], self.eps,
                         grad_scale=1.0 / self.world, lr_dev=self.lr_shell_dev, guard=guard)
         else:
+            if self._pad_mask is not None:
+                self.fp.grad.mul_(self._pad_mask)       # (padded twin: the padded entries' gradients are not zero -- see Trainer)
             self.fp.adam(self.lr_kernel, self.betas, self.eps, 0.0, 1.0 / self.world, self.lr_kernel_dev, guard)
 
     def _both(self, x, t, vx, vt, update=True):
@@ -1651,12 +1676,30 @@ class SearchTrainer:
 
     def step(self, x, t, val_x, val_t):
         """returns (architecture-pass loss, weight-pass loss) as device scalars"""
+        if self._twin is not None:
+            with _padded_flags():
+                return self._step(x, t, val_x, val_t)
+        return self._step(x, t, val_x, val_t)
+
+    def sync_to_module(self):
+        """padded twin: the trained kernel weights back into shell.kernel (reference shapes)"""
+        if self._twin is not None:
+            tp = dict(self._twin.twin.named_parameters())
+            with torch.no_grad():
+                for n, r in self.model.kernel.named_parameters():
+                    r.copy_(self._twin.extract(n, tp[n].detach()))
+
+    def sync_from_module(self):
+        if self._twin is not None:
+            self._twin.embed(self.model.kernel)
+
+    def _step(self, x, t, val_x, val_t):
         if self.side is not None:
             self.side.poll()     # host-only: a withheld update (timed-out hand-off) is fatal until recover()
         if not self.use_graph:
             return self._both(x, t, val_x, val_t)
         if getattr(self, "_sx", None) is None or (self._graph is None and self._graphs is None and self._side_graphs is None):
-            drop_snap = _dropout_snapshot(self.model, self.device)   # restored below: masks independent of the warm-up passes
+            drop_snap = _dropout_snapshot(self.net, self.device)   # restored below: masks independent of the warm-up passes
             self._sx, self._st, self._svx, self._svt = x.clone(), t.clone(), val_x.clone(), val_t.clone()
             # warm-up on a side stream (allocator + lazy module state) WITHOUT the optimizer launches: weights, alphas,
             # Adam moments and step counters -- possibly just loaded from a checkpoint (search.py:108-127) -- stay untouched
@@ -1738,7 +1781,7 @@ class SearchTrainer:
     def _choose_schedule(self):
         """time the two captured schedules on the real step (state saved and restored around it) and keep the faster one"""
         snap = _Snapshot([self.fp.flat, self.fp.exp_avg, self.fp.exp_avg_sq, self.fp.step, self.fp.grad_full, self.aflat, self.agrad._n3d_full,
-                          self.a_m, self.a_v, self.a_step] + _dropout_states(self.model))
+                          self.a_m, self.a_v, self.a_step] + _dropout_states(self.net))
         # data parallel: graphs only, no collective and no update while timing; the decision is agreed on (Trainer._choose_schedule)
         ex = not self.dp_path
         tp = _time_schedule(lambda: self._replay_plain(exchange=ex), self.device, warm=1, reps=3)

@@ -96,6 +96,48 @@ def test_search_trajectory_depth4_matches_reference(golden, graph):
             assert abs(mine - ref) <= 1e-2 * ref + 2e-3 * total, (n, step, mine, ref)
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_search_step_on_a_supernet_with_odd_channel_counts_matches_oracle(graph):
+    """round 5: init_n_kernels = 6 (nas.py:13-26 takes any) -- SearchTrainer trains the kernel net's zero-padded twin (unet.PaddedTwin) with
+    the shell's own alphas: two search steps against the fp64 oracle + two torch.optim.Adam (search.py:211-238); the kernel weights reach
+    shell.kernel at check_sync(), padded entries never move"""
+    from nas_3d_unet_amd import nas
+    from nas_3d_unet_amd.train import SearchTrainer
+    cfg = orc.NetCfg(4, 6, 3, 2, 3, True)
+    rng = np.random.default_rng(31)
+    mk = lambda: (rng.standard_normal((2, 4, 8, 8, 16)).astype(np.float32), (rng.uniform(0, 1, (2, 3, 8, 8, 16)) < 0.3).astype(np.float32))
+    (xn, tn), (vxn, vtn) = mk(), mk()
+    P = orc.make_params(orc.supernet_param_specs(cfg), dtype=torch.float64, requires_grad=True)
+    anames = ("alpha2_down", "alpha2_up", "alpha1_down", "alpha1_up")
+    oa, ok = torch.optim.Adam([P[n] for n in anames]), torch.optim.Adam([v for n, v in P.items() if n.startswith("kernel.")])
+    D = lambda a: torch.from_numpy(a).double()
+    ref = []
+    for _ in range(2):
+        oa.zero_grad()
+        la = orc.dice_loss(orc.supernet_forward(P, D(vxn), cfg), D(vtn)); la.backward(); oa.step()
+        ok.zero_grad()
+        lw = orc.dice_loss(orc.supernet_forward(P, D(xn), cfg), D(tn)); lw.backward(); ok.step()
+        ref.append((float(la.detach()), float(lw.detach())))
+    net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)
+    fill_module(net)
+    net.kernel.last_conv[0].dropout = None
+    net = net.cuda()
+    tr = SearchTrainer(net, graph=graph)
+    assert tr._twin is not None
+    x, t, vx, vt = (torch.from_numpy(a).cuda() for a in (xn, tn, vxn, vtn))
+    got = [tuple(float(v) for v in tr.step(x, t, vx, vt)) for _ in range(2)]
+    np.testing.assert_allclose(np.array(got), np.array(ref), rtol=0, atol=3e-4)
+    tr.check_sync()
+    for n in anames:
+        assert np.abs(getattr(net, n).detach().cpu().numpy() - P[n].detach().numpy()).max() <= 2.5e-3, n
+    for n, q in net.kernel.named_parameters():
+        r = float(P["kernel." + n].detach().norm())
+        assert abs(float(q.detach().double().norm()) - r) <= 5e-4 * r + 3e-3, n
+    tot_t = sum(float(p.detach().abs().double().sum()) for p in tr._twin.twin.parameters())
+    tot_m = sum(float(p.detach().abs().double().sum()) for p in net.kernel.parameters())
+    assert abs(tot_t - tot_m) <= 1e-6 * tot_m
+
+
 @pytest.mark.parametrize("schedule", ["single-stream", "side-stream"])
 def test_search_benchmarked_configuration_vs_reference(golden, schedule):
     """BASELINE configs[2] in ONE piece at the benchmarked size, as bench.py times it: depth-4 supernet, 2 + 2 patches of 4x64^3
