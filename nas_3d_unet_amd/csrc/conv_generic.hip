@@ -972,8 +972,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 // depthwise family (groups == C): per-lane weights, float4 over 4 channels
 // ------------------------------------------------------------------------------------------------
 struct DwArgs {
-  const float* src; int64_t sld; int Ds, Hs, Ws;
-  float* dst; int64_t dld; int Dd, Hd, Wd;
+  const void* src; int64_t sld; int Ds, Hs, Ws;      // TS elements (fp32, or bf16 storage: round 5)
+  void* dst; int64_t dld; int Dd, Hd, Wd;            // TD elements
   int C;
   const float* w;   // native (C,1,k,k,k)
   const float* bias;
@@ -981,6 +981,7 @@ struct DwArgs {
   FastDiv fcpb, fWd, fHd;
 };
 
+template <typename TS = float, typename TD = float>
 __device__ __forceinline__ void dw_gather_body(const DwArgs& a) {
   // k = 3, dilation 1 (check_geom).  Branch-free: the weights of all channel quads are staged once in LDS as float4
   // [c4][tap] (one broadcast ds_read_b128 per tap), and the nine source loads of a kd plane are issued from clamped
@@ -1004,12 +1005,12 @@ __device__ __forceinline__ void dw_gather_body(const DwArgs& a) {
   const int c4 = (int)uc;
   const int64_t v = uv;
   const int w_ = (int)uw, h_ = (int)uh, d_ = (int)ud;
-  float4* op = reinterpret_cast<float4*>(a.dst + ((int64_t)b * Nd + v) * a.dld + c4 * 4);
+  TD* op = reinterpret_cast<TD*>(a.dst) + ((int64_t)b * Nd + v) * a.dld + c4 * 4;
   const bool accum = a.flags & N3D_ACCUMULATE;
   float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (accum) prev = *op;
+  if (accum) prev = ld4(op);
   float4 acc = a.bias ? *reinterpret_cast<const float4*>(a.bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* srcb = a.src + (int64_t)b * Ns * a.sld + c4 * 4;
+  const TS* srcb = reinterpret_cast<const TS*>(a.src) + (int64_t)b * Ns * a.sld + c4 * 4;
   const float4* wq = dwl + c4 * 27;
 #pragma unroll
   for (int kd = 0; kd < 3; ++kd) {
@@ -1035,7 +1036,7 @@ __device__ __forceinline__ void dw_gather_body(const DwArgs& a) {
         ok = ok && nw >= 0 && nw < a.Ws;
         const int cw_ = min(max(nw, 0), a.Ws - 1);
         m[kh][kw] = ok ? 1.f : 0.f;
-        q[kh][kw] = *reinterpret_cast<const float4*>(srcb + (((int64_t)cd_ * a.Hs + ch_) * a.Ws + cw_) * a.sld);
+        q[kh][kw] = ld4(srcb + (((int64_t)cd_ * a.Hs + ch_) * a.Ws + cw_) * a.sld);
       }
     }
 #pragma unroll
@@ -1050,9 +1051,10 @@ __device__ __forceinline__ void dw_gather_body(const DwArgs& a) {
         acc.w = fmaf(q[kh][kw].w * mm, wv.w, acc.w);
       }
   }
-  *op = make_float4(acc.x + prev.x, acc.y + prev.y, acc.z + prev.z, acc.w + prev.w);
+  st4(op, make_float4(acc.x + prev.x, acc.y + prev.y, acc.z + prev.z, acc.w + prev.w));
 }
-__global__ __launch_bounds__(256) void dw_gather_kernel(DwArgs a) { N3D_CHAIN_PRIO(); dw_gather_body(a); }
+template <typename TS = float, typename TD = float>
+__global__ __launch_bounds__(256) void dw_gather_kernel(DwArgs a) { N3D_CHAIN_PRIO(); dw_gather_body<TS, TD>(a); }
 // the depthwise convs of up to 8 primitives of a supernet node (one per edge, cell.py:76-81) in one launch: grid.z = job; all
 // jobs share the output shape and channel count (blockIdx.x covers the output voxels), their sources may differ in shape
 struct DwArgsN { DwArgs j[8]; };
@@ -1060,12 +1062,12 @@ __global__ __launch_bounds__(256) void dw_gatherN_kernel(DwArgsN js) { N3D_CHAIN
   DwArgs a;
   switch (blockIdx.z) { case 0: a = js.j[0]; break; case 1: a = js.j[1]; break; case 2: a = js.j[2]; break; case 3: a = js.j[3]; break;
                         case 4: a = js.j[4]; break; case 5: a = js.j[5]; break; case 6: a = js.j[6]; break; default: a = js.j[7]; break; }
-  dw_gather_body(a);
+  dw_gather_body<float, float>(a);
 }
 
 struct DwWgradArgs {
-  const float* x; int64_t xld; int Di, Hi, Wi;
-  const float* dy; int64_t dyld; int Do, Ho, Wo;
+  const void* x; int64_t xld; int Di, Hi, Wi;        // TS elements
+  const void* dy; int64_t dyld; int Do, Ho, Wo;      // TD elements
   int B, C, k, stride, pad;
   float* partial;  // [nchunks][27][C]  (the layout n3d_wgrad_finalize_batch reads with ci_t = 1, co_t = C)
   float* pbias;    // [nchunks][C]
@@ -1076,7 +1078,7 @@ struct DwWgradArgs {
 // POW2: C / 4 is a power of two (every depthwise op of the reference: C = 4 .. 64) -> DPP / permlane class sums, fully
 // unrolled so the 28 x 4 accumulators stay in registers (the generic strided sums made the compiler spill them)
 // CPB: C / 4 when it is a power of two (compile-time, so the 112 class sums are straight-line DPP code), 0 = generic
-template <int CPB>
+template <int CPB, typename TS = float, typename TD = float>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
   constexpr bool POW2 = CPB > 0;
   extern __shared__ float dyn[];
@@ -1099,9 +1101,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
       a.fWo.divmod(uo, q1, uw);
       a.fHo.divmod(q1, ud, uh);
       const int b = (int)ub, ow = (int)uw, oh = (int)uh, od = (int)ud;
-      const float4 g = *reinterpret_cast<const float4*>(a.dy + i * a.dyld + c4 * 4);
+      const float4 g = ld4(reinterpret_cast<const TD*>(a.dy) + i * a.dyld + c4 * 4);
       acc[27][0] += g.x; acc[27][1] += g.y; acc[27][2] += g.z; acc[27][3] += g.w;
-      const float* xb = a.x + (int64_t)b * Ni * a.xld + c4 * 4;
+      const TS* xb = reinterpret_cast<const TS*>(a.x) + (int64_t)b * Ni * a.xld + c4 * 4;
       // one kd plane at a time: its nine loads are issued from clamped addresses before the first use (a branch per
       // tap serialises on one memory latency per tap: 27 per voxel; all 27 at once measured no better and takes 256 VGPRs)
 #pragma unroll
@@ -1121,7 +1123,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
             const int iw = ow * a.stride - a.pad + kw;
             ok[kh][kw] = okh && iw >= 0 && iw < a.Wi;
             const int cw_ = min(max(iw, 0), a.Wi - 1);
-            q[kh][kw] = *reinterpret_cast<const float4*>(xb + (((int64_t)cd_ * a.Hi + ch_) * a.Wi + cw_) * a.xld);
+            q[kh][kw] = ld4(xb + (((int64_t)cd_ * a.Hi + ch_) * a.Wi + cw_) * a.xld);
           }
         }
 #pragma unroll
@@ -1867,12 +1869,17 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
   hipStream_t s = (hipStream_t)stream;
   const bool sb16 = flags & N3D_SRC_BF16, db16 = flags & N3D_DST_BF16;
   if (g->depthwise) {
-    if (flags & N3D_ANY_BF16) N3D_UNSUPPORTED("depthwise conv: bf16 storage is not built");
     N3D_CHECK_ARG(!in_gate && !relu_src && !out_gate && !stats && !(flags & N3D_RELU_IN), "depthwise conv: gate/relu/stats not supported");
-    N3D_CHECK_ARG(sld % 4 == 0 && dld % 4 == 0 && aligned16(src) && aligned16(dst), "depthwise conv: needs 16-byte aligned pitched rows");
+    N3D_CHECK_ARG(sld % 4 == 0 && dld % 4 == 0 && aligned_quad(src, sb16) && aligned_quad(dst, db16), "depthwise conv: needs quad-aligned pitched rows");
     DwArgs a = dw_args(g, data_grad, src, sld, w, bias, dst, dld, flags);
     const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
-    hipLaunchKernelGGL(dw_gather_kernel, dim3((unsigned)cdiv(Nd * (a.C / 4), 256), g->B), dim3(256), (size_t)(a.C / 4) * 27 * sizeof(float4), s, a);
+    const dim3 grid((unsigned)cdiv(Nd * (a.C / 4), 256), g->B);
+    const size_t shm = (size_t)(a.C / 4) * 27 * sizeof(float4);
+    // storage types of source / destination (round 5: bf16 storage of the C <= 8 cells also with depthwise primitives)
+    if (sb16 && db16) hipLaunchKernelGGL((dw_gather_kernel<bf16_t, bf16_t>), grid, dim3(256), shm, s, a);
+    else if (sb16) hipLaunchKernelGGL((dw_gather_kernel<bf16_t, float>), grid, dim3(256), shm, s, a);
+    else if (db16) hipLaunchKernelGGL((dw_gather_kernel<float, bf16_t>), grid, dim3(256), shm, s, a);
+    else hipLaunchKernelGGL((dw_gather_kernel<float, float>), grid, dim3(256), shm, s, a);
     N3D_LAUNCH_CHECK();
     return N3D_OK;
   }
@@ -2076,7 +2083,6 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   const size_t avail = (ws_bytes - skip) / 4;
   const bool sb16 = flags & N3D_SRC_BF16, db16 = flags & N3D_DST_BF16;   // storage of the kernel-role x / dy tensors
   if (g->depthwise) {
-    if (flags & N3D_ANY_BF16) N3D_UNSUPPORTED("depthwise weight gradient: bf16 storage is not built");
     // conv-side roles: X on the i side, DY on the o side (callers of the transposed form pass them swapped)
     N3D_CHECK_ARG(!in_gate && !(flags & N3D_RELU_IN), "depthwise wgrad: gate/relu not supported");
     DwWgradArgs a;
@@ -2086,7 +2092,7 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     const int64_t total = (int64_t)g->B * No;
     {
       // tileable stride-1 shapes with enough (tile, channel quad) units: the LDS-tile kernel
-      constexpr bool notile = false;
+      const bool notile = flags & N3D_ANY_BF16;     // (the LDS-tile kernel fills its tile by 16-byte LDS-DMA of fp32 quads)
       const int quads = g->Ci / 4;
       if (!notile && g->k == 3 && g->stride == 1 && g->dil == 1 && g->pad == 1 && g->Wi % 16 == 0 && g->Hi % 4 == 0 && g->Di % 4 == 0 && g->Ci % 4 == 0 &&
           xld % 4 == 0 && dyld % 4 == 0 && aligned16(x) && aligned16(dy)) {
@@ -2127,6 +2133,12 @@ static int run_wgrad(const n3d_conv_geom* g, const float* x, int64_t xld, const 
     a.pbias = wsf + (size_t)nchunks * 27 * a.C;
     const int cpb = a.C / 4;
     const size_t shm = (size_t)4 * cpb * 28 * 4 * sizeof(float);
+    if (flags & N3D_ANY_BF16) {
+      // bf16 storage (round 5: the C <= 8 cells of the bf16 configuration): both tensors bf16, 4 or 8 channels
+      if (!(sb16 && db16) || (cpb != 1 && cpb != 2)) N3D_UNSUPPORTED("depthwise weight gradient: bf16 storage is built for x and dy both bf16, C = 4 / 8");
+      if (cpb == 1) hipLaunchKernelGGL((dw_wgrad_kernel<1, bf16_t, bf16_t>), dim3(nchunks), dim3(256), shm, s, a);
+      else hipLaunchKernelGGL((dw_wgrad_kernel<2, bf16_t, bf16_t>), dim3(nchunks), dim3(256), shm, s, a);
+    } else
     switch (cpb) {
       case 1: hipLaunchKernelGGL(dw_wgrad_kernel<1>, dim3(nchunks), dim3(256), shm, s, a); break;
       case 2: hipLaunchKernelGGL(dw_wgrad_kernel<2>, dim3(nchunks), dim3(256), shm, s, a); break;

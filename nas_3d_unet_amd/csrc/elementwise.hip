@@ -2032,8 +2032,8 @@ __global__ __launch_bounds__(512) void node_bwd_coeffs_kernel(NodeCoefArgs qs, i
 // ------------------------------------------------------------------------------------------------
 // pooling 2x2x2 / 2
 // ------------------------------------------------------------------------------------------------
-template <bool MAX>
-__global__ __launch_bounds__(256) void pool2_fwd_kernel(const float* __restrict__ x, int64_t xld, float* __restrict__ y, int64_t yld, int Di,
+template <bool MAX, typename T = float>
+__global__ __launch_bounds__(256) void pool2_fwd_kernel(const T* __restrict__ x, int64_t xld, T* __restrict__ y, int64_t yld, int Di,
                                                         int Hi, int Wi, int C) { N3D_CHAIN_PRIO();
   const int Do = Di / 2, Ho = Hi / 2, Wo = Wi / 2;
   const int cpb = C / 4;
@@ -2046,7 +2046,7 @@ __global__ __launch_bounds__(256) void pool2_fwd_kernel(const float* __restrict_
   const int wo = v % Wo; v /= Wo;
   const int ho = v % Ho;
   const int d_o = v / Ho;
-  const float* xb = x + (int64_t)b * Di * Hi * Wi * xld + c4 * 4;
+  const T* xb = x + (int64_t)b * Di * Hi * Wi * xld + c4 * 4;
   float4 acc = MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0, 0, 0, 0);
 #pragma unroll
   for (int kd = 0; kd < 2; ++kd)
@@ -2145,9 +2145,9 @@ __global__ __launch_bounds__(256) void pool2_bwd_both_kernel(const float* __rest
 
 // one thread per OUTPUT voxel quad: routes dy to its 8 inputs (avg: /8; max: first arg-max in
 // (d,h,w) scan order, the choice torch's max_pool3d backward makes)
-template <bool MAX, bool ACC>
-__global__ __launch_bounds__(256) void pool2_bwd_kernel(const float* __restrict__ dy, int64_t dyld, const float* __restrict__ x, int64_t xld,
-                                                        float* __restrict__ dx, int64_t dxld, int Di, int Hi, int Wi, int C,
+template <bool MAX, bool ACC, typename T = float>
+__global__ __launch_bounds__(256) void pool2_bwd_kernel(const T* __restrict__ dy, int64_t dyld, const T* __restrict__ x, int64_t xld,
+                                                        T* __restrict__ dx, int64_t dxld, int Di, int Hi, int Wi, int C,
                                                         const float* __restrict__ wptr) { N3D_CHAIN_PRIO();
   const int Do = Di / 2, Ho = Hi / 2, Wo = Wi / 2;
   const int cpb = C / 4;
@@ -2164,8 +2164,8 @@ __global__ __launch_bounds__(256) void pool2_bwd_kernel(const float* __restrict_
   const float4 gq = ld4(dy + ((int64_t)b * Do * Ho * Wo + vo) * dyld + c4 * 4);
   const float wsc = wptr ? *wptr : 1.0f;   // MixedOp weight of the pooling primitive: dx (+)= w * pool^T(dy)
   const float g[4] = {gq.x * wsc, gq.y * wsc, gq.z * wsc, gq.w * wsc};
-  const float* xb = x ? x + (int64_t)b * Di * Hi * Wi * xld + c4 * 4 : nullptr;
-  float* db = dx + (int64_t)b * Di * Hi * Wi * dxld + c4 * 4;
+  const T* xb = x ? x + (int64_t)b * Di * Hi * Wi * xld + c4 * 4 : nullptr;
+  T* db = dx + (int64_t)b * Di * Hi * Wi * dxld + c4 * 4;
   int arg[4] = {0, 0, 0, 0};
   if (MAX) {
     float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -2185,9 +2185,9 @@ __global__ __launch_bounds__(256) void pool2_bwd_kernel(const float* __restrict_
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = MAX ? (arg[j] == k ? g[j] : 0.f) : g[j] * 0.125f;
-    float4* op = reinterpret_cast<float4*>(db + vi * dxld);
-    if (ACC) { const float4 p = *op; o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
-    *op = make_float4(o[0], o[1], o[2], o[3]);
+    T* op = db + vi * dxld;
+    if (ACC) { const float4 p = ld4(op); o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+    st4(op, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
@@ -3053,11 +3053,16 @@ int n3d_node_bwd_coeffs(const n3d_gn_bwd_term* gn, int n_gn, const n3d_se_term* 
 
 int n3d_pool2_fwd(const float* x, int64_t xld, float* y, int64_t yld, int B, int Di, int Hi, int Wi, int C, int flags, void* stream) {
   N3D_CHECK_ARG(x && y && Di % 2 == 0 && Hi % 2 == 0 && Wi % 2 == 0, "pool2_fwd: spatial dims must be even");
-  if (int e = check_vec(x, xld, C, "pool2_fwd(x)")) return e;
-  if (int e = check_vec(y, yld, C, "pool2_fwd(y)")) return e;
+  const bool bf = flags & N3D_ACT_BF16;       // both tensors in bf16 storage (round 5)
+  if (int e = check_vec(x, xld, C, "pool2_fwd(x)", bf)) return e;
+  if (int e = check_vec(y, yld, C, "pool2_fwd(y)", bf)) return e;
   const int64_t total = (int64_t)(Di / 2) * (Hi / 2) * (Wi / 2) * (C / 4);
   dim3 grid((unsigned)cdiv(total, 256), B), blk(256);
-  if (flags & N3D_POOL_MAX) hipLaunchKernelGGL((pool2_fwd_kernel<true>), grid, blk, 0, (hipStream_t)stream, x, xld, y, yld, Di, Hi, Wi, C);
+  if (bf) {
+    const bf16_t* xb = (const bf16_t*)x; bf16_t* yb = (bf16_t*)y;
+    if (flags & N3D_POOL_MAX) hipLaunchKernelGGL((pool2_fwd_kernel<true, bf16_t>), grid, blk, 0, (hipStream_t)stream, xb, xld, yb, yld, Di, Hi, Wi, C);
+    else hipLaunchKernelGGL((pool2_fwd_kernel<false, bf16_t>), grid, blk, 0, (hipStream_t)stream, xb, xld, yb, yld, Di, Hi, Wi, C);
+  } else if (flags & N3D_POOL_MAX) hipLaunchKernelGGL((pool2_fwd_kernel<true>), grid, blk, 0, (hipStream_t)stream, x, xld, y, yld, Di, Hi, Wi, C);
   else hipLaunchKernelGGL((pool2_fwd_kernel<false>), grid, blk, 0, (hipStream_t)stream, x, xld, y, yld, Di, Hi, Wi, C);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
@@ -3097,14 +3102,23 @@ int n3d_pool2_bwd(const float* dy, int64_t dyld, const float* x, int64_t xld, fl
 
 int n3d_pool2_bwd_scaled(const float* dy, int64_t dyld, const float* x, int64_t xld, float* dx, int64_t dxld, int B, int Di, int Hi, int Wi,
                          int C, int flags, const float* wptr, void* stream) {
-  const bool mx = flags & N3D_POOL_MAX, acc = flags & N3D_ACCUMULATE;
+  const bool mx = flags & N3D_POOL_MAX, acc = flags & N3D_ACCUMULATE, bf = flags & N3D_ACT_BF16;
   N3D_CHECK_ARG(dy && dx && (!mx || x), "pool2_bwd: bad args");
-  if (int e = check_vec(dy, dyld, C, "pool2_bwd(dy)")) return e;
-  if (int e = check_vec(dx, dxld, C, "pool2_bwd(dx)")) return e;
-  if (mx) if (int e = check_vec(x, xld, C, "pool2_bwd(x)")) return e;
+  if (int e = check_vec(dy, dyld, C, "pool2_bwd(dy)", bf)) return e;
+  if (int e = check_vec(dx, dxld, C, "pool2_bwd(dx)", bf)) return e;
+  if (mx) if (int e = check_vec(x, xld, C, "pool2_bwd(x)", bf)) return e;
   const int64_t total = (int64_t)(Di / 2) * (Hi / 2) * (Wi / 2) * (C / 4);
   dim3 grid((unsigned)cdiv(total, 256), B), blk(256);
   hipStream_t s = (hipStream_t)stream;
+  if (bf) {       // all three tensors in bf16 storage (round 5)
+    const bf16_t* dyb = (const bf16_t*)dy; const bf16_t* xb = (const bf16_t*)x; bf16_t* dxb = (bf16_t*)dx;
+    if (mx && acc) hipLaunchKernelGGL((pool2_bwd_kernel<true, true, bf16_t>), grid, blk, 0, s, dyb, dyld, xb, xld, dxb, dxld, Di, Hi, Wi, C, wptr);
+    else if (mx) hipLaunchKernelGGL((pool2_bwd_kernel<true, false, bf16_t>), grid, blk, 0, s, dyb, dyld, xb, xld, dxb, dxld, Di, Hi, Wi, C, wptr);
+    else if (acc) hipLaunchKernelGGL((pool2_bwd_kernel<false, true, bf16_t>), grid, blk, 0, s, dyb, dyld, xb, xld, dxb, dxld, Di, Hi, Wi, C, wptr);
+    else hipLaunchKernelGGL((pool2_bwd_kernel<false, false, bf16_t>), grid, blk, 0, s, dyb, dyld, xb, xld, dxb, dxld, Di, Hi, Wi, C, wptr);
+    N3D_LAUNCH_CHECK();
+    return N3D_OK;
+  }
   if (mx && acc) hipLaunchKernelGGL((pool2_bwd_kernel<true, true>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C, wptr);
   else if (mx) hipLaunchKernelGGL((pool2_bwd_kernel<true, false>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C, wptr);
   else if (acc) hipLaunchKernelGGL((pool2_bwd_kernel<false, true>), grid, blk, 0, s, dy, dyld, x, xld, dx, dxld, Di, Hi, Wi, C, wptr);

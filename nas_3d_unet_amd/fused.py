@@ -897,10 +897,9 @@ class _NetPlan:
         # gradients in bf16; the deep cells (16 .. 64 channels on <= 32^3 voxels, latency-bound, L2-resident) stay fp32
         bf = getattr(net, "_n3d_storage", "fp32") == "bf16"
         for pl in self.cells:
-            # ... and only cells built from plain convs: the depthwise / pooling / SE kernels are fp32 (a cell with one of
-            # those primitives stays fp32 as a whole; its two preprocess convs convert at the boundary)
-            plain = all(isinstance(seg.weight, P.DenseConvW) and seg.se_gate is None for _, _, segs, _, _ in pl.edges for seg, _ in segs)
-            pl.dt = torch.bfloat16 if (bf and pl.c_node <= BF16_MAX_NODE_WIDTH and plain and not supernet) else torch.float32
+            # (round 5: every primitive of the registry has bf16-storage kernels at these widths -- depthwise, pooling, SE gate, identity
+            # next to the convs -- so the policy no longer depends on the genotype; the supernet's N-term kernels stay fp32)
+            pl.dt = torch.bfloat16 if (bf and pl.c_node <= BF16_MAX_NODE_WIDTH and not supernet) else torch.float32
         self.stem_dt = torch.bfloat16 if bf else torch.float32
         self.n_down = len(net.down_cells)
         # activations: 0 = stem0, 1 = stem1, 2 + k = cell k.  wiring[k] = (x0 index, x1 index, output index)

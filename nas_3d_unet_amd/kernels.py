@@ -1320,15 +1320,15 @@ def se_gate_bwdN(terms, N, B, Cc):
 
 
 def pool2_fwd(x: View, y: View, is_max):
-    _need_f32("pool2_fwd", x, y)
-    check(_lib.load().n3d_pool2_fwd(x.p, x.ld, y.p, y.ld, x.B, x.D, x.H, x.W, x.C, POOL_MAX if is_max else 0,
+    _same_dt("pool2_fwd", x, y)
+    check(_lib.load().n3d_pool2_fwd(x.p, x.ld, y.p, y.ld, x.B, x.D, x.H, x.W, x.C, (POOL_MAX if is_max else 0) | _aflag(x),
                                     stream_ptr()), "n3d_pool2_fwd")
 
 
 def pool2_bwd(dy: View, x: View, dx: View, is_max, accumulate=False, wptr=None):
     """dx (+)= w * pool^T(dy); wptr: device scalar (the MixedOp weight of the pooling primitive) or None = 1"""
-    fl = (POOL_MAX if is_max else 0) | (ACCUMULATE if accumulate else 0)
-    _need_f32("pool2_bwd", dy, x, dx)
+    fl = (POOL_MAX if is_max else 0) | (ACCUMULATE if accumulate else 0) | _aflag(dy)
+    _same_dt("pool2_bwd", dy, x, dx)
     check(_lib.load().n3d_pool2_bwd_scaled(dy.p, dy.ld, x.p, x.ld, dx.p, dx.ld, x.B, x.D, x.H, x.W, x.C, fl, wptr, stream_ptr()),
           "n3d_pool2_bwd_scaled")
 

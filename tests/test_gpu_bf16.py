@@ -270,22 +270,24 @@ def test_searched_net_bf16_vs_golden_d4s64(golden):
     assert net._net_plan.stem_dt == torch.bfloat16 and dts[0] == torch.bfloat16 and dts[-1] == torch.bfloat16 and dts[3] == torch.float32
 
 
-@pytest.mark.parametrize("size,batch", [(64, 2), (128, 1), ((32, 64, 96), 3)])
-def test_searched_net_bf16_vs_cpu_oracle(size, batch):
+@pytest.mark.parametrize("size,batch,gname", [(64, 2, "G_CONV"), (128, 1, "G_CONV"), ((32, 64, 96), 3, "G_CONV"), (128, 1, "G_ALL"), (64, 2, "G_ALL")])
+def test_searched_net_bf16_vs_cpu_oracle(size, batch, gname):
     """seeded 64^3 (batch 2) and 128^3 (the configuration's patch size) cases against the fp32 CPU oracle: loss, logits,
-    probabilities, every parameter gradient; and a second run of the same step is bit-identical"""
+    probabilities, every parameter gradient; and a second run of the same step is bit-identical.  G_ALL (round 5): the genotype with
+    depthwise-separable, SE, pooling and identity primitives -- their cells store bf16 too (prim_ops.py:119-174)"""
     from nas_3d_unet_amd import unet
     shape = (size, size, size) if isinstance(size, int) else size     # also a non-cubic patch with a batch of 3
     rng = np.random.default_rng(shape[0] + shape[2])
     xn = rng.standard_normal((batch, 4) + shape).astype(np.float32)
     tn = (rng.uniform(0, 1, (batch, 3) + shape) < 0.3).astype(np.float32)
-    P = orc.make_params(orc.searched_param_specs(orc.DEFAULT_CFG, orc.G_CONV), requires_grad=True)
-    pr, zr = orc.searched_forward(P, torch.from_numpy(xn), orc.G_CONV, return_logits=True)
+    gene = getattr(orc, gname)
+    P = orc.make_params(orc.searched_param_specs(orc.DEFAULT_CFG, gene), requires_grad=True)
+    pr, zr = orc.searched_forward(P, torch.from_numpy(xn), gene, return_logits=True)
     lr = orc.dice_loss(pr, torch.from_numpy(tn))
     lr.backward()
     runs = []
     for _ in range(2):
-        net, _ = build_net("searched", "G_CONV", 4)
+        net, _ = build_net("searched", gname, 4)
         unet.set_storage(net, "bf16")
         l, logits, p = _run_bf16(net, dev(xn), dev(tn))
         runs.append((l, logits, p, {n: q.grad.clone() for n, q in net.named_parameters()}))
@@ -334,9 +336,8 @@ def test_bf16_storage_trains_with_fp32_at_128(scale):
 
 
 def test_searched_net_bf16_with_non_conv_primitives_vs_oracle():
-    """G_ALL (depthwise-separable, SE, pooling, identity primitives): the cells that contain primitives without bf16 kernels stay
-    fp32 as a whole, the stems (and any all-conv cell) store bf16 -- mixed storage with conversions in the cells' preprocess convs.
-    Against the fp32 CPU oracle at the bf16 tolerance."""
+    """G_ALL (depthwise-separable, SE, pooling, identity primitives): since round 5 their cells store bf16 like the all-conv ones (the
+    node-width <= 8 levels; the deep cells fp32).  Against the fp32 CPU oracle at the bf16 tolerance."""
     from nas_3d_unet_amd import unet
     rng = np.random.default_rng(5)
     xn = rng.standard_normal((2, 4, 32, 32, 32)).astype(np.float32)
@@ -348,7 +349,8 @@ def test_searched_net_bf16_with_non_conv_primitives_vs_oracle():
     net, _ = build_net("searched", "G_ALL", 4)
     unet.set_storage(net, "bf16")
     l, logits, p = _run_bf16(net, dev(xn), dev(tn))
-    assert net._net_plan.stem_dt == torch.bfloat16 and all(pl.dt == torch.float32 for pl in net._net_plan.cells)
+    dts = [pl.dt for pl in net._net_plan.cells]
+    assert net._net_plan.stem_dt == torch.bfloat16 and dts[0] == torch.bfloat16 and dts[-1] == torch.bfloat16 and dts[3] == torch.float32
     _check_against_fp32(l, logits, p, {n: q.grad for n, q in net.named_parameters()}, float(lr), zr.detach(), pr.detach(),
                         {n: q.grad for n, q in P.items()})
 
