@@ -388,8 +388,25 @@ struct K1Args {
 constexpr int K1_VPB = 1024;   // voxels per workgroup
 
 // EXTRA: the data-gradient extras (accumulate into dst, ReLU mask source) are in use -- they cost 8 * CDQ registers per voxel
+// storage-form quad (what one load instruction returns): the data-gradient form keeps its ReLU mask source and the destination's
+// previous value this way until they are used -- 2 registers per bf16 quad instead of 4
+template <typename T> struct K1Raw;
+template <> struct K1Raw<float> { typedef float4 type; };
+template <> struct K1Raw<bf16_t> { typedef uint2 type; };
+__device__ __forceinline__ float4 k1_ldraw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ uint2 k1_ldraw(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ float4 k1_f4(const float4 v) { return v; }
+__device__ __forceinline__ float4 k1_f4(const uint2 v) {
+  return make_float4(__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xffff0000u),
+                     __builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xffff0000u));
+}
+// Minimum waves per SIMD the compiler must leave room for.  The data-gradient form is a pure streaming pass (56 bytes per voxel at
+// 4 -> 12 channels, bf16) and lives on the bytes it keeps in flight: with the forward form's extras compiled in (statistics, output
+// coefficients) and 256 VGPRs allowed it took 204 of them -- 2 waves per SIMD, 3.6 TB/s at 2 x 128^3; without them and held to 128:
+// 112 VGPRs, 4 waves, 6.0 TB/s (profiles/r05_k1_ab.log).  Held to 80 it spills (0.2 of peak), so the wider shapes keep 2.
+constexpr int k1_min_waves(int csq, int cdq, bool extra) { return (extra && csq * cdq <= 3) ? 4 : 2; }
 template <int CSQ, int CDQ, bool EXTRA, typename TS = float, typename TD = float>   // Cs = 4 * CSQ, Cd = 4 * CDQ
-__global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
+__global__ __launch_bounds__(256, k1_min_waves(CSQ, CDQ, EXTRA)) void conv_k1_kernel(K1Args a) {
   N3D_CHAIN_PRIO();
   constexpr int VPT = EXTRA ? 2 : K1_VPB / 256;   // data-gradient form: no statistics rows to agree on, fewer registers per voxel
   __shared__ __attribute__((aligned(16))) float4 wl[CSQ * 4 * CDQ];
@@ -417,7 +434,9 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
   const TD* rb = a.relu_src ? reinterpret_cast<const TD*>(a.relu_src) + z * a.relu_node_stride + (int64_t)b * a.N * a.rld : nullptr;
   const bool accum = EXTRA && (a.flags & N3D_ACCUMULATE);
   const float floor_ = (a.flags & N3D_RELU_IN) ? 0.f : -INFINITY;
-  float4 x[VPT][CSQ], prev[EXTRA ? VPT : 1][CDQ], msk[EXTRA ? VPT : 1][CDQ];
+  typedef typename K1Raw<TD>::type raw_t;
+  float4 x[VPT][CSQ];
+  raw_t prev[EXTRA ? VPT : 1][CDQ], msk[EXTRA ? VPT : 1][CDQ];
   bool ok[VPT];
   int64_t vdst[VPT];      // destination voxel of slot i
   const bool sparse = EXTRA && a.sparse;
@@ -454,8 +473,8 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
     if constexpr (EXTRA) {
 #pragma unroll
       for (int q = 0; q < CDQ; ++q) {
-        prev[i][q] = accum ? ld4(db + vc * a.dld + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        msk[i][q] = rb ? ld4(rb + vc * a.rld + q * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        if (accum) prev[i][q] = k1_ldraw(db + vc * a.dld + q * 4);
+        if (rb) msk[i][q] = k1_ldraw(rb + vc * a.rld + q * 4);
       }
     }
   }
@@ -465,8 +484,10 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
     const float4 bq = a.bias ? *reinterpret_cast<const float4*>(a.bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < VPT; ++i) acc[i][q] = bq;
-    osc[q] = a.oscale ? *reinterpret_cast<const float4*>(a.oscale + (int64_t)b * (CDQ * 4) + q * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-    osh[q] = a.oshift ? *reinterpret_cast<const float4*>(a.oshift + (int64_t)b * (CDQ * 4) + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (!EXTRA) {     // (the data-gradient form carries neither output coefficients nor statistics: run_gather refuses them)
+      osc[q] = a.oscale ? *reinterpret_cast<const float4*>(a.oscale + (int64_t)b * (CDQ * 4) + q * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+      osh[q] = a.oshift ? *reinterpret_cast<const float4*>(a.oshift + (int64_t)b * (CDQ * 4) + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -496,25 +517,33 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
     for (int q = 0; q < CDQ; ++q) {
       float4 r = acc[i][q];
       if constexpr (EXTRA) {
-        if (a.relu_src) {
-          r.x = msk[i][q].x > 0.f ? r.x : 0.f; r.y = msk[i][q].y > 0.f ? r.y : 0.f; r.z = msk[i][q].z > 0.f ? r.z : 0.f; r.w = msk[i][q].w > 0.f ? r.w : 0.f;
+        if (rb) {
+          const float4 mk = k1_f4(msk[i][q]);
+          r.x = mk.x > 0.f ? r.x : 0.f; r.y = mk.y > 0.f ? r.y : 0.f; r.z = mk.z > 0.f ? r.z : 0.f; r.w = mk.w > 0.f ? r.w : 0.f;
         }
-        r.x += prev[i][q].x; r.y += prev[i][q].y; r.z += prev[i][q].z; r.w += prev[i][q].w;
+        if (accum) {
+          const float4 pv = k1_f4(prev[i][q]);
+          r.x += pv.x; r.y += pv.y; r.z += pv.z; r.w += pv.w;
+        }
       }
       if (ok[i]) {
-        if (a.oscale) {      // (the statistics of this pass, if any, are those of the stored values)
-          r.x = fmaf(osc[q].x, r.x, osh[q].x); r.y = fmaf(osc[q].y, r.y, osh[q].y); r.z = fmaf(osc[q].z, r.z, osh[q].z); r.w = fmaf(osc[q].w, r.w, osh[q].w);
+        if constexpr (!EXTRA) {
+          if (a.oscale) {      // (the statistics of this pass, if any, are those of the stored values)
+            r.x = fmaf(osc[q].x, r.x, osh[q].x); r.y = fmaf(osc[q].y, r.y, osh[q].y); r.z = fmaf(osc[q].z, r.z, osh[q].z); r.w = fmaf(osc[q].w, r.w, osh[q].w);
+          }
         }
-        if (a.nostore) {}
+        if (!EXTRA && a.nostore) {}
         else if (FLAT_OK && a.flat) st4(stage + ((t >> 6) * 64 + (t & 63)) * (CDQ * 4) + q * 4, r);
         else st4(db + vdst[i] * a.dld + q * 4, r);
-        s1[q * 4] += r.x; s1[q * 4 + 1] += r.y; s1[q * 4 + 2] += r.z; s1[q * 4 + 3] += r.w;
-        s2[q * 4] = fmaf(r.x, r.x, s2[q * 4]); s2[q * 4 + 1] = fmaf(r.y, r.y, s2[q * 4 + 1]);
-        s2[q * 4 + 2] = fmaf(r.z, r.z, s2[q * 4 + 2]); s2[q * 4 + 3] = fmaf(r.w, r.w, s2[q * 4 + 3]);
+        if constexpr (!EXTRA) {
+          s1[q * 4] += r.x; s1[q * 4 + 1] += r.y; s1[q * 4 + 2] += r.z; s1[q * 4 + 3] += r.w;
+          s2[q * 4] = fmaf(r.x, r.x, s2[q * 4]); s2[q * 4 + 1] = fmaf(r.y, r.y, s2[q * 4 + 1]);
+          s2[q * 4 + 2] = fmaf(r.z, r.z, s2[q * 4 + 2]); s2[q * 4 + 3] = fmaf(r.w, r.w, s2[q * 4 + 3]);
+        }
       }
     }
     if constexpr (FLAT_OK) {
-      if (a.flat && !a.nostore) {
+      if (a.flat && !(!EXTRA && a.nostore)) {
         // the wave's 64 voxels (base + i*256 + lane) are one contiguous run of the dense destination
         const int wave = t >> 6, lane = t & 63;
         const int64_t v0 = (int64_t)blockIdx.x * (VPT * 256) + i * 256 + wave * 64;
@@ -545,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void conv_k1_kernel(K1Args a) {
       }
     }
   }
-  if (a.stats) {
+  if (!EXTRA && a.stats) {
     const int wave = t >> 6, lane = t & 63;
     // (four channels per wave sum, wave_classsum4_f: row r of the wave ends up with channel {0, 2, 1, 3}[r] of the quad)
     const int sel = classsum4_sel(lane);
@@ -1950,7 +1979,7 @@ static int run_gather(const n3d_conv_geom* g, bool data_grad, const float* src, 
         if (q.sparse) q.flat = 0;
       }
       const bool extra = (flags & N3D_ACCUMULATE) || relu_src || q.up;
-      N3D_CHECK_ARG(!(extra && stats), "conv(1x1x1): statistics together with accumulate / relu mask are not supported");
+      N3D_CHECK_ARG(!(extra && (stats || q.oscale || q.nostore)), "conv(1x1x1): statistics / output coefficients together with accumulate / relu mask are not supported");
       // node-planar operands: node k of a tensor starts k * (B * voxels * pitch) elements behind node 0
       q.src_node_stride = src_planar ? (int64_t)g->B * q.N * sld : 0;
       q.dst_node_stride = dst_planar ? (int64_t)g->B * q.N * dld : 0;

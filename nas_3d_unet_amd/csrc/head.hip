@@ -49,10 +49,13 @@ struct HeadFwdArgs {
 };
 
 // thread = voxel; lanes walk consecutive voxels (x: Ci * sizeof(TX) contiguous bytes per voxel, p / t: strided per channel)
-template <typename TX, int CIQ>
+// NCO: output channels computed per voxel -- 3 = exactly three (the reference's out_channels, config.yml: no fourth channel of zero
+// weights, no run-time channel tests), HEAD_COMAX = any count up to four
+template <typename TX, int CIQ, int NCO>
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
   N3D_CHAIN_PRIO();
   constexpr int CI = CIQ * 4;
+  constexpr bool ALL = NCO != HEAD_COMAX;     // every computed channel is a real one
   __shared__ float wsm[HEAD_COMAX][CI];
   __shared__ double red[HEAD_COMAX * 3][4];
   const int b = blockIdx.y, tid = threadIdx.x;
@@ -61,22 +64,22 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
     wsm[co][ci] = co < a.Co ? a.w[co * CI + ci] * (a.gate ? a.gate[b * CI + ci] : 1.f) : 0.f;
   }
   __syncthreads();
-  float bias[HEAD_COMAX];
+  float bias[NCO];
 #pragma unroll
-  for (int co = 0; co < HEAD_COMAX; ++co) bias[co] = co < a.Co ? a.bias[co] : 0.f;
+  for (int co = 0; co < NCO; ++co) bias[co] = (ALL || co < a.Co) ? a.bias[co] : 0.f;
   const TX* xb = reinterpret_cast<const TX*>(a.x) + (int64_t)b * a.N * a.xld;
   int64_t qoff[CIQ];
 #pragma unroll
   for (int q = 0; q < CIQ; ++q) qoff[q] = head_quad_off(q, a.qn, a.xns);
   float spt[HEAD_COMAX], sp[HEAD_COMAX], st[HEAD_COMAX];
 #pragma unroll
-  for (int co = 0; co < HEAD_COMAX; ++co) spt[co] = sp[co] = st[co] = 0.f;
+  for (int co = 0; co < HEAD_COMAX; ++co) spt[co] = sp[co] = st[co] = 0.f;     // (a channel that is not computed stays 0)
   const int64_t v0 = (int64_t)blockIdx.x * HEAD_CHUNK;
   // every operand of the workgroup's four voxel rounds is requested before the first use (predicated, no early exit: a `break` in
   // the loop kept each round's loads behind the previous round's stores -- 2.6 TB/s on a 37 MB pass)
   constexpr int NK = HEAD_CHUNK / 256;
   float4 xqs[NK][CIQ];
-  float tvs[NK][HEAD_COMAX];
+  float tvs[NK][NCO];
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const int64_t v = v0 + tid + k * 256;
@@ -84,17 +87,17 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
 #pragma unroll
     for (int q = 0; q < CIQ; ++q) xqs[k][q] = ld4(xb + vc * a.xld + qoff[q]);
 #pragma unroll
-    for (int co = 0; co < HEAD_COMAX; ++co) tvs[k][co] = (a.t && co < a.Co) ? a.t[b * a.tsb + co * a.tsc + vc * a.tsv] : 0.f;
+    for (int co = 0; co < NCO; ++co) tvs[k][co] = (a.t && (ALL || co < a.Co)) ? a.t[b * a.tsb + co * a.tsc + vc * a.tsv] : 0.f;
   }
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const int64_t v = v0 + tid + k * 256;
     if (v >= a.N) break;
     const float4 (&xq)[CIQ] = xqs[k];
-    const float (&tv)[HEAD_COMAX] = tvs[k];
-    float z[HEAD_COMAX];
+    const float (&tv)[NCO] = tvs[k];
+    float z[NCO];
 #pragma unroll
-    for (int co = 0; co < HEAD_COMAX; ++co) {
+    for (int co = 0; co < NCO; ++co) {
       float s = bias[co];
 #pragma unroll
       for (int q = 0; q < CIQ; ++q) {
@@ -104,8 +107,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
       z[co] = s;
     }
 #pragma unroll
-    for (int co = 0; co < HEAD_COMAX; ++co) {
-      if (co < a.Co) {
+    for (int co = 0; co < NCO; ++co) {
+      if (ALL || co < a.Co) {
         const float pr = 1.0f / (1.0f + expf(-z[co]));
         if (a.p) a.p[b * a.psb + co * a.psc + v * a.psv] = pr;
         if (a.logits) a.logits[b * a.psb + co * a.psc + v * a.psv] = z[co];
@@ -170,10 +173,11 @@ struct HeadBwdArgs {
 
 // thread = voxel.  d logit = dp * p * (1 - p) with p recomputed from x (no saved activations are read);
 // dx[ci] = gate[ci] * sum_co W[co][ci] * dlogit[co];  dW[co][ci] = gate[ci] * sum_v dlogit[co] * x[ci];  dbias[co] = sum_v dlogit[co]
-template <typename TX, typename TD, int CIQ>
+template <typename TX, typename TD, int CIQ, int NCO>     // NCO: as head_fwd_kernel
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   N3D_CHAIN_PRIO();
   constexpr int CI = CIQ * 4, NV = HEAD_COMAX * CI + HEAD_COMAX;
+  constexpr bool ALL = NCO != HEAD_COMAX;
   __shared__ float wsm[HEAD_COMAX][CI];
   __shared__ float gsm[CI];
   __shared__ float red[4][NV];
@@ -184,12 +188,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   }
   if (tid < CI) gsm[tid] = a.gate ? a.gate[b * CI + tid] : 1.f;
   __syncthreads();
-  float bias[HEAD_COMAX], k2[HEAD_COMAX], k0[HEAD_COMAX];
+  float bias[NCO], k2[NCO], k0[NCO];
 #pragma unroll
-  for (int co = 0; co < HEAD_COMAX; ++co) {
-    bias[co] = co < a.Co ? a.bias[co] : 0.f;
+  for (int co = 0; co < NCO; ++co) {
+    bias[co] = (ALL || co < a.Co) ? a.bias[co] : 0.f;
     k2[co] = k0[co] = 0.f;
-    if (a.sums && co < a.Co) {
+    if (a.sums && (ALL || co < a.Co)) {
       // d loss / d p = -(1/BC) * (2 t den - num) / den^2   (loss.py:13-14), as n3d_dice_bwd
       const int i = b * a.Co + co;
       const double num = 2.0 * a.sums[i * 3] + a.smooth, den = a.sums[i * 3 + 1] + a.sums[i * 3 + 2] + a.smooth;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   int64_t qoff[CIQ], dqoff[CIQ];
 #pragma unroll
   for (int q = 0; q < CIQ; ++q) { qoff[q] = head_quad_off(q, a.qn, a.xns); dqoff[q] = head_quad_off(q, a.qn, a.dxns); }
-  float acc[HEAD_COMAX][CI], accb[HEAD_COMAX];
+  float acc[HEAD_COMAX][CI], accb[HEAD_COMAX];     // (a channel that is not computed stays 0 and folds away)
 #pragma unroll
   for (int co = 0; co < HEAD_COMAX; ++co) {
     accb[co] = 0.f;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   // the four voxel rounds' input operands are requested before the first use (as head_fwd_kernel)
   constexpr int NK = HEAD_CHUNK / 256;
   float4 xqs[NK][CIQ];
-  float gin[NK][HEAD_COMAX];
+  float gin[NK][NCO];
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const int64_t v = v0 + tid + k * 256;
@@ -222,9 +226,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
 #pragma unroll
     for (int q = 0; q < CIQ; ++q) xqs[k][q] = ld4(xb + vc * a.xld + qoff[q]);
 #pragma unroll
-    for (int co = 0; co < HEAD_COMAX; ++co) {
+    for (int co = 0; co < NCO; ++co) {
       gin[k][co] = 0.f;
-      if (co < a.Co) gin[k][co] = a.sums ? a.t[b * a.tsb + co * a.tsc + vc * a.tsv] : a.dp[b * a.dsb + co * a.dsc + vc * a.dsv];
+      if (ALL || co < a.Co) gin[k][co] = a.sums ? a.t[b * a.tsb + co * a.tsc + vc * a.tsv] : a.dp[b * a.dsb + co * a.dsc + vc * a.dsv];
     }
   }
 #pragma unroll
@@ -232,20 +236,20 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     const int64_t v = v0 + tid + k * 256;
     if (v >= a.N) break;
     const float4 (&xq)[CIQ] = xqs[k];
-    float gp[HEAD_COMAX];
+    float gp[NCO];
 #pragma unroll
-    for (int co = 0; co < HEAD_COMAX; ++co) {
+    for (int co = 0; co < NCO; ++co) {
       gp[co] = 0.f;
-      if (co < a.Co) gp[co] = a.sums ? fmaf(k2[co], gin[k][co], k0[co]) : gin[k][co];
+      if (ALL || co < a.Co) gp[co] = a.sums ? fmaf(k2[co], gin[k][co], k0[co]) : gin[k][co];
     }
     float4 prevq[CIQ];
     if (a.accumulate) {
 #pragma unroll
       for (int q = 0; q < CIQ; ++q) prevq[q] = ld4(dxb + v * a.dxld + dqoff[q]);
     }
-    float dl[HEAD_COMAX];
+    float dl[NCO];
 #pragma unroll
-    for (int co = 0; co < HEAD_COMAX; ++co) {
+    for (int co = 0; co < NCO; ++co) {
       float s = bias[co];
 #pragma unroll
       for (int q = 0; q < CIQ; ++q) {
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
       float o[4] = {0.f, 0.f, 0.f, 0.f};
       const float xe[4] = {xq[q].x, xq[q].y, xq[q].z, xq[q].w};
 #pragma unroll
-      for (int co = 0; co < HEAD_COMAX; ++co) {
+      for (int co = 0; co < NCO; ++co) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           o[e] = fmaf(wsm[co][q * 4 + e], dl[co], o[e]);      // wsm already carries the gate
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   const int sel = classsum4_sel(lane);
   const bool wr = (lane & 15) == 0;
 #pragma unroll
-  for (int co = 0; co < HEAD_COMAX; ++co) {
+  for (int co = 0; co < NCO; ++co) {
 #pragma unroll
     for (int ci = 0; ci < CI; ci += 4) {
       const float s = wave_classsum4_f<1>(acc[co][ci], acc[co][ci + 1], acc[co][ci + 2], acc[co][ci + 3]);
@@ -309,13 +313,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
 template <typename TX>
 static bool launch_head_fwd(const HeadFwdArgs& a, int B, hipStream_t s) {
   const dim3 grid((unsigned)a.rows, (unsigned)B), blk(256);
+  const bool three = a.Co == 3;
   switch (a.Ci / 4) {
-    case 1: hipLaunchKernelGGL((head_fwd_kernel<TX, 1>), grid, blk, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((head_fwd_kernel<TX, 2>), grid, blk, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((head_fwd_kernel<TX, 3>), grid, blk, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((head_fwd_kernel<TX, 4>), grid, blk, 0, s, a); break;
-    case 6: hipLaunchKernelGGL((head_fwd_kernel<TX, 6>), grid, blk, 0, s, a); break;
-    case 8: hipLaunchKernelGGL((head_fwd_kernel<TX, 8>), grid, blk, 0, s, a); break;
+    case 1: if (three) hipLaunchKernelGGL((head_fwd_kernel<TX, 1, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_fwd_kernel<TX, 1, HEAD_COMAX>), grid, blk, 0, s, a); break;
+    case 2: if (three) hipLaunchKernelGGL((head_fwd_kernel<TX, 2, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_fwd_kernel<TX, 2, HEAD_COMAX>), grid, blk, 0, s, a); break;
+    case 3: if (three) hipLaunchKernelGGL((head_fwd_kernel<TX, 3, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_fwd_kernel<TX, 3, HEAD_COMAX>), grid, blk, 0, s, a); break;
+    case 4: if (three) hipLaunchKernelGGL((head_fwd_kernel<TX, 4, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_fwd_kernel<TX, 4, HEAD_COMAX>), grid, blk, 0, s, a); break;
+    case 6: if (three) hipLaunchKernelGGL((head_fwd_kernel<TX, 6, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_fwd_kernel<TX, 6, HEAD_COMAX>), grid, blk, 0, s, a); break;
+    case 8: if (three) hipLaunchKernelGGL((head_fwd_kernel<TX, 8, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_fwd_kernel<TX, 8, HEAD_COMAX>), grid, blk, 0, s, a); break;
     default: return false;
   }
   return true;
@@ -324,13 +329,14 @@ static bool launch_head_fwd(const HeadFwdArgs& a, int B, hipStream_t s) {
 template <typename TX, typename TD>
 static bool launch_head_bwd(const HeadBwdArgs& a, int B, hipStream_t s) {
   const dim3 grid((unsigned)a.chunks_per_sample, (unsigned)B), blk(256);
+  const bool three = a.Co == 3;
   switch (a.Ci / 4) {
-    case 1: hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 1>), grid, blk, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 2>), grid, blk, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 3>), grid, blk, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 4>), grid, blk, 0, s, a); break;
-    case 6: hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 6>), grid, blk, 0, s, a); break;
-    case 8: hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 8>), grid, blk, 0, s, a); break;
+    case 1: if (three) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 1, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 1, HEAD_COMAX>), grid, blk, 0, s, a); break;
+    case 2: if (three) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 2, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 2, HEAD_COMAX>), grid, blk, 0, s, a); break;
+    case 3: if (three) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 3, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 3, HEAD_COMAX>), grid, blk, 0, s, a); break;
+    case 4: if (three) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 4, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 4, HEAD_COMAX>), grid, blk, 0, s, a); break;
+    case 6: if (three) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 6, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 6, HEAD_COMAX>), grid, blk, 0, s, a); break;
+    case 8: if (three) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 8, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 8, HEAD_COMAX>), grid, blk, 0, s, a); break;
     default: return false;
   }
   return true;
