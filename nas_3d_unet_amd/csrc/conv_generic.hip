@@ -1809,6 +1809,15 @@ int mfma_bwd_quad_try(BwdOne* c0, BwdOne* c1, hipStream_t s);
 int mfma_conv_multi_try(int n, const n3d_conv_geom* const* g, const bool* dg, const float* const* src, const int64_t* sld, const float* const* w,
                         const float* const* bias, float* const* dst, const int64_t* dld, const int* flags, const float* const* gate,
                         double* const* stats, void* const* ws, const size_t* wsb, hipStream_t s);
+struct VoxCall {  // one conv of a multi-conv launch of the vox family (same layout as in conv_mfma.hip)
+  const n3d_conv_geom* g; bool data_grad; const float* src; int64_t sld; const float* w; const float* bias; float* dst; int64_t dld; int flags;
+  const float* in_gate; const float* relu_src; const float* out_gate; double* stats; void* ws; size_t ws_bytes;
+};
+int mfma_vox_multi_try(int n, const VoxCall* c, hipStream_t s);
+// forward call -> gather operands (forward conv = gather with data_grad=false, transposed forward = data_grad=true: run_gather's convention)
+static VoxCall vox_call_fwd(const n3d_conv_fwd_call* c) {
+  return VoxCall{c->g, c->transposed != 0, c->x, c->xld, c->w, c->bias, c->y, c->yld, c->flags, c->in_gate, nullptr, nullptr, c->stats, c->ws, c->ws_bytes};
+}
 int mfma_conv_pair_try(const n3d_conv_geom* g0, bool dg0, const float* src0, int64_t sld0, const float* w0, const float* bias0, float* dst0,
                        int64_t dld0, int flags0, const float* gate0, double* stats0, void* ws0, size_t wsb0, const n3d_conv_geom* g1, bool dg1,
                        const float* src1, int64_t sld1, const float* w1, const float* bias1, float* dst1, int64_t dld1, int flags1,
@@ -2367,6 +2376,12 @@ int n3d_conv_fwd2(const n3d_conv_fwd_call* c0, const n3d_conv_fwd_call* c1, void
     N3D_CHECK_ARG(cs[i]->x && cs[i]->w && cs[i]->y, "conv_fwd2: null pointers");
   }
   if (!((c0->flags | c1->flags) & N3D_NO_MFMA) && !c0->g->depthwise && !c1->g->depthwise) {
+    {
+      const VoxCall vc[2] = {vox_call_fwd(c0), vox_call_fwd(c1)};
+      const int r = mfma_vox_multi_try(2, vc, (hipStream_t)stream);
+      if (r < 0) return r;
+      if (r == 1) return N3D_OK;
+    }
     // forward conv = gather with data_grad=false; transposed forward = gather with data_grad=true (run_gather convention)
     const int r = mfma_conv_pair_try(c0->g, c0->transposed != 0, c0->x, c0->xld, c0->w, c0->bias, c0->y, c0->yld, c0->flags, c0->in_gate,
                                      c0->stats, c0->ws, c0->ws_bytes, c1->g, c1->transposed != 0, c1->x, c1->xld, c1->w, c1->bias, c1->y,
@@ -2398,7 +2413,12 @@ int n3d_conv_fwdN(const n3d_conv_fwd_call* calls, int n, void* stream) {
       flags[i] = c->flags; gate[i] = c->in_gate; stats[i] = c->stats; ws[i] = c->ws; wsb[i] = c->ws_bytes;
     }
     if (mf) {
-      const int r = mfma_conv_multi_try(n, g, dg, src, sld, w, bias, dst, dld, flags, gate, stats, ws, wsb, (hipStream_t)stream);
+      VoxCall vc[4];
+      for (int i = 0; i < n; ++i) vc[i] = vox_call_fwd(&calls[i]);
+      int r = mfma_vox_multi_try(n, vc, (hipStream_t)stream);
+      if (r < 0) return r;
+      if (r == 1) return N3D_OK;
+      r = mfma_conv_multi_try(n, g, dg, src, sld, w, bias, dst, dld, flags, gate, stats, ws, wsb, (hipStream_t)stream);
       if (r < 0) return r;
       if (r == 1) return N3D_OK;
     }
@@ -2429,6 +2449,17 @@ int n3d_conv_bwd_data2(const n3d_conv_bwd_call* c0, const n3d_conv_bwd_call* c1,
   }
   if (pair) {
     // data gradient of a conv = gather with data_grad=true, of a transposed conv = gather with data_grad=false (run_gather convention)
+    {
+      VoxCall vc[2];
+      for (int i = 0; i < 2; ++i) {
+        const n3d_conv_bwd_call* c = cs[i];
+        vc[i] = VoxCall{c->g, !c->transposed, c->dy, c->dyld, c->w, nullptr, c->dx, c->dxld, c->flags_data & ~N3D_RELU_IN, nullptr, c->relu_src,
+                        c->out_gate, nullptr, c->ws_data, c->ws_data_bytes};
+      }
+      const int r = mfma_vox_multi_try(2, vc, (hipStream_t)stream);
+      if (r < 0) return r;
+      if (r == 1) return N3D_OK;
+    }
     const PairExtras x0{c0->relu_src, c0->rld, c0->out_gate}, x1{c1->relu_src, c1->rld, c1->out_gate};
     const int r = mfma_conv_pair_try(c0->g, !c0->transposed, c0->dy, c0->dyld, c0->w, nullptr, c0->dx, c0->dxld, c0->flags_data & ~N3D_RELU_IN, nullptr,
                                      nullptr, c0->ws_data, c0->ws_data_bytes, c1->g, !c1->transposed, c1->dy, c1->dyld, c1->w, nullptr, c1->dx,

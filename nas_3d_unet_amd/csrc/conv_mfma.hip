@@ -706,23 +706,25 @@ extern "C" int n3d_debug_vox_stamps2(unsigned long long* host, int n) {
 #ifndef VOX_LB
 #define VOX_LB 2
 #endif
+// The kernel body is a device function of (arguments, workgroup index, workgroup count, LDS base): conv_vox64_kernel runs it for
+// one conv per launch, conv_vox_multi_kernel for several independent convs in one launch (each with its own range of workgroups)
 template <int C, int TD, int DIL, int NW>
-__global__ __launch_bounds__(64 * NW, VOX_LB) void conv_vox64_kernel(VxArgs a) {
-  N3D_CHAIN_PRIO();
+__device__ __forceinline__ void vox64_body(const VxArgs& a, const int wg_raw, const int nwg, float4* const vlds) {
   constexpr int Q = C / 4, GH = 4 * NW, GW = 16;
   constexpr int LD = TD + 2 * DIL, LH = GH + 2 * DIL, LW = GW + 2 * DIL;
   constexpr int PLANE = LH * LW, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64, QSTRIDE = LD * PSTRIDE;
   constexpr int NW4 = 27 * C * Q, NWI = (NW4 + 63) / 64;  // float4 count of the packed weights
-  extern __shared__ __attribute__((aligned(16))) float4 vlds[];  // tile [Q][LD][PSTRIDE >= LH*LW], then weights [27][C][Q]
+  // vlds: tile [Q][LD][PSTRIDE >= LH*LW], then weights [27][C][Q]
   float4* tile = vlds;
   float4* wl = vlds + Q * QSTRIDE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // XCD-aware placement: workgroup ids are dealt round-robin to the 8 XCDs (private L2 each); remap so that every
   // XCD works on one contiguous run of tiles (a D-slab of one sample) and the halo re-reads of neighbouring tiles
-  // hit that XCD's L2 instead of being fetched from HBM once per XCD.
-  int wg = blockIdx.x;
+  // hit that XCD's L2 instead of being fetched from HBM once per XCD.  (Inside a multi-conv launch wg_raw counts from the conv's first
+  // workgroup: indices with equal wg_raw & 7 still share one physical XCD.)
+  int wg = wg_raw;
   {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
   }
   const int b = wg / a.tiles;
@@ -981,6 +983,13 @@ __global__ __launch_bounds__(64 * NW, VOX_LB) void conv_vox64_kernel(VxArgs a) {
 #endif
 }
 
+template <int C, int TD, int DIL, int NW>
+__global__ __launch_bounds__(64 * NW, VOX_LB) void conv_vox64_kernel(VxArgs a) {
+  N3D_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) float4 vlds[];
+  vox64_body<C, TD, DIL, NW>(a, blockIdx.x, gridDim.x, vlds);
+}
+
 // ------------------------------------------------------------------------------------------------
 // vox_s2: the same 4x4x1-MFMA scheme for the STRIDE-2 3x3x3 convs with C = 4 / 8 (down_conv / down_dil_conv forward
 // and the data gradient of up_conv / up_dil_conv, which is a strided gather of dy):
@@ -999,21 +1008,19 @@ struct Vs2Args {
 };
 
 template <int C, int TD, int DIL>
-__global__ __launch_bounds__(64, 2) void conv_vox_s2_kernel(Vs2Args a) {
-  N3D_CHAIN_PRIO();
+__device__ __forceinline__ void vox_s2_body(const Vs2Args& a, const int wg_raw, const int nwg, float4* const vlds) {
   constexpr int Q = C / 4;
   constexpr int LD = 2 * (TD - 1) + 2 * DIL + 1, LH = 7 + 2 * DIL, LW = 31 + 2 * DIL;
   constexpr int HW = (LW + 1) / 2, RW = 2 * HW;              // half-row (one W parity) and row pitch in float4
   constexpr int PLANE = LH * RW, NPOS = (PLANE + 63) / 64, PSTRIDE = NPOS * 64, QSTRIDE = LD * PSTRIDE;
   constexpr int NW4 = 27 * C * Q, NWI = (NW4 + 63) / 64;
   constexpr int ROT = ((2 * RW * 4) % 64) / 4;               // voxels odd lane rows are rotated by (bank-conflict-free reads)
-  extern __shared__ __attribute__((aligned(16))) float4 vlds[];
   float4* tile = vlds;
   float4* wl = vlds + Q * QSTRIDE;
   const int lane = threadIdx.x;
-  int wg = blockIdx.x;
-  {  // XCD-aware placement (see conv_vox64_kernel)
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+  int wg = wg_raw;
+  {  // XCD-aware placement (see vox64_body)
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
   }
   const int b = wg / a.tiles;
@@ -1161,6 +1168,13 @@ __global__ __launch_bounds__(64, 2) void conv_vox_s2_kernel(Vs2Args a) {
       }
     }
   }
+}
+
+template <int C, int TD, int DIL>
+__global__ __launch_bounds__(64, 2) void conv_vox_s2_kernel(Vs2Args a) {
+  N3D_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) float4 vlds[];
+  vox_s2_body<C, TD, DIL>(a, blockIdx.x, gridDim.x, vlds);
 }
 
 struct Vs2Plan { bool ok; int C, td, dil, tiles; size_t lds; };
@@ -1452,6 +1466,113 @@ static int launch_vox_c(VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
   if (p.td == 4) return launch_vox_t<C, 4, 2>(a, p, B, s);
   if (p.td == 2) return launch_vox_t<C, 2, 2>(a, p, B, s);
   return launch_vox_t<C, 1, 2>(a, p, B, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Several INDEPENDENT single-wave convs of the vox family in one launch -- the plain-conv primitives of a supernet node at the C = 8
+// level of 64^3 patches (cell.py:76-81: dil_conv / conv / down_conv / down_dil_conv on 2 x 8 x 32^3): each is 512-1024 one-wave
+// workgroups, one per SIMD at best, so a launch lasts one fill + 216-432 MFMAs + one store whatever the chip has idle; four of them
+// back to back cost 4 x 6.5 us, side by side ~9 (profiles/r05_search_table.log).  Workgroup L belongs to the job whose range
+// [start[k], start[k+1]) holds it and runs that job's kernel BODY (vox64_body / vox_s2_body) on the job's own arguments: results, statistics
+// rows and workspace use are exactly those of the single launches.  Only the one-plane tile forms (38-59 VGPRs) are folded: the
+// deep-tile instantiations hold 130-190 registers and would set the occupancy of every job in the launch.
+// ------------------------------------------------------------------------------------------------
+struct VoxMultiArgs { VxArgs x[4]; Vs2Args s[4]; int kind[4]; int start[5]; };
+enum { VOXK_S1_D1 = 0, VOXK_S1_D2 = 1, VOXK_S2_D1 = 2, VOXK_S2_D2 = 3, VOXK_S2_TD2_D1 = 4, VOXK_S2_TD2_D2 = 5 };
+
+template <int C>
+__global__ __launch_bounds__(64, 2) void conv_vox_multi_kernel(VoxMultiArgs q) {
+  N3D_CHAIN_PRIO();
+  extern __shared__ __attribute__((aligned(16))) float4 vlds[];
+  const int L = blockIdx.x;
+  const int k = (L >= q.start[1]) + (L >= q.start[2]) + (L >= q.start[3]);
+  // the job's descriptor is copied out of the kernel arguments by a switch (static indexing), then ONE body per kind
+  VxArgs xa; Vs2Args sa; int kind, s0, s1;
+  switch (k) {
+    case 0: xa = q.x[0]; sa = q.s[0]; kind = q.kind[0]; s0 = q.start[0]; s1 = q.start[1]; break;
+    case 1: xa = q.x[1]; sa = q.s[1]; kind = q.kind[1]; s0 = q.start[1]; s1 = q.start[2]; break;
+    case 2: xa = q.x[2]; sa = q.s[2]; kind = q.kind[2]; s0 = q.start[2]; s1 = q.start[3]; break;
+    default: xa = q.x[3]; sa = q.s[3]; kind = q.kind[3]; s0 = q.start[3]; s1 = q.start[4]; break;
+  }
+  const int wg = L - s0, nwg = s1 - s0;
+  switch (kind) {
+    case VOXK_S1_D1: vox64_body<C, 1, 1, 1>(xa, wg, nwg, vlds); break;
+    case VOXK_S1_D2: vox64_body<C, 1, 2, 1>(xa, wg, nwg, vlds); break;
+    case VOXK_S2_D1: vox_s2_body<C, 1, 1>(sa, wg, nwg, vlds); break;
+    case VOXK_S2_D2: vox_s2_body<C, 1, 2>(sa, wg, nwg, vlds); break;
+    case VOXK_S2_TD2_D1: if constexpr (C == 4) vox_s2_body<4, 2, 1>(sa, wg, nwg, vlds); break;
+    default: if constexpr (C == 4) vox_s2_body<4, 2, 2>(sa, wg, nwg, vlds); break;
+  }
+}
+
+// one conv of a multi launch as the entry points hand it over (forward-type gather: data_grad as run_gather's)
+struct VoxCall {
+  const n3d_conv_geom* g; bool data_grad; const float* src; int64_t sld; const float* w; const float* bias; float* dst; int64_t dld; int flags;
+  const float* in_gate; const float* relu_src; const float* out_gate; double* stats; void* ws; size_t ws_bytes;
+};
+
+// kind of the job, -1 = this conv is not one the multi launch folds (pure function of geometry, flags and alignment)
+static int vox_multi_kind(const VoxCall& c, int* tiles, size_t* lds) {
+  if (c.flags & (N3D_SRC_BF16 | N3D_DST_BF16 | N3D_NO_MFMA | N3D_RELU_IN)) return -1;
+  if (c.in_gate || c.relu_src || c.out_gate || c.sld % 4 != 0 || c.dld % 4 != 0 || !aligned16(c.src) || !aligned16(c.dst)) return -1;
+  const Vs2Plan v2 = vs2_plan(c.g, c.data_grad);
+  if (v2.ok) {
+    if (v2.td == 2 && v2.C != 4) return -1;
+    *tiles = v2.tiles; *lds = v2.lds;
+    return (v2.td == 2 ? VOXK_S2_TD2_D1 : VOXK_S2_D1) + (v2.dil == 2 ? 1 : 0);
+  }
+  if (vup_plan(c.g, c.data_grad).ok) return -1;
+  const VxPlan v = vx_plan(c.g);
+  if (!v.ok || v.td != 1 || v.nw != 1) return -1;
+  *tiles = v.tiles; *lds = v.lds;
+  return v.dil == 2 ? VOXK_S1_D2 : VOXK_S1_D1;
+}
+
+// n = 2..4 independent convs (distinct destinations) in one launch; 1 = launched, 0 = not foldable (nothing touched), < 0 error
+int mfma_vox_multi_try(int n, const VoxCall* c, hipStream_t s) {
+  if (n < 2 || n > 4) return 0;
+  int kind[4], tiles[4];
+  size_t lds = 0;
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    size_t l = 0;
+    kind[i] = vox_multi_kind(c[i], &tiles[i], &l);
+    if (kind[i] < 0 || c[i].g->Ci != c[0].g->Ci) return 0;
+    if (!c[i].ws || c[i].ws_bytes < (size_t)27 * c[i].g->Ci * c[i].g->Ci * 4) return 0;
+    for (int j = 0; j < i; ++j) if (c[j].dst == c[i].dst) return 0;
+    if (l > lds) lds = l;
+    total += (int64_t)tiles[i] * c[i].g->B;
+  }
+  if (total >= (1ll << 31)) return 0;
+  const void* zp = zero_page_ptr();
+  if (!zp) return 0;
+  const int C = c[0].g->Ci;
+  VoxMultiArgs q;
+  int at = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int k = i < n ? i : n - 1;      // unused slots repeat the last job (never selected: their range is empty)
+    const VoxCall& cc = c[k];
+    const n3d_conv_geom* g = cc.g;
+    float* wq = (float*)cc.ws;
+    const bool s2 = kind[k] >= VOXK_S2_D1;
+    if (i < n && !(cc.flags & N3D_PREPACKED))
+      hipLaunchKernelGGL(pack_vox_kernel, dim3((unsigned)cdiv(27 * C * C, 256)), dim3(256), 0, s, cc.w, wq, C, (!s2 && cc.data_grad) ? 1 : 0);
+    VxArgs& x = q.x[i];
+    x.src = cc.src; x.sld = cc.sld; x.dst = cc.dst; x.dld = cc.dld; x.wq = wq; x.bias = cc.bias; x.D = g->Di; x.H = g->Hi; x.W = g->Wi;
+    x.flags = cc.flags; x.stats = cc.stats; x.rows_per_sample = tiles[k]; x.tiles = tiles[k]; x.zero_page = zp;
+    Vs2Args& v = q.s[i];
+    v.src = cc.src; v.sld = cc.sld; v.D = g->Di; v.H = g->Hi; v.W = g->Wi; v.dst = cc.dst; v.dld = cc.dld; v.oD = g->Do; v.oH = g->Ho; v.oW = g->Wo;
+    v.wq = wq; v.bias = cc.bias; v.flags = cc.flags; v.stats = cc.stats; v.rows_per_sample = tiles[k]; v.tiles = tiles[k]; v.zero_page = zp;
+    q.kind[i] = kind[k];
+    q.start[i] = at;
+    if (i < n) at += tiles[k] * g->B;
+  }
+  q.start[4] = at;
+  if (C == 4) hipLaunchKernelGGL(conv_vox_multi_kernel<4>, dim3((unsigned)at), dim3(64), lds, s, q);
+  else hipLaunchKernelGGL(conv_vox_multi_kernel<8>, dim3((unsigned)at), dim3(64), lds, s, q);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("conv(vox multi) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+  return 1;
 }
 
 // ------------------------------------------------------------------------------------------------

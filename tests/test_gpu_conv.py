@@ -241,6 +241,8 @@ def test_depthwise_family(c, stride, transposed, shape):
     ((16, 16, 3, 1, 1, False, (16, 16, 16)), (16, 16, 3, 1, 2, False, (16, 16, 16))),  # K-split-4 plan
     ((96, 32, 1, 2, 1, False, (8, 8, 8)), (48, 32, 1, 1, 1, False, (4, 4, 4))),      # the two preprocess convs of a cell
     ((8, 8, 3, 1, 1, False, (8, 8, 16)), (64, 64, 3, 1, 1, False, (4, 4, 4))),       # not foldable: falls back to two launches
+    ((8, 8, 3, 1, 2, False, (8, 8, 16)), (8, 8, 3, 2, 1, False, (8, 8, 32))),        # two one-wave-tile convs: one multi-conv launch
+    ((4, 4, 3, 2, 2, False, (8, 8, 32)), (4, 4, 3, 1, 1, False, (8, 8, 16))),        # the same at C = 4 (two-plane stride-2 tile)
 ])
 def test_conv_pairs_match_single_calls(specA, specB):
     """n3d_conv_fwd2 / n3d_conv_bwd_both2 == the two single calls (and torch CPU), whatever launch grouping libn3d picks."""
@@ -306,6 +308,8 @@ def test_conv_pairs_match_single_calls(specA, specB):
     [(64, 64, 3, 1, 1, (4, 4, 4)), (64, 64, 3, 1, 2, (4, 4, 4)), (64, 64, 3, 1, 1, (4, 4, 4)), (64, 64, 3, 1, 2, (4, 4, 4))],   # one launch
     [(32, 32, 3, 1, 1, (8, 8, 8)), (32, 32, 3, 1, 2, (8, 8, 8)), (32, 32, 3, 2, 1, (16, 16, 16))],                            # three
     [(16, 16, 3, 1, 1, (16, 16, 16)), (8, 8, 3, 1, 1, (8, 8, 16)), (64, 64, 3, 1, 1, (4, 4, 4))],                             # not foldable
+    [(8, 8, 3, 1, 2, (16, 16, 16)), (8, 8, 3, 2, 1, (16, 16, 32)), (8, 8, 3, 1, 1, (16, 16, 16)), (8, 8, 3, 2, 2, (16, 16, 32))],  # one multi-conv launch
+    [(4, 4, 3, 1, 1, (8, 8, 16)), (4, 4, 3, 2, 1, (8, 8, 32)), (4, 4, 3, 2, 2, (7, 8, 32))],                                  # C = 4 kinds
 ])
 def test_conv_fwdN_matches_torch(specs):
     """n3d_conv_fwdN (up to four forward convs, as few launches as they fold into) against torch CPU, statistics included"""
@@ -331,3 +335,50 @@ def test_conv_fwdN_matches_torch(specs):
         assert_close(y.t, yc, 2e-5, "y (fwdN)")
         if stats is not None:
             assert_close(stats.sum(dim=1).cpu().numpy()[..., 0], yc.double().sum(dim=(2, 3, 4)).numpy(), 1e-5, "stats (fwdN)")
+
+
+@pytest.mark.parametrize("C", [4, 8])
+def test_multi_conv_launch_is_bit_identical_to_single_launches(C):
+    """The one-wave-tile 3x3x3 convs of a supernet node folded into ONE launch (conv_vox_multi_kernel: each conv's kernel body on its
+    own range of workgroups) give the single launches' outputs and statistics rows bit for bit -- forward (n3d_conv_fwdN / fwd2, one
+    conv accumulating into a pre-filled tensor) and data gradients (n3d_conv_bwd_data2)."""
+    from nas_3d_unet_amd import kernels as K
+    dev = torch.device("cuda")
+    B = 2
+    specs = [(1, 2, (16, 16, 16), 0), (2, 1, (16, 16, 32), K.ACCUMULATE), (1, 1, (16, 16, 16), 0), (2, 2, (16, 16, 32), 0)]
+    for n in (2, 3, 4):
+        calls, singles = [], []
+        for si, (stride, dil, shape, fl) in enumerate(specs[:n]):
+            g = K.conv_geom(B, shape[0], shape[1], shape[2], C, C, 3, stride, dil, dil)
+            x = K.as_view(torch.from_numpy(_mk((B, C) + shape, 150 + si)).to(dev).contiguous(memory_format=torch.channels_last_3d))
+            w, b = torch.from_numpy(_mk((C, C, 3, 3, 3), 160 + si, 0.1)).to(dev), torch.from_numpy(_mk((C,), 170 + si, 0.1)).to(dev)
+            so = tuple(d // stride for d in shape)
+            base = torch.from_numpy(_mk((B, C) + so, 180 + si)).to(dev)
+            rows = K.conv_stats_rows(g, False)
+            ys, sts = [], []
+            for _ in range(2):
+                y = K.as_view(K.empty_ndhwc(B, C, *so, dev)); y.t.copy_(base)
+                ys.append(y); sts.append(torch.zeros((B, rows, C, 2), dtype=torch.float64, device=dev))
+            calls.append((g, x, w, b, ys[0], fl, None, sts[0], False))
+            K.conv_fwd(g, x, w, b, ys[1], fl, None, sts[1], False)
+            singles.append((ys[1], sts[1]))
+        K.conv_fwdN(calls) if n > 2 else K.conv_fwd2(calls)
+        for c, (y1, st1) in zip(calls, singles):
+            assert torch.equal(c[4].t, y1.t) and torch.equal(c[7], st1), f"forward, {n} convs"
+    # data gradients of two stride-1 convs (the kernel on mirrored, transposed weights), one accumulating
+    pair, single = [], []
+    for si, (dil, fl) in enumerate(((1, K.ACCUMULATE), (2, 0))):
+        shape = (16, 16, 16)
+        g = K.conv_geom(B, *shape, C, C, 3, 1, dil, dil)
+        dy = K.as_view(torch.from_numpy(_mk((B, C) + shape, 190 + si)).to(dev).contiguous(memory_format=torch.channels_last_3d))
+        w = torch.from_numpy(_mk((C, C, 3, 3, 3), 195 + si, 0.1)).to(dev)
+        base = torch.from_numpy(_mk((B, C) + shape, 197 + si)).to(dev)
+        t = []
+        for _ in range(2):
+            d = K.as_view(K.empty_ndhwc(B, C, *shape, dev)); d.t.copy_(base); t.append(d)
+        pair.append((g, dy, w, t[0], fl, None, None, False))
+        K.conv_bwd_data(g, dy, w, t[1], fl, None, None, False)
+        single.append(t[1])
+    K.conv_bwd_data2(pair)
+    for c, t1 in zip(pair, single):
+        assert torch.equal(c[3].t, t1.t), "data gradients"
