@@ -1790,7 +1790,7 @@ int vox_wgrad_s2_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
 struct Wg16Args;
 int wgrad_tile16_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                      float* partial, size_t avail_floats, int* nchunks_out, float** pbias_out, hipStream_t s);
-bool wgrad_tile16_plan(const n3d_conv_geom* g, int* chunks, int* tiles_per_wg);
+bool wgrad_tile16_plan(const n3d_conv_geom* g, int* chunks, int* tiles_per_wg, int* tw_out = nullptr);
 int mfma_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                    float* partial, float* pbias, size_t avail_floats, int* nchunks_out, int* ntiles_out, hipStream_t s,
                    Wg16Args* prepared = nullptr);

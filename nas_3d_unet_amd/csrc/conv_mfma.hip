@@ -2928,9 +2928,12 @@ struct WgT16Args {
   const void* zero_page;
 };
 
-template <int DIL>
+// TW: tile width -- 16 (a 2 x 4 x 16 tile) or 8 (4 x 4 x 8: the 8^3 level of 128^3 patches, 64 channels, where a 16-wide tile does not
+// fit and the gather kernel took 25 us for 226 MFLOP); either way 32 groups of four W-consecutive voxels
+template <int DIL, int TW = 16>
 __global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
-  constexpr int TD = 2, TH = 4, TW = 16;
+  constexpr int TH = 4, GPR = TW / 4, TD = 32 / GPR / TH;      // groups per row; tile depth
+  static_assert(TD * TH * GPR == 32, "32 voxel groups per tile");
   constexpr int LD = TD + 2 * DIL, LH = TH + 2 * DIL, LW = TW + 2 * DIL, NV = LD * LH * LW;
   constexpr int NP = NV * 4, NIT = (NP + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float4 wt16[];   // X halo tile: [NIT * 256] float4, voxel-major 64-byte records
@@ -2961,7 +2964,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
       const float* dyb = a.dy + ((int64_t)b * N + ((int64_t)d0 * H + h0) * W + w0 + kk) * a.dyld + cot * 16 + m;
 #pragma unroll
       for (int gi = 0; gi < 32; ++gi) {
-        const int row = gi >> 2, xq = gi & 3, z = row >> 2, y = row & 3;
+        const int row = gi / GPR, xq = gi % GPR, z = row >> 2, y = row & 3;
         bv[gi] = dyb[(((int64_t)z * H + y) * W + xq * 4) * a.dyld];
       }
     }
@@ -2996,7 +2999,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
         const float* ap = xl + abase + (((kd * DIL) * LH + kh * DIL) * LW + kw * DIL) * 16;
 #pragma unroll
         for (int gi = 0; gi < 32; ++gi) {
-          const int row = gi >> 2, xq = gi & 3, z = row >> 2, y = row & 3;
+          const int row = gi / GPR, xq = gi % GPR, z = row >> 2, y = row & 3;
           float av = ap[((z * LH + y) * LW + xq * 4) * 16];
           av = fmaxf(av, floor_) * gq;
           acc[t][gi & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[gi], acc[t][gi & 1], 0, 0, 0);
@@ -3024,13 +3027,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
 // plan of the LDS-tile weight gradient: chunks (grid.x) and tiles per workgroup; false = shape not served.
 // Served: 3x3x3 stride-1 convs (dilation 1 / 2) with channel counts multiples of 16 (<= 64) on tileable volumes with enough tiles x
 // channel tiles to fill a good part of the chip -- below that the K-split kernels (one launch for data + weight gradient) win.
-bool wgrad_tile16_plan(const n3d_conv_geom* g, int* chunks, int* tiles_per_wg) {
+bool wgrad_tile16_plan(const n3d_conv_geom* g, int* chunks, int* tiles_per_wg, int* tw_out) {
   constexpr bool off = false;
   constexpr int min_units = 64;   // (256 -> 64: step 1.89 -> 1.86 ms)
   if (off || g->depthwise || g->k != 3 || g->stride != 1 || g->Ci % 16 != 0 || g->Co % 16 != 0 || g->Ci > 64 || g->Co > 64) return false;
   if ((g->dil != 1 && g->dil != 2) || g->pad != g->dil) return false;
-  if (g->Wi % 16 != 0 || g->Hi % 4 != 0 || g->Di % 2 != 0) return false;
-  const int64_t tiles_total = (int64_t)(g->Wi / 16) * (g->Hi / 4) * (g->Di / 2) * g->B;
+  // tile: 2 x 4 x 16 voxels, or 4 x 4 x 8 on volumes 8 wide
+  const int tw = g->Wi % 16 == 0 ? 16 : 8, td = tw == 16 ? 2 : 4;
+  if (g->Wi % tw != 0 || g->Hi % 4 != 0 || g->Di % td != 0) return false;
+  if (tw_out) *tw_out = tw;
+  const int64_t tiles_total = (int64_t)(g->Wi / tw) * (g->Hi / 4) * (g->Di / td) * g->B;
   const int combos = (g->Ci / 16) * (g->Co / 16);
   if (tiles_total * combos < min_units || tiles_total >= (1 << 30)) return false;
   int64_t nx = N3D_WGT16_MAX_WG / combos;
@@ -3045,8 +3051,9 @@ bool wgrad_tile16_plan(const n3d_conv_geom* g, int* chunks, int* tiles_per_wg) {
 // 1 = launched (partial slabs [chunks][27 * tci * tco][256] at `partial`, bias rows [chunks][tco][16] behind them), 0 = shape not served
 int wgrad_tile16_try(const n3d_conv_geom* g, const float* x, int64_t xld, const float* dy, int64_t dyld, int flags, const float* in_gate,
                      float* partial, size_t avail_floats, int* nchunks_out, float** pbias_out, hipStream_t s) {
-  int chunks = 0, tpw = 0;
-  if (!wgrad_tile16_plan(g, &chunks, &tpw)) return 0;
+  int chunks = 0, tpw = 0, tw = 16;
+  if (!wgrad_tile16_plan(g, &chunks, &tpw, &tw)) return 0;
+  const int td = tw == 16 ? 2 : 4;
   if (xld % 4 != 0 || !aligned16(x) || (flags & (N3D_SRC_BF16 | N3D_DST_BF16 | N3D_NO_MFMA))) return 0;
   const int tci = g->Ci / 16, tco = g->Co / 16;
   const size_t slabs = (size_t)chunks * 27 * tci * tco;
@@ -3054,16 +3061,21 @@ int wgrad_tile16_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   WgT16Args a;
   a.x = x; a.xld = xld; a.dy = dy; a.dyld = dyld; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.B = g->B; a.flags = flags; a.in_gate = in_gate;
   a.partial = partial; a.pbias = partial + slabs * 256;
-  a.tiles_per_sample = (g->Wi / 16) * (g->Hi / 4) * (g->Di / 2); a.tiles_total = a.tiles_per_sample * g->B; a.tiles_per_wg = tpw;
+  a.tiles_per_sample = (g->Wi / tw) * (g->Hi / 4) * (g->Di / td); a.tiles_total = a.tiles_per_sample * g->B; a.tiles_per_wg = tpw;
   a.Ci = g->Ci; a.Co = g->Co;
   a.zero_page = zero_page_ptr();
   if (!a.zero_page) return 0;
   const int d = g->dil;
-  const int nv = (2 + 2 * d) * (4 + 2 * d) * (16 + 2 * d);
+  const int nv = (td + 2 * d) * (4 + 2 * d) * (tw + 2 * d);
   const size_t shm = (size_t)((nv * 4 + 255) / 256) * 256 * 16;
   const dim3 grid((unsigned)chunks, (unsigned)(tci * tco));
-  if (d == 1) hipLaunchKernelGGL(wgrad_tile16_kernel<1>, grid, dim3(256), shm, s, a);
-  else hipLaunchKernelGGL(wgrad_tile16_kernel<2>, grid, dim3(256), shm, s, a);
+  if (tw == 16) {
+    if (d == 1) hipLaunchKernelGGL((wgrad_tile16_kernel<1, 16>), grid, dim3(256), shm, s, a);
+    else hipLaunchKernelGGL((wgrad_tile16_kernel<2, 16>), grid, dim3(256), shm, s, a);
+  } else {
+    if (d == 1) hipLaunchKernelGGL((wgrad_tile16_kernel<1, 8>), grid, dim3(256), shm, s, a);
+    else hipLaunchKernelGGL((wgrad_tile16_kernel<2, 8>), grid, dim3(256), shm, s, a);
+  }
   *nchunks_out = chunks; *pbias_out = a.pbias;
   return 1;
 }
@@ -3122,7 +3134,7 @@ int mfma_bwd_quad_ok(const n3d_conv_geom* g0, bool t0, const n3d_conv_geom* g1, 
   // a conv whose weight gradient the LDS-tile kernel serves keeps it in every schedule (the same arithmetic whether the weight
   // gradients are deferred to the side stream or launched in place)
   int ch = 0, tpw = 0;
-  if ((!t0 && wgrad_tile16_plan(g0, &ch, &tpw)) || (!t1 && wgrad_tile16_plan(g1, &ch, &tpw))) return 0;
+  if ((!t0 && wgrad_tile16_plan(g0, &ch, &tpw, nullptr)) || (!t1 && wgrad_tile16_plan(g1, &ch, &tpw, nullptr))) return 0;
   const G16Plan p0 = g16_plan(g0, !t0), p1 = g16_plan(g1, !t1);
   return p0.ok && p1.ok && p0.ksplit == p1.ksplit && p0.ksplit != 1;
 }

@@ -33,6 +33,9 @@ CASES = [
     (32, 32, 3, 1, 1, False, 2, (16, 16, 16)),   # 64 tiles x 4 channel tiles: the LDS-tile weight gradient on 32 channels
     (32, 32, 3, 1, 2, False, 2, (16, 16, 16)),
     (32, 16, 3, 1, 1, False, 2, (16, 16, 32)),   # Ci != Co
+    (64, 64, 3, 1, 1, False, 2, (8, 8, 8)),      # the 8^3 level of 128^3 patches: LDS-tile weight gradient on 4 x 4 x 8 tiles (8 tiles x 16 channel tiles)
+    (64, 64, 3, 1, 2, False, 2, (8, 8, 8)),
+    (64, 32, 3, 1, 1, False, 3, (12, 8, 8)),     # ... ragged: 9 tiles x 8 channel tiles, workgroups span samples
     (16, 48, 3, 1, 1, False, 1, (16, 32, 32)),
     # tile16_up: transposed forward / stride-2 data gradient of the 16-channel level with >= 32k destination voxels
     (16, 16, 3, 2, 1, True, 2, (8, 16, 32)),
