@@ -39,3 +39,5 @@ def run(inputs, steps=20, warmup=4):
 
 for inp in ((1,), (0, 1), (0,), (), (1,)):
     run(inp)
+# round 5 (one box): (1,) 11.03 / (0, 1) 11.52 / (0,) 11.24 / () 12.03 / (1,) 11.06 ms; choosing the inputs per cell kind (down / up cells, via a
+# plan -> inputs callable) moved nothing: down (0,) + up (1,) 11.01, every other mix 11.24-11.67
