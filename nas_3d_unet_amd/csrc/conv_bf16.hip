@@ -54,6 +54,7 @@ struct Vx16Args {
   double* stats; int rows_per_sample;
   int tiles;
   const void* zero_page;
+  FastDiv fT, fTw, fTh;      // workgroup -> (sample, tile column, tile row) without run-time divisions: see VxArgs (conv_mfma.hip)
 };
 
 __device__ __forceinline__ f32x4 mfma_bf16_4x4x4(const uint2 a, const uint2 b, const f32x4 c) {
@@ -88,13 +89,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
   }
-  const int b = wg / a.tiles;
-  const int tile_id = wg - b * a.tiles;
-  const int tw_n = a.W / GW, th_n = a.H / GH;
-  int bx = tile_id;
-  const int w0 = (bx % tw_n) * GW; bx /= tw_n;
-  const int h0 = (bx % th_n) * GH;
-  const int d0 = (bx / th_n) * TD;
+  uint32_t ub, utile, ubx, uw, ud, uh;
+  a.fT.divmod((uint32_t)wg, ub, utile);
+  a.fTw.divmod(utile, ubx, uw);
+  a.fTh.divmod(ubx, ud, uh);
+  const int b = (int)ub, tile_id = (int)utile;
+  const int w0 = (int)uw * GW, h0 = (int)uh * GH, d0 = (int)ud * TD;
   const int64_t N = (int64_t)a.D * a.H * a.W;
   const bf16_t* srcb = a.src + (int64_t)b * N * a.sld;
   const int j = lane & 3;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
         const int ch = (lane & 1) * 2 + (lane >> 1);
         // row of the TD = 4 tile this half stands for: its D block is 2 * (d0 / 8) + sr, i.e. tile id + sr * (tiles per D block) + ...
         int row = tile_id * NW + wave;
-        if (SR == 2) row = (((d0 / 4) + sr) * th_n + h0 / GH) * tw_n + w0 / GW;
+        if (SR == 2) row = (((d0 / 4) + sr) * (int)a.fTh.d + (int)uh) * (int)a.fTw.d + (int)uw;     // (fTh.d / fTw.d: tile rows / columns)
         double* o = a.stats + (((int64_t)b * a.rows_per_sample + row) * C + hf * 4 + ch) * 2;
         reinterpret_cast<double2*>(o)[0] = make_double2((double)v1, (double)v2);
       }
@@ -375,6 +375,7 @@ struct Vs2bArgs {
   bf16_t* dst; int64_t dld; int oD, oH, oW;
   const bf16_t* wq; const float* bias; int flags;
   double* stats; int rows_per_sample; int tiles; const void* zero_page;
+  FastDiv fT, fTw, fTh;
 };
 
 template <int C, int TD, int DIL>
@@ -395,13 +396,12 @@ __global__ __launch_bounds__(64, 2) void conv_vox_s2b_kernel(Vs2bArgs a) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
   }
-  const int b = wg / a.tiles;
-  const int tile_id = wg - b * a.tiles;
-  const int tw_n = a.oW / 16, th_n = a.oH / 4;
-  int bx = tile_id;
-  const int w0 = (bx % tw_n) * 16; bx /= tw_n;
-  const int h0 = (bx % th_n) * 4;
-  const int d0 = (bx / th_n) * TD;
+  uint32_t ub, utile, ubx, uw, ud, uh;
+  a.fT.divmod((uint32_t)wg, ub, utile);
+  a.fTw.divmod(utile, ubx, uw);
+  a.fTh.divmod(ubx, ud, uh);
+  const int b = (int)ub, tile_id = (int)utile;
+  const int w0 = (int)uw * 16, h0 = (int)uh * 4, d0 = (int)ud * TD;
   const int64_t Ns = (int64_t)a.D * a.H * a.W, Nd = (int64_t)a.oD * a.oH * a.oW;
   const bf16_t* srcb = a.src + (int64_t)b * Ns * a.sld;
   bf16_t* dstb = a.dst + (int64_t)b * Nd * a.dld;
@@ -504,6 +504,7 @@ struct VupbArgs {
   bf16_t* dst; int64_t dld;
   const bf16_t* wq; const float* bias; int flags;
   double* stats; int rows_per_sample; int tiles; const void* zero_page;
+  FastDiv fT, fTw, fTh;
 };
 __host__ __device__ constexpr int vupb_count(int dil, int s) { return dil == 2 ? 1 : (s == 0 ? 2 : (s == 1 ? 1 : 0)); }
 __host__ __device__ constexpr int vupb_p(int dil, int s, int i) { return dil == 2 ? 0 : (s == 0 ? i : 1); }
@@ -525,13 +526,12 @@ __global__ __launch_bounds__(64, 2) void conv_vox_upb_kernel(VupbArgs a) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
   }
-  const int b = wg / a.tiles;
-  const int tile_id = wg - b * a.tiles;
-  const int tw_n = a.W / 16, th_n = a.H / 4;
-  int bx = tile_id;
-  const int w0 = (bx % tw_n) * 16; bx /= tw_n;
-  const int h0 = (bx % th_n) * 4;
-  const int d0 = bx / th_n;
+  uint32_t ub, utile, ubx, uw, ud, uh;
+  a.fT.divmod((uint32_t)wg, ub, utile);
+  a.fTw.divmod(utile, ubx, uw);
+  a.fTh.divmod(ubx, ud, uh);
+  const int b = (int)ub, tile_id = (int)utile;
+  const int w0 = (int)uw * 16, h0 = (int)uh * 4, d0 = (int)ud;
   const int64_t Ns = (int64_t)a.D * a.H * a.W;
   const int oH = 2 * a.H, oW = 2 * a.W;
   const bf16_t* srcb = a.src + (int64_t)b * Ns * a.sld;
@@ -771,12 +771,14 @@ int vox16_conv_try(const n3d_conv_geom* g, bool data_grad, const void* src, int6
     Vx16Args a;
     a.src = (const bf16_t*)src; a.sld = sld; a.dst = (bf16_t*)dst; a.dld = dld; a.wq = (const bf16_t*)ws; a.bias = bias;
     a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.flags = flags; a.stats = stats; a.rows_per_sample = v.tiles * v.nw; a.tiles = v.tiles; a.zero_page = zp;
+    a.fT = FastDiv((uint32_t)v.tiles); a.fTw = FastDiv((uint32_t)(g->Wi / 16)); a.fTh = FastDiv((uint32_t)(g->Hi / (4 * v.nw)));
     const bool p2 = v.C == 4 && sld == 4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
     if (p2 && v.nw == 1 && v.td == 4 && g->Di % 8 == 0 && (int64_t)v.tiles * g->B / 2 >= 2048) {
       const bool acc = flags & N3D_ACCUMULATE;
       // dense image, many tiles: 8 output planes per tile (the D halo is re-fetched every 8 planes instead of every 4: 24.4 -> 22.1 us at
       // (2,4,128^3)); the kernel still writes one statistics row per 4 planes, in the rows and the order of the 4-plane plan
       a.tiles = v.tiles / 2;
+      a.fT = FastDiv((uint32_t)a.tiles);
       const size_t pstride2 = ((size_t)(4 + 2 * g->dil) * 10 + 63) / 64 * 64, wslots = (((size_t)27 * 16 * 2 + 15) / 16 + 63) / 64 * 64;
       const size_t lds8 = ((size_t)(8 + 2 * g->dil) * pstride2 + wslots) * 16;
       if (g->dil == 1) {
@@ -796,6 +798,7 @@ int vox16_conv_try(const n3d_conv_geom* g, bool data_grad, const void* src, int6
     Vs2bArgs a;
     a.src = (const bf16_t*)src; a.sld = sld; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.dst = (bf16_t*)dst; a.dld = dld; a.oD = g->Do; a.oH = g->Ho; a.oW = g->Wo;
     a.wq = (const bf16_t*)ws; a.bias = bias; a.flags = flags; a.stats = stats; a.rows_per_sample = v.tiles; a.tiles = v.tiles; a.zero_page = zp;
+    a.fT = FastDiv((uint32_t)v.tiles); a.fTw = FastDiv((uint32_t)(g->Wo / 16)); a.fTh = FastDiv((uint32_t)(g->Ho / 4));
     const dim3 grid(v.tiles * g->B), blk(64);
     if (v.C == 4) {
       if (v.td == 2) { if (v.dil == 1) hipLaunchKernelGGL((conv_vox_s2b_kernel<4, 2, 1>), grid, blk, v.lds, s, a); else hipLaunchKernelGGL((conv_vox_s2b_kernel<4, 2, 2>), grid, blk, v.lds, s, a); }
@@ -808,6 +811,7 @@ int vox16_conv_try(const n3d_conv_geom* g, bool data_grad, const void* src, int6
     VupbArgs a;
     a.src = (const bf16_t*)src; a.sld = sld; a.D = g->Do; a.H = g->Ho; a.W = g->Wo; a.dst = (bf16_t*)dst; a.dld = dld;
     a.wq = (const bf16_t*)ws; a.bias = bias; a.flags = flags; a.stats = stats; a.rows_per_sample = v.tiles; a.tiles = v.tiles; a.zero_page = zp;
+    a.fT = FastDiv((uint32_t)v.tiles); a.fTw = FastDiv((uint32_t)(g->Wo / 16)); a.fTh = FastDiv((uint32_t)(g->Ho / 4));
     const dim3 grid(v.tiles * g->B), blk(64);
     if (v.C == 4) { if (v.dil == 1) hipLaunchKernelGGL((conv_vox_upb_kernel<4, 1>), grid, blk, v.lds, s, a); else hipLaunchKernelGGL((conv_vox_upb_kernel<4, 2>), grid, blk, v.lds, s, a); }
     else { if (v.dil == 1) hipLaunchKernelGGL((conv_vox_upb_kernel<8, 1>), grid, blk, v.lds, s, a); else hipLaunchKernelGGL((conv_vox_upb_kernel<8, 2>), grid, blk, v.lds, s, a); }

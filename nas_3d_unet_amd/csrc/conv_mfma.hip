@@ -656,6 +656,9 @@ struct VxArgs {
   double* stats; int rows_per_sample;
   int tiles;            // tiles per sample
   const void* zero_page; // 16 zero bytes in device memory
+  // workgroup index -> (sample, tile row, tile column) without run-time integer divisions (three of them, ~0.2 us of scalar work in front of
+  // the first fill instruction of every wave): by tiles per sample, tile columns (W / 16) and tile rows (H / (4 NW))
+  FastDiv fT, fTw, fTh;
 };
 
 // Wq[tap][cd][cs]; forward: cd=co, cs=ci, tap'=tap; data gradient: cd=ci, cs=co, tap'=26-tap
@@ -727,13 +730,12 @@ __device__ __forceinline__ void vox64_body(const VxArgs& a, const int wg_raw, co
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
   }
-  const int b = wg / a.tiles;
-  const int tile_id = wg - b * a.tiles;
-  const int tw_n = a.W / GW, th_n = a.H / GH;
-  int bx = tile_id;
-  const int w0 = (bx % tw_n) * GW; bx /= tw_n;
-  const int h0 = (bx % th_n) * GH;
-  const int d0 = (bx / th_n) * TD;
+  uint32_t ub, utile, ubx, uw, ud, uh;
+  a.fT.divmod((uint32_t)wg, ub, utile);
+  a.fTw.divmod(utile, ubx, uw);
+  a.fTh.divmod(ubx, ud, uh);
+  const int b = (int)ub, tile_id = (int)utile;
+  const int w0 = (int)uw * GW, h0 = (int)uh * GH, d0 = (int)ud * TD;
   const int64_t N = (int64_t)a.D * a.H * a.W;
   const float* srcb = a.src + (int64_t)b * N * a.sld;
   const int j = lane & 3;
@@ -1005,6 +1007,7 @@ struct Vs2Args {
   float* dst; int64_t dld; int oD, oH, oW;         // output tensor (= ceil(in / 2))
   const float* wq; const float* bias; int flags;
   double* stats; int rows_per_sample; int tiles; const void* zero_page;
+  FastDiv fT, fTw, fTh;      // tiles per sample, tile columns (oW / 16), tile rows (oH / 4): see VxArgs
 };
 
 template <int C, int TD, int DIL>
@@ -1023,13 +1026,12 @@ __device__ __forceinline__ void vox_s2_body(const Vs2Args& a, const int wg_raw, 
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
   }
-  const int b = wg / a.tiles;
-  const int tile_id = wg - b * a.tiles;
-  const int tw_n = a.oW / 16, th_n = a.oH / 4;
-  int bx = tile_id;
-  const int w0 = (bx % tw_n) * 16; bx /= tw_n;
-  const int h0 = (bx % th_n) * 4;
-  const int d0 = (bx / th_n) * TD;
+  uint32_t ub, utile, ubx, uw, ud, uh;
+  a.fT.divmod((uint32_t)wg, ub, utile);
+  a.fTw.divmod(utile, ubx, uw);
+  a.fTh.divmod(ubx, ud, uh);
+  const int b = (int)ub, tile_id = (int)utile;
+  const int w0 = (int)uw * 16, h0 = (int)uh * 4, d0 = (int)ud * TD;
   const int64_t Ns = (int64_t)a.D * a.H * a.W, Nd = (int64_t)a.oD * a.oH * a.oW;
   const float* srcb = a.src + (int64_t)b * Ns * a.sld;
   float* dstb = a.dst + (int64_t)b * Nd * a.dld;
@@ -1225,6 +1227,7 @@ struct VupArgs {
   float* dst; int64_t dld;                         // output tensor (2D x 2H x 2W)
   const float* wq; const float* bias; int flags;
   double* stats; int rows_per_sample; int tiles; const void* zero_page;
+  FastDiv fT, fTw, fTh;      // tiles per sample, tile columns (W / 16), tile rows (H / 4): see VxArgs
 };
 
 __host__ __device__ constexpr int vup_count(int dil, int s) { return dil == 2 ? 1 : (s == 0 ? 2 : (s == 1 ? 1 : 0)); }
@@ -1247,13 +1250,12 @@ __global__ __launch_bounds__(64, 2) void conv_vox_up_kernel(VupArgs a) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
   }
-  const int b = wg / a.tiles;
-  const int tile_id = wg - b * a.tiles;
-  const int tw_n = a.W / 16, th_n = a.H / 4;
-  int bx = tile_id;
-  const int w0 = (bx % tw_n) * 16; bx /= tw_n;
-  const int h0 = (bx % th_n) * 4;
-  const int d0 = bx / th_n;
+  uint32_t ub, utile, ubx, uw, ud, uh;
+  a.fT.divmod((uint32_t)wg, ub, utile);
+  a.fTw.divmod(utile, ubx, uw);
+  a.fTh.divmod(ubx, ud, uh);
+  const int b = (int)ub, tile_id = (int)utile;
+  const int w0 = (int)uw * 16, h0 = (int)uh * 4, d0 = (int)ud;
   const int64_t Ns = (int64_t)a.D * a.H * a.W;
   const int oH = 2 * a.H, oW = 2 * a.W;
   const float* srcb = a.src + (int64_t)b * Ns * a.sld;
@@ -1447,6 +1449,7 @@ static VxPlan vx_plan(const n3d_conv_geom* g) {
 template <int C, int TD, int DIL>
 static int launch_vox_t(VxArgs& a, const VxPlan& p, int B, hipStream_t s) {
   a.tiles = p.tiles;
+  a.fT = FastDiv((uint32_t)p.tiles); a.fTw = FastDiv((uint32_t)(a.W / 16)); a.fTh = FastDiv((uint32_t)(a.H / (4 * p.nw)));
   a.zero_page = zero_page_ptr();
   if (!a.zero_page) return 0;
   if constexpr (C == 4 && TD == 4) {
@@ -1560,9 +1563,11 @@ int mfma_vox_multi_try(int n, const VoxCall* c, hipStream_t s) {
     VxArgs& x = q.x[i];
     x.src = cc.src; x.sld = cc.sld; x.dst = cc.dst; x.dld = cc.dld; x.wq = wq; x.bias = cc.bias; x.D = g->Di; x.H = g->Hi; x.W = g->Wi;
     x.flags = cc.flags; x.stats = cc.stats; x.rows_per_sample = tiles[k]; x.tiles = tiles[k]; x.zero_page = zp;
+    x.fT = FastDiv((uint32_t)tiles[k]); x.fTw = FastDiv((uint32_t)(g->Wi / 16)); x.fTh = FastDiv((uint32_t)(g->Hi / 4));
     Vs2Args& v = q.s[i];
     v.src = cc.src; v.sld = cc.sld; v.D = g->Di; v.H = g->Hi; v.W = g->Wi; v.dst = cc.dst; v.dld = cc.dld; v.oD = g->Do; v.oH = g->Ho; v.oW = g->Wo;
     v.wq = wq; v.bias = cc.bias; v.flags = cc.flags; v.stats = cc.stats; v.rows_per_sample = tiles[k]; v.tiles = tiles[k]; v.zero_page = zp;
+    v.fT = FastDiv((uint32_t)tiles[k]); v.fTw = FastDiv((uint32_t)(g->Wo / 16)); v.fTh = FastDiv((uint32_t)(g->Ho / 4));
     q.kind[i] = kind[k];
     q.start[i] = at;
     if (i < n) at += tiles[k] * g->B;
@@ -2299,7 +2304,7 @@ int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const flo
 //   DG: data gradient = the same conv with mirrored taps (weights packed transposed by the pack kernel).
 // ------------------------------------------------------------------------------------------------
 template <int DIL, bool DG>
-__global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const void* zero_page, int tiles) {
+__global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const void* zero_page, int tiles, FastDiv fT, FastDiv fTw, FastDiv fTh) {
   N3D_CHAIN_PRIO();
   constexpr int TD = 2, TH = 4, TW = 16;
   constexpr int LD = TD + 2 * DIL, LH = TH + 2 * DIL, LW = TW + 2 * DIL, NV = LD * LH * LW;
@@ -2313,10 +2318,13 @@ __global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const voi
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
   }
-  const int b = wg / tiles, tid = wg - b * tiles;
+  uint32_t ub, utile, ubx, uw, ud, uh;       // (by tiles per sample, tile columns, tile rows: no run-time divisions, see VxArgs)
+  fT.divmod((uint32_t)wg, ub, utile);
+  fTw.divmod(utile, ubx, uw);
+  fTh.divmod(ubx, ud, uh);
+  const int b = (int)ub, tid = (int)utile;
   const int D = a.Dd, H = a.Hd, W = a.Wd;
-  const int tw_n = W / TW, th_n = H / TH;
-  const int w0 = (tid % tw_n) * TW, h0 = ((tid / tw_n) % th_n) * TH, d0 = (tid / (tw_n * th_n)) * TD;
+  const int w0 = (int)uw * TW, h0 = (int)uh * TH, d0 = (int)ud * TD;
   const int lz = wave >> 1, ly0 = (wave & 1) * 2;   // this wave: plane lz, rows ly0 and ly0 + 1 of the tile
   const int64_t N = (int64_t)D * H * W;
   const bool accum = a.flags & N3D_ACCUMULATE;
@@ -2431,7 +2439,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const voi
 // one statistics row per workgroup (512 outputs).
 // ------------------------------------------------------------------------------------------------
 template <int DIL>
-__global__ __launch_bounds__(256, 2) void conv_tile16_up_kernel(MfArgs a, const void* zero_page, int tiles) {
+__global__ __launch_bounds__(256, 2) void conv_tile16_up_kernel(MfArgs a, const void* zero_page, int tiles, FastDiv fT, FastDiv fTw, FastDiv fTh) {
   N3D_CHAIN_PRIO();
   constexpr int TH = 4, TW = 16;
   constexpr int LO = DIL == 2 ? 1 : 0;                   // source halo below (above: always 1)
@@ -2447,10 +2455,13 @@ __global__ __launch_bounds__(256, 2) void conv_tile16_up_kernel(MfArgs a, const 
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
   }
-  const int b = wg / tiles, tid = wg - b * tiles;
+  uint32_t ub, utile, ubx, uw, ud, uh;
+  fT.divmod((uint32_t)wg, ub, utile);
+  fTw.divmod(utile, ubx, uw);
+  fTh.divmod(ubx, ud, uh);
+  const int b = (int)ub, tid = (int)utile;
   const int Ds = a.Ds, Hs = a.Hs, Ws = a.Ws, Dd = a.Dd, Hd = a.Hd, Wd = a.Wd;
-  const int tw_n = Ws / TW, th_n = Hs / TH;
-  const int w0 = (tid % tw_n) * TW, h0 = ((tid / tw_n) % th_n) * TH, d0 = tid / (tw_n * th_n);
+  const int w0 = (int)uw * TW, h0 = (int)uh * TH, d0 = (int)ud;
   const int ly = wave;                                    // this wave: source row ly of the tile
   const bool accum = a.flags & N3D_ACCUMULATE;
   const float e_bias = a.bias ? a.bias[m] : 0.f;
@@ -2570,12 +2581,13 @@ static bool launch_tile16(const MfArgs& a, hipStream_t s) {
   const int nv = (2 + 2 * d) * (4 + 2 * d) * (16 + 2 * d);
   const size_t shm = (size_t)((nv * 4 + 255) / 256) * 256 * 16;
   const dim3 grid((unsigned)(tiles * a.B));
+  const FastDiv fT((uint32_t)tiles), fTw((uint32_t)(a.Wd / 16)), fTh((uint32_t)(a.Hd / 4));
   if (d == 1) {
-    if (a.dt > 0) hipLaunchKernelGGL((conv_tile16_kernel<1, false>), grid, dim3(256), shm, s, a, zp, tiles);
-    else hipLaunchKernelGGL((conv_tile16_kernel<1, true>), grid, dim3(256), shm, s, a, zp, tiles);
+    if (a.dt > 0) hipLaunchKernelGGL((conv_tile16_kernel<1, false>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
+    else hipLaunchKernelGGL((conv_tile16_kernel<1, true>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
   } else {
-    if (a.dt > 0) hipLaunchKernelGGL((conv_tile16_kernel<2, false>), grid, dim3(256), shm, s, a, zp, tiles);
-    else hipLaunchKernelGGL((conv_tile16_kernel<2, true>), grid, dim3(256), shm, s, a, zp, tiles);
+    if (a.dt > 0) hipLaunchKernelGGL((conv_tile16_kernel<2, false>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
+    else hipLaunchKernelGGL((conv_tile16_kernel<2, true>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
   }
   return true;
 }
@@ -2665,6 +2677,7 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
       Vs2Args a;
       a.src = src; a.sld = sld; a.D = g->Di; a.H = g->Hi; a.W = g->Wi; a.dst = dst; a.dld = dld; a.oD = g->Do; a.oH = g->Ho; a.oW = g->Wo;
       a.wq = wq; a.bias = bias; a.flags = flags; a.stats = stats; a.rows_per_sample = v2.tiles; a.tiles = v2.tiles; a.zero_page = zero_page_ptr();
+      a.fT = FastDiv((uint32_t)v2.tiles); a.fTw = FastDiv((uint32_t)(g->Wo / 16)); a.fTh = FastDiv((uint32_t)(g->Ho / 4));
       if (!a.zero_page) { set_error("conv(vox_s2): zero page symbol unavailable"); return N3D_ERR_HIP; }
       launch_vs2(a, v2, g->B, s);
       hipError_t e = hipGetLastError();
@@ -2685,6 +2698,7 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
       VupArgs a;
       a.src = src; a.sld = sld; a.D = g->Do; a.H = g->Ho; a.W = g->Wo; a.dst = dst; a.dld = dld;
       a.wq = wq; a.bias = bias; a.flags = flags; a.stats = stats; a.rows_per_sample = v3.tiles; a.tiles = v3.tiles; a.zero_page = zero_page_ptr();
+      a.fT = FastDiv((uint32_t)v3.tiles); a.fTw = FastDiv((uint32_t)(g->Wo / 16)); a.fTh = FastDiv((uint32_t)(g->Ho / 4));
       if (!a.zero_page) { set_error("conv(vox_up): zero page symbol unavailable"); return N3D_ERR_HIP; }
       if (v3.C == 4) { if (v3.dil == 1) hipLaunchKernelGGL((conv_vox_up_kernel<4, 1>), dim3(v3.tiles * g->B), dim3(64), v3.lds, s, a);
                        else hipLaunchKernelGGL((conv_vox_up_kernel<4, 2>), dim3(v3.tiles * g->B), dim3(64), v3.lds, s, a); }
@@ -2734,8 +2748,9 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
         const int nv = (2 + lo) * (4 + lo + 1) * (16 + lo + 1);
         const size_t shm = (size_t)((nv * 4 + 255) / 256) * 256 * 16;
         const dim3 grid((unsigned)(tiles * g->B));
-        if (d == 1) hipLaunchKernelGGL(conv_tile16_up_kernel<1>, grid, dim3(256), shm, s, a, zp, tiles);
-        else hipLaunchKernelGGL(conv_tile16_up_kernel<2>, grid, dim3(256), shm, s, a, zp, tiles);
+        const FastDiv fT((uint32_t)tiles), fTw((uint32_t)(g->Wo / 16)), fTh((uint32_t)(g->Ho / 4));      // (source grid = the o side)
+        if (d == 1) hipLaunchKernelGGL(conv_tile16_up_kernel<1>, grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
+        else hipLaunchKernelGGL(conv_tile16_up_kernel<2>, grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("conv(tile16_up) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
         return 1;
