@@ -404,7 +404,9 @@ __device__ __forceinline__ float4 k1_f4(const uint2 v) {
 // 4 -> 12 channels, bf16) and lives on the bytes it keeps in flight: with the forward form's extras compiled in (statistics, output
 // coefficients) and 256 VGPRs allowed it took 204 of them -- 2 waves per SIMD, 3.6 TB/s at 2 x 128^3; without them and held to 128:
 // 112 VGPRs, 4 waves, 6.0 TB/s (profiles/r05_k1_ab.log).  Held to 80 it spills (0.2 of peak), so the wider shapes keep 2.
-constexpr int k1_min_waves(int csq, int cdq, bool extra) { return (extra && csq * cdq <= 3) ? 4 : 2; }
+// The forward form of the 4 -> 12 conv (the stem's two passes: 213 VGPRs / 2 waves when left alone) is held to 170: 150-158 used, 3 waves,
+// 57 -> 45 us at 2 x 128^3 fp32 (0.59 -> 0.74 of 8 TB/s), bf16 output 45 -> 38; the other forward shapes spill under that cap and keep 2.
+constexpr int k1_min_waves(int csq, int cdq, bool extra) { return (extra && csq * cdq <= 3) ? 4 : ((!extra && csq == 1 && cdq == 3) ? 3 : 2); }
 template <int CSQ, int CDQ, bool EXTRA, typename TS = float, typename TD = float>   // Cs = 4 * CSQ, Cd = 4 * CDQ
 __global__ __launch_bounds__(256, k1_min_waves(CSQ, CDQ, EXTRA)) void conv_k1_kernel(K1Args a) {
   N3D_CHAIN_PRIO();
