@@ -198,7 +198,8 @@ int n3d_conv_fwd2(const n3d_conv_fwd_call* c0, const n3d_conv_fwd_call* c1, void
 /* the same for up to four calls (`calls` = array): the plain-conv primitives of a supernet node (cell.py:76-81).  One launch when
  * all are small MFMA problems of one K-split plan, or all one-plane-tile 3x3x3 convs of one channel count in {4, 8} (stride 1 or 2,
  * distinct outputs); otherwise two at a time as n3d_conv_fwd2, a leftover alone.  Results and statistics rows are those of the
- * single calls bit for bit whatever the grouping. */
+ * single calls bit for bit whatever the grouping.  Calls that are not N3D_PREPACKED should bring distinct workspaces: calls that share
+ * one are never folded (a folded launch reads every call's packed weights at once) and run one after the other. */
 int n3d_conv_fwdN(const n3d_conv_fwd_call* calls, int n, void* stream);
 
 /* The depthwise 3x3x3 convs of up to N3D_MAX_GROUP_TERMS primitives of a supernet node (one depthwise-separable primitive per

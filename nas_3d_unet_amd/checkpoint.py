@@ -18,35 +18,61 @@ from .genotype import Genotype
 
 
 # ------------------------------------------------------------------------------------------------ Adam
-def adam_state_dict(fp, lr, betas=(0.9, 0.999), eps=1e-8):
-    """torch.optim.Adam(params).state_dict() equivalent of a train.FlatParams (params in `fp.params` order)."""
+def _entries(fp, twin=None, real=None):
+    """[(offset in the flat buffers, stored shape, name | None)] in the order torch.optim.Adam(real.parameters()) numbers its parameters.
+    A trainer of a net with odd channel counts keeps the moments of the net's zero-padded TWIN (unet.PaddedTwin): its flat buffers are
+    walked in the REAL module's parameter order and every moment goes through twin.extract / twin.embed_tensor, so the checkpoint holds
+    the reference's shapes (a torch / reference checkpoint of the same net loads, and the other way round)."""
+    if twin is None:
+        return [(o, p.shape, None) for p, o in zip(fp.params, fp.offsets)]
+    off = {id(p): (o, p.shape) for p, o in zip(fp.params, fp.offsets)}
+    tp = dict(twin.twin.named_parameters())
+    out = []
+    for n, _ in real.named_parameters():
+        if n in tp and id(tp[n]) in off:
+            o, shape = off[id(tp[n])]
+            out.append((o, shape, n))
+    if len(out) != len(fp.params):
+        raise ValueError("padded twin: %d of the trainer's %d parameters have no counterpart in the module" % (len(fp.params) - len(out), len(fp.params)))
+    return out
+
+
+def adam_state_dict(fp, lr, betas=(0.9, 0.999), eps=1e-8, twin=None, real=None):
+    """torch.optim.Adam(params).state_dict() equivalent of a train.FlatParams (params in `fp.params` order; with a padded twin: in
+    `real.parameters()` order and the reference's shapes)."""
     step = int(fp.step.item())
     state = {}
-    for i, (p, o) in enumerate(zip(fp.params, fp.offsets)):
-        n = p.numel()
+    ents = _entries(fp, twin, real)
+    for i, (o, shape, name) in enumerate(ents):
+        n = int(torch.Size(shape).numel())
         if step > 0:
-            state[i] = {"step": torch.tensor(float(step)), "exp_avg": fp.exp_avg[o:o + n].view(p.shape).clone(),
-                        "exp_avg_sq": fp.exp_avg_sq[o:o + n].view(p.shape).clone()}
+            m, v = fp.exp_avg[o:o + n].view(shape), fp.exp_avg_sq[o:o + n].view(shape)
+            if name is not None:
+                m, v = twin.extract(name, m), twin.extract(name, v)
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
     group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
              "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
-             "params": list(range(len(fp.params)))}
+             "params": list(range(len(ents)))}
     return {"state": state, "param_groups": [group]}
 
 
-def load_adam_state_dict(fp, sd):
+def load_adam_state_dict(fp, sd, twin=None, real=None):
     """inverse of adam_state_dict; returns the learning rate stored in the checkpoint.
     Limit: the flat Adam keeps ONE step counter, so every parameter with state must be at the same step (true for every
     checkpoint the reference writes: all parameters receive a gradient in every step); otherwise ValueError."""
     steps = set()
     fp.exp_avg.zero_()
     fp.exp_avg_sq.zero_()
-    for i, (p, o) in enumerate(zip(fp.params, fp.offsets)):
+    for i, (o, shape, name) in enumerate(_entries(fp, twin, real)):
         st = sd["state"].get(i)
         if st is None:
             continue
-        n = p.numel()
-        fp.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1).to(fp.exp_avg.device))
-        fp.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1).to(fp.exp_avg.device))
+        n = int(torch.Size(shape).numel())
+        m, v = st["exp_avg"].to(fp.exp_avg.device), st["exp_avg_sq"].to(fp.exp_avg.device)
+        if name is not None:     # reference shapes -> the twin's (zeros at the padded entries, which Adam never moves: masked gradients)
+            m, v = twin.embed_tensor(name, m, shape), twin.embed_tensor(name, v, shape)
+        fp.exp_avg[o:o + n].copy_(m.reshape(-1))
+        fp.exp_avg_sq[o:o + n].copy_(v.reshape(-1))
         steps.add(int(float(st["step"])))
     if len(steps) > 1:
         raise ValueError("checkpoint has different Adam step counts per parameter: %s" % sorted(steps))
@@ -82,10 +108,16 @@ def _checked(trainer):
         chk()
 
 
+def _twin_of(trainer, real):
+    """(twin, real module) of a trainer that trains a padded twin, (None, None) otherwise"""
+    tw = getattr(trainer, "_twin", None)
+    return (tw, real) if tw is not None else (None, None)
+
+
 def train_state_dicts(trainer, epoch, history, best_loss):
     _checked(trainer)
     return {"epoch": epoch, "history": history, "model_param": trainer.model.state_dict(),
-            "optim": adam_state_dict(trainer.fp, trainer.lr, trainer.betas, trainer.eps),
+            "optim": adam_state_dict(trainer.fp, trainer.lr, trainer.betas, trainer.eps, *_twin_of(trainer, trainer.model)),
             "scheduler": scheduler_state_dict(trainer.scheduler), "best_loss": best_loss}
 
 
@@ -94,7 +126,7 @@ def load_train_state_dicts(trainer, sd, new_lr=False):
     trainer.model.load_state_dict(sd["model_param"])   # parameters are views of the flat buffer: copied in place
     getattr(trainer, "sync_from_module", lambda: None)()   # (a padded twin re-embeds the loaded parameters)
     if not new_lr:
-        trainer.set_lr(load_adam_state_dict(trainer.fp, sd["optim"]))
+        trainer.set_lr(load_adam_state_dict(trainer.fp, sd["optim"], *_twin_of(trainer, trainer.model)))
         load_scheduler_state_dict(trainer.scheduler, sd["scheduler"])
     return sd["epoch"] + 1, sd["history"], sd["best_loss"]
 
@@ -106,7 +138,7 @@ def search_state_dicts(trainer, epoch, geno_count, history, best_loss):
     _checked(trainer)
     return {"epoch": epoch, "geno_count": geno_count, "history": history, "model_param": trainer.model.state_dict(),
             "optim_shell": adam_state_dict(trainer.afp, trainer.lr_shell, trainer.betas, trainer.eps),
-            "optim_kernel": adam_state_dict(trainer.fp, trainer.lr_kernel, trainer.betas, trainer.eps),
+            "optim_kernel": adam_state_dict(trainer.fp, trainer.lr_kernel, trainer.betas, trainer.eps, *_twin_of(trainer, trainer.model.kernel)),
             "kernel_scheduler": scheduler_state_dict(trainer.kernel_scheduler),
             "shell_scheduler": scheduler_state_dict(trainer.shell_scheduler), "best_loss": best_loss}
 
@@ -117,7 +149,7 @@ def load_search_state_dicts(trainer, sd, new_lr=False):
     getattr(trainer, "sync_from_module", lambda: None)()   # (a padded twin re-embeds the loaded parameters)
     if not new_lr:
         trainer.set_shell_lr(load_adam_state_dict(trainer.afp, sd["optim_shell"]))
-        trainer.set_kernel_lr(load_adam_state_dict(trainer.fp, sd["optim_kernel"]))
+        trainer.set_kernel_lr(load_adam_state_dict(trainer.fp, sd["optim_kernel"], *_twin_of(trainer, trainer.model.kernel)))
         load_scheduler_state_dict(trainer.shell_scheduler, sd["shell_scheduler"])
         load_scheduler_state_dict(trainer.kernel_scheduler, sd["kernel_scheduler"])
     return sd["epoch"] + 1, sd["geno_count"], sd["history"], sd["best_loss"]

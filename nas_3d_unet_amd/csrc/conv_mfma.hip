@@ -1542,7 +1542,12 @@ int mfma_vox_multi_try(int n, const VoxCall* c, hipStream_t s) {
     kind[i] = vox_multi_kind(c[i], &tiles[i], &l);
     if (kind[i] < 0 || c[i].g->Ci != c[0].g->Ci) return 0;
     if (!c[i].ws || c[i].ws_bytes < (size_t)27 * c[i].g->Ci * c[i].g->Ci * 4) return 0;
-    for (int j = 0; j < i; ++j) if (c[j].dst == c[i].dst) return 0;
+    for (int j = 0; j < i; ++j) {
+      if (c[j].dst == c[i].dst) return 0;
+      // ONE kernel reads every call's packed weights: two calls that pack into the same workspace (a C-ABI caller re-using one
+      // scratch buffer, fine on the sequential path) would both see the last call's weights -> the sequential path
+      if (c[j].ws == c[i].ws && !((c[j].flags & c[i].flags) & N3D_PREPACKED)) return 0;
+    }
     if (l > lds) lds = l;
     total += (int64_t)tiles[i] * c[i].g->B;
   }
@@ -2829,6 +2834,7 @@ int mfma_conv_pair_try(const n3d_conv_geom* g0, bool dg0, const float* src0, int
   const G16Plan p0 = g16_plan(g0, dg0), p1 = g16_plan(g1, dg1);
   if (!p0.ok || !p1.ok || p0.ksplit != p1.ksplit || p0.ksplit == 1) return 0;
   if (sld0 % 4 != 0 || !aligned16(src0) || sld1 % 4 != 0 || !aligned16(src1)) return 0;
+  if (ws0 == ws1 && !((flags0 & flags1) & N3D_PREPACKED)) return 0;   // one kernel reads both packed copies: they must not share a workspace
   PairArgs q;
   G16Plan t0, t1;
   // x0 / x1: the data-gradient extras of a conv (ReLU mask source of the input, per-(b,c) output gate); NULL for a forward conv
@@ -2862,6 +2868,7 @@ int mfma_conv_multi_try(int n, const n3d_conv_geom* const* g, const bool* dg, co
     if (!p.ok || p.ksplit == 1 || (i > 0 && p.ksplit != ksplit)) return 0;
     ksplit = p.ksplit;
     if (sld[i] % 4 != 0 || !aligned16(src[i])) return 0;
+    for (int j = 0; j < i; ++j) if (ws[j] == ws[i] && !((flags[j] & flags[i]) & N3D_PREPACKED)) return 0;   // (as mfma_conv_pair_try)
   }
   MultiArgs q;
   int total = 0;

@@ -568,7 +568,12 @@ def recompute_ok(seg, x):
     if not (RECOMPUTE_K1 and isinstance(w, DenseConvW) and w.k == 1 and w.stride == 1 and not w.transposed and seg.norm is not None
             and not seg.relu_in and not seg.relu_out and seg.se_gate is None and seg.dropout is None and x.C % 4 == 0):
         return False
-    return K.conv_k1_norm_ok(w.geom(x))
+    g = w.geom(x)
+    # the recompute form takes the conv-bias gradient analytically out of the GroupNorm sums (N * Bc + ...): not with a padded norm
+    # (G < 0: the kernels run with the scaled element count of include/n3d.h, "padded channels"), nor with the analytic form off
+    if not ANALYTIC_CONV_BIAS or gn_groups(seg.norm, g.Co) < 0:
+        return False
+    return K.conv_k1_norm_ok(g)
 
 
 def _seg_forward_recompute(seg, x, out=None):

@@ -928,6 +928,8 @@ class Trainer:
         self._capturing_side = False
         self._side_wsegs = 1
         self._side_retired = False   # recover() after a timed-out hand-off: the rest of the run stays on one stream
+        self._n_steps = 0            # step() calls, on every path (the replay monitor's collective verdict is placed by this count)
+        self._bracket_now = False
         self.schedule_times = None   # (plain seconds per step, side seconds per step) measured at capture
         if storage is not None:
             from . import unet as _unet
@@ -1236,8 +1238,10 @@ class Trainer:
 
     def _step(self, x, t):
         self._poll()     # host-only: a withheld update (timed-out hand-off) is fatal until recover()
+        self._n_steps += 1
         if not self.use_graph:
             return self._eager(x, t)
+        self._side_verdict()
         if self._static_x is None or (self._graph is None and self._side_graphs is None):
             self._capture(x, t)
         if x.shape != self._static_x.shape or t.shape != self._static_t.shape:
@@ -1300,17 +1304,12 @@ class Trainer:
             self._update(self._static_loss)
 
     def _watched_side_replay(self):
-        """one replayed step of the side schedule.  Every 256th one is bracketed with events; one step later the trainer checks the
-        time-outs of the device-side waits (raises) and that step's GPU time against the plain schedule's measured time -- a side
-        schedule that has become slower than the plain graph is dropped.  Data parallel: the verdict is COLLECTIVE (every rank counts
-        the same replays, so every rank is at this check in the same step; one tiny all-reduce of "my sample was fast") -- a rank
-        that retired its side schedule on its own would go on with another fp32 summation order than its peers and the replicas
-        would drift apart bit by bit."""
+        """one replayed step of the side schedule.  Every 256th STEP (counted by step() on every path: a rank that ran an eager step
+        for an odd-shaped last batch, or recaptured, still counts it) is bracketed with events; the verdict on that sample is taken
+        at the start of the next step (_side_verdict)."""
         sd = self.side
         sd.replays += 1
-        recheck = getattr(sd, "recheck", 0)
-        if sd.replays % 256 == 0 or recheck > 0:
-            sd.recheck = 0
+        if self._bracket_now:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self._replay_side()
@@ -1318,14 +1317,32 @@ class Trainer:
             sd.watch = (e0, e1)
             return
         self._replay_side()
-        if sd.watch is not None:
-            e0, e1 = sd.watch
-            sd.watch = None
-            e1.synchronize()
-            sd.check()      # (the per-step poll() has seen a withheld update long before; this also catches a time-out whose step
-                            # was not followed by an update yet)
-            ms = e0.elapsed_time(e1)
-            fast = self.schedule_times is None or ms * 1e-3 <= 1.5 * self.schedule_times[0] + 2e-4
+
+    def _side_verdict(self):
+        """start of a step, one step after a bracketed one: the trainer checks the time-outs of the device-side waits (raises) and the
+        bracketed step's GPU time against the plain schedule's measured time -- a side schedule that has become slower than the plain
+        graph is dropped.  Data parallel: the verdict is COLLECTIVE, and its place in the stream of collectives is a function of the
+        STEP COUNT alone (every rank calls step() the same number of times, whatever path each step takes on a rank; a rank without
+        a sample -- its bracketed step ran eagerly -- votes "fast"): one tiny all-reduce of "my sample was fast", issued before
+        anything of this step.  A rank that retired its side schedule on its own would go on with another fp32 summation order than
+        its peers and the replicas would drift apart bit by bit."""
+        sd = self.side
+        n = self._n_steps
+        due, self._bracket_now = self._bracket_now, False
+        # is THIS step a bracketed one?  (uniform over the ranks: the step count, or a re-check every rank agreed on one step ago)
+        want = sd is not None and self._use_side and (n % 256 == 0 or getattr(sd, "recheck", 0) > 0)
+        if want:
+            sd.recheck = 0
+        if sd is not None and self._use_side and due:
+            fast, ms = True, None
+            if sd.watch is not None:
+                e0, e1 = sd.watch
+                sd.watch = None
+                e1.synchronize()
+                sd.check()      # (the per-step poll() has seen a withheld update long before; this also catches a time-out whose
+                                # step was not followed by an update yet)
+                ms = e0.elapsed_time(e1)
+                fast = self.schedule_times is None or ms * 1e-3 <= 1.5 * self.schedule_times[0] + 2e-4
             slow = not (self.sync.all_true(fast) if self.dp_path else fast)
             # ONE slow sample proves nothing -- the bracket also holds whatever the host did between the three graph launches (a
             # 100 000-step soak dropped a healthy schedule on a single 3.5 ms sample): a slow sample is measured again, three in a row
@@ -1334,15 +1351,16 @@ class Trainer:
             sd.recheck = 1 if (slow and sd.slow_run < 3) else 0
             if sd.slow_run >= 3:
                 import warnings
-                warnings.warn("nas_3d_unet_amd: the side-stream schedule degraded (%.2f ms per step on this rank against %.2f ms for the plain "
+                warnings.warn("nas_3d_unet_amd: the side-stream schedule degraded (%s ms per step on this rank against %.2f ms for the plain "
                               "graph, three samples in a row%s); falling back to the plain graph"
-                              % (ms, self.schedule_times[0] * 1e3, " on at least one rank" if self.dp_path else ""))
+                              % ("%.2f" % ms if ms is not None else "?", self.schedule_times[0] * 1e3, " on at least one rank" if self.dp_path else ""))
                 self._use_side = False
                 if self._graph is None:      # ("force": no plain graph was captured -- the next step captures one)
                     torch.cuda.synchronize(self.device)
                     self._retire_side_graphs()
                     self._side_retired = True
                     self._static_x = self._static_t = None
+        self._bracket_now = bool(want and self._use_side)
 
     def _choose_schedule(self):
         """time the two captured schedules on the real step (state saved and restored around it) and keep the faster one"""

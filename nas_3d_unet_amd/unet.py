@@ -51,8 +51,9 @@ class PaddedTwin:
     in front of Adam in train.Trainer); the real channels see the reference's arithmetic -- with ONE correction: a GroupNorm group's element count is that of the
     REAL channels (programs.gn_groups -> a negative group count at the C ABI, include/n3d.h "padded channels").  The user-visible module
     keeps the reference's parameter shapes (state-dict parity); before every forward they are embedded into the twin's parameters and
-    after the backward the twin's gradients are cut back (index plumbing in torch, arithmetic in libn3d).  Module API only (forward /
-    forward_loss under autograd); the flat-buffer trainers refuse such a net."""
+    after the backward the twin's gradients are cut back (index plumbing in torch, arithmetic in libn3d).  That is the module API (forward /
+    forward_loss under autograd, unet.run_padded); the flat-buffer trainers train the twin itself (padded entries masked in front of Adam)
+    and hand the parameters back in the reference's shapes at check_sync() (train.Trainer / SearchTrainer)."""
 
     def __init__(self, real, kind, in_channels, init_n_kernels, out_channels, depth, n_nodes, channel_change, gene=None, head_dropout=0.0):
         import torch
@@ -172,6 +173,9 @@ def run_padded(net, x, alphas=None, loss_target=None, smooth=1e-6):
     rp = dict(net.named_parameters())
     reals = [rp[n] for n in names]
     n_al = 0 if alphas is None else len(alphas)
+    # inference (no_grad / nothing requires a gradient): the twin runs under no_grad too -- no autograd graph, no saved activations
+    need_grad = torch.is_grad_enabled() and (x.requires_grad or any(r.requires_grad for r in reals)
+                                             or any(a.requires_grad for a in (alphas or ())))
 
     class Fn(torch.autograd.Function):
         @staticmethod
@@ -181,16 +185,17 @@ def run_padded(net, x, alphas=None, loss_target=None, smooth=1e-6):
             prev = (P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER)
             P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER = False, False, False, False, False
             try:
-                with torch.enable_grad():
-                    xi = xin.detach().requires_grad_(xin.requires_grad)
-                    ali = tuple(a.detach().requires_grad_(a.requires_grad) for a in al)
+                with torch.set_grad_enabled(need_grad):
+                    xi = xin.detach().requires_grad_(need_grad and xin.requires_grad)
+                    ali = tuple(a.detach().requires_grad_(need_grad and a.requires_grad) for a in al)
                     if loss_target is None:
                         out = (run(tw.twin, xi, ali if n_al else None),)
                     else:
                         out = run_loss(tw.twin, xi, loss_target, ali if n_al else None, smooth)
             finally:
                 P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER = prev
-            ctx.saved = (xi, ali, out)
+            if need_grad:
+                ctx.saved = (xi, ali, out)
             return tuple(o.detach() for o in out)
 
         @staticmethod

@@ -137,7 +137,7 @@ def test_replay_monitor_retires_the_side_schedule_collectively(one_rank_group):
     real = tr.sync.all_true
     tr.sync.all_true = lambda flag: (calls.append(bool(flag)), real(flag))[1]
     tr.schedule_times = (1e-7, 1e-7)
-    tr.side.replays = 254
+    tr._n_steps = 254
     with warnings.catch_warnings(record=True) as wn:
         warnings.simplefilter("always")
         for _ in range(10):

@@ -193,7 +193,7 @@ def test_one_slow_sample_does_not_retire_the_side_schedule():
     assert tr._use_side
     real = tr.schedule_times
     tr.schedule_times = (1e-9, 1e-9)      # every sample now counts as slow against this "plain graph time"
-    tr.side.replays = 255                  # the next replay is a sampled one
+    tr._n_steps = 255                  # the next replay is a sampled one
     tr.step(x, t)                          # sampled (slow sample 1) ...
     with warnings.catch_warnings():
         warnings.simplefilter("error")
@@ -205,7 +205,7 @@ def test_one_slow_sample_does_not_retire_the_side_schedule():
     assert tr._use_side and tr.side.recheck == 0 and tr.side.slow_run == 0
     # three slow samples in a row do retire it
     tr.schedule_times = (1e-9, 1e-9)
-    tr.side.replays = 255
+    tr._n_steps = 255
     with pytest.warns(UserWarning, match="degraded"):
         for _ in range(7):
             tr.step(x, t)

@@ -206,6 +206,28 @@ def test_checkpoint_interop_with_torch_adam_and_scheduler(tmp_path):
         n = p.numel()
         assert torch.equal(tr2.fp.exp_avg[o:o + n], tr.fp.exp_avg[o:o + n]) and torch.equal(tr2.fp.exp_avg_sq[o:o + n], tr.fp.exp_avg_sq[o:o + n])
     assert torch.equal(tr2.fp.flat, tr.fp.flat) and tr2.scheduler.num_bad_epochs == 4
+    # round 6: a net with odd channel counts is trained as its zero-padded twin -- the checkpoint must still hold the
+    # REFERENCE's shapes (moments cut back through the twin's index maps) and resume from a plain torch checkpoint of the same net
+    pnet = searched.SearchedNet(4, 6, 3, 2, 3, True, gene)
+    ptr = Trainer(pnet, graph=False)
+    assert ptr._twin is not None
+    ptr.fp.exp_avg.copy_(torch.randn(ptr.fp.numel, generator=g) * ptr._pad_mask)      # (padded entries: Adam never moves them)
+    ptr.fp.exp_avg_sq.copy_(torch.rand(ptr.fp.numel, generator=g) * ptr._pad_mask)
+    ptr.fp.step.fill_(5)
+    psd = ck.train_state_dicts(ptr, epoch=3, history={}, best_loss=0.4)
+    pref = searched.SearchedNet(4, 6, 3, 2, 3, True, gene)
+    pref.load_state_dict(psd["model_param"])
+    popt = torch.optim.Adam(pref.parameters())
+    popt.load_state_dict(psd["optim"])
+    for q in pref.parameters():      # every moment in the reference's shape, in the module's parameter order
+        assert popt.state[q]["exp_avg"].shape == q.shape and popt.state[q]["exp_avg_sq"].shape == q.shape
+    popt.param_groups[0]["lr"] = 1e-3
+    ptr2 = Trainer(searched.SearchedNet(4, 6, 3, 2, 3, True, gene), graph=False)
+    ck.load_train_state_dicts(ptr2, {"epoch": 3, "history": {}, "model_param": pref.state_dict(), "optim": popt.state_dict(),
+                                     "scheduler": ck.scheduler_state_dict(ptr.scheduler), "best_loss": 0.4})
+    assert int(ptr2.fp.step) == 5
+    assert torch.equal(ptr2.fp.exp_avg, ptr.fp.exp_avg) and torch.equal(ptr2.fp.exp_avg_sq, ptr.fp.exp_avg_sq)
+    assert torch.equal(ptr2.fp.flat, ptr.fp.flat)
     # genotype pickle (search.py:189-194, train.py:36-38)
     gp = tmp_path / "best_genotype.pkl"
     ck.save_genotype(gp, gene, 3)
