@@ -1390,7 +1390,7 @@ static_assert(N3D_PACK_JOBS <= 256 && N3D_FINAL_JOBS <= 256, "job ids are bytes"
 
 // elements of one tap of the packed form (the tap is the slowest index of every layout)
 __host__ __device__ inline int pack_tap_elems(int layout, int Cs, int Cd, int cdp, int Co) {
-  return layout == 0 ? Cs * cdp : ((layout == 1 || layout == 6) ? Cs * Cd : Co * Co);
+  return layout == 0 ? Cs * cdp : (layout == 1 ? Cs * Cd : Co * Co);
 }
 
 // destination channels of the packed form (layout 0 pads them to cdp)
@@ -1414,7 +1414,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
   const int E = pack_tap_elems(layout, Cs, Cd, jb.cdp, Co);
   const float* __restrict__ w = N3D_SEG(jb.w);
   float* __restrict__ dst = N3D_SEG(jb.dst);
-  const bool bf16 = layout == 4 || layout == 5;
+  const bool bf16 = layout >= 4;
   const int t = threadIdx.x;
   if (taps == 27) {
     // The native weight is (Co, Ci, 27): for one output channel, 16 input channels are 432 consecutive floats.  A workgroup
@@ -1438,14 +1438,12 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
     int cs_l, cd_l;
     if (layout == 0) { cd_l = t & 15; cs_l = t >> 4; }
     else if (layout == 1) { cd_l = (t >> 2) & 15; cs_l = (t >> 6) * 4 + (t & 3); }
-    else if (layout == 6) { cs_l = ((t >> 4) & 3) * 4 + (t & 3); cd_l = (t >> 6) * 4 + ((t >> 2) & 3); }
     else { cs_l = t & 15; cd_l = t >> 4; }
     const int cs = cs0 + cs_l, cd = cd0 + cd_l;
     if (cs >= Cs || cd >= CdP) return;
     int r;
     if (layout == 0) r = cs * jb.cdp + cd;
     else if (layout == 1) r = (((cs >> 4) * 4 + ((cs >> 2) & 3)) * Cd + cd) * 4 + (cs & 3);
-    else if (layout == 6) r = (((cd >> 2) * (Cs >> 2) + (cs >> 2)) * 4 + (cd & 3)) * 4 + (cs & 3);     // rows64: [cd / 4][cs / 4][cd & 3][cs & 3]
     else r = cd * Co + cs;
     const bool live = cd < Cd;
     const float* src = tile + (data_grad ? cs_l : cd_l) * N3D_PACK_PITCH + (data_grad ? cd_l : cs_l) * 27;
@@ -1469,9 +1467,6 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackJobs jobs) {
     const int j = r & 3, rest = (r >> 2) / Cd;
     cd = (r >> 2) % Cd;
     cs = (rest >> 2) * 16 + (rest & 3) * 4 + j;
-  } else if (layout == 6) {
-    const int rest = r >> 4, Q = Cs >> 2;
-    cs = (rest % Q) * 4 + (r & 3); cd = (rest / Q) * 4 + ((r >> 2) & 3);
   } else {
     cs = r % Co; cd = r / Co;
   }
@@ -2560,7 +2555,7 @@ int n3d_conv_pack_info(const n3d_conv_geom* g, int data_grad, int flags, int32_t
   if (const int l16 = vox16_layout(g, data_grad != 0, flags)) { *layout = l16; *cdp = Cd; *floats = ((int64_t)27 * Cd * Cs + 1) / 2; return N3D_OK; }   // bf16 [27][cd][cs]
   const int ml = mfma_pack_layout(g, data_grad != 0, flags);
   if (ml == 2 || ml == 3) { *layout = ml; *cdp = Cd; *floats = (int64_t)27 * Cd * Cs; return N3D_OK; }
-  if (ml == 1 || ml == 6) { *layout = ml; *cdp = Cd; *floats = (int64_t)taps * Cs * Cd; return N3D_OK; }
+  if (ml == 1) { *layout = 1; *cdp = Cd; *floats = (int64_t)taps * Cs * Cd; return N3D_OK; }
   const int cot = pick_cot(Cd);
   *layout = 0; *cdp = (int)align_up(Cd, cot); *floats = (int64_t)taps * Cs * (*cdp);
   return N3D_OK;
@@ -2571,7 +2566,7 @@ int n3d_pack_batch(const n3d_pack_job* jobs, int njobs, void* stream) {
   for (int i = 0; i < njobs; ++i) {
     const n3d_pack_job& q = jobs[i];
     N3D_CHECK_ARG(q.w && q.dst && q.Co > 0 && q.Ci > 0 && q.Co < 65536 && q.Ci < 65536 && q.cdp >= 0 && q.cdp < 65536 && q.taps > 0 && q.taps < 256 &&
-                  q.layout >= 0 && q.layout <= 6 && ((uintptr_t)q.w & 3) == 0 && ((uintptr_t)q.dst & 3) == 0, "pack_batch: bad job");
+                  q.layout >= 0 && q.layout <= 5 && ((uintptr_t)q.w & 3) == 0 && ((uintptr_t)q.dst & 3) == 0, "pack_batch: bad job");
   }
   int base = 0;
   while (base < njobs) {

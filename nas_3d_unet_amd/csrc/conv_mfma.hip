@@ -13,7 +13,6 @@
 //   src coordinate = (dst*sn + off + tap*dt) / den   (valid iff divisible and in range).
 #include <stdlib.h>
 #include "n3d_common.h"
-#include "conv_r64.h"
 #include <type_traits>
 // cache policy of the weight-gradient kernels' LDS-DMA loads (cpol bits: 1 = sc0, 2 = nt, 16 = sc1).  These kernels run on the side
 // stream next to the backward chain and stream 8-25 MB tensors through the L2s that hold the chain's working set.
@@ -2623,7 +2622,6 @@ int mfma_pack_layout(const n3d_conv_geom* g, bool data_grad, int flags) {
   if (flags & (N3D_NO_MFMA | N3D_SRC_BF16 | N3D_DST_BF16)) return 0;
   if (vup_plan(g, data_grad).ok) return 3;   // vox layout, channels transposed, taps not flipped
   if (vx_plan(g).ok || vs2_plan(g, data_grad).ok) return 2;
-  if (r64_plan(g, data_grad).ok) return 6;   // rows64 layout (conv_r64.hip)
   if (g16_plan(g, data_grad).ok) return 1;
   return 0;
 }
@@ -2638,7 +2636,6 @@ int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags) {
     VupPlan v3 = vup_plan(g, data_grad);
     if (v3.ok) return v3.tiles;
   }
-  if (r64_plan(g, data_grad).ok) return r64_stats_rows(g, data_grad);
   G16Plan p = g16_plan(g, data_grad);
   if (!p.ok) return 0;
   if (p.ksplit == 1) { const int t = tile16_up_tiles(g, data_grad); if (t) return t; }
@@ -2735,12 +2732,6 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
       return 1;
     }
   }
-  {
-    R64Args ra; R64Plan rp;
-    const int r = r64_prepare(g, data_grad, src, sld, w, bias, dst, dld, flags, in_gate, relu_src, rld, out_gate, stats, ws, ws_bytes, s, &ra, &rp);
-    if (r < 0) return r;
-    if (r == 1) return r64_launch(1, &ra, &rp, s);
-  }
   MfArgs a;
   G16Plan p;
   {
@@ -2789,7 +2780,6 @@ int g16_prepare(const n3d_conv_geom* g, bool data_grad, const float* src, int64_
                 int64_t dld, int flags, const float* in_gate, const float* relu_src, int64_t rld, const float* out_gate, double* stats,
                 void* ws, size_t ws_bytes, hipStream_t s, MfArgs* out, G16Plan* plan) {
   if (vx_plan(g).ok) return 0;
-  if (r64_plan(g, data_grad).ok) return 0;      // the rows64 kernel's shapes (its packed layout is another one)
   G16Plan p = g16_plan(g, data_grad);
   if (!p.ok) return 0;
   if (sld % 4 != 0 || !aligned16(src)) {
@@ -2839,22 +2829,6 @@ int mfma_conv_pair_try(const n3d_conv_geom* g0, bool dg0, const float* src0, int
   // decide before touching anything (g16_prepare packs weights)
   if ((flags0 | flags1) & (N3D_SRC_BF16 | N3D_DST_BF16)) return 0;
   if (vx_plan(g0).ok || vx_plan(g1).ok) return 0;
-  if (!((flags0 | flags1) & N3D_NO_MFMA)) {
-    const R64Plan r0 = r64_plan(g0, dg0), r1 = r64_plan(g1, dg1);
-    if (r0.ok != r1.ok) return 0;     // one conv each way: two single launches
-    if (r0.ok) {
-      if (r0.ct != r1.ct || (ws0 == ws1 && !((flags0 & flags1) & N3D_PREPACKED))) return 0;
-      R64Args as[2]; R64Plan ps[2];
-      int r = r64_prepare(g0, dg0, src0, sld0, w0, bias0, dst0, dld0, flags0, gate0, x0 ? x0->relu_src : nullptr, x0 ? x0->rld : 0,
-                          x0 ? x0->out_gate : nullptr, stats0, ws0, wsb0, s, &as[0], &ps[0]);
-      if (r < 0) return r;
-      if (r == 0) return 0;
-      r = r64_prepare(g1, dg1, src1, sld1, w1, bias1, dst1, dld1, flags1, gate1, x1 ? x1->relu_src : nullptr, x1 ? x1->rld : 0,
-                      x1 ? x1->out_gate : nullptr, stats1, ws1, wsb1, s, &as[1], &ps[1]);
-      if (r <= 0) return r < 0 ? r : N3D_ERR_INVALID;
-      return r64_launch(2, as, ps, s);
-    }
-  }
   const G16Plan p0 = g16_plan(g0, dg0), p1 = g16_plan(g1, dg1);
   if (!p0.ok || !p1.ok || p0.ksplit != p1.ksplit || p0.ksplit == 1) return 0;
   if (sld0 % 4 != 0 || !aligned16(src0) || sld1 % 4 != 0 || !aligned16(src1)) return 0;
@@ -2885,26 +2859,6 @@ int mfma_conv_multi_try(int n, const n3d_conv_geom* const* g, const bool* dg, co
                         const float* const* bias, float* const* dst, const int64_t* dld, const int* flags, const float* const* gate,
                         double* const* stats, void* const* ws, const size_t* wsb, hipStream_t s) {
   if (n < 3 || n > 4) return 0;
-  {
-    int nr = 0, ct = 0;
-    for (int i = 0; i < n; ++i) {
-      const R64Plan rp = r64_plan(g[i], dg[i]);
-      if (rp.ok && !(flags[i] & (N3D_NO_MFMA | N3D_SRC_BF16 | N3D_DST_BF16)) && (nr == 0 || rp.ct == ct)) { ++nr; ct = rp.ct; }
-    }
-    if (nr != 0 && nr != n) return 0;
-    if (nr == n) {
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j < i; ++j) if (ws[j] == ws[i] && !((flags[j] & flags[i]) & N3D_PREPACKED)) return 0;
-      R64Args as[4]; R64Plan ps[4];
-      for (int i = 0; i < n; ++i) {
-        const int r = r64_prepare(g[i], dg[i], src[i], sld[i], w[i], bias[i], dst[i], dld[i], flags[i], gate[i], nullptr, 0, nullptr, stats[i],
-                                  ws[i], wsb[i], s, &as[i], &ps[i]);
-        if (r < 0) return r;
-        if (r == 0) return i == 0 ? 0 : N3D_ERR_INVALID;
-      }
-      return r64_launch(n, as, ps, s);
-    }
-  }
   int ksplit = 0;
   for (int i = 0; i < n; ++i) {
     if (vx_plan(g[i]).ok) return 0;
@@ -3156,7 +3110,6 @@ int mfma_bwd_dual_try(const n3d_conv_geom* g, bool transposed, const float* dy, 
   // gradient kernel sees dy as its i-side operand and x as its o-side operand (roles swapped by the caller's convention)
   const bool dgrad_is_data_grad = !transposed;
   if (vx_plan(g).ok) return 0;
-  if (r64_plan(g, dgrad_is_data_grad).ok) return 0;    // the data gradient is a rows64 launch of its own (the same arithmetic in every schedule)
   const G16Plan p = g16_plan(g, dgrad_is_data_grad);
   if (!p.ok || p.ksplit == 1) return 0;
   if (dyld % 4 != 0 || !aligned16(dy)) return 0;
@@ -3202,7 +3155,6 @@ int mfma_bwd_quad_ok(const n3d_conv_geom* g0, bool t0, const n3d_conv_geom* g1, 
   // gradients are deferred to the side stream or launched in place)
   int ch = 0, tpw = 0;
   if ((!t0 && wgrad_tile16_plan(g0, &ch, &tpw, nullptr)) || (!t1 && wgrad_tile16_plan(g1, &ch, &tpw, nullptr))) return 0;
-  if (r64_plan(g0, !t0).ok || r64_plan(g1, !t1).ok) return 0;
   const G16Plan p0 = g16_plan(g0, !t0), p1 = g16_plan(g1, !t1);
   return p0.ok && p1.ok && p0.ksplit == p1.ksplit && p0.ksplit != 1;
 }
