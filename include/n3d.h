@@ -57,6 +57,11 @@ extern "C" {
 #define N3D_SRC_BF16 64
 #define N3D_DST_BF16 128
 #define N3D_ACT_BF16 64
+/* bf16 configuration, the C >= 16 levels (fp32 storage): the MFMA kernels of the conv family (forward, data and weight gradients with
+ * channel counts that are multiples of 16) round BOTH operands of their matrix products to bfloat16 in registers and accumulate in
+ * fp32 (v_mfma_f32_16x16x16_bf16 instead of four v_mfma_f32_16x16x4_f32).  Ignored by every other kernel.  Never set by the fp32
+ * configuration, whose arithmetic is exact fp32. */
+#define N3D_MM_BF16 256
 
 /* storage type of an activation tensor (entry points that take a dtype argument; all others are fp32) */
 #define N3D_F32 0

@@ -223,6 +223,7 @@ PROTOTYPES = {
 RELU_IN, RELU, ACCUMULATE, POOL_MAX, NO_MFMA, PREPACKED = 1, 2, 4, 8, 16, 32
 F32, BF16 = 0, 1   # N3D_F32 / N3D_BF16
 SRC_BF16, DST_BF16, ACT_BF16 = 64, 128, 64   # storage flags of the conv / epilogue families
+MM_BF16 = 256   # conv family, bf16 configuration: the C >= 16 MFMA kernels round their operands to bf16 (fp32 storage, fp32 accumulate)
 
 _lib = None
 

@@ -24,6 +24,21 @@ namespace n3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// N3D_MM_BF16 (the bf16 configuration, BASELINE configs[4]): the C >= 16 levels keep fp32 STORAGE, but their matrix products round both
+// operands to bfloat16 in registers and run on v_mfma_f32_16x16x16_bf16 (fp32 accumulate): lane (m, kk) of the fp32 kernels holds the
+// four K values 4 kk + j of its row as a float4 -- exactly the bf16x4 operand of the 16-deep instruction -- so four
+// v_mfma_f32_16x16x4_f32 (128 cycles) become two v_cvt_pk_bf16_f32 per operand and ONE 16-cycle MFMA.  The fp32 configuration never
+// sets the flag: its arithmetic stays exact fp32.
+typedef short mm_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mm_bf16x4 mm_cvt4(float a, float b, float c, float d) {
+  const uint2 p = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+  return __builtin_bit_cast(mm_bf16x4, p);
+}
+__device__ __forceinline__ mm_bf16x4 mm_cvt4(const float4 v) { return mm_cvt4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ f32x4 mm_bf16(const mm_bf16x4 a, const mm_bf16x4 b, const f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
 struct MfArgs {
   const float* src; int64_t sld; int Ds, Hs, Ws, Cs;
   float* dst; int64_t dld; int Dd, Hd, Wd, Cd;
@@ -65,8 +80,8 @@ extern "C" int n3d_debug_g16_stamps(unsigned long long* host, int n) {
 #define GSTAMP(k)
 #endif
 
-template <int MT, int NT, int KSPLIT>
-__device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const int by, float* lds) {
+template <int MT, int NT, int KSPLIT, bool BF = false>
+__device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, const int by, float* lds) {
   N3D_CHAIN_PRIO();
   // the wave index as a SCALAR: the K-slice a wave owns (tap, channel block, their offsets) is then computed on the scalar unit
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -247,6 +262,19 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
     acc[0][0][0] += av[0].x * bv[0].x + av[0].y * bv[0].y + av[0].z * bv[0].z + av[0].w * bv[0].w;
     return;
 #endif
+    if constexpr (BF) {
+      // N3D_MM_BF16: one 16-deep bf16 MFMA per tile and group (operands rounded in registers)
+      mm_bf16x4 ab[MT], bb[NT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) ab[t] = mm_cvt4(av[t]);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bb[n] = mm_cvt4(bv[n]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = mm_bf16(ab[t], bb[n], acc[t][n]);
+      return;
+    }
     // two accumulator chains per tile (x,z / y,w): a dependent 16x16x4 MFMA has 40 cycles latency vs 32 issue
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -430,6 +458,12 @@ __device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const
 }
 
 template <int MT, int NT, int KSPLIT>
+__device__ __forceinline__ void gemm16_body(const MfArgs& a, const int bx, const int by, float* lds) {
+  if (a.flags & N3D_MM_BF16) gemm16_body_t<MT, NT, KSPLIT, true>(a, bx, by, lds);
+  else gemm16_body_t<MT, NT, KSPLIT, false>(a, bx, by, lds);
+}
+
+template <int MT, int NT, int KSPLIT>
 __global__ __launch_bounds__(KSPLIT == 16 ? 1024 : 256, KSPLIT == 16 ? 4 : 2) void conv_gemm16_kernel(MfArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   gemm16_body<MT, NT, KSPLIT>(a, blockIdx.x, blockIdx.y, lds);
@@ -505,10 +539,17 @@ __device__ __forceinline__ void wgrad16_body(const Wg16Args& a, const int tile, 
         if (++oh >= a.Ho) { oh = 0; if (++od >= a.Do) { od = 0; ++b; } }
       }
     }
+    if (a.flags & N3D_MM_BF16) {
+      // (the K index of the 16-deep instruction is 4 kk + u: any one-to-one map of K onto voxels serves a sum over voxels)
+      acc = mm_bf16(mm_cvt4(av[0], av[1], av[2], av[3]), mm_cvt4(bv[0], bv[1], bv[2], bv[3]), acc);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
-      bsum += bv[u];
+      for (int u = 0; u < 4; ++u) bsum += bv[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        bsum += bv[u];
+      }
     }
   }
   if (wave > 0) l4[(wave - 1) * 64 + lane] = acc;
@@ -2306,14 +2347,13 @@ int vox_wgrad_try(const n3d_conv_geom* g, const float* x, int64_t xld, const flo
 // accumulate), same statistics rows (one per 128 voxels) as the gemm16 plan it replaces.
 //   DG: data gradient = the same conv with mirrored taps (weights packed transposed by the pack kernel).
 // ------------------------------------------------------------------------------------------------
-template <int DIL, bool DG>
-__global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const void* zero_page, int tiles, FastDiv fT, FastDiv fTw, FastDiv fTh) {
+template <int DIL, bool DG, bool BF>
+__device__ __forceinline__ void tile16_body(const MfArgs& a, const void* zero_page, int tiles, const FastDiv& fT, const FastDiv& fTw, const FastDiv& fTh,
+                                            float4* const t16, double* const red) {
   N3D_CHAIN_PRIO();
   constexpr int TD = 2, TH = 4, TW = 16;
   constexpr int LD = TD + 2 * DIL, LH = TH + 2 * DIL, LW = TW + 2 * DIL, NV = LD * LH * LW;
   constexpr int NP = NV * 4, NIT = (NP + 255) / 256;   // float4 pieces of the halo tile, DMA instructions per thread
-  extern __shared__ __attribute__((aligned(16))) float4 t16[];   // [NIT * 256] float4: voxel-major, 4 pieces per voxel
-  __shared__ double red[4 * 16 * 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, kk = lane >> 4;
   int wg = blockIdx.x;
@@ -2385,6 +2425,11 @@ __global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const voi
   for (int t = 0; t < 2; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   const float relu_floor = (a.flags & N3D_RELU_IN) ? 0.f : -INFINITY;
   const float4* arow = t16 + ((lz * LH + ly0) * LW + m) * 4 + kk;
+  mm_bf16x4 bb[BF ? 27 : 1];     // N3D_MM_BF16: the weights rounded once per tile
+  if constexpr (BF) {
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) bb[tap] = mm_cvt4(bv[tap]);
+  }
 #pragma unroll
   for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
@@ -2398,6 +2443,12 @@ __global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const voi
         for (int t = 0; t < 2; ++t) {
           float4 av = arow[((oz * LH + oy + t) * LW + ox) * 4];
           av.x = fmaxf(av.x, relu_floor); av.y = fmaxf(av.y, relu_floor); av.z = fmaxf(av.z, relu_floor); av.w = fmaxf(av.w, relu_floor);
+          if constexpr (BF) {
+            // (two chains over the taps: even taps into acc, odd taps into acc2)
+            if (((kd * 3 + kh) * 3 + kw) & 1) acc2[t] = mm_bf16(mm_cvt4(av), bb[(kd * 3 + kh) * 3 + kw], acc2[t]);
+            else acc[t] = mm_bf16(mm_cvt4(av), bb[(kd * 3 + kh) * 3 + kw], acc[t]);
+            continue;
+          }
           // two accumulator chains per row (x,z / y,w): a dependent 16x16x4 MFMA has 40 cycles latency vs 32 issue
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, w4.x, acc[t], 0, 0, 0);
           acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, w4.y, acc2[t], 0, 0, 0);
@@ -2431,6 +2482,14 @@ __global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const voi
   }
 }
 
+// (BF = N3D_MM_BF16 is a kernel of its own: the fp32 form keeps its register budget -- 164 VGPRs, three waves per SIMD)
+template <int DIL, bool DG, bool BF = false>
+__global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const void* zero_page, int tiles, FastDiv fT, FastDiv fTw, FastDiv fTh) {
+  extern __shared__ __attribute__((aligned(16))) float4 t16[];   // [NIT * 256] float4: voxel-major, 4 pieces per voxel
+  __shared__ double red[4 * 16 * 2];
+  tile16_body<DIL, DG, BF>(a, zero_page, tiles, fT, fTw, fTh, t16, red);
+}
+
 // ------------------------------------------------------------------------------------------------
 // tile16_up: the den = 2 gather of the 16-channel level -- forward of a stride-2 transposed 3x3x3 conv and data gradient of a
 // stride-2 conv (destination grid = 2 x source grid exactly):   dst[o] = sum_k W[k] . src[(o + pad - k*dil) / 2]   (if divisible).
@@ -2441,16 +2500,15 @@ __global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const voi
 // source row feeding four v_mfma_f32_16x16x4_f32 (the A-operand scheme of conv_tile16).  Same arguments and epilogue as gemm16;
 // one statistics row per workgroup (512 outputs).
 // ------------------------------------------------------------------------------------------------
-template <int DIL>
-__global__ __launch_bounds__(256, 2) void conv_tile16_up_kernel(MfArgs a, const void* zero_page, int tiles, FastDiv fT, FastDiv fTw, FastDiv fTh) {
+template <int DIL, bool BF>
+__device__ __forceinline__ void tile16_up_body(const MfArgs& a, const void* zero_page, int tiles, const FastDiv& fT, const FastDiv& fTw, const FastDiv& fTh,
+                                               float4* const t16, double* const red) {
   N3D_CHAIN_PRIO();
   constexpr int TH = 4, TW = 16;
   constexpr int LO = DIL == 2 ? 1 : 0;                   // source halo below (above: always 1)
   constexpr int LD = 1 + LO + 1, LH = TH + LO + 1, LW = TW + LO + 1, NV = LD * LH * LW;
   constexpr int NP = NV * 4, NIT = (NP + 255) / 256;
   constexpr int NCLS = DIL == 1 ? 8 : 1;                 // output parity classes that receive taps
-  extern __shared__ __attribute__((aligned(16))) float4 t16[];
-  __shared__ double red[4 * 16 * 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, kk = lane >> 4;
   int wg = blockIdx.x;
@@ -2518,6 +2576,10 @@ __global__ __launch_bounds__(256, 2) void conv_tile16_up_kernel(MfArgs a, const 
         const float4 w4 = bv[(kd * 3 + kh) * 3 + kw];
         float4 av = arow[((sd * LH + sh) * LW + sw) * 4];
         av.x = fmaxf(av.x, relu_floor); av.y = fmaxf(av.y, relu_floor); av.z = fmaxf(av.z, relu_floor); av.w = fmaxf(av.w, relu_floor);
+        if constexpr (BF) {      // N3D_MM_BF16: one 16-deep bf16 MFMA per tap (operands rounded in registers)
+          acc[cls] = mm_bf16(mm_cvt4(av), mm_cvt4(w4), acc[cls]);
+          continue;
+        }
         acc[cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, w4.x, acc[cls], 0, 0, 0);
         acc2[cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, w4.y, acc2[cls], 0, 0, 0);
         acc[cls] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, w4.z, acc[cls], 0, 0, 0);
@@ -2556,6 +2618,13 @@ __global__ __launch_bounds__(256, 2) void conv_tile16_up_kernel(MfArgs a, const 
   }
 }
 
+template <int DIL, bool BF = false>
+__global__ __launch_bounds__(256, 2) void conv_tile16_up_kernel(MfArgs a, const void* zero_page, int tiles, FastDiv fT, FastDiv fTw, FastDiv fTh) {
+  extern __shared__ __attribute__((aligned(16))) float4 t16[];
+  __shared__ double red[4 * 16 * 2];
+  tile16_up_body<DIL, BF>(a, zero_page, tiles, fT, fTw, fTh, t16, red);
+}
+
 // geometry-only decision (n3d_conv_stats_rows must agree with the launch): tiles per sample, 0 = not this kernel
 static int tile16_up_tiles(const n3d_conv_geom* g, bool data_grad) {
   constexpr bool off = false;
@@ -2585,13 +2654,15 @@ static bool launch_tile16(const MfArgs& a, hipStream_t s) {
   const size_t shm = (size_t)((nv * 4 + 255) / 256) * 256 * 16;
   const dim3 grid((unsigned)(tiles * a.B));
   const FastDiv fT((uint32_t)tiles), fTw((uint32_t)(a.Wd / 16)), fTh((uint32_t)(a.Hd / 4));
+  const bool bf = a.flags & N3D_MM_BF16;
+#define N3D_T16_LAUNCH(DIL_, DG_) do { if (bf) hipLaunchKernelGGL((conv_tile16_kernel<DIL_, DG_, true>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh); \
+    else hipLaunchKernelGGL((conv_tile16_kernel<DIL_, DG_, false>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh); } while (0)
   if (d == 1) {
-    if (a.dt > 0) hipLaunchKernelGGL((conv_tile16_kernel<1, false>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
-    else hipLaunchKernelGGL((conv_tile16_kernel<1, true>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
+    if (a.dt > 0) N3D_T16_LAUNCH(1, false); else N3D_T16_LAUNCH(1, true);
   } else {
-    if (a.dt > 0) hipLaunchKernelGGL((conv_tile16_kernel<2, false>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
-    else hipLaunchKernelGGL((conv_tile16_kernel<2, true>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
+    if (a.dt > 0) N3D_T16_LAUNCH(2, false); else N3D_T16_LAUNCH(2, true);
   }
+#undef N3D_T16_LAUNCH
   return true;
 }
 
@@ -2752,8 +2823,11 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
         const size_t shm = (size_t)((nv * 4 + 255) / 256) * 256 * 16;
         const dim3 grid((unsigned)(tiles * g->B));
         const FastDiv fT((uint32_t)tiles), fTw((uint32_t)(g->Wo / 16)), fTh((uint32_t)(g->Ho / 4));      // (source grid = the o side)
-        if (d == 1) hipLaunchKernelGGL(conv_tile16_up_kernel<1>, grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
-        else hipLaunchKernelGGL(conv_tile16_up_kernel<2>, grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
+        const bool bf = a.flags & N3D_MM_BF16;
+        if (d == 1) { if (bf) hipLaunchKernelGGL((conv_tile16_up_kernel<1, true>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
+                      else hipLaunchKernelGGL((conv_tile16_up_kernel<1, false>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh); }
+        else { if (bf) hipLaunchKernelGGL((conv_tile16_up_kernel<2, true>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh);
+               else hipLaunchKernelGGL((conv_tile16_up_kernel<2, false>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh); }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { set_error("conv(tile16_up) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
         return 1;
@@ -2950,7 +3024,7 @@ struct WgT16Args {
 
 // TW: tile width -- 16 (a 2 x 4 x 16 tile) or 8 (4 x 4 x 8: the 8^3 level of 128^3 patches, 64 channels, where a 16-wide tile does not
 // fit and the gather kernel took 25 us for 226 MFLOP); either way 32 groups of four W-consecutive voxels
-template <int DIL, int TW = 16>
+template <int DIL, int TW = 16, bool BF = false>
 __global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
   constexpr int TH = 4, GPR = TW / 4, TD = 32 / GPR / TH;      // groups per row; tile depth
   static_assert(TD * TH * GPR == 32, "32 voxel groups per tile");
@@ -2967,6 +3041,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
   const int tw_n = W / TW, th_n = H / TH;
   const int64_t N = (int64_t)D * H * W;
   const float floor_ = (a.flags & N3D_RELU_IN) ? 0.f : -INFINITY;
+  constexpr bool bfmm = BF;     // N3D_MM_BF16: a kernel of its own (the fp32 form keeps its registers)
   f32x4 acc[7][2];
 #pragma unroll
   for (int t = 0; t < 7; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -3011,18 +3086,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile16_kernel(WgT16Args a) {
 #pragma unroll
       for (int gi = 0; gi < 32; ++gi) bsum += bv[gi];
     }
+    mm_bf16x4 bb[8];
+    if constexpr (bfmm) {
+#pragma unroll
+      for (int g4 = 0; g4 < 8; ++g4) bb[g4] = mm_cvt4(bv[g4 * 4], bv[g4 * 4 + 1], bv[g4 * 4 + 2], bv[g4 * 4 + 3]);
+    }
 #pragma unroll
     for (int t = 0; t < 7; ++t) {
       if (t < ntap) {
         const int tap = tap0 + t;
         const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
         const float* ap = xl + abase + (((kd * DIL) * LH + kh * DIL) * LW + kw * DIL) * 16;
+        if constexpr (bfmm) {
+          // N3D_MM_BF16: four voxel groups per 16-deep bf16 MFMA (K index 4 kk + jj = voxel kk of group 4 g4 + jj; dY rounded once per tile)
+#pragma unroll
+          for (int g4 = 0; g4 < 8; ++g4) {
+            float a4[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int gi = g4 * 4 + jj;
+              const int row = gi / GPR, xq = gi % GPR, z = row >> 2, y = row & 3;
+              a4[jj] = fmaxf(ap[((z * LH + y) * LW + xq * 4) * 16], floor_) * gq;
+            }
+            acc[t][g4 & 1] = mm_bf16(mm_cvt4(a4[0], a4[1], a4[2], a4[3]), bb[g4], acc[t][g4 & 1]);
+          }
+        } else {
 #pragma unroll
         for (int gi = 0; gi < 32; ++gi) {
           const int row = gi / GPR, xq = gi % GPR, z = row >> 2, y = row & 3;
           float av = ap[((z * LH + y) * LW + xq * 4) * 16];
           av = fmaxf(av, floor_) * gq;
           acc[t][gi & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[gi], acc[t][gi & 1], 0, 0, 0);
+        }
         }
       }
     }
@@ -3089,13 +3184,15 @@ int wgrad_tile16_try(const n3d_conv_geom* g, const float* x, int64_t xld, const 
   const int nv = (td + 2 * d) * (4 + 2 * d) * (tw + 2 * d);
   const size_t shm = (size_t)((nv * 4 + 255) / 256) * 256 * 16;
   const dim3 grid((unsigned)chunks, (unsigned)(tci * tco));
+  const bool bf = flags & N3D_MM_BF16;
+#define N3D_WT16_LAUNCH(DIL_, TW_) do { if (bf) hipLaunchKernelGGL((wgrad_tile16_kernel<DIL_, TW_, true>), grid, dim3(256), shm, s, a); \
+    else hipLaunchKernelGGL((wgrad_tile16_kernel<DIL_, TW_, false>), grid, dim3(256), shm, s, a); } while (0)
   if (tw == 16) {
-    if (d == 1) hipLaunchKernelGGL((wgrad_tile16_kernel<1, 16>), grid, dim3(256), shm, s, a);
-    else hipLaunchKernelGGL((wgrad_tile16_kernel<2, 16>), grid, dim3(256), shm, s, a);
+    if (d == 1) N3D_WT16_LAUNCH(1, 16); else N3D_WT16_LAUNCH(2, 16);
   } else {
-    if (d == 1) hipLaunchKernelGGL((wgrad_tile16_kernel<1, 8>), grid, dim3(256), shm, s, a);
-    else hipLaunchKernelGGL((wgrad_tile16_kernel<2, 8>), grid, dim3(256), shm, s, a);
+    if (d == 1) N3D_WT16_LAUNCH(1, 8); else N3D_WT16_LAUNCH(2, 8);
   }
+#undef N3D_WT16_LAUNCH
   *nchunks_out = chunks; *pbias_out = a.pbias;
   return 1;
 }

@@ -177,7 +177,7 @@ def _run_forward(plan, x0, x1, alpha1, alpha2, pre0_early=None, planar=False):
     already been launched on the side stream (NetFn.forward, SIDE_FWD); the cell joins it instead of running it.
     planar (searched cells): the node outputs stay dense tensors (kernels.Planar, a 6-D output) instead of channel slices of one
     concatenation buffer -- for the net's LAST cell, whose only reader is the fused head."""
-    with K.stats_cache(), K.storage(plan.dt):
+    with K.stats_cache(), K.storage(plan.dt, getattr(plan, "mm_bf16", False)):
         return _run_forward_impl(plan, x0, x1, alpha1, alpha2, pre0_early, planar)
 
 
@@ -429,7 +429,7 @@ def _run_backward(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha,
     (NetFn passes the producers' gradient buffers); own_dout: `dout` is a private buffer the cell may accumulate into;
     late_joins: flags of side-stream work that is still writing one of the two target buffers -- joined in front of the preprocess
     backward, the first thing of this cell that touches them."""
-    with K.storage(plan.dt):
+    with K.storage(plan.dt, getattr(plan, "mm_bf16", False)):
         if SIDE_BWD is not None and not plan.pairs:
             with SIDE_BWD.arena_mode():      # (this runs on autograd's thread: the mode of the forward pass is not active here)
                 return _run_backward_impl(plan, st, dout, alpha1, alpha2, need_x0, need_x1, want_dalpha, dx_targets, own_dout, late_joins)
@@ -900,6 +900,8 @@ class _NetPlan:
             # (round 5: every primitive of the registry has bf16-storage kernels at these widths -- depthwise, pooling, SE gate, identity
             # next to the convs -- so the policy no longer depends on the genotype; the supernet's N-term kernels stay fp32)
             pl.dt = torch.bfloat16 if (bf and pl.c_node <= BF16_MAX_NODE_WIDTH and not supernet) else torch.float32
+            # (round 6) the deep cells of the bf16 configuration: fp32 storage, bf16 operands in their MFMA conv kernels (N3D_MM_BF16)
+            pl.mm_bf16 = bool(bf and not supernet and pl.dt == torch.float32)
         self.stem_dt = torch.bfloat16 if bf else torch.float32
         self.n_down = len(net.down_cells)
         # activations: 0 = stem0, 1 = stem1, 2 + k = cell k.  wiring[k] = (x0 index, x1 index, output index)
@@ -966,7 +968,7 @@ class NetFn(torch.autograd.Function):
                 pl = nplan.cells[k]
                 if nplan.wiring[k][0] == act_index and pl.pairs and pl.pre0.dropout is None:
                     f = sf.fork()
-                    with sf.side(f), K.storage(pl.dt):
+                    with sf.side(f), K.storage(pl.dt, getattr(pl, "mm_bf16", False)):
                         p0, s_pre0 = P.seg_forward(pl.pre0, K.as_view(acts[act_index], "x0"))
                         early[k] = (p0, s_pre0, sf.side_signal())
 

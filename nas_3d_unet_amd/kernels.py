@@ -70,21 +70,30 @@ def ptr(t):
 # the bf16 configuration (BASELINE configs[4]) switches it per cell (fused._Plan.dt).  Gradient buffers never consult it: they
 # take the type of the forward tensor they belong to (`like`).
 _act_dtype = torch.float32
+# bf16 configuration, the cells that keep fp32 storage (16 .. 64 channels): their MFMA conv kernels round the operands of the matrix
+# products to bf16 in registers (include/n3d.h, N3D_MM_BF16) -- set per cell next to the storage type (fused._Plan.mm_bf16)
+_mm_bf16 = False
 
 
 class storage:
-    def __init__(self, dtype):
-        self.dtype = dtype
+    def __init__(self, dtype, mm_bf16=False):
+        self.dtype, self.mm = dtype, bool(mm_bf16)
 
     def __enter__(self):
-        global _act_dtype
+        global _act_dtype, _mm_bf16
         self.prev, _act_dtype = _act_dtype, self.dtype
+        self.prev_mm, _mm_bf16 = _mm_bf16, self.mm
         return self
 
     def __exit__(self, *exc):
-        global _act_dtype
-        _act_dtype = self.prev
+        global _act_dtype, _mm_bf16
+        _act_dtype, _mm_bf16 = self.prev, self.prev_mm
         return False
+
+
+def _mm(flags):
+    """conv flags + N3D_MM_BF16 while a cell of the bf16 configuration with fp32 storage is running"""
+    return flags | (_lib.MM_BF16 if _mm_bf16 else 0)
 
 
 def empty_ndhwc(B, Cc, D, H, W, device, dtype=None):
@@ -131,7 +140,7 @@ def _need_f32(what, *views):
 
 def _cflags(flags, src, dst):
     """conv-family storage flags: src / dst = the first / second activation tensor of the call"""
-    return flags | (_lib.SRC_BF16 if src.dt == _lib.BF16 else 0) | (_lib.DST_BF16 if dst.dt == _lib.BF16 else 0)
+    return _mm(flags) | (_lib.SRC_BF16 if src.dt == _lib.BF16 else 0) | (_lib.DST_BF16 if dst.dt == _lib.BF16 else 0)
 
 
 def _aflag(v):
@@ -596,6 +605,7 @@ def conv_bwd_both2(calls):
     cs, keep, jobs = [], [], []
     for (g, x, dy, w, dx, dw, dbias, flags_data, relu_src, out_gate, flags_weight, in_gate, transposed) in calls:
         _need_f32("conv_bwd_both2", x, dy, dx)
+        flags_data, flags_weight = _mm(flags_data), _mm(flags_weight)
         wsd, wspd, nd, flags_data = _packed(w, g, not transposed, flags_data, dy.t.device)
         ws, n = _ws(g, x.t.device)
         job = FinalJob() if _ctx is not None else None
@@ -630,7 +640,7 @@ def conv_bwd_data2(calls):
     cs, keep = [], []
     for (g, dy, w, dx, flags, relu_src, out_gate, transposed) in calls:
         _need_f32("conv_bwd_data2", dy, dx)
-        ws, wsp, n, flags = _packed(w, g, not transposed, flags, dy.t.device)
+        ws, wsp, n, flags = _packed(w, g, not transposed, _mm(flags), dy.t.device)
         keep.append((ws, g))
         cs.append(ConvBwdCall(C.pointer(g), 1 if transposed else 0, flags, 0, 0, None, 0, dy.p.value, dy.ld, w.data_ptr(), dx.p.value, dx.ld,
                               relu_src.p.value if relu_src is not None else None, relu_src.ld if relu_src is not None else 0,
@@ -646,6 +656,7 @@ def conv_bwd_both(g, x: View, dy: View, w, dx: View, dw, dbias, flags_data=0, re
         conv_bwd_weight(g, x, dy, dw, dbias, flags_weight, in_gate, transposed)      # queued for the side stream
         conv_bwd_data(g, dy, w, dx, flags_data, relu_src, out_gate, transposed)
         return
+    flags_data, flags_weight = _mm(flags_data), _mm(flags_weight)
     wsd, wspd, nd, flags_data = _packed(w, g, not transposed, flags_data, dy.t.device)
     ws, n = _ws(g, x.t.device)
     job = FinalJob() if (_ctx is not None and not g.depthwise) else None

@@ -372,3 +372,74 @@ def test_foreign_bf16_tensor_without_slack_is_repacked():
     assert K.as_view(wide).t.data_ptr() == wide.data_ptr()
     inner = K.empty_ndhwc(2, 12, 8, 8, 8, torch.device("cuda"), torch.bfloat16)[:, 4:8]               # a channel slice of a wider buffer
     assert K.as_view(inner).t.data_ptr() == inner.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------ round 6: N3D_MM_BF16
+# The C >= 16 levels of the bf16 configuration keep fp32 storage; their MFMA conv kernels round BOTH operands of the matrix products to
+# bfloat16 in registers and accumulate in fp32 (include/n3d.h, N3D_MM_BF16).  The exact statement of that arithmetic is a conv of the
+# bf16-ROUNDED tensors evaluated in fp64: per conv, forward / data gradient / weight gradient, every kernel form of the family.
+MM_CASES = [
+    # (Cin, Cout, stride, dil, transposed, B, spatial of the conv input): kernel form
+    (16, 16, 1, 1, False, 2, (32, 32, 32)),   # tile16 + LDS-tile weight gradient (the C = 16 level of 128^3 patches)
+    (16, 16, 1, 2, False, 2, (16, 32, 32)),   # ... dilation 2
+    (16, 16, 1, 1, False, 2, (16, 16, 16)),   # gemm16 K-split 4 (forward / data gradient), LDS-tile weight gradient
+    (16, 16, 2, 1, False, 2, (16, 32, 64)),   # stride 2: tile16_up data gradient
+    (16, 16, 2, 2, True, 2, (8, 16, 32)),     # transposed: tile16_up forward
+    (32, 32, 1, 1, False, 2, (16, 16, 16)),   # gemm16 K-split 4, LDS-tile weight gradient on 32 channels
+    (32, 32, 1, 2, False, 2, (16, 16, 16)),
+    (32, 32, 2, 1, False, 2, (16, 16, 16)),   # gemm16 K-split 16 + conv_wgrad16
+    (64, 64, 1, 1, False, 2, (8, 8, 8)),      # K-split 16, 4 x 4 x 8 weight-gradient tiles
+    (64, 64, 1, 1, False, 2, (4, 4, 4)),
+    (64, 64, 2, 1, True, 2, (2, 2, 2)),
+    (48, 32, 1, 1, False, 2, (16, 16, 16)),   # 1x1x1 preprocess conv (k = 1 below)
+]
+
+
+def _r16(a):
+    return torch.from_numpy(a).to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("cin,cout,stride,dil,transposed,B,shape", MM_CASES)
+def test_mm_bf16_conv_family_vs_rounded_operands(cin, cout, stride, dil, transposed, B, shape):
+    import torch.nn.functional as F
+    from nas_3d_unet_amd import kernels as K
+    from nas_3d_unet_amd.prim_ops import _padding
+    k = 1 if cin == 48 else 3
+    pad = _padding(k, stride, dil)
+    rng = np.random.default_rng(11)
+    xn = rng.standard_normal((B, cin) + shape).astype(np.float32)
+    wn = (rng.standard_normal((cin, cout, k, k, k) if transposed else (cout, cin, k, k, k)) / np.sqrt(cin * k ** 3)).astype(np.float32)
+    # reference: the same conv on operands rounded to bf16, in fp64
+    xc, wc = _r16(xn).requires_grad_(True), _r16(wn).requires_grad_(True)
+    if transposed:
+        yc = F.conv_transpose3d(xc, wc, None, stride=stride, padding=pad, output_padding=0 if stride == 1 else 1, dilation=dil)
+    else:
+        yc = F.conv3d(xc, wc, None, stride=stride, padding=pad, dilation=dil)
+    rn = rng.standard_normal(tuple(yc.shape)).astype(np.float32)
+    dev_ = torch.device("cuda")
+    x = K.as_view(torch.from_numpy(xn).to(dev_))
+    w = torch.from_numpy(wn).to(dev_)
+    if transposed:
+        g = K.conv_geom(B, yc.shape[2], yc.shape[3], yc.shape[4], cout, cin, k, stride, dil, pad)
+    else:
+        g = K.conv_geom(B, shape[0], shape[1], shape[2], cin, cout, k, stride, dil, pad)
+    y = K.as_view(K.empty_ndhwc(B, cout, yc.shape[2], yc.shape[3], yc.shape[4], dev_))
+    y32 = K.as_view(K.empty_ndhwc(B, cout, yc.shape[2], yc.shape[3], yc.shape[4], dev_))
+    dy = K.as_view(torch.from_numpy(rn).to(dev_))
+    dx = K.as_view(K.empty_ndhwc(B, cin, *shape, dev_))
+    dw = torch.zeros_like(w)
+    K.conv_fwd(g, x, w, None, y32, 0, None, None, transposed)
+    with K.storage(torch.float32, True):
+        K.conv_fwd(g, x, w, None, y, 0, None, None, transposed)
+        K.conv_bwd_data(g, dy, w, dx, 0, None, None, transposed)
+        K.conv_bwd_weight(g, x, dy, dw, None, 0, None, transposed)
+    # the data / weight gradients round dy too
+    (yc * _r16(rn)).sum().backward()
+    tol = 2e-5     # fp32 accumulation of exactly representable products: the fp32 kernels' own tolerance
+    assert_close(y.t, yc.detach().float(), tol, "y (bf16 operands)")
+    assert_close(dx.t, xc.grad.float(), 5e-5, "dx (bf16 operands)")
+    assert_close(dw, wc.grad.float(), 1e-4, "dw (bf16 operands)")
+    if k == 3:
+        # and the flag does select another arithmetic: the fp32 result differs from it at the bf16 rounding level
+        d = float((y.t - y32.t).abs().max() / y32.t.abs().max())
+        assert 1e-4 < d < 3e-2, d
