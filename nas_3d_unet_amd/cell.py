@@ -29,6 +29,11 @@ class MixedOp(nn.Module):
         self._segs = None
 
     def forward(self, x, alpha1, alpha2):
+        if self._ops[0]._n3d_io[0] % 4 != 0:
+            # channel counts that are not multiples of 4: every primitive runs through its zero-padded twin (prim_ops._OpTwin) and the
+            # weighted sum is the reference's own expression (cell.py:24-32)
+            alpha = alpha1 if self.stride == 1 else alpha2
+            return sum([w * op(x) for w, op in zip(alpha, self._ops)])
         if self._segs is None:
             self._segs = [fused._single_segment(op) for op in self._ops]
             self._plist = [p for seg in self._segs for p in seg.params()]
@@ -53,6 +58,20 @@ class Cell(nn.Module):
         return self.c_node * self.n_nodes
 
     def forward(self, x0, x1, alpha1, alpha2):
+        if self.c_node % 4 != 0:
+            # channel counts that are not multiples of 4 (a caller that builds its own net from these cells: the reference's unchanged
+            # nas.py with init_n_kernels = 6, say): op by op through the zero-padded twins, the cell algebra as the reference states it
+            # (cell.py:67-82).  The build-side nets run such a net as ONE padded twin instead (unet.PaddedTwin): faster, same results.
+            import torch
+            xs = [self.preprocess0(x0), self.preprocess1(x1)]
+            i = 0
+            for _ in range(self.n_nodes):
+                outputs = []
+                for x in xs:
+                    outputs.append(self._ops[i](x, alpha1[i], alpha2[i]))
+                    i += 1
+                xs.append(sum(outputs))
+            return torch.cat(xs[-self.n_nodes:], dim=1)
         # one launch program per cell (fused.py); the result is the channel concatenation of the node outputs
         if not fused.current(self._plan):
             self._plan = fused.supernet_plan(self)

@@ -54,6 +54,87 @@ def _padding(kernel_size, stride, dilation):
     return max(0, ceil((dilation * (kernel_size - 1) - stride + 1) / 2))
 
 
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+class _OpTwin:
+    """Zero-padded twin of ONE op whose channel counts are not multiples of 4 -- the per-op form of unet.PaddedTwin, for callers that
+    compose the registry ops themselves (the reference's unchanged nas.py / searched.py with any `init_n_kernels`, nas.py:13-49,
+    searched.py:55-90).  The kernels move channels four at a time: the twin is the same op built on pad4(channels), its padded
+    parameter entries are zero, so padded channels hold exactly 0 in every forward tensor; its GroupNorm counts the REAL channels
+    (programs.gn_groups -> a negative group count at the C ABI).  Before every forward the op's parameters are embedded into the twin's
+    (leading slices), the input is copied into a zero-padded tensor, and the output / the gradients are cut back: index plumbing in
+    torch, arithmetic in libn3d.  Slower than the build-side nets' whole-net twin (a copy and a slice per op); same results."""
+
+    def __init__(self, op):
+        cin, cout = op._n3d_io
+        self.cin, self.cout = cin, cout
+        twin = type(op)(_pad4(cin), _pad4(cout), **op._n3d_ctor)
+        plist = list(op.parameters())
+        self.twin = twin.to(plist[0].device) if plist else twin
+        for q in self.twin.parameters():
+            q.requires_grad_(True)
+        if self.twin.norm is not None:
+            self.twin.norm._n3d_real_c = int(op.norm.num_channels)
+
+    def embed(self, op):
+        import torch
+        tp = dict(self.twin.named_parameters())
+        with torch.no_grad():
+            for n, r in op.named_parameters():
+                t = tp[n]
+                if t.shape == r.shape:
+                    t.copy_(r)
+                else:
+                    t.zero_()
+                    t[tuple(slice(0, k) for k in r.shape)].copy_(r)
+        self.twin.train(op.training)
+        if (op.dropout is None) != (self.twin.dropout is None):
+            self.twin.dropout = None if op.dropout is None else nn.Dropout3d(op.dropout.p)
+
+
+def _run_padded_op(op, x):
+    import torch
+    from .train import _padded_flags
+    tw = op.__dict__.get("_n3d_optwin")
+    plist = list(op.parameters())
+    if tw is None or (plist and next(tw.twin.parameters()).device != plist[0].device):
+        tw = op.__dict__["_n3d_optwin"] = _OpTwin(op)      # (kept out of the module tree: the state dict stays the reference's)
+    names = [n for n, _ in op.named_parameters()]
+    need_grad = torch.is_grad_enabled() and (x.requires_grad or any(q.requires_grad for q in plist))
+    cin, cout = tw.cin, tw.cout
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, xin, *_):
+            tw.embed(op)
+            B, _c, D, H, W = xin.shape
+            xp = torch.zeros((B, D, H, W, _pad4(cin)), dtype=xin.dtype, device=xin.device).permute(0, 4, 1, 2, 3)
+            xp[:, :cin].copy_(xin)
+            with _padded_flags(), torch.set_grad_enabled(need_grad):
+                xi = xp.requires_grad_(need_grad and xin.requires_grad)
+                out = BaseOp._run_segments(tw.twin, xi)
+            if need_grad:
+                ctx.saved = (xi, out)
+            return out.detach()[:, :cout]
+
+        @staticmethod
+        def backward(ctx, dout):
+            xi, out = ctx.saved
+            tp = dict(tw.twin.named_parameters())
+            dp = torch.zeros_like(out)
+            dp[:, :cout].copy_(dout)
+            wanted = ([xi] if xi.requires_grad else []) + [tp[n] for n in names]
+            with _padded_flags():
+                gs = list(torch.autograd.grad([out], wanted, [dp], allow_unused=True))
+            gx = gs.pop(0)[:, :cin] if xi.requires_grad else None
+            gpar = [None if g is None else g[tuple(slice(0, k) for k in r.shape)] for g, r in zip(gs, plist)]
+            return (gx, *gpar)
+
+    return Fn.apply(x, *plist)
+
+
 class BaseOp(nn.Module):
     """Sequences weight / norm / act by the ``ops_order`` string (prim_ops.py:48-83)."""
 
@@ -67,6 +148,10 @@ class BaseOp(nn.Module):
         self.activation = nn.ReLU() if "act" in self.ops_list else None
         self.dropout = nn.Dropout3d(dropout_rate) if dropout_rate > 0 else None
         self._segments = None
+        # channel counts (the kernels move channels four at a time; odd counts run through a zero-padded twin of the op: _OpTwin).  A
+        # dense conv takes any number of INPUT channels as it is (copies), and any output count when no norm follows (the head)
+        self._n3d_io = (in_channels, out_channels)
+        self._n3d_ctor = {}
 
     def __setattr__(self, name, value):
         # the launch programs are built once from (ops_list, norm, dropout, weight modules): re-assigning one of them
@@ -137,12 +222,22 @@ class BaseOp(nn.Module):
         flush()
         return segs
 
-    def forward(self, x):
+    def _odd_channels(self):
+        cin, cout = self._n3d_io
+        dense = isinstance(self, ConvOps) and not self.depthwised
+        return (cout % 4 != 0 and not (dense and self.norm is None)) or (cin % 4 != 0 and not dense)
+
+    def _run_segments(self, x):
         if self._segments is None:
             self._segments = self._build_segments()
         for seg in self._segments:
             x = P.run_segment(seg, x, self.training)
         return x
+
+    def forward(self, x):
+        if self._odd_channels():
+            return _run_padded_op(self, x)
+        return self._run_segments(x)
 
 
 class ConvOps(BaseOp):
@@ -151,6 +246,8 @@ class ConvOps(BaseOp):
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilation=1, transposed=False,
                  depthwised=False, dropout_rate=0, ops_order="weight_norm_act"):
         super().__init__(in_channels, out_channels, dropout_rate, ops_order)
+        self._n3d_ctor = dict(kernel_size=kernel_size, stride=stride, dilation=dilation, transposed=transposed, depthwised=depthwised,
+                              dropout_rate=dropout_rate, ops_order=ops_order)
         self.depthwised = depthwised
         self._k, self._stride, self._transposed = kernel_size, stride, transposed
         self._pad = _padding(kernel_size, stride, dilation)
@@ -192,6 +289,8 @@ class SEConvOp(BaseOp):
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilation=1, transposed=False,
                  dropout_rate=0, ops_order="weight_norm"):
         super().__init__(in_channels, out_channels, dropout_rate, ops_order=ops_order if stride > 1 else "weight")
+        self._n3d_ctor = dict(kernel_size=kernel_size, stride=stride, dilation=dilation, transposed=transposed, dropout_rate=dropout_rate,
+                              ops_order=ops_order)
         self.stride = stride
         self._transposed = transposed
         self._k = kernel_size
@@ -225,6 +324,7 @@ class PoolingOp(BaseOp):
 
     def __init__(self, in_channels, out_channels, pool_type, kernel_size=2, stride=2, ops_order="weight"):
         super().__init__(in_channels, out_channels, ops_order=ops_order)
+        self._n3d_ctor = dict(pool_type=pool_type, kernel_size=kernel_size, stride=stride, ops_order=ops_order)
         if pool_type == "avg":
             self.pool = nn.AvgPool3d(kernel_size, stride=stride)
         elif pool_type == "max":
@@ -247,6 +347,7 @@ class IdentityOp(BaseOp):
 
     def __init__(self, in_channels, out_channels, ops_order="weight_norm_act"):
         super().__init__(in_channels, out_channels, ops_order=ops_order)
+        self._n3d_ctor = dict(ops_order=ops_order)
 
     def _weight_program(self):
         return P.IdentityW()

@@ -24,6 +24,13 @@ class SearchedCell(nn.Module):
         return self.c_node * self.n_nodes
 
     def forward(self, x0, x1):
+        if self.c_node % 4 != 0:
+            # odd channel counts outside a build-side net (which runs as one padded twin): op by op, the reference's algebra (searched.py:36-51)
+            import torch
+            xs = [self.preprocess0(x0), self.preprocess1(x1)]
+            for k in range(self.n_nodes):
+                xs.append(sum([self._ops[2 * k + j](xs[self.genolist[2 * k + j][1]]) for j in range(2)]))
+            return torch.cat(xs[-self.n_nodes:], dim=1)
         # one launch program per cell (fused.py): node k = op[2k](xs[i]) + op[2k+1](xs[j]) written straight into its channel
         # slice of the output buffer, which IS the concatenation the reference builds with torch.cat
         if not fused.current(self._plan):

@@ -41,3 +41,58 @@ def test_unfused_cell_algebra_equals_fused():
     assert_close(a0.grad, dx0, 2e-5, "dx0")
     for n, p in cell.named_parameters():
         assert_close(p.grad, g_fused[n], 2e-4, n)
+
+
+@pytest.mark.parametrize("kind,cfg", [("searched", (4, 6, 3, 2, 3, True)), ("searched", (3, 5, 2, 2, 2, False)), ("supernet", (4, 6, 3, 2, 2, True)),
+                                      ("supernet", (4, 2, 3, 2, 2, False))])
+def test_reference_forward_bodies_on_odd_channel_counts(kind, cfg):
+    """round 6 (missing 3): the reference builds any `init_n_kernels` (nas.py:13-49, searched.py:55-90).  When ITS unchanged
+    nas.py / searched.py drive this repo's prim_ops / cell, every op and cell sees channel counts that are not multiples of 4 on its own:
+    each op then runs through its zero-padded twin (prim_ops._OpTwin), MixedOp / Cell / SearchedCell fall back to the reference's own
+    algebra over those ops.  Here the reference's forward bodies (KernelNet.forward nas.py:54-79, SearchedNet.forward searched.py:95-111
+    = unet.route) run op by op on such a net: loss, probabilities and every gradient against the oracle in fp64."""
+    import torch.nn.functional as F
+    from nas_3d_unet_amd import loss, nas, searched, unet
+    from test_gpu_nets import _genotype_for
+    cfg = orc.NetCfg(*cfg)
+    assert unet.needs_padding(cfg.init_n_kernels, cfg.depth, cfg.n_nodes, cfg.channel_change)
+    odt = torch.float64
+    rng = np.random.default_rng(18)
+    size = 2 ** (cfg.depth + 1)
+    xn = rng.standard_normal((2, cfg.in_channels, size, size, 2 * size)).astype(np.float32)
+    tn = (rng.uniform(0, 1, (2, cfg.out_channels, size, size, 2 * size)) < 0.3).astype(np.float32)
+    x = torch.from_numpy(xn).cuda()
+    if kind == "searched":
+        gene = _genotype_for(cfg.n_nodes)
+        net = searched.SearchedNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, cfg.channel_change,
+                                   searched.Genotype(list(gene.down), list(gene.up)))
+        P = orc.make_params(orc.searched_param_specs(cfg, gene), dtype=odt, requires_grad=True)
+        pr = orc.searched_forward(P, torch.from_numpy(xn).to(odt), gene, cfg)
+        fill_module(net)
+        net.last_conv[0].dropout = None
+        net = net.cuda()
+        plain = lambda cell, skip, cur: cell(skip, cur)
+        p = unet.route(net, x, plain, plain)          # the reference's SearchedNet.forward body over the per-op modules
+    else:
+        net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)
+        P = orc.make_params(orc.supernet_param_specs(cfg), dtype=odt, requires_grad=True)
+        pr = orc.supernet_forward(P, torch.from_numpy(xn).to(odt), cfg)
+        fill_module(net)
+        net.kernel.last_conv[0].dropout = None
+        net = net.cuda()
+        a1d, a1u, a2d, a2u = (F.softmax(a, dim=-1) for a in (net.alpha1_down, net.alpha1_up, net.alpha2_down, net.alpha2_up))
+        p = unet.route(net.kernel, x, lambda cell, skip, cur: cell(skip, cur, a1d, a2d), lambda cell, skip, cur: cell(skip, cur, a1u, a2u))
+    lr = orc.dice_loss(pr, torch.from_numpy(tn).to(odt))
+    lr.backward()
+    l = loss.WeightedDiceLoss()(p, torch.from_numpy(tn).cuda())
+    l.backward()
+    assert abs(float(l.detach()) - float(lr.detach())) < 5e-6
+    assert float((p.detach().cpu().double() - pr.detach().double()).abs().max()) < 3e-5
+    total = float(torch.sqrt(sum((q.grad.double() ** 2).sum() for q in P.values() if q.grad is not None)))
+    for n, q in net.named_parameters():
+        ref = P[n].grad if P[n].grad is not None else torch.zeros_like(P[n])
+        assert q.grad is not None, n
+        d = float((q.grad.cpu().double() - ref.double()).abs().max())
+        assert d <= 3e-4 * float(ref.abs().max()) + 2e-5 * total, (n, d)
+    # a twin never shows in the module tree: the state dict stays the reference's
+    assert not any("twin" in k for k in net.state_dict())

@@ -136,6 +136,24 @@ def test_dropin_under_the_reference_network_files():
         m2 = drop_searched.SearchedNet(4, 4, 3, 4, 3, True, drop_searched.Genotype(*orc.G_ALL))
         assert {k: tuple(v.shape) for k, v in m2.state_dict().items()} == ref_sd2
         assert isinstance(m2.down_cells[0]._ops[0], nas_3d_unet_amd.prim_ops.SEConvOp)
+        # round 6: the reference takes ANY init_n_kernels (nas.py:13-49, searched.py:55-90).  Over this repo's prim_ops / cell such a net
+        # builds with the reference's parameter shapes; its ops and cells mark themselves for the zero-padded per-op path
+        # (prim_ops._OpTwin; the forward itself needs the GPU: tests/test_gpu_dropin.py), and the twin of an op keeps the op's names
+        m6 = drop_searched.SearchedNet(4, 6, 3, 2, 3, True, drop_searched.Genotype(*orc.G_ALL))
+        for k in saved:
+            sys.modules.pop(k, None)
+        ref6 = importlib.import_module("searched").SearchedNet(4, 6, 3, 2, 3, True, importlib.import_module("searched").Genotype(*orc.G_ALL))
+        assert {k: tuple(v.shape) for k, v in m6.state_dict().items()} == {k: tuple(v.shape) for k, v in ref6.state_dict().items()}
+        assert m6.stem0._odd_channels() and m6.up_cells[-1].preprocess0._odd_channels() and not m6.last_conv[0]._odd_channels()
+        assert not m6.down_cells[0].preprocess0._odd_channels()     # 18 -> 12 channels: a dense conv takes any input count as it is
+        for op in [m6.stem0, m6.stem1] + list(m6.up_cells[-1]._ops):
+            tw = nas_3d_unet_amd.prim_ops._OpTwin(op)
+            tw.embed(op)
+            tp = dict(tw.twin.named_parameters())
+            for n, r in op.named_parameters():
+                assert all(a % 4 == 0 or a == b or a in (1, 3) for a, b in zip(tp[n].shape, r.shape)), (n, tp[n].shape)
+                lead = tp[n].detach()[tuple(slice(0, k) for k in r.shape)]
+                assert torch.equal(lead, r.detach()) and float(tp[n].detach().abs().double().sum()) == float(r.detach().abs().double().sum())   # the rest zero
     finally:
         sys.path.remove("/root/reference")
         for k, v in saved.items():

@@ -23,7 +23,8 @@ def case(c, size, stride, dil, batch=2):
     rows = K.conv_stats_rows(g, False, 0, x, y)
     stats = torch.empty((batch, max(rows, 1), c, 2), dtype=torch.float64, device=dev) if rows > 0 else None
     ctx = K.StepContext(dev)
-    with K.step_context(ctx):
+    # DEEP_AB_MM=1: the bf16 configuration's form of these levels (N3D_MM_BF16: operands rounded to bf16 in registers)
+    with K.step_context(ctx), K.storage(torch.float32, os.environ.get("DEEP_AB_MM") == "1"):
         K.conv_fwd(g, x, w, b, y, 0, None, stats, False)
         K.conv_bwd_data(g, y, w, x, 0, None, None, False)
         ctx.freeze()
