@@ -219,19 +219,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_vox64b_kernel(Vx16Args a) {
           const int g = dz - kd * DIL;
           if (g >= 0 && g < TD) {
             // two accumulator chains per output plane (even / odd tap)
-#ifdef VXB_ONE_CHAIN
-            acc[g][0] = mfma_bf16_4x4x4(wr[kd * 9 + t9], av[t9], acc[g][0]);
-#else
             if (t9 & 1) acc2[g] = mfma_bf16_4x4x4(wr[kd * 9 + t9], av[t9], acc2[g]);
             else acc[g][0] = mfma_bf16_4x4x4(wr[kd * 9 + t9], av[t9], acc[g][0]);
-#endif
           }
         }
       }
       if (dz - 2 * DIL >= 0) {
-#ifndef VXB_ONE_CHAIN
         acc[dz - 2 * DIL][0] += acc2[dz - 2 * DIL];
-#endif
         emit_plane(dz - 2 * DIL);
       }
     }

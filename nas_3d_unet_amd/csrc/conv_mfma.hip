@@ -16,9 +16,7 @@
 #include <type_traits>
 // cache policy of the weight-gradient kernels' LDS-DMA loads (cpol bits: 1 = sc0, 2 = nt, 16 = sc1).  These kernels run on the side
 // stream next to the backward chain and stream 8-25 MB tensors through the L2s that hold the chain's working set.
-#ifndef N3D_WGRAD_AUX
 #define N3D_WGRAD_AUX 0
-#endif
 
 namespace n3d {
 
@@ -68,25 +66,12 @@ __global__ void pack16_kernel(const float* __restrict__ w, float* __restrict__ w
   wp[i] = w[((int64_t)co * Ci + ci) * taps + tap];
 }
 
-#ifdef G16_STAMP
-// debug build only (tools/g16_stamps.py): phase stamps of wave 0 / wave 15 of every gemm16 workgroup
-__device__ unsigned long long g16_stamp_buf[4096 * 16];
-#define GSTAMP(k) do { if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == 15)) { const int wgl_ = blockIdx.x + gridDim.x * blockIdx.y; \
-    if (wgl_ < 4096) g16_stamp_buf[wgl_ * 16 + (wave ? 8 : 0) + (k)] = clock64(); } } while (0)
-extern "C" int n3d_debug_g16_stamps(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g16_stamp_buf), (size_t)n * 8);
-}
-#else
-#define GSTAMP(k)
-#endif
-
 template <int MT, int NT, int KSPLIT, bool BF = false>
 __device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, const int by, float* lds) {
   N3D_CHAIN_PRIO();
   // the wave index as a SCALAR: the K-slice a wave owns (tap, channel block, their offsets) is then computed on the scalar unit
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 15, kk = lane >> 4;
-  GSTAMP(0);
   const int64_t Nd = (int64_t)a.Dd * a.Hd * a.Wd;
   const int64_t Mtot = (int64_t)a.B * Nd;
   constexpr int ROWS_PER_WAVE = 16 * MT;
@@ -157,7 +142,7 @@ __device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, con
   //
   // Operand addressing (round 3).  Sixteen waves share four SIMDs here, so what a wave spends before its loads are out is VALU
   // issue slots: the per-group, per-lane address arithmetic (tap offsets, 64-bit pointer, range tests, zero select) was ~40 VALU
-  // instructions and the load phase 5 of this kernel's 8 us (tools/g16_stamps.py).  The voxel index is linear in (lane part) +
+  // instructions and the load phase 5 of this kernel's 8 us (round-3 phase stamps: profiles/r03_gemm16_anatomy.log).  The voxel index is linear in (lane part) +
   // (tap part) -- also for the stride-2 data gradient, where the source voxel is (row + tap) / 2 and exists only when row and tap
   // agree in parity: then (row + tap) / 2 = (row >> 1) + ((tap + (tap & 1)) >> 1) -- so the lane part is a byte offset computed ONCE
   // (voffA), the tap part moves the base of a BUFFER resource on the scalar unit, and a lane whose tap falls outside the volume
@@ -204,10 +189,8 @@ __device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, con
     *reinterpret_cast<int4*>(&gtab[g * 4]) = e;
   }
   __syncthreads();
-#ifndef VOX_NO_LOAD
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src) - bias_el, 0, 0x7fffffff, RSRC_FLAGS);
   const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, 0x7fffffff, RSRC_FLAGS);
-#endif
   typedef int v4i_t __attribute__((ext_vector_type(4)));
   // GATE (a std::bool_constant): the per-(sample, channel) input gate of the SE primitives; the run-time test is made once, around
   // the load phase (a branch per group would make every group its own basic block)
@@ -223,12 +206,8 @@ __device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, con
       const int nd = pd[t] + sd, nh = ph[t] + sh, nw = pw[t] + sw;
       // unsigned compares fold the two-sided range tests (bitwise &: a short-circuit && becomes control flow)
       const bool ok = ((unsigned)nd < (unsigned)a.Ds) & ((unsigned)nh < (unsigned)a.Hs) & ((unsigned)nw < (unsigned)a.Ws) & (lpar[t] == spar);
-#ifdef VOX_NO_LOAD
-      float4 v = make_float4((float)nd, 1.f, 2.f, ok ? 3.f : 0.f);
-#else
       const v4i_t raw = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(ok ? voffA[t] : OOB), soffA, 0);
       float4 v = __builtin_bit_cast(float4, raw);
-#endif
       // (the input ReLU and the gate are applied in mfma_group: anything that touches the loaded value HERE makes the compiler
       // wait for it between the groups' requests -- s_waitcnt vmcnt(2) in the middle of the load phase -- and the round trips of
       // a wave's groups then follow each other instead of overlapping)
@@ -240,11 +219,7 @@ __device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, con
     }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-#ifdef VOX_NO_LOAD
-      bv[n] = make_float4((float)g, 1.f, (float)m, 3.f);
-#else
       bv[n] = __builtin_bit_cast(float4, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(rwt, (int)(voffB + n * 256), soffB, 0));
-#endif
     }
   };
   auto mfma_group = [&](auto gate_c, const float4 (&av0)[MT], const float4 (&bv)[NT], const float4 (&gv)[MT]) {
@@ -258,10 +233,6 @@ __device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, con
       if constexpr (GATE) { v.x *= gv[t].x; v.y *= gv[t].y; v.z *= gv[t].z; v.w *= gv[t].w; }
       av[t] = v;
     }
-#ifdef VOX_NO_MFMA
-    acc[0][0][0] += av[0].x * bv[0].x + av[0].y * bv[0].y + av[0].z * bv[0].z + av[0].w * bv[0].w;
-    return;
-#endif
     if constexpr (BF) {
       // N3D_MM_BF16: one 16-deep bf16 MFMA per tile and group (operands rounded in registers)
       mm_bf16x4 ab[MT], bb[NT];
@@ -291,7 +262,6 @@ __device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, con
         acc2[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t].w, bv[n].w, acc2[t][n], 0, 0, 0);
       }
   };
-  GSTAMP(1);
   if ((KSPLIT == 16 || (KSPLIT == 4 && MT == 1 && NT == 1)) && ngroups <= KSPLIT * 8) {
     // tiny GEMM: every operand this wave will ever need is requested up front (<= 8 groups, 16 float4 per lane),
     // so the whole K loop costs one memory round trip.  (KSPLIT == 4: the 16-channel convs of the 16^3 level, 27 groups over four
@@ -309,7 +279,6 @@ __device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, con
           const int g = wave + i * KSPLIT;
           load_group(std::true_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i], gvs[i]);
         }
-        GSTAMP(2);
 #pragma unroll
         for (int i = 0; i < NI; ++i)
           if (wave + i * KSPLIT < ngroups) mfma_group(std::true_type{}, avs[i], bvs[i], gvs[i]);
@@ -320,11 +289,6 @@ __device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, con
           const int g = wave + i * KSPLIT;
           load_group(std::false_type{}, g < ngroups ? g : ngroups - 1, avs[i], bvs[i], gnone);
         }
-        GSTAMP(2);
-#ifdef G16_STAMP
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        GSTAMP(3);
-#endif
 #pragma unroll
         for (int i = 0; i < NI; ++i)
           if (wave + i * KSPLIT < ngroups) mfma_group(std::false_type{}, avs[i], bvs[i], gnone);
@@ -353,7 +317,6 @@ __device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, con
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[t][n] += acc2[t][n];
 
-  GSTAMP(4);
   if (KSPLIT > 1) {
     // reduce the K-slices through LDS into wave 0
     f32x4* l4 = reinterpret_cast<f32x4*>(lds);
@@ -374,7 +337,6 @@ __device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, con
     }
   }
 
-  GSTAMP(5);
   // ---- epilogue: D layout -> lane holds column n = lane&15, rows 4*(lane>>4) + r
   float csum[NT], csq[NT];
 #pragma unroll
@@ -398,7 +360,6 @@ __device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, con
       }
     }
   }
-  GSTAMP(6);
   if (a.stats && KSPLIT > 1) {
     // only wave 0 holds data: its lanes kk == 0 write the block's partial row directly (no LDS, no barrier)
     if (wave == 0) {
@@ -451,10 +412,6 @@ __device__ __forceinline__ void gemm16_body_t(const MfArgs& a, const int bx, con
       a.stats[(((int64_t)b * a.rows_per_sample + row) * a.Cd + n0 + n * 16 + col) * 2 + q2] = s;
     }
   }
-#ifdef G16_STAMP
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  GSTAMP(7);
-#endif
 }
 
 template <int MT, int NT, int KSPLIT>
@@ -711,43 +668,11 @@ __global__ void pack_vox_kernel(const float* __restrict__ w, float* __restrict__
   wq[i] = w[((int64_t)co * C + ci) * 27 + t2];
 }
 
-#ifdef VOX_STAMP
-// debug build only (tools/build_ablate.sh): per-workgroup phase stamps of the vox64 kernel
-__device__ unsigned long long vox_stamp_buf[8192 * 8];
-__device__ unsigned long long vox_stamp_buf2[8192 * 8];
-#define VSTAMP_NW(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) vox_stamp_buf2[blockIdx.x * 8 + (k)] = clock64(); } while (0)
-#define VSTAMP(k)                                                                                          \
-  do {                                                                                                     \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
-    if (threadIdx.x == 0 && blockIdx.x < 8192)                                                             \
-      vox_stamp_buf[blockIdx.x * 8 + (k)] = (k) >= 6 ? wall_clock64() : clock64(); \
-  } while (0)
-extern "C" int n3d_debug_vox_stamps(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vox_stamp_buf), (size_t)n * 8);
-}
-extern "C" int n3d_debug_vox_stamps2(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vox_stamp_buf2), (size_t)n * 8);
-}
-#else
-#define VSTAMP(k)
-#define VSTAMP_NW(k)
-#endif
-
-#ifdef VOX_NO_LDSREAD
-#define TILE_RD(idx) make_float4(__builtin_bit_cast(float, (idx) + lane), 1.f, 2.f, __builtin_bit_cast(float, lane))
-#define WL_RD(idx) make_float4(__builtin_bit_cast(float, (idx) * 3 + lane), 1.5f, 2.5f, __builtin_bit_cast(float, lane * 7))
-#else
-#define TILE_RD(idx) tile[idx]
-#define WL_RD(idx) wl[idx]
-#endif
-
 // NW = waves per workgroup (1 or 2).  With NW = 2 the workgroup owns an 8-row tile: each wave computes its own 4 rows
 // from ONE shared halo tile (6 x 10 x 18 positions instead of 2 x 6 x 6 x 18), which cuts the LDS-DMA instructions
 // per output voxel by 29 % -- the fill is bound by the texture-address path (16 cycles per 1 KiB instruction per CU).
 // The two waves split the fill chunk-wise and meet at ONE workgroup barrier before the MFMA phase.
-#ifndef VOX_LB
-#define VOX_LB 2
-#endif
+#define VOX_LB 2     // minimum waves per SIMD the vox64 kernels are compiled for (190 VGPRs: held to 170 or 128 they are 8-55 % slower)
 // The kernel body is a device function of (arguments, workgroup index, workgroup count, LDS base): conv_vox64_kernel runs it for
 // one conv per launch, conv_vox_multi_kernel for several independent convs in one launch (each with its own range of workgroups)
 template <int C, int TD, int DIL, int NW>
@@ -778,8 +703,6 @@ __device__ __forceinline__ void vox64_body(const VxArgs& a, const int wg_raw, co
   const int64_t N = (int64_t)a.D * a.H * a.W;
   const float* srcb = a.src + (int64_t)b * N * a.sld;
   const int j = lane & 3;
-  VSTAMP(6);
-  VSTAMP(0);
 
   // lane -> voxel: row hh = lane/16; odd rows are rotated by LW % 16 voxels so that the fixed 16-lane groups a
   // ds_read_b128 is serviced in ({0-3,12-15,20-27}, ...: 8 lanes of an even row + 8 of the next odd row) fall on
@@ -814,10 +737,8 @@ __device__ __forceinline__ void vox64_body(const VxArgs& a, const int wg_raw, co
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
       const int idx = lane + i * 64;
-#ifndef VOX_NO_LOAD
       if (NW == 1 || (i % NW) == wave)
         __builtin_amdgcn_global_load_lds((gptr_t)(idx < NW4 ? wq4 + idx : zp), (lptr_t)(wl + i * 64), 16, 0, 0);
-#endif
     }
     const int64_t pstride = (int64_t)a.H * a.W * a.sld;
 #pragma unroll
@@ -838,18 +759,14 @@ __device__ __forceinline__ void vox64_body(const VxArgs& a, const int wg_raw, co
         const float* p = prow + gd * pstride;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-#ifndef VOX_NO_LOAD
           __builtin_amdgcn_global_load_lds((gptr_t)(inb ? reinterpret_cast<const float4*>(p + q * 4) : zp),
                                            (lptr_t)(tile + q * QSTRIDE + dz * PSTRIDE + i * 64), 16, 0, 0);
-#endif
         }
       }
     }
-    VSTAMP(1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (NW > 1) __syncthreads();  // each wave reads rows the other wave's DMA filled
-  VSTAMP(2);
 
   // accumulators: the WEIGHTS are the MFMA A operand (row i = output channel) and the voxels the B operand
   // (column j = voxel), so lane l ends up with all four channels of ITS OWN voxel in the four accumulator
@@ -879,14 +796,9 @@ __device__ __forceinline__ void vox64_body(const VxArgs& a, const int wg_raw, co
       float4* op = reinterpret_cast<float4*>(o + hf * 4);
       float4 w4 = make_float4(v[0], v[1], v[2], v[3]);
       { const float4 pv = prevv[g][hf]; w4.x += pv.x; w4.y += pv.y; w4.z += pv.z; w4.w += pv.w; }
-#ifdef VOX_NO_STORE
-      if (w4.x == 123456.f) *op = w4;
-#else
       *op = w4;
-#endif
     }
   };
-#ifndef VOX_NO_MFMA
   if constexpr (Q == 1) {
     // C = 4: all 27 weight quads live in registers (108 VGPRs) and the loop is INPUT-PLANE major: plane dz feeds
     // the output planes dz, dz-DIL, dz-2*DIL, and an output plane is stored as soon as its last input plane is
@@ -895,25 +807,25 @@ __device__ __forceinline__ void vox64_body(const VxArgs& a, const int wg_raw, co
     // plane 0, kd = 1 during plane 0, ...) so the start of the MFMA phase is not one 45-read LDS burst per wave
     float4 wr[27];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wr[t] = WL_RD(t * 4 + j);
+    for (int t = 0; t < 9; ++t) wr[t] = wl[t * 4 + j];
     f32x4 acc2[TD];
 #pragma unroll
     for (int g = 0; g < TD; ++g) acc2[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // the nine A reads of plane dz+1 are issued before the MFMAs of plane dz (register double buffer)
     float4 avb[2][9];
 #pragma unroll
-    for (int t9 = 0; t9 < 9; ++t9) avb[0][t9] = TILE_RD((hrow + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL));
+    for (int t9 = 0; t9 < 9; ++t9) avb[0][t9] = tile[(hrow + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL)];
 #pragma unroll
     for (int dz = 0; dz < LD; ++dz) {
       if (dz + 1 < LD) {
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9)
-          avb[(dz + 1) & 1][t9] = TILE_RD((dz + 1) * PSTRIDE + (hrow + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL));
+          avb[(dz + 1) & 1][t9] = tile[(dz + 1) * PSTRIDE + (hrow + (t9 / 3) * DIL) * LW + (ww + (t9 % 3) * DIL)];
       }
       if (dz == 0 || dz == DIL) {
         const int kd = dz / DIL + 1;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wr[kd * 9 + t] = WL_RD((kd * 9 + t) * 4 + j);
+        for (int t = 0; t < 9; ++t) wr[kd * 9 + t] = wl[(kd * 9 + t) * 4 + j];
       }
       const float4* av = avb[dz & 1];
 #pragma unroll
@@ -935,7 +847,6 @@ __device__ __forceinline__ void vox64_body(const VxArgs& a, const int wg_raw, co
           }
         }
       }
-      VSTAMP_NW(dz < 7 ? dz : 7);
       if (dz - 2 * DIL >= 0) {
         acc[dz - 2 * DIL][0] += acc2[dz - 2 * DIL];
         emit_plane(dz - 2 * DIL);
@@ -986,11 +897,6 @@ __device__ __forceinline__ void vox64_body(const VxArgs& a, const int wg_raw, co
 #pragma unroll
     for (int g = 0; g < TD; ++g) emit_plane(g);
   }
-#else
-#pragma unroll
-  for (int g = 0; g < TD; ++g) emit_plane(g);
-#endif
-  VSTAMP(3);
   // ---- GroupNorm partial row of this tile: 8 per-lane sums (4 channels x {sum, sum of squares}) per half are
   // folded with a halving butterfly (lane^1 keeps channels {0,1} | {2,3}, lane^2 keeps one of the two), then one
   // class sum over the 16 lanes that ended up with the same channel.  fp32 tree, rows are added in fp64 downstream.
@@ -1016,12 +922,6 @@ __device__ __forceinline__ void vox64_body(const VxArgs& a, const int wg_raw, co
       }
     }
   }
-  VSTAMP(4);
-  VSTAMP(5);
-#ifdef VOX_STAMP
-  if (threadIdx.x == 0 && blockIdx.x < 8192)
-    vox_stamp_buf[blockIdx.x * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
-#endif
 }
 
 template <int C, int TD, int DIL, int NW>
@@ -1471,8 +1371,6 @@ static VxPlan vx_plan(const n3d_conv_geom* g) {
   int td = 1;
   if (D % 4 == 0 && groups / 4 >= 2048 && g->Ci == 4) td = 4;
   else if (D % 2 == 0 && groups / 2 >= 2048) td = 2;
-#if defined(VOX_STAMP) || defined(VOX_TUNE)
-#endif
   p.ok = true; p.C = g->Ci; p.td = td; p.dil = g->dil;
   // two waves per workgroup on an 8-row tile (shared halo): pays for dilation 2, whose +-2 halo makes the single-wave
   // tile 8 x 8 x 20 positions for 256 outputs (measured at (2,4,64^3): 12.8 -> 8.0 us); for dilation 1 it is neutral at
@@ -1652,16 +1550,13 @@ struct VwArgs {
 // high half, so ONE add folds lane ^ 32 for both; the same with (r2, r3), then a v_permlane16_swap of the two results folds lane ^ 16
 // for all four and leaves row 0 / 1 / 2 / 3 of the wave with r0 / r2 / r1 / r3; two DPP row rotations finish inside the rows.
 // 3 swaps + 5 adds + 1 store of 16 lanes per tile instead of 4 x (2 swaps + 2 DPP + 4 adds + a 4-lane store): the epilogue was
-// 3 (C = 4) / 7 us (C = 8) of these 12 us kernels (tools/wgrad_ns.py with -DVW_NO_EPI).
+// 3 (C = 4) / 7 us (C = 8) of these 12 us kernels (round-3 ablation: profiles/r03_wgrad_anatomy.log).
 template <int C, int QC>
 __device__ __forceinline__ void vw_store_tiles(const f32x4 (&acc)[7][QC][QC], float* __restrict__ out, const int tap0, const int lane,
                                                const int tap_stride = C * C) {
   const int rsel = ((lane >> 4) & 1) * 2 + (lane >> 5);     // the accumulator register this lane's row ends up with
   const bool writer = (lane & 15) < 4;
   float* o = out + rsel * C + (lane & 3);
-#ifdef VW_NO_EPI
-  if (tap0 < 0)
-#endif
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     if (tap0 + t < 27) {
@@ -1766,7 +1661,7 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
   // soff[m] = element offset from plane d0 of the chunk's tensor, sdz[m] = the slot's plane relative to d0 (a value that fails the
   // plane test for slots outside the volume in H / W and for padding slots).  Per tile and chunk that leaves a compare, a select and
   // a 64-bit add in front of the DMA -- the arithmetic was 3.9 of this kernel's 13.5 us at (2,4,64^3) and 26 of 83 us at (2,4,128^3)
-  // (tools/wgrad_ns.py, -DVW_NO_STAGE2).
+  // (profiles/r03_wgrad_anatomy.log).
   constexpr int M = NCH / 4;
   int soff[M], sdz[M];
 #pragma unroll
@@ -1796,9 +1691,6 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
   }
   const int64_t xplane = (int64_t)a.H * a.W * a.xld, yplane = (int64_t)a.H * a.W * a.dyld;
   auto stage = [&](int d0, float4* buf) {
-#ifdef VW_NO_STAGE2
-    if (a.D > 0) return;
-#endif
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int c = m * 4 + wave;                       // uniform
@@ -1813,7 +1705,6 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
     const float* yf = tf + NXC * 64 * 4;
     const bf16_t* th = reinterpret_cast<const bf16_t*>(buf);
     const bf16_t* yh = th + NXC * 64 * 8;
-#if !defined(VW_BF16_K1)
     if constexpr (B16) {
       // bf16 storage (round 4): v_mfma_f32_4x4x4_16b_bf16 with K = the FOUR ROWS of an output plane.  Block b is still W voxel b; lane
       // (b, i) holds channel i of that voxel column in rows hh = 0..3 -- four 2-byte LDS reads packed into two registers, no widening
@@ -1845,8 +1736,6 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
       }
       return;
     }
-#endif
-#if !defined(VW_NO_PREFETCH) && !defined(VW_NO_LDS) && !defined(VW_NO_MFMA)
     if constexpr (!B16) {
       // fp32: the operands of row r + PF are requested before the MFMAs of row r are issued (three register sets, rotation resolved
       // by the full unroll).  hipcc's own schedule asked for a row's operands 3 - 7 MFMAs ahead of their use and then sat on
@@ -1879,7 +1768,6 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
       }
       return;
     }
-#endif
     // ---- 16 rows of 16 voxels: row r = (g, hh) -> output plane d0+g, row h0+hh
 #pragma unroll
     for (int r = 0; r < TD * GH; ++r) {
@@ -1895,32 +1783,19 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_kernel(VwArgs a) {
 #pragma unroll
           for (int qa = 0; qa < QC; ++qa) avs[t][qa] = ld1(th + rbase + toff[t] + qa * 4);
       } else {
-#ifdef VW_NO_LDS
-#pragma unroll
-        for (int qb = 0; qb < QC; ++qb) bvs[qb] = (float)(r + qb + lane);
-#pragma unroll
-        for (int t = 0; t < 7; ++t)
-#pragma unroll
-          for (int qa = 0; qa < QC; ++qa) avs[t][qa] = (float)(toff[t] + r + qa);
-#else
 #pragma unroll
         for (int qb = 0; qb < QC; ++qb) bvs[qb] = yf[((r * GW + blk) * Q + qb) * 4 + i4];
 #pragma unroll
         for (int t = 0; t < 7; ++t)
 #pragma unroll
           for (int qa = 0; qa < QC; ++qa) avs[t][qa] = tf[qa * NVOX * 4 + rbase + toff[t]];
-#endif
       }
 #pragma unroll
       for (int t = 0; t < 7; ++t)
 #pragma unroll
         for (int qa = 0; qa < QC; ++qa)
 #pragma unroll
-#ifdef VW_NO_MFMA
-          for (int qb = 0; qb < QC; ++qb) acc[t][qa][qb][0] += avs[t][qa] * bvs[qb];
-#else
           for (int qb = 0; qb < QC; ++qb) acc[t][qa][qb] = __builtin_amdgcn_mfma_f32_4x4x1f32(avs[t][qa], bvs[qb], acc[t][qa][qb], 0, 0, 0);
-#endif
     }
   };
   if constexpr (NS > 0) {
@@ -2127,7 +2002,6 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
       }
       continue;
     }
-#if !defined(VW_NO_PREFETCH)
     if constexpr (!B16 && !BY16) {
       // fp32: operands of row r + 2 requested before the MFMAs of row r (see vox_wgrad_kernel)
       constexpr int PF = 2, NR = TD * GH;
@@ -2157,7 +2031,6 @@ __global__ __launch_bounds__(256, 2) void vox_wgrad_s2_kernel(Vw2Args a) {
       }
       continue;
     }
-#endif
 #pragma unroll
     for (int r = 0; r < TD * GH; ++r) {
       const int g = r >> 2, hh = r & 3;

@@ -1155,21 +1155,6 @@ __global__ __launch_bounds__(256) void affine_act_gn2_kernel(GnFwdTerm t0, GnFwd
   }
 }
 
-#ifdef EW_STAMP
-#define EW_STAMP_ON 1
-// debug build only (tools/ew_stamps.py): phase stamps of wave 0 of every workgroup of the apply_gn2 / reduce2 kernels
-__device__ unsigned long long ew_stamp_buf[4096 * 8];
-#define ESTAMP(k) do { if (threadIdx.x == 0 && EW_STAMP_ON) { const int wgl_ = blockIdx.x + gridDim.x * blockIdx.y; if (wgl_ < 4096) ew_stamp_buf[wgl_ * 8 + (k)] = clock64(); } } while (0)
-extern "C" int n3d_debug_ew_stamps(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ew_stamp_buf), (size_t)n * 8); }
-#else
-#define ESTAMP(k)
-#endif
-#ifdef EW_STAMP_R2
-#define AESTAMP(k)
-#else
-#define AESTAMP(k) ESTAMP(k)
-#endif
-
 // backward pass 1 for two ops that share the node gradient dout: sums0 / sums1 rows as affine_bwd_reduce_kernel
 struct BwdRedTerm { const float* raw; int64_t rld; const float* a; const float* b; double* sums; int relu; };
 
@@ -1181,9 +1166,6 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const T* __rest
   __shared__ double lds[4 * 64 * 12];
   const int b = blockIdx.y;
   const int t = threadIdx.x;
-#ifdef EW_STAMP_R2
-  ESTAMP(0);
-#endif
   const int vl = (int)m.fcpb.div((uint32_t)t), c4 = t - vl * m.cpb;
   const bool active = vl < m.vpb;
   float s1[2][4], s2[2][4], sz[2][4];
@@ -1236,9 +1218,6 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const T* __rest
       }
     }
   }
-#ifdef EW_STAMP_R2
-  ESTAMP(1);
-#endif
   if (m.cpb <= 16) {
     const int64_t ro = ((int64_t)b * gridDim.x + blockIdx.x) * C * 3;
     double* const rows[2] = {t0.sums + ro, t1.sums + ro};
@@ -1251,15 +1230,8 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const T* __rest
         X[3 * k + 1] = wave_classsum4_f<CPB>(s2[k][0], s2[k][1], s2[k][2], s2[k][3]);
         X[3 * k + 2] = wave_classsum4_f<CPB>(sz[k][0], sz[k][1], sz[k][2], sz[k][3]);
       }
-#ifdef EW_STAMP_R2
-      ESTAMP(2);
-#endif
       block_reduce_packed_rows<2, 3, CPB>(X, rows, reinterpret_cast<float*>(lds));
     });
-#ifdef EW_STAMP_R2
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ESTAMP(6);
-#endif
     return;
   }
 #pragma unroll
@@ -1271,18 +1243,8 @@ __global__ __launch_bounds__(256) void affine_bwd_reduce2_kernel(const T* __rest
     }
     double* row = (k == 0 ? t0.sums : t1.sums) + ((int64_t)b * gridDim.x + blockIdx.x) * C * 3;
     if (k == 1) __syncthreads();
-#ifdef EW_STAMP_R2
-    ESTAMP(2 + 2 * k);
-#endif
     block_reduce_to_row<3>(vals, m.cpb, row, lds, true);
-#ifdef EW_STAMP_R2
-    ESTAMP(3 + 2 * k);
-#endif
   }
-#ifdef EW_STAMP_R2
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  ESTAMP(6);
-#endif
 }
 
 
@@ -1294,7 +1256,6 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __re
   N3D_CHAIN_PRIO();
   __shared__ __attribute__((aligned(16))) float cw[4][2][3][64];  // [wave][term][A|B|C][channel]
   const int t = threadIdx.x, wave = t >> 6;
-  AESTAMP(0);
   if (!PRE && blockIdx.x == gridDim.x - 1) {
     // the extra workgroup of the launch (grid.x = rows + 1): the parameter gradients, which need the partial rows of EVERY sample.
     // They used to be the job of wave 0 of workgroup (0, 0) in front of its share of the apply work, and a launch lasts as long
@@ -1332,9 +1293,7 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __re
     cA[0] = ld4(t0.cA + co); cB[0] = ld4(t0.cB + co); cC[0] = ld4(t0.cC + co);
     cA[1] = ld4(t1.cA + co); cB[1] = ld4(t1.cB + co); cC[1] = ld4(t1.cC + co);
   } else {
-    AESTAMP(1);
     gn_bwd_prologue_wave2(t0, t1, B, C, G, count, false, cw[wave]);
-    AESTAMP(3);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1369,21 +1328,11 @@ __global__ __launch_bounds__(256) void affine_bwd_apply_gn2_kernel(const T* __re
     }
     st4(op, make_float4(o[0], o[1], o[2], o[3]));
   };
-  AESTAMP(4);
-#ifdef EW_STAMP
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  AESTAMP(5);
-#endif
 #pragma unroll
   for (int i = 0; i < PF; ++i) {
     const int64_t v = v0 + (int64_t)i * m.vpb;
     if (i < m.iters && v < N) { one(0, dq[i], r0[i], o0 + v * t0.drld); one(1, TWO ? dq1[TWO ? i : 0] : dq[i], r1[i], o1 + v * t1.drld); }
   }
-#ifdef EW_STAMP
-  AESTAMP(6);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  AESTAMP(7);
-#endif
   for (int it = PF; it < m.iters; it += PF) {   // four iterations at a time, loads first
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
@@ -2332,9 +2281,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   };
   // ADAM_U float4 per lane and array, all requested before the first update (the flat buffers are 16-byte aligned; n % 4 == 0 by
   // construction of the flat layout, a ragged tail goes element by element)
-#ifndef ADAM_U
-#define ADAM_U 2
-#endif
+  constexpr int ADAM_U = 2;
   const bool vec = (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
   const int64_t n4 = vec ? n / 4 : 0;
   const int64_t stride = (int64_t)gridDim.x * 256;

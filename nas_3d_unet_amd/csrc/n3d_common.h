@@ -108,9 +108,7 @@ static inline EwMap ew_map(int64_t N, int C) {
 // Kernels of the dependent chain raise their waves' issue priority (s_setprio 0..3, 0 = the reset value): the weight-gradient
 // kernels, which only ever run beside the chain on the side streams, stay at 0, so where both have waves on a SIMD the chain's
 // instructions go first.  No effect when a kernel has the chip to itself.
-#ifndef N3D_PRIO
 #define N3D_PRIO 3
-#endif
 #define N3D_CHAIN_PRIO() __builtin_amdgcn_s_setprio(N3D_PRIO)
 // ---- activation storage types.  fp32 is the reference's arithmetic; bf16 is the STORAGE format of the HBM-bound
 // levels in the bf16 configuration (BASELINE configs[4]): every kernel converts on load / store and computes in fp32.

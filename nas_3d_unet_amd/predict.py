@@ -4,8 +4,6 @@ one by one through the host, prediction.py:132-138), device stitching and label 
 are n3d_patch_batch, the net's own ops, n3d_stitch and n3d_tumor_labels."""
 from __future__ import annotations
 
-import itertools
-
 import numpy as np
 import torch
 
@@ -13,43 +11,54 @@ from . import datastep, poststep
 from ._lib import N3DError
 
 
-def _grid(start, stop, step):
-    """corner grid of np.mgrid[start:stop:step] per axis, first axis slowest, truncated to integers (patches.py:72-74)"""
-    axes = [np.arange(start[d], stop[d], step[d]) for d in range(3)]
-    return np.asarray(list(itertools.product(*axes)), dtype=np.float64).reshape(-1, 3).astype(np.int64)
+def _corner_lattice(first, pitch, count):
+    """All corners first + i * pitch, i < count per axis (first axis slowest), truncated towards zero: the lattice np.mgrid walks for
+    the reference (patches.py:72-74).  first / pitch may be fractional -- the reference spreads the patches evenly with a real-valued
+    pitch and lets the integer cast place them."""
+    axes = [first[d] + np.arange(int(count[d])) * pitch[d] for d in range(3)]
+    return np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, 3).astype(np.int64)
 
 
-def _autofit(img, patch):
-    """least number of patches covering the image symmetrically + the central cube (patches.py:9-34)"""
+def _even_cover(img, patch):
+    """The auto-fitting strategy of patches.py:9-34 in closed form, all three axes at once.  An axis needs n = ceil(img / patch) patches.
+    n = 1: the one patch is centred (it overhangs by patch - img, the odd voxel on the low side).  n > 1: the n patches share their
+    total excess n * patch - img evenly, i.e. neighbours overlap by excess / (n - 1) and the pitch is patch - that; what is left
+    over after the real-valued division (zero up to rounding, and the reference keeps the rounding) is split around the image like
+    the overhang.  Returns (first corner, pitch, count) per axis."""
+    img, patch = img.astype(np.float64), patch.astype(np.float64)
     n = np.ceil(img / patch)
-    start, step = np.zeros(3), np.zeros(3)
-    for d in range(3):
-        if n[d] == 1:
-            start[d] = -(patch[d] - img[d]) // 2
-            step[d] = patch[d]
-        else:
-            overlap = np.floor(n[d] * patch[d] - img[d]) / (n[d] - 1)
-            overflow = n[d] * patch[d] - (n[d] - 1) * overlap - img[d]
-            start[d] = -overflow // 2
-            step[d] = patch[d] - overlap
-    stop = start + n * step
-    return np.vstack((_grid(start, stop, step), (img - patch) // 2))
+    lone = n == 1
+    gaps = np.where(lone, 1.0, n - 1.0)
+    share = np.floor(n * patch - img) / gaps                      # overlap between neighbours (n > 1)
+    rest = n * patch - (n - 1.0) * share - img                    # excess the even split leaves
+    first = np.where(lone, (-(patch - img)) // 2, (-rest) // 2)
+    pitch = np.where(lone, patch, patch - share)
+    # the reference walks mgrid[first : first + n * pitch : pitch]: ceil(((first + n * pitch) - first) / pitch) corners
+    count = np.ceil(((first + n * pitch) - first) / pitch)
+    return first, pitch, count
+
+
+def _fixed_overlap_cover(img, patch, ov):
+    """The given-overlap strategy of patches.py:59-67: pitch patch - ov, as many patches as it takes, the overhang split around the image"""
+    img, patch, ov = img.astype(np.float64), patch.astype(np.float64), ov.astype(np.float64)
+    pitch = patch - ov
+    n = np.ceil(img / pitch)
+    first = (-(patch * n - (n - 1.0) * ov - img)) // 2
+    count = np.ceil(((first + n * pitch) - first) / pitch)
+    return first, pitch, count
 
 
 def patching(img_shape, patch_shape, overlap=None, both_ps=False):
-    """bottom-left patch corners, as patches.patching (patches.py:36-70)"""
+    """bottom-left patch corners as the reference's patches.patching lists them (patches.py:36-70): the evenly spread cover followed
+    by the centred cube; with `overlap` the centred cube followed by the fixed-overlap cover; with both_ps the first list, then the second."""
     img, patch = np.asarray(img_shape), np.asarray(patch_shape)
-    auto = _autofit(img, patch)
+    centre = ((img - patch) // 2).reshape(1, 3).astype(np.int64)
+    even = np.concatenate((_corner_lattice(*_even_cover(img, patch)), centre))
     if overlap is None:
-        return auto
-    ov = np.asarray([overlap] * 3) if isinstance(overlap, int) else np.asarray(overlap)
-    n = np.ceil(img / (patch - ov))
-    overflow = patch * n - (n - 1) * ov - img
-    start = -overflow // 2
-    step = patch - ov
-    stop = start + n * step
-    ol = np.vstack(((img - patch) // 2, _grid(start, stop, step)))
-    return np.vstack((auto, ol)) if both_ps else ol
+        return even
+    ov = np.full(3, overlap) if isinstance(overlap, int) else np.asarray(overlap)
+    fixed = np.concatenate((centre, _corner_lattice(*_fixed_overlap_cover(img, patch, ov))))
+    return np.concatenate((even, fixed)) if both_ps else fixed
 
 
 class Predictor:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes of round 5 over the bf16-storage 3x3x3 conv at (2,4,128^3) (conv_vox64b_kernel<4,8,1,1,true,0>): one counter
 # group per run, counters only -- never combined with a trace -- then the kernel's time from a kernel-trace run of the same command.
-#   N3D_LIB=<another build> selects the library (tools/build_variant.sh); TAG names the output:  TAG=after tools/collect_pmc_r05.sh
+#   TAG names the output:  TAG=after tools/collect_pmc_r05.sh
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r05; mkdir -p $O
 TAG=${TAG:-after}
