@@ -2364,6 +2364,182 @@ __global__ __launch_bounds__(256, 2) void conv_tile16_kernel(MfArgs a, const voi
 }
 
 // ------------------------------------------------------------------------------------------------
+// tile32 (round 6): the tile16 scheme for 32 -> 32 channels (3x3x3, stride 1, dilation 1 / 2) on volumes >= 16 wide -- the C = 32
+// level of 128^3 patches (2 x 16^3), which the K-split gather plan ran at 0.20 of the fp32 MFMA peak, latency-bound on its 54
+// gathered operand loads per wave (profiles/r06_pmc_gemm16_before.json: 58 % of the wave cycles parked in s_waitcnt).  A
+// workgroup owns 1 x 4 x 16 output voxels and ONE half of the output channels (grid.y): 256 workgroups at 2 x 16^3, all compute
+// units.  LDS: the halo tile as 128-byte voxel records (eight 16-byte channel quads, XOR-swizzled by the voxel index so that the
+// 16 voxels of a row land on distinct banks: 41 KB at dilation 1, 102 KB at dilation 2) and the workgroup's weight columns
+// Wp[tap][c16][kk][16 cd][j] (54 KB), both by LDS-DMA.  Wave w = row w of the tile: per (tap, 16-channel block) one ds_read_b128
+// of the A operand (lane (m, kk): channels 4 kk .. 4 kk + 3 of voxel m), one of the B operand, four v_mfma_f32_16x16x4_f32
+// (N3D_MM_BF16: one v_mfma_f32_16x16x16_bf16).  Same arguments, epilogue and packed-weight layout as gemm16; one statistics
+// row per tile.   DG: data gradient = the same conv with mirrored taps (weights packed transposed by the pack kernel).
+// ------------------------------------------------------------------------------------------------
+template <int DIL, bool DG, bool BF>
+__global__ __launch_bounds__(256, 1) void conv_tile32_kernel(MfArgs a, const void* zero_page, int tiles, FastDiv fT, FastDiv fTw, FastDiv fTh) {
+  N3D_CHAIN_PRIO();
+  constexpr int TH = 4, TW = 16;
+  constexpr int LD = 1 + 2 * DIL, LH = TH + 2 * DIL, LW = TW + 2 * DIL, NV = LD * LH * LW;
+  constexpr int NP = NV * 8, NIT = (NP + 255) / 256;     // float4 pieces of the halo tile (8 per voxel), DMA instructions per thread
+  constexpr int WSL = 27 * 2 * 64, WIT = (WSL + 255) / 256;   // float4 slots of this workgroup's weight columns
+  extern __shared__ __attribute__((aligned(16))) float4 t32[];   // [NIT * 256] halo pieces, [WIT * 256] weights, 64 float4 of reduction space
+  float4* const wl = t32 + NIT * 256;
+  double* const red = reinterpret_cast<double*>(wl + WIT * 256);   // [4 * 16 * 2]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, kk = lane >> 4;
+  const int nh = blockIdx.y;                              // which 16 of the 32 output channels
+  int wg = blockIdx.x;
+  {  // XCD-aware placement (see conv_vox64_kernel): every XCD takes one contiguous run of tiles
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  uint32_t ub, utile, ubx, uw, ud, uh;
+  fT.divmod((uint32_t)wg, ub, utile);
+  fTw.divmod(utile, ubx, uw);
+  fTh.divmod(ubx, ud, uh);
+  const int b = (int)ub, tid = (int)utile;
+  const int D = a.Dd, H = a.Hd, W = a.Wd;
+  const int w0 = (int)uw * TW, h0 = (int)uh * TH, d0 = (int)ud;
+  const int64_t N = (int64_t)D * H * W;
+  const bool accum = a.flags & N3D_ACCUMULATE;
+  const int cd = nh * 16 + m;
+
+  // epilogue operands first (ordinary loads, in flight behind the fill)
+  const float e_bias = a.bias ? a.bias[cd] : 0.f;
+  const float e_gate = a.out_gate ? a.out_gate[(int64_t)b * 32 + cd] : 1.f;
+  float e_relu[4], e_prev[4];
+  const int64_t orow = (int64_t)b * N + ((int64_t)d0 * H + h0 + wave) * W + w0 + kk * 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    e_relu[r] = a.relu_src ? a.relu_src[(orow + r) * a.rld + cd] : 1.f;
+    e_prev[r] = accum ? a.dst[(orow + r) * a.dld + cd] : 0.f;
+  }
+  {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const float4* zp = reinterpret_cast<const float4*>(zero_page);
+    const float* srcb = a.src + (int64_t)b * N * a.sld;
+    // halo: piece pc -> voxel v = pc >> 3, LDS quad x = pc & 7 holding channel quad q = x ^ ((v >> 1) & 7)
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int pc = (i * 4 + wave) * 64 + lane;
+      const int v = pc >> 3, q = (pc & 7) ^ ((v >> 1) & 7);
+      const int x = v % LW, y = (v / LW) % LH, z = v / (LW * LH);
+      const int gd = d0 - DIL + z, gh = h0 - DIL + y, gw = w0 - DIL + x;
+      const bool ok = v < NV && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+      const float* sp = srcb + (((int64_t)gd * H + gh) * W + gw) * a.sld + q * 4;
+      __builtin_amdgcn_global_load_lds((gptr_t)(ok ? reinterpret_cast<const float4*>(sp) : zp), (lptr_t)(t32 + (i * 4 + wave) * 64), 16, 0, 0);
+    }
+    // weights: slot s = ((tap * 2 + c16) * 4 + kq) * 16 + mm  <-  Wp float4 ((tap * 2 + c16) * 4 + kq) * 32 + nh * 16 + mm
+    const float4* wp4 = reinterpret_cast<const float4*>(a.wp);
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) {
+      const int sidx = (i * 4 + wave) * 64 + lane;
+      const float4* gp = sidx < WSL ? wp4 + (sidx >> 4) * 32 + nh * 16 + (sidx & 15) : zp;
+      __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(wl + (i * 4 + wave) * 64), 16, 0, 0);
+    }
+  }
+  float4 gq[2];
+  gq[0] = gq[1] = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (a.in_gate) {
+    gq[0] = *reinterpret_cast<const float4*>(a.in_gate + (int64_t)b * 32 + kk * 4);
+    gq[1] = *reinterpret_cast<const float4*>(a.in_gate + (int64_t)b * 32 + 16 + kk * 4);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+  const float relu_floor = (a.flags & N3D_RELU_IN) ? 0.f : -INFINITY;
+  const bool gated = a.in_gate != nullptr;
+  const int vrow = (DIL * LH + wave + DIL) * LW + DIL + m;      // halo index of this lane's output voxel (tap offset 0,0,0 = centre - DIL)
+  const float4* wlane = wl + kk * 16 + m;
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int oz = (DG ? 1 - kd : kd - 1) * DIL, oy = (DG ? 1 - kh : kh - 1) * DIL, ox = (DG ? 1 - kw : kw - 1) * DIL;
+        const int tap = (kd * 3 + kh) * 3 + kw;
+        const int v = vrow + (oz * LH + oy) * LW + ox;
+        const int sw = (v >> 1) & 7;
+#pragma unroll
+        for (int c16 = 0; c16 < 2; ++c16) {
+          float4 av = t32[v * 8 + ((c16 * 4 + kk) ^ sw)];
+          const float4 w4 = wlane[(tap * 2 + c16) * 64];
+          av.x = fmaxf(av.x, relu_floor); av.y = fmaxf(av.y, relu_floor); av.z = fmaxf(av.z, relu_floor); av.w = fmaxf(av.w, relu_floor);
+          if (gated) { av.x *= gq[c16].x; av.y *= gq[c16].y; av.z *= gq[c16].z; av.w *= gq[c16].w; }
+          if constexpr (BF) {
+            if (c16) acc2 = mm_bf16(mm_cvt4(av), mm_cvt4(w4), acc2);
+            else acc = mm_bf16(mm_cvt4(av), mm_cvt4(w4), acc);
+          } else {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, w4.x, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, w4.y, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, w4.z, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, w4.w, acc2, 0, 0, 0);
+          }
+        }
+      }
+
+  // ---- epilogue: lane holds channel cd of voxels 4kk .. 4kk+3 of its row
+  float csum = 0.f, csq = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = acc[r] + acc2[r] + e_bias;
+    if (!(e_relu[r] > 0.f)) v = 0.f;
+    v = v * e_gate + e_prev[r];
+    a.dst[(orow + r) * a.dld + cd] = v;
+    csum += v; csq = fmaf(v, v, csq);
+  }
+  if (a.stats) {
+    const double s = xsum32_d(xsum16_d((double)csum)), q = xsum32_d(xsum16_d((double)csq));
+    if (kk == 0) { red[(wave * 16 + m) * 2] = s; red[(wave * 16 + m) * 2 + 1] = q; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int q2 = threadIdx.x & 1, col = threadIdx.x >> 1;
+      double tot = 0;
+      for (int w = 0; w < 4; ++w) tot += red[(w * 16 + col) * 2 + q2];
+      a.stats[(((int64_t)b * a.rows_per_sample + tid) * 32 + nh * 16 + col) * 2 + q2] = tot;
+    }
+  }
+}
+
+// geometry-only decision (n3d_conv_stats_rows must agree with the launch): tiles per sample, 0 = not this kernel
+static int tile32_tiles(const n3d_conv_geom* g) {
+  if (g->depthwise || g->k != 3 || g->stride != 1 || g->Ci != 32 || g->Co != 32) return 0;
+  if ((g->dil != 1 && g->dil != 2) || g->pad != g->dil) return 0;
+  if (g->Wi % 16 != 0 || g->Hi % 4 != 0) return 0;
+  const int tiles = (g->Wi / 16) * (g->Hi / 4) * g->Di;
+  if ((int64_t)tiles * g->B < 128) return 0;      // fewer tiles than half the compute units: the K-split plans serve the small levels
+  return tiles;
+}
+
+static bool launch_tile32(const MfArgs& a, int tiles, hipStream_t s) {
+  const void* zp = zero_page_ptr();
+  if (!zp || a.sld % 4 != 0 || !aligned16(a.src) || !aligned16(a.wp)) return false;
+  const int d = a.dt < 0 ? -a.dt : a.dt;
+  const int nv = (1 + 2 * d) * (4 + 2 * d) * (16 + 2 * d);
+  const size_t shm = ((size_t)((nv * 8 + 255) / 256) * 256 + (size_t)((27 * 2 * 64 + 255) / 256) * 256 + 64) * 16;
+  const dim3 grid((unsigned)(tiles * a.B), 2);
+  const FastDiv fT((uint32_t)tiles), fTw((uint32_t)(a.Wd / 16)), fTh((uint32_t)(a.Hd / 4));
+  const bool bf = a.flags & N3D_MM_BF16;
+  static bool attr_set = false;
+  if (!attr_set) {
+#define N3D_T32_ATTR(DIL_, DG_, BF_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tile32_kernel<DIL_, DG_, BF_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    N3D_T32_ATTR(1, false, false); N3D_T32_ATTR(1, true, false); N3D_T32_ATTR(2, false, false); N3D_T32_ATTR(2, true, false);
+    N3D_T32_ATTR(1, false, true); N3D_T32_ATTR(1, true, true); N3D_T32_ATTR(2, false, true); N3D_T32_ATTR(2, true, true);
+#undef N3D_T32_ATTR
+    attr_set = true;
+  }
+#define N3D_T32_LAUNCH(DIL_, DG_) do { if (bf) hipLaunchKernelGGL((conv_tile32_kernel<DIL_, DG_, true>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh); \
+    else hipLaunchKernelGGL((conv_tile32_kernel<DIL_, DG_, false>), grid, dim3(256), shm, s, a, zp, tiles, fT, fTw, fTh); } while (0)
+  if (d == 1) { if (a.dt > 0) N3D_T32_LAUNCH(1, false); else N3D_T32_LAUNCH(1, true); }
+  else { if (a.dt > 0) N3D_T32_LAUNCH(2, false); else N3D_T32_LAUNCH(2, true); }
+#undef N3D_T32_LAUNCH
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // tile16_up: the den = 2 gather of the 16-channel level -- forward of a stride-2 transposed 3x3x3 conv and data gradient of a
 // stride-2 conv (destination grid = 2 x source grid exactly):   dst[o] = sum_k W[k] . src[(o + pad - k*dil) / 2]   (if divisible).
 // Through the gemm16 gather map every output voxel visits all 27 taps and masks the 23.6 that do not divide (27 us at 2 x 32^3
@@ -2540,6 +2716,7 @@ static bool launch_tile16(const MfArgs& a, hipStream_t s) {
 }
 
 struct G16Plan { int mt, nt, ksplit, rows_per_block; bool ok; };
+static int tile32_tiles(const n3d_conv_geom* g);
 
 static G16Plan g16_plan(const n3d_conv_geom* g, bool data_grad) {
   G16Plan p; p.ok = false; p.mt = 1; p.nt = 1; p.ksplit = 4; p.rows_per_block = 16;
@@ -2580,6 +2757,7 @@ int mfma_conv_stats_rows(const n3d_conv_geom* g, bool data_grad, int flags) {
     VupPlan v3 = vup_plan(g, data_grad);
     if (v3.ok) return v3.tiles;
   }
+  { const int t = tile32_tiles(g); if (t) return t; }     // the LDS-tile kernel of the 32-channel level: one row per 1 x 4 x 16 tile
   G16Plan p = g16_plan(g, data_grad);
   if (!p.ok) return 0;
   if (p.ksplit == 1) { const int t = tile16_up_tiles(g, data_grad); if (t) return t; }
@@ -2707,6 +2885,17 @@ int mfma_conv_try(const n3d_conv_geom* g, bool data_grad, const float* src, int6
       }
     }
   }
+  if (const int t32 = tile32_tiles(g)) {
+    if (a.sn == 1 && a.den == 1 && a.Cs == 32 && a.Cd == 32) {
+      if (stats) a.rows_per_sample = t32;
+      if (launch_tile32(a, t32, s)) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error("conv(tile32) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
+        return 1;
+      }
+      if (stats) { set_error("conv(tile32): misaligned source with statistics requested"); return N3D_ERR_UNSUPPORTED; }
+    }
+  }
   if (tile16_applies(a, p.ksplit) && launch_tile16(a, s)) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("conv(tile16) launch: %s", hipGetErrorString(e)); return N3D_ERR_HIP; }
@@ -2776,6 +2965,7 @@ int mfma_conv_pair_try(const n3d_conv_geom* g0, bool dg0, const float* src0, int
   // decide before touching anything (g16_prepare packs weights)
   if ((flags0 | flags1) & (N3D_SRC_BF16 | N3D_DST_BF16)) return 0;
   if (vx_plan(g0).ok || vx_plan(g1).ok) return 0;
+  if (tile32_tiles(g0) || tile32_tiles(g1)) return 0;      // the LDS-tile kernel takes these one at a time (two launches beat the K-split pair)
   const G16Plan p0 = g16_plan(g0, dg0), p1 = g16_plan(g1, dg1);
   if (!p0.ok || !p1.ok || p0.ksplit != p1.ksplit || p0.ksplit == 1) return 0;
   if (sld0 % 4 != 0 || !aligned16(src0) || sld1 % 4 != 0 || !aligned16(src1)) return 0;
@@ -2808,7 +2998,7 @@ int mfma_conv_multi_try(int n, const n3d_conv_geom* const* g, const bool* dg, co
   if (n < 3 || n > 4) return 0;
   int ksplit = 0;
   for (int i = 0; i < n; ++i) {
-    if (vx_plan(g[i]).ok) return 0;
+    if (vx_plan(g[i]).ok || tile32_tiles(g[i])) return 0;
     const G16Plan p = g16_plan(g[i], dg[i]);
     if (!p.ok || p.ksplit == 1 || (i > 0 && p.ksplit != ksplit)) return 0;
     ksplit = p.ksplit;
