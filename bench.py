@@ -97,9 +97,9 @@ def conv_kernel_roofline(device, batch, size, iters=40, bf16=False, c=4):
     bytes_ = 2.0 * batch * size ** 3 * c * (2 if bf16 else 4)
     ach = flops / sec / 1e12
     # HBM traffic per launch: PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) need their own rocprofv3 --pmc passes, so the
-    # figure is read from the tracked summary of that pass (tools/collect_pmc_r04.sh), not measured inside this run
+    # figure is read from the tracked summary of that pass (tools/collect_pmc_r05.sh, run by tools/collect_r06.sh), not measured inside this run
     traffic, src = None, None
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         pmc = os.path.join(ROOT, "profiles", "%s_pmc_conv_vox64%s_%s_2x%dx%d.json" % (rnd, "b" if bf16 else "", "bf16" if bf16 else "f32", c, size))
         if os.path.exists(pmc):
             try:
