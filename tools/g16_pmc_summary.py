@@ -4,7 +4,7 @@ pair -- the same kernel template serves several levels, the grid tells them apar
 the same command.   usage: g16_pmc_summary.py <dir with pmc_*/ and kt/> <out.json>"""
 import csv, glob, json, re, statistics, sys, collections
 root, out = sys.argv[1], sys.argv[2]
-KEEP = ("gemm16", "bwd16", "tile16", "wgrad16")
+KEEP = ("gemm16", "bwd16", "tile16", "tile32", "wgrad16")
 
 
 def short(name):
