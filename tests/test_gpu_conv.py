@@ -32,6 +32,10 @@ CASES = [
     (16, 16, 3, 1, 1, False, 3, (12, 32, 32)),   # 576 tiles over 256 workgroups: ragged tiles-per-workgroup, workgroups span samples
     (32, 32, 3, 1, 1, False, 2, (16, 16, 16)),   # 64 tiles x 4 channel tiles: the LDS-tile weight gradient on 32 channels
     (32, 32, 3, 1, 2, False, 2, (16, 16, 16)),
+    # tile32 (round 6: LDS halo tile + weight columns, 1 x 4 x 16 voxels x 16 output channels per workgroup): 32 -> 32, stride 1, >= 128 tiles
+    (32, 32, 3, 1, 1, False, 1, (16, 32, 32)),   # one sample, 256 tiles
+    (32, 32, 3, 1, 2, False, 3, (6, 16, 32)),    # three samples, D not a multiple of anything: 144 tiles x 3
+    (32, 32, 3, 1, 1, False, 1, (8, 16, 16)),    # 32 tiles: below the tile kernel's floor, the K-split plan
     (32, 16, 3, 1, 1, False, 2, (16, 16, 32)),   # Ci != Co
     (64, 64, 3, 1, 1, False, 2, (8, 8, 8)),      # the 8^3 level of 128^3 patches: LDS-tile weight gradient on 4 x 4 x 8 tiles (8 tiles x 16 channel tiles)
     (64, 64, 3, 1, 2, False, 2, (8, 8, 8)),

@@ -96,3 +96,28 @@ def test_reference_forward_bodies_on_odd_channel_counts(kind, cfg):
         assert d <= 3e-4 * float(ref.abs().max()) + 2e-5 * total, (n, d)
     # a twin never shows in the module tree: the state dict stays the reference's
     assert not any("twin" in k for k in net.state_dict())
+
+
+def test_op_twin_follows_the_op_in_eval_mode_and_without_autograd():
+    """prim_ops._OpTwin: inference of an odd-channel op under no_grad keeps no autograd state, eval / train and a dropout switched
+    off after construction follow the op, and the twin never appears in the state dict"""
+    from nas_3d_unet_amd import prim_ops as po
+    torch.manual_seed(3)
+    op = po.ConvOps(6, 6, kernel_size=3, dropout_rate=0.5).cuda()
+    x = torch.randn(2, 6, 8, 8, 8, device="cuda")
+    op.eval()
+    with torch.no_grad():
+        y0 = op(x)
+    assert not y0.requires_grad and y0.shape == (2, 6, 8, 8, 8)
+    tw = op.__dict__["_n3d_optwin"]
+    assert not tw.twin.training and tw.twin.dropout is not None
+    # eval-mode forward equals the oracle's functional conv + GroupNorm + ReLU on the same parameters
+    ref = torch.nn.functional.conv3d(x.double().cpu(), op.conv.weight.detach().double().cpu(), op.conv.bias.detach().double().cpu(), padding=1)
+    ref = torch.relu(torch.nn.functional.group_norm(ref, 1, op.norm.weight.detach().double().cpu(), op.norm.bias.detach().double().cpu(), 1e-5))
+    assert_close(y0, ref.float(), 2e-5, "eval forward")
+    op.dropout = None
+    op.train()
+    y1 = op(x)
+    assert op.__dict__["_n3d_optwin"].twin.dropout is None and op.__dict__["_n3d_optwin"].twin.training
+    assert_close(y1, ref.float(), 2e-5, "train forward without dropout")
+    assert sorted(op.state_dict()) == ["conv.bias", "conv.weight", "norm.bias", "norm.weight"]
