@@ -11,6 +11,7 @@ from __future__ import annotations
 
 from math import ceil
 
+import torch
 import torch.nn as nn
 
 from . import programs as P
@@ -79,7 +80,6 @@ class _OpTwin:
             self.twin.norm._n3d_real_c = int(op.norm.num_channels)
 
     def embed(self, op):
-        import torch
         tp = dict(self.twin.named_parameters())
         with torch.no_grad():
             for n, r in op.named_parameters():
@@ -94,45 +94,47 @@ class _OpTwin:
             self.twin.dropout = None if op.dropout is None else nn.Dropout3d(op.dropout.p)
 
 
+class _PaddedOpFn(torch.autograd.Function):
+    """forward / backward of ONE op through its zero-padded twin (see _OpTwin); inputs: (op, twin, need_grad, x, *the op's parameters)"""
+
+    @staticmethod
+    def forward(ctx, op, tw, need_grad, xin, *_params):
+        from .train import _padded_flags
+        tw.embed(op)
+        cin, cout = tw.cin, tw.cout
+        B, _c, D, H, W = xin.shape
+        xp = torch.zeros((B, D, H, W, _pad4(cin)), dtype=xin.dtype, device=xin.device).permute(0, 4, 1, 2, 3)
+        xp[:, :cin].copy_(xin)
+        with _padded_flags(), torch.set_grad_enabled(need_grad):
+            xi = xp.requires_grad_(need_grad and xin.requires_grad)
+            out = BaseOp._run_segments(tw.twin, xi)
+        if need_grad:
+            ctx.saved = (op, tw, xi, out)
+        return out.detach()[:, :cout]
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .train import _padded_flags
+        op, tw, xi, out = ctx.saved
+        tp = dict(tw.twin.named_parameters())
+        reals = list(op.named_parameters())
+        dp = torch.zeros_like(out)
+        dp[:, :tw.cout].copy_(dout)
+        wanted = ([xi] if xi.requires_grad else []) + [tp[n] for n, _ in reals]
+        with _padded_flags():
+            gs = list(torch.autograd.grad([out], wanted, [dp], allow_unused=True))
+        gx = gs.pop(0)[:, :tw.cin] if xi.requires_grad else None
+        gpar = [None if g is None else g[tuple(slice(0, k) for k in r.shape)] for g, (_, r) in zip(gs, reals)]
+        return (None, None, None, gx, *gpar)
+
+
 def _run_padded_op(op, x):
-    import torch
-    from .train import _padded_flags
     tw = op.__dict__.get("_n3d_optwin")
     plist = list(op.parameters())
     if tw is None or (plist and next(tw.twin.parameters()).device != plist[0].device):
         tw = op.__dict__["_n3d_optwin"] = _OpTwin(op)      # (kept out of the module tree: the state dict stays the reference's)
-    names = [n for n, _ in op.named_parameters()]
     need_grad = torch.is_grad_enabled() and (x.requires_grad or any(q.requires_grad for q in plist))
-    cin, cout = tw.cin, tw.cout
-
-    class Fn(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, xin, *_):
-            tw.embed(op)
-            B, _c, D, H, W = xin.shape
-            xp = torch.zeros((B, D, H, W, _pad4(cin)), dtype=xin.dtype, device=xin.device).permute(0, 4, 1, 2, 3)
-            xp[:, :cin].copy_(xin)
-            with _padded_flags(), torch.set_grad_enabled(need_grad):
-                xi = xp.requires_grad_(need_grad and xin.requires_grad)
-                out = BaseOp._run_segments(tw.twin, xi)
-            if need_grad:
-                ctx.saved = (xi, out)
-            return out.detach()[:, :cout]
-
-        @staticmethod
-        def backward(ctx, dout):
-            xi, out = ctx.saved
-            tp = dict(tw.twin.named_parameters())
-            dp = torch.zeros_like(out)
-            dp[:, :cout].copy_(dout)
-            wanted = ([xi] if xi.requires_grad else []) + [tp[n] for n in names]
-            with _padded_flags():
-                gs = list(torch.autograd.grad([out], wanted, [dp], allow_unused=True))
-            gx = gs.pop(0)[:, :cin] if xi.requires_grad else None
-            gpar = [None if g is None else g[tuple(slice(0, k) for k in r.shape)] for g, r in zip(gs, plist)]
-            return (gx, *gpar)
-
-    return Fn.apply(x, *plist)
+    return _PaddedOpFn.apply(op, tw, need_grad, x, *plist)
 
 
 class BaseOp(nn.Module):

@@ -162,63 +162,81 @@ class PaddedTwin:
         return g
 
 
-def run_padded(net, x, alphas=None, loss_target=None, smooth=1e-6):
-    """forward (probabilities, or (Dice loss, probabilities) with loss_target) of a net with odd channel counts through its padded twin"""
-    import torch
-    from . import programs as P
-    tw = net.__dict__.get("_n3d_twin")
-    if tw is None or next(net.parameters()).device != next(tw.twin.parameters()).device:
-        tw = net.__dict__["_n3d_twin"] = net._n3d_make_twin()      # (kept out of the module tree: the state dict stays the reference's)
-    names = tw.names
-    rp = dict(net.named_parameters())
-    reals = [rp[n] for n in names]
-    n_al = 0 if alphas is None else len(alphas)
-    # inference (no_grad / nothing requires a gradient): the twin runs under no_grad too -- no autograd graph, no saved activations
-    need_grad = torch.is_grad_enabled() and (x.requires_grad or any(r.requires_grad for r in reals)
-                                             or any(a.requires_grad for a in (alphas or ())))
+class _padded_switches:
+    """while kernels of a padded twin are launched: conv-bias gradients by summation, per-term GroupNorm launches (the node-level ones
+    share their element count with SE gates), no node-planar inner cells (train._padded_flags is the same set)"""
 
-    class Fn(torch.autograd.Function):
+    def __enter__(self):
+        from . import programs as P
+        self.prev = (P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER)
+        P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER = False, False, False, False, False
+
+    def __exit__(self, *exc):
+        from . import programs as P
+        P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER = self.prev
+        return False
+
+
+def _padded_net_fn():
+    """the autograd node of run_padded (built on first use: torch is imported lazily in this module)"""
+    global _PaddedNetFn
+    if _PaddedNetFn is not None:
+        return _PaddedNetFn
+    import torch
+
+    class PaddedNetFn(torch.autograd.Function):
+        """inputs: (net, twin, need_grad, loss target | None, smooth, number of alphas, x, *alphas, *the net's parameters in twin.names order)"""
+
         @staticmethod
-        def forward(ctx, xin, *rest):
-            al, _ = rest[:n_al], rest[n_al:]
+        def forward(ctx, net, tw, need_grad, loss_target, smooth, n_al, xin, *rest):
+            al = rest[:n_al]
             tw.embed(net)
-            prev = (P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER)
-            P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER = False, False, False, False, False
-            try:
-                with torch.set_grad_enabled(need_grad):
-                    xi = xin.detach().requires_grad_(need_grad and xin.requires_grad)
-                    ali = tuple(a.detach().requires_grad_(need_grad and a.requires_grad) for a in al)
-                    if loss_target is None:
-                        out = (run(tw.twin, xi, ali if n_al else None),)
-                    else:
-                        out = run_loss(tw.twin, xi, loss_target, ali if n_al else None, smooth)
-            finally:
-                P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER = prev
+            with _padded_switches(), torch.set_grad_enabled(need_grad):
+                xi = xin.detach().requires_grad_(need_grad and xin.requires_grad)
+                ali = tuple(a.detach().requires_grad_(need_grad and a.requires_grad) for a in al)
+                if loss_target is None:
+                    out = (run(tw.twin, xi, ali if n_al else None),)
+                else:
+                    out = run_loss(tw.twin, xi, loss_target, ali if n_al else None, smooth)
             if need_grad:
-                ctx.saved = (xi, ali, out)
+                ctx.saved = (tw, xi, ali, out)
             return tuple(o.detach() for o in out)
 
         @staticmethod
         def backward(ctx, *douts):
-            xi, ali, out = ctx.saved
+            tw, xi, ali, out = ctx.saved
             tp = dict(tw.twin.named_parameters())
             wanted = [xi] if xi.requires_grad else []
             wanted += [a for a in ali if a.requires_grad]
-            wanted += [tp[n] for n in names]
+            wanted += [tp[n] for n in tw.names]
             outs = [o for o, d in zip(out, douts) if d is not None and o.requires_grad]
             gouts = [d for o, d in zip(out, douts) if d is not None and o.requires_grad]
-            prev = (P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER)
-            P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER = False, False, False, False, False
-            try:
+            with _padded_switches():
                 gs = list(torch.autograd.grad(outs, wanted, gouts, allow_unused=True))
-            finally:
-                P.ANALYTIC_CONV_BIAS, fused.NODE_PHASES, fused.NODE_APPLY, P.NODE_FWD_COEFFS, fused.PLANAR_INNER = prev
             gx = gs.pop(0) if xi.requires_grad else None
             gal = [gs.pop(0) if a.requires_grad else None for a in ali]
-            gpar = [tw.extract(n, g) if g is not None else None for n, g in zip(names, gs)]
-            return (gx, *gal, *gpar)
+            gpar = [tw.extract(n, g) if g is not None else None for n, g in zip(tw.names, gs)]
+            return (None, None, None, None, None, None, gx, *gal, *gpar)
 
-    res = Fn.apply(x, *(alphas if alphas is not None else ()), *reals)
+    _PaddedNetFn = PaddedNetFn
+    return _PaddedNetFn
+
+
+_PaddedNetFn = None
+
+
+def run_padded(net, x, alphas=None, loss_target=None, smooth=1e-6):
+    """forward (probabilities, or (Dice loss, probabilities) with loss_target) of a net with odd channel counts through its padded twin"""
+    import torch
+    tw = net.__dict__.get("_n3d_twin")
+    if tw is None or next(net.parameters()).device != next(tw.twin.parameters()).device:
+        tw = net.__dict__["_n3d_twin"] = net._n3d_make_twin()      # (kept out of the module tree: the state dict stays the reference's)
+    rp = dict(net.named_parameters())
+    reals = [rp[n] for n in tw.names]
+    als = tuple(alphas) if alphas is not None else ()
+    # inference (no_grad / nothing requires a gradient): the twin runs under no_grad too -- no autograd graph, no saved activations
+    need_grad = torch.is_grad_enabled() and (x.requires_grad or any(r.requires_grad for r in reals) or any(a.requires_grad for a in als))
+    res = _padded_net_fn().apply(net, tw, need_grad, loss_target, smooth, len(als), x, *als, *reals)
     return res[0] if loss_target is None else res
 
 
