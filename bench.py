@@ -234,7 +234,7 @@ def search_step_bench(args, device):
                    "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "loss_arch": round(float(la), 5), "loss_weight": round(float(lw), 5)}, **extra}), flush=True)
 
 
-def other_configs(device, batch, no_graph):
+def other_configs(device, batch, no_graph, targets="f32"):
     """The other single-GPU BASELINE configs, timed in the same process after the headline measurement (10 steps each after 3 warm-up
     steps, HIP-graph replay) so that the driver's own run of the default command carries them: configs[2] (supernet search step at
     4x64^3), the 4x128^3 train step in fp32 and configs[4] (4x128^3 with bf16 storage).  Each entry is a measurement or an error string."""
@@ -281,6 +281,8 @@ def other_configs(device, batch, no_graph):
         tr = Trainer(net, graph=not no_graph, storage=storage)
         xn, tn = synthetic_batch(batch, 128, 1234)
         x, t = to_patch_layout(torch.from_numpy(xn).to(device)), torch.from_numpy(tn).to(device)
+        if targets == "u8":
+            t = t.to(torch.uint8)
         sec = timed(tr, (x, t))
         return {"ms_per_step": round(sec * 1e3, 3), "patches_per_s": round(batch / sec, 2),
                 "schedule_ms": [round(v * 1e3, 3) for v in tr.schedule_times] if getattr(tr, "schedule_times", None) else None}
@@ -306,6 +308,9 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32: the reference's arithmetic and storage (the contract default); bf16: bf16 STORAGE of the HBM-bound levels' "
                          "activations, fp32 arithmetic (BASELINE configs[4], quoted at --size 128)")
+    ap.add_argument("--targets", choices=["f32", "u8"], default="f32",
+                    help="storage of the three target maps in HBM: f32 (the reference's cast, train.py:118; the contract default) or u8 "
+                         "(the generator's booleans as bytes, n3d_patch_batch's N3D_PATCH_T_U8: same losses bit for bit)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -362,6 +367,8 @@ def main():
 
     xn, tn = synthetic_batch(args.batch, args.size, 1234 + rank)
     x, t = to_patch_layout(torch.from_numpy(xn).to(device)), torch.from_numpy(tn).to(device)
+    if args.targets == "u8":
+        t = t.to(torch.uint8)
 
     for _ in range(args.warmup):
         loss = trainer.step(x, t)
@@ -405,7 +412,7 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.dtype == "f32" else "bf16 storage (levels with <= 8 channels per node, stems, head input) / f32 arithmetic", "data": "synthetic",
             "config": {"workload": "searched.py SearchedNet/G_conv train step, batch=%d 4x%d^3 %s per GPU" % (args.batch, args.size, "fp32" if args.dtype == "f32" else "bf16-storage"),
                        "global_batch": world * args.batch, "patch": [4, args.size, args.size, args.size],
-                       "parallelism": "dp%d" % world, "dp_buckets": len(trainer.sync.ranges) if trainer.dp_path else None, "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "final_loss": round(final_loss, 5),
+                       "parallelism": "dp%d" % world, "dp_buckets": len(trainer.sync.ranges) if trainer.dp_path else None, "hip_graph": not args.no_graph, "input_layout": "NDHWC (as n3d_patch_batch emits)", "targets": args.targets, "final_loss": round(final_loss, 5),
                        "schedule": ("side-stream weight gradients" if getattr(trainer, "_use_side", False) else "single stream"),
                        "schedule_ms": [round(v * 1e3, 3) for v in trainer.schedule_times] if getattr(trainer, "schedule_times", None) else None},
             # algorithmic work per patch scales with the voxel count (figures quoted at 64^3); bf16 storage halves the
@@ -442,7 +449,7 @@ def main():
         if world == 1 and not args.no_other_configs and args.size == 64 and args.dtype == "f32":
             del trainer
             torch.cuda.empty_cache()
-            out["other_configs"] = other_configs(device, args.batch, args.no_graph)
+            out["other_configs"] = other_configs(device, args.batch, args.no_graph, args.targets)
     else:
         out = None
     if dist.is_initialized():

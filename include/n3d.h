@@ -66,6 +66,7 @@ extern "C" {
 /* storage type of an activation tensor (entry points that take a dtype argument; all others are fp32) */
 #define N3D_F32 0
 #define N3D_BF16 1        /* bfloat16 storage, fp32 arithmetic: BASELINE configs[4] (4x128^3 patches, HBM-bound levels) */
+#define N3D_U8 2          /* bytes holding exactly {0, 1}: the targets of n3d_head_fwd / n3d_head_bwd (n3d_head.t_dtype) and of n3d_patch_batch */
 
 /* Geometry of a (possibly strided / dilated) 3-D convolution, torch Conv3d semantics:
  * o = floor((i + 2*pad - dil*(k-1) - 1)/stride) + 1.  "i side" is what the window slides over.
@@ -463,15 +464,17 @@ int n3d_dice_bwd(const float* p, int64_t psb, int64_t psc, int64_t psv, const fl
 typedef struct n3d_head {
   const void* x; int64_t xld; int32_t x_dtype; int32_t B; int32_t Ci; int32_t Co; int64_t N;
   const float* w; const float* bias; const float* gate;
-  int64_t x_node_stride; int64_t dx_node_stride; int32_t node_c; int32_t pad_;
+  int64_t x_node_stride; int64_t dx_node_stride; int32_t node_c;
+  int32_t t_dtype;      /* storage of the targets t: N3D_F32, or N3D_U8 (Co = 3: generator.py:230-248 yields three boolean maps; the strides
+                           count elements; same sums and gradients bit for bit, a quarter of the target bytes) */
 } n3d_head;
 float n3d_dropout3d_uniform(uint64_t seed, uint32_t counter, uint32_t index);
 int n3d_dropout3d_gate(uint32_t* state, float p, int B, int C, float* gate, void* stream);
 int n3d_head_rows(int64_t N);
 size_t n3d_head_workspace_bytes(const n3d_head* h);
-int n3d_head_fwd(const n3d_head* h, float* p, int64_t psb, int64_t psc, int64_t psv, float* logits, const float* t, int64_t tsb,
+int n3d_head_fwd(const n3d_head* h, float* p, int64_t psb, int64_t psc, int64_t psv, float* logits, const void* t, int64_t tsb,
                  int64_t tsc, int64_t tsv, float smooth, double* partial, double* sums, float* loss, void* stream);
-int n3d_head_bwd(const n3d_head* h, const float* dp, int64_t dsb, int64_t dsc, int64_t dsv, const float* t, int64_t tsb, int64_t tsc,
+int n3d_head_bwd(const n3d_head* h, const float* dp, int64_t dsb, int64_t dsc, int64_t dsv, const void* t, int64_t tsb, int64_t tsc,
                  int64_t tsv, float smooth, const double* sums, const float* dloss, void* dx, int64_t dxld, int dx_dtype, int flags,
                  float* dw, float* dbias, void* ws, size_t ws_bytes, n3d_final_job* deferred, void* stream);
 
@@ -484,11 +487,14 @@ int n3d_ndhwc_to_ncdhw(const float* src, int64_t sld, float* dst, int B, int C, 
  * for data and truth) + label expansion to three binary channels (generator.py:230-248, including its quirk that the
  * inclusive "WT" channel is labels {1,2}).  out[b][i] = vol[corner + src(i)], src_a(i) = i[perm[a]] or P-1-i[perm[a]]
  * (flip[a]); zero outside the volume.  vol: (Cv, X, Y, Z) contiguous fp32; truth: (X, Y, Z) uint8 labels {0,1,2,4} or
- * NULL; x_out: pitched NDHWC (B, Cv, P, P, P); t_out: (B, 3, P, P, P) contiguous fp32 or NULL.  descs: HOST array. */
+ * NULL; x_out: pitched NDHWC (B, Cv, P, P, P); t_out: (B, 3, P, P, P) contiguous fp32 -- uint8 with N3D_PATCH_T_U8 -- or NULL.
+ * flags: N3D_PATCH_INCLUSIVE (the reference's `inclusive_label`) | N3D_PATCH_T_U8.  descs: HOST array. */
 #define N3D_PATCH_MAX_BATCH 64
+#define N3D_PATCH_INCLUSIVE 1
+#define N3D_PATCH_T_U8 2       /* the three boolean maps as bytes (generator.py:230-248 yields booleans; train.py:118 casts them) */
 typedef struct n3d_patch_desc { int32_t corner[3]; int32_t perm[3]; int32_t flip[3]; } n3d_patch_desc;
 int n3d_patch_batch(const float* vol, int Cv, const uint8_t* truth, int X, int Y, int Z, const n3d_patch_desc* descs, int B, int P,
-                    int inclusive, float* x_out, int64_t xld, float* t_out, void* stream);
+                    int flags, float* x_out, int64_t xld, void* t_out, void* stream);
 
 /* ---- step after the hot path (prediction.py:120-170): stitch the per-patch predictions into the brain-wide volume with
  * mean blending (patches.py:172-207) and fuse the three sigmoid channels into one label volume.

@@ -92,7 +92,7 @@ class Head(C.Structure):
     """n3d_head (include/n3d.h)"""
     _fields_ = [("x", C.c_void_p), ("xld", C.c_int64), ("x_dtype", C.c_int32), ("B", C.c_int32), ("Ci", C.c_int32), ("Co", C.c_int32),
                 ("N", C.c_int64), ("w", C.c_void_p), ("bias", C.c_void_p), ("gate", C.c_void_p),
-                ("x_node_stride", C.c_int64), ("dx_node_stride", C.c_int64), ("node_c", C.c_int32), ("pad_", C.c_int32)]
+                ("x_node_stride", C.c_int64), ("dx_node_stride", C.c_int64), ("node_c", C.c_int32), ("t_dtype", C.c_int32)]
 
 
 class PatchDesc(C.Structure):
@@ -221,7 +221,8 @@ PROTOTYPES = {
 
 # flags (include/n3d.h)
 RELU_IN, RELU, ACCUMULATE, POOL_MAX, NO_MFMA, PREPACKED = 1, 2, 4, 8, 16, 32
-F32, BF16 = 0, 1   # N3D_F32 / N3D_BF16
+F32, BF16, U8 = 0, 1, 2   # N3D_F32 / N3D_BF16 / N3D_U8 (byte targets of the head passes and of the data step)
+PATCH_INCLUSIVE, PATCH_T_U8 = 1, 2   # n3d_patch_batch flags
 SRC_BF16, DST_BF16, ACT_BF16 = 64, 128, 64   # storage flags of the conv / epilogue families
 MM_BF16 = 256   # conv family, bf16 configuration: the C >= 16 MFMA kernels round their operands to bf16 (fp32 storage, fp32 accumulate)
 

@@ -10,9 +10,12 @@ namespace n3d {
 struct PatchDescs { n3d_patch_desc d[N3D_PATCH_MAX_BATCH]; };
 
 // one thread = one output voxel (b, i0, i1, i2); writes are lane-consecutive along i2 (x: Cv floats per voxel)
+// TT: storage of the three target maps -- float, or uint8_t (N3D_PATCH_T_U8: the generator's booleans as bytes, what n3d_head_fwd /
+// n3d_head_bwd read with t_dtype = N3D_U8)
+template <typename TT>
 __global__ __launch_bounds__(256) void patch_batch_kernel(const float* __restrict__ vol, int Cv, const uint8_t* __restrict__ truth, int X, int Y, int Z,
                                                           PatchDescs descs, int P, int inclusive, float* __restrict__ x_out, int64_t xld,
-                                                          float* __restrict__ t_out, FastDiv fP, FastDiv fPP) {
+                                                          TT* __restrict__ t_out, FastDiv fP, FastDiv fPP) {
   const int b = blockIdx.y;
   const n3d_patch_desc d = descs.d[b];
   const uint32_t v = blockIdx.x * 256 + threadIdx.x;
@@ -43,10 +46,10 @@ __global__ __launch_bounds__(256) void patch_batch_kernel(const float* __restric
     const int l = in ? (int)truth[sv] : 0;
     // generator.py:241-243 -- the inclusive "whole tumour" channel is labels {1, 2}: np.logical_or's third argument
     // is its OUT array there, so label 4 does not enter (reproduced, not corrected)
-    const float c0 = inclusive ? (float)(l == 1 || l == 4) : (float)(l == 1);
-    const float c1 = inclusive ? (float)(l == 1 || l == 2) : (float)(l == 2);
-    const float c2 = (float)(l == 4);
-    float* to = t_out + (int64_t)b * 3 * P3 + v;
+    const TT c0 = inclusive ? (TT)(l == 1 || l == 4) : (TT)(l == 1);
+    const TT c1 = inclusive ? (TT)(l == 1 || l == 2) : (TT)(l == 2);
+    const TT c2 = (TT)(l == 4);
+    TT* to = t_out + (int64_t)b * 3 * P3 + v;
     to[0] = c0; to[P3] = c1; to[2 * (int64_t)P3] = c2;
   }
 }
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void patch_batch_kernel(const float* __restric
 using namespace n3d;
 
 extern "C" int n3d_patch_batch(const float* vol, int Cv, const uint8_t* truth, int X, int Y, int Z, const n3d_patch_desc* descs, int B, int P,
-                               int inclusive, float* x_out, int64_t xld, float* t_out, void* stream) {
+                               int flags, float* x_out, int64_t xld, void* t_out, void* stream) {
   N3D_CHECK_ARG(vol && descs && x_out && Cv >= 1 && X > 0 && Y > 0 && Z > 0 && P > 0 && B >= 1 && xld >= Cv, "patch_batch: bad args");
   N3D_CHECK_ARG(B <= N3D_PATCH_MAX_BATCH, "patch_batch: at most %d patches per call", N3D_PATCH_MAX_BATCH);
   N3D_CHECK_ARG(!t_out || truth, "patch_batch: targets requested without a truth volume");
@@ -73,8 +76,15 @@ extern "C" int n3d_patch_batch(const float* vol, int Cv, const uint8_t* truth, i
   }
   for (int i = B; i < N3D_PATCH_MAX_BATCH; ++i) pd.d[i] = pd.d[0];
   const uint32_t P3 = (uint32_t)P * P * P;
-  hipLaunchKernelGGL(patch_batch_kernel, dim3((unsigned)cdiv(P3, 256), B), dim3(256), 0, (hipStream_t)stream, vol, Cv, truth, X, Y, Z, pd, P, inclusive,
-                     x_out, xld, t_out, FastDiv((uint32_t)P), FastDiv((uint32_t)P * P));
+  N3D_CHECK_ARG((flags & ~(N3D_PATCH_INCLUSIVE | N3D_PATCH_T_U8)) == 0, "patch_batch: unknown flag bits %d", flags);
+  const int inclusive = flags & N3D_PATCH_INCLUSIVE;
+  const dim3 grid((unsigned)cdiv(P3, 256), B);
+  if (flags & N3D_PATCH_T_U8)
+    hipLaunchKernelGGL(patch_batch_kernel<uint8_t>, grid, dim3(256), 0, (hipStream_t)stream, vol, Cv, truth, X, Y, Z, pd, P, inclusive, x_out, xld,
+                       (uint8_t*)t_out, FastDiv((uint32_t)P), FastDiv((uint32_t)P * P));
+  else
+    hipLaunchKernelGGL(patch_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, vol, Cv, truth, X, Y, Z, pd, P, inclusive, x_out, xld,
+                       (float*)t_out, FastDiv((uint32_t)P), FastDiv((uint32_t)P * P));
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }

@@ -40,18 +40,40 @@ __device__ __forceinline__ int64_t head_quad_off(int q, int qn, int64_t node_str
   return qn ? (int64_t)(q / qn) * node_stride + (q % qn) * 4 : (int64_t)q * 4;
 }
 
+// Byte targets of a workgroup's 1024-voxel chunk: one 4-byte load per lane and channel (voxels 4 * tid .. 4 * tid + 3) instead of four
+// 1-byte loads (a byte load moves 64 B per wave instruction: the byte form of the per-voxel loads was SLOWER than the float form),
+// handed to the lanes that own the voxels (tid + 256 k) through LDS.
+template <int NCO>
+__device__ __forceinline__ void head_target_quads_issue(const void* t, int64_t base, int64_t tsc, int tid, uint32_t (&q)[NCO]) {
+#pragma unroll
+  for (int co = 0; co < NCO; ++co) q[co] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(t) + base + co * tsc)[tid];
+}
+template <int NCO, int NK>
+__device__ __forceinline__ void head_target_quads_take(const uint32_t (&q)[NCO], uint32_t (*lds)[256], int tid, float (&tv)[NK][NCO]) {
+#pragma unroll
+  for (int co = 0; co < NCO; ++co) lds[co][tid] = q[co];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NK; ++k)
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) tv[k][co] = (float)((lds[co][(tid >> 2) + 64 * k] >> (8 * (tid & 3))) & 0xffu);
+}
+
 struct HeadFwdArgs {
   const void* x; int64_t xld; int64_t N; int64_t xns; int qn;   // xns / qn: node stride and quads per node (qn == 0: pitched layout)
   const float* w; const float* bias; const float* gate;
   float* p; int64_t psb, psc, psv; float* logits;
-  const float* t; int64_t tsb, tsc, tsv;
+  const void* t; int64_t tsb, tsc, tsv;      // targets: float, or bytes {0, 1} (TT = uint8_t; strides in elements)
   double* partial; int rows; int Ci, Co;
+  int t_quad;   // byte targets, dense and 4-aligned, whole chunks: a lane fetches FOUR voxels' bytes (head_target_quads)
 };
 
 // thread = voxel; lanes walk consecutive voxels (x: Ci * sizeof(TX) contiguous bytes per voxel, p / t: strided per channel)
 // NCO: output channels computed per voxel -- 3 = exactly three (the reference's out_channels, config.yml: no fourth channel of zero
 // weights, no run-time channel tests), HEAD_COMAX = any count up to four
-template <typename TX, int CIQ, int NCO>
+// TT: storage of the targets -- float, or uint8_t holding exactly {0, 1} (generator.py:230-248 yields booleans): a quarter of the
+// target bytes, the same sums bit for bit
+template <typename TX, int CIQ, int NCO, typename TT = float>
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
   N3D_CHAIN_PRIO();
   constexpr int CI = CIQ * 4;
@@ -78,17 +100,26 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
   // every operand of the workgroup's four voxel rounds is requested before the first use (predicated, no early exit: a `break` in
   // the loop kept each round's loads behind the previous round's stores -- 2.6 TB/s on a 37 MB pass)
   constexpr int NK = HEAD_CHUNK / 256;
+  constexpr bool TU8 = sizeof(TT) == 1;
+  __shared__ uint32_t tql[TU8 ? NCO : 1][256];
+  const bool tquad = TU8 && a.t_quad;     // (uniform)
   float4 xqs[NK][CIQ];
   float tvs[NK][NCO];
+  uint32_t tq[NCO];
+  if (tquad) head_target_quads_issue<NCO>(a.t, b * a.tsb + v0, a.tsc, tid, tq);
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const int64_t v = v0 + tid + k * 256;
     const int64_t vc = v < a.N ? v : v0;
 #pragma unroll
     for (int q = 0; q < CIQ; ++q) xqs[k][q] = ld4(xb + vc * a.xld + qoff[q]);
+    if (!tquad) {
 #pragma unroll
-    for (int co = 0; co < NCO; ++co) tvs[k][co] = (a.t && (ALL || co < a.Co)) ? a.t[b * a.tsb + co * a.tsc + vc * a.tsv] : 0.f;
+      for (int co = 0; co < NCO; ++co)
+        tvs[k][co] = (a.t && (ALL || co < a.Co)) ? (float)reinterpret_cast<const TT*>(a.t)[b * a.tsb + co * a.tsc + vc * a.tsv] : 0.f;
+    }
   }
+  if (tquad) head_target_quads_take<NCO, NK>(tq, tql, tid, tvs);
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const int64_t v = v0 + tid + k * 256;
@@ -216,7 +247,7 @@ struct HeadBwdArgs {
   const void* x; int64_t xld; int64_t N; int64_t xns, dxns; int qn;
   const float* w; const float* bias; const float* gate;
   const float* dp; int64_t dsb, dsc, dsv;
-  const float* t; int64_t tsb, tsc, tsv;
+  const void* t; int64_t tsb, tsc, tsv; int t_quad;
   const double* sums; const float* dloss; double smooth; int BC;
   void* dx; int64_t dxld; int accumulate;
   float* partial; float* pbias; int chunks_per_sample; int Ci, Co;
@@ -224,7 +255,7 @@ struct HeadBwdArgs {
 
 // thread = voxel.  d logit = dp * p * (1 - p) with p recomputed from x (no saved activations are read);
 // dx[ci] = gate[ci] * sum_co W[co][ci] * dlogit[co];  dW[co][ci] = gate[ci] * sum_v dlogit[co] * x[ci];  dbias[co] = sum_v dlogit[co]
-template <typename TX, typename TD, int CIQ, int NCO>     // NCO: as head_fwd_kernel
+template <typename TX, typename TD, int CIQ, int NCO, typename TT = float>     // NCO, TT: as head_fwd_kernel
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   N3D_CHAIN_PRIO();
   constexpr int CI = CIQ * 4, NV = HEAD_COMAX * CI + HEAD_COMAX;
@@ -268,20 +299,29 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   const int64_t v0 = (int64_t)blockIdx.x * HEAD_CHUNK;
   // the four voxel rounds' input operands are requested before the first use (as head_fwd_kernel)
   constexpr int NK = HEAD_CHUNK / 256;
+  constexpr bool TU8 = sizeof(TT) == 1;
+  __shared__ uint32_t tql[TU8 ? NCO : 1][256];
+  const bool tquad = TU8 && a.t_quad && a.sums;     // (uniform)
   float4 xqs[NK][CIQ];
   float gin[NK][NCO];
+  uint32_t tq[NCO];
+  if (tquad) head_target_quads_issue<NCO>(a.t, b * a.tsb + v0, a.tsc, tid, tq);
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const int64_t v = v0 + tid + k * 256;
     const int64_t vc = v < a.N ? v : v0;
 #pragma unroll
     for (int q = 0; q < CIQ; ++q) xqs[k][q] = ld4(xb + vc * a.xld + qoff[q]);
+    if (!tquad) {
 #pragma unroll
-    for (int co = 0; co < NCO; ++co) {
-      gin[k][co] = 0.f;
-      if (ALL || co < a.Co) gin[k][co] = a.sums ? a.t[b * a.tsb + co * a.tsc + vc * a.tsv] : a.dp[b * a.dsb + co * a.dsc + vc * a.dsv];
+      for (int co = 0; co < NCO; ++co) {
+        gin[k][co] = 0.f;
+        if (ALL || co < a.Co)
+          gin[k][co] = a.sums ? (float)reinterpret_cast<const TT*>(a.t)[b * a.tsb + co * a.tsc + vc * a.tsv] : a.dp[b * a.dsb + co * a.dsc + vc * a.dsv];
+      }
     }
   }
+  if (tquad) head_target_quads_take<NCO, NK>(tq, tql, tid, gin);
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const int64_t v = v0 + tid + k * 256;
@@ -361,35 +401,40 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   }
 }
 
+// (byte targets: the three-channel form only -- the reference's out_channels, the generator's three boolean maps)
 template <typename TX>
-static bool launch_head_fwd(const HeadFwdArgs& a, int B, hipStream_t s) {
+static bool launch_head_fwd(const HeadFwdArgs& a, int B, bool t_u8, hipStream_t s) {
   const dim3 grid((unsigned)a.rows, (unsigned)B), blk(256);
   const bool three = a.Co == 3;
+  if (t_u8 && !three) return false;
+#define N3D_HEAD_FWD(Q_)                                                                                                     \
+  case Q_: if (t_u8) hipLaunchKernelGGL((head_fwd_kernel<TX, Q_, 3, uint8_t>), grid, blk, 0, s, a);                           \
+           else if (three) hipLaunchKernelGGL((head_fwd_kernel<TX, Q_, 3>), grid, blk, 0, s, a);                              \
+           else hipLaunchKernelGGL((head_fwd_kernel<TX, Q_, HEAD_COMAX>), grid, blk, 0, s, a);                                \
+           break;
   switch (a.Ci / 4) {
-    case 1: if (three) hipLaunchKernelGGL((head_fwd_kernel<TX, 1, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_fwd_kernel<TX, 1, HEAD_COMAX>), grid, blk, 0, s, a); break;
-    case 2: if (three) hipLaunchKernelGGL((head_fwd_kernel<TX, 2, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_fwd_kernel<TX, 2, HEAD_COMAX>), grid, blk, 0, s, a); break;
-    case 3: if (three) hipLaunchKernelGGL((head_fwd_kernel<TX, 3, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_fwd_kernel<TX, 3, HEAD_COMAX>), grid, blk, 0, s, a); break;
-    case 4: if (three) hipLaunchKernelGGL((head_fwd_kernel<TX, 4, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_fwd_kernel<TX, 4, HEAD_COMAX>), grid, blk, 0, s, a); break;
-    case 6: if (three) hipLaunchKernelGGL((head_fwd_kernel<TX, 6, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_fwd_kernel<TX, 6, HEAD_COMAX>), grid, blk, 0, s, a); break;
-    case 8: if (three) hipLaunchKernelGGL((head_fwd_kernel<TX, 8, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_fwd_kernel<TX, 8, HEAD_COMAX>), grid, blk, 0, s, a); break;
+    N3D_HEAD_FWD(1) N3D_HEAD_FWD(2) N3D_HEAD_FWD(3) N3D_HEAD_FWD(4) N3D_HEAD_FWD(6) N3D_HEAD_FWD(8)
     default: return false;
   }
+#undef N3D_HEAD_FWD
   return true;
 }
 
 template <typename TX, typename TD>
-static bool launch_head_bwd(const HeadBwdArgs& a, int B, hipStream_t s) {
+static bool launch_head_bwd(const HeadBwdArgs& a, int B, bool t_u8, hipStream_t s) {
   const dim3 grid((unsigned)a.chunks_per_sample, (unsigned)B), blk(256);
   const bool three = a.Co == 3;
+  if (t_u8 && !three) return false;
+#define N3D_HEAD_BWD(Q_)                                                                                                     \
+  case Q_: if (t_u8) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, Q_, 3, uint8_t>), grid, blk, 0, s, a);                       \
+           else if (three) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, Q_, 3>), grid, blk, 0, s, a);                          \
+           else hipLaunchKernelGGL((head_bwd_kernel<TX, TD, Q_, HEAD_COMAX>), grid, blk, 0, s, a);                            \
+           break;
   switch (a.Ci / 4) {
-    case 1: if (three) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 1, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 1, HEAD_COMAX>), grid, blk, 0, s, a); break;
-    case 2: if (three) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 2, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 2, HEAD_COMAX>), grid, blk, 0, s, a); break;
-    case 3: if (three) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 3, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 3, HEAD_COMAX>), grid, blk, 0, s, a); break;
-    case 4: if (three) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 4, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 4, HEAD_COMAX>), grid, blk, 0, s, a); break;
-    case 6: if (three) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 6, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 6, HEAD_COMAX>), grid, blk, 0, s, a); break;
-    case 8: if (three) hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 8, 3>), grid, blk, 0, s, a); else hipLaunchKernelGGL((head_bwd_kernel<TX, TD, 8, HEAD_COMAX>), grid, blk, 0, s, a); break;
+    N3D_HEAD_BWD(1) N3D_HEAD_BWD(2) N3D_HEAD_BWD(3) N3D_HEAD_BWD(4) N3D_HEAD_BWD(6) N3D_HEAD_BWD(8)
     default: return false;
   }
+#undef N3D_HEAD_BWD
   return true;
 }
 
@@ -399,6 +444,8 @@ static int check_head(const n3d_head* h, const char* what) {
   if (h->Ci % 4 != 0 || !(q == 1 || q == 2 || q == 3 || q == 4 || q == 6 || q == 8) || h->Co < 1 || h->Co > HEAD_COMAX)
     N3D_UNSUPPORTED("%s: Ci in {4,8,12,16,24,32} and Co <= %d are built (Ci=%d Co=%d)", what, HEAD_COMAX, h->Ci, h->Co);
   N3D_CHECK_ARG(h->x_dtype == N3D_F32 || h->x_dtype == N3D_BF16, "%s: unknown dtype %d", what, h->x_dtype);
+  N3D_CHECK_ARG(h->t_dtype == N3D_F32 || h->t_dtype == N3D_U8, "%s: targets are N3D_F32 or N3D_U8 (t_dtype=%d)", what, h->t_dtype);
+  if (h->t_dtype == N3D_U8 && h->Co != 3) N3D_UNSUPPORTED("%s: byte targets are built for Co = 3 (Co=%d)", what, h->Co);
   const int esz = h->x_dtype == N3D_BF16 ? 2 : 4;
   if (h->node_c) {
     N3D_CHECK_ARG(h->node_c > 0 && h->node_c % 4 == 0 && h->Ci % h->node_c == 0 && h->xld >= h->node_c && h->xld % 4 == 0 &&
@@ -432,7 +479,7 @@ size_t n3d_head_workspace_bytes(const n3d_head* h) {
   return (size_t)h->B * cdiv(h->N, HEAD_CHUNK) * ((size_t)h->Ci * h->Co + h->Co) * sizeof(float);
 }
 
-int n3d_head_fwd(const n3d_head* h, float* p, int64_t psb, int64_t psc, int64_t psv, float* logits, const float* t, int64_t tsb,
+int n3d_head_fwd(const n3d_head* h, float* p, int64_t psb, int64_t psc, int64_t psv, float* logits, const void* t, int64_t tsb,
                  int64_t tsc, int64_t tsv, float smooth, double* partial, double* sums, float* loss, void* stream) {
   if (int e = check_head(h, "head_fwd")) return e;
   N3D_CHECK_ARG(p || t, "head_fwd: no output (p may be NULL only in the Dice mode: the trainers' step needs the loss alone)");
@@ -444,14 +491,16 @@ int n3d_head_fwd(const n3d_head* h, float* p, int64_t psb, int64_t psc, int64_t 
   a.t = t; a.tsb = tsb; a.tsc = tsc; a.tsv = tsv; a.partial = t ? partial : nullptr; a.rows = (int)cdiv(h->N, HEAD_CHUNK);
   a.Ci = h->Ci; a.Co = h->Co;
   hipStream_t s = (hipStream_t)stream;
-  const bool ok = h->x_dtype == N3D_BF16 ? launch_head_fwd<bf16_t>(a, h->B, s) : launch_head_fwd<float>(a, h->B, s);
+  const bool u8 = t && h->t_dtype == N3D_U8;
+  a.t_quad = u8 && tsv == 1 && h->N % HEAD_CHUNK == 0 && tsb % 4 == 0 && tsc % 4 == 0 && reinterpret_cast<uintptr_t>(t) % 4 == 0;
+  const bool ok = h->x_dtype == N3D_BF16 ? launch_head_fwd<bf16_t>(a, h->B, u8, s) : launch_head_fwd<float>(a, h->B, u8, s);
   if (!ok) N3D_UNSUPPORTED("head_fwd: Ci=%d", h->Ci);
   if (t) hipLaunchKernelGGL(head_dice_finalize_kernel, dim3(1), dim3(256), 0, s, partial, a.rows, h->B * h->Co, (double)smooth, sums, loss);
   N3D_LAUNCH_CHECK();
   return N3D_OK;
 }
 
-int n3d_head_bwd(const n3d_head* h, const float* dp, int64_t dsb, int64_t dsc, int64_t dsv, const float* t, int64_t tsb, int64_t tsc,
+int n3d_head_bwd(const n3d_head* h, const float* dp, int64_t dsb, int64_t dsc, int64_t dsv, const void* t, int64_t tsb, int64_t tsc,
                  int64_t tsv, float smooth, const double* sums, const float* dloss, void* dx, int64_t dxld, int dx_dtype, int flags,
                  float* dw, float* dbias, void* ws, size_t ws_bytes, n3d_final_job* deferred, void* stream) {
   if (deferred) deferred->nchunks = 0;
@@ -475,8 +524,10 @@ int n3d_head_bwd(const n3d_head* h, const float* dp, int64_t dsb, int64_t dsc, i
   a.chunks_per_sample = cps; a.Ci = h->Ci; a.Co = h->Co;
   hipStream_t s = (hipStream_t)stream;
   bool ok;
-  if (h->x_dtype == N3D_BF16) ok = dx_dtype == N3D_BF16 ? launch_head_bwd<bf16_t, bf16_t>(a, h->B, s) : launch_head_bwd<bf16_t, float>(a, h->B, s);
-  else ok = dx_dtype == N3D_BF16 ? launch_head_bwd<float, bf16_t>(a, h->B, s) : launch_head_bwd<float, float>(a, h->B, s);
+  const bool u8 = !dp && h->t_dtype == N3D_U8;
+  a.t_quad = u8 && tsv == 1 && h->N % HEAD_CHUNK == 0 && tsb % 4 == 0 && tsc % 4 == 0 && reinterpret_cast<uintptr_t>(t) % 4 == 0;
+  if (h->x_dtype == N3D_BF16) ok = dx_dtype == N3D_BF16 ? launch_head_bwd<bf16_t, bf16_t>(a, h->B, u8, s) : launch_head_bwd<bf16_t, float>(a, h->B, u8, s);
+  else ok = dx_dtype == N3D_BF16 ? launch_head_bwd<float, bf16_t>(a, h->B, u8, s) : launch_head_bwd<float, float>(a, h->B, u8, s);
   if (!ok) N3D_UNSUPPORTED("head_bwd: Ci=%d", h->Ci);
   N3D_LAUNCH_CHECK();
   if (want_w) {

@@ -110,9 +110,11 @@ def run_loss(head, x, t, smooth=1e-6):
     """(Dice loss, probabilities) of the head on features x against the target t.  The probabilities are returned for
     inspection only and carry NO gradient on either path (the fused kernels form the Dice gradient inside the head's backward
     pass): a caller who wants another loss on them uses run() and differentiates through that."""
-    if not fusable(head, x) or t.dtype != torch.float32:
+    fused = fusable(head, x)
+    byte_ok = fused and t.dtype == torch.uint8 and head[0].conv.weight.shape[0] == 3      # {0, 1} bytes: the three-channel head kernels read them as they are
+    if not fused or not (t.dtype == torch.float32 or byte_ok):
         from .loss import WeightedDiceLoss
         p = head(x)
-        return WeightedDiceLoss(smooth=smooth)(p, t), p.detach()
+        return WeightedDiceLoss(smooth=smooth)(p, t if t.dtype == torch.float32 else t.to(torch.float32)), p.detach()
     op = head[0]
     return HeadDiceFn.apply(_gate(op, x), float(smooth), x, t, op.conv.weight, op.conv.bias)

@@ -1537,21 +1537,31 @@ def dropout3d_gate(state, p, B, Cc):
     return gate
 
 
-def _head_desc(x, w, bias, gate, dx=None):
-    """x (and dx): View, or Planar -- the node-planar layout of include/n3d.h"""
+def _target_dtype(t):
+    """N3D_F32 / N3D_U8 of a target tensor (None: no targets in the call)"""
+    if t is None or t.dtype == torch.float32:
+        return _lib.F32
+    if t.dtype == torch.uint8:
+        return _lib.U8
+    raise N3DError(f"head: targets are float32 or uint8 ({{0, 1}} bytes), got {t.dtype}")
+
+
+def _head_desc(x, w, bias, gate, dx=None, t=None):
+    """x (and dx): View, or Planar -- the node-planar layout of include/n3d.h; t: the target tensor of the call (its storage type)"""
+    td = _target_dtype(t)
     if isinstance(x, Planar):
         if dx is not None and not (isinstance(dx, Planar) and dx.cn == x.cn and dx.nn == x.nn):
             raise N3DError("head: a node-planar input needs a node-planar gradient of the same node layout")
         return _lib.Head(x.nodes[0].p.value, x.cn, x.dt, x.B, x.C, int(w.shape[0]), x.N, w.data_ptr(), bias.data_ptr(), _vp(gate),
-                         x.node_stride, dx.node_stride if dx is not None else 0, x.cn, 0)
-    return _lib.Head(x.p.value, x.ld, x.dt, x.B, x.C, int(w.shape[0]), x.N, w.data_ptr(), bias.data_ptr(), _vp(gate), 0, 0, 0, 0)
+                         x.node_stride, dx.node_stride if dx is not None else 0, x.cn, td)
+    return _lib.Head(x.p.value, x.ld, x.dt, x.B, x.C, int(w.shape[0]), x.N, w.data_ptr(), bias.data_ptr(), _vp(gate), 0, 0, 0, td)
 
 
 def head_fwd(x, w, bias, gate, t=None, smooth=1e-6, want_logits=False, want_p=True):
     """p = sigmoid(conv1x1x1(x * gate) + bias) as a contiguous (B, Co, D, H, W) tensor; with a target t also the Dice sums
-    and loss from the same pass.  Returns (p, logits | None, sums | None, loss | None)."""
+    and loss from the same pass (t: float32, or uint8 bytes {0, 1}).  Returns (p, logits | None, sums | None, loss | None)."""
     lib = _lib.load()
-    h = _head_desc(x, w, bias, gate)
+    h = _head_desc(x, w, bias, gate, t=t)
     dev = x.t.device
     Co = int(w.shape[0])
     if not want_p and (t is None or want_logits):
@@ -1575,7 +1585,7 @@ def head_bwd(x, w, bias, gate, dx, dw, dbias, dp=None, t=None, sums=None, dloss=
     """backward of head_fwd in one pass: dx (+)=, dw, dbias.  Either dp (gradient w.r.t. p, any uniform strides) or
     (t, sums[, dloss]) for the fused Dice gradient.  x / dx: Views, or both Planar."""
     lib = _lib.load()
-    h = _head_desc(x, w, bias, gate, dx if isinstance(x, Planar) else None)
+    h = _head_desc(x, w, bias, gate, dx if isinstance(x, Planar) else None, t=t)
     ws = None
     n = 0
     job = None

@@ -41,6 +41,29 @@ def test_patch_batch_all_keys_vs_oracle():
     assert K._pitch_of(x) == 4
 
 
+def test_patch_batch_byte_targets_and_caller_buffers():
+    """the three boolean maps as bytes (N3D_PATCH_T_U8) equal the float maps; out=(x, t) writes into the caller's tensors"""
+    from nas_3d_unet_amd import datastep as hd, kernels as K
+    from nas_3d_unet_amd._lib import N3DError
+    rng = np.random.default_rng(5)
+    vol = rng.standard_normal((4, 24, 20, 28)).astype(np.float32)
+    truth = rng.choice(np.array([0, 0, 1, 2, 4], dtype=np.uint8), size=(24, 20, 28))
+    keys = gc.permutation_keys()[:6]
+    corners = [tuple(int(v) for v in rng.integers(-6, 16, 3)) for _ in keys]
+    dv, dt = torch.from_numpy(vol).cuda(), torch.from_numpy(truth).cuda()
+    for incl in (True, False):
+        x, t = hd.patch_batch(dv, dt, corners, keys, 12, inclusive_label=incl)
+        xb, tb = hd.patch_batch(dv, dt, corners, keys, 12, inclusive_label=incl, target_dtype=torch.uint8)
+        assert tb.dtype == torch.uint8 and torch.equal(xb, x) and torch.equal(tb.to(torch.float32), t)
+        ox, ot = K.empty_ndhwc(6, 4, 12, 12, 12, dv.device), torch.full((6, 3, 12, 12, 12), 7, dtype=torch.uint8, device=dv.device)
+        rx, rt = hd.patch_batch(dv, dt, corners, keys, 12, inclusive_label=incl, out=(ox, ot))
+        assert rx is ox and rt is ot and torch.equal(ox, x) and torch.equal(ot, tb)
+    with pytest.raises(N3DError):
+        hd.patch_batch(dv, dt, corners, keys, 12, out=(torch.empty(6, 4, 12, 12, 12, device=dv.device), ot))      # NCDHW storage: not written in place
+    with pytest.raises(N3DError):
+        hd.patch_batch(dv, dt, corners, keys, 12, target_dtype=torch.int32)
+
+
 def test_patch_batch_errors():
     from nas_3d_unet_amd import datastep as hd
     from nas_3d_unet_amd._lib import N3DError

@@ -65,6 +65,46 @@ def test_head_matches_torch(ci, co, shape, batch, use_gate, mode):
         assert_close(dx.t, 2 * dxr, 2e-5, "dx accumulate")
 
 
+@pytest.mark.parametrize("ci,shape,batch,use_gate,storage", [(12, (8, 12, 16), 2, True, "f32"), (12, (32, 32, 32), 2, False, "f32"),
+                                                             (8, (5, 3, 7), 3, True, "f32"), (12, (16, 16, 16), 2, False, "bf16")])
+def test_head_byte_targets_are_bit_identical_to_float_targets(ci, shape, batch, use_gate, storage):
+    """generator.py:230-248 yields three BOOLEAN maps and train.py:118 casts them to float: the head passes read the bytes as they are
+    (n3d_head.t_dtype = N3D_U8) -- the same loss, Dice sums and gradients bit for bit, a quarter of the target traffic"""
+    from nas_3d_unet_amd import kernels as K
+    rng = np.random.default_rng(ci + batch)
+    xn = rng.standard_normal((batch, ci) + shape).astype(np.float32)
+    w = dev((rng.standard_normal((3, ci, 1, 1, 1)) * 0.4).astype(np.float32))
+    b = dev(rng.standard_normal(3).astype(np.float32) * 0.2)
+    tb = rng.uniform(0, 1, (batch, 3) + shape) < 0.3
+    gate = dev(((rng.uniform(0, 1, (batch, ci)) >= 0.5) / 0.5).astype(np.float32)) if use_gate else None
+    x = dev(xn)
+    if storage == "bf16":
+        x = K.empty_ndhwc(batch, ci, *shape, x.device, torch.bfloat16).copy_(x)
+    xv = K.as_view(x)
+    res = {}
+    for name, t in (("float", dev(tb.astype(np.float32))), ("bytes", dev(tb.astype(np.uint8)))):
+        p, _, sums, loss = K.head_fwd(xv, w, b, gate, t)
+        dx = K.as_view(K.empty_ndhwc(batch, ci, *shape, x.device, x.dtype), bf16_ok=True)
+        dw, db = torch.empty_like(w), torch.empty_like(b)
+        K.head_bwd(xv, w, b, gate, dx, dw, db, t=t, sums=sums)
+        res[name] = [v.clone() for v in (p, sums, loss, dx.t, dw, db)]
+    for a, c, what in zip(res["float"], res["bytes"], ("p", "sums", "loss", "dx", "dw", "db")):
+        assert torch.equal(a, c), what
+    # a strided byte target (a channel slice of a wider buffer) goes through the same element strides
+    wide = dev(np.concatenate([tb.astype(np.uint8), np.zeros((batch, 1) + shape, np.uint8)], axis=1))
+    _, _, sums2, loss2 = K.head_fwd(xv, w, b, gate, wide[:, :3])
+    assert torch.equal(sums2, res["float"][1]) and torch.equal(loss2, res["float"][2])
+
+
+def test_head_byte_targets_need_three_channels_and_a_known_type():
+    from nas_3d_unet_amd import kernels as K
+    from nas_3d_unet_amd._lib import N3DError
+    xv = K.as_view(torch.randn(1, 8, 4, 4, 4).cuda())
+    for co, t in ((2, torch.zeros(1, 2, 4, 4, 4, dtype=torch.uint8)), (3, torch.zeros(1, 3, 4, 4, 4, dtype=torch.int32))):
+        with pytest.raises(N3DError):
+            K.head_fwd(xv, torch.randn(co, 8, 1, 1, 1).cuda(), torch.zeros(co).cuda(), None, t.cuda())
+
+
 def test_head_bf16_storage():
     """bf16 storage of the head input / its gradient (BASELINE configs[4]): same kernels, conversions on load / store.
     Reference: fp32 torch on the bf16-rounded input; dx compared after rounding to bf16 (one ulp = 2^-8 relative)."""

@@ -119,6 +119,25 @@ def test_remainder_batch_runs_eagerly():
     np.testing.assert_allclose(out[:2], out[2:], rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("graph", [True, False])
+def test_byte_targets_train_exactly_like_float_targets(graph):
+    """the reference's generator yields boolean maps (generator.py:230-248) that train.py:118 casts to float: a trainer fed the bytes
+    (datastep.patch_batch(target_dtype=torch.uint8)) takes the same steps bit for bit -- the head passes read N3D_U8 targets"""
+    from nas_3d_unet_amd.train import Trainer
+    key, kind, gname, depth, size, batch, adam = [c for c in gc.net_cases() if c[6] and c[1] == "searched"][0]
+    xn, tn = gc.net_batch(key, batch, size)
+    tb = (tn > 0.5)
+    x = dev(xn)
+    losses = []
+    for t in (dev(tb.astype(np.float32)), dev(tb.astype(np.uint8))):
+        net, _ = build_net(kind, gname, depth)
+        tr = Trainer(net, graph=graph)
+        losses.append([float(tr.step(x, t)) for _ in range(3)])
+        if graph:
+            assert tr.input_buffers()[1].dtype == t.dtype
+    assert losses[0] == losses[1], losses
+
+
 def test_data_parallel_property_on_the_hip_path():
     """SURVEY 5.8 / 8(e) on ONE GPU through the HIP kernels: the gradient of a batch of 4 equals the mean of the gradients of
     its two halves (GroupNorm / SE are per sample, Dice is a mean over (b, c) rows) -- what the all-reduce relies on."""
