@@ -53,6 +53,26 @@ def test_search_step_matches_oracle(graph):
     assert len(gene.down) == 6 and len(gene.up) == 6
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_search_step_with_byte_targets_equals_float_targets(graph):
+    """both passes of the search step (search.py:211-238) on the generator's boolean maps as bytes: the same losses bit for bit"""
+    from nas_3d_unet_amd import nas
+    from nas_3d_unet_amd.train import SearchTrainer
+    cfg = orc.DEFAULT_CFG._replace(depth=2)
+    rng = np.random.default_rng(12)
+    xn, vxn = (rng.standard_normal((2, 4, 16, 16, 16)).astype(np.float32) for _ in range(2))
+    tb, vtb = (rng.uniform(0, 1, (2, 3, 16, 16, 16)) < 0.3 for _ in range(2))
+    out = []
+    for dt in (np.float32, np.uint8):
+        net = nas.ShellNet(cfg.in_channels, cfg.init_n_kernels, cfg.out_channels, cfg.depth, cfg.n_nodes, False, cfg.channel_change)
+        fill_module(net)
+        net.kernel.last_conv[0].dropout = None
+        tr = SearchTrainer(net.cuda(), graph=graph)
+        x, t, vx, vt = (torch.from_numpy(a).cuda() for a in (xn, tb.astype(dt), vxn, vtb.astype(dt)))
+        out.append([tuple(float(v) for v in tr.step(x, t, vx, vt)) for _ in range(2)])
+    assert out[0] == out[1], out
+
+
 @pytest.mark.parametrize("graph", [True, False])
 def test_search_trajectory_depth4_matches_reference(golden, graph):
     """BASELINE configs[2] as benchmarked -- depth-4 supernet through SearchTrainer (HIP-graph replay) -- against the trajectory
